@@ -1,0 +1,224 @@
+/*
+ * qtts.h -- C ABI of the MI355X-native Qwen3-TTS hot path (libqtts.so, gfx950 only).
+ *
+ * The reference (QwenLM/Qwen3-TTS) is 100 % Python and has no FFI of its own; its drop-in
+ * boundary is the Python API of `qwen_tts.inference`.  This header is the native
+ * seam *below* that API.  Each entry point replaces one reference call (cited per function);
+ * the Python host code in `qwen3-tts_amd/` keeps the reference's names/arguments and calls these
+ * through ctypes (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Rules of the boundary
+ *   - plain C types only: pointers, sizes, POD structs.  No torch / HIP types in signatures
+ *     (`stream` is a `hipStream_t` passed as `void*`; NULL = the default stream).
+ *   - return 0 (QTTS_OK) or a negative QTTS_ERR_*; qtts_last_error() gives the message of the
+ *     last failure on the calling thread.  No exceptions cross the ABI.
+ *   - weights are bound from HOST memory in the reference's own state_dict layout and naming
+ *     (SURVEY.md Appendix B); the library repacks them once into its streaming layouts in HBM.
+ *   - activations / codes / waveforms are DEVICE pointers owned by the caller (PyTorch-ROCm
+ *     allocations in the shipped host code); the library borrows them for the call only.
+ *   - one handle per (process, device); a handle is not re-entrant (the reference keeps
+ *     per-call state on the module too: modeling_qwen3_tts.py:1704 `self.rope_deltas`).
+ */
+#ifndef QTTS_H
+#define QTTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QTTS_OK 0
+#define QTTS_ERR_ARG (-1)     /* bad argument / shape                                      */
+#define QTTS_ERR_HIP (-2)     /* a HIP runtime call failed                                 */
+#define QTTS_ERR_STATE (-3)   /* call order violated (e.g. decode before finalize/prefill) */
+#define QTTS_ERR_UNBOUND (-4) /* finalize(): a required weight was never bound             */
+#define QTTS_ERR_NAME (-5)    /* bind(): unknown parameter name                            */
+#define QTTS_ERR_LIMIT (-6)   /* exceeds max_batch / max_seq given at create               */
+
+/* storage / arithmetic type of weights and KV cache inside the engine */
+#define QTTS_F32 0  /* parity mode: fp32 weights, exact-f32 MFMA (v_mfma_f32_16x16x4_f32)   */
+#define QTTS_BF16 1 /* perf mode:   bf16 weights + KV, v_mfma_f32_16x16x32_bf16, f32 accum  */
+
+const char* qtts_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int qtts_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Codec decoder: Qwen3-TTS-Tokenizer-12Hz  codes -> 24 kHz waveform.
+ * Replaces Qwen3TTSTokenizerV2Model.decode / Qwen3TTSTokenizerV2Decoder.{forward,chunked_decode}
+ * (qwen_tts/core/tokenizer_12hz/modeling_qwen3_tts_tokenizer_v2.py:993-1024, 869-896).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct qtts_codec qtts_codec;
+
+typedef struct {
+    /* fields of Qwen3TTSTokenizerV2DecoderConfig (configuration_qwen3_tts_tokenizer_v2.py:72-93) */
+    int32_t codebook_size;
+    int32_t codebook_dim;
+    int32_t hidden_size;
+    int32_t latent_dim;
+    int32_t num_attention_heads;
+    int32_t num_key_value_heads;
+    int32_t head_dim;
+    int32_t sliding_window;
+    int32_t intermediate_size;
+    int32_t num_hidden_layers;
+    int32_t num_quantizers;
+    int32_t n_upsample_rates;
+    int32_t upsample_rates[8];
+    int32_t n_upsampling_ratios;
+    int32_t upsampling_ratios[8];
+    int32_t decoder_dim;
+    float rms_norm_eps;
+    float rope_theta;
+    /* engine options */
+    int32_t compute_dtype; /* QTTS_F32 | QTTS_BF16 */
+    int32_t max_batch;     /* largest B of one decode call                     */
+    int32_t max_frames;    /* largest frames per *chunk* (reference: 300 + 25) */
+} qtts_codec_config;
+
+int qtts_codec_create(const qtts_codec_config* cfg, qtts_codec** out);
+void qtts_codec_destroy(qtts_codec* c);
+
+/* Bind one parameter.  `name` is the reference state_dict key relative to `decoder.`
+ * (e.g. "quantizer.rvq_first.vq.layers.0._codebook.embedding_sum", "decoder.1.block.1.conv.weight").
+ * `host` points to HOST memory, row-major, `src_dtype` QTTS_F32 or QTTS_BF16.  The data is
+ * copied/repacked before the call returns. */
+int qtts_codec_bind(qtts_codec* c, const char* name, const void* host, int32_t src_dtype,
+                    int32_t ndim, const int64_t* shape);
+/* Verify every parameter is bound, precompute derived tables (normalised codebooks V2:677,
+ * exp(alpha), 1/(exp(beta)+1e-9) V2:608-613) and allocate workspaces. */
+int qtts_codec_finalize(qtts_codec* c);
+
+/* One un-chunked Qwen3TTSTokenizerV2Decoder.forward (V2:869-884).
+ * codes_dev: int64 (B, Q, T) device, values in [0, codebook_size).
+ * wav_dev:   float (B, T*total_upsample) device.
+ * pre_clamp_dev: optional float (B, T*total_upsample) device, the tensor before clamp(-1,1). */
+int qtts_codec_forward(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, float* wav_dev,
+                       float* pre_clamp_dev, void* stream);
+
+/* Qwen3TTSTokenizerV2Model.decode (V2:993-1024): codes_dev int64 (B, T, Q) device padded with -1,
+ * clamp(min=0), chunked_decode(chunk_size, left_context) (V2:886-896; reference defaults 300, 25),
+ * wav_dev float (B, T*total_upsample) device.  lengths_host (B) receives
+ * (#frames with code > -1) * total_upsample -- the caller trims, as V2:1017 does. */
+int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, int32_t chunk_size,
+                      int32_t left_context, float* wav_dev, int64_t* lengths_host, void* stream);
+
+/* Test/diagnostic hook: copy an intermediate stage of the LAST qtts_codec_forward to `out_dev`
+ * (channel-last float (B, L, C)); stage names: "rvq","pre_conv","pre_transformer","upsample0",
+ * "upsample1","decoder0","block1".."block4".  Returns rows*cols written via *n. */
+int qtts_codec_stage(qtts_codec* c, const char* stage, float* out_dev, int64_t cap, int64_t* L, int64_t* C,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Talker + code predictor: the autoregressive speech-token decoder.
+ * Replaces `self.talker.generate(inputs_embeds, attention_mask, trailing_text_hidden,
+ * tts_pad_embed, **talker_kwargs)` (modeling_qwen3_tts.py:2272-2278) = HF GenerationMixin._sample
+ * around Qwen3TTSTalkerForConditionalGeneration.forward (modeling_qwen3_tts.py:1636-1744) and its
+ * nested code_predictor.generate (modeling_qwen3_tts.py:1671-1680, 1250-1312).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct qtts_talker qtts_talker;
+
+typedef struct {
+    /* Qwen3TTSTalkerConfig (configuration_qwen3_tts.py:370-454) */
+    int32_t vocab_size;
+    int32_t hidden_size;
+    int32_t intermediate_size;
+    int32_t num_hidden_layers;
+    int32_t num_attention_heads;
+    int32_t num_key_value_heads;
+    int32_t head_dim;
+    float rms_norm_eps;
+    float rope_theta;
+    int32_t num_code_groups;
+    int32_t text_hidden_size;
+    int32_t codec_eos_token_id;
+    /* Qwen3TTSTalkerCodePredictorConfig (configuration_qwen3_tts.py:189-258) */
+    int32_t cp_vocab_size;
+    int32_t cp_hidden_size;
+    int32_t cp_intermediate_size;
+    int32_t cp_num_hidden_layers;
+    int32_t cp_num_attention_heads;
+    int32_t cp_num_key_value_heads;
+    int32_t cp_head_dim;
+    float cp_rms_norm_eps;
+    float cp_rope_theta;
+    /* engine options */
+    int32_t weight_dtype; /* QTTS_F32 | QTTS_BF16 (weights and KV cache)            */
+    int32_t max_batch;    /* sequences per generate call                              */
+    int32_t max_seq;      /* prompt + generated frames per sequence (KV pages reserved) */
+    int32_t use_graph;    /* 1: replay the frame step as a hipGraph; 0: eager launches  */
+} qtts_talker_config;
+
+/* HF sampling knobs (generation defaults: qwen_tts/inference/qwen3_tts_model.py:319-352). */
+typedef struct {
+    int32_t do_sample;
+    int32_t top_k;   /* 0 = off */
+    float top_p;     /* 1.0 = off */
+    float temperature;
+    float repetition_penalty;
+    int32_t subtalker_dosample;
+    int32_t subtalker_top_k;
+    float subtalker_top_p;
+    float subtalker_temperature;
+    uint64_t seed;   /* Philox key; torch's global-RNG stream cannot be reproduced across devices */
+} qtts_sampling;
+
+int qtts_talker_create(const qtts_talker_config* cfg, qtts_talker** out);
+void qtts_talker_destroy(qtts_talker* t);
+/* `name` = reference state_dict key relative to `talker.` (e.g. "model.layers.0.self_attn.q_proj.weight",
+ * "code_predictor.lm_head.3.weight").  Host pointer, row-major. */
+int qtts_talker_bind(qtts_talker* t, const char* name, const void* host, int32_t src_dtype, int32_t ndim,
+                     const int64_t* shape);
+int qtts_talker_finalize(qtts_talker* t);
+
+/* y = text_projection(x): Qwen3TTSTalkerResizeMLP (modeling_qwen3_tts.py:808-816,1575-1577), used by
+ * the prompt assembly (modeling_qwen3_tts.py:2076-2232).  x_dev float (rows, text_hidden) device,
+ * y_dev float (rows, hidden) device. */
+int qtts_talker_text_projection(qtts_talker* t, const float* x_dev, int32_t rows, float* y_dev, void* stream);
+
+/* Prefill (modeling_qwen3_tts.py:1665-1667, 1693-1727): embeds_dev float (B, T, H) LEFT-padded,
+ * n_pad_host (B) = number of left pads per row (attention_mask = [0]*n_pad + [1]*(T-n_pad),
+ * modeling_qwen3_tts.py:2251-2254), trailing_dev float (B, Tt, H) right-padded with tts_pad
+ * (modeling_qwen3_tts.py:2255-2269), tts_pad_dev float (H).  Fills the KV cache and leaves the
+ * first-step logits / past_hidden on device. */
+int qtts_talker_prefill(qtts_talker* t, const float* embeds_dev, int32_t B, int32_t T, const int32_t* n_pad_host,
+                        const float* trailing_dev, int32_t Tt, const float* tts_pad_dev, void* stream);
+
+/* The sampling loop after prefill, with HF `_sample` semantics:
+ *   processors RepetitionPenalty -> MinNewTokensLength(min_new_tokens, eos) -> SuppressTokens ->
+ *   [Temperature -> TopK -> TopP], finished rows keep receiving eos, stop when every row hit eos or
+ *   max_new_tokens tokens were drawn.
+ * suppress_host: list of suppressed token ids (modeling_qwen3_tts.py:2059-2063), n_suppress entries.
+ * codes_dev:  int64 (B, max_new_tokens-1, num_code_groups) device, row-major; frame f of row b holds
+ *             [cb0, 15 sub-codes] (modeling_qwen3_tts.py:1681); frames >= *n_frames_host are undefined.
+ * hidden_dev: optional float (B, max_new_tokens-1, H): `past_hidden` per frame (modeling_qwen3_tts.py:2281).
+ * tokens_dev: optional int64 (B, max_new_tokens): every sampled cb0 token incl. the final one.
+ * n_frames_host: number of complete frames (= HF steps - 1, modeling_qwen3_tts.py:2280).
+ * Synchronises the stream before returning. */
+int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_new_tokens, int32_t min_new_tokens,
+                         int32_t eos_token_id, const int32_t* suppress_host, int32_t n_suppress,
+                         int64_t* codes_dev, float* hidden_dev, int64_t* tokens_dev, int32_t* n_frames_host,
+                         void* stream);
+
+/* Test/diagnostic hooks (device -> caller device buffers, after prefill / a generate call). */
+int qtts_talker_debug_logits(qtts_talker* t, float* logits_dev /* (B, vocab) */, void* stream);
+
+/* Per-call statistics of the last generate (for bench.py): kernel-side byte model inputs. */
+typedef struct {
+    int32_t frames_run;       /* frame steps executed on device (>= n_frames, poll granularity)   */
+    int32_t graph_nodes;      /* kernel nodes in the captured frame step (0 if eager)              */
+    double weight_bytes_per_frame; /* bytes of packed weights one frame step streams              */
+    double gemm_ms_last;      /* HIP-event time of the dominant kernel class over the call, if enabled */
+    int64_t gemm_launches_last;
+} qtts_talker_stats;
+int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
+/* Enable per-launch HIP-event timing of the dominant kernel (skinny weight-streaming GEMM) in
+ * eager mode; used by bench.py's roofline leg only. */
+int qtts_talker_set_profile(qtts_talker* t, int32_t enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QTTS_H */

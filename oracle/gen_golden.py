@@ -1,0 +1,406 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+Generates tests/golden/*.npz by running the UNMODIFIED reference modules
+(/root/reference/qwen_tts, via oracle/ref_shims.py) on seeded synthetic weights
+(oracle/synth.py).  Runs only in the build container (the reference tree is absent
+on the GPU box); the fixtures it writes are committed.
+
+    python oracle/gen_golden.py [--only codec_tiny,codec_real,talker_tiny,talker_06b,talker_17b,prompt_tiny]
+
+What drives what:
+  * codec:  Qwen3TTSTokenizerV2Decoder.forward / .chunked_decode (V2:869-896) and the body of
+            Qwen3TTSTokenizerV2Model.decode (V2:993-1024) called unbound on a stand-in `self`
+            (so the Mimi encoder never has to be built).
+  * talker: Qwen3TTSTalkerForConditionalGeneration.forward (M:1636-1744) incl. its nested
+            `code_predictor.generate` (runs unmodified), driven by a hand-written HF-4.57.3
+            `_sample` loop (the installed transformers 5.x outer loop no longer passes
+            `cache_position`) -- `restated_sample_loop` below.
+  * prompt: Qwen3TTSForConditionalGeneration.generate (M:2022-2292) with `talker.generate`
+            replaced by a recorder, so the embeddings / mask / trailing text it assembles are pinned.
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+import synth  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def _load(module, w, prefix=""):
+    import torch
+    sd = module.state_dict()
+    new = {}
+    for k in sd:
+        kk = k[len(prefix):] if prefix and k.startswith(prefix) else k
+        if kk in w:
+            new[k] = torch.from_numpy(w[kk])
+    missing = [k for k in sd if k not in new]
+    assert not missing, f"synthetic weights do not cover: {missing[:8]}"
+    module.load_state_dict(new, strict=True)
+
+
+# ----------------------------------------------------------------------------- codec
+def ref_codec_decoder(c: synth.CodecCfg, w):
+    ref_shims.install()
+    from qwen_tts.core.tokenizer_12hz.configuration_qwen3_tts_tokenizer_v2 import Qwen3TTSTokenizerV2DecoderConfig
+    from qwen_tts.core.tokenizer_12hz.modeling_qwen3_tts_tokenizer_v2 import Qwen3TTSTokenizerV2Decoder
+    cfg = Qwen3TTSTokenizerV2DecoderConfig(
+        codebook_size=c.codebook_size, codebook_dim=c.codebook_dim, hidden_size=c.hidden_size,
+        latent_dim=c.latent_dim, num_attention_heads=c.num_attention_heads,
+        num_key_value_heads=c.num_key_value_heads, head_dim=c.head_dim, sliding_window=c.sliding_window,
+        intermediate_size=c.intermediate_size, num_hidden_layers=c.num_hidden_layers,
+        num_quantizers=c.num_quantizers, upsample_rates=c.upsample_rates,
+        upsampling_ratios=c.upsampling_ratios, decoder_dim=c.decoder_dim, rms_norm_eps=c.rms_norm_eps,
+        rope_theta=c.rope_theta, max_position_embeddings=c.max_position_embeddings)
+    cfg._attn_implementation = "eager"
+    m = Qwen3TTSTokenizerV2Decoder(cfg).eval()
+    _load(m, w)
+    return m
+
+
+def ref_model_decode(dec, c, audio_codes):
+    """Run the reference's Qwen3TTSTokenizerV2Model.decode body (V2:993-1024) on a stand-in self."""
+    from qwen_tts.core.tokenizer_12hz.modeling_qwen3_tts_tokenizer_v2 import Qwen3TTSTokenizerV2Model
+    fake = types.SimpleNamespace(config=types.SimpleNamespace(return_dict=True),
+                                 decode_upsample_rate=c.total_upsample, decoder=dec)
+    return Qwen3TTSTokenizerV2Model.decode(fake, audio_codes).audio_values
+
+
+def gen_codec_tiny():
+    import torch
+    c = synth.codec_tiny()
+    w = synth.codec_weights(c)
+    dec = ref_codec_decoder(c, w)
+    g = np.random.default_rng(11)
+    out = {"weights_checksum": synth.weights_checksum(w)}
+    # (a) single forward, all stage outputs (hooks on the reference's own submodules)
+    codes = torch.from_numpy(g.integers(0, c.codebook_size, (1, c.num_quantizers, 6)))   # small: every stage is stored
+    stages = {}
+    hooks = []
+
+    def hook(name):
+        return lambda mod, inp, o: stages.__setitem__(name, (o.last_hidden_state if hasattr(o, "last_hidden_state") else o).detach().clone())
+    hooks.append(dec.pre_conv.register_forward_hook(hook("pre_conv")))
+    hooks.append(dec.pre_transformer.register_forward_hook(hook("pre_transformer_btc")))
+    for u in range(len(c.upsampling_ratios)):
+        hooks.append(dec.upsample[u][1].register_forward_hook(hook(f"upsample{u}")))
+    hooks.append(dec.decoder[0].register_forward_hook(hook("decoder0")))
+    for i in range(len(c.upsample_rates)):
+        hooks.append(dec.decoder[i + 1].register_forward_hook(hook(f"block{i + 1}")))
+    hooks.append(dec.decoder[-1].register_forward_hook(hook("pre_clamp")))
+    with torch.no_grad():
+        rvq = dec.quantizer.decode(codes)
+        wav = dec(codes)
+    for h in hooks:
+        h.remove()
+    out["fwd_codes"] = codes.numpy()
+    out["fwd_rvq"] = rvq.numpy()
+    out["fwd_wav"] = wav.numpy()
+    for k, v in stages.items():
+        out["fwd_" + k] = v.numpy()
+    # (b) chunked decode with a small chunk so several boundaries are crossed (V2:886-896 takes the sizes as args)
+    codes2 = torch.from_numpy(g.integers(0, c.codebook_size, (2, c.num_quantizers, 41)))
+    with torch.no_grad():
+        out["chunk_codes"] = codes2.numpy()
+        out["chunk_wav_16_5"] = dec.chunked_decode(codes2, chunk_size=16, left_context_size=5).numpy()
+        out["chunk_wav_default"] = dec.chunked_decode(codes2).numpy()
+    # (c) model.decode on a ragged, -1 padded batch (V2:993-1024)
+    lens = [13, 4, 19]
+    ac = torch.full((3, max(lens), c.num_quantizers), -1, dtype=torch.long)
+    for i, l in enumerate(lens):
+        ac[i, :l] = torch.from_numpy(g.integers(0, c.codebook_size, (l, c.num_quantizers)))
+    with torch.no_grad():
+        wavs = ref_model_decode(dec, c, ac)
+    out["ragged_codes"] = ac.numpy()
+    for i, a in enumerate(wavs):
+        out[f"ragged_wav{i}"] = a.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "codec_tiny.npz"), **out)
+    print("codec_tiny:", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+def gen_codec_real():
+    import torch
+    c = synth.codec_real()
+    w = synth.codec_weights(c)
+    dec = ref_codec_decoder(c, w)
+    g = np.random.default_rng(11)
+    out = {"weights_checksum": synth.weights_checksum(w)}
+    # BASELINE config 2: 10 s = 125 frames of random codes, B=1
+    codes = torch.from_numpy(g.integers(0, c.codebook_size, (1, 125, c.num_quantizers)))
+    t = time.time()
+    with torch.no_grad():
+        wav = ref_model_decode(dec, c, codes)[0]
+    out["t125_seconds_ref_cpu"] = time.time() - t
+    out["t125_codes"] = codes.numpy().astype(np.int16)
+    out["t125_wav"] = wav.numpy()
+    # two-chunk path (325 frames > 300): keep the region around the chunk seam + a strided sample
+    codes2 = torch.from_numpy(g.integers(0, c.codebook_size, (1, 325, c.num_quantizers)))
+    with torch.no_grad():
+        wav2 = ref_model_decode(dec, c, codes2)[0].numpy()
+    seam = 300 * c.total_upsample
+    out["t325_codes"] = codes2.numpy().astype(np.int16)
+    out["t325_seam_lo"] = seam - 4096
+    out["t325_seam"] = wav2[seam - 4096: seam + 8192]
+    out["t325_stride"] = 61
+    out["t325_strided"] = wav2[::61]
+    out["t325_sum"] = float(wav2.astype(np.float64).sum())
+    out["t325_len"] = wav2.shape[0]
+    np.savez_compressed(os.path.join(GOLDEN, "codec_real.npz"), **out)
+    print("codec_real: ref cpu 125 frames %.2fs" % out["t125_seconds_ref_cpu"], wav.shape, wav2.shape)
+
+
+# ----------------------------------------------------------------------------- talker
+def ref_talker_cfgs(t: synth.TalkerCfg):
+    ref_shims.install()
+    from qwen_tts.core.models.configuration_qwen3_tts import Qwen3TTSTalkerConfig, Qwen3TTSConfig
+    hd2 = t.head_dim // 2
+    sec = [hd2 - 2 * (hd2 // 3), hd2 // 3, hd2 // 3]
+    cp = dict(vocab_size=t.cp_vocab_size, hidden_size=t.cp_hidden_size, intermediate_size=t.cp_intermediate_size,
+              num_hidden_layers=t.cp_num_hidden_layers, num_attention_heads=t.cp_num_attention_heads,
+              num_key_value_heads=t.cp_num_key_value_heads, head_dim=t.cp_head_dim,
+              rms_norm_eps=t.cp_rms_norm_eps, rope_theta=t.cp_rope_theta, num_code_groups=t.num_code_groups,
+              pad_token_id=None)
+    tk = dict(code_predictor_config=cp, vocab_size=t.vocab_size, hidden_size=t.hidden_size,
+              intermediate_size=t.intermediate_size, num_hidden_layers=t.num_hidden_layers,
+              num_attention_heads=t.num_attention_heads, num_key_value_heads=t.num_key_value_heads,
+              head_dim=t.head_dim, rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta,
+              rope_scaling={"rope_type": "default", "mrope_section": sec, "interleaved": True},
+              num_code_groups=t.num_code_groups, text_hidden_size=t.text_hidden_size,
+              text_vocab_size=t.text_vocab_size, codec_eos_token_id=t.codec_eos_token_id,
+              codec_think_id=t.codec_think_id, codec_nothink_id=t.codec_nothink_id,
+              codec_think_bos_id=t.codec_think_bos_id, codec_think_eos_id=t.codec_think_eos_id,
+              codec_pad_id=t.codec_pad_id, codec_bos_id=t.codec_bos_id, spk_id=t.spk_id,
+              spk_is_dialect=t.spk_is_dialect, codec_language_id=t.codec_language_id, pad_token_id=None)
+    return Qwen3TTSTalkerConfig, Qwen3TTSConfig, tk
+
+
+def ref_talker(t: synth.TalkerCfg, w):
+    from qwen_tts.core.models.modeling_qwen3_tts import Qwen3TTSTalkerForConditionalGeneration  # noqa
+    TalkerConfig, _, tk = ref_talker_cfgs(t)
+    from qwen_tts.core.models.modeling_qwen3_tts import Qwen3TTSTalkerForConditionalGeneration
+    cfg = TalkerConfig(**tk)
+    cfg._attn_implementation = "eager"
+    cfg.code_predictor_config._attn_implementation = "eager"
+    import torch
+    with torch.device("meta"):
+        m = Qwen3TTSTalkerForConditionalGeneration(cfg)
+    m = m.to_empty(device="cpu").eval()
+    # non-persistent rotary buffers are lost by to_empty: rebuild them
+    for mod in m.modules():
+        if hasattr(mod, "rope_init_fn") and hasattr(mod, "inv_freq"):
+            inv, _ = mod.rope_init_fn(mod.config, "cpu")
+            mod.inv_freq = inv
+            mod.original_inv_freq = inv
+    _load(m, w)
+    m.config._attn_implementation = "eager"
+    return m
+
+
+def restated_sample_loop(talker, t: synth.TalkerCfg, embeds, mask, trailing, tts_pad, max_new_tokens,
+                         min_new_tokens=2, eos_token_id=None, repetition_penalty=1.05, trace=None):
+    """Greedy HF-4.57.3 `_sample` around the REFERENCE talker.forward.
+    Processors restated from transformers generation/logits_process.py in `_get_logits_processor`
+    order: RepetitionPenalty -> MinNewTokensLength -> SuppressTokens; then argmax."""
+    import torch
+    eos = t.codec_eos_token_id if eos_token_id is None else eos_token_id
+    suppress = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != t.codec_eos_token_id]
+    B, T, _ = embeds.shape
+    talker.rope_deltas = None
+    o = talker(inputs_embeds=embeds, attention_mask=mask, use_cache=True, output_hidden_states=True,
+               trailing_text_hidden=trailing, tts_pad_embed=tts_pad)
+    generated = torch.zeros(B, 0, dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.long)
+    frames, hiddens = [], []
+    step = 0
+    while True:
+        s = o.logits[:, -1].float().clone()
+        if trace is not None:
+            trace.setdefault("logits", []).append(s.clone())
+        if generated.shape[1] > 0:
+            sc = torch.gather(s, 1, generated)
+            sc = torch.where(sc < 0, sc * repetition_penalty, sc / repetition_penalty)
+            s = s.scatter(1, generated, sc)
+        if generated.shape[1] < min_new_tokens:
+            s[:, eos] = float("-inf")
+        s[:, suppress] = float("-inf")
+        if trace is not None:
+            top2 = torch.topk(s, 2, dim=-1)[0]
+            trace.setdefault("margin", []).append((top2[:, 0] - top2[:, 1]).clone())
+        tok = torch.argmax(s, dim=-1)
+        tok = tok * unfinished + eos * (1 - unfinished)
+        generated = torch.cat((generated, tok[:, None]), dim=1)
+        unfinished = unfinished & (tok != eos).long()
+        if generated.shape[1] >= max_new_tokens or unfinished.max() == 0:
+            break
+        mask = torch.cat([mask, mask.new_ones(B, 1)], 1)
+        hiddens.append(o.past_hidden[:, 0])
+        o = talker(input_ids=tok[:, None], attention_mask=mask, past_key_values=o.past_key_values, use_cache=True,
+                   cache_position=torch.tensor([T + step]), past_hidden=o.past_hidden,
+                   generation_step=o.generation_step, trailing_text_hidden=trailing, tts_pad_embed=tts_pad,
+                   output_hidden_states=True, subtalker_dosample=False, subtalker_top_k=None,
+                   subtalker_top_p=None, subtalker_temperature=None)
+        frames.append(o.hidden_states[1])
+        step += 1
+    codes = torch.stack(frames, dim=1) if frames else torch.zeros(B, 0, t.num_code_groups, dtype=torch.long)
+    hidden = torch.stack(hiddens, dim=1) if hiddens else torch.zeros(B, 0, embeds.shape[-1])
+    return codes, generated, hidden
+
+
+def _rand_prompt(g, t, lens, n_trail, scale=0.05):
+    """Synthetic S2-seam inputs: ragged left-padded embeds, mask, trailing text, tts_pad."""
+    import torch
+    B, Tm, H = len(lens), max(lens), t.hidden_size
+    emb = np.zeros((B, Tm, H), np.float32)
+    mask = np.zeros((B, Tm), np.int64)
+    for i, l in enumerate(lens):
+        emb[i, Tm - l:] = g.standard_normal((l, H), dtype=np.float32) * scale
+        mask[i, Tm - l:] = 1
+    trailing = g.standard_normal((B, n_trail, H), dtype=np.float32) * scale
+    pad = g.standard_normal((1, 1, H), dtype=np.float32) * scale
+    return torch.from_numpy(emb), torch.from_numpy(mask), torch.from_numpy(trailing), torch.from_numpy(pad)
+
+
+def gen_talker_tiny():
+    import torch
+    t = synth.talker_tiny()
+    w = synth.talker_weights(t)
+    talker = ref_talker(t, w)
+    g = np.random.default_rng(21)
+    out = {"weights_checksum": synth.weights_checksum(w)}
+    emb, mask, trailing, pad = _rand_prompt(g, t, [9, 14, 5], 4, scale=0.5)
+    with torch.no_grad():
+        tr = {}
+        codes, toks, hidden = restated_sample_loop(talker, t, emb, mask, trailing, pad, max_new_tokens=14, trace=tr)
+        # EOS handling: re-run with eos := row 0's 6th token so that row finishes early while others go on
+        eos2 = int(toks[0, 5])
+        codes2, toks2, hidden2 = restated_sample_loop(talker, t, emb, mask, trailing, pad, max_new_tokens=14,
+                                                      eos_token_id=eos2)
+    out.update(embeds=emb.numpy(), mask=mask.numpy(), trailing=trailing.numpy(), tts_pad=pad.numpy(),
+               codes=codes.numpy(), tokens=toks.numpy(), hidden=hidden.numpy(),
+               logits=torch.stack(tr["logits"], 1).numpy(), margin=torch.stack(tr["margin"], 1).numpy(),
+               eos2=eos2, codes_eos2=codes2.numpy(), tokens_eos2=toks2.numpy())
+    np.savez_compressed(os.path.join(GOLDEN, "talker_tiny.npz"), **out)
+    print("talker_tiny: codes", codes.shape, "eos2", eos2, "tokens_eos2", toks2.tolist())
+
+
+def _gen_talker_real(name, t, lens, n_trail, max_new, seed):
+    import torch
+    w = synth.talker_weights(t, with_text=False)
+    t0 = time.time()
+    # the reference module still owns text_embedding / text_projection parameters: fill the unused ones with zeros
+    shapes = synth.talker_param_shapes(t, with_text=True)
+    wz = dict(w)
+    # keep RAM bounded: a 1-row stand-in cannot be loaded strictly, so build the module with a small text vocab
+    t_small = synth.TalkerCfg(**{**synth.cfg_dict(t), "text_vocab_size": 8})
+    for k, shp in synth.talker_param_shapes(t_small, with_text=True).items():
+        if k not in wz:
+            wz[k] = np.zeros(shp, np.float32)
+    talker = ref_talker(t_small, wz)
+    g = np.random.default_rng(seed)
+    emb, mask, trailing, pad = _rand_prompt(g, t, lens, n_trail, scale=0.05)
+    tr = {}
+    t1 = time.time()
+    with torch.no_grad():
+        codes, toks, hidden = restated_sample_loop(talker, t, emb, mask, trailing, pad, max_new_tokens=max_new, trace=tr)
+    dt = time.time() - t1
+    out = {"weights_checksum": synth.weights_checksum(w), "lens": np.array(lens), "n_trail": n_trail,
+           "seed": seed, "max_new": max_new, "codes": codes.numpy(), "tokens": toks.numpy(),
+           "margin": torch.stack(tr["margin"], 1).numpy(), "logits0": tr["logits"][0].numpy(),
+           "hidden_last": hidden[:, -1].numpy(), "ref_cpu_seconds": dt,
+           "ref_cpu_threads": torch.get_num_threads()}
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
+    print(f"{name}: codes {tuple(codes.shape)} ref cpu loop {dt:.1f}s (build {t1 - t0:.1f}s) min margin {out['margin'].min():.5f}")
+
+
+def gen_talker_06b():
+    # BASELINE config 1: 0.6B dims, 1 utterance, greedy, 64 new tokens (-> 63 frames)
+    _gen_talker_real("talker_06b", synth.talker_06b(), [61], 1, 64, 7)
+
+
+def gen_talker_17b():
+    # bench dims (1.7B), ragged batch of 3, short
+    _gen_talker_real("talker_17b", synth.talker_17b(), [40, 52, 33], 6, 20, 8)
+
+
+def gen_prompt_tiny():
+    """Pin the prompt assembly (M:2068-2269) by recording what generate() hands to talker.generate."""
+    import torch
+    t = synth.talker_tiny()
+    w = synth.talker_weights(t)
+    TalkerConfig, TopConfig, tk = ref_talker_cfgs(t)
+    from qwen_tts.core.models.modeling_qwen3_tts import Qwen3TTSForConditionalGeneration
+    top = TopConfig(talker_config=tk, tts_model_type="custom_voice", tts_model_size="tiny", tokenizer_type="12hz",
+                    im_start_token_id=t.im_start_token_id, im_end_token_id=t.im_end_token_id,
+                    tts_pad_token_id=t.tts_pad_token_id, tts_bos_token_id=t.tts_bos_token_id,
+                    tts_eos_token_id=t.tts_eos_token_id)
+    top.talker_config._attn_implementation = "eager"
+    top.talker_config.code_predictor_config._attn_implementation = "eager"
+    model = Qwen3TTSForConditionalGeneration(top).eval()
+    _load(model.talker, w)
+    g = np.random.default_rng(31)
+    rec = {}
+
+    class Stop(Exception):
+        pass
+
+    def recorder(**kw):
+        rec.update(kw)
+        raise Stop()
+    model.talker.generate = recorder
+    out = {"weights_checksum": synth.weights_checksum(w)}
+    a, n = 77, 198
+    cases = {
+        "cv_ns": dict(non_streaming_mode=True, speakers=["vivian", "ryan", "vivian"], languages=["chinese", "english", "auto"], instruct=[None, 6, None]),
+        "cv_st": dict(non_streaming_mode=False, speakers=["vivian", "ryan", "vivian"], languages=["chinese", "english", "auto"], instruct=[None, 6, None]),
+        "vd_st": dict(non_streaming_mode=False, speakers=None, languages=["auto", "english"], instruct=[5, 9]),
+    }
+    for cname, cs in cases.items():
+        B = len(cs["languages"])
+        ids, ins = [], []
+        for i in range(B):
+            body = g.integers(0, 490, (int(g.integers(6, 14)),)).tolist()
+            ids.append(torch.tensor([[t.im_start_token_id, a, n] + body + [t.im_end_token_id, n, t.im_start_token_id, a, n]]))
+            k = cs["instruct"][i]
+            ins.append(None if k is None else torch.tensor([[t.im_start_token_id] + g.integers(0, 490, (k,)).tolist() + [t.im_end_token_id, n]]))
+        try:
+            model.generate(input_ids=ids, instruct_ids=ins, languages=cs["languages"], speakers=cs["speakers"],
+                           non_streaming_mode=cs["non_streaming_mode"], do_sample=False, subtalker_dosample=False)
+        except Stop:
+            pass
+        for i in range(B):
+            out[f"{cname}_ids{i}"] = ids[i].numpy()
+            if ins[i] is not None:
+                out[f"{cname}_ins{i}"] = ins[i].numpy()
+        out[f"{cname}_embeds"] = rec["inputs_embeds"].detach().numpy()
+        out[f"{cname}_mask"] = rec["attention_mask"].numpy()
+        out[f"{cname}_trailing"] = rec["trailing_text_hidden"].detach().numpy()
+        out[f"{cname}_tts_pad"] = rec["tts_pad_embed"].detach().numpy()
+        out[f"{cname}_suppress"] = np.array(rec["suppress_tokens"])
+        out[f"{cname}_eos"] = rec["eos_token_id"]
+        out[f"{cname}_min_new"] = rec["min_new_tokens"]
+        print(cname, rec["inputs_embeds"].shape, rec["trailing_text_hidden"].shape)
+    np.savez_compressed(os.path.join(GOLDEN, "prompt_tiny.npz"), **out)
+
+
+ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
+       "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=",".join(ALL))
+    args = ap.parse_args()
+    os.makedirs(GOLDEN, exist_ok=True)
+    import torch
+    torch.set_num_threads(os.cpu_count())
+    for k in args.only.split(","):
+        t = time.time()
+        ALL[k]()
+        print(f"[{k}] done in {time.time() - t:.1f}s")

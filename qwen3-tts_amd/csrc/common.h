@@ -1,0 +1,108 @@
+// common.h -- shared device/host helpers for libqtts (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <stdexcept>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+
+#include "../../include/qtts.h"
+
+namespace qtts {
+
+// ------------------------------------------------------------------------------------------ errors
+void set_last_error(const std::string& s);
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define QTTS_CHECK_HIP(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            throw ::qtts::Error(QTTS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define QTTS_REQUIRE(cond, code, msg)                                  \
+    do {                                                               \
+        if (!(cond)) throw ::qtts::Error((code), std::string(msg));    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ bf16
+typedef uint16_t bf16_t;
+
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(bf16_t h) {
+    union { float f; uint32_t u; } v;
+    v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));  // 8 bf16 = 4 VGPRs (MFMA operand type)
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------ device memory
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        QTTS_CHECK_HIP(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void ensure(size_t n) { if (n > bytes) alloc(n); }
+    void upload(const void* host, size_t n) {
+        ensure(n);
+        QTTS_CHECK_HIP(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// host-side source tensor view (bind)
+struct HostTensor {
+    const void* data;
+    int dtype;  // QTTS_F32 | QTTS_BF16
+    std::vector<int64_t> shape;
+    int64_t numel() const { int64_t n = 1; for (auto s : shape) n *= s; return n; }
+    float at(int64_t i) const {
+        return dtype == QTTS_F32 ? ((const float*)data)[i] : bf16_to_f32(((const bf16_t*)data)[i]);
+    }
+    std::vector<float> to_f32() const {
+        std::vector<float> v((size_t)numel());
+        if (dtype == QTTS_F32) memcpy(v.data(), data, v.size() * 4);
+        else for (size_t i = 0; i < v.size(); ++i) v[i] = bf16_to_f32(((const bf16_t*)data)[i]);
+        return v;
+    }
+};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace qtts

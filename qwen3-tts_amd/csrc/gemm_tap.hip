@@ -1,0 +1,262 @@
+// gemm_tap.hip -- LDS-tiled MFMA "tap GEMM" for gfx950.
+//
+//   C[m, n] = epi( sum_{tap} sum_{k} A[row(m, tap), k] * W[tap][n][k] )
+//
+// with row(m, tap) = m + shift[tap] (shift <= 0) and a zero row whenever the shifted row would
+// leave the sequence the output row belongs to ((m % T) + shift < 0): exactly the causal left
+// padding of Qwen3TTSTokenizerV2CausalConvNet (tokenizer v2:189-192).  Activations are kept
+// CHANNEL-LAST ([rows = batch*time][channels]) so that the contraction dimension is contiguous for
+// both MFMA operands; in that layout
+//   * nn.Linear                      = 1 tap, shift 0, W = weight (out,in) as stored
+//   * causal Conv1d(k, dilation d)   = k taps, shift_j = -(k-1-j)*d, W[j] = weight[:, :, j]
+//   * ConvTranspose1d(2r, stride r) then trim r (tokenizer v2:204-208)
+//                                    = 2 taps (shift 0 / -1), N = r*Cout (output row m holds the r
+//                                      upsampled positions m*r .. m*r+r-1), W[0][p*Cout+co] =
+//                                      weight[:, co, p], W[1][p*Cout+co] = weight[:, co, p+r]
+// so one kernel covers ~96 % of the codec decoder's FLOPs and all of the talker prefill GEMMs.
+//
+// Tiling: 128 x BN block tile, BK = 32, 256 threads = 4 waves (2x2), each wave owns 64 x BN/2 as
+// 4 x BN/32 MFMA 16x16 tiles.  F32 mode uses v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chain,
+// 157 TF peak), BF16 mode v_mfma_f32_16x16x32_bf16 (A converted fp32->bf16 while staging).
+// Global -> registers -> LDS staging with the next tile's loads in flight during the MFMAs.
+#include <type_traits>
+#include "common.h"
+#include "kernels.h"
+
+namespace qtts {
+
+template <int BN, bool BF16>
+__global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
+    constexpr int BM = 128, BK = 32;
+    constexpr int TM = 4, TN = BN / 32;
+    constexpr int LDS_STRIDE = BF16 ? 40 : 36;  // elements per LDS row (pad keeps 16-B alignment)
+    using elem_t = typename std::conditional<BF16, bf16_t, float>::type;
+    __shared__ __attribute__((aligned(16))) elem_t As[BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) elem_t Ws[BN * LDS_STRIDE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // XCD-aware tile order: consecutive remapped ids share the A row-panel, and each XCD (bid % 8)
+    // works on a contiguous range of tiles so the panel is fetched into ONE L2.
+    const int n_tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / n_tiles_n) * BM;
+    const int n0 = (bid % n_tiles_n) * BN;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ksteps = p.K / BK;
+    const int nsteps = ksteps * p.taps;
+
+    // staging registers
+    float4 ra[4];
+    constexpr int WREG = BF16 ? (BN * 4 + 255) / 256 : (BN * 8 + 255) / 256;
+    uint4 rw[WREG];
+
+    const int a_c4 = tid & 7;    // float4 column within the 32-wide k slab
+    const int a_r = tid >> 3;    // 0..31 (+32*i)
+    int a_t[4];                  // position of the row inside its sequence (for tap validity)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_t[i] = (m0 + a_r + 32 * i) % p.T;
+
+    auto load_tiles = [&](int s) {
+        const int tap = s / ksteps;
+        const int k0 = (s - tap * ksteps) * BK;
+        const int sh = p.shift[tap];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + a_r + 32 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M && a_t[i] + sh >= 0)
+                v = *reinterpret_cast<const float4*>(p.A + (size_t)(m + sh) * p.lda + k0 + a_c4 * 4);
+            ra[i] = v;
+        }
+        if constexpr (BF16) {
+            const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W) + (size_t)tap * p.N * p.K;
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 2, c = idx & 3;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r < BN && n0 + r < p.N)
+                    v = *reinterpret_cast<const uint4*>(W + (size_t)(n0 + r) * p.K + k0 + c * 8);
+                rw[i] = v;
+            }
+        } else {
+            const float* W = reinterpret_cast<const float*>(p.W) + (size_t)tap * p.N * p.K;
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 3, c = idx & 7;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r < BN && n0 + r < p.N)
+                    v = *reinterpret_cast<const uint4*>(W + (size_t)(n0 + r) * p.K + k0 + c * 4);
+                rw[i] = v;
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+        if constexpr (BF16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ushort4 h;
+                h.x = f32_to_bf16(ra[i].x); h.y = f32_to_bf16(ra[i].y);
+                h.z = f32_to_bf16(ra[i].z); h.w = f32_to_bf16(ra[i].w);
+                *reinterpret_cast<ushort4*>(&As[(a_r + 32 * i) * LDS_STRIDE + a_c4 * 4]) = h;
+            }
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 2, c = idx & 3;
+                if (r < BN) *reinterpret_cast<uint4*>(&Ws[r * LDS_STRIDE + c * 8]) = rw[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(&As[(a_r + 32 * i) * LDS_STRIDE + a_c4 * 4]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < WREG; ++i) {
+                const int idx = tid + 256 * i;
+                const int r = idx >> 3, c = idx & 7;
+                if (r < BN) *reinterpret_cast<uint4*>(&Ws[r * LDS_STRIDE + c * 4]) = rw[i];
+            }
+        }
+    };
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) load_tiles(s + 1);  // global loads stay in flight under the MFMAs
+        if constexpr (BF16) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 16 + li) * LDS_STRIDE + lq * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(&Ws[(wn * (BN / 2) + j * 16 + li) * LDS_STRIDE + lq * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + i * 16 + li) * LDS_STRIDE + kk * 16 + lq * 4]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const f32x4*>(&Ws[(wn * (BN / 2) + j * 16 + li) * LDS_STRIDE + kk * 16 + lq * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (s + 1 < nsteps) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // acc[i][j][r] = C[m0 + wm*64 + i*16 + lq*4 + r][n0 + wn*BN/2 + j*16 + li]
+    if (p.act == ACT_SWIGLU) {
+        // W rows come in 16-row blocks alternating gate / up for the same 16 features, so tiles
+        // (j, j+1) of one wave hold gate/up of the same output columns in the same lane/register.
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int n_packed = n0 + wn * (BN / 2) + j * 16 + li;
+                    const int no = (n_packed / 32) * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
+                        if (m < p.M && n_packed < p.N) {
+                            const float g = acc[i][j][r], u = acc[i][j + 1][r];
+                            p.C[(size_t)m * p.ldc + no] = (g / (1.f + expf(-g))) * u;
+                        }
+                    }
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + li;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            const float scale = p.scale ? p.scale[n] : 1.f;
+            float ea = 0.f, ib = 0.f;
+            if (p.act == ACT_SNAKE) { ea = p.snake_ea[n]; ib = p.snake_ib[n]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                else if (p.act == ACT_SNAKE) { const float sn = sinf(v * ea); v = v + ib * (sn * sn); }
+                v *= scale;
+                if (p.res) v += p.res[(size_t)m * p.ldr + n];
+                p.C[(size_t)m * p.ldc + n] = v;
+            }
+        }
+}
+
+template <int BN, bool BF16>
+static void launch_t(const GemmTapParams& p, hipStream_t st) {
+    const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_tap_kernel<BN, BF16>), dim3(nb), dim3(256), 0, st, p);
+}
+
+void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st) {
+    QTTS_REQUIRE(p.K % 32 == 0, QTTS_ERR_ARG, "gemm_tap: K must be a multiple of 32");
+    QTTS_REQUIRE(p.taps >= 1 && p.taps <= 8, QTTS_ERR_ARG, "gemm_tap: 1..8 taps");
+    QTTS_REQUIRE(p.M > 0 && p.N > 0, QTTS_ERR_ARG, "gemm_tap: empty problem");
+    QTTS_REQUIRE(p.lda % 4 == 0, QTTS_ERR_ARG, "gemm_tap: lda must be a multiple of 4");
+    int bn;
+    if (p.act == ACT_SWIGLU) {
+        QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "gemm_tap: swiglu needs N % 32 == 0");
+        bn = (p.N % 128 == 0) ? 128 : 64;
+    } else if (p.N % 128 == 0) bn = 128;
+    else if (p.N % 96 == 0) bn = 96;
+    else if (p.N <= 64) bn = 64;
+    else bn = 128;
+    if (bf16) {
+        if (bn == 128) launch_t<128, true>(p, st);
+        else if (bn == 96) launch_t<96, true>(p, st);
+        else launch_t<64, true>(p, st);
+    } else {
+        if (bn == 128) launch_t<128, false>(p, st);
+        else if (bn == 96) launch_t<96, false>(p, st);
+        else launch_t<64, false>(p, st);
+    }
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace qtts
