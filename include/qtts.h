@@ -105,11 +105,11 @@ int qtts_codec_forward(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32
 int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, int32_t chunk_size,
                       int32_t left_context, float* wav_dev, int64_t* lengths_host, void* stream);
 
-/* Test/diagnostic hook: copy an intermediate stage of the LAST qtts_codec_forward to `out_dev`
- * (channel-last float (B, L, C)); stage names: "rvq","pre_conv","pre_transformer","upsample0",
- * "upsample1","decoder0","block1".."block4".  Returns rows*cols written via *n. */
-int qtts_codec_stage(qtts_codec* c, const char* stage, float* out_dev, int64_t cap, int64_t* L, int64_t* C,
-                     void* stream);
+/* Test/diagnostic hook: run Qwen3TTSTokenizerV2Decoder.forward on codes_dev (B, Q, T) up to and including
+ * `stage` and copy that stage's activation, channel-last float (B, L, C), to out_dev (capacity `cap` floats).
+ * Stage names: "rvq","pre_conv","pre_transformer","upsample0","upsample1","decoder0","block1".."block4". */
+int qtts_codec_forward_stage(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, const char* stage,
+                             float* out_dev, int64_t cap, int64_t* L, int64_t* C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Talker + code predictor: the autoregressive speech-token decoder.

@@ -1,0 +1,125 @@
+"""ctypes binding of libqtts.so (include/qtts.h).  The product path has NO fallback: if the HIP
+library is missing or a call fails, a QttsError is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+QTTS_F32, QTTS_BF16 = 0, 1
+
+
+class QttsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libqtts error {code}: {msg}")
+        self.code = code
+
+
+class CodecConfigC(C.Structure):
+    _fields_ = [("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("hidden_size", C.c_int32),
+                ("latent_dim", C.c_int32), ("num_attention_heads", C.c_int32), ("num_key_value_heads", C.c_int32),
+                ("head_dim", C.c_int32), ("sliding_window", C.c_int32), ("intermediate_size", C.c_int32),
+                ("num_hidden_layers", C.c_int32), ("num_quantizers", C.c_int32), ("n_upsample_rates", C.c_int32),
+                ("upsample_rates", C.c_int32 * 8), ("n_upsampling_ratios", C.c_int32),
+                ("upsampling_ratios", C.c_int32 * 8), ("decoder_dim", C.c_int32), ("rms_norm_eps", C.c_float),
+                ("rope_theta", C.c_float), ("compute_dtype", C.c_int32), ("max_batch", C.c_int32),
+                ("max_frames", C.c_int32)]
+
+
+class TalkerConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32),
+                ("num_hidden_layers", C.c_int32), ("num_attention_heads", C.c_int32),
+                ("num_key_value_heads", C.c_int32), ("head_dim", C.c_int32), ("rms_norm_eps", C.c_float),
+                ("rope_theta", C.c_float), ("num_code_groups", C.c_int32), ("text_hidden_size", C.c_int32),
+                ("codec_eos_token_id", C.c_int32), ("cp_vocab_size", C.c_int32), ("cp_hidden_size", C.c_int32),
+                ("cp_intermediate_size", C.c_int32), ("cp_num_hidden_layers", C.c_int32),
+                ("cp_num_attention_heads", C.c_int32), ("cp_num_key_value_heads", C.c_int32),
+                ("cp_head_dim", C.c_int32), ("cp_rms_norm_eps", C.c_float), ("cp_rope_theta", C.c_float),
+                ("weight_dtype", C.c_int32), ("max_batch", C.c_int32), ("max_seq", C.c_int32),
+                ("use_graph", C.c_int32)]
+
+
+class SamplingC(C.Structure):
+    _fields_ = [("do_sample", C.c_int32), ("top_k", C.c_int32), ("top_p", C.c_float), ("temperature", C.c_float),
+                ("repetition_penalty", C.c_float), ("subtalker_dosample", C.c_int32),
+                ("subtalker_top_k", C.c_int32), ("subtalker_top_p", C.c_float),
+                ("subtalker_temperature", C.c_float), ("seed", C.c_uint64)]
+
+
+class TalkerStatsC(C.Structure):
+    _fields_ = [("frames_run", C.c_int32), ("graph_nodes", C.c_int32), ("weight_bytes_per_frame", C.c_double),
+                ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64)]
+
+
+# every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
+SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
+           "qtts_codec_finalize", "qtts_codec_forward", "qtts_codec_decode", "qtts_codec_forward_stage",
+           "qtts_talker_create", "qtts_talker_destroy", "qtts_talker_bind", "qtts_talker_finalize",
+           "qtts_talker_text_projection", "qtts_talker_prefill", "qtts_talker_generate",
+           "qtts_talker_debug_logits", "qtts_talker_get_stats", "qtts_talker_set_profile"]
+
+
+def library_path() -> str:
+    return os.environ.get("QTTS_LIBRARY", os.path.join(_HERE, "libqtts.so"))
+
+
+def load_library():
+    """Load libqtts.so; raises QttsError (never falls back to anything) when it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise QttsError(-100, f"{path} not found -- run `python qwen3-tts_amd/build.py` (or __graft_entry__.build())")
+    lib = C.CDLL(path)
+    vp, i32, i64p, f32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p
+    lib.qtts_last_error.restype = C.c_char_p
+    lib.qtts_abi_version.restype = C.c_int
+    lib.qtts_codec_create.argtypes = [C.POINTER(CodecConfigC), C.POINTER(vp)]
+    lib.qtts_codec_destroy.argtypes = [vp]
+    lib.qtts_codec_destroy.restype = None
+    lib.qtts_codec_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, i64p]
+    lib.qtts_codec_finalize.argtypes = [vp]
+    lib.qtts_codec_forward.argtypes = [vp, vp, i32, i32, f32p, f32p, vp]
+    lib.qtts_codec_decode.argtypes = [vp, vp, i32, i32, i32, i32, f32p, i64p, vp]
+    lib.qtts_codec_forward_stage.argtypes = [vp, vp, i32, i32, C.c_char_p, f32p, C.c_int64, i64p, i64p, vp]
+    lib.qtts_talker_create.argtypes = [C.POINTER(TalkerConfigC), C.POINTER(vp)]
+    lib.qtts_talker_destroy.argtypes = [vp]
+    lib.qtts_talker_destroy.restype = None
+    lib.qtts_talker_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, i64p]
+    lib.qtts_talker_finalize.argtypes = [vp]
+    lib.qtts_talker_text_projection.argtypes = [vp, f32p, i32, f32p, vp]
+    lib.qtts_talker_prefill.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_int32), f32p, i32, f32p, vp]
+    lib.qtts_talker_generate.argtypes = [vp, C.POINTER(SamplingC), i32, i32, i32, C.POINTER(C.c_int32), i32, vp, vp,
+                                         vp, C.POINTER(C.c_int32), vp]
+    lib.qtts_talker_debug_logits.argtypes = [vp, f32p, vp]
+    lib.qtts_talker_get_stats.argtypes = [vp, C.POINTER(TalkerStatsC)]
+    lib.qtts_talker_set_profile.argtypes = [vp, i32]
+    for s in SYMBOLS:
+        if s not in ("qtts_last_error", "qtts_codec_destroy", "qtts_talker_destroy"):
+            getattr(lib, s).restype = C.c_int
+    if lib.qtts_abi_version() != 1:
+        raise QttsError(-101, "libqtts.so ABI version mismatch; rebuild")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise QttsError(rc, (load_library().qtts_last_error() or b"").decode(errors="replace"))
+
+
+def bind_tensor(bind_fn, handle, name: str, t):
+    """Bind one torch CPU tensor (fp32 or bf16, contiguous) under `name`."""
+    import torch
+    t = t.detach()
+    if t.device.type != "cpu":
+        t = t.cpu()
+    if t.dtype == torch.bfloat16:
+        dt = QTTS_BF16
+    else:
+        t = t.to(torch.float32)
+        dt = QTTS_F32
+    t = t.contiguous()
+    shape = (C.c_int64 * max(1, t.dim()))(*([int(s) for s in t.shape] or [1]))
+    check(bind_fn(handle, name.encode(), C.c_void_p(t.data_ptr()), dt, max(1, t.dim()), shape))

@@ -1,0 +1,364 @@
+// attention.hip -- attention kernels for gfx950 (wave64).
+//
+//  attn_rows         one wave per (batch, head, query row) over a fused fp32 qkv buffer; causal, optional
+//                    sliding window and left-pad mask.  Used by the talker prefill and by the codec's
+//                    8-layer window-72 transformer.  16 lanes cooperate on one key (hd/16 dims per lane,
+//                    16-B loads), 4 keys in flight per wave, two passes (max, then exp/sum/PV) so the
+//                    softmax is the plain fp32 softmax of the reference (M:652, tokenizer v2:139).
+//  qknorm_rope_store prefill: per-head RMSNorm (M:752-757) + rotate-half RoPE (M:660-724 == plain RoPE,
+//                    SURVEY.md 3.2) in place on q,k and append of K,V to the paged cache.
+//  attn_decode       decode: the same norm/RoPE/append fused with single-query GQA attention over the
+//                    paged KV cache; one workgroup per (sequence, kv head) serves the whole q-head group so
+//                    each K/V tile is read once; scores staged in LDS; fp32 softmax.
+#include "common.h"
+#include "kernels.h"
+
+namespace qtts {
+
+__device__ inline float group16_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ inline float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline float wave_max64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// =================================================================================== attn_rows
+template <int HD>
+__global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
+    constexpr int DPL = HD / 16;  // dims per lane
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, li = lane & 15;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;   // (b, h, tq)
+    const int64_t total = (int64_t)p.B * p.nh * p.T;
+    if (item >= total) return;
+    const int tq = (int)(item % p.T);
+    const int h = (int)((item / p.T) % p.nh);
+    const int b = (int)(item / ((int64_t)p.T * p.nh));
+    const int npad = p.n_pad ? p.n_pad[b] : 0;
+    float* orow = p.out + ((size_t)b * p.T + tq) * p.ldo + h * HD + li * DPL;
+    if (tq < npad) {  // left-pad query row: never read downstream
+        if (g == 0)
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) orow[d] = 0.f;
+        return;
+    }
+    const int kvh = h / (p.nh / p.nkv);
+    const float scale = rsqrtf((float)HD);
+    const float* base = p.qkv + (size_t)b * p.T * p.ld;
+    float q[DPL];
+    {
+        const float* qp = base + (size_t)tq * p.ld + p.q_off + h * HD + li * DPL;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) q[d] = qp[d];
+    }
+    int lo = npad;
+    if (p.window > 0 && tq - p.window + 1 > lo) lo = tq - p.window + 1;
+    const int hi = tq;
+    const float* kb = base + p.k_off + kvh * HD + li * DPL;
+    const float* vb = base + p.v_off + kvh * HD + li * DPL;
+    // pass 1: row max
+    float m = -INFINITY;
+    for (int s = lo + g; s <= hi; s += 4) {
+        const float* kp = kb + (size_t)s * p.ld;
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) d += q[e] * kp[e];
+        d = group16_sum(d) * scale;
+        m = fmaxf(m, d);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    // pass 2: exp, sum, PV
+    float l = 0.f, acc[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[e] = 0.f;
+    for (int s = lo + g; s <= hi; s += 4) {
+        const float* kp = kb + (size_t)s * p.ld;
+        const float* vp = vb + (size_t)s * p.ld;
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) d += q[e] * kp[e];
+        d = group16_sum(d) * scale;
+        const float pr = expf(d - m);
+        l += pr;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) acc[e] += pr * vp[e];
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (g == 0) {
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) orow[e] = acc[e] * inv;
+    }
+}
+
+void launch_attn_rows(const AttnRowsParams& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.B * p.nh * p.T;
+    const int grid = (int)((total + 3) / 4);
+    if (p.hd == 64) hipLaunchKernelGGL(attn_rows_kernel<64>, dim3(grid), dim3(256), 0, st, p);
+    else if (p.hd == 128) hipLaunchKernelGGL(attn_rows_kernel<128>, dim3(grid), dim3(256), 0, st, p);
+    else throw Error(QTTS_ERR_ARG, "attn_rows: head_dim must be 64 or 128");
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// =================================================================================== KV cache helpers
+template <typename KVT> __device__ inline KVT kv_cast(float v);
+template <> __device__ inline float kv_cast<float>(float v) { return v; }
+template <> __device__ inline bf16_t kv_cast<bf16_t>(float v) { return f32_to_bf16(v); }
+__device__ inline float kv_load(const float* p) { return *p; }
+__device__ inline float kv_load(const bf16_t* p) { return bf16_to_f32(*p); }
+
+// element offset of (layer, sequence b, position s, kv head) in a pool [layer][page][kvh][16][hd]
+__device__ inline size_t kv_offset(const KvCache& c, int layer, int b, int s, int kvh) {
+    const int page = c.page_table[b * c.pages_per_seq + (s >> 4)];
+    return ((((size_t)layer * c.n_pages + page) * c.nkv + kvh) * 16 + (s & 15)) * c.hd;
+}
+
+// =================================================================================== qknorm_rope_store
+// one wave per (b, t, head) for q and k heads (norm + RoPE in place, k also to the cache),
+// v heads are copied to the cache.
+template <typename KVT>
+__global__ __launch_bounds__(256) void qknorm_rope_store_kernel(QkNormRopeParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int heads = p.nh + 2 * p.nkv;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+    if (item >= (int64_t)p.B * p.T * heads) return;
+    const int hh = (int)(item % heads);
+    const int t = (int)((item / heads) % p.T);
+    const int b = (int)(item / ((int64_t)heads * p.T));
+    const int npad = p.n_pad[b];
+    if (t < npad) return;  // pad rows: K/V slots stay unused (masked by s < n_pad everywhere)
+    const int hd = p.hd, half = hd / 2;
+    float* v = p.qkv + ((size_t)b * p.T + t) * p.ld + hh * hd;
+    KVT* kc = reinterpret_cast<KVT*>(p.kv.k);
+    KVT* vc = reinterpret_cast<KVT*>(p.kv.v);
+    if (hh >= p.nh + p.nkv) {  // value head: straight copy
+        const int kvh = hh - p.nh - p.nkv;
+        const size_t o = kv_offset(p.kv, p.layer, b, t, kvh);
+        for (int d = lane; d < hd; d += 64) vc[o + d] = kv_cast<KVT>(v[d]);
+        return;
+    }
+    const bool is_k = hh >= p.nh;
+    const float* w = is_k ? p.kw : p.qw;
+    // hd <= 128: lane owns d = lane and d + 64 (second only when hd == 128) -> pairs (d, d+half)
+    float x0 = lane < hd ? v[lane] : 0.f;
+    float x1 = lane + 64 < hd ? v[lane + 64] : 0.f;
+    float ss = wave_sum64(x0 * x0 + x1 * x1);
+    const float r = rsqrtf(ss / (float)hd + p.eps);
+    x0 = w[lane < hd ? lane : 0] * (x0 * r);
+    x1 = (lane + 64 < hd) ? w[lane + 64] * (x1 * r) : 0.f;
+    const float pos = (float)(t - npad);
+    float o0, o1;
+    if (hd == 128) {  // pair (lane, lane+64)
+        const float ang = pos * p.inv_freq[lane];
+        const float c = cosf(ang), s = sinf(ang);
+        o0 = x0 * c - x1 * s;
+        o1 = x1 * c + x0 * s;
+    } else {          // hd == 64: pair (lane, lane^32) inside the wave
+        const float other = __shfl_xor(x0, 32);
+        const float ang = pos * p.inv_freq[lane & 31];
+        const float c = cosf(ang), s = sinf(ang);
+        o0 = (lane < 32) ? x0 * c - other * s : x0 * c + other * s;
+        o1 = 0.f;
+    }
+    if (lane < hd) v[lane] = o0;
+    if (lane + 64 < hd) v[lane + 64] = o1;
+    if (is_k) {
+        const size_t o = kv_offset(p.kv, p.layer, b, t, hh - p.nh);
+        if (lane < hd) kc[o + lane] = kv_cast<KVT>(o0);
+        if (lane + 64 < hd) kc[o + lane + 64] = kv_cast<KVT>(o1);
+    }
+    (void)half;
+}
+
+void launch_qknorm_rope_store(const QkNormRopeParams& p, hipStream_t st) {
+    QTTS_REQUIRE(p.hd == 64 || p.hd == 128, QTTS_ERR_ARG, "qknorm_rope_store: head_dim 64|128");
+    const int64_t total = (int64_t)p.B * p.T * (p.nh + 2 * p.nkv);
+    const int grid = (int)((total + 3) / 4);
+    if (p.kv.bf16) hipLaunchKernelGGL(qknorm_rope_store_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(qknorm_rope_store_kernel<float>, dim3(grid), dim3(256), 0, st, p);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// =================================================================================== attn_decode
+// grid = B * nkv workgroups of 256 threads.  HD = 128 only (talker and code predictor).
+// LDS: qs[n_new*GQ][128] | kn[n_new][128] | vn[n_new][128] | red[4][n_new*GQ][128] | sc[n_new*GQ][max_len]
+template <typename KVT>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
+    if (p.done_flag && *p.done_flag) return;
+    constexpr int HD = 128;
+    extern __shared__ __attribute__((aligned(16))) float sm_ad[];
+    const int GQ = p.nh / p.nkv;
+    const int NQ = p.n_new * GQ;
+    float* qs = sm_ad;                         // [NQ][HD]   (query index = t*GQ + gq)
+    float* kn = qs + NQ * HD;                  // [n_new][HD]
+    float* vn = kn + p.n_new * HD;             // [n_new][HD]
+    float* red = vn + p.n_new * HD;            // [4][NQ][HD]
+    float* sc = red + 4 * NQ * HD;             // [NQ][max_len]
+    float* stat = sc + NQ * p.max_len;         // [NQ][2] (max, 1/sum)
+
+    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step
+    const int npad = p.n_pad ? p.n_pad[b] : 0;
+    KVT* kc = reinterpret_cast<KVT*>(p.kv.k);
+    KVT* vc = reinterpret_cast<KVT*>(p.kv.v);
+
+    // ---- 1. q/k RMSNorm + RoPE for the new tokens (one wave per vector), K/V append
+    const int nvec = NQ + 2 * p.n_new;  // q vectors, then k, then v
+    for (int vi = wave; vi < nvec; vi += 4) {
+        int t, col;
+        const float* w = nullptr;
+        float* dst;
+        if (vi < NQ) { t = vi / GQ; col = (kvh * GQ + vi % GQ) * HD; w = p.qw; dst = qs + vi * HD; }
+        else if (vi < NQ + p.n_new) { t = vi - NQ; col = (p.nh + kvh) * HD; w = p.kw; dst = kn + t * HD; }
+        else { t = vi - NQ - p.n_new; col = (p.nh + p.nkv + kvh) * HD; dst = vn + t * HD; }
+        const float* src = p.qkv + ((size_t)t * p.B + b) * p.ld + col;
+        float x0 = src[lane], x1 = src[lane + 64];
+        if (w) {
+            const float ss = wave_sum64(x0 * x0 + x1 * x1);
+            const float r = rsqrtf(ss / (float)HD + p.eps);
+            x0 = w[lane] * (x0 * r);
+            x1 = w[lane + 64] * (x1 * r);
+            const float ang = (float)(S0 + t - npad) * p.inv_freq[lane];
+            const float c = cosf(ang), s = sinf(ang);
+            const float o0 = x0 * c - x1 * s, o1 = x1 * c + x0 * s;
+            x0 = o0; x1 = o1;
+        }
+        if (vi >= NQ) {  // K or V of a new token: round through the cache type, append
+            const size_t o = kv_offset(p.kv, p.layer, b, S0 + t, kvh);
+            KVT* c = (vi < NQ + p.n_new) ? kc : vc;
+            const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
+            c[o + lane] = h0; c[o + lane + 64] = h1;
+            x0 = kv_load(&h0); x1 = kv_load(&h1);
+        }
+        dst[lane] = x0; dst[lane + 64] = x1;
+    }
+    __syncthreads();
+
+    // ---- 2. scores: 16 lanes per key (8 dims each), 16 keys per sweep
+    const int g = tid >> 4, li = tid & 15;
+    const float scale = rsqrtf((float)HD);
+    const int S1 = S0 + p.n_new;  // total keys
+    for (int s = npad + g; s < S1; s += 16) {
+        float kx[8];
+        if (s >= S0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kx[e] = kn[(s - S0) * HD + li * 8 + e];
+        } else {
+            const KVT* kp = kc + kv_offset(p.kv, p.layer, b, s, kvh) + li * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kx[e] = kv_load(kp + e);
+        }
+        for (int qi = 0; qi < NQ; ++qi) {
+            const float* qp = qs + qi * HD + li * 8;
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += qp[e] * kx[e];
+            d = group16_sum(d) * scale;
+            const int tq = qi / GQ;
+            if (li == 0) sc[qi * p.max_len + s] = (s <= S0 + tq) ? d : -INFINITY;  // causal among new tokens
+        }
+    }
+    __syncthreads();
+    // ---- 3. softmax statistics: wave qi % 4 handles query qi
+    for (int qi = wave; qi < NQ; qi += 4) {
+        float m = -INFINITY;
+        for (int s = npad + lane; s < S1; s += 64) m = fmaxf(m, sc[qi * p.max_len + s]);
+        m = wave_max64(m);
+        float l = 0.f;
+        for (int s = npad + lane; s < S1; s += 64) {
+            const float e = expf(sc[qi * p.max_len + s] - m);
+            sc[qi * p.max_len + s] = e;
+            l += e;
+        }
+        l = wave_sum64(l);
+        if (lane == 0) stat[qi] = 1.f / l;
+    }
+    __syncthreads();
+    // ---- 4. PV: 16 lanes per key, 16 keys per sweep, accumulate 8 dims per lane per query
+    float acc[4][8];
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
+    for (int s = npad + g; s < S1; s += 16) {
+        float vx[8];
+        if (s >= S0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vx[e] = vn[(s - S0) * HD + li * 8 + e];
+        } else {
+            const KVT* vp = vc + kv_offset(p.kv, p.layer, b, s, kvh) + li * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vx[e] = kv_load(vp + e);
+        }
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            if (qi < NQ) {
+                const float pr = sc[qi * p.max_len + s];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[qi][e] += pr * vx[e];
+            }
+        }
+    }
+    // reduce the 4 key groups of a wave (lanes l, l^16, l^32), then the 4 waves through LDS
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[qi][e] += __shfl_xor(acc[qi][e], 16);
+            acc[qi][e] += __shfl_xor(acc[qi][e], 32);
+        }
+    if (lane < 16) {
+        for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(wave * NQ + qi) * HD + lane * 8 + e] = acc[qi][e];
+    }
+    __syncthreads();
+    for (int i = tid; i < NQ * HD; i += 256) {
+        const int qi = i / HD, d = i % HD;
+        const float v = (red[(0 * NQ + qi) * HD + d] + red[(1 * NQ + qi) * HD + d]) +
+                        (red[(2 * NQ + qi) * HD + d] + red[(3 * NQ + qi) * HD + d]);
+        const int t = qi / GQ, gq = qi % GQ;
+        p.out[((size_t)t * p.B + b) * p.ldo + (kvh * GQ + gq) * HD + d] = v * stat[qi];
+    }
+}
+
+void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
+    QTTS_REQUIRE(p.hd == 128, QTTS_ERR_ARG, "attn_decode: head_dim must be 128");
+    const int GQ = p.nh / p.nkv, NQ = p.n_new * GQ;
+    QTTS_REQUIRE(NQ <= 4 && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: at most 4 queries per kv head");
+    const size_t lds = ((size_t)NQ * 128 + 2 * p.n_new * 128 + 4 * NQ * 128 + (size_t)NQ * p.max_len + 8) * sizeof(float);
+    QTTS_REQUIRE(lds <= 150 * 1024, QTTS_ERR_LIMIT, "attn_decode: max_len too large for LDS scores");
+    auto kern = p.kv.bf16 ? attn_decode_kernel<bf16_t> : attn_decode_kernel<float>;
+    if (lds > 48 * 1024) {
+        static bool set_bf = false, set_f = false;
+        bool& flag = p.kv.bf16 ? set_bf : set_f;
+        if (!flag) {
+            QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            flag = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B * p.nkv), dim3(256), lds, st, p);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace qtts

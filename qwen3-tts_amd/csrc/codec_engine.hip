@@ -1,0 +1,490 @@
+// codec_engine.hip -- host-side orchestration of the Qwen3-TTS-Tokenizer-12Hz decoder on gfx950.
+//
+// Data layout in HBM: every activation is CHANNEL-LAST fp32 [batch*time][channels]; weights are repacked
+// once at finalize() into [tap][out][in] (fp32 or bf16) so that each causal conv / conv-transpose / linear
+// is one `gemm_tap` launch (see gemm_tap.hip).  Stage order follows Qwen3TTSTokenizerV2Decoder.forward
+// (tokenizer v2:869-884); chunking follows chunked_decode (v2:886-896).
+#include <map>
+#include <functional>
+#include <algorithm>
+#include "common.h"
+#include "kernels.h"
+
+namespace qtts {
+
+struct Lin {                 // one gemm_tap operator
+    DevBuf W, bias;
+    int N = 0, K = 0, taps = 1;
+    int shift[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool has_bias = false;
+};
+struct Snake { DevBuf ea, ib; };
+
+}  // namespace qtts
+
+using namespace qtts;
+
+struct qtts_codec {
+    qtts_codec_config cfg;
+    bool bf16 = false, finalized = false;
+    std::map<std::string, std::vector<float>> host;
+    std::map<std::string, std::vector<int64_t>> shapes;
+
+    int vq = 0, up_total = 1;
+    DevBuf tables, inv_freq;
+    Lin rvq_out, pre_conv, in_proj, out_proj, dec0;
+    DevBuf t_norm;
+    struct TLayer { Lin qkv, o, gu, down; DevBuf n1, n2, ls1, ls2; };
+    std::vector<TLayer> tl;
+    struct Up { Lin tconv, pw1, pw2; DevBuf dw_w, dw_b, ln_w, ln_b, gamma; };
+    std::vector<Up> ups;
+    struct Unit { Snake a1, a2; Lin c1, c2; };
+    struct Block { Snake act; Lin tconv; Unit u[3]; int r, cin, cout; };
+    std::vector<Block> blocks;
+    Snake final_act;
+    DevBuf final_w; float final_b = 0.f; int final_c = 0;
+
+    DevBuf buf[4];
+    size_t buf_elems = 0;
+
+    std::vector<float>& P(const std::string& n) {
+        auto it = host.find(n);
+        if (it == host.end()) throw Error(QTTS_ERR_UNBOUND, "codec weight not bound: " + n);
+        return it->second;
+    }
+    void upload_w(DevBuf& d, const std::vector<float>& w) {
+        if (bf16) {
+            std::vector<bf16_t> h(w.size());
+            for (size_t i = 0; i < w.size(); ++i) h[i] = f32_to_bf16(w[i]);
+            d.upload(h.data(), h.size() * 2);
+        } else d.upload(w.data(), w.size() * 4);
+    }
+    void upload_f(DevBuf& d, const std::vector<float>& w) { d.upload(w.data(), w.size() * 4); }
+
+    // nn.Linear weight (N,K) (+bias)
+    void make_linear(Lin& l, const std::string& wname, const std::string& bname) {
+        auto& w = P(wname); auto& s = shapes[wname];
+        l.N = (int)s[0]; l.K = (int)s[1]; l.taps = 1; l.shift[0] = 0;
+        upload_w(l.W, w);
+        if (!bname.empty()) { upload_f(l.bias, P(bname)); l.has_bias = true; }
+    }
+    // causal Conv1d weight (Cout, Cin, k), dilation d
+    void make_conv(Lin& l, const std::string& pfx, int dil) {
+        auto& w = P(pfx + ".weight"); auto& s = shapes[pfx + ".weight"];
+        const int Co = (int)s[0], Ci = (int)s[1], k = (int)s[2];
+        QTTS_REQUIRE(k <= 8, QTTS_ERR_ARG, "conv kernel > 8");
+        std::vector<float> r((size_t)k * Co * Ci);
+        for (int j = 0; j < k; ++j)
+            for (int n = 0; n < Co; ++n)
+                for (int c = 0; c < Ci; ++c) r[((size_t)j * Co + n) * Ci + c] = w[((size_t)n * Ci + c) * k + j];
+        l.N = Co; l.K = Ci; l.taps = k;
+        for (int j = 0; j < k; ++j) l.shift[j] = -(k - 1 - j) * dil;
+        upload_w(l.W, r);
+        upload_f(l.bias, P(pfx + ".bias")); l.has_bias = true;
+    }
+    // ConvTranspose1d weight (Cin, Cout, k) with stride r, right-trim k - r  (k == r or k == 2r)
+    void make_tconv(Lin& l, const std::string& pfx, int r) {
+        auto& w = P(pfx + ".weight"); auto& s = shapes[pfx + ".weight"];
+        const int Ci = (int)s[0], Co = (int)s[1], k = (int)s[2];
+        QTTS_REQUIRE(k == r || k == 2 * r, QTTS_ERR_ARG, "transposed conv: kernel must be r or 2r");
+        const int taps = k / r;
+        std::vector<float> rp((size_t)taps * r * Co * Ci);
+        for (int t = 0; t < taps; ++t)
+            for (int p = 0; p < r; ++p)
+                for (int co = 0; co < Co; ++co)
+                    for (int ci = 0; ci < Ci; ++ci)
+                        rp[(((size_t)t * r + p) * Co + co) * Ci + ci] = w[((size_t)ci * Co + co) * k + p + t * r];
+        l.N = r * Co; l.K = Ci; l.taps = taps; l.shift[0] = 0; l.shift[1] = -1;
+        upload_w(l.W, rp);
+        auto& b = P(pfx + ".bias");
+        std::vector<float> be((size_t)r * Co);
+        for (int p = 0; p < r; ++p) for (int co = 0; co < Co; ++co) be[(size_t)p * Co + co] = b[co];
+        upload_f(l.bias, be); l.has_bias = true;
+    }
+    void make_snake(Snake& s, const std::string& pfx) {
+        auto& a = P(pfx + ".alpha"); auto& b = P(pfx + ".beta");
+        std::vector<float> ea(a.size()), ib(b.size());
+        for (size_t i = 0; i < a.size(); ++i) { ea[i] = expf(a[i]); ib[i] = 1.0f / (expf(b[i]) + 1e-9f); }
+        upload_f(s.ea, ea); upload_f(s.ib, ib);
+    }
+
+    void gemm(const Lin& l, const float* A, int lda, int M, int T, float* C, int ldc, int act = ACT_NONE,
+              const float* res = nullptr, int ldr = 0, const float* scale = nullptr, const Snake* sn = nullptr,
+              hipStream_t st = nullptr) {
+        GemmTapParams p;
+        p.A = A; p.lda = lda; p.M = M; p.T = T; p.W = l.W.p; p.N = l.N; p.K = l.K; p.taps = l.taps;
+        for (int i = 0; i < 8; ++i) p.shift[i] = l.shift[i];
+        p.bias = l.has_bias ? l.bias.as<float>() : nullptr;
+        p.scale = scale; p.res = res; p.ldr = ldr;
+        p.snake_ea = sn ? sn->ea.as<float>() : nullptr; p.snake_ib = sn ? sn->ib.as<float>() : nullptr;
+        p.act = act; p.C = C; p.ldc = ldc;
+        launch_gemm_tap(p, bf16, st);
+    }
+
+    void finalize();
+    // one forward over frames [t0, t0+Tc) of `codes` (strides in elements).  If stage != null, stop after that
+    // stage and copy it (channel-last) to stage_out.
+    void forward(const int64_t* codes, int B, int64_t sb, int64_t sq, int64_t stt, int t0, int Tc, float* wav,
+                 float* pre, int64_t wav_stride_b, int64_t skip_samples, const char* stage, float* stage_out,
+                 int64_t cap, int64_t* L_out, int64_t* C_out, hipStream_t st);
+};
+
+void qtts_codec::finalize() {
+    const auto& c = cfg;
+    vq = c.codebook_dim / 2;
+    up_total = 1;
+    for (int i = 0; i < c.n_upsample_rates; ++i) up_total *= c.upsample_rates[i];
+    for (int i = 0; i < c.n_upsampling_ratios; ++i) up_total *= c.upsampling_ratios[i];
+    QTTS_REQUIRE(c.head_dim == 64 || c.head_dim == 128, QTTS_ERR_ARG, "codec head_dim must be 64 or 128");
+    // normalised codebooks: embedding_sum / clamp(cluster_usage, 1e-5) (v2:676-679), computed once
+    {
+        std::vector<float> t((size_t)c.num_quantizers * c.codebook_size * vq);
+        for (int q = 0; q < c.num_quantizers; ++q) {
+            const std::string p = q == 0 ? "quantizer.rvq_first.vq.layers.0._codebook."
+                                         : "quantizer.rvq_rest.vq.layers." + std::to_string(q - 1) + "._codebook.";
+            auto& es = P(p + "embedding_sum"); auto& cu = P(p + "cluster_usage");
+            for (int i = 0; i < c.codebook_size; ++i) {
+                const float d = std::max(cu[i], 1e-5f);
+                for (int j = 0; j < vq; ++j)
+                    t[((size_t)q * c.codebook_size + i) * vq + j] = es[(size_t)i * vq + j] / d;
+            }
+        }
+        upload_f(tables, t);
+    }
+    {   // fused output_proj: [N = codebook_dim][K = 2*vq] = [first | rest] (v2:764-766, 815-821)
+        auto& wf = P("quantizer.rvq_first.output_proj.weight"); auto& wr = P("quantizer.rvq_rest.output_proj.weight");
+        std::vector<float> w((size_t)c.codebook_dim * 2 * vq);
+        for (int n = 0; n < c.codebook_dim; ++n)
+            for (int k = 0; k < vq; ++k) {
+                w[(size_t)n * 2 * vq + k] = wf[(size_t)n * vq + k];
+                w[(size_t)n * 2 * vq + vq + k] = wr[(size_t)n * vq + k];
+            }
+        rvq_out.N = c.codebook_dim; rvq_out.K = 2 * vq; rvq_out.taps = 1;
+        upload_w(rvq_out.W, w);
+    }
+    make_conv(pre_conv, "pre_conv.conv", 1);
+    make_linear(in_proj, "pre_transformer.input_proj.weight", "pre_transformer.input_proj.bias");
+    make_linear(out_proj, "pre_transformer.output_proj.weight", "pre_transformer.output_proj.bias");
+    upload_f(t_norm, P("pre_transformer.norm.weight"));
+    if (host.count("pre_transformer.rotary_emb.inv_freq")) upload_f(inv_freq, P("pre_transformer.rotary_emb.inv_freq"));
+    else {
+        std::vector<float> f(c.head_dim / 2);
+        for (int i = 0; i < c.head_dim / 2; ++i) f[i] = 1.0f / powf(c.rope_theta, (float)(2 * i) / (float)c.head_dim);
+        upload_f(inv_freq, f);
+    }
+    const int H = c.hidden_size, I = c.intermediate_size;
+    QTTS_REQUIRE(I % 16 == 0, QTTS_ERR_ARG, "codec intermediate_size % 16");
+    tl.resize(c.num_hidden_layers);
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const std::string p = "pre_transformer.layers." + std::to_string(l) + ".";
+        auto& L = tl[l];
+        {   // fused q|k|v rows
+            auto& q = P(p + "self_attn.q_proj.weight"); auto& k = P(p + "self_attn.k_proj.weight");
+            auto& v = P(p + "self_attn.v_proj.weight");
+            std::vector<float> w; w.reserve(q.size() + k.size() + v.size());
+            w.insert(w.end(), q.begin(), q.end()); w.insert(w.end(), k.begin(), k.end()); w.insert(w.end(), v.begin(), v.end());
+            L.qkv.N = (int)(w.size() / H); L.qkv.K = H; upload_w(L.qkv.W, w);
+        }
+        make_linear(L.o, p + "self_attn.o_proj.weight", "");
+        {   // gate/up interleaved in 16-row blocks for the SwiGLU epilogue
+            auto& g = P(p + "mlp.gate_proj.weight"); auto& u = P(p + "mlp.up_proj.weight");
+            std::vector<float> w((size_t)2 * I * H);
+            for (int f = 0; f < I; ++f) {
+                memcpy(&w[((size_t)(f / 16) * 32 + f % 16) * H], &g[(size_t)f * H], H * 4);
+                memcpy(&w[((size_t)(f / 16) * 32 + 16 + f % 16) * H], &u[(size_t)f * H], H * 4);
+            }
+            L.gu.N = 2 * I; L.gu.K = H; upload_w(L.gu.W, w);
+        }
+        make_linear(L.down, p + "mlp.down_proj.weight", "");
+        upload_f(L.n1, P(p + "input_layernorm.weight"));
+        upload_f(L.n2, P(p + "post_attention_layernorm.weight"));
+        upload_f(L.ls1, P(p + "self_attn_layer_scale.scale"));
+        upload_f(L.ls2, P(p + "mlp_layer_scale.scale"));
+    }
+    ups.resize(c.n_upsampling_ratios);
+    for (int u = 0; u < c.n_upsampling_ratios; ++u) {
+        const std::string p = "upsample." + std::to_string(u) + ".";
+        make_tconv(ups[u].tconv, p + "0.conv", c.upsampling_ratios[u]);
+        upload_f(ups[u].dw_w, P(p + "1.dwconv.conv.weight"));
+        upload_f(ups[u].dw_b, P(p + "1.dwconv.conv.bias"));
+        upload_f(ups[u].ln_w, P(p + "1.norm.weight"));
+        upload_f(ups[u].ln_b, P(p + "1.norm.bias"));
+        make_linear(ups[u].pw1, p + "1.pwconv1.weight", p + "1.pwconv1.bias");
+        make_linear(ups[u].pw2, p + "1.pwconv2.weight", p + "1.pwconv2.bias");
+        upload_f(ups[u].gamma, P(p + "1.gamma"));
+    }
+    make_conv(dec0, "decoder.0.conv", 1);
+    blocks.resize(c.n_upsample_rates);
+    const int dil[3] = {1, 3, 9};
+    for (int i = 0; i < c.n_upsample_rates; ++i) {
+        const std::string p = "decoder." + std::to_string(i + 1) + ".block.";
+        auto& b = blocks[i];
+        b.r = c.upsample_rates[i]; b.cin = c.decoder_dim >> i; b.cout = c.decoder_dim >> (i + 1);
+        make_snake(b.act, p + "0");
+        make_tconv(b.tconv, p + "1.conv", b.r);
+        for (int j = 0; j < 3; ++j) {
+            const std::string up = p + std::to_string(j + 2) + ".";
+            make_snake(b.u[j].a1, up + "act1");
+            make_snake(b.u[j].a2, up + "act2");
+            make_conv(b.u[j].c1, up + "conv1.conv", dil[j]);
+            make_conv(b.u[j].c2, up + "conv2.conv", 1);
+        }
+    }
+    const int n = c.n_upsample_rates;
+    make_snake(final_act, "decoder." + std::to_string(n + 1));
+    {
+        const std::string p = "decoder." + std::to_string(n + 2) + ".conv";
+        auto& w = P(p + ".weight"); auto& s = shapes[p + ".weight"];
+        final_c = (int)s[1];
+        QTTS_REQUIRE(s[0] == 1 && s[2] == 7, QTTS_ERR_ARG, "final conv must be (1, C, 7)");
+        std::vector<float> r((size_t)7 * final_c);
+        for (int k = 0; k < 7; ++k) for (int ch = 0; ch < final_c; ++ch) r[(size_t)k * final_c + ch] = w[(size_t)ch * 7 + k];
+        upload_f(final_w, r);
+        final_b = P(p + ".bias")[0];
+    }
+    // workspaces: the largest activation of any stage, per frame
+    size_t per_frame = 0;
+    {
+        size_t L = 1;
+        per_frame = std::max<size_t>({(size_t)2 * vq, (size_t)c.codebook_dim, (size_t)c.latent_dim,
+                                      (size_t)(c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim,
+                                      (size_t)c.hidden_size, (size_t)c.intermediate_size});
+        for (int u = 0; u < c.n_upsampling_ratios; ++u) { L *= c.upsampling_ratios[u]; per_frame = std::max(per_frame, L * 4 * c.latent_dim); }
+        per_frame = std::max(per_frame, L * c.decoder_dim);
+        for (int i = 0; i < c.n_upsample_rates; ++i) { L *= c.upsample_rates[i]; per_frame = std::max(per_frame, L * (size_t)(c.decoder_dim >> (i + 1))); }
+    }
+    buf_elems = per_frame * (size_t)std::max(1, c.max_batch) * (size_t)std::max(1, c.max_frames);
+    for (auto& b : buf) b.alloc(buf_elems * sizeof(float));
+    host.clear();  // host copies no longer needed
+    finalized = true;
+}
+
+void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, int64_t stt, int t0, int Tc, float* wav,
+                         float* pre, int64_t wav_stride_b, int64_t skip_samples, const char* stage, float* stage_out,
+                         int64_t cap, int64_t* L_out, int64_t* C_out, hipStream_t st) {
+    const auto& c = cfg;
+    QTTS_REQUIRE(finalized, QTTS_ERR_STATE, "codec: finalize() first");
+    QTTS_REQUIRE(B >= 1 && Tc >= 1, QTTS_ERR_ARG, "codec: empty input");
+    QTTS_REQUIRE((size_t)B * Tc <= (size_t)c.max_batch * c.max_frames, QTTS_ERR_LIMIT,
+                 "codec: B*T exceeds max_batch*max_frames given at create");
+    float *x = buf[0].as<float>(), *s1 = buf[1].as<float>(), *s2 = buf[2].as<float>(), *s3 = buf[3].as<float>();
+    int L = Tc;          // positions per sequence at the current stage
+    int C = 0;           // channels of x
+    auto want = [&](const char* name) { return stage && strcmp(stage, name) == 0; };
+    auto emit = [&](const float* src) {
+        const int64_t n = (int64_t)B * L * C;
+        QTTS_REQUIRE(n <= cap, QTTS_ERR_ARG, "codec stage: output buffer too small");
+        QTTS_CHECK_HIP(hipMemcpyAsync(stage_out, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (L_out) *L_out = L;
+        if (C_out) *C_out = C;
+    };
+
+    // ---- RVQ dequant: gather-sum then the two 1x1 output projections as one GEMM (v2:815-821)
+    launch_rvq_gather(codes, B, c.num_quantizers, Tc, sb, sq, stt, t0, Tc, tables.as<float>(), c.codebook_size, vq, s1, st);
+    gemm(rvq_out, s1, 2 * vq, B * L, L, x, c.codebook_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+    C = c.codebook_dim;
+    if (want("rvq")) { emit(x); return; }
+    // ---- pre_conv (k=3 causal) (v2:874)
+    gemm(pre_conv, x, C, B * L, L, s1, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+    std::swap(x, s1); C = c.latent_dim;
+    if (want("pre_conv")) { emit(x); return; }
+    // ---- pre_transformer (v2:501-575)
+    {
+        const int H = c.hidden_size, I = c.intermediate_size;
+        const int qd = c.num_attention_heads * c.head_dim, kvd = c.num_key_value_heads * c.head_dim;
+        const int M = B * L;
+        float* h = s1;
+        gemm(in_proj, x, C, M, L, h, H, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        float *a = x, *b2 = s2, *b3 = s3;     // scratch
+        for (auto& Ly : tl) {
+            launch_rmsnorm(h, H, Ly.n1.as<float>(), c.rms_norm_eps, a, H, M, H, st);
+            gemm(Ly.qkv, a, H, M, L, b2, qd + 2 * kvd, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+            launch_rope_inplace(b2, qd + 2 * kvd, M, L, c.num_attention_heads + c.num_key_value_heads, c.head_dim,
+                                inv_freq.as<float>(), st);
+            AttnRowsParams ap;
+            ap.qkv = b2; ap.ld = qd + 2 * kvd; ap.q_off = 0; ap.k_off = qd; ap.v_off = qd + kvd;
+            ap.B = B; ap.T = L; ap.nh = c.num_attention_heads; ap.nkv = c.num_key_value_heads; ap.hd = c.head_dim;
+            ap.window = c.sliding_window; ap.n_pad = nullptr; ap.out = a; ap.ldo = qd;
+            launch_attn_rows(ap, st);
+            gemm(Ly.o, a, qd, M, L, h, H, ACT_NONE, h, H, Ly.ls1.as<float>(), nullptr, st);
+            launch_rmsnorm(h, H, Ly.n2.as<float>(), c.rms_norm_eps, a, H, M, H, st);
+            gemm(Ly.gu, a, H, M, L, b3, I, ACT_SWIGLU, nullptr, 0, nullptr, nullptr, st);
+            gemm(Ly.down, b3, I, M, L, h, H, ACT_NONE, h, H, Ly.ls2.as<float>(), nullptr, st);
+        }
+        launch_rmsnorm(h, H, t_norm.as<float>(), c.rms_norm_eps, a, H, M, H, st);
+        gemm(out_proj, a, H, M, L, b2, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        // b2 now holds the stage output; rotate so that x points at it
+        float* old_x = x; x = b2; s2 = old_x; C = c.latent_dim;
+    }
+    if (want("pre_transformer")) { emit(x); return; }
+    // ---- upsample: ConvTranspose(k = s = f) + ConvNeXt (v2:878-880)
+    for (int u = 0; u < c.n_upsampling_ratios; ++u) {
+        const int f = c.upsampling_ratios[u];
+        float *y = (x == s1 ? s2 : s1), *d = (x == s3 || y == s3) ? (x == s2 || y == s2 ? s1 : s2) : s3;
+        // pick three distinct scratch buffers among {buf0..3} \ {x}
+        float* all[4] = {buf[0].as<float>(), buf[1].as<float>(), buf[2].as<float>(), buf[3].as<float>()};
+        float* fr[3]; int nf = 0;
+        for (auto p : all) if (p != x) fr[nf++] = p;
+        y = fr[0]; d = fr[1]; float* e = fr[2];
+        gemm(ups[u].tconv, x, C, B * L, L, y, f * C, ACT_NONE, nullptr, 0, nullptr, nullptr, st);   // [B*L][f*C] == [B*L*f][C]
+        L *= f;
+        launch_dwconv_ln(y, ups[u].dw_w.as<float>(), ups[u].dw_b.as<float>(), ups[u].ln_w.as<float>(),
+                         ups[u].ln_b.as<float>(), 1e-6f, d, B * L, L, C, st);
+        gemm(ups[u].pw1, d, C, B * L, L, e, 4 * C, ACT_GELU, nullptr, 0, nullptr, nullptr, st);
+        gemm(ups[u].pw2, e, 4 * C, B * L, L, y, C, ACT_NONE, y, C, ups[u].gamma.as<float>(), nullptr, st);
+        x = y;
+        const std::string nm = "upsample" + std::to_string(u);
+        if (want(nm.c_str())) { emit(x); return; }
+    }
+    auto scratch3 = [&](float*& a, float*& b, float*& cc) {
+        float* all[4] = {buf[0].as<float>(), buf[1].as<float>(), buf[2].as<float>(), buf[3].as<float>()};
+        float* fr[3]; int nf = 0;
+        for (auto p : all) if (p != x) fr[nf++] = p;
+        a = fr[0]; b = fr[1]; cc = fr[2];
+    };
+    // ---- decoder.0: conv k=7 latent -> decoder_dim (v2:857)
+    {
+        float *a, *b, *cc; scratch3(a, b, cc);
+        gemm(dec0, x, C, B * L, L, a, c.decoder_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        x = a; C = c.decoder_dim;
+    }
+    if (want("decoder0")) { emit(x); return; }
+    // ---- 4 decoder blocks: SnakeBeta, ConvTranspose(2r, r), 3 residual units (v2:645-658, 628-635)
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        auto& bk = blocks[i];
+        float *a, *b, *cc; scratch3(a, b, cc);
+        launch_snake(x, bk.act.ea.as<float>(), bk.act.ib.as<float>(), a, (int64_t)B * L, C, st);
+        gemm(bk.tconv, a, C, B * L, L, b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        L *= bk.r; C = bk.cout;
+        float* cur = b;              // unit input / residual
+        float* sA = a; float* sB = cc; float* alt = x;   // x's old buffer is free now
+        for (int j = 0; j < 3; ++j) {
+            auto& un = bk.u[j];
+            launch_snake(cur, un.a1.ea.as<float>(), un.a1.ib.as<float>(), sA, (int64_t)B * L, C, st);
+            gemm(un.c1, sA, C, B * L, L, sB, C, ACT_SNAKE, nullptr, 0, nullptr, &un.a2, st);        // conv7 + snake(act2)
+            gemm(un.c2, sB, C, B * L, L, alt, C, ACT_NONE, cur, C, nullptr, nullptr, st);           // 1x1 + residual
+            std::swap(cur, alt);
+        }
+        x = cur;
+        const std::string nm = "block" + std::to_string(i + 1);
+        if (want(nm.c_str())) { emit(x); return; }
+    }
+    // ---- final SnakeBeta + conv(C -> 1, k=7) + clamp (v2:861-864, 884)
+    {
+        float *a, *b, *cc; scratch3(a, b, cc);
+        launch_snake(x, final_act.ea.as<float>(), final_act.ib.as<float>(), a, (int64_t)B * L, C, st);
+        QTTS_REQUIRE(C == final_c, QTTS_ERR_ARG, "final conv channel mismatch");
+        if (wav)
+            launch_final_conv(a, final_w.as<float>(), final_b, wav, pre, (int64_t)B * L, L, C, wav_stride_b, skip_samples, st);
+    }
+    if (L_out) *L_out = L;
+    if (C_out) *C_out = 1;
+}
+
+// ============================================================================================ C ABI
+namespace qtts {
+thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+}  // namespace qtts
+
+#define QTTS_API_BEGIN try {
+#define QTTS_API_END                                                        \
+    }                                                                       \
+    catch (const qtts::Error& e) { qtts::set_last_error(e.what()); return e.code; } \
+    catch (const std::exception& e) { qtts::set_last_error(e.what()); return QTTS_ERR_ARG; } \
+    return QTTS_OK;
+
+extern "C" {
+
+const char* qtts_last_error(void) { return qtts::g_last_error.c_str(); }
+int qtts_abi_version(void) { return 1; }
+
+int qtts_codec_create(const qtts_codec_config* cfg, qtts_codec** out) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(cfg && out, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(cfg->compute_dtype == QTTS_F32 || cfg->compute_dtype == QTTS_BF16, QTTS_ERR_ARG, "compute_dtype");
+    QTTS_REQUIRE(cfg->n_upsample_rates >= 1 && cfg->n_upsample_rates <= 8 && cfg->n_upsampling_ratios >= 0 &&
+                     cfg->n_upsampling_ratios <= 8, QTTS_ERR_ARG, "upsample lists");
+    QTTS_REQUIRE(cfg->codebook_dim % 64 == 0 && cfg->latent_dim % 32 == 0 && cfg->hidden_size % 32 == 0 &&
+                     cfg->intermediate_size % 32 == 0 && (cfg->decoder_dim >> cfg->n_upsample_rates) % 32 == 0,
+                 QTTS_ERR_ARG, "channel counts must be multiples of 32");
+    int ndev = 0;
+    QTTS_CHECK_HIP(hipGetDeviceCount(&ndev));
+    QTTS_REQUIRE(ndev > 0, QTTS_ERR_HIP, "no HIP device");
+    auto* c = new qtts_codec();
+    c->cfg = *cfg;
+    c->bf16 = cfg->compute_dtype == QTTS_BF16;
+    *out = c;
+    QTTS_API_END
+}
+void qtts_codec_destroy(qtts_codec* c) { delete c; }
+
+int qtts_codec_bind(qtts_codec* c, const char* name, const void* host, int32_t src_dtype, int32_t ndim,
+                    const int64_t* shape) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c && name && host && shape, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(!c->finalized, QTTS_ERR_STATE, "bind after finalize");
+    QTTS_REQUIRE(src_dtype == QTTS_F32 || src_dtype == QTTS_BF16, QTTS_ERR_ARG, "src_dtype");
+    HostTensor t{host, src_dtype, std::vector<int64_t>(shape, shape + ndim)};
+    c->host[name] = t.to_f32();
+    c->shapes[name] = t.shape;
+    QTTS_API_END
+}
+int qtts_codec_finalize(qtts_codec* c) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c, QTTS_ERR_ARG, "null handle");
+    c->finalize();
+    QTTS_API_END
+}
+int qtts_codec_forward(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, float* wav_dev,
+                       float* pre_clamp_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c && codes_dev && wav_dev, QTTS_ERR_ARG, "null argument");
+    const int Q = c->cfg.num_quantizers;
+    c->forward(codes_dev, B, (int64_t)Q * T, T, 1, 0, T, wav_dev, pre_clamp_dev, (int64_t)T * c->up_total, 0, nullptr,
+               nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    QTTS_API_END
+}
+int qtts_codec_forward_stage(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, const char* stage,
+                             float* out_dev, int64_t cap, int64_t* L, int64_t* C, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c && codes_dev && stage && out_dev, QTTS_ERR_ARG, "null argument");
+    const int Q = c->cfg.num_quantizers;
+    int64_t l = -1, ch = -1;
+    c->forward(codes_dev, B, (int64_t)Q * T, T, 1, 0, T, nullptr, nullptr, 0, 0, stage, out_dev, cap, &l, &ch,
+               (hipStream_t)stream);
+    QTTS_REQUIRE(ch > 1 || strcmp(stage, "none") == 0, QTTS_ERR_NAME, std::string("unknown stage: ") + stage);
+    if (L) *L = l;
+    if (C) *C = ch;
+    QTTS_API_END
+}
+int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, int32_t chunk_size,
+                      int32_t left_context, float* wav_dev, int64_t* lengths_host, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c && codes_dev && wav_dev, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(chunk_size >= 1 && left_context >= 0, QTTS_ERR_ARG, "chunk sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int Q = c->cfg.num_quantizers;
+    const int64_t up = c->up_total;
+    if (lengths_host) {  // audio_lengths = (codes[..., 0] > -1).sum(1) * decode_upsample_rate (v2:1012)
+        std::vector<int64_t> h((size_t)B * T * Q);
+        QTTS_CHECK_HIP(hipMemcpyAsync(h.data(), codes_dev, h.size() * 8, hipMemcpyDeviceToHost, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) {
+            int64_t n = 0;
+            for (int t = 0; t < T; ++t) n += h[((size_t)b * T + t) * Q] > -1;
+            lengths_host[b] = n * up;
+        }
+    }
+    int start = 0;
+    while (start < T) {  // chunked_decode (v2:886-896)
+        const int end = std::min(start + chunk_size, T);
+        const int ctx = (start - left_context > 0) ? left_context : start;
+        c->forward(codes_dev, B, (int64_t)T * Q, 1, Q, start - ctx, end - (start - ctx), wav_dev + (int64_t)start * up, nullptr,
+                   (int64_t)T * up, (int64_t)ctx * up, nullptr, nullptr, 0, nullptr, nullptr, st);
+        start = end;
+    }
+    QTTS_API_END
+}
+
+}  // extern "C"

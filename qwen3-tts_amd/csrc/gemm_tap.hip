@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
                 float v = acc[i][j][r] + bias;
                 if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
                 else if (p.act == ACT_SNAKE) { const float sn = sinf(v * ea); v = v + ib * (sn * sn); }
+                else if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
                 v *= scale;
                 if (p.res) v += p.res[(size_t)m * p.ldr + n];
                 p.C[(size_t)m * p.ldc + n] = v;

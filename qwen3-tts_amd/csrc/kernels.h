@@ -1,0 +1,137 @@
+// kernels.h -- launch interfaces of the HIP kernels (all gfx950, wave64).
+#pragma once
+#include "common.h"
+
+namespace qtts {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SWIGLU = 2, ACT_SNAKE = 3, ACT_SILU = 4 };
+
+// --------------------------------------------------------------------------------- gemm_tap.hip
+struct GemmTapParams {
+    const float* A; int lda;     // activations, channel-last [rows][lda]
+    int M;                       // output rows
+    int T;                       // rows per sequence (tap validity); M % T == 0
+    const void* W;               // [taps][N][K], float or bf16
+    int N, K, taps;
+    int shift[8];                // per-tap row shift (<= 0)
+    const float* bias;           // [N] or null
+    const float* scale;          // [N] or null  (LayerScale / ConvNeXt gamma): v = scale * act(acc + bias)
+    const float* res; int ldr;   // residual [M][ldr] or null, added last
+    const float* snake_ea;       // ACT_SNAKE: exp(alpha)[N]
+    const float* snake_ib;       // ACT_SNAKE: 1/(exp(beta)+1e-9)[N]
+    int act;
+    float* C; int ldc;           // ACT_SWIGLU writes N/2 columns
+};
+void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
+
+// --------------------------------------------------------------------------------- skinny.hip
+// Weight-streaming GEMM for decode: out[M <= 16*MT][N] = x[M][K] . W[N][K]^T, W pre-packed into
+// 1-KiB MFMA-operand tiles (see pack_skinny_weight).
+struct SkinnyParams {
+    const float* x; int ldx; int M;
+    const void* Wp;              // packed tiles [N/16][K/KT][64 lanes][16 B]
+    int N, K;
+    const float* g;              // optional RMSNorm weight [K] applied to x on the fly
+    const unsigned long long* ss_in;  // optional fixed-point sum-of-squares per row [M] -> rstd
+    float eps;
+    const float* bias;           // [N] or null
+    const float* res; int ldr;   // residual [M][ldr] or null
+    float* out; int ldo;
+    unsigned long long* ss_out;  // optional: accumulate fixed-point sum(out^2) per row [M]
+    unsigned long long* ss_zero; // optional: block 0 zeroes these [M] entries (next buffer in the ring)
+    int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns)
+    const int* done_flag;        // optional device flag: when non-zero the kernel exits immediately
+};
+constexpr double SS_SCALE = 16777216.0;  // 2^24 fixed point for the sum-of-squares accumulators
+void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);
+size_t skinny_packed_bytes(int N, int K, bool bf16);
+// Pack W[N][K] (row-major f32) into the streaming tile layout; gate/up interleaving is the caller's.
+void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host);
+
+// --------------------------------------------------------------------------------- elementwise.hip
+void launch_rmsnorm(const float* x, int ldx, const float* w, float eps, float* y, int ldy, int rows, int C,
+                    hipStream_t st);
+void launch_snake(const float* x, const float* ea, const float* ib, float* y, int64_t rows, int C, hipStream_t st);
+// y[t][c] = LayerNorm_c(sum_k w[c][k] x[t-6+k][c] + b[c]) (ConvNeXt dwconv k=7 + LN eps)
+void launch_dwconv_ln(const float* x, const float* w7, const float* b, const float* ln_w, const float* ln_b,
+                      float eps, float* y, int rows, int T, int C, hipStream_t st);
+// out[bt][0:vq] = tab0[code0], out[bt][vq:2vq] = sum_{q>=1} tab_q[code_q]  (codes (B,Q,T) or (B,T,Q))
+void launch_rvq_gather(const int64_t* codes, int B, int Q, int T, int64_t stride_b, int64_t stride_q,
+                       int64_t stride_t, int t0, int Tc, const float* tables, int bins, int vq, float* out,
+                       hipStream_t st);
+// final conv (C -> 1, k = 7, causal) + clamp; x already snake-activated, channel-last
+void launch_final_conv(const float* x, const float* w /*[7][C]*/, float bias, float* wav, float* pre_clamp,
+                       int64_t rows, int64_t T, int C, int64_t out_stride_b, int64_t skip, hipStream_t st);
+// in-place rotate-half RoPE on the q and k parts of a fused qkv buffer (codec transformer: no q/k norm)
+void launch_rope_inplace(float* qkv, int ld, int rows, int T, int n_heads_total /* q + k heads */, int hd,
+                         const float* inv_freq, hipStream_t st);
+
+// --------------------------------------------------------------------------------- attention.hip
+// Generic row attention over a fused qkv buffer (prefill + codec transformer).
+struct AttnRowsParams {
+    const float* qkv; int ld; int q_off, k_off, v_off;   // column offsets of the q / k / v blocks
+    int B, T, nh, nkv, hd;
+    int window;                  // 0 = full causal; else keys in (tq - window, tq]
+    const int* n_pad;            // optional [B]: keys < n_pad masked, query rows < n_pad skipped
+    float* out; int ldo;
+};
+void launch_attn_rows(const AttnRowsParams& p, hipStream_t st);
+
+// Prefill: per-head RMSNorm + RoPE in place on q,k of the fused qkv buffer, and K/V append to the cache.
+struct KvCache {
+    void* k; void* v;            // pools [layer][page][kvh][16][hd] (float or bf16)
+    const int* page_table;       // [B][pages_per_seq]
+    int pages_per_seq, n_pages, nkv, hd;
+    int bf16;
+};
+struct QkNormRopeParams {
+    float* qkv; int ld; int B, T, nh, nkv, hd;
+    const float* qw; const float* kw; float eps;
+    const float* inv_freq;       // [hd/2]
+    const int* n_pad;            // [B]
+    KvCache kv; int layer;
+};
+void launch_qknorm_rope_store(const QkNormRopeParams& p, hipStream_t st);
+
+// Decode: fused q/k RMSNorm + RoPE + KV append + attention for n_new (1|2) new tokens per sequence.
+struct AttnDecodeParams {
+    const float* qkv; int ld;    // rows t*B + b
+    int B, n_new, nh, nkv, hd;
+    const float* qw; const float* kw; float eps;
+    const float* inv_freq;
+    const int* n_pad;            // optional [B]
+    const int* len_dev;          // device int: KV length before this step (talker) or null
+    int len_static;              // used when len_dev == null (code predictor)
+    KvCache kv; int layer;
+    float* out; int ldo;         // rows t*B + b, columns nh*hd
+    int max_len;                 // LDS score capacity
+    const int* done_flag;
+};
+void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st);
+
+// --------------------------------------------------------------------------------- sampling.hip
+struct SampleParams {
+    const float* logits; int ld; int V; int B;
+    // processors
+    const int* generated; int gen_stride;   // [B][gen_stride] tokens so far (talker) or null
+    const int* n_generated_dev;              // device count of tokens generated so far (or null -> 0)
+    float repetition_penalty;
+    int eos; int min_new_tokens;             // eos < 0: no eos handling
+    const unsigned char* suppress_mask;      // [V] or null
+    int do_sample; int top_k; float top_p; float temperature;
+    unsigned long long seed; unsigned int stream_id;   // Philox key / sub-stream (codebook index)
+    const int* step_dev;                     // device step counter feeding the Philox offset
+    // outputs
+    int* tok_out; int tok_stride;            // token of row b -> tok_out[b * tok_stride]
+    // talker-only bookkeeping (null for the code predictor)
+    int* unfinished;                         // [B] in/out
+    int* generated_out;                      // append position = n_generated
+    int* n_generated_inc;                    // incremented by 1 (single block does it)
+    int* done_flag;                          // set when all finished or n_generated >= max_new
+    int* final_count;                        // n_generated at the moment done was set
+    int max_new_tokens;
+    const int* done_in;                      // early exit
+};
+void launch_sample(const SampleParams& p, hipStream_t st);
+
+}  // namespace qtts

@@ -1,0 +1,324 @@
+// sampling.hip -- on-device HF logits processors + sampler, and the frame-step glue kernels.
+//
+// Processor order and formulas are those of transformers 4.57.3 `_get_logits_processor`
+// (SURVEY.md 3.3): RepetitionPenalty -> MinNewTokensLength -> SuppressTokens ->
+// [Temperature -> TopK] -> argmax | softmax + multinomial.  argmax breaks ties towards the lowest
+// index (torch.argmax).  Sampling draws from a counter-based Philox4x32-10 stream keyed by
+// (seed; step, row, codebook) -- torch's global RNG stream is not reproducible across devices, so
+// sampled runs are compared distributionally, greedy runs bit-exactly.
+#include "common.h"
+#include "kernels.h"
+#include "glue.h"
+
+namespace qtts {
+
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                     uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ inline uint32_t float_key(float f) {  // monotone float -> uint (larger float = larger key)
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+constexpr int SAMPLE_MAX_V = 8192;
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
+    if (p.done_in && *p.done_in) return;
+    __shared__ float sc[SAMPLE_MAX_V];
+    __shared__ int hist[256];
+    __shared__ float fred[4];
+    __shared__ int ired[4];
+    __shared__ float scan[256];
+    __shared__ int sel_prefix, sel_need, pick_lo, pick_hi;
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = p.V;
+    const float* lg = p.logits + (size_t)b * p.ld;
+    const int n_gen = p.n_generated_dev ? *p.n_generated_dev : 0;
+    for (int v = tid; v < V; v += 256) sc[v] = lg[v];
+    __syncthreads();
+    if (p.generated && p.repetition_penalty != 1.0f) {
+        for (int i = tid; i < n_gen; i += 256) {
+            const int tok = p.generated[(size_t)b * p.gen_stride + i];
+            const float s = lg[tok];
+            sc[tok] = s < 0.f ? s * p.repetition_penalty : s / p.repetition_penalty;  // same value for duplicates
+        }
+        __syncthreads();
+    }
+    if (p.eos >= 0 && n_gen < p.min_new_tokens && tid == 0) sc[p.eos] = -INFINITY;
+    __syncthreads();
+    if (p.suppress_mask) {
+        for (int v = tid; v < V; v += 256)
+            if (p.suppress_mask[v]) sc[v] = -INFINITY;
+        __syncthreads();
+    }
+
+    int token;
+    if (!p.do_sample) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += 256) {
+            const float s = sc[v];
+            if (s > bv || (s == bv && v < bi)) { bv = s; bi = v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { fred[wave] = bv; ired[wave] = bi; }
+        __syncthreads();
+        bv = fred[0]; bi = ired[0];
+        for (int w = 1; w < 4; ++w)
+            if (fred[w] > bv || (fred[w] == bv && ired[w] < bi)) { bv = fred[w]; bi = ired[w]; }
+        token = bi;
+    } else {
+        if (p.temperature != 1.0f) {
+            for (int v = tid; v < V; v += 256) sc[v] = sc[v] / p.temperature;
+            __syncthreads();
+        }
+        if (p.top_k > 0 && p.top_k < V) {
+            // radix select of the k-th largest key, 8 bits per pass from the MSB
+            uint32_t prefix = 0;
+            int need = p.top_k;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                hist[tid] = 0;
+                __syncthreads();
+                const uint32_t mask_hi = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+                for (int v = tid; v < V; v += 256) {
+                    const uint32_t k = float_key(sc[v]);
+                    if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int cum = 0, d = 255;
+                    for (; d > 0; --d) {
+                        if (cum + hist[d] >= need) break;
+                        cum += hist[d];
+                    }
+                    sel_prefix = (int)(prefix | ((uint32_t)d << shift));
+                    sel_need = need - cum;
+                }
+                __syncthreads();
+                prefix = (uint32_t)sel_prefix;
+                need = sel_need;
+                __syncthreads();
+            }
+            // prefix is now the key of the k-th largest score; drop everything strictly below (HF TopK)
+            for (int v = tid; v < V; v += 256)
+                if (float_key(sc[v]) < prefix) sc[v] = -INFINITY;
+            __syncthreads();
+        }
+        // softmax numerators
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += 256) m = fmaxf(m, sc[v]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) fred[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+        __syncthreads();
+        const int chunk = (V + 255) / 256;
+        const int v0 = tid * chunk, v1 = min(V, v0 + chunk);
+        float mine = 0.f;
+        for (int v = v0; v < v1; ++v) {
+            const float e = expf(sc[v] - m);
+            sc[v] = e;
+            mine += e;
+        }
+        scan[tid] = mine;
+        if (tid == 0) { pick_lo = 0x7fffffff; pick_hi = -1; }
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan in index order
+            const float add = tid >= o ? scan[tid - o] : 0.f;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        const float total = scan[255];
+        uint32_t r[4];
+        const uint32_t step = p.step_dev ? (uint32_t)*p.step_dev : 0u;
+        philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
+        const float u = (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+        const float target = u * total;
+        float run = scan[tid] - mine;
+        for (int v = v0; v < v1; ++v) {
+            const float e = sc[v];
+            if (e > 0.f) {
+                atomicMax(&pick_hi, v);
+                if (run + e > target) { atomicMin(&pick_lo, v); break; }
+            }
+            run += e;
+        }
+        __syncthreads();
+        token = pick_lo != 0x7fffffff ? pick_lo : pick_hi;
+    }
+
+    if (tid == 0) {
+        if (p.unfinished) {
+            const int uf = p.unfinished[b];
+            if (!uf) token = p.eos;                        // finished rows keep receiving pad (= eos)
+            p.unfinished[b] = uf && (token != p.eos);
+            if (p.generated_out) p.generated_out[(size_t)b * p.gen_stride + n_gen] = token;
+        }
+        p.tok_out[(size_t)b * p.tok_stride] = token;
+    }
+}
+
+void launch_sample(const SampleParams& p, hipStream_t st) {
+    QTTS_REQUIRE(p.V <= SAMPLE_MAX_V, QTTS_ERR_LIMIT, "sample: vocab too large");
+    QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f), QTTS_ERR_ARG,
+                 "sample: top_p < 1 is not implemented on device yet (use top_k)");
+    hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, st, p);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------- loop bookkeeping
+// After every row sampled token #n: n_generated++, kv_len++, and latch `done` exactly where HF's
+// stopping criteria would break (all rows finished, or max_new_tokens reached).
+__global__ void sample_finish_kernel(StepState st, int B, int max_new_tokens) {
+    if (*st.done) return;
+    if (threadIdx.x == 0) {
+        const int n = *st.n_generated + 1;
+        *st.n_generated = n;
+        *st.gen_step += 1;
+        *st.kv_len += 1;
+        int any = 0;
+        for (int b = 0; b < B; ++b) any |= st.unfinished[b];
+        if (n >= max_new_tokens || !any) { *st.done = 1; *st.final_count = n; }
+    }
+}
+void launch_sample_finish(const StepState& s, int B, int max_new_tokens, hipStream_t st) {
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, st, s, B, max_new_tokens);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------- glue kernels
+__device__ inline float block_sum256(float v, float* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__device__ inline unsigned long long ss_fixed(float s) { return (unsigned long long)((double)s * SS_SCALE + 0.5); }
+
+// code-predictor input rows (M:1671-1672, 1281).  pass 0: rows [0,B) = past_hidden, rows [B,2B) =
+// talker codec_embedding[cur_tok]; pass j>0: rows [0,B) = cp codec_embedding[j-1][sub[b][j-1]].
+__global__ __launch_bounds__(256) void cp_gather_kernel(CpGatherParams p) {
+    if (p.done && *p.done) return;
+    __shared__ float sm[4];
+    const int r = blockIdx.x;
+    if (p.ss_zero && r == 0 && threadIdx.x < 64) p.ss_zero[threadIdx.x] = 0ull;
+    const float* src;
+    if (p.pass == 0) {
+        const int t = r / p.B, b = r % p.B;
+        src = t == 0 ? p.past_hidden + (size_t)b * p.H : p.talker_emb + (size_t)p.cur_tok[b] * p.H;
+    } else {
+        src = p.cp_emb + ((size_t)(p.pass - 1) * p.cp_vocab + p.sub[(size_t)r * p.sub_stride + p.pass - 1]) * p.H;
+    }
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        *reinterpret_cast<float4*>(p.out + (size_t)r * p.H + c) = v;
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = block_sum256(s, sm);
+    if (threadIdx.x == 0 && p.ss) p.ss[r] = ss_fixed(s);
+}
+void launch_cp_gather(const CpGatherParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(cp_gather_kernel, dim3(p.pass == 0 ? 2 * p.B : p.B), dim3(256), 0, st, p);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// next talker input (M:1681-1692): sum of the 16 codebook embeddings (+ trailing text or tts_pad), and
+// the frame's outputs: codes[b][f][:] (int64) and hidden[b][f] = past_hidden.
+__global__ __launch_bounds__(256) void embed_sum_kernel(EmbedSumParams p) {
+    if (*p.st.done) return;
+    __shared__ float sm[4];
+    const int b = blockIdx.x;
+    const int f = *p.st.gen_step;          // frame index == generation_step
+    const int tok0 = p.cur_tok[b];
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
+        float4 a = *reinterpret_cast<const float4*>(p.talker_emb + (size_t)tok0 * p.H + c);
+        for (int i = 0; i < p.G - 1; ++i) {
+            const int tk = p.sub[(size_t)b * p.sub_stride + i];
+            const float4 e = *reinterpret_cast<const float4*>(p.cp_emb + ((size_t)i * p.cp_vocab + tk) * p.H + c);
+            a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w;
+        }
+        const float* tp = f < p.Tt ? p.trailing + ((size_t)b * p.Tt + f) * p.H : p.tts_pad;
+        const float4 t = *reinterpret_cast<const float4*>(tp + c);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        *reinterpret_cast<float4*>(p.x_out + (size_t)b * p.H + c) = a;
+        s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        if (p.hidden_out) {
+            const float4 h = *reinterpret_cast<const float4*>(p.past_hidden + (size_t)b * p.H + c);
+            *reinterpret_cast<float4*>(p.hidden_out + ((size_t)b * p.max_frames + f) * p.H + c) = h;
+        }
+    }
+    s = block_sum256(s, sm);
+    if (threadIdx.x == 0) p.ss[b] = ss_fixed(s);
+    if (threadIdx.x < p.G && f < p.max_frames) {
+        const int64_t v = threadIdx.x == 0 ? tok0 : p.sub[(size_t)b * p.sub_stride + threadIdx.x - 1];
+        p.codes_out[((size_t)b * p.max_frames + f) * p.G + threadIdx.x] = v;
+    }
+}
+void launch_embed_sum(const EmbedSumParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(embed_sum_kernel, dim3(p.B), dim3(256), 0, st, p);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// y = g * (x * rstd) with rstd from the fixed-point sum of squares (final talker norm -> past_hidden)
+__global__ __launch_bounds__(256) void apply_norm_kernel(const float* x, int ldx, const unsigned long long* ss,
+                                                         const float* g, float eps, float* y, int ldy, int C,
+                                                         const int* done) {
+    if (done && *done) return;
+    const int r = blockIdx.x;
+    const float rstd = rsqrtf((float)((double)ss[r] * (1.0 / SS_SCALE)) / (float)C + eps);
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        const float4 w = *reinterpret_cast<const float4*>(g + c);
+        float4 o;
+        o.x = w.x * (v.x * rstd); o.y = w.y * (v.y * rstd); o.z = w.z * (v.z * rstd); o.w = w.w * (v.w * rstd);
+        *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = o;
+    }
+}
+void launch_apply_norm(const float* x, int ldx, const unsigned long long* ss, const float* g, float eps, float* y,
+                       int ldy, int rows, int C, const int* done, hipStream_t st) {
+    hipLaunchKernelGGL(apply_norm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, ss, g, eps, y, ldy, C, done);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// per-row fixed-point sum of squares of an arbitrary [rows][C] buffer
+__global__ __launch_bounds__(256) void row_ss_kernel(const float* x, int ldx, int C, unsigned long long* ss) {
+    __shared__ float sm[4];
+    const int r = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = block_sum256(s, sm);
+    if (threadIdx.x == 0) ss[r] = ss_fixed(s);
+}
+void launch_row_ss(const float* x, int ldx, int rows, int C, unsigned long long* ss, hipStream_t st) {
+    hipLaunchKernelGGL(row_ss_kernel, dim3(rows), dim3(256), 0, st, x, ldx, C, ss);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace qtts

@@ -1,0 +1,606 @@
+// talker_engine.hip -- host-side orchestration of the autoregressive speech-token decoder on gfx950:
+// talker prefill, the per-frame step (15-pass code predictor -> 16-way embedding sum -> 28-layer talker
+// -> codec_head -> HF sampler) and its hipGraph capture.
+//
+// Everything that changes from frame to frame (KV length, positions, generation_step, finished flags,
+// token history, RNG offset) lives in device memory and is advanced by kernels, so one captured graph
+// is replayed for every frame; the host only polls a `done` flag every few frames.
+//
+// HBM layout:
+//   weights   decode: packed 1-KiB MFMA tiles (skinny.hip), fp32 or bf16; prefill: row-major [N][K] copy
+//   KV cache  paged, 16 tokens per page: pool[layer][page][kv_head][16][128] (fp32 or bf16), page table per
+//             sequence reserved at create for max_seq tokens (no growth inside the captured step)
+//   state     residual stream / qkv / mlp activations fp32 [rows <= 64][dim]; rows = t*B + b
+#include <map>
+#include <algorithm>
+#include "common.h"
+#include "kernels.h"
+#include "glue.h"
+
+using namespace qtts;
+
+namespace {
+
+struct LayerW {
+    DevBuf qkv_p, o_p, gu_p, d_p;     // packed (decode)
+    DevBuf qkv_r, o_r, gu_r, d_r;     // row-major (prefill, talker only)
+    DevBuf g1, g2, qn, kn;
+};
+struct StackDims { int H, I, nh, nkv, hd, qd, kvd; float eps; };
+
+}  // namespace
+
+struct qtts_talker {
+    qtts_talker_config cfg;
+    bool bf16 = false, finalized = false, prefilled = false;
+    std::map<std::string, std::vector<float>> host;
+    std::map<std::string, std::vector<int64_t>> shapes;
+
+    StackDims td, cd;
+    std::vector<LayerW> tl, cl;
+    DevBuf t_norm, c_norm, head_p, emb_talker, emb_cp, proj_p, proj_b, inv_freq_t, inv_freq_c;
+    std::vector<DevBuf> lm_head_p;
+    DevBuf tp_fc1, tp_b1, tp_fc2, tp_b2;
+    bool has_proj = false, has_text_proj = false;
+    double weight_bytes_frame = 0;
+
+    // KV caches
+    DevBuf kpool_t, vpool_t, kpool_c, vpool_c, ptab_t, ptab_c;
+    KvCache kv_t, kv_c;
+    // decode state / scratch
+    DevBuf x, qkv, att, act, logits, past_hidden, cp_in, cp_x, cp_qkv, cp_att, cp_act, cp_logits;
+    DevBuf cur_tok, sub, generated, ss_ring, ints, n_pad_d, suppress, trailing, tts_pad;
+    // prefill scratch
+    DevBuf pf_x, pf_n, pf_qkv, pf_att, pf_act, tp_tmp;
+    StepState ss;
+    int B = 0, T0 = 0, Tt = 0, gen_cap = 0;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_nodes = 0;
+    // profiling of the dominant kernel
+    bool profile = false, timing_now = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double prof_ms = 0; int64_t prof_launches = 0;
+    int frames_run = 0;
+
+    std::vector<float>& P(const std::string& n) {
+        auto it = host.find(n);
+        if (it == host.end()) throw Error(QTTS_ERR_UNBOUND, "talker weight not bound: " + n);
+        return it->second;
+    }
+    void upload_f(DevBuf& d, const std::vector<float>& w) { d.upload(w.data(), w.size() * 4); }
+    void upload_rows(DevBuf& d, const std::vector<float>& w) {
+        if (bf16) {
+            std::vector<bf16_t> h(w.size());
+            for (size_t i = 0; i < w.size(); ++i) h[i] = f32_to_bf16(w[i]);
+            d.upload(h.data(), h.size() * 2);
+        } else d.upload(w.data(), w.size() * 4);
+    }
+    void upload_packed(DevBuf& d, const std::vector<float>& w, int N, int K) {
+        std::vector<char> h(skinny_packed_bytes(N, K, bf16));
+        pack_skinny_weight(w.data(), N, K, bf16, h.data());
+        d.upload(h.data(), h.size());
+    }
+    static std::vector<float> cat3(const std::vector<float>& a, const std::vector<float>& b, const std::vector<float>& c) {
+        std::vector<float> w; w.reserve(a.size() + b.size() + c.size());
+        w.insert(w.end(), a.begin(), a.end()); w.insert(w.end(), b.begin(), b.end()); w.insert(w.end(), c.begin(), c.end());
+        return w;
+    }
+    static std::vector<float> interleave_gu(const std::vector<float>& g, const std::vector<float>& u, int I, int H) {
+        std::vector<float> w((size_t)2 * I * H);
+        for (int f = 0; f < I; ++f) {
+            memcpy(&w[((size_t)(f / 16) * 32 + f % 16) * H], &g[(size_t)f * H], (size_t)H * 4);
+            memcpy(&w[((size_t)(f / 16) * 32 + 16 + f % 16) * H], &u[(size_t)f * H], (size_t)H * 4);
+        }
+        return w;
+    }
+    void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
+        auto qkvw = cat3(P(p + "self_attn.q_proj.weight"), P(p + "self_attn.k_proj.weight"), P(p + "self_attn.v_proj.weight"));
+        auto guw = interleave_gu(P(p + "mlp.gate_proj.weight"), P(p + "mlp.up_proj.weight"), d.I, d.H);
+        upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H);
+        upload_packed(L.o_p, P(p + "self_attn.o_proj.weight"), d.H, d.qd);
+        upload_packed(L.gu_p, guw, 2 * d.I, d.H);
+        upload_packed(L.d_p, P(p + "mlp.down_proj.weight"), d.H, d.I);
+        if (rows) {
+            upload_rows(L.qkv_r, qkvw);
+            upload_rows(L.o_r, P(p + "self_attn.o_proj.weight"));
+            upload_rows(L.gu_r, guw);
+            upload_rows(L.d_r, P(p + "mlp.down_proj.weight"));
+        }
+        upload_f(L.g1, P(p + "input_layernorm.weight"));
+        upload_f(L.g2, P(p + "post_attention_layernorm.weight"));
+        upload_f(L.qn, P(p + "self_attn.q_norm.weight"));
+        upload_f(L.kn, P(p + "self_attn.k_norm.weight"));
+    }
+    void finalize();
+
+    unsigned long long* ring(int i) { return ss_ring.as<unsigned long long>() + (size_t)(i % 3) * 64; }
+
+    void skinny(const SkinnyParams& p, hipStream_t st) {
+        if (timing_now) {
+            hipEvent_t a, b;
+            QTTS_CHECK_HIP(hipEventCreate(&a)); QTTS_CHECK_HIP(hipEventCreate(&b));
+            QTTS_CHECK_HIP(hipEventRecord(a, st));
+            launch_skinny(p, bf16, st);
+            QTTS_CHECK_HIP(hipEventRecord(b, st));
+            ev.push_back({a, b});
+        } else launch_skinny(p, bf16, st);
+    }
+
+    // one decoder layer on `M = n_new * B` rows of `xs` (in place), fixed-point sum-of-squares ring index r
+    void decode_layer(const LayerW& L, const StackDims& d, float* xs, float* qkvb, float* attb, float* actb, int M,
+                      int n_new, KvCache& kv, int layer, const int* len_dev, int len_static, const int* npad,
+                      const float* inv_freq, int max_len, int& r, hipStream_t st) {
+        SkinnyParams p{};
+        p.done_flag = ss.done;
+        p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
+        p.g = L.g1.as<float>(); p.ss_in = ring(r); p.eps = d.eps; p.ss_zero = ring(r + 1);
+        p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
+        skinny(p, st);
+        AttnDecodeParams a{};
+        a.qkv = qkvb; a.ld = d.qd + 2 * d.kvd; a.B = B; a.n_new = n_new; a.nh = d.nh; a.nkv = d.nkv; a.hd = d.hd;
+        a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
+        a.len_dev = len_dev; a.len_static = len_static; a.kv = kv; a.layer = layer; a.out = attb; a.ldo = d.qd;
+        a.max_len = max_len; a.done_flag = ss.done;
+        launch_attn_decode(a, st);
+        SkinnyParams o{};
+        o.done_flag = ss.done;
+        o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
+        o.out = xs; o.ldo = d.H; o.ss_out = ring(r + 1); o.act = ACT_NONE;
+        skinny(o, st);
+        r = (r + 1) % 3;
+        SkinnyParams g{};
+        g.done_flag = ss.done;
+        g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.g = L.g2.as<float>();
+        g.ss_in = ring(r); g.eps = d.eps; g.ss_zero = ring(r + 1); g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
+        skinny(g, st);
+        SkinnyParams dn{};
+        dn.done_flag = ss.done;
+        dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
+        dn.out = xs; dn.ldo = d.H; dn.ss_out = ring(r + 1); dn.act = ACT_NONE;
+        skinny(dn, st);
+        r = (r + 1) % 3;
+    }
+
+    void prefill(const float* embeds, int B_, int T, const int32_t* n_pad_host, const float* trailing_dev, int Tt_,
+                 const float* tts_pad_dev, hipStream_t st);
+    void sample_talker(const qtts_sampling& sp, int eos, int min_new, int max_new, hipStream_t st);
+    void frame_step(const qtts_sampling& sp, int eos, int min_new, int max_new, int64_t* codes, float* hidden,
+                    int max_frames, hipStream_t st);
+    void destroy_graph() {
+        if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+    }
+    ~qtts_talker() { destroy_graph(); }
+};
+
+void qtts_talker::finalize() {
+    const auto& c = cfg;
+    td = {c.hidden_size, c.intermediate_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim,
+          c.num_attention_heads * c.head_dim, c.num_key_value_heads * c.head_dim, c.rms_norm_eps};
+    cd = {c.cp_hidden_size, c.cp_intermediate_size, c.cp_num_attention_heads, c.cp_num_key_value_heads, c.cp_head_dim,
+          c.cp_num_attention_heads * c.cp_head_dim, c.cp_num_key_value_heads * c.cp_head_dim, c.cp_rms_norm_eps};
+    QTTS_REQUIRE(td.hd == 128 && cd.hd == 128, QTTS_ERR_ARG, "talker/code-predictor head_dim must be 128");
+    QTTS_REQUIRE(td.nh / td.nkv <= 2 && cd.nh / cd.nkv <= 2, QTTS_ERR_ARG, "GQA group size must be <= 2");
+    QTTS_REQUIRE(c.max_batch >= 1 && c.max_batch <= 32, QTTS_ERR_LIMIT, "max_batch must be 1..32");
+    QTTS_REQUIRE(td.I % 16 == 0 && cd.I % 16 == 0, QTTS_ERR_ARG, "intermediate sizes % 16");
+    const int G = c.num_code_groups;
+    tl.resize(c.num_hidden_layers);
+    for (int l = 0; l < c.num_hidden_layers; ++l) build_layer(tl[l], "model.layers." + std::to_string(l) + ".", td, true);
+    cl.resize(c.cp_num_hidden_layers);
+    for (int l = 0; l < c.cp_num_hidden_layers; ++l)
+        build_layer(cl[l], "code_predictor.model.layers." + std::to_string(l) + ".", cd, false);
+    upload_f(t_norm, P("model.norm.weight"));
+    upload_f(c_norm, P("code_predictor.model.norm.weight"));
+    upload_packed(head_p, P("codec_head.weight"), c.vocab_size, td.H);
+    upload_f(emb_talker, P("model.codec_embedding.weight"));
+    {
+        std::vector<float> e((size_t)(G - 1) * c.cp_vocab_size * td.H);
+        for (int g = 0; g < G - 1; ++g) {
+            auto& w = P("code_predictor.model.codec_embedding." + std::to_string(g) + ".weight");
+            memcpy(&e[(size_t)g * c.cp_vocab_size * td.H], w.data(), w.size() * 4);
+        }
+        upload_f(emb_cp, e);
+    }
+    lm_head_p.resize(G - 1);
+    for (int g = 0; g < G - 1; ++g)
+        upload_packed(lm_head_p[g], P("code_predictor.lm_head." + std::to_string(g) + ".weight"), c.cp_vocab_size, cd.H);
+    has_proj = cd.H != td.H;
+    if (has_proj) {
+        upload_packed(proj_p, P("code_predictor.small_to_mtp_projection.weight"), cd.H, td.H);
+        upload_f(proj_b, P("code_predictor.small_to_mtp_projection.bias"));
+    }
+    has_text_proj = host.count("text_projection.linear_fc1.weight") > 0;
+    if (has_text_proj) {
+        upload_rows(tp_fc1, P("text_projection.linear_fc1.weight")); upload_f(tp_b1, P("text_projection.linear_fc1.bias"));
+        upload_rows(tp_fc2, P("text_projection.linear_fc2.weight")); upload_f(tp_b2, P("text_projection.linear_fc2.bias"));
+    }
+    auto mk_freq = [&](DevBuf& d, const char* name, float theta, int hd) {
+        if (host.count(name)) { upload_f(d, P(name)); return; }
+        std::vector<float> f(hd / 2);
+        for (int i = 0; i < hd / 2; ++i) f[i] = 1.0f / powf(theta, (float)(2 * i) / (float)hd);
+        upload_f(d, f);
+    };
+    mk_freq(inv_freq_t, "model.rotary_emb.inv_freq", c.rope_theta, td.hd);
+    mk_freq(inv_freq_c, "code_predictor.model.rotary_emb.inv_freq", c.cp_rope_theta, cd.hd);
+
+    // bytes of packed weights one frame step streams (bench.py's roofline numerator)
+    const double eb = bf16 ? 2.0 : 4.0;
+    auto layer_b = [&](const StackDims& d) { return eb * ((double)(d.qd + 2 * d.kvd) * d.H + (double)d.H * d.qd + 3.0 * d.I * d.H); };
+    weight_bytes_frame = c.num_hidden_layers * layer_b(td) + eb * (double)c.vocab_size * td.H +
+                         (G - 1) * (c.cp_num_hidden_layers * layer_b(cd) + eb * (double)c.cp_vocab_size * cd.H +
+                                    (has_proj ? eb * (double)cd.H * td.H : 0.0));
+
+    // ---- KV caches (pages of 16 tokens, reserved up front)
+    const size_t esz = bf16 ? 2 : 4;
+    const int pps = cdiv(c.max_seq, 16);
+    kv_t = {nullptr, nullptr, nullptr, pps, pps * c.max_batch, td.nkv, td.hd, bf16 ? 1 : 0};
+    const size_t tb = (size_t)c.num_hidden_layers * kv_t.n_pages * td.nkv * 16 * td.hd * esz;
+    kpool_t.alloc(tb); vpool_t.alloc(tb);
+    const int cpps = cdiv(G + 1, 16);
+    kv_c = {nullptr, nullptr, nullptr, cpps, cpps * c.max_batch, cd.nkv, cd.hd, bf16 ? 1 : 0};
+    const size_t cb = (size_t)c.cp_num_hidden_layers * kv_c.n_pages * cd.nkv * 16 * cd.hd * esz;
+    kpool_c.alloc(cb); vpool_c.alloc(cb);
+    {
+        std::vector<int> t((size_t)c.max_batch * pps), u((size_t)c.max_batch * cpps);
+        for (size_t i = 0; i < t.size(); ++i) t[i] = (int)i;
+        for (size_t i = 0; i < u.size(); ++i) u[i] = (int)i;
+        ptab_t.upload(t.data(), t.size() * 4); ptab_c.upload(u.data(), u.size() * 4);
+    }
+    kv_t.k = kpool_t.p; kv_t.v = vpool_t.p; kv_t.page_table = ptab_t.as<int>();
+    kv_c.k = kpool_c.p; kv_c.v = vpool_c.p; kv_c.page_table = ptab_c.as<int>();
+
+    // ---- decode scratch (rows <= 64)
+    const int R = 64;
+    x.alloc((size_t)R * td.H * 4); qkv.alloc((size_t)R * (td.qd + 2 * td.kvd) * 4); att.alloc((size_t)R * td.qd * 4);
+    act.alloc((size_t)R * td.I * 4); logits.alloc((size_t)R * c.vocab_size * 4); past_hidden.alloc((size_t)R * td.H * 4);
+    cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
+    cp_att.alloc((size_t)R * cd.qd * 4); cp_act.alloc((size_t)R * cd.I * 4); cp_logits.alloc((size_t)R * c.cp_vocab_size * 4);
+    cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_ring.alloc(3 * 64 * 8); ints.alloc(64 * 4 + R * 4);
+    n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size);
+    QTTS_CHECK_HIP(hipMemset(ss_ring.p, 0, ss_ring.bytes));
+    int* ip = ints.as<int>();
+    ss = {ip + 0, ip + 1, ip + 2, ip + 3, ip + 4, ip + 64};
+    host.clear();
+    finalized = true;
+}
+
+// ------------------------------------------------------------------------------------------ prefill
+void qtts_talker::prefill(const float* embeds, int B_, int T, const int32_t* n_pad_host, const float* trailing_dev,
+                          int Tt_, const float* tts_pad_dev, hipStream_t st) {
+    const auto& c = cfg;
+    QTTS_REQUIRE(finalized, QTTS_ERR_STATE, "talker: finalize() first");
+    QTTS_REQUIRE(B_ >= 1 && B_ <= c.max_batch, QTTS_ERR_LIMIT, "talker: batch exceeds max_batch");
+    QTTS_REQUIRE(T >= 1 && T < c.max_seq, QTTS_ERR_LIMIT, "talker: prompt longer than max_seq");
+    QTTS_REQUIRE(Tt_ >= 1, QTTS_ERR_ARG, "talker: trailing_text_hidden must have >= 1 row");
+    B = B_; T0 = T; Tt = Tt_;
+    for (int b = 0; b < B; ++b) QTTS_REQUIRE(n_pad_host[b] >= 0 && n_pad_host[b] < T, QTTS_ERR_ARG, "talker: n_pad out of range");
+    const int M = B * T, H = td.H, W = td.qd + 2 * td.kvd;
+    pf_x.ensure((size_t)M * H * 4); pf_n.ensure((size_t)M * std::max(H, td.qd) * 4); pf_qkv.ensure((size_t)M * W * 4);
+    pf_att.ensure((size_t)M * td.qd * 4); pf_act.ensure((size_t)M * td.I * 4);
+    trailing.ensure((size_t)B * Tt * H * 4); tts_pad.ensure((size_t)H * 4);
+    QTTS_CHECK_HIP(hipMemcpyAsync(pf_x.p, embeds, (size_t)M * H * 4, hipMemcpyDeviceToDevice, st));
+    QTTS_CHECK_HIP(hipMemcpyAsync(trailing.p, trailing_dev, (size_t)B * Tt * H * 4, hipMemcpyDeviceToDevice, st));
+    QTTS_CHECK_HIP(hipMemcpyAsync(tts_pad.p, tts_pad_dev, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+    QTTS_CHECK_HIP(hipMemcpyAsync(n_pad_d.p, n_pad_host, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    float *xs = pf_x.as<float>(), *nb = pf_n.as<float>(), *qb = pf_qkv.as<float>(), *ab = pf_att.as<float>(), *mb = pf_act.as<float>();
+    auto gemm = [&](const DevBuf& Wr, int N, int K, const float* A, int lda, float* C, int ldc, int act_, const float* res) {
+        GemmTapParams p{};
+        p.A = A; p.lda = lda; p.M = M; p.T = T; p.W = Wr.p; p.N = N; p.K = K; p.taps = 1; p.act = act_;
+        p.res = res; p.ldr = H; p.C = C; p.ldc = ldc;
+        launch_gemm_tap(p, bf16, st);
+    };
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        auto& L = tl[l];
+        launch_rmsnorm(xs, H, L.g1.as<float>(), td.eps, nb, H, M, H, st);
+        gemm(L.qkv_r, W, H, nb, H, qb, W, ACT_NONE, nullptr);
+        QkNormRopeParams q{};
+        q.qkv = qb; q.ld = W; q.B = B; q.T = T; q.nh = td.nh; q.nkv = td.nkv; q.hd = td.hd; q.qw = L.qn.as<float>();
+        q.kw = L.kn.as<float>(); q.eps = td.eps; q.inv_freq = inv_freq_t.as<float>(); q.n_pad = n_pad_d.as<int>();
+        q.kv = kv_t; q.layer = l;
+        launch_qknorm_rope_store(q, st);
+        AttnRowsParams a{};
+        a.qkv = qb; a.ld = W; a.q_off = 0; a.k_off = td.qd; a.v_off = td.qd + td.kvd; a.B = B; a.T = T; a.nh = td.nh;
+        a.nkv = td.nkv; a.hd = td.hd; a.window = 0; a.n_pad = n_pad_d.as<int>(); a.out = ab; a.ldo = td.qd;
+        launch_attn_rows(a, st);
+        gemm(L.o_r, H, td.qd, ab, td.qd, xs, H, ACT_NONE, xs);
+        launch_rmsnorm(xs, H, L.g2.as<float>(), td.eps, nb, H, M, H, st);
+        gemm(L.gu_r, 2 * td.I, H, nb, H, mb, td.I, ACT_SWIGLU, nullptr);
+        gemm(L.d_r, H, td.I, mb, td.I, xs, H, ACT_NONE, xs);
+    }
+    // last position of every (left-padded) row -> final norm -> past_hidden, logits (M:1726-1740)
+    for (int b = 0; b < B; ++b)
+        QTTS_CHECK_HIP(hipMemcpyAsync(x.as<float>() + (size_t)b * H, xs + ((size_t)b * T + T - 1) * H, (size_t)H * 4,
+                                      hipMemcpyDeviceToDevice, st));
+    launch_rmsnorm(x.as<float>(), H, t_norm.as<float>(), td.eps, past_hidden.as<float>(), H, B, H, st);
+    // loop state: the first sample+finish turns these into n_generated = 1, gen_step = 0, kv_len = T
+    int init[5] = {0, -1, T - 1, 0, 0};
+    QTTS_CHECK_HIP(hipMemcpyAsync(ss.n_generated, init, sizeof(init), hipMemcpyHostToDevice, st));
+    std::vector<int> ones(B, 1);
+    QTTS_CHECK_HIP(hipMemcpyAsync(ss.unfinished, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    SkinnyParams h{};
+    h.x = past_hidden.as<float>(); h.ldx = H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = H;
+    h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE;
+    launch_skinny(h, bf16, st);
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));  // host buffers (n_pad, init, ones) must outlive the copies
+    prefilled = true;
+}
+
+// ------------------------------------------------------------------------------------------ sampling of cb-0
+void qtts_talker::sample_talker(const qtts_sampling& sp, int eos, int min_new, int max_new, hipStream_t st) {
+    SampleParams p{};
+    p.logits = logits.as<float>(); p.ld = cfg.vocab_size; p.V = cfg.vocab_size; p.B = B;
+    p.generated = generated.as<int>(); p.gen_stride = gen_cap; p.n_generated_dev = ss.n_generated;
+    p.repetition_penalty = sp.repetition_penalty; p.eos = eos; p.min_new_tokens = min_new;
+    p.suppress_mask = suppress.as<unsigned char>();
+    p.do_sample = sp.do_sample; p.top_k = sp.top_k; p.top_p = sp.top_p; p.temperature = sp.temperature;
+    p.seed = sp.seed; p.stream_id = 0; p.step_dev = ss.n_generated;
+    p.tok_out = cur_tok.as<int>(); p.tok_stride = 1; p.unfinished = ss.unfinished; p.generated_out = generated.as<int>();
+    p.max_new_tokens = max_new; p.done_in = ss.done;
+    launch_sample(p, st);
+    launch_sample_finish(ss, B, max_new, st);
+}
+
+// ------------------------------------------------------------------------------------------ one frame
+void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int max_new, int64_t* codes, float* hidden,
+                             int max_frames, hipStream_t st) {
+    const auto& c = cfg;
+    const int G = c.num_code_groups;
+    int r = 0;
+    // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
+    for (int j = 0; j < G - 1; ++j) {
+        const int n_new = j == 0 ? 2 : 1, M = n_new * B;
+        CpGatherParams gp{};
+        gp.pass = j; gp.B = B; gp.H = td.H; gp.past_hidden = past_hidden.as<float>(); gp.talker_emb = emb_talker.as<float>();
+        gp.cur_tok = cur_tok.as<int>(); gp.cp_emb = emb_cp.as<float>(); gp.cp_vocab = c.cp_vocab_size;
+        gp.sub = sub.as<int>(); gp.sub_stride = G; gp.done = ss.done;
+        // invariant: ring(r) holds sum(x^2) of the current residual stream; a producer of a fresh x writes
+        // ring(r+1) (direct store, or accumulation into entries zeroed by the previous consumer / the gather)
+        if (has_proj) {
+            gp.out = cp_in.as<float>(); gp.ss = nullptr; gp.ss_zero = ring(r + 1);
+            launch_cp_gather(gp, st);
+            SkinnyParams pj{};
+            pj.done_flag = ss.done;
+            pj.x = cp_in.as<float>(); pj.ldx = td.H; pj.M = M; pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
+            pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.ss_out = ring(r + 1); pj.act = ACT_NONE;
+            skinny(pj, st);
+        } else {
+            gp.out = cp_x.as<float>(); gp.ss = ring(r + 1); gp.ss_zero = nullptr;
+            launch_cp_gather(gp, st);
+        }
+        r = (r + 1) % 3;
+        for (int l = 0; l < c.cp_num_hidden_layers; ++l)
+            decode_layer(cl[l], cd, cp_x.as<float>(), cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
+                         kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, r, st);
+        // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
+        SkinnyParams lh{};
+        lh.done_flag = ss.done;
+        const int off = (n_new - 1) * B;
+        lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
+        lh.K = cd.H; lh.g = c_norm.as<float>(); lh.ss_in = ring(r) + off; lh.eps = cd.eps; lh.out = cp_logits.as<float>();
+        lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE;
+        lh.ss_zero = ring(r + 1);
+        skinny(lh, st);
+        SampleParams s{};
+        s.logits = cp_logits.as<float>(); s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
+        s.repetition_penalty = 1.0f; s.eos = -1; s.do_sample = sp.subtalker_dosample; s.top_k = sp.subtalker_top_k;
+        s.top_p = sp.subtalker_top_p; s.temperature = sp.subtalker_temperature; s.seed = sp.seed; s.stream_id = 1 + j;
+        s.step_dev = ss.n_generated; s.tok_out = sub.as<int>() + j; s.tok_stride = G; s.done_in = ss.done;
+        launch_sample(s, st);
+    }
+    // ---- next talker input + frame outputs (M:1681-1692)
+    EmbedSumParams e{};
+    e.B = B; e.H = td.H; e.G = G; e.cp_vocab = c.cp_vocab_size; e.talker_emb = emb_talker.as<float>();
+    e.cp_emb = emb_cp.as<float>(); e.cur_tok = cur_tok.as<int>(); e.sub = sub.as<int>(); e.sub_stride = G;
+    e.trailing = trailing.as<float>(); e.Tt = Tt; e.tts_pad = tts_pad.as<float>(); e.past_hidden = past_hidden.as<float>();
+    e.x_out = x.as<float>(); e.ss = ring(r + 1); e.codes_out = codes; e.hidden_out = hidden; e.max_frames = max_frames; e.st = ss;
+    launch_embed_sum(e, st);
+    r = (r + 1) % 3;
+    // ---- talker decode forward (M:1706-1727)
+    for (int l = 0; l < c.num_hidden_layers; ++l)
+        decode_layer(tl[l], td, x.as<float>(), qkv.as<float>(), att.as<float>(), act.as<float>(), B, 1, kv_t, l, ss.kv_len, 0,
+                     n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, r, st);
+    launch_apply_norm(x.as<float>(), td.H, ring(r), t_norm.as<float>(), td.eps, past_hidden.as<float>(), td.H, B, td.H,
+                      ss.done, st);
+    SkinnyParams h{};
+    h.done_flag = ss.done;
+    h.x = past_hidden.as<float>(); h.ldx = td.H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = td.H;
+    h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE;
+    skinny(h, st);
+    sample_talker(sp, eos, min_new, max_new, st);
+}
+
+// ============================================================================================ C ABI
+#define QTTS_API_BEGIN try {
+#define QTTS_API_END                                                        \
+    }                                                                       \
+    catch (const qtts::Error& e) { qtts::set_last_error(e.what()); return e.code; } \
+    catch (const std::exception& e) { qtts::set_last_error(e.what()); return QTTS_ERR_ARG; } \
+    return QTTS_OK;
+
+extern "C" {
+
+int qtts_talker_create(const qtts_talker_config* cfg, qtts_talker** out) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(cfg && out, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(cfg->weight_dtype == QTTS_F32 || cfg->weight_dtype == QTTS_BF16, QTTS_ERR_ARG, "weight_dtype");
+    QTTS_REQUIRE(cfg->num_code_groups >= 2 && cfg->num_code_groups <= 32, QTTS_ERR_ARG, "num_code_groups");
+    QTTS_REQUIRE(cfg->hidden_size % 128 == 0 && cfg->cp_hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0 &&
+                     cfg->cp_intermediate_size % 128 == 0, QTTS_ERR_ARG, "hidden/intermediate sizes must be multiples of 128");
+    QTTS_REQUIRE(cfg->vocab_size % 16 == 0 && cfg->cp_vocab_size % 16 == 0, QTTS_ERR_ARG, "vocab sizes % 16");
+    int ndev = 0;
+    QTTS_CHECK_HIP(hipGetDeviceCount(&ndev));
+    QTTS_REQUIRE(ndev > 0, QTTS_ERR_HIP, "no HIP device");
+    auto* t = new qtts_talker();
+    t->cfg = *cfg;
+    t->bf16 = cfg->weight_dtype == QTTS_BF16;
+    *out = t;
+    QTTS_API_END
+}
+void qtts_talker_destroy(qtts_talker* t) { delete t; }
+
+int qtts_talker_bind(qtts_talker* t, const char* name, const void* host, int32_t src_dtype, int32_t ndim,
+                     const int64_t* shape) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && name && host && shape, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(!t->finalized, QTTS_ERR_STATE, "bind after finalize");
+    QTTS_REQUIRE(src_dtype == QTTS_F32 || src_dtype == QTTS_BF16, QTTS_ERR_ARG, "src_dtype");
+    HostTensor ht{host, src_dtype, std::vector<int64_t>(shape, shape + ndim)};
+    t->host[name] = ht.to_f32();
+    t->shapes[name] = ht.shape;
+    QTTS_API_END
+}
+int qtts_talker_finalize(qtts_talker* t) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t, QTTS_ERR_ARG, "null handle");
+    t->finalize();
+    QTTS_API_END
+}
+
+int qtts_talker_text_projection(qtts_talker* t, const float* x_dev, int32_t rows, float* y_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && x_dev && y_dev && rows >= 1, QTTS_ERR_ARG, "bad argument");
+    QTTS_REQUIRE(t->finalized && t->has_text_proj, QTTS_ERR_STATE, "text_projection weights were not bound");
+    hipStream_t st = (hipStream_t)stream;
+    const int TH = t->cfg.text_hidden_size;
+    QTTS_REQUIRE(TH % 32 == 0, QTTS_ERR_ARG, "text_hidden_size % 32");
+    t->tp_tmp.ensure((size_t)rows * TH * 4);
+    // fc1 + bias, SiLU, fc2 + bias (M:815-816).  SiLU is applied by a SwiGLU-free path: act(v) = v*sigmoid(v)
+    GemmTapParams p{};
+    p.A = x_dev; p.lda = TH; p.M = rows; p.T = rows; p.W = t->tp_fc1.p; p.N = TH; p.K = TH; p.taps = 1;
+    p.bias = t->tp_b1.as<float>(); p.act = ACT_SILU; p.C = t->tp_tmp.as<float>(); p.ldc = TH;
+    launch_gemm_tap(p, t->bf16, st);
+    GemmTapParams q{};
+    q.A = t->tp_tmp.as<float>(); q.lda = TH; q.M = rows; q.T = rows; q.W = t->tp_fc2.p; q.N = t->td.H; q.K = TH; q.taps = 1;
+    q.bias = t->tp_b2.as<float>(); q.act = ACT_NONE; q.C = y_dev; q.ldc = t->td.H;
+    launch_gemm_tap(q, t->bf16, st);
+    QTTS_API_END
+}
+
+int qtts_talker_prefill(qtts_talker* t, const float* embeds_dev, int32_t B, int32_t T, const int32_t* n_pad_host,
+                        const float* trailing_dev, int32_t Tt, const float* tts_pad_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && embeds_dev && n_pad_host && trailing_dev && tts_pad_dev, QTTS_ERR_ARG, "null argument");
+    t->prefill(embeds_dev, B, T, n_pad_host, trailing_dev, Tt, tts_pad_dev, (hipStream_t)stream);
+    QTTS_API_END
+}
+
+int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_new_tokens, int32_t min_new_tokens,
+                         int32_t eos_token_id, const int32_t* suppress_host, int32_t n_suppress, int64_t* codes_dev,
+                         float* hidden_dev, int64_t* tokens_dev, int32_t* n_frames_host, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && sp && codes_dev && n_frames_host, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(t->prefilled, QTTS_ERR_STATE, "generate: prefill() first");
+    QTTS_REQUIRE(max_new_tokens >= 1, QTTS_ERR_ARG, "max_new_tokens >= 1");
+    QTTS_REQUIRE(t->T0 + max_new_tokens <= t->cfg.max_seq, QTTS_ERR_LIMIT, "prompt + max_new_tokens exceeds max_seq");
+    QTTS_REQUIRE(eos_token_id >= 0 && eos_token_id < t->cfg.vocab_size, QTTS_ERR_ARG, "eos_token_id");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = t->B, V = t->cfg.vocab_size;
+    t->prefilled = false;  // the KV cache / loop state are consumed by this call
+    {
+        std::vector<unsigned char> m(V, 0);
+        for (int i = 0; i < n_suppress; ++i) {
+            QTTS_REQUIRE(suppress_host[i] >= 0 && suppress_host[i] < V, QTTS_ERR_ARG, "suppress token out of range");
+            m[suppress_host[i]] = 1;
+        }
+        QTTS_CHECK_HIP(hipMemcpyAsync(t->suppress.p, m.data(), V, hipMemcpyHostToDevice, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    t->gen_cap = max_new_tokens;
+    t->generated.ensure((size_t)B * max_new_tokens * 4);
+    const int max_frames = std::max(1, max_new_tokens - 1);
+    t->frames_run = 0; t->graph_nodes = 0; t->prof_ms = 0; t->prof_launches = 0;
+
+    t->sample_talker(*sp, eos_token_id, min_new_tokens, max_new_tokens, st);      // token 0
+    int done = 0;
+    auto poll = [&]() {
+        QTTS_CHECK_HIP(hipMemcpyAsync(&done, t->ss.done, 4, hipMemcpyDeviceToHost, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    };
+    poll();
+    const bool use_graph = t->cfg.use_graph && !t->profile;
+    const int total = max_new_tokens - 1;      // at most this many frame steps
+    int f = 0;
+    t->destroy_graph();
+    while (!done && f < total) {
+        if (!use_graph || f == 0) {
+            t->timing_now = t->profile;
+            t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st);
+            t->timing_now = false;
+            ++f;
+            if (!use_graph && (f % 8 == 0)) poll();
+            if (use_graph) poll();
+            continue;
+        }
+        if (!t->graph_exec) {   // capture frame step #1 (not executed by the capture), then replay it
+            QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            try {
+                t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st);
+            } catch (...) {
+                hipGraph_t g = nullptr;
+                (void)hipStreamEndCapture(st, &g);
+                if (g) (void)hipGraphDestroy(g);
+                throw;
+            }
+            QTTS_CHECK_HIP(hipStreamEndCapture(st, &t->graph));
+            size_t nn = 0;
+            QTTS_CHECK_HIP(hipGraphGetNodes(t->graph, nullptr, &nn));
+            t->graph_nodes = (int)nn;
+            QTTS_CHECK_HIP(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
+        }
+        const int burst = std::min(8, total - f);
+        for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(t->graph_exec, st));
+        f += burst;
+        poll();
+    }
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    t->frames_run = f;
+    int fin[5];
+    QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    QTTS_REQUIRE(fin[3] == 1, QTTS_ERR_STATE, "generate: loop ended without the stop condition being latched");
+    *n_frames_host = fin[4] - 1;
+    if (tokens_dev) {   // int32 history -> int64 (B, max_new_tokens)
+        std::vector<int> h((size_t)B * max_new_tokens);
+        QTTS_CHECK_HIP(hipMemcpy(h.data(), t->generated.p, h.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int64_t> w(h.size(), -1);
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < fin[4]; ++i) w[(size_t)b * max_new_tokens + i] = h[(size_t)b * max_new_tokens + i];
+        QTTS_CHECK_HIP(hipMemcpy(tokens_dev, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+    }
+    if (t->profile) {
+        double ms = 0;
+        for (auto& e : t->ev) {
+            float m = 0;
+            QTTS_CHECK_HIP(hipEventElapsedTime(&m, e.first, e.second));
+            ms += m;
+            (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+        }
+        t->prof_ms = ms; t->prof_launches = (int64_t)t->ev.size();
+        t->ev.clear();
+    }
+    QTTS_API_END
+}
+
+int qtts_talker_debug_logits(qtts_talker* t, float* logits_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && logits_dev, QTTS_ERR_ARG, "null argument");
+    QTTS_CHECK_HIP(hipMemcpyAsync(logits_dev, t->logits.p, (size_t)t->B * t->cfg.vocab_size * 4, hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    QTTS_API_END
+}
+int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && out, QTTS_ERR_ARG, "null argument");
+    out->frames_run = t->frames_run; out->graph_nodes = t->graph_nodes; out->weight_bytes_per_frame = t->weight_bytes_frame;
+    out->gemm_ms_last = t->prof_ms; out->gemm_launches_last = t->prof_launches;
+    QTTS_API_END
+}
+int qtts_talker_set_profile(qtts_talker* t, int32_t enable) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t, QTTS_ERR_ARG, "null handle");
+    t->profile = enable != 0;
+    QTTS_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+"""Drop-in mirrors of the reference's top-level model and inference wrapper.
+
+  * Qwen3TTSForConditionalGeneration.generate   qwen_tts/core/models/modeling_qwen3_tts.py:2022-2292
+    (prompt assembly -> talker generate -> EOS trim).  Prompt assembly is host-side torch indexing +
+    one batched `text_projection` call into the HIP library; the decode loop is the HIP engine.
+  * Qwen3TTSModel                               qwen_tts/inference/qwen3_tts_model.py:54-877
+    (`from_pretrained`, `generate_custom_voice`, `generate_voice_design`, `generate_voice_clone`,
+    kwargs merging, validation, same exception types).
+
+Out of the hot path: building a voice-clone prompt from raw audio needs the codec
+*encoder* and the ECAPA speaker encoder; `create_voice_clone_prompt` therefore raises, while
+`generate_voice_clone(voice_clone_prompt=...)` with precomputed items is fully supported.
+"""
+import json
+import os
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .config import TalkerConfig
+from .talker import TalkerEngine
+
+
+@dataclass
+class VoiceClonePromptItem:
+    """Same fields as the reference container (qwen3_tts_model.py:41-51)."""
+    ref_code: Optional[torch.Tensor]
+    ref_spk_embedding: torch.Tensor
+    x_vector_only_mode: bool
+    icl_mode: bool
+    ref_text: Optional[str] = None
+
+
+class Qwen3TTSForConditionalGeneration:
+    """Talker-side model object: owns the HIP talker engine and the embedding tables the prompt needs."""
+
+    def __init__(self, config: Any, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0",
+                 dtype: torch.dtype = torch.bfloat16, max_batch: int = 8, max_seq: int = 4096,
+                 use_graph: bool = True):
+        self.config = TalkerConfig.from_any(config)
+        self.device = torch.device(device)
+        self.dtype = dtype
+        sd = state_dict
+        if any(k.startswith("talker.") for k in sd):
+            sd = {k[len("talker."):]: v for k, v in sd.items() if k.startswith("talker.")}
+        self.talker = TalkerEngine(self.config, sd, weight_dtype=dtype, device=device, max_batch=max_batch,
+                                   max_seq=max_seq, use_graph=use_graph)
+        f32 = lambda t: t.detach().to(self.device, torch.float32).contiguous()
+        G = self.config.num_code_groups
+        self.text_embedding = sd["model.text_embedding.weight"].detach().to(self.device).contiguous()
+        self.codec_embedding = f32(sd["model.codec_embedding.weight"])
+        self.cp_codec_embedding = [f32(sd[f"code_predictor.model.codec_embedding.{g}.weight"]) for g in range(G - 1)]
+        self.speech_tokenizer = None
+        self.generate_config = None
+        self.speaker_encoder = None
+        self.supported_speakers = list(self.config.spk_id.keys())
+        self.supported_languages = ["auto"] + [k for k in self.config.codec_language_id if "dialect" not in k]   # M:1831-1834
+        self.tokenizer_type = self.config.tokenizer_type
+        self.tts_model_size = self.config.tts_model_size
+        self.tts_model_type = self.config.tts_model_type
+
+    def load_speech_tokenizer(self, speech_tokenizer):
+        self.speech_tokenizer = speech_tokenizer
+
+    def load_generate_config(self, generate_config):
+        self.generate_config = generate_config
+
+    def get_supported_speakers(self):
+        return self.supported_speakers
+
+    def get_supported_languages(self):
+        return self.supported_languages
+
+    # ------------------------------------------------------------------ prompt assembly helpers
+    def _project_text(self, id_lists: List[torch.Tensor]) -> List[torch.Tensor]:
+        """text_projection(text_embedding(ids)) for many id vectors with ONE gather + ONE engine call."""
+        lens = [int(x.numel()) for x in id_lists]
+        if sum(lens) == 0:
+            return [torch.zeros(0, self.config.hidden_size, device=self.device) for _ in id_lists]
+        ids = torch.cat([x.reshape(-1).to(self.device, torch.long) for x in id_lists])
+        emb = self.text_embedding[ids].to(torch.float32)
+        out = self.talker.text_projection(emb)
+        return list(torch.split(out, lens, dim=0))
+
+    def _codec(self, ids: List[int]) -> torch.Tensor:
+        return self.codec_embedding[torch.tensor(ids, dtype=torch.long, device=self.device)]
+
+    def assemble_prompts(self, input_ids, languages, speakers=None, instruct_ids=None, non_streaming_mode=False,
+                         ref_ids=None, voice_clone_prompt=None):
+        """M:2068-2269.  Returns (inputs_embeds (B,T,H) left-padded, attention_mask (B,T), trailing_text_hidden
+        (B,Tt,H) right-padded with tts_pad, tts_pad_embed (1,1,H))."""
+        c = self.config
+        n = len(input_ids)
+        if speakers is None:
+            speakers = [None] * n
+        spk_embeds = None
+        if voice_clone_prompt is not None:
+            spk_embeds = [e.to(self.device, torch.float32) for e in voice_clone_prompt["ref_spk_embedding"]]   # M:1957-1966
+
+        # ---- resolve per-request metadata first (raises before any GPU work, like the reference's loop order)
+        metas = []
+        for i in range(n):
+            speaker, language = speakers[i], languages[i]
+            if spk_embeds is None:
+                if speaker == "" or speaker is None:
+                    spk = None
+                else:
+                    if speaker.lower() not in c.spk_id:
+                        raise NotImplementedError(f"Speaker {speaker} not implemented")
+                    spk = self.codec_embedding[c.spk_id[speaker.lower()]]
+            else:
+                use = voice_clone_prompt["x_vector_only_mode"][i] or voice_clone_prompt["icl_mode"][i]
+                spk = spk_embeds[i] if use else None
+            assert language is not None
+            if language.lower() == "auto":
+                lang_id = None
+            else:
+                if language.lower() not in c.codec_language_id:
+                    raise NotImplementedError(f"Language {language} not implemented")
+                lang_id = c.codec_language_id[language.lower()]
+            if (language.lower() in ["chinese", "auto"] and speaker != "" and speaker is not None
+                    and c.spk_is_dialect[speaker.lower()] != False):  # noqa: E712  (reference compares with != False)
+                lang_id = c.codec_language_id[c.spk_is_dialect[speaker.lower()]]
+            icl = bool(voice_clone_prompt is not None and voice_clone_prompt.get("ref_code") is not None
+                       and voice_clone_prompt["icl_mode"][i])
+            metas.append((spk, lang_id, icl))
+
+        # ---- one batched text projection for every text segment of every request
+        segs: List[torch.Tensor] = [torch.tensor([c.tts_bos_token_id, c.tts_eos_token_id, c.tts_pad_token_id])]
+        index = []
+        for i in range(n):
+            ids = input_ids[i].reshape(-1)
+            ent = {"role": len(segs)}
+            segs.append(ids[:3])
+            if metas[i][2]:
+                ent["icl"] = len(segs)
+                segs.append(torch.cat([ref_ids[i].reshape(-1)[3:-2].to(ids.device), ids[3:-5]]))
+            else:
+                ent["first"] = len(segs)
+                segs.append(ids[3:4])
+                ent["rest"] = len(segs)
+                segs.append(ids[3:-5] if non_streaming_mode else ids[4:-5])
+            if instruct_ids is not None and instruct_ids[i] is not None:
+                ent["ins"] = len(segs)
+                segs.append(instruct_ids[i].reshape(-1))
+            index.append(ent)
+        proj = self._project_text(segs)
+        bos_e, eos_e, pad_e = proj[0][0:1], proj[0][1:2], proj[0][2:3]
+
+        seqs, trails = [], []
+        pad_codec = self.codec_embedding[c.codec_pad_id]
+        bos_codec = self.codec_embedding[c.codec_bos_id]
+        for i in range(n):
+            spk, lang_id, icl = metas[i]
+            ent = index[i]
+            if lang_id is None:
+                pre = [c.codec_nothink_id, c.codec_think_bos_id, c.codec_think_eos_id]
+            else:
+                pre = [c.codec_think_id, c.codec_think_bos_id, lang_id, c.codec_think_eos_id]
+            rows = [self._codec(pre)]
+            if spk is not None:
+                rows.append(spk.reshape(1, -1))
+            rows.append(torch.stack([pad_codec, bos_codec]))
+            cin = torch.cat(rows, dim=0)                                         # codec prefix, last two = pad, bos
+            text_side = torch.cat([pad_e.expand(cin.shape[0] - 2, -1), bos_e], dim=0)
+            parts = []
+            if "ins" in ent:
+                parts.append(proj[ent["ins"]])
+            parts += [proj[ent["role"]], text_side + cin[:-1]]
+            if icl:
+                te = torch.cat([proj[ent["icl"]], eos_e], dim=0)
+                rc = voice_clone_prompt["ref_code"][i].to(self.device, torch.long)
+                ce = self.codec_embedding[rc[:, 0]]
+                for g in range(1, c.num_code_groups):
+                    ce = ce + self.cp_codec_embedding[g - 1][rc[:, g]]
+                ce = torch.cat([bos_codec[None], ce], dim=0)                     # M:1983-1998
+                tl, cl = te.shape[0], ce.shape[0]
+                if non_streaming_mode:
+                    parts += [te + pad_codec[None], ce + pad_e]
+                    trail = pad_e
+                elif tl > cl:
+                    parts.append(te[:cl] + ce)
+                    trail = te[cl:]
+                else:
+                    parts.append(torch.cat([te, pad_e.expand(cl - tl, -1)], dim=0) + ce)
+                    trail = pad_e
+            elif non_streaming_mode:
+                parts += [torch.cat([proj[ent["rest"]], eos_e], dim=0) + pad_codec[None], pad_e + bos_codec[None]]
+                trail = pad_e
+            else:
+                parts.append(proj[ent["first"]] + cin[-1:])
+                trail = torch.cat([proj[ent["rest"]], eos_e], dim=0)
+            seqs.append(torch.cat(parts, dim=0))
+            trails.append(trail)
+
+        H = c.hidden_size
+        Tm = max(s.shape[0] for s in seqs)
+        embeds = torch.zeros(n, Tm, H, dtype=torch.float32, device=self.device)
+        mask = torch.zeros(n, Tm, dtype=torch.long)
+        for i, s in enumerate(seqs):
+            embeds[i, Tm - s.shape[0]:] = s
+            mask[i, Tm - s.shape[0]:] = 1
+        Tt = max(t.shape[0] for t in trails)
+        trailing = pad_e.reshape(1, 1, H).repeat(n, Tt, 1)
+        for i, t in enumerate(trails):
+            trailing[i, : t.shape[0]] = t
+        return embeds, mask.to(self.device), trailing, pad_e.reshape(1, 1, H)
+
+    # ------------------------------------------------------------------ generate (seam S1)
+    @torch.no_grad()
+    def generate(self, input_ids: Optional[List[torch.Tensor]] = None, instruct_ids: Optional[List[torch.Tensor]] = None,
+                 ref_ids: Optional[List[torch.Tensor]] = None, voice_clone_prompt: Optional[dict] = None,
+                 languages: List[str] = None, speakers: List[str] = None, non_streaming_mode: bool = False,
+                 max_new_tokens: int = 4096, do_sample: bool = True, top_k: int = 50, top_p: float = 1.0,
+                 temperature: float = 0.9, subtalker_dosample: bool = True, subtalker_top_k: int = 50,
+                 subtalker_top_p: float = 1.0, subtalker_temperature: float = 0.9, eos_token_id: Optional[int] = None,
+                 repetition_penalty: float = 1.05, **kwargs):
+        c = self.config
+        embeds, mask, trailing, pad = self.assemble_prompts(input_ids, languages, speakers, instruct_ids,
+                                                            non_streaming_mode, ref_ids, voice_clone_prompt)
+        suppress = [i for i in range(c.vocab_size - 1024, c.vocab_size) if i != c.codec_eos_token_id]      # M:2059-2063
+        codes_all, hidden_all = [], []
+        mb = self.talker.max_batch
+        for b0 in range(0, embeds.shape[0], mb):     # larger request lists run as waves of max_batch rows
+            sl = slice(b0, b0 + mb)
+            e, m = embeds[sl], mask[sl]
+            drop = int((1 - m).sum(-1).min())        # a wave may be over-padded relative to its own longest row
+            out = self.talker.generate(e[:, drop:], m[:, drop:], trailing[sl], pad, max_new_tokens=max_new_tokens,
+                                       min_new_tokens=2, do_sample=do_sample, top_k=top_k, top_p=top_p,
+                                       temperature=temperature, subtalker_dosample=subtalker_dosample,
+                                       subtalker_top_k=subtalker_top_k, subtalker_top_p=subtalker_top_p,
+                                       subtalker_temperature=subtalker_temperature,
+                                       eos_token_id=eos_token_id if eos_token_id is not None else c.codec_eos_token_id,
+                                       repetition_penalty=repetition_penalty, suppress_tokens=suppress,
+                                       seed=kwargs.get("seed"))
+            first = out.codes[:, :, 0]
+            stop = first == c.codec_eos_token_id                                                           # M:2283-2289
+            for i in range(first.shape[0]):
+                n_eff = int(torch.argmax(stop[i].int())) if bool(stop[i].any()) else first.shape[1]
+                codes_all.append(out.codes[i, :n_eff])
+                hidden_all.append(out.hidden[i, :n_eff] if out.hidden is not None else None)
+        return codes_all, hidden_all
+
+
+# ====================================================================================== inference wrapper
+class _TextProcessor:
+    """The reference's processor is a thin wrapper over the HF Qwen2 tokenizer
+    (core/models/processing_qwen3_tts.py:27); this is the same call surface on AutoTokenizer."""
+
+    def __init__(self, path: str):
+        from transformers import AutoTokenizer
+        self.tok = AutoTokenizer.from_pretrained(path)
+
+    def __call__(self, text=None, return_tensors="pt", padding=True, **kw):
+        return self.tok(text, return_tensors=return_tensors, padding=padding)
+
+
+MaybeList = Union[Any, List[Any]]
+
+
+class Qwen3TTSModel:
+    """Mirror of qwen_tts.inference.Qwen3TTSModel (qwen3_tts_model.py:54)."""
+
+    def __init__(self, model: Qwen3TTSForConditionalGeneration, processor, generate_defaults: Optional[Dict[str, Any]] = None):
+        self.model = model
+        self.processor = processor
+        self.generate_defaults = generate_defaults or {}
+        self.device = model.device
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, **kwargs) -> "Qwen3TTSModel":
+        """Same kwargs as the reference (qwen3_tts_model.py:82-121): `device_map`, `dtype`,
+        `attn_implementation` (accepted; the HIP engine has one attention path)."""
+        from safetensors.torch import load_file
+        from .codec import Qwen3TTSTokenizer
+        path = pretrained_model_name_or_path
+        if not os.path.isdir(path):
+            raise OSError(f"{path} is not a local directory (this build has no hub access)")
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = json.load(f)
+        sd = {}
+        for fn in sorted(os.listdir(path)):
+            if fn.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(path, fn)))
+        device = str(kwargs.get("device_map", kwargs.get("device", "cuda:0")))
+        dtype = kwargs.get("dtype", kwargs.get("torch_dtype", torch.bfloat16))
+        model = Qwen3TTSForConditionalGeneration(cfg, sd, device=device, dtype=dtype,
+                                                 max_batch=kwargs.get("max_batch", 8), max_seq=kwargs.get("max_seq", 4096))
+        st_dir = os.path.join(path, "speech_tokenizer")                       # M:1900-1920
+        if os.path.isdir(st_dir):
+            model.load_speech_tokenizer(Qwen3TTSTokenizer.from_pretrained(st_dir, device_map=device, dtype=dtype,
+                                                                          max_batch=kwargs.get("max_batch", 8)))
+        gc_path = os.path.join(path, "generation_config.json")                # M:1922-1936
+        if os.path.exists(gc_path):
+            with open(gc_path) as f:
+                model.load_generate_config(json.load(f))
+        return cls(model=model, processor=_TextProcessor(path), generate_defaults=model.generate_config)
+
+    # ---- helpers (qwen3_tts_model.py:123-185, 263-352)
+    def _supported_languages_set(self) -> Optional[set]:
+        v = self.model.get_supported_languages()
+        return None if v is None else set(str(x).lower() for x in v)
+
+    def _supported_speakers_set(self) -> Optional[set]:
+        v = self.model.get_supported_speakers()
+        return None if v is None else set(str(x).lower() for x in v)
+
+    def _validate_languages(self, languages: List[str]) -> None:
+        supported = self._supported_languages_set()
+        if supported is None:
+            return
+        bad = [l for l in languages if l is None or str(l).lower() not in supported]
+        if bad:
+            raise ValueError(f"Unsupported languages: {bad}. Supported: {sorted(supported)}")
+
+    def _validate_speakers(self, speakers: List[Optional[str]]) -> None:
+        supported = self._supported_speakers_set()
+        if supported is None:
+            return
+        bad = [s for s in speakers if s is not None and s != "" and str(s).lower() not in supported]
+        if bad:
+            raise ValueError(f"Unsupported speakers: {bad}. Supported: {sorted(supported)}")
+
+    def _ensure_list(self, x: MaybeList) -> List[Any]:
+        return x if isinstance(x, list) else [x]
+
+    def _build_assistant_text(self, text: str) -> str:
+        return f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n"
+
+    def _build_ref_text(self, text: str) -> str:
+        return f"<|im_start|>assistant\n{text}<|im_end|>\n"
+
+    def _build_instruct_text(self, instruct: str) -> str:
+        return f"<|im_start|>user\n{instruct}<|im_end|>\n"
+
+    def _tokenize_texts(self, texts: List[str]) -> List[torch.Tensor]:
+        out = []
+        for text in texts:
+            ids = self.processor(text=text, return_tensors="pt", padding=True)["input_ids"].to(self.device)
+            out.append(ids.unsqueeze(0) if ids.dim() == 1 else ids)
+        return out
+
+    def _merge_generate_kwargs(self, do_sample=None, top_k=None, top_p=None, temperature=None, repetition_penalty=None,
+                               subtalker_dosample=None, subtalker_top_k=None, subtalker_top_p=None,
+                               subtalker_temperature=None, max_new_tokens=None, **kwargs) -> Dict[str, Any]:
+        """user value > generate_config.json > hard default (qwen3_tts_model.py:287-352)."""
+        hard = dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9, repetition_penalty=1.05,
+                    subtalker_dosample=True, subtalker_top_k=50, subtalker_top_p=1.0, subtalker_temperature=0.9,
+                    max_new_tokens=2048)
+        user = dict(do_sample=do_sample, top_k=top_k, top_p=top_p, temperature=temperature,
+                    repetition_penalty=repetition_penalty, subtalker_dosample=subtalker_dosample,
+                    subtalker_top_k=subtalker_top_k, subtalker_top_p=subtalker_top_p,
+                    subtalker_temperature=subtalker_temperature, max_new_tokens=max_new_tokens)
+        merged = dict(kwargs)
+        for k, dv in hard.items():
+            merged[k] = user[k] if user[k] is not None else self.generate_defaults.get(k, dv)
+        return merged
+
+    def _unsupported(self, what: str):
+        m = self.model
+        return ValueError(f"model with \ntokenizer_type: {m.tokenizer_type}\ntts_model_size: {m.tts_model_size}\n"
+                          f"tts_model_type: {m.tts_model_type}\ndoes not support {what}, Please check Model Card or "
+                          "Readme for more details.")
+
+    def _lang_list(self, language, n):
+        if isinstance(language, list):
+            langs = language
+        else:
+            langs = [language] * n if language is not None else ["Auto"] * n
+        return langs * n if len(langs) == 1 and n > 1 else langs
+
+    def _instruct_ids(self, instructs):
+        out = []
+        for ins in instructs:
+            out.append(None if ins is None or ins == "" else self._tokenize_texts([self._build_instruct_text(ins)])[0])
+        return out
+
+    # ---- voice clone (qwen3_tts_model.py:356-636)
+    def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode=False):
+        raise NotImplementedError(
+            "create_voice_clone_prompt needs the codec encoder and the speaker encoder, which are outside the MI355X "
+            "hot path (SURVEY.md 8f3/8f4); pass precomputed VoiceClonePromptItem objects via `voice_clone_prompt=`.")
+
+    def _prompt_items_to_voice_clone_prompt(self, items: List[VoiceClonePromptItem]) -> Dict[str, Any]:
+        return dict(ref_code=[it.ref_code for it in items], ref_spk_embedding=[it.ref_spk_embedding for it in items],
+                    x_vector_only_mode=[it.x_vector_only_mode for it in items], icl_mode=[it.icl_mode for it in items])
+
+    @torch.no_grad()
+    def generate_voice_clone(self, text, language=None, ref_audio=None, ref_text=None, x_vector_only_mode=False,
+                             voice_clone_prompt=None, non_streaming_mode: bool = False, **kwargs
+                             ) -> Tuple[List[np.ndarray], int]:
+        if self.model.tts_model_type != "base":
+            raise self._unsupported("generate_voice_clone")
+        texts = self._ensure_list(text)
+        languages = self._lang_list(language, len(texts))
+        if len(texts) != len(languages):
+            raise ValueError(f"Batch size mismatch: text={len(texts)}, language={len(languages)}")
+        self._validate_languages(languages)
+        if voice_clone_prompt is None:
+            if ref_audio is None:
+                raise ValueError("Either `voice_clone_prompt` or `ref_audio` must be provided.")
+            voice_clone_prompt = self.create_voice_clone_prompt(ref_audio=ref_audio, ref_text=ref_text,
+                                                                x_vector_only_mode=x_vector_only_mode)
+        if isinstance(voice_clone_prompt, list):
+            items = voice_clone_prompt
+            if len(items) == 1 and len(texts) > 1:
+                items = items * len(texts)
+            if len(items) != len(texts):
+                raise ValueError(f"Batch size mismatch: prompt={len(items)}, text={len(texts)}")
+            vcp = self._prompt_items_to_voice_clone_prompt(items)
+            ref_texts = [it.ref_text for it in items]
+        else:
+            vcp, ref_texts = voice_clone_prompt, None
+        input_ids = self._tokenize_texts([self._build_assistant_text(t) for t in texts])
+        ref_ids = None
+        if ref_texts is not None:
+            ref_ids = [None if rt is None or rt == "" else self._tokenize_texts([self._build_ref_text(rt)])[0]
+                       for rt in ref_texts]
+        gen_kwargs = self._merge_generate_kwargs(**kwargs)
+        codes_list, _ = self.model.generate(input_ids=input_ids, ref_ids=ref_ids, voice_clone_prompt=vcp,
+                                            languages=languages, non_streaming_mode=non_streaming_mode, **gen_kwargs)
+        ref_codes = vcp.get("ref_code", None)
+        full = []
+        for i, codes in enumerate(codes_list):
+            if ref_codes is not None and ref_codes[i] is not None:
+                full.append(torch.cat([ref_codes[i].to(codes.device), codes], dim=0))       # IM:612-618
+            else:
+                full.append(codes)
+        wavs_all, fs = self.model.speech_tokenizer.decode([{"audio_codes": c} for c in full])
+        out = []
+        for i, wav in enumerate(wavs_all):
+            if ref_codes is not None and ref_codes[i] is not None:
+                cut = int(int(ref_codes[i].shape[0]) / max(int(full[i].shape[0]), 1) * wav.shape[0])   # IM:622-631
+                out.append(wav[cut:])
+            else:
+                out.append(wav)
+        return out, fs
+
+    # ---- voice design (qwen3_tts_model.py:637-730)
+    @torch.no_grad()
+    def generate_voice_design(self, text, instruct, language=None, non_streaming_mode: bool = True, **kwargs
+                              ) -> Tuple[List[np.ndarray], int]:
+        if self.model.tts_model_type != "voice_design":
+            raise self._unsupported("generate_voice_design")
+        texts = self._ensure_list(text)
+        languages = self._lang_list(language, len(texts))
+        instructs = self._ensure_list(instruct)
+        if len(instructs) == 1 and len(texts) > 1:
+            instructs = instructs * len(texts)
+        if not (len(texts) == len(languages) == len(instructs)):
+            raise ValueError(f"Batch size mismatch: text={len(texts)}, language={len(languages)}, instruct={len(instructs)}")
+        self._validate_languages(languages)
+        input_ids = self._tokenize_texts([self._build_assistant_text(t) for t in texts])
+        gen_kwargs = self._merge_generate_kwargs(**kwargs)
+        codes_list, _ = self.model.generate(input_ids=input_ids, instruct_ids=self._instruct_ids(instructs),
+                                            languages=languages, non_streaming_mode=non_streaming_mode, **gen_kwargs)
+        return self.model.speech_tokenizer.decode([{"audio_codes": c} for c in codes_list])
+
+    # ---- custom voice (qwen3_tts_model.py:732-840)
+    @torch.no_grad()
+    def generate_custom_voice(self, text, speaker, language=None, instruct=None, non_streaming_mode: bool = True,
+                              **kwargs) -> Tuple[List[np.ndarray], int]:
+        if self.model.tts_model_type != "custom_voice":
+            raise self._unsupported("generate_custom_voice")
+        texts = self._ensure_list(text)
+        languages = self._lang_list(language, len(texts))
+        speakers = self._ensure_list(speaker)
+        if self.model.tts_model_size in "0b6":      # 0.6B has no instruct support (IM:799-800)
+            instruct = None
+        if isinstance(instruct, list):
+            instructs = instruct
+        else:
+            instructs = [instruct] * len(texts) if instruct is not None else [""] * len(texts)
+        if len(speakers) == 1 and len(texts) > 1:
+            speakers = speakers * len(texts)
+        if len(instructs) == 1 and len(texts) > 1:
+            instructs = instructs * len(texts)
+        if not (len(texts) == len(languages) == len(speakers) == len(instructs)):
+            raise ValueError(f"Batch size mismatch: text={len(texts)}, language={len(languages)}, "
+                             f"speaker={len(speakers)}, instruct={len(instructs)}")
+        self._validate_languages(languages)
+        self._validate_speakers(speakers)
+        input_ids = self._tokenize_texts([self._build_assistant_text(t) for t in texts])
+        gen_kwargs = self._merge_generate_kwargs(**kwargs)
+        codes_list, _ = self.model.generate(input_ids=input_ids, instruct_ids=self._instruct_ids(instructs),
+                                            languages=languages, speakers=speakers,
+                                            non_streaming_mode=non_streaming_mode, **gen_kwargs)
+        return self.model.speech_tokenizer.decode([{"audio_codes": c} for c in codes_list])
+
+    def get_supported_speakers(self) -> Optional[List[str]]:
+        s = self._supported_speakers_set()
+        return None if s is None else sorted(s)
+
+    def get_supported_languages(self) -> Optional[List[str]]:
+        s = self._supported_languages_set()
+        return None if s is None else sorted(s)

@@ -1,0 +1,184 @@
+"""Host side of the autoregressive speech-token decoder (talker + code predictor) over libqtts.
+
+`TalkerEngine.generate` mirrors the seam S2 of the reference:
+`self.talker.generate(inputs_embeds, attention_mask, trailing_text_hidden, tts_pad_embed, **talker_kwargs)`
+(qwen_tts/core/models/modeling_qwen3_tts.py:2272-2278), i.e. HF `_sample` around
+Qwen3TTSTalkerForConditionalGeneration.forward (M:1636-1744).  All arithmetic runs in the HIP library.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .config import TalkerConfig
+
+
+def _default_inv_freq(theta: float, head_dim: int) -> torch.Tensor:
+    """HF 'default' rope init exactly as the reference's rotary modules compute it (M:538-541, 573-576)."""
+    return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(dtype=torch.float) / head_dim))
+
+
+@dataclass
+class TalkerGenerateOutput:
+    codes: torch.Tensor        # (B, n_frames, G) int64, untrimmed (M:2280)
+    hidden: Optional[torch.Tensor]  # (B, n_frames, H) float32 `past_hidden` per frame (M:2281)
+    tokens: torch.Tensor       # (B, n_tokens) int64 sampled codebook-0 tokens (HF `sequences`)
+    n_frames: int
+
+
+_SKIP_PREFIXES = ("speaker_encoder.", "model.text_embedding.")
+
+
+class TalkerEngine:
+    """Owns one `qtts_talker` handle."""
+
+    def __init__(self, config: Any, state_dict: Dict[str, torch.Tensor], weight_dtype: torch.dtype = torch.bfloat16,
+                 device: str = "cuda:0", max_batch: int = 8, max_seq: int = 4096, use_graph: bool = True):
+        self.config = TalkerConfig.from_any(config)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.QttsError(-102, "TalkerEngine requires a HIP device (torch device 'cuda:N'); there is no CPU path")
+        self.weight_dtype = weight_dtype
+        self.max_batch, self.max_seq = int(max_batch), int(max_seq)
+        self._lib = _lib.load_library()
+        c = self.config
+        tc = _lib.TalkerConfigC()
+        for f in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                  "num_key_value_heads", "head_dim", "num_code_groups", "text_hidden_size", "codec_eos_token_id",
+                  "cp_vocab_size", "cp_hidden_size", "cp_intermediate_size", "cp_num_hidden_layers",
+                  "cp_num_attention_heads", "cp_num_key_value_heads", "cp_head_dim"):
+            setattr(tc, f, int(getattr(c, f)))
+        tc.rms_norm_eps, tc.rope_theta = float(c.rms_norm_eps), float(c.rope_theta)
+        tc.cp_rms_norm_eps, tc.cp_rope_theta = float(c.cp_rms_norm_eps), float(c.cp_rope_theta)
+        tc.weight_dtype = _lib.QTTS_BF16 if weight_dtype == torch.bfloat16 else _lib.QTTS_F32
+        tc.max_batch, tc.max_seq, tc.use_graph = self.max_batch, self.max_seq, 1 if use_graph else 0
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.qtts_talker_create(C.byref(tc), C.byref(self._h)))
+            has_prefix = any(k.startswith("talker.") for k in state_dict)
+            for name, t in state_dict.items():
+                if has_prefix:
+                    if not name.startswith("talker."):
+                        continue
+                    name = name[len("talker."):]
+                if name.startswith(_SKIP_PREFIXES):
+                    continue
+                _lib.bind_tensor(self._lib.qtts_talker_bind, self._h, name, t)
+            _lib.bind_tensor(self._lib.qtts_talker_bind, self._h, "model.rotary_emb.inv_freq",
+                             _default_inv_freq(c.rope_theta, c.head_dim))
+            _lib.bind_tensor(self._lib.qtts_talker_bind, self._h, "code_predictor.model.rotary_emb.inv_freq",
+                             _default_inv_freq(c.cp_rope_theta, c.cp_head_dim))
+            _lib.check(self._lib.qtts_talker_finalize(self._h))
+            # hipGraph capture needs a non-default stream; everything the engine does runs on this one
+            self._stream = torch.cuda.Stream(device=self.device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.qtts_talker_destroy(h)
+
+    def _s(self):
+        return C.c_void_p(self._stream.cuda_stream)
+
+    def set_profile(self, enable: bool):
+        _lib.check(self._lib.qtts_talker_set_profile(self._h, 1 if enable else 0))
+
+    def stats(self) -> dict:
+        st = _lib.TalkerStatsC()
+        _lib.check(self._lib.qtts_talker_get_stats(self._h, C.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in st._fields_}
+
+    # ------------------------------------------------------------------ text_projection (prompt assembly)
+    def text_projection(self, x: torch.Tensor) -> torch.Tensor:
+        """Qwen3TTSTalkerResizeMLP (M:808-816): (..., text_hidden) -> (..., hidden), fp32."""
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).to(self.device, torch.float32).contiguous()
+        y = torch.empty(x2.shape[0], self.config.hidden_size, dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+            _lib.check(self._lib.qtts_talker_text_projection(self._h, C.c_void_p(x2.data_ptr()), x2.shape[0],
+                                                             C.c_void_p(y.data_ptr()), self._s()))
+        cur.wait_stream(self._stream)
+        x2.record_stream(self._stream)
+        return y.reshape(*shp[:-1], self.config.hidden_size)
+
+    # ------------------------------------------------------------------ generate (seam S2)
+    def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, trailing_text_hidden: torch.Tensor,
+                 tts_pad_embed: torch.Tensor, max_new_tokens: int = 2048, min_new_tokens: int = 2,
+                 do_sample: bool = True, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,
+                 temperature: Optional[float] = 0.9, subtalker_dosample: bool = True,
+                 subtalker_top_k: Optional[int] = 50, subtalker_top_p: Optional[float] = 1.0,
+                 subtalker_temperature: Optional[float] = 0.9, eos_token_id: Optional[int] = None,
+                 repetition_penalty: float = 1.05, suppress_tokens: Optional[List[int]] = None,
+                 output_hidden_states: bool = True, return_dict_in_generate: bool = True,
+                 seed: Optional[int] = None, **unused) -> TalkerGenerateOutput:
+        c = self.config
+        if inputs_embeds.dim() != 3 or inputs_embeds.shape[-1] != c.hidden_size:
+            raise ValueError(f"inputs_embeds must be (B, T, {c.hidden_size})")
+        B, T, H = inputs_embeds.shape
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch} given at construction")
+        mask = attention_mask.to("cpu", torch.long)
+        if mask.shape != (B, T):
+            raise ValueError("attention_mask must be (B, T)")
+        n_pad = (1 - mask).sum(-1)
+        # the reference only ever builds LEFT-padded masks (M:2251-2254); anything else is not this path
+        expect = (torch.arange(T)[None, :] >= n_pad[:, None]).long()
+        if not torch.equal(mask, expect) or int(n_pad.max()) >= T:
+            raise ValueError("attention_mask must be left-padded: [0]*n_pad + [1]*(T-n_pad) per row")
+        if T + max_new_tokens > self.max_seq:
+            raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_seq ({self.max_seq})")
+        eos = c.codec_eos_token_id if eos_token_id is None else int(eos_token_id)
+        if suppress_tokens is None:
+            suppress_tokens = []
+        sp = _lib.SamplingC()
+        sp.do_sample = 1 if do_sample else 0
+        sp.top_k = int(top_k) if top_k else 0
+        sp.top_p = float(top_p) if top_p is not None else 1.0
+        sp.temperature = float(temperature) if temperature is not None else 1.0
+        sp.repetition_penalty = float(repetition_penalty) if repetition_penalty is not None else 1.0
+        sp.subtalker_dosample = 1 if subtalker_dosample else 0
+        sp.subtalker_top_k = int(subtalker_top_k) if subtalker_top_k else 0
+        sp.subtalker_top_p = float(subtalker_top_p) if subtalker_top_p is not None else 1.0
+        sp.subtalker_temperature = float(subtalker_temperature) if subtalker_temperature is not None else 1.0
+        sp.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)
+
+        dev = self.device
+        emb = inputs_embeds.to(dev, torch.float32).contiguous()
+        trail = trailing_text_hidden.to(dev, torch.float32).contiguous()
+        if trail.dim() != 3 or trail.shape[0] != B or trail.shape[2] != H or trail.shape[1] < 1:
+            raise ValueError("trailing_text_hidden must be (B, Tt >= 1, H)")
+        pad = tts_pad_embed.to(dev, torch.float32).reshape(-1).contiguous()
+        if pad.numel() != H:
+            raise ValueError("tts_pad_embed must have H elements")
+        max_frames = max(1, max_new_tokens - 1)
+        codes = torch.zeros(B, max_frames, c.num_code_groups, dtype=torch.int64, device=dev)
+        hidden = torch.zeros(B, max_frames, H, dtype=torch.float32, device=dev) if output_hidden_states else None
+        tokens = torch.full((B, max_new_tokens), -1, dtype=torch.int64, device=dev)
+        npad_c = (C.c_int32 * B)(*[int(x) for x in n_pad])
+        sup_c = (C.c_int32 * max(1, len(suppress_tokens)))(*[int(x) for x in suppress_tokens])
+        n_frames = C.c_int32(0)
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+            _lib.check(self._lib.qtts_talker_prefill(self._h, C.c_void_p(emb.data_ptr()), B, T, npad_c,
+                                                     C.c_void_p(trail.data_ptr()), trail.shape[1],
+                                                     C.c_void_p(pad.data_ptr()), self._s()))
+            _lib.check(self._lib.qtts_talker_generate(
+                self._h, C.byref(sp), int(max_new_tokens), int(min_new_tokens), eos, sup_c, len(suppress_tokens),
+                C.c_void_p(codes.data_ptr()), C.c_void_p(hidden.data_ptr()) if hidden is not None else None,
+                C.c_void_p(tokens.data_ptr()), C.byref(n_frames), self._s()))
+        cur.wait_stream(self._stream)
+        nf = int(n_frames.value)
+        return TalkerGenerateOutput(codes=codes[:, :nf], hidden=hidden[:, :nf] if hidden is not None else None,
+                                    tokens=tokens[:, : nf + 1], n_frames=nf)
+
+    def debug_logits(self) -> torch.Tensor:
+        out = torch.empty(self.max_batch, self.config.vocab_size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.qtts_talker_debug_logits(self._h, C.c_void_p(out.data_ptr()), self._s()))
+            self._stream.synchronize()
+        return out
