@@ -144,9 +144,7 @@ class TalkerConfig:
         top = src if tk is not None else None
         tk = tk if tk is not None else src
         kw = {}
-        for f in fields(cls):
-            if f.name.startswith("cp_"):
-                continue
+        for f in fields(cls):      # flat `cp_*` keys are accepted too (dataclass dicts); the nested config wins
             v = _get(tk, f.name, None)
             if v is not None:
                 kw[f.name] = v

@@ -52,6 +52,16 @@ struct qtts_codec {
         if (it == host.end()) throw Error(QTTS_ERR_UNBOUND, "codec weight not bound: " + n);
         return it->second;
     }
+    void expect(const std::string& n, std::initializer_list<int64_t> want) {
+        P(n);
+        auto& s = shapes[n];
+        if (s.size() != want.size() || !std::equal(s.begin(), s.end(), want.begin())) {
+            std::string a, b;
+            for (auto d : s) a += std::to_string(d) + ",";
+            for (auto d : want) b += std::to_string(d) + ",";
+            throw Error(QTTS_ERR_ARG, "codec weight " + n + " has shape (" + a + ") but the config implies (" + b + ")");
+        }
+    }
     void upload_w(DevBuf& d, const std::vector<float>& w) {
         if (bf16) {
             std::vector<bf16_t> h(w.size());
@@ -136,6 +146,74 @@ void qtts_codec::finalize() {
     for (int i = 0; i < c.n_upsample_rates; ++i) up_total *= c.upsample_rates[i];
     for (int i = 0; i < c.n_upsampling_ratios; ++i) up_total *= c.upsampling_ratios[i];
     QTTS_REQUIRE(c.head_dim == 64 || c.head_dim == 128, QTTS_ERR_ARG, "codec head_dim must be 64 or 128");
+    {   // every tensor whose shape the config determines is checked before anything is repacked
+        const int64_t H = c.hidden_size, I = c.intermediate_size, Ld = c.latent_dim, D = c.decoder_dim;
+        const int64_t qd = (int64_t)c.num_attention_heads * c.head_dim, kvd = (int64_t)c.num_key_value_heads * c.head_dim;
+        for (int q = 0; q < c.num_quantizers; ++q) {
+            const std::string p = q == 0 ? "quantizer.rvq_first.vq.layers.0._codebook."
+                                         : "quantizer.rvq_rest.vq.layers." + std::to_string(q - 1) + "._codebook.";
+            expect(p + "embedding_sum", {c.codebook_size, vq});
+            expect(p + "cluster_usage", {c.codebook_size});
+        }
+        expect("quantizer.rvq_first.output_proj.weight", {c.codebook_dim, vq, 1});
+        expect("quantizer.rvq_rest.output_proj.weight", {c.codebook_dim, vq, 1});
+        expect("pre_conv.conv.weight", {Ld, c.codebook_dim, 3});
+        expect("pre_conv.conv.bias", {Ld});
+        expect("pre_transformer.input_proj.weight", {H, Ld});
+        expect("pre_transformer.input_proj.bias", {H});
+        expect("pre_transformer.output_proj.weight", {Ld, H});
+        expect("pre_transformer.output_proj.bias", {Ld});
+        expect("pre_transformer.norm.weight", {H});
+        for (int l = 0; l < c.num_hidden_layers; ++l) {
+            const std::string p = "pre_transformer.layers." + std::to_string(l) + ".";
+            expect(p + "self_attn.q_proj.weight", {qd, H});
+            expect(p + "self_attn.k_proj.weight", {kvd, H});
+            expect(p + "self_attn.v_proj.weight", {kvd, H});
+            expect(p + "self_attn.o_proj.weight", {H, qd});
+            expect(p + "mlp.gate_proj.weight", {I, H});
+            expect(p + "mlp.up_proj.weight", {I, H});
+            expect(p + "mlp.down_proj.weight", {H, I});
+            expect(p + "input_layernorm.weight", {H});
+            expect(p + "post_attention_layernorm.weight", {H});
+            expect(p + "self_attn_layer_scale.scale", {H});
+            expect(p + "mlp_layer_scale.scale", {H});
+        }
+        for (int u = 0; u < c.n_upsampling_ratios; ++u) {
+            const std::string p = "upsample." + std::to_string(u) + ".";
+            expect(p + "0.conv.weight", {Ld, Ld, c.upsampling_ratios[u]});
+            expect(p + "0.conv.bias", {Ld});
+            expect(p + "1.dwconv.conv.weight", {Ld, 1, 7});
+            expect(p + "1.dwconv.conv.bias", {Ld});
+            expect(p + "1.norm.weight", {Ld});
+            expect(p + "1.norm.bias", {Ld});
+            expect(p + "1.pwconv1.weight", {4 * Ld, Ld});
+            expect(p + "1.pwconv1.bias", {4 * Ld});
+            expect(p + "1.pwconv2.weight", {Ld, 4 * Ld});
+            expect(p + "1.pwconv2.bias", {Ld});
+            expect(p + "1.gamma", {Ld});
+        }
+        expect("decoder.0.conv.weight", {D, Ld, 7});
+        expect("decoder.0.conv.bias", {D});
+        for (int i = 0; i < c.n_upsample_rates; ++i) {
+            const std::string p = "decoder." + std::to_string(i + 1) + ".block.";
+            const int64_t ci = D >> i, co = D >> (i + 1), r = c.upsample_rates[i];
+            expect(p + "0.alpha", {ci}); expect(p + "0.beta", {ci});
+            expect(p + "1.conv.weight", {ci, co, 2 * r}); expect(p + "1.conv.bias", {co});
+            for (int j = 2; j <= 4; ++j) {
+                const std::string up = p + std::to_string(j) + ".";
+                expect(up + "act1.alpha", {co}); expect(up + "act1.beta", {co});
+                expect(up + "act2.alpha", {co}); expect(up + "act2.beta", {co});
+                expect(up + "conv1.conv.weight", {co, co, 7}); expect(up + "conv1.conv.bias", {co});
+                expect(up + "conv2.conv.weight", {co, co, 1}); expect(up + "conv2.conv.bias", {co});
+            }
+        }
+        const int n = c.n_upsample_rates;
+        const int64_t cl = D >> n;
+        expect("decoder." + std::to_string(n + 1) + ".alpha", {cl});
+        expect("decoder." + std::to_string(n + 1) + ".beta", {cl});
+        expect("decoder." + std::to_string(n + 2) + ".conv.weight", {1, cl, 7});
+        expect("decoder." + std::to_string(n + 2) + ".conv.bias", {1});
+    }
     // normalised codebooks: embedding_sum / clamp(cluster_usage, 1e-5) (v2:676-679), computed once
     {
         std::vector<float> t((size_t)c.num_quantizers * c.codebook_size * vq);

@@ -69,6 +69,18 @@ struct qtts_talker {
         if (it == host.end()) throw Error(QTTS_ERR_UNBOUND, "talker weight not bound: " + n);
         return it->second;
     }
+    // bound tensor with its shape checked against the configuration (a mismatch must never reach a memcpy)
+    std::vector<float>& PS(const std::string& n, std::initializer_list<int64_t> want) {
+        auto& v = P(n);
+        auto& s = shapes[n];
+        if (s.size() != want.size() || !std::equal(s.begin(), s.end(), want.begin())) {
+            std::string a, b;
+            for (auto d : s) a += std::to_string(d) + ",";
+            for (auto d : want) b += std::to_string(d) + ",";
+            throw Error(QTTS_ERR_ARG, "talker weight " + n + " has shape (" + a + ") but the config implies (" + b + ")");
+        }
+        return v;
+    }
     void upload_f(DevBuf& d, const std::vector<float>& w) { d.upload(w.data(), w.size() * 4); }
     void upload_rows(DevBuf& d, const std::vector<float>& w) {
         if (bf16) {
@@ -96,22 +108,25 @@ struct qtts_talker {
         return w;
     }
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
-        auto qkvw = cat3(P(p + "self_attn.q_proj.weight"), P(p + "self_attn.k_proj.weight"), P(p + "self_attn.v_proj.weight"));
-        auto guw = interleave_gu(P(p + "mlp.gate_proj.weight"), P(p + "mlp.up_proj.weight"), d.I, d.H);
+        auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
+                         PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
+        auto guw = interleave_gu(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H);
+        auto& ow = PS(p + "self_attn.o_proj.weight", {d.H, d.qd});
+        auto& dw = PS(p + "mlp.down_proj.weight", {d.H, d.I});
         upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H);
-        upload_packed(L.o_p, P(p + "self_attn.o_proj.weight"), d.H, d.qd);
+        upload_packed(L.o_p, ow, d.H, d.qd);
         upload_packed(L.gu_p, guw, 2 * d.I, d.H);
-        upload_packed(L.d_p, P(p + "mlp.down_proj.weight"), d.H, d.I);
+        upload_packed(L.d_p, dw, d.H, d.I);
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
-            upload_rows(L.o_r, P(p + "self_attn.o_proj.weight"));
+            upload_rows(L.o_r, ow);
             upload_rows(L.gu_r, guw);
-            upload_rows(L.d_r, P(p + "mlp.down_proj.weight"));
+            upload_rows(L.d_r, dw);
         }
-        upload_f(L.g1, P(p + "input_layernorm.weight"));
-        upload_f(L.g2, P(p + "post_attention_layernorm.weight"));
-        upload_f(L.qn, P(p + "self_attn.q_norm.weight"));
-        upload_f(L.kn, P(p + "self_attn.k_norm.weight"));
+        upload_f(L.g1, PS(p + "input_layernorm.weight", {d.H}));
+        upload_f(L.g2, PS(p + "post_attention_layernorm.weight", {d.H}));
+        upload_f(L.qn, PS(p + "self_attn.q_norm.weight", {d.hd}));
+        upload_f(L.kn, PS(p + "self_attn.k_norm.weight", {d.hd}));
     }
     void finalize();
 
@@ -191,33 +206,34 @@ void qtts_talker::finalize() {
     cl.resize(c.cp_num_hidden_layers);
     for (int l = 0; l < c.cp_num_hidden_layers; ++l)
         build_layer(cl[l], "code_predictor.model.layers." + std::to_string(l) + ".", cd, false);
-    upload_f(t_norm, P("model.norm.weight"));
-    upload_f(c_norm, P("code_predictor.model.norm.weight"));
-    upload_packed(head_p, P("codec_head.weight"), c.vocab_size, td.H);
-    upload_f(emb_talker, P("model.codec_embedding.weight"));
+    upload_f(t_norm, PS("model.norm.weight", {td.H}));
+    upload_f(c_norm, PS("code_predictor.model.norm.weight", {cd.H}));
+    upload_packed(head_p, PS("codec_head.weight", {c.vocab_size, td.H}), c.vocab_size, td.H);
+    upload_f(emb_talker, PS("model.codec_embedding.weight", {c.vocab_size, td.H}));
     {
         std::vector<float> e((size_t)(G - 1) * c.cp_vocab_size * td.H);
         for (int g = 0; g < G - 1; ++g) {
-            auto& w = P("code_predictor.model.codec_embedding." + std::to_string(g) + ".weight");
+            auto& w = PS("code_predictor.model.codec_embedding." + std::to_string(g) + ".weight", {c.cp_vocab_size, td.H});
             memcpy(&e[(size_t)g * c.cp_vocab_size * td.H], w.data(), w.size() * 4);
         }
         upload_f(emb_cp, e);
     }
     lm_head_p.resize(G - 1);
     for (int g = 0; g < G - 1; ++g)
-        upload_packed(lm_head_p[g], P("code_predictor.lm_head." + std::to_string(g) + ".weight"), c.cp_vocab_size, cd.H);
+        upload_packed(lm_head_p[g], PS("code_predictor.lm_head." + std::to_string(g) + ".weight", {c.cp_vocab_size, cd.H}), c.cp_vocab_size, cd.H);
     has_proj = cd.H != td.H;
     if (has_proj) {
-        upload_packed(proj_p, P("code_predictor.small_to_mtp_projection.weight"), cd.H, td.H);
-        upload_f(proj_b, P("code_predictor.small_to_mtp_projection.bias"));
+        upload_packed(proj_p, PS("code_predictor.small_to_mtp_projection.weight", {cd.H, td.H}), cd.H, td.H);
+        upload_f(proj_b, PS("code_predictor.small_to_mtp_projection.bias", {cd.H}));
     }
     has_text_proj = host.count("text_projection.linear_fc1.weight") > 0;
     if (has_text_proj) {
-        upload_rows(tp_fc1, P("text_projection.linear_fc1.weight")); upload_f(tp_b1, P("text_projection.linear_fc1.bias"));
-        upload_rows(tp_fc2, P("text_projection.linear_fc2.weight")); upload_f(tp_b2, P("text_projection.linear_fc2.bias"));
+        const int TH = c.text_hidden_size;
+        upload_rows(tp_fc1, PS("text_projection.linear_fc1.weight", {TH, TH})); upload_f(tp_b1, PS("text_projection.linear_fc1.bias", {TH}));
+        upload_rows(tp_fc2, PS("text_projection.linear_fc2.weight", {td.H, TH})); upload_f(tp_b2, PS("text_projection.linear_fc2.bias", {td.H}));
     }
     auto mk_freq = [&](DevBuf& d, const char* name, float theta, int hd) {
-        if (host.count(name)) { upload_f(d, P(name)); return; }
+        if (host.count(name)) { upload_f(d, PS(name, {hd / 2})); return; }
         std::vector<float> f(hd / 2);
         for (int i = 0; i < hd / 2; ++i) f[i] = 1.0f / powf(theta, (float)(2 * i) / (float)hd);
         upload_f(d, f);
@@ -430,8 +446,10 @@ int qtts_talker_create(const qtts_talker_config* cfg, qtts_talker** out) {
                      cfg->cp_intermediate_size % 128 == 0, QTTS_ERR_ARG, "hidden/intermediate sizes must be multiples of 128");
     QTTS_REQUIRE(cfg->vocab_size % 16 == 0 && cfg->cp_vocab_size % 16 == 0, QTTS_ERR_ARG, "vocab sizes % 16");
     int ndev = 0;
-    QTTS_CHECK_HIP(hipGetDeviceCount(&ndev));
-    QTTS_REQUIRE(ndev > 0, QTTS_ERR_HIP, "no HIP device");
+    if (!getenv("QTTS_DEBUG_NO_DEVICE")) {
+        QTTS_CHECK_HIP(hipGetDeviceCount(&ndev));
+        QTTS_REQUIRE(ndev > 0, QTTS_ERR_HIP, "no HIP device");
+    }
     auto* t = new qtts_talker();
     t->cfg = *cfg;
     t->bf16 = cfg->weight_dtype == QTTS_BF16;
