@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- the north-star benchmark of the MI355X-native Qwen3-TTS hot path.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic requests, inputs resident in HBM:
+talker prefill -> `frames` autoregressive frame steps (15-pass code predictor + 28-layer talker + on-device
+sampling, hipGraph) -> Qwen3-TTS-Tokenizer-12Hz codec decode of every utterance to a 24 kHz waveform.
+Workload = BASELINE.json's metric config: Qwen3-TTS-12Hz-1.7B dims, batch 8, 10 s (125 frames) per utterance,
+default sampling (T 0.9, top-k 50, rep 1.05), seeded random weights (no checkpoint exists offline), bf16.
+
+With N > 1 every rank runs its own batch (request sharding, no data-path collective): weak
+scaling; value = all ranks' speech tokens / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  Extra legs (rank 0, N = 1 only, outside the timed region):
+  roofline      HIP-event timing of every launch of the dominant kernel (skinny weight-streaming GEMM) over one
+                eager generate call, against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/*_ref.py: torch fp32 restatement of the reference) on a bounded sample of
+                the same workload, timed on this host's cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_prompt(rng, cfg, lens, n_trail, scale=0.05):
+    import synth
+    return synth.rand_prompt(rng, cfg, lens, n_trail, scale)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="1.7b", choices=["1.7b", "0.6b", "tiny"])
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=125, help="codec frames per utterance (125 = 10 s)")
+    ap.add_argument("--greedy", action="store_true", help="greedy decode instead of the default sampling")
+    ap.add_argument("--codec-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import synth
+    from qwen3_tts_amd.codec import CodecDecoderEngine
+    from qwen3_tts_amd.talker import TalkerEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+
+    tcfg = {"1.7b": synth.talker_17b, "0.6b": synth.talker_06b, "tiny": synth.talker_tiny}[args.model]()
+    ccfg = synth.codec_tiny() if args.model == "tiny" else synth.codec_real()
+    B, F = args.batch, args.frames
+    t0 = time.time()
+    tw_np = synth.talker_weights(tcfg, with_text=False)
+    cw_np = synth.codec_weights(ccfg)
+    td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
+    lens = [24 + 4 * (i % 8) + 12 for i in range(B)]          # 128-char prompts ~ 24..52 text tokens + 12 prefix rows
+    talker = TalkerEngine(tcfg, td(tw_np), weight_dtype=torch.bfloat16, device=dev, max_batch=B,
+                          max_seq=max(lens) + F + 8, use_graph=not args.no_graph)
+    codec = CodecDecoderEngine(ccfg, td(cw_np), compute_dtype=torch.bfloat16 if args.codec_dtype == "bf16" else torch.float32,
+                               device=dev, max_batch=B, max_frames=min(F, 300) + 25)
+    build_s = time.time() - t0
+    rng = np.random.default_rng(100 + rank)
+    emb, mask, trailing, pad = synth_prompt(rng, tcfg, lens, 1)
+    emb, mask, trailing, pad = emb.to(dev), mask.to(dev), trailing.to(dev), pad.to(dev)
+    sup = [i for i in range(tcfg.vocab_size - 1024, tcfg.vocab_size) if i != tcfg.codec_eos_token_id]
+    gen_kw = dict(max_new_tokens=F + 1, min_new_tokens=F + 1, suppress_tokens=sup, repetition_penalty=1.05,
+                  output_hidden_states=False)
+    if args.greedy:
+        gen_kw.update(do_sample=False, subtalker_dosample=False)
+    else:
+        gen_kw.update(do_sample=True, top_k=50, top_p=1.0, temperature=0.9, subtalker_dosample=True, subtalker_top_k=50,
+                      subtalker_top_p=1.0, subtalker_temperature=0.9)
+
+    def step(seed):
+        out = talker.generate(emb, mask, trailing, pad, seed=seed, **gen_kw)
+        assert out.n_frames == F, f"expected {F} frames, got {out.n_frames}"
+        wav, wl = codec.decode_padded(out.codes)
+        return out, wav, wl
+
+    for i in range(args.warmup):
+        step(1000 + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_ar = 0.0
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        ta = time.perf_counter()
+        out = talker.generate(emb, mask, trailing, pad, seed=2000 + i, **gen_kw)
+        torch.cuda.synchronize()
+        t_ar += time.perf_counter() - ta
+        assert out.n_frames == F
+        wav, wl = codec.decode_padded(out.codes)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([elapsed, t_ar], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, t_ar = float(tt[0]), float(tt[1])
+    assert all(int(x) == F * ccfg.total_upsample for x in wl)
+    assert bool(torch.isfinite(wav).all())
+
+    G = tcfg.num_code_groups
+    tokens_total = world * B * F * G * args.steps
+    audio_s_total = world * B * F * (ccfg.total_upsample / 24000.0) * args.steps
+    value = tokens_total / elapsed
+    res = {
+        "metric": "speech-tokens/sec (+ audio RTF), Qwen3-TTS-12Hz-1.7B batch=8",
+        "value": round(value, 1), "unit": "speech-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Qwen3-TTS-12Hz-{args.model} dims, seeded random weights, batch={B} per GPU, ragged prompts "
+                               f"{min(lens)}..{max(lens)} rows, {F} frames ({F * 0.08:.1f} s) per utterance, "
+                               f"{'greedy' if args.greedy else 'sampling T=0.9 top-k=50 rep=1.05'}; prefill + AR decode "
+                               f"(hipGraph={'off' if args.no_graph else 'on'}) + codec decode to 24 kHz ({args.codec_dtype})",
+                   "global_batch": world * B, "frames_per_utterance": F, "parallelism": f"request-shard x{world}"},
+        "rtf_x": round(audio_s_total / elapsed, 2),
+        "frames_per_s": round(world * B * F * args.steps / elapsed, 1),
+        "ar_ms_per_frame": round(1000 * t_ar / (args.steps * F), 4),
+        "codec_ms_per_step": round(1000 * (elapsed - t_ar) / args.steps, 2),
+        "build_seconds": round(build_s, 1),
+    }
+
+    if rank == 0 and world == 1:
+        st = talker.stats()
+        wbytes = st["weight_bytes_per_frame"]
+        kvb = 2.0 * B * tcfg.num_hidden_layers * 2 * tcfg.num_key_value_heads * tcfg.head_dim * (np.mean(lens) + F / 2)
+        res["frame_bytes_model"] = {"weights": wbytes, "kv_avg": kvb}
+        res["frame_hbm_frac_of_8TBs"] = round((wbytes + kvb) / (res["ar_ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if not args.no_roofline:
+            talker.set_profile(True)
+            o2 = talker.generate(emb, mask, trailing, pad, seed=7, **dict(gen_kw, max_new_tokens=9, min_new_tokens=9))
+            talker.set_profile(False)
+            st = talker.stats()
+            frames_prof = o2.n_frames
+            launches = st["gemm_launches_last"]
+            ms = st["gemm_ms_last"]
+            if launches > 0 and ms > 0:
+                bytes_per_launch = wbytes * frames_prof / launches
+                avg_ms = ms / launches
+                ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+                res["roofline"] = {"bound": "hbm", "kernel": "skinny_kernel (weight-streaming decode GEMM)",
+                                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                   "launches_per_frame": launches // max(1, frames_prof),
+                                   "avg_launch_us": round(1000 * avg_ms, 3),
+                                   "algorithmic_bytes_per_launch": round(bytes_per_launch)}
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, args.cpu_frames)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, n_frames):
+    """The CPU oracle (kind "port": torch fp32 restatement of the reference, oracle/*_ref.py) on a bounded sample
+    of the same workload: same batch and prompts, `n_frames` frames instead of 125, then codec decode of those
+    frames.  Uses every host core torch can see."""
+    import numpy as np
+    import torch
+    import codec_ref
+    import talker_ref
+    torch.set_num_threads(os.cpu_count())
+    tw = {k: torch.from_numpy(v) for k, v in tw_np.items()}
+    cw = {k: torch.from_numpy(v) for k, v in cw_np.items()}
+    rng = np.random.default_rng(100)
+    emb, mask, trailing, pad = synth_prompt(rng, tcfg, lens, 1)
+    sp = talker_ref.SamplingParams()
+    gen = torch.Generator().manual_seed(0)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        r = talker_ref.talker_generate(tw, tcfg, emb, mask, trailing, pad, max_new_tokens=n_frames + 1,
+                                       min_new_tokens=n_frames + 1, sp=sp, generator=gen)
+        t_ar = time.perf_counter() - t0
+        wavs = codec_ref.model_decode(cw, ccfg, r["codes"])
+    dt = time.perf_counter() - t0
+    B = len(lens)
+    toks = B * r["codes"].shape[1] * tcfg.num_code_groups
+    model = "n/a"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": round(toks / dt, 1), "unit": "speech-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"same batch ({B} prompts), prefill + {r['codes'].shape[1]} frames + codec decode of those frames, "
+                      f"fp32 torch CPU oracle, {dt:.1f} s wall ({t_ar:.1f} s AR)",
+            "rtf_x": round(B * r["codes"].shape[1] * 0.08 / dt, 3), "cpu_model": model, "os_cpu_count": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

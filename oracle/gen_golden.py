@@ -254,18 +254,7 @@ def restated_sample_loop(talker, t: synth.TalkerCfg, embeds, mask, trailing, tts
     return codes, generated, hidden
 
 
-def _rand_prompt(g, t, lens, n_trail, scale=0.05):
-    """Synthetic S2-seam inputs: ragged left-padded embeds, mask, trailing text, tts_pad."""
-    import torch
-    B, Tm, H = len(lens), max(lens), t.hidden_size
-    emb = np.zeros((B, Tm, H), np.float32)
-    mask = np.zeros((B, Tm), np.int64)
-    for i, l in enumerate(lens):
-        emb[i, Tm - l:] = g.standard_normal((l, H), dtype=np.float32) * scale
-        mask[i, Tm - l:] = 1
-    trailing = g.standard_normal((B, n_trail, H), dtype=np.float32) * scale
-    pad = g.standard_normal((1, 1, H), dtype=np.float32) * scale
-    return torch.from_numpy(emb), torch.from_numpy(mask), torch.from_numpy(trailing), torch.from_numpy(pad)
+_rand_prompt = synth.rand_prompt
 
 
 def gen_talker_tiny():

@@ -339,3 +339,18 @@ def weights_checksum(w: Dict[str, np.ndarray]) -> float:
 
 def cfg_dict(c) -> dict:
     return asdict(c)
+
+
+def rand_prompt(g: np.random.Generator, t: TalkerCfg, lens, n_trail: int, scale: float = 0.05):
+    """Synthetic inputs at the `talker.generate` seam: ragged LEFT-padded embeds (B,T,H), mask (B,T),
+    trailing text (B,n_trail,H), tts_pad (1,1,H) as torch tensors.  Shared by gen_golden / tests / bench."""
+    import torch
+    B, Tm, H = len(lens), max(lens), t.hidden_size
+    emb = np.zeros((B, Tm, H), np.float32)
+    mask = np.zeros((B, Tm), np.int64)
+    for i, l in enumerate(lens):
+        emb[i, Tm - l:] = g.standard_normal((l, H), dtype=np.float32) * scale
+        mask[i, Tm - l:] = 1
+    trailing = g.standard_normal((B, n_trail, H), dtype=np.float32) * scale
+    pad = g.standard_normal((1, 1, H), dtype=np.float32) * scale
+    return torch.from_numpy(emb), torch.from_numpy(mask), torch.from_numpy(trailing), torch.from_numpy(pad)

@@ -1,0 +1,132 @@
+"""CPU: host-side logic that needs no GPU -- C-ABI surface, configuration views, request sharding
+(world_size-2 gloo), input normalisation errors of the mirrored API."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol(libqtts):
+    hdr = open(os.path.join(ROOT, "include", "qtts.h")).read()
+    declared = set(re.findall(r"\b(qtts_[a-z_]+)\s*\(", hdr))
+    assert len(declared) >= 19
+    lib = ctypes.CDLL(libqtts)
+    for s in declared:
+        assert hasattr(lib, s), f"libqtts.so does not export {s}"
+    from qwen3_tts_amd import _lib
+    assert declared == set(_lib.SYMBOLS), "python binding and header disagree"
+    lib.qtts_abi_version.restype = ctypes.c_int
+    assert lib.qtts_abi_version() == 1
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
+    from qwen3_tts_amd import _lib
+    from qwen3_tts_amd.codec import CodecDecoderEngine
+    from qwen3_tts_amd.talker import TalkerEngine
+    with pytest.raises(_lib.QttsError):
+        CodecDecoderEngine({}, {}, device="cpu")
+    with pytest.raises(_lib.QttsError):
+        TalkerEngine({}, {}, device="cpu")
+    monkeypatch.setenv("QTTS_LIBRARY", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    with pytest.raises(_lib.QttsError):
+        _lib.load_library()
+
+
+def test_config_views():
+    from qwen3_tts_amd.config import CodecDecoderConfig, TalkerConfig
+    import synth
+    c = CodecDecoderConfig.from_any({"decoder_config": {"codebook_dim": 512, "upsample_rates": [8, 5, 4, 3]},
+                                     "decode_upsample_rate": 1920})
+    assert c.head_dim == 64 and c.total_upsample == 1920 and c.upsample_rates == (8, 5, 4, 3)
+    t = TalkerConfig.from_any({"talker_config": {"hidden_size": 2048, "head_dim": 128, "num_code_groups": 16,
+                                                 "code_predictor_config": {"hidden_size": 1024, "num_hidden_layers": 5},
+                                                 "spk_id": {"vivian": 3000}}, "tts_model_type": "custom_voice"})
+    assert t.hidden_size == 2048 and t.cp_hidden_size == 1024 and t.head_dim == 128 and t.tts_model_type == "custom_voice"
+    s = synth.talker_tiny()
+    t2 = TalkerConfig.from_any(s)
+    assert t2.cp_hidden_size == s.cp_hidden_size and t2.codec_eos_token_id == s.codec_eos_token_id
+
+
+def test_lpt_partition_and_waves():
+    from qwen3_tts_amd.sharding import lpt_partition, waves
+    costs = [5, 9, 1, 7, 3, 8, 2, 6]
+    parts = lpt_partition(costs, 3)
+    assert sorted(sum(parts, [])) == list(range(8))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(costs)
+    assert lpt_partition(costs, 3) == parts                      # deterministic
+    assert lpt_partition([], 2) == [[], []]
+    assert waves(list(range(10)), 4) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+
+
+def test_gather_waveforms_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np, torch, torch.distributed as dist
+        from qwen3_tts_amd.sharding import lpt_partition, gather_waveforms
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        costs = [30, 10, 20, 40, 25]
+        parts = lpt_partition(costs, world)
+        mine = parts[rank]
+        wavs = [np.full((100 * costs[i] + i,), float(i), np.float32) for i in mine]
+        out = gather_waveforms(wavs, mine, len(costs))
+        if rank == 0:
+            assert [o.shape[0] for o in out] == [100 * c + i for i, c in enumerate(costs)]
+            assert all((o == i).all() for i, o in enumerate(out))
+            print("GATHER_OK")
+        else:
+            assert out is None
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29653", str(script)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GATHER_OK" in r.stdout
+
+
+def test_tokenizer_decode_input_errors():
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    tk = Qwen3TTSTokenizer()
+    with pytest.raises(TypeError):
+        tk.decode(3.14)
+    with pytest.raises(NotImplementedError):
+        tk.encode(np.zeros(10), sr=24000)
+
+
+def test_model_wrapper_validation():
+    """Wrapper-level validation happens before any device work, so it is testable with a stand-in model."""
+    from qwen3_tts_amd.model import Qwen3TTSModel
+
+    class M:
+        device = torch.device("cpu")
+        tts_model_type, tts_model_size, tokenizer_type = "custom_voice", "1b7", "12hz"
+        def get_supported_languages(self): return ["auto", "chinese", "english"]
+        def get_supported_speakers(self): return ["vivian", "ryan"]
+    w = Qwen3TTSModel(M(), processor=None, generate_defaults={"top_k": 20})
+    with pytest.raises(ValueError, match="does not support generate_voice_design"):
+        w.generate_voice_design("hi", "a voice")
+    with pytest.raises(ValueError, match="does not support generate_voice_clone"):
+        w.generate_voice_clone("hi")
+    with pytest.raises(ValueError, match="Unsupported languages"):
+        w.generate_custom_voice("hi", "vivian", language="klingon")
+    with pytest.raises(ValueError, match="Unsupported speakers"):
+        w.generate_custom_voice("hi", "nobody", language="english")
+    with pytest.raises(ValueError, match="Batch size mismatch"):
+        w.generate_custom_voice(["a", "b", "c"], ["vivian", "ryan"], language="english")
+    kw = w._merge_generate_kwargs(temperature=0.5, foo=1)
+    assert kw["top_k"] == 20 and kw["temperature"] == 0.5 and kw["max_new_tokens"] == 2048 and kw["foo"] == 1
+    assert w.get_supported_speakers() == ["ryan", "vivian"]

@@ -1,0 +1,146 @@
+"""CPU: the oracle (oracle/*_ref.py) against the golden vectors produced by the reference's own modules
+(oracle/gen_golden.py).  These pin the restatement; the GPU tests then compare the HIP path with both."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import codec_ref
+import synth
+import talker_ref
+
+
+def _td(w):
+    return {k: torch.from_numpy(v) for k, v in w.items()}
+
+
+@pytest.fixture(scope="module")
+def codec_tiny(golden_dir):
+    c = synth.codec_tiny()
+    w = synth.codec_weights(c)
+    g = np.load(os.path.join(golden_dir, "codec_tiny.npz"))
+    assert abs(synth.weights_checksum(w) - float(g["weights_checksum"])) < 1e-6, "synthetic weights drifted from the golden run"
+    return c, _td(w), g
+
+
+def test_codec_forward_stages(codec_tiny):
+    c, w, g = codec_tiny
+    st = {}
+    with torch.no_grad():
+        wav = codec_ref.decoder_forward(w, c, torch.from_numpy(g["fwd_codes"]), st)
+    assert np.abs(wav.numpy() - g["fwd_wav"]).max() <= 1e-6
+    for k in ("rvq", "pre_conv", "upsample0", "upsample1", "decoder0", "block1", "block2", "block3", "block4", "pre_clamp"):
+        assert np.abs(st[k].numpy() - g["fwd_" + k]).max() <= 1e-5, k
+    assert np.abs(st["pre_transformer"].numpy().transpose(0, 2, 1) - g["fwd_pre_transformer_btc"]).max() <= 1e-5
+    assert (np.abs(g["fwd_pre_clamp"]) > 1).any() and (np.abs(g["fwd_pre_clamp"]) < 1).mean() > 0.9, "fixture must exercise the clamp but not only the clamp"
+
+
+def test_codec_chunked_and_ragged(codec_tiny):
+    c, w, g = codec_tiny
+    codes = torch.from_numpy(g["chunk_codes"])
+    with torch.no_grad():
+        a = codec_ref.chunked_decode(w, c, codes, 16, 5).numpy()
+        b = codec_ref.chunked_decode(w, c, codes).numpy()
+        ws = codec_ref.model_decode(w, c, torch.from_numpy(g["ragged_codes"]))
+    assert np.abs(a - g["chunk_wav_16_5"]).max() <= 1e-6
+    assert np.abs(b - g["chunk_wav_default"]).max() <= 1e-6
+    assert np.abs(a - b).max() > 1e-3, "chunking with 5 frames of context must differ from un-chunked decode (sanity of the fixture)"
+    for i, x in enumerate(ws):
+        assert x.shape[0] == g[f"ragged_wav{i}"].shape[0]
+        assert np.abs(x.numpy() - g[f"ragged_wav{i}"]).max() <= 1e-6
+
+
+def test_codec_rejects_wrong_codebook_count(codec_tiny):
+    c, w, _ = codec_tiny
+    with pytest.raises(ValueError):
+        codec_ref.decoder_forward(w, c, torch.zeros(1, c.num_quantizers - 1, 3, dtype=torch.long))
+
+
+@pytest.fixture(scope="module")
+def talker_tiny(golden_dir):
+    t = synth.talker_tiny()
+    w = synth.talker_weights(t)
+    g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
+    assert abs(synth.weights_checksum(w) - float(g["weights_checksum"])) < 1e-6
+    return t, _td(w), g
+
+
+def _run(t, w, g, **kw):
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    tr = {}
+    with torch.no_grad():
+        r = talker_ref.talker_generate(w, t, torch.from_numpy(g["embeds"]), torch.from_numpy(g["mask"]),
+                                       torch.from_numpy(g["trailing"]), torch.from_numpy(g["tts_pad"]),
+                                       max_new_tokens=14, sp=sp, trace=tr, **kw)
+    return r, tr
+
+
+def test_talker_greedy_bit_exact(talker_tiny):
+    t, w, g = talker_tiny
+    r, tr = _run(t, w, g)
+    assert np.array_equal(r["tokens"].numpy(), g["tokens"])
+    assert np.array_equal(r["codes"].numpy(), g["codes"])
+    assert np.abs(torch.stack(tr["logits"], 1).numpy() - g["logits"]).max() <= 1e-5
+    assert np.abs(r["hidden"].numpy() - g["hidden"]).max() <= 1e-5
+
+
+def test_talker_eos_and_finished_rows(talker_tiny):
+    t, w, g = talker_tiny
+    r, _ = _run(t, w, g, eos_token_id=int(g["eos2"]))
+    assert np.array_equal(r["tokens"].numpy(), g["tokens_eos2"])
+    assert np.array_equal(r["codes"].numpy(), g["codes_eos2"])
+    trimmed = talker_ref.trim_at_eos(r["codes"], int(g["eos2"]))
+    assert [int(x.shape[0]) for x in trimmed] == [5, 6, 6]
+
+
+def test_prompt_assembly(golden_dir):
+    t = synth.talker_tiny()
+    w = _td(synth.talker_weights(t))
+    g = np.load(os.path.join(golden_dir, "prompt_tiny.npz"))
+    cases = {"cv_ns": (True, ["vivian", "ryan", "vivian"], ["chinese", "english", "auto"]),
+             "cv_st": (False, ["vivian", "ryan", "vivian"], ["chinese", "english", "auto"]),
+             "vd_st": (False, None, ["auto", "english"])}
+    for name, (ns, spk, langs) in cases.items():
+        B = len(langs)
+        ids = [torch.from_numpy(g[f"{name}_ids{i}"]) for i in range(B)]
+        ins = [torch.from_numpy(g[f"{name}_ins{i}"]) if f"{name}_ins{i}" in g else None for i in range(B)]
+        with torch.no_grad():
+            e, m, tr, pad = talker_ref.assemble_prompts(w, t, ids, langs, spk, ins, ns)
+        assert np.array_equal(m.numpy(), g[f"{name}_mask"])
+        assert np.abs(e.numpy() - g[f"{name}_embeds"]).max() <= 1e-6, name
+        assert np.abs(tr.numpy() - g[f"{name}_trailing"]).max() <= 1e-6, name
+        assert np.abs(pad.numpy() - g[f"{name}_tts_pad"]).max() <= 1e-6, name
+        sup = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != t.codec_eos_token_id]
+        assert sup == g[f"{name}_suppress"].tolist() and int(g[f"{name}_eos"]) == t.codec_eos_token_id
+        assert int(g[f"{name}_min_new"]) == 2
+
+
+def test_prompt_errors():
+    t = synth.talker_tiny()
+    w = _td(synth.talker_weights(t))
+    ids = [torch.tensor([[500, 1, 2, 3, 4, 5, 501, 2, 500, 1, 2]])]
+    with pytest.raises(NotImplementedError):
+        talker_ref.assemble_prompts(w, t, ids, ["klingon"], ["vivian"])
+    with pytest.raises(NotImplementedError):
+        talker_ref.assemble_prompts(w, t, ids, ["english"], ["nobody"])
+
+
+def test_logits_processors_match_hf_formulas():
+    torch.manual_seed(0)
+    s = torch.randn(2, 40)
+    gen = torch.tensor([[3, 3, 7], [1, 2, 2]])
+    out = talker_ref.process_logits(s, gen, repetition_penalty=1.3, eos_id=5, min_new_tokens=4, suppress=[30, 31],
+                                    do_sample=True, temperature=0.7, top_k=6)
+    assert torch.isinf(out[:, 5]).all() and torch.isinf(out[:, 30:32]).all()
+    assert (torch.isfinite(out).sum(-1) <= 6).all()
+    pen = torch.where(s[0, 3] < 0, s[0, 3] * 1.3, s[0, 3] / 1.3) / 0.7
+    if torch.isfinite(out[0, 3]):
+        assert torch.allclose(out[0, 3], pen)
+    # top-p keeps the smallest set whose mass >= top_p
+    o2 = talker_ref.process_logits(s, gen[:, :0], do_sample=True, top_p=0.5)
+    p = torch.softmax(s, -1)
+    for b in range(2):
+        kept = torch.isfinite(o2[b])
+        assert p[b][kept].sum() >= 0.5 - 1e-6
+        assert p[b][kept].min() >= p[b][~kept].max()
