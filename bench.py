@@ -31,6 +31,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def synth_prompt(rng, cfg, lens, n_trail, scale=0.05):
@@ -51,7 +56,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=10, help="frames of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-budget-s", type=float, default=90.0, help="wall-clock cap of the CPU-baseline leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,6 +92,7 @@ def main():
     codec = CodecDecoderEngine(ccfg, td(cw_np), compute_dtype=torch.bfloat16 if args.codec_dtype == "bf16" else torch.float32,
                                device=dev, max_batch=B, max_frames=min(F, 300) + 25)
     build_s = time.time() - t0
+    log(f"engines built in {build_s:.1f}s")
     rng = np.random.default_rng(100 + rank)
     emb, mask, trailing, pad = synth_prompt(rng, tcfg, lens, 1)
     emb, mask, trailing, pad = emb.to(dev), mask.to(dev), trailing.to(dev), pad.to(dev)
@@ -106,6 +113,7 @@ def main():
 
     for i in range(args.warmup):
         step(1000 + i)
+    log("warmup done")
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -124,6 +132,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
+    log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
     if dist is not None:
         tt = torch.tensor([elapsed, t_ar], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -176,37 +185,64 @@ def main():
                                    "launches_per_frame": launches // max(1, frames_prof),
                                    "avg_launch_us": round(1000 * avg_ms, 3),
                                    "algorithmic_bytes_per_launch": round(bytes_per_launch)}
+        log("roofline leg done")
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, args.cpu_frames)
+            res["cpu_baseline"] = cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, args.cpu_frames, args.cpu_budget_s)
+            log("cpu baseline done")
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, n_frames):
+def _host_threads():
+    """Cores this process may actually run on (cgroup/affinity aware) -- os.cpu_count() can report the whole
+    host and oversubscribing torch's thread pool makes the CPU leg pathologically slow."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 cpu.max = "<quota> <period>"
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, n_frames, budget_s):
     """The CPU oracle (kind "port": torch fp32 restatement of the reference, oracle/*_ref.py) on a bounded sample
     of the same workload: same batch and prompts, `n_frames` frames instead of 125, then codec decode of those
-    frames.  Uses every host core torch can see."""
+    frames.  Threads = the cores this process is allowed to use.  The AR loop is cut short if it would exceed
+    the wall-clock budget (the sample actually run is reported)."""
     import numpy as np
     import torch
     import codec_ref
     import talker_ref
-    torch.set_num_threads(os.cpu_count())
+    nthreads = _host_threads()
+    torch.set_num_threads(nthreads)
     tw = {k: torch.from_numpy(v) for k, v in tw_np.items()}
     cw = {k: torch.from_numpy(v) for k, v in cw_np.items()}
     rng = np.random.default_rng(100)
     emb, mask, trailing, pad = synth_prompt(rng, tcfg, lens, 1)
     sp = talker_ref.SamplingParams()
     gen = torch.Generator().manual_seed(0)
+    B = len(lens)
     t0 = time.perf_counter()
     with torch.no_grad():
+        # probe: prefill + 1 frame, to size the sample to the budget
+        r = talker_ref.talker_generate(tw, tcfg, emb, mask, trailing, pad, max_new_tokens=2, min_new_tokens=2, sp=sp, generator=gen)
+        t_probe = time.perf_counter() - t0
+        log(f"cpu probe (prefill + 1 frame, {nthreads} threads): {t_probe:.1f}s")
+        if t_probe * (1 + 0.5 * n_frames) > budget_s:
+            n_frames = max(1, int((budget_s / t_probe - 1) / 0.5))
+        t0 = time.perf_counter()
         r = talker_ref.talker_generate(tw, tcfg, emb, mask, trailing, pad, max_new_tokens=n_frames + 1,
                                        min_new_tokens=n_frames + 1, sp=sp, generator=gen)
         t_ar = time.perf_counter() - t0
         wavs = codec_ref.model_decode(cw, ccfg, r["codes"])
     dt = time.perf_counter() - t0
-    B = len(lens)
     toks = B * r["codes"].shape[1] * tcfg.num_code_groups
     model = "n/a"
     try:
@@ -214,7 +250,7 @@ def cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, n_frames):
             model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": round(toks / dt, 1), "unit": "speech-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(toks / dt, 1), "unit": "speech-tokens/s", "cores": nthreads, "kind": "port",
             "sample": f"same batch ({B} prompts), prefill + {r['codes'].shape[1]} frames + codec decode of those frames, "
                       f"fp32 torch CPU oracle, {dt:.1f} s wall ({t_ar:.1f} s AR)",
             "rtf_x": round(B * r["codes"].shape[1] * 0.08 / dt, 3), "cpu_model": model, "os_cpu_count": os.cpu_count()}

@@ -7,7 +7,10 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <algorithm>
 #include <cmath>
+#include <thread>
+#include <functional>
 
 #include "../../include/qtts.h"
 
@@ -104,5 +107,21 @@ struct HostTensor {
 };
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// host-side helper for the one-time weight repacking at bind/finalize
+inline void parallel_for(int64_t n, const std::function<void(int64_t, int64_t)>& fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    if (n < 64 || nt == 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int64_t a = t * chunk, b = std::min<int64_t>(n, a + chunk);
+        if (a >= b) break;
+        th.emplace_back([=, &fn] { fn(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
 
 }  // namespace qtts

@@ -41,6 +41,7 @@ struct SkinnyParams {
     unsigned long long* ss_zero; // optional: block 0 zeroes these [M] entries (next buffer in the ring)
     int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns)
     const int* done_flag;        // optional device flag: when non-zero the kernel exits immediately
+    int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x/g loads, 4 no epilogue loads, 8 no weight loads
 };
 constexpr double SS_SCALE = 16777216.0;  // 2^24 fixed point for the sum-of-squares accumulators
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);

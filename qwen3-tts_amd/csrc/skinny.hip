@@ -12,7 +12,7 @@
 //     (batch padded to 16), so D holds 4 consecutive features per lane -> float4 epilogue stores.
 //     bf16: v_mfma_f32_16x16x32_bf16 (x converted fp32->bf16 in registers);
 //     f32 : v_mfma_f32_16x16x4_f32   (exact fp32 fma chain, parity mode).
-//   * a workgroup = 4 waves that split K of one strip (or a gate/up strip PAIR for SwiGLU) and
+//   * a workgroup = 8 (or 4) waves that split K of one strip (or a gate/up strip PAIR for SwiGLU) and
 //     combine through LDS in a fixed order (deterministic, no atomics on the data path).
 //   * the producing RMSNorm is folded in: rstd[m] factors out of the dot product, so the kernel takes
 //     the per-row sum of squares (fixed-point integer accumulator -> order-independent, deterministic)
@@ -25,19 +25,21 @@ namespace qtts {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF16, int MT, int SPW>
-__global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
-    if (p.done_flag && *p.done_flag) return;
+template <bool BF16, int MT, int SPW, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
+    if (!(p.ablate & 1) && p.done_flag && *p.done_flag) return;
     constexpr int KT = BF16 ? 32 : 16;     // k per tile
     constexpr int XV = BF16 ? 8 : 4;       // x values per lane per tile
-    constexpr int U = 4;                   // k-tiles in flight per wave
-    __shared__ __attribute__((aligned(16))) f32x4 red[4 * SPW * MT * 64];
+    constexpr int U = 16 / SPW;            // k-tiles per chunk: 16 x 1-KiB weight loads in flight per wave
+    __shared__ __attribute__((aligned(16))) f32x4 red[NW * SPW * MT * 64];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lj = lane & 15, lq = lane >> 4;
     const int nkt = p.K / KT;
-    const int per_wave = nkt / 4;
-    const int kt_begin = wave * per_wave, kt_end = kt_begin + per_wave;
+    // k-tiles are dealt round-robin to the NW waves (tile = wave + NW*i): the workgroup's concurrent loads
+    // cover one contiguous NW-KiB run of the strip's stream.
+    const int my_tiles = (nkt - wave + NW - 1) / NW;
+    const int nchunks = (my_tiles + U - 1) / U;
     const int strip0 = blockIdx.x * SPW;
 
     if (p.ss_zero && blockIdx.x == 0 && tid < 64) p.ss_zero[tid] = 0ull;
@@ -53,20 +55,24 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
     for (int s = 0; s < SPW; ++s)
         wbase[s] = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)(strip0 + s) * nkt) * 64 + lane;
 
-    for (int kt0 = kt_begin; kt0 < kt_end; kt0 += U) {
-        u32x4 w[SPW][U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int s = 0; s < SPW; ++s)
-                w[s][u] = (kt0 + u < kt_end) ? __builtin_nontemporal_load(wbase[s] + (size_t)(kt0 + u) * 64)
-                                             : (u32x4){0u, 0u, 0u, 0u};
+    auto load_chunk = [&](u32x4 (&w)[SPW][U], int c) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (kt0 + u >= kt_end) break;
-            const int k = (kt0 + u) * KT + lq * XV;
+            const int i = c * U + u;
+            const int kt = wave + NW * i;
+#pragma unroll
+            for (int s = 0; s < SPW; ++s)
+                w[s][u] = (i < my_tiles && !(p.ablate & 8)) ? __builtin_nontemporal_load(wbase[s] + (size_t)kt * 64) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto compute_chunk = [&](u32x4 (&w)[SPW][U], int c) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = c * U + u;
+            if (i >= my_tiles) break;
+            const int k = (wave + NW * i) * KT + lq * XV;
             float gv[XV];
-            if (p.g) {
+            if (p.g && !(p.ablate & 2)) {
 #pragma unroll
                 for (int e = 0; e < XV; e += 4) {
                     const float4 t = *reinterpret_cast<const float4*>(p.g + k + e);
@@ -77,13 +83,16 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
             for (int m = 0; m < MT; ++m) {
                 const int row = m * 16 + lj;
                 float xv[XV];
-                if (row < p.M) {
+                if (row < p.M && (p.ablate & 2)) {
+#pragma unroll
+                    for (int e = 0; e < XV; ++e) xv[e] = 1.0f + (float)(lane + e);
+                } else if (row < p.M) {
 #pragma unroll
                     for (int e = 0; e < XV; e += 4) {
                         const float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + k + e);
                         xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
                     }
-                    if (p.g) {
+                    if (p.g && !(p.ablate & 2)) {
 #pragma unroll
                         for (int e = 0; e < XV; ++e) xv[e] *= gv[e];
                     }
@@ -113,6 +122,16 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
                 }
             }
         }
+    };
+
+    // ping-pong: the next chunk's 16 KiB of weight loads are in flight while the current chunk is consumed
+    u32x4 wA[SPW][U], wB[SPW][U];
+    load_chunk(wA, 0);
+    for (int c = 0; c < nchunks; c += 2) {
+        if (c + 1 < nchunks) load_chunk(wB, c + 1);
+        compute_chunk(wA, c);
+        if (c + 2 < nchunks) load_chunk(wA, c + 2);
+        if (c + 1 < nchunks) compute_chunk(wB, c + 1);
     }
 
     // ---- cross-wave combine (fixed order) ----
@@ -132,11 +151,11 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
         for (int s = 0; s < SPW; ++s) {
             f32x4 t = red[((0 * SPW + s) * MT + m) * 64 + lane];
 #pragma unroll
-            for (int w2 = 1; w2 < 4; ++w2) t += red[((w2 * SPW + s) * MT + m) * 64 + lane];
+            for (int w2 = 1; w2 < NW; ++w2) t += red[((w2 * SPW + s) * MT + m) * 64 + lane];
             v[s] = t;
         }
         float rstd = 1.f;
-        if (p.ss_in && row < p.M) {
+        if (p.ss_in && row < p.M && !(p.ablate & 4)) {
             const float ssum = (float)((double)p.ss_in[row] * (1.0 / SS_SCALE));
             rstd = rsqrtf(ssum / (float)p.K + p.eps);
         }
@@ -162,9 +181,9 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
             for (int s = 0; s < SPW; ++s) {
                 const int col = (strip0 + s) * 16 + lq * 4;
                 f32x4 o = v[s] * rstd;
-                if (p.bias) o += *reinterpret_cast<const f32x4*>(p.bias + col);
+                if (p.bias && !(p.ablate & 4)) o += *reinterpret_cast<const f32x4*>(p.bias + col);
                 if (row < p.M) {
-                    if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+                    if (p.res && !(p.ablate & 4)) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
                     *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
                     sq += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
                 }
@@ -180,16 +199,21 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyParams p) {
 }
 
 template <bool BF16, int MT>
-static void launch_mt(const SkinnyParams& p, int spw, hipStream_t st) {
+static void launch_mt(const SkinnyParams& p, int spw, int nw, hipStream_t st) {
     const int strips = p.N / 16;
-    if (spw == 2) hipLaunchKernelGGL((skinny_kernel<BF16, MT, 2>), dim3(strips / 2), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((skinny_kernel<BF16, MT, 1>), dim3(strips), dim3(256), 0, st, p);
+    if (nw == 8) {
+        if (spw == 2) hipLaunchKernelGGL((skinny_kernel<BF16, MT, 2, 8>), dim3(strips / 2), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((skinny_kernel<BF16, MT, 1, 8>), dim3(strips), dim3(512), 0, st, p);
+    } else {
+        if (spw == 2) hipLaunchKernelGGL((skinny_kernel<BF16, MT, 2, 4>), dim3(strips / 2), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((skinny_kernel<BF16, MT, 1, 4>), dim3(strips), dim3(256), 0, st, p);
+    }
 }
 
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int KT = bf16 ? 32 : 16;
     QTTS_REQUIRE(p.N % 16 == 0, QTTS_ERR_ARG, "skinny: N % 16");
-    QTTS_REQUIRE(p.K % (KT * 4) == 0, QTTS_ERR_ARG, "skinny: K must be a multiple of 4 k-tiles");
+    QTTS_REQUIRE(p.K % KT == 0, QTTS_ERR_ARG, "skinny: K must be a multiple of the k-tile");
     QTTS_REQUIRE(p.M >= 1 && p.M <= 64, QTTS_ERR_LIMIT, "skinny: 1 <= M <= 64");
     QTTS_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, QTTS_ERR_ARG, "skinny: ldx/ldo % 4");
     int spw = 1;
@@ -197,15 +221,16 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
         QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "skinny: swiglu N % 32");
         spw = 2;
     } else if (p.N / 16 >= 1024 && (p.N / 16) % 2 == 0) spw = 2;
+    const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16) {
-        if (mt == 1) launch_mt<true, 1>(p, spw, st);
-        else if (mt == 2) launch_mt<true, 2>(p, spw, st);
-        else launch_mt<true, 4>(p, spw, st);
+        if (mt == 1) launch_mt<true, 1>(p, spw, nw, st);
+        else if (mt == 2) launch_mt<true, 2>(p, spw, nw, st);
+        else launch_mt<true, 4>(p, spw, nw, st);
     } else {
-        if (mt == 1) launch_mt<false, 1>(p, spw, st);
-        else if (mt == 2) launch_mt<false, 2>(p, spw, st);
-        else launch_mt<false, 4>(p, spw, st);
+        if (mt == 1) launch_mt<false, 1>(p, spw, nw, st);
+        else if (mt == 2) launch_mt<false, 2>(p, spw, nw, st);
+        else launch_mt<false, 4>(p, spw, nw, st);
     }
     QTTS_CHECK_HIP(hipGetLastError());
 }
@@ -215,20 +240,22 @@ size_t skinny_packed_bytes(int N, int K, bool bf16) { return (size_t)N * K * (bf
 void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host) {
     const int KT = bf16 ? 32 : 16;
     const int nkt = K / KT, strips = N / 16;
-    for (int s = 0; s < strips; ++s)
-        for (int kt = 0; kt < nkt; ++kt)
-            for (int l = 0; l < 64; ++l) {
-                const int i = l & 15, q = l >> 4;
-                const size_t tile = ((size_t)s * nkt + kt) * 64 + l;
-                const float* src = W + (size_t)(s * 16 + i) * K + kt * KT + q * (bf16 ? 8 : 4);
-                if (bf16) {
-                    bf16_t* d = reinterpret_cast<bf16_t*>(out_host) + tile * 8;
-                    for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16(src[e]);
-                } else {
-                    float* d = reinterpret_cast<float*>(out_host) + tile * 4;
-                    for (int e = 0; e < 4; ++e) d[e] = src[e];
+    parallel_for(strips, [&](int64_t s0, int64_t s1) {
+        for (int64_t s = s0; s < s1; ++s)
+            for (int kt = 0; kt < nkt; ++kt)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = l & 15, q = l >> 4;
+                    const size_t tile = ((size_t)s * nkt + kt) * 64 + l;
+                    const float* src = W + (size_t)(s * 16 + i) * K + kt * KT + q * (bf16 ? 8 : 4);
+                    if (bf16) {
+                        bf16_t* d = reinterpret_cast<bf16_t*>(out_host) + tile * 8;
+                        for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16(src[e]);
+                    } else {
+                        float* d = reinterpret_cast<float*>(out_host) + tile * 4;
+                        for (int e = 0; e < 4; ++e) d[e] = src[e];
+                    }
                 }
-            }
+    });
 }
 
 }  // namespace qtts

@@ -85,7 +85,7 @@ struct qtts_talker {
     void upload_rows(DevBuf& d, const std::vector<float>& w) {
         if (bf16) {
             std::vector<bf16_t> h(w.size());
-            for (size_t i = 0; i < w.size(); ++i) h[i] = f32_to_bf16(w[i]);
+            parallel_for((int64_t)w.size(), [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) h[i] = f32_to_bf16(w[i]); });
             d.upload(h.data(), h.size() * 2);
         } else d.upload(w.data(), w.size() * 4);
     }
@@ -614,6 +614,85 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     out->gemm_ms_last = t->prof_ms; out->gemm_launches_last = t->prof_launches;
     QTTS_API_END
 }
+__global__ void null_kernel(int* p, int mode) {
+    if (mode == 1) { if (*p) return; }
+    if (mode == 2) { __shared__ int s[64]; s[threadIdx.x & 63] = threadIdx.x; __syncthreads(); if (threadIdx.x == 0 && s[5] == 12345) *p = 1; }
+}
+// DEBUG: hipGraph chain of trivial kernels (grid x block) -> us per launch: the dependent-kernel boundary here.
+int qtts_debug_null_chain(int32_t grid, int32_t block, int32_t mode, int32_t iters, int32_t reps, double* us) {
+    QTTS_API_BEGIN
+    DevBuf d; d.alloc(64); QTTS_CHECK_HIP(hipMemset(d.p, 0, 64));
+    hipStream_t st; QTTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipGraph_t gr; hipGraphExec_t ge;
+    QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(null_kernel, dim3(grid), dim3(block), 0, st, d.as<int>(), mode);
+    QTTS_CHECK_HIP(hipStreamEndCapture(st, &gr));
+    QTTS_CHECK_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+    QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    hipEvent_t a, b; QTTS_CHECK_HIP(hipEventCreate(&a)); QTTS_CHECK_HIP(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        QTTS_CHECK_HIP(hipEventRecord(a, st)); QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipEventRecord(b, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        float ms = 0; QTTS_CHECK_HIP(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
+    }
+    *us = 1000.0 * best / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr); (void)hipStreamDestroy(st);
+    QTTS_API_END
+}
+
+// DEBUG/perf tooling (not part of the product surface): time a hipGraph chain of `iters` identical skinny GEMM
+// launches (bf16, packed random-ish weights) and return the average microseconds per launch.
+int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_t with_norm, int32_t with_res,
+                            int32_t ablate, int32_t iters, int32_t reps, double* us_per_launch) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(us_per_launch && iters > 0 && reps > 0, QTTS_ERR_ARG, "bad argument");
+    DevBuf W, x, g, out, res, ssin, ssout, done;
+    W.alloc(skinny_packed_bytes(N, K, true));
+    {
+        std::vector<uint16_t> h((size_t)N * K);
+        uint32_t r = 12345;
+        for (auto& v : h) { r = r * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((r >> 16) & 0x3ff) - 0x200 + ((r >> 31) << 15)); }
+        W.upload(h.data(), h.size() * 2);
+    }
+    const int No = act == ACT_SWIGLU ? N / 2 : N;
+    x.alloc((size_t)64 * K * 4); g.alloc((size_t)K * 4); out.alloc((size_t)64 * No * 4); res.alloc((size_t)64 * No * 4);
+    ssin.alloc(64 * 8); ssout.alloc(64 * 8); done.alloc(64);
+    QTTS_CHECK_HIP(hipMemset(x.p, 0x3c, x.bytes)); QTTS_CHECK_HIP(hipMemset(g.p, 0x3c, g.bytes));
+    QTTS_CHECK_HIP(hipMemset(res.p, 0, res.bytes)); QTTS_CHECK_HIP(hipMemset(ssin.p, 1, ssin.bytes));
+    QTTS_CHECK_HIP(hipMemset(ssout.p, 0, ssout.bytes)); QTTS_CHECK_HIP(hipMemset(done.p, 0, done.bytes));
+    SkinnyParams p{};
+    p.x = x.as<float>(); p.ldx = K; p.M = M; p.Wp = W.p; p.N = N; p.K = K; p.eps = 1e-6f; p.act = act;
+    if (with_norm) { p.g = g.as<float>(); p.ss_in = ssin.as<unsigned long long>(); p.ss_zero = ssout.as<unsigned long long>(); }
+    if (with_res) { p.res = res.as<float>(); p.ldr = No; p.ss_out = ssout.as<unsigned long long>(); }
+    p.out = out.as<float>(); p.ldo = No; p.done_flag = done.as<int>(); p.ablate = ablate;
+    hipStream_t st;
+    QTTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    launch_skinny(p, true, st);
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    hipGraph_t gr; hipGraphExec_t ge;
+    QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < iters; ++i) launch_skinny(p, true, st);
+    QTTS_CHECK_HIP(hipStreamEndCapture(st, &gr));
+    QTTS_CHECK_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+    QTTS_CHECK_HIP(hipGraphLaunch(ge, st));
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    hipEvent_t a, b;
+    QTTS_CHECK_HIP(hipEventCreate(&a)); QTTS_CHECK_HIP(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int r = 0; r < reps; ++r) {
+        QTTS_CHECK_HIP(hipEventRecord(a, st));
+        QTTS_CHECK_HIP(hipGraphLaunch(ge, st));
+        QTTS_CHECK_HIP(hipEventRecord(b, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        float ms = 0; QTTS_CHECK_HIP(hipEventElapsedTime(&ms, a, b));
+        best = std::min(best, ms);
+    }
+    *us_per_launch = 1000.0 * best / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr); (void)hipStreamDestroy(st);
+    QTTS_API_END
+}
+
 int qtts_talker_set_profile(qtts_talker* t, int32_t enable) {
     QTTS_API_BEGIN
     QTTS_REQUIRE(t, QTTS_ERR_ARG, "null handle");
