@@ -199,11 +199,18 @@ void launch_qknorm_rope_store(const QkNormRopeParams& p, hipStream_t st) {
 
 // =================================================================================== attn_decode
 // grid = B * nkv workgroups of 256 threads.  HD = 128 only (talker and code predictor).
-// LDS: qs[n_new*GQ][128] | kn[n_new][128] | vn[n_new][128] | red[4][n_new*GQ][128] | sc[n_new*GQ][max_len]
+// Latency-first structure (this kernel runs 103x per frame on 17..300 keys): all loads that do not depend on
+// the freshly produced qkv row -- the first KV chunk of every 16-lane key group, the length and pad scalars --
+// are issued at kernel entry; q/k RMSNorm + RoPE of the new tokens runs underneath them; later KV chunks are
+// prefetched one chunk ahead.  Key s is owned by lane group (s % 16); new keys come from LDS, old ones from
+// the paged cache (page = table[b][s/16], or b*pages_per_seq + s/16 when the pool is laid out contiguously).
+// LDS: qs[NQ][128] | kn[n_new][128] | vn[n_new][128] | red[4][NQ][128] | sc[NQ][max_len] | stat[NQ]
 template <typename KVT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
-    if (p.done_flag && *p.done_flag) return;
     constexpr int HD = 128;
+    constexpr int CH = 4;                      // keys per lane group per chunk (64 keys per workgroup chunk)
+    constexpr int KW = sizeof(KVT) == 2 ? 1 : 2;   // 16-B vectors per key per lane (8 dims)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float sm_ad[];
     const int GQ = p.nh / p.nkv;
     const int NQ = p.n_new * GQ;
@@ -212,79 +219,147 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     float* vn = kn + p.n_new * HD;             // [n_new][HD]
     float* red = vn + p.n_new * HD;            // [4][NQ][HD]
     float* sc = red + 4 * NQ * HD;             // [NQ][max_len]
-    float* stat = sc + NQ * p.max_len;         // [NQ][2] (max, 1/sum)
+    float* stat = sc + NQ * p.max_len;         // [NQ]
 
     const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = tid >> 4, li = tid & 15;
+    const KVT* kc = reinterpret_cast<const KVT*>(p.kv.k);
+    const KVT* vc = reinterpret_cast<const KVT*>(p.kv.v);
+    const int pool_keys = p.kv.pages_per_seq * 16;
+
+    auto kv_off = [&](int s) -> size_t {       // element offset of key s, this lane's 8 dims
+        s = s < pool_keys ? s : pool_keys - 1;  // speculative loads stay inside the sequence's pages
+        const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+        return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD + li * 8;
+    };
+    auto load_chunk = [&](u32x4 (&r)[CH][KW], const KVT* base, int c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(base + kv_off(g + 16 * (c * CH + i)));
+#pragma unroll
+            for (int w = 0; w < KW; ++w) r[i][w] = src[w];
+        }
+    };
+    auto unpack = [&](const u32x4 (&r)[KW], float (&x)[8]) {
+        if constexpr (KW == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[2 * e] = __uint_as_float(r[0][e] << 16);
+                x[2 * e + 1] = __uint_as_float(r[0][e] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = __uint_as_float(r[0][e]); x[4 + e] = __uint_as_float(r[1][e]); }
+        }
+    };
+
+    // ---- 0. loads that do not depend on this step's qkv: first K and V chunk, scalars
+    u32x4 kA[CH][KW], vA[CH][KW];
+    load_chunk(kA, kc, 0);
+    load_chunk(vA, vc, 0);
     const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step
     const int npad = p.n_pad ? p.n_pad[b] : 0;
-    KVT* kc = reinterpret_cast<KVT*>(p.kv.k);
-    KVT* vc = reinterpret_cast<KVT*>(p.kv.v);
+    const int done = p.done_flag ? *p.done_flag : 0;
 
     // ---- 1. q/k RMSNorm + RoPE for the new tokens (one wave per vector), K/V append
     const int nvec = NQ + 2 * p.n_new;  // q vectors, then k, then v
-    for (int vi = wave; vi < nvec; vi += 4) {
-        int t, col;
+    float x0v[2], x1v[2];               // up to 2 vectors per wave (nvec <= 8)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int vi = wave + 4 * r;
+        x0v[r] = x1v[r] = 0.f;
+        if (vi < nvec) {
+            int t, col;
+            if (vi < NQ) { t = vi / GQ; col = (kvh * GQ + vi % GQ) * HD; }
+            else if (vi < NQ + p.n_new) { t = vi - NQ; col = (p.nh + kvh) * HD; }
+            else { t = vi - NQ - p.n_new; col = (p.nh + p.nkv + kvh) * HD; }
+            const float* src = p.qkv + ((size_t)t * p.B + b) * p.ld + col;
+            x0v[r] = src[lane]; x1v[r] = src[lane + 64];
+        }
+    }
+    if (done) return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int vi = wave + 4 * r;
+        if (vi >= nvec) continue;
+        int t;
         const float* w = nullptr;
         float* dst;
-        if (vi < NQ) { t = vi / GQ; col = (kvh * GQ + vi % GQ) * HD; w = p.qw; dst = qs + vi * HD; }
-        else if (vi < NQ + p.n_new) { t = vi - NQ; col = (p.nh + kvh) * HD; w = p.kw; dst = kn + t * HD; }
-        else { t = vi - NQ - p.n_new; col = (p.nh + p.nkv + kvh) * HD; dst = vn + t * HD; }
-        const float* src = p.qkv + ((size_t)t * p.B + b) * p.ld + col;
-        float x0 = src[lane], x1 = src[lane + 64];
+        if (vi < NQ) { t = vi / GQ; w = p.qw; dst = qs + vi * HD; }
+        else if (vi < NQ + p.n_new) { t = vi - NQ; w = p.kw; dst = kn + t * HD; }
+        else { t = vi - NQ - p.n_new; dst = vn + t * HD; }
+        float x0 = x0v[r], x1 = x1v[r];
         if (w) {
             const float ss = wave_sum64(x0 * x0 + x1 * x1);
-            const float r = rsqrtf(ss / (float)HD + p.eps);
-            x0 = w[lane] * (x0 * r);
-            x1 = w[lane + 64] * (x1 * r);
+            const float rs = rsqrtf(ss / (float)HD + p.eps);
+            x0 = w[lane] * (x0 * rs);
+            x1 = w[lane + 64] * (x1 * rs);
             const float ang = (float)(S0 + t - npad) * p.inv_freq[lane];
-            const float c = cosf(ang), s = sinf(ang);
-            const float o0 = x0 * c - x1 * s, o1 = x1 * c + x0 * s;
+            const float c = cosf(ang), sn = sinf(ang);
+            const float o0 = x0 * c - x1 * sn, o1 = x1 * c + x0 * sn;
             x0 = o0; x1 = o1;
         }
         if (vi >= NQ) {  // K or V of a new token: round through the cache type, append
-            const size_t o = kv_offset(p.kv, p.layer, b, S0 + t, kvh);
-            KVT* c = (vi < NQ + p.n_new) ? kc : vc;
+            const int s = S0 + t;
+            const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+            const size_t o = ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD;
+            KVT* cdst = reinterpret_cast<KVT*>(vi < NQ + p.n_new ? p.kv.k : p.kv.v);
             const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
-            c[o + lane] = h0; c[o + lane + 64] = h1;
+            cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
             x0 = kv_load(&h0); x1 = kv_load(&h1);
         }
         dst[lane] = x0; dst[lane + 64] = x1;
     }
     __syncthreads();
 
-    // ---- 2. scores: 16 lanes per key (8 dims each), 16 keys per sweep
-    const int g = tid >> 4, li = tid & 15;
+    // ---- 2. scores: 16 lanes per key (8 dims each), 16 keys per sweep, chunked with one-chunk-ahead prefetch
     const float scale = rsqrtf((float)HD);
-    const int S1 = S0 + p.n_new;  // total keys
-    for (int s = npad + g; s < S1; s += 16) {
-        float kx[8];
-        if (s >= S0) {
+    const int S1 = S0 + p.n_new;               // total keys
+    const int nchunk = (S1 + 16 * CH - 1) / (16 * CH);
+    float qreg[4][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) kx[e] = kn[(s - S0) * HD + li * 8 + e];
-        } else {
-            const KVT* kp = kc + kv_offset(p.kv, p.layer, b, s, kvh) + li * 8;
+    for (int qi = 0; qi < 4; ++qi)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) kx[e] = kv_load(kp + e);
+        for (int e = 0; e < 8; ++e) qreg[qi][e] = qi < NQ ? qs[qi * HD + li * 8 + e] : 0.f;
+    auto score_chunk = [&](const u32x4 (&r)[CH][KW], int c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int s = g + 16 * (c * CH + i);
+            if (s >= S1) break;
+            float kx[8];
+            if (s >= S0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kx[e] = kn[(s - S0) * HD + li * 8 + e];
+            } else unpack(r[i], kx);
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                if (qi >= NQ) break;
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d += qreg[qi][e] * kx[e];
+                d = group16_sum(d) * scale;
+                if (li == 0) sc[qi * p.max_len + s] = (s >= npad && s <= S0 + qi / GQ) ? d : -INFINITY;
+            }
         }
-        for (int qi = 0; qi < NQ; ++qi) {
-            const float* qp = qs + qi * HD + li * 8;
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) d += qp[e] * kx[e];
-            d = group16_sum(d) * scale;
-            const int tq = qi / GQ;
-            if (li == 0) sc[qi * p.max_len + s] = (s <= S0 + tq) ? d : -INFINITY;  // causal among new tokens
+    };
+    {
+        u32x4 kB[CH][KW];
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 1 < nchunk) load_chunk(kB, kc, c + 1);
+            score_chunk(kA, c);
+            if (c + 2 < nchunk) load_chunk(kA, kc, c + 2);
+            if (c + 1 < nchunk) score_chunk(kB, c + 1);
         }
     }
     __syncthreads();
     // ---- 3. softmax statistics: wave qi % 4 handles query qi
     for (int qi = wave; qi < NQ; qi += 4) {
         float m = -INFINITY;
-        for (int s = npad + lane; s < S1; s += 64) m = fmaxf(m, sc[qi * p.max_len + s]);
+        for (int s = lane; s < S1; s += 64) m = fmaxf(m, sc[qi * p.max_len + s]);
         m = wave_max64(m);
         float l = 0.f;
-        for (int s = npad + lane; s < S1; s += 64) {
+        for (int s = lane; s < S1; s += 64) {
             const float e = expf(sc[qi * p.max_len + s] - m);
             sc[qi * p.max_len + s] = e;
             l += e;
@@ -293,29 +368,39 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         if (lane == 0) stat[qi] = 1.f / l;
     }
     __syncthreads();
-    // ---- 4. PV: 16 lanes per key, 16 keys per sweep, accumulate 8 dims per lane per query
+    // ---- 4. PV: same key ownership, accumulate 8 dims per lane per query
     float acc[4][8];
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
-    for (int s = npad + g; s < S1; s += 16) {
-        float vx[8];
-        if (s >= S0) {
+    auto pv_chunk = [&](const u32x4 (&r)[CH][KW], int c) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vx[e] = vn[(s - S0) * HD + li * 8 + e];
-        } else {
-            const KVT* vp = vc + kv_offset(p.kv, p.layer, b, s, kvh) + li * 8;
+        for (int i = 0; i < CH; ++i) {
+            const int s = g + 16 * (c * CH + i);
+            if (s >= S1) break;
+            if (s < npad) continue;            // left-pad slots were never written: 0 * garbage could be NaN
+            float vx[8];
+            if (s >= S0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vx[e] = kv_load(vp + e);
-        }
+                for (int e = 0; e < 8; ++e) vx[e] = vn[(s - S0) * HD + li * 8 + e];
+            } else unpack(r[i], vx);
 #pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            if (qi < NQ) {
+            for (int qi = 0; qi < 4; ++qi) {
+                if (qi >= NQ) break;
                 const float pr = sc[qi * p.max_len + s];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[qi][e] += pr * vx[e];
             }
+        }
+    };
+    {
+        u32x4 vB[CH][KW];
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 1 < nchunk) load_chunk(vB, vc, c + 1);
+            pv_chunk(vA, c);
+            if (c + 2 < nchunk) load_chunk(vA, vc, c + 2);
+            if (c + 1 < nchunk) pv_chunk(vB, c + 1);
         }
     }
     // reduce the 4 key groups of a wave (lanes l, l^16, l^32), then the 4 waves through LDS
@@ -327,9 +412,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             acc[qi][e] += __shfl_xor(acc[qi][e], 32);
         }
     if (lane < 16) {
-        for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            if (qi >= NQ) break;
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[(wave * NQ + qi) * HD + lane * 8 + e] = acc[qi][e];
+        }
     }
     __syncthreads();
     for (int i = tid; i < NQ * HD; i += 256) {

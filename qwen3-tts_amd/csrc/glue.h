@@ -24,8 +24,6 @@ struct CpGatherParams {
     int cp_vocab;
     const int* sub; int sub_stride;   // [B][G-1] sub-codes sampled so far
     float* out;                 // [rows][H]
-    unsigned long long* ss;     // [rows] fixed-point sum of squares (or null)
-    unsigned long long* ss_zero; // optional: 64 entries zeroed (the projection GEMM accumulates into them)
     const int* done;
 };
 void launch_cp_gather(const CpGatherParams& p, hipStream_t st);
@@ -36,14 +34,16 @@ struct EmbedSumParams {
     const int* cur_tok; const int* sub; int sub_stride;
     const float* trailing; int Tt; const float* tts_pad;
     const float* past_hidden;
-    float* x_out; unsigned long long* ss;
+    float* x_out;
     int64_t* codes_out; float* hidden_out; int max_frames;
     StepState st;
 };
 void launch_embed_sum(const EmbedSumParams& p, hipStream_t st);
 
-void launch_apply_norm(const float* x, int ldx, const unsigned long long* ss, const float* g, float eps, float* y,
-                       int ldy, int rows, int C, const int* done, hipStream_t st);
-void launch_row_ss(const float* x, int ldx, int rows, int C, unsigned long long* ss, hipStream_t st);
+// y = g * (x * rsqrt(mean(x^2)+eps)) per row (final talker norm -> past_hidden), early-exit on *done
+void launch_apply_norm(const float* x, int ldx, const float* g, float eps, float* y, int ldy, int rows, int C,
+                       const int* done, hipStream_t st);
+// ss[r] = sum_c x[r][c]^2 (only for GEMMs that cannot stage x through LDS)
+void launch_row_ss(const float* x, int ldx, int rows, int C, float* ss, const int* done, hipStream_t st);
 
 }  // namespace qtts

@@ -29,25 +29,24 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
 // 1-KiB MFMA-operand tiles (see pack_skinny_weight).
 struct SkinnyParams {
     const float* x; int ldx; int M;
-    const void* Wp;              // packed tiles [N/16][K/KT][64 lanes][16 B]
+    const void* Wp;              // packed tiles [N/16][K/KT][64 lanes][16 B] (RMSNorm weight already folded in)
     int N, K;
-    const float* g;              // optional RMSNorm weight [K] applied to x on the fly
-    const unsigned long long* ss_in;  // optional fixed-point sum-of-squares per row [M] -> rstd
+    int norm;                    // 1: out = rstd[m] * (x . W'^T) with rstd = rsqrt(mean_k x^2 + eps)
+    const float* ss_in;          // only when the kernel cannot stage x through LDS: sum_k x[m][k]^2 per row [M]
     float eps;
     const float* bias;           // [N] or null
     const float* res; int ldr;   // residual [M][ldr] or null
     float* out; int ldo;
-    unsigned long long* ss_out;  // optional: accumulate fixed-point sum(out^2) per row [M]
-    unsigned long long* ss_zero; // optional: block 0 zeroes these [M] entries (next buffer in the ring)
     int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns)
-    const int* done_flag;        // optional device flag: when non-zero the kernel exits immediately
-    int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x/g loads, 4 no epilogue loads, 8 no weight loads
+    const int* done_flag;        // optional device flag: when non-zero the kernel exits early
+    int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
 };
-constexpr double SS_SCALE = 16777216.0;  // 2^24 fixed point for the sum-of-squares accumulators
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);
+bool skinny_can_stage(int M, int K, bool bf16);
 size_t skinny_packed_bytes(int N, int K, bool bf16);
-// Pack W[N][K] (row-major f32) into the streaming tile layout; gate/up interleaving is the caller's.
-void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host);
+// Pack W[N][K] (row-major f32), optionally scaled per input column by g[K], into the streaming tile layout;
+// gate/up interleaving is the caller's.
+void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host, const float* g = nullptr);
 
 // --------------------------------------------------------------------------------- elementwise.hip
 void launch_rmsnorm(const float* x, int ldx, const float* w, float eps, float* y, int ldy, int rows, int C,
@@ -84,6 +83,7 @@ struct KvCache {
     const int* page_table;       // [B][pages_per_seq]
     int pages_per_seq, n_pages, nkv, hd;
     int bf16;
+    int contig;                  // 1: page_table[b][i] == b*pages_per_seq + i (skip the indirection load)
 };
 struct QkNormRopeParams {
     float* qkv; int ld; int B, T, nh, nkv, hd;

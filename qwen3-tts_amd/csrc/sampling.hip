@@ -32,15 +32,17 @@ __device__ inline uint32_t float_key(float f) {  // monotone float -> uint (larg
 }
 
 constexpr int SAMPLE_MAX_V = 8192;
+constexpr int TOPK_COMPACT_MAX = 256;   // survivors of top-k that one wave samples from directly
 
 __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     if (p.done_in && *p.done_in) return;
     __shared__ float sc[SAMPLE_MAX_V];
-    __shared__ int hist[256];
     __shared__ float fred[4];
-    __shared__ int ired[4];
+    __shared__ int ired[8];
     __shared__ float scan[256];
-    __shared__ int sel_prefix, sel_need, pick_lo, pick_hi;
+    __shared__ float cval[TOPK_COMPACT_MAX];
+    __shared__ int cidx[TOPK_COMPACT_MAX];
+    __shared__ int pick_lo, pick_hi;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = p.V;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
         __syncthreads();
     }
 
-    int token;
+    int token = 0;
     if (!p.do_sample) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
@@ -89,84 +91,126 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
             for (int v = tid; v < V; v += 256) sc[v] = sc[v] / p.temperature;
             __syncthreads();
         }
-        if (p.top_k > 0 && p.top_k < V) {
-            // radix select of the k-th largest key, 8 bits per pass from the MSB
-            uint32_t prefix = 0;
-            int need = p.top_k;
-            for (int pass = 0; pass < 4; ++pass) {
-                const int shift = 24 - 8 * pass;
-                hist[tid] = 0;
-                __syncthreads();
-                const uint32_t mask_hi = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-                for (int v = tid; v < V; v += 256) {
-                    const uint32_t k = float_key(sc[v]);
-                    if ((k & mask_hi) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    int cum = 0, d = 255;
-                    for (; d > 0; --d) {
-                        if (cum + hist[d] >= need) break;
-                        cum += hist[d];
-                    }
-                    sel_prefix = (int)(prefix | ((uint32_t)d << shift));
-                    sel_need = need - cum;
-                }
-                __syncthreads();
-                prefix = (uint32_t)sel_prefix;
-                need = sel_need;
-                __syncthreads();
-            }
-            // prefix is now the key of the k-th largest score; drop everything strictly below (HF TopK)
-            for (int v = tid; v < V; v += 256)
-                if (float_key(sc[v]) < prefix) sc[v] = -INFINITY;
-            __syncthreads();
-        }
-        // softmax numerators
-        float m = -INFINITY;
-        for (int v = tid; v < V; v += 256) m = fmaxf(m, sc[v]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        if (lane == 0) fred[wave] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
-        __syncthreads();
-        const int chunk = (V + 255) / 256;
-        const int v0 = tid * chunk, v1 = min(V, v0 + chunk);
-        float mine = 0.f;
-        for (int v = v0; v < v1; ++v) {
-            const float e = expf(sc[v] - m);
-            sc[v] = e;
-            mine += e;
-        }
-        scan[tid] = mine;
-        if (tid == 0) { pick_lo = 0x7fffffff; pick_hi = -1; }
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan in index order
-            const float add = tid >= o ? scan[tid - o] : 0.f;
-            __syncthreads();
-            scan[tid] += add;
-            __syncthreads();
-        }
-        const float total = scan[255];
-        uint32_t r[4];
         const uint32_t step = p.step_dev ? (uint32_t)*p.step_dev : 0u;
-        philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
-        const float u = (float)(r[0] >> 8) * (1.0f / 16777216.0f);
-        const float target = u * total;
-        float run = scan[tid] - mine;
-        for (int v = v0; v < v1; ++v) {
-            const float e = sc[v];
-            if (e > 0.f) {
-                atomicMax(&pick_hi, v);
-                if (run + e > target) { atomicMin(&pick_lo, v); break; }
+        uint32_t rnd[4];
+        philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+        const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+        bool sampled = false;
+        if (p.top_k > 0 && p.top_k < V) {
+            // ---- k-th largest key by a bitwise binary search (atomics-free: ballot + popcount counts) ----
+            // invariant: count(key >= prefix) >= k; set bits from the MSB down while that still holds.
+            uint32_t prefix = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = prefix | (1u << bit);
+                int cnt = 0;
+                for (int v = tid; v < V; v += 256) cnt += __popcll(__ballot(float_key(sc[v]) >= cand));
+                // every lane of a wave holds the same cnt (sum of wave-wide ballots over its strided slice)
+                if (lane == 0) ired[(bit & 1) * 4 + wave] = cnt;
+                __syncthreads();
+                const int* r4 = ired + (bit & 1) * 4;
+                if (r4[0] + r4[1] + r4[2] + r4[3] >= p.top_k) prefix = cand;
             }
-            run += e;
+            // prefix == key of the k-th largest score; HF TopK keeps every score >= it (ties included)
+            int mycnt = 0;
+            for (int v = tid; v < V; v += 256) mycnt += __popcll(__ballot(float_key(sc[v]) >= prefix));
+            __syncthreads();
+            if (lane == 0) ired[wave] = mycnt;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += ired[w];
+            const int n_keep = ired[0] + ired[1] + ired[2] + ired[3];
+            if (n_keep <= TOPK_COMPACT_MAX) {
+                // ---- compact the survivors (deterministic order: wave, slice, lane), one wave samples ----
+                for (int v = tid; v < V; v += 256) {
+                    const bool keep = float_key(sc[v]) >= prefix;
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) {
+                        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                        cval[slot] = sc[v];
+                        cidx[slot] = v;
+                    }
+                    base += __popcll(m);
+                }
+                __syncthreads();
+                if (wave == 0) {       // softmax over <= 256 survivors + inverse-CDF draw
+                    float mx = -INFINITY;
+                    for (int i = lane; i < n_keep; i += 64) mx = fmaxf(mx, cval[i]);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                    float tot = 0.f;
+                    for (int i = lane; i < n_keep; i += 64) { const float e = expf(cval[i] - mx); cval[i] = e; tot += e; }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                    const float target = u * tot;
+                    float run = 0.f;
+                    int pick = -1;
+                    for (int i0 = 0; i0 < n_keep && pick < 0; i0 += 64) {
+                        const int i = i0 + lane;
+                        const float e = i < n_keep ? cval[i] : 0.f;
+                        float inc = e;                                  // inclusive wave scan
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+                        const unsigned long long hit = __ballot(i < n_keep && run + inc > target);
+                        if (hit) pick = i0 + __ffsll((long long)hit) - 1;
+                        run += __shfl(inc, 63);
+                    }
+                    if (pick < 0) pick = n_keep - 1;                    // rounding at the very top of the CDF
+                    if (lane == 0) pick_lo = cidx[pick];
+                }
+                __syncthreads();
+                token = pick_lo;
+                sampled = true;
+            } else {
+                // more survivors than the compact buffer holds (k > 256 or massive ties): mask, general path
+                for (int v = tid; v < V; v += 256)
+                    if (float_key(sc[v]) < prefix) sc[v] = -INFINITY;
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        token = pick_lo != 0x7fffffff ? pick_lo : pick_hi;
+        if (!sampled) {
+            // ---- general path: softmax numerators over the whole vocabulary, block scan, inverse CDF ----
+            float m = -INFINITY;
+            for (int v = tid; v < V; v += 256) m = fmaxf(m, sc[v]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if (lane == 0) fred[wave] = m;
+            __syncthreads();
+            m = fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+            __syncthreads();
+            const int chunk = (V + 255) / 256;
+            const int v0 = tid * chunk, v1 = min(V, v0 + chunk);
+            float mine = 0.f;
+            for (int v = v0; v < v1; ++v) {
+                const float e = expf(sc[v] - m);
+                sc[v] = e;
+                mine += e;
+            }
+            scan[tid] = mine;
+            if (tid == 0) { pick_lo = 0x7fffffff; pick_hi = -1; }
+            __syncthreads();
+            for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan in index order
+                const float add = tid >= o ? scan[tid - o] : 0.f;
+                __syncthreads();
+                scan[tid] += add;
+                __syncthreads();
+            }
+            const float total = scan[255];
+            const float target = u * total;
+            float run = scan[tid] - mine;
+            for (int v = v0; v < v1; ++v) {
+                const float e = sc[v];
+                if (e > 0.f) {
+                    atomicMax(&pick_hi, v);
+                    if (run + e > target) { atomicMin(&pick_lo, v); break; }
+                }
+                run += e;
+            }
+            __syncthreads();
+            token = pick_lo != 0x7fffffff ? pick_lo : pick_hi;
+        }
     }
 
+    if (token < 0 || token >= V) token = 0;   // all-NaN logits must not turn into an out-of-range gather index
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];
@@ -215,15 +259,12 @@ __device__ inline float block_sum256(float v, float* sm) {
     __syncthreads();
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
-__device__ inline unsigned long long ss_fixed(float s) { return (unsigned long long)((double)s * SS_SCALE + 0.5); }
 
 // code-predictor input rows (M:1671-1672, 1281).  pass 0: rows [0,B) = past_hidden, rows [B,2B) =
 // talker codec_embedding[cur_tok]; pass j>0: rows [0,B) = cp codec_embedding[j-1][sub[b][j-1]].
 __global__ __launch_bounds__(256) void cp_gather_kernel(CpGatherParams p) {
     if (p.done && *p.done) return;
-    __shared__ float sm[4];
     const int r = blockIdx.x;
-    if (p.ss_zero && r == 0 && threadIdx.x < 64) p.ss_zero[threadIdx.x] = 0ull;
     const float* src;
     if (p.pass == 0) {
         const int t = r / p.B, b = r % p.B;
@@ -231,14 +272,8 @@ __global__ __launch_bounds__(256) void cp_gather_kernel(CpGatherParams p) {
     } else {
         src = p.cp_emb + ((size_t)(p.pass - 1) * p.cp_vocab + p.sub[(size_t)r * p.sub_stride + p.pass - 1]) * p.H;
     }
-    float s = 0.f;
-    for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(src + c);
-        *reinterpret_cast<float4*>(p.out + (size_t)r * p.H + c) = v;
-        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    s = block_sum256(s, sm);
-    if (threadIdx.x == 0 && p.ss) p.ss[r] = ss_fixed(s);
+    for (int c = threadIdx.x * 4; c < p.H; c += 1024)
+        *reinterpret_cast<float4*>(p.out + (size_t)r * p.H + c) = *reinterpret_cast<const float4*>(src + c);
 }
 void launch_cp_gather(const CpGatherParams& p, hipStream_t st) {
     hipLaunchKernelGGL(cp_gather_kernel, dim3(p.pass == 0 ? 2 * p.B : p.B), dim3(256), 0, st, p);
@@ -249,11 +284,9 @@ void launch_cp_gather(const CpGatherParams& p, hipStream_t st) {
 // the frame's outputs: codes[b][f][:] (int64) and hidden[b][f] = past_hidden.
 __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedSumParams p) {
     if (*p.st.done) return;
-    __shared__ float sm[4];
     const int b = blockIdx.x;
     const int f = *p.st.gen_step;          // frame index == generation_step
     const int tok0 = p.cur_tok[b];
-    float s = 0.f;
     for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
         float4 a = *reinterpret_cast<const float4*>(p.talker_emb + (size_t)tok0 * p.H + c);
         for (int i = 0; i < p.G - 1; ++i) {
@@ -265,14 +298,11 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedSumParams p) {
         const float4 t = *reinterpret_cast<const float4*>(tp + c);
         a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         *reinterpret_cast<float4*>(p.x_out + (size_t)b * p.H + c) = a;
-        s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
         if (p.hidden_out) {
             const float4 h = *reinterpret_cast<const float4*>(p.past_hidden + (size_t)b * p.H + c);
             *reinterpret_cast<float4*>(p.hidden_out + ((size_t)b * p.max_frames + f) * p.H + c) = h;
         }
     }
-    s = block_sum256(s, sm);
-    if (threadIdx.x == 0) p.ss[b] = ss_fixed(s);
     if (threadIdx.x < p.G && f < p.max_frames) {
         const int64_t v = threadIdx.x == 0 ? tok0 : p.sub[(size_t)b * p.sub_stride + threadIdx.x - 1];
         p.codes_out[((size_t)b * p.max_frames + f) * p.G + threadIdx.x] = v;
@@ -283,29 +313,10 @@ void launch_embed_sum(const EmbedSumParams& p, hipStream_t st) {
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
-// y = g * (x * rstd) with rstd from the fixed-point sum of squares (final talker norm -> past_hidden)
-__global__ __launch_bounds__(256) void apply_norm_kernel(const float* x, int ldx, const unsigned long long* ss,
-                                                         const float* g, float eps, float* y, int ldy, int C,
-                                                         const int* done) {
+// y = g * (x * rsqrt(mean(x^2) + eps)) (Qwen3TTSRMSNorm M:605-610) for the final talker norm -> past_hidden
+__global__ __launch_bounds__(256) void apply_norm_kernel(const float* x, int ldx, const float* g, float eps, float* y,
+                                                         int ldy, int C, const int* done) {
     if (done && *done) return;
-    const int r = blockIdx.x;
-    const float rstd = rsqrtf((float)((double)ss[r] * (1.0 / SS_SCALE)) / (float)C + eps);
-    for (int c = threadIdx.x * 4; c < C; c += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
-        const float4 w = *reinterpret_cast<const float4*>(g + c);
-        float4 o;
-        o.x = w.x * (v.x * rstd); o.y = w.y * (v.y * rstd); o.z = w.z * (v.z * rstd); o.w = w.w * (v.w * rstd);
-        *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = o;
-    }
-}
-void launch_apply_norm(const float* x, int ldx, const unsigned long long* ss, const float* g, float eps, float* y,
-                       int ldy, int rows, int C, const int* done, hipStream_t st) {
-    hipLaunchKernelGGL(apply_norm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, ss, g, eps, y, ldy, C, done);
-    QTTS_CHECK_HIP(hipGetLastError());
-}
-
-// per-row fixed-point sum of squares of an arbitrary [rows][C] buffer
-__global__ __launch_bounds__(256) void row_ss_kernel(const float* x, int ldx, int C, unsigned long long* ss) {
     __shared__ float sm[4];
     const int r = blockIdx.x;
     float s = 0.f;
@@ -314,10 +325,35 @@ __global__ __launch_bounds__(256) void row_ss_kernel(const float* x, int ldx, in
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     s = block_sum256(s, sm);
-    if (threadIdx.x == 0) ss[r] = ss_fixed(s);
+    const float rstd = rsqrtf(s / (float)C + eps);
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        const float4 w = *reinterpret_cast<const float4*>(g + c);
+        float4 o;
+        o.x = w.x * (v.x * rstd); o.y = w.y * (v.y * rstd); o.z = w.z * (v.z * rstd); o.w = w.w * (v.w * rstd);
+        *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = o;
+    }
 }
-void launch_row_ss(const float* x, int ldx, int rows, int C, unsigned long long* ss, hipStream_t st) {
-    hipLaunchKernelGGL(row_ss_kernel, dim3(rows), dim3(256), 0, st, x, ldx, C, ss);
+void launch_apply_norm(const float* x, int ldx, const float* g, float eps, float* y, int ldy, int rows, int C,
+                       const int* done, hipStream_t st) {
+    hipLaunchKernelGGL(apply_norm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, g, eps, y, ldy, C, done);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void row_ss_kernel(const float* x, int ldx, int C, float* ss, const int* done) {
+    if (done && *done) return;
+    __shared__ float sm[4];
+    const int r = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = block_sum256(s, sm);
+    if (threadIdx.x == 0) ss[r] = s;
+}
+void launch_row_ss(const float* x, int ldx, int rows, int C, float* ss, const int* done, hipStream_t st) {
+    hipLaunchKernelGGL(row_ss_kernel, dim3(rows), dim3(256), 0, st, x, ldx, C, ss, done);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 

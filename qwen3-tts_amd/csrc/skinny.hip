@@ -1,48 +1,56 @@
 // skinny.hip -- weight-streaming "skinny" GEMM for the autoregressive decode step (gfx950).
 //
-//   out[M][N] = epi( rstd[m] * sum_k (x[m][k] * g[k]) * W[n][k] )          M = batch rows (<= 64)
+//   out[M][N] = epi( rstd[m] * sum_k x[m][k] * W'[n][k] )      M = batch rows (<= 64),  W' = W . diag(g)
 //
-// Decode is HBM-bound (8 flop/B at batch 8): the kernel's only job is to pull every
-// weight byte across HBM exactly once at full rate.  Design:
+// Decode is HBM-bound (8 flop/B at batch 8): the kernel's job is to pull every weight byte
+// across HBM exactly once, with as little fixed latency around that stream as possible (a frame step is a
+// chain of ~450 of these launches, so every serialized memory round trip inside the kernel is paid 450x).
 //   * weights are re-packed at bind time into 1-KiB tiles that ARE the MFMA A-operand image
-//     ([N/16 strips][K/KT k-tiles][64 lanes][16 B]); a wave's `global_load_dwordx4` therefore reads
-//     1 KiB fully contiguous and the stream of a strip is one linear run -> perfectly coalesced,
-//     no LDS round trip for the streamed operand (each byte is used once).
+//     ([N/16 strips][K/KT k-tiles][64 lanes][16 B]); a wave's `global_load_dwordx4` reads 1 KiB fully
+//     contiguous, non-temporal, straight to VGPRs (each byte is used once: no LDS round trip).
+//     The RMSNorm weight g is folded into W at bind (W' = W.diag(g)); rstd[m] factors out of the dot product.
 //   * MFMA roles are swapped w.r.t. the textbook: A = 16 output features x k, B = k x 16 batch rows
 //     (batch padded to 16), so D holds 4 consecutive features per lane -> float4 epilogue stores.
-//     bf16: v_mfma_f32_16x16x32_bf16 (x converted fp32->bf16 in registers);
-//     f32 : v_mfma_f32_16x16x4_f32   (exact fp32 fma chain, parity mode).
-//   * a workgroup = 8 (or 4) waves that split K of one strip (or a gate/up strip PAIR for SwiGLU) and
-//     combine through LDS in a fixed order (deterministic, no atomics on the data path).
-//   * the producing RMSNorm is folded in: rstd[m] factors out of the dot product, so the kernel takes
-//     the per-row sum of squares (fixed-point integer accumulator -> order-independent, deterministic)
-//     from the previous kernel's epilogue and applies g[k] to x on the fly; its own epilogue can emit
-//     the sum of squares of what it writes (residual stream) for the next norm.
+//     bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, parity mode).
+//   * a workgroup = 8 (or 4) waves; k-tiles are dealt round-robin to the waves; every wave keeps two chunks
+//     (16 KiB) of weight loads in flight; partial sums are combined through LDS in a fixed order
+//     (deterministic, no atomics anywhere).
+//   * bf16 mode, M <= 16: x (M x K fp32, produced by the previous kernel) is staged ONCE per workgroup through
+//     LDS with fully coalesced 16-B loads and converted by v_cvt_pk_bf16_f32; because every workgroup then sees
+//     the complete rows it computes rstd = rsqrt(mean(x^2)+eps) itself (fp32, fixed reduction order) -- no
+//     cross-kernel reduction at all.  Other modes load x fragments directly and take row sums from `ss_in`.
+//   * everything the epilogue needs (residual, bias) is loaded at kernel entry, under the weight stream.
 #include "common.h"
 #include "kernels.h"
 
 namespace qtts {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
 
-template <bool BF16, int MT, int SPW, int NW>
+__device__ inline unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE)
+    hwbf16x2 v = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<unsigned*>(&v);
+}
+
+template <bool BF16, int MT, int SPW, int NW, bool STAGE>
 __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
-    if (!(p.ablate & 1) && p.done_flag && *p.done_flag) return;
     constexpr int KT = BF16 ? 32 : 16;     // k per tile
     constexpr int XV = BF16 ? 8 : 4;       // x values per lane per tile
-    constexpr int U = 16 / SPW;            // k-tiles per chunk: 16 x 1-KiB weight loads in flight per wave
-    __shared__ __attribute__((aligned(16))) f32x4 red[NW * SPW * MT * 64];
+    constexpr int U = 8 / SPW;             // k-tiles per chunk; two chunks (16 x 1 KiB) in flight per wave
+    constexpr int NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem_sk);                                    // [NW*SPW*MT*64]
+    float* rsum = reinterpret_cast<float*>(smem_sk + (size_t)NW * SPW * MT * 64 * 16); // [16][NW] partial sum(x^2)
+    unsigned short* xs = reinterpret_cast<unsigned short*>(rsum + 16 * NW);            // STAGE: [M][K+8] bf16
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lj = lane & 15, lq = lane >> 4;
     const int nkt = p.K / KT;
-    // k-tiles are dealt round-robin to the NW waves (tile = wave + NW*i): the workgroup's concurrent loads
-    // cover one contiguous NW-KiB run of the strip's stream.
-    const int my_tiles = (nkt - wave + NW - 1) / NW;
+    const int my_tiles = (nkt - wave + NW - 1) / NW;       // tile = wave + NW*i
     const int nchunks = (my_tiles + U - 1) / U;
     const int strip0 = blockIdx.x * SPW;
-
-    if (p.ss_zero && blockIdx.x == 0 && tid < 64) p.ss_zero[tid] = 0ull;
+    const int XS = p.K + 8;                                // LDS row stride (elements): rows shift by 4 banks
 
     f32x4 acc[SPW][MT];
 #pragma unroll
@@ -62,48 +70,118 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
             const int kt = wave + NW * i;
 #pragma unroll
             for (int s = 0; s < SPW; ++s)
-                w[s][u] = (i < my_tiles && !(p.ablate & 8)) ? __builtin_nontemporal_load(wbase[s] + (size_t)kt * 64) : (u32x4){0u, 0u, 0u, 0u};
+                w[s][u] = (i < my_tiles && !(p.ablate & 8)) ? __builtin_nontemporal_load(wbase[s] + (size_t)kt * 64)
+                                                            : (u32x4){0u, 0u, 0u, 0u};
         }
     };
+
+    // ---- 1. the weight stream starts first: two chunks per wave in flight
+    u32x4 wA[SPW][U], wB[SPW][U];
+    load_chunk(wA, 0);
+    load_chunk(wB, 1);
+
+    // ---- 2. epilogue operands of wave 0 are fetched now, under the weight stream
+    f32x4 resv[SPW][MT], biasv[SPW];
+    const bool epi_loads = wave == 0 && !(p.ablate & 4);
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * 16) + lq * 4;
+        biasv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (epi_loads && p.bias) biasv[s] = *reinterpret_cast<const f32x4*>(p.bias + (strip0 + s) * 16 + lq * 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            resv[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = m * 16 + lj;
+            if (epi_loads && p.res && row < p.M && (p.act != ACT_SWIGLU || s == 0))
+                resv[s][m] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+        }
+    }
+    const int done = (p.done_flag && !(p.ablate & 1)) ? *p.done_flag : 0;
+
+    // ---- 3. x: coalesced global -> bf16 -> LDS, with the per-row sum of squares on the way
+    float rstd_l[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rstd_l[m] = 1.f;
+    if constexpr (STAGE) {
+        const int k4 = p.K >> 2;                            // float4 per row; k4 % 64 == 0 (launcher checks)
+        const int total = p.M * k4;
+        if (lane < 16) rsum[lane * NW + wave] = 0.f;        // this wave's private slots
+        for (int i0 = 0; i0 < total; i0 += NT * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * NT + tid;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < total && !(p.ablate & 2)) {
+                    const int row = idx / k4, c = idx - row * k4;
+                    v[u] = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + c * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * NT + tid;
+                const int row = idx / k4, c = idx - row * k4;   // wave-uniform row (64 consecutive idx, k4 % 64 == 0)
+                if (idx < total) {
+                    uint2 h;
+                    h.x = pack_bf16(v[u].x, v[u].y);
+                    h.y = pack_bf16(v[u].z, v[u].w);
+                    *reinterpret_cast<uint2*>(&xs[row * XS + c * 4]) = h;
+                }
+                if (p.norm) {
+                    float q = v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                    if (lane == 0 && idx < total) rsum[row * NW + wave] += q;
+                }
+            }
+        }
+    }
+    if (done) return;
+    if constexpr (STAGE) {
+        __syncthreads();
+        if (p.norm) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int row = m * 16 + lj;
+                if (row < p.M) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; ++w2) s += rsum[row * NW + w2];     // fixed order
+                    rstd_l[m] = rsqrtf(s / (float)p.K + p.eps);
+                }
+            }
+        }
+    } else if (p.norm) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = m * 16 + lj;
+            if (row < p.M) rstd_l[m] = rsqrtf(p.ss_in[row] / (float)p.K + p.eps);
+        }
+    }
+
     auto compute_chunk = [&](u32x4 (&w)[SPW][U], int c) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = c * U + u;
             if (i >= my_tiles) break;
             const int k = (wave + NW * i) * KT + lq * XV;
-            float gv[XV];
-            if (p.g && !(p.ablate & 2)) {
-#pragma unroll
-                for (int e = 0; e < XV; e += 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(p.g + k + e);
-                    gv[e] = t.x; gv[e + 1] = t.y; gv[e + 2] = t.z; gv[e + 3] = t.w;
-                }
-            }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int row = m * 16 + lj;
-                float xv[XV];
-                if (row < p.M && (p.ablate & 2)) {
-#pragma unroll
-                    for (int e = 0; e < XV; ++e) xv[e] = 1.0f + (float)(lane + e);
-                } else if (row < p.M) {
-#pragma unroll
-                    for (int e = 0; e < XV; e += 4) {
-                        const float4 t = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + k + e);
-                        xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
-                    }
-                    if (p.g && !(p.ablate & 2)) {
-#pragma unroll
-                        for (int e = 0; e < XV; ++e) xv[e] *= gv[e];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < XV; ++e) xv[e] = 0.f;
-                }
                 if constexpr (BF16) {
+                    u32x4 t = (u32x4){0u, 0u, 0u, 0u};
+                    if constexpr (STAGE) {
+                        if (row < p.M) t = *reinterpret_cast<const u32x4*>(&xs[row * XS + k]);
+                    } else {
+                        if (row < p.M && !(p.ablate & 2)) {
+                            const float4 a = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + k);
+                            const float4 b = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + k + 4);
+                            t[0] = pack_bf16(a.x, a.y); t[1] = pack_bf16(a.z, a.w);
+                            t[2] = pack_bf16(b.x, b.y); t[3] = pack_bf16(b.z, b.w);
+                        }
+                    }
                     bf16x8 xb;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xb[e] = (short)f32_to_bf16(xv[e]);
+                    *reinterpret_cast<u32x4*>(&xb) = t;
 #pragma unroll
                     for (int s = 0; s < SPW; ++s) {
                         bf16x8 wa;
@@ -111,30 +189,31 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
                         acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[s][m], 0, 0, 0);
                     }
                 } else {
+                    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < p.M && !(p.ablate & 2)) xv = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + k);
 #pragma unroll
                     for (int s = 0; s < SPW; ++s) {
                         f32x4 wa;
                         *reinterpret_cast<u32x4*>(&wa) = w[s][u];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xv[e], acc[s][m], 0, 0, 0);
+                        acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0], xv.x, acc[s][m], 0, 0, 0);
+                        acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1], xv.y, acc[s][m], 0, 0, 0);
+                        acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2], xv.z, acc[s][m], 0, 0, 0);
+                        acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[3], xv.w, acc[s][m], 0, 0, 0);
                     }
                 }
             }
         }
     };
 
-    // ping-pong: the next chunk's 16 KiB of weight loads are in flight while the current chunk is consumed
-    u32x4 wA[SPW][U], wB[SPW][U];
-    load_chunk(wA, 0);
+    // ---- 4. consume: ping-pong, the chunk after next is requested as soon as a buffer frees up
     for (int c = 0; c < nchunks; c += 2) {
-        if (c + 1 < nchunks) load_chunk(wB, c + 1);
         compute_chunk(wA, c);
         if (c + 2 < nchunks) load_chunk(wA, c + 2);
         if (c + 1 < nchunks) compute_chunk(wB, c + 1);
+        if (c + 3 < nchunks) load_chunk(wB, c + 3);
     }
 
-    // ---- cross-wave combine (fixed order) ----
+    // ---- 5. cross-wave combine (fixed order) and epilogue by wave 0
 #pragma unroll
     for (int s = 0; s < SPW; ++s)
 #pragma unroll
@@ -142,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     __syncthreads();
     if (wave != 0) return;
 
-    // acc[s][m][r] = partial of out[row = m*16 + lj][feature = (strip0+s)*16 + lq*4 + r]
+    // v[s][r] = out[row = m*16 + lj][feature = (strip0+s)*16 + lq*4 + r]
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = m * 16 + lj;
@@ -152,62 +231,58 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
             f32x4 t = red[((0 * SPW + s) * MT + m) * 64 + lane];
 #pragma unroll
             for (int w2 = 1; w2 < NW; ++w2) t += red[((w2 * SPW + s) * MT + m) * 64 + lane];
-            v[s] = t;
+            v[s] = t * rstd_l[m] + biasv[s];
         }
-        float rstd = 1.f;
-        if (p.ss_in && row < p.M && !(p.ablate & 4)) {
-            const float ssum = (float)((double)p.ss_in[row] * (1.0 / SS_SCALE));
-            rstd = rsqrtf(ssum / (float)p.K + p.eps);
-        }
-        float sq = 0.f;
+        if (row >= p.M) continue;
         if (p.act == ACT_SWIGLU) {
             if constexpr (SPW == 2) {
                 const int col = blockIdx.x * 16 + lq * 4;
                 f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gte = v[0][r] * rstd + (p.bias ? p.bias[(strip0)*16 + lq * 4 + r] : 0.f);
-                    const float up = v[1][r] * rstd + (p.bias ? p.bias[(strip0 + 1) * 16 + lq * 4 + r] : 0.f);
-                    o[r] = (gte / (1.f + expf(-gte))) * up;
-                }
-                if (row < p.M) {
-                    if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
-                    sq = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
-                }
+                for (int r = 0; r < 4; ++r) o[r] = (v[0][r] / (1.f + expf(-v[0][r]))) * v[1][r];
+                o += resv[0][m];
+                *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
             }
         } else {
 #pragma unroll
             for (int s = 0; s < SPW; ++s) {
                 const int col = (strip0 + s) * 16 + lq * 4;
-                f32x4 o = v[s] * rstd;
-                if (p.bias && !(p.ablate & 4)) o += *reinterpret_cast<const f32x4*>(p.bias + col);
-                if (row < p.M) {
-                    if (p.res && !(p.ablate & 4)) o += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
-                    *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
-                    sq += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
-                }
+                *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = v[s] + resv[s][m];
             }
-        }
-        if (p.ss_out) {
-            sq += __shfl_xor(sq, 16);
-            sq += __shfl_xor(sq, 32);
-            if (lq == 0 && row < p.M)
-                atomicAdd(p.ss_out + row, (unsigned long long)((double)sq * SS_SCALE + 0.5));
         }
     }
 }
 
-template <bool BF16, int MT>
-static void launch_mt(const SkinnyParams& p, int spw, int nw, hipStream_t st) {
-    const int strips = p.N / 16;
-    if (nw == 8) {
-        if (spw == 2) hipLaunchKernelGGL((skinny_kernel<BF16, MT, 2, 8>), dim3(strips / 2), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((skinny_kernel<BF16, MT, 1, 8>), dim3(strips), dim3(512), 0, st, p);
-    } else {
-        if (spw == 2) hipLaunchKernelGGL((skinny_kernel<BF16, MT, 2, 4>), dim3(strips / 2), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((skinny_kernel<BF16, MT, 1, 4>), dim3(strips), dim3(256), 0, st, p);
+bool skinny_can_stage(int M, int K, bool bf16) {
+    return bf16 && M <= 16 && K % 256 == 0 && (size_t)M * (K + 8) * 2 <= 112 * 1024;
+}
+
+template <bool BF16, int MT, int SPW, int NW, bool STAGE>
+static void launch_one(const SkinnyParams& p, int grid, hipStream_t st) {
+    size_t lds = (size_t)NW * SPW * MT * 64 * 16 + (size_t)16 * NW * sizeof(float);
+    if (STAGE) lds += (size_t)p.M * (p.K + 8) * 2;
+    auto kern = skinny_kernel<BF16, MT, SPW, NW, STAGE>;
+    static bool attr_set = false;          // one flag per instantiation
+    if (lds > 48 * 1024 && !attr_set) {
+        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        attr_set = true;
     }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
+}
+
+template <bool BF16, int MT>
+static void launch_mt(const SkinnyParams& p, int spw, int nw, bool stage, hipStream_t st) {
+    const int strips = p.N / 16;
+    if constexpr (BF16 && MT == 1) {
+        if (stage) {
+            if (nw == 8) { if (spw == 2) launch_one<true, 1, 2, 8, true>(p, strips / 2, st); else launch_one<true, 1, 1, 8, true>(p, strips, st); }
+            else         { if (spw == 2) launch_one<true, 1, 2, 4, true>(p, strips / 2, st); else launch_one<true, 1, 1, 4, true>(p, strips, st); }
+            return;
+        }
+    }
+    if (nw == 8) { if (spw == 2) launch_one<BF16, MT, 2, 8, false>(p, strips / 2, st); else launch_one<BF16, MT, 1, 8, false>(p, strips, st); }
+    else         { if (spw == 2) launch_one<BF16, MT, 2, 4, false>(p, strips / 2, st); else launch_one<BF16, MT, 1, 4, false>(p, strips, st); }
 }
 
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
@@ -216,6 +291,8 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(p.K % KT == 0, QTTS_ERR_ARG, "skinny: K must be a multiple of the k-tile");
     QTTS_REQUIRE(p.M >= 1 && p.M <= 64, QTTS_ERR_LIMIT, "skinny: 1 <= M <= 64");
     QTTS_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, QTTS_ERR_ARG, "skinny: ldx/ldo % 4");
+    const bool stage = skinny_can_stage(p.M, p.K, bf16);
+    QTTS_REQUIRE(!p.norm || stage || p.ss_in, QTTS_ERR_ARG, "skinny: norm without LDS staging needs ss_in (row sums of squares)");
     int spw = 1;
     if (p.act == ACT_SWIGLU) {
         QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "skinny: swiglu N % 32");
@@ -224,20 +301,21 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16) {
-        if (mt == 1) launch_mt<true, 1>(p, spw, nw, st);
-        else if (mt == 2) launch_mt<true, 2>(p, spw, nw, st);
-        else launch_mt<true, 4>(p, spw, nw, st);
+        if (mt == 1) launch_mt<true, 1>(p, spw, nw, stage, st);
+        else if (mt == 2) launch_mt<true, 2>(p, spw, nw, false, st);
+        else launch_mt<true, 4>(p, spw, nw, false, st);
     } else {
-        if (mt == 1) launch_mt<false, 1>(p, spw, nw, st);
-        else if (mt == 2) launch_mt<false, 2>(p, spw, nw, st);
-        else launch_mt<false, 4>(p, spw, nw, st);
+        if (mt == 1) launch_mt<false, 1>(p, spw, nw, false, st);
+        else if (mt == 2) launch_mt<false, 2>(p, spw, nw, false, st);
+        else launch_mt<false, 4>(p, spw, nw, false, st);
     }
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
 size_t skinny_packed_bytes(int N, int K, bool bf16) { return (size_t)N * K * (bf16 ? 2 : 4); }
 
-void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host) {
+// Pack W[N][K] (row-major f32), optionally scaled per column by g[K] (folded RMSNorm weight), into the tile layout.
+void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host, const float* g) {
     const int KT = bf16 ? 32 : 16;
     const int nkt = K / KT, strips = N / 16;
     parallel_for(strips, [&](int64_t s0, int64_t s1) {
@@ -246,13 +324,14 @@ void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host)
                 for (int l = 0; l < 64; ++l) {
                     const int i = l & 15, q = l >> 4;
                     const size_t tile = ((size_t)s * nkt + kt) * 64 + l;
-                    const float* src = W + (size_t)(s * 16 + i) * K + kt * KT + q * (bf16 ? 8 : 4);
+                    const int k0 = kt * KT + q * (bf16 ? 8 : 4);
+                    const float* src = W + (size_t)(s * 16 + i) * K + k0;
                     if (bf16) {
                         bf16_t* d = reinterpret_cast<bf16_t*>(out_host) + tile * 8;
-                        for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16(src[e]);
+                        for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16(g ? src[e] * g[k0 + e] : src[e]);
                     } else {
                         float* d = reinterpret_cast<float*>(out_host) + tile * 4;
-                        for (int e = 0; e < 4; ++e) d[e] = src[e];
+                        for (int e = 0; e < 4; ++e) d[e] = g ? src[e] * g[k0 + e] : src[e];
                     }
                 }
     });

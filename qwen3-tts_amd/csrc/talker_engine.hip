@@ -89,9 +89,9 @@ struct qtts_talker {
             d.upload(h.data(), h.size() * 2);
         } else d.upload(w.data(), w.size() * 4);
     }
-    void upload_packed(DevBuf& d, const std::vector<float>& w, int N, int K) {
+    void upload_packed(DevBuf& d, const std::vector<float>& w, int N, int K, const std::vector<float>* g = nullptr) {
         std::vector<char> h(skinny_packed_bytes(N, K, bf16));
-        pack_skinny_weight(w.data(), N, K, bf16, h.data());
+        pack_skinny_weight(w.data(), N, K, bf16, h.data(), g ? g->data() : nullptr);     // g: folded RMSNorm weight
         d.upload(h.data(), h.size());
     }
     static std::vector<float> cat3(const std::vector<float>& a, const std::vector<float>& b, const std::vector<float>& c) {
@@ -113,9 +113,9 @@ struct qtts_talker {
         auto guw = interleave_gu(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H);
         auto& ow = PS(p + "self_attn.o_proj.weight", {d.H, d.qd});
         auto& dw = PS(p + "mlp.down_proj.weight", {d.H, d.I});
-        upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H);
+        upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H, &PS(p + "input_layernorm.weight", {d.H}));
         upload_packed(L.o_p, ow, d.H, d.qd);
-        upload_packed(L.gu_p, guw, 2 * d.I, d.H);
+        upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         upload_packed(L.d_p, dw, d.H, d.I);
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
@@ -130,7 +130,7 @@ struct qtts_talker {
     }
     void finalize();
 
-    unsigned long long* ring(int i) { return ss_ring.as<unsigned long long>() + (size_t)(i % 3) * 64; }
+    float* ssbuf() { return ss_ring.as<float>(); }
 
     void skinny(const SkinnyParams& p, hipStream_t st) {
         if (timing_now) {
@@ -143,15 +143,24 @@ struct qtts_talker {
         } else launch_skinny(p, bf16, st);
     }
 
-    // one decoder layer on `M = n_new * B` rows of `xs` (in place), fixed-point sum-of-squares ring index r
+    // x-side handling of a GEMM whose input is RMS-normalised: staged kernels compute rstd themselves; the
+    // others (fp32 parity mode, M > 16) get the row sums of squares from one extra tiny kernel.
+    void norm_input(SkinnyParams& p, const StackDims& d, hipStream_t st) {
+        p.norm = 1; p.eps = d.eps;
+        if (!skinny_can_stage(p.M, p.K, bf16)) {
+            launch_row_ss(p.x, p.ldx, p.M, p.K, ssbuf(), ss.done, st);
+            p.ss_in = ssbuf();
+        }
+    }
+    // one decoder layer on `M = n_new * B` rows of `xs` (in place)
     void decode_layer(const LayerW& L, const StackDims& d, float* xs, float* qkvb, float* attb, float* actb, int M,
                       int n_new, KvCache& kv, int layer, const int* len_dev, int len_static, const int* npad,
-                      const float* inv_freq, int max_len, int& r, hipStream_t st) {
+                      const float* inv_freq, int max_len, hipStream_t st) {
         SkinnyParams p{};
         p.done_flag = ss.done;
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
-        p.g = L.g1.as<float>(); p.ss_in = ring(r); p.eps = d.eps; p.ss_zero = ring(r + 1);
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
+        norm_input(p, d, st);
         skinny(p, st);
         AttnDecodeParams a{};
         a.qkv = qkvb; a.ld = d.qd + 2 * d.kvd; a.B = B; a.n_new = n_new; a.nh = d.nh; a.nkv = d.nkv; a.hd = d.hd;
@@ -162,20 +171,18 @@ struct qtts_talker {
         SkinnyParams o{};
         o.done_flag = ss.done;
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
-        o.out = xs; o.ldo = d.H; o.ss_out = ring(r + 1); o.act = ACT_NONE;
+        o.out = xs; o.ldo = d.H; o.act = ACT_NONE;
         skinny(o, st);
-        r = (r + 1) % 3;
         SkinnyParams g{};
         g.done_flag = ss.done;
-        g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.g = L.g2.as<float>();
-        g.ss_in = ring(r); g.eps = d.eps; g.ss_zero = ring(r + 1); g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
+        g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
+        norm_input(g, d, st);
         skinny(g, st);
         SkinnyParams dn{};
         dn.done_flag = ss.done;
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
-        dn.out = xs; dn.ldo = d.H; dn.ss_out = ring(r + 1); dn.act = ACT_NONE;
+        dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE;
         skinny(dn, st);
-        r = (r + 1) % 3;
     }
 
     void prefill(const float* embeds, int B_, int T, const int32_t* n_pad_host, const float* trailing_dev, int Tt_,
@@ -220,7 +227,8 @@ void qtts_talker::finalize() {
     }
     lm_head_p.resize(G - 1);
     for (int g = 0; g < G - 1; ++g)
-        upload_packed(lm_head_p[g], PS("code_predictor.lm_head." + std::to_string(g) + ".weight", {c.cp_vocab_size, cd.H}), c.cp_vocab_size, cd.H);
+        upload_packed(lm_head_p[g], PS("code_predictor.lm_head." + std::to_string(g) + ".weight", {c.cp_vocab_size, cd.H}), c.cp_vocab_size, cd.H,
+                      &PS("code_predictor.model.norm.weight", {cd.H}));
     has_proj = cd.H != td.H;
     if (has_proj) {
         upload_packed(proj_p, PS("code_predictor.small_to_mtp_projection.weight", {cd.H, td.H}), cd.H, td.H);
@@ -251,13 +259,15 @@ void qtts_talker::finalize() {
     // ---- KV caches (pages of 16 tokens, reserved up front)
     const size_t esz = bf16 ? 2 : 4;
     const int pps = cdiv(c.max_seq, 16);
-    kv_t = {nullptr, nullptr, nullptr, pps, pps * c.max_batch, td.nkv, td.hd, bf16 ? 1 : 0};
+    kv_t = {nullptr, nullptr, nullptr, pps, pps * c.max_batch, td.nkv, td.hd, bf16 ? 1 : 0, 1};
     const size_t tb = (size_t)c.num_hidden_layers * kv_t.n_pages * td.nkv * 16 * td.hd * esz;
     kpool_t.alloc(tb); vpool_t.alloc(tb);
+    QTTS_CHECK_HIP(hipMemset(kpool_t.p, 0, tb)); QTTS_CHECK_HIP(hipMemset(vpool_t.p, 0, tb));
     const int cpps = cdiv(G + 1, 16);
-    kv_c = {nullptr, nullptr, nullptr, cpps, cpps * c.max_batch, cd.nkv, cd.hd, bf16 ? 1 : 0};
+    kv_c = {nullptr, nullptr, nullptr, cpps, cpps * c.max_batch, cd.nkv, cd.hd, bf16 ? 1 : 0, 1};
     const size_t cb = (size_t)c.cp_num_hidden_layers * kv_c.n_pages * cd.nkv * 16 * cd.hd * esz;
     kpool_c.alloc(cb); vpool_c.alloc(cb);
+    QTTS_CHECK_HIP(hipMemset(kpool_c.p, 0, cb)); QTTS_CHECK_HIP(hipMemset(vpool_c.p, 0, cb));
     {
         std::vector<int> t((size_t)c.max_batch * pps), u((size_t)c.max_batch * cpps);
         for (size_t i = 0; i < t.size(); ++i) t[i] = (int)i;
@@ -273,7 +283,7 @@ void qtts_talker::finalize() {
     act.alloc((size_t)R * td.I * 4); logits.alloc((size_t)R * c.vocab_size * 4); past_hidden.alloc((size_t)R * td.H * 4);
     cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
     cp_att.alloc((size_t)R * cd.qd * 4); cp_act.alloc((size_t)R * cd.I * 4); cp_logits.alloc((size_t)R * c.cp_vocab_size * 4);
-    cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_ring.alloc(3 * 64 * 8); ints.alloc(64 * 4 + R * 4);
+    cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_ring.alloc(64 * 8); ints.alloc(64 * 4 + R * 4);
     n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size);
     QTTS_CHECK_HIP(hipMemset(ss_ring.p, 0, ss_ring.bytes));
     int* ip = ints.as<int>();
@@ -363,7 +373,6 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
                              int max_frames, hipStream_t st) {
     const auto& c = cfg;
     const int G = c.num_code_groups;
-    int r = 0;
     // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
     for (int j = 0; j < G - 1; ++j) {
         const int n_new = j == 0 ? 2 : 1, M = n_new * B;
@@ -371,32 +380,28 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         gp.pass = j; gp.B = B; gp.H = td.H; gp.past_hidden = past_hidden.as<float>(); gp.talker_emb = emb_talker.as<float>();
         gp.cur_tok = cur_tok.as<int>(); gp.cp_emb = emb_cp.as<float>(); gp.cp_vocab = c.cp_vocab_size;
         gp.sub = sub.as<int>(); gp.sub_stride = G; gp.done = ss.done;
-        // invariant: ring(r) holds sum(x^2) of the current residual stream; a producer of a fresh x writes
-        // ring(r+1) (direct store, or accumulation into entries zeroed by the previous consumer / the gather)
         if (has_proj) {
-            gp.out = cp_in.as<float>(); gp.ss = nullptr; gp.ss_zero = ring(r + 1);
+            gp.out = cp_in.as<float>();
             launch_cp_gather(gp, st);
             SkinnyParams pj{};
             pj.done_flag = ss.done;
             pj.x = cp_in.as<float>(); pj.ldx = td.H; pj.M = M; pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
-            pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.ss_out = ring(r + 1); pj.act = ACT_NONE;
+            pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.act = ACT_NONE;
             skinny(pj, st);
         } else {
-            gp.out = cp_x.as<float>(); gp.ss = ring(r + 1); gp.ss_zero = nullptr;
+            gp.out = cp_x.as<float>();
             launch_cp_gather(gp, st);
         }
-        r = (r + 1) % 3;
         for (int l = 0; l < c.cp_num_hidden_layers; ++l)
             decode_layer(cl[l], cd, cp_x.as<float>(), cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
-                         kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, r, st);
+                         kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st);
         // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
         SkinnyParams lh{};
         lh.done_flag = ss.done;
         const int off = (n_new - 1) * B;
         lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
-        lh.K = cd.H; lh.g = c_norm.as<float>(); lh.ss_in = ring(r) + off; lh.eps = cd.eps; lh.out = cp_logits.as<float>();
-        lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE;
-        lh.ss_zero = ring(r + 1);
+        lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE;
+        norm_input(lh, cd, st);
         skinny(lh, st);
         SampleParams s{};
         s.logits = cp_logits.as<float>(); s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
@@ -410,15 +415,13 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     e.B = B; e.H = td.H; e.G = G; e.cp_vocab = c.cp_vocab_size; e.talker_emb = emb_talker.as<float>();
     e.cp_emb = emb_cp.as<float>(); e.cur_tok = cur_tok.as<int>(); e.sub = sub.as<int>(); e.sub_stride = G;
     e.trailing = trailing.as<float>(); e.Tt = Tt; e.tts_pad = tts_pad.as<float>(); e.past_hidden = past_hidden.as<float>();
-    e.x_out = x.as<float>(); e.ss = ring(r + 1); e.codes_out = codes; e.hidden_out = hidden; e.max_frames = max_frames; e.st = ss;
+    e.x_out = x.as<float>(); e.codes_out = codes; e.hidden_out = hidden; e.max_frames = max_frames; e.st = ss;
     launch_embed_sum(e, st);
-    r = (r + 1) % 3;
     // ---- talker decode forward (M:1706-1727)
     for (int l = 0; l < c.num_hidden_layers; ++l)
         decode_layer(tl[l], td, x.as<float>(), qkv.as<float>(), att.as<float>(), act.as<float>(), B, 1, kv_t, l, ss.kv_len, 0,
-                     n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, r, st);
-    launch_apply_norm(x.as<float>(), td.H, ring(r), t_norm.as<float>(), td.eps, past_hidden.as<float>(), td.H, B, td.H,
-                      ss.done, st);
+                     n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, st);
+    launch_apply_norm(x.as<float>(), td.H, t_norm.as<float>(), td.eps, past_hidden.as<float>(), td.H, B, td.H, ss.done, st);
     SkinnyParams h{};
     h.done_flag = ss.done;
     h.x = past_hidden.as<float>(); h.ldx = td.H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = td.H;
@@ -647,7 +650,7 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
                             int32_t ablate, int32_t iters, int32_t reps, double* us_per_launch) {
     QTTS_API_BEGIN
     QTTS_REQUIRE(us_per_launch && iters > 0 && reps > 0, QTTS_ERR_ARG, "bad argument");
-    DevBuf W, x, g, out, res, ssin, ssout, done;
+    DevBuf W, x, out, res, ssin, done;
     W.alloc(skinny_packed_bytes(N, K, true));
     {
         std::vector<uint16_t> h((size_t)N * K);
@@ -656,15 +659,15 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
         W.upload(h.data(), h.size() * 2);
     }
     const int No = act == ACT_SWIGLU ? N / 2 : N;
-    x.alloc((size_t)64 * K * 4); g.alloc((size_t)K * 4); out.alloc((size_t)64 * No * 4); res.alloc((size_t)64 * No * 4);
-    ssin.alloc(64 * 8); ssout.alloc(64 * 8); done.alloc(64);
-    QTTS_CHECK_HIP(hipMemset(x.p, 0x3c, x.bytes)); QTTS_CHECK_HIP(hipMemset(g.p, 0x3c, g.bytes));
-    QTTS_CHECK_HIP(hipMemset(res.p, 0, res.bytes)); QTTS_CHECK_HIP(hipMemset(ssin.p, 1, ssin.bytes));
-    QTTS_CHECK_HIP(hipMemset(ssout.p, 0, ssout.bytes)); QTTS_CHECK_HIP(hipMemset(done.p, 0, done.bytes));
+    x.alloc((size_t)64 * K * 4); out.alloc((size_t)64 * No * 4); res.alloc((size_t)64 * No * 4);
+    ssin.alloc(64 * 8); done.alloc(64);
+    QTTS_CHECK_HIP(hipMemset(x.p, 0x3c, x.bytes));
+    QTTS_CHECK_HIP(hipMemset(res.p, 0, res.bytes)); QTTS_CHECK_HIP(hipMemset(ssin.p, 0x3c, ssin.bytes));
+    QTTS_CHECK_HIP(hipMemset(done.p, 0, done.bytes));
     SkinnyParams p{};
     p.x = x.as<float>(); p.ldx = K; p.M = M; p.Wp = W.p; p.N = N; p.K = K; p.eps = 1e-6f; p.act = act;
-    if (with_norm) { p.g = g.as<float>(); p.ss_in = ssin.as<unsigned long long>(); p.ss_zero = ssout.as<unsigned long long>(); }
-    if (with_res) { p.res = res.as<float>(); p.ldr = No; p.ss_out = ssout.as<unsigned long long>(); }
+    if (with_norm) { p.norm = 1; p.ss_in = ssin.as<float>(); }
+    if (with_res) { p.res = res.as<float>(); p.ldr = No; }
     p.out = out.as<float>(); p.ldo = No; p.done_flag = done.as<int>(); p.ablate = ablate;
     hipStream_t st;
     QTTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

@@ -45,7 +45,7 @@ if "codec" in what:
 if "talker" in what:
     t = synth.talker_tiny(); w = synth.talker_weights(t); g = np.load(os.path.join(G, "talker_tiny.npz"))
     sup = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != t.codec_eos_token_id]
-    for dt, graph in ((torch.float32, False), (torch.float32, True), (torch.bfloat16, True)):
+    for dt, graph in ((torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, True)):
         eng = TalkerEngine(t, td(w), weight_dtype=dt, max_batch=4, max_seq=256, use_graph=graph)
         out = eng.generate(torch.from_numpy(g["embeds"]), torch.from_numpy(g["mask"]), torch.from_numpy(g["trailing"]),
                            torch.from_numpy(g["tts_pad"]), max_new_tokens=14, min_new_tokens=2, do_sample=False,
