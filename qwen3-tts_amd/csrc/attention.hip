@@ -425,7 +425,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         const float v = (red[(0 * NQ + qi) * HD + d] + red[(1 * NQ + qi) * HD + d]) +
                         (red[(2 * NQ + qi) * HD + d] + red[(3 * NQ + qi) * HD + d]);
         const int t = qi / GQ, gq = qi % GQ;
-        p.out[((size_t)t * p.B + b) * p.ldo + (kvh * GQ + gq) * HD + d] = v * stat[qi];
+        const size_t o = ((size_t)t * p.B + b) * p.ldo + (kvh * GQ + gq) * HD + d;
+        if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v * stat[qi]);
+        else p.out[o] = v * stat[qi];
     }
 }
 

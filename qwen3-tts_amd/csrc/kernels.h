@@ -29,6 +29,8 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
 // 1-KiB MFMA-operand tiles (see pack_skinny_weight).
 struct SkinnyParams {
     const float* x; int ldx; int M;
+    int x_bf16;                  // 1: x points to bf16 [M][ldx] (written by a bf16-output producer); no norm; staged by LDS-DMA
+    int out_bf16;                // 1: out is written as bf16 [M][ldo] (feeds an x_bf16 consumer)
     const void* Wp;              // packed tiles [N/16][K/KT][64 lanes][16 B] (RMSNorm weight already folded in)
     int N, K;
     int norm;                    // 1: out = rstd[m] * (x . W'^T) with rstd = rsqrt(mean_k x^2 + eps)
@@ -105,6 +107,7 @@ struct AttnDecodeParams {
     int len_static;              // used when len_dev == null (code predictor)
     KvCache kv; int layer;
     float* out; int ldo;         // rows t*B + b, columns nh*hd
+    int out_bf16;                // 1: write bf16 (consumed by an x_bf16 GEMM)
     int max_len;                 // LDS score capacity
     const int* done_flag;
 };

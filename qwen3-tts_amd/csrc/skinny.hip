@@ -103,6 +103,23 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) rstd_l[m] = 1.f;
     if constexpr (STAGE) {
+        if (p.x_bf16) {
+            // x is already bf16: LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPRs, all requests in
+            // flight at once).  The LDS image is lane-linear, so the row padding is applied on the SOURCE side:
+            // LDS byte o -> (row, col) = divmod(o, RS); lanes that land in the 16-B row pad fetch a dummy.
+            const int RS = XS * 2;
+            const int nbytes = p.M * RS;
+            const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x);
+            unsigned char* xs_b = reinterpret_cast<unsigned char*>(xs);
+            for (int c = wave; c * 1024 < nbytes; c += NW) {
+                const int o = c * 1024 + lane * 16;
+                const int row = o / RS, col = o - row * RS;
+                const bool ok = row < p.M && col < p.K * 2 && !(p.ablate & 2);
+                const unsigned char* src = ok ? xb + (size_t)row * p.ldx * 2 + col : xb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs_b + c * 1024), 16, 0, 0);
+            }
+        } else {
         const int k4 = p.K >> 2;                            // float4 per row; k4 % 64 == 0 (launcher checks)
         const int total = p.M * k4;
         if (lane < 16) rsum[lane * NW + wave] = 0.f;        // this wave's private slots
@@ -134,6 +151,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
                     if (lane == 0 && idx < total) rsum[row * NW + wave] += q;
                 }
             }
+        }
         }
     }
     if (done) return;
@@ -241,26 +259,33 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (v[0][r] / (1.f + expf(-v[0][r]))) * v[1][r];
                 o += resv[0][m];
-                *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
+                if (p.out_bf16) {
+                    uint2 h; h.x = pack_bf16(o[0], o[1]); h.y = pack_bf16(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)row * p.ldo + col) = h;
+                } else *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
             }
         } else {
 #pragma unroll
             for (int s = 0; s < SPW; ++s) {
                 const int col = (strip0 + s) * 16 + lq * 4;
-                *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = v[s] + resv[s][m];
+                const f32x4 o = v[s] + resv[s][m];
+                if (p.out_bf16) {
+                    uint2 h; h.x = pack_bf16(o[0], o[1]); h.y = pack_bf16(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)row * p.ldo + col) = h;
+                } else *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
             }
         }
     }
 }
 
 bool skinny_can_stage(int M, int K, bool bf16) {
-    return bf16 && M <= 16 && K % 256 == 0 && (size_t)M * (K + 8) * 2 <= 112 * 1024;
+    return bf16 && M <= 16 && K % 256 == 0 && (size_t)M * (K + 8) * 2 <= 111 * 1024;
 }
 
 template <bool BF16, int MT, int SPW, int NW, bool STAGE>
 static void launch_one(const SkinnyParams& p, int grid, hipStream_t st) {
     size_t lds = (size_t)NW * SPW * MT * 64 * 16 + (size_t)16 * NW * sizeof(float);
-    if (STAGE) lds += (size_t)p.M * (p.K + 8) * 2;
+    if (STAGE) lds += (((size_t)p.M * (p.K + 8) * 2 + 1023) / 1024) * 1024;
     auto kern = skinny_kernel<BF16, MT, SPW, NW, STAGE>;
     static bool attr_set = false;          // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
@@ -293,6 +318,8 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, QTTS_ERR_ARG, "skinny: ldx/ldo % 4");
     const bool stage = skinny_can_stage(p.M, p.K, bf16);
     QTTS_REQUIRE(!p.norm || stage || p.ss_in, QTTS_ERR_ARG, "skinny: norm without LDS staging needs ss_in (row sums of squares)");
+    QTTS_REQUIRE(!p.x_bf16 || (stage && !p.norm), QTTS_ERR_ARG, "skinny: bf16 x needs the staged kernel and no norm");
+    QTTS_REQUIRE(!p.out_bf16 || bf16, QTTS_ERR_ARG, "skinny: bf16 output only in bf16 mode");
     int spw = 1;
     if (p.act == ACT_SWIGLU) {
         QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "skinny: swiglu N % 32");

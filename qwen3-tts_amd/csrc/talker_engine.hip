@@ -167,19 +167,26 @@ struct qtts_talker {
         a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
         a.len_dev = len_dev; a.len_static = len_static; a.kv = kv; a.layer = layer; a.out = attb; a.ldo = d.qd;
         a.max_len = max_len; a.done_flag = ss.done;
+        // bf16 mode: attention output and SwiGLU output travel as bf16 (as in the reference's bf16 path) and are
+        // staged into the consuming GEMM by LDS-DMA
+        const bool att16 = bf16 && skinny_can_stage(M, d.qd, true), act16 = bf16 && skinny_can_stage(M, d.I, true);
+        a.out_bf16 = att16;
         launch_attn_decode(a, st);
         SkinnyParams o{};
         o.done_flag = ss.done;
+        o.x_bf16 = att16;
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
         o.out = xs; o.ldo = d.H; o.act = ACT_NONE;
         skinny(o, st);
         SkinnyParams g{};
         g.done_flag = ss.done;
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
+        g.out_bf16 = act16;
         norm_input(g, d, st);
         skinny(g, st);
         SkinnyParams dn{};
         dn.done_flag = ss.done;
+        dn.x_bf16 = act16;
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
         dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE;
         skinny(dn, st);
