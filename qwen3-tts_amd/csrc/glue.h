@@ -24,6 +24,7 @@ struct CpGatherParams {
     int cp_vocab;
     const int* sub; int sub_stride;   // [B][G-1] sub-codes sampled so far
     float* out;                 // [rows][H]
+    unsigned short* out16;      // optional bf16 copy [rows][H]
     const int* done;
 };
 void launch_cp_gather(const CpGatherParams& p, hipStream_t st);
@@ -34,7 +35,7 @@ struct EmbedSumParams {
     const int* cur_tok; const int* sub; int sub_stride;
     const float* trailing; int Tt; const float* tts_pad;
     const float* past_hidden;
-    float* x_out;
+    float* x_out; unsigned short* x_out16;   // fp32 hidden state (+ optional bf16 copy)
     int64_t* codes_out; float* hidden_out; int max_frames;
     StepState st;
 };

@@ -31,6 +31,7 @@ struct SkinnyParams {
     const float* x; int ldx; int M;
     int x_bf16;                  // 1: x points to bf16 [M][ldx] (written by a bf16-output producer); no norm; staged by LDS-DMA
     int out_bf16;                // 1: out is written as bf16 [M][ldo] (feeds an x_bf16 consumer)
+    void* out16;                 // optional second output: bf16 copy [M][ldo] of the fp32 `out` (hidden state for the next norm'd GEMM)
     const void* Wp;              // packed tiles [N/16][K/KT][64 lanes][16 B] (RMSNorm weight already folded in)
     int N, K;
     int norm;                    // 1: out = rstd[m] * (x . W'^T) with rstd = rsqrt(mean_k x^2 + eps)

@@ -32,7 +32,7 @@ __device__ inline uint32_t float_key(float f) {  // monotone float -> uint (larg
 }
 
 constexpr int SAMPLE_MAX_V = 8192;
-constexpr int TOPK_COMPACT_MAX = 256;   // survivors of top-k that one wave samples from directly
+constexpr int CAND_MAX = 1024;          // top-k candidates (scores >= the k-th largest per-thread max) ranked exactly in LDS
 
 __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     if (p.done_in && *p.done_in) return;
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     __shared__ float fred[4];
     __shared__ int ired[8];
     __shared__ float scan[256];
-    __shared__ float cval[TOPK_COMPACT_MAX];
-    __shared__ int cidx[TOPK_COMPACT_MAX];
+    __shared__ float cval[CAND_MAX];
+    __shared__ int cidx[CAND_MAX];
     __shared__ int pick_lo, pick_hi;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,33 +96,35 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
         philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
         const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
         bool sampled = false;
-        if (p.top_k > 0 && p.top_k < V) {
-            // ---- k-th largest key by a bitwise binary search (atomics-free: ballot + popcount counts) ----
-            // invariant: count(key >= prefix) >= k; set bits from the MSB down while that still holds.
-            uint32_t prefix = 0;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t cand = prefix | (1u << bit);
-                int cnt = 0;
-                for (int v = tid; v < V; v += 256) cnt += __popcll(__ballot(float_key(sc[v]) >= cand));
-                // every lane of a wave holds the same cnt (sum of wave-wide ballots over its strided slice)
-                if (lane == 0) ired[(bit & 1) * 4 + wave] = cnt;
-                __syncthreads();
-                const int* r4 = ired + (bit & 1) * 4;
-                if (r4[0] + r4[1] + r4[2] + r4[3] >= p.top_k) prefix = cand;
-            }
-            // prefix == key of the k-th largest score; HF TopK keeps every score >= it (ties included)
-            int mycnt = 0;
-            for (int v = tid; v < V; v += 256) mycnt += __popcll(__ballot(float_key(sc[v]) >= prefix));
+        bool need_search = p.top_k > 0 && p.top_k < V;
+        if (need_search && p.top_k <= 256) {
+            // ---- fast top-k: the k-th largest score is >= the k-th largest PER-THREAD maximum, so only scores at or
+            // above that bound can be in the top-k.  Compact those few candidates and rank them exactly.
+            float tm = -INFINITY;
+            for (int v = tid; v < V; v += 256) tm = fmaxf(tm, sc[v]);
+            scan[tid] = tm;
             __syncthreads();
+            {
+                const uint32_t mk = float_key(tm);
+                int rank = 0;
+                for (int j = 0; j < 256; ++j) {
+                    const uint32_t kj = float_key(scan[j]);
+                    rank += (kj > mk) || (kj == mk && j < tid);
+                }
+                if (rank == p.top_k - 1) pick_hi = (int)mk;     // lower bound T0 (as a key)
+            }
+            __syncthreads();
+            const uint32_t T0 = (uint32_t)pick_hi;
+            int mycnt = 0;
+            for (int v = tid; v < V; v += 256) mycnt += __popcll(__ballot(float_key(sc[v]) >= T0));
             if (lane == 0) ired[wave] = mycnt;
             __syncthreads();
-            int base = 0;
-            for (int w = 0; w < wave; ++w) base += ired[w];
-            const int n_keep = ired[0] + ired[1] + ired[2] + ired[3];
-            if (n_keep <= TOPK_COMPACT_MAX) {
-                // ---- compact the survivors (deterministic order: wave, slice, lane), one wave samples ----
-                for (int v = tid; v < V; v += 256) {
-                    const bool keep = float_key(sc[v]) >= prefix;
+            const int n_c = ired[0] + ired[1] + ired[2] + ired[3];
+            if (n_c <= CAND_MAX) {
+                int base = 0;
+                for (int w = 0; w < wave; ++w) base += ired[w];
+                for (int v = tid; v < V; v += 256) {          // deterministic order: wave, slice, lane
+                    const bool keep = float_key(sc[v]) >= T0;
                     const unsigned long long m = __ballot(keep);
                     if (keep) {
                         const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -132,40 +134,72 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
                     base += __popcll(m);
                 }
                 __syncthreads();
-                if (wave == 0) {       // softmax over <= 256 survivors + inverse-CDF draw
+                for (int i = tid; i < n_c; i += 256) {        // exact rank among the candidates (value desc, slot asc)
+                    const uint32_t mk = float_key(cval[i]);
+                    int rank = 0;
+                    for (int j = 0; j < n_c; ++j) {
+                        const uint32_t kj = float_key(cval[j]);
+                        rank += (kj > mk) || (kj == mk && j < i);
+                    }
+                    if (rank == p.top_k - 1) pick_lo = (int)mk;  // key of the k-th largest score
+                }
+                __syncthreads();
+                const uint32_t thr = (uint32_t)pick_lo;          // HF TopK keeps every score >= it (ties included)
+                __syncthreads();
+                if (wave == 0) {       // softmax over the survivors + inverse-CDF draw, one wave
                     float mx = -INFINITY;
-                    for (int i = lane; i < n_keep; i += 64) mx = fmaxf(mx, cval[i]);
+                    for (int i = lane; i < n_c; i += 64) mx = fmaxf(mx, cval[i]);
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
                     float tot = 0.f;
-                    for (int i = lane; i < n_keep; i += 64) { const float e = expf(cval[i] - mx); cval[i] = e; tot += e; }
+                    for (int i = lane; i < n_c; i += 64) {
+                        const float e = float_key(cval[i]) >= thr ? expf(cval[i] - mx) : 0.f;
+                        cval[i] = e;
+                        tot += e;
+                    }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
                     const float target = u * tot;
                     float run = 0.f;
-                    int pick = -1;
-                    for (int i0 = 0; i0 < n_keep && pick < 0; i0 += 64) {
+                    int pick = -1, last = 0;
+                    for (int i0 = 0; i0 < n_c && pick < 0; i0 += 64) {
                         const int i = i0 + lane;
-                        const float e = i < n_keep ? cval[i] : 0.f;
+                        const float e = i < n_c ? cval[i] : 0.f;
                         float inc = e;                                  // inclusive wave scan
 #pragma unroll
                         for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-                        const unsigned long long hit = __ballot(i < n_keep && run + inc > target);
+                        const unsigned long long nz = __ballot(e > 0.f);
+                        if (nz) last = i0 + 63 - __clzll((long long)nz);
+                        const unsigned long long hit = __ballot(e > 0.f && run + inc > target);
                         if (hit) pick = i0 + __ffsll((long long)hit) - 1;
                         run += __shfl(inc, 63);
                     }
-                    if (pick < 0) pick = n_keep - 1;                    // rounding at the very top of the CDF
+                    if (pick < 0) pick = last;                          // rounding at the very top of the CDF
                     if (lane == 0) pick_lo = cidx[pick];
                 }
                 __syncthreads();
                 token = pick_lo;
                 sampled = true;
-            } else {
-                // more survivors than the compact buffer holds (k > 256 or massive ties): mask, general path
-                for (int v = tid; v < V; v += 256)
-                    if (float_key(sc[v]) < prefix) sc[v] = -INFINITY;
-                __syncthreads();
+                need_search = false;
             }
+        }
+        if (need_search) {
+            // ---- general top-k: k-th largest key by a bitwise binary search (atomics-free: ballot + popcount) ----
+            // invariant: count(key >= prefix) >= k; set bits from the MSB down while that still holds.
+            uint32_t prefix = 0;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = prefix | (1u << bit);
+                int cnt = 0;
+                for (int v = tid; v < V; v += 256) cnt += __popcll(__ballot(float_key(sc[v]) >= cand));
+                if (lane == 0) ired[(bit & 1) * 4 + wave] = cnt;
+                __syncthreads();
+                const int* r4 = ired + (bit & 1) * 4;
+                if (r4[0] + r4[1] + r4[2] + r4[3] >= p.top_k) prefix = cand;
+            }
+            __syncthreads();
+            for (int v = tid; v < V; v += 256)
+                if (float_key(sc[v]) < prefix) sc[v] = -INFINITY;
+            __syncthreads();
         }
         if (!sampled) {
             // ---- general path: softmax numerators over the whole vocabulary, block scan, inverse CDF ----
@@ -272,8 +306,14 @@ __global__ __launch_bounds__(256) void cp_gather_kernel(CpGatherParams p) {
     } else {
         src = p.cp_emb + ((size_t)(p.pass - 1) * p.cp_vocab + p.sub[(size_t)r * p.sub_stride + p.pass - 1]) * p.H;
     }
-    for (int c = threadIdx.x * 4; c < p.H; c += 1024)
-        *reinterpret_cast<float4*>(p.out + (size_t)r * p.H + c) = *reinterpret_cast<const float4*>(src + c);
+    for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        *reinterpret_cast<float4*>(p.out + (size_t)r * p.H + c) = v;
+        if (p.out16) {
+            ushort4 h; h.x = f32_to_bf16(v.x); h.y = f32_to_bf16(v.y); h.z = f32_to_bf16(v.z); h.w = f32_to_bf16(v.w);
+            *reinterpret_cast<ushort4*>(p.out16 + (size_t)r * p.H + c) = h;
+        }
+    }
 }
 void launch_cp_gather(const CpGatherParams& p, hipStream_t st) {
     hipLaunchKernelGGL(cp_gather_kernel, dim3(p.pass == 0 ? 2 * p.B : p.B), dim3(256), 0, st, p);
@@ -298,6 +338,10 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedSumParams p) {
         const float4 t = *reinterpret_cast<const float4*>(tp + c);
         a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         *reinterpret_cast<float4*>(p.x_out + (size_t)b * p.H + c) = a;
+        if (p.x_out16) {
+            ushort4 h; h.x = f32_to_bf16(a.x); h.y = f32_to_bf16(a.y); h.z = f32_to_bf16(a.z); h.w = f32_to_bf16(a.w);
+            *reinterpret_cast<ushort4*>(p.x_out16 + (size_t)b * p.H + c) = h;
+        }
         if (p.hidden_out) {
             const float4 h = *reinterpret_cast<const float4*>(p.past_hidden + (size_t)b * p.H + c);
             *reinterpret_cast<float4*>(p.hidden_out + ((size_t)b * p.max_frames + f) * p.H + c) = h;

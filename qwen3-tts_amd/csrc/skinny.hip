@@ -157,7 +157,29 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     if (done) return;
     if constexpr (STAGE) {
         __syncthreads();
-        if (p.norm) {
+        if (p.norm && p.x_bf16) {
+            // variance from the bf16 image (what the reference's bf16 path sees): wave w reduces rows w, w+NW, ...
+            for (int row = wave; row < p.M; row += NW) {
+                float q = 0.f;
+                for (int c = lane * 8; c < p.K; c += 512) {
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(&xs[row * XS + c]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = __uint_as_float(t[e] << 16), b2 = __uint_as_float(t[e] & 0xffff0000u);
+                        q += a * a + b2 * b2;
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                if (lane == 0) rsum[row * NW] = q;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int row = m * 16 + lj;
+                if (row < p.M) rstd_l[m] = rsqrtf(rsum[row * NW] / (float)p.K + p.eps);
+            }
+        } else if (p.norm) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int row = m * 16 + lj;
@@ -269,6 +291,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
             for (int s = 0; s < SPW; ++s) {
                 const int col = (strip0 + s) * 16 + lq * 4;
                 const f32x4 o = v[s] + resv[s][m];
+                if (p.out16) {
+                    uint2 h; h.x = pack_bf16(o[0], o[1]); h.y = pack_bf16(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out16) + (size_t)row * p.ldo + col) = h;
+                }
                 if (p.out_bf16) {
                     uint2 h; h.x = pack_bf16(o[0], o[1]); h.y = pack_bf16(o[2], o[3]);
                     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)row * p.ldo + col) = h;
@@ -318,7 +344,7 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, QTTS_ERR_ARG, "skinny: ldx/ldo % 4");
     const bool stage = skinny_can_stage(p.M, p.K, bf16);
     QTTS_REQUIRE(!p.norm || stage || p.ss_in, QTTS_ERR_ARG, "skinny: norm without LDS staging needs ss_in (row sums of squares)");
-    QTTS_REQUIRE(!p.x_bf16 || (stage && !p.norm), QTTS_ERR_ARG, "skinny: bf16 x needs the staged kernel and no norm");
+    QTTS_REQUIRE(!p.x_bf16 || stage, QTTS_ERR_ARG, "skinny: bf16 x needs the staged kernel");
     QTTS_REQUIRE(!p.out_bf16 || bf16, QTTS_ERR_ARG, "skinny: bf16 output only in bf16 mode");
     int spw = 1;
     if (p.act == ACT_SWIGLU) {

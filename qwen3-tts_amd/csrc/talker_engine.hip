@@ -48,7 +48,7 @@ struct qtts_talker {
     DevBuf kpool_t, vpool_t, kpool_c, vpool_c, ptab_t, ptab_c;
     KvCache kv_t, kv_c;
     // decode state / scratch
-    DevBuf x, qkv, att, act, logits, past_hidden, cp_in, cp_x, cp_qkv, cp_att, cp_act, cp_logits;
+    DevBuf x, qkv, att, act, logits, past_hidden, cp_in, cp_x, cp_qkv, cp_att, cp_act, cp_logits, x16, cp_x16;
     DevBuf cur_tok, sub, generated, ss_ring, ints, n_pad_d, suppress, trailing, tts_pad;
     // prefill scratch
     DevBuf pf_x, pf_n, pf_qkv, pf_att, pf_act, tp_tmp;
@@ -145,22 +145,26 @@ struct qtts_talker {
 
     // x-side handling of a GEMM whose input is RMS-normalised: staged kernels compute rstd themselves; the
     // others (fp32 parity mode, M > 16) get the row sums of squares from one extra tiny kernel.
-    void norm_input(SkinnyParams& p, const StackDims& d, hipStream_t st) {
+    void norm_input(SkinnyParams& p, const StackDims& d, const void* x16v, hipStream_t st) {
         p.norm = 1; p.eps = d.eps;
-        if (!skinny_can_stage(p.M, p.K, bf16)) {
+        if (skinny_can_stage(p.M, p.K, bf16)) {
+            if (x16v) { p.x = reinterpret_cast<const float*>(x16v); p.x_bf16 = 1; }     // LDS-DMA of the bf16 hidden state
+        } else {
             launch_row_ss(p.x, p.ldx, p.M, p.K, ssbuf(), ss.done, st);
             p.ss_in = ssbuf();
         }
     }
     // one decoder layer on `M = n_new * B` rows of `xs` (in place)
-    void decode_layer(const LayerW& L, const StackDims& d, float* xs, float* qkvb, float* attb, float* actb, int M,
-                      int n_new, KvCache& kv, int layer, const int* len_dev, int len_static, const int* npad,
-                      const float* inv_freq, int max_len, hipStream_t st) {
+    void decode_layer(const LayerW& L, const StackDims& d, float* xs, unsigned short* xs16, float* qkvb, float* attb,
+                      float* actb, int M, int n_new, KvCache& kv, int layer, const int* len_dev, int len_static,
+                      const int* npad, const float* inv_freq, int max_len, hipStream_t st) {
+        // xs16: bf16 copy of the hidden state kept in step with xs by every producer (bf16 mode, M <= 16), or null
+        const bool h16 = xs16 && skinny_can_stage(M, d.H, bf16);
         SkinnyParams p{};
         p.done_flag = ss.done;
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
-        norm_input(p, d, st);
+        norm_input(p, d, h16 ? xs16 : nullptr, st);
         skinny(p, st);
         AttnDecodeParams a{};
         a.qkv = qkvb; a.ld = d.qd + 2 * d.kvd; a.B = B; a.n_new = n_new; a.nh = d.nh; a.nkv = d.nkv; a.hd = d.hd;
@@ -176,19 +180,19 @@ struct qtts_talker {
         o.done_flag = ss.done;
         o.x_bf16 = att16;
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
-        o.out = xs; o.ldo = d.H; o.act = ACT_NONE;
+        o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr;
         skinny(o, st);
         SkinnyParams g{};
         g.done_flag = ss.done;
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
         g.out_bf16 = act16;
-        norm_input(g, d, st);
+        norm_input(g, d, h16 ? xs16 : nullptr, st);
         skinny(g, st);
         SkinnyParams dn{};
         dn.done_flag = ss.done;
         dn.x_bf16 = act16;
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
-        dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE;
+        dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE; dn.out16 = h16 ? xs16 : nullptr;
         skinny(dn, st);
     }
 
@@ -286,6 +290,7 @@ void qtts_talker::finalize() {
 
     // ---- decode scratch (rows <= 64)
     const int R = 64;
+    x16.alloc((size_t)R * td.H * 2); cp_x16.alloc((size_t)R * cd.H * 2);
     x.alloc((size_t)R * td.H * 4); qkv.alloc((size_t)R * (td.qd + 2 * td.kvd) * 4); att.alloc((size_t)R * td.qd * 4);
     act.alloc((size_t)R * td.I * 4); logits.alloc((size_t)R * c.vocab_size * 4); past_hidden.alloc((size_t)R * td.H * 4);
     cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
@@ -387,20 +392,22 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         gp.pass = j; gp.B = B; gp.H = td.H; gp.past_hidden = past_hidden.as<float>(); gp.talker_emb = emb_talker.as<float>();
         gp.cur_tok = cur_tok.as<int>(); gp.cp_emb = emb_cp.as<float>(); gp.cp_vocab = c.cp_vocab_size;
         gp.sub = sub.as<int>(); gp.sub_stride = G; gp.done = ss.done;
+        unsigned short* c16 = bf16 ? cp_x16.as<unsigned short>() : nullptr;
         if (has_proj) {
-            gp.out = cp_in.as<float>();
+            gp.out = cp_in.as<float>(); gp.out16 = nullptr;
             launch_cp_gather(gp, st);
             SkinnyParams pj{};
             pj.done_flag = ss.done;
             pj.x = cp_in.as<float>(); pj.ldx = td.H; pj.M = M; pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
             pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.act = ACT_NONE;
+            pj.out16 = (c16 && skinny_can_stage(M, cd.H, bf16)) ? c16 : nullptr;
             skinny(pj, st);
         } else {
-            gp.out = cp_x.as<float>();
+            gp.out = cp_x.as<float>(); gp.out16 = c16;
             launch_cp_gather(gp, st);
         }
         for (int l = 0; l < c.cp_num_hidden_layers; ++l)
-            decode_layer(cl[l], cd, cp_x.as<float>(), cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
+            decode_layer(cl[l], cd, cp_x.as<float>(), c16, cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
                          kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st);
         // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
         SkinnyParams lh{};
@@ -408,7 +415,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         const int off = (n_new - 1) * B;
         lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
         lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE;
-        norm_input(lh, cd, st);
+        norm_input(lh, cd, (c16 && skinny_can_stage(M, cd.H, bf16)) ? c16 + (size_t)off * cd.H : nullptr, st);
         skinny(lh, st);
         SampleParams s{};
         s.logits = cp_logits.as<float>(); s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
@@ -422,11 +429,11 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     e.B = B; e.H = td.H; e.G = G; e.cp_vocab = c.cp_vocab_size; e.talker_emb = emb_talker.as<float>();
     e.cp_emb = emb_cp.as<float>(); e.cur_tok = cur_tok.as<int>(); e.sub = sub.as<int>(); e.sub_stride = G;
     e.trailing = trailing.as<float>(); e.Tt = Tt; e.tts_pad = tts_pad.as<float>(); e.past_hidden = past_hidden.as<float>();
-    e.x_out = x.as<float>(); e.codes_out = codes; e.hidden_out = hidden; e.max_frames = max_frames; e.st = ss;
+    e.x_out = x.as<float>(); e.x_out16 = bf16 ? x16.as<unsigned short>() : nullptr; e.codes_out = codes; e.hidden_out = hidden; e.max_frames = max_frames; e.st = ss;
     launch_embed_sum(e, st);
     // ---- talker decode forward (M:1706-1727)
     for (int l = 0; l < c.num_hidden_layers; ++l)
-        decode_layer(tl[l], td, x.as<float>(), qkv.as<float>(), att.as<float>(), act.as<float>(), B, 1, kv_t, l, ss.kv_len, 0,
+        decode_layer(tl[l], td, x.as<float>(), bf16 ? x16.as<unsigned short>() : nullptr, qkv.as<float>(), att.as<float>(), act.as<float>(), B, 1, kv_t, l, ss.kv_len, 0,
                      n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, st);
     launch_apply_norm(x.as<float>(), td.H, t_norm.as<float>(), td.eps, past_hidden.as<float>(), td.H, B, td.H, ss.done, st);
     SkinnyParams h{};
