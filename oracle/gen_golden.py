@@ -351,6 +351,14 @@ def gen_prompt_tiny():
         "cv_st": dict(non_streaming_mode=False, speakers=["vivian", "ryan", "vivian"], languages=["chinese", "english", "auto"], instruct=[None, 6, None]),
         "vd_st": dict(non_streaming_mode=False, speakers=None, languages=["auto", "english"], instruct=[5, 9]),
     }
+    # voice-clone prompts (Base model, M:2188-2197, 1968-2019): precomputed ref_code / x-vector, ICL + x-vector-only rows
+    vc = {
+        "vc_st": dict(non_streaming_mode=False, speakers=None, languages=["english", "auto", "chinese"], instruct=[None, None, None],
+                      icl=[True, False, True], ref_frames=[7, 0, 30]),
+        "vc_ns": dict(non_streaming_mode=True, speakers=None, languages=["english", "auto", "chinese"], instruct=[None, None, None],
+                      icl=[True, False, True], ref_frames=[7, 0, 30]),
+    }
+    cases.update(vc)
     for cname, cs in cases.items():
         B = len(cs["languages"])
         ids, ins = [], []
@@ -359,9 +367,25 @@ def gen_prompt_tiny():
             ids.append(torch.tensor([[t.im_start_token_id, a, n] + body + [t.im_end_token_id, n, t.im_start_token_id, a, n]]))
             k = cs["instruct"][i]
             ins.append(None if k is None else torch.tensor([[t.im_start_token_id] + g.integers(0, 490, (k,)).tolist() + [t.im_end_token_id, n]]))
+        extra = {}
+        if "icl" in cs:
+            ref_ids, ref_code, spk = [], [], []
+            for i in range(B):
+                rbody = g.integers(0, 490, (int(g.integers(3, 9)),)).tolist()
+                ref_ids.append(torch.tensor([[t.im_start_token_id, a, n] + rbody + [t.im_end_token_id, n]]))
+                nf = cs["ref_frames"][i]
+                rc = np.concatenate([g.integers(0, 256, (nf, 1)), g.integers(0, t.cp_vocab_size, (nf, t.num_code_groups - 1))], 1) if nf else None
+                ref_code.append(None if rc is None else torch.from_numpy(rc))
+                spk.append(torch.from_numpy(g.standard_normal(t.hidden_size).astype(np.float32) * 0.1))
+                out[f"{cname}_refids{i}"] = ref_ids[i].numpy()
+                if rc is not None:
+                    out[f"{cname}_refcode{i}"] = rc
+                out[f"{cname}_spk{i}"] = spk[i].numpy()
+            extra = dict(ref_ids=ref_ids, voice_clone_prompt=dict(ref_code=ref_code, ref_spk_embedding=spk,
+                                                                  x_vector_only_mode=[not x for x in cs["icl"]], icl_mode=cs["icl"]))
         try:
             model.generate(input_ids=ids, instruct_ids=ins, languages=cs["languages"], speakers=cs["speakers"],
-                           non_streaming_mode=cs["non_streaming_mode"], do_sample=False, subtalker_dosample=False)
+                           non_streaming_mode=cs["non_streaming_mode"], do_sample=False, subtalker_dosample=False, **extra)
         except Stop:
             pass
         for i in range(B):

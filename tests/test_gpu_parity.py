@@ -326,23 +326,23 @@ def test_prompt_assembly_and_generate_vs_reference_golden(dev, golden_dir):
     g = np.load(os.path.join(golden_dir, "prompt_tiny.npz"))
     cfgd = dict(synth.cfg_dict(t), tts_model_type="custom_voice", tts_model_size="tiny", tokenizer_type="12hz")
     model = Qwen3TTSForConditionalGeneration(cfgd, _td(wn), device=dev, dtype=torch.float32, max_batch=4, max_seq=128)
-    cases = {"cv_ns": (True, ["vivian", "ryan", "vivian"], ["chinese", "english", "auto"]),
-             "cv_st": (False, ["vivian", "ryan", "vivian"], ["chinese", "english", "auto"]),
-             "vd_st": (False, None, ["auto", "english"])}
-    for name, (ns, spk, langs) in cases.items():
-        B = len(langs)
-        ids = [torch.from_numpy(g[f"{name}_ids{i}"]) for i in range(B)]
-        ins = [torch.from_numpy(g[f"{name}_ins{i}"]) if f"{name}_ins{i}" in g else None for i in range(B)]
-        e, m, tr, pad = model.assemble_prompts(ids, langs, spk, ins, ns)
-        assert np.array_equal(m.cpu().numpy(), g[f"{name}_mask"])
+    from prompt_cases import CASES, load_case
+    for name in CASES:
+        c = load_case(g, name)
+        e, m, tr, pad = model.assemble_prompts(c["ids"], c["languages"], c["speakers"], c["ins"], c["non_streaming_mode"],
+                                               c["ref_ids"], c["voice_clone_prompt"])
+        assert np.array_equal(m.cpu().numpy(), g[f"{name}_mask"]), name
         assert np.abs(e.cpu().numpy() - g[f"{name}_embeds"]).max() <= 2e-5, name
         assert np.abs(tr.cpu().numpy() - g[f"{name}_trailing"]).max() <= 2e-5, name
         assert np.abs(pad.cpu().numpy() - g[f"{name}_tts_pad"]).max() <= 2e-5, name
-        codes, hid = model.generate(input_ids=ids, instruct_ids=ins, languages=langs, speakers=spk, non_streaming_mode=ns,
-                                    max_new_tokens=10, do_sample=False, subtalker_dosample=False)
+        codes, hid = model.generate(input_ids=c["ids"], instruct_ids=c["ins"], languages=c["languages"], speakers=c["speakers"],
+                                    non_streaming_mode=c["non_streaming_mode"], ref_ids=c["ref_ids"],
+                                    voice_clone_prompt=c["voice_clone_prompt"], max_new_tokens=10, do_sample=False,
+                                    subtalker_dosample=False)
         sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
         with torch.no_grad():
-            rc, _ = talker_ref.generate(_td(wn), t, ids, langs, spk, ins, ns, max_new_tokens=10, sp=sp)
+            rc, _ = talker_ref.generate(_td(wn), t, c["ids"], c["languages"], c["speakers"], c["ins"], c["non_streaming_mode"],
+                                        max_new_tokens=10, sp=sp, ref_ids=c["ref_ids"], voice_clone_prompt=c["voice_clone_prompt"])
         assert len(codes) == len(rc)
         for a, b in zip(codes, rc):
             assert np.array_equal(a.cpu().numpy(), b.numpy()), name
@@ -366,3 +366,69 @@ def test_end_to_end_tokenizer_wrapper(codec_tiny, dev):
     assert np.array_equal(wavs[0], wavs[2])
     w1, _ = tk.decode({"audio_codes": a})
     assert np.array_equal(w1[0], wavs[0])
+
+
+def test_talker_large_batch_paths(talker_tiny, dev):
+    """Batches above 16 rows take the non-staged GEMM path (MT = 2 / 4 m-tiles, row sums of squares from a side
+    kernel): B = 20 -> M = 20 per step and M = 40 in the code predictor's 2-token first pass.  fp32 bit-exact vs the
+    oracle; bf16 must run the same shapes and stay close."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    t, w, g = talker_tiny
+    rng = np.random.default_rng(9)
+    lens = [3 + (7 * i) % 13 for i in range(20)]
+    emb, mask, tr, pad = synth.rand_prompt(rng, t, lens, 2, scale=0.5)
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    trace = {}
+    with torch.no_grad():
+        r = talker_ref.talker_generate(w, t, emb, mask, tr, pad, max_new_tokens=6, sp=sp, trace=trace)
+    sc = torch.stack(trace["scores"], 1)
+    top2 = torch.topk(sc, 2, dim=-1)[0]
+    margin = (top2[..., 0] - top2[..., 1]).numpy()
+    eng = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=20, max_seq=64, use_graph=True)
+    out = eng.generate(emb, mask, tr, pad, max_new_tokens=6, do_sample=False, subtalker_dosample=False, suppress_tokens=_suppress(t))
+    _compare_greedy(out.codes.cpu().numpy(), out.tokens.cpu().numpy(), r["codes"].numpy(), r["tokens"].numpy(), margin)
+    e16 = TalkerEngine(t, w, weight_dtype=torch.bfloat16, device=dev, max_batch=20, max_seq=64, use_graph=True)
+    o16 = e16.generate(emb, mask, tr, pad, max_new_tokens=6, do_sample=False, subtalker_dosample=False, suppress_tokens=_suppress(t))
+    agree = float((o16.codes.cpu().numpy()[:, :2] == r["codes"].numpy()[:, :2]).mean())
+    print(f"B=20 bf16 agreement (first 2 frames) {agree:.2f}")
+    assert agree >= 0.7
+
+
+def test_wrapper_end_to_end_custom_voice(dev):
+    """The mirrored `Qwen3TTSModel.generate_custom_voice` from text ids to waveforms (tiny talker + matching tiny
+    codec), against oracle talker + oracle codec on the same ids."""
+    from qwen3_tts_amd.model import Qwen3TTSForConditionalGeneration, Qwen3TTSModel
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    t = synth.talker_tiny()
+    wn = synth.talker_weights(t)
+    c = synth.codec_tiny()
+    c.codebook_size = t.cp_vocab_size                 # codec codebooks must cover the talker's code range
+    cw = synth.codec_weights(c)
+    cfgd = dict(synth.cfg_dict(t), tts_model_type="custom_voice", tts_model_size="1b7", tokenizer_type="12hz")
+    model = Qwen3TTSForConditionalGeneration(cfgd, _td(wn), device=dev, dtype=torch.float32, max_batch=4, max_seq=128)
+    model.load_speech_tokenizer(Qwen3TTSTokenizer.from_state_dict(synth.cfg_dict(c), _td(cw), device=dev, max_batch=4, max_frames=64))
+
+    class FakeProcessor:                               # deterministic stand-in for the HF text tokenizer
+        def __call__(self, text=None, return_tensors="pt", padding=True):
+            body = [(ord(ch) * 7) % 490 for ch in text if ch not in "<|>_\\n"][:40]
+            a, n = 77, 198
+            if text.startswith("<|im_start|>user"):
+                ids = [t.im_start_token_id] + body + [t.im_end_token_id, n]
+            else:
+                ids = [t.im_start_token_id, a, n] + body + [t.im_end_token_id, n, t.im_start_token_id, a, n]
+            return {"input_ids": torch.tensor([ids])}
+    tts = Qwen3TTSModel(model, FakeProcessor(), generate_defaults={})
+    texts, spk, langs = ["hello world", "a rather longer sentence to speak"], ["vivian", "ryan"], ["english", "chinese"]
+    wavs, sr = tts.generate_custom_voice(texts, spk, language=langs, instruct=["whisper", ""], do_sample=False,
+                                         subtalker_dosample=False, max_new_tokens=9)
+    assert sr == 24000 and len(wavs) == 2 and all(w_.dtype == np.float32 and w_.ndim == 1 for w_ in wavs)
+    ids = tts._tokenize_texts([tts._build_assistant_text(x) for x in texts])
+    ins = [tts._tokenize_texts([tts._build_instruct_text("whisper")])[0], None]
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    with torch.no_grad():
+        rc, _ = talker_ref.generate(_td(wn), t, [i.cpu() for i in ids], langs, spk, [ins[0].cpu(), None], True, max_new_tokens=9, sp=sp)
+        rw = codec_ref.model_decode(_td(cw), c, torch.nn.utils.rnn.pad_sequence(rc, batch_first=True, padding_value=-1))
+    for a, b in zip(wavs, rw):
+        assert a.shape[0] == b.shape[0] == 8 * 1920
+        assert _rms(a, b.numpy()) <= RMS_BAR
+    assert tts.get_supported_languages() == ["auto", "chinese", "english"]

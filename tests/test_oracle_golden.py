@@ -95,19 +95,17 @@ def test_talker_eos_and_finished_rows(talker_tiny):
 
 
 def test_prompt_assembly(golden_dir):
+    """custom-voice / voice-design / voice-clone (ICL + x-vector) prompts, streaming and non-streaming."""
+    from prompt_cases import CASES, load_case
     t = synth.talker_tiny()
     w = _td(synth.talker_weights(t))
     g = np.load(os.path.join(golden_dir, "prompt_tiny.npz"))
-    cases = {"cv_ns": (True, ["vivian", "ryan", "vivian"], ["chinese", "english", "auto"]),
-             "cv_st": (False, ["vivian", "ryan", "vivian"], ["chinese", "english", "auto"]),
-             "vd_st": (False, None, ["auto", "english"])}
-    for name, (ns, spk, langs) in cases.items():
-        B = len(langs)
-        ids = [torch.from_numpy(g[f"{name}_ids{i}"]) for i in range(B)]
-        ins = [torch.from_numpy(g[f"{name}_ins{i}"]) if f"{name}_ins{i}" in g else None for i in range(B)]
+    for name in CASES:
+        c = load_case(g, name)
         with torch.no_grad():
-            e, m, tr, pad = talker_ref.assemble_prompts(w, t, ids, langs, spk, ins, ns)
-        assert np.array_equal(m.numpy(), g[f"{name}_mask"])
+            e, m, tr, pad = talker_ref.assemble_prompts(w, t, c["ids"], c["languages"], c["speakers"], c["ins"],
+                                                        c["non_streaming_mode"], c["ref_ids"], c["voice_clone_prompt"])
+        assert np.array_equal(m.numpy(), g[f"{name}_mask"]), name
         assert np.abs(e.numpy() - g[f"{name}_embeds"]).max() <= 1e-6, name
         assert np.abs(tr.numpy() - g[f"{name}_trailing"]).max() <= 1e-6, name
         assert np.abs(pad.numpy() - g[f"{name}_tts_pad"]).max() <= 1e-6, name
