@@ -168,22 +168,30 @@ def main():
         res["frame_bytes_model"] = {"weights": wbytes, "kv_avg": kvb}
         res["frame_hbm_frac_of_8TBs"] = round((wbytes + kvb) / (res["ar_ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if not args.no_roofline:
+            # Live measurement of the dominant kernel: the engine re-captures ONLY the skinny weight-streaming GEMM
+            # launches of one frame step (same shapes, order and buffers) as a hipGraph and replays it 20x between two
+            # HIP events on its own stream (qtts_talker_set_profile).
             talker.set_profile(True)
-            o2 = talker.generate(emb, mask, trailing, pad, seed=7, **dict(gen_kw, max_new_tokens=9, min_new_tokens=9))
+            talker.generate(emb, mask, trailing, pad, seed=7, **dict(gen_kw, max_new_tokens=9, min_new_tokens=9))
             talker.set_profile(False)
             st = talker.stats()
-            frames_prof = o2.n_frames - 1          # frame 0 of the profiled call is warm-up (not timed)
             launches = st["gemm_launches_last"]
             ms = st["gemm_ms_last"]
+            per_frame = st["graph_nodes"]
             if launches > 0 and ms > 0:
-                bytes_per_launch = wbytes * frames_prof / launches
+                bytes_per_launch = wbytes / per_frame
                 avg_ms = ms / launches
                 ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+                traffic = None
+                try:     # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), x2 gfx950 correction
+                    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                        traffic = json.load(f).get(args.model, {}).get("bytes_per_launch")
+                except Exception:
+                    pass
                 res["roofline"] = {"bound": "hbm", "kernel": "skinny_kernel (weight-streaming decode GEMM)",
                                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                                   "launches_per_frame": launches // max(1, frames_prof),
-                                   "avg_launch_us": round(1000 * avg_ms, 3),
+                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                   "launches_per_frame": per_frame, "avg_launch_us": round(1000 * avg_ms, 3),
                                    "algorithmic_bytes_per_launch": round(bytes_per_launch)}
         log("roofline leg done")
         if not args.no_cpu_baseline:
