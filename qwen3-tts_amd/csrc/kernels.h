@@ -34,6 +34,7 @@ struct SkinnyParams {
     void* out16;                 // optional second output: bf16 copy [M][ldo] of the fp32 `out` (hidden state for the next norm'd GEMM)
     const void* Wp;              // packed tiles [N/16][K/KT][64 lanes][16 B] (RMSNorm weight already folded in)
     int N, K;
+    int fs;                      // output features per strip the weights were packed with: 16 (default, 0) | 8 | 4
     int norm;                    // 1: out = rstd[m] * (x . W'^T) with rstd = rsqrt(mean_k x^2 + eps)
     const float* ss_in;          // only when the kernel cannot stage x through LDS: sum_k x[m][k]^2 per row [M]
     float eps;
@@ -49,7 +50,7 @@ bool skinny_can_stage(int M, int K, bool bf16);
 size_t skinny_packed_bytes(int N, int K, bool bf16);
 // Pack W[N][K] (row-major f32), optionally scaled per input column by g[K], into the streaming tile layout;
 // gate/up interleaving is the caller's.
-void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host, const float* g = nullptr);
+void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host, const float* g = nullptr, int fs = 16);
 
 // --------------------------------------------------------------------------------- elementwise.hip
 void launch_rmsnorm(const float* x, int ldx, const float* w, float eps, float* y, int ldy, int rows, int C,

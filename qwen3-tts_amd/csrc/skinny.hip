@@ -33,7 +33,9 @@ __device__ inline unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 
     return *reinterpret_cast<unsigned*>(&v);
 }
 
-template <bool BF16, int MT, int SPW, int NW, bool STAGE>
+// FS = output features per strip (16 | 8 | 4).  Narrow strips put GEMMs with few output features on all 256 CUs
+// (a CU pulls only ~24 GB/s); lanes with (lane & 15) >= FS carry no weights and their MFMA rows are ignored.
+template <bool BF16, int MT, int SPW, int NW, bool STAGE, int FS>
 __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     constexpr int KT = BF16 ? 32 : 16;     // k per tile
     constexpr int XV = BF16 ? 8 : 4;       // x values per lane per tile
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     const u32x4* wbase[SPW];
 #pragma unroll
     for (int s = 0; s < SPW; ++s)
-        wbase[s] = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)(strip0 + s) * nkt) * 64 + lane;
+        wbase[s] = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)(strip0 + s) * nkt) * (FS * 4) + lq * FS + lj;
 
     auto load_chunk = [&](u32x4 (&w)[SPW][U], int c) {
 #pragma unroll
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
             const int kt = wave + NW * i;
 #pragma unroll
             for (int s = 0; s < SPW; ++s)
-                w[s][u] = (i < my_tiles && !(p.ablate & 8)) ? __builtin_nontemporal_load(wbase[s] + (size_t)kt * 64)
+                w[s][u] = (i < my_tiles && lj < FS && !(p.ablate & 8)) ? __builtin_nontemporal_load(wbase[s] + (size_t)kt * (FS * 4))
                                                             : (u32x4){0u, 0u, 0u, 0u};
         }
     };
@@ -85,14 +87,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     const bool epi_loads = wave == 0 && !(p.ablate & 4);
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
-        const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * 16) + lq * 4;
+        const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * FS) + lq * 4;
         biasv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (epi_loads && p.bias) biasv[s] = *reinterpret_cast<const f32x4*>(p.bias + (strip0 + s) * 16 + lq * 4);
+        if (epi_loads && p.bias && lq * 4 < FS) biasv[s] = *reinterpret_cast<const f32x4*>(p.bias + (strip0 + s) * FS + lq * 4);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             resv[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int row = m * 16 + lj;
-            if (epi_loads && p.res && row < p.M && (p.act != ACT_SWIGLU || s == 0))
+            if (epi_loads && p.res && row < p.M && lq * 4 < FS && (p.act != ACT_SWIGLU || s == 0))
                 resv[s][m] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
         }
     }
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
             for (int w2 = 1; w2 < NW; ++w2) t += red[((w2 * SPW + s) * MT + m) * 64 + lane];
             v[s] = t * rstd_l[m] + biasv[s];
         }
-        if (row >= p.M) continue;
+        if (row >= p.M || lq * 4 >= FS) continue;
         if (p.act == ACT_SWIGLU) {
             if constexpr (SPW == 2) {
                 const int col = blockIdx.x * 16 + lq * 4;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
         } else {
 #pragma unroll
             for (int s = 0; s < SPW; ++s) {
-                const int col = (strip0 + s) * 16 + lq * 4;
+                const int col = (strip0 + s) * FS + lq * 4;
                 const f32x4 o = v[s] + resv[s][m];
                 if (p.out16) {
                     uint2 h; h.x = pack_bf16(o[0], o[1]); h.y = pack_bf16(o[2], o[3]);
@@ -308,11 +310,12 @@ bool skinny_can_stage(int M, int K, bool bf16) {
     return bf16 && M <= 16 && K % 256 == 0 && (size_t)M * (K + 8) * 2 <= 111 * 1024;
 }
 
-template <bool BF16, int MT, int SPW, int NW, bool STAGE>
-static void launch_one(const SkinnyParams& p, int grid, hipStream_t st) {
+template <bool BF16, int MT, int SPW, int NW, bool STAGE, int FS>
+static void launch_one(const SkinnyParams& p, hipStream_t st) {
+    const int grid = p.N / (FS * SPW);
     size_t lds = (size_t)NW * SPW * MT * 64 * 16 + (size_t)16 * NW * sizeof(float);
     if (STAGE) lds += (((size_t)p.M * (p.K + 8) * 2 + 1023) / 1024) * 1024;
-    auto kern = skinny_kernel<BF16, MT, SPW, NW, STAGE>;
+    auto kern = skinny_kernel<BF16, MT, SPW, NW, STAGE, FS>;
     static bool attr_set = false;          // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -323,21 +326,25 @@ static void launch_one(const SkinnyParams& p, int grid, hipStream_t st) {
 }
 
 template <bool BF16, int MT>
-static void launch_mt(const SkinnyParams& p, int spw, int nw, bool stage, hipStream_t st) {
-    const int strips = p.N / 16;
+static void launch_mt(const SkinnyParams& p, int spw, int nw, bool stage, int fs, hipStream_t st) {
     if constexpr (BF16 && MT == 1) {
         if (stage) {
-            if (nw == 8) { if (spw == 2) launch_one<true, 1, 2, 8, true>(p, strips / 2, st); else launch_one<true, 1, 1, 8, true>(p, strips, st); }
-            else         { if (spw == 2) launch_one<true, 1, 2, 4, true>(p, strips / 2, st); else launch_one<true, 1, 1, 4, true>(p, strips, st); }
+            if (spw == 2) { if (nw == 8) launch_one<true, 1, 2, 8, true, 16>(p, st); else launch_one<true, 1, 2, 4, true, 16>(p, st); }
+            else if (fs == 16) { if (nw == 8) launch_one<true, 1, 1, 8, true, 16>(p, st); else launch_one<true, 1, 1, 4, true, 16>(p, st); }
+            else if (fs == 8) { if (nw == 8) launch_one<true, 1, 1, 8, true, 8>(p, st); else launch_one<true, 1, 1, 4, true, 8>(p, st); }
+            else { if (nw == 8) launch_one<true, 1, 1, 8, true, 4>(p, st); else launch_one<true, 1, 1, 4, true, 4>(p, st); }
             return;
         }
     }
-    if (nw == 8) { if (spw == 2) launch_one<BF16, MT, 2, 8, false>(p, strips / 2, st); else launch_one<BF16, MT, 1, 8, false>(p, strips, st); }
-    else         { if (spw == 2) launch_one<BF16, MT, 2, 4, false>(p, strips / 2, st); else launch_one<BF16, MT, 1, 4, false>(p, strips, st); }
+    QTTS_REQUIRE(fs == 16, QTTS_ERR_ARG, "skinny: narrow strips (fs < 16) are only built for the staged bf16 M<=16 kernel");
+    if (nw == 8) { if (spw == 2) launch_one<BF16, MT, 2, 8, false, 16>(p, st); else launch_one<BF16, MT, 1, 8, false, 16>(p, st); }
+    else         { if (spw == 2) launch_one<BF16, MT, 2, 4, false, 16>(p, st); else launch_one<BF16, MT, 1, 4, false, 16>(p, st); }
 }
 
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int KT = bf16 ? 32 : 16;
+    const int fs = p.fs ? p.fs : 16;
+    QTTS_REQUIRE(fs == 16 || fs == 8 || fs == 4, QTTS_ERR_ARG, "skinny: fs must be 16, 8 or 4");
     QTTS_REQUIRE(p.N % 16 == 0, QTTS_ERR_ARG, "skinny: N % 16");
     QTTS_REQUIRE(p.K % KT == 0, QTTS_ERR_ARG, "skinny: K must be a multiple of the k-tile");
     QTTS_REQUIRE(p.M >= 1 && p.M <= 64, QTTS_ERR_LIMIT, "skinny: 1 <= M <= 64");
@@ -348,45 +355,46 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(!p.out_bf16 || bf16, QTTS_ERR_ARG, "skinny: bf16 output only in bf16 mode");
     int spw = 1;
     if (p.act == ACT_SWIGLU) {
-        QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "skinny: swiglu N % 32");
+        QTTS_REQUIRE(p.N % 32 == 0 && fs == 16, QTTS_ERR_ARG, "skinny: swiglu needs N % 32 and fs == 16");
         spw = 2;
-    } else if (p.N / 16 >= 1024 && (p.N / 16) % 2 == 0) spw = 2;
+    } else if (fs == 16 && p.N / 16 >= 1024 && (p.N / 16) % 2 == 0) spw = 2;
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16) {
-        if (mt == 1) launch_mt<true, 1>(p, spw, nw, stage, st);
-        else if (mt == 2) launch_mt<true, 2>(p, spw, nw, false, st);
-        else launch_mt<true, 4>(p, spw, nw, false, st);
+        if (mt == 1) launch_mt<true, 1>(p, spw, nw, stage, fs, st);
+        else if (mt == 2) launch_mt<true, 2>(p, spw, nw, false, fs, st);
+        else launch_mt<true, 4>(p, spw, nw, false, fs, st);
     } else {
-        if (mt == 1) launch_mt<false, 1>(p, spw, nw, false, st);
-        else if (mt == 2) launch_mt<false, 2>(p, spw, nw, false, st);
-        else launch_mt<false, 4>(p, spw, nw, false, st);
+        if (mt == 1) launch_mt<false, 1>(p, spw, nw, false, fs, st);
+        else if (mt == 2) launch_mt<false, 2>(p, spw, nw, false, fs, st);
+        else launch_mt<false, 4>(p, spw, nw, false, fs, st);
     }
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
 size_t skinny_packed_bytes(int N, int K, bool bf16) { return (size_t)N * K * (bf16 ? 2 : 4); }
 
-// Pack W[N][K] (row-major f32), optionally scaled per column by g[K] (folded RMSNorm weight), into the tile layout.
-void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host, const float* g) {
+// Pack W[N][K] (row-major f32), optionally scaled per column by g[K] (folded RMSNorm weight), into the tile layout
+// [N/fs strips][K/KT k-tiles][4 k-slices][fs features][16 B].
+void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host, const float* g, int fs) {
     const int KT = bf16 ? 32 : 16;
-    const int nkt = K / KT, strips = N / 16;
+    const int nkt = K / KT, strips = N / fs;
     parallel_for(strips, [&](int64_t s0, int64_t s1) {
         for (int64_t s = s0; s < s1; ++s)
             for (int kt = 0; kt < nkt; ++kt)
-                for (int l = 0; l < 64; ++l) {
-                    const int i = l & 15, q = l >> 4;
-                    const size_t tile = ((size_t)s * nkt + kt) * 64 + l;
-                    const int k0 = kt * KT + q * (bf16 ? 8 : 4);
-                    const float* src = W + (size_t)(s * 16 + i) * K + k0;
-                    if (bf16) {
-                        bf16_t* d = reinterpret_cast<bf16_t*>(out_host) + tile * 8;
-                        for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16(g ? src[e] * g[k0 + e] : src[e]);
-                    } else {
-                        float* d = reinterpret_cast<float*>(out_host) + tile * 4;
-                        for (int e = 0; e < 4; ++e) d[e] = g ? src[e] * g[k0 + e] : src[e];
+                for (int q = 0; q < 4; ++q)
+                    for (int i = 0; i < fs; ++i) {
+                        const size_t tile = ((size_t)s * nkt + kt) * (fs * 4) + q * fs + i;
+                        const int k0 = kt * KT + q * (bf16 ? 8 : 4);
+                        const float* src = W + (size_t)(s * fs + i) * K + k0;
+                        if (bf16) {
+                            bf16_t* d = reinterpret_cast<bf16_t*>(out_host) + tile * 8;
+                            for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16(g ? src[e] * g[k0 + e] : src[e]);
+                        } else {
+                            float* d = reinterpret_cast<float*>(out_host) + tile * 4;
+                            for (int e = 0; e < 4; ++e) d[e] = g ? src[e] * g[k0 + e] : src[e];
+                        }
                     }
-                }
     });
 }
 

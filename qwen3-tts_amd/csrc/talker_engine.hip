@@ -30,6 +30,7 @@ __global__ void gate_kernel(long long cycles, int* sink) {
 namespace {
 
 struct LayerW {
+    int fs_o = 16, fs_d = 16;         // features per strip of o_p / d_p
     DevBuf qkv_p, o_p, gu_p, d_p;     // packed (decode)
     DevBuf qkv_r, o_r, gu_r, d_r;     // row-major (prefill, talker only)
     DevBuf g1, g2, qn, kn;
@@ -48,6 +49,7 @@ struct qtts_talker {
     std::vector<LayerW> tl, cl;
     DevBuf t_norm, c_norm, head_p, emb_talker, emb_cp, proj_p, proj_b, inv_freq_t, inv_freq_c;
     std::vector<DevBuf> lm_head_p;
+    int fs_proj = 16, fs_lm = 16, fs_head = 16;
     DevBuf tp_fc1, tp_b1, tp_fc2, tp_b2;
     bool has_proj = false, has_text_proj = false;
     double weight_bytes_frame = 0;
@@ -97,10 +99,19 @@ struct qtts_talker {
             d.upload(h.data(), h.size() * 2);
         } else d.upload(w.data(), w.size() * 4);
     }
-    void upload_packed(DevBuf& d, const std::vector<float>& w, int N, int K, const std::vector<float>* g = nullptr) {
+    void upload_packed(DevBuf& d, const std::vector<float>& w, int N, int K, const std::vector<float>* g = nullptr, int fs = 16) {
         std::vector<char> h(skinny_packed_bytes(N, K, bf16));
-        pack_skinny_weight(w.data(), N, K, bf16, h.data(), g ? g->data() : nullptr);     // g: folded RMSNorm weight
+        pack_skinny_weight(w.data(), N, K, bf16, h.data(), g ? g->data() : nullptr, fs);     // g: folded RMSNorm weight
         d.upload(h.data(), h.size());
+    }
+    // Narrow strips when the GEMM would otherwise launch far fewer than 256 workgroups.  Only the staged bf16 M<=16
+    // kernel has them, so they are used when every decode GEMM is guaranteed to take that path (max_batch <= 8:
+    // the code predictor's first pass has M = 2B rows).
+    int choose_fs(int N, int K) const {
+        if (!bf16 || cfg.max_batch > 8 || !skinny_can_stage(16, K, true)) return 16;
+        int fs = 16;
+        while (fs > 4 && N / fs < 192) fs /= 2;
+        return fs;
     }
     static std::vector<float> cat3(const std::vector<float>& a, const std::vector<float>& b, const std::vector<float>& c) {
         std::vector<float> w; w.reserve(a.size() + b.size() + c.size());
@@ -122,9 +133,10 @@ struct qtts_talker {
         auto& ow = PS(p + "self_attn.o_proj.weight", {d.H, d.qd});
         auto& dw = PS(p + "mlp.down_proj.weight", {d.H, d.I});
         upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H, &PS(p + "input_layernorm.weight", {d.H}));
-        upload_packed(L.o_p, ow, d.H, d.qd);
+        L.fs_o = choose_fs(d.H, d.qd); L.fs_d = choose_fs(d.H, d.I);
+        upload_packed(L.o_p, ow, d.H, d.qd, nullptr, L.fs_o);
         upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
-        upload_packed(L.d_p, dw, d.H, d.I);
+        upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
             upload_rows(L.o_r, ow);
@@ -180,7 +192,7 @@ struct qtts_talker {
         o.done_flag = ss.done;
         o.x_bf16 = att16;
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
-        o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr;
+        o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr; o.fs = L.fs_o;
         skinny(o, st);
         SkinnyParams g{};
         g.done_flag = ss.done;
@@ -192,7 +204,7 @@ struct qtts_talker {
         dn.done_flag = ss.done;
         dn.x_bf16 = act16;
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
-        dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE; dn.out16 = h16 ? xs16 : nullptr;
+        dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE; dn.out16 = h16 ? xs16 : nullptr; dn.fs = L.fs_d;
         skinny(dn, st);
     }
 
@@ -226,7 +238,8 @@ void qtts_talker::finalize() {
         build_layer(cl[l], "code_predictor.model.layers." + std::to_string(l) + ".", cd, false);
     upload_f(t_norm, PS("model.norm.weight", {td.H}));
     upload_f(c_norm, PS("code_predictor.model.norm.weight", {cd.H}));
-    upload_packed(head_p, PS("codec_head.weight", {c.vocab_size, td.H}), c.vocab_size, td.H);
+    fs_head = choose_fs(c.vocab_size, td.H); fs_lm = choose_fs(c.cp_vocab_size, cd.H); fs_proj = choose_fs(cd.H, td.H);
+    upload_packed(head_p, PS("codec_head.weight", {c.vocab_size, td.H}), c.vocab_size, td.H, nullptr, fs_head);
     upload_f(emb_talker, PS("model.codec_embedding.weight", {c.vocab_size, td.H}));
     {
         std::vector<float> e((size_t)(G - 1) * c.cp_vocab_size * td.H);
@@ -239,10 +252,10 @@ void qtts_talker::finalize() {
     lm_head_p.resize(G - 1);
     for (int g = 0; g < G - 1; ++g)
         upload_packed(lm_head_p[g], PS("code_predictor.lm_head." + std::to_string(g) + ".weight", {c.cp_vocab_size, cd.H}), c.cp_vocab_size, cd.H,
-                      &PS("code_predictor.model.norm.weight", {cd.H}));
+                      &PS("code_predictor.model.norm.weight", {cd.H}), fs_lm);
     has_proj = cd.H != td.H;
     if (has_proj) {
-        upload_packed(proj_p, PS("code_predictor.small_to_mtp_projection.weight", {cd.H, td.H}), cd.H, td.H);
+        upload_packed(proj_p, PS("code_predictor.small_to_mtp_projection.weight", {cd.H, td.H}), cd.H, td.H, nullptr, fs_proj);
         upload_f(proj_b, PS("code_predictor.small_to_mtp_projection.bias", {cd.H}));
     }
     has_text_proj = host.count("text_projection.linear_fc1.weight") > 0;
@@ -359,7 +372,7 @@ void qtts_talker::prefill(const float* embeds, int B_, int T, const int32_t* n_p
     QTTS_CHECK_HIP(hipMemcpyAsync(ss.unfinished, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     SkinnyParams h{};
     h.x = past_hidden.as<float>(); h.ldx = H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = H;
-    h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE;
+    h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE; h.fs = fs_head;
     launch_skinny(h, bf16, st);
     QTTS_CHECK_HIP(hipStreamSynchronize(st));  // host buffers (n_pad, init, ones) must outlive the copies
     prefilled = true;
@@ -399,7 +412,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
             SkinnyParams pj{};
             pj.done_flag = ss.done;
             pj.x = cp_in.as<float>(); pj.ldx = td.H; pj.M = M; pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
-            pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.act = ACT_NONE;
+            pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.act = ACT_NONE; pj.fs = fs_proj;
             pj.out16 = (c16 && skinny_can_stage(M, cd.H, bf16)) ? c16 : nullptr;
             skinny(pj, st);
         } else {
@@ -414,7 +427,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         lh.done_flag = ss.done;
         const int off = (n_new - 1) * B;
         lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
-        lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE;
+        lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE; lh.fs = fs_lm;
         norm_input(lh, cd, (c16 && skinny_can_stage(M, cd.H, bf16)) ? c16 + (size_t)off * cd.H : nullptr, st);
         skinny(lh, st);
         SampleParams s{};
@@ -439,7 +452,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     SkinnyParams h{};
     h.done_flag = ss.done;
     h.x = past_hidden.as<float>(); h.ldx = td.H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = td.H;
-    h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE;
+    h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE; h.fs = fs_head;
     skinny(h, st);
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
 }
