@@ -254,13 +254,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         }
     };
 
-    // ---- 0. loads that do not depend on this step's qkv: first K and V chunk, scalars
-    u32x4 kA[CH][KW], vA[CH][KW];
-    load_chunk(kA, kc, 0);
-    load_chunk(vA, vc, 0);
+    // ---- 0. loads that do not depend on this step's qkv: the first K and V chunk speculatively, then -- as soon as
+    // the length scalar is back -- every further chunk that is needed (up to NPRE chunks = 256 keys with a bf16
+    // cache), so the whole KV read of a typical step is ONE latency round instead of one per chunk.
+    constexpr int NPRE = KW == 1 ? 4 : 2;
+    u32x4 kR[NPRE][CH][KW], vR[NPRE][CH][KW];
+    load_chunk(kR[0], kc, 0);
+    load_chunk(vR[0], vc, 0);
     const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step
     const int npad = p.n_pad ? p.n_pad[b] : 0;
     const int done = p.done_flag ? *p.done_flag : 0;
+    const int S1 = S0 + p.n_new;               // total keys
+    const int nchunk = (S1 + 16 * CH - 1) / (16 * CH);
+#pragma unroll
+    for (int c = 1; c < NPRE; ++c)
+        if (c < nchunk) { load_chunk(kR[c], kc, c); load_chunk(vR[c], vc, c); }
 
     // ---- 1. q/k RMSNorm + RoPE for the new tokens (one wave per vector), K/V append
     const int nvec = NQ + 2 * p.n_new;  // q vectors, then k, then v
@@ -315,8 +323,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 
     // ---- 2. scores: 16 lanes per key (8 dims each), 16 keys per sweep, chunked with one-chunk-ahead prefetch
     const float scale = rsqrtf((float)HD);
-    const int S1 = S0 + p.n_new;               // total keys
-    const int nchunk = (S1 + 16 * CH - 1) / (16 * CH);
     float qreg[4][8];
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi)
@@ -343,14 +349,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             }
         }
     };
-    {
+#pragma unroll
+    for (int c = 0; c < NPRE; ++c)
+        if (c < nchunk) score_chunk(kR[c], c);
+    for (int c = NPRE; c < nchunk; ++c) {       // very long sequences: plain loop
         u32x4 kB[CH][KW];
-        for (int c = 0; c < nchunk; c += 2) {
-            if (c + 1 < nchunk) load_chunk(kB, kc, c + 1);
-            score_chunk(kA, c);
-            if (c + 2 < nchunk) load_chunk(kA, kc, c + 2);
-            if (c + 1 < nchunk) score_chunk(kB, c + 1);
-        }
+        load_chunk(kB, kc, c);
+        score_chunk(kB, c);
     }
     __syncthreads();
     // ---- 3. softmax statistics: wave qi % 4 handles query qi
@@ -394,14 +399,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             }
         }
     };
-    {
+#pragma unroll
+    for (int c = 0; c < NPRE; ++c)
+        if (c < nchunk) pv_chunk(vR[c], c);
+    for (int c = NPRE; c < nchunk; ++c) {
         u32x4 vB[CH][KW];
-        for (int c = 0; c < nchunk; c += 2) {
-            if (c + 1 < nchunk) load_chunk(vB, vc, c + 1);
-            pv_chunk(vA, c);
-            if (c + 2 < nchunk) load_chunk(vA, vc, c + 2);
-            if (c + 1 < nchunk) pv_chunk(vB, c + 1);
-        }
+        load_chunk(vB, vc, c);
+        pv_chunk(vB, c);
     }
     // reduce the 4 key groups of a wave (lanes l, l^16, l^32), then the 4 waves through LDS
 #pragma unroll

@@ -39,9 +39,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     __shared__ float sc[SAMPLE_MAX_V];
     __shared__ float fred[4];
     __shared__ int ired[8];
-    __shared__ float scan[256];
+    __shared__ __attribute__((aligned(16))) float scan[256];
     __shared__ float cval[CAND_MAX];
     __shared__ int cidx[CAND_MAX];
+    __shared__ __attribute__((aligned(16))) uint32_t ckey[CAND_MAX + 4];
     __shared__ int pick_lo, pick_hi;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,14 +103,18 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
             // above that bound can be in the top-k.  Compact those few candidates and rank them exactly.
             float tm = -INFINITY;
             for (int v = tid; v < V; v += 256) tm = fmaxf(tm, sc[v]);
-            scan[tid] = tm;
+            uint32_t* keys = reinterpret_cast<uint32_t*>(scan);
+            keys[tid] = float_key(tm);
             __syncthreads();
             {
-                const uint32_t mk = float_key(tm);
+                const uint32_t mk = keys[tid];
                 int rank = 0;
-                for (int j = 0; j < 256; ++j) {
-                    const uint32_t kj = float_key(scan[j]);
-                    rank += (kj > mk) || (kj == mk && j < tid);
+                for (int j = 0; j < 256; j += 4) {                // all-pairs rank, 16-B LDS reads
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(&keys[j]);
+                    rank += (k4.x > mk) || (k4.x == mk && j < tid);
+                    rank += (k4.y > mk) || (k4.y == mk && j + 1 < tid);
+                    rank += (k4.z > mk) || (k4.z == mk && j + 2 < tid);
+                    rank += (k4.w > mk) || (k4.w == mk && j + 3 < tid);
                 }
                 if (rank == p.top_k - 1) pick_hi = (int)mk;     // lower bound T0 (as a key)
             }
@@ -130,16 +135,21 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
                         const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
                         cval[slot] = sc[v];
                         cidx[slot] = v;
+                        ckey[slot] = float_key(sc[v]);
                     }
                     base += __popcll(m);
                 }
+                for (int i = n_c + tid; i < ((n_c + 3) & ~3); i += 256) ckey[i] = 0u;   // pad to a multiple of 4 (key 0 < any real key)
                 __syncthreads();
                 for (int i = tid; i < n_c; i += 256) {        // exact rank among the candidates (value desc, slot asc)
-                    const uint32_t mk = float_key(cval[i]);
+                    const uint32_t mk = ckey[i];
                     int rank = 0;
-                    for (int j = 0; j < n_c; ++j) {
-                        const uint32_t kj = float_key(cval[j]);
-                        rank += (kj > mk) || (kj == mk && j < i);
+                    for (int j = 0; j < n_c; j += 4) {
+                        const uint4 k4 = *reinterpret_cast<const uint4*>(&ckey[j]);
+                        rank += (k4.x > mk) || (k4.x == mk && j < i);
+                        rank += (k4.y > mk) || (k4.y == mk && j + 1 < i);
+                        rank += (k4.z > mk) || (k4.z == mk && j + 2 < i);
+                        rank += (k4.w > mk) || (k4.w == mk && j + 3 < i);
                     }
                     if (rank == p.top_k - 1) pick_lo = (int)mk;  // key of the k-th largest score
                 }
