@@ -183,6 +183,7 @@ def ref_talker_cfgs(t: synth.TalkerCfg):
 
 
 def ref_talker(t: synth.TalkerCfg, w):
+    ref_shims.install()
     from qwen_tts.core.models.modeling_qwen3_tts import Qwen3TTSTalkerForConditionalGeneration  # noqa
     TalkerConfig, _, tk = ref_talker_cfgs(t)
     from qwen_tts.core.models.modeling_qwen3_tts import Qwen3TTSTalkerForConditionalGeneration
@@ -280,7 +281,7 @@ def gen_talker_tiny():
     print("talker_tiny: codes", codes.shape, "eos2", eos2, "tokens_eos2", toks2.tolist())
 
 
-def _gen_talker_real(name, t, lens, n_trail, max_new, seed):
+def _gen_talker_real(name, t, lens, n_trail, max_new, seed, min_new=2):
     import torch
     w = synth.talker_weights(t, with_text=False)
     t0 = time.time()
@@ -298,10 +299,11 @@ def _gen_talker_real(name, t, lens, n_trail, max_new, seed):
     tr = {}
     t1 = time.time()
     with torch.no_grad():
-        codes, toks, hidden = restated_sample_loop(talker, t, emb, mask, trailing, pad, max_new_tokens=max_new, trace=tr)
+        codes, toks, hidden = restated_sample_loop(talker, t, emb, mask, trailing, pad, max_new_tokens=max_new,
+                                                   min_new_tokens=min_new, trace=tr)
     dt = time.time() - t1
     out = {"weights_checksum": synth.weights_checksum(w), "lens": np.array(lens), "n_trail": n_trail,
-           "seed": seed, "max_new": max_new, "codes": codes.numpy(), "tokens": toks.numpy(),
+           "seed": seed, "max_new": max_new, "min_new": min_new, "codes": codes.numpy(), "tokens": toks.numpy(),
            "margin": torch.stack(tr["margin"], 1).numpy(), "logits0": tr["logits"][0].numpy(),
            "hidden_last": hidden[:, -1].numpy(), "ref_cpu_seconds": dt,
            "ref_cpu_threads": torch.get_num_threads()}
@@ -317,6 +319,18 @@ def gen_talker_06b():
 def gen_talker_17b():
     # bench dims (1.7B), ragged batch of 3, short
     _gen_talker_real("talker_17b", synth.talker_17b(), [40, 52, 33], 6, 20, 8)
+
+
+def gen_talker_06b_b8():
+    # BASELINE config 3: 0.6B dims, batch 8, ragged prompts (text 24..52 ids + 12 role/codec-prefix rows), length forced
+    # to 125 frames (10 s) with min_new_tokens = max_new_tokens = 126, greedy
+    _gen_talker_real("talker_06b_b8", synth.talker_06b(), [36, 40, 44, 48, 52, 56, 60, 64], 1, 126, 9, min_new=126)
+
+
+def gen_talker_17b_b32():
+    # BASELINE config 4 shape: 1.7B dims, batch 32, streaming text input (24 trailing text rows fed one per frame,
+    # M:2229-2232), ragged prompts, greedy, 12 frames
+    _gen_talker_real("talker_17b_b32", synth.talker_17b(), [40 + (7 * i) % 32 for i in range(32)], 24, 13, 10)
 
 
 def gen_prompt_tiny():
@@ -404,7 +418,8 @@ def gen_prompt_tiny():
 
 
 ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
-       "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny}
+       "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
+       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -25,6 +25,63 @@
 
 namespace qtts {
 
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE), == f32_to_bf16 for finite values
+    hw_bf16x2 v = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<unsigned*>(&v);
+}
+
+// acc[i][j][r] = C[m0 + wm*64 + i*16 + lq*4 + r][n0 + wn*BN/2 + j*16 + li]
+template <int BN, int TM, int TN>
+__device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                             int li, int lq) {
+    if (p.act == ACT_SWIGLU) {
+        // W rows come in 16-row blocks alternating gate / up for the same 16 features, so tiles
+        // (j, j+1) of one wave hold gate/up of the same output columns in the same lane/register.
+        if constexpr (TN % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    const int n_packed = n0 + wn * (BN / 2) + j * 16 + li;
+                    const int no = (n_packed / 32) * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
+                        if (m < p.M && n_packed < p.N) {
+                            const float g = acc[i][j][r], u = acc[i][j + 1][r];
+                            p.C[(size_t)m * p.ldc + no] = (g / (1.f + expf(-g))) * u;
+                        }
+                    }
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + li;
+            if (n >= p.N) continue;
+            const float bias = p.bias ? p.bias[n] : 0.f;
+            const float scale = p.scale ? p.scale[n] : 1.f;
+            float ea = 0.f, ib = 0.f;
+            if (p.act == ACT_SNAKE) { ea = p.snake_ea[n]; ib = p.snake_ib[n]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                else if (p.act == ACT_SNAKE) { const float sn = sinf(v * ea); v = v + ib * (sn * sn); }
+                else if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                v *= scale;
+                if (p.res) v += p.res[(size_t)m * p.ldr + n];
+                p.C[(size_t)m * p.ldc + n] = v;
+            }
+        }
+}
+
 template <int BN, bool BF16>
 __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
     constexpr int BM = 128, BK = 32;
@@ -111,10 +168,10 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
         if constexpr (BF16) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ushort4 h;
-                h.x = f32_to_bf16(ra[i].x); h.y = f32_to_bf16(ra[i].y);
-                h.z = f32_to_bf16(ra[i].z); h.w = f32_to_bf16(ra[i].w);
-                *reinterpret_cast<ushort4*>(&As[(a_r + 32 * i) * LDS_STRIDE + a_c4 * 4]) = h;
+                uint2 h;
+                h.x = cvt_pk_bf16(ra[i].x, ra[i].y);
+                h.y = cvt_pk_bf16(ra[i].z, ra[i].w);
+                *reinterpret_cast<uint2*>(&As[(a_r + 32 * i) * LDS_STRIDE + a_c4 * 4]) = h;
             }
 #pragma unroll
             for (int i = 0; i < WREG; ++i) {
@@ -180,53 +237,119 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
         }
     }
 
-    // ---------------------------------------------------------------- epilogue
-    // acc[i][j][r] = C[m0 + wm*64 + i*16 + lq*4 + r][n0 + wn*BN/2 + j*16 + li]
-    if (p.act == ACT_SWIGLU) {
-        // W rows come in 16-row blocks alternating gate / up for the same 16 features, so tiles
-        // (j, j+1) of one wave hold gate/up of the same output columns in the same lane/register.
-        if constexpr (TN % 2 == 0) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; j += 2) {
-                    const int n_packed = n0 + wn * (BN / 2) + j * 16 + li;
-                    const int no = (n_packed / 32) * 16 + li;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
-                        if (m < p.M && n_packed < p.N) {
-                            const float g = acc[i][j][r], u = acc[i][j + 1][r];
-                            p.C[(size_t)m * p.ldc + no] = (g / (1.f + expf(-g))) * u;
-                        }
-                    }
-                }
-        }
-        return;
+    tap_epilogue<BN, TM, TN>(p, acc, m0, n0, wm, wn, li, lq);
+}
+
+// ---- wide-K variant for SMALL grids (talker prefill, text projection): bf16, 1 tap, BK = 128.
+// With fewer workgroups than CUs nothing hides the global-load latency of a k-step (~0.9 us measured per step with
+// BK = 32), so the step is made 4x deeper instead: 4x fewer exposed round trips, 16 + 8 16-B loads in flight per
+// thread.  128 x BN tile, 4 waves (2x2) as above; LDS rows are 128 + 8 bf16.
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
+    constexpr int BM = 128, BK = 128;
+    constexpr int TM = 4, TN = BN / 32;
+    constexpr int STR = BK + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gw[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem_gw);
+    bf16_t* Ws = As + BM * STR;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n_tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int m0 = (bid / n_tiles_n) * BM;
+    const int n0 = (bid % n_tiles_n) * BN;
+
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + li;
-            if (n >= p.N) continue;
-            const float bias = p.bias ? p.bias[n] : 0.f;
-            const float scale = p.scale ? p.scale[n] : 1.f;
-            float ea = 0.f, ib = 0.f;
-            if (p.act == ACT_SNAKE) { ea = p.snake_ea[n]; ib = p.snake_ib[n]; }
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = p.K / BK;
+    constexpr int AREG = 16;                 // 128 rows x 32 float4 / 256 threads
+    constexpr int WREG = BN * 16 / 256;      // BN rows x 16 uint4 / 256 threads
+    float4 ra[AREG];
+    uint4 rw[WREG];
+    const int a_c4 = tid & 31, a_r = tid >> 5;      // rows a_r + 8*i
+    const int w_c = tid & 15, w_r = tid >> 4;       // rows w_r + 16*i
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
+
+    auto load_tiles = [&](int s) {
+        const int k0 = s * BK;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-                else if (p.act == ACT_SNAKE) { const float sn = sinf(v * ea); v = v + ib * (sn * sn); }
-                else if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
-                v *= scale;
-                if (p.res) v += p.res[(size_t)m * p.ldr + n];
-                p.C[(size_t)m * p.ldc + n] = v;
-            }
+        for (int i = 0; i < AREG; ++i) {
+            const int m = m0 + a_r + 8 * i;
+            ra[i] = m < p.M ? *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + k0 + a_c4 * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int r = w_r + 16 * i;
+            rw[i] = (n0 + r < p.N) ? *reinterpret_cast<const uint4*>(W + (size_t)(n0 + r) * p.K + k0 + w_c * 8)
+                                   : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < AREG; ++i) {
+            uint2 h;
+            h.x = cvt_pk_bf16(ra[i].x, ra[i].y);
+            h.y = cvt_pk_bf16(ra[i].z, ra[i].w);
+            *reinterpret_cast<uint2*>(&As[(a_r + 8 * i) * STR + a_c4 * 4]) = h;
+        }
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) *reinterpret_cast<uint4*>(&Ws[(w_r + 16 * i) * STR + w_c * 8]) = rw[i];
+    };
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) load_tiles(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 16 + li) * STR + kk * 32 + lq * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(&Ws[(wn * (BN / 2) + j * 16 + li) * STR + kk * 32 + lq * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (s + 1 < nsteps) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+    tap_epilogue<BN, TM, TN>(p, acc, m0, n0, wm, wn, li, lq);
+}
+
+template <int BN>
+static void launch_wide(const GemmTapParams& p, hipStream_t st) {
+    const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
+    const size_t lds = (size_t)(128 + BN) * (128 + 8) * 2;
+    auto kern = gemm_wide_kernel<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p);
 }
 
 template <int BN, bool BF16>
@@ -248,6 +371,13 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st) {
     else if (p.N % 96 == 0) bn = 96;
     else if (p.N <= 64) bn = 64;
     else bn = 128;
+    // small grids are latency-bound per k-step: use the deep-k kernel (bf16, plain Linear)
+    const int nb = cdiv(p.M, 128) * cdiv(p.N, bn);
+    if (bf16 && p.taps == 1 && p.shift[0] == 0 && p.K % 128 == 0 && p.K >= 512 && nb <= 1024 && (bn == 128 || bn == 64)) {
+        if (bn == 128) launch_wide<128>(p, st); else launch_wide<64>(p, st);
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     if (bf16) {
         if (bn == 128) launch_t<128, true>(p, st);
         else if (bn == 96) launch_t<96, true>(p, st);

@@ -163,12 +163,42 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
                     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
                     float tot = 0.f;
                     for (int i = lane; i < n_c; i += 64) {
-                        const float e = float_key(cval[i]) >= thr ? expf(cval[i] - mx) : 0.f;
+                        const float e = ckey[i] >= thr ? expf(cval[i] - mx) : 0.f;
                         cval[i] = e;
                         tot += e;
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                    if (p.top_p < 1.0f) {
+                        // HF TopPLogitsWarper after TopK: ascending cumulative softmax <= 1 - top_p is removed, i.e. a token
+                        // stays iff the probability mass of everything ranked strictly above it is < top_p (the top token
+                        // always stays).  Ranks are exact (value desc, slot asc); all-pairs over the <= CAND_MAX candidates.
+                        float keep_e[CAND_MAX / 64];
+                        float tot2 = 0.f;
+#pragma unroll
+                        for (int q = 0; q < CAND_MAX / 64; ++q) {
+                            const int i = q * 64 + lane;
+                            keep_e[q] = 0.f;
+                            if (i < n_c && cval[i] > 0.f) {
+                                const uint32_t mk = ckey[i];
+                                float above = 0.f;
+                                for (int j = 0; j < n_c; ++j) {
+                                    const uint32_t kj = ckey[j];
+                                    if (kj > mk || (kj == mk && j < i)) above += cval[j];
+                                }
+                                if (above < p.top_p * tot) keep_e[q] = cval[i];
+                            }
+                            tot2 += keep_e[q];
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) tot2 += __shfl_xor(tot2, o);
+#pragma unroll
+                        for (int q = 0; q < CAND_MAX / 64; ++q) {
+                            const int i = q * 64 + lane;
+                            if (i < n_c) cval[i] = keep_e[q];
+                        }
+                        tot = tot2;
+                    }
                     const float target = u * tot;
                     float run = 0.f;
                     int pick = -1, last = 0;
@@ -268,8 +298,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
 
 void launch_sample(const SampleParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.V <= SAMPLE_MAX_V, QTTS_ERR_LIMIT, "sample: vocab too large");
-    QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f), QTTS_ERR_ARG,
-                 "sample: top_p < 1 is not implemented on device yet (use top_k)");
+    QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f) || (p.top_k > 0 && p.top_k <= 256), QTTS_ERR_ARG,
+                 "sample: top_p < 1 on device needs 0 < top_k <= 256 (the reference default is top_k = 50)");
     hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, st, p);
     QTTS_CHECK_HIP(hipGetLastError());
 }

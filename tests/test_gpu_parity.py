@@ -252,8 +252,9 @@ def _real_golden(dev, golden_dir, name, cfg):
     emb, mask, tr, pad = synth.rand_prompt(rng, cfg, lens, int(g["n_trail"]), scale=0.05)
     eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.float32, device=dev, max_batch=len(lens), max_seq=256, use_graph=True)
     del wn
-    out = eng.generate(emb, mask, tr, pad, max_new_tokens=int(g["max_new"]), do_sample=False, subtalker_dosample=False,
-                       suppress_tokens=_suppress(cfg))
+    min_new = int(g["min_new"]) if "min_new" in g.files else 2
+    out = eng.generate(emb, mask, tr, pad, max_new_tokens=int(g["max_new"]), min_new_tokens=min_new, do_sample=False,
+                       subtalker_dosample=False, suppress_tokens=_suppress(cfg))
     n = _compare_greedy(out.codes.cpu().numpy(), out.tokens.cpu().numpy(), g["codes"], g["tokens"], g["margin"])
     print(f"{name}: {n} frames x {cfg.num_code_groups} codebooks bit-exact vs the reference golden "
           f"(min reference margin {float(g['margin'].min()):.4f})")
@@ -269,6 +270,18 @@ def test_talker_06b_one_utterance_greedy_vs_reference_golden(dev, golden_dir):
 def test_talker_17b_ragged_batch_greedy_vs_reference_golden(dev, golden_dir):
     """Bench dims (1.7B, H=2048 so small_to_mtp_projection is live), ragged batch of 3."""
     _real_golden(dev, golden_dir, "talker_17b", synth.talker_17b())
+
+
+def test_talker_06b_batch8_10s_greedy_vs_reference_golden(dev, golden_dir):
+    """BASELINE config 3: 0.6B dims, batch 8, ragged left-padded prompts, length forced to 125 frames (10 s), greedy:
+    8 x 125 x 16 codebook indices bit-exact vs the reference CPU path."""
+    _real_golden(dev, golden_dir, "talker_06b_b8", synth.talker_06b())
+
+
+def test_talker_17b_batch32_streaming_text_greedy_vs_reference_golden(dev, golden_dir):
+    """BASELINE config 4 shape: 1.7B dims, batch 32 (M = 64 rows in code-predictor pass 0), 24 trailing text rows fed one
+    per frame (streaming text input, M:2229-2232), greedy."""
+    _real_golden(dev, golden_dir, "talker_17b_b32", synth.talker_17b())
 
 
 def test_talker_bf16_mode_tracks_fp32(talker_tiny, dev):
@@ -293,21 +306,30 @@ def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
     t, w, g = talker_tiny
     eng = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=4, max_seq=64, use_graph=False)
     args = [torch.from_numpy(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
-    sc = talker_ref.process_logits(torch.from_numpy(g["logits"][:, 0]), torch.zeros(3, 0, dtype=torch.long), eos_id=t.codec_eos_token_id,
-                                   min_new_tokens=2, suppress=_suppress(t), do_sample=True, temperature=0.8, top_k=6)
-    p = torch.softmax(sc, -1).numpy()
     N = 600
-    counts = np.zeros_like(p)
-    for s in range(N):
-        out = eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=6, temperature=0.8, suppress_tokens=_suppress(t), seed=s)
-        for b, tok in enumerate(out.tokens.cpu().numpy()[:, 0]):
-            counts[b, tok] += 1
-    for b in range(3):
-        assert (counts[b][p[b] == 0] == 0).all(), "sampled a token outside HF's top-k support"
-        sup = p[b] > 0
-        assert sup.sum() == 6
-        chi2 = float((((counts[b][sup] - N * p[b][sup]) ** 2) / (N * p[b][sup])).sum())
-        assert chi2 < 30.0, f"row {b}: chi-square {chi2:.1f} with 5 dof"     # p ~ 1e-5 under H0
+    for top_k, top_p in ((6, 1.0), (12, 0.7)):
+        sc = talker_ref.process_logits(torch.from_numpy(g["logits"][:, 0]), torch.zeros(3, 0, dtype=torch.long),
+                                       eos_id=t.codec_eos_token_id, min_new_tokens=2, suppress=_suppress(t), do_sample=True,
+                                       temperature=0.8, top_k=top_k, top_p=top_p)
+        p = torch.softmax(sc, -1).numpy()
+        counts = np.zeros_like(p)
+        for s in range(N):
+            out = eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=top_k, top_p=top_p, temperature=0.8,
+                               suppress_tokens=_suppress(t), seed=s)
+            for b, tok in enumerate(out.tokens.cpu().numpy()[:, 0]):
+                counts[b, tok] += 1
+        for b in range(3):
+            assert (counts[b][p[b] == 0] == 0).all(), "sampled a token outside HF's top-k / top-p support"
+            sup = p[b] > 0
+            assert sup.sum() == top_k if top_p >= 1.0 else 1 <= sup.sum() < top_k
+            e, o = N * p[b][sup], counts[b][sup]
+            small = e < 5.0                                  # pool sparse cells so the statistic is chi-square-like
+            if small.sum() > 1:
+                e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
+            chi2 = float((((o - e) ** 2) / e).sum())
+            assert chi2 < 35.0, f"top_k={top_k} top_p={top_p} row {b}: chi-square {chi2:.1f} with {len(e) - 1} dof"
+    with pytest.raises(Exception, match="top_p"):            # top_p without a top-k bound is rejected, not ignored
+        eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=0, top_p=0.9, suppress_tokens=_suppress(t))
     # same seed -> same draw; different seed -> (almost surely) a different sequence
     kw = dict(max_new_tokens=8, suppress_tokens=_suppress(t))
     a = eng.generate(*args, seed=11, **kw).codes.cpu().numpy()
