@@ -178,6 +178,26 @@ int qtts_talker_finalize(qtts_talker* t);
  * y_dev float (rows, hidden) device. */
 int qtts_talker_text_projection(qtts_talker* t, const float* x_dev, int32_t rows, float* y_dev, void* stream);
 
+/* Prompt assembly on device (Qwen3TTSForConditionalGeneration.generate, modeling_qwen3_tts.py:2076-2269, and
+ * generate_icl_prompt, :1968-2019).  The host resolves WHICH rows make up each prompt (integers only); the device
+ * does every gather, projection and sum.
+ *
+ * qtts_talker_text_embed: y[r] = text_projection(text_embedding[ids[r]]) (:2076-2080, 2177, 2207, 2229) --
+ *   ids_dev int64 (rows) device, y_dev float (rows, hidden) device.  Needs "model.text_embedding.weight" and the
+ *   text_projection weights bound.  An id outside the table is QTTS_ERR_ARG.
+ * qtts_talker_assemble_rows: out[r] = T + C with, from desc_dev int32 (rows, 4) = {text_row, codec_id, spk_row,
+ *   ref_frame} (-1 = absent; all four absent = a zero row, i.e. left padding :2251-2254):
+ *     T = proj[text_row]                               (proj_dev float (proj_rows, hidden): text_embed output)
+ *     C = codec_embedding[codec_id]                    (:2142-2172 codec prefix / pad / bos, speaker ids :2092)
+ *       | spk[spk_row]                                 (spk_dev float (n_spk, hidden): voice-clone x-vectors :1957-1966)
+ *       | codec_embedding[ref[f][0]] + sum_g cp_embedding[g-1][ref[f][g]]   (ref_codes_dev int64 (n_ref_frames, G):
+ *                                                        in-context reference codes :1983-1990)
+ *   out_dev float (rows, hidden).  Indices out of range are QTTS_ERR_ARG. */
+int qtts_talker_text_embed(qtts_talker* t, const int64_t* ids_dev, int32_t rows, float* y_dev, void* stream);
+int qtts_talker_assemble_rows(qtts_talker* t, const int32_t* desc_dev, int32_t rows, const float* proj_dev, int32_t proj_rows,
+                              const float* spk_dev, int32_t n_spk, const int64_t* ref_codes_dev, int32_t n_ref_frames,
+                              float* out_dev, void* stream);
+
 /* Prefill (modeling_qwen3_tts.py:1665-1667, 1693-1727): embeds_dev float (B, T, H) LEFT-padded,
  * n_pad_host (B) = number of left pads per row (attention_mask = [0]*n_pad + [1]*(T-n_pad),
  * modeling_qwen3_tts.py:2251-2254), trailing_dev float (B, Tt, H) right-padded with tts_pad

@@ -55,7 +55,8 @@ class TalkerStatsC(C.Structure):
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
            "qtts_codec_finalize", "qtts_codec_forward", "qtts_codec_decode", "qtts_codec_forward_stage",
            "qtts_talker_create", "qtts_talker_destroy", "qtts_talker_bind", "qtts_talker_finalize",
-           "qtts_talker_text_projection", "qtts_talker_prefill", "qtts_talker_generate",
+           "qtts_talker_text_projection", "qtts_talker_text_embed", "qtts_talker_assemble_rows", "qtts_talker_prefill",
+           "qtts_talker_generate",
            "qtts_talker_debug_logits", "qtts_talker_get_stats", "qtts_talker_set_profile"]
 
 
@@ -89,6 +90,8 @@ def load_library():
     lib.qtts_talker_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, i64p]
     lib.qtts_talker_finalize.argtypes = [vp]
     lib.qtts_talker_text_projection.argtypes = [vp, f32p, i32, f32p, vp]
+    lib.qtts_talker_text_embed.argtypes = [vp, vp, i32, f32p, vp]
+    lib.qtts_talker_assemble_rows.argtypes = [vp, vp, i32, f32p, i32, f32p, i32, vp, i32, f32p, vp]
     lib.qtts_talker_prefill.argtypes = [vp, f32p, i32, i32, C.POINTER(C.c_int32), f32p, i32, f32p, vp]
     lib.qtts_talker_generate.argtypes = [vp, C.POINTER(SamplingC), i32, i32, i32, C.POINTER(C.c_int32), i32, vp, vp,
                                          vp, C.POINTER(C.c_int32), vp]
@@ -98,7 +101,7 @@ def load_library():
     for s in SYMBOLS:
         if s not in ("qtts_last_error", "qtts_codec_destroy", "qtts_talker_destroy"):
             getattr(lib, s).restype = C.c_int
-    if lib.qtts_abi_version() != 1:
+    if lib.qtts_abi_version() != 2:
         raise QttsError(-101, "libqtts.so ABI version mismatch; rebuild")
     _LIB = lib
     return lib

@@ -47,4 +47,21 @@ void launch_apply_norm(const float* x, int ldx, const float* g, float eps, float
 // ss[r] = sum_c x[r][c]^2 (only for GEMMs that cannot stage x through LDS)
 void launch_row_ss(const float* x, int ldx, int rows, int C, float* ss, const int* done, hipStream_t st);
 
+// ---- prompt assembly (M:2076-2269): every prompt / trailing row is a sum of at most one text-side row and one codec-side
+// term; the host resolves WHICH (integers only), the device does all the floating point.
+struct AssembleParams {
+    const int32_t* desc;        // [rows][4] = {text_row, codec_id, spk_row, ref_frame}; -1 = absent
+    int rows, H, G, cp_vocab, vocab;
+    const float* proj; int proj_rows;           // projected text rows [proj_rows][H]
+    const float* talker_emb; const float* cp_emb;
+    const float* spk; int n_spk;                // speaker vectors [n_spk][H] (voice clone)
+    const int64_t* ref_codes; int n_ref;        // ICL reference codes [n_ref][G]
+    float* out;                                 // [rows][H]
+    int* err;                                   // set to 1 on an out-of-range index (row is zeroed)
+};
+void launch_assemble_rows(const AssembleParams& p, hipStream_t st);
+// out[r][:] = table[ids[r]][:] as fp32 (table fp32 or bf16); out-of-range ids set *err and give a zero row
+void launch_gather_rows(const void* table, bool table_bf16, int64_t n_table, int C, const int64_t* ids, int rows, float* out,
+                        int* err, hipStream_t st);
+
 }  // namespace qtts

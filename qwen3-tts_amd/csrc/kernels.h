@@ -126,6 +126,7 @@ struct SampleParams {
     const unsigned char* suppress_mask;      // [V] or null
     int do_sample; int top_k; float top_p; float temperature;
     unsigned long long seed; unsigned int stream_id;   // Philox key / sub-stream (codebook index)
+    const unsigned long long* seed_dev;                // if set, the key is read from device memory (graph replay across calls)
     const int* step_dev;                     // device step counter feeding the Philox offset
     // outputs
     int* tok_out; int tok_stride;            // token of row b -> tok_out[b * tok_stride]

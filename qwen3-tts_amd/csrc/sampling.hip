@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
         }
         const uint32_t step = p.step_dev ? (uint32_t)*p.step_dev : 0u;
         uint32_t rnd[4];
-        philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rnd);
+        const unsigned long long seed = p.seed_dev ? *p.seed_dev : p.seed;
+        philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
         const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
         bool sampled = false;
         bool need_search = p.top_k > 0 && p.top_k < V;
@@ -438,6 +439,82 @@ __global__ __launch_bounds__(256) void row_ss_kernel(const float* x, int ldx, in
 }
 void launch_row_ss(const float* x, int ldx, int rows, int C, float* ss, const int* done, hipStream_t st) {
     hipLaunchKernelGGL(row_ss_kernel, dim3(rows), dim3(256), 0, st, x, ldx, C, ss, done);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+
+// ---- prompt assembly -----------------------------------------------------------------------------------------------
+// One workgroup per output row.  The codec side of an ICL row is the 16-way codebook embedding sum in codebook order
+// (M:1983-1990), then text + codec (commutative for two terms), exactly the reference's association.
+__global__ __launch_bounds__(256) void assemble_rows_kernel(AssembleParams p) {
+    const int r = blockIdx.x;
+    const int tr = p.desc[r * 4 + 0], cid = p.desc[r * 4 + 1], sr = p.desc[r * 4 + 2], rf = p.desc[r * 4 + 3];
+    bool bad = tr >= p.proj_rows || cid >= p.vocab || sr >= p.n_spk || rf >= p.n_ref;
+    int64_t rc0 = 0;
+    if (rf >= 0 && !bad) {
+        rc0 = p.ref_codes[(size_t)rf * p.G];
+        bad = rc0 < 0 || rc0 >= p.vocab;
+        for (int g = 1; g < p.G; ++g) {
+            const int64_t v = p.ref_codes[(size_t)rf * p.G + g];
+            bad = bad || v < 0 || v >= p.cp_vocab;
+        }
+    }
+    if (bad && threadIdx.x == 0) *p.err = 1;
+    for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool have = false;
+        if (!bad) {
+            if (cid >= 0) { a = *reinterpret_cast<const float4*>(p.talker_emb + (size_t)cid * p.H + c); have = true; }
+            if (sr >= 0) {
+                const float4 e = *reinterpret_cast<const float4*>(p.spk + (size_t)sr * p.H + c);
+                if (have) { a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w; } else { a = e; have = true; }
+            }
+            if (rf >= 0) {
+                float4 e = *reinterpret_cast<const float4*>(p.talker_emb + (size_t)rc0 * p.H + c);
+                for (int g = 1; g < p.G; ++g) {
+                    const int64_t v = p.ref_codes[(size_t)rf * p.G + g];
+                    const float4 f = *reinterpret_cast<const float4*>(p.cp_emb + ((size_t)(g - 1) * p.cp_vocab + v) * p.H + c);
+                    e.x += f.x; e.y += f.y; e.z += f.z; e.w += f.w;
+                }
+                if (have) { a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w; } else { a = e; have = true; }
+            }
+            if (tr >= 0) {
+                const float4 t = *reinterpret_cast<const float4*>(p.proj + (size_t)tr * p.H + c);
+                if (have) { a.x = t.x + a.x; a.y = t.y + a.y; a.z = t.z + a.z; a.w = t.w + a.w; } else a = t;
+            }
+        }
+        *reinterpret_cast<float4*>(p.out + (size_t)r * p.H + c) = a;
+    }
+}
+void launch_assemble_rows(const AssembleParams& p, hipStream_t st) {
+    QTTS_REQUIRE(p.H % 4 == 0, QTTS_ERR_ARG, "assemble: H % 4");
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3(p.rows), dim3(256), 0, st, p);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const void* table, int64_t n_table, int C, const int64_t* ids, float* out,
+                                                          int* err) {
+    const int r = blockIdx.x;
+    const int64_t id = ids[r];
+    const bool bad = id < 0 || id >= n_table;
+    if (bad && threadIdx.x == 0) *err = 1;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!bad) {
+            if constexpr (BF16) {
+                const ushort4 h = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(table) + (size_t)id * C + c);
+                v = make_float4(bf16_to_f32(h.x), bf16_to_f32(h.y), bf16_to_f32(h.z), bf16_to_f32(h.w));
+            } else v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(table) + (size_t)id * C + c);
+        }
+        *reinterpret_cast<float4*>(out + (size_t)r * C + c) = v;
+    }
+}
+void launch_gather_rows(const void* table, bool table_bf16, int64_t n_table, int C, const int64_t* ids, int rows, float* out,
+                        int* err, hipStream_t st) {
+    QTTS_REQUIRE(C % 4 == 0, QTTS_ERR_ARG, "gather: C % 4");
+    if (table_bf16) hipLaunchKernelGGL(gather_rows_kernel<true>, dim3(rows), dim3(256), 0, st, table, n_table, C, ids, out, err);
+    else hipLaunchKernelGGL(gather_rows_kernel<false>, dim3(rows), dim3(256), 0, st, table, n_table, C, ids, out, err);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 

@@ -51,7 +51,9 @@ struct qtts_talker {
     std::vector<DevBuf> lm_head_p;
     int fs_proj = 16, fs_lm = 16, fs_head = 16;
     DevBuf tp_fc1, tp_b1, tp_fc2, tp_b2;
-    bool has_proj = false, has_text_proj = false;
+    bool has_proj = false, has_text_proj = false, has_text_emb = false;
+    DevBuf emb_text, tp_in, err_flag;          // text embedding table (prompt assembly), gathered rows, device error flag
+    int64_t text_vocab = 0;
     double weight_bytes_frame = 0;
 
     // KV caches
@@ -67,6 +69,16 @@ struct qtts_talker {
     // graph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // everything a captured frame step bakes into its kernel arguments and that can differ between generate() calls;
+    // the graph is re-captured only when this changes (the Philox seed lives in device memory for the same reason)
+    struct GraphKey {
+        int B, Tt, eos, min_new, max_new, max_frames;
+        int do_sample, top_k, sub_do_sample, sub_top_k;
+        float top_p, temperature, rep, sub_top_p, sub_temperature;
+        const void *codes, *hidden, *trailing, *tts_pad, *generated;
+        bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+    } graph_key;
+    DevBuf seed_d;
     int graph_nodes = 0;
     // profiling of the dominant kernel
     bool profile = false, timing_now = false, skinny_only = false;
@@ -264,6 +276,16 @@ void qtts_talker::finalize() {
         upload_rows(tp_fc1, PS("text_projection.linear_fc1.weight", {TH, TH})); upload_f(tp_b1, PS("text_projection.linear_fc1.bias", {TH}));
         upload_rows(tp_fc2, PS("text_projection.linear_fc2.weight", {td.H, TH})); upload_f(tp_b2, PS("text_projection.linear_fc2.bias", {td.H}));
     }
+    has_text_emb = host.count("model.text_embedding.weight") > 0;
+    if (has_text_emb) {
+        const auto& shp = shapes["model.text_embedding.weight"];
+        QTTS_REQUIRE(shp.size() == 2 && shp[1] == c.text_hidden_size, QTTS_ERR_ARG,
+                     "model.text_embedding.weight must be [text_vocab][text_hidden_size]");
+        text_vocab = shp[0];
+        upload_rows(emb_text, host["model.text_embedding.weight"]);
+    }
+    err_flag.alloc(4);
+    QTTS_CHECK_HIP(hipMemset(err_flag.p, 0, 4));
     auto mk_freq = [&](DevBuf& d, const char* name, float theta, int hd) {
         if (host.count(name)) { upload_f(d, PS(name, {hd / 2})); return; }
         std::vector<float> f(hd / 2);
@@ -309,7 +331,7 @@ void qtts_talker::finalize() {
     cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
     cp_att.alloc((size_t)R * cd.qd * 4); cp_act.alloc((size_t)R * cd.I * 4); cp_logits.alloc((size_t)R * c.cp_vocab_size * 4);
     cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_ring.alloc(64 * 8); ints.alloc(64 * 4 + R * 4);
-    n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size);
+    n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size); seed_d.alloc(8);
     QTTS_CHECK_HIP(hipMemset(ss_ring.p, 0, ss_ring.bytes));
     int* ip = ints.as<int>();
     ss = {ip + 0, ip + 1, ip + 2, ip + 3, ip + 4, ip + 64};
@@ -386,7 +408,7 @@ void qtts_talker::sample_talker(const qtts_sampling& sp, int eos, int min_new, i
     p.repetition_penalty = sp.repetition_penalty; p.eos = eos; p.min_new_tokens = min_new;
     p.suppress_mask = suppress.as<unsigned char>();
     p.do_sample = sp.do_sample; p.top_k = sp.top_k; p.top_p = sp.top_p; p.temperature = sp.temperature;
-    p.seed = sp.seed; p.stream_id = 0; p.step_dev = ss.n_generated;
+    p.seed = sp.seed; p.seed_dev = seed_d.as<unsigned long long>(); p.stream_id = 0; p.step_dev = ss.n_generated;
     p.tok_out = cur_tok.as<int>(); p.tok_stride = 1; p.unfinished = ss.unfinished; p.generated_out = generated.as<int>();
     p.max_new_tokens = max_new; p.done_in = ss.done;
     launch_sample(p, st);
@@ -434,6 +456,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         s.logits = cp_logits.as<float>(); s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
         s.repetition_penalty = 1.0f; s.eos = -1; s.do_sample = sp.subtalker_dosample; s.top_k = sp.subtalker_top_k;
         s.top_p = sp.subtalker_top_p; s.temperature = sp.subtalker_temperature; s.seed = sp.seed; s.stream_id = 1 + j;
+        s.seed_dev = seed_d.as<unsigned long long>();
         s.step_dev = ss.n_generated; s.tok_out = sub.as<int>() + j; s.tok_stride = G; s.done_in = ss.done;
         if (!skinny_only) launch_sample(s, st);
     }
@@ -506,15 +529,11 @@ int qtts_talker_finalize(qtts_talker* t) {
     QTTS_API_END
 }
 
-int qtts_talker_text_projection(qtts_talker* t, const float* x_dev, int32_t rows, float* y_dev, void* stream) {
-    QTTS_API_BEGIN
-    QTTS_REQUIRE(t && x_dev && y_dev && rows >= 1, QTTS_ERR_ARG, "bad argument");
-    QTTS_REQUIRE(t->finalized && t->has_text_proj, QTTS_ERR_STATE, "text_projection weights were not bound");
-    hipStream_t st = (hipStream_t)stream;
+static void text_project(qtts_talker* t, const float* x_dev, int rows, float* y_dev, hipStream_t st) {
     const int TH = t->cfg.text_hidden_size;
     QTTS_REQUIRE(TH % 32 == 0, QTTS_ERR_ARG, "text_hidden_size % 32");
     t->tp_tmp.ensure((size_t)rows * TH * 4);
-    // fc1 + bias, SiLU, fc2 + bias (M:815-816).  SiLU is applied by a SwiGLU-free path: act(v) = v*sigmoid(v)
+    // fc1 + bias, SiLU, fc2 + bias (M:815-816)
     GemmTapParams p{};
     p.A = x_dev; p.lda = TH; p.M = rows; p.T = rows; p.W = t->tp_fc1.p; p.N = TH; p.K = TH; p.taps = 1;
     p.bias = t->tp_b1.as<float>(); p.act = ACT_SILU; p.C = t->tp_tmp.as<float>(); p.ldc = TH;
@@ -523,6 +542,55 @@ int qtts_talker_text_projection(qtts_talker* t, const float* x_dev, int32_t rows
     q.A = t->tp_tmp.as<float>(); q.lda = TH; q.M = rows; q.T = rows; q.W = t->tp_fc2.p; q.N = t->td.H; q.K = TH; q.taps = 1;
     q.bias = t->tp_b2.as<float>(); q.act = ACT_NONE; q.C = y_dev; q.ldc = t->td.H;
     launch_gemm_tap(q, t->bf16, st);
+}
+static void check_err_flag(qtts_talker* t, hipStream_t st, const char* what) {
+    int e = 0;
+    QTTS_CHECK_HIP(hipMemcpyAsync(&e, t->err_flag.p, 4, hipMemcpyDeviceToHost, st));
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    if (e) {
+        QTTS_CHECK_HIP(hipMemset(t->err_flag.p, 0, 4));
+        throw Error(QTTS_ERR_ARG, what);
+    }
+}
+
+int qtts_talker_text_projection(qtts_talker* t, const float* x_dev, int32_t rows, float* y_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && x_dev && y_dev && rows >= 1, QTTS_ERR_ARG, "bad argument");
+    QTTS_REQUIRE(t->finalized && t->has_text_proj, QTTS_ERR_STATE, "text_projection weights were not bound");
+    text_project(t, x_dev, rows, y_dev, (hipStream_t)stream);
+    QTTS_API_END
+}
+
+int qtts_talker_text_embed(qtts_talker* t, const int64_t* ids_dev, int32_t rows, float* y_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && ids_dev && y_dev && rows >= 1, QTTS_ERR_ARG, "bad argument");
+    QTTS_REQUIRE(t->finalized && t->has_text_proj && t->has_text_emb, QTTS_ERR_STATE,
+                 "text_embed: model.text_embedding / text_projection weights were not bound");
+    hipStream_t st = (hipStream_t)stream;
+    const int TH = t->cfg.text_hidden_size;
+    t->tp_in.ensure((size_t)rows * TH * 4);
+    launch_gather_rows(t->emb_text.p, t->bf16, t->text_vocab, TH, ids_dev, rows, t->tp_in.as<float>(), t->err_flag.as<int>(), st);
+    text_project(t, t->tp_in.as<float>(), rows, y_dev, st);
+    check_err_flag(t, st, "text_embed: text token id out of range");
+    QTTS_API_END
+}
+
+int qtts_talker_assemble_rows(qtts_talker* t, const int32_t* desc_dev, int32_t rows, const float* proj_dev, int32_t proj_rows,
+                              const float* spk_dev, int32_t n_spk, const int64_t* ref_codes_dev, int32_t n_ref_frames,
+                              float* out_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && desc_dev && out_dev && rows >= 1, QTTS_ERR_ARG, "bad argument");
+    QTTS_REQUIRE(t->finalized, QTTS_ERR_STATE, "assemble_rows before finalize");
+    QTTS_REQUIRE(proj_rows >= 0 && n_spk >= 0 && n_ref_frames >= 0 && (proj_rows == 0 || proj_dev) && (n_spk == 0 || spk_dev) &&
+                     (n_ref_frames == 0 || ref_codes_dev), QTTS_ERR_ARG, "assemble_rows: table pointer / count mismatch");
+    hipStream_t st = (hipStream_t)stream;
+    AssembleParams p{};
+    p.desc = desc_dev; p.rows = rows; p.H = t->td.H; p.G = t->cfg.num_code_groups; p.cp_vocab = t->cfg.cp_vocab_size;
+    p.vocab = t->cfg.vocab_size; p.proj = proj_dev; p.proj_rows = proj_rows; p.talker_emb = t->emb_talker.as<float>();
+    p.cp_emb = t->emb_cp.as<float>(); p.spk = spk_dev; p.n_spk = n_spk; p.ref_codes = ref_codes_dev; p.n_ref = n_ref_frames;
+    p.out = out_dev; p.err = t->err_flag.as<int>();
+    launch_assemble_rows(p, st);
+    check_err_flag(t, st, "assemble_rows: descriptor index or reference code out of range");
     QTTS_API_END
 }
 
@@ -553,12 +621,14 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
             m[suppress_host[i]] = 1;
         }
         QTTS_CHECK_HIP(hipMemcpyAsync(t->suppress.p, m.data(), V, hipMemcpyHostToDevice, st));
+        const unsigned long long seed = sp->seed;
+        QTTS_CHECK_HIP(hipMemcpyAsync(t->seed_d.p, &seed, 8, hipMemcpyHostToDevice, st));
         QTTS_CHECK_HIP(hipStreamSynchronize(st));
     }
     t->gen_cap = max_new_tokens;
     t->generated.ensure((size_t)B * max_new_tokens * 4);
     const int max_frames = std::max(1, max_new_tokens - 1);
-    t->frames_run = 0; t->graph_nodes = 0;
+    t->frames_run = 0;
     if (!t->profile) { t->prof_ms = 0; t->prof_launches = 0; }
 
     t->sample_talker(*sp, eos_token_id, min_new_tokens, max_new_tokens, st);      // token 0
@@ -571,7 +641,14 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     const bool use_graph = t->cfg.use_graph && !t->profile;
     const int total = max_new_tokens - 1;      // at most this many frame steps
     int f = 0;
-    t->destroy_graph();
+    qtts_talker::GraphKey key;
+    memset(&key, 0, sizeof(key));          // (padding bytes take part in the comparison)
+    key.B = B; key.Tt = t->Tt; key.eos = eos_token_id; key.min_new = min_new_tokens; key.max_new = max_new_tokens;
+    key.max_frames = max_frames; key.do_sample = sp->do_sample; key.top_k = sp->top_k; key.sub_do_sample = sp->subtalker_dosample;
+    key.sub_top_k = sp->subtalker_top_k; key.top_p = sp->top_p; key.temperature = sp->temperature; key.rep = sp->repetition_penalty;
+    key.sub_top_p = sp->subtalker_top_p; key.sub_temperature = sp->subtalker_temperature; key.codes = codes_dev;
+    key.hidden = hidden_dev; key.trailing = t->trailing.p; key.tts_pad = t->tts_pad.p; key.generated = t->generated.p;
+    if (!use_graph || !t->graph_exec || !(key == t->graph_key)) { t->destroy_graph(); t->graph_nodes = 0; }
     while (!done && f < total) {
         if (t->profile && f == 1) {
             // roofline leg: ONLY the dominant kernel (every skinny GEMM of one frame step, same shapes/order) as a
@@ -604,7 +681,7 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
             done = 1;
             break;
         }
-        if (!use_graph || f == 0) {
+        if (!use_graph || (f == 0 && !t->graph_exec)) {      // (a capture does not execute: frame 0 runs eagerly once)
             t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st);
             ++f;
             if (!use_graph && (f % 8 == 0)) poll();
@@ -626,6 +703,7 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
             QTTS_CHECK_HIP(hipGraphGetNodes(t->graph, nullptr, &nn));
             t->graph_nodes = (int)nn;
             QTTS_CHECK_HIP(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
+            t->graph_key = key;
         }
         const int burst = std::min(8, total - f);
         for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(t->graph_exec, st));

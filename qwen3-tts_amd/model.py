@@ -1,8 +1,9 @@
 """Drop-in mirrors of the reference's top-level model and inference wrapper.
 
   * Qwen3TTSForConditionalGeneration.generate   qwen_tts/core/models/modeling_qwen3_tts.py:2022-2292
-    (prompt assembly -> talker generate -> EOS trim).  Prompt assembly is host-side torch indexing +
-    one batched `text_projection` call into the HIP library; the decode loop is the HIP engine.
+    (prompt assembly -> talker generate -> EOS trim).  Prompt assembly = integer row plan on the host
+    (`build_prompt_plan`) + two calls into the HIP library (text embed/projection, row assembly); the decode
+    loop is the HIP engine.
   * Qwen3TTSModel                               qwen_tts/inference/qwen3_tts_model.py:54-877
     (`from_pretrained`, `generate_custom_voice`, `generate_voice_design`, `generate_voice_clone`,
     kwargs merging, validation, same exception types).
@@ -33,6 +34,126 @@ class VoiceClonePromptItem:
     ref_text: Optional[str] = None
 
 
+PLAN_BOS_ROW, PLAN_EOS_ROW, PLAN_PAD_ROW = 0, 1, 2      # rows of the projected special text tokens in every plan
+
+
+def build_prompt_plan(config, input_ids, languages, speakers=None, instruct_ids=None, non_streaming_mode=False,
+                      ref_ids=None, voice_clone_prompt=None) -> Dict[str, Any]:
+    """Host half of the prompt assembly (M:2068-2269, generate_icl_prompt M:1968-2019): pure integer bookkeeping, no
+    device work.  Every prompt / trailing row becomes a descriptor {text_row, codec_id, spk_row, ref_frame} (-1 =
+    absent) that `qtts_talker_assemble_rows` turns into `text_projection(text_embedding[..]) + codec-side term`.
+
+    Returns: text_ids int64 (R,) -- ids to embed+project, rows 0..2 = tts_bos / tts_eos / tts_pad;
+    desc int32 (n*Tm + n*Tt, 4) -- left-padded prompt rows of all requests, then the trailing-text rows (padded with
+    tts_pad); mask int64 (n, Tm); spk_vectors / ref_codes -- the tensors spk_row / ref_frame index into."""
+    c = config
+    n = len(input_ids)
+    if speakers is None:
+        speakers = [None] * n
+    ids_np = lambda t: np.asarray(t.detach().cpu().reshape(-1).numpy() if torch.is_tensor(t) else t, dtype=np.int64).reshape(-1)
+
+    # ---- per-request metadata first (raises before any device work, in the reference's loop order)
+    spk_vectors: List[torch.Tensor] = []
+    metas = []
+    for i in range(n):
+        speaker, language = speakers[i], languages[i]
+        spk = None                                  # ("codec", id) | ("vec", row) | None
+        if voice_clone_prompt is None:
+            if not (speaker == "" or speaker is None):
+                if speaker.lower() not in c.spk_id:
+                    raise NotImplementedError(f"Speaker {speaker} not implemented")
+                spk = ("codec", int(c.spk_id[speaker.lower()]))
+        elif voice_clone_prompt["x_vector_only_mode"][i] or voice_clone_prompt["icl_mode"][i]:      # M:1957-1966
+            spk = ("vec", len(spk_vectors))
+            spk_vectors.append(voice_clone_prompt["ref_spk_embedding"][i])
+        assert language is not None
+        if language.lower() == "auto":
+            lang_id = None
+        else:
+            if language.lower() not in c.codec_language_id:
+                raise NotImplementedError(f"Language {language} not implemented")
+            lang_id = c.codec_language_id[language.lower()]
+        if (language.lower() in ["chinese", "auto"] and speaker != "" and speaker is not None
+                and c.spk_is_dialect[speaker.lower()] != False):  # noqa: E712  (reference compares with != False)
+            lang_id = c.codec_language_id[c.spk_is_dialect[speaker.lower()]]
+        icl = bool(voice_clone_prompt is not None and voice_clone_prompt.get("ref_code") is not None
+                   and voice_clone_prompt["icl_mode"][i])
+        metas.append((spk, lang_id, icl))
+
+    text_ids: List[int] = [c.tts_bos_token_id, c.tts_eos_token_id, c.tts_pad_token_id]
+
+    def seg(ids) -> List[int]:                      # register a text segment, return its projected-row indices
+        a = ids_np(ids)
+        r0 = len(text_ids)
+        text_ids.extend(int(x) for x in a)
+        return list(range(r0, r0 + len(a)))
+
+    T = lambda r: (r, -1, -1, -1)                   # text only
+    ref_codes: List[torch.Tensor] = []
+    n_ref = 0
+    seqs, trails = [], []
+    for i in range(n):
+        spk, lang_id, icl = metas[i]
+        ids = ids_np(input_ids[i])
+        role = seg(ids[:3])
+        if lang_id is None:
+            pre = [c.codec_nothink_id, c.codec_think_bos_id, c.codec_think_eos_id]
+        else:
+            pre = [c.codec_think_id, c.codec_think_bos_id, lang_id, c.codec_think_eos_id]
+        cin = [(-1, int(x), -1, -1) for x in pre]                                # codec prefix (M:2142-2172)
+        if spk is not None:
+            cin.append((-1, spk[1], -1, -1) if spk[0] == "codec" else (-1, -1, spk[1], -1))
+        cin += [(-1, int(c.codec_pad_id), -1, -1), (-1, int(c.codec_bos_id), -1, -1)]
+        rows = []
+        if instruct_ids is not None and instruct_ids[i] is not None:
+            rows += [T(r) for r in seg(instruct_ids[i])]
+        rows += [T(r) for r in role]
+        for k in range(len(cin) - 1):                                            # tts_pad x (len-2), tts_bos  +  cin[:-1]
+            rows.append((PLAN_PAD_ROW if k < len(cin) - 2 else PLAN_BOS_ROW,) + cin[k][1:])
+        if icl:
+            te = seg(np.concatenate([ids_np(ref_ids[i])[3:-2], ids[3:-5]])) + [PLAN_EOS_ROW]
+            rc = voice_clone_prompt["ref_code"][i]
+            ce = [(-1, int(c.codec_bos_id), -1, -1)] + [(-1, -1, -1, n_ref + f) for f in range(int(rc.shape[0]))]   # M:1983-1998
+            ref_codes.append(rc)
+            n_ref += int(rc.shape[0])
+            tl, cl = len(te), len(ce)
+            if non_streaming_mode:
+                rows += [(r, int(c.codec_pad_id), -1, -1) for r in te]
+                rows += [(PLAN_PAD_ROW,) + e[1:] for e in ce]
+                trail = [PLAN_PAD_ROW]
+            elif tl > cl:
+                rows += [(te[k],) + ce[k][1:] for k in range(cl)]
+                trail = te[cl:]
+            else:
+                rows += [((te[k] if k < tl else PLAN_PAD_ROW),) + ce[k][1:] for k in range(cl)]
+                trail = [PLAN_PAD_ROW]
+        elif non_streaming_mode:
+            rest = seg(ids[3:-5]) + [PLAN_EOS_ROW]
+            rows += [(r, int(c.codec_pad_id), -1, -1) for r in rest]
+            rows.append((PLAN_PAD_ROW, int(c.codec_bos_id), -1, -1))
+            trail = [PLAN_PAD_ROW]
+        else:
+            first = seg(ids[3:4])
+            rows.append((first[0],) + cin[-1][1:])
+            trail = seg(ids[4:-5]) + [PLAN_EOS_ROW]
+        seqs.append(rows)
+        trails.append(trail)
+
+    Tm = max(len(r) for r in seqs)
+    Tt = max(len(t) for t in trails)
+    desc = np.full((n * Tm + n * Tt, 4), -1, dtype=np.int32)
+    mask = np.zeros((n, Tm), dtype=np.int64)
+    for i, r in enumerate(seqs):
+        desc[i * Tm + Tm - len(r): (i + 1) * Tm] = np.asarray(r, dtype=np.int32)
+        mask[i, Tm - len(r):] = 1
+    for i, t in enumerate(trails):
+        base = n * Tm + i * Tt
+        desc[base: base + Tt, 0] = PLAN_PAD_ROW
+        desc[base: base + len(t), 0] = np.asarray(t, dtype=np.int32)
+    return {"n": n, "Tm": Tm, "Tt": Tt, "text_ids": np.asarray(text_ids, dtype=np.int64), "desc": desc, "mask": mask,
+            "spk_vectors": spk_vectors, "ref_codes": ref_codes}
+
+
 class Qwen3TTSForConditionalGeneration:
     """Talker-side model object: owns the HIP talker engine and the embedding tables the prompt needs."""
 
@@ -47,11 +168,8 @@ class Qwen3TTSForConditionalGeneration:
             sd = {k[len("talker."):]: v for k, v in sd.items() if k.startswith("talker.")}
         self.talker = TalkerEngine(self.config, sd, weight_dtype=dtype, device=device, max_batch=max_batch,
                                    max_seq=max_seq, use_graph=use_graph)
-        f32 = lambda t: t.detach().to(self.device, torch.float32).contiguous()
-        G = self.config.num_code_groups
-        self.text_embedding = sd["model.text_embedding.weight"].detach().to(self.device).contiguous()
-        self.codec_embedding = f32(sd["model.codec_embedding.weight"])
-        self.cp_codec_embedding = [f32(sd[f"code_predictor.model.codec_embedding.{g}.weight"]) for g in range(G - 1)]
+        if "model.text_embedding.weight" not in sd:
+            raise KeyError("state_dict has no talker.model.text_embedding.weight (needed by the prompt assembly)")
         self.speech_tokenizer = None
         self.generate_config = None
         self.speaker_encoder = None
@@ -73,140 +191,27 @@ class Qwen3TTSForConditionalGeneration:
     def get_supported_languages(self):
         return self.supported_languages
 
-    # ------------------------------------------------------------------ prompt assembly helpers
-    def _project_text(self, id_lists: List[torch.Tensor]) -> List[torch.Tensor]:
-        """text_projection(text_embedding(ids)) for many id vectors with ONE gather + ONE engine call."""
-        lens = [int(x.numel()) for x in id_lists]
-        if sum(lens) == 0:
-            return [torch.zeros(0, self.config.hidden_size, device=self.device) for _ in id_lists]
-        ids = torch.cat([x.reshape(-1).to(self.device, torch.long) for x in id_lists])
-        emb = self.text_embedding[ids].to(torch.float32)
-        out = self.talker.text_projection(emb)
-        return list(torch.split(out, lens, dim=0))
-
-    def _codec(self, ids: List[int]) -> torch.Tensor:
-        return self.codec_embedding[torch.tensor(ids, dtype=torch.long, device=self.device)]
-
+    # ------------------------------------------------------------------ prompt assembly (device, M:2068-2269)
     def assemble_prompts(self, input_ids, languages, speakers=None, instruct_ids=None, non_streaming_mode=False,
                          ref_ids=None, voice_clone_prompt=None):
         """M:2068-2269.  Returns (inputs_embeds (B,T,H) left-padded, attention_mask (B,T), trailing_text_hidden
-        (B,Tt,H) right-padded with tts_pad, tts_pad_embed (1,1,H))."""
-        c = self.config
-        n = len(input_ids)
-        if speakers is None:
-            speakers = [None] * n
-        spk_embeds = None
-        if voice_clone_prompt is not None:
-            spk_embeds = [e.to(self.device, torch.float32) for e in voice_clone_prompt["ref_spk_embedding"]]   # M:1957-1966
+        (B,Tt,H) right-padded with tts_pad, tts_pad_embed (1,1,H)).
 
-        # ---- resolve per-request metadata first (raises before any GPU work, like the reference's loop order)
-        metas = []
-        for i in range(n):
-            speaker, language = speakers[i], languages[i]
-            if spk_embeds is None:
-                if speaker == "" or speaker is None:
-                    spk = None
-                else:
-                    if speaker.lower() not in c.spk_id:
-                        raise NotImplementedError(f"Speaker {speaker} not implemented")
-                    spk = self.codec_embedding[c.spk_id[speaker.lower()]]
-            else:
-                use = voice_clone_prompt["x_vector_only_mode"][i] or voice_clone_prompt["icl_mode"][i]
-                spk = spk_embeds[i] if use else None
-            assert language is not None
-            if language.lower() == "auto":
-                lang_id = None
-            else:
-                if language.lower() not in c.codec_language_id:
-                    raise NotImplementedError(f"Language {language} not implemented")
-                lang_id = c.codec_language_id[language.lower()]
-            if (language.lower() in ["chinese", "auto"] and speaker != "" and speaker is not None
-                    and c.spk_is_dialect[speaker.lower()] != False):  # noqa: E712  (reference compares with != False)
-                lang_id = c.codec_language_id[c.spk_is_dialect[speaker.lower()]]
-            icl = bool(voice_clone_prompt is not None and voice_clone_prompt.get("ref_code") is not None
-                       and voice_clone_prompt["icl_mode"][i])
-            metas.append((spk, lang_id, icl))
-
-        # ---- one batched text projection for every text segment of every request
-        segs: List[torch.Tensor] = [torch.tensor([c.tts_bos_token_id, c.tts_eos_token_id, c.tts_pad_token_id])]
-        index = []
-        for i in range(n):
-            ids = input_ids[i].reshape(-1)
-            ent = {"role": len(segs)}
-            segs.append(ids[:3])
-            if metas[i][2]:
-                ent["icl"] = len(segs)
-                segs.append(torch.cat([ref_ids[i].reshape(-1)[3:-2].to(ids.device), ids[3:-5]]))
-            else:
-                ent["first"] = len(segs)
-                segs.append(ids[3:4])
-                ent["rest"] = len(segs)
-                segs.append(ids[3:-5] if non_streaming_mode else ids[4:-5])
-            if instruct_ids is not None and instruct_ids[i] is not None:
-                ent["ins"] = len(segs)
-                segs.append(instruct_ids[i].reshape(-1))
-            index.append(ent)
-        proj = self._project_text(segs)
-        bos_e, eos_e, pad_e = proj[0][0:1], proj[0][1:2], proj[0][2:3]
-
-        seqs, trails = [], []
-        pad_codec = self.codec_embedding[c.codec_pad_id]
-        bos_codec = self.codec_embedding[c.codec_bos_id]
-        for i in range(n):
-            spk, lang_id, icl = metas[i]
-            ent = index[i]
-            if lang_id is None:
-                pre = [c.codec_nothink_id, c.codec_think_bos_id, c.codec_think_eos_id]
-            else:
-                pre = [c.codec_think_id, c.codec_think_bos_id, lang_id, c.codec_think_eos_id]
-            rows = [self._codec(pre)]
-            if spk is not None:
-                rows.append(spk.reshape(1, -1))
-            rows.append(torch.stack([pad_codec, bos_codec]))
-            cin = torch.cat(rows, dim=0)                                         # codec prefix, last two = pad, bos
-            text_side = torch.cat([pad_e.expand(cin.shape[0] - 2, -1), bos_e], dim=0)
-            parts = []
-            if "ins" in ent:
-                parts.append(proj[ent["ins"]])
-            parts += [proj[ent["role"]], text_side + cin[:-1]]
-            if icl:
-                te = torch.cat([proj[ent["icl"]], eos_e], dim=0)
-                rc = voice_clone_prompt["ref_code"][i].to(self.device, torch.long)
-                ce = self.codec_embedding[rc[:, 0]]
-                for g in range(1, c.num_code_groups):
-                    ce = ce + self.cp_codec_embedding[g - 1][rc[:, g]]
-                ce = torch.cat([bos_codec[None], ce], dim=0)                     # M:1983-1998
-                tl, cl = te.shape[0], ce.shape[0]
-                if non_streaming_mode:
-                    parts += [te + pad_codec[None], ce + pad_e]
-                    trail = pad_e
-                elif tl > cl:
-                    parts.append(te[:cl] + ce)
-                    trail = te[cl:]
-                else:
-                    parts.append(torch.cat([te, pad_e.expand(cl - tl, -1)], dim=0) + ce)
-                    trail = pad_e
-            elif non_streaming_mode:
-                parts += [torch.cat([proj[ent["rest"]], eos_e], dim=0) + pad_codec[None], pad_e + bos_codec[None]]
-                trail = pad_e
-            else:
-                parts.append(proj[ent["first"]] + cin[-1:])
-                trail = torch.cat([proj[ent["rest"]], eos_e], dim=0)
-            seqs.append(torch.cat(parts, dim=0))
-            trails.append(trail)
-
-        H = c.hidden_size
-        Tm = max(s.shape[0] for s in seqs)
-        embeds = torch.zeros(n, Tm, H, dtype=torch.float32, device=self.device)
-        mask = torch.zeros(n, Tm, dtype=torch.long)
-        for i, s in enumerate(seqs):
-            embeds[i, Tm - s.shape[0]:] = s
-            mask[i, Tm - s.shape[0]:] = 1
-        Tt = max(t.shape[0] for t in trails)
-        trailing = pad_e.reshape(1, 1, H).repeat(n, Tt, 1)
-        for i, t in enumerate(trails):
-            trailing[i, : t.shape[0]] = t
-        return embeds, mask.to(self.device), trailing, pad_e.reshape(1, 1, H)
+        The host only decides WHICH rows make up each prompt (`build_prompt_plan`, integers); every gather,
+        the text projection and every sum run in the HIP library: one `qtts_talker_text_embed` call over all text
+        ids of the batch and one `qtts_talker_assemble_rows` call over all prompt + trailing rows."""
+        plan = build_prompt_plan(self.config, input_ids, languages, speakers, instruct_ids, non_streaming_mode, ref_ids,
+                                 voice_clone_prompt)
+        H = self.config.hidden_size
+        n, Tm, Tt = plan["n"], plan["Tm"], plan["Tt"]
+        proj = self.talker.text_embed(torch.from_numpy(plan["text_ids"]))
+        spk = torch.stack([e.reshape(-1).to(self.device, torch.float32) for e in plan["spk_vectors"]]) if plan["spk_vectors"] else None
+        ref = torch.cat([r.to(self.device, torch.long) for r in plan["ref_codes"]], dim=0) if plan["ref_codes"] else None
+        rows = self.talker.assemble_rows(torch.from_numpy(plan["desc"]), proj, spk, ref)
+        embeds = rows[: n * Tm].reshape(n, Tm, H)
+        trailing = rows[n * Tm:].reshape(n, Tt, H)
+        mask = torch.from_numpy(plan["mask"]).to(self.device)
+        return embeds, mask, trailing, proj[PLAN_PAD_ROW].reshape(1, 1, H)
 
     # ------------------------------------------------------------------ generate (seam S1)
     @torch.no_grad()

@@ -28,7 +28,7 @@ class TalkerGenerateOutput:
     n_frames: int
 
 
-_SKIP_PREFIXES = ("speaker_encoder.", "model.text_embedding.")
+_SKIP_PREFIXES = ("speaker_encoder.",)
 
 
 class TalkerEngine:
@@ -106,6 +106,43 @@ class TalkerEngine:
         return y.reshape(*shp[:-1], self.config.hidden_size)
 
     # ------------------------------------------------------------------ generate (seam S2)
+    def text_embed(self, ids: torch.Tensor) -> torch.Tensor:
+        """text_projection(text_embedding[ids]) on device (M:2076-2080): ids int64 (n,) -> (n, H) fp32."""
+        ids = ids.reshape(-1).to(self.device, torch.long).contiguous()
+        y = torch.empty(ids.numel(), self.config.hidden_size, dtype=torch.float32, device=self.device)
+        if ids.numel() == 0:
+            return y
+        with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+            self._stream.wait_stream(torch.cuda.current_stream(self.device))
+            _lib.check(self._lib.qtts_talker_text_embed(self._h, C.c_void_p(ids.data_ptr()), ids.numel(),
+                                                        C.c_void_p(y.data_ptr()), self._s()))
+        torch.cuda.current_stream(self.device).wait_stream(self._stream)
+        return y
+
+    def assemble_rows(self, desc: torch.Tensor, proj: Optional[torch.Tensor] = None, spk: Optional[torch.Tensor] = None,
+                      ref_codes: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out[r] = proj[text_row] + codec-side term, from int32 descriptors (rows, 4) = {text_row, codec_id, spk_row,
+        ref_frame} (-1 = absent).  See include/qtts.h `qtts_talker_assemble_rows`."""
+        dev = self.device
+        desc = desc.reshape(-1, 4).to(dev, torch.int32).contiguous()
+        out = torch.empty(desc.shape[0], self.config.hidden_size, dtype=torch.float32, device=dev)
+        if desc.shape[0] == 0:
+            return out
+        proj = None if proj is None or proj.numel() == 0 else proj.to(dev, torch.float32).contiguous()
+        spk = None if spk is None or spk.numel() == 0 else spk.to(dev, torch.float32).contiguous()
+        ref = None if ref_codes is None or ref_codes.numel() == 0 else ref_codes.to(dev, torch.long).contiguous()
+        if ref is not None and (ref.dim() != 2 or ref.shape[1] != self.config.num_code_groups):
+            raise ValueError(f"ref_codes must be (frames, {self.config.num_code_groups})")
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
+            _lib.check(self._lib.qtts_talker_assemble_rows(
+                self._h, C.c_void_p(desc.data_ptr()), desc.shape[0], ptr(proj), 0 if proj is None else proj.shape[0],
+                ptr(spk), 0 if spk is None else spk.shape[0], ptr(ref), 0 if ref is None else ref.shape[0],
+                C.c_void_p(out.data_ptr()), self._s()))
+        torch.cuda.current_stream(dev).wait_stream(self._stream)
+        return out
+
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, trailing_text_hidden: torch.Tensor,
                  tts_pad_embed: torch.Tensor, max_new_tokens: int = 2048, min_new_tokens: int = 2,
                  do_sample: bool = True, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,

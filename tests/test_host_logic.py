@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol(libqtts):
     from qwen3_tts_amd import _lib
     assert declared == set(_lib.SYMBOLS), "python binding and header disagree"
     lib.qtts_abi_version.restype = ctypes.c_int
-    assert lib.qtts_abi_version() == 1
+    assert lib.qtts_abi_version() == 2
 
 
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
@@ -130,3 +130,60 @@ def test_model_wrapper_validation():
     kw = w._merge_generate_kwargs(temperature=0.5, foo=1)
     assert kw["top_k"] == 20 and kw["temperature"] == 0.5 and kw["max_new_tokens"] == 2048 and kw["foo"] == 1
     assert w.get_supported_speakers() == ["ryan", "vivian"]
+
+
+def test_prompt_plan_reproduces_reference_prompts(golden_dir):
+    """Host half of the device prompt assembly (qwen3_tts_amd.model.build_prompt_plan): execute the integer row plan
+    with a CPU stand-in for the two HIP calls (oracle text_projection + table lookups, the arithmetic
+    qtts_talker_text_embed / qtts_talker_assemble_rows perform) and compare with what the REFERENCE's generate() hands
+    to talker.generate in all five golden cases (custom voice / voice design / voice clone ICL + x-vector, streaming
+    and non-streaming)."""
+    import os
+    import numpy as np
+    import torch
+    import synth
+    import talker_ref
+    from prompt_cases import CASES, load_case
+    from qwen3_tts_amd.config import TalkerConfig
+    from qwen3_tts_amd.model import build_prompt_plan, PLAN_PAD_ROW
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t).items()}
+    cfg = TalkerConfig.from_any(synth.cfg_dict(t))
+    g = np.load(os.path.join(golden_dir, "prompt_tiny.npz"))
+    emb, H, G = w["model.codec_embedding.weight"], t.hidden_size, t.num_code_groups
+    for name in CASES:
+        c = load_case(g, name)
+        plan = build_prompt_plan(cfg, c["ids"], c["languages"], c["speakers"], c["ins"], c["non_streaming_mode"], c["ref_ids"],
+                                 c["voice_clone_prompt"])
+        assert plan["desc"].dtype == np.int32 and plan["text_ids"].dtype == np.int64
+        with torch.no_grad():
+            proj = talker_ref.text_projection(w, w["model.text_embedding.weight"][torch.from_numpy(plan["text_ids"])])
+        spk = torch.stack([x.reshape(-1).float() for x in plan["spk_vectors"]]) if plan["spk_vectors"] else None
+        ref = torch.cat(plan["ref_codes"], 0) if plan["ref_codes"] else None
+        rows = torch.zeros(plan["desc"].shape[0], H)
+        for r, (tr, cid, sr, rf) in enumerate(plan["desc"].tolist()):
+            cterm = None
+            if cid >= 0:
+                cterm = emb[cid]
+            if sr >= 0:
+                assert cterm is None
+                cterm = spk[sr]
+            if rf >= 0:
+                assert cterm is None
+                cterm = emb[ref[rf, 0]]
+                for k in range(1, G):
+                    cterm = cterm + w[f"code_predictor.model.codec_embedding.{k - 1}.weight"][ref[rf, k]]
+            if tr >= 0:
+                rows[r] = proj[tr] + cterm if cterm is not None else proj[tr]
+            elif cterm is not None:
+                rows[r] = cterm
+        n, Tm, Tt = plan["n"], plan["Tm"], plan["Tt"]
+        assert np.array_equal(plan["mask"], g[f"{name}_mask"]), name
+        assert np.abs(rows[: n * Tm].reshape(n, Tm, H).numpy() - g[f"{name}_embeds"]).max() <= 1e-6, name
+        assert np.abs(rows[n * Tm:].reshape(n, Tt, H).numpy() - g[f"{name}_trailing"]).max() <= 1e-6, name
+        assert np.abs(proj[PLAN_PAD_ROW].numpy() - g[f"{name}_tts_pad"].reshape(-1)).max() <= 1e-6, name
+    import pytest
+    with pytest.raises(NotImplementedError):
+        build_prompt_plan(cfg, [torch.from_numpy(g["cv_ns_ids0"])], ["klingon"], ["vivian"])
+    with pytest.raises(NotImplementedError):
+        build_prompt_plan(cfg, [torch.from_numpy(g["cv_ns_ids0"])], ["english"], ["nobody"])
