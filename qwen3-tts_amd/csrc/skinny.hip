@@ -41,10 +41,15 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     constexpr int XV = BF16 ? 8 : 4;       // x values per lane per tile
     constexpr int U = 8 / SPW;             // k-tiles per chunk; two chunks (16 x 1 KiB) in flight per wave
     constexpr int NT = NW * 64;
+    // LDS: rsum [16*MT][NW] partial sum(x^2) | red [NW*SPW*MT*64] f32x4 | xs [M][K+8] bf16 (STAGE).  With more than one
+    // m-tile the x image (up to 132 KB at M = 32, K = 2048) and `red` do not both fit, and `red` is only written after
+    // the last read of xs -- so they share the space (one extra barrier, ALIAS kernels only).
+    constexpr bool ALIAS = STAGE && MT > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
-    f32x4* red = reinterpret_cast<f32x4*>(smem_sk);                                    // [NW*SPW*MT*64]
-    float* rsum = reinterpret_cast<float*>(smem_sk + (size_t)NW * SPW * MT * 64 * 16); // [16][NW] partial sum(x^2)
-    unsigned short* xs = reinterpret_cast<unsigned short*>(rsum + 16 * NW);            // STAGE: [M][K+8] bf16
+    float* rsum = reinterpret_cast<float*>(smem_sk);
+    f32x4* red = reinterpret_cast<f32x4*>(smem_sk + (size_t)16 * MT * NW * 4);
+    unsigned short* xs = reinterpret_cast<unsigned short*>(smem_sk + (size_t)16 * MT * NW * 4 +
+                                                           (ALIAS ? 0 : (size_t)NW * SPW * MT * 64 * 16));
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lj = lane & 15, lq = lane >> 4;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
         } else {
         const int k4 = p.K >> 2;                            // float4 per row; k4 % 64 == 0 (launcher checks)
         const int total = p.M * k4;
-        if (lane < 16) rsum[lane * NW + wave] = 0.f;        // this wave's private slots
+        for (int r = lane; r < 16 * MT; r += 64) rsum[r * NW + wave] = 0.f;        // this wave's private slots
         for (int i0 = 0; i0 < total; i0 += NT * 4) {
             float4 v[4];
 #pragma unroll
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     }
 
     // ---- 5. cross-wave combine (fixed order) and epilogue by wave 0
+    if constexpr (ALIAS) __syncthreads();          // every wave is done reading xs before red overwrites it
 #pragma unroll
     for (int s = 0; s < SPW; ++s)
 #pragma unroll
@@ -306,15 +312,20 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     }
 }
 
+// The staged kernel needs the whole x (M x K bf16) in LDS: M <= 16 up to K = 7096, M <= 32 up to K = 2344 (red aliases xs).
 bool skinny_can_stage(int M, int K, bool bf16) {
-    return bf16 && M <= 16 && K % 256 == 0 && (size_t)M * (K + 8) * 2 <= 111 * 1024;
+    if (!bf16 || K % 256 != 0) return false;
+    if (M <= 16) return (size_t)M * (K + 8) * 2 <= 111 * 1024;
+    return M <= 32 && (size_t)M * (K + 8) * 2 <= 150 * 1024;
 }
 
 template <bool BF16, int MT, int SPW, int NW, bool STAGE, int FS>
 static void launch_one(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
-    size_t lds = (size_t)NW * SPW * MT * 64 * 16 + (size_t)16 * NW * sizeof(float);
-    if (STAGE) lds += (((size_t)p.M * (p.K + 8) * 2 + 1023) / 1024) * 1024;
+    const size_t red_b = (size_t)NW * SPW * MT * 64 * 16, rs_b = (size_t)16 * MT * NW * sizeof(float);
+    const size_t xs_b = STAGE ? (((size_t)p.M * (p.K + 8) * 2 + 1023) / 1024) * 1024 : 0;
+    const size_t lds = rs_b + ((STAGE && MT > 1) ? std::max(red_b, xs_b) : red_b + xs_b);
+    QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "skinny: LDS budget exceeded");
     auto kern = skinny_kernel<BF16, MT, SPW, NW, STAGE, FS>;
     static bool attr_set = false;          // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
@@ -333,6 +344,14 @@ static void launch_mt(const SkinnyParams& p, int spw, int nw, bool stage, int fs
             else if (fs == 16) { if (nw == 8) launch_one<true, 1, 1, 8, true, 16>(p, st); else launch_one<true, 1, 1, 4, true, 16>(p, st); }
             else if (fs == 8) { if (nw == 8) launch_one<true, 1, 1, 8, true, 8>(p, st); else launch_one<true, 1, 1, 4, true, 8>(p, st); }
             else { if (nw == 8) launch_one<true, 1, 1, 8, true, 4>(p, st); else launch_one<true, 1, 1, 4, true, 4>(p, st); }
+            return;
+        }
+    }
+    if constexpr (BF16 && MT == 2) {
+        if (stage) {
+            QTTS_REQUIRE(fs == 16, QTTS_ERR_ARG, "skinny: narrow strips (fs < 16) are only built for the staged bf16 M<=16 kernel");
+            if (spw == 2) { if (nw == 8) launch_one<true, 2, 2, 8, true, 16>(p, st); else launch_one<true, 2, 2, 4, true, 16>(p, st); }
+            else { if (nw == 8) launch_one<true, 2, 1, 8, true, 16>(p, st); else launch_one<true, 2, 1, 4, true, 16>(p, st); }
             return;
         }
     }
@@ -362,7 +381,7 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16) {
         if (mt == 1) launch_mt<true, 1>(p, spw, nw, stage, fs, st);
-        else if (mt == 2) launch_mt<true, 2>(p, spw, nw, false, fs, st);
+        else if (mt == 2) launch_mt<true, 2>(p, spw, nw, stage, fs, st);
         else launch_mt<true, 4>(p, spw, nw, false, fs, st);
     } else {
         if (mt == 1) launch_mt<false, 1>(p, spw, nw, false, fs, st);

@@ -414,6 +414,16 @@ def test_talker_large_batch_paths(talker_tiny, dev):
     agree = float((o16.codes.cpu().numpy()[:, :2] == r["codes"].numpy()[:, :2]).mean())
     print(f"B=20 bf16 agreement (first 2 frames) {agree:.2f}")
     assert agree >= 0.7
+    # M = 17..32 rows take the LDS-staged GEMM with two m-tiles; M <= 16 the one-tile kernel.  Per row both do the same
+    # arithmetic in the same order, so bf16 results must not depend on how the requests are batched: B = 20 in one batch
+    # == two batches of 10 with the same left padding (row 9 / row 19 are the longest prompt of either half).
+    lens2 = [3 + (5 * i) % 11 for i in range(9)] + [15]
+    lens2 = lens2 + lens2
+    emb2, mask2, tr2, pad2 = synth.rand_prompt(np.random.default_rng(10), t, lens2, 2, scale=0.5)
+    kw = dict(max_new_tokens=6, do_sample=False, subtalker_dosample=False, suppress_tokens=_suppress(t))
+    full = e16.generate(emb2, mask2, tr2, pad2, **kw).codes.cpu().numpy()
+    halves = [e16.generate(emb2[h], mask2[h], tr2[h], pad2, **kw).codes.cpu().numpy() for h in (slice(0, 10), slice(10, 20))]
+    assert np.array_equal(full, np.concatenate(halves, 0)), "bf16 decode is not batch-invariant across the M<=16 / M<=32 kernels"
 
 
 def test_wrapper_end_to_end_custom_voice(dev):
