@@ -426,6 +426,47 @@ def test_talker_large_batch_paths(talker_tiny, dev):
     assert np.array_equal(full, np.concatenate(halves, 0)), "bf16 decode is not batch-invariant across the M<=16 / M<=32 kernels"
 
 
+def test_talker_long_generation_crosses_kv_chunks(talker_tiny, dev):
+    """KV lengths beyond the attention kernel's preloaded window (128 keys fp32 / 256 keys bf16) and across many
+    16-token pages: 290 forced frames.  fp32 bit-exact vs the oracle; bf16 eager == bf16 hipGraph exactly and tracks
+    fp32 on the first frames."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    t, w, g = talker_tiny
+    args = [torch.from_numpy(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
+    N = 291
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    trace = {}
+    with torch.no_grad():
+        r = talker_ref.talker_generate(w, t, *args, max_new_tokens=N, min_new_tokens=N, sp=sp, trace=trace)
+    sc = torch.stack(trace["scores"], 1)
+    top2 = torch.topk(sc, 2, dim=-1)[0]
+    margin = (top2[..., 0] - top2[..., 1]).numpy()
+    kw = dict(max_new_tokens=N, min_new_tokens=N, do_sample=False, subtalker_dosample=False, suppress_tokens=_suppress(t))
+    eng = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=4, max_seq=320, use_graph=True)
+    out = eng.generate(*args, **kw)
+    assert out.n_frames == N - 1
+    oc, rc = out.codes.cpu().numpy(), r["codes"].numpy()
+    diff = np.nonzero((oc != rc).any(axis=(0, 2)))[0]
+    n = int(diff[0]) if diff.size else N - 1
+    print(f"long generation: {n} of {N - 1} frames bit-exact vs the oracle (KV length up to {args[0].shape[1] + n}); "
+          f"min cb-0 margin {float(margin.min()):.2e}")
+    # a wrong key past the preloaded window would show at frame ~115; a last-ulp argmax tie (fp32 summation order) may
+    # legitimately end the comparison late in a 290 x 16 x 3 greedy chain, after which the sequences diverge
+    assert n >= 200, f"first mismatch at frame {n}"
+    del eng
+    res = []
+    for graph in (False, True):
+        e16 = TalkerEngine(t, w, weight_dtype=torch.bfloat16, device=dev, max_batch=4, max_seq=320, use_graph=graph)
+        o16 = e16.generate(*args, **kw)
+        assert o16.n_frames == N - 1
+        c16 = o16.codes.cpu().numpy()
+        assert (c16 >= 0).all() and (c16[..., 0] < t.vocab_size).all() and (c16[..., 1:] < t.cp_vocab_size).all()
+        res.append(c16)
+        del e16
+    assert np.array_equal(res[0], res[1]), "bf16 eager and hipGraph decode differ"
+    assert float((res[0][:, :4] == r["codes"].numpy()[:, :4]).mean()) >= 0.7
+
+
 def test_wrapper_end_to_end_custom_voice(dev):
     """The mirrored `Qwen3TTSModel.generate_custom_voice` from text ids to waveforms (tiny talker + matching tiny
     codec), against oracle talker + oracle codec on the same ids."""
