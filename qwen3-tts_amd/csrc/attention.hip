@@ -33,6 +33,37 @@ __device__ inline float wave_max64(float v) {
     return v;
 }
 
+// DPP row rotations (VALU rate) instead of ds_bpermute shuffles (LDS crossbar, ~100 cycles each) for the reductions the
+// decode kernel runs once per key: after ror 8/4/2/1 every lane of a 16-lane row holds the row's sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x122>(v);   // row_ror:2
+    v += dpp_mov<0x121>(v);   // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x122>(v));
+    v = fmaxf(v, dpp_mov<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// whole-wave results combined from the four row results in a fixed order, identical in every lane
+__device__ __forceinline__ float wave_sum64_dpp(float v) {
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max64_dpp(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+
 // =================================================================================== attn_rows
 template <int HD>
 __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
@@ -204,8 +235,10 @@ void launch_qknorm_rope_store(const QkNormRopeParams& p, hipStream_t st) {
 // are issued at kernel entry; q/k RMSNorm + RoPE of the new tokens runs underneath them; later KV chunks are
 // prefetched one chunk ahead.  Key s is owned by lane group (s % 16); new keys come from LDS, old ones from
 // the paged cache (page = table[b][s/16], or b*pages_per_seq + s/16 when the pool is laid out contiguously).
-// LDS: qs[NQ][128] | kn[n_new][128] | vn[n_new][128] | red[4][NQ][128] | sc[NQ][max_len] | stat[NQ]
-template <typename KVT>
+// The per-key inner loops are branch-free over the 4 keys of a chunk (independent dot products interleave), use DPP
+// row reductions, and handle the 1-2 NEW keys in a separate tiny pass; the 16 key groups combine through LDS.
+// LDS: qs[NQ][128] | kn[n_new][128] | vn[n_new][128] | red[16][NQ][128] | sc[NQ][max_len] | stat[NQ]
+template <typename KVT, int NQ>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     constexpr int HD = 128;
     constexpr int CH = 4;                      // keys per lane group per chunk (64 keys per workgroup chunk)
@@ -213,12 +246,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float sm_ad[];
     const int GQ = p.nh / p.nkv;
-    const int NQ = p.n_new * GQ;
     float* qs = sm_ad;                         // [NQ][HD]   (query index = t*GQ + gq)
     float* kn = qs + NQ * HD;                  // [n_new][HD]
     float* vn = kn + p.n_new * HD;             // [n_new][HD]
-    float* red = vn + p.n_new * HD;            // [4][NQ][HD]
-    float* sc = red + 4 * NQ * HD;             // [NQ][max_len]
+    float* red = vn + p.n_new * HD;            // [16][NQ][HD]
+    float* sc = red + 16 * NQ * HD;            // [NQ][max_len]
     float* stat = sc + NQ * p.max_len;         // [NQ]
 
     const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
@@ -261,16 +293,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     u32x4 kR[NPRE][CH][KW], vR[NPRE][CH][KW];
     load_chunk(kR[0], kc, 0);
     load_chunk(vR[0], vc, 0);
-    const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step
-    const int npad = p.n_pad ? p.n_pad[b] : 0;
-    const int done = p.done_flag ? *p.done_flag : 0;
-    const int S1 = S0 + p.n_new;               // total keys
-    const int nchunk = (S1 + 16 * CH - 1) / (16 * CH);
-#pragma unroll
-    for (int c = 1; c < NPRE; ++c)
-        if (c < nchunk) { load_chunk(kR[c], kc, c); load_chunk(vR[c], vc, c); }
-
-    // ---- 1. q/k RMSNorm + RoPE for the new tokens (one wave per vector), K/V append
+    const bool deep = p.max_len > 64;          // long-sequence stack (talker): the second chunk is almost always needed
+    if (deep) { load_chunk(kR[1], kc, 1); load_chunk(vR[1], vc, 1); }
+    // this step's q/k/v rows are requested BEFORE the length-dependent chunks: loads return in order, and stage 1
+    // (norm + RoPE + append) should overlap the rest of the KV stream instead of queueing behind it
     const int nvec = NQ + 2 * p.n_new;  // q vectors, then k, then v
     float x0v[2], x1v[2];               // up to 2 vectors per wave (nvec <= 8)
 #pragma unroll
@@ -286,6 +312,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
             x0v[r] = src[lane]; x1v[r] = src[lane + 64];
         }
     }
+    const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step
+    const int npad = p.n_pad ? p.n_pad[b] : 0;
+    const int done = p.done_flag ? *p.done_flag : 0;
+    const int S1 = S0 + p.n_new;               // total keys
+    const int nchunk = (S1 + 16 * CH - 1) / (16 * CH);
+#pragma unroll
+    for (int c = 1; c < NPRE; ++c)
+        if (c < nchunk && !(deep && c == 1)) { load_chunk(kR[c], kc, c); load_chunk(vR[c], vc, c); }
+
+    // ---- 1. q/k RMSNorm + RoPE for the new tokens (one wave per vector), K/V append
     if (done) return;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         else { t = vi - NQ - p.n_new; dst = vn + t * HD; }
         float x0 = x0v[r], x1 = x1v[r];
         if (w) {
-            const float ss = wave_sum64(x0 * x0 + x1 * x1);
+            const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
             const float rs = rsqrtf(ss / (float)HD + p.eps);
             x0 = w[lane] * (x0 * rs);
             x1 = w[lane + 64] * (x1 * rs);
@@ -321,31 +357,40 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
     __syncthreads();
 
-    // ---- 2. scores: 16 lanes per key (8 dims each), 16 keys per sweep, chunked with one-chunk-ahead prefetch
+    // ---- 2. scores: 16 lanes per key (8 dims each), 16 keys per sweep.  Old keys (s < S0) come from the cache
+    // registers, branch-free; the n_new fresh keys from LDS in their own pass.
     const float scale = rsqrtf((float)HD);
-    float qreg[4][8];
+    float qreg[NQ][8];
 #pragma unroll
-    for (int qi = 0; qi < 4; ++qi)
+    for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qreg[qi][e] = qi < NQ ? qs[qi * HD + li * 8 + e] : 0.f;
+        for (int e = 0; e < 8; ++e) qreg[qi][e] = qs[qi * HD + li * 8 + e];
     auto score_chunk = [&](const u32x4 (&r)[CH][KW], int c) {
+        float d[CH][NQ];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int s = g + 16 * (c * CH + i);
-            if (s >= S1) break;
             float kx[8];
-            if (s >= S0) {
+            unpack(r[i], kx);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) kx[e] = kn[(s - S0) * HD + li * 8 + e];
-            } else unpack(r[i], kx);
+            for (int qi = 0; qi < NQ; ++qi) {
+                float a = 0.f;
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) {
-                if (qi >= NQ) break;
-                float d = 0.f;
+                for (int e = 0; e < 8; ++e) a += qreg[qi][e] * kx[e];
+                d[i][qi] = a;
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) d += qreg[qi][e] * kx[e];
-                d = group16_sum(d) * scale;
-                if (li == 0) sc[qi * p.max_len + s] = (s >= npad && s <= S0 + qi / GQ) ? d : -INFINITY;
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) d[i][qi] = row16_sum(d[i][qi]);
+        if (li == 0) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int s = g + 16 * (c * CH + i);
+                if (s < S0) {
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) sc[qi * p.max_len + s] = s >= npad ? d[i][qi] * scale : -INFINITY;
+                }
             }
         }
     };
@@ -357,45 +402,54 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         load_chunk(kB, kc, c);
         score_chunk(kB, c);
     }
+    for (int t = 0; t < p.n_new; ++t) {         // the fresh keys: key S0+t belongs to group (S0+t) % 16
+        const int s = S0 + t;
+        if (g == (s & 15)) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += qreg[qi][e] * kn[t * HD + li * 8 + e];
+                a = row16_sum(a) * scale;
+                if (li == 0) sc[qi * p.max_len + s] = (s >= npad && s <= S0 + qi / GQ) ? a : -INFINITY;
+            }
+        }
+    }
     __syncthreads();
-    // ---- 3. softmax statistics: wave qi % 4 handles query qi
-    for (int qi = wave; qi < NQ; qi += 4) {
+    // ---- 3. softmax statistics: wave qi handles query qi
+    if (wave < NQ) {
+        const int qi = wave;
         float m = -INFINITY;
         for (int s = lane; s < S1; s += 64) m = fmaxf(m, sc[qi * p.max_len + s]);
-        m = wave_max64(m);
+        m = wave_max64_dpp(m);
         float l = 0.f;
         for (int s = lane; s < S1; s += 64) {
             const float e = expf(sc[qi * p.max_len + s] - m);
             sc[qi * p.max_len + s] = e;
             l += e;
         }
-        l = wave_sum64(l);
+        l = wave_sum64_dpp(l);
         if (lane == 0) stat[qi] = 1.f / l;
     }
     __syncthreads();
     // ---- 4. PV: same key ownership, accumulate 8 dims per lane per query
-    float acc[4][8];
+    float acc[NQ][8];
 #pragma unroll
-    for (int qi = 0; qi < 4; ++qi)
+    for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
     auto pv_chunk = [&](const u32x4 (&r)[CH][KW], int c) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int s = g + 16 * (c * CH + i);
-            if (s >= S1) break;
-            if (s < npad) continue;            // left-pad slots were never written: 0 * garbage could be NaN
+            const bool valid = s < S0 && s >= npad;      // left-pad slots were never written; slots >= S0 hold nothing yet
             float vx[8];
-            if (s >= S0) {
+            unpack(r[i], vx);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vx[e] = vn[(s - S0) * HD + li * 8 + e];
-            } else unpack(r[i], vx);
+            for (int qi = 0; qi < NQ; ++qi) {
+                const float pr = valid ? sc[qi * p.max_len + s] : 0.f;
 #pragma unroll
-            for (int qi = 0; qi < 4; ++qi) {
-                if (qi >= NQ) break;
-                const float pr = sc[qi * p.max_len + s];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[qi][e] += pr * vx[e];
+                for (int e = 0; e < 8; ++e) acc[qi][e] += pr * (valid ? vx[e] : 0.f);
             }
         }
     };
@@ -407,27 +461,30 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         load_chunk(vB, vc, c);
         pv_chunk(vB, c);
     }
-    // reduce the 4 key groups of a wave (lanes l, l^16, l^32), then the 4 waves through LDS
+    for (int t = 0; t < p.n_new; ++t) {
+        const int s = S0 + t;
+        if (g == (s & 15) && s >= npad) {
 #pragma unroll
-    for (int qi = 0; qi < 4; ++qi)
+            for (int qi = 0; qi < NQ; ++qi) {
+                const float pr = sc[qi * p.max_len + s];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            acc[qi][e] += __shfl_xor(acc[qi][e], 16);
-            acc[qi][e] += __shfl_xor(acc[qi][e], 32);
+                for (int e = 0; e < 8; ++e) acc[qi][e] += pr * vn[t * HD + li * 8 + e];
+            }
         }
-    if (lane < 16) {
+    }
+    // the 16 key groups combine through LDS in a fixed order
 #pragma unroll
-        for (int qi = 0; qi < 4; ++qi) {
-            if (qi >= NQ) break;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[(wave * NQ + qi) * HD + lane * 8 + e] = acc[qi][e];
-        }
+    for (int qi = 0; qi < NQ; ++qi) {
+        float4* dst = reinterpret_cast<float4*>(red + (g * NQ + qi) * HD + li * 8);
+        dst[0] = make_float4(acc[qi][0], acc[qi][1], acc[qi][2], acc[qi][3]);
+        dst[1] = make_float4(acc[qi][4], acc[qi][5], acc[qi][6], acc[qi][7]);
     }
     __syncthreads();
     for (int i = tid; i < NQ * HD; i += 256) {
         const int qi = i / HD, d = i % HD;
-        const float v = (red[(0 * NQ + qi) * HD + d] + red[(1 * NQ + qi) * HD + d]) +
-                        (red[(2 * NQ + qi) * HD + d] + red[(3 * NQ + qi) * HD + d]);
+        float v = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) v += red[(gg * NQ + qi) * HD + d];
         const int t = qi / GQ, gq = qi % GQ;
         const size_t o = ((size_t)t * p.B + b) * p.ldo + (kvh * GQ + gq) * HD + d;
         if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(v * stat[qi]);
@@ -435,23 +492,33 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
 }
 
+template <typename KVT, int NQ>
+static void launch_attn_decode_t(const AttnDecodeParams& p, size_t lds, hipStream_t st) {
+    auto kern = attn_decode_kernel<KVT, NQ>;
+    static bool attr_set = false;      // one flag per instantiation
+    if (lds > 48 * 1024 && !attr_set) {
+        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B * p.nkv), dim3(256), lds, st, p);
+}
+
 void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.hd == 128, QTTS_ERR_ARG, "attn_decode: head_dim must be 128");
     const int GQ = p.nh / p.nkv, NQ = p.n_new * GQ;
-    QTTS_REQUIRE(NQ <= 4 && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: at most 4 queries per kv head");
-    const size_t lds = ((size_t)NQ * 128 + 2 * p.n_new * 128 + 4 * NQ * 128 + (size_t)NQ * p.max_len + 8) * sizeof(float);
+    QTTS_REQUIRE((NQ == 1 || NQ == 2 || NQ == 4) && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: 1, 2 or 4 queries per kv head");
+    const size_t lds = ((size_t)NQ * 128 + 2 * p.n_new * 128 + 16 * NQ * 128 + (size_t)NQ * p.max_len + 8) * sizeof(float);
     QTTS_REQUIRE(lds <= 150 * 1024, QTTS_ERR_LIMIT, "attn_decode: max_len too large for LDS scores");
-    auto kern = p.kv.bf16 ? attn_decode_kernel<bf16_t> : attn_decode_kernel<float>;
-    if (lds > 48 * 1024) {
-        static bool set_bf = false, set_f = false;
-        bool& flag = p.kv.bf16 ? set_bf : set_f;
-        if (!flag) {
-            QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            flag = true;
-        }
+    if (p.kv.bf16) {
+        if (NQ == 1) launch_attn_decode_t<bf16_t, 1>(p, lds, st);
+        else if (NQ == 2) launch_attn_decode_t<bf16_t, 2>(p, lds, st);
+        else launch_attn_decode_t<bf16_t, 4>(p, lds, st);
+    } else {
+        if (NQ == 1) launch_attn_decode_t<float, 1>(p, lds, st);
+        else if (NQ == 2) launch_attn_decode_t<float, 2>(p, lds, st);
+        else launch_attn_decode_t<float, 4>(p, lds, st);
     }
-    hipLaunchKernelGGL(kern, dim3(p.B * p.nkv), dim3(256), lds, st, p);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
