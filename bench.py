@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-budget-s", type=float, default=90.0, help="wall-clock cap of the CPU-baseline leg")
     args = ap.parse_args()
 

@@ -15,54 +15,9 @@
 
 namespace qtts {
 
-__device__ inline float group16_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    return v;
-}
-__device__ inline float wave_sum64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ inline float wave_max64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
-// DPP row rotations (VALU rate) instead of ds_bpermute shuffles (LDS crossbar, ~100 cycles each) for the reductions the
-// decode kernel runs once per key: after ror 8/4/2/1 every lane of a 16-lane row holds the row's sum.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_mov<0x128>(v);   // row_ror:8
-    v += dpp_mov<0x124>(v);   // row_ror:4
-    v += dpp_mov<0x122>(v);   // row_ror:2
-    v += dpp_mov<0x121>(v);   // row_ror:1
-    return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_mov<0x128>(v));
-    v = fmaxf(v, dpp_mov<0x124>(v));
-    v = fmaxf(v, dpp_mov<0x122>(v));
-    v = fmaxf(v, dpp_mov<0x121>(v));
-    return v;
-}
-__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-// whole-wave results combined from the four row results in a fixed order, identical in every lane
-__device__ __forceinline__ float wave_sum64_dpp(float v) {
-    v = row16_sum(v);
-    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
-}
-__device__ __forceinline__ float wave_max64_dpp(float v) {
-    v = row16_max(v);
-    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
-}
+__device__ inline float group16_sum(float v) { return row16_sum(v); }
+__device__ inline float wave_sum64(float v) { return wave_sum64_dpp(v); }
+__device__ inline float wave_max64(float v) { return wave_max64_dpp(v); }
 
 // =================================================================================== attn_rows
 template <int HD>

@@ -57,6 +57,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));  // 8 bf16 = 4 VGPRs (MFMA operand type)
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
+// ------------------------------------------------------------------------------------------ cross-lane reductions
+// DPP row rotations (VALU rate) instead of ds_bpermute shuffles (LDS crossbar, ~100 cycles each) for the reductions the
+// hot kernels run per key / per row: after ror 8/4/2/1 every lane of a 16-lane row holds the row's sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x122>(v);   // row_ror:2
+    v += dpp_mov<0x121>(v);   // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x122>(v));
+    v = fmaxf(v, dpp_mov<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// whole-wave results combined from the four row results in a fixed order, identical in every lane
+__device__ __forceinline__ float wave_sum64_dpp(float v) {
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max64_dpp(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+
+
 // ------------------------------------------------------------------------------------------ device memory
 struct DevBuf {
     void* p = nullptr;

@@ -153,8 +153,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
                 }
                 if (p.norm) {
                     float q = v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                    q = wave_sum64_dpp(q);
                     if (lane == 0 && idx < total) rsum[row * NW + wave] += q;
                 }
             }
@@ -176,8 +175,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
                         q += a * a + b2 * b2;
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                q = wave_sum64_dpp(q);
                 if (lane == 0) rsum[row * NW] = q;
             }
             __syncthreads();
