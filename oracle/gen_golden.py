@@ -417,9 +417,49 @@ def gen_prompt_tiny():
     np.savez_compressed(os.path.join(GOLDEN, "prompt_tiny.npz"), **out)
 
 
+def gen_ckpt_tiny():
+    """The JSON side of a checkpoint directory, written by the REFERENCE's own config classes, so that the mirrored
+    `from_pretrained` is tested against the reference's serialisation (nested talker_config / code_predictor_config /
+    decoder_config, rope_scaling, speaker tables...).  Weights and the text tokenizer are produced by the test itself
+    (tests/ckpt_util.py) from oracle/synth.py."""
+    ref_shims.install()
+    import json
+    from qwen_tts.core.tokenizer_12hz.configuration_qwen3_tts_tokenizer_v2 import (Qwen3TTSTokenizerV2Config,
+                                                                                   Qwen3TTSTokenizerV2DecoderConfig)
+    t = synth.talker_tiny()
+    c = synth.codec_tiny()
+    c.codebook_size = t.cp_vocab_size                 # the codec codebooks must cover the talker's code range
+    _, TopConfig, tk = ref_talker_cfgs(t)
+    top = TopConfig(talker_config=tk, tts_model_type="custom_voice", tts_model_size="tiny", tokenizer_type="12hz",
+                    im_start_token_id=t.im_start_token_id, im_end_token_id=t.im_end_token_id,
+                    tts_pad_token_id=t.tts_pad_token_id, tts_bos_token_id=t.tts_bos_token_id,
+                    tts_eos_token_id=t.tts_eos_token_id)
+    dec = Qwen3TTSTokenizerV2DecoderConfig(
+        codebook_size=c.codebook_size, codebook_dim=c.codebook_dim, hidden_size=c.hidden_size,
+        latent_dim=c.latent_dim, num_attention_heads=c.num_attention_heads,
+        num_key_value_heads=c.num_key_value_heads, head_dim=c.head_dim, sliding_window=c.sliding_window,
+        intermediate_size=c.intermediate_size, num_hidden_layers=c.num_hidden_layers,
+        num_quantizers=c.num_quantizers, upsample_rates=c.upsample_rates,
+        upsampling_ratios=c.upsampling_ratios, decoder_dim=c.decoder_dim, rms_norm_eps=c.rms_norm_eps,
+        rope_theta=c.rope_theta, max_position_embeddings=c.max_position_embeddings)
+    tokc = Qwen3TTSTokenizerV2Config(decoder_config=dec.to_dict(), decode_upsample_rate=c.total_upsample,
+                                     encode_downsample_rate=c.total_upsample)
+    out = os.path.join(GOLDEN, "ckpt_tiny")
+    os.makedirs(os.path.join(out, "speech_tokenizer"), exist_ok=True)
+    with open(os.path.join(out, "config.json"), "w") as f:
+        f.write(top.to_json_string())
+    with open(os.path.join(out, "speech_tokenizer", "config.json"), "w") as f:
+        f.write(tokc.to_json_string())
+    with open(os.path.join(out, "generation_config.json"), "w") as f:      # the keys the wrapper reads (IM:287-352)
+        json.dump(dict(do_sample=True, top_k=50, top_p=1.0, temperature=0.9, repetition_penalty=1.05,
+                       subtalker_dosample=True, subtalker_top_k=50, subtalker_top_p=1.0, subtalker_temperature=0.9,
+                       max_new_tokens=8192), f, indent=1)
+    print("ckpt_tiny: wrote", sorted(os.listdir(out)))
+
+
 ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
        "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
-       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32}
+       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

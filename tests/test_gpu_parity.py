@@ -505,3 +505,45 @@ def test_wrapper_end_to_end_custom_voice(dev):
         assert a.shape[0] == b.shape[0] == 8 * 1920
         assert _rms(a, b.numpy()) <= RMS_BAR
     assert tts.get_supported_languages() == ["auto", "chinese", "english"]
+
+
+def test_from_pretrained_checkpoint_directory_custom_voice(dev, golden_dir, tmp_path):
+    """The examples' entry point, unchanged (examples/test_model_12hz_custom_voice.py): `Qwen3TTSModel.from_pretrained(dir,
+    device_map="cuda:0", dtype=..., attn_implementation="flash_attention_2")` on a checkpoint DIRECTORY whose JSON files
+    were written by the reference's own config classes (tests/golden/ckpt_tiny), weights in safetensors under the
+    reference's key prefixes, an HF fast tokenizer -- then `generate_custom_voice` from plain text, against oracle
+    talker + oracle codec on the same token ids."""
+    import json
+    from ckpt_util import make_tiny_checkpoint
+    from qwen3_tts_amd import Qwen3TTSModel
+    t = synth.talker_tiny()
+    wn = synth.talker_weights(t)
+    c = synth.codec_tiny()
+    c.codebook_size = t.cp_vocab_size
+    cw = synth.codec_weights(c)
+    path = make_tiny_checkpoint(str(tmp_path / "ckpt"), golden_dir, t, wn, c, cw)
+    tts = Qwen3TTSModel.from_pretrained(path, device_map=dev, dtype=torch.float32, attn_implementation="flash_attention_2",
+                                        max_batch=4, max_seq=160)
+    assert tts.model.tts_model_type == "custom_voice" and tts.model.tokenizer_type == "12hz"
+    assert sorted(tts.get_supported_speakers()) == ["ryan", "vivian"]
+    with open(os.path.join(path, "generation_config.json")) as f:
+        assert tts.generate_defaults == json.load(f)
+    texts, spk, langs = ["hello world", "a rather longer sentence to speak"], ["Vivian", "ryan"], ["English", "Chinese"]
+    wavs, sr = tts.generate_custom_voice(text=texts, speaker=spk, language=langs, instruct=["whisper", ""], do_sample=False,
+                                         subtalker_dosample=False, max_new_tokens=9)
+    assert sr == 24000 and len(wavs) == 2
+    ids = tts._tokenize_texts([tts._build_assistant_text(x) for x in texts])
+    assert ids[0][0, :3].tolist() == [t.im_start_token_id, 77, 198] and ids[0][0, -5:].tolist() == [t.im_end_token_id, 198, t.im_start_token_id, 77, 198]
+    ins = tts._tokenize_texts([tts._build_instruct_text("whisper")])[0]
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    with torch.no_grad():
+        rc, _ = talker_ref.generate(_td(wn), t, [i.cpu() for i in ids], [x.lower() for x in langs], [x.lower() for x in spk],
+                                    [ins.cpu(), None], True, max_new_tokens=9, sp=sp)
+        rw = codec_ref.model_decode(_td(cw), c, torch.nn.utils.rnn.pad_sequence(rc, batch_first=True, padding_value=-1))
+    for a, b in zip(wavs, rw):
+        assert a.shape[0] == b.shape[0]
+        assert _rms(a, b.numpy()) <= RMS_BAR
+    with pytest.raises(ValueError):
+        tts.generate_custom_voice(text="x", speaker="nobody", language="english")
+    with pytest.raises(ValueError):
+        tts.generate_voice_design(text="x", instruct="y")            # wrong model type for this checkpoint (IM:401-407)

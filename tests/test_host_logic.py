@@ -187,3 +187,40 @@ def test_prompt_plan_reproduces_reference_prompts(golden_dir):
         build_prompt_plan(cfg, [torch.from_numpy(g["cv_ns_ids0"])], ["klingon"], ["vivian"])
     with pytest.raises(NotImplementedError):
         build_prompt_plan(cfg, [torch.from_numpy(g["cv_ns_ids0"])], ["english"], ["nobody"])
+
+
+def test_checkpoint_directory_configs_and_no_cpu_path(golden_dir, tmp_path):
+    """`from_pretrained` inputs without a GPU: the reference-written config.json files parse to the right dimensions,
+    the HF tokenizer in the directory produces the id layout the prompt slicing assumes, and loading onto a CPU
+    device fails loudly (there is no CPU product path)."""
+    import json
+    import os
+    import pytest
+    import synth
+    from ckpt_util import make_tiny_checkpoint
+    from qwen3_tts_amd import Qwen3TTSModel, _lib
+    from qwen3_tts_amd.config import CodecDecoderConfig, TalkerConfig
+    from qwen3_tts_amd.model import _TextProcessor
+    t = synth.talker_tiny()
+    c = synth.codec_tiny()
+    c.codebook_size = t.cp_vocab_size
+    path = make_tiny_checkpoint(str(tmp_path / "ckpt"), golden_dir, t, synth.talker_weights(t), c, synth.codec_weights(c))
+    with open(os.path.join(path, "config.json")) as f:
+        tc = TalkerConfig.from_any(json.load(f))
+    want = synth.cfg_dict(t)
+    for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads",
+              "head_dim", "num_code_groups", "text_hidden_size", "text_vocab_size", "codec_eos_token_id", "codec_pad_id",
+              "codec_bos_id", "cp_vocab_size", "cp_hidden_size", "cp_intermediate_size", "cp_num_hidden_layers",
+              "cp_num_attention_heads", "cp_num_key_value_heads", "cp_head_dim", "im_start_token_id", "tts_pad_token_id"):
+        assert getattr(tc, k) == want[k], k
+    assert tc.spk_id == t.spk_id and tc.codec_language_id == t.codec_language_id and tc.tts_model_type == "custom_voice"
+    with open(os.path.join(path, "speech_tokenizer", "config.json")) as f:
+        cc = CodecDecoderConfig.from_any(json.load(f))
+    for k, v in synth.cfg_dict(c).items():
+        got = getattr(cc, k)
+        assert (tuple(got) == tuple(v)) if isinstance(v, (tuple, list)) else (got == v), k
+    ids = _TextProcessor(path)("<|im_start|>assistant\nhi<|im_end|>\n<|im_start|>assistant\n")["input_ids"][0].tolist()
+    assert ids[:3] == [t.im_start_token_id, 77, 198] and ids[-5:] == [t.im_end_token_id, 198, t.im_start_token_id, 77, 198]
+    assert len(ids) == 3 + 2 + 5
+    with pytest.raises(_lib.QttsError):
+        Qwen3TTSModel.from_pretrained(path, device_map="cpu")
