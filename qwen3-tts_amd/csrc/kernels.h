@@ -138,6 +138,9 @@ struct SampleParams {
     int* final_count;                        // n_generated at the moment done was set
     int max_new_tokens;
     const int* done_in;                      // early exit
+    // optional fused gather (code predictor): gather_out[b][:] = gather_emb[token][:] -- the NEXT pass's input row
+    // (codec_embedding[j](token), M:1281), so no separate gather kernel sits between sampler and GEMM
+    const float* gather_emb; int gather_C; float* gather_out; unsigned short* gather_out16;
 };
 void launch_sample(const SampleParams& p, hipStream_t st);
 

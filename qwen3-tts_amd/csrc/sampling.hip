@@ -286,6 +286,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
 
     if (token < 0 || token >= V) token = 0;   // all-NaN logits must not turn into an out-of-range gather index
+    if (p.gather_emb) {                         // every thread holds the same token (block-uniform by construction)
+        const float* src = p.gather_emb + (size_t)token * p.gather_C;
+        for (int c = tid * 4; c < p.gather_C; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v;
+            if (p.gather_out16) {
+                ushort4 h; h.x = f32_to_bf16(v.x); h.y = f32_to_bf16(v.y); h.z = f32_to_bf16(v.z); h.w = f32_to_bf16(v.w);
+                *reinterpret_cast<ushort4*>(p.gather_out16 + (size_t)b * p.gather_C + c) = h;
+            }
+        }
+    }
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];

@@ -428,9 +428,10 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         gp.cur_tok = cur_tok.as<int>(); gp.cp_emb = emb_cp.as<float>(); gp.cp_vocab = c.cp_vocab_size;
         gp.sub = sub.as<int>(); gp.sub_stride = G; gp.done = ss.done;
         unsigned short* c16 = bf16 ? cp_x16.as<unsigned short>() : nullptr;
+        // passes j >= 1 get their input row from the previous pass's sampler (fused gather): only pass 0 gathers here
         if (has_proj) {
             gp.out = cp_in.as<float>(); gp.out16 = nullptr;
-            if (!skinny_only) launch_cp_gather(gp, st);
+            if (!skinny_only && j == 0) launch_cp_gather(gp, st);
             SkinnyParams pj{};
             pj.done_flag = ss.done;
             pj.x = cp_in.as<float>(); pj.ldx = td.H; pj.M = M; pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
@@ -439,7 +440,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
             skinny(pj, st);
         } else {
             gp.out = cp_x.as<float>(); gp.out16 = c16;
-            if (!skinny_only) launch_cp_gather(gp, st);
+            if (!skinny_only && j == 0) launch_cp_gather(gp, st);
         }
         for (int l = 0; l < c.cp_num_hidden_layers; ++l)
             decode_layer(cl[l], cd, cp_x.as<float>(), c16, cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
@@ -458,6 +459,11 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         s.top_p = sp.subtalker_top_p; s.temperature = sp.subtalker_temperature; s.seed = sp.seed; s.stream_id = 1 + j;
         s.seed_dev = seed_d.as<unsigned long long>();
         s.step_dev = ss.n_generated; s.tok_out = sub.as<int>() + j; s.tok_stride = G; s.done_in = ss.done;
+        if (j + 1 < G - 1) {       // next pass's input = codec_embedding[j](this token) (M:1281)
+            s.gather_emb = emb_cp.as<float>() + (size_t)j * c.cp_vocab_size * td.H; s.gather_C = td.H;
+            s.gather_out = has_proj ? cp_in.as<float>() : cp_x.as<float>();
+            s.gather_out16 = has_proj ? nullptr : c16;
+        }
         if (!skinny_only) launch_sample(s, st);
     }
     // ---- next talker input + frame outputs (M:1681-1692)
