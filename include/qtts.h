@@ -42,7 +42,8 @@ extern "C" {
 #define QTTS_BF16 1 /* perf mode:   bf16 weights + KV, v_mfma_f32_16x16x32_bf16, f32 accum  */
 
 const char* qtts_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows). */
+#define QTTS_ABI_VERSION 2
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------

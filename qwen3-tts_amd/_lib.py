@@ -51,6 +51,8 @@ class TalkerStatsC(C.Structure):
                 ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64)]
 
 
+ABI_VERSION = 2           # include/qtts.h; bumped on any signature change
+
 # every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
            "qtts_codec_finalize", "qtts_codec_forward", "qtts_codec_decode", "qtts_codec_forward_stage",
@@ -101,7 +103,7 @@ def load_library():
     for s in SYMBOLS:
         if s not in ("qtts_last_error", "qtts_codec_destroy", "qtts_talker_destroy"):
             getattr(lib, s).restype = C.c_int
-    if lib.qtts_abi_version() != 2:
+    if lib.qtts_abi_version() != ABI_VERSION:
         raise QttsError(-101, "libqtts.so ABI version mismatch; rebuild")
     _LIB = lib
     return lib

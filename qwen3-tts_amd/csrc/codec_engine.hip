@@ -475,7 +475,7 @@ void set_last_error(const std::string& s) { g_last_error = s; }
 extern "C" {
 
 const char* qtts_last_error(void) { return qtts::g_last_error.c_str(); }
-int qtts_abi_version(void) { return 2; }
+int qtts_abi_version(void) { return QTTS_ABI_VERSION; }
 
 int qtts_codec_create(const qtts_codec_config* cfg, qtts_codec** out) {
     QTTS_API_BEGIN

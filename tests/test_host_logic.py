@@ -24,7 +24,8 @@ def test_abi_exports_every_declared_symbol(libqtts):
     from qwen3_tts_amd import _lib
     assert declared == set(_lib.SYMBOLS), "python binding and header disagree"
     lib.qtts_abi_version.restype = ctypes.c_int
-    assert lib.qtts_abi_version() == 2
+    from qwen3_tts_amd import _lib as _l
+    assert lib.qtts_abi_version() == _l.ABI_VERSION
 
 
 def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
