@@ -109,6 +109,18 @@ def load_library():
     return lib
 
 
+def locked(fn):
+    """One engine handle per (process, device), not re-entrant (include/qtts.h): serialise callers that share an
+    engine object -- the reference's demo serves from a worker pool (cli/demo.py:629)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self._lock:
+            return fn(self, *a, **k)
+    return wrapper
+
+
 def check(rc: int):
     if rc != 0:
         raise QttsError(rc, (load_library().qtts_last_error() or b"").decode(errors="replace"))

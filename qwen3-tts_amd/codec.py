@@ -7,6 +7,7 @@ Reference classes mirrored (same names, argument meaning and error behaviour):
 All arithmetic runs in the HIP library; torch only owns the device buffers.
 """
 import ctypes as C
+import threading
 import json
 import os
 from dataclasses import dataclass
@@ -46,6 +47,7 @@ class CodecDecoderEngine:
         self.compute_dtype = compute_dtype
         self.max_batch, self.max_frames = int(max_batch), int(max_frames)
         self._lib = _lib.load_library()
+        self._lock = threading.RLock()
         c = self.config
         cc = _lib.CodecConfigC()
         for f in ("codebook_size", "codebook_dim", "hidden_size", "latent_dim", "num_attention_heads",
@@ -87,6 +89,7 @@ class CodecDecoderEngine:
         if codes.shape[q_dim] != self.config.num_quantizers:
             raise ValueError(f"Expected {self.config.num_quantizers} layer of codes, got {codes.shape[q_dim]}")  # v2:870-871
 
+    @_lib.locked
     def forward(self, codes: torch.Tensor, return_pre_clamp: bool = False):
         """Qwen3TTSTokenizerV2Decoder.forward (v2:869-884): codes (B, Q, T) -> (B, 1, T*1920)."""
         self._check_codes(codes, 1)
@@ -102,6 +105,7 @@ class CodecDecoderEngine:
 
     __call__ = forward
 
+    @_lib.locked
     def forward_stage(self, codes: torch.Tensor, stage: str) -> torch.Tensor:
         """Diagnostic: activation after `stage`, channel-last (B, L, C)."""
         self._check_codes(codes, 1)
@@ -115,6 +119,7 @@ class CodecDecoderEngine:
                                                           C.c_void_p(out.data_ptr()), cap, C.byref(L), C.byref(Cc), self._stream()))
         return out[: B * L.value * Cc.value].view(B, L.value, Cc.value)
 
+    @_lib.locked
     def decode_padded(self, audio_codes: torch.Tensor, chunk_size: int = 300, left_context_size: int = 25
                       ) -> Tuple[torch.Tensor, List[int]]:
         """Body of Qwen3TTSTokenizerV2Model.decode (v2:1012-1015): audio_codes (B, T, Q) padded with -1

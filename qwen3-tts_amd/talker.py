@@ -6,6 +6,7 @@
 Qwen3TTSTalkerForConditionalGeneration.forward (M:1636-1744).  All arithmetic runs in the HIP library.
 """
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
 
@@ -43,6 +44,7 @@ class TalkerEngine:
         self.weight_dtype = weight_dtype
         self.max_batch, self.max_seq = int(max_batch), int(max_seq)
         self._lib = _lib.load_library()
+        self._lock = threading.RLock()
         c = self.config
         tc = _lib.TalkerConfigC()
         for f in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
@@ -82,15 +84,18 @@ class TalkerEngine:
     def _s(self):
         return C.c_void_p(self._stream.cuda_stream)
 
+    @_lib.locked
     def set_profile(self, enable: bool):
         _lib.check(self._lib.qtts_talker_set_profile(self._h, 1 if enable else 0))
 
+    @_lib.locked
     def stats(self) -> dict:
         st = _lib.TalkerStatsC()
         _lib.check(self._lib.qtts_talker_get_stats(self._h, C.byref(st)))
         return {f[0]: getattr(st, f[0]) for f in st._fields_}
 
     # ------------------------------------------------------------------ text_projection (prompt assembly)
+    @_lib.locked
     def text_projection(self, x: torch.Tensor) -> torch.Tensor:
         """Qwen3TTSTalkerResizeMLP (M:808-816): (..., text_hidden) -> (..., hidden), fp32."""
         shp = x.shape
@@ -106,6 +111,7 @@ class TalkerEngine:
         return y.reshape(*shp[:-1], self.config.hidden_size)
 
     # ------------------------------------------------------------------ generate (seam S2)
+    @_lib.locked
     def text_embed(self, ids: torch.Tensor) -> torch.Tensor:
         """text_projection(text_embedding[ids]) on device (M:2076-2080): ids int64 (n,) -> (n, H) fp32."""
         ids = ids.reshape(-1).to(self.device, torch.long).contiguous()
@@ -119,6 +125,7 @@ class TalkerEngine:
         torch.cuda.current_stream(self.device).wait_stream(self._stream)
         return y
 
+    @_lib.locked
     def assemble_rows(self, desc: torch.Tensor, proj: Optional[torch.Tensor] = None, spk: Optional[torch.Tensor] = None,
                       ref_codes: Optional[torch.Tensor] = None) -> torch.Tensor:
         """out[r] = proj[text_row] + codec-side term, from int32 descriptors (rows, 4) = {text_row, codec_id, spk_row,
@@ -143,6 +150,7 @@ class TalkerEngine:
         torch.cuda.current_stream(dev).wait_stream(self._stream)
         return out
 
+    @_lib.locked
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, trailing_text_hidden: torch.Tensor,
                  tts_pad_embed: torch.Tensor, max_new_tokens: int = 2048, min_new_tokens: int = 2,
                  do_sample: bool = True, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,
@@ -213,6 +221,7 @@ class TalkerEngine:
         return TalkerGenerateOutput(codes=codes[:, :nf], hidden=hidden[:, :nf] if hidden is not None else None,
                                     tokens=tokens[:, : nf + 1], n_frames=nf)
 
+    @_lib.locked
     def debug_logits(self) -> torch.Tensor:
         out = torch.empty(self.max_batch, self.config.vocab_size, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

@@ -225,3 +225,40 @@ def test_checkpoint_directory_configs_and_no_cpu_path(golden_dir, tmp_path):
     assert len(ids) == 3 + 2 + 5
     with pytest.raises(_lib.QttsError):
         Qwen3TTSModel.from_pretrained(path, device_map="cpu")
+
+
+def test_engine_calls_are_serialised_per_handle():
+    """`_lib.locked`: the C handles are not re-entrant, so every public engine method holds the engine's lock."""
+    import threading
+    import time
+    from qwen3_tts_amd import _lib
+    from qwen3_tts_amd.codec import CodecDecoderEngine
+    from qwen3_tts_amd.talker import TalkerEngine
+
+    class Dummy:
+        def __init__(self):
+            self._lock = threading.RLock()
+            self.inside = 0
+            self.overlap = False
+
+        @_lib.locked
+        def call(self):
+            self.inside += 1
+            self.overlap = self.overlap or self.inside > 1
+            time.sleep(0.005)
+            self.nested()                      # re-entrant from the same thread
+            self.inside -= 1
+
+        @_lib.locked
+        def nested(self):
+            return 1
+
+    d = Dummy()
+    th = [threading.Thread(target=lambda: [d.call() for _ in range(5)]) for _ in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not d.overlap
+    for cls, names in ((TalkerEngine, ("generate", "text_embed", "assemble_rows", "text_projection")),
+                       (CodecDecoderEngine, ("forward", "decode_padded", "forward_stage"))):
+        for n in names:
+            assert hasattr(getattr(cls, n), "__wrapped__"), f"{cls.__name__}.{n} is not serialised"
