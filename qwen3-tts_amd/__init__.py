@@ -6,13 +6,10 @@ reference's `qwen_tts.inference` API.
 """
 from .config import CodecDecoderConfig, TalkerConfig  # noqa: F401
 from ._lib import QttsError, load_library, library_path  # noqa: F401
-from .codec import CodecDecoderEngine, Qwen3TTSTokenizerV2Model, Qwen3TTSTokenizer  # noqa: F401
+from .codec import CodecDecoderEngine, CodecStreamDecoder, Qwen3TTSTokenizerV2Model, Qwen3TTSTokenizer  # noqa: F401
 from .talker import TalkerEngine  # noqa: F401
-try:
-    from .model import Qwen3TTSForConditionalGeneration, Qwen3TTSModel, VoiceClonePromptItem  # noqa: F401
-except ImportError:  # pragma: no cover - model.py lands in a later commit
-    pass
+from .model import Qwen3TTSForConditionalGeneration, Qwen3TTSModel, VoiceClonePromptItem  # noqa: F401
 
 __all__ = ["CodecDecoderConfig", "TalkerConfig", "QttsError", "load_library", "library_path",
-           "CodecDecoderEngine", "Qwen3TTSTokenizerV2Model", "Qwen3TTSTokenizer", "TalkerEngine",
+           "CodecDecoderEngine", "CodecStreamDecoder", "Qwen3TTSTokenizerV2Model", "Qwen3TTSTokenizer", "TalkerEngine",
            "Qwen3TTSForConditionalGeneration", "Qwen3TTSModel", "VoiceClonePromptItem"]

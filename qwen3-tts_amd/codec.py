@@ -135,11 +135,50 @@ class CodecDecoderEngine:
                                                    int(left_context_size), C.c_void_p(wav.data_ptr()), lens, self._stream()))
         return wav, [int(x) for x in lens]
 
+    def stream(self, left_context_size: int = 25) -> "CodecStreamDecoder":
+        """A packet-by-packet decoder bound to this engine (see CodecStreamDecoder)."""
+        return CodecStreamDecoder(self.forward, self.config.total_upsample, left_context_size)
+
     def chunked_decode(self, codes: torch.Tensor, chunk_size: int = 300, left_context_size: int = 25) -> torch.Tensor:
         """Qwen3TTSTokenizerV2Decoder.chunked_decode (v2:886-896): codes (B, Q, T) -> (B, 1, T*1920)."""
         self._check_codes(codes, 1)
         wav, _ = self.decode_padded(codes.transpose(1, 2), chunk_size, left_context_size)
         return wav.unsqueeze(1)
+
+
+class CodecStreamDecoder:
+    """Packet-by-packet decode for streaming output (first-packet latency, BASELINE config 4).
+
+    The reference has no streaming OUTPUT API (qwen3_tts_model.py:513-515), but its decoder defines how a long code
+    sequence is cut: `chunked_decode(codes, chunk_size, left_context_size)` (tokenizer v2:886-896) decodes every chunk
+    together with up to `left_context_size` previous frames and drops the context's samples.  Pushing packets of k
+    frames through this class emits exactly `chunked_decode(all_codes, chunk_size=k, left_context_size=L)`, chunk by
+    chunk, while holding only the last L frames of codes.  `forward` is any `(B, Q, T) int64 -> (B, 1, T*upsample)`
+    callable: `CodecDecoderEngine.forward` in the product, the oracle's decoder in the CPU test."""
+
+    def __init__(self, forward, total_upsample: int, left_context_size: int = 25):
+        self._forward = forward
+        self.total_upsample = int(total_upsample)
+        self.left_context_size = int(left_context_size)
+        self.reset()
+
+    def reset(self):
+        self._ctx = None            # (B, Q, <= L) codes kept from earlier packets
+        self._start = 0             # frames emitted so far (`start_index` of v2:888)
+
+    def push(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes (B, Q, k) int64 -> waveform (B, 1, k * total_upsample) for exactly these k frames."""
+        if codes.dim() != 3 or codes.shape[-1] < 1:
+            raise ValueError(f"Expected codes of shape (B, Q, k >= 1), got {tuple(codes.shape)}")
+        L = self.left_context_size
+        ctx = L if self._start - L > 0 else self._start                        # v2:891
+        chunk = codes if ctx == 0 else torch.cat([self._ctx[..., self._ctx.shape[-1] - ctx:].to(codes.device), codes], dim=-1)
+        wav = self._forward(chunk)
+        out = wav[..., ctx * self.total_upsample:]
+        keep = chunk[..., max(0, chunk.shape[-1] - L):] if L > 0 else None
+        self._ctx = keep
+        self._start += int(codes.shape[-1])
+        return out
 
 
 @dataclass

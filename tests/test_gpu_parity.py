@@ -99,6 +99,21 @@ def test_codec_edge_cases(codec_tiny):
     assert _rms(wav[0].cpu().numpy(), refs[0].numpy()) <= RMS_BAR and refs[1].numel() == 0
 
 
+def test_codec_stream_decoder_packets(codec_tiny):
+    """Streaming output: packets of 4 frames through `engine.stream(L)` == the engine's (and the oracle's)
+    chunked_decode(chunk_size=4, left_context_size=L) -- the reference's own chunking rule (tokenizer v2:886-896)."""
+    c, w, g, eng = codec_tiny
+    codes = torch.from_numpy(np.random.default_rng(5).integers(0, c.codebook_size, (2, c.num_quantizers, 14)))
+    sd = eng.stream(left_context_size=3)
+    got = torch.cat([sd.push(codes[..., i:i + 4].cuda()) for i in range(0, 14, 4)], dim=-1).cpu()
+    whole = eng.chunked_decode(codes.cuda(), chunk_size=4, left_context_size=3).cpu()
+    assert got.shape == whole.shape == (2, 1, 14 * c.total_upsample)
+    assert torch.equal(got, whole)
+    with torch.no_grad():
+        ref = codec_ref.chunked_decode(w, c, codes, chunk_size=4, left_context_size=3)
+    assert _rms(got.numpy(), ref.numpy()) <= RMS_BAR
+
+
 def test_codec_batch_invariance_and_causality(codec_tiny):
     """Size-independent properties: every row of a batch of identical inputs is identical; the decoder is causal
     (a change in frame t leaves all samples before t*1920 untouched)."""

@@ -262,3 +262,35 @@ def test_engine_calls_are_serialised_per_handle():
                        (CodecDecoderEngine, ("forward", "decode_padded", "forward_stage"))):
         for n in names:
             assert hasattr(getattr(cls, n), "__wrapped__"), f"{cls.__name__}.{n} is not serialised"
+
+
+def test_stream_decoder_equals_reference_chunked_decode(golden_dir):
+    """CodecStreamDecoder (host logic) driven by the ORACLE decoder: packets of k frames == the reference's
+    chunked_decode(chunk_size=k, left_context_size=L) (tokenizer v2:886-896), for several (k, L) incl. L = 0 and
+    T not a multiple of k; ragged packet sizes == the same rule applied packet by packet."""
+    import numpy as np
+    import torch
+    import codec_ref
+    import synth
+    from qwen3_tts_amd.codec import CodecStreamDecoder
+    c = synth.codec_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.codec_weights(c).items()}
+    codes = torch.from_numpy(np.random.default_rng(3).integers(0, c.codebook_size, (2, c.num_quantizers, 11)))
+    fwd = lambda x: codec_ref.decoder_forward(w, c, x)
+    with torch.no_grad():
+        for k, L in ((4, 3), (3, 0), (5, 25), (11, 2)):
+            sd = CodecStreamDecoder(fwd, c.total_upsample, L)
+            got = torch.cat([sd.push(codes[..., i:i + k]) for i in range(0, 11, k)], dim=-1)
+            ref = codec_ref.chunked_decode(w, c, codes, chunk_size=k, left_context_size=L)
+            assert got.shape == ref.shape == (2, 1, 11 * c.total_upsample)
+            assert torch.equal(got, ref), (k, L)
+        sd = CodecStreamDecoder(fwd, c.total_upsample, 3)
+        cuts = [0, 2, 7, 8, 11]
+        got = torch.cat([sd.push(codes[..., a:b]) for a, b in zip(cuts[:-1], cuts[1:])], dim=-1)
+        parts = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ctx = 3 if a - 3 > 0 else a
+            parts.append(fwd(codes[..., a - ctx:b])[..., ctx * c.total_upsample:])
+        assert torch.equal(got, torch.cat(parts, dim=-1))
+        sd.reset()
+        assert torch.equal(sd.push(codes[..., :4]), fwd(codes[..., :4]))
