@@ -294,3 +294,77 @@ def test_stream_decoder_equals_reference_chunked_decode(golden_dir):
         assert torch.equal(got, torch.cat(parts, dim=-1))
         sd.reset()
         assert torch.equal(sd.push(codes[..., :4]), fwd(codes[..., :4]))
+
+
+def test_prompt_plan_randomised_against_oracle():
+    """Differential test of the host row plan over many random batches (mode x streaming x instruct x speaker x language
+    x ICL / x-vector, random lengths): executing the plan with CPU stand-ins for the two HIP calls must reproduce the
+    oracle's `assemble_prompts` (which is itself pinned to the reference in tests/test_oracle_golden.py)."""
+    import numpy as np
+    import torch
+    import synth
+    import talker_ref
+    from qwen3_tts_amd.config import TalkerConfig
+    from qwen3_tts_amd.model import build_prompt_plan, PLAN_PAD_ROW
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t).items()}
+    cfg = TalkerConfig.from_any(synth.cfg_dict(t))
+    emb, H, G = w["model.codec_embedding.weight"], t.hidden_size, t.num_code_groups
+    rng = np.random.default_rng(77)
+
+    def ids(n_body):
+        body = rng.integers(0, 490, n_body).tolist()
+        return torch.tensor([[t.im_start_token_id, 77, 198] + body + [t.im_end_token_id, 198, t.im_start_token_id, 77, 198]])
+
+    for trial in range(40):
+        n = int(rng.integers(1, 5))
+        mode = ["custom", "design", "clone"][trial % 3]
+        ns = bool(rng.integers(0, 2))
+        input_ids = [ids(int(rng.integers(1, 12))) for _ in range(n)]
+        langs = [["chinese", "english", "auto"][int(rng.integers(0, 3))] for _ in range(n)]
+        spk = ins = ref_ids = vcp = None
+        if mode == "custom":
+            spk = [["vivian", "ryan"][int(rng.integers(0, 2))] for _ in range(n)]
+            ins = [torch.tensor([[t.im_start_token_id, 78, 198] + rng.integers(0, 490, int(rng.integers(1, 6))).tolist() +
+                                 [t.im_end_token_id, 198]]) if rng.integers(0, 2) else None for _ in range(n)]
+        elif mode == "design":
+            ins = [torch.tensor([[t.im_start_token_id, 78, 198] + rng.integers(0, 490, int(rng.integers(1, 6))).tolist() +
+                                 [t.im_end_token_id, 198]]) for _ in range(n)]
+        else:
+            icl = [bool(rng.integers(0, 2)) for _ in range(n)]
+            ref_ids = [torch.tensor([[t.im_start_token_id, 77, 198] + rng.integers(0, 490, int(rng.integers(1, 9))).tolist() +
+                                     [t.im_end_token_id, 198]]) for _ in range(n)]
+            def ref_code():
+                m = int(rng.integers(1, 9))
+                return torch.from_numpy(np.concatenate([rng.integers(0, t.vocab_size - 1024, (m, 1)),
+                                                        rng.integers(0, t.cp_vocab_size, (m, G - 1))], 1))
+            vcp = dict(ref_code=[ref_code() if icl[i] else None for i in range(n)],
+                       ref_spk_embedding=[torch.from_numpy(rng.standard_normal(H).astype(np.float32)) for _ in range(n)],
+                       x_vector_only_mode=[not x for x in icl], icl_mode=icl)
+        with torch.no_grad():
+            e0, m0, tr0, pad0 = talker_ref.assemble_prompts(w, t, input_ids, langs, spk, ins, ns, ref_ids, vcp)
+            plan = build_prompt_plan(cfg, input_ids, langs, spk, ins, ns, ref_ids, vcp)
+            proj = talker_ref.text_projection(w, w["model.text_embedding.weight"][torch.from_numpy(plan["text_ids"])])
+        spkm = torch.stack([x.reshape(-1).float() for x in plan["spk_vectors"]]) if plan["spk_vectors"] else None
+        ref = torch.cat(plan["ref_codes"], 0) if plan["ref_codes"] else None
+        rows = torch.zeros(plan["desc"].shape[0], H)
+        for r, (tr, cid, sr, rf) in enumerate(plan["desc"].tolist()):
+            cterm = None
+            if cid >= 0:
+                cterm = emb[cid]
+            if sr >= 0:
+                cterm = spkm[sr]
+            if rf >= 0:
+                cterm = emb[ref[rf, 0]]
+                for k in range(1, G):
+                    cterm = cterm + w[f"code_predictor.model.codec_embedding.{k - 1}.weight"][ref[rf, k]]
+            if tr >= 0:
+                rows[r] = proj[tr] + cterm if cterm is not None else proj[tr]
+            elif cterm is not None:
+                rows[r] = cterm
+        nn, Tm, Tt = plan["n"], plan["Tm"], plan["Tt"]
+        tag = (trial, mode, ns)
+        assert np.array_equal(plan["mask"], m0.numpy()), tag
+        assert (rows[: nn * Tm].reshape(nn, Tm, H) - e0).abs().max() <= 1e-6, tag
+        assert (rows[nn * Tm:].reshape(nn, Tt, H) - tr0).abs().max() <= 1e-6, tag
+        assert (proj[PLAN_PAD_ROW] - pad0.reshape(-1)).abs().max() <= 1e-6, tag
