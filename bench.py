@@ -165,7 +165,7 @@ def main():
         "build_seconds": round(build_s, 1),
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:                      # extra legs, outside the timed region: roofline at any N, cpu_baseline at N = 1
         st = talker.stats()
         wbytes = st["weight_bytes_per_frame"]
         kvb = 2.0 * B * tcfg.num_hidden_layers * 2 * tcfg.num_key_value_heads * tcfg.head_dim * (np.mean(lens) + F / 2)
@@ -198,7 +198,7 @@ def main():
                                    "launches_per_frame": per_frame, "avg_launch_us": round(1000 * avg_ms, 3),
                                    "algorithmic_bytes_per_launch": round(bytes_per_launch)}
         log("roofline leg done")
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, args.cpu_frames, args.cpu_budget_s)
             log("cpu baseline done")
     if rank == 0:
