@@ -142,3 +142,40 @@ def test_logits_processors_match_hf_formulas():
         kept = torch.isfinite(o2[b])
         assert p[b][kept].sum() >= 0.5 - 1e-6
         assert p[b][kept].min() >= p[b][~kept].max()
+
+
+def test_incremental_decoder_equals_full_forward(codec_tiny):
+    """oracle/codec_stream_ref.py (design reference for the streaming codec decode): carrying conv
+    halos, one transposed-conv column and a (window-1)-deep KV cache per layer, packet-by-packet decode equals the
+    whole-sequence decoder forward -- for ragged packets, single-frame packets, and sequences several times the
+    attention window (tiny config: window 8; 45 frames)."""
+    import codec_stream_ref
+    c, w, g = codec_tiny[:3]
+    rng = np.random.default_rng(12)
+    T = 45
+    codes = torch.from_numpy(rng.integers(0, c.codebook_size, (2, c.num_quantizers, T)))
+    with torch.no_grad():
+        full = codec_ref.decoder_forward(w, c, codes)
+        for cuts in ([0, 1, 2, 3, 10, 11, 30, 45], list(range(0, 46, 5)), [0, 45], list(range(0, 46))):
+            st, outs = None, []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                y, st = codec_stream_ref.decoder_step(w, c, codes[..., a:b], st)
+                assert y.shape == (2, 1, (b - a) * c.total_upsample)
+                outs.append(y)
+            got = torch.cat(outs, dim=-1)
+            err = (got - full).abs().max().item()
+            assert err <= 2e-5, (cuts[:4], err)
+            assert st.t == T
+    # per-stream state at the real dimensions (what a HIP implementation has to carry)
+    cr = synth.codec_real()
+    halo = lambda k, d=1: (k - 1) * d
+    cols = 2 * cr.codebook_dim                                                    # pre_conv k=3
+    cols += cr.num_hidden_layers * 2 * (cr.sliding_window - 1) * cr.num_key_value_heads * cr.head_dim
+    cols += len(cr.upsampling_ratios) * halo(7) * cr.latent_dim + halo(7) * cr.latent_dim   # convnext dwconv + decoder.0
+    ch = cr.decoder_dim
+    for r in cr.upsample_rates:
+        cols += ch                                                                 # transposed conv: one input column
+        ch //= 2
+        cols += sum(halo(7, d) for d in (1, 3, 9)) * ch
+    cols += halo(7) * ch
+    assert cols * 4 < 8 * 2 ** 20, "streaming state should stay a few MB per stream"
