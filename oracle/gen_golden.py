@@ -457,9 +457,42 @@ def gen_ckpt_tiny():
     print("ckpt_tiny: wrote", sorted(os.listdir(out)))
 
 
+def gen_speaker_tiny():
+    """Pin oracle/speaker_ref.py to the reference's Qwen3TTSSpeakerEncoder (M:95-393) and to the
+    arithmetic of its mel_spectrogram (M:402-464) fed with the restated Slaney filterbank (librosa is absent here)."""
+    ref_shims.install()
+    import torch
+    import speaker_ref
+    from qwen_tts.core.models import modeling_qwen3_tts as M
+    from qwen_tts.core.models.configuration_qwen3_tts import Qwen3TTSSpeakerEncoderConfig
+    c = synth.speaker_tiny()
+    w = synth.speaker_weights(c)
+    cfg = Qwen3TTSSpeakerEncoderConfig(mel_dim=c.mel_dim, enc_dim=c.enc_dim, enc_channels=list(c.enc_channels),
+                                       enc_kernel_sizes=list(c.enc_kernel_sizes), enc_dilations=list(c.enc_dilations),
+                                       enc_attention_channels=c.enc_attention_channels, enc_res2net_scale=c.enc_res2net_scale,
+                                       enc_se_channels=c.enc_se_channels)
+    m = M.Qwen3TTSSpeakerEncoder(cfg).eval()
+    sd = m.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == synth.speaker_param_shapes(c)
+    _load(m, w)
+    g = np.random.default_rng(31)
+    mels = torch.from_numpy(g.standard_normal((2, 41, c.mel_dim)).astype(np.float32))
+    audio = (g.standard_normal(12000) * 0.2).clip(-1, 1).astype(np.float32)
+    fb = speaker_ref.mel_filterbank_slaney(24000, 1024, 128, 0, 12000)
+    M.librosa_mel_fn = lambda sr, n_fft, n_mels, fmin, fmax: fb                 # the stubbed third-party call
+    with torch.no_grad():
+        emb = m(mels)
+        mel = M.mel_spectrogram(torch.from_numpy(audio).unsqueeze(0), n_fft=1024, num_mels=128, sampling_rate=24000,
+                                hop_size=256, win_size=1024, fmin=0, fmax=12000)
+    np.savez_compressed(os.path.join(GOLDEN, "speaker_tiny.npz"), weights_checksum=synth.weights_checksum(w),
+                        mels=mels.numpy(), embedding=emb.numpy(), audio=audio, mel=mel.numpy(),
+                        fb_checksum=float(np.abs(fb).sum()), fb_row0=fb[0, :8], fb_peak_bins=fb.argmax(1).astype(np.int32))
+    print("speaker_tiny: embedding", tuple(emb.shape), "mel", tuple(mel.shape))
+
+
 ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
        "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
-       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny}
+       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -328,6 +328,66 @@ def talker_weights(t: TalkerCfg, seed: int = 1234, with_text: bool = True) -> Di
     return {k: _talker_value(seed, k, shp) for k, shp in talker_param_shapes(t, with_text).items()}
 
 
+# ----------------------------------------------------------------------------- speaker encoder
+@dataclass
+class SpeakerCfg:
+    """Qwen3TTSSpeakerEncoderConfig (configuration_qwen3_tts.py:22-67)."""
+    mel_dim: int = 128
+    enc_dim: int = 1024
+    enc_channels: tuple = (512, 512, 512, 512, 1536)
+    enc_kernel_sizes: tuple = (5, 3, 3, 3, 1)
+    enc_dilations: tuple = (1, 2, 3, 4, 1)
+    enc_attention_channels: int = 128
+    enc_res2net_scale: int = 8
+    enc_se_channels: int = 128
+    sample_rate: int = 24000
+
+
+def speaker_real(enc_dim: int = 2048) -> SpeakerCfg:
+    return SpeakerCfg(enc_dim=enc_dim)          # enc_dim = talker hidden size (the x-vector is a prompt row, M:2092)
+
+
+def speaker_tiny() -> SpeakerCfg:
+    return SpeakerCfg(mel_dim=16, enc_dim=24, enc_channels=(32, 32, 32, 32, 96), enc_attention_channels=8,
+                      enc_res2net_scale=4, enc_se_channels=8)
+
+
+def speaker_param_shapes(c: SpeakerCfg) -> Dict[str, tuple]:
+    """state_dict names / shapes of Qwen3TTSSpeakerEncoder (modeling_qwen3_tts.py:312-367), relative to `speaker_encoder.`."""
+    ch, ks = list(c.enc_channels), list(c.enc_kernel_sizes)
+    out: Dict[str, tuple] = {}
+
+    def conv(name, cout, cin, k):
+        out[name + ".weight"] = (cout, cin, k)
+        out[name + ".bias"] = (cout,)
+
+    conv("blocks.0.conv", ch[0], c.mel_dim, ks[0])
+    for i in range(1, len(ch) - 1):
+        p = f"blocks.{i}."
+        conv(p + "tdnn1.conv", ch[i], ch[i - 1], 1)
+        for j in range(c.enc_res2net_scale - 1):
+            conv(p + f"res2net_block.blocks.{j}.conv", ch[i] // c.enc_res2net_scale, ch[i] // c.enc_res2net_scale, ks[i])
+        conv(p + "tdnn2.conv", ch[i], ch[i], 1)
+        conv(p + "se_block.conv1", c.enc_se_channels, ch[i], 1)
+        conv(p + "se_block.conv2", ch[i], c.enc_se_channels, 1)
+    conv("mfa.conv", ch[-1], ch[-1], ks[-1])
+    conv("asp.tdnn.conv", c.enc_attention_channels, ch[-1] * 3, 1)
+    conv("asp.conv", ch[-1], c.enc_attention_channels, 1)
+    conv("fc", c.enc_dim, ch[-1] * 2, 1)
+    return out
+
+
+def speaker_weights(c: SpeakerCfg, seed: int = 1234) -> Dict[str, np.ndarray]:
+    out = {}
+    for k, shp in speaker_param_shapes(c).items():
+        if k.endswith(".bias"):
+            out[k] = _normal(seed, k, shp, 0.05)
+        else:
+            fan_in = shp[1] * shp[2]
+            out[k] = _normal(seed, k, shp, 1.0 / np.sqrt(fan_in))
+    return out
+
+
 def weights_checksum(w: Dict[str, np.ndarray]) -> float:
     """Cheap order-independent fingerprint stored in goldens to prove both sides built the same weights."""
     acc = 0.0

@@ -179,3 +179,31 @@ def test_incremental_decoder_equals_full_forward(codec_tiny):
         cols += sum(halo(7, d) for d in (1, 3, 9)) * ch
     cols += halo(7) * ch
     assert cols * 4 < 8 * 2 ** 20, "streaming state should stay a few MB per stream"
+
+
+def test_speaker_encoder_oracle_vs_reference_golden(golden_dir):
+    """oracle/speaker_ref.py against the reference's ECAPA-TDNN module and its mel arithmetic
+    (tests/golden/speaker_tiny.npz).  The Slaney filterbank itself is a restatement of librosa's published algorithm
+    (librosa is absent here): its structural properties are checked, its values are part of the golden."""
+    import speaker_ref
+    g = np.load(os.path.join(golden_dir, "speaker_tiny.npz"))
+    c = synth.speaker_tiny()
+    w = synth.speaker_weights(c)
+    assert abs(synth.weights_checksum(w) - float(g["weights_checksum"])) < 1e-6
+    with torch.no_grad():
+        emb = speaker_ref.speaker_encoder_forward(_td(w), c, torch.from_numpy(g["mels"]))
+        mel = speaker_ref.mel_spectrogram(torch.from_numpy(g["audio"]).unsqueeze(0))
+        e2 = speaker_ref.extract_speaker_embedding(_td(synth.speaker_weights(synth.SpeakerCfg(
+            mel_dim=128, enc_dim=24, enc_channels=(32, 32, 32, 32, 96), enc_attention_channels=8, enc_res2net_scale=4,
+            enc_se_channels=8))), synth.SpeakerCfg(mel_dim=128, enc_dim=24, enc_channels=(32, 32, 32, 32, 96),
+                                                    enc_attention_channels=8, enc_res2net_scale=4, enc_se_channels=8),
+            g["audio"], 24000)
+    assert np.abs(emb.numpy() - g["embedding"]).max() <= 1e-6
+    assert np.abs(mel.numpy() - g["mel"]).max() <= 1e-5
+    assert e2.shape == (24,) and bool(torch.isfinite(e2).all())
+    fb = speaker_ref.mel_filterbank_slaney(24000, 1024, 128, 0, 12000)
+    assert fb.shape == (128, 513) and (fb >= 0).all() and abs(float(np.abs(fb).sum()) - float(g["fb_checksum"])) < 1e-4
+    assert np.array_equal(fb.argmax(1).astype(np.int32), g["fb_peak_bins"]) and (np.diff(fb.argmax(1)) >= 0).all()
+    # Slaney area normalisation: every triangle integrates to ~1 over frequency (bin width sr / n_fft)
+    area = fb.sum(1) * (24000 / 1024)
+    assert np.all(np.abs(area[5:] - 1.0) < 0.35)
