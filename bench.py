@@ -28,7 +28,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 _T0 = time.time()
@@ -230,6 +229,7 @@ def cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, n_frames, budget_s):
     the wall-clock budget (the sample actually run is reported)."""
     import numpy as np
     import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))      # the oracle is reachable from this leg only
     import codec_ref
     import talker_ref
     nthreads = _host_threads()

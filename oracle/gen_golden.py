@@ -2,7 +2,7 @@
 
 Generates tests/golden/*.npz by running the UNMODIFIED reference modules
 (/root/reference/qwen_tts, via oracle/ref_shims.py) on seeded synthetic weights
-(oracle/synth.py).  Runs only in the build container (the reference tree is absent
+(synth.py at the repo root).  Runs only in the build container (the reference tree is absent
 on the GPU box); the fixtures it writes are committed.
 
     python oracle/gen_golden.py [--only codec_tiny,codec_real,talker_tiny,talker_06b,talker_17b,prompt_tiny]
@@ -28,6 +28,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))      # synth.py (synthetic weights) lives at the repo root
 import ref_shims  # noqa: E402
 import synth  # noqa: E402
 
@@ -421,7 +422,7 @@ def gen_ckpt_tiny():
     """The JSON side of a checkpoint directory, written by the REFERENCE's own config classes, so that the mirrored
     `from_pretrained` is tested against the reference's serialisation (nested talker_config / code_predictor_config /
     decoder_config, rope_scaling, speaker tables...).  Weights and the text tokenizer are produced by the test itself
-    (tests/ckpt_util.py) from oracle/synth.py."""
+    (tests/ckpt_util.py) from synth.py."""
     ref_shims.install()
     import json
     from qwen_tts.core.tokenizer_12hz.configuration_qwen3_tts_tokenizer_v2 import (Qwen3TTSTokenizerV2Config,

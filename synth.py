@@ -1,4 +1,6 @@
-"""TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+"""Synthetic workload generator (configurations, seeded weights, prompts) -- shared by bench.py, tests/, tools/ and the
+golden generation under oracle/.  It contains NO model arithmetic and nothing of the reference's algorithm: it only
+fills reference-shaped tensors with seeded random numbers (it is neither the product nor the oracle).
 
 Deterministic synthetic configurations and weights for the Qwen3-TTS hot path.
 

@@ -2,7 +2,7 @@
 (qwen_tts/inference/qwen3_tts_model.py:82-121, modeling_qwen3_tts.py:1886-1938):
 
     config.json, generation_config.json            <- tests/golden/ckpt_tiny (written by the REFERENCE's config classes)
-    model.safetensors                               <- oracle/synth.py talker weights under the `talker.` prefix
+    model.safetensors                               <- synth.py talker weights under the `talker.` prefix
     tokenizer.json, tokenizer_config.json           <- a tiny character-level text tokenizer (no Qwen vocabulary offline)
     speech_tokenizer/config.json, model.safetensors <- codec decoder weights under the `decoder.` prefix
 """

@@ -3,7 +3,7 @@ weights and time the AR loop and the codec decode.  `--prof` prints the per-laun
 skinny GEMM.  Usage on the GPU box:  python tools/perf_frame.py --model 1.7b --frames 40 [--codec]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 import synth
 from qwen3_tts_amd.talker import TalkerEngine
