@@ -491,9 +491,70 @@ def gen_speaker_tiny():
     print("speaker_tiny: embedding", tuple(emb.shape), "mel", tuple(mel.shape))
 
 
+def ref_mimi_encoder(c, w):
+    """The reference's encoder class (tokenizer v2:897-908) on a MimiConfig built from synth.MimiEncCfg."""
+    ref_shims.install()
+    from transformers import MimiConfig
+    from qwen_tts.core.tokenizer_12hz.modeling_qwen3_tts_tokenizer_v2 import Qwen3TTSTokenizerV2Encoder
+    hop = int(np.prod(c.upsampling_ratios))
+    mc = MimiConfig(sampling_rate=c.sampling_rate, hidden_size=c.hidden_size, num_filters=c.num_filters,
+                    num_residual_layers=c.num_residual_layers, upsampling_ratios=list(c.upsampling_ratios),
+                    kernel_size=c.kernel_size, last_kernel_size=c.last_kernel_size, residual_kernel_size=c.residual_kernel_size,
+                    dilation_growth_rate=c.dilation_growth_rate, compress=c.compress, codebook_size=c.codebook_size,
+                    codebook_dim=c.codebook_dim, vector_quantization_hidden_dimension=c.codebook_dim,
+                    num_quantizers=c.num_quantizers, num_semantic_quantizers=c.num_semantic_quantizers,
+                    num_hidden_layers=c.num_hidden_layers, intermediate_size=c.intermediate_size,
+                    num_attention_heads=c.num_attention_heads, num_key_value_heads=c.num_key_value_heads, head_dim=c.head_dim,
+                    sliding_window=c.sliding_window, norm_eps=c.norm_eps, upsample_groups=c.hidden_size,
+                    frame_rate=c.sampling_rate / (hop * 2))
+    mc._attn_implementation = "eager"
+    m = Qwen3TTSTokenizerV2Encoder(mc).eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == synth.mimi_enc_param_shapes(c)
+    _load(m, w)
+    for mod in m.modules():                  # the codebook caches embed_sum / cluster_usage lazily
+        if hasattr(mod, "_embed"):
+            mod._embed = None
+    return m
+
+
+def gen_codec_enc_tiny():
+    """Pin oracle/codec_enc_ref.py: MimiModel.encode through the reference's encoder class, and the body
+    of Qwen3TTSTokenizerV2Model.encode (v2:961-991: first 4 codebooks here, per-row trim from the padding mask) called
+    unbound on a stand-in `self`."""
+    import torch
+    ref_shims.install()
+    from qwen_tts.core.tokenizer_12hz.modeling_qwen3_tts_tokenizer_v2 import Qwen3TTSTokenizerV2Model
+    c = synth.mimi_enc_tiny()
+    w = synth.mimi_enc_weights(c)
+    m = ref_mimi_encoder(c, w)
+    g = np.random.default_rng(41)
+    out = {"weights_checksum": synth.weights_checksum(w)}
+    for n in (16, 160, 203, 331):
+        x = torch.from_numpy((g.standard_normal((2, 1, n)) * 0.5).astype(np.float32))
+        with torch.no_grad():
+            out[f"wav{n}"] = x.numpy()
+            out[f"codes{n}"] = m.encode(input_values=x, return_dict=True).audio_codes.numpy()
+    lens = [331, 170]
+    wav = np.zeros((2, 331), np.float32)
+    mask = np.zeros((2, 331), np.int64)
+    for i, l in enumerate(lens):
+        wav[i, :l] = (g.standard_normal(l) * 0.5).astype(np.float32)
+        mask[i, :l] = 1
+    fake = types.SimpleNamespace(config=types.SimpleNamespace(return_dict=True), encoder=m,
+                                 encoder_valid_num_quantizers=c.encoder_valid_num_quantizers,
+                                 encode_downsample_rate=c.encode_downsample_rate)
+    with torch.no_grad():
+        codes = Qwen3TTSTokenizerV2Model.encode(fake, torch.from_numpy(wav), torch.from_numpy(mask)).audio_codes
+    out.update(batch_wav=wav, batch_mask=mask)
+    for i, cd in enumerate(codes):
+        out[f"batch_codes{i}"] = cd.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "codec_enc_tiny.npz"), **out)
+    print("codec_enc_tiny:", {k: v.shape for k, v in out.items() if k.startswith(("codes", "batch_codes"))})
+
+
 ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
        "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
-       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny}
+       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

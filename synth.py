@@ -390,6 +390,120 @@ def speaker_weights(c: SpeakerCfg, seed: int = 1234) -> Dict[str, np.ndarray]:
     return out
 
 
+# ----------------------------------------------------------------------------- codec encoder (Mimi)
+@dataclass
+class MimiEncCfg:
+    """The encoder-side fields of transformers.MimiConfig as the reference uses it (tokenizer v2:897-908) plus the two
+    Qwen3TTSTokenizerV2Config fields of the call site (v2:940-944)."""
+    sampling_rate: int = 24000
+    audio_channels: int = 1
+    hidden_size: int = 512
+    num_filters: int = 64
+    num_residual_layers: int = 1
+    upsampling_ratios: tuple = (8, 6, 5, 4)
+    kernel_size: int = 7
+    last_kernel_size: int = 3
+    residual_kernel_size: int = 3
+    dilation_growth_rate: int = 2
+    compress: int = 2
+    codebook_size: int = 2048
+    codebook_dim: int = 256
+    num_quantizers: int = 32
+    num_semantic_quantizers: int = 1
+    num_hidden_layers: int = 8
+    intermediate_size: int = 2048
+    num_attention_heads: int = 8
+    num_key_value_heads: int = 8
+    head_dim: int = 64
+    sliding_window: int = 250
+    rope_theta: float = 10000.0
+    norm_eps: float = 1e-5
+    encoder_valid_num_quantizers: int = 16
+    encode_downsample_rate: int = 1920
+
+
+def mimi_enc_real() -> MimiEncCfg:
+    return MimiEncCfg()
+
+
+def mimi_enc_tiny() -> MimiEncCfg:
+    return MimiEncCfg(hidden_size=32, num_filters=4, upsampling_ratios=(4, 2), codebook_size=16, codebook_dim=8,
+                      num_quantizers=6, num_hidden_layers=2, intermediate_size=48, num_attention_heads=2,
+                      num_key_value_heads=2, head_dim=16, sliding_window=6, encoder_valid_num_quantizers=4,
+                      encode_downsample_rate=16)
+
+
+def mimi_enc_param_shapes(c: MimiEncCfg) -> Dict[str, tuple]:
+    """Encoder-side state_dict of MimiModel (modeling_mimi.py MimiEncoder / MimiTransformerModel / downsample /
+    MimiSplitResidualVectorQuantizer), names relative to `encoder.` of the Qwen3-TTS tokenizer checkpoint."""
+    out: Dict[str, tuple] = {}
+
+    def conv(name, cout, cin, k, bias=True):
+        out[name + ".conv.weight"] = (cout, cin, k)
+        if bias:
+            out[name + ".conv.bias"] = (cout,)
+
+    idx, ch = 0, c.num_filters
+    conv(f"encoder.layers.{idx}", ch, c.audio_channels, c.kernel_size)
+    idx += 1
+    for ratio in reversed(c.upsampling_ratios):
+        for _ in range(c.num_residual_layers):
+            conv(f"encoder.layers.{idx}.block.1", ch // c.compress, ch, c.residual_kernel_size)
+            conv(f"encoder.layers.{idx}.block.3", ch, ch // c.compress, 1)
+            idx += 1
+        idx += 1                                                   # ELU
+        conv(f"encoder.layers.{idx}", ch * 2, ch, 2 * ratio)
+        idx += 1
+        ch *= 2
+    idx += 1                                                       # ELU
+    conv(f"encoder.layers.{idx}", c.hidden_size, ch, c.last_kernel_size)
+    H, I, qd, kvd = c.hidden_size, c.intermediate_size, c.num_attention_heads * c.head_dim, c.num_key_value_heads * c.head_dim
+    for l in range(c.num_hidden_layers):
+        p = f"encoder_transformer.layers.{l}."
+        out[p + "self_attn.q_proj.weight"] = (qd, H)
+        out[p + "self_attn.k_proj.weight"] = (kvd, H)
+        out[p + "self_attn.v_proj.weight"] = (kvd, H)
+        out[p + "self_attn.o_proj.weight"] = (H, qd)
+        out[p + "mlp.fc1.weight"] = (I, H)
+        out[p + "mlp.fc2.weight"] = (H, I)
+        for n in ("input_layernorm", "post_attention_layernorm"):
+            out[p + n + ".weight"] = (H,)
+            out[p + n + ".bias"] = (H,)
+        out[p + "self_attn_layer_scale.scale"] = (H,)
+        out[p + "mlp_layer_scale.scale"] = (H,)
+    out["downsample.conv.weight"] = (H, H, 4)
+    for name, n in (("semantic", c.num_semantic_quantizers), ("acoustic", c.num_quantizers - c.num_semantic_quantizers)):
+        p = f"quantizer.{name}_residual_vector_quantizer."
+        out[p + "input_proj.weight"] = (c.codebook_dim, H, 1)
+        out[p + "output_proj.weight"] = (H, c.codebook_dim, 1)
+        for i in range(n):
+            out[p + f"layers.{i}.codebook.initialized"] = (1,)
+            out[p + f"layers.{i}.codebook.cluster_usage"] = (c.codebook_size,)
+            out[p + f"layers.{i}.codebook.embed_sum"] = (c.codebook_size, c.codebook_dim)
+    return out
+
+
+def mimi_enc_weights(c: MimiEncCfg, seed: int = 1234) -> Dict[str, np.ndarray]:
+    out = {}
+    for k, shp in mimi_enc_param_shapes(c).items():
+        if k.endswith("initialized"):
+            out[k] = np.ones(shp, np.float32)
+        elif k.endswith("cluster_usage"):
+            out[k] = _uniform(seed, k, shp, 0.5, 2.0)
+        elif k.endswith("embed_sum"):
+            out[k] = _normal(seed, k, shp, 1.0)
+        elif k.endswith("layer_scale.scale"):
+            out[k] = _normal(seed, k, shp, 0.05, 0.3)
+        elif k.endswith("layernorm.weight"):
+            out[k] = _normal(seed, k, shp, 0.05, 1.0)
+        elif k.endswith(".bias"):
+            out[k] = _normal(seed, k, shp, 0.05)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            out[k] = _normal(seed, k, shp, 1.3 / np.sqrt(fan_in))
+    return out
+
+
 def weights_checksum(w: Dict[str, np.ndarray]) -> float:
     """Cheap order-independent fingerprint stored in goldens to prove both sides built the same weights."""
     acc = 0.0

@@ -207,3 +207,24 @@ def test_speaker_encoder_oracle_vs_reference_golden(golden_dir):
     # Slaney area normalisation: every triangle integrates to ~1 over frequency (bin width sr / n_fft)
     area = fb.sum(1) * (24000 / 1024)
     assert np.all(np.abs(area[5:] - 1.0) < 0.35)
+
+
+def test_codec_encoder_oracle_vs_reference_golden(golden_dir):
+    """oracle/codec_enc_ref.py (restated Mimi encode) against codes produced by the reference's own
+    encoder class and by the body of Qwen3TTSTokenizerV2Model.encode (tests/golden/codec_enc_tiny.npz): bit-exact
+    indices, incl. waveforms whose length is not a multiple of the hop and a padded ragged batch."""
+    import codec_enc_ref
+    g = np.load(os.path.join(golden_dir, "codec_enc_tiny.npz"))
+    c = synth.mimi_enc_tiny()
+    w = synth.mimi_enc_weights(c)
+    assert abs(synth.weights_checksum(w) - float(g["weights_checksum"])) < 1e-6
+    wt = _td(w)
+    with torch.no_grad():
+        for n in (16, 160, 203, 331):
+            codes = codec_enc_ref.mimi_encode(wt, c, torch.from_numpy(g[f"wav{n}"]))
+            assert np.array_equal(codes.numpy(), g[f"codes{n}"]), n
+        rows = codec_enc_ref.model_encode(wt, c, torch.from_numpy(g["batch_wav"]), torch.from_numpy(g["batch_mask"]))
+    for i, r in enumerate(rows):
+        assert r.shape[1] == c.encoder_valid_num_quantizers
+        assert np.array_equal(r.numpy(), g[f"batch_codes{i}"]), i
+    assert [r.shape[0] for r in rows] == [21, 11]          # ceil(331 / 16), ceil(170 / 16)
