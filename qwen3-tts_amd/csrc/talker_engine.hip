@@ -19,14 +19,6 @@
 
 using namespace qtts;
 
-// Spins for ~`cycles` shader clocks: lets the host enqueue a whole eager frame (kernels + timing events) behind it
-// so that the profiled kernels then run back-to-back, as they do under hipGraph replay.
-__global__ void gate_kernel(long long cycles, int* sink) {
-    const long long t0 = clock64();
-    while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
-    if (sink && cycles < 0) *sink = 1;
-}
-
 namespace {
 
 struct LayerW {
@@ -61,7 +53,7 @@ struct qtts_talker {
     KvCache kv_t, kv_c;
     // decode state / scratch
     DevBuf x, qkv, att, act, logits, past_hidden, cp_in, cp_x, cp_qkv, cp_att, cp_act, cp_logits, x16, cp_x16;
-    DevBuf cur_tok, sub, generated, ss_ring, ints, n_pad_d, suppress, trailing, tts_pad;
+    DevBuf cur_tok, sub, generated, ss_rows, ints, n_pad_d, suppress, trailing, tts_pad;
     // prefill scratch
     DevBuf pf_x, pf_n, pf_qkv, pf_att, pf_act, tp_tmp;
     StepState ss;
@@ -162,7 +154,7 @@ struct qtts_talker {
     }
     void finalize();
 
-    float* ssbuf() { return ss_ring.as<float>(); }
+    float* ssbuf() { return ss_rows.as<float>(); }     // row sums of squares for GEMMs that cannot stage x (M > 32 / fp32)
 
     void skinny(const SkinnyParams& p, hipStream_t st) { launch_skinny(p, bf16, st); ++skinny_count; }
     int64_t skinny_count = 0;
@@ -330,9 +322,9 @@ void qtts_talker::finalize() {
     act.alloc((size_t)R * td.I * 4); logits.alloc((size_t)R * c.vocab_size * 4); past_hidden.alloc((size_t)R * td.H * 4);
     cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
     cp_att.alloc((size_t)R * cd.qd * 4); cp_act.alloc((size_t)R * cd.I * 4); cp_logits.alloc((size_t)R * c.cp_vocab_size * 4);
-    cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_ring.alloc(64 * 8); ints.alloc(64 * 4 + R * 4);
+    cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_rows.alloc(64 * 8); ints.alloc(64 * 4 + R * 4);
     n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size); seed_d.alloc(8);
-    QTTS_CHECK_HIP(hipMemset(ss_ring.p, 0, ss_ring.bytes));
+    QTTS_CHECK_HIP(hipMemset(ss_rows.p, 0, ss_rows.bytes));
     int* ip = ints.as<int>();
     ss = {ip + 0, ip + 1, ip + 2, ip + 3, ip + 4, ip + 64};
     host.clear();
