@@ -98,10 +98,16 @@ def clone_shard(args):
     mine = parts[rank]
     my_waves = sharding.waves(sorted(mine, key=lambda i: -text[i]), B)   # similar lengths share a wave
     Fmax = max(frames)
-    tcfg, ccfg, talker, codec = _engines(args, B, REF + 16 + 72 + 12 + Fmax + 8, min(Fmax, 300) + 25, dev)
+    # --engines E: E independent (talker, codec) engine pairs on this GPU, each on its own HIP stream and host thread
+    # (ctypes releases the GIL inside the C calls).  The frame step is latency-bound -- ~570 dependent launches that each
+    # leave most of the 256 CUs idle -- so a second stream can fill the gaps; weights are replicated per engine (3.9 GB each).
+    E = max(1, args.engines)
+    pairs = [_engines(args, B, REF + 16 + 72 + 12 + Fmax + 8, min(Fmax, 300) + 25, dev) for _ in range(E)]
+    tcfg, ccfg = pairs[0][0], pairs[0][1]
     base = _sampling(tcfg)
 
-    def run_wave(w, seed):
+    def run_wave(w, seed, e=0):
+        talker, codec = pairs[e][2], pairs[e][3]
         # ICL prompt (M:1968-2019): role + codec prefix + [ref text + text] over [ref codes] -> lens = 12 + REF + ref text (16)
         lens = [12 + REF + 16 + (text[i] % 7) for i in w]
         g = np.random.default_rng(1000 + w[0])
@@ -114,16 +120,41 @@ def clone_shard(args):
         wav, wl = codec.decode_padded(codes)
         return [wav[j, :int(wl[j])] for j in range(len(w))]
 
-    run_wave(my_waves[0], 1)                                     # warm-up (graph capture, allocator)
+    for e in range(E):
+        run_wave(my_waves[0], 1, e)                              # warm-up (graph capture, allocator) on every engine
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     local_wavs, local_idx = [], []
-    for k, w in enumerate(my_waves):
-        for i, x in zip(w, run_wave(w, 100 + k)):
-            local_idx.append(i)
-            local_wavs.append(x)
+    if E == 1:
+        for k, w in enumerate(my_waves):
+            for i, x in zip(w, run_wave(w, 100 + k)):
+                local_idx.append(i)
+                local_wavs.append(x)
+    else:
+        import threading
+        results, errors = [None] * len(my_waves), []
+
+        def worker(e):
+            try:
+                torch.cuda.set_device(local_rank)
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):   # per-thread current stream: copies and the codec
+                    for k in range(e, len(my_waves), E):                 # stay off the shared default stream
+                        results[k] = run_wave(my_waves[k], 100 + k, e)   # static round-robin: wave k -> engine k % E
+                    torch.cuda.current_stream().synchronize()
+            except Exception as ex:                              # surface worker failures on the main thread
+                errors.append(ex)
+
+        th = [threading.Thread(target=worker, args=(e,)) for e in range(E)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if errors:
+            raise errors[0]
+        for w, r in zip(my_waves, results):
+            for i, x in zip(w, r):
+                local_idx.append(i)
+                local_wavs.append(x)
     torch.cuda.synchronize()
     t_compute = time.perf_counter() - t0
     if dist is not None:
@@ -143,7 +174,8 @@ def clone_shard(args):
     assert all(allw[i] is not None and allw[i].shape[0] == frames[i] * ccfg.total_upsample for i in range(NREQ))
     tok = sum(frames) * tcfg.num_code_groups
     audio_s = sum(frames) * ccfg.total_upsample / 24000.0
-    return {"config": "clone_shard", "model": args.model, "requests": NREQ, "n_gpus": world, "waves_rank0": len(my_waves),
+    return {"config": "clone_shard", "model": args.model, "requests": NREQ, "n_gpus": world, "engines_per_gpu": E,
+            "waves_rank0": len(my_waves),
             "seconds": round(elapsed, 3), "compute_seconds_max_rank": round(t_compute, 3),
             "speech_tokens_per_s": round(tok / elapsed, 1), "rtf_x": round(audio_s / elapsed, 2),
             "padding_waste": round(1.0 - sum(frames) / sum(max(frames[i] for i in w) * len(w) for p in parts
@@ -158,6 +190,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--trials", type=int, default=20)
     ap.add_argument("--requests", type=int, default=256)
+    ap.add_argument("--engines", type=int, default=1, help="clone_shard: engine pairs per GPU running waves concurrently")
     a = ap.parse_args()
     r = first_packet(a) if a.config == "first_packet" else clone_shard(a)
     if r is not None:
