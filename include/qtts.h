@@ -42,8 +42,9 @@ extern "C" {
 #define QTTS_BF16 1 /* perf mode:   bf16 weights + KV, v_mfma_f32_16x16x32_bf16, f32 accum  */
 
 const char* qtts_last_error(void);
-/* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows). */
-#define QTTS_ABI_VERSION 2
+/* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
+ * 3: + qtts_codec_stream_begin, qtts_codec_stream_push). */
+#define QTTS_ABI_VERSION 3
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -105,6 +106,19 @@ int qtts_codec_forward(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32
  * (#frames with code > -1) * total_upsample -- the caller trims, as V2:1017 does. */
 int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, int32_t chunk_size,
                       int32_t left_context, float* wav_dev, int64_t* lengths_host, void* stream);
+
+/* Streaming (state-carrying) decode -- SURVEY.md 8(f2).  The decoder is causal end to end
+ * (Qwen3TTSTokenizerV2CausalConvNet / CausalTransConvNet, tokenizer v2:159-208; sliding-window transformer :491), so
+ * packets of new frames can be decoded one after the other while the handle carries, per stateful layer, the last
+ * (k-1)*dilation input rows (one row per k = 2r transposed conv, window-1 rotated q|k|v rows per transformer layer).
+ * The concatenated packets equal Qwen3TTSTokenizerV2Decoder.forward (:869-884) on the whole sequence -- without
+ * chunked_decode's (:886-896) re-decode of 25 context frames; algorithm in oracle/codec_stream_ref.py.
+ * One session per handle: `begin` zeroes the state for `batch` sequences that advance in lockstep; `push` decodes
+ * codes_dev int64 (batch, num_quantizers, n_frames) into wav_dev float (batch, n_frames * total_upsample).
+ * STATUS (round 1): compiled for gfx950, parity test written (tests/test_gpu_parity.py, QTTS_EXPERIMENTAL=1), not yet
+ * executed on hardware. */
+int qtts_codec_stream_begin(qtts_codec* c, int32_t batch);
+int qtts_codec_stream_push(qtts_codec* c, const int64_t* codes_dev, int32_t n_frames, float* wav_dev, void* stream);
 
 /* Test/diagnostic hook: run Qwen3TTSTokenizerV2Decoder.forward on codes_dev (B, Q, T) up to and including
  * `stage` and copy that stage's activation, channel-last float (B, L, C), to out_dev (capacity `cap` floats).

@@ -51,11 +51,12 @@ class TalkerStatsC(C.Structure):
                 ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64)]
 
 
-ABI_VERSION = 2           # include/qtts.h; bumped on any signature change
+ABI_VERSION = 3           # include/qtts.h; bumped on any signature change
 
 # every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
            "qtts_codec_finalize", "qtts_codec_forward", "qtts_codec_decode", "qtts_codec_forward_stage",
+           "qtts_codec_stream_begin", "qtts_codec_stream_push",
            "qtts_talker_create", "qtts_talker_destroy", "qtts_talker_bind", "qtts_talker_finalize",
            "qtts_talker_text_projection", "qtts_talker_text_embed", "qtts_talker_assemble_rows", "qtts_talker_prefill",
            "qtts_talker_generate",
@@ -86,6 +87,8 @@ def load_library():
     lib.qtts_codec_forward.argtypes = [vp, vp, i32, i32, f32p, f32p, vp]
     lib.qtts_codec_decode.argtypes = [vp, vp, i32, i32, i32, i32, f32p, i64p, vp]
     lib.qtts_codec_forward_stage.argtypes = [vp, vp, i32, i32, C.c_char_p, f32p, C.c_int64, i64p, i64p, vp]
+    lib.qtts_codec_stream_begin.argtypes = [vp, i32]
+    lib.qtts_codec_stream_push.argtypes = [vp, vp, i32, f32p, vp]
     lib.qtts_talker_create.argtypes = [C.POINTER(TalkerConfigC), C.POINTER(vp)]
     lib.qtts_talker_destroy.argtypes = [vp]
     lib.qtts_talker_destroy.restype = None

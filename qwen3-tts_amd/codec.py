@@ -135,6 +135,31 @@ class CodecDecoderEngine:
                                                    int(left_context_size), C.c_void_p(wav.data_ptr()), lens, self._stream()))
         return wav, [int(x) for x in lens]
 
+    @_lib.locked
+    def stream_begin(self, batch: int):
+        """Start a state-carrying streaming session for `batch` sequences (include/qtts.h `qtts_codec_stream_begin`).
+        EXPERIMENTAL in round 1: compiled, not yet run on hardware -- `stream()` below is the validated packet API."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.qtts_codec_stream_begin(self._h, int(batch)))
+        self._stream_batch = int(batch)
+
+    @_lib.locked
+    def stream_push(self, codes: torch.Tensor) -> torch.Tensor:
+        """Decode the next packet: codes (B, Q, k) int64 -> (B, 1, k * total_upsample); the handle carries the conv /
+        attention state, so the concatenated packets equal `forward` on the whole sequence."""
+        self._check_codes(codes, 1)
+        B, _, k = codes.shape
+        if getattr(self, "_stream_batch", 0) != B:
+            raise ValueError("stream_push: call stream_begin(batch) with this batch size first")
+        if int(codes.min()) < 0 or int(codes.max()) >= self.config.codebook_size:
+            raise ValueError("stream_push: code index out of range")
+        codes = codes.to(self.device, torch.long).contiguous()
+        wav = torch.empty(B, k * self.config.total_upsample, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.qtts_codec_stream_push(self._h, C.c_void_p(codes.data_ptr()), int(k),
+                                                        C.c_void_p(wav.data_ptr()), self._stream()))
+        return wav.unsqueeze(1)
+
     def stream(self, left_context_size: int = 25) -> "CodecStreamDecoder":
         """A packet-by-packet decoder bound to this engine (see CodecStreamDecoder)."""
         return CodecStreamDecoder(self.forward, self.config.total_upsample, left_context_size)

@@ -47,6 +47,16 @@ struct qtts_codec {
     DevBuf buf[4];
     size_t buf_elems = 0;
 
+    // ---- streaming (state-carrying) decode: one session per handle, B sequences advancing in lockstep
+    struct Carry { DevBuf d; int h = 0, C = 0; };
+    std::vector<Carry> carry;           // in the order the stateful layers run
+    DevBuf stream_npad;                 // [B] left-pad count of the staged KV window
+    std::vector<int> stream_npad_host;
+    int stream_B = 0;                   // 0 = no session
+    int64_t stream_t = 0;               // frames decoded so far
+    void stream_begin(int B);
+    void stream_push(const int64_t* codes, int n, float* wav, hipStream_t st);
+
     std::vector<float>& P(const std::string& n) {
         auto it = host.find(n);
         if (it == host.end()) throw Error(QTTS_ERR_UNBOUND, "codec weight not bound: " + n);
@@ -459,6 +469,190 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     if (C_out) *C_out = 1;
 }
 
+// ------------------------------------------------------------------------------------------ streaming decode
+// The decoder is causal end to end (v2:159-208, 491), so a packet of n new frames needs, per stateful layer, only the
+// last (k-1)*dilation input rows of what came before (one row for the k = 2r transposed convs, window-1 roped k/v rows
+// per transformer layer): algorithm and its equality with the whole-sequence forward in oracle/codec_stream_ref.py.
+// Every stateful layer is run by the UNCHANGED kernels of forward() on a staged buffer [carried rows | new rows]; the
+// outputs of the carried rows are discarded by the next staging step (`skip`).
+void qtts_codec::stream_begin(int B) {
+    QTTS_REQUIRE(finalized, QTTS_ERR_STATE, "codec: finalize() first");
+    QTTS_REQUIRE(B >= 1 && B <= cfg.max_batch, QTTS_ERR_LIMIT, "codec stream: batch exceeds max_batch");
+    const auto& c = cfg;
+    std::vector<std::pair<int, int>> want;            // (rows, channels) per stateful layer, in execution order
+    want.push_back({2, c.codebook_dim});                                                          // pre_conv k=3
+    const int qkvw = (c.num_attention_heads + 2 * c.num_key_value_heads) * c.head_dim;
+    for (int l = 0; l < c.num_hidden_layers; ++l) want.push_back({c.sliding_window - 1, qkvw});   // roped q|k|v rows
+    for (int u = 0; u < c.n_upsampling_ratios; ++u) want.push_back({6, c.latent_dim});            // ConvNeXt dwconv k=7
+    want.push_back({6, c.latent_dim});                                                            // decoder.0 k=7
+    const int dil[3] = {1, 3, 9};
+    for (int i = 0; i < c.n_upsample_rates; ++i) {
+        want.push_back({1, c.decoder_dim >> i});                                                  // transposed conv k=2r
+        for (int j = 0; j < 3; ++j) want.push_back({6 * dil[j], c.decoder_dim >> (i + 1)});       // residual unit conv7
+    }
+    want.push_back({6, c.decoder_dim >> c.n_upsample_rates});                                     // final conv k=7
+    carry.resize(want.size());
+    for (size_t i = 0; i < want.size(); ++i) {
+        carry[i].h = want[i].first; carry[i].C = want[i].second;
+        const size_t bytes = (size_t)B * want[i].first * want[i].second * sizeof(float);
+        carry[i].d.ensure(std::max<size_t>(bytes, 16));
+        QTTS_CHECK_HIP(hipMemset(carry[i].d.p, 0, std::max<size_t>(bytes, 16)));   // zeros == the causal left padding
+    }
+    stream_npad.ensure((size_t)B * sizeof(int));
+    stream_npad_host.assign(B, 0);
+    stream_B = B;
+    stream_t = 0;
+}
+
+void qtts_codec::stream_push(const int64_t* codes, int n, float* wav, hipStream_t st) {
+    const auto& c = cfg;
+    QTTS_REQUIRE(stream_B > 0, QTTS_ERR_STATE, "codec stream: stream_begin() first");
+    QTTS_REQUIRE(n >= 1 && codes && wav, QTTS_ERR_ARG, "codec stream: empty packet");
+    const int B = stream_B;
+    float* pool[4] = {buf[0].as<float>(), buf[1].as<float>(), buf[2].as<float>(), buf[3].as<float>()};
+    auto fits = [&](int64_t rows, int C) {
+        QTTS_REQUIRE((size_t)rows * (size_t)C <= buf_elems, QTTS_ERR_LIMIT,
+                     "codec stream: packet + carried rows exceed the workspace (raise max_frames at create)");
+    };
+    auto other = [&](std::initializer_list<const float*> busy) -> float* {     // a workspace buffer not in `busy`
+        for (float* p : pool) {
+            bool used = false;
+            for (const float* q : busy) used = used || q == p;
+            if (!used) return p;
+        }
+        throw Error(QTTS_ERR_STATE, "codec stream: out of workspace buffers");
+    };
+    size_t ci = 0;                                   // next carry slot
+    // x: current activation, T rows per sequence of which the first `skip` are to be ignored, C channels
+    float* x = nullptr; int T = n, skip = 0, C = 0;
+    auto stage = [&](float* dst) {                   // dst = [carry | valid rows of x]; refresh the carry; x <- dst
+        Carry& k = carry[ci++];
+        QTTS_REQUIRE(k.C == C, QTTS_ERR_STATE, "codec stream: carry/channel mismatch");
+        const int nv = T - skip;
+        fits((int64_t)B * (k.h + nv), C);
+        launch_stage_rows(x, T, skip, nv, k.d.as<float>(), k.h, dst, B, C, st);
+        launch_save_tail(dst, k.h + nv, k.d.as<float>(), k.h, B, C, st);
+        x = dst; T = k.h + nv; skip = k.h;
+    };
+    auto compact = [&](float* dst) {                 // drop the ignored rows
+        const int nv = T - skip;
+        launch_stage_rows(x, T, skip, nv, nullptr, 0, dst, B, C, st);
+        x = dst; T = nv; skip = 0;
+    };
+
+    // ---- RVQ dequant (stateless)
+    float* g = pool[1];
+    x = pool[0]; C = c.codebook_dim;
+    fits((int64_t)B * n, std::max(2 * vq, C));
+    launch_rvq_gather(codes, B, c.num_quantizers, n, (int64_t)c.num_quantizers * n, n, 1, 0, n, tables.as<float>(),
+                      c.codebook_size, vq, g, st);
+    gemm(rvq_out, g, 2 * vq, B * n, n, x, C, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+    // ---- pre_conv k=3
+    {
+        float* s = other({x}); stage(s);
+        float* y = other({x});
+        fits((int64_t)B * T, c.latent_dim);
+        gemm(pre_conv, x, C, B * T, T, y, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        x = y; C = c.latent_dim;
+        compact(other({x}));
+    }
+    // ---- pre_transformer with a (window-1)-row KV carry per layer
+    {
+        const int H = c.hidden_size, I = c.intermediate_size, W1 = c.sliding_window - 1;
+        const int qd = c.num_attention_heads * c.head_dim, kvd = c.num_key_value_heads * c.head_dim, qw = qd + 2 * kvd;
+        const int M = B * n;
+        const int pad = W1 - (int)std::min<int64_t>(stream_t, W1);          // carried rows that do not exist yet
+        for (int b = 0; b < B; ++b) stream_npad_host[b] = pad;
+        QTTS_CHECK_HIP(hipMemcpyAsync(stream_npad.p, stream_npad_host.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+        float* h = other({x});
+        fits((int64_t)B * (W1 + n), std::max({qw, H, I}));
+        gemm(in_proj, x, C, M, n, h, H, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        float* a = other({h});
+        float* b2 = other({h, a});
+        for (auto& Ly : tl) {
+            launch_rmsnorm(h, H, Ly.n1.as<float>(), c.rms_norm_eps, a, H, M, H, st);
+            gemm(Ly.qkv, a, H, M, n, b2, qw, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+            launch_rope_offset(b2, qw, M, n, (int)stream_t, c.num_attention_heads + c.num_key_value_heads, c.head_dim,
+                               inv_freq.as<float>(), st);
+            // a <- [carried roped q|k|v rows | new rows]
+            Carry& k = carry[ci++];
+            QTTS_REQUIRE(k.C == qw && k.h == W1, QTTS_ERR_STATE, "codec stream: KV carry mismatch");
+            launch_stage_rows(b2, n, 0, n, k.d.as<float>(), W1, a, B, qw, st);
+            launch_save_tail(a, W1 + n, k.d.as<float>(), W1, B, qw, st);
+            AttnRowsParams ap;
+            ap.qkv = a; ap.ld = qw; ap.q_off = 0; ap.k_off = qd; ap.v_off = qd + kvd;
+            ap.B = B; ap.T = W1 + n; ap.nh = c.num_attention_heads; ap.nkv = c.num_key_value_heads; ap.hd = c.head_dim;
+            ap.window = c.sliding_window; ap.n_pad = stream_npad.as<int>(); ap.out = b2; ap.ldo = qd;
+            launch_attn_rows(ap, st);                                       // b2: [B][W1+n][qd], rows >= W1 are the new ones
+            launch_stage_rows(b2, W1 + n, W1, n, nullptr, 0, a, B, qd, st);  // a: compact [B*n][qd]
+            gemm(Ly.o, a, qd, M, n, h, H, ACT_NONE, h, H, Ly.ls1.as<float>(), nullptr, st);
+            launch_rmsnorm(h, H, Ly.n2.as<float>(), c.rms_norm_eps, a, H, M, H, st);
+            gemm(Ly.gu, a, H, M, n, b2, I, ACT_SWIGLU, nullptr, 0, nullptr, nullptr, st);
+            gemm(Ly.down, b2, I, M, n, h, H, ACT_NONE, h, H, Ly.ls2.as<float>(), nullptr, st);
+        }
+        launch_rmsnorm(h, H, t_norm.as<float>(), c.rms_norm_eps, a, H, M, H, st);
+        gemm(out_proj, a, H, M, n, b2, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        x = b2; T = n; skip = 0; C = c.latent_dim;
+    }
+    // ---- upsample: ConvTranspose(k = s = f, column-local) + ConvNeXt (dwconv k=7 carries 6 rows)
+    for (int u = 0; u < c.n_upsampling_ratios; ++u) {
+        const int f = c.upsampling_ratios[u];
+        float* y = other({x});
+        fits((int64_t)B * T * f, 4 * C);
+        gemm(ups[u].tconv, x, C, B * T, T, y, f * C, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        x = y; T *= f; skip *= f;
+        float* s = other({x}); stage(s);                                   // x = staged y (also the residual)
+        float* d = other({x});
+        float* e = other({x, d});
+        fits((int64_t)B * T, 4 * C);
+        launch_dwconv_ln(x, ups[u].dw_w.as<float>(), ups[u].dw_b.as<float>(), ups[u].ln_w.as<float>(),
+                         ups[u].ln_b.as<float>(), 1e-6f, d, B * T, T, C, st);
+        gemm(ups[u].pw1, d, C, B * T, T, e, 4 * C, ACT_GELU, nullptr, 0, nullptr, nullptr, st);
+        gemm(ups[u].pw2, e, 4 * C, B * T, T, x, C, ACT_NONE, x, C, ups[u].gamma.as<float>(), nullptr, st);
+    }
+    // ---- decoder.0 conv k=7
+    {
+        float* s = other({x}); stage(s);
+        float* y = other({x});
+        fits((int64_t)B * T, c.decoder_dim);
+        gemm(dec0, x, C, B * T, T, y, c.decoder_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        x = y; C = c.decoder_dim;
+    }
+    // ---- decoder blocks
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        auto& bk = blocks[i];
+        {   // SnakeBeta (elementwise) + ConvTranspose(2r, r): output block t mixes input rows t and t-1
+            float* s = other({x}); stage(s);                               // carry = 1 pre-activation row
+            float* a = other({x});
+            launch_snake(x, bk.act.ea.as<float>(), bk.act.ib.as<float>(), a, (int64_t)B * T, C, st);
+            float* b = other({x, a});
+            fits((int64_t)B * T * bk.r, bk.cout);
+            gemm(bk.tconv, a, C, B * T, T, b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+            x = b; T *= bk.r; skip *= bk.r; C = bk.cout;
+        }
+        for (int j = 0; j < 3; ++j) {
+            auto& un = bk.u[j];
+            float* s = other({x}); stage(s);                               // x = [carried unit inputs | new], also the residual
+            float* sA = other({x});
+            float* sB = other({x, sA});
+            launch_snake(x, un.a1.ea.as<float>(), un.a1.ib.as<float>(), sA, (int64_t)B * T, C, st);
+            gemm(un.c1, sA, C, B * T, T, sB, C, ACT_SNAKE, nullptr, 0, nullptr, &un.a2, st);
+            gemm(un.c2, sB, C, B * T, T, sA, C, ACT_NONE, x, C, nullptr, nullptr, st);
+            x = sA;
+        }
+    }
+    // ---- final SnakeBeta + conv(C -> 1, k=7) + clamp
+    {
+        float* s = other({x}); stage(s);
+        float* a = other({x});
+        launch_snake(x, final_act.ea.as<float>(), final_act.ib.as<float>(), a, (int64_t)B * T, C, st);
+        QTTS_REQUIRE(C == final_c, QTTS_ERR_ARG, "final conv channel mismatch");
+        launch_final_conv(a, final_w.as<float>(), final_b, wav, nullptr, (int64_t)B * T, T, C, (int64_t)n * up_total, skip, st);
+    }
+    QTTS_REQUIRE(ci == carry.size(), QTTS_ERR_STATE, "codec stream: carry bookkeeping out of step");
+    stream_t += n;
+}
+
 // ============================================================================================ C ABI
 namespace qtts {
 thread_local std::string g_last_error;
@@ -562,6 +756,19 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
                    (int64_t)T * up, (int64_t)ctx * up, nullptr, nullptr, 0, nullptr, nullptr, st);
         start = end;
     }
+    QTTS_API_END
+}
+
+int qtts_codec_stream_begin(qtts_codec* c, int32_t B) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c, QTTS_ERR_ARG, "null handle");
+    c->stream_begin(B);
+    QTTS_API_END
+}
+int qtts_codec_stream_push(qtts_codec* c, const int64_t* codes_dev, int32_t n_frames, float* wav_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c && codes_dev && wav_dev, QTTS_ERR_ARG, "null argument");
+    c->stream_push(codes_dev, n_frames, wav_dev, (hipStream_t)stream);
     QTTS_API_END
 }
 

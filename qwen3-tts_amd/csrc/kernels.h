@@ -70,6 +70,17 @@ void launch_final_conv(const float* x, const float* w /*[7][C]*/, float bias, fl
 void launch_rope_inplace(float* qkv, int ld, int rows, int T, int n_heads_total /* q + k heads */, int hd,
                          const float* inv_freq, hipStream_t st);
 
+// ---- streaming (state-carrying) codec decode helpers
+// dst[b] = [state[b] (h rows) | src[b][skip : skip + n]] per sequence (channel-last rows of C floats, C % 4 == 0);
+// src has src_T rows per sequence, dst h + n.  state may be null when h == 0 (plain compaction).
+void launch_stage_rows(const float* src, int src_T, int skip, int n, const float* state, int h, float* dst, int B, int C,
+                       hipStream_t st);
+// state[b] = the last h rows of buf[b] (Tp rows per sequence)
+void launch_save_tail(const float* buf, int Tp, float* state, int h, int B, int C, hipStream_t st);
+// launch_rope_inplace with positions pos0 + (row % T)
+void launch_rope_offset(float* qkv, int ld, int rows, int T, int pos0, int n_heads_total, int hd, const float* inv_freq,
+                        hipStream_t st);
+
 // --------------------------------------------------------------------------------- attention.hip
 // Generic row attention over a fused qkv buffer (prefill + codec transformer).
 struct AttnRowsParams {
