@@ -228,3 +228,19 @@ def test_codec_encoder_oracle_vs_reference_golden(golden_dir):
         assert r.shape[1] == c.encoder_valid_num_quantizers
         assert np.array_equal(r.numpy(), g[f"batch_codes{i}"]), i
     assert [r.shape[0] for r in rows] == [21, 11]          # ceil(331 / 16), ceil(170 / 16)
+
+
+def test_staged_stream_bookkeeping_matches_full_forward(codec_tiny):
+    """oracle/codec_stage_emul.py mirrors the staging / skip / carry bookkeeping of the C++ `stream_push`
+    (codec_engine.hip) with whole-buffer oracle ops: any packetisation must reproduce the whole-sequence forward."""
+    import codec_stage_emul
+    c, w, g = codec_tiny[:3]
+    codes = torch.from_numpy(np.random.default_rng(12).integers(0, c.codebook_size, (2, c.num_quantizers, 45)))
+    with torch.no_grad():
+        full = codec_ref.decoder_forward(w, c, codes)
+        for cuts in ([0, 1, 2, 3, 10, 11, 30, 45], list(range(0, 46, 5)), [0, 45], list(range(46))):
+            e = codec_stage_emul.StagedStream(w, c, 2)
+            e.begin()
+            got = torch.cat([e.push(codes[..., a:b]) for a, b in zip(cuts[:-1], cuts[1:])], dim=-1)
+            assert got.shape == full.shape
+            assert (got - full).abs().max().item() <= 3e-5, cuts[:4]
