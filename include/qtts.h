@@ -43,8 +43,8 @@ extern "C" {
 
 const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
- * 3: + qtts_codec_stream_begin, qtts_codec_stream_push). */
-#define QTTS_ABI_VERSION 3
+ * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*). */
+#define QTTS_ABI_VERSION 4
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -125,6 +125,59 @@ int qtts_codec_stream_push(qtts_codec* c, const int64_t* codes_dev, int32_t n_fr
  * Stage names: "rvq","pre_conv","pre_transformer","upsample0","upsample1","decoder0","block1".."block4". */
 int qtts_codec_forward_stage(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, const char* stage,
                              float* out_dev, int64_t cap, int64_t* L, int64_t* C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Codec ENCODER: 24 kHz waveform -> Qwen3-TTS-Tokenizer-12Hz codes -- SURVEY.md 8(f3).
+ * Replaces Qwen3TTSTokenizerV2Model.encode (tokenizer v2:961-991), i.e. transformers.MimiModel.encode behind
+ * Qwen3TTSTokenizerV2Encoder (v2:897-908): SEANet encoder -> causal transformer -> stride-2 downsample -> split
+ * residual VQ; only the first `valid_num_quantizers` codebooks are produced (v2:982-983).
+ * STATUS (round 1): compiled for gfx950, oracle + goldens + gated parity test in place, not yet executed on hardware.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct qtts_encoder qtts_encoder;
+
+typedef struct {
+    /* encoder-side fields of transformers.MimiConfig as the reference instantiates it */
+    int32_t hidden_size;
+    int32_t num_filters;
+    int32_t num_residual_layers;
+    int32_t n_ratios;
+    int32_t ratios[8];              /* MimiConfig.upsampling_ratios (the encoder applies them reversed) */
+    int32_t kernel_size;
+    int32_t last_kernel_size;
+    int32_t residual_kernel_size;
+    int32_t dilation_growth_rate;
+    int32_t compress;
+    int32_t codebook_size;
+    int32_t codebook_dim;
+    int32_t num_quantizers;
+    int32_t num_semantic_quantizers;
+    int32_t valid_num_quantizers;   /* Qwen3TTSTokenizerV2Config.encoder_valid_num_quantizers (16) */
+    int32_t num_hidden_layers;
+    int32_t intermediate_size;
+    int32_t num_attention_heads;
+    int32_t num_key_value_heads;
+    int32_t head_dim;
+    int32_t sliding_window;
+    float rope_theta;
+    float norm_eps;
+    /* engine options */
+    int32_t compute_dtype;          /* QTTS_F32 | QTTS_BF16 (the quantiser always runs in fp32) */
+    int32_t max_batch;
+    int32_t max_samples;            /* longest waveform of one encode call */
+} qtts_encoder_config;
+
+int qtts_encoder_create(const qtts_encoder_config* cfg, qtts_encoder** out);
+void qtts_encoder_destroy(qtts_encoder* e);
+/* `name` = reference state_dict key relative to `encoder.` (e.g. "encoder.layers.0.conv.weight",
+ * "quantizer.acoustic_residual_vector_quantizer.layers.3.codebook.embed_sum").  Host pointer, row-major. */
+int qtts_encoder_bind(qtts_encoder* e, const char* name, const void* host, int32_t src_dtype, int32_t ndim,
+                      const int64_t* shape);
+int qtts_encoder_finalize(qtts_encoder* e);
+/* frames produced for a waveform of `samples` samples (MimiModel.get_encoded_length) */
+int qtts_encoder_frames(qtts_encoder* e, int64_t samples, int64_t* frames);
+/* wav_dev float (B, samples) device, zero-padded rows; codes_dev int64 (B, valid_num_quantizers, frames) device.
+ * The caller trims each row to ceil(valid_samples / encode_downsample_rate) frames and transposes, as v2:984-985. */
+int qtts_encoder_encode(qtts_encoder* e, const float* wav_dev, int32_t B, int32_t samples, int64_t* codes_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Talker + code predictor: the autoregressive speech-token decoder.

@@ -517,6 +517,23 @@ def ref_mimi_encoder(c, w):
     return m
 
 
+def gen_codec_enc_small():
+    """The same pin at GEMM-friendly dimensions (synth.mimi_enc_small): the fixture the HIP encoder is tested against."""
+    import torch
+    c = synth.mimi_enc_small()
+    w = synth.mimi_enc_weights(c)
+    m = ref_mimi_encoder(c, w)
+    g = np.random.default_rng(43)
+    out = {"weights_checksum": synth.weights_checksum(w)}
+    for n in (16, 203, 331):
+        x = torch.from_numpy((g.standard_normal((2, 1, n)) * 0.5).astype(np.float32))
+        with torch.no_grad():
+            out[f"wav{n}"] = x.numpy()
+            out[f"codes{n}"] = m.encode(input_values=x, return_dict=True).audio_codes.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "codec_enc_small.npz"), **out)
+    print("codec_enc_small:", {k: v.shape for k, v in out.items() if k.startswith("codes")})
+
+
 def gen_codec_enc_tiny():
     """Pin oracle/codec_enc_ref.py: MimiModel.encode through the reference's encoder class, and the body
     of Qwen3TTSTokenizerV2Model.encode (v2:961-991: first 4 codebooks here, per-row trim from the padding mask) called
@@ -554,7 +571,7 @@ def gen_codec_enc_tiny():
 
 ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
        "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
-       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny}
+       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny, "codec_enc_small": gen_codec_enc_small}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

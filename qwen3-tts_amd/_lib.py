@@ -46,17 +46,30 @@ class SamplingC(C.Structure):
                 ("subtalker_temperature", C.c_float), ("seed", C.c_uint64)]
 
 
+class EncoderConfigC(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("num_filters", C.c_int32), ("num_residual_layers", C.c_int32),
+                ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8), ("kernel_size", C.c_int32), ("last_kernel_size", C.c_int32),
+                ("residual_kernel_size", C.c_int32), ("dilation_growth_rate", C.c_int32), ("compress", C.c_int32),
+                ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32), ("num_quantizers", C.c_int32),
+                ("num_semantic_quantizers", C.c_int32), ("valid_num_quantizers", C.c_int32), ("num_hidden_layers", C.c_int32),
+                ("intermediate_size", C.c_int32), ("num_attention_heads", C.c_int32), ("num_key_value_heads", C.c_int32),
+                ("head_dim", C.c_int32), ("sliding_window", C.c_int32), ("rope_theta", C.c_float), ("norm_eps", C.c_float),
+                ("compute_dtype", C.c_int32), ("max_batch", C.c_int32), ("max_samples", C.c_int32)]
+
+
 class TalkerStatsC(C.Structure):
     _fields_ = [("frames_run", C.c_int32), ("graph_nodes", C.c_int32), ("weight_bytes_per_frame", C.c_double),
                 ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64)]
 
 
-ABI_VERSION = 3           # include/qtts.h; bumped on any signature change
+ABI_VERSION = 4           # include/qtts.h; bumped on any signature change
 
 # every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
            "qtts_codec_finalize", "qtts_codec_forward", "qtts_codec_decode", "qtts_codec_forward_stage",
            "qtts_codec_stream_begin", "qtts_codec_stream_push",
+           "qtts_encoder_create", "qtts_encoder_destroy", "qtts_encoder_bind", "qtts_encoder_finalize", "qtts_encoder_frames",
+           "qtts_encoder_encode",
            "qtts_talker_create", "qtts_talker_destroy", "qtts_talker_bind", "qtts_talker_finalize",
            "qtts_talker_text_projection", "qtts_talker_text_embed", "qtts_talker_assemble_rows", "qtts_talker_prefill",
            "qtts_talker_generate",
@@ -89,6 +102,13 @@ def load_library():
     lib.qtts_codec_forward_stage.argtypes = [vp, vp, i32, i32, C.c_char_p, f32p, C.c_int64, i64p, i64p, vp]
     lib.qtts_codec_stream_begin.argtypes = [vp, i32]
     lib.qtts_codec_stream_push.argtypes = [vp, vp, i32, f32p, vp]
+    lib.qtts_encoder_create.argtypes = [C.POINTER(EncoderConfigC), C.POINTER(vp)]
+    lib.qtts_encoder_destroy.argtypes = [vp]
+    lib.qtts_encoder_destroy.restype = None
+    lib.qtts_encoder_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, i64p]
+    lib.qtts_encoder_finalize.argtypes = [vp]
+    lib.qtts_encoder_frames.argtypes = [vp, C.c_int64, i64p]
+    lib.qtts_encoder_encode.argtypes = [vp, f32p, i32, i32, vp, vp]
     lib.qtts_talker_create.argtypes = [C.POINTER(TalkerConfigC), C.POINTER(vp)]
     lib.qtts_talker_destroy.argtypes = [vp]
     lib.qtts_talker_destroy.restype = None
@@ -104,7 +124,7 @@ def load_library():
     lib.qtts_talker_get_stats.argtypes = [vp, C.POINTER(TalkerStatsC)]
     lib.qtts_talker_set_profile.argtypes = [vp, i32]
     for s in SYMBOLS:
-        if s not in ("qtts_last_error", "qtts_codec_destroy", "qtts_talker_destroy"):
+        if s not in ("qtts_last_error", "qtts_codec_destroy", "qtts_talker_destroy", "qtts_encoder_destroy"):
             getattr(lib, s).restype = C.c_int
     if lib.qtts_abi_version() != ABI_VERSION:
         raise QttsError(-101, "libqtts.so ABI version mismatch; rebuild")

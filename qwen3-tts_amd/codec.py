@@ -207,6 +207,12 @@ class CodecStreamDecoder:
 
 
 @dataclass
+class Qwen3TTSTokenizerV2EncoderOutput:
+    """tokenizer v2:55-62."""
+    audio_codes: List[torch.Tensor] = None
+
+
+@dataclass
 class Qwen3TTSTokenizerV2DecoderOutput:
     """tokenizer v2:63-72."""
     audio_values: List[torch.Tensor] = None
@@ -228,6 +234,10 @@ class Qwen3TTSTokenizerV2Model:
         self.output_sample_rate = self.decoder_config.output_sample_rate
         self.decode_upsample_rate = self.decoder_config.decode_upsample_rate
         self.encode_downsample_rate = self.decoder_config.encode_downsample_rate
+        # encoder (Mimi) weights are kept on the host until the first encode() call builds the HIP encoder
+        enc = {k: v for k, v in state_dict.items() if k.startswith("encoder.")}
+        self._encoder_state = enc if any(k.startswith("encoder.encoder.layers.") for k in enc) else None
+        self._encoder = None
 
     def get_model_type(self):
         return "qwen3_tts_tokenizer_12hz"
@@ -244,8 +254,22 @@ class Qwen3TTSTokenizerV2Model:
     def get_decode_upsample_rate(self):
         return self.decode_upsample_rate
 
-    def encode(self, *a, **k):
-        raise NotImplementedError("codec *encode* (Mimi encoder) is outside the MI355X hot path (SURVEY.md 8f3)")
+    def encode(self, input_values: torch.Tensor, padding_mask: Optional[torch.Tensor] = None, return_dict: Optional[bool] = None):
+        """tokenizer v2:961-991.  Needs the encoder weights (`encoder.*` keys of the tokenizer checkpoint); the HIP
+        encoder is built on first use.  EXPERIMENTAL in round 1 (compiled, hardware run pending)."""
+        if self._encoder is None:
+            if not self._encoder_state:
+                raise NotImplementedError("this tokenizer was built without encoder weights (`encoder.*` keys): "
+                                          "codec encode is unavailable (SURVEY.md 8f3)")
+            from .encoder import CodecEncoderEngine
+            self._encoder = CodecEncoderEngine(self.config, self._encoder_state, compute_dtype=self.dtype, device=str(self.device))
+            self._encoder_state = None
+        if padding_mask is None:
+            padding_mask = torch.ones_like(input_values, dtype=torch.long)
+        codes = self._encoder.encode(input_values, padding_mask)
+        if return_dict is False:
+            return (codes,)
+        return Qwen3TTSTokenizerV2EncoderOutput(codes)
 
     def decode(self, audio_codes: torch.Tensor, return_dict: Optional[bool] = None):
         """v2:993-1024: audio_codes (B, T, Q) int64 padded with -1 -> list of 1-D waveforms."""
@@ -299,7 +323,24 @@ class Qwen3TTSTokenizer:
         return inst
 
     def encode(self, audios, sr: Optional[int] = None, return_dict: bool = True):
-        raise NotImplementedError("Qwen3TTSTokenizer.encode is outside the MI355X hot path (SURVEY.md 8f3)")
+        """qwen3_tts_tokenizer.py:208-257 for numpy / tensor waveforms at the model's input rate.  File paths, base64
+        strings and resampling go through librosa / soundfile in the reference, which this build does not have."""
+        if isinstance(audios, (str, bytes)) or (isinstance(audios, list) and audios and isinstance(audios[0], (str, bytes))):
+            raise NotImplementedError("encode(): audio files / base64 need librosa + soundfile; pass waveforms (np.ndarray) and sr")
+        if sr is None:
+            raise ValueError("For numpy waveform input, `sr` must be provided.")                 # IT:181
+        if int(sr) != int(self.model.input_sample_rate):
+            raise NotImplementedError(f"encode(): resampling {sr} -> {self.model.input_sample_rate} Hz needs librosa")
+        wavs = audios if isinstance(audios, list) else [audios]
+        wavs = [np.asarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else w, dtype=np.float32) for w in wavs]
+        wavs = [w.mean(axis=-1) if w.ndim > 1 else w for w in wavs]                               # mono, as IT:166-168
+        L = max(w.shape[0] for w in wavs)
+        x = torch.zeros(len(wavs), L, dtype=torch.float32)
+        m = torch.zeros(len(wavs), L, dtype=torch.long)
+        for i, w in enumerate(wavs):                        # EncodecFeatureExtractor semantics: right zero padding + mask
+            x[i, : w.shape[0]] = torch.from_numpy(w)
+            m[i, : w.shape[0]] = 1
+        return self.model.encode(x, m, return_dict=return_dict)
 
     def decode(self, encoded) -> Tuple[List[np.ndarray], int]:
         """qwen3_tts_tokenizer.py:259-365 for the 12 Hz model: accepts an encode() output, a dict or a list of

@@ -83,6 +83,58 @@ class CodecDecoderConfig:
 
 
 @dataclass
+class CodecEncoderConfig:
+    """Encoder-side view of the tokenizer config: `encoder_config` is a transformers.MimiConfig dict
+    (configuration_qwen3_tts_tokenizer_v2.py:143-170), plus the two call-site fields of tokenizer v2:940-944."""
+    hidden_size: int = 512
+    num_filters: int = 64
+    num_residual_layers: int = 1
+    upsampling_ratios: Tuple[int, ...] = (8, 6, 5, 4)
+    kernel_size: int = 7
+    last_kernel_size: int = 3
+    residual_kernel_size: int = 3
+    dilation_growth_rate: int = 2
+    compress: int = 2
+    codebook_size: int = 2048
+    codebook_dim: int = 256
+    num_quantizers: int = 32
+    num_semantic_quantizers: int = 1
+    num_hidden_layers: int = 8
+    intermediate_size: int = 2048
+    num_attention_heads: int = 8
+    num_key_value_heads: int = 8
+    head_dim: Optional[int] = None
+    sliding_window: int = 250
+    rope_theta: float = 10000.0
+    norm_eps: float = 1e-5
+    encoder_valid_num_quantizers: int = 16
+    encode_downsample_rate: int = 1920
+    input_sample_rate: int = 24000
+
+    def __post_init__(self):
+        if self.head_dim is None:
+            self.head_dim = self.hidden_size // self.num_attention_heads
+        self.upsampling_ratios = tuple(int(x) for x in self.upsampling_ratios)
+
+    @classmethod
+    def from_any(cls, src: Any) -> "CodecEncoderConfig":
+        """`src`: this class, a dict / object of the full tokenizer config (with `encoder_config`), or of the Mimi
+        config itself (dataclass-style flat dicts work too)."""
+        if isinstance(src, cls):
+            return src
+        enc = _get(src, "encoder_config", None)
+        kw = _pick(cls, enc if enc is not None else src)
+        rp = _get(enc if enc is not None else src, "rope_parameters", None)       # transformers 5.x spelling
+        if rp is not None and _get(rp, "rope_theta", None) is not None:
+            kw["rope_theta"] = float(_get(rp, "rope_theta"))
+        for k in ("encoder_valid_num_quantizers", "encode_downsample_rate", "input_sample_rate"):
+            v = _get(src, k, None)
+            if v is not None:
+                kw[k] = v
+        return cls(**kw)
+
+
+@dataclass
 class TalkerConfig:
     """Qwen3TTSTalkerConfig + its code_predictor_config + the token ids of Qwen3TTSConfig."""
     vocab_size: int = 3072

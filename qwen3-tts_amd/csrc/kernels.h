@@ -81,6 +81,20 @@ void launch_save_tail(const float* buf, int Tp, float* state, int h, int B, int 
 void launch_rope_offset(float* qkv, int ld, int rows, int T, int pos0, int n_heads_total, int hd, const float* inv_freq,
                         hipStream_t st);
 
+// ---- codec ENCODER helpers (Mimi encode) -- encoder_kernels.hip
+void launch_elu(const float* x, float* y, int64_t n, hipStream_t st);
+// first SEANet conv: wav (B, L) -> out channel-last [B*L][C], causal k taps, zero left pad (C_in = 1 cannot be a GEMM)
+void launch_conv_in1(const float* wav, const float* w /*[C][k]*/, const float* bias, float* out, int B, int L, int C, int k,
+                     hipStream_t st);
+void launch_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, float* y, int ldy, int rows, int C,
+                      hipStream_t st);
+// dst[b][i] = src[b][clamp(i - left, 0, T-1)] (replicate) or 0 outside [left, left+T) (zeros); rows of C floats
+void launch_pad_rows(const float* src, int T, int left, int right, int replicate, float* dst, int B, int C, hipStream_t st);
+// nearest codebook entry by argmin_j (enorm[j] - 2*scores[row][j]) (lowest index wins ties), then residual update
+// r[row] -= table[idx]; codes_out[b*stride_b + t] = idx   (row = b*T + t)
+void launch_vq_argmin_update(const float* scores, int bins, const float* enorm, const float* table, int D, float* r,
+                             int64_t* codes_out, int64_t stride_b, int B, int T, hipStream_t st);
+
 // --------------------------------------------------------------------------------- attention.hip
 // Generic row attention over a fused qkv buffer (prefill + codec transformer).
 struct AttnRowsParams {

@@ -433,6 +433,15 @@ def mimi_enc_tiny() -> MimiEncCfg:
                       encode_downsample_rate=16)
 
 
+def mimi_enc_small() -> MimiEncCfg:
+    """Smallest configuration whose every contraction is a multiple of 32 and whose head_dim the attention kernel
+    supports: what the HIP encoder's parity test runs."""
+    return MimiEncCfg(hidden_size=128, num_filters=64, upsampling_ratios=(4, 2), codebook_size=64, codebook_dim=32,
+                      num_quantizers=6, num_hidden_layers=2, intermediate_size=256, num_attention_heads=2,
+                      num_key_value_heads=2, head_dim=64, sliding_window=6, encoder_valid_num_quantizers=4,
+                      encode_downsample_rate=16)
+
+
 def mimi_enc_param_shapes(c: MimiEncCfg) -> Dict[str, tuple]:
     """Encoder-side state_dict of MimiModel (modeling_mimi.py MimiEncoder / MimiTransformerModel / downsample /
     MimiSplitResidualVectorQuantizer), names relative to `encoder.` of the Qwen3-TTS tokenizer checkpoint."""

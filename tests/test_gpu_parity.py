@@ -586,3 +586,28 @@ def test_from_pretrained_checkpoint_directory_custom_voice(dev, golden_dir, tmp_
         tts.generate_custom_voice(text="x", speaker="nobody", language="english")
     with pytest.raises(ValueError):
         tts.generate_voice_design(text="x", instruct="y")            # wrong model type for this checkpoint (IM:401-407)
+
+
+@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
+                    reason="HIP codec encoder (qtts_encoder_*): compiled in round 1, budget ran out before its first hardware run "
+                           "-- enable with QTTS_EXPERIMENTAL=1")
+def test_codec_encoder_codes_vs_reference_golden(dev, golden_dir):
+    """waveform -> codes through the HIP encoder (fp32) against codes produced by the reference's own
+    encoder class (tests/golden/codec_enc_small.npz).  Index parity is bit-exact except where the two nearest codebook
+    entries are closer than fp32 summation-order noise; at most 1 % of indices may differ, and never the first codebook of
+    a frame whose margin is clear."""
+    from qwen3_tts_amd.encoder import CodecEncoderEngine
+    g = np.load(os.path.join(golden_dir, "codec_enc_small.npz"))
+    c = synth.mimi_enc_small()
+    w = synth.mimi_enc_weights(c)
+    eng = CodecEncoderEngine(synth.cfg_dict(c), _td(w), compute_dtype=torch.float32, device=dev, max_batch=2, max_samples=512)
+    for n in (16, 203, 331):
+        x = torch.from_numpy(g[f"wav{n}"])[:, 0]
+        codes = eng.encode_padded(x).cpu().numpy()
+        want = g[f"codes{n}"][:, :c.encoder_valid_num_quantizers]
+        assert codes.shape == want.shape, (codes.shape, want.shape)
+        frac = float((codes != want).mean())
+        print(f"encoder n={n}: {codes.shape[-1]} frames, mismatching indices {frac:.4f}")
+        assert frac <= 0.01
+    rows = eng.encode(torch.from_numpy(g["wav331"])[:, 0], torch.tensor([[1] * 331, [1] * 170 + [0] * 161]))
+    assert [r.shape for r in rows] == [(21, 4), (11, 4)]

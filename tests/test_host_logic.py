@@ -104,8 +104,19 @@ def test_tokenizer_decode_input_errors():
     tk = Qwen3TTSTokenizer()
     with pytest.raises(TypeError):
         tk.decode(3.14)
+    class NoEncoder:                       # a tokenizer whose checkpoint had no `encoder.*` weights
+        input_sample_rate = 24000
+        def encode(self, x, m, return_dict=True):
+            raise NotImplementedError("no encoder weights")
+    tk.model = NoEncoder()
     with pytest.raises(NotImplementedError):
         tk.encode(np.zeros(10), sr=24000)
+    with pytest.raises(NotImplementedError, match="librosa"):
+        tk.encode("ref.wav")                                   # audio files need librosa / soundfile
+    with pytest.raises(NotImplementedError, match="resampling"):
+        tk.encode(np.zeros(10), sr=16000)
+    with pytest.raises(ValueError):
+        tk.encode(np.zeros(10))                                # numpy input without sr (IT:181)
 
 
 def test_model_wrapper_validation():

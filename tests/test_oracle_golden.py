@@ -244,3 +244,30 @@ def test_staged_stream_bookkeeping_matches_full_forward(codec_tiny):
             got = torch.cat([e.push(codes[..., a:b]) for a, b in zip(cuts[:-1], cuts[1:])], dim=-1)
             assert got.shape == full.shape
             assert (got - full).abs().max().item() <= 3e-5, cuts[:4]
+
+
+def test_encoder_staging_mirror_and_small_golden(golden_dir):
+    """(1) oracle/codec_enc_stage_emul.py -- the channel-last / super-row orchestration the HIP encoder uses -- gives the
+    oracle's codes bit for bit; (2) at the GEMM-friendly dimensions of the HIP parity test both equal the reference's own
+    encoder class (tests/golden/codec_enc_small.npz)."""
+    import codec_enc_ref
+    import codec_enc_stage_emul
+    rng = np.random.default_rng(2)
+    c = synth.mimi_enc_tiny()
+    w = _td(synth.mimi_enc_weights(c))
+    with torch.no_grad():
+        for n in (7, 16, 160, 203, 331):
+            x = torch.from_numpy((rng.standard_normal((2, n)) * 0.5).astype(np.float32))
+            ref = codec_enc_ref.mimi_encode(w, c, x.unsqueeze(1))[:, :c.encoder_valid_num_quantizers]
+            assert torch.equal(codec_enc_stage_emul.encode(w, c, x), ref), n
+    g = np.load(os.path.join(golden_dir, "codec_enc_small.npz"))
+    c = synth.mimi_enc_small()
+    wn = synth.mimi_enc_weights(c)
+    assert abs(synth.weights_checksum(wn) - float(g["weights_checksum"])) < 1e-6
+    w = _td(wn)
+    with torch.no_grad():
+        for n in (16, 203, 331):
+            x = torch.from_numpy(g[f"wav{n}"])
+            assert np.array_equal(codec_enc_ref.mimi_encode(w, c, x).numpy(), g[f"codes{n}"]), n
+            assert np.array_equal(codec_enc_stage_emul.encode(w, c, x[:, 0]).numpy(),
+                                  g[f"codes{n}"][:, :c.encoder_valid_num_quantizers]), n
