@@ -379,3 +379,23 @@ def test_prompt_plan_randomised_against_oracle():
         assert (rows[: nn * Tm].reshape(nn, Tm, H) - e0).abs().max() <= 1e-6, tag
         assert (rows[nn * Tm:].reshape(nn, Tt, H) - tr0).abs().max() <= 1e-6, tag
         assert (proj[PLAN_PAD_ROW] - pad0.reshape(-1)).abs().max() <= 1e-6, tag
+
+
+def test_encoder_config_from_reference_tokenizer_json(golden_dir):
+    """CodecEncoderConfig reads the Mimi `encoder_config` the reference's tokenizer config serialises
+    (tests/golden/ckpt_tiny/speech_tokenizer/config.json, written by Qwen3TTSTokenizerV2Config)."""
+    import json
+    import os
+    import synth
+    from qwen3_tts_amd.config import CodecEncoderConfig
+    with open(os.path.join(golden_dir, "ckpt_tiny", "speech_tokenizer", "config.json")) as f:
+        cfg = CodecEncoderConfig.from_any(json.load(f))
+    real = synth.mimi_enc_real()
+    for k in ("hidden_size", "num_filters", "num_residual_layers", "kernel_size", "last_kernel_size", "residual_kernel_size",
+              "dilation_growth_rate", "compress", "codebook_size", "codebook_dim", "num_quantizers", "num_semantic_quantizers",
+              "num_hidden_layers", "intermediate_size", "num_attention_heads", "num_key_value_heads", "head_dim",
+              "sliding_window", "encoder_valid_num_quantizers", "encode_downsample_rate"):
+        assert getattr(cfg, k) == getattr(real, k), k
+    assert tuple(cfg.upsampling_ratios) == tuple(real.upsampling_ratios) and abs(cfg.rope_theta - real.rope_theta) < 1e-3
+    small = CodecEncoderConfig.from_any(synth.cfg_dict(synth.mimi_enc_small()))
+    assert small.head_dim == 64 and small.upsampling_ratios == (4, 2) and small.encoder_valid_num_quantizers == 4
