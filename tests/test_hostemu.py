@@ -1,0 +1,167 @@
+"""The engines' REAL orchestration code on the CPU.
+
+tests/hostemu builds csrc/codec_engine.hip and csrc/encoder_engine.hip as host C++ (device memory = host memory) and
+links them with plain-loop CPU versions of the kernel launch interfaces.  What runs here is therefore the product's own
+finalize() weight repacking, buffer rotation, strides, streaming carries and C ABI -- everything of those engines except
+the HIP kernels themselves -- checked against the oracle and the reference goldens.  It is how the two code paths that
+have not had a hardware run yet (state-carrying stream decode, the codec encoder) are exercised in round 1, and it keeps
+the validated decoder orchestration under a CPU regression test."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import codec_ref
+import codec_enc_ref
+import synth
+from qwen3_tts_amd import _lib
+from qwen3_tts_amd.config import CodecDecoderConfig, CodecEncoderConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    sys.path.insert(0, os.path.join(HERE, "hostemu"))
+    import build as hostemu_build
+    lib = C.CDLL(hostemu_build.build())
+    vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
+    lib.qtts_last_error.restype = C.c_char_p
+    lib.qtts_codec_create.argtypes = [C.POINTER(_lib.CodecConfigC), C.POINTER(vp)]
+    lib.qtts_codec_destroy.argtypes = [vp]; lib.qtts_codec_destroy.restype = None
+    lib.qtts_codec_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, i64p]
+    lib.qtts_codec_finalize.argtypes = [vp]
+    lib.qtts_codec_forward.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.qtts_codec_decode.argtypes = [vp, vp, i32, i32, i32, i32, vp, i64p, vp]
+    lib.qtts_codec_stream_begin.argtypes = [vp, i32]
+    lib.qtts_codec_stream_push.argtypes = [vp, vp, i32, vp, vp]
+    lib.qtts_encoder_create.argtypes = [C.POINTER(_lib.EncoderConfigC), C.POINTER(vp)]
+    lib.qtts_encoder_destroy.argtypes = [vp]; lib.qtts_encoder_destroy.restype = None
+    lib.qtts_encoder_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, i64p]
+    lib.qtts_encoder_finalize.argtypes = [vp]
+    lib.qtts_encoder_frames.argtypes = [vp, C.c_int64, i64p]
+    lib.qtts_encoder_encode.argtypes = [vp, vp, i32, i32, vp, vp]
+    return lib
+
+
+def _ok(lib, rc):
+    assert rc == 0, (rc, (lib.qtts_last_error() or b"").decode())
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+@pytest.fixture(scope="module")
+def codec(emu):
+    c = synth.codec_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.codec_weights(c).items()}
+    cfg = CodecDecoderConfig.from_any(synth.cfg_dict(c))
+    cc = _lib.CodecConfigC()
+    for f in ("codebook_size", "codebook_dim", "hidden_size", "latent_dim", "num_attention_heads", "num_key_value_heads",
+              "head_dim", "sliding_window", "intermediate_size", "num_hidden_layers", "num_quantizers", "decoder_dim"):
+        setattr(cc, f, int(getattr(cfg, f)))
+    cc.n_upsample_rates, cc.n_upsampling_ratios = len(cfg.upsample_rates), len(cfg.upsampling_ratios)
+    for i, r in enumerate(cfg.upsample_rates):
+        cc.upsample_rates[i] = int(r)
+    for i, r in enumerate(cfg.upsampling_ratios):
+        cc.upsampling_ratios[i] = int(r)
+    cc.rms_norm_eps, cc.rope_theta = float(cfg.rms_norm_eps), float(cfg.rope_theta)
+    cc.compute_dtype, cc.max_batch, cc.max_frames = _lib.QTTS_F32, 2, 64
+    h = C.c_void_p()
+    _ok(emu, emu.qtts_codec_create(C.byref(cc), C.byref(h)))
+    for name, t in w.items():
+        if ".input_proj." in name and name.startswith("quantizer."):
+            continue
+        _lib.bind_tensor(emu.qtts_codec_bind, h, name, t)
+    _ok(emu, emu.qtts_codec_finalize(h))
+    yield c, w, h
+    emu.qtts_codec_destroy(h)
+
+
+def test_decoder_orchestration_forward_and_chunked(emu, codec):
+    """The validated decoder path, now also under a CPU regression test: finalize() repacking (tap layouts, polyphase
+    transposed convs, fused RVQ projection, gate/up interleave) + forward() + chunked decode with -1 padding."""
+    c, w, h = codec
+    rng = np.random.default_rng(3)
+    codes = rng.integers(0, c.codebook_size, (2, c.num_quantizers, 11))
+    wav = np.zeros((2, 11 * c.total_upsample), np.float32)
+    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 2, 11, _ptr(wav), None, None))
+    with torch.no_grad():
+        ref = codec_ref.decoder_forward(w, c, torch.from_numpy(codes))[:, 0].numpy()
+    assert np.sqrt(((wav - ref) ** 2).mean()) <= 1e-5
+    padded = np.ascontiguousarray(codes.transpose(0, 2, 1)).copy()          # (B, T, Q), row 1 ends after 7 frames
+    padded[1, 7:] = -1
+    out = np.zeros((2, 11 * c.total_upsample), np.float32)
+    lens = (C.c_int64 * 2)()
+    _ok(emu, emu.qtts_codec_decode(h, _ptr(padded), 2, 11, 4, 3, _ptr(out), lens, None))
+    with torch.no_grad():
+        rows = codec_ref.model_decode(w, c, torch.from_numpy(padded))        # default chunking: one chunk here
+        chunked = codec_ref.chunked_decode(w, c, torch.clamp(torch.from_numpy(padded), min=0).transpose(1, 2), 4, 3)[:, 0].numpy()
+    assert [int(x) for x in lens] == [11 * c.total_upsample, 7 * c.total_upsample] == [r.shape[0] for r in rows]
+    assert np.sqrt(((out - chunked) ** 2).mean()) <= 1e-5
+
+
+def test_stream_push_equals_whole_sequence_forward(emu, codec):
+    """qtts_codec_stream_begin / _push (state-carrying streaming decode): the product's C++ orchestration,
+    run here on CPU kernels, reproduces the whole-sequence forward for ragged packets, single frames and streams several
+    attention windows long."""
+    c, w, h = codec
+    T = 45
+    codes = np.random.default_rng(12).integers(0, c.codebook_size, (2, c.num_quantizers, T))
+    with torch.no_grad():
+        ref = codec_ref.decoder_forward(w, c, torch.from_numpy(codes))[:, 0].numpy()
+    for cuts in ([0, 1, 2, 3, 10, 11, 30, 45], list(range(0, 46, 5)), [0, 45], list(range(46))):
+        _ok(emu, emu.qtts_codec_stream_begin(h, 2))
+        outs = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            pk = np.ascontiguousarray(codes[..., a:b])
+            o = np.zeros((2, (b - a) * c.total_upsample), np.float32)
+            _ok(emu, emu.qtts_codec_stream_push(h, _ptr(pk), b - a, _ptr(o), None))
+            outs.append(o)
+        got = np.concatenate(outs, axis=1)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 5e-5, cuts[:4]
+    assert emu.qtts_codec_stream_begin(h, 3) != 0                            # more sequences than max_batch
+
+
+def test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir):
+    """qtts_encoder_* (HIP codec encoder): finalize() repacking (stride-1 taps, super-row strided taps,
+    normalised codebooks) + encode() on CPU kernels against the codes of the reference's own encoder class."""
+    g = np.load(os.path.join(golden_dir, "codec_enc_small.npz"))
+    c = synth.mimi_enc_small()
+    w = {k: torch.from_numpy(v) for k, v in synth.mimi_enc_weights(c).items()}
+    cfg = CodecEncoderConfig.from_any(synth.cfg_dict(c))
+    ec = _lib.EncoderConfigC()
+    for f in ("hidden_size", "num_filters", "num_residual_layers", "kernel_size", "last_kernel_size", "residual_kernel_size",
+              "dilation_growth_rate", "compress", "codebook_size", "codebook_dim", "num_quantizers", "num_semantic_quantizers",
+              "num_hidden_layers", "intermediate_size", "num_attention_heads", "num_key_value_heads", "head_dim", "sliding_window"):
+        setattr(ec, f, int(getattr(cfg, f)))
+    ec.n_ratios = len(cfg.upsampling_ratios)
+    for i, r in enumerate(cfg.upsampling_ratios):
+        ec.ratios[i] = int(r)
+    ec.valid_num_quantizers = cfg.encoder_valid_num_quantizers
+    ec.rope_theta, ec.norm_eps = float(cfg.rope_theta), float(cfg.norm_eps)
+    ec.compute_dtype, ec.max_batch, ec.max_samples = _lib.QTTS_F32, 2, 512
+    h = C.c_void_p()
+    _ok(emu, emu.qtts_encoder_create(C.byref(ec), C.byref(h)))
+    try:
+        for name, t in w.items():
+            if not name.endswith("codebook.initialized"):
+                _lib.bind_tensor(emu.qtts_encoder_bind, h, name, t)
+        _ok(emu, emu.qtts_encoder_finalize(h))
+        for n in (16, 203, 331):
+            x = np.ascontiguousarray(g[f"wav{n}"][:, 0])
+            fr = C.c_int64()
+            _ok(emu, emu.qtts_encoder_frames(h, n, C.byref(fr)))
+            want = g[f"codes{n}"][:, :c.encoder_valid_num_quantizers]
+            assert fr.value == want.shape[-1]
+            codes = np.zeros((2, c.encoder_valid_num_quantizers, fr.value), np.int64)
+            _ok(emu, emu.qtts_encoder_encode(h, _ptr(x), 2, n, _ptr(codes), None))
+            assert np.array_equal(codes, want), (n, float((codes != want).mean()))
+        assert emu.qtts_encoder_encode(h, _ptr(x), 3, 331, _ptr(codes), None) != 0      # batch above max_batch
+    finally:
+        emu.qtts_encoder_destroy(h)
