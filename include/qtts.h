@@ -43,8 +43,8 @@ extern "C" {
 
 const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
- * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*). */
-#define QTTS_ABI_VERSION 4
+ * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*). */
+#define QTTS_ABI_VERSION 5
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -178,6 +178,51 @@ int qtts_encoder_frames(qtts_encoder* e, int64_t samples, int64_t* frames);
 /* wav_dev float (B, samples) device, zero-padded rows; codes_dev int64 (B, valid_num_quantizers, frames) device.
  * The caller trims each row to ceil(valid_samples / encode_downsample_rate) frames and transposes, as v2:984-985. */
 int qtts_encoder_encode(qtts_encoder* e, const float* wav_dev, int32_t B, int32_t samples, int64_t* codes_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Speaker embedding of the Base (voice-clone) model -- SURVEY.md 8(f4).
+ * Replaces Qwen3TTSForConditionalGeneration.extract_speaker_embedding (modeling_qwen3_tts.py:1941-1954):
+ * mel_spectrogram (:402-464; n_fft 1024, hop 256, 128 mels, 0..12 kHz, center=False) -> Qwen3TTSSpeakerEncoder
+ * (ECAPA-TDNN, :95-393).
+ * STATUS (round 1): compiled for gfx950; orchestration executed in the CPU suite on kernel stand-ins
+ * (tests/test_hostemu.py); not yet executed on hardware.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct qtts_speaker qtts_speaker;
+
+typedef struct {
+    /* Qwen3TTSSpeakerEncoderConfig (configuration_qwen3_tts.py:22-67) */
+    int32_t mel_dim;
+    int32_t enc_dim;
+    int32_t n_blocks;               /* len(enc_channels) */
+    int32_t channels[8];
+    int32_t kernel_sizes[8];
+    int32_t dilations[8];
+    int32_t attention_channels;
+    int32_t res2net_scale;
+    int32_t se_channels;
+    /* mel front end (the constants of modeling_qwen3_tts.py:1944-1952) */
+    int32_t n_fft;
+    int32_t hop_size;
+    int32_t win_size;
+    int32_t num_mels;
+    /* engine options */
+    int32_t compute_dtype;          /* QTTS_F32 | QTTS_BF16 (the STFT and mel projection always run in fp32) */
+    int32_t max_batch;
+    int32_t max_samples;
+} qtts_speaker_config;
+
+int qtts_speaker_create(const qtts_speaker_config* cfg, qtts_speaker** out);
+void qtts_speaker_destroy(qtts_speaker* s);
+/* `name` = reference state_dict key relative to `speaker_encoder.` (e.g. "blocks.1.res2net_block.blocks.0.conv.weight"),
+ * plus "mel_basis" float (num_mels, n_fft/2+1): the Slaney filterbank the reference takes from librosa.filters.mel. */
+int qtts_speaker_bind(qtts_speaker* s, const char* name, const void* host, int32_t src_dtype, int32_t ndim,
+                      const int64_t* shape);
+int qtts_speaker_finalize(qtts_speaker* s);
+int qtts_speaker_mel_frames(qtts_speaker* s, int64_t samples, int64_t* frames);
+/* wav_dev float (B, samples) device, 24 kHz, in [-1, 1]; emb_dev float (B, enc_dim); mels_dev optional float
+ * (B, mel_frames, mel_dim) (the log-mel features, for tests). */
+int qtts_speaker_embed(qtts_speaker* s, const float* wav_dev, int32_t B, int32_t samples, float* emb_dev, float* mels_dev,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Talker + code predictor: the autoregressive speech-token decoder.

@@ -57,12 +57,20 @@ class EncoderConfigC(C.Structure):
                 ("compute_dtype", C.c_int32), ("max_batch", C.c_int32), ("max_samples", C.c_int32)]
 
 
+class SpeakerConfigC(C.Structure):
+    _fields_ = [("mel_dim", C.c_int32), ("enc_dim", C.c_int32), ("n_blocks", C.c_int32), ("channels", C.c_int32 * 8),
+                ("kernel_sizes", C.c_int32 * 8), ("dilations", C.c_int32 * 8), ("attention_channels", C.c_int32),
+                ("res2net_scale", C.c_int32), ("se_channels", C.c_int32), ("n_fft", C.c_int32), ("hop_size", C.c_int32),
+                ("win_size", C.c_int32), ("num_mels", C.c_int32), ("compute_dtype", C.c_int32), ("max_batch", C.c_int32),
+                ("max_samples", C.c_int32)]
+
+
 class TalkerStatsC(C.Structure):
     _fields_ = [("frames_run", C.c_int32), ("graph_nodes", C.c_int32), ("weight_bytes_per_frame", C.c_double),
                 ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64)]
 
 
-ABI_VERSION = 4           # include/qtts.h; bumped on any signature change
+ABI_VERSION = 5           # include/qtts.h; bumped on any signature change
 
 # every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
@@ -70,6 +78,8 @@ SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_cod
            "qtts_codec_stream_begin", "qtts_codec_stream_push",
            "qtts_encoder_create", "qtts_encoder_destroy", "qtts_encoder_bind", "qtts_encoder_finalize", "qtts_encoder_frames",
            "qtts_encoder_encode",
+           "qtts_speaker_create", "qtts_speaker_destroy", "qtts_speaker_bind", "qtts_speaker_finalize", "qtts_speaker_mel_frames",
+           "qtts_speaker_embed",
            "qtts_talker_create", "qtts_talker_destroy", "qtts_talker_bind", "qtts_talker_finalize",
            "qtts_talker_text_projection", "qtts_talker_text_embed", "qtts_talker_assemble_rows", "qtts_talker_prefill",
            "qtts_talker_generate",
@@ -109,6 +119,13 @@ def load_library():
     lib.qtts_encoder_finalize.argtypes = [vp]
     lib.qtts_encoder_frames.argtypes = [vp, C.c_int64, i64p]
     lib.qtts_encoder_encode.argtypes = [vp, f32p, i32, i32, vp, vp]
+    lib.qtts_speaker_create.argtypes = [C.POINTER(SpeakerConfigC), C.POINTER(vp)]
+    lib.qtts_speaker_destroy.argtypes = [vp]
+    lib.qtts_speaker_destroy.restype = None
+    lib.qtts_speaker_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, i64p]
+    lib.qtts_speaker_finalize.argtypes = [vp]
+    lib.qtts_speaker_mel_frames.argtypes = [vp, C.c_int64, i64p]
+    lib.qtts_speaker_embed.argtypes = [vp, f32p, i32, i32, f32p, f32p, vp]
     lib.qtts_talker_create.argtypes = [C.POINTER(TalkerConfigC), C.POINTER(vp)]
     lib.qtts_talker_destroy.argtypes = [vp]
     lib.qtts_talker_destroy.restype = None
@@ -124,7 +141,8 @@ def load_library():
     lib.qtts_talker_get_stats.argtypes = [vp, C.POINTER(TalkerStatsC)]
     lib.qtts_talker_set_profile.argtypes = [vp, i32]
     for s in SYMBOLS:
-        if s not in ("qtts_last_error", "qtts_codec_destroy", "qtts_talker_destroy", "qtts_encoder_destroy"):
+        if s not in ("qtts_last_error", "qtts_codec_destroy", "qtts_talker_destroy", "qtts_encoder_destroy",
+                     "qtts_speaker_destroy"):
             getattr(lib, s).restype = C.c_int
     if lib.qtts_abi_version() != ABI_VERSION:
         raise QttsError(-101, "libqtts.so ABI version mismatch; rebuild")

@@ -95,6 +95,29 @@ void launch_pad_rows(const float* src, int T, int left, int right, int replicate
 void launch_vq_argmin_update(const float* scores, int bins, const float* enorm, const float* table, int D, float* r,
                              int64_t* codes_out, int64_t stride_b, int B, int T, hipStream_t st);
 
+// ---- speaker encoder (ECAPA-TDNN + mel front end) -- speaker_kernels.hip
+enum RowAct { ROWACT_NONE = 0, ROWACT_RELU = 1, ROWACT_RELU_TANH = 2, ROWACT_SIGMOID = 3, ROWACT_LOG_CLAMP = 4 };
+// out[b][r][j] = wav[b][reflect(r*hop + j - pad)] for r < R (reflect = torch 'reflect', no edge repeat)
+void launch_reflect_rows_1d(const float* wav, int S, int pad, int R, int hop, float* out, int B, hipStream_t st);
+// out[row][f] = sqrt(re^2 + im^2 + 1e-9) for f < nb (re = y[row][f], im = y[row][nb + f]), 0 for nb <= f < Kp
+void launch_magnitude_pad(const float* y, int ldy, int nb, float* out, int Kp, int64_t rows, hipStream_t st);
+// dst[b][i][c] = src1[b][reflect(i - p)][c] (+ src2[...]) for i in [0, T + 2p): nn.Conv1d(padding="same", padding_mode="reflect")
+void launch_reflect_pad_add_rows(const float* src1, int ld1, const float* src2, int ld2, int T, int p, int C, float* dst, int B,
+                                 hipStream_t st);
+// dst[(b*n + t)*ldd + c] = act(src[(b*Tsrc + skip + t)*lds + c]) for c < C
+void launch_copy_act_rows(const float* src, int lds, int Tsrc, int skip, int n, int C, int act, float* dst, int ldd, int B,
+                          hipStream_t st);
+// mean[b][c] = sum_t w x, sd[b][c] = sqrt(clamp(sum_t w (x - mean)^2, 1e-12)); w = att[b][t][c] or 1/T when att == null
+void launch_col_stats(const float* x, int ldx, const float* att, int T, int C, float* mean, float* sd, int ld_out, int B,
+                      hipStream_t st);
+// out[b][t][c] = h[b][t][c] * gate[b][c] + r[b][t][c]
+void launch_scale_add_rows(const float* h, int ldh, const float* gate, const float* r, int ldr, float* out, int ldo, int T, int C,
+                           int B, hipStream_t st);
+// out[b][t] = [x[b][t] | mean[b] | sd[b]]  (3C columns)
+void launch_concat_stats(const float* x, int ldx, const float* mean, const float* sd, int T, int C, float* out, int B, hipStream_t st);
+// softmax over t for every (b, c), in place
+void launch_softmax_time(float* a, int T, int C, int B, hipStream_t st);
+
 // --------------------------------------------------------------------------------- attention.hip
 // Generic row attention over a fused qkv buffer (prefill + codec transformer).
 struct AttnRowsParams {

@@ -8,9 +8,10 @@
     (`from_pretrained`, `generate_custom_voice`, `generate_voice_design`, `generate_voice_clone`,
     kwargs merging, validation, same exception types).
 
-Out of the hot path: building a voice-clone prompt from raw audio needs the codec
-*encoder* and the ECAPA speaker encoder; `create_voice_clone_prompt` therefore raises, while
-`generate_voice_clone(voice_clone_prompt=...)` with precomputed items is fully supported.
+SURVEY.md 8f3/8f4: building a voice-clone prompt from raw audio runs the codec *encoder* (encoder.py) and the ECAPA
+speaker encoder (speaker.py); both are compiled and CPU-emulated in round 1, their first hardware run is pending, so
+`create_voice_clone_prompt` is experimental, while `generate_voice_clone(voice_clone_prompt=...)` with precomputed
+items is validated.
 """
 import json
 import os
@@ -172,7 +173,11 @@ class Qwen3TTSForConditionalGeneration:
             raise KeyError("state_dict has no talker.model.text_embedding.weight (needed by the prompt assembly)")
         self.speech_tokenizer = None
         self.generate_config = None
-        self.speaker_encoder = None
+        self.speaker_encoder = None             # built on first use from the `speaker_encoder.*` weights (Base model)
+        self.speaker_encoder_sample_rate = 24000
+        full = state_dict
+        self._speaker_state = {k: v for k, v in full.items() if k.startswith("speaker_encoder.")} or None
+        self._speaker_config = config
         self.supported_speakers = list(self.config.spk_id.keys())
         self.supported_languages = ["auto"] + [k for k in self.config.codec_language_id if "dialect" not in k]   # M:1831-1834
         self.tokenizer_type = self.config.tokenizer_type
@@ -212,6 +217,19 @@ class Qwen3TTSForConditionalGeneration:
         trailing = rows[n * Tm:].reshape(n, Tt, H)
         mask = torch.from_numpy(plan["mask"]).to(self.device)
         return embeds, mask, trailing, proj[PLAN_PAD_ROW].reshape(1, 1, H)
+
+    def extract_speaker_embedding(self, audio: np.ndarray, sr: int) -> torch.Tensor:
+        """M:1941-1954: 24 kHz waveform -> (enc_dim,) x-vector, log-mel + ECAPA-TDNN on the HIP speaker engine
+        (EXPERIMENTAL in round 1: compiled and CPU-emulated, hardware run pending)."""
+        assert sr == 24000, "Only support 24kHz audio"
+        if self.speaker_encoder is None:
+            if not self._speaker_state:
+                raise NotImplementedError("this checkpoint has no `speaker_encoder.*` weights (only the Base model does)")
+            from .speaker import SpeakerEncoderEngine
+            self.speaker_encoder = SpeakerEncoderEngine(self._speaker_config, self._speaker_state, compute_dtype=torch.float32,
+                                                        device=str(self.device))
+            self._speaker_state = None
+        return self.speaker_encoder.extract_speaker_embedding(audio, sr)
 
     # ------------------------------------------------------------------ generate (seam S1)
     @torch.no_grad()
@@ -383,10 +401,41 @@ class Qwen3TTSModel:
         return out
 
     # ---- voice clone (qwen3_tts_model.py:356-636)
-    def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode=False):
-        raise NotImplementedError(
-            "create_voice_clone_prompt needs the codec encoder and the speaker encoder, which are outside the MI355X "
-            "hot path (SURVEY.md 8f3/8f4); pass precomputed VoiceClonePromptItem objects via `voice_clone_prompt=`.")
+    def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode=False) -> List[VoiceClonePromptItem]:
+        """qwen3_tts_model.py:356-458: reference audio -> prompt items (speech codes through the tokenizer's encoder,
+        x-vector through the speaker encoder).  Audio must be given as (waveform np.ndarray, sr) at 24 kHz: file paths,
+        URLs, base64 and resampling go through librosa / soundfile in the reference, which this build does not have.
+        EXPERIMENTAL in round 1: both encoders are compiled and CPU-emulated; their first hardware run is pending."""
+        if self.model.tts_model_type != "base":
+            raise self._unsupported("create_voice_clone_prompt")
+        audios = self._ensure_list(ref_audio)
+        texts = self._ensure_list(ref_text) if isinstance(ref_text, list) else [ref_text] * len(audios)
+        xvecs = self._ensure_list(x_vector_only_mode) if isinstance(x_vector_only_mode, list) else [x_vector_only_mode] * len(audios)
+        if len(texts) != len(audios) or len(xvecs) != len(audios):
+            raise ValueError(f"Batch size mismatch: ref_audio={len(audios)}, ref_text={len(texts)}, x_vector_only_mode={len(xvecs)}")
+        normalized = []
+        for a in audios:
+            if isinstance(a, (str, bytes)):
+                raise NotImplementedError("create_voice_clone_prompt: audio files / URLs / base64 need librosa + soundfile; "
+                                          "pass (waveform, sr) tuples")
+            if not (isinstance(a, tuple) and len(a) == 2):
+                raise TypeError(f"Unsupported audio input type: {type(a)}")                          # IM:259
+            wav, sr = np.asarray(a[0], dtype=np.float32), int(a[1])
+            if wav.ndim > 1:
+                wav = wav.mean(axis=-1)
+            if sr != self.model.speaker_encoder_sample_rate:
+                raise NotImplementedError(f"create_voice_clone_prompt: resampling {sr} -> 24000 Hz needs librosa")
+            normalized.append((wav, sr))
+        for i, (rtext, xv) in enumerate(zip(texts, xvecs)):
+            if not xv and (rtext is None or rtext == ""):
+                raise ValueError(f"ref_text is required when x_vector_only_mode=False (ICL mode). Bad index={i}")
+        enc = self.model.speech_tokenizer.encode([w for w, _ in normalized], sr=normalized[0][1])
+        items = []
+        for (wav, sr), code, rtext, xv in zip(normalized, enc.audio_codes, texts, xvecs):
+            items.append(VoiceClonePromptItem(ref_code=None if xv else code,
+                                              ref_spk_embedding=self.model.extract_speaker_embedding(audio=wav, sr=sr),
+                                              x_vector_only_mode=bool(xv), icl_mode=bool(not xv), ref_text=rtext))
+        return items
 
     def _prompt_items_to_voice_clone_prompt(self, items: List[VoiceClonePromptItem]) -> Dict[str, Any]:
         return dict(ref_code=[it.ref_code for it in items], ref_spk_embedding=[it.ref_spk_embedding for it in items],

@@ -354,6 +354,12 @@ def speaker_tiny() -> SpeakerCfg:
                       enc_res2net_scale=4, enc_se_channels=8)
 
 
+def speaker_small() -> SpeakerCfg:
+    """Smallest configuration the HIP speaker encoder accepts (every contraction a multiple of 32, real mel front end)."""
+    return SpeakerCfg(mel_dim=128, enc_dim=64, enc_channels=(128, 128, 128, 128, 384), enc_attention_channels=32,
+                      enc_res2net_scale=4, enc_se_channels=32)
+
+
 def speaker_param_shapes(c: SpeakerCfg) -> Dict[str, tuple]:
     """state_dict names / shapes of Qwen3TTSSpeakerEncoder (modeling_qwen3_tts.py:312-367), relative to `speaker_encoder.`."""
     ch, ks = list(c.enc_channels), list(c.enc_kernel_sizes)

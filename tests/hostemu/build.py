@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: build tests/hostemu/libqtts_hostemu.so = the two engine orchestration files of the product
-(csrc/codec_engine.hip, csrc/encoder_engine.hip) compiled as HOST C++ against tests/hostemu/hip/hip_runtime.h, linked with
+(csrc/codec_engine.hip, csrc/encoder_engine.hip, csrc/speaker_engine.hip) compiled as HOST C++ against tests/hostemu/hip/hip_runtime.h, linked with
 CPU versions of the kernel launch interfaces (cpu_kernels.cpp).  The library exports the codec + encoder part of the C ABI
 on host pointers; tests/test_hostemu.py drives it with numpy arrays and checks it against the oracle."""
 import hashlib
@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
 OUT = os.path.join(HERE, "libqtts_hostemu.so")
-SRCS = [os.path.join(CSRC, "codec_engine.hip"), os.path.join(CSRC, "encoder_engine.hip"), os.path.join(HERE, "cpu_kernels.cpp")]
+SRCS = [os.path.join(CSRC, "codec_engine.hip"), os.path.join(CSRC, "encoder_engine.hip"),
+        os.path.join(CSRC, "speaker_engine.hip"), os.path.join(HERE, "cpu_kernels.cpp")]
 DEPS = SRCS + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")] + [os.path.join(ROOT, "include", "qtts.h"),
                                                                             os.path.join(HERE, "hip", "hip_runtime.h")]
 

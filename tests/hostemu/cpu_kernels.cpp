@@ -263,4 +263,97 @@ void launch_vq_argmin_update(const float* scores, int bins, const float* enorm, 
     }
 }
 
+// ---- speaker encoder helpers
+static int reflect_index(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+void launch_reflect_rows_1d(const float* wav, int S, int pad, int R, int hop, float* out, int B, hipStream_t) {
+    QTTS_REQUIRE(S > pad, QTTS_ERR_ARG, "mel: waveform shorter than the reflect padding");
+    for (int b = 0; b < B; ++b)
+        for (int r = 0; r < R; ++r)
+            for (int j = 0; j < hop; ++j) out[((size_t)b * R + r) * hop + j] = wav[(size_t)b * S + reflect_index(r * hop + j - pad, S)];
+}
+void launch_magnitude_pad(const float* y, int ldy, int nb, float* out, int Kp, int64_t rows, hipStream_t) {
+    for (int64_t row = 0; row < rows; ++row)
+        for (int f = 0; f < Kp; ++f) {
+            float v = 0.f;
+            if (f < nb) { const float re = y[row * ldy + f], im = y[row * ldy + nb + f]; v = sqrtf(re * re + im * im + 1e-9f); }
+            out[row * Kp + f] = v;
+        }
+}
+void launch_reflect_pad_add_rows(const float* src1, int ld1, const float* src2, int ld2, int T, int p, int C, float* dst, int B,
+                                 hipStream_t) {
+    QTTS_REQUIRE(T > p, QTTS_ERR_ARG, "reflect pad: sequence shorter than the padding");
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < T + 2 * p; ++i) {
+            const int s = reflect_index(i - p, T);
+            for (int c = 0; c < C; ++c)
+                dst[((size_t)b * (T + 2 * p) + i) * C + c] =
+                    src1[((size_t)b * T + s) * ld1 + c] + (src2 ? src2[((size_t)b * T + s) * ld2 + c] : 0.f);
+        }
+}
+static float row_act(float v, int act) {
+    switch (act) {
+        case ROWACT_RELU: return fmaxf(v, 0.f);
+        case ROWACT_RELU_TANH: return tanhf(fmaxf(v, 0.f));
+        case ROWACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ROWACT_LOG_CLAMP: return logf(fmaxf(v, 1e-5f));
+        default: return v;
+    }
+}
+void launch_copy_act_rows(const float* src, int lds, int Tsrc, int skip, int n, int C, int act, float* dst, int ldd, int B,
+                          hipStream_t) {
+    QTTS_REQUIRE(n >= 1 && skip >= 0 && skip + n <= Tsrc, QTTS_ERR_ARG, "copy_act_rows: bad shape");
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < n; ++t)
+            for (int c = 0; c < C; ++c)
+                dst[((size_t)b * n + t) * ldd + c] = row_act(src[((size_t)b * Tsrc + skip + t) * lds + c], act);
+}
+void launch_col_stats(const float* x, int ldx, const float* att, int T, int C, float* mean, float* sd, int ld_out, int B,
+                      hipStream_t) {
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float m = 0.f;
+            for (int t = 0; t < T; ++t) m += (att ? att[((size_t)b * T + t) * C + c] : 1.f / (float)T) * x[((size_t)b * T + t) * ldx + c];
+            float q = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float d = x[((size_t)b * T + t) * ldx + c] - m;
+                q += (att ? att[((size_t)b * T + t) * C + c] : 1.f / (float)T) * d * d;
+            }
+            mean[(size_t)b * ld_out + c] = m;
+            if (sd) sd[(size_t)b * ld_out + c] = sqrtf(fmaxf(q, 1e-12f));
+        }
+}
+void launch_scale_add_rows(const float* h, int ldh, const float* gate, const float* r, int ldr, float* out, int ldo, int T, int C,
+                           int B, hipStream_t) {
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < C; ++c) {
+                const size_t row = (size_t)b * T + t;
+                out[row * ldo + c] = h[row * ldh + c] * gate[(size_t)b * C + c] + r[row * ldr + c];
+            }
+}
+void launch_concat_stats(const float* x, int ldx, const float* mean, const float* sd, int T, int C, float* out, int B, hipStream_t) {
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t)
+            for (int c = 0; c < C; ++c) {
+                const size_t row = (size_t)b * T + t;
+                out[row * 3 * C + c] = x[row * ldx + c];
+                out[row * 3 * C + C + c] = mean[(size_t)b * C + c];
+                out[row * 3 * C + 2 * C + c] = sd[(size_t)b * C + c];
+            }
+}
+void launch_softmax_time(float* a, int T, int C, int B, hipStream_t) {
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float m = -INFINITY;
+            for (int t = 0; t < T; ++t) m = fmaxf(m, a[((size_t)b * T + t) * C + c]);
+            float l = 0.f;
+            for (int t = 0; t < T; ++t) { float& e = a[((size_t)b * T + t) * C + c]; e = expf(e - m); l += e; }
+            for (int t = 0; t < T; ++t) a[((size_t)b * T + t) * C + c] /= l;
+        }
+}
+
 }  // namespace qtts

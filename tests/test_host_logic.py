@@ -399,3 +399,50 @@ def test_encoder_config_from_reference_tokenizer_json(golden_dir):
     assert tuple(cfg.upsampling_ratios) == tuple(real.upsampling_ratios) and abs(cfg.rope_theta - real.rope_theta) < 1e-3
     small = CodecEncoderConfig.from_any(synth.cfg_dict(synth.mimi_enc_small()))
     assert small.head_dim == 64 and small.upsampling_ratios == (4, 2) and small.encoder_valid_num_quantizers == 4
+
+
+def test_create_voice_clone_prompt_wrapper_logic():
+    """qwen3_tts_model.py:356-458 mirrored: batching rules, ICL needs ref_text, error types, item fields -- with stand-ins
+    for the two device engines (the wrapper logic runs before / around them)."""
+    import numpy as np
+    import pytest
+    import torch
+    from qwen3_tts_amd.model import Qwen3TTSModel, VoiceClonePromptItem
+
+    class Tok:
+        def encode(self, wavs, sr=None):
+            assert sr == 24000
+            return type("O", (), {"audio_codes": [torch.full((max(1, len(w) // 1920), 16), i) for i, w in enumerate(wavs)]})()
+
+    class M:
+        device = torch.device("cpu")
+        tts_model_type, tts_model_size, tokenizer_type = "base", "1b7", "12hz"
+        speaker_encoder_sample_rate = 24000
+        speech_tokenizer = Tok()
+        def get_supported_languages(self): return None
+        def get_supported_speakers(self): return None
+        def extract_speaker_embedding(self, audio, sr):
+            assert sr == 24000
+            return torch.full((8,), float(len(audio)))
+
+    w = Qwen3TTSModel(M(), processor=None, generate_defaults={})
+    a, b = (np.zeros(4000, np.float32), 24000), (np.zeros(8000, np.float32), 24000)
+    items = w.create_voice_clone_prompt([a, b], ref_text=["hello", "world"])
+    assert all(isinstance(i, VoiceClonePromptItem) for i in items) and [i.icl_mode for i in items] == [True, True]
+    assert items[1].ref_code.shape == (4, 16) and float(items[1].ref_spk_embedding[0]) == 8000.0 and items[0].ref_text == "hello"
+    xv = w.create_voice_clone_prompt(a, x_vector_only_mode=True)
+    assert len(xv) == 1 and xv[0].ref_code is None and xv[0].x_vector_only_mode and not xv[0].icl_mode
+    with pytest.raises(ValueError, match="ref_text is required"):
+        w.create_voice_clone_prompt(a)
+    with pytest.raises(ValueError, match="Batch size mismatch"):
+        w.create_voice_clone_prompt([a, b], ref_text=["only one"])
+    with pytest.raises(NotImplementedError, match="librosa"):
+        w.create_voice_clone_prompt("ref.wav", ref_text="x")
+    with pytest.raises(NotImplementedError, match="resampling"):
+        w.create_voice_clone_prompt((np.zeros(100, np.float32), 16000), ref_text="x")
+    with pytest.raises(TypeError):
+        w.create_voice_clone_prompt(np.zeros(100, np.float32), ref_text="x")
+    M.tts_model_type = "custom_voice"
+    with pytest.raises(ValueError, match="does not support create_voice_clone_prompt"):
+        w.create_voice_clone_prompt(a, ref_text="x")
+    M.tts_model_type = "base"

@@ -165,3 +165,45 @@ def test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir):
         assert emu.qtts_encoder_encode(h, _ptr(x), 3, 331, _ptr(codes), None) != 0      # batch above max_batch
     finally:
         emu.qtts_encoder_destroy(h)
+
+
+def test_speaker_orchestration_embedding_vs_oracle(emu):
+    """qtts_speaker_* (speaker embedding): finalize() (DFT matrix, filterbank padding, conv tap layouts)
+    + embed() on CPU kernels against oracle/speaker_ref.py (torch.stft log-mel + the ECAPA-TDNN restatement that is pinned
+    to the reference module): log-mel features and the embedding, for a length that is not a multiple of the hop."""
+    import speaker_ref
+    from qwen3_tts_amd.speaker import SpeakerEncoderConfig, fill_speaker_config, mel_filterbank_slaney
+    emu.qtts_speaker_create.argtypes = [C.POINTER(_lib.SpeakerConfigC), C.POINTER(C.c_void_p)]
+    emu.qtts_speaker_destroy.argtypes = [C.c_void_p]; emu.qtts_speaker_destroy.restype = None
+    emu.qtts_speaker_bind.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    emu.qtts_speaker_finalize.argtypes = [C.c_void_p]
+    emu.qtts_speaker_mel_frames.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    emu.qtts_speaker_embed.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    c = synth.speaker_small()
+    w = {k: torch.from_numpy(v) for k, v in synth.speaker_weights(c).items()}
+    cfg = SpeakerEncoderConfig.from_any(synth.cfg_dict(c))
+    assert np.array_equal(mel_filterbank_slaney(24000, 1024, 128, 0, 12000), speaker_ref.mel_filterbank_slaney(24000, 1024, 128, 0, 12000))
+    h = C.c_void_p()
+    _ok(emu, emu.qtts_speaker_create(C.byref(fill_speaker_config(cfg, torch.float32, 2, 8192)), C.byref(h)))
+    try:
+        for name, t in w.items():
+            _lib.bind_tensor(emu.qtts_speaker_bind, h, name, t)
+        _lib.bind_tensor(emu.qtts_speaker_bind, h, "mel_basis", torch.from_numpy(mel_filterbank_slaney(24000, 1024, 128, 0, 12000)))
+        _ok(emu, emu.qtts_speaker_finalize(h))
+        g = np.random.default_rng(9)
+        for n in (4096, 6001):
+            wav = (g.standard_normal((2, n)) * 0.2).clip(-1, 1).astype(np.float32)
+            fr = C.c_int64()
+            _ok(emu, emu.qtts_speaker_mel_frames(h, n, C.byref(fr)))
+            with torch.no_grad():
+                mel_ref = speaker_ref.mel_spectrogram(torch.from_numpy(wav)).transpose(1, 2)
+                emb_ref = speaker_ref.speaker_encoder_forward(w, c, mel_ref).numpy()
+            assert fr.value == mel_ref.shape[1]
+            emb = np.zeros((2, c.enc_dim), np.float32)
+            mels = np.zeros((2, fr.value, c.mel_dim), np.float32)
+            _ok(emu, emu.qtts_speaker_embed(h, _ptr(wav), 2, n, _ptr(emb), _ptr(mels), None))
+            assert np.abs(mels - mel_ref.numpy()).max() <= 2e-4, n
+            assert np.abs(emb - emb_ref).max() <= 1e-4 * max(1.0, float(np.abs(emb_ref).max())), n
+        assert emu.qtts_speaker_embed(h, _ptr(wav), 3, n, _ptr(emb), None, None) != 0
+    finally:
+        emu.qtts_speaker_destroy(h)

@@ -271,3 +271,21 @@ def test_encoder_staging_mirror_and_small_golden(golden_dir):
             assert np.array_equal(codec_enc_ref.mimi_encode(w, c, x).numpy(), g[f"codes{n}"]), n
             assert np.array_equal(codec_enc_stage_emul.encode(w, c, x[:, 0]).numpy(),
                                   g[f"codes{n}"][:, :c.encoder_valid_num_quantizers]), n
+
+
+def test_speaker_staging_mirror_matches_oracle():
+    """oracle/speaker_stage_emul.py -- the DFT-as-GEMM mel front end and the channel-last ECAPA orchestration the HIP speaker
+    engine uses -- against oracle/speaker_ref.py (torch.stft / conv1d restatement pinned to the reference module)."""
+    import speaker_ref
+    import speaker_stage_emul
+    c = synth.speaker_small()
+    w = _td(synth.speaker_weights(c))
+    g = np.random.default_rng(7)
+    with torch.no_grad():
+        mels = torch.from_numpy(g.standard_normal((2, 41, 128)).astype(np.float32))
+        assert (speaker_stage_emul.speaker(w, c, mels) - speaker_ref.speaker_encoder_forward(w, c, mels)).abs().max() <= 1e-5
+        for n in (12000, 12345, 4096):
+            wav = torch.from_numpy((g.standard_normal((2, n)) * 0.2).clip(-1, 1).astype(np.float32))
+            a = speaker_ref.mel_spectrogram(wav).transpose(1, 2)
+            b = speaker_stage_emul.mel_gemm(wav)
+            assert a.shape == b.shape and (a - b).abs().max() <= 5e-5, n
