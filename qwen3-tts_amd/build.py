@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libqtts.so")
 SOURCES = ["gemm_tap.hip", "skinny.hip", "elementwise.hip", "attention.hip", "sampling.hip",
            "codec_engine.hip", "talker_engine.hip", "encoder_kernels.hip", "encoder_engine.hip",
-           "speaker_kernels.hip", "speaker_engine.hip"]
+           "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip"]
 HEADERS = ["common.h", "kernels.h", "glue.h", os.path.join("..", "..", "include", "qtts.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]

@@ -1,7 +1,9 @@
 """The engines' REAL orchestration code on the CPU.
 
-tests/hostemu builds csrc/codec_engine.hip and csrc/encoder_engine.hip as host C++ (device memory = host memory) and
-links them with plain-loop CPU versions of the kernel launch interfaces.  What runs here is therefore the product's own
+tests/hostemu builds csrc/{codec,encoder,speaker}_engine.hip as host C++ (device memory = host memory).  Block-cooperative
+kernels (MFMA GEMM, attention, norms) are replaced by plain-loop CPU versions of their launch interfaces; the thread-
+independent kernels (stream_kernels.hip, speaker_kernels.hip, most of encoder_kernels.hip) are compiled FROM THEIR REAL
+SOURCES and run by a sequential block/thread interpreter (hostemu/hip/hip_runtime.h).  What runs here is therefore the product's own
 finalize() weight repacking, buffer rotation, strides, streaming carries and C ABI -- everything of those engines except
 the HIP kernels themselves -- checked against the oracle and the reference goldens.  It is how the two code paths that
 have not had a hardware run yet (state-carrying stream decode, the codec encoder) are exercised in round 1, and it keeps
