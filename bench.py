@@ -158,6 +158,7 @@ def main():
                                f"(hipGraph={'off' if args.no_graph else 'on'}) + codec decode to 24 kHz ({args.codec_dtype})",
                    "global_batch": world * B, "frames_per_utterance": F, "parallelism": f"request-shard x{world}"},
         "rtf_x": round(audio_s_total / elapsed, 2),
+        "rtf_x_per_stream": round(audio_s_total / elapsed / (world * B), 2),
         "frames_per_s": round(world * B * F * args.steps / elapsed, 1),
         "ar_ms_per_frame": round(1000 * t_ar / (args.steps * F), 4),     # prefill + first token amortised in
         "codec_ms_per_step": round(1000 * t_codec / args.steps, 2),
