@@ -14,8 +14,9 @@ SRCS = [os.path.join(CSRC, "codec_engine.hip"), os.path.join(CSRC, "encoder_engi
         os.path.join(CSRC, "speaker_engine.hip"),
         # thread-independent kernels: the REAL sources, run by the sequential interpreter of hip/hip_runtime.h
         os.path.join(CSRC, "stream_kernels.hip"), os.path.join(CSRC, "encoder_kernels.hip"), os.path.join(CSRC, "speaker_kernels.hip"),
+        os.path.join(CSRC, "talker_engine.hip"), os.path.join(HERE, "cpu_talker_kernels.cpp"),
         os.path.join(HERE, "cpu_kernels.cpp")]
-DEPS = SRCS + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")] + [os.path.join(ROOT, "include", "qtts.h"),
+DEPS = SRCS + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h")] + [os.path.join(ROOT, "include", "qtts.h"),
                                                                             os.path.join(HERE, "hip", "hip_runtime.h")]
 
 

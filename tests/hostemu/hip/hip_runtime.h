@@ -51,3 +51,27 @@ inline void qtts_hostemu_launch(dim3 grid, dim3 block, F&& body) {
 }
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     qtts_hostemu_launch((grid), (block), [&] { kern(__VA_ARGS__); })
+
+// ---- the rest of the runtime surface csrc/talker_engine.hip touches.  Stream capture is not emulated: the talker is run
+// with use_graph = 0 here (its eager path launches exactly the kernels a captured frame replays).
+#define __shared__ static
+inline void __syncthreads() {}
+typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+static const unsigned hipStreamNonBlocking = 1;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return 0; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return 801; }       // hipErrorNotSupported
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { if (g) *g = nullptr; return 801; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return 801; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 801; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
+inline hipError_t hipGraphGetNodes(hipGraph_t, hipGraphNode_t*, size_t* n) { if (n) *n = 0; return 0; }

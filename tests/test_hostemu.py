@@ -209,3 +209,76 @@ def test_speaker_orchestration_embedding_vs_oracle(emu):
         assert emu.qtts_speaker_embed(h, _ptr(wav), 3, n, _ptr(emb), None, None) != 0
     finally:
         emu.qtts_speaker_destroy(h)
+
+
+def _talker_emu(emu, t, w, max_batch, max_seq):
+    """Create + bind + finalize a talker handle on the emulation library (fp32, eager: stream capture is not emulated)."""
+    vp, i32 = C.c_void_p, C.c_int32
+    emu.qtts_talker_create.argtypes = [C.POINTER(_lib.TalkerConfigC), C.POINTER(vp)]
+    emu.qtts_talker_destroy.argtypes = [vp]; emu.qtts_talker_destroy.restype = None
+    emu.qtts_talker_bind.argtypes = [vp, C.c_char_p, vp, i32, i32, C.POINTER(C.c_int64)]
+    emu.qtts_talker_finalize.argtypes = [vp]
+    emu.qtts_talker_prefill.argtypes = [vp, vp, i32, i32, C.POINTER(C.c_int32), vp, i32, vp, vp]
+    emu.qtts_talker_generate.argtypes = [vp, C.POINTER(_lib.SamplingC), i32, i32, i32, C.POINTER(C.c_int32), i32, vp, vp, vp,
+                                         C.POINTER(C.c_int32), vp]
+    emu.qtts_talker_text_embed.argtypes = [vp, vp, i32, vp, vp]
+    emu.qtts_talker_assemble_rows.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp]
+    from qwen3_tts_amd.config import TalkerConfig
+    c = TalkerConfig.from_any(synth.cfg_dict(t))
+    tc = _lib.TalkerConfigC()
+    for f in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads",
+              "head_dim", "num_code_groups", "text_hidden_size", "codec_eos_token_id", "cp_vocab_size", "cp_hidden_size",
+              "cp_intermediate_size", "cp_num_hidden_layers", "cp_num_attention_heads", "cp_num_key_value_heads", "cp_head_dim"):
+        setattr(tc, f, int(getattr(c, f)))
+    tc.rms_norm_eps, tc.rope_theta = float(c.rms_norm_eps), float(c.rope_theta)
+    tc.cp_rms_norm_eps, tc.cp_rope_theta = float(c.cp_rms_norm_eps), float(c.cp_rope_theta)
+    tc.weight_dtype, tc.max_batch, tc.max_seq, tc.use_graph = _lib.QTTS_F32, max_batch, max_seq, 0
+    h = vp()
+    _ok(emu, emu.qtts_talker_create(C.byref(tc), C.byref(h)))
+    for name, x in w.items():
+        _lib.bind_tensor(emu.qtts_talker_bind, h, name, x)
+    _ok(emu, emu.qtts_talker_finalize(h))
+    return h
+
+
+def _talker_generate(emu, h, t, emb, mask, trailing, pad, max_new, eos=None, min_new=2):
+    B, T, H = emb.shape
+    n_pad = (mask == 0).sum(1).astype(np.int32)
+    emb, trailing, pad = [np.ascontiguousarray(x, dtype=np.float32) for x in (emb, trailing, pad)]
+    npad_c = (C.c_int32 * B)(*[int(x) for x in n_pad])
+    _ok(emu, emu.qtts_talker_prefill(h, _ptr(emb), B, T, npad_c, _ptr(trailing), trailing.shape[1], _ptr(pad), None))
+    sp = _lib.SamplingC()
+    sp.do_sample, sp.subtalker_dosample, sp.repetition_penalty, sp.top_p, sp.subtalker_top_p = 0, 0, 1.05, 1.0, 1.0
+    sp.temperature, sp.subtalker_temperature = 1.0, 1.0
+    sup = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != t.codec_eos_token_id]
+    sup_c = (C.c_int32 * len(sup))(*sup)
+    mf = max(1, max_new - 1)
+    codes = np.zeros((B, mf, t.num_code_groups), np.int64)
+    hidden = np.zeros((B, mf, H), np.float32)
+    tokens = np.full((B, max_new), -1, np.int64)
+    nf = C.c_int32(0)
+    _ok(emu, emu.qtts_talker_generate(h, C.byref(sp), max_new, min_new, t.codec_eos_token_id if eos is None else eos, sup_c, len(sup),
+                                      _ptr(codes), _ptr(hidden), _ptr(tokens), C.byref(nf), None))
+    n = int(nf.value)
+    return codes[:, :n], tokens[:, :n + 1], hidden[:, :n]
+
+
+def test_talker_orchestration_greedy_vs_reference_golden(emu, golden_dir):
+    """The talker engine's real C++ -- weight packing (fused q|k|v, 16-row gate/up interleave, folded norm weights,
+    streaming tile layout), prefill, the 15-pass code predictor + 28-layer-style frame step, EOS / finished-row
+    bookkeeping, stop latch -- on CPU kernel stand-ins, against the REFERENCE's greedy codes (tests/golden/talker_tiny.npz):
+    bit-exact indices, final hidden state, and the early-EOS variant."""
+    g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64)
+    try:
+        args = [g[k] for k in ("embeds", "mask", "trailing", "tts_pad")]
+        codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=14)
+        assert np.array_equal(tokens, g["tokens"]) and np.array_equal(codes, g["codes"])
+        assert np.abs(hidden - g["hidden"]).max() <= 2e-3
+        codes2, tokens2, _ = _talker_generate(emu, h, t, *args, max_new=14, eos=int(g["eos2"]))
+        assert np.array_equal(tokens2, g["tokens_eos2"]) and np.array_equal(codes2, g["codes_eos2"])
+        assert emu.qtts_talker_generate(h, None, 1, 1, 0, None, 0, None, None, None, None, None) != 0      # null arguments
+    finally:
+        emu.qtts_talker_destroy(h)
