@@ -43,8 +43,9 @@ extern "C" {
 
 const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
- * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*). */
-#define QTTS_ABI_VERSION 5
+ * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
+ * 6: + qtts_talker_stream_*). */
+#define QTTS_ABI_VERSION 6
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -334,6 +335,25 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
                          int32_t eos_token_id, const int32_t* suppress_host, int32_t n_suppress,
                          int64_t* codes_dev, float* hidden_dev, int64_t* tokens_dev, int32_t* n_frames_host,
                          void* stream);
+
+/* Resumable generation -- qtts_talker_generate in three calls, for streaming OUTPUT (BASELINE config 4; the reference
+ * only "simulates streaming text input", qwen3_tts_model.py:513-515, and returns whole utterances):
+ *   stream_begin  after qtts_talker_prefill: same arguments as qtts_talker_generate minus the outputs that only exist at
+ *                 the end; samples the first token.  codes_dev int64 (B, max_new_tokens-1, G) / hidden_dev (optional)
+ *                 are filled progressively.
+ *   stream_step   runs up to max_frames_now more frame steps (the same captured frame graph and device-resident loop
+ *                 state as qtts_talker_generate) and returns, on the host, how many frames are final so far
+ *                 (codes_dev[:, :frames_total]) and whether the stop condition has latched.
+ *   stream_end    the closing bookkeeping: tokens_dev int64 (B, max_new_tokens) padded with -1 (optional) and the frame
+ *                 count, as qtts_talker_generate reports them.  May be called early to abandon a request.
+ * STATUS (round 1): the eager path runs in the CPU suite (tests/test_hostemu.py: packets == one-shot generate == the
+ * reference golden); first hardware run (graph path) pending. */
+int qtts_talker_stream_begin(qtts_talker* t, const qtts_sampling* sp, int32_t max_new_tokens, int32_t min_new_tokens,
+                             int32_t eos_token_id, const int32_t* suppress_host, int32_t n_suppress, int64_t* codes_dev,
+                             float* hidden_dev, void* stream);
+int qtts_talker_stream_step(qtts_talker* t, int32_t max_frames_now, int32_t* frames_total_host, int32_t* finished_host,
+                            void* stream);
+int qtts_talker_stream_end(qtts_talker* t, int64_t* tokens_dev, int32_t* n_frames_host, void* stream);
 
 /* Test/diagnostic hooks (device -> caller device buffers, after prefill / a generate call). */
 int qtts_talker_debug_logits(qtts_talker* t, float* logits_dev /* (B, vocab) */, void* stream);

@@ -71,6 +71,13 @@ struct qtts_talker {
         bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
     } graph_key;
     DevBuf seed_d;
+    // resumable generation (qtts_talker_stream_*): everything a later call needs to keep stepping the same request
+    struct StreamGen {
+        bool active = false;
+        qtts_sampling sp{};
+        int eos = 0, min_new = 0, max_new = 0, max_frames = 0, launched = 0, done = 0;
+        int64_t* codes = nullptr; float* hidden = nullptr;
+    } sg;
     int graph_nodes = 0;
     // profiling of the dominant kernel
     bool profile = false, timing_now = false, skinny_only = false;
@@ -720,6 +727,143 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
         std::vector<int64_t> w(h.size(), -1);
         for (int b = 0; b < B; ++b)
             for (int i = 0; i < fin[4]; ++i) w[(size_t)b * max_new_tokens + i] = h[(size_t)b * max_new_tokens + i];
+        QTTS_CHECK_HIP(hipMemcpy(tokens_dev, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+    }
+    QTTS_API_END
+}
+
+// ------------------------------------------------------------------------------------------ resumable generation
+// qtts_talker_generate in three pieces, so that a caller can take the frames as they are produced (streaming output,
+// BASELINE config 4) instead of waiting for the whole utterance: begin = token 0, step = up to n more frame steps
+// (same captured frame graph, same device-resident loop state, stops at the latch), end = the tail bookkeeping.
+// After k frame steps codes[:, :k] (and hidden[:, :k]) are final: a frame step writes its own frame first.
+static void stream_launch_frames(qtts_talker* t, int n, hipStream_t st) {
+    auto& g = t->sg;
+    const bool use_graph = t->cfg.use_graph != 0;
+    auto poll = [&]() {
+        QTTS_CHECK_HIP(hipMemcpyAsync(&g.done, t->ss.done, 4, hipMemcpyDeviceToHost, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    };
+    const int total = g.max_new - 1;
+    int left = std::min(n, total - g.launched);
+    while (!g.done && left > 0) {
+        if (!use_graph || (g.launched == 0 && !t->graph_exec)) {      // (a capture does not execute: the first frame runs eagerly once)
+            t->frame_step(g.sp, g.eos, g.min_new, g.max_new, g.codes, g.hidden, g.max_frames, st);
+            ++g.launched; --left;
+            poll();
+            continue;
+        }
+        if (!t->graph_exec) {
+            QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            try {
+                t->frame_step(g.sp, g.eos, g.min_new, g.max_new, g.codes, g.hidden, g.max_frames, st);
+            } catch (...) {
+                hipGraph_t gx = nullptr;
+                (void)hipStreamEndCapture(st, &gx);
+                if (gx) (void)hipGraphDestroy(gx);
+                throw;
+            }
+            QTTS_CHECK_HIP(hipStreamEndCapture(st, &t->graph));
+            size_t nn = 0;
+            QTTS_CHECK_HIP(hipGraphGetNodes(t->graph, nullptr, &nn));
+            t->graph_nodes = (int)nn;
+            QTTS_CHECK_HIP(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
+        }
+        const int burst = std::min(8, left);
+        for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(t->graph_exec, st));
+        g.launched += burst; left -= burst;
+        poll();
+    }
+}
+
+int qtts_talker_stream_begin(qtts_talker* t, const qtts_sampling* sp, int32_t max_new_tokens, int32_t min_new_tokens,
+                             int32_t eos_token_id, const int32_t* suppress_host, int32_t n_suppress, int64_t* codes_dev,
+                             float* hidden_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && sp && codes_dev, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(t->prefilled, QTTS_ERR_STATE, "stream_begin: prefill() first");
+    QTTS_REQUIRE(!t->profile, QTTS_ERR_STATE, "stream_begin: not available in profile mode");
+    QTTS_REQUIRE(max_new_tokens >= 1, QTTS_ERR_ARG, "max_new_tokens >= 1");
+    QTTS_REQUIRE(t->T0 + max_new_tokens <= t->cfg.max_seq, QTTS_ERR_LIMIT, "prompt + max_new_tokens exceeds max_seq");
+    QTTS_REQUIRE(eos_token_id >= 0 && eos_token_id < t->cfg.vocab_size, QTTS_ERR_ARG, "eos_token_id");
+    hipStream_t st = (hipStream_t)stream;
+    const int V = t->cfg.vocab_size;
+    t->prefilled = false;
+    {
+        std::vector<unsigned char> m(V, 0);
+        for (int i = 0; i < n_suppress; ++i) {
+            QTTS_REQUIRE(suppress_host[i] >= 0 && suppress_host[i] < V, QTTS_ERR_ARG, "suppress token out of range");
+            m[suppress_host[i]] = 1;
+        }
+        QTTS_CHECK_HIP(hipMemcpyAsync(t->suppress.p, m.data(), V, hipMemcpyHostToDevice, st));
+        const unsigned long long seed = sp->seed;
+        QTTS_CHECK_HIP(hipMemcpyAsync(t->seed_d.p, &seed, 8, hipMemcpyHostToDevice, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    t->gen_cap = max_new_tokens;
+    t->generated.ensure((size_t)t->B * max_new_tokens * 4);
+    auto& g = t->sg;
+    g = qtts_talker::StreamGen{};
+    g.sp = *sp; g.eos = eos_token_id; g.min_new = min_new_tokens; g.max_new = max_new_tokens;
+    g.max_frames = std::max(1, max_new_tokens - 1); g.codes = codes_dev; g.hidden = hidden_dev;
+    t->frames_run = 0;
+    t->sample_talker(*sp, eos_token_id, min_new_tokens, max_new_tokens, st);      // token 0
+    QTTS_CHECK_HIP(hipMemcpyAsync(&g.done, t->ss.done, 4, hipMemcpyDeviceToHost, st));
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    // the cached frame graph is reusable only when everything it baked in is unchanged (as in qtts_talker_generate)
+    qtts_talker::GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.B = t->B; key.Tt = t->Tt; key.eos = g.eos; key.min_new = g.min_new; key.max_new = g.max_new; key.max_frames = g.max_frames;
+    key.do_sample = sp->do_sample; key.top_k = sp->top_k; key.sub_do_sample = sp->subtalker_dosample;
+    key.sub_top_k = sp->subtalker_top_k; key.top_p = sp->top_p; key.temperature = sp->temperature; key.rep = sp->repetition_penalty;
+    key.sub_top_p = sp->subtalker_top_p; key.sub_temperature = sp->subtalker_temperature; key.codes = codes_dev;
+    key.hidden = hidden_dev; key.trailing = t->trailing.p; key.tts_pad = t->tts_pad.p; key.generated = t->generated.p;
+    if (!t->cfg.use_graph || !t->graph_exec || !(key == t->graph_key)) { t->destroy_graph(); t->graph_nodes = 0; }
+    t->graph_key = key;
+    g.active = true;
+    QTTS_API_END
+}
+
+int qtts_talker_stream_step(qtts_talker* t, int32_t max_frames_now, int32_t* frames_total_host, int32_t* finished_host,
+                            void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && frames_total_host && finished_host, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(t->sg.active, QTTS_ERR_STATE, "stream_step: stream_begin() first");
+    QTTS_REQUIRE(max_frames_now >= 1, QTTS_ERR_ARG, "max_frames_now >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    auto& g = t->sg;
+    stream_launch_frames(t, max_frames_now, st);
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    int fin[5];
+    QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    // frames whose codes are final: every launched step that ran before the latch; after the latch exactly final_count - 1
+    const int valid = fin[3] ? fin[4] - 1 : g.launched;
+    *frames_total_host = std::min(valid, g.launched);
+    *finished_host = (fin[3] || g.launched >= g.max_new - 1) ? 1 : 0;
+    QTTS_API_END
+}
+
+int qtts_talker_stream_end(qtts_talker* t, int64_t* tokens_dev, int32_t* n_frames_host, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && n_frames_host, QTTS_ERR_ARG, "null argument");
+    QTTS_REQUIRE(t->sg.active, QTTS_ERR_STATE, "stream_end: stream_begin() first");
+    hipStream_t st = (hipStream_t)stream;
+    auto& g = t->sg;
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
+    int fin[5];
+    QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    g.active = false;
+    t->frames_run = g.launched;
+    // an abandoned stream (ended before the stop condition) reports the frames produced so far
+    const int n_tok = fin[3] ? fin[4] : fin[0];
+    *n_frames_host = std::min(std::max(0, n_tok - 1), g.launched);
+    if (tokens_dev) {
+        const int B = t->B, cap = g.max_new;
+        std::vector<int> h((size_t)B * cap);
+        QTTS_CHECK_HIP(hipMemcpy(h.data(), t->generated.p, h.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int64_t> w(h.size(), -1);
+        for (int b = 0; b < B; ++b)
+            for (int i = 0; i < n_tok && i < cap; ++i) w[(size_t)b * cap + i] = h[(size_t)b * cap + i];
         QTTS_CHECK_HIP(hipMemcpy(tokens_dev, w.data(), w.size() * 8, hipMemcpyHostToDevice));
     }
     QTTS_API_END

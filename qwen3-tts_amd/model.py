@@ -35,6 +35,25 @@ class VoiceClonePromptItem:
     ref_text: Optional[str] = None
 
 
+def split_packet_at_eos(packet: torch.Tensor, alive: List[bool], eos: int) -> List[torch.Tensor]:
+    """Streaming form of the EOS trim of M:2283-2289: `packet` (B, k, G) are the next k frames of every request; a request
+    keeps its frames up to (excluding) the first one whose first codebook is `eos`, and is finished from then on.
+    `alive` is updated in place."""
+    out = []
+    first = packet[:, :, 0].cpu()
+    for i in range(packet.shape[0]):
+        if not alive[i]:
+            out.append(packet[i, :0])
+            continue
+        hit = (first[i] == eos).nonzero()
+        if hit.numel():
+            alive[i] = False
+            out.append(packet[i, : int(hit[0])])
+        else:
+            out.append(packet[i])
+    return out
+
+
 PLAN_BOS_ROW, PLAN_EOS_ROW, PLAN_PAD_ROW = 0, 1, 2      # rows of the projected special text tokens in every plan
 
 
@@ -265,6 +284,37 @@ class Qwen3TTSForConditionalGeneration:
                 codes_all.append(out.codes[i, :n_eff])
                 hidden_all.append(out.hidden[i, :n_eff] if out.hidden is not None else None)
         return codes_all, hidden_all
+
+
+    @torch.no_grad()
+    def generate_stream(self, input_ids: Optional[List[torch.Tensor]] = None, instruct_ids: Optional[List[torch.Tensor]] = None,
+                        ref_ids: Optional[List[torch.Tensor]] = None, voice_clone_prompt: Optional[dict] = None,
+                        languages: List[str] = None, speakers: List[str] = None, non_streaming_mode: bool = False,
+                        packet_frames: int = 4, max_new_tokens: int = 4096, do_sample: bool = True, top_k: int = 50,
+                        top_p: float = 1.0, temperature: float = 0.9, subtalker_dosample: bool = True, subtalker_top_k: int = 50,
+                        subtalker_top_p: float = 1.0, subtalker_temperature: float = 0.9, eos_token_id: Optional[int] = None,
+                        repetition_penalty: float = 1.05, **kwargs):
+        """Streaming OUTPUT variant of `generate` (the reference returns whole utterances, qwen3_tts_model.py:513-515): a
+        generator of packets; each packet is a list with, per request, the (k_i, G) codes it gained (k_i = 0 once the
+        request hit EOS, M:2283-2289).  One wave only: len(input_ids) <= max_batch.  EXPERIMENTAL in round 1."""
+        c = self.config
+        if len(input_ids) > self.talker.max_batch:
+            raise ValueError(f"generate_stream: {len(input_ids)} requests exceed max_batch {self.talker.max_batch}")
+        embeds, mask, trailing, pad = self.assemble_prompts(input_ids, languages, speakers, instruct_ids,
+                                                            non_streaming_mode, ref_ids, voice_clone_prompt)
+        suppress = [i for i in range(c.vocab_size - 1024, c.vocab_size) if i != c.codec_eos_token_id]
+        eos = eos_token_id if eos_token_id is not None else c.codec_eos_token_id
+        alive = [True] * embeds.shape[0]
+        for packet in self.talker.generate_stream(embeds, mask, trailing, pad, packet_frames=packet_frames,
+                                                  max_new_tokens=max_new_tokens, min_new_tokens=2, do_sample=do_sample, top_k=top_k,
+                                                  top_p=top_p, temperature=temperature, subtalker_dosample=subtalker_dosample,
+                                                  subtalker_top_k=subtalker_top_k, subtalker_top_p=subtalker_top_p,
+                                                  subtalker_temperature=subtalker_temperature, eos_token_id=eos,
+                                                  repetition_penalty=repetition_penalty, suppress_tokens=suppress,
+                                                  seed=kwargs.get("seed")):
+            yield split_packet_at_eos(packet, alive, eos)
+            if not any(alive):
+                return
 
 
 # ====================================================================================== inference wrapper
@@ -511,6 +561,47 @@ class Qwen3TTSModel:
         codes_list, _ = self.model.generate(input_ids=input_ids, instruct_ids=self._instruct_ids(instructs),
                                             languages=languages, non_streaming_mode=non_streaming_mode, **gen_kwargs)
         return self.model.speech_tokenizer.decode([{"audio_codes": c} for c in codes_list])
+
+    # ---- streaming output (no reference counterpart: qwen3_tts_model.py:513-515 "only simulates streaming text input")
+    @torch.no_grad()
+    def stream_custom_voice(self, text, speaker, language=None, instruct=None, non_streaming_mode: bool = False,
+                            packet_frames: int = 4, left_context_size: int = 25, **kwargs):
+        """`generate_custom_voice` as a generator of PCM packets: yields (list of np.float32 arrays, one per request --
+        empty once that request has finished --, sample_rate) every `packet_frames` frames (80 ms each).  The codes come
+        from `generate_stream`; each packet is decoded with `left_context_size` frames of context, i.e. exactly the
+        reference's `chunked_decode(chunk_size=packet_frames, left_context_size=...)` rule applied incrementally.
+        EXPERIMENTAL in round 1 (the resumable talker generation has not had its first hardware run)."""
+        if self.model.tts_model_type != "custom_voice":
+            raise self._unsupported("stream_custom_voice")
+        texts = self._ensure_list(text)
+        languages = self._lang_list(language, len(texts))
+        speakers = self._ensure_list(speaker)
+        if len(speakers) == 1 and len(texts) > 1:
+            speakers = speakers * len(texts)
+        instructs = instruct if isinstance(instruct, list) else [instruct] * len(texts)
+        if not (len(texts) == len(languages) == len(speakers) == len(instructs)):
+            raise ValueError(f"Batch size mismatch: text={len(texts)}, language={len(languages)}, speaker={len(speakers)}, instruct={len(instructs)}")
+        self._validate_languages(languages)
+        self._validate_speakers(speakers)
+        input_ids = self._tokenize_texts([self._build_assistant_text(t) for t in texts])
+        gen_kwargs = self._merge_generate_kwargs(**kwargs)
+        dec = self.model.speech_tokenizer.model.decoder
+        stream = dec.stream(left_context_size)
+        cb = dec.config.codebook_size
+        for parts in self.model.generate_stream(input_ids=input_ids, instruct_ids=self._instruct_ids(instructs), languages=languages,
+                                                speakers=speakers, non_streaming_mode=non_streaming_mode,
+                                                packet_frames=packet_frames, **gen_kwargs):
+            k = max(int(p.shape[0]) for p in parts)
+            if k == 0:
+                continue
+            # the codec advances in lockstep: finished / shorter rows are padded with code 0 and their samples dropped
+            batch = torch.zeros(len(parts), k, parts[0].shape[-1], dtype=torch.long, device=self.device)
+            for i, p in enumerate(parts):
+                batch[i, : p.shape[0]] = p.clamp(min=0, max=cb - 1)
+            wav = stream.push(batch.transpose(1, 2))[:, 0]
+            up = wav.shape[-1] // k
+            yield [wav[i, : int(p.shape[0]) * up].cpu().numpy().astype(np.float32) for i, p in enumerate(parts)], \
+                int(self.model.speech_tokenizer.model.output_sample_rate)
 
     # ---- custom voice (qwen3_tts_model.py:732-840)
     @torch.no_grad()

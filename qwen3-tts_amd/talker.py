@@ -221,6 +221,83 @@ class TalkerEngine:
         return TalkerGenerateOutput(codes=codes[:, :nf], hidden=hidden[:, :nf] if hidden is not None else None,
                                     tokens=tokens[:, : nf + 1], n_frames=nf)
 
+    def generate_stream(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, trailing_text_hidden: torch.Tensor,
+                        tts_pad_embed: torch.Tensor, packet_frames: int = 4, max_new_tokens: int = 2048, min_new_tokens: int = 2,
+                        do_sample: bool = True, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,
+                        temperature: Optional[float] = 0.9, subtalker_dosample: bool = True,
+                        subtalker_top_k: Optional[int] = 50, subtalker_top_p: Optional[float] = 1.0,
+                        subtalker_temperature: Optional[float] = 0.9, eos_token_id: Optional[int] = None,
+                        repetition_penalty: float = 1.05, suppress_tokens: Optional[List[int]] = None,
+                        seed: Optional[int] = None, **unused):
+        """Streaming OUTPUT (include/qtts.h `qtts_talker_stream_*`): a generator that yields `codes[:, f0:f1]` (B, k, G)
+        int64 device tensors, k <= packet_frames, as the frames are produced; same arguments and the same frames as
+        `generate`.  Closing the generator early abandons the request.  EXPERIMENTAL in round 1: the C++ runs in the CPU
+        suite (tests/test_hostemu.py); its first hardware run is pending.  Holds the engine lock while active."""
+        c = self.config
+        if inputs_embeds.dim() != 3 or inputs_embeds.shape[-1] != c.hidden_size:
+            raise ValueError(f"inputs_embeds must be (B, T, {c.hidden_size})")
+        B, T, H = inputs_embeds.shape
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch} given at construction")
+        if packet_frames < 1:
+            raise ValueError("packet_frames must be >= 1")
+        mask = attention_mask.to("cpu", torch.long)
+        if mask.shape != (B, T):
+            raise ValueError("attention_mask must be (B, T)")
+        n_pad = (1 - mask).sum(-1)
+        expect = (torch.arange(T)[None, :] >= n_pad[:, None]).long()
+        if not torch.equal(mask, expect) or int(n_pad.max()) >= T:
+            raise ValueError("attention_mask must be left-padded: [0]*n_pad + [1]*(T-n_pad) per row")
+        if T + max_new_tokens > self.max_seq:
+            raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_seq ({self.max_seq})")
+        eos = c.codec_eos_token_id if eos_token_id is None else int(eos_token_id)
+        suppress_tokens = list(suppress_tokens or [])
+        sp = _lib.SamplingC()
+        sp.do_sample = 1 if do_sample else 0
+        sp.top_k = int(top_k) if top_k else 0
+        sp.top_p = float(top_p) if top_p is not None else 1.0
+        sp.temperature = float(temperature) if temperature is not None else 1.0
+        sp.repetition_penalty = float(repetition_penalty) if repetition_penalty is not None else 1.0
+        sp.subtalker_dosample = 1 if subtalker_dosample else 0
+        sp.subtalker_top_k = int(subtalker_top_k) if subtalker_top_k else 0
+        sp.subtalker_top_p = float(subtalker_top_p) if subtalker_top_p is not None else 1.0
+        sp.subtalker_temperature = float(subtalker_temperature) if subtalker_temperature is not None else 1.0
+        sp.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)
+        dev = self.device
+        emb = inputs_embeds.to(dev, torch.float32).contiguous()
+        trail = trailing_text_hidden.to(dev, torch.float32).contiguous()
+        if trail.dim() != 3 or trail.shape[0] != B or trail.shape[2] != H or trail.shape[1] < 1:
+            raise ValueError("trailing_text_hidden must be (B, Tt >= 1, H)")
+        pad = tts_pad_embed.to(dev, torch.float32).reshape(-1).contiguous()
+        if pad.numel() != H:
+            raise ValueError("tts_pad_embed must have H elements")
+        codes = torch.zeros(B, max(1, max_new_tokens - 1), c.num_code_groups, dtype=torch.int64, device=dev)
+        npad_c = (C.c_int32 * B)(*[int(x) for x in n_pad])
+        sup_c = (C.c_int32 * max(1, len(suppress_tokens)))(*[int(x) for x in suppress_tokens])
+        total, fin, nf = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        with self._lock:
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+                _lib.check(self._lib.qtts_talker_prefill(self._h, C.c_void_p(emb.data_ptr()), B, T, npad_c,
+                                                         C.c_void_p(trail.data_ptr()), trail.shape[1],
+                                                         C.c_void_p(pad.data_ptr()), self._s()))
+                _lib.check(self._lib.qtts_talker_stream_begin(self._h, C.byref(sp), int(max_new_tokens), int(min_new_tokens), eos,
+                                                              sup_c, len(suppress_tokens), C.c_void_p(codes.data_ptr()), None,
+                                                              self._s()))
+            seen = 0
+            try:
+                while not fin.value:
+                    with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+                        _lib.check(self._lib.qtts_talker_stream_step(self._h, int(packet_frames), C.byref(total), C.byref(fin),
+                                                                     self._s()))
+                    if total.value > seen:              # stream_step synchronises: these frames are final
+                        yield codes[:, seen:total.value]
+                        seen = total.value
+            finally:
+                with torch.cuda.device(dev), torch.cuda.stream(self._stream):
+                    _lib.check(self._lib.qtts_talker_stream_end(self._h, None, C.byref(nf), self._s()))
+                torch.cuda.current_stream(dev).wait_stream(self._stream)
+
     @_lib.locked
     def debug_logits(self) -> torch.Tensor:
         out = torch.empty(self.max_batch, self.config.vocab_size, dtype=torch.float32, device=self.device)

@@ -633,3 +633,27 @@ def test_speaker_embedding_vs_oracle(dev):
         assert np.abs(emb - ref).max() <= 2e-4 * max(1.0, float(np.abs(ref).max())), n
     one = eng.extract_speaker_embedding(wav[0], 24000).cpu().numpy()
     assert np.abs(one - emb[0]).max() <= 1e-5
+
+
+@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
+                    reason="resumable talker generation (qtts_talker_stream_*): validated on the CPU emulation in round 1, first "
+                           "hardware run (hipGraph path) pending -- enable with QTTS_EXPERIMENTAL=1")
+@pytest.mark.parametrize("graph", [False, True])
+def test_talker_generate_stream_equals_generate(talker_tiny, dev, graph):
+    """Streaming output: the packets of `generate_stream` concatenate to exactly the codes of `generate` (and therefore to
+    the reference golden), eager and hipGraph, for packet sizes that do and do not divide the frame count."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    t, w, g = talker_tiny
+    eng = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=4, max_seq=64, use_graph=graph)
+    args = [torch.from_numpy(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
+    kw = dict(max_new_tokens=14, do_sample=False, subtalker_dosample=False, suppress_tokens=_suppress(t))
+    for packet in (1, 4, 5):
+        parts = [p.cpu().numpy() for p in eng.generate_stream(*args, packet_frames=packet, **kw)]
+        assert all(0 < p.shape[1] <= packet for p in parts)
+        assert np.array_equal(np.concatenate(parts, axis=1), g["codes"]), packet
+    it = eng.generate_stream(*args, packet_frames=2, **kw)
+    first = next(it).cpu().numpy()
+    it.close()                                                   # abandon the request
+    assert np.array_equal(first, g["codes"][:, :2])
+    out = eng.generate(*args, **kw)                              # the engine is reusable afterwards
+    assert np.array_equal(out.codes.cpu().numpy(), g["codes"])

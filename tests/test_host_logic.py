@@ -446,3 +446,53 @@ def test_create_voice_clone_prompt_wrapper_logic():
     with pytest.raises(ValueError, match="does not support create_voice_clone_prompt"):
         w.create_voice_clone_prompt(a, ref_text="x")
     M.tts_model_type = "base"
+
+
+def test_streaming_output_host_logic():
+    """Streaming output wrappers: the EOS packet split (streaming form of M:2283-2289) and `stream_custom_voice`'s packet
+    assembly -- ragged rows padded for the lock-step codec, finished requests yielding empty arrays -- with stand-ins for the
+    two engines."""
+    import numpy as np
+    import torch
+    from qwen3_tts_amd.codec import CodecStreamDecoder
+    from qwen3_tts_amd.model import Qwen3TTSModel, split_packet_at_eos
+    alive = [True, True, False]
+    pk = torch.tensor([[[5, 1], [9, 2], [7, 3]], [[1, 1], [2, 2], [3, 3]], [[9, 9], [9, 9], [9, 9]]])
+    parts = split_packet_at_eos(pk, alive, 9)
+    assert [p.shape[0] for p in parts] == [1, 3, 0] and alive == [False, True, False]
+    assert [p.shape[0] for p in split_packet_at_eos(pk, alive, 9)] == [0, 3, 0]          # a finished row stays finished
+
+    UP = 4
+
+    class Dec:                                   # decoder stand-in: sample value = first code of its frame
+        config = type("C", (), {"codebook_size": 50})()
+        def forward(self, codes):                # (B, Q, T) -> (B, 1, T*UP)
+            return codes[:, 0, :].float().repeat_interleave(UP, dim=-1).unsqueeze(1)
+        def stream(self, left):
+            return CodecStreamDecoder(self.forward, UP, left)
+
+    class Tok:
+        model = type("M", (), {"decoder": Dec(), "output_sample_rate": 24000})()
+
+    class M:
+        device = torch.device("cpu")
+        tts_model_type, tts_model_size, tokenizer_type = "custom_voice", "1b7", "12hz"
+        speech_tokenizer = Tok()
+        def get_supported_languages(self): return None
+        def get_supported_speakers(self): return None
+        def generate_stream(self, **kw):
+            assert kw["packet_frames"] == 2 and kw["speakers"] == ["a", "b"]
+            yield [torch.tensor([[3, 0], [4, 0]]), torch.tensor([[7, 0], [8, 0]])]
+            yield [torch.tensor([[5, 0]]), torch.tensor([[9, 0], [60, 0]])]            # row 0 ends mid-packet; 60 clamps to 49
+            yield [torch.zeros(0, 2, dtype=torch.long), torch.zeros(0, 2, dtype=torch.long)]   # nothing new: no packet
+
+    class Proc:
+        def __call__(self, text=None, return_tensors="pt", padding=True):
+            return {"input_ids": torch.tensor([[1, 2, 3, 4, 5, 6, 7, 8, 9, 10]])}
+
+    w = Qwen3TTSModel(M(), Proc(), generate_defaults={})
+    out = list(w.stream_custom_voice(["x", "y"], ["a", "b"], language="auto", packet_frames=2, left_context_size=1))
+    assert len(out) == 2 and all(sr == 24000 for _, sr in out)
+    (p0, _), (p1, _) = out
+    assert [a.tolist() for a in p0] == [[3.0] * UP + [4.0] * UP, [7.0] * UP + [8.0] * UP]
+    assert [a.tolist() for a in p1] == [[5.0] * UP, [9.0] * UP + [49.0] * UP] and p1[0].dtype == np.float32

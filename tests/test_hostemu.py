@@ -282,3 +282,56 @@ def test_talker_orchestration_greedy_vs_reference_golden(emu, golden_dir):
         assert emu.qtts_talker_generate(h, None, 1, 1, 0, None, 0, None, None, None, None, None) != 0      # null arguments
     finally:
         emu.qtts_talker_destroy(h)
+
+
+def test_talker_stream_generation_equals_one_shot(emu, golden_dir):
+    """qtts_talker_stream_begin / _step / _end (resumable generation for streaming output): stepping the request in packets
+    of 1, 3 or 5 frames yields, frame for frame, the codes of the one-shot generate -- i.e. the reference golden -- with a
+    monotone `frames_total`, the stop latch reported once, for the normal and the early-EOS run; an abandoned stream
+    reports the frames it produced."""
+    vp, i32 = C.c_void_p, C.c_int32
+    emu.qtts_talker_stream_begin.argtypes = [vp, C.POINTER(_lib.SamplingC), i32, i32, i32, C.POINTER(C.c_int32), i32, vp, vp, vp]
+    emu.qtts_talker_stream_step.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
+    emu.qtts_talker_stream_end.argtypes = [vp, vp, C.POINTER(C.c_int32), vp]
+    g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64)
+    sup = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != t.codec_eos_token_id]
+    sup_c = (C.c_int32 * len(sup))(*sup)
+
+    def run(packet, eos, max_new=14, stop_after=None):
+        emb, mask, trailing, pad = [np.ascontiguousarray(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
+        B, T, H = emb.shape
+        npad_c = (C.c_int32 * B)(*[int(x) for x in (mask == 0).sum(1)])
+        _ok(emu, emu.qtts_talker_prefill(h, _ptr(emb), B, T, npad_c, _ptr(trailing), trailing.shape[1], _ptr(pad), None))
+        sp = _lib.SamplingC()
+        sp.do_sample, sp.subtalker_dosample, sp.repetition_penalty, sp.top_p, sp.subtalker_top_p = 0, 0, 1.05, 1.0, 1.0
+        sp.temperature, sp.subtalker_temperature = 1.0, 1.0
+        codes = np.zeros((B, max_new - 1, t.num_code_groups), np.int64)
+        tokens = np.full((B, max_new), -1, np.int64)
+        _ok(emu, emu.qtts_talker_stream_begin(h, C.byref(sp), max_new, 2, eos, sup_c, len(sup), _ptr(codes), None, None))
+        total, fin, seen, packets = C.c_int32(0), C.c_int32(0), 0, 0
+        while not fin.value:
+            _ok(emu, emu.qtts_talker_stream_step(h, packet, C.byref(total), C.byref(fin), None))
+            assert seen <= total.value <= seen + packet
+            seen = total.value
+            packets += 1
+            if stop_after is not None and packets >= stop_after:
+                break
+        nf = C.c_int32(0)
+        _ok(emu, emu.qtts_talker_stream_end(h, _ptr(tokens), C.byref(nf), None))
+        assert nf.value == seen
+        return codes[:, :seen], tokens[:, :seen + 1], packets
+
+    try:
+        for packet in (1, 3, 5):
+            codes, tokens, _ = run(packet, t.codec_eos_token_id)
+            assert np.array_equal(codes, g["codes"]) and np.array_equal(tokens, g["tokens"]), packet
+            codes2, tokens2, _ = run(packet, int(g["eos2"]))
+            assert np.array_equal(codes2, g["codes_eos2"]) and np.array_equal(tokens2, g["tokens_eos2"]), packet
+        part, _, _ = run(2, t.codec_eos_token_id, stop_after=2)               # abandoned after two packets
+        assert part.shape[1] == 4 and np.array_equal(part, g["codes"][:, :4])
+        assert emu.qtts_talker_stream_step(h, 1, C.byref(C.c_int32()), C.byref(C.c_int32()), None) != 0    # no active stream
+    finally:
+        emu.qtts_talker_destroy(h)
