@@ -335,3 +335,42 @@ def test_talker_stream_generation_equals_one_shot(emu, golden_dir):
         assert emu.qtts_talker_stream_step(h, 1, C.byref(C.c_int32()), C.byref(C.c_int32()), None) != 0    # no active stream
     finally:
         emu.qtts_talker_destroy(h)
+
+
+def test_prompt_assembly_orchestration_vs_reference_golden(emu, golden_dir):
+    """qtts_talker_text_embed + qtts_talker_assemble_rows through the real engine C++ (text-embedding table binding, the
+    text_projection MLP on the tap GEMM, descriptor checks) on CPU kernels, driven by the host row plan, against what the
+    REFERENCE's generate() hands to talker.generate in all five prompt modes (tests/golden/prompt_tiny.npz)."""
+    from prompt_cases import CASES, load_case
+    from qwen3_tts_amd.config import TalkerConfig
+    from qwen3_tts_amd.model import build_prompt_plan, PLAN_PAD_ROW
+    g = np.load(os.path.join(golden_dir, "prompt_tiny.npz"))
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t).items()}          # with the text embedding / projection
+    cfg = TalkerConfig.from_any(synth.cfg_dict(t))
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64)
+    H = t.hidden_size
+    try:
+        for name in CASES:
+            c = load_case(g, name)
+            plan = build_prompt_plan(cfg, c["ids"], c["languages"], c["speakers"], c["ins"], c["non_streaming_mode"], c["ref_ids"],
+                                     c["voice_clone_prompt"])
+            ids = np.ascontiguousarray(plan["text_ids"])
+            proj = np.zeros((len(ids), H), np.float32)
+            _ok(emu, emu.qtts_talker_text_embed(h, _ptr(ids), len(ids), _ptr(proj), None))
+            spk = np.ascontiguousarray(np.stack([x.reshape(-1).numpy() for x in plan["spk_vectors"]]).astype(np.float32)) if plan["spk_vectors"] else None
+            ref = np.ascontiguousarray(torch.cat(plan["ref_codes"], 0).numpy().astype(np.int64)) if plan["ref_codes"] else None
+            desc = np.ascontiguousarray(plan["desc"])
+            rows = np.zeros((desc.shape[0], H), np.float32)
+            _ok(emu, emu.qtts_talker_assemble_rows(h, _ptr(desc), desc.shape[0], _ptr(proj), len(ids),
+                                                   _ptr(spk) if spk is not None else None, 0 if spk is None else spk.shape[0],
+                                                   _ptr(ref) if ref is not None else None, 0 if ref is None else ref.shape[0],
+                                                   _ptr(rows), None))
+            n, Tm, Tt = plan["n"], plan["Tm"], plan["Tt"]
+            assert np.abs(rows[: n * Tm].reshape(n, Tm, H) - g[f"{name}_embeds"]).max() <= 2e-5, name
+            assert np.abs(rows[n * Tm:].reshape(n, Tt, H) - g[f"{name}_trailing"]).max() <= 2e-5, name
+            assert np.abs(proj[PLAN_PAD_ROW] - g[f"{name}_tts_pad"].reshape(-1)).max() <= 2e-5, name
+        bad = np.array([10 ** 6], np.int64)                                          # a text id outside the table
+        assert emu.qtts_talker_text_embed(h, _ptr(bad), 1, _ptr(np.zeros((1, H), np.float32)), None) != 0
+    finally:
+        emu.qtts_talker_destroy(h)
