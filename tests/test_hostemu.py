@@ -374,3 +374,23 @@ def test_prompt_assembly_orchestration_vs_reference_golden(emu, golden_dir):
         assert emu.qtts_talker_text_embed(h, _ptr(bad), 1, _ptr(np.zeros((1, H), np.float32)), None) != 0
     finally:
         emu.qtts_talker_destroy(h)
+
+
+def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
+    """Twenty ragged, left-padded prompts (M = 20 rows per decode step, 40 in the code predictor's two-token first pass,
+    several KV pages per sequence) through the real talker C++ on CPU kernels, against the oracle's greedy run."""
+    import talker_ref
+    t = synth.talker_tiny()
+    wn = synth.talker_weights(t, with_text=False)
+    w = {k: torch.from_numpy(v) for k, v in wn.items()}
+    lens = [3 + (7 * i) % 13 for i in range(20)]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(9), t, lens, 2, scale=0.5)
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    with torch.no_grad():
+        r = talker_ref.talker_generate(w, t, emb, mask, tr, pad, max_new_tokens=6, sp=sp)
+    h = _talker_emu(emu, t, w, max_batch=20, max_seq=64)
+    try:
+        codes, tokens, _ = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=6)
+        assert np.array_equal(tokens, r["tokens"].numpy()) and np.array_equal(codes, r["codes"].numpy())
+    finally:
+        emu.qtts_talker_destroy(h)
