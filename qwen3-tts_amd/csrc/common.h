@@ -58,7 +58,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));  // 8 bf16 = 4 VGPRs (
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------ cross-lane reductions
-#ifndef QTTS_HOST_EMU     // (tests/hostemu compiles the engine orchestration for the host: no device intrinsics there)
 // DPP row rotations (VALU rate) instead of ds_bpermute shuffles (LDS crossbar, ~100 cycles each) for the reductions the
 // hot kernels run per key / per row: after ror 8/4/2/1 every lane of a 16-lane row holds the row's sum.
 template <int CTRL>
@@ -90,8 +89,6 @@ __device__ __forceinline__ float wave_max64_dpp(float v) {
     return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
-
-#endif  // QTTS_HOST_EMU
 
 // ------------------------------------------------------------------------------------------ device memory
 struct DevBuf {

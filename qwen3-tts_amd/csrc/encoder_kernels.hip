@@ -49,7 +49,6 @@ void launch_conv_in1(const float* wav, const float* w, const float* bias, float*
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
-#ifndef QTTS_HOST_EMU   // block-cooperative (LDS + cross-lane): the host emulation keeps a plain-loop stand-in for these two
 __device__ inline float block_sum_ln(float v, float* sm) {
     v = wave_sum64_dpp(v);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
@@ -78,8 +77,6 @@ void launch_layernorm(const float* x, int ldx, const float* w, const float* b, f
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
-#endif  // QTTS_HOST_EMU
-
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* src, int T, int left, int Tp, int replicate, float* dst,
                                                        int C4) {
     const int i = blockIdx.x, b = blockIdx.y;
@@ -97,7 +94,6 @@ void launch_pad_rows(const float* src, int T, int left, int right, int replicate
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
-#ifndef QTTS_HOST_EMU
 // One workgroup per row: argmin over the codebook (MimiEuclideanCodebook.quantize: argmin of the Euclidean distance ==
 // argmin of ||e||^2 - 2 r.e), lowest index on ties (torch.argmin), then the residual update of the RVQ loop.
 __global__ __launch_bounds__(256) void vq_argmin_update_kernel(const float* scores, int bins, const float* enorm,
@@ -134,7 +130,5 @@ void launch_vq_argmin_update(const float* scores, int bins, const float* enorm, 
                        stride_b, T);
     QTTS_CHECK_HIP(hipGetLastError());
 }
-
-#endif  // QTTS_HOST_EMU
 
 }  // namespace qtts

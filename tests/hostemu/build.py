@@ -1,23 +1,29 @@
-"""TEST INFRASTRUCTURE: build tests/hostemu/libqtts_hostemu.so = the two engine orchestration files of the product
-(csrc/codec_engine.hip, csrc/encoder_engine.hip, csrc/speaker_engine.hip) compiled as HOST C++ against tests/hostemu/hip/hip_runtime.h, linked with
-CPU versions of the kernel launch interfaces (cpu_kernels.cpp).  The library exports the codec + encoder part of the C ABI
-on host pointers; tests/test_hostemu.py drives it with numpy arrays and checks it against the oracle."""
+"""TEST INFRASTRUCTURE: build tests/hostemu/libqtts_hostemu.so -- the product's C++ / HIP sources compiled for the HOST.
+
+  * engines (csrc/*_engine.hip): plain host C++ against hip/hip_runtime.h (device memory = host memory);
+  * kernels listed in SIMT_KERNELS: their REAL sources, executed by the SIMT emulator of simt.h (one fiber per thread,
+    wave collectives, workgroup barriers, MFMA / DPP semantics) -- the only edit is mechanical: `extern __shared__` ->
+    `extern` (dynamic LDS is a host array, lds_arrays.cpp) and `__shared__` -> `static`;
+  * the remaining kernels (STANDIN): plain-loop CPU versions of their launch interfaces (cpu_kernels.cpp,
+    cpu_talker_kernels.cpp) -- the MFMA-heavy GEMMs, whose emulation would make the suite slow.
+The library exports the whole C ABI on host pointers; tests/test_hostemu.py drives it with numpy arrays."""
 import hashlib
 import os
+import re
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
+GEN = os.path.join(HERE, "gen")
 OUT = os.path.join(HERE, "libqtts_hostemu.so")
-SRCS = [os.path.join(CSRC, "codec_engine.hip"), os.path.join(CSRC, "encoder_engine.hip"),
-        os.path.join(CSRC, "speaker_engine.hip"),
-        # thread-independent kernels: the REAL sources, run by the sequential interpreter of hip/hip_runtime.h
-        os.path.join(CSRC, "stream_kernels.hip"), os.path.join(CSRC, "encoder_kernels.hip"), os.path.join(CSRC, "speaker_kernels.hip"),
-        os.path.join(CSRC, "talker_engine.hip"), os.path.join(HERE, "cpu_talker_kernels.cpp"),
-        os.path.join(HERE, "cpu_kernels.cpp")]
-DEPS = SRCS + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h")] + [os.path.join(ROOT, "include", "qtts.h"),
-                                                                            os.path.join(HERE, "hip", "hip_runtime.h")]
+ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
+SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip"]
+# kernels without barriers / cross-lane ops run as plain per-thread calls (no fibers): much faster for large grids
+SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}
+STANDIN = ["cpu_kernels.cpp", "cpu_talker_kernels.cpp", "lds_arrays.cpp"]
+HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h")] + [
+    os.path.join(ROOT, "include", "qtts.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "simt.h")]
 
 
 def _compiler():
@@ -26,19 +32,41 @@ def _compiler():
             return c
 
 
+def _transform(src_path, dst_path):
+    s = open(src_path).read()
+    s = s.replace("extern __shared__", "extern")
+    s = re.sub(r"\b__shared__\b", "static", s)
+    with open(dst_path, "w") as f:
+        f.write(f'#line 1 "{src_path}"\n' + s)
+
+
 def build(verbose=False):
+    inputs = [os.path.join(CSRC, f) for f in ENGINES + SIMT_KERNELS] + [os.path.join(HERE, f) for f in STANDIN] + HEADERS + [__file__]
     h = hashlib.sha256()
-    for f in DEPS:
+    for f in inputs:
         with open(f, "rb") as fh:
             h.update(fh.read())
     stamp = OUT + ".sha"
     if os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
         return OUT
-    cmd = [_compiler(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DQTTS_HOST_EMU", "-I", HERE, "-I", CSRC,
-           "-Wno-unused-function", "-o", OUT] + SRCS
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    os.makedirs(GEN, exist_ok=True)
+    cc = _compiler()
+    base = [cc, "-std=c++17", "-O2", "-fPIC", "-DQTTS_HOST_EMU", "-I", HERE, "-I", CSRC, "-Wno-unused-function", "-Wno-unused-value"]
+    objs = []
+    for f in ENGINES + SIMT_KERNELS:
+        dst = os.path.join(GEN, f.replace(".hip", ".cpp"))
+        _transform(os.path.join(CSRC, f), dst)
+        objs.append((dst, ["-DQTTS_SIMT_SEQUENTIAL"] if f in SEQUENTIAL else []))
+    objs += [(os.path.join(HERE, f), []) for f in STANDIN]
+    outs = []
+    for src, extra in objs:
+        o = os.path.join(GEN, os.path.basename(src) + ".o")
+        cmd = base + extra + ["-c", src, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        outs.append(o)
+    subprocess.run([cc, "-shared", "-o", OUT] + outs, check=True)
     with open(stamp, "w") as fh:
         fh.write(h.hexdigest())
     return OUT

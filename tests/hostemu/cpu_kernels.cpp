@@ -187,31 +187,4 @@ void launch_attn_rows(const AttnRowsParams& p, hipStream_t) {
     }
 }
 
-// ---- encoder helpers
-void launch_layernorm(const float* x, int ldx, const float* w, const float* b, float eps, float* y, int ldy, int rows, int C,
-                      hipStream_t) {
-    for (int r = 0; r < rows; ++r) {
-        const float* xr = x + (size_t)r * ldx;
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s += xr[c];
-        const float mean = s / (float)C;
-        float q = 0.f;
-        for (int c = 0; c < C; ++c) q += (xr[c] - mean) * (xr[c] - mean);
-        const float rs = 1.f / sqrtf(q / (float)C + eps);
-        for (int c = 0; c < C; ++c) y[(size_t)r * ldy + c] = (xr[c] - mean) * rs * w[c] + b[c];
-    }
-}
-void launch_vq_argmin_update(const float* scores, int bins, const float* enorm, const float* table, int D, float* r,
-                             int64_t* codes_out, int64_t stride_b, int B, int T, hipStream_t) {
-    for (int row = 0; row < B * T; ++row) {
-        float bv = INFINITY; int bi = 0;
-        for (int j = 0; j < bins; ++j) {
-            const float d = enorm[j] - 2.0f * scores[(size_t)row * bins + j];
-            if (d < bv) { bv = d; bi = j; }
-        }
-        for (int c = 0; c < D; ++c) r[(size_t)row * D + c] -= table[(size_t)bi * D + c];
-        codes_out[(size_t)(row / T) * stride_b + (row % T)] = bi;
-    }
-}
-
 }  // namespace qtts

@@ -24,38 +24,25 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 
-// ---- sequential kernel interpreter: enough of the HIP kernel language to EXECUTE thread-independent kernels (no LDS,
-// no __syncthreads, no cross-lane ops) on the host.  hipLaunchKernelGGL walks the grid and the block one thread at a
-// time with threadIdx / blockIdx set, so the real kernel sources (stream_kernels.hip, encoder_kernels.hip,
-// speaker_kernels.hip) run unmodified -- their index arithmetic is what the CPU suite then checks.
+// ---- kernel execution: a SIMT emulator (fibers + wave collectives + workgroup barriers), see ../simt.h.  The build
+// script rewrites `extern __shared__` -> `extern` (dynamic LDS = the host arrays defined in lds_arrays.cpp) and
+// `__shared__` -> `static` (one workgroup runs at a time) in the copies of the kernel sources it compiles.
 #include <cmath>
 #define __global__
 #define __launch_bounds__(n)
-struct dim3 {
-    unsigned x, y, z;
-    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
-};
 struct alignas(16) float4 { float x, y, z, w; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
-inline dim3 threadIdx, blockIdx, blockDim, gridDim;
-template <class F>
-inline void qtts_hostemu_launch(dim3 grid, dim3 block, F&& body) {
-    gridDim = grid; blockDim = block;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx)
-                for (unsigned tx = 0; tx < block.x; ++tx) {
-                    blockIdx = dim3(bx, by, bz); threadIdx = dim3(tx, 0, 0);
-                    body();
-                }
-}
-#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    qtts_hostemu_launch((grid), (block), [&] { kern(__VA_ARGS__); })
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(8) ushort4 { unsigned short x, y, z, w; };
+#include "../simt.h"
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
 // ---- the rest of the runtime surface csrc/talker_engine.hip touches.  Stream capture is not emulated: the talker is run
 // with use_graph = 0 here (its eager path launches exactly the kernels a captured frame replays).
-#define __shared__ static
-inline void __syncthreads() {}
 typedef void* hipEvent_t;
 typedef void* hipGraph_t;
 typedef void* hipGraphExec_t;

@@ -1,0 +1,8 @@
+// TEST INFRASTRUCTURE: host storage for the kernels' dynamic LDS (`extern __shared__ T name[]` in the HIP sources becomes
+// `extern T name[]` in the copies the host build compiles; 160 KB = the CDNA4 LDS size).
+namespace qtts {
+alignas(16) float sm_ad[160 * 1024 / 4];                 // attention.hip   (attn_decode)
+alignas(16) unsigned char smem_sk[160 * 1024];           // skinny.hip
+alignas(16) unsigned char smem_gw[160 * 1024];           // gemm_tap.hip    (wide-K variant)
+alignas(16) float sm_fc[160 * 1024 / 4];                 // elementwise.hip (final conv)
+}  // namespace qtts

@@ -1,0 +1,269 @@
+// TEST INFRASTRUCTURE: a small SIMT emulator for HIP kernels on the host.
+//
+// hipLaunchKernelGGL runs one workgroup at a time; every thread of the workgroup is a cooperatively scheduled fiber
+// (ucontext).  A fiber runs until it finishes or blocks in
+//   * __syncthreads()           -- released when every live thread of the workgroup has arrived, or
+//   * a wave collective         -- __shfl_xor/_up/__shfl, __ballot, DPP (__builtin_amdgcn_update_dpp), readlane, MFMA:
+//                                  the lane deposits its operands and yields; when no lane of its wave is runnable any more,
+//                                  the lanes waiting at the same call site are resolved together
+//                                  with the others treated as inactive (exec mask off), which is what the hardware does
+//                                  for divergent code.
+// Wave = 64 consecutive threadIdx.x.  __shared__ variables become statics (one workgroup runs at a time), dynamic LDS is a
+// fixed host buffer, LDS atomics are plain operations.  This executes the REAL kernel sources -- including their
+// cross-lane reductions and LDS traffic -- so the CPU suite checks their logic; it says nothing about performance and
+// it encodes the MFMA / DPP lane layouts as this project uses them (validated on hardware by the GPU suite).
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace simt {
+
+enum State { RUNNABLE, AT_BARRIER, AT_WAVE_OP, DONE };
+enum Op { OP_NONE, OP_SHFL, OP_BALLOT, OP_MFMA_BF16, OP_MFMA_F32 };
+
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    dim3 tid;
+    State state = RUNNABLE;
+    // pending wave collective
+    Op op = OP_NONE;
+    unsigned site = 0;               // call site of the pending collective: lanes waiting at the same site form one group
+    uint32_t in32 = 0; int src_lane = 0; int pred = 0;
+    uint32_t out32 = 0; uint64_t out64 = 0;
+    short a16[8], b16[8]; float a32 = 0, b32 = 0; float c[4], d[4];
+};
+
+struct Machine {
+    std::vector<Fiber> f;
+    ucontext_t sched;
+    Fiber* cur = nullptr;
+    dim3 block_idx, block_dim, grid_dim;
+    const std::function<void()>* body = nullptr;
+};
+inline Machine& M() { static Machine m; return m; }
+
+inline void yield_to_scheduler() {
+    Machine& m = M();
+    if (m.cur->stack.empty()) {       // launch_sequential: there is no fiber to suspend
+        fprintf(stderr, "simt: a kernel compiled as thread-independent (QTTS_SIMT_SEQUENTIAL) called a barrier / cross-lane op\n");
+        abort();
+    }
+    swapcontext(&m.cur->ctx, &m.sched);
+}
+inline void fiber_entry() {
+    Machine& m = M();
+    (*m.body)();
+    m.cur->state = DONE;
+    swapcontext(&m.cur->ctx, &m.sched);
+}
+
+inline float bf16_bits_to_f32(short h) { uint32_t u = ((uint32_t)(uint16_t)h) << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// resolve the collectives of one wave: lanes [w0, w0+64) that wait with the same (op, seq) form one group
+inline bool resolve_wave(Machine& m, unsigned w0, unsigned w1) {
+    bool any = false;
+    for (unsigned i = w0; i < w1; ++i) {
+        Fiber& lead = m.f[i];
+        if (lead.state != AT_WAVE_OP) continue;
+        const Op op = lead.op; const unsigned site = lead.site;
+        bool active[64] = {false};
+        for (unsigned j = w0; j < w1; ++j) active[j - w0] = m.f[j].state == AT_WAVE_OP && m.f[j].op == op && m.f[j].site == site;
+        if (op == OP_SHFL) {
+            for (unsigned j = w0; j < w1; ++j) {
+                if (!active[j - w0]) continue;
+                int s = m.f[j].src_lane;
+                const bool ok = s >= 0 && s < (int)(w1 - w0) && active[s];
+                m.f[j].out32 = ok ? m.f[w0 + s].in32 : m.f[j].in32;       // inactive / out-of-range source: own value
+            }
+        } else if (op == OP_BALLOT) {
+            uint64_t mask = 0;
+            for (unsigned j = w0; j < w1; ++j) if (active[j - w0] && m.f[j].pred) mask |= 1ull << (j - w0);
+            for (unsigned j = w0; j < w1; ++j) if (active[j - w0]) m.f[j].out64 = mask;
+        } else if (op == OP_MFMA_BF16 || op == OP_MFMA_F32) {
+            // lane l: A[m = l%16][k-block l/16], B[k-block l/16][n = l%16]; D[m = 4*(l/16)+r][n = l%16]
+            const int KB = op == OP_MFMA_BF16 ? 8 : 1;
+            float A[16][32] = {{0}}, B[32][16] = {{0}};
+            for (unsigned j = w0; j < w1; ++j) {
+                const int l = j - w0;
+                if (!active[l]) continue;
+                for (int e = 0; e < KB; ++e) {
+                    const int k = (l / 16) * KB + e;
+                    A[l % 16][k] = op == OP_MFMA_BF16 ? bf16_bits_to_f32(m.f[j].a16[e]) : m.f[j].a32;
+                    B[k][l % 16] = op == OP_MFMA_BF16 ? bf16_bits_to_f32(m.f[j].b16[e]) : m.f[j].b32;
+                }
+            }
+            const int K = 4 * KB;
+            for (unsigned j = w0; j < w1; ++j) {
+                const int l = j - w0;
+                if (!active[l]) continue;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (l / 16) + r, col = l % 16;
+                    float acc = m.f[j].c[r];
+                    for (int k = 0; k < K; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+                    m.f[j].d[r] = acc;
+                }
+            }
+        }
+        for (unsigned j = w0; j < w1; ++j) if (active[j - w0]) { m.f[j].state = RUNNABLE; m.f[j].op = OP_NONE; }
+        any = true;
+    }
+    return any;
+}
+
+inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, dim3 gdim) {
+    Machine& m = M();
+    const unsigned n = bdim.x * bdim.y * bdim.z;
+    m.block_idx = bidx; m.block_dim = bdim; m.grid_dim = gdim; m.body = &body;
+    if (m.f.size() < n) m.f.resize(n);
+    for (unsigned i = 0; i < n; ++i) {
+        Fiber& f = m.f[i];
+        if (f.stack.empty()) f.stack.resize(256 * 1024);
+        f.tid = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
+        f.state = RUNNABLE; f.op = OP_NONE; f.site = 0;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    for (;;) {
+        bool ran = false, live = false;
+        for (unsigned i = 0; i < n; ++i) {
+            Fiber& f = m.f[i];
+            if (f.state == DONE) continue;
+            live = true;
+            if (f.state != RUNNABLE) continue;
+            m.cur = &f;
+            swapcontext(&m.sched, &f.ctx);
+            ran = true;
+        }
+        if (!live) break;
+        if (ran) continue;
+        // nothing runnable: resolve wave collectives first, then the workgroup barrier
+        bool progressed = false;
+        for (unsigned w0 = 0; w0 < n; w0 += 64) progressed |= resolve_wave(m, w0, w0 + 64 < n ? w0 + 64 : n);
+        if (progressed) continue;
+        bool all_at_barrier = true;
+        for (unsigned i = 0; i < n; ++i) if (m.f[i].state != DONE && m.f[i].state != AT_BARRIER) all_at_barrier = false;
+        if (all_at_barrier) { for (unsigned i = 0; i < n; ++i) if (m.f[i].state == AT_BARRIER) m.f[i].state = RUNNABLE; continue; }
+        fprintf(stderr, "simt: deadlock (threads wait at different synchronisation points)\n");
+        abort();
+    }
+}
+
+template <class F>
+inline void launch(dim3 grid, dim3 block, F&& body) {
+    std::function<void()> fn = body;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) run_block(fn, dim3(bx, by, bz), block, grid);
+}
+
+// Thread-independent kernels (no barrier, no cross-lane op) do not need fibers: translation units compiled with
+// -DQTTS_SIMT_SEQUENTIAL run every thread as a plain call (a blocking primitive then aborts with a message).
+template <class F>
+inline void launch_sequential(dim3 grid, dim3 block, F&& body) {
+    Machine& m = M();
+    static Fiber one;
+    m.block_dim = block; m.grid_dim = grid; m.cur = &one;
+    one.state = DONE;                               // marks "not a fiber": see yield_to_scheduler
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                m.block_idx = dim3(bx, by, bz);
+                for (unsigned t = 0; t < block.x; ++t) { one.tid = dim3(t, 0, 0); body(); }
+            }
+}
+template <class K, class... A>
+inline void launch_kernel(dim3 grid, dim3 block, K kern, A... args) {      // arguments are evaluated once, by value, like a real launch
+#ifdef QTTS_SIMT_SEQUENTIAL
+    launch_sequential(grid, block, [=] { kern(args...); });
+#else
+    launch(grid, block, [=] { kern(args...); });
+#endif
+}
+
+// ---- what device code calls
+inline int lane_id() { const Fiber& f = *M().cur; return (int)(f.tid.x % 64); }     // 1-D workgroups only
+inline void barrier() { M().cur->state = AT_BARRIER; yield_to_scheduler(); }
+inline uint32_t shfl_bits(uint32_t v, int src, unsigned site) {
+    Fiber& f = *M().cur;
+    f.op = OP_SHFL; f.site = site; f.in32 = v; f.src_lane = src; f.state = AT_WAVE_OP;
+    yield_to_scheduler();
+    return f.out32;
+}
+template <class T> inline T shfl_any(T v, int src, unsigned site) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    uint32_t b; memcpy(&b, &v, 4); b = shfl_bits(b, src, site); T r; memcpy(&r, &b, 4); return r;
+}
+inline uint64_t ballot(int pred, unsigned site) {
+    Fiber& f = *M().cur;
+    f.op = OP_BALLOT; f.site = site; f.pred = pred; f.state = AT_WAVE_OP;
+    yield_to_scheduler();
+    return f.out64;
+}
+// DPP row rotations / readlane as used by csrc/common.h
+inline int update_dpp(int old, int src, int ctrl, unsigned site) {
+    (void)old;
+    const int l = lane_id();
+    if (ctrl >= 0x121 && ctrl <= 0x12F) { const int nrot = ctrl - 0x120; return shfl_any(src, (l & ~15) | ((l + 16 - nrot) & 15), site); }
+    fprintf(stderr, "simt: unsupported dpp_ctrl 0x%x\n", ctrl); abort();
+}
+// MFMA (lane layouts: see resolve_wave)
+template <class V8, class V4> inline V4 mfma_bf16(V8 a, V8 b, V4 c, unsigned site) {
+    Fiber& f = *M().cur;
+    for (int e = 0; e < 8; ++e) { f.a16[e] = a[e]; f.b16[e] = b[e]; }
+    for (int r = 0; r < 4; ++r) f.c[r] = c[r];
+    f.op = OP_MFMA_BF16; f.site = site; f.state = AT_WAVE_OP;
+    yield_to_scheduler();
+    V4 d; for (int r = 0; r < 4; ++r) d[r] = f.d[r]; return d;
+}
+template <class V4> inline V4 mfma_f32(float a, float b, V4 c, unsigned site) {
+    Fiber& f = *M().cur;
+    f.a32 = a; f.b32 = b;
+    for (int r = 0; r < 4; ++r) f.c[r] = c[r];
+    f.op = OP_MFMA_F32; f.site = site; f.state = AT_WAVE_OP;
+    yield_to_scheduler();
+    V4 d; for (int r = 0; r < 4; ++r) d[r] = f.d[r]; return d;
+}
+// LDS-DMA: lane i's `size` bytes land at dst + i*size (lane-linear destination)
+inline void global_load_lds(uintptr_t src, uintptr_t dst, int size) {
+    memcpy(reinterpret_cast<char*>(dst) + (size_t)lane_id() * size, reinterpret_cast<const void*>(src), (size_t)size);
+}
+
+}  // namespace simt
+
+#define threadIdx (simt::M().cur->tid)
+#define blockIdx (simt::M().block_idx)
+#define blockDim (simt::M().block_dim)
+#define gridDim (simt::M().grid_dim)
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) simt::launch_kernel((grid), (block), kern, ##__VA_ARGS__)
+inline void __syncthreads() { simt::barrier(); }
+#define __shfl_xor(v, mask) simt::shfl_any((v), simt::lane_id() ^ (mask), __COUNTER__ + 1)
+#define __shfl_up(v, delta) simt::shfl_any((v), simt::lane_id() - (delta), __COUNTER__ + 1)
+#define __shfl(v, src) simt::shfl_any((v), (src), __COUNTER__ + 1)
+#define __ballot(pred) simt::ballot((pred), __COUNTER__ + 1)
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clzll(long long v) { return v == 0 ? 64 : __builtin_clzll((unsigned long long)v); }
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp((old), (src), (ctrl), __COUNTER__ + 1)
+#define __builtin_amdgcn_readlane(v, l) simt::shfl_any((v), (l), __COUNTER__ + 1)
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) simt::mfma_bf16((a), (b), (c), __COUNTER__ + 1)
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) simt::mfma_f32((a), (b), (c), __COUNTER__ + 1)
+#define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) simt::global_load_lds((uintptr_t)(src), (uintptr_t)(dst), (size))
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
