@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
 GEN = os.path.join(HERE, "gen")
 OUT = os.path.join(HERE, "libqtts_hostemu.so")
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
-SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip"]
+SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "sampling.hip"]
 # kernels without barriers / cross-lane ops run as plain per-thread calls (no fibers): much faster for large grids
 SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}
 STANDIN = ["cpu_kernels.cpp", "cpu_talker_kernels.cpp", "lds_arrays.cpp"]

@@ -149,42 +149,4 @@ void launch_rope_inplace(float* qkv, int ld, int rows, int T, int n_heads_total,
     rope_rows(qkv, ld, rows, T, 0, n_heads_total, hd, inv_freq);
 }
 
-// attention.hip attn_rows: keys in [max(n_pad, tq - window + 1), tq]; query rows < n_pad write zeros
-void launch_attn_rows(const AttnRowsParams& p, hipStream_t) {
-    QTTS_REQUIRE(p.hd == 64 || p.hd == 128, QTTS_ERR_ARG, "attn_rows: head_dim 64 or 128");
-    const float scale = 1.f / sqrtf((float)p.hd);
-    std::vector<float> sc(p.T);
-    for (int b = 0; b < p.B; ++b) {
-        const int npad = p.n_pad ? p.n_pad[b] : 0;
-        const float* base = p.qkv + (size_t)b * p.T * p.ld;
-        for (int h = 0; h < p.nh; ++h) {
-            const int kvh = h / (p.nh / p.nkv);
-            for (int tq = 0; tq < p.T; ++tq) {
-                float* o = p.out + ((size_t)b * p.T + tq) * p.ldo + h * p.hd;
-                if (tq < npad) { for (int d = 0; d < p.hd; ++d) o[d] = 0.f; continue; }
-                int lo = npad;
-                if (p.window > 0 && tq - p.window + 1 > lo) lo = tq - p.window + 1;
-                const float* q = base + (size_t)tq * p.ld + p.q_off + h * p.hd;
-                float m = -INFINITY;
-                for (int s = lo; s <= tq; ++s) {
-                    const float* k = base + (size_t)s * p.ld + p.k_off + kvh * p.hd;
-                    float d = 0.f;
-                    for (int e = 0; e < p.hd; ++e) d += q[e] * k[e];
-                    sc[s] = d * scale;
-                    m = fmaxf(m, sc[s]);
-                }
-                float l = 0.f;
-                for (int d = 0; d < p.hd; ++d) o[d] = 0.f;
-                for (int s = lo; s <= tq; ++s) {
-                    const float pr = expf(sc[s] - m);
-                    l += pr;
-                    const float* v = base + (size_t)s * p.ld + p.v_off + kvh * p.hd;
-                    for (int d = 0; d < p.hd; ++d) o[d] += pr * v[d];
-                }
-                for (int d = 0; d < p.hd; ++d) o[d] /= l;
-            }
-        }
-    }
-}
-
 }  // namespace qtts

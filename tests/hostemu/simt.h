@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE: a small SIMT emulator for HIP kernels on the host.
 //
 // hipLaunchKernelGGL runs one workgroup at a time; every thread of the workgroup is a cooperatively scheduled fiber
-// (ucontext).  A fiber runs until it finishes or blocks in
+// (a six-register x86-64 stack switch; ucontext's per-switch sigprocmask syscall made it 3x slower).  A fiber runs until it finishes or blocks in
 //   * __syncthreads()           -- released when every live thread of the workgroup has arrived, or
 //   * a wave collective         -- __shfl_xor/_up/__shfl, __ballot, DPP (__builtin_amdgcn_update_dpp), readlane, MFMA:
 //                                  the lane deposits its operands and yields; when no lane of its wave is runnable any more,
@@ -13,7 +13,6 @@
 // cross-lane reductions and LDS traffic -- so the CPU suite checks their logic; it says nothing about performance and
 // it encodes the MFMA / DPP lane layouts as this project uses them (validated on hardware by the GPU suite).
 #pragma once
-#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -27,13 +26,27 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+// simt_switch(&save_sp, load_sp): push the callee-saved registers, park the stack pointer, adopt the other stack.
+extern "C" void simt_switch(void** save_sp, void* load_sp);
+__asm__(
+    ".text\n"
+    ".weak simt_switch\n"
+    ".type simt_switch,@function\n"
+    "simt_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n"
+    ".size simt_switch, .-simt_switch\n");
+
 namespace simt {
 
 enum State { RUNNABLE, AT_BARRIER, AT_WAVE_OP, DONE };
 enum Op { OP_NONE, OP_SHFL, OP_BALLOT, OP_MFMA_BF16, OP_MFMA_F32 };
 
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;               // parked stack pointer while the fiber is suspended
     std::vector<char> stack;
     dim3 tid;
     State state = RUNNABLE;
@@ -47,7 +60,7 @@ struct Fiber {
 
 struct Machine {
     std::vector<Fiber> f;
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     Fiber* cur = nullptr;
     dim3 block_idx, block_dim, grid_dim;
     const std::function<void()>* body = nullptr;
@@ -60,24 +73,39 @@ inline void yield_to_scheduler() {
         fprintf(stderr, "simt: a kernel compiled as thread-independent (QTTS_SIMT_SEQUENTIAL) called a barrier / cross-lane op\n");
         abort();
     }
-    swapcontext(&m.cur->ctx, &m.sched);
+    simt_switch(&m.cur->sp, m.sched_sp);
 }
 inline void fiber_entry() {
     Machine& m = M();
     (*m.body)();
     m.cur->state = DONE;
-    swapcontext(&m.cur->ctx, &m.sched);
+    simt_switch(&m.cur->sp, m.sched_sp);
+    abort();                          // a finished fiber is never resumed
 }
 
 inline float bf16_bits_to_f32(short h) { uint32_t u = ((uint32_t)(uint16_t)h) << 16; float f; memcpy(&f, &u, 4); return f; }
 
-// resolve the collectives of one wave: lanes [w0, w0+64) that wait with the same (op, seq) form one group
+// Resolve ONE pending collective of a wave (lanes [w0, w1)): the lanes waiting at the same call site form a group.
+// Hardware runs a wave in lockstep and reconverges diverged lanes, so lanes that left a loop early must NOT run ahead and
+// complete a later cross-lane op without their partners.  The emulator therefore resolves a single group per pass:
+// a group that contains every lane not parked at the workgroup barrier if there is one, otherwise the group at the
+// textually earliest call site (the lagging lanes -- still inside the loop / the then-branch -- make progress first and
+// meet the others at the later site).
 inline bool resolve_wave(Machine& m, unsigned w0, unsigned w1) {
-    bool any = false;
+    unsigned best_site = 0; Op best_op = OP_NONE; bool found = false;
+    unsigned waiting = 0;
+    for (unsigned i = w0; i < w1; ++i) if (m.f[i].state == AT_WAVE_OP) ++waiting;
+    if (!waiting) return false;
     for (unsigned i = w0; i < w1; ++i) {
-        Fiber& lead = m.f[i];
-        if (lead.state != AT_WAVE_OP) continue;
-        const Op op = lead.op; const unsigned site = lead.site;
+        const Fiber& f = m.f[i];
+        if (f.state != AT_WAVE_OP) continue;
+        unsigned cnt = 0;
+        for (unsigned j = w0; j < w1; ++j) cnt += m.f[j].state == AT_WAVE_OP && m.f[j].op == f.op && m.f[j].site == f.site;
+        if (cnt == waiting) { best_site = f.site; best_op = f.op; found = true; break; }      // everybody is here
+        if (!found || f.site < best_site) { best_site = f.site; best_op = f.op; found = true; }
+    }
+    {
+        const Op op = best_op; const unsigned site = best_site;
         bool active[64] = {false};
         for (unsigned j = w0; j < w1; ++j) active[j - w0] = m.f[j].state == AT_WAVE_OP && m.f[j].op == op && m.f[j].site == site;
         if (op == OP_SHFL) {
@@ -117,9 +145,8 @@ inline bool resolve_wave(Machine& m, unsigned w0, unsigned w1) {
             }
         }
         for (unsigned j = w0; j < w1; ++j) if (active[j - w0]) { m.f[j].state = RUNNABLE; m.f[j].op = OP_NONE; }
-        any = true;
     }
-    return any;
+    return true;
 }
 
 inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, dim3 gdim) {
@@ -132,9 +159,13 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
         if (f.stack.empty()) f.stack.resize(256 * 1024);
         f.tid = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
         f.state = RUNNABLE; f.op = OP_NONE; f.site = 0;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        // fresh stack: six zeroed callee-saved slots, then fiber_entry as the `ret` target (rsp = 8 mod 16 on entry)
+        uintptr_t top = ((uintptr_t)f.stack.data() + f.stack.size()) & ~(uintptr_t)15;
+        void** q = (void**)top;
+        *--q = nullptr;
+        *--q = (void*)&fiber_entry;
+        for (int r = 0; r < 6; ++r) *--q = nullptr;
+        f.sp = (void*)q;
     }
     for (;;) {
         bool ran = false, live = false;
@@ -144,7 +175,7 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
             live = true;
             if (f.state != RUNNABLE) continue;
             m.cur = &f;
-            swapcontext(&m.sched, &f.ctx);
+            simt_switch(&m.sched_sp, f.sp);
             ran = true;
         }
         if (!live) break;
@@ -261,6 +292,10 @@ inline int __clzll(long long v) { return v == 0 ? 64 : __builtin_clzll((unsigned
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) simt::mfma_bf16((a), (b), (c), __COUNTER__ + 1)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) simt::mfma_f32((a), (b), (c), __COUNTER__ + 1)
 #define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) simt::global_load_lds((uintptr_t)(src), (uintptr_t)(dst), (size))
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+template <class T> inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> inline T max(T a, T b) { return a > b ? a : b; }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
