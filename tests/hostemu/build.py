@@ -1,11 +1,12 @@
 """TEST INFRASTRUCTURE: build tests/hostemu/libqtts_hostemu.so -- the product's C++ / HIP sources compiled for the HOST.
 
   * engines (csrc/*_engine.hip): plain host C++ against hip/hip_runtime.h (device memory = host memory);
-  * kernels listed in SIMT_KERNELS: their REAL sources, executed by the SIMT emulator of simt.h (one fiber per thread,
-    wave collectives, workgroup barriers, MFMA / DPP semantics) -- the only edit is mechanical: `extern __shared__` ->
-    `extern` (dynamic LDS is a host array, lds_arrays.cpp) and `__shared__` -> `static`;
-  * the remaining kernels (STANDIN): plain-loop CPU versions of their launch interfaces (cpu_kernels.cpp,
-    cpu_talker_kernels.cpp) -- the MFMA-heavy GEMMs, whose emulation would make the suite slow.
+  * kernels (SIMT_KERNELS = every kernel source of csrc/): their REAL sources, executed by the SIMT emulator of simt.h
+    (one fiber per thread, wave collectives, workgroup barriers, MFMA / DPP / LDS-DMA semantics) -- the only edit is
+    mechanical: `extern __shared__` -> `extern` (dynamic LDS is a host array, lds_arrays.cpp), `__shared__` -> `static`;
+  * one stand-in (cpu_gemm_tap.cpp): the tap GEMM in plain loops, used by the large engine tests because the MFMA
+    emulation is ~15x slower; the real gemm_tap.hip is in the library too (launch_gemm_tap_real) and is selected by
+    hostemu_set_real_gemm(1) / QTTS_HOSTEMU_FULL=1.
 The library exports the whole C ABI on host pointers; tests/test_hostemu.py drives it with numpy arrays."""
 import hashlib
 import os
@@ -18,10 +19,13 @@ CSRC = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
 GEN = os.path.join(HERE, "gen")
 OUT = os.path.join(HERE, "libqtts_hostemu.so")
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
-SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "sampling.hip"]
+SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "sampling.hip",
+                "elementwise.hip", "skinny.hip", "gemm_tap.hip"]
 # kernels without barriers / cross-lane ops run as plain per-thread calls (no fibers): much faster for large grids
 SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}
-STANDIN = ["cpu_kernels.cpp", "cpu_talker_kernels.cpp", "lds_arrays.cpp"]
+# gemm_tap.hip is built as launch_gemm_tap_real; cpu_gemm_tap.cpp owns launch_gemm_tap and forwards to it on request
+EXTRA_DEFS = {"gemm_tap.hip": ["-Dlaunch_gemm_tap=launch_gemm_tap_real"]}
+STANDIN = ["cpu_gemm_tap.cpp", "lds_arrays.cpp"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h")] + [
     os.path.join(ROOT, "include", "qtts.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "simt.h")]
 
@@ -56,7 +60,7 @@ def build(verbose=False):
     for f in ENGINES + SIMT_KERNELS:
         dst = os.path.join(GEN, f.replace(".hip", ".cpp"))
         _transform(os.path.join(CSRC, f), dst)
-        objs.append((dst, ["-DQTTS_SIMT_SEQUENTIAL"] if f in SEQUENTIAL else []))
+        objs.append((dst, (["-DQTTS_SIMT_SEQUENTIAL"] if f in SEQUENTIAL else []) + EXTRA_DEFS.get(f, [])))
     objs += [(os.path.join(HERE, f), []) for f in STANDIN]
     outs = []
     for src, extra in objs:

@@ -1,13 +1,17 @@
-"""The engines' REAL orchestration code on the CPU.
+"""The product's REAL C++ and HIP sources on the CPU.
 
-tests/hostemu builds csrc/{codec,encoder,speaker}_engine.hip as host C++ (device memory = host memory).  Block-cooperative
-kernels (MFMA GEMM, attention, norms) are replaced by plain-loop CPU versions of their launch interfaces; the thread-
-independent kernels (stream_kernels.hip, speaker_kernels.hip, most of encoder_kernels.hip) are compiled FROM THEIR REAL
-SOURCES and run by a sequential block/thread interpreter (hostemu/hip/hip_runtime.h).  What runs here is therefore the product's own
-finalize() weight repacking, buffer rotation, strides, streaming carries and C ABI -- everything of those engines except
-the HIP kernels themselves -- checked against the oracle and the reference goldens.  It is how the two code paths that
-have not had a hardware run yet (state-carrying stream decode, the codec encoder) are exercised in round 1, and it keeps
-the validated decoder orchestration under a CPU regression test."""
+tests/hostemu builds csrc/*_engine.hip as host C++ (device memory = host memory) and EVERY kernel source of csrc/ for a
+small SIMT emulator (hostemu/simt.h: one fiber per thread, workgroup barriers, wave collectives -- shuffles, DPP row
+rotations, ballots, MFMA 16x16x32 bf16 / 16x16x4 f32, LDS-DMA).  What runs here is therefore the product's own code end
+to end: finalize() weight repacking, buffer rotation, strides, streaming carries, the C ABI, and the kernels' tiling,
+LDS traffic and cross-lane reductions -- checked against the oracle and the reference goldens.  One stand-in remains, for
+speed only: the large codec-decoder tests route the tap GEMM through plain loops (hostemu/cpu_gemm_tap.cpp); the
+encoder, the speaker encoder, the short decoder / stream cases and the kernel-level cases below always run the real
+gemm_tap.hip, and QTTS_HOSTEMU_FULL=1 runs the whole file with it (17 min; result recorded in DESIGN.md).
+It is how the code paths that have not had a hardware run yet (state-carrying stream decode, codec encoder, speaker
+encoder, resumable generation) are exercised in round 1, and it keeps the validated paths under a CPU regression test.
+It says nothing about performance, and it encodes the MFMA / DPP lane layouts as this project uses them (validated on
+hardware by the GPU suite)."""
 import ctypes as C
 import os
 import sys
@@ -46,7 +50,143 @@ def emu():
     lib.qtts_encoder_finalize.argtypes = [vp]
     lib.qtts_encoder_frames.argtypes = [vp, C.c_int64, i64p]
     lib.qtts_encoder_encode.argtypes = [vp, vp, i32, i32, vp, vp]
+    fp = C.POINTER(C.c_float)
+    lib.hostemu_set_real_gemm.argtypes = [i32]; lib.hostemu_set_real_gemm.restype = None
+    lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
+    lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     return lib
+
+
+FULL = os.environ.get("QTTS_HOSTEMU_FULL") == "1"
+
+
+class real_gemm:
+    """Route the engines' tap GEMMs through the real gemm_tap.hip kernels inside the block."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __enter__(self):
+        self.lib.hostemu_set_real_gemm(1)
+
+    def __exit__(self, *a):
+        self.lib.hostemu_set_real_gemm(1 if FULL else 0)
+
+
+def _bf16_round(x):
+    """fp32 -> nearest-even bf16, returned as (fp32 values, uint16 bits)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    return (r << 16).astype(np.uint32).view(np.float32).reshape(x.shape), r.astype(np.uint16).reshape(x.shape)
+
+
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SNAKE, ACT_SILU = 0, 1, 2, 3, 4            # csrc/kernels.h enum Act
+
+
+def _gemm_tap_ref(A, T, W, shift, bias, scale, res, ea, ib, act):
+    M, (taps, N, K) = A.shape[0], W.shape
+    acc = np.zeros((M, N), np.float64)
+    for tap in range(taps):
+        for m in range(M):
+            if (m % T) + shift[tap] >= 0:
+                acc[m] += W[tap].astype(np.float64) @ A[m + shift[tap], :K].astype(np.float64)
+    if act == ACT_SWIGLU:
+        g = acc.reshape(M, N // 32, 2, 16)
+        return ((g[:, :, 0] / (1 + np.exp(-g[:, :, 0]))) * g[:, :, 1]).reshape(M, N // 2)
+    v = acc + (bias if bias is not None else 0)
+    if act == ACT_GELU:
+        from scipy.special import erf
+        v = 0.5 * v * (1 + erf(v / np.sqrt(2)))
+    elif act == ACT_SNAKE:
+        v = v + ib * np.sin(v * ea) ** 2
+    elif act == ACT_SILU:
+        v = v / (1 + np.exp(-v))
+    if scale is not None:
+        v = v * scale
+    if res is not None:
+        v = v + res
+    return v
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_gemm_tap_kernel_real_source(emu, bf16):
+    """gemm_tap.hip itself (LDS tiles, MFMA, per-tap row shifts with sequence-start zeroing, every epilogue, the wide-K
+    variant) on the emulator against float64 numpy, for the shapes the engines use: ragged M and N, strided lda / ldc."""
+    g = np.random.default_rng(40 + bf16)
+    cases = [  # M, T, N, K, taps(shifts), act, lda_pad, with bias/scale/res
+        (37, 37, 48, 32, [0], ACT_NONE, 0, (1, 0, 0)),
+        (40, 20, 80, 64, [-2, -1, 0], ACT_GELU, 4, (1, 1, 1)),
+        (33, 11, 64, 96, [-6, -3, 0], ACT_SNAKE, 0, (1, 0, 1)),
+        (18, 9, 64, 32, [-1, 0], ACT_SILU, 8, (1, 0, 0)),
+        (50, 25, 128, 64, [0], ACT_SWIGLU, 0, (0, 0, 0)),
+        (70, 70, 16, 160, [-7, -5, -4, -3, -2, -1, 0], ACT_NONE, 0, (0, 1, 0)),
+        (24, 24, 128, 512, [0], ACT_NONE, 0, (1, 0, 1)),          # wide-K variant (bf16: K % 128 == 0, K >= 512)
+    ]
+    for (M, T, N, K, shift, act, pad, (hb, hs, hr)) in cases:
+        lda = K + pad
+        A = (g.standard_normal((M, lda)) * 0.5).astype(np.float32)
+        W = (g.standard_normal((len(shift), N, K)) / np.sqrt(K * len(shift))).astype(np.float32)
+        bias = g.standard_normal(N).astype(np.float32) if hb else None
+        scale = g.standard_normal(N).astype(np.float32) if hs else None
+        No = N // 2 if act == ACT_SWIGLU else N
+        res = g.standard_normal((M, No + 4)).astype(np.float32) if hr else None
+        ea = np.exp(g.standard_normal(N) * 0.3).astype(np.float32)
+        ib = (1 / (np.exp(g.standard_normal(N) * 0.3) + 1e-9)).astype(np.float32)
+        if bf16:
+            Wv, Wbits = _bf16_round(W)
+            Av = _bf16_round(A)[0]
+            Wdev = Wbits
+        else:
+            Wv, Av, Wdev = W, A, W
+        want = _gemm_tap_ref(Av, T, Wv, shift, bias, scale, res[:, :No] if hr else None, ea, ib, act)
+        ldc = No + 8
+        out = np.full((M, ldc), 7.0, np.float32)
+        sh = (C.c_int32 * len(shift))(*shift)
+        rc = emu.hostemu_gemm_tap(_ptr(A), lda, M, T, _ptr(Wdev), N, K, len(shift), sh, _ptr(bias) if hb else None,
+                                  _ptr(scale) if hs else None, _ptr(res) if hr else None, No + 4, _ptr(ea), _ptr(ib), act,
+                                  _ptr(out), ldc, bf16)
+        assert rc == 0, ((M, N, K, shift, act), (emu.qtts_last_error() or b"").decode())
+        tol = (2e-3 if bf16 else 2e-5) * max(1.0, float(np.abs(want).max()))
+        assert np.abs(out[:, :No] - want).max() <= tol, (M, N, K, shift, act, float(np.abs(out[:, :No] - want).max()))
+        assert np.all(out[:, No:] == 7.0), "wrote outside its columns"
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_skinny_kernel_real_source(emu, bf16):
+    """skinny.hip itself (packed weight tiles, LDS-staged activations, in-kernel RMSNorm statistics, the two m-tile
+    variant, SwiGLU strip pairs, residual) on the emulator against float64 numpy."""
+    g = np.random.default_rng(50 + bf16)
+    for (M, N, K, norm, act, hb, hr) in [(1, 64, 64, 0, ACT_NONE, 1, 0), (5, 96, 128, 1, ACT_NONE, 0, 1), (16, 64, 256, 1, ACT_SWIGLU, 0, 1),
+                                          (23, 128, 128, 1, ACT_NONE, 0, 1), (32, 64, 192, 1, ACT_SWIGLU, 0, 0), (40, 32, 64, 1, ACT_NONE, 1, 0)]:
+        x = g.standard_normal((M, K + 4)).astype(np.float32)
+        W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        gw = (1 + 0.1 * g.standard_normal(K)).astype(np.float32) if norm else None
+        bias = g.standard_normal(N).astype(np.float32) if hb else None
+        No = N // 2 if act == ACT_SWIGLU else N
+        res = g.standard_normal((M, No)).astype(np.float32) if hr else None
+        Wf = W * gw if norm else W
+        if bf16:
+            Wf = _bf16_round(Wf)[0]
+            xv = _bf16_round(x[:, :K])[0]
+        else:
+            xv = x[:, :K]
+        acc = xv.astype(np.float64) @ Wf.astype(np.float64).T
+        if norm:
+            acc *= 1 / np.sqrt((x[:, :K].astype(np.float64) ** 2).mean(1, keepdims=True) + 1e-6)
+        if hb:
+            acc += bias
+        if act == ACT_SWIGLU:
+            a = acc.reshape(M, N // 32, 2, 16)
+            acc = ((a[:, :, 0] / (1 + np.exp(-a[:, :, 0]))) * a[:, :, 1]).reshape(M, No)
+        if hr:
+            acc = acc + res
+        out = np.full((M, No + 4), 7.0, np.float32)
+        rc = emu.hostemu_skinny(_ptr(x), K + 4, M, _ptr(W), N, K, _ptr(gw) if norm else None, norm, 1e-6, _ptr(bias) if hb else None,
+                                _ptr(res) if hr else None, No, act, _ptr(out), No + 4, bf16)
+        assert rc == 0, ((M, N, K), (emu.qtts_last_error() or b"").decode())
+        tol = (4e-3 if bf16 else 2e-5) * max(1.0, float(np.abs(acc).max()))
+        assert np.abs(out[:, :No] - acc).max() <= tol, (M, N, K, norm, act, float(np.abs(out[:, :No] - acc).max()))
+        assert np.all(out[:, No:] == 7.0)
 
 
 def _ok(lib, rc):
@@ -95,6 +235,12 @@ def test_decoder_orchestration_forward_and_chunked(emu, codec):
     with torch.no_grad():
         ref = codec_ref.decoder_forward(w, c, torch.from_numpy(codes))[:, 0].numpy()
     assert np.sqrt(((wav - ref) ** 2).mean()) <= 1e-5
+    with real_gemm(emu):                                                     # and with gemm_tap.hip itself, on a short clip
+        w3 = np.zeros((1, 3 * c.total_upsample), np.float32)
+        _ok(emu, emu.qtts_codec_forward(h, _ptr(np.ascontiguousarray(codes[:1, :, :3])), 1, 3, _ptr(w3), None, None))
+        with torch.no_grad():
+            ref3 = codec_ref.decoder_forward(w, c, torch.from_numpy(codes[:1, :, :3]))[:, 0].numpy()
+        assert np.sqrt(((w3 - ref3) ** 2).mean()) <= 1e-5
     padded = np.ascontiguousarray(codes.transpose(0, 2, 1)).copy()          # (B, T, Q), row 1 ends after 7 frames
     padded[1, 7:] = -1
     out = np.zeros((2, 11 * c.total_upsample), np.float32)
@@ -109,14 +255,14 @@ def test_decoder_orchestration_forward_and_chunked(emu, codec):
 
 def test_stream_push_equals_whole_sequence_forward(emu, codec):
     """qtts_codec_stream_begin / _push (state-carrying streaming decode): the product's C++ orchestration,
-    run here on CPU kernels, reproduces the whole-sequence forward for ragged packets, single frames and streams several
+    run here on the emulated kernels, reproduces the whole-sequence forward for ragged packets, single frames and streams several
     attention windows long."""
     c, w, h = codec
     T = 45
     codes = np.random.default_rng(12).integers(0, c.codebook_size, (2, c.num_quantizers, T))
     with torch.no_grad():
         ref = codec_ref.decoder_forward(w, c, torch.from_numpy(codes))[:, 0].numpy()
-    for cuts in ([0, 1, 2, 3, 10, 11, 30, 45], list(range(0, 46, 5)), [0, 45], list(range(46))):
+    for cuts in ([0, 1, 2, 3, 10, 11, 30, 45], list(range(0, 46, 5)), list(range(20)) + [45]) + (([0, 45], list(range(46))) if FULL else ()):
         _ok(emu, emu.qtts_codec_stream_begin(h, 2))
         outs = []
         for a, b in zip(cuts[:-1], cuts[1:]):
@@ -127,12 +273,22 @@ def test_stream_push_equals_whole_sequence_forward(emu, codec):
         got = np.concatenate(outs, axis=1)
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= 5e-5, cuts[:4]
+    with real_gemm(emu):                                                     # gemm_tap.hip itself on the staged rows
+        _ok(emu, emu.qtts_codec_stream_begin(h, 1))
+        outs = []
+        for a, b in ((0, 1), (1, 3), (3, 4)):
+            o = np.zeros((1, (b - a) * c.total_upsample), np.float32)
+            _ok(emu, emu.qtts_codec_stream_push(h, _ptr(np.ascontiguousarray(codes[:1, :, a:b])), b - a, _ptr(o), None))
+            outs.append(o)
+        assert np.abs(np.concatenate(outs, axis=1) - ref[:1, :4 * c.total_upsample]).max() <= 5e-5
     assert emu.qtts_codec_stream_begin(h, 3) != 0                            # more sequences than max_batch
 
 
-def test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir, dtype):
     """qtts_encoder_* (HIP codec encoder): finalize() repacking (stride-1 taps, super-row strided taps,
-    normalised codebooks) + encode() on CPU kernels against the codes of the reference's own encoder class."""
+    normalised codebooks) + encode() on the emulated kernels against the codes of the reference's own encoder class: bit-exact in fp32; in bf16 (the bf16 MFMA kernels, no oracle
+    of their own) most codes must still agree."""
     g = np.load(os.path.join(golden_dir, "codec_enc_small.npz"))
     c = synth.mimi_enc_small()
     w = {k: torch.from_numpy(v) for k, v in synth.mimi_enc_weights(c).items()}
@@ -147,7 +303,7 @@ def test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir):
         ec.ratios[i] = int(r)
     ec.valid_num_quantizers = cfg.encoder_valid_num_quantizers
     ec.rope_theta, ec.norm_eps = float(cfg.rope_theta), float(cfg.norm_eps)
-    ec.compute_dtype, ec.max_batch, ec.max_samples = _lib.QTTS_F32, 2, 512
+    ec.compute_dtype, ec.max_batch, ec.max_samples = (_lib.QTTS_F32 if dtype == "f32" else _lib.QTTS_BF16), 2, 512
     h = C.c_void_p()
     _ok(emu, emu.qtts_encoder_create(C.byref(ec), C.byref(h)))
     try:
@@ -155,6 +311,7 @@ def test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir):
             if not name.endswith("codebook.initialized"):
                 _lib.bind_tensor(emu.qtts_encoder_bind, h, name, t)
         _ok(emu, emu.qtts_encoder_finalize(h))
+        emu.hostemu_set_real_gemm(1)                                         # gemm_tap.hip itself (restored in `finally`)
         for n in (16, 203, 331):
             x = np.ascontiguousarray(g[f"wav{n}"][:, 0])
             fr = C.c_int64()
@@ -163,15 +320,20 @@ def test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir):
             assert fr.value == want.shape[-1]
             codes = np.zeros((2, c.encoder_valid_num_quantizers, fr.value), np.int64)
             _ok(emu, emu.qtts_encoder_encode(h, _ptr(x), 2, n, _ptr(codes), None))
-            assert np.array_equal(codes, want), (n, float((codes != want).mean()))
+            if dtype == "f32":
+                assert np.array_equal(codes, want), (n, float((codes != want).mean()))
+            else:
+                assert (codes == want).mean() >= 0.85 and codes.min() >= 0 and codes.max() < c.codebook_size, n
         assert emu.qtts_encoder_encode(h, _ptr(x), 3, 331, _ptr(codes), None) != 0      # batch above max_batch
     finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
         emu.qtts_encoder_destroy(h)
 
 
-def test_speaker_orchestration_embedding_vs_oracle(emu):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_speaker_orchestration_embedding_vs_oracle(emu, dtype):
     """qtts_speaker_* (speaker embedding): finalize() (DFT matrix, filterbank padding, conv tap layouts)
-    + embed() on CPU kernels against oracle/speaker_ref.py (torch.stft log-mel + the ECAPA-TDNN restatement that is pinned
+    + embed() on the emulated kernels against oracle/speaker_ref.py (torch.stft log-mel + the ECAPA-TDNN restatement that is pinned
     to the reference module): log-mel features and the embedding, for a length that is not a multiple of the hop."""
     import speaker_ref
     from qwen3_tts_amd.speaker import SpeakerEncoderConfig, fill_speaker_config, mel_filterbank_slaney
@@ -186,12 +348,13 @@ def test_speaker_orchestration_embedding_vs_oracle(emu):
     cfg = SpeakerEncoderConfig.from_any(synth.cfg_dict(c))
     assert np.array_equal(mel_filterbank_slaney(24000, 1024, 128, 0, 12000), speaker_ref.mel_filterbank_slaney(24000, 1024, 128, 0, 12000))
     h = C.c_void_p()
-    _ok(emu, emu.qtts_speaker_create(C.byref(fill_speaker_config(cfg, torch.float32, 2, 8192)), C.byref(h)))
+    _ok(emu, emu.qtts_speaker_create(C.byref(fill_speaker_config(cfg, torch.float32 if dtype == "f32" else torch.bfloat16, 2, 8192)), C.byref(h)))
     try:
         for name, t in w.items():
             _lib.bind_tensor(emu.qtts_speaker_bind, h, name, t)
         _lib.bind_tensor(emu.qtts_speaker_bind, h, "mel_basis", torch.from_numpy(mel_filterbank_slaney(24000, 1024, 128, 0, 12000)))
         _ok(emu, emu.qtts_speaker_finalize(h))
+        emu.hostemu_set_real_gemm(1)                                         # gemm_tap.hip itself (restored in `finally`)
         g = np.random.default_rng(9)
         for n in (4096, 6001):
             wav = (g.standard_normal((2, n)) * 0.2).clip(-1, 1).astype(np.float32)
@@ -204,10 +367,16 @@ def test_speaker_orchestration_embedding_vs_oracle(emu):
             emb = np.zeros((2, c.enc_dim), np.float32)
             mels = np.zeros((2, fr.value, c.mel_dim), np.float32)
             _ok(emu, emu.qtts_speaker_embed(h, _ptr(wav), 2, n, _ptr(emb), _ptr(mels), None))
-            assert np.abs(mels - mel_ref.numpy()).max() <= 2e-4, n
-            assert np.abs(emb - emb_ref).max() <= 1e-4 * max(1.0, float(np.abs(emb_ref).max())), n
+            if dtype == "f32":
+                assert np.abs(mels - mel_ref.numpy()).max() <= 2e-4, n
+                assert np.abs(emb - emb_ref).max() <= 1e-4 * max(1.0, float(np.abs(emb_ref).max())), n
+            else:
+                assert np.abs(mels - mel_ref.numpy()).max() <= 2e-4, n          # the mel front end stays fp32
+                cos = [float(np.dot(a, b) / np.linalg.norm(a) / np.linalg.norm(b)) for a, b in zip(emb, emb_ref)]
+                assert min(cos) >= 0.999, (n, cos)                               # bf16 ECAPA-TDNN GEMMs
         assert emu.qtts_speaker_embed(h, _ptr(wav), 3, n, _ptr(emb), None, None) != 0
     finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
         emu.qtts_speaker_destroy(h)
 
 
@@ -325,11 +494,13 @@ def test_talker_stream_generation_equals_one_shot(emu, golden_dir):
         return codes[:, :seen], tokens[:, :seen + 1], packets
 
     try:
-        for packet in (1, 3, 5):
-            codes, tokens, _ = run(packet, t.codec_eos_token_id)
-            assert np.array_equal(codes, g["codes"]) and np.array_equal(tokens, g["tokens"]), packet
-            codes2, tokens2, _ = run(packet, int(g["eos2"]))
-            assert np.array_equal(codes2, g["codes_eos2"]) and np.array_equal(tokens2, g["tokens_eos2"]), packet
+        for packet, early in ((1, False), (3, True), (5, False)) if not FULL else [(p, e) for p in (1, 3, 5) for e in (False, True)]:
+            if not early:
+                codes, tokens, _ = run(packet, t.codec_eos_token_id)
+                assert np.array_equal(codes, g["codes"]) and np.array_equal(tokens, g["tokens"]), packet
+            else:
+                codes2, tokens2, _ = run(packet, int(g["eos2"]))
+                assert np.array_equal(codes2, g["codes_eos2"]) and np.array_equal(tokens2, g["tokens_eos2"]), packet
         part, _, _ = run(2, t.codec_eos_token_id, stop_after=2)               # abandoned after two packets
         assert part.shape[1] == 4 and np.array_equal(part, g["codes"][:, :4])
         assert emu.qtts_talker_stream_step(h, 1, C.byref(C.c_int32()), C.byref(C.c_int32()), None) != 0    # no active stream
