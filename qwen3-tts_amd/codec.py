@@ -322,18 +322,38 @@ class Qwen3TTSTokenizer:
         inst.device = inst.model.device
         return inst
 
-    def encode(self, audios, sr: Optional[int] = None, return_dict: bool = True):
-        """qwen3_tts_tokenizer.py:208-257 for numpy / tensor waveforms at the model's input rate.  File paths, base64
-        strings and resampling go through librosa / soundfile in the reference, which this build does not have."""
-        if isinstance(audios, (str, bytes)) or (isinstance(audios, list) and audios and isinstance(audios[0], (str, bytes))):
-            raise NotImplementedError("encode(): audio files / base64 need librosa + soundfile; pass waveforms (np.ndarray) and sr")
+    def _normalize_audio_inputs(self, audios, sr: Optional[int]) -> List[np.ndarray]:
+        """qwen3_tts_tokenizer.py:162-206: str (wav path / URL / base64) or waveform, or a list of either -> mono float32
+        waveforms at the model's input rate.  WAVE decoding and resampling are restated in audio_io.py (soundfile /
+        librosa are not in this image; resampling is band-limited polyphase, not soxr -- see that module)."""
+        from . import audio_io
+        target_sr = int(self.model.input_sample_rate)
+        if isinstance(audios, (str, np.ndarray, torch.Tensor)):
+            audios = [audios]
+        if len(audios) == 0:
+            return []
+        if isinstance(audios[0], str):
+            return [audio_io.load_audio(x, target_sr=target_sr) for x in audios]
         if sr is None:
-            raise ValueError("For numpy waveform input, `sr` must be provided.")                 # IT:181
-        if int(sr) != int(self.model.input_sample_rate):
-            raise NotImplementedError(f"encode(): resampling {sr} -> {self.model.input_sample_rate} Hz needs librosa")
-        wavs = audios if isinstance(audios, list) else [audios]
-        wavs = [np.asarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else w, dtype=np.float32) for w in wavs]
-        wavs = [w.mean(axis=-1) if w.ndim > 1 else w for w in wavs]                               # mono, as IT:166-168
+            raise ValueError("For numpy waveform input, you must provide `sr` (original sampling rate).")    # IT:190
+        out = []
+        for a in audios:
+            if isinstance(a, torch.Tensor):
+                a = a.detach().cpu().numpy()
+            if not isinstance(a, np.ndarray):
+                raise TypeError("Mixed input types are not supported. Use all paths/base64 or all numpy arrays.")   # IT:196
+            if a.ndim > 1:
+                a = np.mean(a, axis=-1)
+            if int(sr) != target_sr:
+                a = audio_io.resample(a.astype(np.float32), int(sr), target_sr)
+            out.append(a.astype(np.float32))
+        return out
+
+    def encode(self, audios, sr: Optional[int] = None, return_dict: bool = True):
+        """qwen3_tts_tokenizer.py:208-257: wav path(s) / base64 string(s) / waveform(s) (+ `sr`) -> codes."""
+        wavs = self._normalize_audio_inputs(audios, sr)
+        if not wavs:
+            raise ValueError("encode(): no audio given")
         L = max(w.shape[0] for w in wavs)
         x = torch.zeros(len(wavs), L, dtype=torch.float32)
         m = torch.zeros(len(wavs), L, dtype=torch.long)

@@ -453,8 +453,8 @@ class Qwen3TTSModel:
     # ---- voice clone (qwen3_tts_model.py:356-636)
     def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode=False) -> List[VoiceClonePromptItem]:
         """qwen3_tts_model.py:356-458: reference audio -> prompt items (speech codes through the tokenizer's encoder,
-        x-vector through the speaker encoder).  Audio must be given as (waveform np.ndarray, sr) at 24 kHz: file paths,
-        URLs, base64 and resampling go through librosa / soundfile in the reference, which this build does not have.
+        x-vector through the speaker encoder).  Audio: wav path / URL / base64 string, or (waveform np.ndarray, sr);
+        WAVE decoding and resampling are restated in audio_io.py (soundfile / librosa are not in this image).
         EXPERIMENTAL in round 1: both encoders are compiled and CPU-emulated; their first hardware run is pending."""
         if self.model.tts_model_type != "base":
             raise self._unsupported("create_voice_clone_prompt")
@@ -463,27 +463,32 @@ class Qwen3TTSModel:
         xvecs = self._ensure_list(x_vector_only_mode) if isinstance(x_vector_only_mode, list) else [x_vector_only_mode] * len(audios)
         if len(texts) != len(audios) or len(xvecs) != len(audios):
             raise ValueError(f"Batch size mismatch: ref_audio={len(audios)}, ref_text={len(texts)}, x_vector_only_mode={len(xvecs)}")
-        normalized = []
+        from . import audio_io
+        normalized = []                                                                              # IM:224-262
         for a in audios:
-            if isinstance(a, (str, bytes)):
-                raise NotImplementedError("create_voice_clone_prompt: audio files / URLs / base64 need librosa + soundfile; "
-                                          "pass (waveform, sr) tuples")
-            if not (isinstance(a, tuple) and len(a) == 2):
+            if isinstance(a, str):
+                normalized.append(audio_io.load_audio_to_np(a))
+            elif isinstance(a, tuple) and len(a) == 2 and isinstance(a[0], np.ndarray):
+                normalized.append((a[0].astype(np.float32), int(a[1])))
+            elif isinstance(a, np.ndarray):
+                raise ValueError("For numpy waveform input, pass a tuple (audio, sr).")              # IM:257
+            else:
                 raise TypeError(f"Unsupported audio input type: {type(a)}")                          # IM:259
-            wav, sr = np.asarray(a[0], dtype=np.float32), int(a[1])
-            if wav.ndim > 1:
-                wav = wav.mean(axis=-1)
-            if sr != self.model.speaker_encoder_sample_rate:
-                raise NotImplementedError(f"create_voice_clone_prompt: resampling {sr} -> 24000 Hz needs librosa")
-            normalized.append((wav, sr))
+        normalized = [(w.mean(axis=-1).astype(np.float32) if w.ndim > 1 else w, sr) for w, sr in normalized]
         for i, (rtext, xv) in enumerate(zip(texts, xvecs)):
             if not xv and (rtext is None or rtext == ""):
                 raise ValueError(f"ref_text is required when x_vector_only_mode=False (ICL mode). Bad index={i}")
-        enc = self.model.speech_tokenizer.encode([w for w, _ in normalized], sr=normalized[0][1])
+        srs = [sr for _, sr in normalized]
+        if len(set(srs)) == 1:                                                                       # IM:425-431
+            ref_codes = self.model.speech_tokenizer.encode([w for w, _ in normalized], sr=srs[0]).audio_codes
+        else:
+            ref_codes = [self.model.speech_tokenizer.encode(w, sr=sr).audio_codes[0] for w, sr in normalized]
         items = []
-        for (wav, sr), code, rtext, xv in zip(normalized, enc.audio_codes, texts, xvecs):
+        spk_sr = int(self.model.speaker_encoder_sample_rate)
+        for (wav, sr), code, rtext, xv in zip(normalized, ref_codes, texts, xvecs):
+            wav24 = wav if sr == spk_sr else audio_io.resample(wav, sr, spk_sr)                      # IM:440-444
             items.append(VoiceClonePromptItem(ref_code=None if xv else code,
-                                              ref_spk_embedding=self.model.extract_speaker_embedding(audio=wav, sr=sr),
+                                              ref_spk_embedding=self.model.extract_speaker_embedding(audio=wav24, sr=spk_sr),
                                               x_vector_only_mode=bool(xv), icl_mode=bool(not xv), ref_text=rtext))
         return items
 

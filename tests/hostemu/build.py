@@ -25,7 +25,7 @@ SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hi
 SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}
 # gemm_tap.hip is built as launch_gemm_tap_real; cpu_gemm_tap.cpp owns launch_gemm_tap and forwards to it on request
 EXTRA_DEFS = {"gemm_tap.hip": ["-Dlaunch_gemm_tap=launch_gemm_tap_real"]}
-STANDIN = ["cpu_gemm_tap.cpp", "lds_arrays.cpp"]
+STANDIN = ["cpu_gemm_tap.cpp", "test_entries.cpp", "lds_arrays.cpp"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h")] + [
     os.path.join(ROOT, "include", "qtts.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "simt.h")]
 

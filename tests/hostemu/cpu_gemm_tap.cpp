@@ -4,7 +4,8 @@
 // default and through the REAL kernel when asked:
 //     hostemu_set_real_gemm(1)  /  QTTS_HOSTEMU_FULL=1     -> qtts::launch_gemm_tap_real (gemm_tap.hip, built with
 //                                                            -Dlaunch_gemm_tap=launch_gemm_tap_real)
-// tests/test_hostemu.py runs the encoder / speaker engines and the kernel-level GEMM cases with the real kernel always,
+// (hostemu_set_real_gemm lives in test_entries.cpp.)  tests/test_hostemu.py runs the encoder / speaker engines and the
+// kernel-level GEMM cases with the real kernel always,
 // and the whole file with it under QTTS_HOSTEMU_FULL=1 (17 min; recorded in DESIGN.md).  Not a product path:
 // libqtts_hostemu.so is only loaded by tests/.
 #include <cmath>
@@ -16,7 +17,7 @@
 namespace qtts {
 
 void launch_gemm_tap_real(const GemmTapParams& p, bool bf16, hipStream_t st);      // gemm_tap.hip on the emulator
-static int g_real_gemm = -1;
+int g_real_gemm = -1;              // set by hostemu_set_real_gemm (test_entries.cpp)
 static bool real_gemm() {
     if (g_real_gemm < 0) { const char* e = getenv("QTTS_HOSTEMU_FULL"); g_real_gemm = (e && e[0] == '1') ? 1 : 0; }
     return g_real_gemm == 1;
@@ -70,37 +71,3 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st) {
 }
 
 }  // namespace qtts
-
-// ---- test-only entry points (host pointers): kernel-level cases for tests/test_hostemu.py
-extern "C" void hostemu_set_real_gemm(int on) { qtts::g_real_gemm = on ? 1 : 0; }
-
-// C[M][ldc] = epilogue(sum_tap A[m + shift[tap]] . W[tap]^T) through the REAL gemm_tap.hip kernels; returns 0 / QTTS_ERR_*
-extern "C" int hostemu_gemm_tap(const float* A, int lda, int M, int T, const void* W, int N, int K, int taps, const int* shift,
-                                const float* bias, const float* scale, const float* res, int ldr, const float* snake_ea,
-                                const float* snake_ib, int act, float* C, int ldc, int bf16) {
-    try {
-        qtts::GemmTapParams p{};
-        p.A = A; p.lda = lda; p.M = M; p.T = T; p.W = W; p.N = N; p.K = K; p.taps = taps;
-        for (int i = 0; i < taps && i < 8; ++i) p.shift[i] = shift[i];
-        p.bias = bias; p.scale = scale; p.res = res; p.ldr = ldr; p.snake_ea = snake_ea; p.snake_ib = snake_ib; p.act = act;
-        p.C = C; p.ldc = ldc;
-        qtts::launch_gemm_tap_real(p, bf16 != 0, nullptr);
-        return 0;
-    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
-}
-
-// out[M][ldo] = skinny GEMM of x[M][K] with W[N][K] (row-major fp32, packed here exactly as the engines pack it)
-extern "C" int hostemu_skinny(const float* x, int ldx, int M, const float* W, int N, int K, const float* g, int norm, float eps,
-                              const float* bias, const float* res, int ldr, int act, float* out, int ldo, int bf16) {
-    try {
-        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(N, K, bf16 != 0));
-        qtts::pack_skinny_weight(W, N, K, bf16 != 0, wp.data(), g, 16);
-        std::vector<float> ss(M, 0.f);
-        for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) ss[m] += x[(size_t)m * ldx + k] * x[(size_t)m * ldx + k];
-        qtts::SkinnyParams p{};
-        p.x = x; p.ldx = ldx; p.M = M; p.Wp = wp.data(); p.N = N; p.K = K; p.fs = 16; p.norm = norm; p.ss_in = ss.data(); p.eps = eps;
-        p.bias = bias; p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.act = act;
-        qtts::launch_skinny(p, bf16 != 0, nullptr);
-        return 0;
-    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
-}

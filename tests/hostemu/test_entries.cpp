@@ -1,0 +1,62 @@
+// TEST INFRASTRUCTURE -- kernel-level entry points of libqtts_hostemu.so (host pointers): tests/test_hostemu.py calls the
+// launch_* interfaces of csrc/kernels.h directly, so that single kernels can be checked against numpy / the oracle on the
+// SIMT emulator without an engine around them.  Not part of the product ABI (include/qtts.h).
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+
+// ---- test-only entry points (host pointers): kernel-level cases for tests/test_hostemu.py
+namespace qtts { extern int g_real_gemm; void launch_gemm_tap_real(const GemmTapParams& p, bool bf16, hipStream_t st); }
+extern "C" void hostemu_set_real_gemm(int on) { qtts::g_real_gemm = on ? 1 : 0; }
+
+// C[M][ldc] = epilogue(sum_tap A[m + shift[tap]] . W[tap]^T) through the REAL gemm_tap.hip kernels; returns 0 / QTTS_ERR_*
+extern "C" int hostemu_gemm_tap(const float* A, int lda, int M, int T, const void* W, int N, int K, int taps, const int* shift,
+                                const float* bias, const float* scale, const float* res, int ldr, const float* snake_ea,
+                                const float* snake_ib, int act, float* C, int ldc, int bf16) {
+    try {
+        qtts::GemmTapParams p{};
+        p.A = A; p.lda = lda; p.M = M; p.T = T; p.W = W; p.N = N; p.K = K; p.taps = taps;
+        for (int i = 0; i < taps && i < 8; ++i) p.shift[i] = shift[i];
+        p.bias = bias; p.scale = scale; p.res = res; p.ldr = ldr; p.snake_ea = snake_ea; p.snake_ib = snake_ib; p.act = act;
+        p.C = C; p.ldc = ldc;
+        qtts::launch_gemm_tap_real(p, bf16 != 0, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
+// out[M][ldo] = skinny GEMM of x[M][K] with W[N][K] (row-major fp32, packed here exactly as the engines pack it)
+extern "C" int hostemu_skinny(const float* x, int ldx, int M, const float* W, int N, int K, const float* g, int norm, float eps,
+                              const float* bias, const float* res, int ldr, int act, float* out, int ldo, int bf16) {
+    try {
+        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(N, K, bf16 != 0));
+        qtts::pack_skinny_weight(W, N, K, bf16 != 0, wp.data(), g, 16);
+        std::vector<float> ss(M, 0.f);
+        for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) ss[m] += x[(size_t)m * ldx + k] * x[(size_t)m * ldx + k];
+        qtts::SkinnyParams p{};
+        p.x = x; p.ldx = ldx; p.M = M; p.Wp = wp.data(); p.N = N; p.K = K; p.fs = 16; p.norm = norm; p.ss_in = ss.data(); p.eps = eps;
+        p.bias = bias; p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.act = act;
+        qtts::launch_skinny(p, bf16 != 0, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
+// One launch of sampling.hip's sample_kernel on B rows of logits: HF processors (repetition penalty over `generated`,
+// min-new-tokens EOS block, suppress mask), temperature / top-k / top-p, Philox draw keyed by (seed, stream_id, step).
+extern "C" int hostemu_sample(const float* logits, int ld, int V, int B, const int* generated, int gen_stride, int n_generated,
+                              float repetition_penalty, int eos, int min_new_tokens, const unsigned char* suppress_mask,
+                              int do_sample, int top_k, float top_p, float temperature, unsigned long long seed,
+                              unsigned int stream_id, int step, int* tok_out) {
+    try {
+        qtts::SampleParams p{};
+        p.logits = logits; p.ld = ld; p.V = V; p.B = B;
+        p.generated = generated; p.gen_stride = gen_stride; p.n_generated_dev = generated ? &n_generated : nullptr;
+        p.repetition_penalty = repetition_penalty; p.eos = eos; p.min_new_tokens = min_new_tokens; p.suppress_mask = suppress_mask;
+        p.do_sample = do_sample; p.top_k = top_k; p.top_p = top_p; p.temperature = temperature;
+        p.seed = seed; p.stream_id = stream_id; p.step_dev = &step;
+        p.tok_out = tok_out; p.tok_stride = 1;
+        qtts::launch_sample(p, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}

@@ -111,12 +111,107 @@ def test_tokenizer_decode_input_errors():
     tk.model = NoEncoder()
     with pytest.raises(NotImplementedError):
         tk.encode(np.zeros(10), sr=24000)
-    with pytest.raises(NotImplementedError, match="librosa"):
-        tk.encode("ref.wav")                                   # audio files need librosa / soundfile
-    with pytest.raises(NotImplementedError, match="resampling"):
-        tk.encode(np.zeros(10), sr=16000)
+    with pytest.raises(FileNotFoundError):
+        tk.encode("no_such_ref.wav")                           # a path is opened (IT:150)
     with pytest.raises(ValueError):
-        tk.encode(np.zeros(10))                                # numpy input without sr (IT:181)
+        tk.encode(np.zeros(10))                                # numpy input without sr (IT:190)
+    with pytest.raises(TypeError, match="Mixed input types"):
+        tk.encode([np.zeros(10), "x.wav"], sr=24000)           # IT:196
+
+
+def _wav_bytes(x, sr, kind="int16", channels=1):
+    """A RIFF/WAVE file image for tests: PCM int16 / int24 / uint8 or IEEE float32 / float64 (plain header)."""
+    import struct
+    x = np.asarray(x, np.float64).reshape(-1, channels)
+    if kind == "int16":
+        tag, bits, raw = 1, 16, np.clip(np.round(x * 32768), -32768, 32767).astype("<i2").tobytes()
+    elif kind == "uint8":
+        tag, bits, raw = 1, 8, np.clip(np.round(x * 128 + 128), 0, 255).astype(np.uint8).tobytes()
+    elif kind == "int24":
+        v = np.clip(np.round(x * 8388608), -8388608, 8388607).astype(np.int64).reshape(-1) & 0xFFFFFF
+        tag, bits, raw = 1, 24, np.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], 1).astype(np.uint8).tobytes()
+    elif kind == "float32":
+        tag, bits, raw = 3, 32, x.astype("<f4").tobytes()
+    else:
+        tag, bits, raw = 3, 64, x.astype("<f8").tobytes()
+    fmt = struct.pack("<HHIIHH", tag, channels, sr, sr * channels * bits // 8, channels * bits // 8, bits)
+    junk = b"LIST" + struct.pack("<I", 3) + b"abc" + b"\0"                  # an odd-sized chunk before fmt: word alignment
+    body = b"WAVE" + junk + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(raw)) + raw
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_audio_io_wave_decoding_base64_and_resampling(tmp_path):
+    """audio_io.py restates what the reference gets from soundfile / librosa (IT:101-160, IM:188-222) for WAVE input:
+    exact sample scaling for every PCM / float encoding, the base64 / data-URL / path dispatch, mono down-mix, and a
+    band-limited resampler with librosa's output length (soxr parity is unpinned -- checked against the analytic signal)."""
+    import base64
+    import wave
+    from qwen3_tts_amd import audio_io
+    g = np.random.default_rng(3)
+    x = (g.standard_normal(1000) * 0.3).clip(-0.99, 0.99)
+    for kind, q in (("int16", 32768.0), ("int24", 8388608.0), ("uint8", 128.0)):
+        got, sr = audio_io.read_wav_bytes(_wav_bytes(x, 22050, kind))
+        assert sr == 22050 and got.dtype == np.float32 and got.shape == (1000,)
+        assert np.array_equal(got, (np.clip(np.round(x * q), -q, q - 1) / q).astype(np.float32)), kind
+    for kind in ("float32", "float64"):
+        got, sr = audio_io.read_wav_bytes(_wav_bytes(x, 48000, kind))
+        assert np.array_equal(got, x.astype(np.float32)) and sr == 48000
+    st, _ = audio_io.read_wav_bytes(_wav_bytes(np.stack([x, -x], 1), 24000, "int16", channels=2))
+    assert st.shape == (1000, 2) and np.array_equal(st[:, 0], -st[:, 1])
+    # the stdlib writer's file == our reader's input; path, raw base64, data URL all reach the same samples
+    path = tmp_path / "ref.wav"
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(24000)
+        f.writeframes(np.clip(np.round(np.stack([x, x], 1) * 32768), -32768, 32767).astype("<i2").tobytes())
+    mono, sr = audio_io.load_audio_to_np(str(path))
+    want = (np.clip(np.round(x * 32768), -32768, 32767) / 32768).astype(np.float32)
+    assert sr == 24000 and mono.shape == (1000,) and np.allclose(mono, want, atol=1e-7)
+    b64 = base64.b64encode(path.read_bytes()).decode()
+    assert np.array_equal(audio_io.load_audio_to_np("data:audio/wav;base64," + b64)[0], mono)
+    # the reference's heuristic (IT:101-107): a raw string counts as base64 only if it is long and has no '/' or '\\'
+    assert "/" in b64 and not audio_io.is_probably_base64(b64) and not audio_io.is_probably_base64(str(path))
+    raw = base64.b64encode(_wav_bytes(np.zeros(400), 24000)).decode()
+    assert "/" not in raw and audio_io.is_probably_base64(raw) and audio_io.load_audio_to_np(raw)[0].shape == (400,)
+    assert audio_io.is_url("https://example.com/a.wav") and not audio_io.is_url(str(path))
+    for bad in (b"", b"OggS" + b"\0" * 40, b"RIFF\x04\0\0\0WAVE"):
+        with pytest.raises(ValueError):
+            audio_io.read_wav_bytes(bad)
+    # resampling: librosa's length rule, identity at equal rates, and the analytic band-limited answer away from the edges
+    for sr_in, sr_out, n in ((16000, 24000, 4001), (44100, 24000, 9000), (48000, 24000, 5000), (22050, 24000, 3000)):
+        t_in, t_out = np.arange(n) / sr_in, np.arange(int(np.ceil(n * sr_out / sr_in))) / sr_out
+        sig = lambda t: 0.5 * np.sin(2 * np.pi * 440.0 * t) + 0.3 * np.sin(2 * np.pi * 3100.0 * t + 0.7)
+        y = audio_io.resample(sig(t_in).astype(np.float32), sr_in, sr_out)
+        assert y.dtype == np.float32 and y.shape == t_out.shape, (sr_in, y.shape, t_out.shape)
+        edge = 200
+        assert np.abs(y[edge:-edge] - sig(t_out)[edge:-edge]).max() <= 2e-4, (sr_in, sr_out)
+    z = g.standard_normal(100).astype(np.float32)
+    assert audio_io.resample(z, 24000, 24000) is z and audio_io.resample(np.zeros(0, np.float32), 16000, 24000).shape == (0,)
+    assert np.allclose(audio_io.load_audio(str(path), 24000), mono) and audio_io.load_audio(str(path), 12000).shape == (500,)
+
+
+def test_tokenizer_encode_accepts_paths_and_resamples(tmp_path):
+    """Qwen3TTSTokenizer.encode (IT:208-257): paths / base64 / waveforms at any rate reach the model at 24 kHz, right
+    zero-padded with a mask -- checked with a stand-in model that records what it is given."""
+    import wave
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    seen = {}
+
+    class Rec:
+        input_sample_rate = 24000
+        def encode(self, x, m, return_dict=True):
+            seen["x"], seen["m"] = x, m
+            return "codes"
+    tk = Qwen3TTSTokenizer()
+    tk.model = Rec()
+    path = tmp_path / "a.wav"
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes((np.sin(np.arange(1600) * 0.05) * 20000).astype("<i2").tobytes())
+    assert tk.encode(str(path)) == "codes" and seen["x"].shape == (1, 2400) and int(seen["m"].sum()) == 2400
+    tk.encode([np.zeros(480, np.float32), np.ones((960, 2), np.float32)], sr=48000)
+    assert seen["x"].shape == (2, 480) and seen["m"].sum(1).tolist() == [240, 480]
+    tk.encode(torch.zeros(100), sr=24000)
+    assert seen["x"].shape == (1, 100)
 
 
 def test_model_wrapper_validation():
@@ -411,8 +506,9 @@ def test_create_voice_clone_prompt_wrapper_logic():
 
     class Tok:
         def encode(self, wavs, sr=None):
-            assert sr == 24000
-            return type("O", (), {"audio_codes": [torch.full((max(1, len(w) // 1920), 16), i) for i, w in enumerate(wavs)]})()
+            wavs = wavs if isinstance(wavs, list) else [wavs]
+            self.last_sr = sr
+            return type("O", (), {"audio_codes": [torch.full((max(1, len(w) * 24000 // sr // 1920), 16), i) for i, w in enumerate(wavs)]})()
 
     class M:
         device = torch.device("cpu")
@@ -436,12 +532,18 @@ def test_create_voice_clone_prompt_wrapper_logic():
         w.create_voice_clone_prompt(a)
     with pytest.raises(ValueError, match="Batch size mismatch"):
         w.create_voice_clone_prompt([a, b], ref_text=["only one"])
-    with pytest.raises(NotImplementedError, match="librosa"):
-        w.create_voice_clone_prompt("ref.wav", ref_text="x")
-    with pytest.raises(NotImplementedError, match="resampling"):
-        w.create_voice_clone_prompt((np.zeros(100, np.float32), 16000), ref_text="x")
+    with pytest.raises(FileNotFoundError):
+        w.create_voice_clone_prompt("no_such_ref.wav", ref_text="x")                   # a path is opened (IM:218)
+    # a 16 kHz reference: codes from the tokenizer at the ORIGINAL rate (it resamples itself, IM:425-431), the speaker
+    # encoder gets a 24 kHz copy (IM:440-444); mixed rates are encoded one by one
+    it16 = w.create_voice_clone_prompt((np.zeros(3200, np.float32), 16000), ref_text="x")
+    assert M.speech_tokenizer.last_sr == 16000 and float(it16[0].ref_spk_embedding[0]) == 4800.0
+    mixed = w.create_voice_clone_prompt([a, (np.zeros(3200, np.float32), 16000)], ref_text=["p", "q"])
+    assert len(mixed) == 2 and float(mixed[1].ref_spk_embedding[0]) == 4800.0 and mixed[1].ref_code.shape == (2, 16)
+    with pytest.raises(ValueError, match="pass a tuple"):
+        w.create_voice_clone_prompt(np.zeros(100, np.float32), ref_text="x")            # IM:257
     with pytest.raises(TypeError):
-        w.create_voice_clone_prompt(np.zeros(100, np.float32), ref_text="x")
+        w.create_voice_clone_prompt(3.5, ref_text="x")                                  # IM:259
     M.tts_model_type = "custom_voice"
     with pytest.raises(ValueError, match="does not support create_voice_clone_prompt"):
         w.create_voice_clone_prompt(a, ref_text="x")

@@ -54,6 +54,8 @@ def emu():
     lib.hostemu_set_real_gemm.argtypes = [i32]; lib.hostemu_set_real_gemm.restype = None
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
+    lib.hostemu_sample.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_float, i32, i32, vp, i32, i32, C.c_float, C.c_float,
+                                   C.c_uint64, C.c_uint32, i32, vp]
     return lib
 
 
@@ -380,8 +382,62 @@ def test_speaker_orchestration_embedding_vs_oracle(emu, dtype):
         emu.qtts_speaker_destroy(h)
 
 
-def _talker_emu(emu, t, w, max_batch, max_seq):
-    """Create + bind + finalize a talker handle on the emulation library (fp32, eager: stream capture is not emulated)."""
+def test_sampler_kernel_real_source_vs_hf_processors(emu):
+    """sampling.hip's sample_kernel on the emulator against the oracle's restatement of the HF processor chain
+    (RepetitionPenalty -> MinNewTokens -> Suppress -> Temperature -> TopK -> TopP, talker_ref.process_logits): the greedy
+    pick is the argmax of the processed scores; under sampling every draw stays inside HF's support, the whole support is
+    reached, and the empirical distribution over 3000 Philox (seed, step) pairs passes a chi-square test."""
+    import talker_ref
+    g = np.random.default_rng(77)
+    for V, B in ((3072, 3), (2048, 2), (300, 2)):
+        logits = (g.standard_normal((B, V + 4)) * 2.5).astype(np.float32)
+        logits[0, 5] = logits[0, 9] = logits[0].max() + 1.0                   # a tie at the top: the lower index wins (torch.argmax)
+        gen = g.integers(0, V, (B, 12)).astype(np.int32)
+        n_gen = 7
+        eos = V - 3
+        logits[1, eos] = logits[1].max() + 3.0                                # EOS would win, but min_new_tokens blocks it
+        sup = np.zeros(V, np.uint8)
+        sup[V - 40:V - 8] = 1
+        sup_list = [int(i) for i in np.nonzero(sup)[0]]
+        lt, gt = torch.from_numpy(logits[:, :V].copy()), torch.from_numpy(gen[:, :n_gen].astype(np.int64))
+        tok = np.zeros(B, np.int32)
+
+        def launch(do_sample, top_k, top_p, temp, seed, step, min_new):
+            rc = emu.hostemu_sample(_ptr(logits), V + 4, V, B, _ptr(gen), 12, n_gen, 1.3, eos, min_new, _ptr(sup), do_sample, top_k,
+                                    top_p, temp, seed, 5, step, _ptr(tok))
+            assert rc == 0, (emu.qtts_last_error() or b"").decode()
+            return tok.copy()
+
+        for min_new in (0, 9):
+            want = talker_ref.process_logits(lt, gt, repetition_penalty=1.3, eos_id=eos, min_new_tokens=min_new, suppress=sup_list)
+            assert np.array_equal(launch(0, 0, 1.0, 1.0, 0, 0, min_new), want.argmax(-1).numpy()), (V, min_new)
+        for top_k, top_p, temp in ((6, 1.0, 0.8), (50, 1.0, 0.9), (12, 0.7, 1.0), (0, 1.0, 1.3)):
+            if top_k == 0 and V > 300:
+                continue                                                      # full-vocabulary multinomial: small case only
+            sc = talker_ref.process_logits(lt, gt, repetition_penalty=1.3, eos_id=eos, min_new_tokens=9, suppress=sup_list,
+                                           do_sample=True, temperature=temp, top_k=top_k, top_p=top_p)
+            pr = torch.softmax(sc, -1).numpy()
+            N = 3000 if V == 3072 else 1200
+            counts = np.zeros_like(pr)
+            for i in range(N):
+                for b, tk in enumerate(launch(1, top_k, top_p, temp, 1000 + i // 7, i % 7, 9)):
+                    counts[b, tk] += 1
+            for b in range(B):
+                assert (counts[b][pr[b] == 0] == 0).all(), "sampled a token outside HF's top-k / top-p support"
+                supp = pr[b] > 0
+                if top_k:
+                    assert supp.sum() == top_k if top_p >= 1.0 else 1 <= supp.sum() <= top_k
+                e, o = N * pr[b][supp], counts[b][supp]
+                small = e < 5.0
+                if small.sum() > 1:
+                    e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
+                chi2, dof = float((((o - e) ** 2) / e).sum()), len(e) - 1
+                assert chi2 < dof + 5.0 * np.sqrt(2.0 * max(dof, 1)) + 10.0, (V, top_k, top_p, b, chi2, dof)
+        assert np.array_equal(launch(1, 50, 1.0, 0.9, 42, 3, 9), launch(1, 50, 1.0, 0.9, 42, 3, 9))       # same key -> same draw
+
+
+def _talker_emu(emu, t, w, max_batch, max_seq, dtype=None):
+    """Create + bind + finalize a talker handle on the emulation library (eager: stream capture is not emulated)."""
     vp, i32 = C.c_void_p, C.c_int32
     emu.qtts_talker_create.argtypes = [C.POINTER(_lib.TalkerConfigC), C.POINTER(vp)]
     emu.qtts_talker_destroy.argtypes = [vp]; emu.qtts_talker_destroy.restype = None
@@ -401,7 +457,7 @@ def _talker_emu(emu, t, w, max_batch, max_seq):
         setattr(tc, f, int(getattr(c, f)))
     tc.rms_norm_eps, tc.rope_theta = float(c.rms_norm_eps), float(c.rope_theta)
     tc.cp_rms_norm_eps, tc.cp_rope_theta = float(c.cp_rms_norm_eps), float(c.cp_rope_theta)
-    tc.weight_dtype, tc.max_batch, tc.max_seq, tc.use_graph = _lib.QTTS_F32, max_batch, max_seq, 0
+    tc.weight_dtype, tc.max_batch, tc.max_seq, tc.use_graph = (_lib.QTTS_F32 if dtype is None else dtype), max_batch, max_seq, 0
     h = vp()
     _ok(emu, emu.qtts_talker_create(C.byref(tc), C.byref(h)))
     for name, x in w.items():
@@ -564,4 +620,22 @@ def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
         codes, tokens, _ = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=6)
         assert np.array_equal(tokens, r["tokens"].numpy()) and np.array_equal(codes, r["codes"].numpy())
     finally:
+        emu.qtts_talker_destroy(h)
+    # bf16 weights + bf16 KV pages: the product's serving configuration -- the LDS-staged skinny GEMM with two m-tiles
+    # (M = 20 / 40), LDS-DMA staging of bf16 activations, bf16 attention pages.  No exact oracle; as in the GPU suite the
+    # first frames must mostly agree with fp32, and the result must not depend on how the requests are batched
+    # (B = 20 in one batch == two batches of 10 with the same left padding).
+    h = _talker_emu(emu, t, w, max_batch=20, max_seq=64, dtype=_lib.QTTS_BF16)
+    emu.hostemu_set_real_gemm(1)                                             # the bf16 prefill GEMMs: gemm_tap.hip itself
+    try:
+        c16, _, _ = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=3)
+        assert float((c16[:, :2] == r["codes"].numpy()[:, :2]).mean()) >= 0.7
+        lens2 = ([3 + (5 * i) % 11 for i in range(9)] + [15]) * 2
+        e2, m2, tr2, pad2 = [x.numpy() for x in synth.rand_prompt(np.random.default_rng(10), t, lens2, 2, scale=0.5)]
+        whole, _, _ = _talker_generate(emu, h, t, e2, m2, tr2, pad2, max_new=3)
+        for half in (slice(0, 10), slice(10, 20)):
+            part, _, _ = _talker_generate(emu, h, t, e2[half], m2[half], tr2[half], pad2, max_new=3)
+            assert np.array_equal(part, whole[half])
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
         emu.qtts_talker_destroy(h)
