@@ -16,8 +16,13 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
-GEN = os.path.join(HERE, "gen")
-OUT = os.path.join(HERE, "libqtts_hostemu.so")
+# QTTS_HOSTEMU_ASAN=1: an AddressSanitizer build (libqtts_hostemu_asan.so): heap redzones around every device buffer,
+# global redzones around every static LDS array.  Run it as
+#   LD_PRELOAD=$(python tests/hostemu/build.py --asan-runtime) ASAN_OPTIONS=detect_leaks=0 QTTS_HOSTEMU_ASAN=1 \
+#       python -m pytest tests/test_hostemu.py
+ASAN = os.environ.get("QTTS_HOSTEMU_ASAN") == "1"
+OUT = os.path.join(HERE, "libqtts_hostemu_asan.so" if ASAN else "libqtts_hostemu.so")
+GEN = os.path.join(HERE, "gen_asan" if ASAN else "gen")
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
 SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "sampling.hip",
                 "elementwise.hip", "skinny.hip", "gemm_tap.hip"]
@@ -56,6 +61,8 @@ def build(verbose=False):
     os.makedirs(GEN, exist_ok=True)
     cc = _compiler()
     base = [cc, "-std=c++17", "-O2", "-fPIC", "-DQTTS_HOST_EMU", "-I", HERE, "-I", CSRC, "-Wno-unused-function", "-Wno-unused-value"]
+    san = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g"] if ASAN else []
+    base += san
     objs = []
     for f in ENGINES + SIMT_KERNELS:
         dst = os.path.join(GEN, f.replace(".hip", ".cpp"))
@@ -70,11 +77,17 @@ def build(verbose=False):
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         outs.append(o)
-    subprocess.run([cc, "-shared", "-o", OUT] + outs, check=True)
+    subprocess.run([cc, "-shared", "-o", OUT] + san + outs, check=True)
     with open(stamp, "w") as fh:
         fh.write(h.hexdigest())
     return OUT
 
 
+def asan_runtime():
+    out = subprocess.run([_compiler(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True)
+    return out.stdout.strip()
+
+
 if __name__ == "__main__":
-    print(build(verbose=True))
+    import sys
+    print(asan_runtime() if "--asan-runtime" in sys.argv else build(verbose=True))

@@ -40,6 +40,16 @@ __asm__(
     "  ret\n"
     ".size simt_switch, .-simt_switch\n");
 
+// AddressSanitizer build (QTTS_HOSTEMU_ASAN=1 python tests/hostemu/build.py): tell the runtime about every stack switch.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define SIMT_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+#endif
+#endif
+
 namespace simt {
 
 enum State { RUNNABLE, AT_BARRIER, AT_WAVE_OP, DONE };
@@ -47,6 +57,7 @@ enum Op { OP_NONE, OP_SHFL, OP_BALLOT, OP_MFMA_BF16, OP_MFMA_F32 };
 
 struct Fiber {
     void* sp = nullptr;               // parked stack pointer while the fiber is suspended
+    void* fake = nullptr;             // ASan fake-stack handle of the suspended fiber
     std::vector<char> stack;
     dim3 tid;
     State state = RUNNABLE;
@@ -61,9 +72,11 @@ struct Fiber {
 struct Machine {
     std::vector<Fiber> f;
     void* sched_sp = nullptr;
+    void* sched_fake = nullptr; const void* sched_bottom = nullptr; size_t sched_size = 0;     // ASan bookkeeping
     Fiber* cur = nullptr;
     dim3 block_idx, block_dim, grid_dim;
     const std::function<void()>* body = nullptr;
+    int order = 0;                    // fiber scheduling order: 0 ascending thread id, 1 descending, >= 2 seeded shuffle of waves
 };
 inline Machine& M() { static Machine m; return m; }
 
@@ -73,12 +86,25 @@ inline void yield_to_scheduler() {
         fprintf(stderr, "simt: a kernel compiled as thread-independent (QTTS_SIMT_SEQUENTIAL) called a barrier / cross-lane op\n");
         abort();
     }
+#ifdef SIMT_ASAN
+    Fiber* self = m.cur;
+    __sanitizer_start_switch_fiber(&self->fake, m.sched_bottom, m.sched_size);
+#endif
     simt_switch(&m.cur->sp, m.sched_sp);
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(self->fake, &m.sched_bottom, &m.sched_size);
+#endif
 }
 inline void fiber_entry() {
     Machine& m = M();
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &m.sched_bottom, &m.sched_size);
+#endif
     (*m.body)();
     m.cur->state = DONE;
+#ifdef SIMT_ASAN
+    __sanitizer_start_switch_fiber(nullptr, m.sched_bottom, m.sched_size);      // nullptr: this fiber's fake stack dies
+#endif
     simt_switch(&m.cur->sp, m.sched_sp);
     abort();                          // a finished fiber is never resumed
 }
@@ -160,6 +186,9 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
         f.tid = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
         f.state = RUNNABLE; f.op = OP_NONE; f.site = 0;
         // fresh stack: six zeroed callee-saved slots, then fiber_entry as the `ret` target (rsp = 8 mod 16 on entry)
+#ifdef SIMT_ASAN
+        __asan_unpoison_memory_region(f.stack.data(), f.stack.size());          // redzones of the previous occupant
+#endif
         uintptr_t top = ((uintptr_t)f.stack.data() + f.stack.size()) & ~(uintptr_t)15;
         void** q = (void**)top;
         *--q = nullptr;
@@ -167,15 +196,44 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
         for (int r = 0; r < 6; ++r) *--q = nullptr;
         f.sp = (void*)q;
     }
+    // The hardware runs the waves of a workgroup in no particular order.  Results must not depend on it, so the order in
+    // which runnable fibers are resumed is selectable (hostemu_set_fiber_order): a kernel that lacks a barrier between an
+    // LDS write and a read from another wave passes in one order and fails in another.
+    static thread_local std::vector<unsigned> ord;
+    ord.resize(n);
+    for (unsigned i = 0; i < n; ++i) ord[i] = m.order == 1 ? n - 1 - i : i;
+    if (m.order >= 2) {
+        const unsigned nw = (n + 63) / 64;
+        std::vector<unsigned> wv(nw);
+        for (unsigned w = 0; w < nw; ++w) wv[w] = w;
+        uint64_t st = 0x9E3779B97F4A7C15ull * (uint64_t)m.order + bidx.x * 0x2545F4914F6CDD1Dull + bidx.y;
+        for (unsigned w = nw; w > 1; --w) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(wv[w - 1], wv[(st >> 33) % w]);
+        }
+        const bool rev = (st >> 7) & 1;
+        unsigned k = 0;
+        for (unsigned w = 0; w < nw; ++w) {
+            const unsigned base = wv[w] * 64, c = n - base < 64 ? n - base : 64;
+            for (unsigned l = 0; l < c; ++l) ord[k++] = base + (rev ? c - 1 - l : l);
+        }
+    }
     for (;;) {
         bool ran = false, live = false;
-        for (unsigned i = 0; i < n; ++i) {
+        for (unsigned oi = 0; oi < n; ++oi) {
+            const unsigned i = ord[oi];
             Fiber& f = m.f[i];
             if (f.state == DONE) continue;
             live = true;
             if (f.state != RUNNABLE) continue;
             m.cur = &f;
+#ifdef SIMT_ASAN
+            __sanitizer_start_switch_fiber(&m.sched_fake, f.stack.data(), f.stack.size());
+#endif
             simt_switch(&m.sched_sp, f.sp);
+#ifdef SIMT_ASAN
+            __sanitizer_finish_switch_fiber(m.sched_fake, nullptr, nullptr);
+#endif
             ran = true;
         }
         if (!live) break;
@@ -214,6 +272,16 @@ inline void launch_sequential(dim3 grid, dim3 block, F&& body) {
                 m.block_idx = dim3(bx, by, bz);
                 for (unsigned t = 0; t < block.x; ++t) { one.tid = dim3(t, 0, 0); body(); }
             }
+}
+// the launch limits of the real device (gfx950): a launch the hardware would reject must not pass here either
+inline void check_launch(dim3 grid, dim3 block, size_t shmem, const char* name) {
+    const unsigned long long threads = (unsigned long long)block.x * block.y * block.z;
+    if (threads == 0 || threads > 1024 || grid.x == 0 || grid.y == 0 || grid.z == 0 || grid.x > 2147483647u || grid.y > 65535u ||
+        grid.z > 65535u || shmem > 160 * 1024) {
+        fprintf(stderr, "simt: launch of %s outside the device limits: grid (%u,%u,%u) block (%u,%u,%u) dynamic LDS %zu\n", name,
+                grid.x, grid.y, grid.z, block.x, block.y, block.z, shmem);
+        abort();
+    }
 }
 template <class K, class... A>
 inline void launch_kernel(dim3 grid, dim3 block, K kern, A... args) {      // arguments are evaluated once, by value, like a real launch
@@ -278,7 +346,8 @@ inline void global_load_lds(uintptr_t src, uintptr_t dst, int size) {
 #define blockIdx (simt::M().block_idx)
 #define blockDim (simt::M().block_dim)
 #define gridDim (simt::M().grid_dim)
-#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) simt::launch_kernel((grid), (block), kern, ##__VA_ARGS__)
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+    (simt::check_launch((grid), (block), (size_t)(shmem), #kern), simt::launch_kernel((grid), (block), kern, ##__VA_ARGS__))
 inline void __syncthreads() { simt::barrier(); }
 #define __shfl_xor(v, mask) simt::shfl_any((v), simt::lane_id() ^ (mask), __COUNTER__ + 1)
 #define __shfl_up(v, delta) simt::shfl_any((v), simt::lane_id() - (delta), __COUNTER__ + 1)

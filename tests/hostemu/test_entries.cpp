@@ -9,6 +9,9 @@
 
 // ---- test-only entry points (host pointers): kernel-level cases for tests/test_hostemu.py
 namespace qtts { extern int g_real_gemm; void launch_gemm_tap_real(const GemmTapParams& p, bool bf16, hipStream_t st); }
+// 0: fibers resume in ascending thread order, 1: descending, >= 2: seeded shuffle of the waves (see simt::run_block)
+extern "C" void hostemu_set_fiber_order(int order) { simt::M().order = order; }
+
 extern "C" void hostemu_set_real_gemm(int on) { qtts::g_real_gemm = on ? 1 : 0; }
 
 // C[M][ldc] = epilogue(sum_tap A[m + shift[tap]] . W[tap]^T) through the REAL gemm_tap.hip kernels; returns 0 / QTTS_ERR_*

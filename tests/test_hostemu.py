@@ -52,6 +52,7 @@ def emu():
     lib.qtts_encoder_encode.argtypes = [vp, vp, i32, i32, vp, vp]
     fp = C.POINTER(C.c_float)
     lib.hostemu_set_real_gemm.argtypes = [i32]; lib.hostemu_set_real_gemm.restype = None
+    lib.hostemu_set_fiber_order.argtypes = [i32]; lib.hostemu_set_fiber_order.restype = None
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_sample.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_float, i32, i32, vp, i32, i32, C.c_float, C.c_float,
@@ -639,3 +640,45 @@ def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
     finally:
         emu.hostemu_set_real_gemm(1 if FULL else 0)
         emu.qtts_talker_destroy(h)
+
+
+def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
+    """The hardware runs the waves of a workgroup in no particular order; the emulator's default is ascending thread id.
+    Re-run the kernel-level cases, the encoder, the speaker encoder, a short decode (whole and streamed) and a short talker
+    generation with the fibers resumed
+    in descending order and in a seeded shuffle of the waves (more under QTTS_HOSTEMU_FULL=1): a kernel that lacks a barrier between an LDS write and a
+    read from another wave passes in one order and fails in another."""
+    g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    try:
+        for order in ((1, 2, 3, 4) if FULL else (1, 3)):
+            emu.hostemu_set_fiber_order(order)
+            for bf16 in (0, 1):
+                test_gemm_tap_kernel_real_source(emu, bf16)
+                test_skinny_kernel_real_source(emu, bf16)
+            test_encoder_orchestration_codes_vs_reference_golden(emu, golden_dir, "f32")
+            test_speaker_orchestration_embedding_vs_oracle(emu, "f32")
+            c, cw, ch = codec                                                # decoder: short clip, one stream push sequence
+            codes = np.random.default_rng(21).integers(0, c.codebook_size, (1, c.num_quantizers, 4))
+            with torch.no_grad():
+                ref = codec_ref.decoder_forward(cw, c, torch.from_numpy(codes))[:, 0].numpy()
+            with real_gemm(emu):
+                wav = np.zeros((1, 4 * c.total_upsample), np.float32)
+                _ok(emu, emu.qtts_codec_forward(ch, _ptr(codes), 1, 4, _ptr(wav), None, None))
+                assert np.sqrt(((wav - ref) ** 2).mean()) <= 1e-5, order
+                _ok(emu, emu.qtts_codec_stream_begin(ch, 1))
+                outs = []
+                for a, b in ((0, 2), (2, 3), (3, 4)):
+                    o = np.zeros((1, (b - a) * c.total_upsample), np.float32)
+                    _ok(emu, emu.qtts_codec_stream_push(ch, _ptr(np.ascontiguousarray(codes[..., a:b])), b - a, _ptr(o), None))
+                    outs.append(o)
+                assert np.abs(np.concatenate(outs, axis=1) - ref).max() <= 5e-5, order
+            h = _talker_emu(emu, t, w, max_batch=4, max_seq=64)
+            try:
+                codes, tokens, _ = _talker_generate(emu, h, t, *[g[k] for k in ("embeds", "mask", "trailing", "tts_pad")], max_new=4)
+                assert np.array_equal(tokens, g["tokens"][:, :4]) and np.array_equal(codes, g["codes"][:, :3]), order
+            finally:
+                emu.qtts_talker_destroy(h)
+    finally:
+        emu.hostemu_set_fiber_order(0)
