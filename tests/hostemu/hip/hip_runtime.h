@@ -1,7 +1,7 @@
-// TEST INFRASTRUCTURE: a host stand-in for <hip/hip_runtime.h>, just enough to compile the ENGINE orchestration files
-// (csrc/codec_engine.hip, csrc/encoder_engine.hip) as plain C++ with "device" memory = host memory.  Together with
-// tests/hostemu/cpu_kernels.cpp (CPU versions of the launch_* interfaces) it lets the CPU test-suite execute the real
-// finalize() repacking, buffer rotation, carry bookkeeping and C ABI of those engines.  Never part of the product build.
+// TEST INFRASTRUCTURE: a host stand-in for <hip/hip_runtime.h>, just enough to compile csrc/*.hip -- engines and kernels
+// -- as plain C++ with "device" memory = host memory and kernels executed by the SIMT emulator (../simt.h), so that the
+// CPU test-suite runs the product's real finalize() repacking, buffer rotation, carry bookkeeping, C ABI and kernel code.
+// Never part of the product build.
 #pragma once
 #include <cstdint>
 #include <cstdlib>
@@ -14,7 +14,13 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 #define __host__
 #define __device__
 #define __forceinline__ inline
-inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }
+// Fresh device memory holds garbage on the GPU (the caching allocator recycles blocks): fill it with 0xFF bytes -- NaN
+// as fp32 / bf16, -1 as an integer -- so that code relying on zero-initialised buffers fails here too.
+inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = std::malloc(n ? n : 1);
+    if (*p) std::memset(*p, 0xFF, n ? n : 1);
+    return *p ? 0 : 2;
+}
 inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
