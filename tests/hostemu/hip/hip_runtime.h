@@ -22,11 +22,7 @@ inline hipError_t hipMalloc(void** p, size_t n) {
     return *p ? 0 : 2;
 }
 inline hipError_t hipFree(void* p) { std::free(p); return 0; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return 0; }
-inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 
@@ -44,14 +40,33 @@ inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return
 struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(8) ushort4 { unsigned short x, y, z, w; };
 #include "../simt.h"
+// ---- copies and synchronisation, capture-aware: an asynchronous copy issued while a stream capture is open becomes a
+// graph node (pointers baked, bytes moved at replay); a synchronising call inside a capture is an error on the device
+// (hipErrorStreamCaptureUnsupported = 900) and here.
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    if (simt::capture().open) { simt::capture().open->nodes.push_back([=] { std::memmove(d, s, n); }); return 0; }
+    std::memmove(d, s, n);
+    return 0;
+}
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+    if (simt::capture().open) return 900;
+    std::memcpy(d, s, n);
+    return 0;
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) {
+    if (simt::capture().open) return 900;
+    std::memset(d, v, n);
+    return 0;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return simt::capture().open ? 900 : 0; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
-// ---- the rest of the runtime surface csrc/talker_engine.hip touches.  Stream capture is not emulated: the talker is run
-// with use_graph = 0 here (its eager path launches exactly the kernels a captured frame replays).
+// ---- the rest of the runtime surface csrc/talker_engine.hip touches: events (no clock: elapsed time is a constant) and
+// stream capture / graphs (recorded launches replayed in order, see simt::Graph).
 typedef void* hipEvent_t;
-typedef void* hipGraph_t;
-typedef void* hipGraphExec_t;
+typedef simt::Graph* hipGraph_t;
+typedef simt::Graph* hipGraphExec_t;
 typedef void* hipGraphNode_t;
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
 static const unsigned hipStreamNonBlocking = 1;
@@ -61,10 +76,28 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return 0; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
-inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return 801; }       // hipErrorNotSupported
-inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { if (g) *g = nullptr; return 801; }
-inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return 801; }
-inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 801; }
-inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
-inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
-inline hipError_t hipGraphGetNodes(hipGraph_t, hipGraphNode_t*, size_t* n) { if (n) *n = 0; return 0; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+    if (simt::capture().open) return 900;
+    simt::capture().open = new simt::Graph();
+    return 0;
+}
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+    simt::Graph* gr = simt::capture().open;
+    simt::capture().open = nullptr;
+    if (g) *g = gr; else delete gr;
+    return gr ? 0 : 901;                                              // hipErrorIllegalState: no capture was open
+}
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) {
+    if (!g) return 1;
+    *e = new simt::Graph(*g);                                         // the executable graph is its own copy of the nodes
+    return 0;
+}
+inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+    if (!e) return 1;
+    if (simt::capture().open) return 900;
+    for (auto& n : e->nodes) n();
+    return 0;
+}
+inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return 0; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return 0; }
+inline hipError_t hipGraphGetNodes(hipGraph_t g, hipGraphNode_t*, size_t* n) { if (n) *n = g ? g->nodes.size() : 0; return 0; }

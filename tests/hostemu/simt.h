@@ -283,13 +283,22 @@ inline void check_launch(dim3 grid, dim3 block, size_t shmem, const char* name) 
         abort();
     }
 }
+// Stream capture (hipStreamBeginCapture .. hipStreamEndCapture in hip/hip_runtime.h): while a capture is open, a launch
+// is RECORDED -- kernel, geometry and by-value arguments, exactly what a hipGraph kernel node bakes in -- instead of
+// executed; hipGraphLaunch replays the recorded nodes in order.  Anything the engine keeps in "device" memory is read at
+// replay time, anything it passed by value is frozen at capture time, as on the device.
+struct Graph { std::vector<std::function<void()>> nodes; };
+struct CaptureState { Graph* open = nullptr; };
+inline CaptureState& capture() { static CaptureState c; return c; }
+
 template <class K, class... A>
 inline void launch_kernel(dim3 grid, dim3 block, K kern, A... args) {      // arguments are evaluated once, by value, like a real launch
 #ifdef QTTS_SIMT_SEQUENTIAL
-    launch_sequential(grid, block, [=] { kern(args...); });
+    auto run = [=] { launch_sequential(grid, block, [=] { kern(args...); }); };
 #else
-    launch(grid, block, [=] { kern(args...); });
+    auto run = [=] { launch(grid, block, [=] { kern(args...); }); };
 #endif
+    if (capture().open) capture().open->nodes.push_back(run); else run();
 }
 
 // ---- what device code calls

@@ -467,8 +467,9 @@ def test_sampler_kernel_real_source_vs_hf_processors(emu):
         assert np.array_equal(launch(1, 50, 1.0, 0.9, 42, 3, 9), launch(1, 50, 1.0, 0.9, 42, 3, 9))       # same key -> same draw
 
 
-def _talker_emu(emu, t, w, max_batch, max_seq, dtype=None):
-    """Create + bind + finalize a talker handle on the emulation library (eager: stream capture is not emulated)."""
+def _talker_emu(emu, t, w, max_batch, max_seq, dtype=None, use_graph=0):
+    """Create + bind + finalize a talker handle on the emulation library (eager, or with the frame step captured and
+    replayed through the emulated stream capture of hostemu/hip/hip_runtime.h)."""
     vp, i32 = C.c_void_p, C.c_int32
     emu.qtts_talker_create.argtypes = [C.POINTER(_lib.TalkerConfigC), C.POINTER(vp)]
     emu.qtts_talker_destroy.argtypes = [vp]; emu.qtts_talker_destroy.restype = None
@@ -488,7 +489,7 @@ def _talker_emu(emu, t, w, max_batch, max_seq, dtype=None):
         setattr(tc, f, int(getattr(c, f)))
     tc.rms_norm_eps, tc.rope_theta = float(c.rms_norm_eps), float(c.rope_theta)
     tc.cp_rms_norm_eps, tc.cp_rope_theta = float(c.cp_rms_norm_eps), float(c.cp_rope_theta)
-    tc.weight_dtype, tc.max_batch, tc.max_seq, tc.use_graph = (_lib.QTTS_F32 if dtype is None else dtype), max_batch, max_seq, 0
+    tc.weight_dtype, tc.max_batch, tc.max_seq, tc.use_graph = (_lib.QTTS_F32 if dtype is None else dtype), max_batch, max_seq, use_graph
     h = vp()
     _ok(emu, emu.qtts_talker_create(C.byref(tc), C.byref(h)))
     for name, x in w.items():
@@ -519,15 +520,17 @@ def _talker_generate(emu, h, t, emb, mask, trailing, pad, max_new, eos=None, min
     return codes[:, :n], tokens[:, :n + 1], hidden[:, :n]
 
 
-def test_talker_orchestration_greedy_vs_reference_golden(emu, golden_dir):
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_talker_orchestration_greedy_vs_reference_golden(emu, golden_dir, use_graph):
     """The talker engine's real C++ -- weight packing (fused q|k|v, 16-row gate/up interleave, folded norm weights,
     streaming tile layout), prefill, the 15-pass code predictor + 28-layer-style frame step, EOS / finished-row
-    bookkeeping, stop latch -- on CPU kernel stand-ins, against the REFERENCE's greedy codes (tests/golden/talker_tiny.npz):
+    bookkeeping, stop latch, eager and through the captured frame graph (graph cache keyed by everything a capture bakes
+    in) -- on the emulated kernels, against the REFERENCE's greedy codes (tests/golden/talker_tiny.npz):
     bit-exact indices, final hidden state, and the early-EOS variant."""
     g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
     t = synth.talker_tiny()
     w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
-    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64)
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, use_graph=use_graph)
     try:
         args = [g[k] for k in ("embeds", "mask", "trailing", "tts_pad")]
         codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=14)
@@ -540,11 +543,13 @@ def test_talker_orchestration_greedy_vs_reference_golden(emu, golden_dir):
         emu.qtts_talker_destroy(h)
 
 
-def test_talker_stream_generation_equals_one_shot(emu, golden_dir):
+@pytest.mark.parametrize("use_graph", [0, 1] if FULL else [1])
+def test_talker_stream_generation_equals_one_shot(emu, golden_dir, use_graph):
     """qtts_talker_stream_begin / _step / _end (resumable generation for streaming output): stepping the request in packets
     of 1, 3 or 5 frames yields, frame for frame, the codes of the one-shot generate -- i.e. the reference golden -- with a
     monotone `frames_total`, the stop latch reported once, for the normal and the early-EOS run; an abandoned stream
-    reports the frames it produced."""
+    reports the frames it produced.  Runs the captured-graph path (bursts of hipGraphLaunch between polls of the stop latch),
+    which is what the GPU executes; the eager path too under QTTS_HOSTEMU_FULL=1."""
     vp, i32 = C.c_void_p, C.c_int32
     emu.qtts_talker_stream_begin.argtypes = [vp, C.POINTER(_lib.SamplingC), i32, i32, i32, C.POINTER(C.c_int32), i32, vp, vp, vp]
     emu.qtts_talker_stream_step.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
@@ -552,7 +557,7 @@ def test_talker_stream_generation_equals_one_shot(emu, golden_dir):
     g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
     t = synth.talker_tiny()
     w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
-    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64)
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, use_graph=use_graph)
     sup = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != t.codec_eos_token_id]
     sup_c = (C.c_int32 * len(sup))(*sup)
 
