@@ -322,6 +322,24 @@ class Qwen3TTSTokenizer:
         inst.device = inst.model.device
         return inst
 
+    # ---- audio inputs (qwen3_tts_tokenizer.py:113-160): same helper names; the work is in audio_io.py
+    def _is_probably_base64(self, s: str) -> bool:
+        from . import audio_io
+        return audio_io.is_probably_base64(s)
+
+    def _is_url(self, s: str) -> bool:
+        from . import audio_io
+        return audio_io.is_url(s)
+
+    def _decode_base64_to_wav_bytes(self, b64: str) -> bytes:
+        from . import audio_io
+        return audio_io.decode_base64_to_wav_bytes(b64)
+
+    def load_audio(self, x: str, target_sr: int) -> np.ndarray:
+        """qwen3_tts_tokenizer.py:136-160: wav path / URL / base64 -> mono float32 waveform at `target_sr`."""
+        from . import audio_io
+        return audio_io.load_audio(x, target_sr=target_sr)
+
     def _normalize_audio_inputs(self, audios, sr: Optional[int]) -> List[np.ndarray]:
         """qwen3_tts_tokenizer.py:162-206: str (wav path / URL / base64) or waveform, or a list of either -> mono float32
         waveforms at the model's input rate.  WAVE decoding and resampling are restated in audio_io.py (soundfile /
@@ -333,7 +351,7 @@ class Qwen3TTSTokenizer:
         if len(audios) == 0:
             return []
         if isinstance(audios[0], str):
-            return [audio_io.load_audio(x, target_sr=target_sr) for x in audios]
+            return [self.load_audio(x, target_sr=target_sr) for x in audios]
         if sr is None:
             raise ValueError("For numpy waveform input, you must provide `sr` (original sampling rate).")    # IT:190
         out = []

@@ -450,6 +450,39 @@ class Qwen3TTSModel:
             out.append(None if ins is None or ins == "" else self._tokenize_texts([self._build_instruct_text(ins)])[0])
         return out
 
+    # ---- audio inputs (qwen3_tts_model.py:167-262): same helper names; the work is in audio_io.py
+    def _is_probably_base64(self, s: str) -> bool:
+        from . import audio_io
+        return audio_io.is_probably_base64(s)
+
+    def _is_url(self, s: str) -> bool:
+        from . import audio_io
+        return audio_io.is_url(s)
+
+    def _decode_base64_to_wav_bytes(self, b64: str) -> bytes:
+        from . import audio_io
+        return audio_io.decode_base64_to_wav_bytes(b64)
+
+    def _load_audio_to_np(self, x: str):
+        """IM:196-222: wav path / URL / base64 -> (mono float32 waveform, its own sample rate); no resampling here."""
+        from . import audio_io
+        return audio_io.load_audio_to_np(x)
+
+    def _normalize_audio_inputs(self, audios):
+        """IM:224-262: a str, an (np.ndarray, sr) tuple, or a list of those -> list of (mono float32 waveform, sr)."""
+        items = audios if isinstance(audios, list) else [audios]
+        out = []
+        for a in items:
+            if isinstance(a, str):
+                out.append(self._load_audio_to_np(a))
+            elif isinstance(a, tuple) and len(a) == 2 and isinstance(a[0], np.ndarray):
+                out.append((a[0].astype(np.float32), int(a[1])))
+            elif isinstance(a, np.ndarray):
+                raise ValueError("For numpy waveform input, pass a tuple (audio, sr).")              # IM:257
+            else:
+                raise TypeError(f"Unsupported audio input type: {type(a)}")                          # IM:259
+        return [(w.mean(axis=-1).astype(np.float32) if w.ndim > 1 else w, sr) for w, sr in out]
+
     # ---- voice clone (qwen3_tts_model.py:356-636)
     def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode=False) -> List[VoiceClonePromptItem]:
         """qwen3_tts_model.py:356-458: reference audio -> prompt items (speech codes through the tokenizer's encoder,
@@ -464,17 +497,7 @@ class Qwen3TTSModel:
         if len(texts) != len(audios) or len(xvecs) != len(audios):
             raise ValueError(f"Batch size mismatch: ref_audio={len(audios)}, ref_text={len(texts)}, x_vector_only_mode={len(xvecs)}")
         from . import audio_io
-        normalized = []                                                                              # IM:224-262
-        for a in audios:
-            if isinstance(a, str):
-                normalized.append(audio_io.load_audio_to_np(a))
-            elif isinstance(a, tuple) and len(a) == 2 and isinstance(a[0], np.ndarray):
-                normalized.append((a[0].astype(np.float32), int(a[1])))
-            elif isinstance(a, np.ndarray):
-                raise ValueError("For numpy waveform input, pass a tuple (audio, sr).")              # IM:257
-            else:
-                raise TypeError(f"Unsupported audio input type: {type(a)}")                          # IM:259
-        normalized = [(w.mean(axis=-1).astype(np.float32) if w.ndim > 1 else w, sr) for w, sr in normalized]
+        normalized = self._normalize_audio_inputs(audios)
         for i, (rtext, xv) in enumerate(zip(texts, xvecs)):
             if not xv and (rtext is None or rtext == ""):
                 raise ValueError(f"ref_text is required when x_vector_only_mode=False (ICL mode). Bad index={i}")

@@ -598,3 +598,60 @@ def test_streaming_output_host_logic():
     (p0, _), (p1, _) = out
     assert [a.tolist() for a in p0] == [[3.0] * UP + [4.0] * UP, [7.0] * UP + [8.0] * UP]
     assert [a.tolist() for a in p1] == [[5.0] * UP, [9.0] * UP + [49.0] * UP] and p1[0].dtype == np.float32
+
+
+def test_api_surface_matches_reference(golden_dir):
+    """The drop-in boundary: every method of the reference's `Qwen3TTSModel` / `Qwen3TTSTokenizer` /
+    `VoiceClonePromptItem` exists on the mirrored class with the same parameter names, order, defaults and kind.
+    The expectation is tests/golden/api_surface.json, read from the reference sources by oracle/gen_api_surface.py."""
+    import inspect
+    import json
+    import qwen3_tts_amd as pkg
+    with open(os.path.join(golden_dir, "api_surface.json")) as f:
+        ref = json.load(f)["classes"]
+    assert set(ref) == {"Qwen3TTSModel", "Qwen3TTSTokenizer", "VoiceClonePromptItem"}
+    problems = []
+    for cname, body in ref.items():
+        cls = getattr(pkg, cname)
+        have_fields = list(getattr(cls, "__dataclass_fields__", {}))
+        if have_fields[:len(body["fields"])] != body["fields"]:
+            problems.append(f"{cname}: fields {have_fields} != {body['fields']}")
+        for mname, m in body["methods"].items():
+            raw = inspect.getattr_static(cls, mname, None)
+            if raw is None:
+                problems.append(f"{cname}.{mname}: missing")
+                continue
+            kind = "classmethod" if isinstance(raw, classmethod) else "staticmethod" if isinstance(raw, staticmethod) \
+                else "property" if isinstance(raw, property) else "method"
+            if kind != m["kind"]:
+                problems.append(f"{cname}.{mname}: kind {kind} != {m['kind']}")
+                continue
+            fn = raw.__func__ if kind in ("classmethod", "staticmethod") else raw.fget if kind == "property" else raw
+            fn = inspect.unwrap(fn)                   # through @torch.no_grad() etc.
+            got = []
+            for p in inspect.signature(fn).parameters.values():
+                name = ("*" if p.kind is p.VAR_POSITIONAL else "**" if p.kind is p.VAR_KEYWORD else "") + p.name
+                got.append([name, None if p.default is p.empty else repr(p.default)])
+            if got != m["params"]:
+                problems.append(f"{cname}.{mname}: {got} != {m['params']}")
+    assert not problems, "\n".join(problems)
+
+
+def test_qwen_tts_alias_exports_the_mirrored_classes():
+    """`from qwen_tts import Qwen3TTSModel, Qwen3TTSTokenizer` (the reference examples' import line) resolves to the
+    MI355X classes when the repository root is on the path."""
+    code = ("import sys; sys.path.insert(0, %r); import qwen_tts, qwen3_tts_amd as a; "
+            "assert qwen_tts.Qwen3TTSModel is a.Qwen3TTSModel and qwen_tts.Qwen3TTSTokenizer is a.Qwen3TTSTokenizer "
+            "and qwen_tts.VoiceClonePromptItem is a.VoiceClonePromptItem; print('ok')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_no_kernel_spills_or_scratch(libqtts):
+    """Static check the host emulator cannot make: no gfx950 kernel of libqtts.so spills registers, uses scratch
+    memory or declares more static LDS than a CU has (tools/kernel_resources.py reads the code objects' metadata)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--so", libqtts, "--check"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert re.search(r"^(\d+) kernels; 0 with spills", out.stdout, re.M), out.stdout[-500:]
+    assert int(re.search(r"^(\d+) kernels;", out.stdout, re.M).group(1)) >= 60
