@@ -21,8 +21,14 @@ CSRC = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
 #   LD_PRELOAD=$(python tests/hostemu/build.py --asan-runtime) ASAN_OPTIONS=detect_leaks=0 QTTS_HOSTEMU_ASAN=1 \
 #       python -m pytest tests/test_hostemu.py
 ASAN = os.environ.get("QTTS_HOSTEMU_ASAN") == "1"
-OUT = os.path.join(HERE, "libqtts_hostemu_asan.so" if ASAN else "libqtts_hostemu.so")
-GEN = os.path.join(HERE, "gen_asan" if ASAN else "gen")
+# QTTS_HOSTEMU_UBSAN=1: an UndefinedBehaviorSanitizer build (libqtts_hostemu_ubsan.so), trapping on the first finding:
+# misaligned vector accesses (float4 / uint4 / uint2 are alignas(16 / 8) in the stand-in hip_runtime.h, as the hardware's
+# ds_read_b128 / dwordx4 paths want them), signed overflow in index arithmetic, out-of-range shifts, division by zero,
+# out-of-bounds indexing of fixed-size arrays.  No runtime library needed (-fsanitize-trap): a finding is a SIGILL.
+UBSAN = os.environ.get("QTTS_HOSTEMU_UBSAN") == "1" and not ASAN
+_TAG = "_asan" if ASAN else "_ubsan" if UBSAN else ""
+OUT = os.path.join(HERE, f"libqtts_hostemu{_TAG}.so")
+GEN = os.path.join(HERE, "gen" + _TAG)
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
 SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "sampling.hip",
                 "elementwise.hip", "skinny.hip", "gemm_tap.hip"]
@@ -62,6 +68,9 @@ def build(verbose=False):
     cc = _compiler()
     base = [cc, "-std=c++17", "-O2", "-fPIC", "-DQTTS_HOST_EMU", "-I", HERE, "-I", CSRC, "-Wno-unused-function", "-Wno-unused-value"]
     san = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g"] if ASAN else []
+    if UBSAN:
+        checks = "alignment,signed-integer-overflow,shift,integer-divide-by-zero,bounds,null"
+        san = [f"-fsanitize={checks}", f"-fsanitize-trap={checks}", "-fno-omit-frame-pointer", "-g"]
     base += san
     objs = []
     for f in ENGINES + SIMT_KERNELS:
