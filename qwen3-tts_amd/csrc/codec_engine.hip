@@ -498,6 +498,9 @@ void qtts_codec::stream_begin(int B) {
         carry[i].d.ensure(std::max<size_t>(bytes, 16));
         QTTS_CHECK_HIP(hipMemset(carry[i].d.p, 0, std::max<size_t>(bytes, 16)));   // zeros == the causal left padding
     }
+    // hipMemset runs on the null stream and may return before it has executed; stream_push() launches on the caller's
+    // stream, which does not order against the null stream when it is a non-blocking one (PyTorch's pool streams are).
+    QTTS_CHECK_HIP(hipDeviceSynchronize());
     stream_npad.ensure((size_t)B * sizeof(int));
     stream_npad_host.assign(B, 0);
     stream_B = B;

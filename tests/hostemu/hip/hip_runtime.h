@@ -59,6 +59,7 @@ inline hipError_t hipMemset(void* d, int v, size_t n) {
     return 0;
 }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return simt::capture().open ? 900 : 0; }
+inline hipError_t hipDeviceSynchronize() { return simt::capture().open ? 900 : 0; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 
