@@ -1,8 +1,13 @@
 """Build libqtts.so (the C-ABI HIP library) in-tree for gfx950.
 
-    python qwen3-tts_amd/build.py [--force]
+    python qwen3-tts_amd/build.py [--force] [--variant NAME | --all-variants]
 
 hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box with the tree.
+
+Variants (A/B material, never the default): the same sources with extra -D flags, built into `libqtts_<name>.so`
+next to the product library and selected at run time with `QTTS_LIBRARY=<path>` (see tools/ab_variants.py).  The
+product library is always the flag-free build; a variant becomes the default only by moving its code under the
+default branch of the source after it has been measured on hardware.
 """
 import hashlib
 import os
@@ -20,18 +25,35 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
 
-def _digest(paths):
+# name -> extra compiler flags; what each one tests is written next to the macro in the source.
+VARIANTS = {
+    "wtemporal": ["-DQTTS_SKINNY_WLOAD=1"],        # skinny.hip: plain (temporal) loads for every weight tile
+}
+
+
+def _digest(paths, extra=()):
     h = hashlib.sha256()
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + list(extra)).encode())
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def variant_path(variant: str) -> str:
+    return os.path.join(HERE, f"libqtts_{variant}.so")
+
+
+def build(force: bool = False, verbose: bool = True, variant: str = None) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    extra = []
+    out = OUT
+    if variant is not None:
+        if variant not in VARIANTS:
+            raise ValueError(f"unknown variant {variant!r}; known: {sorted(VARIANTS)}")
+        extra = VARIANTS[variant]
+        out = variant_path(variant)
+    objdir = os.path.join(HERE, "build" if variant is None else f"build_{variant}")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -40,11 +62,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         stamp = obj + ".sha"
-        dig = _digest([src] + hdrs)
+        dig = _digest([src] + hdrs, extra)
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
             continue
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), stamp, dig, s))
@@ -57,13 +79,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 f.write(dig)
     if failed:
         raise RuntimeError(f"hipcc failed for: {failed}")
-    if procs or not os.path.exists(OUT) or force:
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if procs or not os.path.exists(out) or force:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    force = "--force" in sys.argv
+    if "--all-variants" in sys.argv:
+        for v in sorted(VARIANTS):
+            print(build(force=force, variant=v))
+    elif "--variant" in sys.argv:
+        print(build(force=force, variant=sys.argv[sys.argv.index("--variant") + 1]))
+    else:
+        print(build(force=force))

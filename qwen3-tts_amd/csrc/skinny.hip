@@ -33,6 +33,23 @@ __device__ inline unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 
     return *reinterpret_cast<unsigned*>(&v);
 }
 
+// Weight-tile load flavour.  Default (the measured one): non-temporal -- every byte is used once per launch.
+// A/B variant (build.py VARIANTS, never the default build): QTTS_SKINNY_WLOAD=1 plain loads -- hypothesis: the code
+// predictor's 157 MB of layer weights are re-read by all 15 passes of a frame and fit the 256 MB Infinity Cache, which
+// streaming-hinted loads may decline to allocate in.  (A per-GEMM runtime choice between the two flavours does not
+// survive the compiler: it merges `cond ? *p : nontemporal(*p)` into one plain load.)
+#ifndef QTTS_SKINNY_WLOAD
+#define QTTS_SKINNY_WLOAD 0
+#endif
+template <class T>
+__device__ inline T skinny_wload(const T* ptr) {
+#if QTTS_SKINNY_WLOAD == 1
+    return *ptr;
+#else
+    return __builtin_nontemporal_load(ptr);
+#endif
+}
+
 // FS = output features per strip (16 | 8 | 4).  Narrow strips put GEMMs with few output features on all 256 CUs
 // (a CU pulls only ~24 GB/s); lanes with (lane & 15) >= FS carry no weights and their MFMA rows are ignored.
 template <bool BF16, int MT, int SPW, int NW, bool STAGE, int FS>
@@ -77,7 +94,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
             const int kt = wave + NW * i;
 #pragma unroll
             for (int s = 0; s < SPW; ++s)
-                w[s][u] = (i < my_tiles && lj < FS && !(p.ablate & 8)) ? __builtin_nontemporal_load(wbase[s] + (size_t)kt * (FS * 4))
+                w[s][u] = (i < my_tiles && lj < FS && !(p.ablate & 8)) ? skinny_wload(wbase[s] + (size_t)kt * (FS * 4))
                                                             : (u32x4){0u, 0u, 0u, 0u};
         }
     };
