@@ -28,6 +28,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # name -> extra compiler flags; what each one tests is written next to the macro in the source.
 VARIANTS = {
     "wtemporal": ["-DQTTS_SKINNY_WLOAD=1"],        # skinny.hip: plain (temporal) loads for every weight tile
+    # attention.hip: KV beyond the 256-key prefetch window read 4 chunks per latency round instead of 1.  Only long
+    # sequences see it: A/B with `tools/ab_variants.py --frames 600 --only default attn_tail` (S grows to ~650).
+    "attn_tail": ["-DQTTS_ATTN_TAIL_BATCH=1"],
 }
 
 

@@ -193,6 +193,9 @@ void launch_qknorm_rope_store(const QkNormRopeParams& p, hipStream_t st) {
 // The per-key inner loops are branch-free over the 4 keys of a chunk (independent dot products interleave), use DPP
 // row reductions, and handle the 1-2 NEW keys in a separate tiny pass; the 16 key groups combine through LDS.
 // LDS: qs[NQ][128] | kn[n_new][128] | vn[n_new][128] | red[16][NQ][128] | sc[NQ][max_len] | stat[NQ]
+#ifndef QTTS_ATTN_TAIL_BATCH
+#define QTTS_ATTN_TAIL_BATCH 0
+#endif
 template <typename KVT, int NQ>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     constexpr int HD = 128;
@@ -352,11 +355,24 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
     for (int c = 0; c < NPRE; ++c)
         if (c < nchunk) score_chunk(kR[c], c);
+#if QTTS_ATTN_TAIL_BATCH
+    // A/B variant (build.py VARIANTS): beyond the prefetch window the K registers are free again, so the tail is read
+    // NPRE chunks (256 keys bf16) per latency round instead of one -- what a > 20 s utterance runs every layer.
+    for (int c0 = NPRE; c0 < nchunk; c0 += NPRE) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (c0 + j < nchunk) load_chunk(kR[j], kc, c0 + j);
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (c0 + j < nchunk) score_chunk(kR[j], c0 + j);
+    }
+#else
     for (int c = NPRE; c < nchunk; ++c) {       // very long sequences: plain loop
         u32x4 kB[CH][KW];
         load_chunk(kB, kc, c);
         score_chunk(kB, c);
     }
+#endif
     for (int t = 0; t < p.n_new; ++t) {         // the fresh keys: key S0+t belongs to group (S0+t) % 16
         const int s = S0 + t;
         if (g == (s & 15)) {
@@ -411,11 +427,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 #pragma unroll
     for (int c = 0; c < NPRE; ++c)
         if (c < nchunk) pv_chunk(vR[c], c);
+#if QTTS_ATTN_TAIL_BATCH
+    for (int c0 = NPRE; c0 < nchunk; c0 += NPRE) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (c0 + j < nchunk) load_chunk(vR[j], vc, c0 + j);
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (c0 + j < nchunk) pv_chunk(vR[j], c0 + j);
+    }
+#else
     for (int c = NPRE; c < nchunk; ++c) {
         u32x4 vB[CH][KW];
         load_chunk(vB, vc, c);
         pv_chunk(vB, c);
     }
+#endif
     for (int t = 0; t < p.n_new; ++t) {
         const int s = S0 + t;
         if (g == (s & 15) && s >= npad) {

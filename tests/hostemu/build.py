@@ -26,7 +26,10 @@ ASAN = os.environ.get("QTTS_HOSTEMU_ASAN") == "1"
 # ds_read_b128 / dwordx4 paths want them), signed overflow in index arithmetic, out-of-range shifts, division by zero,
 # out-of-bounds indexing of fixed-size arrays.  No runtime library needed (-fsanitize-trap): a finding is a SIGILL.
 UBSAN = os.environ.get("QTTS_HOSTEMU_UBSAN") == "1" and not ASAN
-_TAG = "_asan" if ASAN else "_ubsan" if UBSAN else ""
+# QTTS_HOSTEMU_DEFS="-DQTTS_ATTN_TAIL_BATCH=1 ...": the same emulated library with a build variant's flags
+# (qwen3-tts_amd/build.py VARIANTS), so that a variant is checked against the oracle before it ever meets hardware.
+DEFS = os.environ.get("QTTS_HOSTEMU_DEFS", "").split()
+_TAG = ("_asan" if ASAN else "_ubsan" if UBSAN else "") + ("_v" + hashlib.sha256(" ".join(DEFS).encode()).hexdigest()[:8] if DEFS else "")
 OUT = os.path.join(HERE, f"libqtts_hostemu{_TAG}.so")
 GEN = os.path.join(HERE, "gen" + _TAG)
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
@@ -71,7 +74,7 @@ def build(verbose=False):
     if UBSAN:
         checks = "alignment,signed-integer-overflow,shift,integer-divide-by-zero,bounds,null"
         san = [f"-fsanitize={checks}", f"-fsanitize-trap={checks}", "-fno-omit-frame-pointer", "-g"]
-    base += san
+    base += san + DEFS
     objs = []
     for f in ENGINES + SIMT_KERNELS:
         dst = os.path.join(GEN, f.replace(".hip", ".cpp"))

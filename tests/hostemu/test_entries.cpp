@@ -63,3 +63,21 @@ extern "C" int hostemu_sample(const float* logits, int ld, int V, int B, const i
         return 0;
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
+
+// One launch of attention.hip's attn_decode_kernel: q/k RMSNorm + RoPE + KV append + GQA attention for n_new tokens per
+// sequence on a paged cache of S0 keys (layer 0; contiguous page layout unless a page table is given).
+extern "C" int hostemu_attn_decode(const float* qkv, int ld, int B, int n_new, int nh, int nkv, const float* qw, const float* kw,
+                                   float eps, const float* inv_freq, const int* n_pad, int S0, void* kpool, void* vpool,
+                                   const int* page_table, int pages_per_seq, int bf16, float* out, int ldo, int max_len) {
+    try {
+        qtts::AttnDecodeParams p{};
+        p.qkv = qkv; p.ld = ld; p.B = B; p.n_new = n_new; p.nh = nh; p.nkv = nkv; p.hd = 128;
+        p.qw = qw; p.kw = kw; p.eps = eps; p.inv_freq = inv_freq; p.n_pad = n_pad;
+        p.len_dev = &S0; p.len_static = S0;
+        p.kv.k = kpool; p.kv.v = vpool; p.kv.page_table = page_table; p.kv.pages_per_seq = pages_per_seq;
+        p.kv.n_pages = B * pages_per_seq; p.kv.nkv = nkv; p.kv.hd = 128; p.kv.bf16 = bf16; p.kv.contig = page_table ? 0 : 1;
+        p.layer = 0; p.out = out; p.ldo = ldo; p.out_bf16 = 0; p.max_len = max_len; p.done_flag = nullptr;
+        qtts::launch_attn_decode(p, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}

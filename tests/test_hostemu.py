@@ -57,6 +57,8 @@ def emu():
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_sample.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_float, i32, i32, vp, i32, i32, C.c_float, C.c_float,
                                    C.c_uint64, C.c_uint32, i32, vp]
+    lib.hostemu_attn_decode.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, C.c_float, vp, vp, i32, vp, vp, vp, i32, i32, vp,
+                                        i32, i32]
     return lib
 
 
@@ -190,6 +192,97 @@ def test_skinny_kernel_real_source(emu, bf16):
         tol = (4e-3 if bf16 else 2e-5) * max(1.0, float(np.abs(acc).max()))
         assert np.abs(out[:, :No] - acc).max() <= tol, (M, N, K, norm, act, float(np.abs(out[:, :No] - acc).max()))
         assert np.all(out[:, No:] == 7.0)
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
+    """attention.hip's decode kernel from its real source against float64 numpy: q/k RMSNorm + rotate-half RoPE at position
+    S0 + t - n_pad, K/V append through the cache type, left-pad and causal masks, GQA 2:1, for cache lengths on both sides of
+    the register-prefetch window (<= 256 keys bf16 / 128 fp32) -- the multi-round tail loop is what a long utterance runs --
+    with one and two new tokens, a permuted page table, and bit-identical results across wave scheduling orders."""
+    g = np.random.default_rng(77 + bf16)
+    HD, nh, nkv, eps = 128, 4, 2, 1e-6
+    inv_freq = (1.0 / (10000.0 ** (np.arange(64) / 64.0))).astype(np.float32)
+    qw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+    kw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+
+    def rnd(a):
+        return _bf16_round(a)[0] if bf16 else a
+
+    def normrope(x, w, pos):
+        x = x.astype(np.float64)
+        x = w * (x / np.sqrt((x ** 2).mean() + eps))
+        ang = np.float32(pos) * inv_freq                     # fp32 angle like the kernel, then exact cos / sin
+        c, s = np.cos(ang.astype(np.float64)), np.sin(ang.astype(np.float64))
+        return np.concatenate([x[:64] * c - x[64:] * s, x[64:] * c + x[:64] * s])
+
+    for (B, n_new, S0, npads, permute) in [(2, 1, 37, [0, 5], False), (3, 2, 130, [0, 17, 64], False), (2, 1, 300, [3, 0], True),
+                                           (2, 2, 701, [0, 40], False), (1, 1, 1030, [9], True)]:
+        pps = (S0 + n_new + 15) // 16 + 1
+        n_pages = B * pps
+        table = np.arange(n_pages, dtype=np.int32).reshape(B, pps)
+        if permute:
+            table = g.permutation(n_pages).astype(np.int32).reshape(B, pps)
+        ld = (nh + 2 * nkv) * HD
+        qkv = g.standard_normal((n_new * B, ld)).astype(np.float32)
+        K = rnd((g.standard_normal((B, nkv, S0, HD)) * 0.7).astype(np.float32))
+        V = rnd(g.standard_normal((B, nkv, S0, HD)).astype(np.float32))
+        kp = np.full((n_pages, nkv, 16, HD), np.nan, np.float32)      # never-written slots must never be read into the result
+        vp_ = np.full((n_pages, nkv, 16, HD), np.nan, np.float32)
+        npad = np.asarray(npads, np.int32)
+        for b in range(B):
+            for s in range(npad[b], S0):                                # left-pad slots stay unwritten (as after a real prefill)
+                kp[table[b, s // 16], :, s % 16] = K[b, :, s]
+                vp_[table[b, s // 16], :, s % 16] = V[b, :, s]
+        if bf16:
+            kpool, vpool = _bf16_round(np.nan_to_num(kp, nan=0.0))[1].copy(), _bf16_round(np.nan_to_num(vp_, nan=0.0))[1].copy()
+            nanmask = np.isnan(kp)
+            kpool[nanmask] = 0x7FC0; vpool[nanmask] = 0x7FC0            # bf16 NaN
+        else:
+            kpool, vpool = kp.copy(), vp_.copy()
+        # ---- float64 reference
+        ref = np.zeros((n_new * B, nh * HD))
+        newk = np.zeros((B, nkv, n_new, HD)); newv = np.zeros((B, nkv, n_new, HD))
+        for b in range(B):
+            for h in range(nkv):
+                for t in range(n_new):
+                    row = qkv[t * B + b]
+                    newk[b, h, t] = rnd(normrope(row[(nh + h) * HD:(nh + h + 1) * HD], kw, S0 + t - npad[b]).astype(np.float32))
+                    newv[b, h, t] = rnd(row[(nh + nkv + h) * HD:(nh + nkv + h + 1) * HD])
+                keys = np.concatenate([K[b, h].astype(np.float64), newk[b, h]], 0)
+                vals = np.concatenate([V[b, h].astype(np.float64), newv[b, h]], 0)
+                for t in range(n_new):
+                    for gq in range(nh // nkv):
+                        hq = h * (nh // nkv) + gq
+                        q = normrope(qkv[t * B + b][hq * HD:(hq + 1) * HD], qw, S0 + t - npad[b])
+                        sc = keys @ q / np.sqrt(HD)
+                        sidx = np.arange(S0 + n_new)
+                        sc[(sidx < npad[b]) | (sidx > S0 + t)] = -np.inf
+                        pr = np.exp(sc - sc.max()); pr /= pr.sum()
+                        ref[t * B + b, hq * HD:(hq + 1) * HD] = pr @ np.where(np.isfinite(sc)[:, None], vals, 0.0)
+        outs = []
+        for order in (0, 1, 2):
+            kk, vv = kpool.copy(), vpool.copy()
+            out = np.full((n_new * B, nh * HD + 4), 5.0, np.float32)
+            emu.hostemu_set_fiber_order(order)
+            try:
+                rc = emu.hostemu_attn_decode(_ptr(qkv), ld, B, n_new, nh, nkv, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), _ptr(npad), S0,
+                                             _ptr(kk), _ptr(vv), _ptr(table) if permute else None, pps, bf16, _ptr(out),
+                                             nh * HD + 4, S0 + n_new + 3)
+            finally:
+                emu.hostemu_set_fiber_order(0)
+            assert rc == 0, ((B, n_new, S0), (emu.qtts_last_error() or b"").decode())
+            outs.append(out)
+            err = float(np.abs(out[:, :nh * HD] - ref).max())
+            assert err <= 3e-5 * max(1.0, float(np.abs(ref).max())), (B, n_new, S0, bf16, order, err)
+            assert np.all(out[:, nh * HD:] == 5.0)
+            for b in range(B):                                          # the new K / V rows landed in the cache, rounded once
+                for t in range(n_new):
+                    s = S0 + t
+                    gotk = kk[table[b, s // 16], :, s % 16]
+                    gotk = (gotk.astype(np.uint32) << 16).view(np.float32) if bf16 else gotk
+                    assert np.abs(gotk - newk[b, :, t]).max() <= (2e-2 if bf16 else 1e-5), (b, t)
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 def _ok(lib, rc):
