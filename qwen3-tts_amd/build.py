@@ -31,6 +31,8 @@ VARIANTS = {
     # attention.hip: KV beyond the 256-key prefetch window read 4 chunks per latency round instead of 1.  Only long
     # sequences see it: A/B with `tools/ab_variants.py --frames 600 --only default attn_tail` (S grows to ~650).
     "attn_tail": ["-DQTTS_ATTN_TAIL_BATCH=1"],
+    # sampling.hip: sample_kernel_v2 for 0 < top_k <= 64 (hoisted loads, processors in registers, 64-key bound).
+    "sampler_v2": ["-DQTTS_SAMPLER_V2=1"],
 }
 
 

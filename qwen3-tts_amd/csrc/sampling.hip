@@ -308,10 +308,297 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
 }
 
+#ifndef QTTS_SAMPLER_V2
+#define QTTS_SAMPLER_V2 0
+#endif
+#if QTTS_SAMPLER_V2
+// A/B variant (build.py VARIANTS, never the default build): the sampling path for 0 < top_k <= 64 and V <= 4096 (the
+// reference default is top_k = 50 on 2048 / 3072 logits) with the fixed costs taken out of sample_kernel above:
+//   * every load that does not depend on another load (done flag, counters, Philox key, the row's logits, the suppress
+//     mask) is issued at kernel entry instead of behind the early-exit test and the processors' barriers;
+//   * the processors run on the thread's own V / 256 logits in registers (one barrier instead of four; the repetition
+//     penalty, which is a scatter, goes through presence flags in LDS -- talker call only);
+//   * the candidate bound is the k-th largest of 64 quad maxima (each wave ranks the 64 keys itself: 16 LDS reads and no
+//     second barrier) instead of an all-pairs rank over 256 thread maxima.  The bound is looser (about 1.7x the
+//     candidates) but the exact ranking below it is unchanged.
+// The surviving candidates keep the slot order of sample_kernel (wave, slice, lane), so for the same Philox draw the same
+// token comes out (up to rounding in the inverse-CDF scan); the greedy / parity path never comes here.
+template <int EPT>
+__global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
+    __shared__ float sc[EPT * 256];
+    __shared__ float fred[4];
+    __shared__ int ired[8];
+    __shared__ __attribute__((aligned(16))) float scan[256];
+    __shared__ float cval[CAND_MAX];
+    __shared__ int cidx[CAND_MAX];
+    __shared__ __attribute__((aligned(16))) uint32_t ckey[CAND_MAX + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t gkey[64];
+    __shared__ int pick_lo, pick_hi;
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = p.V;
+    const float* lg = p.logits + (size_t)b * p.ld;
+    // ---- 0. independent loads, all in flight together
+    const int done = p.done_in ? *p.done_in : 0;
+    const int n_gen = p.n_generated_dev ? *p.n_generated_dev : 0;
+    const uint32_t step = p.step_dev ? (uint32_t)*p.step_dev : 0u;
+    const unsigned long long seed = p.seed_dev ? *p.seed_dev : p.seed;
+    float x[EPT];
+    unsigned char sup[EPT];
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+        const int v = it * 256 + tid;
+        x[it] = v < V ? lg[v] : -INFINITY;
+        sup[it] = (p.suppress_mask && v < V) ? p.suppress_mask[v] : (unsigned char)0;
+    }
+    if (done) return;
+    // ---- 1. HF processors, in HF's order, on this thread's own logits
+    if (p.generated && p.repetition_penalty != 1.0f) {       // scatter -> presence flags in LDS (idempotent for duplicates)
+#pragma unroll
+        for (int it = 0; it < EPT; ++it) sc[it * 256 + tid] = 0.f;
+        __syncthreads();
+        for (int i = tid; i < n_gen; i += 256) {
+            const int tok = p.generated[(size_t)b * p.gen_stride + i];
+            if (tok >= 0 && tok < V) sc[tok] = 1.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < EPT; ++it)
+            if (sc[it * 256 + tid] != 0.f) x[it] = x[it] < 0.f ? x[it] * p.repetition_penalty : x[it] / p.repetition_penalty;
+        __syncthreads();                                     // flags consumed before the scores overwrite them
+    }
+    const bool block_eos = p.eos >= 0 && n_gen < p.min_new_tokens;
+    float tm = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+        const int v = it * 256 + tid;
+        if ((block_eos && v == p.eos) || sup[it]) x[it] = -INFINITY;
+        if (p.temperature != 1.0f) x[it] = x[it] / p.temperature;
+        sc[v] = x[it];                                       // for the general fallback paths only
+        if (v < V) tm = fmaxf(tm, x[it]);
+    }
+    uint32_t rnd[4];
+    philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+    const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+    // ---- 2. candidate bound: k-th largest of the 64 quad maxima (<= the k-th largest score), ranked by every wave itself
+    tm = fmaxf(tm, __shfl_xor(tm, 1));
+    tm = fmaxf(tm, __shfl_xor(tm, 2));
+    if ((lane & 3) == 0) gkey[wave * 16 + (lane >> 2)] = float_key(tm);
+    __syncthreads();
+    uint32_t T0;
+    {
+        const uint32_t mk = gkey[lane];
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j += 4) {
+            const uint4 k4 = *reinterpret_cast<const uint4*>(&gkey[j]);
+            rank += (k4.x > mk) || (k4.x == mk && j < lane);
+            rank += (k4.y > mk) || (k4.y == mk && j + 1 < lane);
+            rank += (k4.z > mk) || (k4.z == mk && j + 2 < lane);
+            rank += (k4.w > mk) || (k4.w == mk && j + 3 < lane);
+        }
+        const unsigned long long hit = __ballot(rank == p.top_k - 1);      // exactly one lane: ranks are a permutation
+        T0 = (uint32_t)__shfl((int)mk, __ffsll((long long)hit) - 1);
+    }
+    // ---- 3. compaction in sample_kernel's slot order (wave, slice, lane)
+    unsigned long long mb[EPT];
+    int mycnt = 0;
+#pragma unroll
+    for (int it = 0; it < EPT; ++it) {
+        const int v = it * 256 + tid;
+        mb[it] = __ballot(v < V && float_key(x[it]) >= T0);
+        mycnt += __popcll(mb[it]);
+    }
+    if (lane == 0) ired[wave] = mycnt;
+    __syncthreads();
+    const int n_c = ired[0] + ired[1] + ired[2] + ired[3];
+    int token = 0;
+    bool sampled = false;
+    if (n_c <= CAND_MAX) {
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += ired[w];
+#pragma unroll
+        for (int it = 0; it < EPT; ++it) {
+            if ((mb[it] >> lane) & 1ull) {
+                const int slot = base + __popcll(mb[it] & ((1ull << lane) - 1ull));
+                cval[slot] = x[it];
+                cidx[slot] = it * 256 + tid;
+                ckey[slot] = float_key(x[it]);
+            }
+            base += __popcll(mb[it]);
+        }
+        for (int i = n_c + tid; i < ((n_c + 3) & ~3); i += 256) ckey[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n_c; i += 256) {        // exact rank among the candidates (value desc, slot asc)
+            const uint32_t mk = ckey[i];
+            int rank = 0;
+            for (int j = 0; j < n_c; j += 4) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(&ckey[j]);
+                rank += (k4.x > mk) || (k4.x == mk && j < i);
+                rank += (k4.y > mk) || (k4.y == mk && j + 1 < i);
+                rank += (k4.z > mk) || (k4.z == mk && j + 2 < i);
+                rank += (k4.w > mk) || (k4.w == mk && j + 3 < i);
+            }
+            if (rank == p.top_k - 1) pick_lo = (int)mk;  // key of the k-th largest score
+        }
+        __syncthreads();
+        const uint32_t thr = (uint32_t)pick_lo;          // HF TopK keeps every score >= it (ties included)
+        __syncthreads();
+        if (wave == 0) {       // softmax over the survivors + inverse-CDF draw, one wave (as in sample_kernel)
+            float mx = -INFINITY;
+            for (int i = lane; i < n_c; i += 64) mx = fmaxf(mx, cval[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float tot = 0.f;
+            for (int i = lane; i < n_c; i += 64) {
+                const float e = ckey[i] >= thr ? expf(cval[i] - mx) : 0.f;
+                cval[i] = e;
+                tot += e;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+            if (p.top_p < 1.0f) {
+                float keep_e[CAND_MAX / 64];
+                float tot2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < CAND_MAX / 64; ++q) {
+                    const int i = q * 64 + lane;
+                    keep_e[q] = 0.f;
+                    if (i < n_c && cval[i] > 0.f) {
+                        const uint32_t mk = ckey[i];
+                        float above = 0.f;
+                        for (int j = 0; j < n_c; ++j) {
+                            const uint32_t kj = ckey[j];
+                            if (kj > mk || (kj == mk && j < i)) above += cval[j];
+                        }
+                        if (above < p.top_p * tot) keep_e[q] = cval[i];
+                    }
+                    tot2 += keep_e[q];
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) tot2 += __shfl_xor(tot2, o);
+#pragma unroll
+                for (int q = 0; q < CAND_MAX / 64; ++q) {
+                    const int i = q * 64 + lane;
+                    if (i < n_c) cval[i] = keep_e[q];
+                }
+                tot = tot2;
+            }
+            const float target = u * tot;
+            float run = 0.f;
+            int pick = -1, last = 0;
+            for (int i0 = 0; i0 < n_c && pick < 0; i0 += 64) {
+                const int i = i0 + lane;
+                const float e = i < n_c ? cval[i] : 0.f;
+                float inc = e;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+                const unsigned long long nz = __ballot(e > 0.f);
+                if (nz) last = i0 + 63 - __clzll((long long)nz);
+                const unsigned long long hit = __ballot(e > 0.f && run + inc > target);
+                if (hit) pick = i0 + __ffsll((long long)hit) - 1;
+                run += __shfl(inc, 63);
+            }
+            if (pick < 0) pick = last;
+            if (lane == 0) pick_lo = cidx[pick];
+        }
+        __syncthreads();
+        token = pick_lo;
+        sampled = true;
+    }
+    if (!sampled) {
+        // ---- more than CAND_MAX scores at or above the bound (massive ties): the general paths of sample_kernel on `sc`
+        uint32_t prefix = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = prefix | (1u << bit);
+            int cnt = 0;
+            for (int v = tid; v < V; v += 256) cnt += __popcll(__ballot(float_key(sc[v]) >= cand));
+            if (lane == 0) ired[(bit & 1) * 4 + wave] = cnt;
+            __syncthreads();
+            const int* r4 = ired + (bit & 1) * 4;
+            if (r4[0] + r4[1] + r4[2] + r4[3] >= p.top_k) prefix = cand;
+        }
+        __syncthreads();
+        for (int v = tid; v < V; v += 256)
+            if (float_key(sc[v]) < prefix) sc[v] = -INFINITY;
+        __syncthreads();
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += 256) m = fmaxf(m, sc[v]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) fred[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+        __syncthreads();
+        const int chunk = (V + 255) / 256;
+        const int v0 = tid * chunk, v1 = min(V, v0 + chunk);
+        float mine = 0.f;
+        for (int v = v0; v < v1; ++v) {
+            const float e = expf(sc[v] - m);
+            sc[v] = e;
+            mine += e;
+        }
+        scan[tid] = mine;
+        if (tid == 0) { pick_lo = 0x7fffffff; pick_hi = -1; }
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const float add = tid >= o ? scan[tid - o] : 0.f;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        const float total = scan[255];
+        const float target = u * total;
+        float run = scan[tid] - mine;
+        for (int v = v0; v < v1; ++v) {
+            const float e = sc[v];
+            if (e > 0.f) {
+                atomicMax(&pick_hi, v);
+                if (run + e > target) { atomicMin(&pick_lo, v); break; }
+            }
+            run += e;
+        }
+        __syncthreads();
+        token = pick_lo != 0x7fffffff ? pick_lo : pick_hi;
+    }
+
+    if (token < 0 || token >= V) token = 0;
+    if (p.gather_emb) {
+        const float* src = p.gather_emb + (size_t)token * p.gather_C;
+        for (int c = tid * 4; c < p.gather_C; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v;
+            if (p.gather_out16) {
+                ushort4 h; h.x = f32_to_bf16(v.x); h.y = f32_to_bf16(v.y); h.z = f32_to_bf16(v.z); h.w = f32_to_bf16(v.w);
+                *reinterpret_cast<ushort4*>(p.gather_out16 + (size_t)b * p.gather_C + c) = h;
+            }
+        }
+    }
+    if (tid == 0) {
+        if (p.unfinished) {
+            const int uf = p.unfinished[b];
+            if (!uf) token = p.eos;
+            p.unfinished[b] = uf && (token != p.eos);
+            if (p.generated_out) p.generated_out[(size_t)b * p.gen_stride + n_gen] = token;
+        }
+        p.tok_out[(size_t)b * p.tok_stride] = token;
+    }
+}
+#endif  // QTTS_SAMPLER_V2
+
 void launch_sample(const SampleParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.V <= SAMPLE_MAX_V, QTTS_ERR_LIMIT, "sample: vocab too large");
     QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f) || (p.top_k > 0 && p.top_k <= 256), QTTS_ERR_ARG,
                  "sample: top_p < 1 on device needs 0 < top_k <= 256 (the reference default is top_k = 50)");
+#if QTTS_SAMPLER_V2
+    if (p.do_sample && p.top_k > 0 && p.top_k <= 64 && p.top_k < p.V && p.V <= 4096) {
+        if (p.V <= 2048) hipLaunchKernelGGL(sample_kernel_v2<8>, dim3(p.B), dim3(256), 0, st, p);
+        else if (p.V <= 3072) hipLaunchKernelGGL(sample_kernel_v2<12>, dim3(p.B), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(sample_kernel_v2<16>, dim3(p.B), dim3(256), 0, st, p);
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
+#endif
     hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, st, p);
     QTTS_CHECK_HIP(hipGetLastError());
 }

@@ -810,3 +810,29 @@ def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
                 emu.qtts_talker_destroy(h)
     finally:
         emu.hostemu_set_fiber_order(0)
+
+
+@pytest.mark.skipif(os.environ.get("QTTS_TEST_VARIANTS") != "1",
+                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: two extra emulator builds, ~4 min "
+                           "-- enable with QTTS_TEST_VARIANTS=1")
+def test_build_variants_agree_with_default_on_emulator(tmp_path):
+    """Every kernel-changing build variant, compiled into the emulated library with its -D flag (QTTS_HOSTEMU_DEFS), against
+    the default build: sampler_v2 draws the same tokens for the same Philox keys; attn_tail passes the decode-attention
+    kernel test (long sequences included) and the talker golden."""
+    import subprocess
+    probe = os.path.join(HERE, "hostemu", "variant_probe.py")
+    outs = []
+    for i, defs in enumerate(("", "-DQTTS_SAMPLER_V2=1")):
+        env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs)
+        out = str(tmp_path / f"tok{i}.npy")
+        r = subprocess.run([sys.executable, probe, out], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert outs[0].shape == outs[1].shape and outs[0].size >= 900
+    assert np.array_equal(outs[0], outs[1]), float((outs[0] != outs[1]).mean())
+    for defs, sel in (("-DQTTS_SAMPLER_V2=1", "sampler"), ("-DQTTS_ATTN_TAIL_BATCH=1", "attn_decode or talker_orchestration_greedy")):
+        env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs)
+        env.pop("QTTS_TEST_VARIANTS", None)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel], env=env,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (defs, r.stdout[-2000:])
