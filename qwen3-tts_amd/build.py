@@ -33,6 +33,9 @@ VARIANTS = {
     "attn_tail": ["-DQTTS_ATTN_TAIL_BATCH=1"],
     # sampling.hip: sample_kernel_v2 for 0 < top_k <= 64 (hoisted loads, processors in registers, 64-key bound).
     "sampler_v2": ["-DQTTS_SAMPLER_V2=1"],
+    # skinny.hip + talker_engine.hip: gate/up packed 8 + 8 per strip -> N/16 single-strip workgroups (talker: 768 = 3 per
+    # CU instead of 384 = 1.5 per CU), SwiGLU pair combined across lanes in the epilogue.
+    "gu8": ["-DQTTS_SKINNY_GU8=1"],
 }
 
 

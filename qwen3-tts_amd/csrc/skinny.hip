@@ -41,6 +41,9 @@ __device__ inline unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 
 #ifndef QTTS_SKINNY_WLOAD
 #define QTTS_SKINNY_WLOAD 0
 #endif
+#ifndef QTTS_SKINNY_GU8
+#define QTTS_SKINNY_GU8 0
+#endif
 template <class T>
 __device__ inline T skinny_wload(const T* ptr) {
 #if QTTS_SKINNY_WLOAD == 1
@@ -109,7 +112,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     const bool epi_loads = wave == 0 && !(p.ablate & 4);
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
+#if QTTS_SKINNY_GU8
+        const int col = p.act == ACT_SWIGLU ? blockIdx.x * 8 + (lq & 1) * 4 : (strip0 + s) * FS + lq * 4;
+#else
         const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * FS) + lq * 4;
+#endif
         biasv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (epi_loads && p.bias && lq * 4 < FS) biasv[s] = *reinterpret_cast<const f32x4*>(p.bias + (strip0 + s) * FS + lq * 4);
 #pragma unroll
@@ -297,6 +304,29 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
             v[s] = t * rstd_l[m] + biasv[s];
         }
         if (row >= p.M || lq * 4 >= FS) continue;
+#if QTTS_SKINNY_GU8
+        // A/B variant: a 16-feature strip = 8 gate + 8 up features (talker_engine.hip packs it so); lanes lq < 2 hold the gate
+        // sums, lanes + 32 (same row, lq + 2) the matching up sums, fetched from the same LDS partials.
+        if (p.act == ACT_SWIGLU) {
+            if constexpr (SPW == 1 && FS == 16) {
+                if (lq < 2) {
+                    f32x4 tu = red[((0 * SPW + 0) * MT + m) * 64 + lane + 32];
+#pragma unroll
+                    for (int w2 = 1; w2 < NW; ++w2) tu += red[((w2 * SPW + 0) * MT + m) * 64 + lane + 32];
+                    const f32x4 vu = tu * rstd_l[m] + biasv[0];
+                    const int col = blockIdx.x * 8 + lq * 4;
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (v[0][r] / (1.f + expf(-v[0][r]))) * vu[r];
+                    o += resv[0][m];
+                    if (p.out_bf16) {
+                        uint2 h; h.x = pack_bf16(o[0], o[1]); h.y = pack_bf16(o[2], o[3]);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)row * p.ldo + col) = h;
+                    } else *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
+                }
+            }
+        } else
+#endif
         if (p.act == ACT_SWIGLU) {
             if constexpr (SPW == 2) {
                 const int col = blockIdx.x * 16 + lq * 4;
@@ -390,7 +420,12 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     int spw = 1;
     if (p.act == ACT_SWIGLU) {
         QTTS_REQUIRE(p.N % 32 == 0 && fs == 16, QTTS_ERR_ARG, "skinny: swiglu needs N % 32 and fs == 16");
+#if QTTS_SKINNY_GU8
+        QTTS_REQUIRE(!p.bias, QTTS_ERR_ARG, "skinny: the 8+8 swiglu variant has no bias path");
+        spw = 1;
+#else
         spw = 2;
+#endif
     } else if (fs == 16 && p.N / 16 >= 1024 && (p.N / 16) % 2 == 0) spw = 2;
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);

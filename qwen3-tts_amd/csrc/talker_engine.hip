@@ -17,6 +17,10 @@
 #include "kernels.h"
 #include "glue.h"
 
+#ifndef QTTS_SKINNY_GU8
+#define QTTS_SKINNY_GU8 0
+#endif
+
 using namespace qtts;
 
 namespace {
@@ -141,12 +145,29 @@ struct qtts_talker {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
                          PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
         auto guw = interleave_gu(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H);
+#if QTTS_SKINNY_GU8
+        // A/B variant (build.py VARIANTS): the decode copy interleaves 8 gate + 8 up rows per 16-row strip, so that one
+        // strip is a complete SwiGLU pair and the gate/up GEMM launches N/16 single-strip workgroups (skinny.hip).
+        std::vector<float> guw8((size_t)2 * d.I * d.H);
+        {
+            const auto& gw = PS(p + "mlp.gate_proj.weight", {d.I, d.H});
+            const auto& uw = PS(p + "mlp.up_proj.weight", {d.I, d.H});
+            for (int f = 0; f < d.I; ++f) {
+                memcpy(&guw8[((size_t)(f / 8) * 16 + f % 8) * d.H], &gw[(size_t)f * d.H], (size_t)d.H * 4);
+                memcpy(&guw8[((size_t)(f / 8) * 16 + 8 + f % 8) * d.H], &uw[(size_t)f * d.H], (size_t)d.H * 4);
+            }
+        }
+#endif
         auto& ow = PS(p + "self_attn.o_proj.weight", {d.H, d.qd});
         auto& dw = PS(p + "mlp.down_proj.weight", {d.H, d.I});
         upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H, &PS(p + "input_layernorm.weight", {d.H}));
         L.fs_o = choose_fs(d.H, d.qd); L.fs_d = choose_fs(d.H, d.I);
         upload_packed(L.o_p, ow, d.H, d.qd, nullptr, L.fs_o);
+#if QTTS_SKINNY_GU8
+        upload_packed(L.gu_p, guw8, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
+#else
         upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
+#endif
         upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);
         if (rows) {
             upload_rows(L.qkv_r, qkvw);

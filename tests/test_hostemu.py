@@ -770,6 +770,33 @@ def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
         emu.qtts_talker_destroy(h)
 
 
+def test_talker_bf16_small_batch_staged_path(emu, golden_dir):
+    """The bench configuration's code path at small batch (M = 3 rows per decode step, 6 in the code predictor's first pass):
+    bf16 weights and KV, the LDS-staged single-m-tile skinny GEMM with LDS-DMA staging of bf16 activations, narrow strips.
+    bf16 has no exact oracle: the first frames must mostly agree with the fp32 reference golden, and every row must come out
+    the same whether it is generated in the batch or alone.  With QTTS_PROBE_OUT set the codes are also written there (the
+    build-variant test compares them across builds: the same arithmetic must give the same bits)."""
+    g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16)
+    emu.hostemu_set_real_gemm(1)
+    try:
+        args = [g[k] for k in ("embeds", "mask", "trailing", "tts_pad")]
+        codes, _, _ = _talker_generate(emu, h, t, *args, max_new=5)
+        n = min(codes.shape[1], g["codes"].shape[1], 2)
+        assert float((codes[:, :n] == g["codes"][:, :n]).mean()) >= 0.7
+        for b in range(codes.shape[0]):
+            one, _, _ = _talker_generate(emu, h, t, args[0][b:b + 1], args[1][b:b + 1], args[2][b:b + 1], args[3], max_new=5)
+            m = min(one.shape[1], codes.shape[1])
+            assert np.array_equal(one[0, :m], codes[b, :m]), b
+        if os.environ.get("QTTS_PROBE_OUT"):
+            np.save(os.environ["QTTS_PROBE_OUT"], codes)
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
+        emu.qtts_talker_destroy(h)
+
+
 def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
     """The hardware runs the waves of a workgroup in no particular order; the emulator's default is ascending thread id.
     Re-run the kernel-level cases, the encoder, the speaker encoder, a short decode (whole and streamed) and a short talker
@@ -813,12 +840,13 @@ def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
 
 
 @pytest.mark.skipif(os.environ.get("QTTS_TEST_VARIANTS") != "1",
-                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: two extra emulator builds, ~4 min "
+                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: three extra emulator builds, ~8 min "
                            "-- enable with QTTS_TEST_VARIANTS=1")
 def test_build_variants_agree_with_default_on_emulator(tmp_path):
     """Every kernel-changing build variant, compiled into the emulated library with its -D flag (QTTS_HOSTEMU_DEFS), against
     the default build: sampler_v2 draws the same tokens for the same Philox keys; attn_tail passes the decode-attention
-    kernel test (long sequences included) and the talker golden."""
+    kernel test (long sequences included) and the talker golden; gu8 reproduces the fp32 talker goldens bit for bit and the
+    same bf16 codes as the default build at small and large batch."""
     import subprocess
     probe = os.path.join(HERE, "hostemu", "variant_probe.py")
     outs = []
@@ -830,9 +858,18 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
         outs.append(np.load(out))
     assert outs[0].shape == outs[1].shape and outs[0].size >= 900
     assert np.array_equal(outs[0], outs[1]), float((outs[0] != outs[1]).mean())
-    for defs, sel in (("-DQTTS_SAMPLER_V2=1", "sampler"), ("-DQTTS_ATTN_TAIL_BATCH=1", "attn_decode or talker_orchestration_greedy")):
-        env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs)
+    probes = {}
+    for defs, sel in (("", "bf16_small_batch"),
+                      ("-DQTTS_SAMPLER_V2=1", "sampler"),
+                      ("-DQTTS_ATTN_TAIL_BATCH=1", "attn_decode or talker_orchestration_greedy or bf16_small_batch"),
+                      ("-DQTTS_SKINNY_GU8=1", "talker_orchestration or talker_stream or bf16_small_batch")):
+        env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs, QTTS_PROBE_OUT=str(tmp_path / f"probe{len(probes)}.npy"))
         env.pop("QTTS_TEST_VARIANTS", None)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", sel], env=env,
                            capture_output=True, text=True)
         assert r.returncode == 0, (defs, r.stdout[-2000:])
+        if os.path.exists(env["QTTS_PROBE_OUT"]):
+            probes[defs] = np.load(env["QTTS_PROBE_OUT"])
+    assert len(probes) == 3                                   # same arithmetic in a different schedule: the same bits
+    for defs, codes in probes.items():
+        assert np.array_equal(codes, probes[""]), defs
