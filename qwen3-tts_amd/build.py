@@ -36,6 +36,10 @@ VARIANTS = {
     # skinny.hip + talker_engine.hip: gate/up packed 8 + 8 per strip -> N/16 single-strip workgroups (talker: 768 = 3 per
     # CU instead of 384 = 1.5 per CU), SwiGLU pair combined across lanes in the epilogue.
     "gu8": ["-DQTTS_SKINNY_GU8=1"],
+    # talker_engine.hip: small_to_mtp_projection(codec_embedding[j](token)) tabulated at finalize by the decode GEMM itself
+    # (117 MB at 1.7B dims); the sampler gathers the projected row, 14 projection GEMMs per frame leave the graph.
+    "cp_pretable": ["-DQTTS_CP_PRETABLE=1"],
+    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1"],
 }
 
 

@@ -20,6 +20,9 @@
 #ifndef QTTS_SKINNY_GU8
 #define QTTS_SKINNY_GU8 0
 #endif
+#ifndef QTTS_CP_PRETABLE
+#define QTTS_CP_PRETABLE 0
+#endif
 
 using namespace qtts;
 
@@ -44,6 +47,9 @@ struct qtts_talker {
     StackDims td, cd;
     std::vector<LayerW> tl, cl;
     DevBuf t_norm, c_norm, head_p, emb_talker, emb_cp, proj_p, proj_b, inv_freq_t, inv_freq_c;
+#if QTTS_CP_PRETABLE
+    DevBuf emb_cp_proj;   // [G-2][cp_vocab][cp H] = small_to_mtp_projection(codec_embedding[g](v)), built at finalize by the decode GEMM itself
+#endif
     std::vector<DevBuf> lm_head_p;
     int fs_proj = 16, fs_lm = 16, fs_head = 16;
     DevBuf tp_fc1, tp_b1, tp_fc2, tp_b2;
@@ -290,6 +296,26 @@ void qtts_talker::finalize() {
         upload_packed(proj_p, PS("code_predictor.small_to_mtp_projection.weight", {cd.H, td.H}), cd.H, td.H, nullptr, fs_proj);
         upload_f(proj_b, PS("code_predictor.small_to_mtp_projection.bias", {cd.H}));
     }
+#if QTTS_CP_PRETABLE
+    // A/B variant (build.py VARIANTS): passes 1 .. G-2 of the code predictor feed small_to_mtp_projection with
+    // codec_embedding[j-1](token) (M:1281-1282) -- a function of the token alone.  Tabulate it once, with the SAME decode
+    // GEMM launches the frame step would make (16 rows at a time; a row's result does not depend on the batch around it), so
+    // the sampler's fused gather can fetch the projected row and 14 of the 15 projection GEMMs leave the frame graph.
+    if (has_proj && G > 2) {
+        const int nt = G - 2;
+        emb_cp_proj.alloc((size_t)nt * c.cp_vocab_size * cd.H * 4);
+        for (int g = 0; g < nt; ++g)
+            for (int v0 = 0; v0 < c.cp_vocab_size; v0 += 16) {
+                SkinnyParams pj{};
+                pj.x = emb_cp.as<float>() + ((size_t)g * c.cp_vocab_size + v0) * td.H; pj.ldx = td.H;
+                pj.M = std::min(16, c.cp_vocab_size - v0); pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
+                pj.bias = proj_b.as<float>(); pj.out = emb_cp_proj.as<float>() + ((size_t)g * c.cp_vocab_size + v0) * cd.H;
+                pj.ldo = cd.H; pj.act = ACT_NONE; pj.fs = fs_proj;
+                launch_skinny(pj, bf16, nullptr);
+            }
+        QTTS_CHECK_HIP(hipDeviceSynchronize());
+    }
+#endif
     has_text_proj = host.count("text_projection.linear_fc1.weight") > 0;
     if (has_text_proj) {
         const int TH = c.text_hidden_size;
@@ -321,6 +347,9 @@ void qtts_talker::finalize() {
     weight_bytes_frame = c.num_hidden_layers * layer_b(td) + eb * (double)c.vocab_size * td.H +
                          (G - 1) * (c.cp_num_hidden_layers * layer_b(cd) + eb * (double)c.cp_vocab_size * cd.H +
                                     (has_proj ? eb * (double)cd.H * td.H : 0.0));
+#if QTTS_CP_PRETABLE
+    if (has_proj && G > 2) weight_bytes_frame -= (G - 2) * eb * (double)cd.H * td.H;   // only pass 0 still runs the projection
+#endif
 
     // ---- KV caches (pages of 16 tokens, reserved up front)
     const size_t esz = bf16 ? 2 : 4;
@@ -449,6 +478,11 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         gp.sub = sub.as<int>(); gp.sub_stride = G; gp.done = ss.done;
         unsigned short* c16 = bf16 ? cp_x16.as<unsigned short>() : nullptr;
         // passes j >= 1 get their input row from the previous pass's sampler (fused gather): only pass 0 gathers here
+#if QTTS_CP_PRETABLE
+        if (has_proj && j >= 1) {
+            // the previous pass's sampler gathered the projected row straight into cp_x (and its bf16 shadow)
+        } else
+#endif
         if (has_proj) {
             gp.out = cp_in.as<float>(); gp.out16 = nullptr;
             if (!skinny_only && j == 0) launch_cp_gather(gp, st);
@@ -483,6 +517,13 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
             s.gather_emb = emb_cp.as<float>() + (size_t)j * c.cp_vocab_size * td.H; s.gather_C = td.H;
             s.gather_out = has_proj ? cp_in.as<float>() : cp_x.as<float>();
             s.gather_out16 = has_proj ? nullptr : c16;
+#if QTTS_CP_PRETABLE
+            if (has_proj) {
+                s.gather_emb = emb_cp_proj.as<float>() + (size_t)j * c.cp_vocab_size * cd.H; s.gather_C = cd.H;
+                s.gather_out = cp_x.as<float>();
+                s.gather_out16 = (c16 && skinny_can_stage(B, cd.H, bf16)) ? c16 : nullptr;   // as the projection's out16
+            }
+#endif
         }
         if (!skinny_only) launch_sample(s, st);
     }
