@@ -39,7 +39,9 @@ VARIANTS = {
     # talker_engine.hip: small_to_mtp_projection(codec_embedding[j](token)) tabulated at finalize by the decode GEMM itself
     # (117 MB at 1.7B dims); the sampler gathers the projected row, 14 projection GEMMs per frame leave the graph.
     "cp_pretable": ["-DQTTS_CP_PRETABLE=1"],
-    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1"],
+    # + layer-0 q|k|v of passes >= 1 tabulated the same way (470 MB at real dims): 14 more GEMMs per frame leave the graph
+    "cp_qkvtable": ["-DQTTS_CP_QKVTABLE=1"],
+    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1"],
 }
 
 

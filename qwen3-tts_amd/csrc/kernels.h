@@ -164,6 +164,9 @@ struct AttnDecodeParams {
 void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st);
 
 // --------------------------------------------------------------------------------- sampling.hip
+#ifndef QTTS_CP_QKVTABLE
+#define QTTS_CP_QKVTABLE 0
+#endif
 struct SampleParams {
     const float* logits; int ld; int V; int B;
     // processors
@@ -189,6 +192,10 @@ struct SampleParams {
     // optional fused gather (code predictor): gather_out[b][:] = gather_emb[token][:] -- the NEXT pass's input row
     // (codec_embedding[j](token), M:1281), so no separate gather kernel sits between sampler and GEMM
     const float* gather_emb; int gather_C; float* gather_out; unsigned short* gather_out16;
+#if QTTS_CP_QKVTABLE
+    // A/B variant (build.py VARIANTS): second fused gather -- the next pass's layer-0 q|k|v row, tabulated at finalize
+    const float* gather2_emb; int gather2_C; float* gather2_out;
+#endif
 };
 void launch_sample(const SampleParams& p, hipStream_t st);
 

@@ -297,6 +297,13 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
             }
         }
     }
+#if QTTS_CP_QKVTABLE
+    if (p.gather2_emb) {
+        const float* src2 = p.gather2_emb + (size_t)token * p.gather2_C;
+        for (int c = tid * 4; c < p.gather2_C; c += 1024)
+            *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
+    }
+#endif
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];
@@ -574,6 +581,13 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
             }
         }
     }
+#if QTTS_CP_QKVTABLE
+    if (p.gather2_emb) {
+        const float* src2 = p.gather2_emb + (size_t)token * p.gather2_C;
+        for (int c = tid * 4; c < p.gather2_C; c += 1024)
+            *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
+    }
+#endif
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];

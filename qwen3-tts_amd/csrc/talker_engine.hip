@@ -23,6 +23,10 @@
 #ifndef QTTS_CP_PRETABLE
 #define QTTS_CP_PRETABLE 0
 #endif
+#if QTTS_CP_QKVTABLE && !QTTS_CP_PRETABLE      // the q|k|v table is built from the projected-embedding table
+#undef QTTS_CP_PRETABLE
+#define QTTS_CP_PRETABLE 1
+#endif
 
 using namespace qtts;
 
@@ -47,6 +51,10 @@ struct qtts_talker {
     StackDims td, cd;
     std::vector<LayerW> tl, cl;
     DevBuf t_norm, c_norm, head_p, emb_talker, emb_cp, proj_p, proj_b, inv_freq_t, inv_freq_c;
+#if QTTS_CP_QKVTABLE
+    DevBuf cp_qkv0_tab;   // [G-2][cp_vocab][q|k|v width] = layer-0 qkv GEMM (norm folded) of the pass input row of every token
+    bool skip_qkv = false;
+#endif
 #if QTTS_CP_PRETABLE
     DevBuf emb_cp_proj;   // [G-2][cp_vocab][cp H] = small_to_mtp_projection(codec_embedding[g](v)), built at finalize by the decode GEMM itself
 #endif
@@ -214,8 +222,15 @@ struct qtts_talker {
         p.done_flag = ss.done;
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
+#if QTTS_CP_QKVTABLE
+        if (!skip_qkv) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
+            norm_input(p, d, h16 ? xs16 : nullptr, st);
+            skinny(p, st);
+        }
+#else
         norm_input(p, d, h16 ? xs16 : nullptr, st);
         skinny(p, st);
+#endif
         AttnDecodeParams a{};
         a.qkv = qkvb; a.ld = d.qd + 2 * d.kvd; a.B = B; a.n_new = n_new; a.nh = d.nh; a.nkv = d.nkv; a.hd = d.hd;
         a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
@@ -350,6 +365,9 @@ void qtts_talker::finalize() {
 #if QTTS_CP_PRETABLE
     if (has_proj && G > 2) weight_bytes_frame -= (G - 2) * eb * (double)cd.H * td.H;   // only pass 0 still runs the projection
 #endif
+#if QTTS_CP_QKVTABLE
+    if (G > 2) weight_bytes_frame -= (G - 2) * eb * (double)(cd.qd + 2 * cd.kvd) * cd.H;   // layer-0 qkv GEMM of passes >= 1
+#endif
 
     // ---- KV caches (pages of 16 tokens, reserved up front)
     const size_t esz = bf16 ? 2 : 4;
@@ -384,6 +402,37 @@ void qtts_talker::finalize() {
     QTTS_CHECK_HIP(hipMemset(ss_rows.p, 0, ss_rows.bytes));
     int* ip = ints.as<int>();
     ss = {ip + 0, ip + 1, ip + 2, ip + 3, ip + 4, ip + 64};
+#if QTTS_CP_QKVTABLE
+    // A/B variant (build.py VARIANTS): in passes 1 .. G-2 the code predictor's layer-0 q|k|v GEMM sees only the pass input row,
+    // a function of the previous token alone (has_proj: the projected embedding above; otherwise codec_embedding itself).
+    // Tabulate it with the same launches the frame step makes -- bf16 mode: LDS-staged from the bf16 image of the row with the
+    // variance taken from that image, as at run time for up to 32 rows; fp32 mode: row sums of squares from row_ss_kernel.
+    if (G > 2) {
+        const int nt = G - 2, QW = cd.qd + 2 * cd.kvd, Vc = c.cp_vocab_size;
+        const float* xt = has_proj ? emb_cp_proj.as<float>() : emb_cp.as<float>();
+        const bool staged = skinny_can_stage(16, cd.H, bf16);
+        DevBuf x16t;
+        if (staged) {
+            std::vector<float> hx((size_t)nt * Vc * cd.H);
+            QTTS_CHECK_HIP(hipMemcpy(hx.data(), xt, hx.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<bf16_t> h16(hx.size());
+            parallel_for((int64_t)hx.size(), [&](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) h16[i] = f32_to_bf16(hx[i]); });
+            x16t.upload(h16.data(), h16.size() * 2);
+        }
+        cp_qkv0_tab.alloc((size_t)nt * Vc * QW * 4);
+        for (int g = 0; g < nt; ++g)
+            for (int v0 = 0; v0 < Vc; v0 += 16) {
+                const size_t row0 = (size_t)g * Vc + v0;
+                SkinnyParams p{};
+                p.x = xt + row0 * cd.H; p.ldx = cd.H; p.M = std::min(16, Vc - v0); p.Wp = cl[0].qkv_p.p; p.N = QW; p.K = cd.H;
+                p.out = cp_qkv0_tab.as<float>() + row0 * QW; p.ldo = QW; p.act = ACT_NONE; p.norm = 1; p.eps = cd.eps;
+                if (staged) { p.x = reinterpret_cast<const float*>(x16t.as<bf16_t>() + row0 * cd.H); p.x_bf16 = 1; }
+                else { launch_row_ss(p.x, cd.H, p.M, cd.H, ssbuf(), nullptr, nullptr); p.ss_in = ssbuf(); }
+                launch_skinny(p, bf16, nullptr);
+            }
+        QTTS_CHECK_HIP(hipDeviceSynchronize());
+    }
+#endif
     host.clear();
     finalized = true;
 }
@@ -496,9 +545,16 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
             gp.out = cp_x.as<float>(); gp.out16 = c16;
             if (!skinny_only && j == 0) launch_cp_gather(gp, st);
         }
-        for (int l = 0; l < c.cp_num_hidden_layers; ++l)
+        for (int l = 0; l < c.cp_num_hidden_layers; ++l) {
+#if QTTS_CP_QKVTABLE
+            skip_qkv = j >= 1 && l == 0;
+#endif
             decode_layer(cl[l], cd, cp_x.as<float>(), c16, cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
                          kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st);
+        }
+#if QTTS_CP_QKVTABLE
+        skip_qkv = false;
+#endif
         // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
         SkinnyParams lh{};
         lh.done_flag = ss.done;
@@ -523,6 +579,11 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
                 s.gather_out = cp_x.as<float>();
                 s.gather_out16 = (c16 && skinny_can_stage(B, cd.H, bf16)) ? c16 : nullptr;   // as the projection's out16
             }
+#endif
+#if QTTS_CP_QKVTABLE
+            s.gather2_C = cd.qd + 2 * cd.kvd;
+            s.gather2_emb = cp_qkv0_tab.as<float>() + (size_t)j * c.cp_vocab_size * s.gather2_C;
+            s.gather2_out = cp_qkv.as<float>();
 #endif
         }
         if (!skinny_only) launch_sample(s, st);

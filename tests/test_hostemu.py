@@ -840,12 +840,12 @@ def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
 
 
 @pytest.mark.skipif(os.environ.get("QTTS_TEST_VARIANTS") != "1",
-                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: five extra emulator builds, ~20 min "
+                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: six extra emulator builds, ~25 min "
                            "-- enable with QTTS_TEST_VARIANTS=1")
 def test_build_variants_agree_with_default_on_emulator(tmp_path):
     """Every kernel-changing build variant, compiled into the emulated library with its -D flag (QTTS_HOSTEMU_DEFS), against
     the default build: sampler_v2 draws the same tokens for the same Philox keys; attn_tail passes the decode-attention
-    kernel test (long sequences included) and the talker golden; gu8 and cp_pretable (and all four together) reproduce
+    kernel test (long sequences included) and the talker golden; gu8, cp_pretable and cp_qkvtable (and all of them together) reproduce
     the fp32 talker goldens bit for bit and the same bf16 codes as the default build."""
     import subprocess
     probe = os.path.join(HERE, "hostemu", "variant_probe.py")
@@ -864,7 +864,8 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
                       ("-DQTTS_ATTN_TAIL_BATCH=1", "attn_decode or talker_orchestration_greedy or bf16_small_batch"),
                       ("-DQTTS_SKINNY_GU8=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_CP_PRETABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
-                      ("-DQTTS_SAMPLER_V2=1 -DQTTS_SKINNY_GU8=1 -DQTTS_ATTN_TAIL_BATCH=1 -DQTTS_CP_PRETABLE=1",      # "combo"
+                      ("-DQTTS_CP_QKVTABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
+                      ("-DQTTS_SAMPLER_V2=1 -DQTTS_SKINNY_GU8=1 -DQTTS_ATTN_TAIL_BATCH=1 -DQTTS_CP_PRETABLE=1 -DQTTS_CP_QKVTABLE=1",  # "combo"
                        "talker_orchestration or talker_stream or bf16_small_batch or sampler or attn_decode")):
         env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs, QTTS_PROBE_OUT=str(tmp_path / f"probe{len(probes)}.npy"))
         env.pop("QTTS_TEST_VARIANTS", None)
@@ -873,6 +874,6 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
         assert r.returncode == 0, (defs, r.stdout[-2000:])
         if os.path.exists(env["QTTS_PROBE_OUT"]):
             probes[defs] = np.load(env["QTTS_PROBE_OUT"])
-    assert len(probes) == 5                                   # same arithmetic in a different schedule: the same bits
+    assert len(probes) == 6                                   # same arithmetic in a different schedule: the same bits
     for defs, codes in probes.items():
         assert np.array_equal(codes, probes[""]), defs
