@@ -41,7 +41,10 @@ VARIANTS = {
     "cp_pretable": ["-DQTTS_CP_PRETABLE=1"],
     # + layer-0 q|k|v of passes >= 1 tabulated the same way (470 MB at real dims): 14 more GEMMs per frame leave the graph
     "cp_qkvtable": ["-DQTTS_CP_QKVTABLE=1"],
-    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1"],
+    # attention.hip: attn_cp_kernel for the code predictor's single-token passes (<= 16 keys): one barrier instead of five,
+    # only the keys that exist are read, PV without a cross-lane reduction.  70 launches per frame at ~7.3 us today.
+    "attn_cp": ["-DQTTS_ATTN_CP=1"],
+    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1"],
 }
 
 

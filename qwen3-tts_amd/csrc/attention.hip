@@ -474,6 +474,152 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
 }
 
+#ifndef QTTS_ATTN_CP
+#define QTTS_ATTN_CP 0
+#endif
+#if QTTS_ATTN_CP
+// =================================================================================== attn_cp (A/B variant, build.py VARIANTS)
+// The code predictor's single-token passes (70 of the 103 attention launches of a frame) attend over at most 16 keys, yet
+// go through the general kernel above: 64-key speculative chunks, five workgroup barriers, 16 key groups combined through
+// LDS.  This kernel does the same arithmetic for exactly that case -- one new token, a static cache length S0 <= 15, no
+// left padding, 1 or 2 query heads per kv head, head_dim 128 -- with one barrier:
+//   stage 1 (4 waves):  q head 0 | q head 1 | k | v of the new token: RMSNorm + RoPE (q, k), round through the cache type and
+//                       append (k, v), results to LDS.  The old K rows (key-major: lane = key * 4 + quarter, 32 dims each)
+//                       and old V rows (dim-major: lane owns dims lane and lane + 64 of every key) are requested from the
+//                       cache at kernel entry, before the new row is even read.
+//   stage 2 (wave = query): 32-dim partial dot + quad reduction, fp32 softmax across the 16 key slots (DPP), then
+//                       out[d] = sum_k e_k * v[k][d] with e_k broadcast from its lane -- no cross-lane reduction for PV.
+template <typename KVT>
+__global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
+    constexpr int HD = 128, MAXK = 16;
+    constexpr int KW = sizeof(KVT) == 2 ? 4 : 8;          // 16-B vectors per 32-dim quarter of a key
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float qs[2][HD];
+    __shared__ __attribute__((aligned(16))) float kn[HD];
+    __shared__ float vn[HD];
+    const int GQ = p.nh / p.nkv;
+    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kk = lane >> 2, qq = lane & 3;
+    const int S0 = p.len_static, S1 = S0 + 1;
+    const KVT* kc = reinterpret_cast<const KVT*>(p.kv.k);
+    const KVT* vc = reinterpret_cast<const KVT*>(p.kv.v);
+    auto key_base = [&](int s) -> size_t {                // element offset of key s (dim 0) in this sequence's pages
+        const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+        return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD;
+    };
+    // ---- 0. cache reads (do not depend on this step's qkv row); only the query waves need them
+    u32x4 kr[KW];
+    KVT vr[MAXK][2];
+#pragma unroll
+    for (int w = 0; w < KW; ++w) kr[w] = (u32x4){0u, 0u, 0u, 0u};
+    if (wave < GQ) {
+        if (kk < S0) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(kc + key_base(kk) + qq * 32);
+#pragma unroll
+            for (int w = 0; w < KW; ++w) kr[w] = src[w];
+        }
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            vr[k][0] = vr[k][1] = kv_cast<KVT>(0.f);
+            if (k < S0) {
+                const size_t o = key_base(k);
+                vr[k][0] = vc[o + lane];
+                vr[k][1] = vc[o + lane + 64];
+            }
+        }
+    }
+    // this step's row: wave 0 / 1 -> q heads, wave 2 -> k, wave 3 -> v (with GQ == 1 wave 1 has nothing to do)
+    const bool has_vec = wave >= 2 || wave < GQ;
+    float x0 = 0.f, x1 = 0.f;
+    if (has_vec) {
+        const int col = wave < 2 ? (kvh * GQ + wave) * HD : (wave == 2 ? (p.nh + kvh) * HD : (p.nh + p.nkv + kvh) * HD);
+        const float* src = p.qkv + (size_t)b * p.ld + col;
+        x0 = src[lane]; x1 = src[lane + 64];
+    }
+    const int done = p.done_flag ? *p.done_flag : 0;
+    if (done) return;
+    // ---- 1. q/k RMSNorm + RoPE at position S0, K/V append
+    if (has_vec) {
+        const float* w = wave < 2 ? p.qw : (wave == 2 ? p.kw : nullptr);
+        if (w) {
+            const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
+            const float rs = rsqrtf(ss / (float)HD + p.eps);
+            x0 = w[lane] * (x0 * rs);
+            x1 = w[lane + 64] * (x1 * rs);
+            const float ang = (float)S0 * p.inv_freq[lane];
+            const float c = cosf(ang), sn = sinf(ang);
+            const float o0 = x0 * c - x1 * sn, o1 = x1 * c + x0 * sn;
+            x0 = o0; x1 = o1;
+        }
+        if (wave >= 2) {
+            const size_t o = key_base(S0);
+            KVT* cdst = reinterpret_cast<KVT*>(wave == 2 ? p.kv.k : p.kv.v);
+            const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
+            cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
+            x0 = kv_load(&h0); x1 = kv_load(&h1);
+        }
+        float* dst = wave < 2 ? qs[wave] : (wave == 2 ? kn : vn);
+        dst[lane] = x0; dst[lane + 64] = x1;
+    }
+    __syncthreads();
+    if (wave >= GQ) return;
+    // ---- 2. one wave per query head
+    const float* q = qs[wave] + qq * 32;
+    float kx[32];
+    if (kk == S0) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) kx[e] = kn[qq * 32 + e];
+    } else {
+#pragma unroll
+        for (int w = 0; w < KW; ++w) {
+            if constexpr (KW == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kx[w * 8 + 2 * e] = __uint_as_float(kr[w][e] << 16);
+                    kx[w * 8 + 2 * e + 1] = __uint_as_float(kr[w][e] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) kx[w * 4 + e] = __uint_as_float(kr[w][e]);
+            }
+        }
+    }
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) a += q[e] * kx[e];
+    a += __shfl_xor(a, 1);
+    a += __shfl_xor(a, 2);
+    const float s = kk < S1 ? a * rsqrtf((float)HD) : -INFINITY;
+    const float m = wave_max64_dpp(s);
+    const float e = kk < S1 ? expf(s - m) : 0.f;
+    const float l = wave_sum64_dpp(qq == 0 ? e : 0.f);
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        if (k < S0) {
+            const float ek = __shfl(e, k * 4);
+            acc0 += ek * kv_load(&vr[k][0]);
+            acc1 += ek * kv_load(&vr[k][1]);
+        }
+    }
+    {
+        const float ek = __shfl(e, S0 * 4);
+        acc0 += ek * vn[lane];
+        acc1 += ek * vn[lane + 64];
+    }
+    const float inv = 1.f / l;
+    const size_t o = (size_t)b * p.ldo + (kvh * GQ + wave) * HD;
+    if (p.out_bf16) {
+        reinterpret_cast<bf16_t*>(p.out)[o + lane] = f32_to_bf16(acc0 * inv);
+        reinterpret_cast<bf16_t*>(p.out)[o + lane + 64] = f32_to_bf16(acc1 * inv);
+    } else {
+        p.out[o + lane] = acc0 * inv;
+        p.out[o + lane + 64] = acc1 * inv;
+    }
+}
+#endif  // QTTS_ATTN_CP
+
 template <typename KVT, int NQ>
 static void launch_attn_decode_t(const AttnDecodeParams& p, size_t lds, hipStream_t st) {
     auto kern = attn_decode_kernel<KVT, NQ>;
@@ -490,6 +636,14 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.hd == 128, QTTS_ERR_ARG, "attn_decode: head_dim must be 128");
     const int GQ = p.nh / p.nkv, NQ = p.n_new * GQ;
     QTTS_REQUIRE((NQ == 1 || NQ == 2 || NQ == 4) && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: 1, 2 or 4 queries per kv head");
+#if QTTS_ATTN_CP
+    if (p.n_new == 1 && !p.len_dev && !p.n_pad && p.len_static + 1 <= 16 && GQ <= 2) {     // the code predictor's passes >= 1
+        if (p.kv.bf16) hipLaunchKernelGGL(attn_cp_kernel<bf16_t>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_cp_kernel<float>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
+#endif
     const size_t lds = ((size_t)NQ * 128 + 2 * p.n_new * 128 + 16 * NQ * 128 + (size_t)NQ * p.max_len + 8) * sizeof(float);
     QTTS_REQUIRE(lds <= 150 * 1024, QTTS_ERR_LIMIT, "attn_decode: max_len too large for LDS scores");
     if (p.kv.bf16) {

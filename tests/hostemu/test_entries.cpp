@@ -73,7 +73,8 @@ extern "C" int hostemu_attn_decode(const float* qkv, int ld, int B, int n_new, i
         qtts::AttnDecodeParams p{};
         p.qkv = qkv; p.ld = ld; p.B = B; p.n_new = n_new; p.nh = nh; p.nkv = nkv; p.hd = 128;
         p.qw = qw; p.kw = kw; p.eps = eps; p.inv_freq = inv_freq; p.n_pad = n_pad;
-        p.len_dev = &S0; p.len_static = S0;
+        // the code predictor calls with a static length and a 32-key score buffer; the talker with a device-side length
+        p.len_dev = (max_len <= 32 && !n_pad) ? nullptr : &S0; p.len_static = S0;
         p.kv.k = kpool; p.kv.v = vpool; p.kv.page_table = page_table; p.kv.pages_per_seq = pages_per_seq;
         p.kv.n_pages = B * pages_per_seq; p.kv.nkv = nkv; p.kv.hd = 128; p.kv.bf16 = bf16; p.kv.contig = page_table ? 0 : 1;
         p.layer = 0; p.out = out; p.ldo = ldo; p.out_bf16 = 0; p.max_len = max_len; p.done_flag = nullptr;

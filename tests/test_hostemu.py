@@ -216,8 +216,10 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
         c, s = np.cos(ang.astype(np.float64)), np.sin(ang.astype(np.float64))
         return np.concatenate([x[:64] * c - x[64:] * s, x[64:] * c + x[:64] * s])
 
+    # npads None + S0 <= 15: the code predictor's call shape (static length, no padding, 32-slot score buffer)
     for (B, n_new, S0, npads, permute) in [(2, 1, 37, [0, 5], False), (3, 2, 130, [0, 17, 64], False), (2, 1, 300, [3, 0], True),
-                                           (2, 2, 701, [0, 40], False), (1, 1, 1030, [9], True)]:
+                                           (2, 2, 701, [0, 40], False), (1, 1, 1030, [9], True),
+                                           (3, 1, 1, None, False), (2, 1, 7, None, True), (3, 1, 15, None, False)]:
         pps = (S0 + n_new + 15) // 16 + 1
         n_pages = B * pps
         table = np.arange(n_pages, dtype=np.int32).reshape(B, pps)
@@ -229,7 +231,8 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
         V = rnd(g.standard_normal((B, nkv, S0, HD)).astype(np.float32))
         kp = np.full((n_pages, nkv, 16, HD), np.nan, np.float32)      # never-written slots must never be read into the result
         vp_ = np.full((n_pages, nkv, 16, HD), np.nan, np.float32)
-        npad = np.asarray(npads, np.int32)
+        cp_call = npads is None
+        npad = np.zeros(B, np.int32) if cp_call else np.asarray(npads, np.int32)
         for b in range(B):
             for s in range(npad[b], S0):                                # left-pad slots stay unwritten (as after a real prefill)
                 kp[table[b, s // 16], :, s % 16] = K[b, :, s]
@@ -266,9 +269,9 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
             out = np.full((n_new * B, nh * HD + 4), 5.0, np.float32)
             emu.hostemu_set_fiber_order(order)
             try:
-                rc = emu.hostemu_attn_decode(_ptr(qkv), ld, B, n_new, nh, nkv, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), _ptr(npad), S0,
-                                             _ptr(kk), _ptr(vv), _ptr(table) if permute else None, pps, bf16, _ptr(out),
-                                             nh * HD + 4, S0 + n_new + 3)
+                rc = emu.hostemu_attn_decode(_ptr(qkv), ld, B, n_new, nh, nkv, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq),
+                                             None if cp_call else _ptr(npad), S0, _ptr(kk), _ptr(vv), _ptr(table) if permute else None,
+                                             pps, bf16, _ptr(out), nh * HD + 4, 32 if cp_call else S0 + n_new + 3)
             finally:
                 emu.hostemu_set_fiber_order(0)
             assert rc == 0, ((B, n_new, S0), (emu.qtts_last_error() or b"").decode())
@@ -840,13 +843,14 @@ def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
 
 
 @pytest.mark.skipif(os.environ.get("QTTS_TEST_VARIANTS") != "1",
-                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: six extra emulator builds, ~25 min "
+                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: seven extra emulator builds, ~30 min "
                            "-- enable with QTTS_TEST_VARIANTS=1")
 def test_build_variants_agree_with_default_on_emulator(tmp_path):
     """Every kernel-changing build variant, compiled into the emulated library with its -D flag (QTTS_HOSTEMU_DEFS), against
     the default build: sampler_v2 draws the same tokens for the same Philox keys; attn_tail passes the decode-attention
-    kernel test (long sequences included) and the talker golden; gu8, cp_pretable and cp_qkvtable (and all of them together) reproduce
-    the fp32 talker goldens bit for bit and the same bf16 codes as the default build."""
+    kernel test (long sequences included) and the talker golden; gu8, cp_pretable and cp_qkvtable reproduce the fp32
+    talker goldens bit for bit and the same bf16 codes as the default build; attn_cp (a different summation order inside the
+    attention) reproduces the fp32 goldens bit for bit and >= 95 % of the default's bf16 codes; so does everything together."""
     import subprocess
     probe = os.path.join(HERE, "hostemu", "variant_probe.py")
     outs = []
@@ -865,7 +869,9 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
                       ("-DQTTS_SKINNY_GU8=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_CP_PRETABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_CP_QKVTABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
-                      ("-DQTTS_SAMPLER_V2=1 -DQTTS_SKINNY_GU8=1 -DQTTS_ATTN_TAIL_BATCH=1 -DQTTS_CP_PRETABLE=1 -DQTTS_CP_QKVTABLE=1",  # "combo"
+                      ("-DQTTS_ATTN_CP=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
+                      ("-DQTTS_SAMPLER_V2=1 -DQTTS_SKINNY_GU8=1 -DQTTS_ATTN_TAIL_BATCH=1 -DQTTS_CP_PRETABLE=1 -DQTTS_CP_QKVTABLE=1 "
+                       "-DQTTS_ATTN_CP=1",                                                                                   # "combo"
                        "talker_orchestration or talker_stream or bf16_small_batch or sampler or attn_decode")):
         env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs, QTTS_PROBE_OUT=str(tmp_path / f"probe{len(probes)}.npy"))
         env.pop("QTTS_TEST_VARIANTS", None)
@@ -874,6 +880,9 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
         assert r.returncode == 0, (defs, r.stdout[-2000:])
         if os.path.exists(env["QTTS_PROBE_OUT"]):
             probes[defs] = np.load(env["QTTS_PROBE_OUT"])
-    assert len(probes) == 6                                   # same arithmetic in a different schedule: the same bits
+    assert len(probes) == 7
     for defs, codes in probes.items():
-        assert np.array_equal(codes, probes[""]), defs
+        if "ATTN_CP" in defs:             # a different fp32 summation order inside the attention: bf16 codes agree, not bit for bit
+            assert float((codes == probes[""]).mean()) >= 0.95, defs
+        else:                             # same arithmetic in a different schedule: the same bits
+            assert np.array_equal(codes, probes[""]), defs
