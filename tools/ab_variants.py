@@ -9,6 +9,7 @@ are in profiles/.
 
     python qwen3-tts_amd/build.py --all-variants          # CPU container, before gpurun
     gpurun --timeout 900 -- 'python tools/ab_variants.py --frames 40'
+    gpurun --timeout 1500 -- 'python tools/ab_variants.py --check combo --only default combo default_again'
 """
 import argparse
 import json
@@ -61,6 +62,9 @@ def main():
     ap.add_argument("--model", default="1.7b")
     ap.add_argument("--timeout", type=int, default=240, help="per candidate, seconds")
     ap.add_argument("--only", nargs="*", default=None, help="candidate names to run (default: all)")
+    ap.add_argument("--check", nargs="*", default=None, metavar="VARIANT",
+                    help="before timing, run the talker GPU parity tests (reference goldens, bit-exact greedy codes) against "
+                         "these library variants (no names = every built variant); a variant that fails is not timed")
     args = ap.parse_args()
     cands = [("default", {})]
     for v in sorted(qbuild.VARIANTS):
@@ -74,6 +78,25 @@ def main():
     if args.only:
         cands = [c for c in cands if c[0] in args.only or c[0].split(":", 1)[-1] in args.only]
     results = []
+    if args.check is not None:
+        failed = set()
+        for name, env_extra in list(cands):
+            if not name.startswith("lib:") or (args.check and name[4:] not in args.check):
+                continue
+            env = dict(os.environ, **env_extra)
+            t0 = time.time()
+            try:
+                out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                                      "-m", "gpu", "-k", "talker or sampler or prompt_assembly"], env=env, capture_output=True,
+                                     text=True, timeout=600, cwd=ROOT)
+                rc, tail = out.returncode, (out.stdout + out.stderr)[-400:]
+            except subprocess.TimeoutExpired:
+                rc, tail = -9, "timeout"
+            print(f"[ab] parity {name:28s} rc={rc} ({time.time() - t0:.0f} s)", flush=True)
+            results.append({"name": "parity:" + name, "rc": rc, "tail": tail if rc else ""})
+            if rc != 0:
+                failed.add(name)
+        cands = [c for c in cands if c[0] not in failed]
     for name, env in cands:
         r = run_one(name, env, args.frames, args.model, args.timeout)
         results.append(r)
@@ -82,6 +105,8 @@ def main():
     base = next((r.get("sampling_ms_per_frame") for r in results if r["name"] == "default"), None)
     print("\n| candidate | sampling ms/frame | vs default | greedy ms/frame |\n|---|---|---|---|")
     for r in results:
+        if r["name"].startswith("parity:"):
+            continue
         s = r.get("sampling_ms_per_frame")
         rel = f"{s / base:.3f}x" if (s and base) else "-"
         print(f"| {r['name']} | {s} | {rel} | {r.get('greedy_ms_per_frame')} |")
