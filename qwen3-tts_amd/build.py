@@ -44,7 +44,10 @@ VARIANTS = {
     # attention.hip: attn_cp_kernel for the code predictor's single-token passes (<= 16 keys): one barrier instead of five,
     # only the keys that exist are read, PV without a cross-lane reduction.  70 launches per frame at ~7.3 us today.
     "attn_cp": ["-DQTTS_ATTN_CP=1"],
-    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1"],
+    # attention.hip: attn_t1_kernel for the talker's single-token step when max_seq <= 256 (bf16 cache): per-wave softmax
+    # statistics merged once (flash-decoding inside the workgroup), two barriers instead of five.  28 launches x ~11 us.
+    "attn_t1": ["-DQTTS_ATTN_T1=1"],
+    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1", "-DQTTS_ATTN_T1=1"],
 }
 
 

@@ -219,7 +219,8 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
     # npads None + S0 <= 15: the code predictor's call shape (static length, no padding, 32-slot score buffer)
     for (B, n_new, S0, npads, permute) in [(2, 1, 37, [0, 5], False), (3, 2, 130, [0, 17, 64], False), (2, 1, 300, [3, 0], True),
                                            (2, 2, 701, [0, 40], False), (1, 1, 1030, [9], True),
-                                           (3, 1, 1, None, False), (2, 1, 7, None, True), (3, 1, 15, None, False)]:
+                                           (3, 1, 1, None, False), (2, 1, 7, None, True), (3, 1, 15, None, False),
+                                           (2, 1, 200, [0, 31], True), (3, 1, 252, [5, 0, 100], False), (2, 1, 16, [0, 15], False)]:
         pps = (S0 + n_new + 15) // 16 + 1
         n_pages = B * pps
         table = np.arange(n_pages, dtype=np.int32).reshape(B, pps)
@@ -843,14 +844,14 @@ def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
 
 
 @pytest.mark.skipif(os.environ.get("QTTS_TEST_VARIANTS") != "1",
-                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: seven extra emulator builds, ~30 min "
+                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: eight extra emulator builds, ~35 min "
                            "-- enable with QTTS_TEST_VARIANTS=1")
 def test_build_variants_agree_with_default_on_emulator(tmp_path):
     """Every kernel-changing build variant, compiled into the emulated library with its -D flag (QTTS_HOSTEMU_DEFS), against
     the default build: sampler_v2 draws the same tokens for the same Philox keys; attn_tail passes the decode-attention
     kernel test (long sequences included) and the talker golden; gu8, cp_pretable and cp_qkvtable reproduce the fp32
-    talker goldens bit for bit and the same bf16 codes as the default build; attn_cp (a different summation order inside the
-    attention) reproduces the fp32 goldens bit for bit and >= 95 % of the default's bf16 codes; so does everything together."""
+    talker goldens bit for bit and the same bf16 codes as the default build; attn_cp and attn_t1 (a different summation order inside the
+    attention) reproduce the fp32 goldens bit for bit and >= 95 % of the default's bf16 codes; so does everything together."""
     import subprocess
     probe = os.path.join(HERE, "hostemu", "variant_probe.py")
     outs = []
@@ -870,8 +871,9 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
                       ("-DQTTS_CP_PRETABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_CP_QKVTABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_ATTN_CP=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
+                      ("-DQTTS_ATTN_T1=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_SAMPLER_V2=1 -DQTTS_SKINNY_GU8=1 -DQTTS_ATTN_TAIL_BATCH=1 -DQTTS_CP_PRETABLE=1 -DQTTS_CP_QKVTABLE=1 "
-                       "-DQTTS_ATTN_CP=1",                                                                                   # "combo"
+                       "-DQTTS_ATTN_CP=1 -DQTTS_ATTN_T1=1",                                                                  # "combo"
                        "talker_orchestration or talker_stream or bf16_small_batch or sampler or attn_decode")):
         env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs, QTTS_PROBE_OUT=str(tmp_path / f"probe{len(probes)}.npy"))
         env.pop("QTTS_TEST_VARIANTS", None)
@@ -880,9 +882,9 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
         assert r.returncode == 0, (defs, r.stdout[-2000:])
         if os.path.exists(env["QTTS_PROBE_OUT"]):
             probes[defs] = np.load(env["QTTS_PROBE_OUT"])
-    assert len(probes) == 7
+    assert len(probes) == 8
     for defs, codes in probes.items():
-        if "ATTN_CP" in defs:             # a different fp32 summation order inside the attention: bf16 codes agree, not bit for bit
+        if "ATTN_CP" in defs or "ATTN_T1" in defs:             # a different fp32 summation order inside the attention: bf16 codes agree, not bit for bit
             assert float((codes == probes[""]).mean()) >= 0.95, defs
         else:                             # same arithmetic in a different schedule: the same bits
             assert np.array_equal(codes, probes[""]), defs
