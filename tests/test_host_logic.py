@@ -655,3 +655,31 @@ def test_no_kernel_spills_or_scratch(libqtts):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert re.search(r"^(\d+) kernels; 0 with spills", out.stdout, re.M), out.stdout[-500:]
     assert int(re.search(r"^(\d+) kernels;", out.stdout, re.M).group(1)) >= 60
+
+
+def test_build_variants_are_opt_in_only():
+    """The product library is the flag-free build: variants (A/B material) get their own file names, carry at least one
+    -DQTTS_ flag each, and nothing in the default flag set or in __graft_entry__.build() selects one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("qtts_build_t", os.path.join(ROOT, "qwen3-tts_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert not any(f.startswith("-DQTTS_") for f in m.FLAGS)
+    assert os.path.basename(m.OUT) == "libqtts.so"
+    for name, flags in m.VARIANTS.items():
+        assert flags and all(f.startswith("-DQTTS_") for f in flags), name
+        assert os.path.basename(m.variant_path(name)) == f"libqtts_{name}.so"
+    with pytest.raises(ValueError):
+        m.build(variant="no_such_variant")
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "variant" not in src
+    from qwen3_tts_amd import _lib
+    if "QTTS_LIBRARY" not in os.environ:
+        assert os.path.basename(_lib.library_path()) == "libqtts.so"
+    # every -D name used by a variant is defaulted to 0 in the sources, so the default build never sees it set
+    csrc = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
+    text = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc))
+    for flags in m.VARIANTS.values():
+        for f in flags:
+            macro = f[2:].split("=")[0]
+            assert re.search(r"#ifndef %s\s*\n#define %s 0" % (macro, macro), text), macro
