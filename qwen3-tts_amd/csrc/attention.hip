@@ -618,6 +618,95 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
         p.out[o + lane + 64] = acc1 * inv;
     }
 }
+
+// Pass 0 of the code predictor: an empty cache and TWO new tokens [past_hidden, embedding of codebook 0] (M:1671-1680).
+// Token 0 attends to itself only, so its output IS its v row (softmax of one score = 1, exactly as the general kernel computes
+// it); token 1 attends to both.  One workgroup per (sequence, kv head): 8 vectors (q of 2 tokens x up to 2 heads, k and v of
+// both tokens) get RMSNorm + RoPE at positions 0 / 1 two per wave, k / v are appended, then wave gq < GQ forms the two-key
+// softmax of query (token 1, head gq).
+template <typename KVT>
+__global__ __launch_bounds__(256) void attn_cp0_kernel(AttnDecodeParams p) {
+    constexpr int HD = 128;
+    __shared__ float q1[2][HD];            // normed + roped q of token 1, per head
+    __shared__ float kn[2][HD], vn[2][HD]; // k (normed, roped, rounded through the cache type) and v (rounded) of both tokens
+    const int GQ = p.nh / p.nkv;
+    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // vector vi = wave + 4 * r:  0..3 -> q(token vi / 2, head vi % 2);  4, 5 -> k(token vi - 4);  6, 7 -> v(token vi - 6)
+    float x0v[2], x1v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int vi = wave + 4 * r;
+        x0v[r] = x1v[r] = 0.f;
+        int t, col;
+        bool have = true;
+        if (vi < 4) { t = vi >> 1; col = (kvh * GQ + (vi & 1)) * HD; have = (vi & 1) < GQ && t == 1; }   // token 0's q is never used
+        else if (vi < 6) { t = vi - 4; col = (p.nh + kvh) * HD; }
+        else { t = vi - 6; col = (p.nh + p.nkv + kvh) * HD; }
+        if (have) {
+            const float* src = p.qkv + ((size_t)t * p.B + b) * p.ld + col;
+            x0v[r] = src[lane]; x1v[r] = src[lane + 64];
+        }
+    }
+    const int done = p.done_flag ? *p.done_flag : 0;
+    if (done) return;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int vi = wave + 4 * r;
+        const int t = vi < 4 ? (vi >> 1) : (vi < 6 ? vi - 4 : vi - 6);
+        if (vi < 4 && ((vi & 1) >= GQ || t == 0)) continue;
+        const float* w = vi < 4 ? p.qw : (vi < 6 ? p.kw : nullptr);
+        float x0 = x0v[r], x1 = x1v[r];
+        if (w) {
+            const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
+            const float rs = rsqrtf(ss / (float)HD + p.eps);
+            x0 = w[lane] * (x0 * rs);
+            x1 = w[lane + 64] * (x1 * rs);
+            const float ang = (float)t * p.inv_freq[lane];
+            const float c = cosf(ang), sn = sinf(ang);
+            const float o0 = x0 * c - x1 * sn, o1 = x1 * c + x0 * sn;
+            x0 = o0; x1 = o1;
+        }
+        if (vi >= 4) {                      // K or V of token t: round through the cache type, append at slot t of page 0
+            const int page = p.kv.contig ? b * p.kv.pages_per_seq : p.kv.page_table[b * p.kv.pages_per_seq];
+            const size_t o = ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + t) * HD;
+            KVT* cdst = reinterpret_cast<KVT*>(vi < 6 ? p.kv.k : p.kv.v);
+            const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
+            cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
+            x0 = kv_load(&h0); x1 = kv_load(&h1);
+            float* dst = vi < 6 ? kn[t] : vn[t];
+            dst[lane] = x0; dst[lane + 64] = x1;
+            if (vi >= 6 && t == 0) {        // token 0's attention output = its own v row, for every head of this kv group
+                for (int gq = 0; gq < GQ; ++gq) {
+                    const size_t oo = (size_t)b * p.ldo + (kvh * GQ + gq) * HD;
+                    if (p.out_bf16) {
+                        reinterpret_cast<bf16_t*>(p.out)[oo + lane] = f32_to_bf16(x0);
+                        reinterpret_cast<bf16_t*>(p.out)[oo + lane + 64] = f32_to_bf16(x1);
+                    } else { p.out[oo + lane] = x0; p.out[oo + lane + 64] = x1; }
+                }
+            }
+        } else if (t == 1) {
+            q1[vi & 1][lane] = x0; q1[vi & 1][lane + 64] = x1;
+        }
+    }
+    __syncthreads();
+    if (wave >= GQ) return;
+    // query (token 1, head `wave`) over keys 0 and 1
+    const float qa = q1[wave][lane], qb = q1[wave][lane + 64];
+    const float scale = rsqrtf((float)HD);
+    const float s0 = wave_sum64_dpp(qa * kn[0][lane] + qb * kn[0][lane + 64]) * scale;
+    const float s1 = wave_sum64_dpp(qa * kn[1][lane] + qb * kn[1][lane + 64]) * scale;
+    const float m = fmaxf(s0, s1);
+    const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+    const float inv = 1.f / (e0 + e1);
+    const float o0 = (e0 * vn[0][lane] + e1 * vn[1][lane]) * inv;
+    const float o1 = (e0 * vn[0][lane + 64] + e1 * vn[1][lane + 64]) * inv;
+    const size_t oo = ((size_t)p.B + b) * p.ldo + (kvh * GQ + wave) * HD;     // row t * B + b with t = 1
+    if (p.out_bf16) {
+        reinterpret_cast<bf16_t*>(p.out)[oo + lane] = f32_to_bf16(o0);
+        reinterpret_cast<bf16_t*>(p.out)[oo + lane + 64] = f32_to_bf16(o1);
+    } else { p.out[oo + lane] = o0; p.out[oo + lane + 64] = o1; }
+}
 #endif  // QTTS_ATTN_CP
 
 #ifndef QTTS_ATTN_T1
@@ -821,6 +910,12 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
     const int GQ = p.nh / p.nkv, NQ = p.n_new * GQ;
     QTTS_REQUIRE((NQ == 1 || NQ == 2 || NQ == 4) && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: 1, 2 or 4 queries per kv head");
 #if QTTS_ATTN_CP
+    if (p.n_new == 2 && !p.len_dev && !p.n_pad && p.len_static == 0 && GQ <= 2) {          // the code predictor's pass 0
+        if (p.kv.bf16) hipLaunchKernelGGL(attn_cp0_kernel<bf16_t>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_cp0_kernel<float>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     if (p.n_new == 1 && !p.len_dev && !p.n_pad && p.len_static + 1 <= 16 && GQ <= 2) {     // the code predictor's passes >= 1
         if (p.kv.bf16) hipLaunchKernelGGL(attn_cp_kernel<bf16_t>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_cp_kernel<float>, dim3(p.B * p.nkv), dim3(256), 0, st, p);

@@ -219,7 +219,7 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
     # npads None + S0 <= 15: the code predictor's call shape (static length, no padding, 32-slot score buffer)
     for (B, n_new, S0, npads, permute) in [(2, 1, 37, [0, 5], False), (3, 2, 130, [0, 17, 64], False), (2, 1, 300, [3, 0], True),
                                            (2, 2, 701, [0, 40], False), (1, 1, 1030, [9], True),
-                                           (3, 1, 1, None, False), (2, 1, 7, None, True), (3, 1, 15, None, False),
+                                           (3, 1, 1, None, False), (2, 1, 7, None, True), (3, 1, 15, None, False), (3, 2, 0, None, False),
                                            (2, 1, 200, [0, 31], True), (3, 1, 252, [5, 0, 100], False), (2, 1, 16, [0, 15], False)]:
         pps = (S0 + n_new + 15) // 16 + 1
         n_pages = B * pps
