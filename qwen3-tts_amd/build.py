@@ -47,7 +47,10 @@ VARIANTS = {
     # attention.hip: attn_t1_kernel for the talker's single-token step when max_seq <= 256 (bf16 cache): per-wave softmax
     # statistics merged once (flash-decoding inside the workgroup), two barriers instead of five.  28 launches x ~11 us.
     "attn_t1": ["-DQTTS_ATTN_T1=1"],
-    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1", "-DQTTS_ATTN_T1=1"],
+    # skinny.hip: row variances of a bf16-staged, normalised GEMM taken after the MFMA loop (they ride on the final barrier):
+    # one workgroup barrier less in front of the first MFMA in ~230 of the 443 GEMM launches of a frame.  Same bits.
+    "late_norm": ["-DQTTS_SKINNY_LATE_NORM=1"],
+    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1", "-DQTTS_ATTN_T1=1", "-DQTTS_SKINNY_LATE_NORM=1"],
 }
 
 

@@ -44,6 +44,9 @@ __device__ inline unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 
 #ifndef QTTS_SKINNY_GU8
 #define QTTS_SKINNY_GU8 0
 #endif
+#ifndef QTTS_SKINNY_LATE_NORM
+#define QTTS_SKINNY_LATE_NORM 0
+#endif
 template <class T>
 __device__ inline T skinny_wload(const T* ptr) {
 #if QTTS_SKINNY_WLOAD == 1
@@ -187,6 +190,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
     if (done) return;
     if constexpr (STAGE) {
         __syncthreads();
+#if QTTS_SKINNY_LATE_NORM
+        if (p.norm && p.x_bf16) {
+            // A/B variant (build.py VARIANTS): rstd is only needed by the epilogue, so the row variances are taken AFTER the
+            // MFMA loop (below) and ride on the final barrier -- one workgroup barrier less in front of the first MFMA.
+        } else
+#endif
         if (p.norm && p.x_bf16) {
             // variance from the bf16 image (what the reference's bf16 path sees): wave w reduces rows w, w+NW, ...
             for (int row = wave; row < p.M; row += NW) {
@@ -282,6 +291,25 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
         if (c + 3 < nchunks) load_chunk(wB, c + 3);
     }
 
+#if QTTS_SKINNY_LATE_NORM
+    if constexpr (STAGE) {
+        if (p.norm && p.x_bf16) {                  // same per-row reduction as above, same bits
+            for (int row = wave; row < p.M; row += NW) {
+                float q = 0.f;
+                for (int c = lane * 8; c < p.K; c += 512) {
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(&xs[row * XS + c]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = __uint_as_float(t[e] << 16), b2 = __uint_as_float(t[e] & 0xffff0000u);
+                        q += a * a + b2 * b2;
+                    }
+                }
+                q = wave_sum64_dpp(q);
+                if (lane == 0) rsum[row * NW] = q;
+            }
+        }
+    }
+#endif
     // ---- 5. cross-wave combine (fixed order) and epilogue by wave 0
     if constexpr (ALIAS) __syncthreads();          // every wave is done reading xs before red overwrites it
 #pragma unroll
@@ -290,6 +318,17 @@ __global__ __launch_bounds__(NW * 64) void skinny_kernel(SkinnyParams p) {
         for (int m = 0; m < MT; ++m) red[((wave * SPW + s) * MT + m) * 64 + lane] = acc[s][m];
     __syncthreads();
     if (wave != 0) return;
+#if QTTS_SKINNY_LATE_NORM
+    if constexpr (STAGE) {
+        if (p.norm && p.x_bf16) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int row = m * 16 + lj;
+                if (row < p.M) rstd_l[m] = rsqrtf(rsum[row * NW] / (float)p.K + p.eps);
+            }
+        }
+    }
+#endif
 
     // v[s][r] = out[row = m*16 + lj][feature = (strip0+s)*16 + lq*4 + r]
 #pragma unroll

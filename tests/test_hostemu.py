@@ -844,7 +844,7 @@ def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
 
 
 @pytest.mark.skipif(os.environ.get("QTTS_TEST_VARIANTS") != "1",
-                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: eight extra emulator builds, ~35 min "
+                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: nine extra emulator builds, ~40 min "
                            "-- enable with QTTS_TEST_VARIANTS=1")
 def test_build_variants_agree_with_default_on_emulator(tmp_path):
     """Every kernel-changing build variant, compiled into the emulated library with its -D flag (QTTS_HOSTEMU_DEFS), against
@@ -872,8 +872,9 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
                       ("-DQTTS_CP_QKVTABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_ATTN_CP=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_ATTN_T1=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
+                      ("-DQTTS_SKINNY_LATE_NORM=1", "talker_orchestration or bf16_small_batch or skinny"),
                       ("-DQTTS_SAMPLER_V2=1 -DQTTS_SKINNY_GU8=1 -DQTTS_ATTN_TAIL_BATCH=1 -DQTTS_CP_PRETABLE=1 -DQTTS_CP_QKVTABLE=1 "
-                       "-DQTTS_ATTN_CP=1 -DQTTS_ATTN_T1=1",                                                                  # "combo"
+                       "-DQTTS_ATTN_CP=1 -DQTTS_ATTN_T1=1 -DQTTS_SKINNY_LATE_NORM=1",                                       # "combo"
                        "talker_orchestration or talker_stream or bf16_small_batch or sampler or attn_decode")):
         env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs, QTTS_PROBE_OUT=str(tmp_path / f"probe{len(probes)}.npy"))
         env.pop("QTTS_TEST_VARIANTS", None)
@@ -882,7 +883,7 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
         assert r.returncode == 0, (defs, r.stdout[-2000:])
         if os.path.exists(env["QTTS_PROBE_OUT"]):
             probes[defs] = np.load(env["QTTS_PROBE_OUT"])
-    assert len(probes) == 8
+    assert len(probes) == 9
     for defs, codes in probes.items():
         if "ATTN_CP" in defs or "ATTN_T1" in defs:             # a different fp32 summation order inside the attention: bf16 codes agree, not bit for bit
             assert float((codes == probes[""]).mean()) >= 0.95, defs
