@@ -12,7 +12,7 @@ from its published behaviour.  Pinned against the reference's ow
 by tests/golden/talker_*.npz (oracle/gen_golden.py).
 """
 from dataclasses import dataclass
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.nn.functional as F

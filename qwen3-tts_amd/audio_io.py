@@ -16,7 +16,6 @@ restates what those calls do for RIFF/WAVE files (the format the reference's exa
 Other containers (flac / ogg / mp3) need libsndfile / audioread and raise ValueError here.  Pure host code: no device
 work, nothing on the hot path."""
 import base64
-import io
 import math
 import struct
 import urllib.request
