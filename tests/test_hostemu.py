@@ -774,6 +774,44 @@ def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
         emu.qtts_talker_destroy(h)
 
 
+def test_talker_orchestration_no_projection_vs_oracle(emu):
+    """The 0.6B models' shape of the code predictor: talker hidden == predictor hidden, so small_to_mtp_projection is the
+    identity (M:1171-1174) and the pass input row is the codec embedding itself.  Greedy fp32 against the oracle, then the bf16
+    serving configuration (batch invariance; QTTS_PROBE_OUT2 dump for the build-variant comparison)."""
+    import dataclasses
+    import talker_ref
+    t = dataclasses.replace(synth.talker_tiny(), hidden_size=128, intermediate_size=256)
+    assert t.hidden_size == t.cp_hidden_size
+    wn = synth.talker_weights(t, with_text=False)
+    assert "code_predictor.small_to_mtp_projection.weight" not in wn
+    w = {k: torch.from_numpy(v) for k, v in wn.items()}
+    lens = [5, 9, 3]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(19), t, lens, 2, scale=0.5)
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    with torch.no_grad():
+        r = talker_ref.talker_generate(w, t, emb, mask, tr, pad, max_new_tokens=5, sp=sp)
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64)
+    try:
+        codes, tokens, _ = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=5)
+        assert np.array_equal(tokens, r["tokens"].numpy()) and np.array_equal(codes, r["codes"].numpy())
+    finally:
+        emu.qtts_talker_destroy(h)
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16)
+    emu.hostemu_set_real_gemm(1)
+    try:
+        c16, _, _ = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=4)
+        n = min(c16.shape[1], r["codes"].shape[1], 2)
+        assert float((c16[:, :n] == r["codes"].numpy()[:, :n]).mean()) >= 0.7
+        one, _, _ = _talker_generate(emu, h, t, emb.numpy()[1:2], mask.numpy()[1:2], tr.numpy()[1:2], pad.numpy(), max_new=4)
+        m = min(one.shape[1], c16.shape[1])
+        assert np.array_equal(one[0, :m], c16[1, :m])
+        if os.environ.get("QTTS_PROBE_OUT"):
+            np.save(os.environ["QTTS_PROBE_OUT"].replace(".npy", "_noproj.npy"), c16)
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
+        emu.qtts_talker_destroy(h)
+
+
 def test_talker_bf16_small_batch_staged_path(emu, golden_dir):
     """The bench configuration's code path at small batch (M = 3 rows per decode step, 6 in the code predictor's first pass):
     bf16 weights and KV, the LDS-staged single-m-tile skinny GEMM with LDS-DMA staging of bf16 activations, narrow strips.
@@ -863,13 +901,13 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
         outs.append(np.load(out))
     assert outs[0].shape == outs[1].shape and outs[0].size >= 900
     assert np.array_equal(outs[0], outs[1]), float((outs[0] != outs[1]).mean())
-    probes = {}
-    for defs, sel in (("", "bf16_small_batch"),
+    probes, probes_np = {}, {}
+    for defs, sel in (("", "bf16_small_batch or no_projection"),
                       ("-DQTTS_SAMPLER_V2=1", "sampler"),
                       ("-DQTTS_ATTN_TAIL_BATCH=1", "attn_decode or talker_orchestration_greedy or bf16_small_batch"),
                       ("-DQTTS_SKINNY_GU8=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_CP_PRETABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
-                      ("-DQTTS_CP_QKVTABLE=1", "talker_orchestration or talker_stream or bf16_small_batch"),
+                      ("-DQTTS_CP_QKVTABLE=1", "talker_orchestration or talker_stream or bf16_small_batch or no_projection"),
                       ("-DQTTS_ATTN_CP=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_ATTN_T1=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_SKINNY_LATE_NORM=1", "talker_orchestration or bf16_small_batch or skinny"),
@@ -883,7 +921,14 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
         assert r.returncode == 0, (defs, r.stdout[-2000:])
         if os.path.exists(env["QTTS_PROBE_OUT"]):
             probes[defs] = np.load(env["QTTS_PROBE_OUT"])
-    assert len(probes) == 9
+        if os.path.exists(env["QTTS_PROBE_OUT"].replace(".npy", "_noproj.npy")):
+            probes_np[defs] = np.load(env["QTTS_PROBE_OUT"].replace(".npy", "_noproj.npy"))
+    assert len(probes) == 9 and len(probes_np) >= 3
+    for defs, codes in probes_np.items():                     # the no-projection (0.6B-shaped) configuration, where it was run
+        if "ATTN_CP" in defs or "ATTN_T1" in defs:
+            assert float((codes == probes_np[""]).mean()) >= 0.95, defs
+        else:
+            assert np.array_equal(codes, probes_np[""]), defs
     for defs, codes in probes.items():
         if "ATTN_CP" in defs or "ATTN_T1" in defs:             # a different fp32 summation order inside the attention: bf16 codes agree, not bit for bit
             assert float((codes == probes[""]).mean()) >= 0.95, defs
