@@ -50,7 +50,9 @@ VARIANTS = {
     # skinny.hip: row variances of a bf16-staged, normalised GEMM taken after the MFMA loop (they ride on the final barrier):
     # one workgroup barrier less in front of the first MFMA in ~230 of the 443 GEMM launches of a frame.  Same bits.
     "late_norm": ["-DQTTS_SKINNY_LATE_NORM=1"],
-    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1", "-DQTTS_ATTN_T1=1", "-DQTTS_SKINNY_LATE_NORM=1"],
+    # sampling.hip: embed_sum_kernel fetches the 15 sub-codes once and requests the embedding rows 8 at a time (same sum order)
+    "embed_sum_v2": ["-DQTTS_EMBED_SUM_V2=1"],
+    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1", "-DQTTS_ATTN_T1=1", "-DQTTS_SKINNY_LATE_NORM=1", "-DQTTS_EMBED_SUM_V2=1"],
 }
 
 

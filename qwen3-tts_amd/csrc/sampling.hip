@@ -318,6 +318,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
 #ifndef QTTS_SAMPLER_V2
 #define QTTS_SAMPLER_V2 0
 #endif
+#ifndef QTTS_EMBED_SUM_V2
+#define QTTS_EMBED_SUM_V2 0
+#endif
 #if QTTS_SAMPLER_V2
 // A/B variant (build.py VARIANTS, never the default build): the sampling path for 0 < top_k <= 64 and V <= 4096 (the
 // reference default is top_k = 50 on 2048 / 3072 logits) with the fixed costs taken out of sample_kernel above:
@@ -680,8 +683,31 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedSumParams p) {
     const int b = blockIdx.x;
     const int f = *p.st.gen_step;          // frame index == generation_step
     const int tok0 = p.cur_tok[b];
+#if QTTS_EMBED_SUM_V2
+    // A/B variant (build.py VARIANTS): the loop below chains token load -> row load -> add 15 times (12.8 us measured for a
+    // kernel that moves 130 KB per row).  Here the 15 tokens are fetched once, then the embedding rows are requested 8 at a
+    // time before any of them is added; the additions stay in codebook order, so the sum has the same bits.
+    __shared__ int tk_s[64];
+    const bool staged_tokens = p.G - 1 <= 64;
+    if (staged_tokens && (int)threadIdx.x < p.G - 1) tk_s[threadIdx.x] = p.sub[(size_t)b * p.sub_stride + threadIdx.x];
+    __syncthreads();
+#endif
     for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
         float4 a = *reinterpret_cast<const float4*>(p.talker_emb + (size_t)tok0 * p.H + c);
+#if QTTS_EMBED_SUM_V2
+        if (staged_tokens) {
+            for (int i0 = 0; i0 < p.G - 1; i0 += 8) {
+                float4 e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u < p.G - 1)
+                        e[u] = *reinterpret_cast<const float4*>(p.cp_emb + ((size_t)(i0 + u) * p.cp_vocab + tk_s[i0 + u]) * p.H + c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u < p.G - 1) { a.x += e[u].x; a.y += e[u].y; a.z += e[u].z; a.w += e[u].w; }
+            }
+        } else
+#endif
         for (int i = 0; i < p.G - 1; ++i) {
             const int tk = p.sub[(size_t)b * p.sub_stride + i];
             const float4 e = *reinterpret_cast<const float4*>(p.cp_emb + ((size_t)i * p.cp_vocab + tk) * p.H + c);

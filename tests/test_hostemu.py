@@ -882,7 +882,7 @@ def test_results_do_not_depend_on_wave_scheduling_order(emu, codec, golden_dir):
 
 
 @pytest.mark.skipif(os.environ.get("QTTS_TEST_VARIANTS") != "1",
-                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: nine extra emulator builds, ~40 min "
+                    reason="A/B build variants (qwen3-tts_amd/build.py VARIANTS) on the emulator: ten extra emulator builds, ~45 min "
                            "-- enable with QTTS_TEST_VARIANTS=1")
 def test_build_variants_agree_with_default_on_emulator(tmp_path):
     """Every kernel-changing build variant, compiled into the emulated library with its -D flag (QTTS_HOSTEMU_DEFS), against
@@ -911,8 +911,9 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
                       ("-DQTTS_ATTN_CP=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_ATTN_T1=1", "attn_decode or talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_SKINNY_LATE_NORM=1", "talker_orchestration or bf16_small_batch or skinny"),
+                      ("-DQTTS_EMBED_SUM_V2=1", "talker_orchestration or talker_stream or bf16_small_batch"),
                       ("-DQTTS_SAMPLER_V2=1 -DQTTS_SKINNY_GU8=1 -DQTTS_ATTN_TAIL_BATCH=1 -DQTTS_CP_PRETABLE=1 -DQTTS_CP_QKVTABLE=1 "
-                       "-DQTTS_ATTN_CP=1 -DQTTS_ATTN_T1=1 -DQTTS_SKINNY_LATE_NORM=1",                                       # "combo"
+                       "-DQTTS_ATTN_CP=1 -DQTTS_ATTN_T1=1 -DQTTS_SKINNY_LATE_NORM=1 -DQTTS_EMBED_SUM_V2=1",                # "combo"
                        "talker_orchestration or talker_stream or bf16_small_batch or sampler or attn_decode")):
         env = dict(os.environ, QTTS_HOSTEMU_DEFS=defs, QTTS_PROBE_OUT=str(tmp_path / f"probe{len(probes)}.npy"))
         env.pop("QTTS_TEST_VARIANTS", None)
@@ -923,7 +924,7 @@ def test_build_variants_agree_with_default_on_emulator(tmp_path):
             probes[defs] = np.load(env["QTTS_PROBE_OUT"])
         if os.path.exists(env["QTTS_PROBE_OUT"].replace(".npy", "_noproj.npy")):
             probes_np[defs] = np.load(env["QTTS_PROBE_OUT"].replace(".npy", "_noproj.npy"))
-    assert len(probes) == 9 and len(probes_np) >= 3
+    assert len(probes) == 10 and len(probes_np) >= 3
     for defs, codes in probes_np.items():                     # the no-projection (0.6B-shaped) configuration, where it was run
         if "ATTN_CP" in defs or "ATTN_T1" in defs:
             assert float((codes == probes_np[""]).mean()) >= 0.95, defs
