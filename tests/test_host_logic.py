@@ -683,3 +683,97 @@ def test_build_variants_are_opt_in_only():
         for f in flags:
             macro = f[2:].split("=")[0]
             assert re.search(r"#ifndef %s\s*\n#define %s 0" % (macro, macro), text), macro
+
+
+def test_ctypes_argtypes_match_the_header(libqtts):
+    """Every entry point's ctypes signature in qwen3-tts_amd/_lib.py against its prototype in include/qtts.h: same number of
+    parameters and the same class of each (pointer / int32 / int64 / float).  The emulator tests declare their own
+    argtypes, so a slip here would otherwise first show on hardware."""
+    import ctypes as C
+    from qwen3_tts_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "qtts.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = dict(re.findall(r"\b(?:int|void|const char\*)\s+(qtts_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", hdr))
+    lib = _lib.load_library()
+
+    def klass_c(param):
+        param = param.strip()
+        if param in ("void", ""):
+            return None
+        if "*" in param:
+            return "ptr"
+        if re.search(r"\bint64_t\b|\blong long\b", param):
+            return "i64"
+        if re.search(r"\bfloat\b", param):
+            return "f32"
+        if re.search(r"\bdouble\b", param):
+            return "f64"
+        if re.search(r"\bint32_t\b|\bint\b|\buint32_t\b|\bunsigned\b", param):
+            return "i32"
+        raise AssertionError(f"unclassified parameter {param!r}")
+
+    def klass_py(t):
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or getattr(t, "_type_", None) is not None and t.__name__.startswith("LP_"):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_int: "i32", C.c_uint32: "i32", C.c_int64: "i64", C.c_uint64: "i64", C.c_float: "f32",
+                C.c_double: "f64"}[t]
+
+    checked = 0
+    for name, params in protos.items():
+        if name.startswith("qtts_debug_"):
+            continue
+        want = [k for k in (klass_c(p) for p in params.split(",")) if k]
+        fn = getattr(lib, name)
+        if fn.argtypes is None:
+            assert not want, f"{name}: header has {len(want)} parameters, the binding declares none"
+            continue
+        got = [klass_py(t) for t in fn.argtypes]
+        assert got == want, f"{name}: binding {got} vs header {want}"
+        checked += 1
+    assert checked >= 30, checked
+
+
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """The six by-pointer structs of include/qtts.h against their ctypes mirrors: field names in order, offsets and total
+    size as gcc lays them out (a probe program compiled from the header prints offsetof / sizeof)."""
+    import ctypes as C
+    from qwen3_tts_amd import _lib
+    hdr_path = os.path.join(ROOT, "include", "qtts.h")
+    hdr = re.sub(r"/\*.*?\*/", "", open(hdr_path).read(), flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    structs = re.findall(r"typedef struct\s*\{(.*?)\}\s*(qtts_[a-z_]+)\s*;", hdr, flags=re.S)
+    mirrors = {"qtts_codec_config": _lib.CodecConfigC, "qtts_talker_config": _lib.TalkerConfigC, "qtts_sampling": _lib.SamplingC,
+               "qtts_encoder_config": _lib.EncoderConfigC, "qtts_speaker_config": _lib.SpeakerConfigC,
+               "qtts_talker_stats": _lib.TalkerStatsC}
+    assert {n for _, n in structs} == set(mirrors), {n for _, n in structs} ^ set(mirrors)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr_path}"', 'int main(void) {']
+    fields = {}
+    for body, name in structs:
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                ident = re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*(?:\[[^\]]*\])?\s*$", part.strip())[0]
+                names.append(ident)
+        fields[name] = names
+        lines.append(f'printf("{name} size %zu\\n", sizeof({name}));')
+        lines += [f'printf("{name} {f} %zu\\n", offsetof({name}, {f}));' for f in names]
+    lines += ['return 0; }']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    got = {}
+    for ln in out:
+        if ln.strip():
+            n, f, v = ln.split()
+            got.setdefault(n, {})[f] = int(v)
+    for name, cls in mirrors.items():
+        py_fields = [f[0] for f in cls._fields_]
+        assert py_fields == fields[name], (name, py_fields, fields[name])
+        assert C.sizeof(cls) == got[name]["size"], (name, C.sizeof(cls), got[name]["size"])
+        for f in py_fields:
+            assert getattr(cls, f).offset == got[name][f], (name, f)
