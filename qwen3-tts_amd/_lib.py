@@ -165,6 +165,16 @@ def locked(fn):
     return wrapper
 
 
+def hip_device(device, who: str):
+    """The torch device an engine lives on.  There is no CPU path: anything but a HIP device ('cuda:N' under PyTorch-ROCm)
+    is refused here, for every engine class."""
+    import torch
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise QttsError(-102, f"{who} requires a HIP device (torch device 'cuda:N'); there is no CPU path")
+    return d
+
+
 def check(rc: int):
     if rc != 0:
         raise QttsError(rc, (load_library().qtts_last_error() or b"").decode(errors="replace"))

@@ -41,9 +41,7 @@ class CodecDecoderEngine:
     def __init__(self, config: Any, state_dict: Dict[str, torch.Tensor], compute_dtype: torch.dtype = torch.float32,
                  device: str = "cuda:0", max_batch: int = 8, max_frames: int = 325):
         self.config = CodecDecoderConfig.from_any(config)
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.QttsError(-102, "CodecDecoderEngine requires a HIP device (torch device 'cuda:N'); there is no CPU path")
+        self.device = _lib.hip_device(device, "CodecDecoderEngine")
         self.compute_dtype = compute_dtype
         self.max_batch, self.max_frames = int(max_batch), int(max_frames)
         self._lib = _lib.load_library()

@@ -82,9 +82,7 @@ class SpeakerEncoderEngine:
     def __init__(self, config: Any, state_dict: Dict[str, torch.Tensor], compute_dtype: torch.dtype = torch.float32,
                  device: str = "cuda:0", max_batch: int = 4, max_samples: int = 24000 * 30):
         self.config = SpeakerEncoderConfig.from_any(config)
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.QttsError(-102, "SpeakerEncoderEngine requires a HIP device (torch device 'cuda:N'); there is no CPU path")
+        self.device = _lib.hip_device(device, "SpeakerEncoderEngine")
         self.max_batch, self.max_samples = int(max_batch), int(max_samples)
         self._lib = _lib.load_library()
         self._lock = threading.RLock()

@@ -38,9 +38,7 @@ class TalkerEngine:
     def __init__(self, config: Any, state_dict: Dict[str, torch.Tensor], weight_dtype: torch.dtype = torch.bfloat16,
                  device: str = "cuda:0", max_batch: int = 8, max_seq: int = 4096, use_graph: bool = True):
         self.config = TalkerConfig.from_any(config)
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.QttsError(-102, "TalkerEngine requires a HIP device (torch device 'cuda:N'); there is no CPU path")
+        self.device = _lib.hip_device(device, "TalkerEngine")
         self.weight_dtype = weight_dtype
         self.max_batch, self.max_seq = int(max_batch), int(max_seq)
         self._lib = _lib.load_library()

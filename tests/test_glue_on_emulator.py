@@ -1,0 +1,124 @@
+"""CPU: the product's PYTHON layer -- engine classes, ctypes calls, tensor plumbing -- and the GPU parity TEST BODIES of the
+rows that have not met the hardware yet, executed against the host-emulation build of the same C++ / HIP sources
+(tests/hostemu: device memory = host memory, every kernel on the SIMT emulator).
+
+tests/test_hostemu.py drives the C ABI with numpy arrays; what it cannot see is the Python between the user and that ABI
+(`CodecEncoderEngine`, `SpeakerEncoderEngine`, `CodecDecoderEngine.stream_*`, `TalkerEngine.generate_stream`, the wrappers).
+Here that Python runs unmodified: the library it loads is the emulation build (QTTS_LIBRARY), the one place that insists on
+a HIP device (`_lib.hip_device`) is told to hand out the CPU device, and the handful of `torch.cuda.*` stream / context
+calls are replaced by inert stand-ins.  The test functions called below are the ones in tests/test_gpu_parity.py, i.e. exactly
+what `QTTS_EXPERIMENTAL=1 pytest -m gpu` will run on the MI355X -- so a slip in the Python glue, or in the tests themselves,
+shows here first.  Nothing of this is reachable from the product: the product refuses a CPU device."""
+import contextlib
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _FakeStream:
+    cuda_stream = 0
+
+    def __init__(self, *a, **k):
+        pass
+
+    def wait_stream(self, other):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+class _NullDeviceCtx(contextlib.AbstractContextManager):
+    def __init__(self, *a, **k):
+        pass
+
+    def __exit__(self, *exc):
+        return False
+
+
+@pytest.fixture(scope="module")
+def glue():
+    sys.path.insert(0, os.path.join(HERE, "hostemu"))
+    import build as hostemu_build
+    from qwen3_tts_amd import _lib
+    so = hostemu_build.build()
+    saved_lib, saved_env = _lib._LIB, os.environ.get("QTTS_LIBRARY")
+    os.environ["QTTS_LIBRARY"] = so
+    _lib._LIB = None
+    patches = [
+        mock.patch.object(_lib, "hip_device", lambda device, who: torch.device("cpu")),
+        mock.patch.object(torch.cuda, "device", _NullDeviceCtx),
+        mock.patch.object(torch.cuda, "current_stream", lambda *a, **k: _FakeStream()),
+        mock.patch.object(torch.cuda, "Stream", _FakeStream),
+        mock.patch.object(torch.cuda, "stream", lambda s: contextlib.nullcontext()),
+        mock.patch.object(torch.cuda, "synchronize", lambda *a, **k: None),
+        mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self),
+    ]
+    for p in patches:
+        p.start()
+    try:
+        assert os.path.basename(_lib.library_path()).startswith("libqtts_hostemu")
+        _lib.load_library()
+        import test_gpu_parity as gp
+        yield gp
+    finally:
+        for p in reversed(patches):
+            p.stop()
+        _lib._LIB = saved_lib
+        if saved_env is None:
+            os.environ.pop("QTTS_LIBRARY", None)
+        else:
+            os.environ["QTTS_LIBRARY"] = saved_env
+
+
+def _codec_tiny(gp, golden_dir):
+    import synth
+    from qwen3_tts_amd.codec import CodecDecoderEngine
+    c = synth.codec_tiny()
+    w = gp._td(synth.codec_weights(c))
+    g = np.load(os.path.join(golden_dir, "codec_tiny.npz"))
+    return c, w, g, CodecDecoderEngine(c, w, compute_dtype=torch.float32, device="cpu", max_batch=4, max_frames=64)
+
+
+def _talker_tiny(gp, golden_dir):
+    import synth
+    t = synth.talker_tiny()
+    return t, gp._td(synth.talker_weights(t)), np.load(os.path.join(golden_dir, "talker_tiny.npz"))
+
+
+def test_state_carrying_codec_stream_python_path(glue, golden_dir):
+    """`CodecDecoderEngine.stream_begin / stream_push`: the gated GPU test body, on the emulator."""
+    glue.test_codec_incremental_stream_equals_forward(_codec_tiny(glue, golden_dir))
+
+
+def test_codec_encoder_python_path(glue, golden_dir):
+    """`CodecEncoderEngine.encode_padded / encode` (f3) against the reference's encoder golden: the gated GPU test body."""
+    glue.test_codec_encoder_codes_vs_reference_golden("cpu", golden_dir)
+
+
+def test_speaker_encoder_python_path(glue):
+    """`SpeakerEncoderEngine.embed / extract_speaker_embedding` (f4) against the oracle: the gated GPU test body."""
+    glue.test_speaker_embedding_vs_oracle("cpu")
+
+
+FULL = os.environ.get("QTTS_GLUE_FULL") == "1"      # the default CPU suite keeps to the cases that add something new per minute
+
+
+@pytest.mark.parametrize("graph", [pytest.param(False, marks=pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1")), True])
+def test_talker_generate_stream_python_path(glue, golden_dir, graph):
+    """`TalkerEngine.generate_stream` (streaming output): the gated GPU test body, eager and through the captured frame graph."""
+    glue.test_talker_generate_stream_equals_generate(_talker_tiny(glue, golden_dir), "cpu", graph)
+
+
+@pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1")
+def test_validated_python_paths_still_hold_on_the_emulator(glue, golden_dir):
+    """Two of the hardware-validated test bodies through the same harness, as its own control: if these fail here the harness
+    is wrong, not the product."""
+    glue.test_codec_stream_decoder_packets(_codec_tiny(glue, golden_dir))
+    glue.test_talker_tiny_greedy_bit_exact(_talker_tiny(glue, golden_dir), "cpu", False)
