@@ -122,3 +122,10 @@ def test_validated_python_paths_still_hold_on_the_emulator(glue, golden_dir):
     is wrong, not the product."""
     glue.test_codec_stream_decoder_packets(_codec_tiny(glue, golden_dir))
     glue.test_talker_tiny_greedy_bit_exact(_talker_tiny(glue, golden_dir), "cpu", False)
+
+
+def test_voice_clone_wrapper_end_to_end_python_path(glue, tmp_path):
+    """`create_voice_clone_prompt` + `generate_voice_clone` from a reference WAVE file (BASELINE config 5's call sequence):
+    audio_io -> codec encoder -> speaker encoder -> device prompt assembly -> talker -> decoder -> ICL cut, every engine the
+    emulated build of its real sources -- the gated GPU test body."""
+    glue.test_wrapper_voice_clone_from_waveform_end_to_end("cpu", tmp_path)

@@ -657,3 +657,69 @@ def test_talker_generate_stream_equals_generate(talker_tiny, dev, graph):
     assert np.array_equal(first, g["codes"][:, :2])
     out = eng.generate(*args, **kw)                              # the engine is reusable afterwards
     assert np.array_equal(out.codes.cpu().numpy(), g["codes"])
+
+
+@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
+                    reason="voice clone from a reference WAVEFORM goes through the codec encoder and the speaker encoder, which "
+                           "have not had their first hardware run -- enable with QTTS_EXPERIMENTAL=1")
+def test_wrapper_voice_clone_from_waveform_end_to_end(dev, tmp_path):
+    """BASELINE config 5's call sequence on one tiny Base-type model (examples/test_model_12hz_base.py): a reference WAVE file
+    -> `create_voice_clone_prompt` (audio_io -> codec encoder -> ref codes; speaker encoder -> x-vector) -> `generate_voice_clone`
+    in ICL and in x-vector-only mode -> waveforms.  The two encoders, the prompt assembly, the talker and the decoder are each
+    checked against the oracle elsewhere; this checks the wiring between them: the prompt items are what the engines
+    produce on their own, the direct call equals the call through precomputed prompt items, the ICL cut (IM:622-631) leaves
+    exactly the generated frames, and a second identical call reproduces the first."""
+    import dataclasses
+    import wave
+    from qwen3_tts_amd.model import Qwen3TTSForConditionalGeneration, Qwen3TTSModel
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    t = synth.talker_tiny()
+    G = t.num_code_groups
+    c = synth.codec_tiny()
+    c.codebook_size = t.cp_vocab_size
+    enc = dataclasses.replace(synth.mimi_enc_small(), num_quantizers=G, encoder_valid_num_quantizers=G)
+    spk = dataclasses.replace(synth.speaker_small(), enc_dim=t.hidden_size)
+    assert c.num_quantizers == G and enc.codebook_size <= t.cp_vocab_size
+    sd = dict(synth.talker_weights(t))
+    sd.update({"speaker_encoder." + k: v for k, v in synth.speaker_weights(spk).items()})
+    tok_sd = dict(synth.codec_weights(c))
+    tok_sd.update({"encoder." + k: v for k, v in synth.mimi_enc_weights(enc).items()})
+    cfgd = dict(synth.cfg_dict(t), tts_model_type="base", tts_model_size="1b7", tokenizer_type="12hz",
+                speaker_encoder_config=synth.cfg_dict(spk))
+    tok_cfg = dict(synth.cfg_dict(c), encoder_config=synth.cfg_dict(enc), encoder_valid_num_quantizers=G,
+                   encode_downsample_rate=enc.encode_downsample_rate, input_sample_rate=24000)
+    model = Qwen3TTSForConditionalGeneration(cfgd, _td(sd), device=dev, dtype=torch.float32, max_batch=2, max_seq=512)
+    model.load_speech_tokenizer(Qwen3TTSTokenizer.from_state_dict(tok_cfg, _td(tok_sd), device=dev, max_batch=2, max_frames=320))
+
+    class FakeProcessor:                               # deterministic stand-in for the HF text tokenizer
+        def __call__(self, text=None, return_tensors="pt", padding=True):
+            body = [(ord(ch) * 7) % 490 for ch in text if ch not in "<|>_\\n"][:24]
+            a, n = 77, 198
+            return {"input_ids": torch.tensor([[t.im_start_token_id, a, n] + body + [t.im_end_token_id, n, t.im_start_token_id, a, n]])}
+    tts = Qwen3TTSModel(model, FakeProcessor(), generate_defaults={})
+    n = 2048                                            # 128 reference frames at this encoder's 16 samples per frame
+    ref = (np.random.default_rng(4).standard_normal(n) * 0.2).clip(-1, 1)
+    path = str(tmp_path / "ref.wav")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(24000)
+        f.writeframes((ref * 32767).astype("<i2").tobytes())
+    kw = dict(do_sample=False, subtalker_dosample=False, max_new_tokens=7)
+    items = tts.create_voice_clone_prompt(ref_audio=path, ref_text="reference words")
+    assert len(items) == 1 and items[0].icl_mode and items[0].ref_code.shape == (n // enc.encode_downsample_rate, G)
+    wav16 = (ref * 32767).astype("<i2").astype(np.float32) / 32768.0          # what a 16-bit WAVE file holds (libsndfile scaling)
+    own_codes = model.speech_tokenizer.encode(wav16, sr=24000).audio_codes[0]
+    assert torch.equal(items[0].ref_code.cpu(), own_codes.cpu())
+    own_emb = model.extract_speaker_embedding(audio=wav16, sr=24000)
+    assert items[0].ref_spk_embedding.shape == (t.hidden_size,) and torch.allclose(items[0].ref_spk_embedding.cpu(), own_emb.cpu())
+    w1, sr = tts.generate_voice_clone(text="clone me", language="english", voice_clone_prompt=items, **kw)
+    w2, _ = tts.generate_voice_clone(text="clone me", language="english", ref_audio=path, ref_text="reference words", **kw)
+    assert sr == 24000 and len(w1) == 1 and w1[0].dtype == np.float32 and np.isfinite(w1[0]).all()
+    assert w1[0].shape == w2[0].shape and np.array_equal(w1[0], w2[0])
+    up = c.total_upsample
+    assert w1[0].shape[0] % up == 0 and 1 <= w1[0].shape[0] // up <= 6          # only the generated frames survive the ICL cut
+    wx, _ = tts.generate_voice_clone(text=["clone me", "and me"], language=["english", "chinese"], ref_audio=path,
+                                     x_vector_only_mode=True, **kw)
+    assert len(wx) == 2 and all(np.isfinite(w_).all() and w_.shape[0] % up == 0 and w_.shape[0] > 0 for w_ in wx)
+    wx2, _ = tts.generate_voice_clone(text=["clone me", "and me"], language=["english", "chinese"], ref_audio=path,
+                                      x_vector_only_mode=True, **kw)
+    assert all(np.array_equal(a, b) for a, b in zip(wx, wx2))
