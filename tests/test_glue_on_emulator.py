@@ -129,3 +129,8 @@ def test_voice_clone_wrapper_end_to_end_python_path(glue, tmp_path):
     audio_io -> codec encoder -> speaker encoder -> device prompt assembly -> talker -> decoder -> ICL cut, every engine the
     emulated build of its real sources -- the gated GPU test body."""
     glue.test_wrapper_voice_clone_from_waveform_end_to_end("cpu", tmp_path)
+
+
+def test_stream_custom_voice_wrapper_python_path(glue):
+    """`Qwen3TTSModel.stream_custom_voice` (PCM packets) equals `generate_custom_voice`: the gated GPU test body."""
+    glue.test_wrapper_stream_custom_voice_equals_one_shot("cpu")

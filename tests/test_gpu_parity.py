@@ -723,3 +723,52 @@ def test_wrapper_voice_clone_from_waveform_end_to_end(dev, tmp_path):
     wx2, _ = tts.generate_voice_clone(text=["clone me", "and me"], language=["english", "chinese"], ref_audio=path,
                                       x_vector_only_mode=True, **kw)
     assert all(np.array_equal(a, b) for a, b in zip(wx, wx2))
+
+
+@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
+                    reason="streaming output sits on the resumable talker generation, which has not had its first hardware run "
+                           "-- enable with QTTS_EXPERIMENTAL=1")
+def test_wrapper_stream_custom_voice_equals_one_shot(dev):
+    """`Qwen3TTSModel.stream_custom_voice` (PCM packets every k frames, BASELINE config 4) against `generate_custom_voice` on
+    the same requests: the packets of each request concatenate to its one-shot waveform (utterances shorter than the
+    25-frame decode context, so the packet rule and the one-shot rule see the same frames), rows that finish early stop
+    yielding, and the packet sizes are what was asked for."""
+    from qwen3_tts_amd.model import Qwen3TTSForConditionalGeneration, Qwen3TTSModel
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    t = synth.talker_tiny()
+    c = synth.codec_tiny()
+    c.codebook_size = t.cp_vocab_size
+    cfgd = dict(synth.cfg_dict(t), tts_model_type="custom_voice", tts_model_size="1b7", tokenizer_type="12hz")
+    model = Qwen3TTSForConditionalGeneration(cfgd, _td(synth.talker_weights(t)), device=dev, dtype=torch.float32, max_batch=4, max_seq=128)
+    model.load_speech_tokenizer(Qwen3TTSTokenizer.from_state_dict(synth.cfg_dict(c), _td(synth.codec_weights(c)), device=dev,
+                                                                  max_batch=4, max_frames=64))
+
+    class FakeProcessor:
+        def __call__(self, text=None, return_tensors="pt", padding=True):
+            body = [(ord(ch) * 7) % 490 for ch in text if ch not in "<|>_\\n"][:40]
+            a, n = 77, 198
+            if text.startswith("<|im_start|>user"):
+                ids = [t.im_start_token_id] + body + [t.im_end_token_id, n]
+            else:
+                ids = [t.im_start_token_id, a, n] + body + [t.im_end_token_id, n, t.im_start_token_id, a, n]
+            return {"input_ids": torch.tensor([ids])}
+    tts = Qwen3TTSModel(model, FakeProcessor(), generate_defaults={})
+    texts, spk, langs = ["hello world", "a rather longer sentence to speak"], ["vivian", "ryan"], ["english", "chinese"]
+    kw = dict(do_sample=False, subtalker_dosample=False, max_new_tokens=11)
+    # streaming text input in both calls (the wrapper's default for streaming output), so both see the same prompt
+    whole, sr = tts.generate_custom_voice(texts, spk, language=langs, non_streaming_mode=False, **kw)
+    up = c.total_upsample
+    for k in (3, 4):
+        got = [[] for _ in texts]
+        n_packets = 0
+        for packet, sr2 in tts.stream_custom_voice(texts, spk, language=langs, packet_frames=k, **kw):
+            assert sr2 == sr == 24000 and len(packet) == len(texts)
+            n_packets += 1
+            for i, p in enumerate(packet):
+                assert p.dtype == np.float32 and p.shape[0] % up == 0 and p.shape[0] // up <= k
+                got[i].append(p)
+        assert n_packets >= 2
+        for i, parts in enumerate(got):
+            cat = np.concatenate(parts)
+            assert cat.shape == whole[i].shape, (k, i, cat.shape, whole[i].shape)
+            assert _rms(cat, whole[i]) <= 1e-5, (k, i)

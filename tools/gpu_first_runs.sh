@@ -23,7 +23,7 @@ run() {   # run <name> <timeout-s> <command...>
 run validated_suite 600 env -u QTTS_EXPERIMENTAL python -m pytest tests -q -m gpu -x
 for t in test_codec_incremental_stream_equals_forward test_codec_encoder_codes_vs_reference_golden \
          test_speaker_embedding_vs_oracle "test_talker_generate_stream_equals_generate" \
-         test_wrapper_voice_clone_from_waveform_end_to_end; do
+         test_wrapper_voice_clone_from_waveform_end_to_end test_wrapper_stream_custom_voice_equals_one_shot; do
     run "exp_$t" 180 python -m pytest tests/test_gpu_parity.py -q -x -s -k "$t"
 done
 run bench 420 python bench.py --steps 3 --warmup 1
