@@ -110,7 +110,8 @@ def test_speaker_encoder_python_path(glue):
 FULL = os.environ.get("QTTS_GLUE_FULL") == "1"      # the default CPU suite keeps to the cases that add something new per minute
 
 
-@pytest.mark.parametrize("graph", [pytest.param(False, marks=pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1")), True])
+@pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1 (the streaming wrapper test below goes through generate_stream too)")
+@pytest.mark.parametrize("graph", [False, True])
 def test_talker_generate_stream_python_path(glue, golden_dir, graph):
     """`TalkerEngine.generate_stream` (streaming output): the gated GPU test body, eager and through the captured frame graph."""
     glue.test_talker_generate_stream_equals_generate(_talker_tiny(glue, golden_dir), "cpu", graph)
