@@ -11,8 +11,13 @@ sampling, hipGraph) -> Qwen3-TTS-Tokenizer-12Hz codec decode of every utterance 
 Workload = BASELINE.json's metric config: Qwen3-TTS-12Hz-1.7B dims, batch 8, 10 s (125 frames) per utterance,
 default sampling (T 0.9, top-k 50, rep 1.05), seeded random weights (no checkpoint exists offline), bf16.
 
-With N > 1 every rank runs its own batch (request sharding, no data-path collective): weak
-scaling; value = all ranks' speech tokens / max-over-ranks time.
+With N > 1 every rank runs its own batch (request sharding, no data-path collective) and every step ends
+with the shard's one exchange -- the waveforms gathered on rank 0 (`sharding.gather_padded`, nccl = RCCL over xGMI), inside
+the timed region: weak scaling; value = all ranks' speech tokens / max-over-ranks time.
+
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment launches the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) and fails loudly when the
+box has fewer than N GPUs; under an existing launcher (WORLD_SIZE set) it is one rank of that job.
 
 Prints ONE JSON line on rank 0.  Extra legs (rank 0, N = 1 only, outside the timed region):
   roofline      HIP-event timing of every launch of the dominant kernel (skinny weight-streaming GEMM) over one
@@ -42,6 +47,28 @@ def synth_prompt(rng, cfg, lens, n_trail, scale=0.05):
     return synth.rand_prompt(rng, cfg, lens, n_trail, scale)
 
 
+def self_launch(n_gpus, argv, backend):
+    """`--gpus N` (N > 1) outside a torch.distributed launcher: start the N ranks of this node here, one per GPU, and
+    return the launcher's exit code.  Refuses (exit code 2) when the box has fewer than N GPUs -- never a silent 1-rank run."""
+    import socket
+    import subprocess
+    if backend == "nccl":
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n_gpus:
+            print(f"[bench] FATAL: --gpus {n_gpus} but this box exposes {have} GPU(s); refusing to run fewer ranks than asked",
+                  file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("self-launch: " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,12 +79,27 @@ def main():
     ap.add_argument("--frames", type=int, default=125, help="codec frames per utterance (125 = 10 s)")
     ap.add_argument("--greedy", action="store_true", help="greedy decode instead of the default sampling")
     ap.add_argument("--codec-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--talker-dtype", default="bf16", choices=["bf16", "f32"],
+                    help="bf16 = the benchmarked mode (the reference examples' dtype); f32 = the exact-fp32 parity mode")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-budget-s", type=float, default=90.0, help="wall-clock cap of the CPU-baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 job (nccl = RCCL; gloo only for the CPU launcher test)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.backend))
+    # TEST HOOK (tests/test_host_logic.py, launcher test): run the product's Python against the host-emulation build of the
+    # library so that the N-rank launch path executes on a CPU container.  The output line is marked as not-a-measurement.
+    hostemu = os.environ.get("QTTS_BENCH_HOSTEMU") == "1"
+    if hostemu:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hostemu"))
+        import pyshim
+        pyshim.install()
 
     import numpy as np
     import torch
@@ -69,14 +111,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.gpus != world:
+        print(f"[bench] FATAL: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
+        from qwen3_tts_amd.sharding import gather_padded
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    dev = "cpu" if hostemu else f"cuda:{local_rank}"
+    if not hostemu:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
 
     tcfg = {"1.7b": synth.talker_17b, "0.6b": synth.talker_06b, "tiny": synth.talker_tiny}[args.model]()
     ccfg = synth.codec_tiny() if args.model == "tiny" else synth.codec_real()
@@ -86,7 +134,7 @@ def main():
     cw_np = synth.codec_weights(ccfg)
     td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
     lens = [24 + 4 * (i % 8) + 12 for i in range(B)]          # 128-char prompts ~ 24..52 text tokens + 12 prefix rows
-    talker = TalkerEngine(tcfg, td(tw_np), weight_dtype=torch.bfloat16, device=dev, max_batch=B,
+    talker = TalkerEngine(tcfg, td(tw_np), weight_dtype=torch.bfloat16 if args.talker_dtype == "bf16" else torch.float32, device=dev, max_batch=B,
                           max_seq=max(lens) + F + 8, use_graph=not args.no_graph)
     codec = CodecDecoderEngine(ccfg, td(cw_np), compute_dtype=torch.bfloat16 if args.codec_dtype == "bf16" else torch.float32,
                                device=dev, max_batch=B, max_frames=min(F, 300) + 25)
@@ -108,6 +156,8 @@ def main():
         out = talker.generate(emb, mask, trailing, pad, seed=seed, **gen_kw)
         assert out.n_frames == F, f"expected {F} frames, got {out.n_frames}"
         wav, wl = codec.decode_padded(out.codes)
+        if dist is not None:                  # the request shard's one exchange: every rank's waveforms land on rank 0
+            gather_padded(wav, torch.as_tensor(wl), None)
         return out, wav, wl
 
     for i in range(args.warmup):
@@ -119,6 +169,8 @@ def main():
     torch.cuda.synchronize()
     t_ar = 0.0
     t_codec = 0.0
+    t_gather = 0.0
+    gathered = None
     t1 = time.perf_counter()
     for i in range(args.steps):
         ta = time.perf_counter()
@@ -129,7 +181,12 @@ def main():
         assert out.n_frames == F
         wav, wl = codec.decode_padded(out.codes)
         torch.cuda.synchronize()            # split the two legs for the breakdown fields (a few us per step)
-        t_codec += time.perf_counter() - tb
+        tc = time.perf_counter()
+        t_codec += tc - tb
+        if dist is not None:
+            gathered = gather_padded(wav, torch.as_tensor(wl), None)
+            torch.cuda.synchronize()
+            t_gather += time.perf_counter() - tc
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -137,9 +194,13 @@ def main():
     elapsed = time.perf_counter() - t1
     log(f"timed region: {elapsed:.3f}s for {args.steps} steps")
     if dist is not None:
-        tt = torch.tensor([elapsed, t_ar, t_codec], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, t_ar, t_codec, t_gather], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, t_ar, t_codec = float(tt[0]), float(tt[1]), float(tt[2])
+        elapsed, t_ar, t_codec, t_gather = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
+        if rank == 0:                         # the gather really delivered every rank's batch
+            gw, gl = gathered
+            assert tuple(gw.shape) == (world, B, wav.shape[1]) and bool((gl == F * ccfg.total_upsample).all())
+            assert bool(torch.isfinite(gw).all())
     assert all(int(x) == F * ccfg.total_upsample for x in wl)
     assert bool(torch.isfinite(wav).all())
 
@@ -151,7 +212,7 @@ def main():
         "metric": "speech-tokens/sec (+ audio RTF), Qwen3-TTS-12Hz-1.7B batch=8",
         "value": round(value, 1), "unit": "speech-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if args.talker_dtype == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": f"Qwen3-TTS-12Hz-{args.model} dims, seeded random weights, batch={B} per GPU, ragged prompts "
                                f"{min(lens)}..{max(lens)} rows, {F} frames ({F * 0.08:.1f} s) per utterance, "
                                f"{'greedy' if args.greedy else 'sampling T=0.9 top-k=50 rep=1.05'}; prefill + AR decode "
@@ -163,7 +224,15 @@ def main():
         "ar_ms_per_frame": round(1000 * t_ar / (args.steps * F), 4),     # prefill + first token amortised in
         "codec_ms_per_step": round(1000 * t_codec / args.steps, 2),
         "build_seconds": round(build_s, 1),
+        "timed_region": "seam S2 -> device waveform: talker prefill + AR decode + codec decode"
+                        + (" + gather of all ranks' waveforms on rank 0 (RCCL)" if world > 1 else "")
+                        + "; prompt embeddings already in HBM (tokenisation, prompt assembly a1/f1 and D2H are outside)",
     }
+    if world > 1:
+        res["gather_ms_per_step"] = round(1000 * t_gather / args.steps, 3)
+        res["backend"] = args.backend
+    if hostemu:
+        res["INVALID"] = "host emulation build (QTTS_BENCH_HOSTEMU=1): launcher test only, not a measurement"
 
     if rank == 0:                      # extra legs, outside the timed region: roofline at any N, cpu_baseline at N = 1
         st = talker.stats()
@@ -186,21 +255,30 @@ def main():
                 bytes_per_launch = wbytes / per_frame
                 avg_ms = ms / launches
                 ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-                traffic = None
+                traffic, traffic_src = None, None
                 try:     # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), x2 gfx950 correction
                     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                        traffic = json.load(f).get(args.model, {}).get("bytes_per_launch")
+                        tj = json.load(f)
+                    traffic = tj.get(args.model, {}).get("bytes_per_launch")
+                    traffic_src = ("profiles/pmc_traffic.json (builder-run rocprofv3 --pmc FETCH_SIZE pass: "
+                                   + str(tj.get(args.model, {}).get("source", tj.get("source", "see profiles/"))) + "), not measured by this run")
                 except Exception:
                     pass
                 res["roofline"] = {"bound": "hbm", "kernel": "skinny_kernel (weight-streaming decode GEMM)",
                                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                    "launches_per_frame": per_frame, "avg_launch_us": round(1000 * avg_ms, 3),
                                    "algorithmic_bytes_per_launch": round(bytes_per_launch)}
         log("roofline leg done")
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, args.cpu_frames, args.cpu_budget_s)
             log("cpu baseline done")
+            try:     # the reference's OWN modules (via oracle/ref_shims.py) cannot run on the GPU box (no /root/reference there):
+                     # their timing on the build container is carried as a second, clearly labelled number
+                with open(os.path.join(ROOT, "profiles", "reference_cpu_timing.json")) as f:
+                    res["cpu_baseline_reference"] = json.load(f).get(args.model)
+            except Exception:
+                res["cpu_baseline_reference"] = None
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -67,3 +67,21 @@ def gather_waveforms(local_wavs: List[np.ndarray], local_indices: List[int], n_t
             if idx >= 0:
                 out[idx] = b[j, :ln].copy()
     return out
+
+
+def gather_padded(wav: torch.Tensor, lengths: torch.Tensor, group=None):
+    """The request shard's exchange for DEVICE-resident results: every rank holds one padded batch `wav (B, L) float32` and
+    `lengths (B,) int64` on its own device; rank 0 receives all of them with two `torch.distributed.gather` calls (nccl =
+    RCCL over xGMI: one (B, L) tensor per rank, ~0.96 MB per 10 s utterance) and returns `(wavs (world, B, L), lens (world, B))`
+    still on the device; other ranks return None.  Shapes must agree across ranks (the bench's fixed-length utterances; the
+    variable-length serving path is `gather_waveforms`)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    wav = wav.contiguous()
+    lengths = lengths.to(device=wav.device, dtype=torch.int64).contiguous()
+    wl = [torch.empty_like(wav) for _ in range(world)] if rank == 0 else None
+    ll = [torch.empty_like(lengths) for _ in range(world)] if rank == 0 else None
+    dist.gather(wav, wl, dst=0, group=group)
+    dist.gather(lengths, ll, dst=0, group=group)
+    if rank != 0:
+        return None
+    return torch.stack(wl), torch.stack(ll)

@@ -9,10 +9,8 @@ a HIP device (`_lib.hip_device`) is told to hand out the CPU device, and the han
 calls are replaced by inert stand-ins.  The test functions called below are the ones in tests/test_gpu_parity.py, i.e. exactly
 what `QTTS_EXPERIMENTAL=1 pytest -m gpu` will run on the MI355X -- so a slip in the Python glue, or in the tests themselves,
 shows here first.  Nothing of this is reachable from the product: the product refuses a CPU device."""
-import contextlib
 import os
 import sys
-from unittest import mock
 
 import numpy as np
 import pytest
@@ -21,60 +19,16 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-class _FakeStream:
-    cuda_stream = 0
-
-    def __init__(self, *a, **k):
-        pass
-
-    def wait_stream(self, other):
-        pass
-
-    def synchronize(self):
-        pass
-
-
-class _NullDeviceCtx(contextlib.AbstractContextManager):
-    def __init__(self, *a, **k):
-        pass
-
-    def __exit__(self, *exc):
-        return False
-
-
 @pytest.fixture(scope="module")
 def glue():
     sys.path.insert(0, os.path.join(HERE, "hostemu"))
-    import build as hostemu_build
-    from qwen3_tts_amd import _lib
-    so = hostemu_build.build()
-    saved_lib, saved_env = _lib._LIB, os.environ.get("QTTS_LIBRARY")
-    os.environ["QTTS_LIBRARY"] = so
-    _lib._LIB = None
-    patches = [
-        mock.patch.object(_lib, "hip_device", lambda device, who: torch.device("cpu")),
-        mock.patch.object(torch.cuda, "device", _NullDeviceCtx),
-        mock.patch.object(torch.cuda, "current_stream", lambda *a, **k: _FakeStream()),
-        mock.patch.object(torch.cuda, "Stream", _FakeStream),
-        mock.patch.object(torch.cuda, "stream", lambda s: contextlib.nullcontext()),
-        mock.patch.object(torch.cuda, "synchronize", lambda *a, **k: None),
-        mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self),
-    ]
-    for p in patches:
-        p.start()
+    import pyshim
+    pyshim.install()
     try:
-        assert os.path.basename(_lib.library_path()).startswith("libqtts_hostemu")
-        _lib.load_library()
         import test_gpu_parity as gp
         yield gp
     finally:
-        for p in reversed(patches):
-            p.stop()
-        _lib._LIB = saved_lib
-        if saved_env is None:
-            os.environ.pop("QTTS_LIBRARY", None)
-        else:
-            os.environ["QTTS_LIBRARY"] = saved_env
+        pyshim.uninstall()
 
 
 def _codec_tiny(gp, golden_dir):

@@ -1,6 +1,7 @@
 """CPU: host-side logic that needs no GPU -- C-ABI surface, configuration views, request sharding
 (world_size-2 gloo), input normalisation errors of the mirrored API."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -97,6 +98,59 @@ def test_gather_waveforms_gloo_world2(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GATHER_OK" in r.stdout
+
+
+def test_bench_gpus_n_refuses_to_run_fewer_ranks():
+    """`python bench.py --gpus 2` on a box with < 2 GPUs must fail loudly (exit code 2), never print an n_gpus: 1 line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                       text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")})
+    assert r.returncode == 2, r.stdout + r.stderr
+    assert "FATAL" in r.stderr and "refusing" in r.stderr
+    assert "{" not in r.stdout
+
+
+def test_bench_self_launches_two_ranks_gloo_on_the_emulator():
+    """`python bench.py --gpus 2` starts its own 2-rank torch.distributed job; every step ends with the request shard's
+    gather on rank 0.  Here: gloo backend, tiny dims, the host-emulation build of the library (QTTS_BENCH_HOSTEMU=1 -- the
+    line is marked INVALID as a measurement); on an N-GPU box the same path runs nccl = RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["QTTS_BENCH_HOSTEMU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "tiny",
+                        "--batch", "2", "--frames", "3", "--steps", "1", "--warmup", "0", "--no-roofline", "--no-cpu-baseline",
+                        "--talker-dtype", "f32", "--codec-dtype", "f32"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["backend"] == "gloo"
+    assert j["gather_ms_per_step"] > 0 and "INVALID" in j and j["scaling"] == "weak"
+
+
+def test_gather_padded_gloo_world2(tmp_path):
+    script = tmp_path / "g.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as dist
+        from qwen3_tts_amd.sharding import gather_padded
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        wav = torch.full((3, 50), float(rank + 1))
+        out = gather_padded(wav, torch.tensor([50, 40 + rank, 7]))
+        if rank == 0:
+            w, l = out
+            assert tuple(w.shape) == (world, 3, 50) and all(bool((w[r] == r + 1).all()) for r in range(world))
+            assert l.tolist() == [[50, 40 + r, 7] for r in range(world)]
+            print("GATHER_PADDED_OK")
+        else:
+            assert out is None
+        dist.destroy_process_group()
+    """))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29655", str(script)],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GATHER_PADDED_OK" in r.stdout
 
 
 def test_tokenizer_decode_input_errors():
