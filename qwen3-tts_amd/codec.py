@@ -81,6 +81,17 @@ class CodecDecoderEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @staticmethod
+    def _call(rc: int):
+        """`_lib.check`, with the library's "code index out of range" mapped to the IndexError the reference's embedding
+        lookup raises for a code >= codebook_size (v2:721-727)."""
+        try:
+            _lib.check(rc)
+        except _lib.QttsError as e:
+            if "code index out of range" in str(e):
+                raise IndexError(str(e)) from e
+            raise
+
     def _check_codes(self, codes: torch.Tensor, q_dim: int):
         if codes.dim() != 3:
             raise ValueError(f"codes must be 3-D, got shape {tuple(codes.shape)}")
@@ -97,7 +108,7 @@ class CodecDecoderEngine:
         wav = torch.empty(B, T * up, dtype=torch.float32, device=self.device)
         pre = torch.empty_like(wav) if return_pre_clamp else None
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.qtts_codec_forward(self._h, C.c_void_p(codes.data_ptr()), B, T, C.c_void_p(wav.data_ptr()),
+            self._call(self._lib.qtts_codec_forward(self._h, C.c_void_p(codes.data_ptr()), B, T, C.c_void_p(wav.data_ptr()),
                                                     C.c_void_p(pre.data_ptr()) if pre is not None else None, self._stream()))
         return (wav.unsqueeze(1), pre.unsqueeze(1)) if return_pre_clamp else wav.unsqueeze(1)
 
@@ -129,7 +140,7 @@ class CodecDecoderEngine:
         wav = torch.empty(B, T * up, dtype=torch.float32, device=self.device)
         lens = (C.c_int64 * B)()
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.qtts_codec_decode(self._h, C.c_void_p(codes.data_ptr()), B, T, int(chunk_size),
+            self._call(self._lib.qtts_codec_decode(self._h, C.c_void_p(codes.data_ptr()), B, T, int(chunk_size),
                                                    int(left_context_size), C.c_void_p(wav.data_ptr()), lens, self._stream()))
         return wav, [int(x) for x in lens]
 
@@ -255,16 +266,25 @@ class Qwen3TTSTokenizerV2Model:
     def encode(self, input_values: torch.Tensor, padding_mask: Optional[torch.Tensor] = None, return_dict: Optional[bool] = None):
         """tokenizer v2:961-991.  Needs the encoder weights (`encoder.*` keys of the tokenizer checkpoint); the HIP
         encoder is built on first use.  EXPERIMENTAL in round 1 (compiled, hardware run pending)."""
-        if self._encoder is None:
-            if not self._encoder_state:
-                raise NotImplementedError("this tokenizer was built without encoder weights (`encoder.*` keys): "
-                                          "codec encode is unavailable (SURVEY.md 8f3)")
+        if not self._encoder_state and self._encoder is None:
+            raise NotImplementedError("this tokenizer was built without encoder weights (`encoder.*` keys): "
+                                      "codec encode is unavailable (SURVEY.md 8f3)")
+        n_samples = int(input_values.shape[-1])
+        if self._encoder is None or n_samples > self._encoder.max_samples:
+            # built on first use; re-created with a larger workspace when a longer reference arrives (the reference has no
+            # length limit).  Batch capacity follows the tokenizer's max_batch; larger batches run as waves below.
             from .encoder import CodecEncoderEngine
-            self._encoder = CodecEncoderEngine(self.config, self._encoder_state, compute_dtype=self.dtype, device=str(self.device))
-            self._encoder_state = None
+            sr = int(self.input_sample_rate)
+            cap = max(30 * sr, -(-n_samples // (10 * sr)) * 10 * sr)
+            self._encoder = None
+            self._encoder = CodecEncoderEngine(self.config, self._encoder_state, compute_dtype=self.dtype, device=str(self.device),
+                                               max_batch=self.decoder.max_batch, max_samples=cap)
         if padding_mask is None:
             padding_mask = torch.ones_like(input_values, dtype=torch.long)
-        codes = self._encoder.encode(input_values, padding_mask)
+        codes = []
+        mb = self._encoder.max_batch
+        for b0 in range(0, input_values.shape[0], mb):
+            codes += self._encoder.encode(input_values[b0:b0 + mb], padding_mask[b0:b0 + mb])
         if return_dict is False:
             return (codes,)
         return Qwen3TTSTokenizerV2EncoderOutput(codes)

@@ -46,6 +46,16 @@ struct qtts_codec {
 
     DevBuf buf[4];
     size_t buf_elems = 0;
+    DevBuf err_flag;                    // device int: a code index >= codebook_size was seen (checked by the entry points)
+    void check_codes_flag(hipStream_t st) {
+        int e = 0;
+        QTTS_CHECK_HIP(hipMemcpyAsync(&e, err_flag.p, 4, hipMemcpyDeviceToHost, st));
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        if (e) {
+            QTTS_CHECK_HIP(hipMemset(err_flag.p, 0, 4));
+            throw Error(QTTS_ERR_ARG, "codec: code index out of range (>= codebook_size)");
+        }
+    }
 
     // ---- streaming (state-carrying) decode: one session per handle, B sequences advancing in lockstep
     struct Carry { DevBuf d; int h = 0, C = 0; };
@@ -343,6 +353,8 @@ void qtts_codec::finalize() {
     }
     buf_elems = per_frame * (size_t)std::max(1, c.max_batch) * (size_t)std::max(1, c.max_frames);
     for (auto& b : buf) b.alloc(buf_elems * sizeof(float));
+    err_flag.alloc(4);
+    QTTS_CHECK_HIP(hipMemset(err_flag.p, 0, 4));
     host.clear();  // host copies no longer needed
     finalized = true;
 }
@@ -368,7 +380,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     };
 
     // ---- RVQ dequant: gather-sum then the two 1x1 output projections as one GEMM (v2:815-821)
-    launch_rvq_gather(codes, B, c.num_quantizers, Tc, sb, sq, stt, t0, Tc, tables.as<float>(), c.codebook_size, vq, s1, st);
+    launch_rvq_gather(codes, B, c.num_quantizers, Tc, sb, sq, stt, t0, Tc, tables.as<float>(), c.codebook_size, vq, s1, err_flag.as<int>(), st);
     gemm(rvq_out, s1, 2 * vq, B * L, L, x, c.codebook_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
     C = c.codebook_dim;
     if (want("rvq")) { emit(x); return; }
@@ -548,7 +560,7 @@ void qtts_codec::stream_push(const int64_t* codes, int n, float* wav, hipStream_
     x = pool[0]; C = c.codebook_dim;
     fits((int64_t)B * n, std::max(2 * vq, C));
     launch_rvq_gather(codes, B, c.num_quantizers, n, (int64_t)c.num_quantizers * n, n, 1, 0, n, tables.as<float>(),
-                      c.codebook_size, vq, g, st);
+                      c.codebook_size, vq, g, err_flag.as<int>(), st);
     gemm(rvq_out, g, 2 * vq, B * n, n, x, C, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
     // ---- pre_conv k=3
     {
@@ -718,6 +730,7 @@ int qtts_codec_forward(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32
     const int Q = c->cfg.num_quantizers;
     c->forward(codes_dev, B, (int64_t)Q * T, T, 1, 0, T, wav_dev, pre_clamp_dev, (int64_t)T * c->up_total, 0, nullptr,
                nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    c->check_codes_flag((hipStream_t)stream);
     QTTS_API_END
 }
 int qtts_codec_forward_stage(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_t T, const char* stage,
@@ -750,6 +763,8 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
             for (int t = 0; t < T; ++t) n += h[((size_t)b * T + t) * Q] > -1;
             lengths_host[b] = n * up;
         }
+        for (int64_t v : h)   // the reference's embedding lookup raises on an index past the codebook
+            QTTS_REQUIRE(v < c->cfg.codebook_size, QTTS_ERR_ARG, "codec: code index out of range (>= codebook_size)");
     }
     int start = 0;
     while (start < T) {  // chunked_decode (v2:886-896)
@@ -759,6 +774,7 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
                    (int64_t)T * up, (int64_t)ctx * up, nullptr, nullptr, 0, nullptr, nullptr, st);
         start = end;
     }
+    if (!lengths_host) c->check_codes_flag(st);      // (with lengths the codes were validated on the host above)
     QTTS_API_END
 }
 

@@ -114,19 +114,21 @@ void launch_dwconv_ln(const float* x, const float* w7, const float* b, const flo
 // out row = [ table_0[code_0] | sum_{q=1..Q-1} table_q[code_q] ] (sequential sum order = v2:721-727).
 __global__ __launch_bounds__(256) void rvq_gather_kernel(const int64_t* codes, int Q, int64_t sb, int64_t sq,
                                                          int64_t stt, int t0, int Tc, const float* tables,
-                                                         int bins, int vq, float* out) {
+                                                         int bins, int vq, float* out, int* err) {
     const int row = blockIdx.x;          // b * Tc + t
     const int b = row / Tc, t = row % Tc + t0;
     const int64_t* cp = codes + b * sb + t * stt;
+    // an index past the codebook is an error (the reference's embedding lookup raises): flag it for the host, read row 0
+    if (threadIdx.x < Q && cp[threadIdx.x * sq] >= bins) *err = 1;
     for (int j = threadIdx.x; j < 2 * vq; j += 256) {
         float acc;
         if (j < vq) {
-            int64_t c = cp[0]; if (c < 0) c = 0;
+            int64_t c = cp[0]; if (c < 0 || c >= bins) c = 0;
             acc = tables[((size_t)c) * vq + j];
         } else {
             acc = 0.f;
             for (int q = 1; q < Q; ++q) {
-                int64_t c = cp[q * sq]; if (c < 0) c = 0;
+                int64_t c = cp[q * sq]; if (c < 0 || c >= bins) c = 0;
                 const float e = tables[((size_t)q * bins + c) * vq + (j - vq)];
                 acc = (q == 1) ? e : acc + e;
             }
@@ -136,10 +138,11 @@ __global__ __launch_bounds__(256) void rvq_gather_kernel(const int64_t* codes, i
 }
 void launch_rvq_gather(const int64_t* codes, int B, int Q, int T, int64_t stride_b, int64_t stride_q,
                        int64_t stride_t, int t0, int Tc, const float* tables, int bins, int vq, float* out,
-                       hipStream_t st) {
+                       int* err, hipStream_t st) {
     (void)T;
+    QTTS_REQUIRE(Q <= 256 && err, QTTS_ERR_ARG, "rvq_gather: Q <= 256 and an error flag");
     hipLaunchKernelGGL(rvq_gather_kernel, dim3(B * Tc), dim3(256), 0, st, codes, Q, stride_b, stride_q, stride_t,
-                       t0, Tc, tables, bins, vq, out);
+                       t0, Tc, tables, bins, vq, out, err);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 

@@ -62,7 +62,7 @@ void launch_dwconv_ln(const float* x, const float* w7, const float* b, const flo
 // out[bt][0:vq] = tab0[code0], out[bt][vq:2vq] = sum_{q>=1} tab_q[code_q]  (codes (B,Q,T) or (B,T,Q))
 void launch_rvq_gather(const int64_t* codes, int B, int Q, int T, int64_t stride_b, int64_t stride_q,
                        int64_t stride_t, int t0, int Tc, const float* tables, int bins, int vq, float* out,
-                       hipStream_t st);
+                       int* err /* set to 1 when a code >= bins is seen */, hipStream_t st);
 // final conv (C -> 1, k = 7, causal) + clamp; x already snake-activated, channel-last
 void launch_final_conv(const float* x, const float* w /*[7][C]*/, float bias, float* wav, float* pre_clamp,
                        int64_t rows, int64_t T, int C, int64_t out_stride_b, int64_t skip, hipStream_t st);

@@ -241,13 +241,16 @@ class Qwen3TTSForConditionalGeneration:
         """M:1941-1954: 24 kHz waveform -> (enc_dim,) x-vector, log-mel + ECAPA-TDNN on the HIP speaker engine
         (EXPERIMENTAL in round 1: compiled and CPU-emulated, hardware run pending)."""
         assert sr == 24000, "Only support 24kHz audio"
-        if self.speaker_encoder is None:
-            if not self._speaker_state:
-                raise NotImplementedError("this checkpoint has no `speaker_encoder.*` weights (only the Base model does)")
+        if not self._speaker_state:
+            raise NotImplementedError("this checkpoint has no `speaker_encoder.*` weights (only the Base model does)")
+        n = int(np.asarray(audio).shape[-1])
+        if self.speaker_encoder is None or n > self.speaker_encoder.max_samples:
+            # built on first use; re-created with a larger workspace for a longer reference (the reference has no limit)
             from .speaker import SpeakerEncoderEngine
+            cap = max(30 * 24000, -(-n // 240000) * 240000)
+            self.speaker_encoder = None
             self.speaker_encoder = SpeakerEncoderEngine(self._speaker_config, self._speaker_state, compute_dtype=torch.float32,
-                                                        device=str(self.device))
-            self._speaker_state = None
+                                                        device=str(self.device), max_samples=cap)
         return self.speaker_encoder.extract_speaker_embedding(audio, sr)
 
     # ------------------------------------------------------------------ generate (seam S1)
@@ -265,6 +268,10 @@ class Qwen3TTSForConditionalGeneration:
         suppress = [i for i in range(c.vocab_size - 1024, c.vocab_size) if i != c.codec_eos_token_id]      # M:2059-2063
         codes_all, hidden_all = [], []
         mb = self.talker.max_batch
+        # one base seed per call (torch's advancing generator unless given); wave w samples with base + w so that equal rows of
+        # different waves do not repeat each other's random draws (the Philox counter is (step, row-in-wave, codebook))
+        from .talker import _fresh_seed
+        base_seed = int(kwargs["seed"]) if kwargs.get("seed") is not None else _fresh_seed()
         for b0 in range(0, embeds.shape[0], mb):     # larger request lists run as waves of max_batch rows
             sl = slice(b0, b0 + mb)
             e, m = embeds[sl], mask[sl]
@@ -276,7 +283,7 @@ class Qwen3TTSForConditionalGeneration:
                                        subtalker_temperature=subtalker_temperature,
                                        eos_token_id=eos_token_id if eos_token_id is not None else c.codec_eos_token_id,
                                        repetition_penalty=repetition_penalty, suppress_tokens=suppress,
-                                       seed=kwargs.get("seed"))
+                                       seed=base_seed + b0 // mb)
             first = out.codes[:, :, 0]
             stop = first == c.codec_eos_token_id                                                           # M:2283-2289
             for i in range(first.shape[0]):
@@ -359,16 +366,25 @@ class Qwen3TTSModel:
                 sd.update(load_file(os.path.join(path, fn)))
         device = str(kwargs.get("device_map", kwargs.get("device", "cuda:0")))
         dtype = kwargs.get("dtype", kwargs.get("torch_dtype", torch.bfloat16))
+        gen_cfg = None
+        gc_path = os.path.join(path, "generation_config.json")                # M:1922-1936
+        if os.path.exists(gc_path):
+            with open(gc_path) as f:
+                gen_cfg = json.load(f)
+        # KV capacity: the checkpoint's own `max_new_tokens` (8192 in the released generation_config.json; README default 2048)
+        # plus room for the prompt, unless the caller sizes it.  288 GB of HBM makes this cheap (1.7B, batch 8: 0.9 MB per token).
+        max_seq = kwargs.get("max_seq")
+        if max_seq is None:
+            want = int((gen_cfg or {}).get("max_new_tokens", 2048) or 2048)
+            max_seq = min(16384, ((want + 1024 + 255) // 256) * 256)
         model = Qwen3TTSForConditionalGeneration(cfg, sd, device=device, dtype=dtype,
-                                                 max_batch=kwargs.get("max_batch", 8), max_seq=kwargs.get("max_seq", 4096))
+                                                 max_batch=kwargs.get("max_batch", 8), max_seq=int(max_seq))
         st_dir = os.path.join(path, "speech_tokenizer")                       # M:1900-1920
         if os.path.isdir(st_dir):
             model.load_speech_tokenizer(Qwen3TTSTokenizer.from_pretrained(st_dir, device_map=device, dtype=dtype,
                                                                           max_batch=kwargs.get("max_batch", 8)))
-        gc_path = os.path.join(path, "generation_config.json")                # M:1922-1936
-        if os.path.exists(gc_path):
-            with open(gc_path) as f:
-                model.load_generate_config(json.load(f))
+        if gen_cfg is not None:
+            model.load_generate_config(gen_cfg)
         return cls(model=model, processor=_TextProcessor(path), generate_defaults=model.generate_config)
 
     # ---- helpers (qwen3_tts_model.py:123-185, 263-352)
@@ -606,7 +622,11 @@ class Qwen3TTSModel:
         speakers = self._ensure_list(speaker)
         if len(speakers) == 1 and len(texts) > 1:
             speakers = speakers * len(texts)
+        if self.model.tts_model_size in "0b6":      # 0.6B has no instruct support (IM:799-800), as in generate_custom_voice
+            instruct = None
         instructs = instruct if isinstance(instruct, list) else [instruct] * len(texts)
+        if len(instructs) == 1 and len(texts) > 1:
+            instructs = instructs * len(texts)
         if not (len(texts) == len(languages) == len(speakers) == len(instructs)):
             raise ValueError(f"Batch size mismatch: text={len(texts)}, language={len(languages)}, speaker={len(speakers)}, instruct={len(instructs)}")
         self._validate_languages(languages)

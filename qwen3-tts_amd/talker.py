@@ -21,6 +21,13 @@ def _default_inv_freq(theta: float, head_dim: int) -> torch.Tensor:
     return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).to(dtype=torch.float) / head_dim))
 
 
+def _fresh_seed() -> int:
+    """Default Philox seed of a sampling call: drawn from torch's ADVANCING default generator, so that two calls give two
+    takes (as the reference's torch.multinomial does) while `torch.manual_seed(s)` still makes a run reproducible."""
+    return int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+
+
+
 @dataclass
 class TalkerGenerateOutput:
     codes: torch.Tensor        # (B, n_frames, G) int64, untrimmed (M:2280)
@@ -108,6 +115,23 @@ class TalkerEngine:
         x2.record_stream(self._stream)
         return y.reshape(*shp[:-1], self.config.hidden_size)
 
+    def _clamp_new_tokens(self, T: int, max_new_tokens: int) -> int:
+        """HF treats `max_new_tokens` as an upper bound (generation_config.json of the released checkpoints asks for 8192);
+        the engine's KV capacity is `max_seq`, fixed at construction.  A request that asks for more than fits is cut at the
+        capacity (with a warning, once) instead of being refused; a prompt that leaves no room at all is an error."""
+        room = self.max_seq - T
+        if room < 1:
+            raise ValueError(f"prompt ({T} rows) does not fit max_seq ({self.max_seq}) given at construction")
+        if max_new_tokens > room:
+            if not getattr(self, "_warned_clamp", False):
+                import warnings
+                warnings.warn(f"max_new_tokens={max_new_tokens} exceeds the KV capacity left after the prompt "
+                              f"(max_seq {self.max_seq} - prompt {T} = {room}); generation is capped at {room} tokens. "
+                              f"Pass a larger max_seq at construction for longer utterances.")
+                self._warned_clamp = True
+            max_new_tokens = room
+        return max_new_tokens
+
     # ------------------------------------------------------------------ generate (seam S2)
     @_lib.locked
     def text_embed(self, ids: torch.Tensor) -> torch.Tensor:
@@ -116,8 +140,8 @@ class TalkerEngine:
         y = torch.empty(ids.numel(), self.config.hidden_size, dtype=torch.float32, device=self.device)
         if ids.numel() == 0:
             return y
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))     # `ids` was produced on the caller's stream
         with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
-            self._stream.wait_stream(torch.cuda.current_stream(self.device))
             _lib.check(self._lib.qtts_talker_text_embed(self._h, C.c_void_p(ids.data_ptr()), ids.numel(),
                                                         C.c_void_p(y.data_ptr()), self._s()))
         torch.cuda.current_stream(self.device).wait_stream(self._stream)
@@ -139,8 +163,8 @@ class TalkerEngine:
         if ref is not None and (ref.dim() != 2 or ref.shape[1] != self.config.num_code_groups):
             raise ValueError(f"ref_codes must be (frames, {self.config.num_code_groups})")
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        self._stream.wait_stream(torch.cuda.current_stream(dev))             # desc / proj / spk / ref come from the caller's stream
         with torch.cuda.device(dev), torch.cuda.stream(self._stream):
-            self._stream.wait_stream(torch.cuda.current_stream(dev))
             _lib.check(self._lib.qtts_talker_assemble_rows(
                 self._h, C.c_void_p(desc.data_ptr()), desc.shape[0], ptr(proj), 0 if proj is None else proj.shape[0],
                 ptr(spk), 0 if spk is None else spk.shape[0], ptr(ref), 0 if ref is None else ref.shape[0],
@@ -172,8 +196,7 @@ class TalkerEngine:
         expect = (torch.arange(T)[None, :] >= n_pad[:, None]).long()
         if not torch.equal(mask, expect) or int(n_pad.max()) >= T:
             raise ValueError("attention_mask must be left-padded: [0]*n_pad + [1]*(T-n_pad) per row")
-        if T + max_new_tokens > self.max_seq:
-            raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_seq ({self.max_seq})")
+        max_new_tokens = self._clamp_new_tokens(T, int(max_new_tokens))
         eos = c.codec_eos_token_id if eos_token_id is None else int(eos_token_id)
         if suppress_tokens is None:
             suppress_tokens = []
@@ -187,7 +210,7 @@ class TalkerEngine:
         sp.subtalker_top_k = int(subtalker_top_k) if subtalker_top_k else 0
         sp.subtalker_top_p = float(subtalker_top_p) if subtalker_top_p is not None else 1.0
         sp.subtalker_temperature = float(subtalker_temperature) if subtalker_temperature is not None else 1.0
-        sp.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)
+        sp.seed = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else _fresh_seed()
 
         dev = self.device
         emb = inputs_embeds.to(dev, torch.float32).contiguous()
@@ -246,8 +269,7 @@ class TalkerEngine:
         expect = (torch.arange(T)[None, :] >= n_pad[:, None]).long()
         if not torch.equal(mask, expect) or int(n_pad.max()) >= T:
             raise ValueError("attention_mask must be left-padded: [0]*n_pad + [1]*(T-n_pad) per row")
-        if T + max_new_tokens > self.max_seq:
-            raise ValueError(f"prompt ({T}) + max_new_tokens ({max_new_tokens}) exceeds max_seq ({self.max_seq})")
+        max_new_tokens = self._clamp_new_tokens(T, int(max_new_tokens))
         eos = c.codec_eos_token_id if eos_token_id is None else int(eos_token_id)
         suppress_tokens = list(suppress_tokens or [])
         sp = _lib.SamplingC()
@@ -260,7 +282,7 @@ class TalkerEngine:
         sp.subtalker_top_k = int(subtalker_top_k) if subtalker_top_k else 0
         sp.subtalker_top_p = float(subtalker_top_p) if subtalker_top_p is not None else 1.0
         sp.subtalker_temperature = float(subtalker_temperature) if subtalker_temperature is not None else 1.0
-        sp.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0xFFFFFFFFFFFFFFFF)
+        sp.seed = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else _fresh_seed()
         dev = self.device
         emb = inputs_embeds.to(dev, torch.float32).contiguous()
         trail = trailing_text_hidden.to(dev, torch.float32).contiguous()

@@ -89,3 +89,10 @@ def test_voice_clone_wrapper_end_to_end_python_path(glue, tmp_path):
 def test_stream_custom_voice_wrapper_python_path(glue):
     """`Qwen3TTSModel.stream_custom_voice` (PCM packets) equals `generate_custom_voice`: the gated GPU test body."""
     glue.test_wrapper_stream_custom_voice_equals_one_shot("cpu")
+
+
+def test_round1_advice_fixes_python_path(glue, golden_dir):
+    """Out-of-range codec codes raise IndexError (device flag / host check), and the default Philox seed advances between
+    calls while `torch.manual_seed` reproduces a run: the GPU test bodies, on the emulator."""
+    glue.test_codec_edge_cases(_codec_tiny(glue, golden_dir))
+    glue.test_default_seed_advances_and_manual_seed_reproduces(_talker_tiny(glue, golden_dir), "cpu")

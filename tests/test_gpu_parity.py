@@ -85,6 +85,13 @@ def test_codec_edge_cases(codec_tiny):
     from qwen3_tts_amd import QttsError
     with pytest.raises(QttsError):                        # beyond the workspace reserved at create
         eng.forward(torch.zeros(4, c.num_quantizers, 200, dtype=torch.long).cuda())
+    # a code index past the codebook: the reference's embedding lookup raises IndexError; so do we (no silent OOB read)
+    bad = torch.zeros(1, c.num_quantizers, 3, dtype=torch.long)
+    bad[0, c.num_quantizers - 1, 2] = c.codebook_size
+    with pytest.raises(IndexError):
+        eng.forward(bad.cuda())
+    with pytest.raises(IndexError):
+        eng.decode_padded(bad.transpose(1, 2).contiguous().cuda())
     # single frame, and a fully padded row (length 0) next to a real one
     one = torch.randint(0, c.codebook_size, (1, c.num_quantizers, 1))
     with torch.no_grad():
@@ -114,9 +121,6 @@ def test_codec_stream_decoder_packets(codec_tiny):
     assert _rms(got.numpy(), ref.numpy()) <= RMS_BAR
 
 
-@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
-                    reason="state-carrying stream decode (qtts_codec_stream_*): compiled in round 1, budget ran out before its "
-                           "first hardware run -- enable with QTTS_EXPERIMENTAL=1")
 def test_codec_incremental_stream_equals_forward(codec_tiny):
     """packets pushed through the state-carrying decoder equal the whole-sequence forward (and the
     oracle's incremental restatement) for ragged packet sizes, single frames, and streams several windows long."""
@@ -250,8 +254,33 @@ def test_talker_input_validation(talker_tiny, dev):
         eng.generate(e, m, tr, pad, max_new_tokens=4)
     with pytest.raises(ValueError, match="left-padded"):
         eng.generate(e[:2], m[:2].flip(1), tr[:2], pad, max_new_tokens=4)
-    with pytest.raises(ValueError, match="max_seq"):
-        eng.generate(e[:2], m[:2], tr[:2], pad, max_new_tokens=400)
+    # HF treats max_new_tokens as an upper bound (the released generation_config.json asks for 8192): a request for more than the
+    # KV capacity is capped with a warning, not refused; a prompt that leaves no room at all is an error
+    T = e.shape[1]
+    with pytest.warns(UserWarning, match="capped"):
+        out = eng.generate(e[:2], m[:2], tr[:2], pad, max_new_tokens=400, min_new_tokens=400, do_sample=False,
+                           subtalker_dosample=False, suppress_tokens=_suppress(t))
+    assert out.tokens.shape[1] == 64 - T and out.n_frames == 64 - T - 1
+    small = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=2, max_seq=T, use_graph=False)
+    with pytest.raises(ValueError, match="does not fit"):
+        small.generate(e[:2], m[:2], tr[:2], pad, max_new_tokens=4)
+
+
+def test_default_seed_advances_and_manual_seed_reproduces(talker_tiny, dev):
+    """No `seed=`: every sampling call draws a fresh Philox seed from torch's advancing generator (two calls = two takes, as
+    with the reference's torch.multinomial); `torch.manual_seed` makes a run reproducible."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    t, w, g = talker_tiny
+    eng = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=2, max_seq=64, use_graph=False)
+    e, m, tr, pad = [torch.from_numpy(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
+    kw = dict(max_new_tokens=5, min_new_tokens=5, suppress_tokens=_suppress(t), temperature=2.0, subtalker_temperature=2.0)
+    torch.manual_seed(1234)
+    a = eng.generate(e[:2], m[:2], tr[:2], pad, **kw).codes.cpu()
+    b = eng.generate(e[:2], m[:2], tr[:2], pad, **kw).codes.cpu()
+    torch.manual_seed(1234)
+    a2 = eng.generate(e[:2], m[:2], tr[:2], pad, **kw).codes.cpu()
+    assert torch.equal(a, a2)
+    assert not torch.equal(a, b)
 
 
 def test_talker_vs_oracle_fresh_inputs(talker_tiny, dev):
@@ -586,11 +615,18 @@ def test_from_pretrained_checkpoint_directory_custom_voice(dev, golden_dir, tmp_
         tts.generate_custom_voice(text="x", speaker="nobody", language="english")
     with pytest.raises(ValueError):
         tts.generate_voice_design(text="x", instruct="y")            # wrong model type for this checkpoint (IM:401-407)
+    # the README quick start: no max_new_tokens -> the checkpoint's generation_config.json (8192) is an upper bound that the
+    # engine caps at its KV capacity instead of refusing the call
+    with open(os.path.join(path, "generation_config.json")) as f:
+        assert json.load(f)["max_new_tokens"] > 160
+    with pytest.warns(UserWarning, match="capped"):
+        wavs, sr = tts.generate_custom_voice(text="hi", speaker="ryan", language="english")
+    assert len(wavs) == 1 and wavs[0].ndim == 1 and wavs[0].shape[0] <= 160 * c.total_upsample
+    # without an explicit max_seq the KV capacity is sized from generation_config.json: max_new_tokens + prompt room
+    tts2 = Qwen3TTSModel.from_pretrained(path, device_map=dev, dtype=torch.float32, max_batch=2)
+    assert tts2.model.talker.max_seq >= 8192 + 512
 
 
-@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
-                    reason="HIP codec encoder (qtts_encoder_*): compiled in round 1, budget ran out before its first hardware run "
-                           "-- enable with QTTS_EXPERIMENTAL=1")
 def test_codec_encoder_codes_vs_reference_golden(dev, golden_dir):
     """waveform -> codes through the HIP encoder (fp32) against codes produced by the reference's own
     encoder class (tests/golden/codec_enc_small.npz).  Index parity is bit-exact except where the two nearest codebook
@@ -613,9 +649,6 @@ def test_codec_encoder_codes_vs_reference_golden(dev, golden_dir):
     assert [r.shape for r in rows] == [(21, 4), (11, 4)]
 
 
-@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
-                    reason="HIP speaker encoder (qtts_speaker_*): compiled in round 1, budget ran out before its first hardware "
-                           "run -- enable with QTTS_EXPERIMENTAL=1")
 def test_speaker_embedding_vs_oracle(dev):
     """waveform -> log-mel -> ECAPA-TDNN embedding through the HIP speaker engine (fp32) against
     oracle/speaker_ref.py (the ECAPA part is bit-identical to the reference module, tests/golden/speaker_tiny.npz)."""
@@ -635,9 +668,6 @@ def test_speaker_embedding_vs_oracle(dev):
     assert np.abs(one - emb[0]).max() <= 1e-5
 
 
-@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
-                    reason="resumable talker generation (qtts_talker_stream_*): validated on the CPU emulation in round 1, first "
-                           "hardware run (hipGraph path) pending -- enable with QTTS_EXPERIMENTAL=1")
 @pytest.mark.parametrize("graph", [False, True])
 def test_talker_generate_stream_equals_generate(talker_tiny, dev, graph):
     """Streaming output: the packets of `generate_stream` concatenate to exactly the codes of `generate` (and therefore to
@@ -659,9 +689,6 @@ def test_talker_generate_stream_equals_generate(talker_tiny, dev, graph):
     assert np.array_equal(out.codes.cpu().numpy(), g["codes"])
 
 
-@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
-                    reason="voice clone from a reference WAVEFORM goes through the codec encoder and the speaker encoder, which "
-                           "have not had their first hardware run -- enable with QTTS_EXPERIMENTAL=1")
 def test_wrapper_voice_clone_from_waveform_end_to_end(dev, tmp_path):
     """BASELINE config 5's call sequence on one tiny Base-type model (examples/test_model_12hz_base.py): a reference WAVE file
     -> `create_voice_clone_prompt` (audio_io -> codec encoder -> ref codes; speaker encoder -> x-vector) -> `generate_voice_clone`
@@ -725,9 +752,6 @@ def test_wrapper_voice_clone_from_waveform_end_to_end(dev, tmp_path):
     assert all(np.array_equal(a, b) for a, b in zip(wx, wx2))
 
 
-@pytest.mark.skipif(os.environ.get("QTTS_EXPERIMENTAL") != "1",
-                    reason="streaming output sits on the resumable talker generation, which has not had its first hardware run "
-                           "-- enable with QTTS_EXPERIMENTAL=1")
 def test_wrapper_stream_custom_voice_equals_one_shot(dev):
     """`Qwen3TTSModel.stream_custom_voice` (PCM packets every k frames, BASELINE config 4) against `generate_custom_voice` on
     the same requests: the packets of each request concatenate to its one-shot waveform (utterances shorter than the
