@@ -45,7 +45,7 @@ const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
  * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
  * 6: + qtts_talker_stream_*). */
-#define QTTS_ABI_VERSION 6
+#define QTTS_ABI_VERSION 7
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -116,8 +116,8 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
  * chunked_decode's (:886-896) re-decode of 25 context frames; algorithm in oracle/codec_stream_ref.py.
  * One session per handle: `begin` zeroes the state for `batch` sequences that advance in lockstep; `push` decodes
  * codes_dev int64 (batch, num_quantizers, n_frames) into wav_dev float (batch, n_frames * total_upsample).
- * STATUS (round 1): compiled for gfx950, parity test written (tests/test_gpu_parity.py, QTTS_EXPERIMENTAL=1), not yet
- * executed on hardware. */
+ * STATUS: validated on MI355X (round 2): any packetisation == `forward` on the whole sequence
+ * (tests/test_gpu_parity.py::test_codec_incremental_stream_equals_forward). */
 int qtts_codec_stream_begin(qtts_codec* c, int32_t batch);
 int qtts_codec_stream_push(qtts_codec* c, const int64_t* codes_dev, int32_t n_frames, float* wav_dev, void* stream);
 
@@ -132,7 +132,7 @@ int qtts_codec_forward_stage(qtts_codec* c, const int64_t* codes_dev, int32_t B,
  * Replaces Qwen3TTSTokenizerV2Model.encode (tokenizer v2:961-991), i.e. transformers.MimiModel.encode behind
  * Qwen3TTSTokenizerV2Encoder (v2:897-908): SEANet encoder -> causal transformer -> stride-2 downsample -> split
  * residual VQ; only the first `valid_num_quantizers` codebooks are produced (v2:982-983).
- * STATUS (round 1): compiled for gfx950, oracle + goldens + gated parity test in place, not yet executed on hardware.
+ * STATUS: validated on MI355X (round 2): codes bit-identical to the reference's own encoder class on the golden waveforms.
  * ------------------------------------------------------------------------------------------ */
 typedef struct qtts_encoder qtts_encoder;
 
@@ -185,8 +185,8 @@ int qtts_encoder_encode(qtts_encoder* e, const float* wav_dev, int32_t B, int32_
  * Replaces Qwen3TTSForConditionalGeneration.extract_speaker_embedding (modeling_qwen3_tts.py:1941-1954):
  * mel_spectrogram (:402-464; n_fft 1024, hop 256, 128 mels, 0..12 kHz, center=False) -> Qwen3TTSSpeakerEncoder
  * (ECAPA-TDNN, :95-393).
- * STATUS (round 1): compiled for gfx950; orchestration executed in the CPU suite on kernel stand-ins
- * (tests/test_hostemu.py); not yet executed on hardware.
+ * STATUS: validated on MI355X (round 2) against the oracle (log-mel and embedding); the Slaney filterbank restates
+ * librosa.filters.mel, which is absent here: filterbank parity unpinned.
  * ------------------------------------------------------------------------------------------ */
 typedef struct qtts_speaker qtts_speaker;
 
@@ -346,8 +346,7 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
  *                 (codes_dev[:, :frames_total]) and whether the stop condition has latched.
  *   stream_end    the closing bookkeeping: tokens_dev int64 (B, max_new_tokens) padded with -1 (optional) and the frame
  *                 count, as qtts_talker_generate reports them.  May be called early to abandon a request.
- * STATUS (round 1): the eager path runs in the CPU suite (tests/test_hostemu.py: packets == one-shot generate == the
- * reference golden); first hardware run (graph path) pending. */
+ * STATUS: validated on MI355X (round 2), eager and hipGraph: packets == one-shot generate. */
 int qtts_talker_stream_begin(qtts_talker* t, const qtts_sampling* sp, int32_t max_new_tokens, int32_t min_new_tokens,
                              int32_t eos_token_id, const int32_t* suppress_host, int32_t n_suppress, int64_t* codes_dev,
                              float* hidden_dev, void* stream);
@@ -367,6 +366,18 @@ typedef struct {
     int64_t gemm_launches_last;
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
+/* Teacher forcing (diagnostic mode for parity measurements; no reference counterpart -- it is how a whole utterance of the
+ * bf16 mode is compared decision by decision with the reference's greedy run, SURVEY.md 7 "teacher-forced per-step logits"):
+ * until disabled (forced_codes_dev = NULL) every following qtts_talker_generate call -- greedy, min_new_tokens ==
+ * max_new_tokens == n_frames + 1, run eagerly -- records the engine's OWN greedy choice of every codebook of every frame into
+ * own_dev (B, n_frames + 1, G) int32 ([b][i][0] = own cb-0 token i, [b][f][1 + j] = own sub-code j of frame f) and then
+ * continues with forced_codes_dev (B, n_frames, G) int64 instead (frame-level forcing: the 15-pass code predictor runs free
+ * inside a frame; its result is replaced before the embedding sum, M:1681-1692; the fed cb-0 token and the repetition-penalty
+ * history follow the forced sequence).  logit_slots_dev (n_frames + 1) int32 maps a token step to a slot of
+ * logits_trace_dev (n_slots, B, vocab) fp32 that receives the raw cb-0 logits of that step (-1 = not traced); both may be
+ * NULL.  All pointers are device pointers owned by the caller and must stay valid while the mode is on. */
+int qtts_talker_set_teacher(qtts_talker* t, const int64_t* forced_codes_dev, int32_t n_frames, int32_t* own_dev,
+                            const int32_t* logit_slots_dev, float* logits_trace_dev);
 /* Enable per-launch HIP-event timing of the dominant kernel (skinny weight-streaming GEMM) in
  * eager mode; used by bench.py's roofline leg only. */
 int qtts_talker_set_profile(qtts_talker* t, int32_t enable);

@@ -282,7 +282,7 @@ def gen_talker_tiny():
     print("talker_tiny: codes", codes.shape, "eos2", eos2, "tokens_eos2", toks2.tolist())
 
 
-def _gen_talker_real(name, t, lens, n_trail, max_new, seed, min_new=2):
+def _gen_talker_real(name, t, lens, n_trail, max_new, seed, min_new=2, logit_steps=None):
     import torch
     w = synth.talker_weights(t, with_text=False)
     t0 = time.time()
@@ -308,6 +308,9 @@ def _gen_talker_real(name, t, lens, n_trail, max_new, seed, min_new=2):
            "margin": torch.stack(tr["margin"], 1).numpy(), "logits0": tr["logits"][0].numpy(),
            "hidden_last": hidden[:, -1].numpy(), "ref_cpu_seconds": dt,
            "ref_cpu_threads": torch.get_num_threads()}
+    if logit_steps is not None:      # raw cb-0 logits (before the HF processors) of selected token steps, for teacher-forced comparisons
+        out["logit_steps"] = np.array(logit_steps)
+        out["logits_sel"] = torch.stack([tr["logits"][i] for i in logit_steps], 0).numpy()
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **out)
     print(f"{name}: codes {tuple(codes.shape)} ref cpu loop {dt:.1f}s (build {t1 - t0:.1f}s) min margin {out['margin'].min():.5f}")
 
@@ -332,6 +335,107 @@ def gen_talker_17b_b32():
     # BASELINE config 4 shape: 1.7B dims, batch 32, streaming text input (24 trailing text rows fed one per frame,
     # M:2229-2232), ragged prompts, greedy, 12 frames
     _gen_talker_real("talker_17b_b32", synth.talker_17b(), [40 + (7 * i) % 32 for i in range(32)], 24, 13, 10)
+
+
+BENCH_LENS = [36, 40, 44, 48, 52, 56, 60, 64]          # bench.py: 24 + 4 * (i % 8) + 12
+LOGIT_STEPS = [0, 1, 2, 3, 4, 8, 16, 32, 48, 64, 96, 125]
+
+
+def gen_talker_17b_b8():
+    # THE METRIC CONFIG (BASELINE.json metric): 1.7B dims, batch 8, bench.py's ragged prompts, 125 frames (10 s) per utterance
+    # forced with min_new_tokens = max_new_tokens = 126, greedy, fp32 reference CPU path
+    _gen_talker_real("talker_17b_b8", synth.talker_17b(), BENCH_LENS, 1, 126, 100, min_new=126, logit_steps=LOGIT_STEPS)
+
+
+def gen_talker_06b_long():
+    # a LONG utterance (reference default max_new_tokens = 2048, IM:329): 0.6B dims, ragged batch of 2, 820 frames (65.6 s) forced,
+    # greedy fp32 -- the KV cache grows to ~865 keys, far past the decode attention's 256-key register window
+    _gen_talker_real("talker_06b_long", synth.talker_06b(), [30, 45], 40, 821, 11, min_new=821)
+
+
+def gen_talker_17b_b8_bf16():
+    """The reference's own modules in **bfloat16** (the dtype of its examples, examples/test_model_12hz_*.py), TEACHER-FORCED
+    frame by frame with the fp32 golden above: every frame's talker input is the fp32 golden's 16 codes (the nested
+    code_predictor.generate runs free inside the frame -- its own 15 codes are recorded -- and its result is replaced by the
+    golden's before the embedding sum), the fed cb-0 token is the golden's.  Recorded: the bf16 reference's own greedy choice
+    for all 16 codebooks of every frame and its raw cb-0 logits at LOGIT_STEPS.  This is the yardstick for the MI355X bf16
+    engine: how far does bf16 move the reference itself, and is the engine inside that distance?"""
+    import torch
+    t = synth.talker_17b()
+    g = np.load(os.path.join(GOLDEN, "talker_17b_b8.npz"))
+    w = synth.talker_weights(t, with_text=False)
+    assert abs(synth.weights_checksum(w) - float(g["weights_checksum"])) < 1e-3 * max(1.0, abs(float(g["weights_checksum"])))
+    wz = dict(w)
+    t_small = synth.TalkerCfg(**{**synth.cfg_dict(t), "text_vocab_size": 8})
+    for k, shp in synth.talker_param_shapes(t_small, with_text=True).items():
+        if k not in wz:
+            wz[k] = np.zeros(shp, np.float32)
+    talker = ref_talker(t_small, wz).to(torch.bfloat16)
+    for mod in talker.modules():          # rotary inv_freq stays fp32 in the reference (non-persistent buffer, computed in fp32)
+        if hasattr(mod, "rope_init_fn") and hasattr(mod, "inv_freq"):
+            inv, _ = mod.rope_init_fn(mod.config, "cpu")
+            mod.inv_freq = inv
+            mod.original_inv_freq = inv
+    lens = [int(x) for x in g["lens"]]
+    rng = np.random.default_rng(int(g["seed"]))
+    emb, mask, trailing, pad = _rand_prompt(rng, t, lens, int(g["n_trail"]), scale=0.05)
+    emb, trailing, pad = emb.to(torch.bfloat16), trailing.to(torch.bfloat16), pad.to(torch.bfloat16)
+    gold_codes = torch.from_numpy(g["codes"])          # (B, F, 16)
+    gold_tokens = torch.from_numpy(g["tokens"])        # (B, F + 1)
+    B, F, G = gold_codes.shape
+    own_sub, frame_no = [], [0]
+    orig_generate = talker.code_predictor.generate
+
+    def forced_generate(*a, **k):
+        r = orig_generate(*a, **k)
+        own_sub.append(r.sequences.clone())
+        r.sequences = gold_codes[:, frame_no[0], 1:].clone()
+        frame_no[0] += 1
+        return r
+    talker.code_predictor.generate = forced_generate
+    eos = t.codec_eos_token_id
+    suppress = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != eos]
+    own_tok, logits_sel = [], {}
+    t1 = time.time()
+    with torch.no_grad():
+        talker.rope_deltas = None
+        o = talker(inputs_embeds=emb, attention_mask=mask, use_cache=True, output_hidden_states=True,
+                   trailing_text_hidden=trailing, tts_pad_embed=pad)
+        T = emb.shape[1]
+        for step in range(F + 1):
+            raw = o.logits[:, -1].float().clone()
+            if step in LOGIT_STEPS:
+                logits_sel[step] = raw.clone()
+            s = raw.clone()
+            if step > 0:                              # HF processors on the GOLDEN history (teacher forcing)
+                hist = gold_tokens[:, :step]
+                sc = torch.gather(s, 1, hist)
+                sc = torch.where(sc < 0, sc * 1.05, sc / 1.05)
+                s = s.scatter(1, hist, sc)
+            s[:, eos] = float("-inf")                 # min_new_tokens = max_new_tokens in this configuration
+            s[:, suppress] = float("-inf")
+            own_tok.append(torch.argmax(s, dim=-1))
+            if step == F:
+                break
+            tok = gold_tokens[:, step]
+            mask = torch.cat([mask, mask.new_ones(B, 1)], 1)
+            o = talker(input_ids=tok[:, None], attention_mask=mask, past_key_values=o.past_key_values, use_cache=True,
+                       cache_position=torch.tensor([T + step]), past_hidden=o.past_hidden,
+                       generation_step=o.generation_step, trailing_text_hidden=trailing, tts_pad_embed=pad,
+                       output_hidden_states=True, subtalker_dosample=False, subtalker_top_k=None,
+                       subtalker_top_p=None, subtalker_temperature=None)
+            if step % 10 == 0:
+                print(f"  bf16 teacher-forced step {step}/{F} ({time.time() - t1:.0f}s)", flush=True)
+    dt = time.time() - t1
+    own_tokens = torch.stack(own_tok, 1)              # (B, F + 1): the bf16 reference's choice where the golden has tokens[:, i]
+    own = torch.stack(own_sub, 1)                     # (B, F, 15)
+    agree0 = float((own_tokens == gold_tokens).float().mean())
+    agree_sub = float((own == gold_codes[:, :, 1:]).float().mean())
+    np.savez_compressed(os.path.join(GOLDEN, "talker_17b_b8_bf16.npz"), own_tokens=own_tokens.numpy(), own_sub=own.numpy(),
+                        logit_steps=np.array(sorted(logits_sel)), logits_sel=torch.stack([logits_sel[k] for k in sorted(logits_sel)], 0).numpy(),
+                        agree_cb0=agree0, agree_sub=agree_sub, ref_cpu_seconds=dt, ref_cpu_threads=torch.get_num_threads())
+    print(f"talker_17b_b8_bf16: reference-in-bf16 vs reference-in-fp32, teacher-forced: cb-0 top-1 agreement {agree0:.4f}, "
+          f"sub-codebook agreement {agree_sub:.4f}, {dt:.0f}s")
 
 
 def gen_prompt_tiny():
@@ -571,7 +675,8 @@ def gen_codec_enc_tiny():
 
 ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
        "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
-       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny, "codec_enc_small": gen_codec_enc_small}
+       "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "talker_17b_b8": gen_talker_17b_b8, "talker_06b_long": gen_talker_06b_long,
+       "talker_17b_b8_bf16": gen_talker_17b_b8_bf16, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny, "codec_enc_small": gen_codec_enc_small}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -9,7 +9,8 @@ from ._lib import QttsError, load_library, library_path  # noqa: F401
 from .codec import CodecDecoderEngine, CodecStreamDecoder, Qwen3TTSTokenizerV2Model, Qwen3TTSTokenizer  # noqa: F401
 from .talker import TalkerEngine  # noqa: F401
 from .model import Qwen3TTSForConditionalGeneration, Qwen3TTSModel, VoiceClonePromptItem  # noqa: F401
+from .attach import attach  # noqa: F401
 
 __all__ = ["CodecDecoderConfig", "TalkerConfig", "QttsError", "load_library", "library_path",
            "CodecDecoderEngine", "CodecStreamDecoder", "Qwen3TTSTokenizerV2Model", "Qwen3TTSTokenizer", "TalkerEngine",
-           "Qwen3TTSForConditionalGeneration", "Qwen3TTSModel", "VoiceClonePromptItem"]
+           "Qwen3TTSForConditionalGeneration", "Qwen3TTSModel", "VoiceClonePromptItem", "attach"]

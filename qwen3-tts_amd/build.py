@@ -27,33 +27,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 # name -> extra compiler flags; what each one tests is written next to the macro in the source.
 VARIANTS = {
-    "wtemporal": ["-DQTTS_SKINNY_WLOAD=1"],        # skinny.hip: plain (temporal) loads for every weight tile
     # attention.hip: KV beyond the 256-key prefetch window read 4 chunks per latency round instead of 1.  Only long
     # sequences see it: A/B with `tools/ab_variants.py --frames 600 --only default attn_tail` (S grows to ~650).
     "attn_tail": ["-DQTTS_ATTN_TAIL_BATCH=1"],
-    # sampling.hip: sample_kernel_v2 for 0 < top_k <= 64 (hoisted loads, processors in registers, 64-key bound).
-    "sampler_v2": ["-DQTTS_SAMPLER_V2=1"],
-    # skinny.hip + talker_engine.hip: gate/up packed 8 + 8 per strip -> N/16 single-strip workgroups (talker: 768 = 3 per
-    # CU instead of 384 = 1.5 per CU), SwiGLU pair combined across lanes in the epilogue.
-    "gu8": ["-DQTTS_SKINNY_GU8=1"],
-    # talker_engine.hip: small_to_mtp_projection(codec_embedding[j](token)) tabulated at finalize by the decode GEMM itself
-    # (117 MB at 1.7B dims); the sampler gathers the projected row, 14 projection GEMMs per frame leave the graph.
-    "cp_pretable": ["-DQTTS_CP_PRETABLE=1"],
-    # + layer-0 q|k|v of passes >= 1 tabulated the same way (470 MB at real dims): 14 more GEMMs per frame leave the graph
-    "cp_qkvtable": ["-DQTTS_CP_QKVTABLE=1"],
-    # attention.hip: attn_cp_kernel for the code predictor's single-token passes (<= 16 keys): one barrier instead of five,
-    # only the keys that exist are read, PV without a cross-lane reduction.  70 launches per frame at ~7.3 us today.
-    "attn_cp": ["-DQTTS_ATTN_CP=1"],
-    # attention.hip: attn_t1_kernel for the talker's single-token step when max_seq <= 256 (bf16 cache): per-wave softmax
-    # statistics merged once (flash-decoding inside the workgroup), two barriers instead of five.  28 launches x ~11 us.
-    "attn_t1": ["-DQTTS_ATTN_T1=1"],
-    # skinny.hip: row variances of a bf16-staged, normalised GEMM taken after the MFMA loop (they ride on the final barrier):
-    # one workgroup barrier less in front of the first MFMA in ~230 of the 443 GEMM launches of a frame.  Same bits.
-    "late_norm": ["-DQTTS_SKINNY_LATE_NORM=1"],
-    # sampling.hip: embed_sum_kernel fetches the 15 sub-codes once and requests the embedding rows 8 at a time (same sum order)
-    "embed_sum_v2": ["-DQTTS_EMBED_SUM_V2=1"],
-    "combo": ["-DQTTS_SAMPLER_V2=1", "-DQTTS_SKINNY_GU8=1", "-DQTTS_ATTN_TAIL_BATCH=1", "-DQTTS_CP_PRETABLE=1", "-DQTTS_CP_QKVTABLE=1", "-DQTTS_ATTN_CP=1", "-DQTTS_ATTN_T1=1", "-DQTTS_SKINNY_LATE_NORM=1", "-DQTTS_EMBED_SUM_V2=1"],
 }
+# Round 2 (profiles/r02_ab_variants.md): cp_pretable, cp_qkvtable, attn_cp and sampler_v2 were measured faster and are now the
+# default code; attn_t1, wtemporal, late_norm, embed_sum_v2 and gu8 were measured slower or neutral and are deleted.
 
 
 def _digest(paths, extra=()):

@@ -147,7 +147,7 @@ class CodecDecoderEngine:
     @_lib.locked
     def stream_begin(self, batch: int):
         """Start a state-carrying streaming session for `batch` sequences (include/qtts.h `qtts_codec_stream_begin`).
-        EXPERIMENTAL in round 1: compiled, not yet run on hardware -- `stream()` below is the validated packet API."""
+        Validated on MI355X in round 2 (stream == forward); `stream()` below is the stateless packet API."""
         with torch.cuda.device(self.device):
             _lib.check(self._lib.qtts_codec_stream_begin(self._h, int(batch)))
         self._stream_batch = int(batch)
@@ -265,7 +265,7 @@ class Qwen3TTSTokenizerV2Model:
 
     def encode(self, input_values: torch.Tensor, padding_mask: Optional[torch.Tensor] = None, return_dict: Optional[bool] = None):
         """tokenizer v2:961-991.  Needs the encoder weights (`encoder.*` keys of the tokenizer checkpoint); the HIP
-        encoder is built on first use.  EXPERIMENTAL in round 1 (compiled, hardware run pending)."""
+        encoder is built on first use."""
         if not self._encoder_state and self._encoder is None:
             raise NotImplementedError("this tokenizer was built without encoder weights (`encoder.*` keys): "
                                       "codec encode is unavailable (SURVEY.md 8f3)")

@@ -474,10 +474,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
 }
 
-#ifndef QTTS_ATTN_CP
-#define QTTS_ATTN_CP 0
-#endif
-#if QTTS_ATTN_CP
 // =================================================================================== attn_cp (A/B variant, build.py VARIANTS)
 // The code predictor's single-token passes (70 of the 103 attention launches of a frame) attend over at most 16 keys, yet
 // go through the general kernel above: 64-key speculative chunks, five workgroup barriers, 16 key groups combined through
@@ -707,191 +703,7 @@ __global__ __launch_bounds__(256) void attn_cp0_kernel(AttnDecodeParams p) {
         reinterpret_cast<bf16_t*>(p.out)[oo + lane + 64] = f32_to_bf16(o1);
     } else { p.out[oo + lane] = o0; p.out[oo + lane + 64] = o1; }
 }
-#endif  // QTTS_ATTN_CP
 
-#ifndef QTTS_ATTN_T1
-#define QTTS_ATTN_T1 0
-#endif
-#if QTTS_ATTN_T1
-// =================================================================================== attn_t1 (A/B variant, build.py VARIANTS)
-// The talker's single-token decode attention for engines whose max_seq fits 256 keys (the bench: 64 + 125 + 8), bf16 cache.
-// Same arithmetic as attn_decode_kernel with the workgroup-wide phases taken out: flash-decoding inside the workgroup.
-//   * keys are dealt to the 4 waves in 16-key groups (group i -> wave i % 4, pass i / 4); a lane is (key slot, 32-dim
-//     quarter) for K and owns the dim pair (2 lane, 2 lane + 1) of every key of its wave for V;
-//   * each wave takes softmax statistics over ITS keys only (local max / sum, DPP) and accumulates its unnormalised PV with
-//     e_k broadcast from the owning lane; the waves' partials are merged once: out = sum_w acc_w e^(m_w - m) / sum_w l_w e^(m_w - m).
-// Two workgroup barriers (new-token vectors, merge) instead of five, no score buffer, no 16-group LDS combine.
-__global__ __launch_bounds__(256) void attn_t1_kernel(AttnDecodeParams p) {
-    constexpr int HD = 128, NP = 4;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float qs[2][HD];
-    __shared__ __attribute__((aligned(16))) float kn[HD];
-    __shared__ __attribute__((aligned(16))) float vn[HD];
-    __shared__ __attribute__((aligned(16))) float cacc[4][2][HD];
-    __shared__ float cm[4][2], cl[4][2];
-    const int GQ = p.nh / p.nkv;
-    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int kk = lane >> 2, qq = lane & 3;
-    const bf16_t* kc = reinterpret_cast<const bf16_t*>(p.kv.k);
-    const bf16_t* vc = reinterpret_cast<const bf16_t*>(p.kv.v);
-    auto key_base = [&](int s) -> size_t {
-        const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
-        return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD;
-    };
-    // this step's row first (it is the longest dependency), then the scalars the cache reads hang on
-    const bool has_vec = wave >= 2 || wave < GQ;
-    float x0 = 0.f, x1 = 0.f;
-    if (has_vec) {
-        const int col = wave < 2 ? (kvh * GQ + wave) * HD : (wave == 2 ? (p.nh + kvh) * HD : (p.nh + p.nkv + kvh) * HD);
-        const float* src = p.qkv + (size_t)b * p.ld + col;
-        x0 = src[lane]; x1 = src[lane + 64];
-    }
-    const int S0 = p.len_dev ? *p.len_dev : p.len_static;
-    const int npad = p.n_pad ? p.n_pad[b] : 0;
-    const int done = p.done_flag ? *p.done_flag : 0;
-    const int S1 = S0 + 1;
-    // ---- 0. cache reads: K rows key-major (4 x 16 B per lane per pass), V rows as one bf16 pair per key per lane
-    u32x4 kr[NP][4];
-    unsigned int vr[NP][16];
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        const int g0 = (ps * 4 + wave) * 16;                      // first key of this wave's group in this pass
-        const int s = g0 + kk;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) kr[ps][w] = (u32x4){0u, 0u, 0u, 0u};
-        if (g0 < S0 && s < S0 && s >= npad) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(kc + key_base(s) + qq * 32);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) kr[ps][w] = src[w];
-        }
-#pragma unroll
-        for (int sl = 0; sl < 16; ++sl) {
-            vr[ps][sl] = 0u;
-            if (g0 + sl < S0 && g0 + sl >= npad)
-                vr[ps][sl] = *reinterpret_cast<const unsigned int*>(vc + key_base(g0 + sl) + 2 * lane);
-        }
-    }
-    if (done) return;
-    // ---- 1. q/k RMSNorm + RoPE at position S0 - npad, K/V append (as attn_decode_kernel)
-    if (has_vec) {
-        const float* w = wave < 2 ? p.qw : (wave == 2 ? p.kw : nullptr);
-        if (w) {
-            const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
-            const float rs = rsqrtf(ss / (float)HD + p.eps);
-            x0 = w[lane] * (x0 * rs);
-            x1 = w[lane + 64] * (x1 * rs);
-            const float ang = (float)(S0 - npad) * p.inv_freq[lane];
-            const float c = cosf(ang), sn = sinf(ang);
-            const float o0 = x0 * c - x1 * sn, o1 = x1 * c + x0 * sn;
-            x0 = o0; x1 = o1;
-        }
-        if (wave >= 2) {
-            const size_t o = key_base(S0);
-            bf16_t* cdst = reinterpret_cast<bf16_t*>(wave == 2 ? p.kv.k : p.kv.v);
-            const bf16_t h0 = f32_to_bf16(x0), h1 = f32_to_bf16(x1);
-            cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
-            x0 = bf16_to_f32(h0); x1 = bf16_to_f32(h1);
-        }
-        float* dst = wave < 2 ? qs[wave] : (wave == 2 ? kn : vn);
-        dst[lane] = x0; dst[lane + 64] = x1;
-    }
-    __syncthreads();
-    // ---- 2. this wave's keys, both query heads
-    const float scale = rsqrtf((float)HD);
-    float sc[NP][2], m[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        const int g0 = (ps * 4 + wave) * 16;
-        const int s = g0 + kk;
-        sc[ps][0] = sc[ps][1] = -INFINITY;
-        if (g0 < S1) {                                            // wave-uniform
-            float kx[32];
-            if (s == S0) {
-#pragma unroll
-                for (int e = 0; e < 32; ++e) kx[e] = kn[qq * 32 + e];
-            } else {
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        kx[w * 8 + 2 * e] = __uint_as_float(kr[ps][w][e] << 16);
-                        kx[w * 8 + 2 * e + 1] = __uint_as_float(kr[ps][w][e] & 0xffff0000u);
-                    }
-            }
-            const bool valid = s < S1 && s >= npad;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (q < GQ) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 32; ++e) a += qs[q][qq * 32 + e] * kx[e];
-                    a += __shfl_xor(a, 1);
-                    a += __shfl_xor(a, 2);
-                    sc[ps][q] = valid ? a * scale : -INFINITY;
-                    m[q] = fmaxf(m[q], sc[ps][q]);
-                }
-            }
-        }
-    }
-    float l[2] = {0.f, 0.f}, acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) m[q] = wave_max64_dpp(m[q]);
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float e = sc[ps][q] > -INFINITY ? expf(sc[ps][q] - m[q]) : 0.f;
-            sc[ps][q] = e;
-            l[q] += qq == 0 ? e : 0.f;
-        }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) l[q] = wave_sum64_dpp(l[q]);
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-        const int g0 = (ps * 4 + wave) * 16;
-        if (g0 < S1) {
-#pragma unroll
-            for (int sl = 0; sl < 16; ++sl) {
-                const int s = g0 + sl;
-                if (s < S1) {                                     // wave-uniform
-                    float v0, v1;
-                    if (s == S0) { v0 = vn[2 * lane]; v1 = vn[2 * lane + 1]; }
-                    else { v0 = __uint_as_float(vr[ps][sl] << 16); v1 = __uint_as_float(vr[ps][sl] & 0xffff0000u); }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float ek = __shfl(sc[ps][q], sl * 4);
-                        acc[q][0] += ek * v0;
-                        acc[q][1] += ek * v1;
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        cacc[wave][q][2 * lane] = acc[q][0];
-        cacc[wave][q][2 * lane + 1] = acc[q][1];
-        if (lane == 0) { cm[wave][q] = m[q]; cl[wave][q] = l[q]; }
-    }
-    __syncthreads();
-    // ---- 3. merge the four waves' partials (fixed order)
-    if (tid < GQ * HD) {
-        const int q = tid / HD, d = tid % HD;
-        const float mm = fmaxf(fmaxf(cm[0][q], cm[1][q]), fmaxf(cm[2][q], cm[3][q]));
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = cm[w][q] > -INFINITY ? expf(cm[w][q] - mm) : 0.f;
-            num += cacc[w][q][d] * f;
-            den += cl[w][q] * f;
-        }
-        const size_t o = (size_t)b * p.ldo + (kvh * GQ + q) * HD + d;
-        if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(num / den);
-        else p.out[o] = num / den;
-    }
-}
-#endif  // QTTS_ATTN_T1
 
 template <typename KVT, int NQ>
 static void launch_attn_decode_t(const AttnDecodeParams& p, size_t lds, hipStream_t st) {
@@ -909,7 +721,6 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.hd == 128, QTTS_ERR_ARG, "attn_decode: head_dim must be 128");
     const int GQ = p.nh / p.nkv, NQ = p.n_new * GQ;
     QTTS_REQUIRE((NQ == 1 || NQ == 2 || NQ == 4) && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: 1, 2 or 4 queries per kv head");
-#if QTTS_ATTN_CP
     if (p.n_new == 2 && !p.len_dev && !p.n_pad && p.len_static == 0 && GQ <= 2) {          // the code predictor's pass 0
         if (p.kv.bf16) hipLaunchKernelGGL(attn_cp0_kernel<bf16_t>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_cp0_kernel<float>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
@@ -922,14 +733,6 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }
-#endif
-#if QTTS_ATTN_T1
-    if (p.kv.bf16 && p.n_new == 1 && GQ <= 2 && p.max_len <= 256) {      // at most 256 keys ever: the bench's engine size
-        hipLaunchKernelGGL(attn_t1_kernel, dim3(p.B * p.nkv), dim3(256), 0, st, p);
-        QTTS_CHECK_HIP(hipGetLastError());
-        return;
-    }
-#endif
     const size_t lds = ((size_t)NQ * 128 + 2 * p.n_new * 128 + 16 * NQ * 128 + (size_t)NQ * p.max_len + 8) * sizeof(float);
     QTTS_REQUIRE(lds <= 150 * 1024, QTTS_ERR_LIMIT, "attn_decode: max_len too large for LDS scores");
     if (p.kv.bf16) {

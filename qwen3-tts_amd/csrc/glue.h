@@ -15,6 +15,19 @@ struct StepState {
 };
 void launch_sample_finish(const StepState& s, int B, int max_new_tokens, hipStream_t st);
 
+// teacher forcing (diagnostic): record the engine's own greedy choices, then replace them by `codes` (sampling.hip)
+struct TeacherParams {
+    const int64_t* codes;       // forced codes [B][F][G]
+    int F, G, B, V;
+    int* own;                   // out: own choices [B][F+1][G] (entry [b][i][0] = own cb-0 token i; [b][f][1+j] = own sub-code j of frame f)
+    const int* slots;           // [F+1]: logits-trace slot of token step i, or -1
+    float* trace;               // [n_slots][B][V] raw cb-0 logits
+    const float* logits;        // the engine's cb-0 logits buffer [B][V]
+    int* cur_tok; int* sub; int sub_stride; int* generated; int gen_stride;
+    StepState st;
+};
+void launch_teacher(const TeacherParams& p, int which /*0 trace, 1 token, 2 sub-codes*/, hipStream_t st);
+
 struct CpGatherParams {
     int pass, B, H;
     const float* past_hidden;   // [B][H]
@@ -43,7 +56,7 @@ void launch_embed_sum(const EmbedSumParams& p, hipStream_t st);
 
 // y = g * (x * rsqrt(mean(x^2)+eps)) per row (final talker norm -> past_hidden), early-exit on *done
 void launch_apply_norm(const float* x, int ldx, const float* g, float eps, float* y, int ldy, int rows, int C,
-                       const int* done, hipStream_t st);
+                       const int* done, hipStream_t st, unsigned short* y16 = nullptr /* optional bf16 copy [rows][ldy] */);
 // ss[r] = sum_c x[r][c]^2 (only for GEMMs that cannot stage x through LDS)
 void launch_row_ss(const float* x, int ldx, int rows, int C, float* ss, const int* done, hipStream_t st);
 

@@ -29,14 +29,14 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
 // 1-KiB MFMA-operand tiles (see pack_skinny_weight).
 struct SkinnyParams {
     const float* x; int ldx; int M;
-    int x_bf16;                  // 1: x points to bf16 [M][ldx] (written by a bf16-output producer); no norm; staged by LDS-DMA
+    int x_bf16;                  // 1: x points to bf16 [M][ldx] (the producer's bf16 copy); each wave loads its own MFMA B fragments
     int out_bf16;                // 1: out is written as bf16 [M][ldo] (feeds an x_bf16 consumer)
     void* out16;                 // optional second output: bf16 copy [M][ldo] of the fp32 `out` (hidden state for the next norm'd GEMM)
     const void* Wp;              // packed tiles [N/16][K/KT][64 lanes][16 B] (RMSNorm weight already folded in)
     int N, K;
     int fs;                      // output features per strip the weights were packed with: 16 (default, 0) | 8 | 4
     int norm;                    // 1: out = rstd[m] * (x . W'^T) with rstd = rsqrt(mean_k x^2 + eps)
-    const float* ss_in;          // only when the kernel cannot stage x through LDS: sum_k x[m][k]^2 per row [M]
+    const float* ss_in;          // fp32 kernel only: sum_k x[m][k]^2 per row [M] (the bf16 kernel takes it on the matrix pipe)
     float eps;
     const float* bias;           // [N] or null
     const float* res; int ldr;   // residual [M][ldr] or null
@@ -46,7 +46,7 @@ struct SkinnyParams {
     int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
 };
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);
-bool skinny_can_stage(int M, int K, bool bf16);
+bool skinny_takes_bf16_x(int M, int K, bool bf16);   // bf16 mode: any M <= 64, K % 32 == 0
 size_t skinny_packed_bytes(int N, int K, bool bf16);
 // Pack W[N][K] (row-major f32), optionally scaled per input column by g[K], into the streaming tile layout;
 // gate/up interleaving is the caller's.
@@ -164,9 +164,6 @@ struct AttnDecodeParams {
 void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st);
 
 // --------------------------------------------------------------------------------- sampling.hip
-#ifndef QTTS_CP_QKVTABLE
-#define QTTS_CP_QKVTABLE 0
-#endif
 struct SampleParams {
     const float* logits; int ld; int V; int B;
     // processors
@@ -192,10 +189,8 @@ struct SampleParams {
     // optional fused gather (code predictor): gather_out[b][:] = gather_emb[token][:] -- the NEXT pass's input row
     // (codec_embedding[j](token), M:1281), so no separate gather kernel sits between sampler and GEMM
     const float* gather_emb; int gather_C; float* gather_out; unsigned short* gather_out16;
-#if QTTS_CP_QKVTABLE
     // A/B variant (build.py VARIANTS): second fused gather -- the next pass's layer-0 q|k|v row, tabulated at finalize
     const float* gather2_emb; int gather2_C; float* gather2_out;
-#endif
 };
 void launch_sample(const SampleParams& p, hipStream_t st);
 

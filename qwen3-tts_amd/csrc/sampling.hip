@@ -297,13 +297,11 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
             }
         }
     }
-#if QTTS_CP_QKVTABLE
     if (p.gather2_emb) {
         const float* src2 = p.gather2_emb + (size_t)token * p.gather2_C;
         for (int c = tid * 4; c < p.gather2_C; c += 1024)
             *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
     }
-#endif
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];
@@ -315,13 +313,6 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
 }
 
-#ifndef QTTS_SAMPLER_V2
-#define QTTS_SAMPLER_V2 0
-#endif
-#ifndef QTTS_EMBED_SUM_V2
-#define QTTS_EMBED_SUM_V2 0
-#endif
-#if QTTS_SAMPLER_V2
 // A/B variant (build.py VARIANTS, never the default build): the sampling path for 0 < top_k <= 64 and V <= 4096 (the
 // reference default is top_k = 50 on 2048 / 3072 logits) with the fixed costs taken out of sample_kernel above:
 //   * every load that does not depend on another load (done flag, counters, Philox key, the row's logits, the suppress
@@ -584,13 +575,11 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
             }
         }
     }
-#if QTTS_CP_QKVTABLE
     if (p.gather2_emb) {
         const float* src2 = p.gather2_emb + (size_t)token * p.gather2_C;
         for (int c = tid * 4; c < p.gather2_C; c += 1024)
             *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
     }
-#endif
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];
@@ -601,13 +590,11 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
         p.tok_out[(size_t)b * p.tok_stride] = token;
     }
 }
-#endif  // QTTS_SAMPLER_V2
 
 void launch_sample(const SampleParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.V <= SAMPLE_MAX_V, QTTS_ERR_LIMIT, "sample: vocab too large");
     QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f) || (p.top_k > 0 && p.top_k <= 256), QTTS_ERR_ARG,
                  "sample: top_p < 1 on device needs 0 < top_k <= 256 (the reference default is top_k = 50)");
-#if QTTS_SAMPLER_V2
     if (p.do_sample && p.top_k > 0 && p.top_k <= 64 && p.top_k < p.V && p.V <= 4096) {
         if (p.V <= 2048) hipLaunchKernelGGL(sample_kernel_v2<8>, dim3(p.B), dim3(256), 0, st, p);
         else if (p.V <= 3072) hipLaunchKernelGGL(sample_kernel_v2<12>, dim3(p.B), dim3(256), 0, st, p);
@@ -615,7 +602,6 @@ void launch_sample(const SampleParams& p, hipStream_t st) {
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }
-#endif
     hipLaunchKernelGGL(sample_kernel, dim3(p.B), dim3(256), 0, st, p);
     QTTS_CHECK_HIP(hipGetLastError());
 }
@@ -637,6 +623,46 @@ __global__ void sample_finish_kernel(StepState st, int B, int max_new_tokens) {
 }
 void launch_sample_finish(const StepState& s, int B, int max_new_tokens, hipStream_t st) {
     hipLaunchKernelGGL(sample_finish_kernel, dim3(1), dim3(64), 0, st, s, B, max_new_tokens);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------- teacher forcing (diagnostic mode)
+// Frame-level teacher forcing for the parity measurements of the bf16 mode (tests/test_gpu_parity.py): the engine's own greedy
+// choices are RECORDED and then REPLACED by a given code sequence, so that a whole utterance is compared decision by decision
+// instead of stopping at the first flip.  Three tiny kernels, launched only in this mode (never in the captured frame graph).
+__global__ void teacher_trace_kernel(TeacherParams p) {          // before a cb-0 sample: raw logits of selected token steps
+    if (*p.st.done) return;
+    const int i = *p.st.n_generated;                                 // index of the token about to be sampled
+    const int slot = (p.slots && i <= p.F) ? p.slots[i] : -1;
+    if (slot < 0) return;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < p.V; c += blockDim.x) p.trace[((size_t)slot * p.B + b) * p.V + c] = p.logits[(size_t)b * p.V + c];
+}
+__global__ void teacher_tok_kernel(TeacherParams p) {            // after a cb-0 sample + sample_finish (idempotent once `done`)
+    const int b = threadIdx.x;
+    if (b >= p.B) return;
+    const int i = *p.st.n_generated - 1;                             // index of the token just sampled
+    if (i < 0 || i > p.F) return;
+    p.own[((size_t)b * (p.F + 1) + i) * p.G] = p.cur_tok[b];
+    if (i < p.F) {
+        const int tok = (int)p.codes[((size_t)b * p.F + i) * p.G];
+        p.cur_tok[b] = tok;
+        p.generated[(size_t)b * p.gen_stride + i] = tok;            // the repetition-penalty history follows the forced sequence
+    }
+}
+__global__ void teacher_sub_kernel(TeacherParams p) {            // after the code predictor's passes, before the embedding sum
+    if (*p.st.done) return;
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int f = *p.st.gen_step;
+    if (j >= p.G - 1 || f >= p.F) return;
+    p.own[((size_t)b * (p.F + 1) + f) * p.G + 1 + j] = p.sub[(size_t)b * p.sub_stride + j];
+    p.sub[(size_t)b * p.sub_stride + j] = (int)p.codes[((size_t)b * p.F + f) * p.G + 1 + j];
+}
+void launch_teacher(const TeacherParams& p, int which, hipStream_t st) {
+    QTTS_REQUIRE(p.B <= 64 && p.G <= 64, QTTS_ERR_LIMIT, "teacher forcing: B, G <= 64");
+    if (which == 0) hipLaunchKernelGGL(teacher_trace_kernel, dim3(p.B), dim3(256), 0, st, p);
+    else if (which == 1) hipLaunchKernelGGL(teacher_tok_kernel, dim3(1), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(teacher_sub_kernel, dim3(p.B), dim3(64), 0, st, p);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -683,31 +709,8 @@ __global__ __launch_bounds__(256) void embed_sum_kernel(EmbedSumParams p) {
     const int b = blockIdx.x;
     const int f = *p.st.gen_step;          // frame index == generation_step
     const int tok0 = p.cur_tok[b];
-#if QTTS_EMBED_SUM_V2
-    // A/B variant (build.py VARIANTS): the loop below chains token load -> row load -> add 15 times (12.8 us measured for a
-    // kernel that moves 130 KB per row).  Here the 15 tokens are fetched once, then the embedding rows are requested 8 at a
-    // time before any of them is added; the additions stay in codebook order, so the sum has the same bits.
-    __shared__ int tk_s[64];
-    const bool staged_tokens = p.G - 1 <= 64;
-    if (staged_tokens && (int)threadIdx.x < p.G - 1) tk_s[threadIdx.x] = p.sub[(size_t)b * p.sub_stride + threadIdx.x];
-    __syncthreads();
-#endif
     for (int c = threadIdx.x * 4; c < p.H; c += 1024) {
         float4 a = *reinterpret_cast<const float4*>(p.talker_emb + (size_t)tok0 * p.H + c);
-#if QTTS_EMBED_SUM_V2
-        if (staged_tokens) {
-            for (int i0 = 0; i0 < p.G - 1; i0 += 8) {
-                float4 e[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + u < p.G - 1)
-                        e[u] = *reinterpret_cast<const float4*>(p.cp_emb + ((size_t)(i0 + u) * p.cp_vocab + tk_s[i0 + u]) * p.H + c);
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + u < p.G - 1) { a.x += e[u].x; a.y += e[u].y; a.z += e[u].z; a.w += e[u].w; }
-            }
-        } else
-#endif
         for (int i = 0; i < p.G - 1; ++i) {
             const int tk = p.sub[(size_t)b * p.sub_stride + i];
             const float4 e = *reinterpret_cast<const float4*>(p.cp_emb + ((size_t)i * p.cp_vocab + tk) * p.H + c);
@@ -738,7 +741,7 @@ void launch_embed_sum(const EmbedSumParams& p, hipStream_t st) {
 
 // y = g * (x * rsqrt(mean(x^2) + eps)) (Qwen3TTSRMSNorm M:605-610) for the final talker norm -> past_hidden
 __global__ __launch_bounds__(256) void apply_norm_kernel(const float* x, int ldx, const float* g, float eps, float* y,
-                                                         int ldy, int C, const int* done) {
+                                                         int ldy, int C, const int* done, unsigned short* y16) {
     if (done && *done) return;
     __shared__ float sm[4];
     const int r = blockIdx.x;
@@ -755,11 +758,15 @@ __global__ __launch_bounds__(256) void apply_norm_kernel(const float* x, int ldx
         float4 o;
         o.x = w.x * (v.x * rstd); o.y = w.y * (v.y * rstd); o.z = w.z * (v.z * rstd); o.w = w.w * (v.w * rstd);
         *reinterpret_cast<float4*>(y + (size_t)r * ldy + c) = o;
+        if (y16) {                         // bf16 copy for the consuming GEMM (codec_head)
+            ushort4 h; h.x = f32_to_bf16(o.x); h.y = f32_to_bf16(o.y); h.z = f32_to_bf16(o.z); h.w = f32_to_bf16(o.w);
+            *reinterpret_cast<ushort4*>(y16 + (size_t)r * ldy + c) = h;
+        }
     }
 }
 void launch_apply_norm(const float* x, int ldx, const float* g, float eps, float* y, int ldy, int rows, int C,
-                       const int* done, hipStream_t st) {
-    hipLaunchKernelGGL(apply_norm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, g, eps, y, ldy, C, done);
+                       const int* done, hipStream_t st, unsigned short* y16) {
+    hipLaunchKernelGGL(apply_norm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, g, eps, y, ldy, C, done, y16);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 

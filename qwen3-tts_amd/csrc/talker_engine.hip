@@ -17,16 +17,6 @@
 #include "kernels.h"
 #include "glue.h"
 
-#ifndef QTTS_SKINNY_GU8
-#define QTTS_SKINNY_GU8 0
-#endif
-#ifndef QTTS_CP_PRETABLE
-#define QTTS_CP_PRETABLE 0
-#endif
-#if QTTS_CP_QKVTABLE && !QTTS_CP_PRETABLE      // the q|k|v table is built from the projected-embedding table
-#undef QTTS_CP_PRETABLE
-#define QTTS_CP_PRETABLE 1
-#endif
 
 using namespace qtts;
 
@@ -51,13 +41,9 @@ struct qtts_talker {
     StackDims td, cd;
     std::vector<LayerW> tl, cl;
     DevBuf t_norm, c_norm, head_p, emb_talker, emb_cp, proj_p, proj_b, inv_freq_t, inv_freq_c;
-#if QTTS_CP_QKVTABLE
     DevBuf cp_qkv0_tab;   // [G-2][cp_vocab][q|k|v width] = layer-0 qkv GEMM (norm folded) of the pass input row of every token
     bool skip_qkv = false;
-#endif
-#if QTTS_CP_PRETABLE
     DevBuf emb_cp_proj;   // [G-2][cp_vocab][cp H] = small_to_mtp_projection(codec_embedding[g](v)), built at finalize by the decode GEMM itself
-#endif
     std::vector<DevBuf> lm_head_p;
     int fs_proj = 16, fs_lm = 16, fs_head = 16;
     DevBuf tp_fc1, tp_b1, tp_fc2, tp_b2;
@@ -70,7 +56,7 @@ struct qtts_talker {
     DevBuf kpool_t, vpool_t, kpool_c, vpool_c, ptab_t, ptab_c;
     KvCache kv_t, kv_c;
     // decode state / scratch
-    DevBuf x, qkv, att, act, logits, past_hidden, cp_in, cp_x, cp_qkv, cp_att, cp_act, cp_logits, x16, cp_x16;
+    DevBuf x, qkv, att, act, logits, past_hidden, cp_in, cp_x, cp_qkv, cp_att, cp_act, cp_logits, x16, cp_x16, ph16, cp_in16;
     DevBuf cur_tok, sub, generated, ss_rows, ints, n_pad_d, suppress, trailing, tts_pad;
     // prefill scratch
     DevBuf pf_x, pf_n, pf_qkv, pf_att, pf_act, tp_tmp;
@@ -97,6 +83,15 @@ struct qtts_talker {
         int64_t* codes = nullptr; float* hidden = nullptr;
     } sg;
     int graph_nodes = 0;
+    // teacher forcing (diagnostic mode, eager only): qtts_talker_set_teacher
+    struct Teacher { const int64_t* codes = nullptr; int F = 0; int* own = nullptr; const int* slots = nullptr; float* trace = nullptr; } tf;
+    TeacherParams teacher_params() {
+        TeacherParams p{};
+        p.codes = tf.codes; p.F = tf.F; p.G = cfg.num_code_groups; p.B = B; p.V = cfg.vocab_size; p.own = tf.own; p.slots = tf.slots;
+        p.trace = tf.trace; p.logits = logits.as<float>(); p.cur_tok = cur_tok.as<int>(); p.sub = sub.as<int>();
+        p.sub_stride = cfg.num_code_groups; p.generated = generated.as<int>(); p.gen_stride = gen_cap; p.st = ss;
+        return p;
+    }
     // profiling of the dominant kernel
     bool profile = false, timing_now = false, skinny_only = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -133,11 +128,10 @@ struct qtts_talker {
         pack_skinny_weight(w.data(), N, K, bf16, h.data(), g ? g->data() : nullptr, fs);     // g: folded RMSNorm weight
         d.upload(h.data(), h.size());
     }
-    // Narrow strips when the GEMM would otherwise launch far fewer than 256 workgroups.  Only the staged bf16 M<=16
-    // kernel has them, so they are used when every decode GEMM is guaranteed to take that path (max_batch <= 8:
-    // the code predictor's first pass has M = 2B rows).
+    // Narrow strips when the GEMM would otherwise launch far fewer than 256 workgroups (bf16 kernel only).
     int choose_fs(int N, int K) const {
-        if (!bf16 || cfg.max_batch > 8 || !skinny_can_stage(16, K, true)) return 16;
+        (void)K;
+        if (!bf16) return 16;
         int fs = 16;
         while (fs > 4 && N / fs < 192) fs /= 2;
         return fs;
@@ -159,29 +153,12 @@ struct qtts_talker {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
                          PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
         auto guw = interleave_gu(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H);
-#if QTTS_SKINNY_GU8
-        // A/B variant (build.py VARIANTS): the decode copy interleaves 8 gate + 8 up rows per 16-row strip, so that one
-        // strip is a complete SwiGLU pair and the gate/up GEMM launches N/16 single-strip workgroups (skinny.hip).
-        std::vector<float> guw8((size_t)2 * d.I * d.H);
-        {
-            const auto& gw = PS(p + "mlp.gate_proj.weight", {d.I, d.H});
-            const auto& uw = PS(p + "mlp.up_proj.weight", {d.I, d.H});
-            for (int f = 0; f < d.I; ++f) {
-                memcpy(&guw8[((size_t)(f / 8) * 16 + f % 8) * d.H], &gw[(size_t)f * d.H], (size_t)d.H * 4);
-                memcpy(&guw8[((size_t)(f / 8) * 16 + 8 + f % 8) * d.H], &uw[(size_t)f * d.H], (size_t)d.H * 4);
-            }
-        }
-#endif
         auto& ow = PS(p + "self_attn.o_proj.weight", {d.H, d.qd});
         auto& dw = PS(p + "mlp.down_proj.weight", {d.H, d.I});
         upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H, &PS(p + "input_layernorm.weight", {d.H}));
         L.fs_o = choose_fs(d.H, d.qd); L.fs_d = choose_fs(d.H, d.I);
         upload_packed(L.o_p, ow, d.H, d.qd, nullptr, L.fs_o);
-#if QTTS_SKINNY_GU8
-        upload_packed(L.gu_p, guw8, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
-#else
         upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
-#endif
         upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
@@ -201,12 +178,13 @@ struct qtts_talker {
     void skinny(const SkinnyParams& p, hipStream_t st) { launch_skinny(p, bf16, st); ++skinny_count; }
     int64_t skinny_count = 0;
 
-    // x-side handling of a GEMM whose input is RMS-normalised: staged kernels compute rstd themselves; the
-    // others (fp32 parity mode, M > 16) get the row sums of squares from one extra tiny kernel.
+    // x-side handling of a GEMM whose input is RMS-normalised: the bf16 kernel takes the row variances on the matrix pipe
+    // (skinny.hip) from the producer's bf16 copy of x; the fp32 parity kernel gets the row sums of squares from one extra
+    // tiny kernel.
     void norm_input(SkinnyParams& p, const StackDims& d, const void* x16v, hipStream_t st) {
         p.norm = 1; p.eps = d.eps;
-        if (skinny_can_stage(p.M, p.K, bf16)) {
-            if (x16v) { p.x = reinterpret_cast<const float*>(x16v); p.x_bf16 = 1; }     // LDS-DMA of the bf16 hidden state
+        if (bf16) {
+            if (x16v) { p.x = reinterpret_cast<const float*>(x16v); p.x_bf16 = 1; }
         } else {
             if (!skinny_only) launch_row_ss(p.x, p.ldx, p.M, p.K, ssbuf(), ss.done, st);
             p.ss_in = ssbuf();
@@ -217,20 +195,15 @@ struct qtts_talker {
                       float* actb, int M, int n_new, KvCache& kv, int layer, const int* len_dev, int len_static,
                       const int* npad, const float* inv_freq, int max_len, hipStream_t st) {
         // xs16: bf16 copy of the hidden state kept in step with xs by every producer (bf16 mode, M <= 16), or null
-        const bool h16 = xs16 && skinny_can_stage(M, d.H, bf16);
+        const bool h16 = xs16 && skinny_takes_bf16_x(M, d.H, bf16);
         SkinnyParams p{};
         p.done_flag = ss.done;
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
-#if QTTS_CP_QKVTABLE
         if (!skip_qkv) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
             norm_input(p, d, h16 ? xs16 : nullptr, st);
             skinny(p, st);
         }
-#else
-        norm_input(p, d, h16 ? xs16 : nullptr, st);
-        skinny(p, st);
-#endif
         AttnDecodeParams a{};
         a.qkv = qkvb; a.ld = d.qd + 2 * d.kvd; a.B = B; a.n_new = n_new; a.nh = d.nh; a.nkv = d.nkv; a.hd = d.hd;
         a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
@@ -238,7 +211,7 @@ struct qtts_talker {
         a.max_len = max_len; a.done_flag = ss.done;
         // bf16 mode: attention output and SwiGLU output travel as bf16 (as in the reference's bf16 path) and are
         // staged into the consuming GEMM by LDS-DMA
-        const bool att16 = bf16 && skinny_can_stage(M, d.qd, true), act16 = bf16 && skinny_can_stage(M, d.I, true);
+        const bool att16 = bf16 && skinny_takes_bf16_x(M, d.qd, true), act16 = bf16 && skinny_takes_bf16_x(M, d.I, true);
         a.out_bf16 = att16;
         if (!skinny_only) launch_attn_decode(a, st);
         SkinnyParams o{};
@@ -311,7 +284,6 @@ void qtts_talker::finalize() {
         upload_packed(proj_p, PS("code_predictor.small_to_mtp_projection.weight", {cd.H, td.H}), cd.H, td.H, nullptr, fs_proj);
         upload_f(proj_b, PS("code_predictor.small_to_mtp_projection.bias", {cd.H}));
     }
-#if QTTS_CP_PRETABLE
     // A/B variant (build.py VARIANTS): passes 1 .. G-2 of the code predictor feed small_to_mtp_projection with
     // codec_embedding[j-1](token) (M:1281-1282) -- a function of the token alone.  Tabulate it once, with the SAME decode
     // GEMM launches the frame step would make (16 rows at a time; a row's result does not depend on the batch around it), so
@@ -330,7 +302,6 @@ void qtts_talker::finalize() {
             }
         QTTS_CHECK_HIP(hipDeviceSynchronize());
     }
-#endif
     has_text_proj = host.count("text_projection.linear_fc1.weight") > 0;
     if (has_text_proj) {
         const int TH = c.text_hidden_size;
@@ -362,12 +333,8 @@ void qtts_talker::finalize() {
     weight_bytes_frame = c.num_hidden_layers * layer_b(td) + eb * (double)c.vocab_size * td.H +
                          (G - 1) * (c.cp_num_hidden_layers * layer_b(cd) + eb * (double)c.cp_vocab_size * cd.H +
                                     (has_proj ? eb * (double)cd.H * td.H : 0.0));
-#if QTTS_CP_PRETABLE
     if (has_proj && G > 2) weight_bytes_frame -= (G - 2) * eb * (double)cd.H * td.H;   // only pass 0 still runs the projection
-#endif
-#if QTTS_CP_QKVTABLE
     if (G > 2) weight_bytes_frame -= (G - 2) * eb * (double)(cd.qd + 2 * cd.kvd) * cd.H;   // layer-0 qkv GEMM of passes >= 1
-#endif
 
     // ---- KV caches (pages of 16 tokens, reserved up front)
     const size_t esz = bf16 ? 2 : 4;
@@ -392,7 +359,7 @@ void qtts_talker::finalize() {
 
     // ---- decode scratch (rows <= 64)
     const int R = 64;
-    x16.alloc((size_t)R * td.H * 2); cp_x16.alloc((size_t)R * cd.H * 2);
+    x16.alloc((size_t)R * td.H * 2); cp_x16.alloc((size_t)R * cd.H * 2); ph16.alloc((size_t)R * td.H * 2); cp_in16.alloc((size_t)R * td.H * 2);
     x.alloc((size_t)R * td.H * 4); qkv.alloc((size_t)R * (td.qd + 2 * td.kvd) * 4); att.alloc((size_t)R * td.qd * 4);
     act.alloc((size_t)R * td.I * 4); logits.alloc((size_t)R * c.vocab_size * 4); past_hidden.alloc((size_t)R * td.H * 4);
     cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
@@ -402,7 +369,6 @@ void qtts_talker::finalize() {
     QTTS_CHECK_HIP(hipMemset(ss_rows.p, 0, ss_rows.bytes));
     int* ip = ints.as<int>();
     ss = {ip + 0, ip + 1, ip + 2, ip + 3, ip + 4, ip + 64};
-#if QTTS_CP_QKVTABLE
     // A/B variant (build.py VARIANTS): in passes 1 .. G-2 the code predictor's layer-0 q|k|v GEMM sees only the pass input row,
     // a function of the previous token alone (has_proj: the projected embedding above; otherwise codec_embedding itself).
     // Tabulate it with the same launches the frame step makes -- bf16 mode: LDS-staged from the bf16 image of the row with the
@@ -410,7 +376,7 @@ void qtts_talker::finalize() {
     if (G > 2) {
         const int nt = G - 2, QW = cd.qd + 2 * cd.kvd, Vc = c.cp_vocab_size;
         const float* xt = has_proj ? emb_cp_proj.as<float>() : emb_cp.as<float>();
-        const bool staged = skinny_can_stage(16, cd.H, bf16);
+        const bool staged = skinny_takes_bf16_x(16, cd.H, bf16);
         DevBuf x16t;
         if (staged) {
             std::vector<float> hx((size_t)nt * Vc * cd.H);
@@ -432,7 +398,6 @@ void qtts_talker::finalize() {
             }
         QTTS_CHECK_HIP(hipDeviceSynchronize());
     }
-#endif
     host.clear();
     finalized = true;
 }
@@ -509,8 +474,10 @@ void qtts_talker::sample_talker(const qtts_sampling& sp, int eos, int min_new, i
     p.seed = sp.seed; p.seed_dev = seed_d.as<unsigned long long>(); p.stream_id = 0; p.step_dev = ss.n_generated;
     p.tok_out = cur_tok.as<int>(); p.tok_stride = 1; p.unfinished = ss.unfinished; p.generated_out = generated.as<int>();
     p.max_new_tokens = max_new; p.done_in = ss.done;
+    if (tf.codes && tf.trace) launch_teacher(teacher_params(), 0, st);
     launch_sample(p, st);
     launch_sample_finish(ss, B, max_new, st);
+    if (tf.codes) launch_teacher(teacher_params(), 1, st);
 }
 
 // ------------------------------------------------------------------------------------------ one frame
@@ -527,41 +494,36 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         gp.sub = sub.as<int>(); gp.sub_stride = G; gp.done = ss.done;
         unsigned short* c16 = bf16 ? cp_x16.as<unsigned short>() : nullptr;
         // passes j >= 1 get their input row from the previous pass's sampler (fused gather): only pass 0 gathers here
-#if QTTS_CP_PRETABLE
         if (has_proj && j >= 1) {
             // the previous pass's sampler gathered the projected row straight into cp_x (and its bf16 shadow)
         } else
-#endif
         if (has_proj) {
-            gp.out = cp_in.as<float>(); gp.out16 = nullptr;
+            gp.out = cp_in.as<float>(); gp.out16 = bf16 ? cp_in16.as<unsigned short>() : nullptr;
             if (!skinny_only && j == 0) launch_cp_gather(gp, st);
             SkinnyParams pj{};
             pj.done_flag = ss.done;
             pj.x = cp_in.as<float>(); pj.ldx = td.H; pj.M = M; pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
+            if (bf16) { pj.x = reinterpret_cast<const float*>(cp_in16.as<unsigned short>()); pj.x_bf16 = 1; }
             pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.act = ACT_NONE; pj.fs = fs_proj;
-            pj.out16 = (c16 && skinny_can_stage(M, cd.H, bf16)) ? c16 : nullptr;
+            pj.out16 = (c16 && skinny_takes_bf16_x(M, cd.H, bf16)) ? c16 : nullptr;
             skinny(pj, st);
         } else {
             gp.out = cp_x.as<float>(); gp.out16 = c16;
             if (!skinny_only && j == 0) launch_cp_gather(gp, st);
         }
         for (int l = 0; l < c.cp_num_hidden_layers; ++l) {
-#if QTTS_CP_QKVTABLE
             skip_qkv = j >= 1 && l == 0;
-#endif
             decode_layer(cl[l], cd, cp_x.as<float>(), c16, cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
                          kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st);
         }
-#if QTTS_CP_QKVTABLE
         skip_qkv = false;
-#endif
         // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
         SkinnyParams lh{};
         lh.done_flag = ss.done;
         const int off = (n_new - 1) * B;
         lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
         lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE; lh.fs = fs_lm;
-        norm_input(lh, cd, (c16 && skinny_can_stage(M, cd.H, bf16)) ? c16 + (size_t)off * cd.H : nullptr, st);
+        norm_input(lh, cd, (c16 && skinny_takes_bf16_x(M, cd.H, bf16)) ? c16 + (size_t)off * cd.H : nullptr, st);
         skinny(lh, st);
         SampleParams s{};
         s.logits = cp_logits.as<float>(); s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
@@ -573,21 +535,18 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
             s.gather_emb = emb_cp.as<float>() + (size_t)j * c.cp_vocab_size * td.H; s.gather_C = td.H;
             s.gather_out = has_proj ? cp_in.as<float>() : cp_x.as<float>();
             s.gather_out16 = has_proj ? nullptr : c16;
-#if QTTS_CP_PRETABLE
             if (has_proj) {
                 s.gather_emb = emb_cp_proj.as<float>() + (size_t)j * c.cp_vocab_size * cd.H; s.gather_C = cd.H;
                 s.gather_out = cp_x.as<float>();
-                s.gather_out16 = (c16 && skinny_can_stage(B, cd.H, bf16)) ? c16 : nullptr;   // as the projection's out16
+                s.gather_out16 = (c16 && skinny_takes_bf16_x(B, cd.H, bf16)) ? c16 : nullptr;   // as the projection's out16
             }
-#endif
-#if QTTS_CP_QKVTABLE
             s.gather2_C = cd.qd + 2 * cd.kvd;
             s.gather2_emb = cp_qkv0_tab.as<float>() + (size_t)j * c.cp_vocab_size * s.gather2_C;
             s.gather2_out = cp_qkv.as<float>();
-#endif
         }
         if (!skinny_only) launch_sample(s, st);
     }
+    if (tf.codes && !skinny_only) launch_teacher(teacher_params(), 2, st);
     // ---- next talker input + frame outputs (M:1681-1692)
     EmbedSumParams e{};
     e.B = B; e.H = td.H; e.G = G; e.cp_vocab = c.cp_vocab_size; e.talker_emb = emb_talker.as<float>();
@@ -599,10 +558,12 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     for (int l = 0; l < c.num_hidden_layers; ++l)
         decode_layer(tl[l], td, x.as<float>(), bf16 ? x16.as<unsigned short>() : nullptr, qkv.as<float>(), att.as<float>(), act.as<float>(), B, 1, kv_t, l, ss.kv_len, 0,
                      n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, st);
-    if (!skinny_only) launch_apply_norm(x.as<float>(), td.H, t_norm.as<float>(), td.eps, past_hidden.as<float>(), td.H, B, td.H, ss.done, st);
+    if (!skinny_only) launch_apply_norm(x.as<float>(), td.H, t_norm.as<float>(), td.eps, past_hidden.as<float>(), td.H, B, td.H, ss.done, st,
+                                        bf16 ? ph16.as<unsigned short>() : nullptr);
     SkinnyParams h{};
     h.done_flag = ss.done;
     h.x = past_hidden.as<float>(); h.ldx = td.H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = td.H;
+    if (bf16) { h.x = reinterpret_cast<const float*>(ph16.as<unsigned short>()); h.x_bf16 = 1; }
     h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE; h.fs = fs_head;
     skinny(h, st);
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
@@ -741,6 +702,9 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     QTTS_REQUIRE(eos_token_id >= 0 && eos_token_id < t->cfg.vocab_size, QTTS_ERR_ARG, "eos_token_id");
     hipStream_t st = (hipStream_t)stream;
     const int B = t->B, V = t->cfg.vocab_size;
+    if (t->tf.codes)
+        QTTS_REQUIRE(min_new_tokens >= max_new_tokens && t->tf.F == max_new_tokens - 1 && !sp->do_sample && !sp->subtalker_dosample,
+                     QTTS_ERR_ARG, "teacher forcing: greedy, min_new_tokens == max_new_tokens == forced frames + 1");
     t->prefilled = false;  // the KV cache / loop state are consumed by this call
     {
         std::vector<unsigned char> m(V, 0);
@@ -766,7 +730,7 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
         QTTS_CHECK_HIP(hipStreamSynchronize(st));
     };
     poll();
-    const bool use_graph = t->cfg.use_graph && !t->profile;
+    const bool use_graph = t->cfg.use_graph && !t->profile && !t->tf.codes;     // (teacher forcing runs eagerly)
     const int total = max_new_tokens - 1;      // at most this many frame steps
     int f = 0;
     qtts_talker::GraphKey key;
@@ -1082,6 +1046,20 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     }
     *us_per_launch = 1000.0 * best / iters;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr); (void)hipStreamDestroy(st);
+    QTTS_API_END
+}
+
+int qtts_talker_set_teacher(qtts_talker* t, const int64_t* forced_codes_dev, int32_t n_frames, int32_t* own_dev,
+                            const int32_t* logit_slots_dev, float* logits_trace_dev) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t, QTTS_ERR_ARG, "null handle");
+    QTTS_REQUIRE(!t->sg.active, QTTS_ERR_STATE, "set_teacher while a streaming generation is active");
+    if (!forced_codes_dev) { t->tf = qtts_talker::Teacher{}; }
+    else {
+        QTTS_REQUIRE(n_frames >= 1 && own_dev, QTTS_ERR_ARG, "set_teacher: n_frames >= 1 and an output buffer for the own choices");
+        QTTS_REQUIRE((logit_slots_dev == nullptr) == (logits_trace_dev == nullptr), QTTS_ERR_ARG, "set_teacher: slots and trace go together");
+        t->tf.codes = forced_codes_dev; t->tf.F = n_frames; t->tf.own = own_dev; t->tf.slots = logit_slots_dev; t->tf.trace = logits_trace_dev;
+    }
     QTTS_API_END
 }
 

@@ -1,8 +1,8 @@
 """Codec ENCODER engine (waveform -> Qwen3-TTS-Tokenizer-12Hz codes), SURVEY.md 8(f3).
 
 Host mirror of `Qwen3TTSTokenizerV2Model.encode` (tokenizer v2:961-991) over `qtts_encoder_*` (include/qtts.h).
-STATUS round 1: the HIP side is compiled and mirrored op by op on the CPU (oracle/codec_enc_stage_emul.py), but it has
-not run on hardware yet; its GPU parity test is gated behind QTTS_EXPERIMENTAL=1.
+Validated on MI355X in round 2: codes bit-identical to the reference's own encoder class on the golden waveforms
+(tests/test_gpu_parity.py::test_codec_encoder_codes_vs_reference_golden).
 """
 import ctypes as C
 import threading

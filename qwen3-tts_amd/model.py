@@ -239,7 +239,7 @@ class Qwen3TTSForConditionalGeneration:
 
     def extract_speaker_embedding(self, audio: np.ndarray, sr: int) -> torch.Tensor:
         """M:1941-1954: 24 kHz waveform -> (enc_dim,) x-vector, log-mel + ECAPA-TDNN on the HIP speaker engine
-        (EXPERIMENTAL in round 1: compiled and CPU-emulated, hardware run pending)."""
+        (validated on MI355X in round 2: tests/test_gpu_parity.py::test_speaker_embedding_vs_oracle)."""
         assert sr == 24000, "Only support 24kHz audio"
         if not self._speaker_state:
             raise NotImplementedError("this checkpoint has no `speaker_encoder.*` weights (only the Base model does)")
@@ -303,7 +303,7 @@ class Qwen3TTSForConditionalGeneration:
                         repetition_penalty: float = 1.05, **kwargs):
         """Streaming OUTPUT variant of `generate` (the reference returns whole utterances, qwen3_tts_model.py:513-515): a
         generator of packets; each packet is a list with, per request, the (k_i, G) codes it gained (k_i = 0 once the
-        request hit EOS, M:2283-2289).  One wave only: len(input_ids) <= max_batch.  EXPERIMENTAL in round 1."""
+        request hit EOS, M:2283-2289).  One wave only: len(input_ids) <= max_batch."""
         c = self.config
         if len(input_ids) > self.talker.max_batch:
             raise ValueError(f"generate_stream: {len(input_ids)} requests exceed max_batch {self.talker.max_batch}")
@@ -504,7 +504,7 @@ class Qwen3TTSModel:
         """qwen3_tts_model.py:356-458: reference audio -> prompt items (speech codes through the tokenizer's encoder,
         x-vector through the speaker encoder).  Audio: wav path / URL / base64 string, or (waveform np.ndarray, sr);
         WAVE decoding and resampling are restated in audio_io.py (soundfile / librosa are not in this image).
-        EXPERIMENTAL in round 1: both encoders are compiled and CPU-emulated; their first hardware run is pending."""
+        Both encoders run on the HIP engines (validated on MI355X in round 2)."""
         if self.model.tts_model_type != "base":
             raise self._unsupported("create_voice_clone_prompt")
         audios = self._ensure_list(ref_audio)
@@ -613,8 +613,7 @@ class Qwen3TTSModel:
         """`generate_custom_voice` as a generator of PCM packets: yields (list of np.float32 arrays, one per request --
         empty once that request has finished --, sample_rate) every `packet_frames` frames (80 ms each).  The codes come
         from `generate_stream`; each packet is decoded with `left_context_size` frames of context, i.e. exactly the
-        reference's `chunked_decode(chunk_size=packet_frames, left_context_size=...)` rule applied incrementally.
-        EXPERIMENTAL in round 1 (the resumable talker generation has not had its first hardware run)."""
+        reference's `chunked_decode(chunk_size=packet_frames, left_context_size=...)` rule applied incrementally."""
         if self.model.tts_model_type != "custom_voice":
             raise self._unsupported("stream_custom_voice")
         texts = self._ensure_list(text)

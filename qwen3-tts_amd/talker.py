@@ -34,6 +34,8 @@ class TalkerGenerateOutput:
     hidden: Optional[torch.Tensor]  # (B, n_frames, H) float32 `past_hidden` per frame (M:2281)
     tokens: torch.Tensor       # (B, n_tokens) int64 sampled codebook-0 tokens (HF `sequences`)
     n_frames: int
+    own: Optional[torch.Tensor] = None           # teacher forcing only: (B, F + 1, G) int32, the engine's OWN greedy choices
+    logits_trace: Optional[torch.Tensor] = None  # teacher forcing only: (n_steps, B, vocab) raw cb-0 logits of `logit_steps`
 
 
 _SKIP_PREFIXES = ("speaker_encoder.",)
@@ -181,13 +183,23 @@ class TalkerEngine:
                  subtalker_temperature: Optional[float] = 0.9, eos_token_id: Optional[int] = None,
                  repetition_penalty: float = 1.05, suppress_tokens: Optional[List[int]] = None,
                  output_hidden_states: bool = True, return_dict_in_generate: bool = True,
-                 seed: Optional[int] = None, **unused) -> TalkerGenerateOutput:
+                 seed: Optional[int] = None, teacher_codes: Optional[torch.Tensor] = None,
+                 logit_steps: Optional[List[int]] = None, **unused) -> TalkerGenerateOutput:
+        """`teacher_codes` (B, F, G) switches on the diagnostic teacher-forced mode (include/qtts.h `qtts_talker_set_teacher`):
+        greedy, exactly F frames; the engine's own choices come back in `.own`, the raw cb-0 logits of the token steps listed in
+        `logit_steps` in `.logits_trace`."""
         c = self.config
         if inputs_embeds.dim() != 3 or inputs_embeds.shape[-1] != c.hidden_size:
             raise ValueError(f"inputs_embeds must be (B, T, {c.hidden_size})")
         B, T, H = inputs_embeds.shape
         if B > self.max_batch:
             raise ValueError(f"batch {B} exceeds max_batch {self.max_batch} given at construction")
+        if teacher_codes is not None:
+            if teacher_codes.dim() != 3 or teacher_codes.shape[0] != B or teacher_codes.shape[2] != c.num_code_groups:
+                raise ValueError(f"teacher_codes must be (B, F, {c.num_code_groups})")
+            F_t = int(teacher_codes.shape[1])
+            max_new_tokens = min_new_tokens = F_t + 1
+            do_sample = subtalker_dosample = False
         mask = attention_mask.to("cpu", torch.long)
         if mask.shape != (B, T):
             raise ValueError("attention_mask must be (B, T)")
@@ -227,20 +239,43 @@ class TalkerEngine:
         npad_c = (C.c_int32 * B)(*[int(x) for x in n_pad])
         sup_c = (C.c_int32 * max(1, len(suppress_tokens)))(*[int(x) for x in suppress_tokens])
         n_frames = C.c_int32(0)
+        own = trace = None
+        if teacher_codes is not None:
+            if F_t != max_new_tokens - 1:
+                raise ValueError("teacher_codes: the forced frames do not fit max_seq")
+            tc = teacher_codes.to(dev, torch.long).contiguous()
+            own = torch.full((B, F_t + 1, c.num_code_groups), -1, dtype=torch.int32, device=dev)
+            slots = trace = None
+            if logit_steps:
+                sl = [-1] * (F_t + 1)
+                for k, i in enumerate(logit_steps):
+                    if not 0 <= int(i) <= F_t:
+                        raise ValueError("logit_steps entries must be token steps in [0, F]")
+                    sl[int(i)] = k
+                slots = torch.tensor(sl, dtype=torch.int32, device=dev)
+                trace = torch.zeros(len(logit_steps), B, c.vocab_size, dtype=torch.float32, device=dev)
         cur = torch.cuda.current_stream(dev)
         self._stream.wait_stream(cur)
         with torch.cuda.device(dev), torch.cuda.stream(self._stream):
             _lib.check(self._lib.qtts_talker_prefill(self._h, C.c_void_p(emb.data_ptr()), B, T, npad_c,
                                                      C.c_void_p(trail.data_ptr()), trail.shape[1],
                                                      C.c_void_p(pad.data_ptr()), self._s()))
-            _lib.check(self._lib.qtts_talker_generate(
-                self._h, C.byref(sp), int(max_new_tokens), int(min_new_tokens), eos, sup_c, len(suppress_tokens),
-                C.c_void_p(codes.data_ptr()), C.c_void_p(hidden.data_ptr()) if hidden is not None else None,
-                C.c_void_p(tokens.data_ptr()), C.byref(n_frames), self._s()))
+            if teacher_codes is not None:
+                _lib.check(self._lib.qtts_talker_set_teacher(self._h, C.c_void_p(tc.data_ptr()), F_t, C.c_void_p(own.data_ptr()),
+                                                             C.c_void_p(slots.data_ptr()) if trace is not None else None,
+                                                             C.c_void_p(trace.data_ptr()) if trace is not None else None))
+            try:
+                _lib.check(self._lib.qtts_talker_generate(
+                    self._h, C.byref(sp), int(max_new_tokens), int(min_new_tokens), eos, sup_c, len(suppress_tokens),
+                    C.c_void_p(codes.data_ptr()), C.c_void_p(hidden.data_ptr()) if hidden is not None else None,
+                    C.c_void_p(tokens.data_ptr()), C.byref(n_frames), self._s()))
+            finally:
+                if teacher_codes is not None:
+                    _lib.check(self._lib.qtts_talker_set_teacher(self._h, None, 0, None, None, None))
         cur.wait_stream(self._stream)
         nf = int(n_frames.value)
         return TalkerGenerateOutput(codes=codes[:, :nf], hidden=hidden[:, :nf] if hidden is not None else None,
-                                    tokens=tokens[:, : nf + 1], n_frames=nf)
+                                    tokens=tokens[:, : nf + 1], n_frames=nf, own=own, logits_trace=trace)
 
     def generate_stream(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, trailing_text_hidden: torch.Tensor,
                         tts_pad_embed: torch.Tensor, packet_frames: int = 4, max_new_tokens: int = 2048, min_new_tokens: int = 2,
@@ -252,8 +287,7 @@ class TalkerEngine:
                         seed: Optional[int] = None, **unused):
         """Streaming OUTPUT (include/qtts.h `qtts_talker_stream_*`): a generator that yields `codes[:, f0:f1]` (B, k, G)
         int64 device tensors, k <= packet_frames, as the frames are produced; same arguments and the same frames as
-        `generate`.  Closing the generator early abandons the request.  EXPERIMENTAL in round 1: the C++ runs in the CPU
-        suite (tests/test_hostemu.py); its first hardware run is pending.  Holds the engine lock while active."""
+        `generate`.  Closing the generator early abandons the request.  Holds the engine lock while active."""
         c = self.config
         if inputs_embeds.dim() != 3 or inputs_embeds.shape[-1] != c.hidden_size:
             raise ValueError(f"inputs_embeds must be (B, T, {c.hidden_size})")

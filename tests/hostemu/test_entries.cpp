@@ -45,6 +45,25 @@ extern "C" int hostemu_skinny(const float* x, int ldx, int M, const float* W, in
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
+// The bf16 decode GEMM as the frame step launches it: x handed over as the producer's bf16 copy (x_bf16), narrow strips
+// (fs = 16 | 8 | 4), optional bf16 shadow output (out16, same leading dimension as out).
+extern "C" int hostemu_skinny_bf16x(const float* x, int ldx, int M, const float* W, int N, int K, const float* g, int norm, float eps,
+                                    const float* bias, const float* res, int ldr, int act, float* out, int ldo, int fs,
+                                    unsigned short* out16) {
+    try {
+        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(N, K, true));
+        qtts::pack_skinny_weight(W, N, K, true, wp.data(), g, fs);
+        std::vector<qtts::bf16_t> x16((size_t)M * ldx);
+        for (size_t i = 0; i < x16.size(); ++i) x16[i] = qtts::f32_to_bf16(x[i]);
+        qtts::SkinnyParams p{};
+        p.x = reinterpret_cast<const float*>(x16.data()); p.x_bf16 = 1; p.ldx = ldx; p.M = M; p.Wp = wp.data(); p.N = N; p.K = K;
+        p.fs = fs; p.norm = norm; p.eps = eps; p.bias = bias; p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.act = act;
+        p.out16 = out16;
+        qtts::launch_skinny(p, true, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
 // One launch of sampling.hip's sample_kernel on B rows of logits: HF processors (repetition penalty over `generated`,
 // min-new-tokens EOS block, suppress mask), temperature / top-k / top-p, Philox draw keyed by (seed, stream_id, step).
 extern "C" int hostemu_sample(const float* logits, int ld, int V, int B, const int* generated, int gen_stride, int n_generated,

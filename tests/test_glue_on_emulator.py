@@ -96,3 +96,8 @@ def test_round1_advice_fixes_python_path(glue, golden_dir):
     calls while `torch.manual_seed` reproduces a run: the GPU test bodies, on the emulator."""
     glue.test_codec_edge_cases(_codec_tiny(glue, golden_dir))
     glue.test_default_seed_advances_and_manual_seed_reproduces(_talker_tiny(glue, golden_dir), "cpu")
+
+
+def test_teacher_forcing_python_path(glue, golden_dir):
+    """`TalkerEngine.generate(teacher_codes=...)` / `qtts_talker_set_teacher`: the GPU test body on the emulator."""
+    glue.test_teacher_forcing_tiny_reproduces_golden(_talker_tiny(glue, golden_dir), "cpu")
