@@ -128,6 +128,8 @@ def main():
 
     tcfg = {"1.7b": synth.talker_17b, "0.6b": synth.talker_06b, "tiny": synth.talker_tiny}[args.model]()
     ccfg = synth.codec_tiny() if args.model == "tiny" else synth.codec_real()
+    if args.model == "tiny":
+        ccfg.codebook_size = tcfg.cp_vocab_size          # the codec codebooks must cover the talker's code range
     B, F = args.batch, args.frames
     t0 = time.time()
     tw_np = synth.talker_weights(tcfg, with_text=False)

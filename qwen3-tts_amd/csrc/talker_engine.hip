@@ -1019,6 +1019,8 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     QTTS_CHECK_HIP(hipMemset(done.p, 0, done.bytes));
     SkinnyParams p{};
     p.x = x.as<float>(); p.ldx = K; p.M = M; p.Wp = W.p; p.N = N; p.K = K; p.eps = 1e-6f; p.act = act;
+    p.x_bf16 = 1;                                   // as in the frame step: the producer's bf16 copy of x
+    if (act != ACT_SWIGLU) { int fs = 16; while (fs > 4 && N / fs < 192) fs /= 2; p.fs = fs; }     // the engine's choose_fs
     if (with_norm) { p.norm = 1; p.ss_in = ssin.as<float>(); }
     if (with_res) { p.res = res.as<float>(); p.ldr = No; }
     p.out = out.as<float>(); p.ldo = No; p.done_flag = done.as<int>(); p.ablate = ablate;

@@ -35,6 +35,8 @@ def _engines(args, B, max_seq, max_frames, dev):
     from qwen3_tts_amd.talker import TalkerEngine
     tcfg = {"1.7b": synth.talker_17b, "0.6b": synth.talker_06b, "tiny": synth.talker_tiny}[args.model]()
     ccfg = synth.codec_tiny() if args.model == "tiny" else synth.codec_real()
+    if args.model == "tiny":
+        ccfg.codebook_size = tcfg.cp_vocab_size
     td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
     talker = TalkerEngine(tcfg, td(synth.talker_weights(tcfg, with_text=False)), weight_dtype=torch.bfloat16, device=dev,
                           max_batch=B, max_seq=max_seq, use_graph=True)
