@@ -57,7 +57,9 @@ __device__ inline void skinny_store4(const SkinnyParams& p, int row, int col, co
 // U = k-tiles per chunk; two chunks of loads are in flight per wave.  EXACT: every wave owns the same number of k-tiles and
 // that number is a multiple of U (all shapes of the real models) -- the chunk loads are then unconditional, back-to-back
 // requests; the generic variant guards the tail tile by tile (tiny test dimensions, odd K).
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT>
+// NCH > 0 (EXACT only): the number of chunks is a compile-time constant (1..3) and the whole kernel is straight-line code -- no
+// branch, hence no register merge (a merge copy of a load result waits for that load) between the request bursts.
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
 __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     constexpr int KT = 32;                                       // k per tile
     constexpr int NS = SPW * MT + MT;                            // accumulators per wave: the GEMM's + one X.X^T per m-tile
@@ -80,65 +82,121 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
         for (int s = 0; s < SPW; ++s) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    // Every load below is issued by ALL lanes (no exec-mask branches around the ~32 requests a wave makes at entry): lanes
-    // without a weight row (lj >= FS) and lanes without an x row (row >= M) re-read a neighbour's address -- same cache
-    // lines, no extra traffic -- and what they feed to the MFMA only reaches output rows / columns nobody stores.
-    const int ljw = lj < FS ? lj : FS - 1;
+    // The texture-address unit of a CU takes 64 B per clock: a 16-B-per-lane load costs 16 clocks when all 64 lanes are
+    // active, and the ~32 requests per wave x 8 waves of a launch are a measurable part of it (round-2 ablation: +0.7 us per
+    // 1024 of K with every lane loading).  So only the lanes that own a weight row (lj < FS: 16 / 32 / 64 lanes) and the lanes
+    // that own an x row (row < M: 32 lanes at batch 8) issue requests -- under ONE exec mask per chunk and operand, not one
+    // branch per load; the other lanes hold zeros, and what they feed to the MFMA only reaches output rows / columns nobody
+    // stores.
+    const bool wlane = lj < FS;
     const u32x4* wbase[SPW];
 #pragma unroll
     for (int s = 0; s < SPW; ++s)
-        wbase[s] = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)(strip0 + s) * nkt) * (FS * 4) + lq * FS + ljw;
+        wbase[s] = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)(strip0 + s) * nkt) * (FS * 4) + lq * FS + (wlane ? lj : 0);
     // B operand of tile kt, m-tile m: lane (lj, lq) <- x[m*16 + lj][kt*32 + lq*8 .. +8]
     const unsigned short* xp16[MT];
     const float* xp32[MT];
+    bool xlane[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int row = min(m * 16 + lj, p.M - 1);
+        xlane[m] = m * 16 + lj < p.M;
+        const int row = xlane[m] ? m * 16 + lj : 0;
         xp16[m] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)row * p.ldx + lq * 8;
         xp32[m] = p.x + (size_t)row * p.ldx + lq * 8;
     }
     // perf ablation (DEBUG): "no weight stream" / "no x fetch" collapse the tile stride to 0 -- every request of a wave then hits
-    // one resident line -- so that the instruction stream is unchanged and branch-free
+    // one resident line -- so that the instruction stream is unchanged
     const size_t wstep = (p.ablate & 8) ? 0 : (size_t)(FS * 4);
     const int xstep = (p.ablate & 2) ? 0 : KT;
 
-    auto load_tile = [&](u32x4 (&w)[SPW][U], u32x4 (&xq)[MT][U], int u, int kt) {
-#pragma unroll
-        for (int s = 0; s < SPW; ++s) w[s][u] = skinny_wload(wbase[s] + (size_t)kt * wstep);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if constexpr (XB16) xq[m][u] = *reinterpret_cast<const u32x4*>(xp16[m] + kt * xstep);
-            else {    // fp32 x (no bf16 copy from the producer): converted here; not on the frame step's hot path
-                const float4 a = *reinterpret_cast<const float4*>(xp32[m] + kt * xstep);
-                const float4 b = *reinterpret_cast<const float4*>(xp32[m] + kt * xstep + 4);
-                u32x4 t;
-                t[0] = pack_bf16(a.x, a.y); t[1] = pack_bf16(a.z, a.w);
-                t[2] = pack_bf16(b.x, b.y); t[3] = pack_bf16(b.z, b.w);
-                xq[m][u] = t;
-            }
+    auto load_x = [&](int m, int kt) -> u32x4 {
+        if constexpr (XB16) return *reinterpret_cast<const u32x4*>(xp16[m] + kt * xstep);
+        else {    // fp32 x (no bf16 copy from the producer): converted here; not on the frame step's hot path
+            const float4 a = *reinterpret_cast<const float4*>(xp32[m] + kt * xstep);
+            const float4 b = *reinterpret_cast<const float4*>(xp32[m] + kt * xstep + 4);
+            u32x4 t;
+            t[0] = pack_bf16(a.x, a.y); t[1] = pack_bf16(a.z, a.w);
+            t[2] = pack_bf16(b.x, b.y); t[3] = pack_bf16(b.z, b.w);
+            return t;
         }
     };
+    // (the operand registers are zeroed ONCE, below: lanes outside the masks never write them again, so a masked request is an
+    // in-place update and needs no merge copy -- a copy would wait for the load it copies)
     auto load_chunk = [&](u32x4 (&w)[SPW][U], u32x4 (&xq)[MT][U], int c) {
         if constexpr (EXACT) {
+            if (FS == 16 || wlane) {                             // one exec mask for all weight requests of the chunk
 #pragma unroll
-            for (int u = 0; u < U; ++u) load_tile(w, xq, u, wave + NW * (c * U + u));
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int s = 0; s < SPW; ++s) w[s][u] = skinny_wload(wbase[s] + (size_t)(wave + NW * (c * U + u)) * wstep);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if (xlane[m]) {                                  // one exec mask per m-tile for its x requests
+#pragma unroll
+                    for (int u = 0; u < U; ++u) xq[m][u] = load_x(m, wave + NW * (c * U + u));
+                }
         } else {
             const int n = my_tiles - c * U;                      // wave-uniform: tiles of this chunk that exist
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                if (u < n) {
+                    const int kt = wave + NW * (c * U + u);
+                    if (wlane) {
 #pragma unroll
-                for (int s = 0; s < SPW; ++s) w[s][u] = (u32x4){0u, 0u, 0u, 0u};
+                        for (int s = 0; s < SPW; ++s) w[s][u] = skinny_wload(wbase[s] + (size_t)kt * wstep);
+                    }
 #pragma unroll
-                for (int m = 0; m < MT; ++m) xq[m][u] = (u32x4){0u, 0u, 0u, 0u};
-                if (u < n) load_tile(w, xq, u, wave + NW * (c * U + u));
+                    for (int m = 0; m < MT; ++m)
+                        if (xlane[m]) xq[m][u] = load_x(m, kt);
+                }
             }
         }
     };
 
-    // ---- 1. the weight stream and this wave's x fragments start first: two chunks per wave in flight
-    u32x4 wA[SPW][U], wB[SPW][U], xA[MT][U], xB[MT][U];
-    load_chunk(wA, xA, 0);
-    if (!EXACT || nchunks > 1) load_chunk(wB, xB, 1);
+    // ---- 1. the weight stream and this wave's x fragments start first.  Straight-line kernels (NCH = 1..3 chunks): EVERY chunk
+    // has its own registers and is requested right here (up to 24 KiB per wave in flight); the generic kernel keeps two chunks
+    // in flight and ping-pongs.
+    constexpr int NSET = NCH > 0 ? NCH : 2;
+    u32x4 wR[NSET][SPW][U], xR[NSET][MT][U];
+#pragma unroll
+    for (int k = 0; k < NSET; ++k)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) wR[k][s][u] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xR[k][m][u] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) load_chunk(wR[k], xR[k], k);
+    } else {
+        load_chunk(wR[0], xR[0], 0);
+        if (!EXACT || nchunks > 1) load_chunk(wR[1], xR[1], 1);
+    }
+
+    // ---- 1b. warm the NEXT GEMM's weights (they do not depend on anything this chain computes): one dword per 128-B line
+    // pulls the head of every strip that the next launch's workgroup b2 will stream into THIS XCD's L2 -- workgroup b2 of the
+    // next launch lands on XCD b2 % 8 like this one (grids are multiples of 8), so block b takes b2 = b, b + grid, ...
+    // The frame step is latency-bound (HBM is idle three quarters of the time): the requests cost one VGPR and ride under
+    // this launch's own stream; the next launch then finds its first tiles one L2 hop away instead of one HBM round trip.
+    // (two requests per thread at most, results untouched until the very end: nothing here may wait for a load)
+    constexpr int PFN = 2;
+    int pfv[PFN];
+#pragma unroll
+    for (int q = 0; q < PFN; ++q) {
+        pfv[q] = 0;
+        if (p.pf_base) {
+            const int idx = tid + q * NW * 64;                   // line index within this workgroup's share
+            const int b2 = blockIdx.x + (idx >> p.pf_b2_shift) * gridDim.x;
+            const int ln = idx & ((1 << p.pf_b2_shift) - 1);    // line within workgroup b2's head: strip (ln >> seg_shift), line
+            if (b2 < p.pf_grid)
+                pfv[q] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.pf_base) + (size_t)b2 * p.pf_spw * p.pf_strip +
+                                                       (size_t)(ln >> p.pf_seg_shift) * p.pf_strip +
+                                                       ((size_t)(ln & ((1 << p.pf_seg_shift) - 1)) << 7));
+        }
+    }
 
     // ---- 2. epilogue operands of wave 0 are fetched now, under the weight stream
     f32x4 resv[SPW][MT], biasv[SPW];
@@ -185,12 +243,17 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
         }
     };
 
-    // ---- 3. consume: ping-pong, the chunk after next is requested as soon as a buffer frees up
-    for (int c = 0; c < nchunks; c += 2) {
-        compute_chunk(wA, xA, c);
-        if (c + 2 < nchunks) load_chunk(wA, xA, c + 2);
-        if (c + 1 < nchunks) compute_chunk(wB, xB, c + 1);
-        if (c + 3 < nchunks) load_chunk(wB, xB, c + 3);
+    // ---- 3. consume
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) compute_chunk(wR[k], xR[k], k);
+    } else {                               // ping-pong: the chunk after next is requested as soon as a buffer frees up
+        for (int c = 0; c < nchunks; c += 2) {
+            compute_chunk(wR[0], xR[0], c);
+            if (c + 2 < nchunks) load_chunk(wR[0], xR[0], c + 2);
+            if (c + 1 < nchunks) compute_chunk(wR[1], xR[1], c + 1);
+            if (c + 3 < nchunks) load_chunk(wR[1], xR[1], c + 3);
+        }
     }
 
     // ---- 4. cross-wave combine (fixed order) and epilogue by wave 0: the kernel's only barrier
@@ -200,6 +263,7 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
         for (int s = 0; s < SPW; ++s) red[(wave * NS + s * MT + m) * 64 + lane] = acc[s][m];
         red[(wave * NS + SPW * MT + m) * 64 + lane] = acc_ss[m];
     }
+    if (p.pf_base && (pfv[0] ^ pfv[1]) == 0x5a5aa5a5) red[0][0] = 1.f;     // (practically never true: keeps the warm-up loads alive)
     __syncthreads();
     if (wave != 0) return;
 
@@ -376,12 +440,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
 // more, so there is no capacity condition left (round 1: M <= 16 up to K = 7096, M <= 32 up to K = 2344).
 bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <= 64 && K % 32 == 0; }
 
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT>
-static void launch2_u(const SkinnyParams& p, hipStream_t st) {
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
+static void launch2_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
     const size_t lds = (size_t)NW * (SPW * MT + MT) * 64 * 16;
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "skinny: LDS budget exceeded");
-    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT>;
+    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH>;
     static bool attr_set = false;          // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -390,6 +454,15 @@ static void launch2_u(const SkinnyParams& p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
 }
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT>
+static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
+    if constexpr (EXACT && MT == 1) {      // the frame step at batch <= 16: straight-line kernels for 1, 2 or 3 chunks
+        if (nchunks == 1) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 1>(p, st); return; }
+        if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2>(p, st); return; }
+        if (nchunks == 3) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 3>(p, st); return; }
+    }
+    launch2_n<MT, SPW, NW, FS, XB16, U, EXACT, 0>(p, st);
+}
 template <int MT, int SPW, int NW, int FS, bool XB16>
 static void launch2_x(const SkinnyParams& p, hipStream_t st) {
     constexpr int UMAX = (MT == 1 ? 8 : (MT == 2 ? 4 : 2)) / SPW;
@@ -397,13 +470,13 @@ static void launch2_x(const SkinnyParams& p, hipStream_t st) {
         const int nkt = p.K / 32;
         if (nkt % NW == 0) {
             const int tpw = nkt / NW;
-            if (tpw % UMAX == 0) { launch2_u<MT, SPW, NW, FS, XB16, UMAX, true>(p, st); return; }
+            if (tpw % UMAX == 0) { launch2_u<MT, SPW, NW, FS, XB16, UMAX, true>(p, tpw / UMAX, st); return; }
             if constexpr (UMAX == 8) {
-                if (tpw % 4 == 0) { launch2_u<MT, SPW, NW, FS, XB16, 4, true>(p, st); return; }
+                if (tpw % 4 == 0) { launch2_u<MT, SPW, NW, FS, XB16, 4, true>(p, tpw / 4, st); return; }
             }
         }
     }
-    launch2_u<MT, SPW, NW, FS, XB16, UMAX, false>(p, st);
+    launch2_u<MT, SPW, NW, FS, XB16, UMAX, false>(p, 0, st);
 }
 template <int MT, int SPW, int NW, int FS>
 static void launch2_one(const SkinnyParams& p, hipStream_t st) {
@@ -429,6 +502,32 @@ static void launch_f32_mt(const SkinnyParams& p, int spw, int nw, hipStream_t st
     else         { if (spw == 2) launch_f32_one<MT, 2, 4>(p, st); else launch_f32_one<MT, 1, 4>(p, st); }
 }
 
+static int skinny_spw(int N, int fs, bool swiglu) {
+    if (swiglu) return 2;
+    return (fs == 16 && N / 16 >= 1024 && (N / 16) % 2 == 0) ? 2 : 1;
+}
+
+void skinny_prefetch(SkinnyParams& p, const void* Wp, int N, int K, int fs, bool swiglu, size_t budget_bytes) {
+    p.pf_base = nullptr;
+    if (!fs) fs = 16;
+    const int my_fs = p.fs ? p.fs : 16;
+    const int my_grid = p.N / (my_fs * skinny_spw(p.N, my_fs, p.act == ACT_SWIGLU));       // the launch that does the warming
+    const int spw = skinny_spw(N, fs, swiglu);
+    const int strip = (K / 32) * fs * 64;                    // bytes of one packed strip (bf16)
+    const int strips = N / fs, grid = strips / spw;
+    if (!Wp || strip % 128 != 0 || my_grid < 1 || my_grid % 8 != 0 || grid % 8 != 0) return;   // (XCD of block b = b % 8)
+    // head of every strip: a power-of-two number of 128-B lines, within the byte budget and within what the warming launch
+    // can request (2 lines per thread, 512 threads per workgroup)
+    const int rounds = (grid + my_grid - 1) / my_grid;       // next-launch workgroups per warming workgroup
+    size_t lines = std::min<size_t>((size_t)strip / 128, budget_bytes / 128 / (size_t)strips);
+    lines = std::min<size_t>(lines, (size_t)(2 * 512) / (size_t)(rounds * spw));
+    int shift = 0;
+    while (((size_t)2 << shift) <= lines) ++shift;
+    if (lines < 1) return;
+    p.pf_base = Wp; p.pf_grid = grid; p.pf_spw = spw; p.pf_strip = strip; p.pf_seg_shift = shift;
+    p.pf_b2_shift = shift + (spw == 2 ? 1 : 0);
+}
+
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int KT = bf16 ? 32 : 16;
     const int fs = p.fs ? p.fs : 16;
@@ -441,11 +540,9 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(!p.x_bf16 || (bf16 && p.ldx % 8 == 0), QTTS_ERR_ARG, "skinny: bf16 x needs the bf16 kernel and ldx % 8");
     QTTS_REQUIRE(!p.out_bf16 || bf16, QTTS_ERR_ARG, "skinny: bf16 output only in bf16 mode");
     QTTS_REQUIRE(bf16 || !p.norm || p.ss_in, QTTS_ERR_ARG, "skinny: the fp32 kernel takes the row sums of squares from ss_in");
-    int spw = 1;
-    if (p.act == ACT_SWIGLU) {
-        QTTS_REQUIRE(p.N % 32 == 0 && fs == 16, QTTS_ERR_ARG, "skinny: swiglu needs N % 32 and fs == 16");
-        spw = 2;
-    } else if (fs == 16 && p.N / 16 >= 1024 && (p.N / 16) % 2 == 0) spw = 2;
+    if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.N % 32 == 0 && fs == 16, QTTS_ERR_ARG, "skinny: swiglu needs N % 32 and fs == 16");
+    const int spw = skinny_spw(p.N, fs, p.act == ACT_SWIGLU);
+    QTTS_REQUIRE(!p.pf_base || bf16, QTTS_ERR_ARG, "skinny: weight warm-up is a bf16-kernel feature");
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16) {
