@@ -46,6 +46,7 @@ struct SkinnyParams {
     int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
     // optional (bf16 kernel): warm the head of the NEXT decode GEMM's packed weights into this XCD's L2 -- see skinny_prefetch()
     const void* pf_base; int pf_grid, pf_spw, pf_strip, pf_seg_shift, pf_b2_shift;
+    int w_temporal;              // 1: plain weight loads (re-read soon, fits the Infinity Cache) instead of non-temporal ones
 };
 // Fill the pf_* fields of `p` for a following launch_skinny call on packed weights `Wp` [N][K] (bf16, strips of fs features,
 // swiglu = gate/up strip pairs): at most `budget_bytes` in total, the first bytes of every strip.

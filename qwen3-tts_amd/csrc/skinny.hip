@@ -59,7 +59,9 @@ __device__ inline void skinny_store4(const SkinnyParams& p, int row, int col, co
 // requests; the generic variant guards the tail tile by tile (tiny test dimensions, odd K).
 // NCH > 0 (EXACT only): the number of chunks is a compile-time constant (1..3) and the whole kernel is straight-line code -- no
 // branch, hence no register merge (a merge copy of a load result waits for that load) between the request bursts.
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
+// WT: plain (temporal) weight loads instead of non-temporal ones -- for weights that are re-read soon and fit the 256 MB Infinity
+// Cache (the code predictor's 157 MB, read by 15 passes per frame); a per-GEMM choice of the engine (SkinnyParams::w_temporal).
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH, bool WT>
 __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     constexpr int KT = 32;                                       // k per tile
     constexpr int NS = SPW * MT + MT;                            // accumulators per wave: the GEMM's + one X.X^T per m-tile
@@ -109,6 +111,9 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     const size_t wstep = (p.ablate & 8) ? 0 : (size_t)(FS * 4);
     const int xstep = (p.ablate & 2) ? 0 : KT;
 
+    auto wload = [&](const u32x4* ptr) -> u32x4 {
+        if constexpr (WT) return *ptr; else return skinny_wload(ptr);
+    };
     auto load_x = [&](int m, int kt) -> u32x4 {
         if constexpr (XB16) return *reinterpret_cast<const u32x4*>(xp16[m] + kt * xstep);
         else {    // fp32 x (no bf16 copy from the producer): converted here; not on the frame step's hot path
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int s = 0; s < SPW; ++s) w[s][u] = skinny_wload(wbase[s] + (size_t)(wave + NW * (c * U + u)) * wstep);
+                    for (int s = 0; s < SPW; ++s) w[s][u] = wload(wbase[s] + (size_t)(wave + NW * (c * U + u)) * wstep);
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
                     const int kt = wave + NW * (c * U + u);
                     if (wlane) {
 #pragma unroll
-                        for (int s = 0; s < SPW; ++s) w[s][u] = skinny_wload(wbase[s] + (size_t)kt * wstep);
+                        for (int s = 0; s < SPW; ++s) w[s][u] = wload(wbase[s] + (size_t)kt * wstep);
                     }
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
@@ -440,12 +445,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
 // more, so there is no capacity condition left (round 1: M <= 16 up to K = 7096, M <= 32 up to K = 2344).
 bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <= 64 && K % 32 == 0; }
 
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
-static void launch2_n(const SkinnyParams& p, hipStream_t st) {
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH, bool WT>
+static void launch2_w(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
     const size_t lds = (size_t)NW * (SPW * MT + MT) * 64 * 16;
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "skinny: LDS budget exceeded");
-    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH>;
+    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH, WT>;
     static bool attr_set = false;          // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -453,6 +458,13 @@ static void launch2_n(const SkinnyParams& p, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
+}
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
+static void launch2_n(const SkinnyParams& p, hipStream_t st) {
+    if constexpr (NCH > 0) {               // the straight-line (frame step) kernels exist in both load flavours
+        if (p.w_temporal) { launch2_w<MT, SPW, NW, FS, XB16, U, EXACT, NCH, true>(p, st); return; }
+    }
+    launch2_w<MT, SPW, NW, FS, XB16, U, EXACT, NCH, false>(p, st);
 }
 template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT>
 static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {

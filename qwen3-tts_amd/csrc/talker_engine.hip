@@ -181,6 +181,9 @@ struct qtts_talker {
     int64_t skinny_count = 0;
     // QTTS_SKINNY_PREFETCH=0 switches the next-weights warm-up off (A/B on hardware); bf16 mode only
     bool prefetch_on = [] { const char* e = getenv("QTTS_SKINNY_PREFETCH"); return !e || atoi(e) != 0; }();
+    // QTTS_CP_TEMPORAL=1: the code predictor's GEMMs (157 MB re-read by 15 passes per frame) use plain weight loads (A/B)
+    bool cp_temporal = [] { const char* e = getenv("QTTS_CP_TEMPORAL"); return e && atoi(e) != 0; }();
+    int debug_fs = [] { const char* e = getenv("QTTS_DEBUG_FS"); return e ? atoi(e) : 0; }();
     void warm(SkinnyParams& p, const NextW& n) const {
         if (bf16 && prefetch_on && n.p) skinny_prefetch(p, n.p, n.N, n.K, n.fs, n.swiglu);
     }
@@ -204,8 +207,9 @@ struct qtts_talker {
                       const int* npad, const float* inv_freq, int max_len, hipStream_t st, const NextW& after_down = NextW()) {
         // xs16: bf16 copy of the hidden state kept in step with xs by every producer (bf16 mode, M <= 16), or null
         const bool h16 = xs16 && skinny_takes_bf16_x(M, d.H, bf16);
+        const int wt = (&d == &cd && cp_temporal) ? 1 : 0;
         SkinnyParams p{};
-        p.done_flag = ss.done;
+        p.done_flag = ss.done; p.w_temporal = wt;
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
         if (!skip_qkv) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
@@ -224,21 +228,21 @@ struct qtts_talker {
         a.out_bf16 = att16;
         if (!skinny_only) launch_attn_decode(a, st);
         SkinnyParams o{};
-        o.done_flag = ss.done;
+        o.done_flag = ss.done; o.w_temporal = wt;
         o.x_bf16 = att16;
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
         o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr; o.fs = L.fs_o;
         warm(o, NextW{L.gu_p.p, 2 * d.I, d.H, 16, true});
         skinny(o, st);
         SkinnyParams g{};
-        g.done_flag = ss.done;
+        g.done_flag = ss.done; g.w_temporal = wt;
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
         g.out_bf16 = act16;
         norm_input(g, d, h16 ? xs16 : nullptr, st);
         warm(g, NextW{L.d_p.p, d.H, d.I, L.fs_d, false});
         skinny(g, st);
         SkinnyParams dn{};
-        dn.done_flag = ss.done;
+        dn.done_flag = ss.done; dn.w_temporal = wt;
         dn.x_bf16 = act16;
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
         dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE; dn.out16 = h16 ? xs16 : nullptr; dn.fs = L.fs_d;
@@ -533,7 +537,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         skip_qkv = false;
         // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
         SkinnyParams lh{};
-        lh.done_flag = ss.done;
+        lh.done_flag = ss.done; lh.w_temporal = cp_temporal ? 1 : 0;
         const int off = (n_new - 1) * B;
         lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
         lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE; lh.fs = fs_lm;
@@ -1039,6 +1043,8 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     p.x = x.as<float>(); p.ldx = K; p.M = M; p.Wp = W.p; p.N = N; p.K = K; p.eps = 1e-6f; p.act = act;
     p.x_bf16 = 1;                                   // as in the frame step: the producer's bf16 copy of x
     if (act != ACT_SWIGLU) { int fs = 16; while (fs > 4 && N / fs < 192) fs /= 2; p.fs = fs; }     // the engine's choose_fs
+    if (const char* e = getenv("QTTS_DEBUG_FS")) { if (act != ACT_SWIGLU && atoi(e) > 0) p.fs = atoi(e); }
+    if (const char* e = getenv("QTTS_CP_TEMPORAL")) p.w_temporal = atoi(e) != 0;
     if (with_norm) { p.norm = 1; p.ss_in = ssin.as<float>(); }
     if (with_res) { p.res = res.as<float>(); p.ldr = No; }
     p.out = out.as<float>(); p.ldo = No; p.done_flag = done.as<int>(); p.ablate = ablate;
