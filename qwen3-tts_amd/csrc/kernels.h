@@ -44,13 +44,7 @@ struct SkinnyParams {
     int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns)
     const int* done_flag;        // optional device flag: when non-zero the kernel exits early
     int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
-    // optional (bf16 kernel): warm the head of the NEXT decode GEMM's packed weights into this XCD's L2 -- see skinny_prefetch()
-    const void* pf_base; int pf_grid, pf_spw, pf_strip, pf_seg_shift, pf_b2_shift;
-    int w_temporal;              // 1: plain weight loads (re-read soon, fits the Infinity Cache) instead of non-temporal ones
 };
-// Fill the pf_* fields of `p` for a following launch_skinny call on packed weights `Wp` [N][K] (bf16, strips of fs features,
-// swiglu = gate/up strip pairs): at most `budget_bytes` in total, the first bytes of every strip.
-void skinny_prefetch(SkinnyParams& p, const void* Wp, int N, int K, int fs, bool swiglu, size_t budget_bytes = 12u << 20);
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);
 bool skinny_takes_bf16_x(int M, int K, bool bf16);   // bf16 mode: any M <= 64, K % 32 == 0
 size_t skinny_packed_bytes(int N, int K, bool bf16);

@@ -59,9 +59,7 @@ __device__ inline void skinny_store4(const SkinnyParams& p, int row, int col, co
 // requests; the generic variant guards the tail tile by tile (tiny test dimensions, odd K).
 // NCH > 0 (EXACT only): the number of chunks is a compile-time constant (1..3) and the whole kernel is straight-line code -- no
 // branch, hence no register merge (a merge copy of a load result waits for that load) between the request bursts.
-// WT: plain (temporal) weight loads instead of non-temporal ones -- for weights that are re-read soon and fit the 256 MB Infinity
-// Cache (the code predictor's 157 MB, read by 15 passes per frame); a per-GEMM choice of the engine (SkinnyParams::w_temporal).
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH, bool WT>
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
 __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     constexpr int KT = 32;                                       // k per tile
     constexpr int NS = SPW * MT + MT;                            // accumulators per wave: the GEMM's + one X.X^T per m-tile
@@ -111,9 +109,9 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     const size_t wstep = (p.ablate & 8) ? 0 : (size_t)(FS * 4);
     const int xstep = (p.ablate & 2) ? 0 : KT;
 
-    auto wload = [&](const u32x4* ptr) -> u32x4 {
-        if constexpr (WT) return *ptr; else return skinny_wload(ptr);
-    };
+    // (non-temporal: measured twice -- round 1 whole-frame +7.6 % with plain loads; round 2 per GEMM class, plain loads for the code
+    // predictor's re-read 157 MB: no gain with, +3.5 % without a warm-up -- profiles/r02_ab_inproc_prefetch_temporal.json)
+    auto wload = [&](const u32x4* ptr) -> u32x4 { return skinny_wload(ptr); };
     auto load_x = [&](int m, int kt) -> u32x4 {
         if constexpr (XB16) return *reinterpret_cast<const u32x4*>(xp16[m] + kt * xstep);
         else {    // fp32 x (no bf16 copy from the producer): converted here; not on the frame step's hot path
@@ -181,28 +179,6 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
         if (!EXACT || nchunks > 1) load_chunk(wR[1], xR[1], 1);
     }
 
-    // ---- 1b. warm the NEXT GEMM's weights (they do not depend on anything this chain computes): one dword per 128-B line
-    // pulls the head of every strip that the next launch's workgroup b2 will stream into THIS XCD's L2 -- workgroup b2 of the
-    // next launch lands on XCD b2 % 8 like this one (grids are multiples of 8), so block b takes b2 = b, b + grid, ...
-    // The frame step is latency-bound (HBM is idle three quarters of the time): the requests cost one VGPR and ride under
-    // this launch's own stream; the next launch then finds its first tiles one L2 hop away instead of one HBM round trip.
-    // (two requests per thread at most, results untouched until the very end: nothing here may wait for a load)
-    constexpr int PFN = 2;
-    int pfv[PFN];
-#pragma unroll
-    for (int q = 0; q < PFN; ++q) {
-        pfv[q] = 0;
-        if (p.pf_base) {
-            const int idx = tid + q * NW * 64;                   // line index within this workgroup's share
-            const int b2 = blockIdx.x + (idx >> p.pf_b2_shift) * gridDim.x;
-            const int ln = idx & ((1 << p.pf_b2_shift) - 1);    // line within workgroup b2's head: strip (ln >> seg_shift), line
-            if (b2 < p.pf_grid)
-                pfv[q] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(p.pf_base) + (size_t)b2 * p.pf_spw * p.pf_strip +
-                                                       (size_t)(ln >> p.pf_seg_shift) * p.pf_strip +
-                                                       ((size_t)(ln & ((1 << p.pf_seg_shift) - 1)) << 7));
-        }
-    }
-
     // ---- 2. epilogue operands of wave 0 are fetched now, under the weight stream
     f32x4 resv[SPW][MT], biasv[SPW];
     const bool epi_loads = wave == 0 && !(p.ablate & 4);
@@ -268,7 +244,6 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
         for (int s = 0; s < SPW; ++s) red[(wave * NS + s * MT + m) * 64 + lane] = acc[s][m];
         red[(wave * NS + SPW * MT + m) * 64 + lane] = acc_ss[m];
     }
-    if (p.pf_base && (pfv[0] ^ pfv[1]) == 0x5a5aa5a5) red[0][0] = 1.f;     // (practically never true: keeps the warm-up loads alive)
     __syncthreads();
     if (wave != 0) return;
 
@@ -445,12 +420,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
 // more, so there is no capacity condition left (round 1: M <= 16 up to K = 7096, M <= 32 up to K = 2344).
 bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <= 64 && K % 32 == 0; }
 
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH, bool WT>
-static void launch2_w(const SkinnyParams& p, hipStream_t st) {
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
+static void launch2_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
     const size_t lds = (size_t)NW * (SPW * MT + MT) * 64 * 16;
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "skinny: LDS budget exceeded");
-    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH, WT>;
+    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH>;
     static bool attr_set = false;          // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -458,13 +433,6 @@ static void launch2_w(const SkinnyParams& p, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
-}
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
-static void launch2_n(const SkinnyParams& p, hipStream_t st) {
-    if constexpr (NCH > 0) {               // the straight-line (frame step) kernels exist in both load flavours
-        if (p.w_temporal) { launch2_w<MT, SPW, NW, FS, XB16, U, EXACT, NCH, true>(p, st); return; }
-    }
-    launch2_w<MT, SPW, NW, FS, XB16, U, EXACT, NCH, false>(p, st);
 }
 template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT>
 static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
@@ -519,27 +487,6 @@ static int skinny_spw(int N, int fs, bool swiglu) {
     return (fs == 16 && N / 16 >= 1024 && (N / 16) % 2 == 0) ? 2 : 1;
 }
 
-void skinny_prefetch(SkinnyParams& p, const void* Wp, int N, int K, int fs, bool swiglu, size_t budget_bytes) {
-    p.pf_base = nullptr;
-    if (!fs) fs = 16;
-    const int my_fs = p.fs ? p.fs : 16;
-    const int my_grid = p.N / (my_fs * skinny_spw(p.N, my_fs, p.act == ACT_SWIGLU));       // the launch that does the warming
-    const int spw = skinny_spw(N, fs, swiglu);
-    const int strip = (K / 32) * fs * 64;                    // bytes of one packed strip (bf16)
-    const int strips = N / fs, grid = strips / spw;
-    if (!Wp || strip % 128 != 0 || my_grid < 1 || my_grid % 8 != 0 || grid % 8 != 0) return;   // (XCD of block b = b % 8)
-    // head of every strip: a power-of-two number of 128-B lines, within the byte budget and within what the warming launch
-    // can request (2 lines per thread, 512 threads per workgroup)
-    const int rounds = (grid + my_grid - 1) / my_grid;       // next-launch workgroups per warming workgroup
-    size_t lines = std::min<size_t>((size_t)strip / 128, budget_bytes / 128 / (size_t)strips);
-    lines = std::min<size_t>(lines, (size_t)(2 * 512) / (size_t)(rounds * spw));
-    int shift = 0;
-    while (((size_t)2 << shift) <= lines) ++shift;
-    if (lines < 1) return;
-    p.pf_base = Wp; p.pf_grid = grid; p.pf_spw = spw; p.pf_strip = strip; p.pf_seg_shift = shift;
-    p.pf_b2_shift = shift + (spw == 2 ? 1 : 0);
-}
-
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int KT = bf16 ? 32 : 16;
     const int fs = p.fs ? p.fs : 16;
@@ -554,7 +501,6 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(bf16 || !p.norm || p.ss_in, QTTS_ERR_ARG, "skinny: the fp32 kernel takes the row sums of squares from ss_in");
     if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.N % 32 == 0 && fs == 16, QTTS_ERR_ARG, "skinny: swiglu needs N % 32 and fs == 16");
     const int spw = skinny_spw(p.N, fs, p.act == ACT_SWIGLU);
-    QTTS_REQUIRE(!p.pf_base || bf16, QTTS_ERR_ARG, "skinny: weight warm-up is a bf16-kernel feature");
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16) {

@@ -29,8 +29,6 @@ struct LayerW {
     DevBuf g1, g2, qn, kn;
 };
 struct StackDims { int H, I, nh, nkv, hd, qd, kvd; float eps; };
-// the decode GEMM that follows a launch in the frame's dependency chain (its packed weights get warmed by the predecessor)
-struct NextW { const void* p = nullptr; int N = 0, K = 0, fs = 16; bool swiglu = false; };
 
 }  // namespace
 
@@ -130,12 +128,15 @@ struct qtts_talker {
         pack_skinny_weight(w.data(), N, K, bf16, h.data(), g ? g->data() : nullptr, fs);     // g: folded RMSNorm weight
         d.upload(h.data(), h.size());
     }
-    // Narrow strips when the GEMM would otherwise launch far fewer than 256 workgroups (bf16 kernel only).
+    // Narrow strips when the GEMM would otherwise launch too few workgroups to pull its weights (bf16 kernel only).  Every
+    // workgroup re-reads the whole x (M x K bf16) through its XCD's L2, so MORE workgroups also cost more (round-2 sweep,
+    // profiles/r02_skinny_sweep_fs_M_temporal.txt); QTTS_FS_MIN_WGS (default 192) sets the floor for A/B runs.
+    int fs_min_wgs = [] { const char* e = getenv("QTTS_FS_MIN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 192; }();
     int choose_fs(int N, int K) const {
         (void)K;
         if (!bf16) return 16;
         int fs = 16;
-        while (fs > 4 && N / fs < 192) fs /= 2;
+        while (fs > 4 && N / fs < fs_min_wgs) fs /= 2;
         return fs;
     }
     static std::vector<float> cat3(const std::vector<float>& a, const std::vector<float>& b, const std::vector<float>& c) {
@@ -179,15 +180,6 @@ struct qtts_talker {
 
     void skinny(const SkinnyParams& p, hipStream_t st) { launch_skinny(p, bf16, st); ++skinny_count; }
     int64_t skinny_count = 0;
-    // QTTS_SKINNY_PREFETCH=0 switches the next-weights warm-up off (A/B on hardware); bf16 mode only
-    bool prefetch_on = [] { const char* e = getenv("QTTS_SKINNY_PREFETCH"); return !e || atoi(e) != 0; }();
-    // QTTS_CP_TEMPORAL=1: the code predictor's GEMMs (157 MB re-read by 15 passes per frame) use plain weight loads (A/B)
-    bool cp_temporal = [] { const char* e = getenv("QTTS_CP_TEMPORAL"); return e && atoi(e) != 0; }();
-    int debug_fs = [] { const char* e = getenv("QTTS_DEBUG_FS"); return e ? atoi(e) : 0; }();
-    void warm(SkinnyParams& p, const NextW& n) const {
-        if (bf16 && prefetch_on && n.p) skinny_prefetch(p, n.p, n.N, n.K, n.fs, n.swiglu);
-    }
-    NextW nw_qkv(const LayerW& L, const StackDims& d) const { return {L.qkv_p.p, d.qd + 2 * d.kvd, d.H, 16, false}; }
 
     // x-side handling of a GEMM whose input is RMS-normalised: the bf16 kernel takes the row variances on the matrix pipe
     // (skinny.hip) from the producer's bf16 copy of x; the fp32 parity kernel gets the row sums of squares from one extra
@@ -204,17 +196,15 @@ struct qtts_talker {
     // one decoder layer on `M = n_new * B` rows of `xs` (in place)
     void decode_layer(const LayerW& L, const StackDims& d, float* xs, unsigned short* xs16, float* qkvb, float* attb,
                       float* actb, int M, int n_new, KvCache& kv, int layer, const int* len_dev, int len_static,
-                      const int* npad, const float* inv_freq, int max_len, hipStream_t st, const NextW& after_down = NextW()) {
+                      const int* npad, const float* inv_freq, int max_len, hipStream_t st) {
         // xs16: bf16 copy of the hidden state kept in step with xs by every producer (bf16 mode, M <= 16), or null
         const bool h16 = xs16 && skinny_takes_bf16_x(M, d.H, bf16);
-        const int wt = (&d == &cd && cp_temporal) ? 1 : 0;
         SkinnyParams p{};
-        p.done_flag = ss.done; p.w_temporal = wt;
+        p.done_flag = ss.done;
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
         if (!skip_qkv) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
             norm_input(p, d, h16 ? xs16 : nullptr, st);
-            warm(p, NextW{L.o_p.p, d.H, d.qd, L.fs_o, false});
             skinny(p, st);
         }
         AttnDecodeParams a{};
@@ -228,25 +218,22 @@ struct qtts_talker {
         a.out_bf16 = att16;
         if (!skinny_only) launch_attn_decode(a, st);
         SkinnyParams o{};
-        o.done_flag = ss.done; o.w_temporal = wt;
+        o.done_flag = ss.done;
         o.x_bf16 = att16;
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
         o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr; o.fs = L.fs_o;
-        warm(o, NextW{L.gu_p.p, 2 * d.I, d.H, 16, true});
         skinny(o, st);
         SkinnyParams g{};
-        g.done_flag = ss.done; g.w_temporal = wt;
+        g.done_flag = ss.done;
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
         g.out_bf16 = act16;
         norm_input(g, d, h16 ? xs16 : nullptr, st);
-        warm(g, NextW{L.d_p.p, d.H, d.I, L.fs_d, false});
         skinny(g, st);
         SkinnyParams dn{};
-        dn.done_flag = ss.done; dn.w_temporal = wt;
+        dn.done_flag = ss.done;
         dn.x_bf16 = act16;
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
         dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE; dn.out16 = h16 ? xs16 : nullptr; dn.fs = L.fs_d;
-        warm(dn, after_down);
         skinny(dn, st);
     }
 
@@ -520,7 +507,6 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
             pj.done_flag = ss.done;
             pj.x = cp_in.as<float>(); pj.ldx = td.H; pj.M = M; pj.Wp = proj_p.p; pj.N = cd.H; pj.K = td.H;
             if (bf16) { pj.x = reinterpret_cast<const float*>(cp_in16.as<unsigned short>()); pj.x_bf16 = 1; }
-            warm(pj, nw_qkv(cl[0], cd));
             pj.bias = proj_b.as<float>(); pj.out = cp_x.as<float>(); pj.ldo = cd.H; pj.act = ACT_NONE; pj.fs = fs_proj;
             pj.out16 = (c16 && skinny_takes_bf16_x(M, cd.H, bf16)) ? c16 : nullptr;
             skinny(pj, st);
@@ -531,19 +517,16 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         for (int l = 0; l < c.cp_num_hidden_layers; ++l) {
             skip_qkv = j >= 1 && l == 0;
             decode_layer(cl[l], cd, cp_x.as<float>(), c16, cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
-                         kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st,
-                         l + 1 < c.cp_num_hidden_layers ? nw_qkv(cl[l + 1], cd) : NextW{lm_head_p[j].p, c.cp_vocab_size, cd.H, fs_lm, false});
+                         kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st);
         }
         skip_qkv = false;
         // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
         SkinnyParams lh{};
-        lh.done_flag = ss.done; lh.w_temporal = cp_temporal ? 1 : 0;
+        lh.done_flag = ss.done;
         const int off = (n_new - 1) * B;
         lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
         lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE; lh.fs = fs_lm;
         norm_input(lh, cd, (c16 && skinny_takes_bf16_x(M, cd.H, bf16)) ? c16 + (size_t)off * cd.H : nullptr, st);
-        // next in the chain: layer 0 of the next pass starts at its o projection (its q|k|v row comes from the table), or the talker
-        warm(lh, j + 1 < G - 1 ? NextW{cl[0].o_p.p, cd.H, cd.qd, cl[0].fs_o, false} : nw_qkv(tl[0], td));
         skinny(lh, st);
         SampleParams s{};
         s.logits = cp_logits.as<float>(); s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
@@ -577,8 +560,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     // ---- talker decode forward (M:1706-1727)
     for (int l = 0; l < c.num_hidden_layers; ++l)
         decode_layer(tl[l], td, x.as<float>(), bf16 ? x16.as<unsigned short>() : nullptr, qkv.as<float>(), att.as<float>(), act.as<float>(), B, 1, kv_t, l, ss.kv_len, 0,
-                     n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, st,
-                     l + 1 < c.num_hidden_layers ? nw_qkv(tl[l + 1], td) : NextW{head_p.p, c.vocab_size, td.H, fs_head, false});
+                     n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, st);
     if (!skinny_only) launch_apply_norm(x.as<float>(), td.H, t_norm.as<float>(), td.eps, past_hidden.as<float>(), td.H, B, td.H, ss.done, st,
                                         bf16 ? ph16.as<unsigned short>() : nullptr);
     SkinnyParams h{};
@@ -586,7 +568,6 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     h.x = past_hidden.as<float>(); h.ldx = td.H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = td.H;
     if (bf16) { h.x = reinterpret_cast<const float*>(ph16.as<unsigned short>()); h.x_bf16 = 1; }
     h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE; h.fs = fs_head;
-    warm(h, has_proj ? NextW{proj_p.p, cd.H, td.H, fs_proj, false} : nw_qkv(cl[0], cd));      // the next frame's first GEMM
     skinny(h, st);
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
 }
@@ -1044,7 +1025,6 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     p.x_bf16 = 1;                                   // as in the frame step: the producer's bf16 copy of x
     if (act != ACT_SWIGLU) { int fs = 16; while (fs > 4 && N / fs < 192) fs /= 2; p.fs = fs; }     // the engine's choose_fs
     if (const char* e = getenv("QTTS_DEBUG_FS")) { if (act != ACT_SWIGLU && atoi(e) > 0) p.fs = atoi(e); }
-    if (const char* e = getenv("QTTS_CP_TEMPORAL")) p.w_temporal = atoi(e) != 0;
     if (with_norm) { p.norm = 1; p.ss_in = ssin.as<float>(); }
     if (with_res) { p.res = res.as<float>(); p.ldr = No; }
     p.out = out.as<float>(); p.ldo = No; p.done_flag = done.as<int>(); p.ablate = ablate;

@@ -14,9 +14,8 @@ from qwen3_tts_amd.talker import TalkerEngine
 
 CONFIGS = {
     "default": {},
-    "prefetch_off": {"QTTS_SKINNY_PREFETCH": "0"},
-    "cp_temporal": {"QTTS_CP_TEMPORAL": "1"},
-    "cp_temporal+prefetch_off": {"QTTS_CP_TEMPORAL": "1", "QTTS_SKINNY_PREFETCH": "0"},
+    "fs_min_wgs_96": {"QTTS_FS_MIN_WGS": "96"},
+    "fs_min_wgs_48": {"QTTS_FS_MIN_WGS": "48"},
 }
 KEYS = sorted({k for c in CONFIGS.values() for k in c})
 
