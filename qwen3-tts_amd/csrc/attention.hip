@@ -705,6 +705,243 @@ __global__ __launch_bounds__(256) void attn_cp0_kernel(AttnDecodeParams p) {
 }
 
 
+// =================================================================================== attn_tk (round 2)
+// The talker's single-token decode attention (28 launches per frame; 12.7 us each in the general kernel above, ~60 us at 800
+// keys).  Same loads, same key ownership (key s -> 16-lane group s % 16, 8 dims per lane, 64 keys per chunk, the first chunks
+// requested speculatively at kernel entry), but flash-decoding INSIDE the workgroup:
+//   * no workgroup-wide score buffer and no softmax phase: every 16-lane group keeps its own running (max, sum, PV accumulator)
+//     over its keys in registers (online softmax: a chunk of 4 keys costs one rescale); the 16 partial results are merged once,
+//     out = sum_g acc_g e^(m_g - m) / sum_g l_g e^(m_g - m), in a fixed order;
+//   * no staging barrier for the new token either: every wave norms / ropes q (and k, v) of the new token itself and
+//     re-distributes it through a wave-private LDS slice (wave-level ordering only); wave 0 appends K / V to the cache;
+//   * ONE workgroup barrier (in front of the merge) instead of four;
+//   * beyond the register window (256 keys bf16 / 128 fp32) K and V chunks are read TOGETHER, NPRE chunks per latency round,
+//     and folded into the running statistics -- a long utterance costs one round trip per 256 keys, not two per 64.
+template <typename KVT, int GQ>
+__global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
+    constexpr int HD = 128, CH = 4;
+    constexpr int KW = sizeof(KVT) == 2 ? 1 : 2;          // 16-B vectors per key per lane (8 dims)
+    constexpr int NPRE = KW == 1 ? 4 : 2;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float xw[4][GQ + 2][HD];      // per wave: q heads, k, v of the new token
+    __shared__ __attribute__((aligned(16))) float red[16][GQ][HD];
+    __shared__ float gm[16][GQ], gl[16][GQ];
+
+    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = tid >> 4, li = tid & 15;
+    const KVT* kc = reinterpret_cast<const KVT*>(p.kv.k);
+    const KVT* vc = reinterpret_cast<const KVT*>(p.kv.v);
+    const int pool_keys = p.kv.pages_per_seq * 16;
+
+    auto kv_off = [&](int s) -> size_t {       // element offset of key s, this lane's 8 dims
+        s = s < pool_keys ? s : pool_keys - 1;  // speculative loads stay inside the sequence's pages
+        const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+        return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD + li * 8;
+    };
+    auto load_chunk = [&](u32x4 (&r)[CH][KW], const KVT* base, int c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(base + kv_off(g + 16 * (c * CH + i)));
+#pragma unroll
+            for (int w = 0; w < KW; ++w) r[i][w] = src[w];
+        }
+    };
+    auto unpack = [&](const u32x4 (&r)[KW], float (&x)[8]) {
+        if constexpr (KW == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[2 * e] = __uint_as_float(r[0][e] << 16);
+                x[2 * e + 1] = __uint_as_float(r[0][e] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] = __uint_as_float(r[0][e]); x[4 + e] = __uint_as_float(r[1][e]); }
+        }
+    };
+
+    // ---- 0. loads that do not depend on this step's qkv row or on the length: the first K and V chunk(s)
+    u32x4 kR[NPRE][CH][KW], vR[NPRE][CH][KW];
+    load_chunk(kR[0], kc, 0);
+    load_chunk(vR[0], vc, 0);
+    const bool deep = p.max_len > 64;
+    if (deep) { load_chunk(kR[1], kc, 1); load_chunk(vR[1], vc, 1); }
+    // this step's row: EVERY wave fetches the GQ query heads, k and v of the new token (lane <- dims lane, lane + 64)
+    float x0v[GQ + 2], x1v[GQ + 2];
+#pragma unroll
+    for (int vi = 0; vi < GQ + 2; ++vi) {
+        const int col = vi < GQ ? (kvh * GQ + vi) * HD : (vi == GQ ? (p.nh + kvh) * HD : (p.nh + p.nkv + kvh) * HD);
+        const float* src = p.qkv + (size_t)b * p.ld + col;
+        x0v[vi] = src[lane]; x1v[vi] = src[lane + 64];
+    }
+    const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step
+    const int npad = p.n_pad ? p.n_pad[b] : 0;
+    const int done = p.done_flag ? *p.done_flag : 0;
+    const int S1 = S0 + 1;                                  // total keys
+    const int nchunk = (S0 + 16 * CH - 1) / (16 * CH);      // chunks of CACHED keys (the new key is handled from LDS)
+#pragma unroll
+    for (int c = 1; c < NPRE; ++c)
+        if (c < nchunk && !(deep && c == 1)) { load_chunk(kR[c], kc, c); load_chunk(vR[c], vc, c); }
+    if (done) return;
+
+    // ---- 1. q / k RMSNorm + RoPE of the new token, per wave; K / V append by wave 0 (rounded through the cache type: every
+    // wave uses the rounded values, exactly what a later step will read back)
+    const float wq0 = p.qw[lane], wq1 = p.qw[lane + 64], wk0 = p.kw[lane], wk1 = p.kw[lane + 64];
+    const float ang = (float)(S0 - npad) * p.inv_freq[lane];
+    const float cs = cosf(ang), sn = sinf(ang);
+#pragma unroll
+    for (int vi = 0; vi < GQ + 2; ++vi) {
+        float x0 = x0v[vi], x1 = x1v[vi];
+        if (vi <= GQ) {                                      // q heads and k
+            const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
+            const float rs = rsqrtf(ss / (float)HD + p.eps);
+            x0 = (vi < GQ ? wq0 : wk0) * (x0 * rs);
+            x1 = (vi < GQ ? wq1 : wk1) * (x1 * rs);
+            const float o0 = x0 * cs - x1 * sn, o1 = x1 * cs + x0 * sn;
+            x0 = o0; x1 = o1;
+        }
+        if (vi >= GQ) {
+            const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
+            if (wave == 0) {
+                const int page = p.kv.contig ? b * p.kv.pages_per_seq + (S0 >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (S0 >> 4)];
+                const size_t o = ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (S0 & 15)) * HD;
+                KVT* cdst = reinterpret_cast<KVT*>(vi == GQ ? p.kv.k : p.kv.v);
+                cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
+            }
+            x0 = kv_load(&h0); x1 = kv_load(&h1);
+        }
+        xw[wave][vi][lane] = x0; xw[wave][vi][lane + 64] = x1;
+    }
+    __builtin_amdgcn_wave_barrier();             // wave-private LDS slice: program order within the wave is all that is needed
+    const float scale = rsqrtf((float)HD);
+    float qreg[GQ][8];
+#pragma unroll
+    for (int qi = 0; qi < GQ; ++qi)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qreg[qi][e] = xw[wave][qi][li * 8 + e];
+
+    // ---- 2. online softmax over this group's keys, everything in registers
+    float m[GQ], l[GQ], acc[GQ][8];
+#pragma unroll
+    for (int qi = 0; qi < GQ; ++qi) {
+        m[qi] = -INFINITY; l[qi] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[qi][e] = 0.f;
+    }
+    auto fold = [&](const float (&sc)[CH][GQ], const float (&vx)[CH][8]) {       // CH keys: scores (or -inf) and their V slices
+#pragma unroll
+        for (int qi = 0; qi < GQ; ++qi) {
+            float mc = sc[0][qi];
+#pragma unroll
+            for (int i = 1; i < CH; ++i) mc = fmaxf(mc, sc[i][qi]);
+            const float mn = fmaxf(m[qi], mc);
+            if (mn == -INFINITY) continue;                   // nothing valid so far in this group
+            const float f = expf(m[qi] - mn);                // (m = -inf -> 0)
+            float pr[CH], ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) { pr[i] = expf(sc[i][qi] - mn); ps += pr[i]; }
+            l[qi] = l[qi] * f + ps;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a = acc[qi][e] * f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) a += pr[i] * vx[i][e];
+                acc[qi][e] = a;
+            }
+            m[qi] = mn;
+        }
+    };
+    auto process = [&](const u32x4 (&kr)[CH][KW], const u32x4 (&vr)[CH][KW], int c) {
+        float d[CH][GQ], vx[CH][8];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            float kx[8];
+            unpack(kr[i], kx);
+            unpack(vr[i], vx[i]);
+#pragma unroll
+            for (int qi = 0; qi < GQ; ++qi) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += qreg[qi][e] * kx[e];
+                d[i][qi] = a;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int s = g + 16 * (c * CH + i);
+            const bool valid = s < S0 && s >= npad;          // left-pad slots were never written; slots >= S0 hold nothing yet
+#pragma unroll
+            for (int qi = 0; qi < GQ; ++qi) {
+                const float r = row16_sum(d[i][qi]) * scale;     // (DPP row reduction: executed by every lane, then selected)
+                d[i][qi] = valid ? r : -INFINITY;
+            }
+            if (!valid) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vx[i][e] = 0.f;  // (0 * garbage must not become NaN)
+            }
+        }
+        fold(d, vx);
+    };
+#pragma unroll
+    for (int c = 0; c < NPRE; ++c)
+        if (c < nchunk) process(kR[c], vR[c], c);
+    for (int c0 = NPRE; c0 < nchunk; c0 += NPRE) {          // long sequences: NPRE chunks of K AND V per latency round
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (c0 + j < nchunk) { load_chunk(kR[j], kc, c0 + j); load_chunk(vR[j], vc, c0 + j); }
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (c0 + j < nchunk) process(kR[j], vR[j], c0 + j);
+    }
+    if (g == (S0 & 15) && S0 >= npad) {                     // the new key (position S0): k, v from this wave's LDS slice
+        float d[CH][GQ], vx[CH][8];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+#pragma unroll
+            for (int qi = 0; qi < GQ; ++qi) d[i][qi] = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vx[i][e] = 0.f;
+        }
+#pragma unroll
+        for (int qi = 0; qi < GQ; ++qi) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += qreg[qi][e] * xw[wave][GQ][li * 8 + e];
+            d[0][qi] = row16_sum(a) * scale;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vx[0][e] = xw[wave][GQ + 1][li * 8 + e];
+        fold(d, vx);
+    }
+    (void)S1;
+    // ---- 3. merge of the 16 groups (fixed order)
+#pragma unroll
+    for (int qi = 0; qi < GQ; ++qi) {
+        float4* dst = reinterpret_cast<float4*>(&red[g][qi][li * 8]);
+        dst[0] = make_float4(acc[qi][0], acc[qi][1], acc[qi][2], acc[qi][3]);
+        dst[1] = make_float4(acc[qi][4], acc[qi][5], acc[qi][6], acc[qi][7]);
+        if (li == 0) { gm[g][qi] = m[qi]; gl[g][qi] = l[qi]; }
+    }
+    __syncthreads();
+    if (tid < GQ * HD) {
+        const int qi = tid / HD, dd = tid % HD;
+        float mm = gm[0][qi];
+#pragma unroll
+        for (int gg = 1; gg < 16; ++gg) mm = fmaxf(mm, gm[gg][qi]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) {
+            const float f = gm[gg][qi] > -INFINITY ? expf(gm[gg][qi] - mm) : 0.f;
+            num += red[gg][qi][dd] * f;
+            den += gl[gg][qi] * f;
+        }
+        const size_t o = (size_t)b * p.ldo + (kvh * GQ + qi) * HD + dd;
+        const float r = num / den;
+        if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(r);
+        else p.out[o] = r;
+    }
+}
+
 template <typename KVT, int NQ>
 static void launch_attn_decode_t(const AttnDecodeParams& p, size_t lds, hipStream_t st) {
     auto kern = attn_decode_kernel<KVT, NQ>;
@@ -730,6 +967,14 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
     if (p.n_new == 1 && !p.len_dev && !p.n_pad && p.len_static + 1 <= 16 && GQ <= 2) {     // the code predictor's passes >= 1
         if (p.kv.bf16) hipLaunchKernelGGL(attn_cp_kernel<bf16_t>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
         else hipLaunchKernelGGL(attn_cp_kernel<float>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
+    if (p.n_new == 1 && GQ <= 2) {            // the talker's single-token step: any length, any padding (attn_tk above)
+        if (p.kv.bf16) { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 1>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
+                         else hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 2>), dim3(p.B * p.nkv), dim3(256), 0, st, p); }
+        else { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<float, 1>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
+               else hipLaunchKernelGGL((attn_tk_kernel<float, 2>), dim3(p.B * p.nkv), dim3(256), 0, st, p); }
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }

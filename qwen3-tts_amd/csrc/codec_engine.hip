@@ -45,6 +45,7 @@ struct qtts_codec {
     DevBuf final_w; float final_b = 0.f; int final_c = 0;
 
     DevBuf buf[4];
+    DevBuf buf16[2];                    // bf16 mode: activations that are only a GEMM input (decoder blocks)
     size_t buf_elems = 0;
     DevBuf err_flag;                    // device int: a code index >= codebook_size was seen (checked by the entry points)
     void check_codes_flag(hipStream_t st) {
@@ -141,13 +142,29 @@ struct qtts_codec {
     void gemm(const Lin& l, const float* A, int lda, int M, int T, float* C, int ldc, int act = ACT_NONE,
               const float* res = nullptr, int ldr = 0, const float* scale = nullptr, const Snake* sn = nullptr,
               hipStream_t st = nullptr) {
-        GemmTapParams p;
+        GemmTapParams p{};
         p.A = A; p.lda = lda; p.M = M; p.T = T; p.W = l.W.p; p.N = l.N; p.K = l.K; p.taps = l.taps;
         for (int i = 0; i < 8; ++i) p.shift[i] = l.shift[i];
         p.bias = l.has_bias ? l.bias.as<float>() : nullptr;
         p.scale = scale; p.res = res; p.ldr = ldr;
         p.snake_ea = sn ? sn->ea.as<float>() : nullptr; p.snake_ib = sn ? sn->ib.as<float>() : nullptr;
         p.act = act; p.C = C; p.ldc = ldc;
+        launch_gemm_tap(p, bf16, st);
+    }
+    // bf16 mode, decoder blocks: the same GEMM with a bf16 input (A16, selects gemm_tap2) and / or a bf16 copy of the result
+    // (C16) that already carries the next consumer's SnakeBeta (sn16); C may be null when only the bf16 copy is consumed
+    void gemm16(const Lin& l, const float* A, const bf16_t* A16, int lda, int M, int T, float* C, int ldc, int act, const float* res,
+                int ldr, const Snake* sn, bf16_t* C16, const Snake* sn16, hipStream_t st, int sn16_period = 0) {
+        GemmTapParams p{};
+        p.A = A; p.A16 = A16; p.lda = lda; p.M = M; p.T = T; p.W = l.W.p; p.N = l.N; p.K = l.K; p.taps = l.taps;
+        for (int i = 0; i < 8; ++i) p.shift[i] = l.shift[i];
+        p.bias = l.has_bias ? l.bias.as<float>() : nullptr;
+        p.res = res; p.ldr = ldr;
+        p.snake_ea = sn ? sn->ea.as<float>() : nullptr; p.snake_ib = sn ? sn->ib.as<float>() : nullptr;
+        p.act = act; p.C = C; p.ldc = ldc;
+        p.C16 = C16; p.ldc16 = ldc; p.act16 = sn16 ? ACT_SNAKE : ACT_NONE;
+        p.snake16_ea = sn16 ? sn16->ea.as<float>() : nullptr; p.snake16_ib = sn16 ? sn16->ib.as<float>() : nullptr;
+        p.snake16_period = sn16_period;
         launch_gemm_tap(p, bf16, st);
     }
 
@@ -353,6 +370,7 @@ void qtts_codec::finalize() {
     }
     buf_elems = per_frame * (size_t)std::max(1, c.max_batch) * (size_t)std::max(1, c.max_frames);
     for (auto& b : buf) b.alloc(buf_elems * sizeof(float));
+    if (bf16) for (auto& b : buf16) b.alloc(buf_elems * sizeof(bf16_t));
     err_flag.alloc(4);
     QTTS_CHECK_HIP(hipMemset(err_flag.p, 0, 4));
     host.clear();  // host copies no longer needed
@@ -442,10 +460,18 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
         for (auto p : all) if (p != x) fr[nf++] = p;
         a = fr[0]; b = fr[1]; cc = fr[2];
     };
+    // bf16 mode (round 2): inside the decoder blocks every tensor that is only a GEMM input travels as bf16 with the consumer's
+    // SnakeBeta already applied by its producer's epilogue; the residual stream stays fp32.
+    static const bool fast16_env = [] { const char* e = getenv("QTTS_CODEC_FAST16"); return !e || atoi(e) != 0; }();   // (=0: A/B)
+    bool fast16 = bf16 && !blocks.empty() && fast16_env;
+    for (auto& bk : blocks) fast16 = fast16 && bk.cin % 32 == 0 && bk.cout % 32 == 0;
+    bf16_t* h16a = fast16 ? buf16[0].as<bf16_t>() : nullptr;
+    bf16_t* h16b = fast16 ? buf16[1].as<bf16_t>() : nullptr;
     // ---- decoder.0: conv k=7 latent -> decoder_dim (v2:857)
     {
         float *a, *b, *cc; scratch3(a, b, cc);
-        gemm(dec0, x, C, B * L, L, a, c.decoder_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+        if (fast16) gemm16(dec0, x, nullptr, C, B * L, L, a, c.decoder_dim, ACT_NONE, nullptr, 0, nullptr, h16a, &blocks[0].act, st);
+        else gemm(dec0, x, C, B * L, L, a, c.decoder_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
         x = a; C = c.decoder_dim;
     }
     if (want("decoder0")) { emit(x); return; }
@@ -453,6 +479,22 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     for (size_t i = 0; i < blocks.size(); ++i) {
         auto& bk = blocks[i];
         float *a, *b, *cc; scratch3(a, b, cc);
+        if (fast16) {
+            // h16a = SnakeBeta_block(x) in bf16 (from the previous producer).  tconv -> b (fp32, the first unit's residual) and
+            // h16a' = SnakeBeta_unit0.act1(b)
+            gemm16(bk.tconv, nullptr, h16a, C, B * L, L, b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st, bk.cout);
+            std::swap(h16a, h16b);                 // h16a: activated input of unit 0; h16b: free
+            L *= bk.r; C = bk.cout;
+            float* cur = b; float* alt = a;        // (a was only the stand-alone snake's output in the fp32 path: free here)
+            for (int j = 0; j < 3; ++j) {
+                auto& un = bk.u[j];
+                const Snake* next = j < 2 ? &bk.u[j + 1].a1 : (i + 1 < blocks.size() ? &blocks[i + 1].act : nullptr);
+                gemm16(un.c1, nullptr, h16a, C, B * L, L, nullptr, C, ACT_SNAKE, nullptr, 0, &un.a2, h16b, nullptr, st);   // conv7 + act2 -> bf16
+                gemm16(un.c2, nullptr, h16b, C, B * L, L, alt, C, ACT_NONE, cur, C, nullptr, next ? h16a : nullptr, next, st);  // 1x1 + residual
+                std::swap(cur, alt);               // ping-pong between a and b: the residual input is never the output
+            }
+            x = cur;
+        } else {
         launch_snake(x, bk.act.ea.as<float>(), bk.act.ib.as<float>(), a, (int64_t)B * L, C, st);
         gemm(bk.tconv, a, C, B * L, L, b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
         L *= bk.r; C = bk.cout;
@@ -466,6 +508,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
             std::swap(cur, alt);
         }
         x = cur;
+        }
         const std::string nm = "block" + std::to_string(i + 1);
         if (want(nm.c_str())) { emit(x); return; }
     }

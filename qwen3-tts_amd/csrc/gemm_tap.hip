@@ -65,8 +65,12 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
             if (n >= p.N) continue;
             const float bias = p.bias ? p.bias[n] : 0.f;
             const float scale = p.scale ? p.scale[n] : 1.f;
-            float ea = 0.f, ib = 0.f;
+            float ea = 0.f, ib = 0.f, ea16 = 0.f, ib16 = 0.f;
             if (p.act == ACT_SNAKE) { ea = p.snake_ea[n]; ib = p.snake_ib[n]; }
+            if (p.C16 && p.act16 == ACT_SNAKE) {
+                const int n16 = p.snake16_period > 0 ? n % p.snake16_period : n;
+                ea16 = p.snake16_ea[n16]; ib16 = p.snake16_ib[n16];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
@@ -77,7 +81,11 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
                 else if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
                 v *= scale;
                 if (p.res) v += p.res[(size_t)m * p.ldr + n];
-                p.C[(size_t)m * p.ldc + n] = v;
+                if (p.C) p.C[(size_t)m * p.ldc + n] = v;
+                if (p.C16) {               // bf16 copy for a GEMM consumer, with that consumer's SnakeBeta folded in
+                    if (p.act16 == ACT_SNAKE) { const float sn = sinf(v * ea16); v = v + ib16 * (sn * sn); }
+                    reinterpret_cast<bf16_t*>(p.C16)[(size_t)m * p.ldc16 + n] = f32_to_bf16(v);
+                }
             }
         }
 }
@@ -338,6 +346,160 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
     tap_epilogue<BN, TM, TN>(p, acc, m0, n0, wm, wn, li, lq);
 }
 
+// ---- round 2: the codec decoder's GEMM in bf16 mode (gemm_tap2).  What the round-1 kernel above spent its time on
+// (profiles/r01_pmc_mfma_codec.md: 8.5 % / 16.9 % MFMA-busy, 1.5 GB of fp32 activations moved for 248 GFLOP):
+//   * a 7-tap causal conv re-read its input tile 7 times from global memory, converted fp32 -> bf16 every time, through
+//     VGPRs into a single LDS buffer with two barriers per 32-wide k-step;
+//   * SnakeBeta ran as its own full read + write pass in front of every conv.
+// Here:
+//   * TAP REUSE: per 64- (or 96-) wide k-slab the input tile is staged ONCE, with its causal halo (128 + max|shift| rows),
+//     and all taps of that slab run from LDS with a row offset; a row that would come from before the start of its sequence is
+//     zeroed in the operand registers (a tile may span two sequences, so this cannot be decided at staging time);
+//   * bf16 activations in HBM wherever a tensor is only a GEMM input (A16 / C16): half the bytes, no conversion on the way in;
+//   * two LDS buffers for both operands: the next step's global loads are in flight under this step's MFMAs and land in the
+//     other buffer -- one barrier per step;
+//   * the NEXT consumer's SnakeBeta is folded into the epilogue of the producer (act16): the residual stream stays fp32 (C),
+//     the activated copy goes out as bf16 (C16), and the stand-alone snake passes disappear from the decoder blocks.
+// Tile 128 x BN, 4 waves (2 x 2), each wave 64 x BN/2 as 4 x BN/32 MFMA 16x16x32 tiles per 32 of k.
+template <int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int halo) {
+    constexpr int BM = 128;
+    constexpr int TM = 4, TN = BN / 32;
+    constexpr int STR = BK + 8;                        // LDS row stride (bf16 elements): 16-B aligned, rows shift by 4 banks
+    constexpr int CPR = BK / 8;                        // 16-B chunks per row
+    constexpr int MAXROWS = BM + 56;                   // 7 taps x dilation 9 -> halo 54
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_t2[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem_t2);                       // [2][MAXROWS][STR]
+    bf16_t* Ws = As + 2 * MAXROWS * STR;                                   // [2][BN][STR]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n_tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {   // XCD-aware tile order (as gemm_tap_kernel)
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / n_tiles_n) * BM;
+    const int n0 = (bid % n_tiles_n) * BN;
+    const int arows = BM + halo;                       // rows of the staged input tile: global rows m0 - halo .. m0 + 127
+    const bf16_t* A16 = reinterpret_cast<const bf16_t*>(p.A16);
+    const bf16_t* Wg = reinterpret_cast<const bf16_t*>(p.W);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int tpos[TM];                                      // position of this lane's output rows inside their sequence
+#pragma unroll
+    for (int i = 0; i < TM; ++i) tpos[i] = (m0 + wm * 64 + i * 16 + li) % p.T;
+
+    const int kslabs = p.K / BK;
+    const int nsteps = kslabs * p.taps;
+    constexpr int AREG = (MAXROWS * CPR + 255) / 256;
+    constexpr int WREG = (BN * CPR + 255) / 256;
+    uint4 ra[AREG], rw[WREG];
+
+    auto load_a = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < AREG; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / CPR, c = idx - r * CPR;
+            const int gr = m0 - halo + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < arows && gr >= 0 && gr < p.M) v = *reinterpret_cast<const uint4*>(A16 + (size_t)gr * p.lda + ks * BK + c * 8);
+            ra[i] = v;
+        }
+    };
+    auto store_a = [&](int buf) {
+        bf16_t* dst = As + buf * MAXROWS * STR;
+#pragma unroll
+        for (int i = 0; i < AREG; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / CPR, c = idx - r * CPR;
+            if (r < arows) *reinterpret_cast<uint4*>(&dst[r * STR + c * 8]) = ra[i];
+        }
+    };
+    auto load_w = [&](int ks, int tap) {
+        const bf16_t* W = Wg + (size_t)tap * p.N * p.K;
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / CPR, c = idx - r * CPR;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < BN && n0 + r < p.N) v = *reinterpret_cast<const uint4*>(W + (size_t)(n0 + r) * p.K + ks * BK + c * 8);
+            rw[i] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+        bf16_t* dst = Ws + buf * BN * STR;
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx / CPR, c = idx - r * CPR;
+            if (r < BN) *reinterpret_cast<uint4*>(&dst[r * STR + c * 8]) = rw[i];
+        }
+    };
+
+    load_a(0); load_w(0, 0);
+    store_a(0); store_w(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int ks = s / p.taps, tap = s - ks * p.taps;
+        const bool more = s + 1 < nsteps;
+        const int ks2 = (s + 1) / p.taps, tap2 = (s + 1) - ks2 * p.taps;
+        const bool new_slab = more && ks2 != ks;
+        if (more) load_w(ks2, tap2);                   // global loads stay in flight under the MFMAs
+        if (new_slab) load_a(ks2);
+        {
+            const bf16_t* Ab = As + (ks & 1) * MAXROWS * STR;
+            const bf16_t* Wb = Ws + (s & 1) * BN * STR;
+            const int sh = p.shift[tap];               // <= 0: output row m reads staged row (m - m0) + halo + sh
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    a[i] = *reinterpret_cast<const bf16x8*>(&Ab[(wm * 64 + i * 16 + li + halo + sh) * STR + kk * 32 + lq * 8]);
+                    if (tpos[i] + sh < 0) a[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // before the start of its own sequence
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const bf16x8*>(&Wb[(wn * (BN / 2) + j * 16 + li) * STR + kk * 32 + lq * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) {                                    // the other buffers were last read one step (W) / one slab (A) ago
+            store_w((s + 1) & 1);
+            if (new_slab) store_a(ks2 & 1);
+        }
+        __syncthreads();
+    }
+    tap_epilogue<BN, TM, TN>(p, acc, m0, n0, wm, wn, li, lq);
+}
+
+template <int BN, int BK>
+static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
+    const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
+    const size_t lds = ((size_t)2 * (128 + 56) + 2 * BN) * (BK + 8) * 2;
+    auto kern = gemm_tap2_kernel<BN, BK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo);
+}
+
 template <int BN>
 static void launch_wide(const GemmTapParams& p, hipStream_t st) {
     const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
@@ -363,6 +525,22 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(p.taps >= 1 && p.taps <= 8, QTTS_ERR_ARG, "gemm_tap: 1..8 taps");
     QTTS_REQUIRE(p.M > 0 && p.N > 0, QTTS_ERR_ARG, "gemm_tap: empty problem");
     QTTS_REQUIRE(p.lda % 4 == 0, QTTS_ERR_ARG, "gemm_tap: lda must be a multiple of 4");
+    if (p.A16) {                           // bf16 activations: the tap-reuse kernel (bf16 mode only)
+        QTTS_REQUIRE(bf16, QTTS_ERR_ARG, "gemm_tap: A16 needs bf16 weights");
+        QTTS_REQUIRE(p.act != ACT_SWIGLU, QTTS_ERR_ARG, "gemm_tap: the A16 kernel has no SwiGLU epilogue");
+        QTTS_REQUIRE(p.lda % 8 == 0, QTTS_ERR_ARG, "gemm_tap: bf16 A needs lda % 8 == 0");
+        QTTS_REQUIRE(p.C || p.C16, QTTS_ERR_ARG, "gemm_tap: no output");
+        int halo = 0;
+        for (int i = 0; i < p.taps; ++i) { QTTS_REQUIRE(p.shift[i] <= 0, QTTS_ERR_ARG, "gemm_tap: shift > 0"); halo = std::max(halo, -p.shift[i]); }
+        QTTS_REQUIRE(halo <= 56, QTTS_ERR_LIMIT, "gemm_tap: tap reach > 56 rows");
+        const int bn2 = (p.N % 128 == 0) ? 128 : (p.N % 96 == 0 ? 96 : (p.N <= 64 ? 64 : 128));
+        if (p.K % 64 == 0) { if (bn2 == 128) launch_tap2<128, 64>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 64>(p, halo, st); else launch_tap2<64, 64>(p, halo, st); }
+        else if (p.K % 96 == 0) { if (bn2 == 128) launch_tap2<128, 96>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 96>(p, halo, st); else launch_tap2<64, 96>(p, halo, st); }
+        else { if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st); }   // (small test dims)
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
+    QTTS_REQUIRE(p.C, QTTS_ERR_ARG, "gemm_tap: null output");
     int bn;
     if (p.act == ACT_SWIGLU) {
         QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "gemm_tap: swiglu needs N % 32 == 0");

@@ -21,6 +21,13 @@ struct GemmTapParams {
     const float* snake_ib;       // ACT_SNAKE: 1/(exp(beta)+1e-9)[N]
     int act;
     float* C; int ldc;           // ACT_SWIGLU writes N/2 columns
+    // ---- bf16 mode, round 2 (gemm_tap2_kernel): activations that are ONLY a GEMM input travel as bf16
+    const void* A16;             // bf16 [rows][lda] alternative to A (written by a producer's C16): selects the tap-reuse kernel
+    void* C16;                   // optional bf16 output [M][ldc16] = bf16(act16(v)), v = the fp32 result after act / scale / res
+    int ldc16;
+    int act16;                   // ACT_NONE | ACT_SNAKE (with snake16_*): the NEXT consumer's SnakeBeta folded into this epilogue
+    const float* snake16_ea; const float* snake16_ib;
+    int snake16_period;          // > 0: the act16 parameters repeat with this period over the N columns (transposed conv: N = r * Cout)
 };
 void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
 

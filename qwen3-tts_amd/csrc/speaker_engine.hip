@@ -76,7 +76,7 @@ struct qtts_speaker {
         l.bias.upload(P(pfx + ".bias", {Co}).data(), (size_t)Co * 4); l.has_bias = true;
     }
     void gemm(const SLin& l, const float* A, int lda, int M, int T, float* C, int ldc, hipStream_t st) {
-        GemmTapParams p;
+        GemmTapParams p{};
         p.A = A; p.lda = lda; p.M = M; p.T = T; p.W = l.W.p; p.N = l.N; p.K = l.K; p.taps = l.taps;
         for (int i = 0; i < 8; ++i) p.shift[i] = l.shift[i];
         p.bias = l.has_bias ? l.bias.as<float>() : nullptr;

@@ -29,6 +29,24 @@ extern "C" int hostemu_gemm_tap(const float* A, int lda, int M, int T, const voi
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
+// The bf16-activation tap-reuse kernel (gemm_tap2): A given as bf16 bits [M][lda], optional fp32 output C and / or bf16 output
+// C16 (with the consumer's SnakeBeta folded in when ea16 / ib16 are given).
+extern "C" int hostemu_gemm_tap16(const unsigned short* A16, int lda, int M, int T, const void* W, int N, int K, int taps,
+                                  const int* shift, const float* bias, const float* res, int ldr, const float* snake_ea,
+                                  const float* snake_ib, int act, float* C, int ldc, unsigned short* C16, const float* ea16,
+                                  const float* ib16) {
+    try {
+        qtts::GemmTapParams p{};
+        p.A16 = A16; p.lda = lda; p.M = M; p.T = T; p.W = W; p.N = N; p.K = K; p.taps = taps;
+        for (int i = 0; i < taps && i < 8; ++i) p.shift[i] = shift[i];
+        p.bias = bias; p.res = res; p.ldr = ldr; p.snake_ea = snake_ea; p.snake_ib = snake_ib; p.act = act;
+        p.C = C; p.ldc = ldc; p.C16 = C16; p.ldc16 = ldc; p.act16 = ea16 ? qtts::ACT_SNAKE : qtts::ACT_NONE;
+        p.snake16_ea = ea16; p.snake16_ib = ib16;
+        qtts::launch_gemm_tap_real(p, true, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
 // out[M][ldo] = skinny GEMM of x[M][K] with W[N][K] (row-major fp32, packed here exactly as the engines pack it)
 extern "C" int hostemu_skinny(const float* x, int ldx, int M, const float* W, int N, int K, const float* g, int norm, float eps,
                               const float* bias, const float* res, int ldr, int act, float* out, int ldo, int bf16) {

@@ -185,7 +185,25 @@ def test_codec_bf16_mode_tracks_fp32(codec_tiny, dev):
     r = _rms(e16.forward(codes).cpu().numpy(), g["fwd_wav"])
     ref = float(np.sqrt((g["fwd_wav"].astype(np.float64) ** 2).mean()))
     print(f"bf16 codec relative rms error {r / ref:.3f}")
-    assert r <= 0.15 * ref
+    assert r <= 0.08 * ref                  # measured 0.049 on the tiny dims (emulator and MI355X); round 1's bar was 0.15
+
+
+def test_codec_bf16_mode_at_real_dims_vs_reference_golden(dev, golden_dir):
+    """The benchmarked codec mode at the benchmarked size: real dims, 10 s (125 frames) of random codes,
+    bf16 engine (tap-reuse GEMM, bf16 activations inside the decoder blocks) against the REFERENCE's fp32 waveform
+    (`codec_real.npz`), as relative RMS; and the round-1 activation path (QTTS_CODEC_FAST16=0 is a process-wide switch, so
+    that comparison lives in tools/bench_configs.py) -- the bar is a doubling of the measured error."""
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizerV2Model
+    c = synth.codec_real()
+    wn = synth.codec_weights(c)
+    g = np.load(os.path.join(golden_dir, "codec_real.npz"))
+    model = Qwen3TTSTokenizerV2Model(synth.cfg_dict(c), _td(wn), device=dev, dtype=torch.bfloat16, max_batch=2, max_frames=325)
+    out = model.decode(torch.from_numpy(g["t125_codes"].astype(np.int64)).cuda()).audio_values
+    assert out[0].shape[0] == 240000
+    ref = g["t125_wav"].astype(np.float64)
+    rel = _rms(out[0].cpu().numpy(), g["t125_wav"]) / float(np.sqrt((ref ** 2).mean()))
+    print(f"bf16 codec at real dims, 125 frames: relative rms error {rel:.4f} vs the reference's fp32 waveform")
+    assert np.isfinite(rel) and rel <= 0.10
 
 
 # ============================================================================================ talker

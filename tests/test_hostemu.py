@@ -55,6 +55,7 @@ def emu():
     lib.hostemu_set_fiber_order.argtypes = [i32]; lib.hostemu_set_fiber_order.restype = None
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
+    lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
     lib.hostemu_skinny_bf16x.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32, vp]
     lib.hostemu_sample.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_float, i32, i32, vp, i32, i32, C.c_float, C.c_float,
                                    C.c_uint64, C.c_uint32, i32, vp]
@@ -155,6 +156,50 @@ def test_gemm_tap_kernel_real_source(emu, bf16):
         tol = (2e-3 if bf16 else 2e-5) * max(1.0, float(np.abs(want).max()))
         assert np.abs(out[:, :No] - want).max() <= tol, (M, N, K, shift, act, float(np.abs(out[:, :No] - want).max()))
         assert np.all(out[:, No:] == 7.0), "wrote outside its columns"
+
+
+def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
+    """gemm_tap2 (round 2, the codec decoder's bf16 GEMM): bf16 input tile staged once per k-slab with its causal halo and reused
+    by every tap, sequence-start zeroing applied in the operand registers (tiles that span two sequences included), k-slabs of
+    64 and 96, two LDS buffers, fp32 and / or bf16 output with the consumer's SnakeBeta folded in -- against float64 numpy."""
+    g = np.random.default_rng(47)
+    cases = [  # M, T, N, K, shifts, act, bias, res, out32, out16, snake16
+        (300, 100, 96, 96, [-6, -5, -4, -3, -2, -1, 0], ACT_SNAKE, 1, 0, 0, 1, 0),       # conv7 (d = 1) + act2 -> bf16 only
+        (200, 50, 64, 192, [-54, -45, -36, -27, -18, -9, 0], ACT_SNAKE, 1, 0, 0, 1, 0),  # dilation 9: halo 54, 4 sequences in 2 tiles
+        (260, 130, 128, 64, [0], ACT_NONE, 1, 1, 1, 1, 1),                               # 1x1 + residual -> fp32 and snake'd bf16
+        (150, 75, 192, 128, [-1, 0], ACT_NONE, 1, 0, 1, 1, 1),                           # transposed-conv form (2 taps), N = 2 column tiles
+        (129, 43, 96, 288, [-18, -15, -12, -9, -6, -3, 0], ACT_NONE, 0, 0, 1, 0, 0),     # K = 3 slabs of 96, dilation 3
+        (40, 40, 64, 64, [-2, -1, 0], ACT_GELU, 1, 1, 1, 0, 0),
+    ]
+    for (M, T, N, K, shift, act, hb, hr, o32, o16, s16) in cases:
+        A = (g.standard_normal((M, K + 8)) * 0.5).astype(np.float32)
+        Av, Abits = _bf16_round(A)
+        W = (g.standard_normal((len(shift), N, K)) / np.sqrt(K * len(shift))).astype(np.float32)
+        Wv, Wbits = _bf16_round(W)
+        bias = g.standard_normal(N).astype(np.float32) if hb else None
+        res = g.standard_normal((M, N)).astype(np.float32) if hr else None
+        ea = np.exp(g.standard_normal(N) * 0.3).astype(np.float32)
+        ib = (1 / (np.exp(g.standard_normal(N) * 0.3) + 1e-9)).astype(np.float32)
+        ea16 = np.exp(g.standard_normal(N) * 0.3).astype(np.float32)
+        ib16 = (1 / (np.exp(g.standard_normal(N) * 0.3) + 1e-9)).astype(np.float32)
+        want = _gemm_tap_ref(Av[:, :K], T, Wv, shift, bias, None, res, ea, ib, act)
+        want16 = want + ib16 * np.sin(want * ea16) ** 2 if s16 else want
+        out = np.full((M, N + 8), 7.0, np.float32)
+        out16 = np.full((M, N + 8), 0x4242, np.uint16)
+        sh = (C.c_int32 * len(shift))(*shift)
+        rc = emu.hostemu_gemm_tap16(Abits.ctypes.data_as(C.c_void_p), K + 8, M, T, _ptr(Wbits), N, K, len(shift), sh,
+                                    _ptr(bias) if hb else None, _ptr(res) if hr else None, N, _ptr(ea), _ptr(ib), act,
+                                    _ptr(out) if o32 else None, N + 8, out16.ctypes.data_as(C.c_void_p) if o16 else None,
+                                    _ptr(ea16) if s16 else None, _ptr(ib16) if s16 else None)
+        assert rc == 0, ((M, N, K, shift, act), (emu.qtts_last_error() or b"").decode())
+        tol = 2e-3 * max(1.0, float(np.abs(want).max()))
+        if o32:
+            assert np.abs(out[:, :N] - want).max() <= tol, (M, N, K, shift, act, float(np.abs(out[:, :N] - want).max()))
+            assert np.all(out[:, N:] == 7.0)
+        if o16:
+            got = (out16[:, :N].astype(np.uint32) << 16).view(np.float32)
+            assert np.abs(got - want16).max() <= 1e-2 * max(1.0, float(np.abs(want16).max())), (M, N, K, shift, float(np.abs(got - want16).max()))
+            assert np.all(out16[:, N:] == 0x4242)
 
 
 @pytest.mark.parametrize("bf16", [0, 1])
@@ -378,9 +423,10 @@ def codec(emu):
 
 
 def test_decoder_bf16_forward_and_stream(emu):
-    """The codec decoder in its serving precision (bf16 MFMA GEMMs, fp32 activations in memory) on the emulator: within
-    the GPU suite's 15 % relative RMS of the fp32 oracle on these random weights, and the state-carrying stream decode
-    reproduces the bf16 whole-sequence forward EXACTLY (per-row arithmetic does not depend on the staging)."""
+    """The codec decoder in its serving precision on the emulator (bf16 MFMA GEMMs; round 2: inside the decoder blocks the
+    GEMM-only activations travel as bf16 through the tap-reuse kernel, the residual stream stays fp32): within 8 % relative RMS
+    of the fp32 oracle on these random weights (measured 4.9 %, the same as with fp32 activations), and the state-carrying
+    stream decode -- which keeps fp32 activations between its layers -- stays within 3 % (measured 1.3 %) of the whole-sequence forward."""
     c, w, h = _codec_emu(emu, _lib.QTTS_BF16)
     try:
         T = 8
@@ -390,14 +436,15 @@ def test_decoder_bf16_forward_and_stream(emu):
         with real_gemm(emu):
             wav = np.zeros((1, T * c.total_upsample), np.float32)
             _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, T, _ptr(wav), None, None))
-            assert np.sqrt(((wav - ref) ** 2).mean()) <= 0.15 * np.sqrt((ref ** 2).mean())
+            assert np.sqrt(((wav - ref) ** 2).mean()) <= 0.08 * np.sqrt((ref ** 2).mean())
             _ok(emu, emu.qtts_codec_stream_begin(h, 1))
             outs = []
             for a, b in ((0, 1), (1, 4), (4, 5), (5, 8)):
                 o = np.zeros((1, (b - a) * c.total_upsample), np.float32)
                 _ok(emu, emu.qtts_codec_stream_push(h, _ptr(np.ascontiguousarray(codes[..., a:b])), b - a, _ptr(o), None))
                 outs.append(o)
-            assert np.array_equal(np.concatenate(outs, axis=1), wav)
+            st_wav = np.concatenate(outs, axis=1)
+            assert np.sqrt(((st_wav - wav) ** 2).mean()) <= 0.03 * np.sqrt((wav ** 2).mean())     # measured 1.3 %
     finally:
         emu.qtts_codec_destroy(h)
 
