@@ -31,63 +31,120 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_p
     return *reinterpret_cast<unsigned*>(&v);
 }
 
-// acc[i][j][r] = C[m0 + wm*64 + i*16 + lq*4 + r][n0 + wn*BN/2 + j*16 + li]
-template <int BN, int TM, int TN>
+// MFMA roles are swapped w.r.t. the textbook (A operand = the W fragment, B operand = the activation fragment; both have the same
+// lane layout, so the swap is free): a lane then holds FOUR CONSECUTIVE output columns of one output row,
+//     acc[i][j][r] = C[m0 + wm*64 + i*16 + li][n0 + wn*BN/2 + j*16 + lq*4 + r],
+// and the epilogue moves 16-byte vectors: all residual / bias / parameter vectors of a lane are requested first (one latency
+// round instead of one dependent round trip per element -- round 1's epilogue was a chain of 64 scalar load -> store pairs per
+// lane and dominated the small-channel convolutions), then the activations run, then the stores go out.
+// SnakeBeta y = v + ib * sin^2(v * ea).  FAST (bf16 mode): v_sin_f32 (input in revolutions) -- the result is rounded to bf16 or
+// carries bf16-level noise anyway, and the library sinf (~60 instructions with its range reduction) would cost more than the
+// MFMAs of a small-channel convolution tile; the exact-fp32 parity mode keeps sinf.
+template <bool FAST>
+__device__ __forceinline__ float snake1(float v, float ea, float ib) {
+    float sn;
+    if constexpr (FAST) sn = __builtin_amdgcn_sinf(v * ea * 0.15915494309189535f); else sn = sinf(v * ea);
+    return v + ib * (sn * sn);
+}
+
+template <int BN, int TM, int TN, bool FAST>
 __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                              int li, int lq) {
     if (p.act == ACT_SWIGLU) {
-        // W rows come in 16-row blocks alternating gate / up for the same 16 features, so tiles
-        // (j, j+1) of one wave hold gate/up of the same output columns in the same lane/register.
+        // W rows come in 16-row blocks alternating gate / up for the same 16 features, so tiles (j, j+1) of one wave hold
+        // gate / up of the same output columns in the same lane / register.
         if constexpr (TN % 2 == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * 64 + i * 16 + li;
 #pragma unroll
                 for (int j = 0; j < TN; j += 2) {
-                    const int n_packed = n0 + wn * (BN / 2) + j * 16 + li;
-                    const int no = (n_packed / 32) * 16 + li;
+                    const int n_packed = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+                    const int no = (n_packed / 32) * 16 + lq * 4;
+                    if (m < p.M && n_packed < p.N) {
+                        f32x4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
-                        if (m < p.M && n_packed < p.N) {
-                            const float g = acc[i][j][r], u = acc[i][j + 1][r];
-                            p.C[(size_t)m * p.ldc + no] = (g / (1.f + expf(-g))) * u;
-                        }
+                        for (int r = 0; r < 4; ++r) { const float g = acc[i][j][r], u = acc[i][j + 1][r]; o[r] = (g / (1.f + expf(-g))) * u; }
+                        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + no) = o;
                     }
                 }
+            }
         }
         return;
     }
+    if (!p.vec4) {                       // ragged N or unaligned views (e.g. the speaker encoder's 1026-column DFT): element by element
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + li;
-            if (n >= p.N) continue;
-            const float bias = p.bias ? p.bias[n] : 0.f;
-            const float scale = p.scale ? p.scale[n] : 1.f;
-            float ea = 0.f, ib = 0.f, ea16 = 0.f, ib16 = 0.f;
-            if (p.act == ACT_SNAKE) { ea = p.snake_ea[n]; ib = p.snake_ib[n]; }
-            if (p.C16 && p.act16 == ACT_SNAKE) {
-                const int n16 = p.snake16_period > 0 ? n % p.snake16_period : n;
-                ea16 = p.snake16_ea[n16]; ib16 = p.snake16_ib[n16];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + lq * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-                else if (p.act == ACT_SNAKE) { const float sn = sinf(v * ea); v = v + ib * (sn * sn); }
-                else if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
-                v *= scale;
-                if (p.res) v += p.res[(size_t)m * p.ldr + n];
-                if (p.C) p.C[(size_t)m * p.ldc + n] = v;
-                if (p.C16) {               // bf16 copy for a GEMM consumer, with that consumer's SnakeBeta folded in
-                    if (p.act16 == ACT_SNAKE) { const float sn = sinf(v * ea16); v = v + ib16 * (sn * sn); }
-                    reinterpret_cast<bf16_t*>(p.C16)[(size_t)m * p.ldc16 + n] = f32_to_bf16(v);
+            for (int j = 0; j < TN; ++j) {
+                const int m = m0 + wm * 64 + i * 16 + li;
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4 + r;
+                    if (m >= p.M || n >= p.N) continue;
+                    float v = acc[i][j][r] + (p.bias ? p.bias[n] : 0.f);
+                    if (p.act == ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                    else if (p.act == ACT_SNAKE) v = snake1<FAST>(v, p.snake_ea[n], p.snake_ib[n]);
+                    else if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
+                    v *= p.scale ? p.scale[n] : 1.f;
+                    if (p.res) v += p.res[(size_t)m * p.ldr + n];
+                    if (p.C) p.C[(size_t)m * p.ldc + n] = v;
+                    if (p.C16) {
+                        if (p.act16 == ACT_SNAKE) { const int n16 = p.snake16_period > 0 ? n % p.snake16_period : n; v = snake1<FAST>(v, p.snake16_ea[n16], p.snake16_ib[n16]); }
+                        reinterpret_cast<bf16_t*>(p.C16)[(size_t)m * p.ldc16 + n] = f32_to_bf16(v);
+                    }
                 }
             }
+        return;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {                                   // one column quad of this lane at a time
+        const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
+        if (n >= p.N) continue;                                      // (N % 4 == 0: a quad is in or out as a whole)
+        // everything this quad needs from memory is requested first: parameters, then the TM residual vectors
+        const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+        const f32x4 scale = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : one4;
+        f32x4 ea = zero4, ib = zero4, ea16 = zero4, ib16 = zero4;
+        if (p.act == ACT_SNAKE) { ea = *reinterpret_cast<const f32x4*>(p.snake_ea + n); ib = *reinterpret_cast<const f32x4*>(p.snake_ib + n); }
+        if (p.C16 && p.act16 == ACT_SNAKE) {
+            const int n16 = p.snake16_period > 0 ? n % p.snake16_period : n;       // (period % 4 == 0)
+            ea16 = *reinterpret_cast<const f32x4*>(p.snake16_ea + n16); ib16 = *reinterpret_cast<const f32x4*>(p.snake16_ib + n16);
         }
+        f32x4 res[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + li;
+            res[i] = (p.res && m < p.M) ? *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + li;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + bias;
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752440f));
+            } else if (p.act == ACT_SNAKE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = snake1<FAST>(v[r], ea[r], ib[r]);
+            } else if (p.act == ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + expf(-v[r]));
+            }
+            v = v * scale + res[i];
+            if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            if (p.C16) {               // bf16 copy for a GEMM consumer, with that consumer's SnakeBeta folded in
+                if (p.act16 == ACT_SNAKE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = snake1<FAST>(v[r], ea16[r], ib16[r]);
+                }
+                uint2 h;
+                h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C16) + (size_t)m * p.ldc16 + n) = h;
+            }
+        }
+    }
 }
 
 template <int BN, bool BF16>
@@ -218,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -235,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -245,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
         }
     }
 
-    tap_epilogue<BN, TM, TN>(p, acc, m0, n0, wm, wn, li, lq);
+    tap_epilogue<BN, TM, TN, BF16>(p, acc, m0, n0, wm, wn, li, lq);
 }
 
 // ---- wide-K variant for SMALL grids (talker prefill, text projection): bf16, 1 tap, BK = 128.
@@ -335,7 +392,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (s + 1 < nsteps) {
@@ -343,7 +400,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
             __syncthreads();
         }
     }
-    tap_epilogue<BN, TM, TN>(p, acc, m0, n0, wm, wn, li, lq);
+    tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);
 }
 
 // ---- round 2: the codec decoder's GEMM in bf16 mode (gemm_tap2).  What the round-1 kernel above spent its time on
@@ -362,15 +419,15 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
 //     the activated copy goes out as bf16 (C16), and the stand-alone snake passes disappear from the decoder blocks.
 // Tile 128 x BN, 4 waves (2 x 2), each wave 64 x BN/2 as 4 x BN/32 MFMA 16x16x32 tiles per 32 of k.
 template <int BN, int BK>
-__global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int halo) {
+__global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int halo, int cap /* rows of one A buffer: 128 + halo, rounded up */) {
     constexpr int BM = 128;
     constexpr int TM = 4, TN = BN / 32;
     constexpr int STR = BK + 8;                        // LDS row stride (bf16 elements): 16-B aligned, rows shift by 4 banks
     constexpr int CPR = BK / 8;                        // 16-B chunks per row
     constexpr int MAXROWS = BM + 56;                   // 7 taps x dilation 9 -> halo 54
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t2[];
-    bf16_t* As = reinterpret_cast<bf16_t*>(smem_t2);                       // [2][MAXROWS][STR]
-    bf16_t* Ws = As + 2 * MAXROWS * STR;                                   // [2][BN][STR]
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem_t2);                       // [2][cap][STR]  (LDS is sized for the actual halo:
+    bf16_t* Ws = As + 2 * cap * STR;                                       // [2][BN][STR]    occupancy 2-3 workgroups per CU)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -416,7 +473,7 @@ __global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int hal
         }
     };
     auto store_a = [&](int buf) {
-        bf16_t* dst = As + buf * MAXROWS * STR;
+        bf16_t* dst = As + buf * cap * STR;
 #pragma unroll
         for (int i = 0; i < AREG; ++i) {
             const int idx = tid + 256 * i;
@@ -456,7 +513,7 @@ __global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int hal
         if (more) load_w(ks2, tap2);                   // global loads stay in flight under the MFMAs
         if (new_slab) load_a(ks2);
         {
-            const bf16_t* Ab = As + (ks & 1) * MAXROWS * STR;
+            const bf16_t* Ab = As + (ks & 1) * cap * STR;
             const bf16_t* Wb = Ws + (s & 1) * BN * STR;
             const int sh = p.shift[tap];               // <= 0: output row m reads staged row (m - m0) + halo + sh
 #pragma unroll
@@ -474,7 +531,7 @@ __global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int hal
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
         if (more) {                                    // the other buffers were last read one step (W) / one slab (A) ago
@@ -483,13 +540,14 @@ __global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int hal
         }
         __syncthreads();
     }
-    tap_epilogue<BN, TM, TN>(p, acc, m0, n0, wm, wn, li, lq);
+    tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);
 }
 
 template <int BN, int BK>
 static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
     const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
-    const size_t lds = ((size_t)2 * (128 + 56) + 2 * BN) * (BK + 8) * 2;
+    const int cap = (128 + halo + 7) & ~7;
+    const size_t lds = ((size_t)2 * cap + 2 * BN) * (BK + 8) * 2;
     auto kern = gemm_tap2_kernel<BN, BK>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -497,7 +555,7 @@ static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
                                            160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo, cap);
 }
 
 template <int BN>
@@ -520,11 +578,18 @@ static void launch_t(const GemmTapParams& p, hipStream_t st) {
     hipLaunchKernelGGL((gemm_tap_kernel<BN, BF16>), dim3(nb), dim3(256), 0, st, p);
 }
 
-void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st) {
+void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
+    GemmTapParams p = p_in;
     QTTS_REQUIRE(p.K % 32 == 0, QTTS_ERR_ARG, "gemm_tap: K must be a multiple of 32");
     QTTS_REQUIRE(p.taps >= 1 && p.taps <= 8, QTTS_ERR_ARG, "gemm_tap: 1..8 taps");
     QTTS_REQUIRE(p.M > 0 && p.N > 0, QTTS_ERR_ARG, "gemm_tap: empty problem");
     QTTS_REQUIRE(p.lda % 4 == 0, QTTS_ERR_ARG, "gemm_tap: lda must be a multiple of 4");
+    // the epilogue moves 4-column vectors (16 B fp32 / 8 B bf16) whenever shapes and pointers allow it
+    auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+    p.vec4 = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.res || p.ldr % 4 == 0) && (!p.C16 || (p.ldc16 % 4 == 0 && reinterpret_cast<uintptr_t>(p.C16) % 8 == 0)) &&
+             al16(p.C) && al16(p.res) && al16(p.bias) && al16(p.scale) && al16(p.snake_ea) && al16(p.snake_ib) && al16(p.snake16_ea) &&
+             al16(p.snake16_ib) && (p.snake16_period % 4 == 0);
+    if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.ldc % 4 == 0 && al16(p.C), QTTS_ERR_ARG, "gemm_tap: swiglu output must be 16-byte aligned with ldc % 4 == 0");
     if (p.A16) {                           // bf16 activations: the tap-reuse kernel (bf16 mode only)
         QTTS_REQUIRE(bf16, QTTS_ERR_ARG, "gemm_tap: A16 needs bf16 weights");
         QTTS_REQUIRE(p.act != ACT_SWIGLU, QTTS_ERR_ARG, "gemm_tap: the A16 kernel has no SwiGLU epilogue");
@@ -534,7 +599,9 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st) {
         for (int i = 0; i < p.taps; ++i) { QTTS_REQUIRE(p.shift[i] <= 0, QTTS_ERR_ARG, "gemm_tap: shift > 0"); halo = std::max(halo, -p.shift[i]); }
         QTTS_REQUIRE(halo <= 56, QTTS_ERR_LIMIT, "gemm_tap: tap reach > 56 rows");
         const int bn2 = (p.N % 128 == 0) ? 128 : (p.N % 96 == 0 ? 96 : (p.N <= 64 ? 64 : 128));
-        if (p.K % 64 == 0) { if (bn2 == 128) launch_tap2<128, 64>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 64>(p, halo, st); else launch_tap2<64, 64>(p, halo, st); }
+        static const int bk_env = [] { const char* e = getenv("QTTS_TAP2_BK"); return e ? atoi(e) : 0; }();   // (A/B: force BK = 32)
+        if (bk_env == 32) { if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st); }
+        else if (p.K % 64 == 0) { if (bn2 == 128) launch_tap2<128, 64>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 64>(p, halo, st); else launch_tap2<64, 64>(p, halo, st); }
         else if (p.K % 96 == 0) { if (bn2 == 128) launch_tap2<128, 96>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 96>(p, halo, st); else launch_tap2<64, 96>(p, halo, st); }
         else { if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st); }   // (small test dims)
         QTTS_CHECK_HIP(hipGetLastError());

@@ -28,6 +28,7 @@ struct GemmTapParams {
     int act16;                   // ACT_NONE | ACT_SNAKE (with snake16_*): the NEXT consumer's SnakeBeta folded into this epilogue
     const float* snake16_ea; const float* snake16_ib;
     int snake16_period;          // > 0: the act16 parameters repeat with this period over the N columns (transposed conv: N = r * Cout)
+    int vec4;                    // set by launch_gemm_tap: N / leading dimensions / pointers allow 4-column vector epilogue accesses
 };
 void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
 

@@ -532,6 +532,65 @@ def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
     assert (a[..., 1:] < t.cp_vocab_size).all() and (a >= 0).all()
 
 
+def test_code_predictor_sampling_distribution_matches_hf(talker_tiny, dev):
+    """15 of the 16 tokens of a frame are sampled inside the code predictor (`subtalker_dosample`, M:1671-1680): with the talker
+    head greedy, the empirical distribution of frame 0's first sub-code over many Philox seeds must match the oracle's processed
+    softmax of the pass-0 logits (chi-square, support exactly HF's top-k), and -- conditional on the most frequent first
+    sub-code of each row -- so must the SECOND sub-code (pass 1: a different lm_head, the projected-embedding / q|k|v tables
+    gathered by the previous pass's sampler)."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    t, w, g = talker_tiny
+    eng = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=4, max_seq=64, use_graph=False)
+    args = [torch.from_numpy(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
+    N, K, TEMP = int(os.environ.get("QTTS_TEST_CP_SAMPLES", "600")), 8, 0.8
+    codes = np.zeros((N, 3, 2), np.int64)
+    for s in range(N):
+        out = eng.generate(*args, max_new_tokens=2, min_new_tokens=2, do_sample=False, subtalker_dosample=True, subtalker_top_k=K,
+                           subtalker_top_p=1.0, subtalker_temperature=TEMP, suppress_tokens=_suppress(t), seed=s)
+        codes[s] = out.codes.cpu().numpy()[:, 0, 1:3]
+    v0 = np.array([np.bincount(codes[:, b, 0]).argmax() for b in range(3)])
+    # the oracle's logits of pass 0, and of pass 1 given v0 (its `pick` is told to return v0 for the first sampled call)
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=True, subtalker_top_k=K, subtalker_top_p=1.0,
+                                   subtalker_temperature=TEMP)
+    trace, calls, orig_pick = {}, [0], talker_ref.pick
+
+    def forced_pick(scores, do_sample, generator=None):
+        if do_sample:
+            calls[0] += 1
+            if calls[0] == 1:
+                return torch.from_numpy(v0)
+        return orig_pick(scores, do_sample, generator)
+    talker_ref.pick = forced_pick
+    try:
+        with torch.no_grad():
+            talker_ref.talker_generate(w, t, *args, max_new_tokens=2, min_new_tokens=2, sp=sp, trace=trace,
+                                       generator=torch.Generator().manual_seed(0))
+    finally:
+        talker_ref.pick = orig_pick
+
+    def check(obs, logits, what):
+        sc = talker_ref.process_logits(logits[None], torch.zeros(1, 0, dtype=torch.long), do_sample=True, temperature=TEMP,
+                                       top_k=K, top_p=1.0)
+        p = torch.softmax(sc, -1).numpy()[0]
+        counts = np.bincount(obs, minlength=p.shape[0]).astype(np.float64)
+        assert (counts[p == 0] == 0).all(), f"{what}: sampled outside HF's top-k support"
+        sup = p > 0
+        assert sup.sum() == K
+        e, o = len(obs) * p[sup], counts[sup]
+        small = e < 5.0
+        if small.sum() > 1:
+            e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
+        chi2 = float((((o - e) ** 2) / e).sum())
+        assert chi2 < 30.0, f"{what}: chi-square {chi2:.1f} with {len(e) - 1} dof over {len(obs)} draws"
+        return chi2
+    for b in range(3):
+        c0 = check(codes[:, b, 0], trace["cp_logits"][0][b], f"row {b} sub-code 0")
+        sel = codes[:, b, 0] == v0[b]
+        assert sel.sum() >= 60
+        c1 = check(codes[sel, b, 1], trace["cp_logits"][1][b], f"row {b} sub-code 1 | sub-code 0 = {v0[b]}")
+        print(f"code-predictor sampling row {b}: chi2 {c0:.1f} (sub-code 0, {N} draws), {c1:.1f} (sub-code 1 | {v0[b]}, {int(sel.sum())} draws)")
+
+
 def test_prompt_assembly_and_generate_vs_reference_golden(dev, golden_dir):
     """Seam S1: Qwen3TTSForConditionalGeneration.generate -- prompt assembly (incl. the HIP text_projection) against
     what the reference's generate() hands to talker.generate, then the full generate against the oracle."""
