@@ -760,12 +760,16 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         }
     };
 
+    // split-KV: workgroup y of gridDim.y handles the chunks [c0s, cend_static) of the (static) key capacity
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int cps = ((p.max_len + 16 * CH - 1) / (16 * CH) + nsplit - 1) / nsplit;     // chunks per split
+    const int c0s = split * cps, cend_static = c0s + cps;
     // ---- 0. loads that do not depend on this step's qkv row or on the length: the first K and V chunk(s)
     u32x4 kR[NPRE][CH][KW], vR[NPRE][CH][KW];
-    load_chunk(kR[0], kc, 0);
-    load_chunk(vR[0], vc, 0);
-    const bool deep = p.max_len > 64;
-    if (deep) { load_chunk(kR[1], kc, 1); load_chunk(vR[1], vc, 1); }
+    load_chunk(kR[0], kc, c0s);
+    load_chunk(vR[0], vc, c0s);
+    const bool deep = p.max_len > 64 && cps > 1;
+    if (deep) { load_chunk(kR[1], kc, c0s + 1); load_chunk(vR[1], vc, c0s + 1); }
     // this step's row: EVERY wave fetches the GQ query heads, k and v of the new token (lane <- dims lane, lane + 64)
     float x0v[GQ + 2], x1v[GQ + 2];
 #pragma unroll
@@ -778,10 +782,10 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     const int npad = p.n_pad ? p.n_pad[b] : 0;
     const int done = p.done_flag ? *p.done_flag : 0;
     const int S1 = S0 + 1;                                  // total keys
-    const int nchunk = (S0 + 16 * CH - 1) / (16 * CH);      // chunks of CACHED keys (the new key is handled from LDS)
+    const int nchunk = min(cend_static, (S0 + 16 * CH - 1) / (16 * CH));   // chunks of CACHED keys of this split (the new key comes from LDS)
 #pragma unroll
     for (int c = 1; c < NPRE; ++c)
-        if (c < nchunk && !(deep && c == 1)) { load_chunk(kR[c], kc, c); load_chunk(vR[c], vc, c); }
+        if (c0s + c < nchunk && !(deep && c == 1)) { load_chunk(kR[c], kc, c0s + c); load_chunk(vR[c], vc, c0s + c); }
     if (done) return;
 
     // ---- 1. q / k RMSNorm + RoPE of the new token, per wave; K / V append by wave 0 (rounded through the cache type: every
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         }
         if (vi >= GQ) {
             const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
-            if (wave == 0) {
+            if (wave == 0 && split == 0) {
                 const int page = p.kv.contig ? b * p.kv.pages_per_seq + (S0 >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (S0 >> 4)];
                 const size_t o = ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (S0 & 15)) * HD;
                 KVT* cdst = reinterpret_cast<KVT*>(vi == GQ ? p.kv.k : p.kv.v);
@@ -884,8 +888,8 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     };
 #pragma unroll
     for (int c = 0; c < NPRE; ++c)
-        if (c < nchunk) process(kR[c], vR[c], c);
-    for (int c0 = NPRE; c0 < nchunk; c0 += NPRE) {          // long sequences: NPRE chunks of K AND V per latency round
+        if (c0s + c < nchunk) process(kR[c], vR[c], c0s + c);
+    for (int c0 = c0s + NPRE; c0 < nchunk; c0 += NPRE) {    // long sequences: NPRE chunks of K AND V per latency round
 #pragma unroll
         for (int j = 0; j < NPRE; ++j)
             if (c0 + j < nchunk) { load_chunk(kR[j], kc, c0 + j); load_chunk(vR[j], vc, c0 + j); }
@@ -893,7 +897,8 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         for (int j = 0; j < NPRE; ++j)
             if (c0 + j < nchunk) process(kR[j], vR[j], c0 + j);
     }
-    if (g == (S0 & 15) && S0 >= npad) {                     // the new key (position S0): k, v from this wave's LDS slice
+    const int split_new = min(nsplit - 1, (S0 / (16 * CH)) / cps);      // the split whose key range holds position S0
+    if (split == split_new && g == (S0 & 15) && S0 >= npad) {   // the new key (position S0): k, v from this wave's LDS slice
         float d[CH][GQ], vx[CH][8];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -935,11 +940,43 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
             num += red[gg][qi][dd] * f;
             den += gl[gg][qi] * f;
         }
+        if (nsplit > 1) {                                    // partial result of this split: numerator | max | denominator
+            float* pp = p.part + (((size_t)blockIdx.x * nsplit + split) * GQ + qi) * (HD + 2);
+            pp[dd] = num;
+            if (dd == 0) { pp[HD] = mm; pp[HD + 1] = den; }
+            return;
+        }
         const size_t o = (size_t)b * p.ldo + (kvh * GQ + qi) * HD + dd;
         const float r = num / den;
         if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(r);
         else p.out[o] = r;
     }
+}
+
+// merge of the split-KV partial results (fixed order): out = sum_s num_s e^(m_s - m) / sum_s den_s e^(m_s - m)
+template <int GQ>
+__global__ __launch_bounds__(256) void attn_merge_kernel(AttnDecodeParams p) {
+    constexpr int HD = 128;
+    if (p.done_flag && *p.done_flag) return;
+    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
+    const int tid = threadIdx.x;
+    if (tid >= GQ * HD) return;
+    const int qi = tid / HD, dd = tid % HD;
+    const float* base = p.part + ((size_t)blockIdx.x * p.nsplit * GQ + qi) * (HD + 2);
+    const size_t stride = (size_t)GQ * (HD + 2);
+    float mm = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) mm = fmaxf(mm, base[s * stride + HD]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float ms = base[s * stride + HD];
+        const float f = ms > -INFINITY ? expf(ms - mm) : 0.f;
+        num += base[s * stride + dd] * f;
+        den += base[s * stride + HD + 1] * f;
+    }
+    const size_t o = (size_t)b * p.ldo + (kvh * GQ + qi) * HD + dd;
+    const float r = num / den;
+    if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(r);
+    else p.out[o] = r;
 }
 
 template <typename KVT, int NQ>
@@ -971,10 +1008,17 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
         return;
     }
     if (p.n_new == 1 && GQ <= 2) {            // the talker's single-token step: any length, any padding (attn_tk above)
-        if (p.kv.bf16) { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 1>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
-                         else hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 2>), dim3(p.B * p.nkv), dim3(256), 0, st, p); }
-        else { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<float, 1>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
-               else hipLaunchKernelGGL((attn_tk_kernel<float, 2>), dim3(p.B * p.nkv), dim3(256), 0, st, p); }
+        const int ns = p.nsplit > 1 ? p.nsplit : 1;
+        QTTS_REQUIRE(ns == 1 || p.part, QTTS_ERR_ARG, "attn_decode: split-KV needs the partial-result buffer");
+        const dim3 grid(p.B * p.nkv, ns);
+        if (p.kv.bf16) { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 1>), grid, dim3(256), 0, st, p);
+                         else hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 2>), grid, dim3(256), 0, st, p); }
+        else { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<float, 1>), grid, dim3(256), 0, st, p);
+               else hipLaunchKernelGGL((attn_tk_kernel<float, 2>), grid, dim3(256), 0, st, p); }
+        if (ns > 1) {
+            if (GQ == 1) hipLaunchKernelGGL((attn_merge_kernel<1>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_merge_kernel<2>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        }
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
 //     VGPRs into a single LDS buffer with two barriers per 32-wide k-step;
 //   * SnakeBeta ran as its own full read + write pass in front of every conv.
 // Here:
-//   * TAP REUSE: per 64- (or 96-) wide k-slab the input tile is staged ONCE, with its causal halo (128 + max|shift| rows),
+//   * TAP REUSE: per 32-wide k-slab the input tile is staged ONCE, with its causal halo (128 + max|shift| rows),
 //     and all taps of that slab run from LDS with a row offset; a row that would come from before the start of its sequence is
 //     zeroed in the operand registers (a tile may span two sequences, so this cannot be decided at staging time);
 //   * bf16 activations in HBM wherever a tensor is only a GEMM input (A16 / C16): half the bytes, no conversion on the way in;
@@ -599,11 +599,9 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         for (int i = 0; i < p.taps; ++i) { QTTS_REQUIRE(p.shift[i] <= 0, QTTS_ERR_ARG, "gemm_tap: shift > 0"); halo = std::max(halo, -p.shift[i]); }
         QTTS_REQUIRE(halo <= 56, QTTS_ERR_LIMIT, "gemm_tap: tap reach > 56 rows");
         const int bn2 = (p.N % 128 == 0) ? 128 : (p.N % 96 == 0 ? 96 : (p.N <= 64 ? 64 : 128));
-        static const int bk_env = [] { const char* e = getenv("QTTS_TAP2_BK"); return e ? atoi(e) : 0; }();   // (A/B: force BK = 32)
-        if (bk_env == 32) { if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st); }
-        else if (p.K % 64 == 0) { if (bn2 == 128) launch_tap2<128, 64>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 64>(p, halo, st); else launch_tap2<64, 64>(p, halo, st); }
-        else if (p.K % 96 == 0) { if (bn2 == 128) launch_tap2<128, 96>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 96>(p, halo, st); else launch_tap2<64, 96>(p, halo, st); }
-        else { if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st); }   // (small test dims)
+        // k-slab of 32: measured 7 % faster than 64 / 96 on the codec (14.8 vs 15.95 ms per 8 x 10 s,
+        // profiles/r02_config2_codec_tap2*.json) -- the smaller LDS footprint (<= 50 KB) keeps 3 workgroups per CU resident
+        if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st);
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }

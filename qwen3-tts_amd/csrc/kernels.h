@@ -168,8 +168,12 @@ struct AttnDecodeParams {
     int out_bf16;                // 1: write bf16 (consumed by an x_bf16 GEMM)
     int max_len;                 // LDS score capacity
     const int* done_flag;
+    // split-KV (talker, long sequences): nsplit > 1 workgroups per (sequence, kv head), each over max_len / nsplit keys, partial
+    // results in `part` [B*nkv][nsplit][GQ][128 + 2] fp32 (numerator | max | denominator), merged by a second tiny kernel
+    int nsplit; float* part;
 };
 void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st);
+inline size_t attn_part_floats(int B, int nkv, int nsplit, int gq) { return (size_t)B * nkv * nsplit * gq * 130; }
 
 // --------------------------------------------------------------------------------- sampling.hip
 struct SampleParams {

@@ -53,7 +53,8 @@ struct qtts_talker {
     double weight_bytes_frame = 0;
 
     // KV caches
-    DevBuf kpool_t, vpool_t, kpool_c, vpool_c, ptab_t, ptab_c;
+    DevBuf kpool_t, vpool_t, kpool_c, vpool_c, ptab_t, ptab_c, attn_part;
+    int attn_nsplit = 1;               // talker decode attention: workgroups per (sequence, kv head); > 1 when max_seq > 512
     KvCache kv_t, kv_c;
     // decode state / scratch
     DevBuf x, qkv, att, act, logits, past_hidden, cp_in, cp_x, cp_qkv, cp_att, cp_act, cp_logits, x16, cp_x16, ph16, cp_in16;
@@ -130,8 +131,9 @@ struct qtts_talker {
     }
     // Narrow strips when the GEMM would otherwise launch too few workgroups to pull its weights (bf16 kernel only).  Every
     // workgroup re-reads the whole x (M x K bf16) through its XCD's L2, so MORE workgroups also cost more (round-2 sweep,
-    // profiles/r02_skinny_sweep_fs_M_temporal.txt); QTTS_FS_MIN_WGS (default 192) sets the floor for A/B runs.
-    int fs_min_wgs = [] { const char* e = getenv("QTTS_FS_MIN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 192; }();
+    // profiles/r02_skinny_sweep_fs_M_temporal.txt).  Floor of 96 workgroups: measured 1.2 % faster per frame than 192 and than 48
+    // (profiles/r02_ab_inproc_fs_floor.txt); QTTS_FS_MIN_WGS overrides it for A/B runs.
+    int fs_min_wgs = [] { const char* e = getenv("QTTS_FS_MIN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
     int choose_fs(int N, int K) const {
         (void)K;
         if (!bf16) return 16;
@@ -212,6 +214,7 @@ struct qtts_talker {
         a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
         a.len_dev = len_dev; a.len_static = len_static; a.kv = kv; a.layer = layer; a.out = attb; a.ldo = d.qd;
         a.max_len = max_len; a.done_flag = ss.done;
+        if (len_dev && attn_nsplit > 1) { a.nsplit = attn_nsplit; a.part = attn_part.as<float>(); }   // talker, long sequences: split-KV
         // bf16 mode: attention output and SwiGLU output travel as bf16 (as in the reference's bf16 path) and are
         // staged into the consuming GEMM by LDS-DMA
         const bool att16 = bf16 && skinny_takes_bf16_x(M, d.qd, true), act16 = bf16 && skinny_takes_bf16_x(M, d.I, true);
@@ -357,6 +360,11 @@ void qtts_talker::finalize() {
         for (size_t i = 0; i < u.size(); ++i) u[i] = (int)i;
         ptab_t.upload(t.data(), t.size() * 4); ptab_c.upload(u.data(), u.size() * 4);
     }
+    // a sequence that can grow past 512 keys is read by several workgroups per (sequence, kv head): one CU pulls ~25 GB/s, and a
+    // 60 s utterance has 0.4 MB of K / V per head and layer (measured 52 us per layer at 800 keys with one workgroup)
+    if (const char* e = getenv("QTTS_ATTN_NSPLIT")) attn_nsplit = std::max(1, std::min(16, atoi(e)));
+    else attn_nsplit = c.max_seq > 512 ? std::min(8, cdiv(c.max_seq, 256)) : 1;
+    if (attn_nsplit > 1) attn_part.alloc(attn_part_floats(c.max_batch, td.nkv, attn_nsplit, td.nh / td.nkv) * sizeof(float));
     kv_t.k = kpool_t.p; kv_t.v = vpool_t.p; kv_t.page_table = ptab_t.as<int>();
     kv_c.k = kpool_c.p; kv_c.v = vpool_c.p; kv_c.page_table = ptab_c.as<int>();
 

@@ -115,6 +115,14 @@ extern "C" int hostemu_attn_decode(const float* qkv, int ld, int B, int n_new, i
         p.kv.k = kpool; p.kv.v = vpool; p.kv.page_table = page_table; p.kv.pages_per_seq = pages_per_seq;
         p.kv.n_pages = B * pages_per_seq; p.kv.nkv = nkv; p.kv.hd = 128; p.kv.bf16 = bf16; p.kv.contig = page_table ? 0 : 1;
         p.layer = 0; p.out = out; p.ldo = ldo; p.out_bf16 = 0; p.max_len = max_len; p.done_flag = nullptr;
+        std::vector<float> part;
+        if (const char* e = getenv("QTTS_DEBUG_ATTN_NSPLIT")) {      // split-KV variant of the talker call shape
+            if (atoi(e) > 1 && n_new == 1 && p.len_dev) {
+                p.nsplit = atoi(e);
+                part.assign(qtts::attn_part_floats(B, nkv, p.nsplit, nh / nkv), NAN);
+                p.part = part.data();
+            }
+        }
         qtts::launch_attn_decode(p, nullptr);
         return 0;
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }

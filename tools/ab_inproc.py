@@ -14,8 +14,7 @@ from qwen3_tts_amd.talker import TalkerEngine
 
 CONFIGS = {
     "default": {},
-    "fs_min_wgs_96": {"QTTS_FS_MIN_WGS": "96"},
-    "fs_min_wgs_48": {"QTTS_FS_MIN_WGS": "48"},
+    "fs_min_wgs_192": {"QTTS_FS_MIN_WGS": "192"},
 }
 KEYS = sorted({k for c in CONFIGS.values() for k in c})
 
