@@ -214,7 +214,7 @@ struct qtts_talker {
         a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
         a.len_dev = len_dev; a.len_static = len_static; a.kv = kv; a.layer = layer; a.out = attb; a.ldo = d.qd;
         a.max_len = max_len; a.done_flag = ss.done;
-        if (len_dev && attn_nsplit > 1) { a.nsplit = attn_nsplit; a.part = attn_part.as<float>(); }   // talker, long sequences: split-KV
+        if (len_dev && attn_nsplit_active > 1) { a.nsplit = attn_nsplit_active; a.part = attn_part.as<float>(); }   // talker, long sequences: split-KV
         // bf16 mode: attention output and SwiGLU output travel as bf16 (as in the reference's bf16 path) and are
         // staged into the consuming GEMM by LDS-DMA
         const bool att16 = bf16 && skinny_takes_bf16_x(M, d.qd, true), act16 = bf16 && skinny_takes_bf16_x(M, d.I, true);
@@ -245,7 +245,41 @@ struct qtts_talker {
     void sample_talker(const qtts_sampling& sp, int eos, int min_new, int max_new, hipStream_t st);
     void frame_step(const qtts_sampling& sp, int eos, int min_new, int max_new, int64_t* codes, float* hidden,
                     int max_frames, hipStream_t st);
+    // Two captured frame graphs per configuration: the short-sequence one (one attention workgroup per (sequence, kv head)) and,
+    // for engines whose max_seq exceeds 512, the long-sequence one (split-KV attention + merge kernel, 28 more nodes): measured
+    // on MI355X the split costs +0.29 ms per frame at 100-200 keys and saves 0.9 ms at 800 (profiles/r02_long_utterance_*),
+    // so a generation switches graphs when its KV length passes SPLIT_FROM keys.
+    int SPLIT_FROM = [] { const char* e = getenv("QTTS_ATTN_SPLIT_FROM"); return e && atoi(e) > 0 ? atoi(e) : 320; }();   // (env: tests)
+    hipGraph_t graph_long = nullptr;
+    hipGraphExec_t graph_exec_long = nullptr;
+    int attn_nsplit_active = 1;        // what decode_layer launches (and what a capture in progress bakes in)
+    bool long_mode(int kv_len_after) const { return attn_nsplit > 1 && kv_len_after > SPLIT_FROM; }
+    // the captured graph for this mode, capturing `step` (which is NOT executed by the capture) on first use
+    template <class F>
+    hipGraphExec_t ensure_graph(bool lng, hipStream_t st, F&& step) {
+        hipGraph_t& g = lng ? graph_long : graph;
+        hipGraphExec_t& ge = lng ? graph_exec_long : graph_exec;
+        if (!ge) {
+            attn_nsplit_active = lng ? attn_nsplit : 1;
+            QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            try { step(); }
+            catch (...) {
+                hipGraph_t gx = nullptr;
+                (void)hipStreamEndCapture(st, &gx);
+                if (gx) (void)hipGraphDestroy(gx);
+                throw;
+            }
+            QTTS_CHECK_HIP(hipStreamEndCapture(st, &g));
+            size_t nn = 0;
+            QTTS_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
+            graph_nodes = (int)nn;
+            QTTS_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        }
+        return ge;
+    }
     void destroy_graph() {
+        if (graph_exec_long) { (void)hipGraphExecDestroy(graph_exec_long); graph_exec_long = nullptr; }
+        if (graph_long) { (void)hipGraphDestroy(graph_long); graph_long = nullptr; }
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
         if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
     }
@@ -785,31 +819,18 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
             break;
         }
         if (!use_graph || (f == 0 && !t->graph_exec)) {      // (a capture does not execute: frame 0 runs eagerly once)
+            t->attn_nsplit_active = t->long_mode(t->T0 + f + 1) ? t->attn_nsplit : 1;
             t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st);
             ++f;
             if (!use_graph && (f % 8 == 0)) poll();
             if (use_graph) poll();
             continue;
         }
-        if (!t->graph_exec) {   // capture frame step #1 (not executed by the capture), then replay it
-            QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            try {
-                t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st);
-            } catch (...) {
-                hipGraph_t g = nullptr;
-                (void)hipStreamEndCapture(st, &g);
-                if (g) (void)hipGraphDestroy(g);
-                throw;
-            }
-            QTTS_CHECK_HIP(hipStreamEndCapture(st, &t->graph));
-            size_t nn = 0;
-            QTTS_CHECK_HIP(hipGraphGetNodes(t->graph, nullptr, &nn));
-            t->graph_nodes = (int)nn;
-            QTTS_CHECK_HIP(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
-            t->graph_key = key;
-        }
         const int burst = std::min(8, total - f);
-        for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(t->graph_exec, st));
+        hipGraphExec_t ge = t->ensure_graph(t->long_mode(t->T0 + f + burst), st, [&] {
+            t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st); });
+        t->graph_key = key;
+        for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(ge, st));
         f += burst;
         poll();
     }
@@ -846,29 +867,16 @@ static void stream_launch_frames(qtts_talker* t, int n, hipStream_t st) {
     int left = std::min(n, total - g.launched);
     while (!g.done && left > 0) {
         if (!use_graph || (g.launched == 0 && !t->graph_exec)) {      // (a capture does not execute: the first frame runs eagerly once)
+            t->attn_nsplit_active = t->long_mode(t->T0 + g.launched + 1) ? t->attn_nsplit : 1;
             t->frame_step(g.sp, g.eos, g.min_new, g.max_new, g.codes, g.hidden, g.max_frames, st);
             ++g.launched; --left;
             poll();
             continue;
         }
-        if (!t->graph_exec) {
-            QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            try {
-                t->frame_step(g.sp, g.eos, g.min_new, g.max_new, g.codes, g.hidden, g.max_frames, st);
-            } catch (...) {
-                hipGraph_t gx = nullptr;
-                (void)hipStreamEndCapture(st, &gx);
-                if (gx) (void)hipGraphDestroy(gx);
-                throw;
-            }
-            QTTS_CHECK_HIP(hipStreamEndCapture(st, &t->graph));
-            size_t nn = 0;
-            QTTS_CHECK_HIP(hipGraphGetNodes(t->graph, nullptr, &nn));
-            t->graph_nodes = (int)nn;
-            QTTS_CHECK_HIP(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
-        }
         const int burst = std::min(8, left);
-        for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(t->graph_exec, st));
+        hipGraphExec_t ge = t->ensure_graph(t->long_mode(t->T0 + g.launched + burst), st, [&] {
+            t->frame_step(g.sp, g.eos, g.min_new, g.max_new, g.codes, g.hidden, g.max_frames, st); });
+        for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(ge, st));
         g.launched += burst; left -= burst;
         poll();
     }

@@ -735,6 +735,28 @@ def test_talker_orchestration_greedy_vs_reference_golden(emu, golden_dir, use_gr
         emu.qtts_talker_destroy(h)
 
 
+def test_talker_split_kv_attention_and_graph_switch(emu, golden_dir, monkeypatch):
+    """Long-sequence mode of the talker's decode attention: an engine told to use split-KV (two attention workgroups per
+    (sequence, kv head) + merge kernel) from 20 keys on starts a generation on the short-sequence frame graph and SWITCHES to the
+    long-sequence graph mid-way (the knobs default to max_seq > 512 / 320 keys; QTTS_ATTN_NSPLIT / QTTS_ATTN_SPLIT_FROM bring the
+    switch into the range of the tiny golden).  The reference's greedy codes must still come out bit for bit."""
+    monkeypatch.setenv("QTTS_ATTN_NSPLIT", "2")
+    monkeypatch.setenv("QTTS_ATTN_SPLIT_FROM", "20")
+    g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
+    t = synth.talker_tiny()
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, use_graph=1)
+    try:
+        args = [g[k] for k in ("embeds", "mask", "trailing", "tts_pad")]
+        assert args[0].shape[1] < 20 < args[0].shape[1] + 13, "the switch point must fall inside the generation"
+        for _ in range(2):                      # second call: both graphs come from the cache
+            codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=14)
+            assert np.array_equal(tokens, g["tokens"]) and np.array_equal(codes, g["codes"])
+            assert np.abs(hidden - g["hidden"]).max() <= 2e-3
+    finally:
+        emu.qtts_talker_destroy(h)
+
+
 @pytest.mark.parametrize("use_graph", [0, 1] if FULL else [1])
 def test_talker_stream_generation_equals_one_shot(emu, golden_dir, use_graph):
     """qtts_talker_stream_begin / _step / _end (resumable generation for streaming output): stepping the request in packets
