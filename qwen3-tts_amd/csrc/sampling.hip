@@ -34,6 +34,55 @@ __device__ inline uint32_t float_key(float f) {  // monotone float -> uint (larg
 constexpr int SAMPLE_MAX_V = 8192;
 constexpr int CAND_MAX = 1024;          // top-k candidates (scores >= the k-th largest per-thread max) ranked exactly in LDS
 
+// The next pass's input rows (tabulated projected embedding, tabulated layer-0 q|k|v) are random rows of 117 / 470 MB tables:
+// every request is an HBM round trip (~1 us), so ALL of a thread's requests are issued before the first store -- the round-1
+// loops waited for each 16-byte piece in turn (up to 5 dependent round trips at the end of every code-predictor pass).
+__device__ __forceinline__ void gather_next_rows(const SampleParams& p, int token, int b, int tid) {
+    constexpr int G1 = 2, G2 = 4;                           // 16-byte pieces per thread: rows of <= 2048 / <= 4096 floats
+    float4 v1[G1], v2[G2];
+    const float* src = p.gather_emb ? p.gather_emb + (size_t)token * p.gather_C : nullptr;
+    const float* src2 = p.gather2_emb ? p.gather2_emb + (size_t)token * p.gather2_C : nullptr;
+#pragma unroll
+    for (int it = 0; it < G1; ++it) {
+        const int c = tid * 4 + it * 1024;
+        v1[it] = (src && c < p.gather_C) ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < G2; ++it) {
+        const int c = tid * 4 + it * 1024;
+        v2[it] = (src2 && c < p.gather2_C) ? *reinterpret_cast<const float4*>(src2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (src) {
+#pragma unroll
+        for (int it = 0; it < G1; ++it) {
+            const int c = tid * 4 + it * 1024;
+            if (c >= p.gather_C) continue;
+            *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v1[it];
+            if (p.gather_out16) {
+                ushort4 h; h.x = f32_to_bf16(v1[it].x); h.y = f32_to_bf16(v1[it].y); h.z = f32_to_bf16(v1[it].z); h.w = f32_to_bf16(v1[it].w);
+                *reinterpret_cast<ushort4*>(p.gather_out16 + (size_t)b * p.gather_C + c) = h;
+            }
+        }
+        for (int c = tid * 4 + G1 * 1024; c < p.gather_C; c += 1024) {          // (wider rows: the plain loop)
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v;
+            if (p.gather_out16) {
+                ushort4 h; h.x = f32_to_bf16(v.x); h.y = f32_to_bf16(v.y); h.z = f32_to_bf16(v.z); h.w = f32_to_bf16(v.w);
+                *reinterpret_cast<ushort4*>(p.gather_out16 + (size_t)b * p.gather_C + c) = h;
+            }
+        }
+    }
+    if (src2) {
+#pragma unroll
+        for (int it = 0; it < G2; ++it) {
+            const int c = tid * 4 + it * 1024;
+            if (c < p.gather2_C) *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = v2[it];
+        }
+        for (int c = tid * 4 + G2 * 1024; c < p.gather2_C; c += 1024)
+            *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
+    }
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     if (p.done_in && *p.done_in) return;
     __shared__ float sc[SAMPLE_MAX_V];
@@ -286,22 +335,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
 
     if (token < 0 || token >= V) token = 0;   // all-NaN logits must not turn into an out-of-range gather index
-    if (p.gather_emb) {                         // every thread holds the same token (block-uniform by construction)
-        const float* src = p.gather_emb + (size_t)token * p.gather_C;
-        for (int c = tid * 4; c < p.gather_C; c += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(src + c);
-            *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v;
-            if (p.gather_out16) {
-                ushort4 h; h.x = f32_to_bf16(v.x); h.y = f32_to_bf16(v.y); h.z = f32_to_bf16(v.z); h.w = f32_to_bf16(v.w);
-                *reinterpret_cast<ushort4*>(p.gather_out16 + (size_t)b * p.gather_C + c) = h;
-            }
-        }
-    }
-    if (p.gather2_emb) {
-        const float* src2 = p.gather2_emb + (size_t)token * p.gather2_C;
-        for (int c = tid * 4; c < p.gather2_C; c += 1024)
-            *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
-    }
+    gather_next_rows(p, token, b, tid);        // every thread holds the same token (block-uniform by construction)
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
 }
 
-// A/B variant (build.py VARIANTS, never the default build): the sampling path for 0 < top_k <= 64 and V <= 4096 (the
+// Round 2 (measured 1.1 % faster per frame, profiles/r02_ab_variants.md, now the default): the sampling path for 0 < top_k <= 64 and V <= 4096 (the
 // reference default is top_k = 50 on 2048 / 3072 logits) with the fixed costs taken out of sample_kernel above:
 //   * every load that does not depend on another load (done flag, counters, Philox key, the row's logits, the suppress
 //     mask) is issued at kernel entry instead of behind the early-exit test and the processors' barriers;
@@ -564,22 +598,7 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
     }
 
     if (token < 0 || token >= V) token = 0;
-    if (p.gather_emb) {
-        const float* src = p.gather_emb + (size_t)token * p.gather_C;
-        for (int c = tid * 4; c < p.gather_C; c += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(src + c);
-            *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v;
-            if (p.gather_out16) {
-                ushort4 h; h.x = f32_to_bf16(v.x); h.y = f32_to_bf16(v.y); h.z = f32_to_bf16(v.z); h.w = f32_to_bf16(v.w);
-                *reinterpret_cast<ushort4*>(p.gather_out16 + (size_t)b * p.gather_C + c) = h;
-            }
-        }
-    }
-    if (p.gather2_emb) {
-        const float* src2 = p.gather2_emb + (size_t)token * p.gather2_C;
-        for (int c = tid * 4; c < p.gather2_C; c += 1024)
-            *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
-    }
+    gather_next_rows(p, token, b, tid);
     if (tid == 0) {
         if (p.unfinished) {
             const int uf = p.unfinished[b];

@@ -135,10 +135,13 @@ struct qtts_talker {
     // (profiles/r02_ab_inproc_fs_floor.txt); QTTS_FS_MIN_WGS overrides it for A/B runs.
     int fs_min_wgs = [] { const char* e = getenv("QTTS_FS_MIN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
     int choose_fs(int N, int K) const {
-        (void)K;
         if (!bf16) return 16;
+        // a matrix of 16 MB or more is bound by what a CU can pull (~25 GB/s): it gets the full 192-workgroup floor (talker down,
+        // 25 MB: 6.7 us in 256 workgroups vs 9.4 us in 128, profiles/r02_rocprofv3_kernel_trace_bench*.md); smaller ones are
+        // latency-bound and pay for every extra workgroup's x re-read
+        const int floor_wgs = (size_t)N * K * 2 >= ((size_t)16 << 20) ? std::max(192, fs_min_wgs) : fs_min_wgs;
         int fs = 16;
-        while (fs > 4 && N / fs < fs_min_wgs) fs /= 2;
+        while (fs > 4 && N / fs < floor_wgs) fs /= 2;
         return fs;
     }
     static std::vector<float> cat3(const std::vector<float>& a, const std::vector<float>& b, const std::vector<float>& c) {

@@ -8,7 +8,7 @@ for n, c, v, g, w in rows:
     k = (re.sub(r"\(.*", "", n).replace("qtts::", "")[:60], c)
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += v
 lines = ["| kernel | counter | dispatches | mean per dispatch | total |", "|---|---|---|---|---|"]
-for (k, c), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+for (k, c), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:80]:
     lines.append(f"| `{k}` | {c} | {a[0]} | {a[1]/a[0]:.1f} | {a[1]:.0f} |")
 out = "\n".join(lines); print(out)
 if "--out" in sys.argv: open(sys.argv[sys.argv.index("--out") + 1], "w").write(out + "\n")
