@@ -46,6 +46,10 @@ def _talker_tiny(gp, golden_dir):
     return t, gp._td(synth.talker_weights(t)), np.load(os.path.join(golden_dir, "talker_tiny.npz"))
 
 
+FULL = os.environ.get("QTTS_GLUE_FULL") == "1"      # the default CPU suite keeps to the cases that add something new per minute
+
+
+@pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1 (green on the MI355X in round 2: tests/test_gpu_parity.py runs the same body through the HIP build)")
 def test_state_carrying_codec_stream_python_path(glue, golden_dir):
     """`CodecDecoderEngine.stream_begin / stream_push`: the gated GPU test body, on the emulator."""
     glue.test_codec_incremental_stream_equals_forward(_codec_tiny(glue, golden_dir))
@@ -61,7 +65,6 @@ def test_speaker_encoder_python_path(glue):
     glue.test_speaker_embedding_vs_oracle("cpu")
 
 
-FULL = os.environ.get("QTTS_GLUE_FULL") == "1"      # the default CPU suite keeps to the cases that add something new per minute
 
 
 @pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1 (the streaming wrapper test below goes through generate_stream too)")
@@ -79,6 +82,7 @@ def test_validated_python_paths_still_hold_on_the_emulator(glue, golden_dir):
     glue.test_talker_tiny_greedy_bit_exact(_talker_tiny(glue, golden_dir), "cpu", False)
 
 
+@pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1 (green on the MI355X in round 2: tests/test_gpu_parity.py runs the same body through the HIP build)")
 def test_voice_clone_wrapper_end_to_end_python_path(glue, tmp_path):
     """`create_voice_clone_prompt` + `generate_voice_clone` from a reference WAVE file (BASELINE config 5's call sequence):
     audio_io -> codec encoder -> speaker encoder -> device prompt assembly -> talker -> decoder -> ICL cut, every engine the
@@ -86,6 +90,7 @@ def test_voice_clone_wrapper_end_to_end_python_path(glue, tmp_path):
     glue.test_wrapper_voice_clone_from_waveform_end_to_end("cpu", tmp_path)
 
 
+@pytest.mark.skipif(not FULL, reason="QTTS_GLUE_FULL=1 (green on the MI355X in round 2: tests/test_gpu_parity.py runs the same body through the HIP build)")
 def test_stream_custom_voice_wrapper_python_path(glue):
     """`Qwen3TTSModel.stream_custom_voice` (PCM packets) equals `generate_custom_voice`: the gated GPU test body."""
     glue.test_wrapper_stream_custom_voice_equals_one_shot("cpu")
