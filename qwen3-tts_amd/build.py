@@ -30,6 +30,9 @@ VARIANTS = {
     # attention.hip: KV beyond the 256-key prefetch window read 4 chunks per latency round instead of 1.  Only long
     # sequences see it: A/B with `tools/ab_variants.py --frames 600 --only default attn_tail` (S grows to ~650).
     "attn_tail": ["-DQTTS_ATTN_TAIL_BATCH=1"],
+    # csrc/tstamp.h: phase timestamps inside the frame step's kernels (decode GEMM, both decode attentions, sampler); a
+    # measuring build for tools/ts_frame.py, never the product.
+    "tstamp": ["-DQTTS_TSTAMP=1"],
 }
 # Round 2 (profiles/r02_ab_variants.md): cp_pretable, cp_qkvtable, attn_cp and sampler_v2 were measured faster and are now the
 # default code; attn_t1, wtemporal, late_norm, embed_sum_v2 and gu8 were measured slower or neutral and are deleted.

@@ -12,6 +12,9 @@
 //                    each K/V tile is read once; scores staged in LDS; fp32 softmax.
 #include "common.h"
 #include "kernels.h"
+#include "tstamp.h"
+
+QTTS_TS_UNIT(attn)
 
 namespace qtts {
 
@@ -494,6 +497,7 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     __shared__ __attribute__((aligned(16))) float kn[HD];
     __shared__ float vn[HD];
     const int GQ = p.nh / p.nkv;
+    QTTS_TS_BEGIN();
     const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = lane >> 2, qq = lane & 3;
@@ -534,7 +538,9 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
         x0 = src[lane]; x1 = src[lane + 64];
     }
     const int done = p.done_flag ? *p.done_flag : 0;
+    QTTS_TS(1);
     if (done) return;
+    QTTS_TS_DRAINED(2);                    // cache rows and this step's qkv row have arrived
     // ---- 1. q/k RMSNorm + RoPE at position S0, K/V append
     if (has_vec) {
         const float* w = wave < 2 ? p.qw : (wave == 2 ? p.kw : nullptr);
@@ -558,7 +564,9 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
         float* dst = wave < 2 ? qs[wave] : (wave == 2 ? kn : vn);
         dst[lane] = x0; dst[lane + 64] = x1;
     }
+    QTTS_TS_DRAINED(3);                    // norm + RoPE + append done
     __syncthreads();
+    QTTS_TS(4);
     if (wave >= GQ) return;
     // ---- 2. one wave per query head
     const float* q = qs[wave] + qq * 32;
@@ -613,6 +621,8 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
         p.out[o + lane] = acc0 * inv;
         p.out[o + lane + 64] = acc1 * inv;
     }
+    QTTS_TS_DRAINED(5);
+    QTTS_TS_END(attn, 1, S0, 0);
 }
 
 // Pass 0 of the code predictor: an empty cache and TWO new tokens [past_hidden, embedding of codebook 0] (M:1671-1680).
@@ -727,6 +737,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     __shared__ __attribute__((aligned(16))) float red[16][GQ][HD];
     __shared__ float gm[16][GQ], gl[16][GQ];
 
+    QTTS_TS_BEGIN();
     const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = tid >> 4, li = tid & 15;
@@ -787,6 +798,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     for (int c = 1; c < NPRE; ++c)
         if (c0s + c < nchunk && !(deep && c == 1)) { load_chunk(kR[c], kc, c0s + c); load_chunk(vR[c], vc, c0s + c); }
     if (done) return;
+    QTTS_TS_DRAINED(1);                    // (tstamp build: phases 1..5 = arrived | normed | keys folded | barrier | stored)
 
     // ---- 1. q / k RMSNorm + RoPE of the new token, per wave; K / V append by wave 0 (rounded through the cache type: every
     // wave uses the rounded values, exactly what a later step will read back)
@@ -823,6 +835,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     for (int qi = 0; qi < GQ; ++qi)
 #pragma unroll
         for (int e = 0; e < 8; ++e) qreg[qi][e] = xw[wave][qi][li * 8 + e];
+    QTTS_TS_DRAINED(2);
 
     // ---- 2. online softmax over this group's keys, everything in registers
     float m[GQ], l[GQ], acc[GQ][8];
@@ -927,7 +940,9 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         dst[1] = make_float4(acc[qi][4], acc[qi][5], acc[qi][6], acc[qi][7]);
         if (li == 0) { gm[g][qi] = m[qi]; gl[g][qi] = l[qi]; }
     }
+    QTTS_TS_DRAINED(3);
     __syncthreads();
+    QTTS_TS(4);
     if (tid < GQ * HD) {
         const int qi = tid / HD, dd = tid % HD;
         float mm = gm[0][qi];
@@ -944,6 +959,8 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
             float* pp = p.part + (((size_t)blockIdx.x * nsplit + split) * GQ + qi) * (HD + 2);
             pp[dd] = num;
             if (dd == 0) { pp[HD] = mm; pp[HD + 1] = den; }
+            QTTS_TS_DRAINED(5);
+            QTTS_TS_END(attn, 2, S0, nsplit);
             return;
         }
         const size_t o = (size_t)b * p.ldo + (kvh * GQ + qi) * HD + dd;
@@ -951,6 +968,8 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(r);
         else p.out[o] = r;
     }
+    QTTS_TS_DRAINED(5);
+    QTTS_TS_END(attn, 2, S0, nsplit);
 }
 
 // merge of the split-KV partial results (fixed order): out = sum_s num_s e^(m_s - m) / sum_s den_s e^(m_s - m)

@@ -8,7 +8,10 @@
 // sampled runs are compared distributionally, greedy runs bit-exactly.
 #include "common.h"
 #include "kernels.h"
+#include "tstamp.h"
 #include "glue.h"
+
+QTTS_TS_UNIT(sample)
 
 namespace qtts {
 
@@ -347,6 +350,51 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
     }
 }
 
+// Wave-level tail of the top-k sampler (round 2, second pass -- the in-kernel timestamps of profiles/r02_tstamp_frame.md showed
+// 6.8 of the sampler's 12.1 us in the all-pairs ranking): this lane holds the candidates of slots lane, lane + 64, ... in
+// registers (key 0 = no candidate: below every real key).  The key of the k-th largest score (HF TopK keeps every score >= it,
+// ties included) comes from a bit-by-bit selection -- the largest v with #{key >= v} >= k -- one compare and one scalar
+// popcount per slot and bit, no LDS traffic and no barrier; then the softmax numerators of the survivors go back to `cval`
+// (slot order) and their sum is returned, accumulated in the order sample_kernel uses (slots ascending per lane, butterfly).
+template <int NQ>
+__device__ inline float topk_softmax_wave(int n_c, int top_k, int lane, float* cval, const uint32_t* ckey) {
+    uint32_t kq[NQ];
+    float vq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = q * 64 + lane;
+        kq[q] = i < n_c ? ckey[i] : 0u;
+        vq[q] = i < n_c ? cval[i] : -INFINITY;
+    }
+    uint32_t thr = 0u;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = thr | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cnt += __popcll(__ballot(kq[q] >= cand));
+        if (cnt >= top_k) thr = cand;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) mx = fmaxf(mx, vq[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int i = q * 64 + lane;
+        if (i < n_c) {
+            const float e = kq[q] >= thr ? expf(vq[q] - mx) : 0.f;
+            cval[i] = e;
+            tot += e;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    return tot;
+}
+
 // Round 2 (measured 1.1 % faster per frame, profiles/r02_ab_variants.md, now the default): the sampling path for 0 < top_k <= 64 and V <= 4096 (the
 // reference default is top_k = 50 on 2048 / 3072 logits) with the fixed costs taken out of sample_kernel above:
 //   * every load that does not depend on another load (done flag, counters, Philox key, the row's logits, the suppress
@@ -370,6 +418,7 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
     __shared__ __attribute__((aligned(16))) uint32_t gkey[64];
     __shared__ int pick_lo, pick_hi;
 
+    QTTS_TS_BEGIN();
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = p.V;
     const float* lg = p.logits + (size_t)b * p.ld;
@@ -387,6 +436,7 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
         sup[it] = (p.suppress_mask && v < V) ? p.suppress_mask[v] : (unsigned char)0;
     }
     if (done) return;
+    QTTS_TS_DRAINED(1);                    // (tstamp build: phases 1..5 = logits arrived | bound | candidates ranked | drawn | rows gathered)
     // ---- 1. HF processors, in HF's order, on this thread's own logits
     if (p.generated && p.repetition_penalty != 1.0f) {       // scatter -> presence flags in LDS (idempotent for duplicates)
 #pragma unroll
@@ -420,20 +470,17 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
     tm = fmaxf(tm, __shfl_xor(tm, 2));
     if ((lane & 3) == 0) gkey[wave * 16 + (lane >> 2)] = float_key(tm);
     __syncthreads();
-    uint32_t T0;
+    QTTS_TS(2);
+    // (bit-by-bit selection on the wave's 64 keys: the largest value v with #{key >= v} >= k IS the k-th largest key; one
+    // compare + one scalar popcount per bit, no LDS traffic and a twentieth of the all-pairs rank's instructions)
+    uint32_t T0 = 0u;
     {
         const uint32_t mk = gkey[lane];
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < 64; j += 4) {
-            const uint4 k4 = *reinterpret_cast<const uint4*>(&gkey[j]);
-            rank += (k4.x > mk) || (k4.x == mk && j < lane);
-            rank += (k4.y > mk) || (k4.y == mk && j + 1 < lane);
-            rank += (k4.z > mk) || (k4.z == mk && j + 2 < lane);
-            rank += (k4.w > mk) || (k4.w == mk && j + 3 < lane);
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t cand = T0 | (1u << bit);
+            if (__popcll(__ballot(mk >= cand)) >= p.top_k) T0 = cand;
         }
-        const unsigned long long hit = __ballot(rank == p.top_k - 1);      // exactly one lane: ranks are a permutation
-        T0 = (uint32_t)__shfl((int)mk, __ffsll((long long)hit) - 1);
     }
     // ---- 3. compaction in sample_kernel's slot order (wave, slice, lane)
     unsigned long long mb[EPT];
@@ -462,36 +509,11 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
             }
             base += __popcll(mb[it]);
         }
-        for (int i = n_c + tid; i < ((n_c + 3) & ~3); i += 256) ckey[i] = 0u;
         __syncthreads();
-        for (int i = tid; i < n_c; i += 256) {        // exact rank among the candidates (value desc, slot asc)
-            const uint32_t mk = ckey[i];
-            int rank = 0;
-            for (int j = 0; j < n_c; j += 4) {
-                const uint4 k4 = *reinterpret_cast<const uint4*>(&ckey[j]);
-                rank += (k4.x > mk) || (k4.x == mk && j < i);
-                rank += (k4.y > mk) || (k4.y == mk && j + 1 < i);
-                rank += (k4.z > mk) || (k4.z == mk && j + 2 < i);
-                rank += (k4.w > mk) || (k4.w == mk && j + 3 < i);
-            }
-            if (rank == p.top_k - 1) pick_lo = (int)mk;  // key of the k-th largest score
-        }
-        __syncthreads();
-        const uint32_t thr = (uint32_t)pick_lo;          // HF TopK keeps every score >= it (ties included)
-        __syncthreads();
-        if (wave == 0) {       // softmax over the survivors + inverse-CDF draw, one wave (as in sample_kernel)
-            float mx = -INFINITY;
-            for (int i = lane; i < n_c; i += 64) mx = fmaxf(mx, cval[i]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            float tot = 0.f;
-            for (int i = lane; i < n_c; i += 64) {
-                const float e = ckey[i] >= thr ? expf(cval[i] - mx) : 0.f;
-                cval[i] = e;
-                tot += e;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        QTTS_TS(3);
+        if (wave == 0) {       // exact top-k threshold, softmax over the survivors and the inverse-CDF draw: one wave, no barrier
+            float tot = n_c <= 128 ? topk_softmax_wave<2>(n_c, p.top_k, lane, cval, ckey)      // (typical: ~1.7 k candidates)
+                                   : topk_softmax_wave<CAND_MAX / 64>(n_c, p.top_k, lane, cval, ckey);
             if (p.top_p < 1.0f) {
                 float keep_e[CAND_MAX / 64];
                 float tot2 = 0.f;
@@ -538,6 +560,7 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
             if (lane == 0) pick_lo = cidx[pick];
         }
         __syncthreads();
+        QTTS_TS(4);
         token = pick_lo;
         sampled = true;
     }
@@ -608,6 +631,8 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
         }
         p.tok_out[(size_t)b * p.tok_stride] = token;
     }
+    QTTS_TS_DRAINED(5);
+    QTTS_TS_END(sample, 3, V, 0);
 }
 
 void launch_sample(const SampleParams& p, hipStream_t st) {

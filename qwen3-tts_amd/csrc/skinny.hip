@@ -25,6 +25,9 @@
 //   * everything the epilogue needs (residual, bias) is loaded at kernel entry, under the weight stream.
 #include "common.h"
 #include "kernels.h"
+#include "tstamp.h"
+
+QTTS_TS_UNIT(skinny)
 
 namespace qtts {
 
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     constexpr int NS = SPW * MT + MT;                            // accumulators per wave: the GEMM's + one X.X^T per m-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
     f32x4* red = reinterpret_cast<f32x4*>(smem_sk);              // [NW][NS][64]
+    QTTS_TS_BEGIN();
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile validity becomes a scalar branch
@@ -196,7 +200,9 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
         }
     }
     const int done = (p.done_flag && !(p.ablate & 1)) ? *p.done_flag : 0;
+    QTTS_TS(1);                            // every request of the straight-line kernels has been issued (and `done` has arrived)
     if (done) return;
+    QTTS_TS_DRAINED(2);                    // ... and has arrived
 
     auto compute_tile = [&](u32x4 (&w)[SPW][U], u32x4 (&xq)[MT][U], int u) {
 #pragma unroll
@@ -244,7 +250,9 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
         for (int s = 0; s < SPW; ++s) red[(wave * NS + s * MT + m) * 64 + lane] = acc[s][m];
         red[(wave * NS + SPW * MT + m) * 64 + lane] = acc_ss[m];
     }
+    QTTS_TS_DRAINED(3);                    // MFMAs done, partial sums in LDS
     __syncthreads();
+    QTTS_TS(4);
     if (wave != 0) return;
 
     // v[s][r] = out[row = m*16 + lj][feature = (strip0+s)*FS + lq*4 + r]
@@ -284,6 +292,8 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
             for (int s = 0; s < SPW; ++s) skinny_store4(p, row, (strip0 + s) * FS + lq * 4, v[s] + resv[s][m], true);
         }
     }
+    QTTS_TS_DRAINED(5);                    // stores acknowledged
+    QTTS_TS_END(skinny, 0, p.K, p.N);
 }
 
 // ------------------------------------------------------------------------------------------ fp32 (exact parity mode)
