@@ -360,6 +360,7 @@ template <int NQ>
 __device__ inline float topk_softmax_wave(int n_c, int top_k, int lane, float* cval, const uint32_t* ckey) {
     uint32_t kq[NQ];
     float vq[NQ];
+    const int nq = (n_c + 63) >> 6;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int i = q * 64 + lane;
@@ -372,7 +373,8 @@ __device__ inline float topk_softmax_wave(int n_c, int top_k, int lane, float* c
         const uint32_t cand = thr | (1u << bit);
         int cnt = 0;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) cnt += __popcll(__ballot(kq[q] >= cand));
+        for (int q = 0; q < NQ; ++q)
+            if (NQ <= 2 || q < nq) cnt += __popcll(__ballot(kq[q] >= cand));     // (nq: wave-uniform, a scalar branch)
         if (cnt >= top_k) thr = cand;
     }
     float mx = -INFINITY;

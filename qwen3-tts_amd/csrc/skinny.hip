@@ -296,6 +296,149 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     QTTS_TS_END(skinny, 0, p.K, p.N);
 }
 
+// ------------------------------------------------------------------------------------------ bf16, batch <= 8 (the benchmarked shape)
+// The frame step at batch <= 8 (round 2, after the in-kernel timestamps of profiles/r02_tstamp_frame.md): the same arithmetic as
+// skinny2_kernel<1, SPW, 8, FS, true, ..., EXACT> with every request unconditional and twice as wide.
+//   * A wave owns PAIRS of adjacent k-tiles (pair j = wave + 8 i).  At batch <= 8 the MFMA's batch columns 8..15 are padding, so
+//     the x operand of a pair is ONE request of all 64 lanes for 8 rows x 128 B -- whole cache lines -- instead of two
+//     requests of 32 lanes for 8 rows x 64 B: lane (lj, lq) reads row lj & 7, 16-B piece lq + 4 (lj >> 3).  Lanes lj < 8 then hold
+//     the B fragment of the even tile in place; the odd tile's fragment sits in the padding columns lj >= 8 and a DPP row
+//     rotation by 8 brings it to the columns lj < 8.  Narrow strips (FS = 8: feature rows 8..15 of the A operand are padding)
+//     fetch their weights the same way: one 1-KiB request per pair and strip, rotated for the odd tile.  What a rotation leaves in
+//     the padding rows / columns only reaches output features >= FS or batch rows >= 8, which nobody stores.
+//   * No exec mask and no conditional load anywhere: a conditional load makes the compiler merge the loaded value with the
+//     register's previous value, and where the register allocator turned that merge into a copy it waited for the load --
+//     `s_waitcnt vmcnt(0)` in the middle of the request burst, one full memory round trip (seen in several instantiations of
+//     skinny2_kernel, different ones after every edit).  Rows >= M re-read row 0, absent residual / bias operands read x; the
+//     epilogue selects.
+// NP = pairs per wave (K = 512 NP), NORM: RMSNorm folded in (acc_ss rides on the matrix pipe as in skinny2_kernel).
+__device__ inline u32x4 dpp_ror8(const u32x4& v) {
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[e], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+    return r;
+}
+
+template <int SPW, int FS, int NP, bool NORM>
+__global__ __launch_bounds__(512) void skinny8_kernel(SkinnyParams p) {
+    static_assert(FS == 16 || (FS == 8 && SPW == 1), "skinny8: strips of 16 features, or single strips of 8");
+    constexpr int NW = 8, NS = SPW + 1;
+    constexpr int WPP = FS == 16 ? 2 : 1;                        // weight requests per pair and strip (1 KiB each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem_sk);              // [NW][NS][64]
+    QTTS_TS_BEGIN();
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int nkt = p.K >> 5;
+    const int strip0 = blockIdx.x * SPW;
+
+    // 16-B units; a pair of tiles is 2 x FS x 4 units
+    const u32x4* wb[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s)
+        wb[s] = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)(strip0 + s) * nkt * (FS * 4)
+                + (FS == 16 ? lq * 16 + lj : (lj >> 3) * 32 + lq * 8 + (lj & 7)) + (size_t)wave * (FS * 8);
+    const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + (size_t)((lj & 7) < p.M ? (lj & 7) : 0) * p.ldx
+                               + (lq + 4 * (lj >> 3)) * 8 + wave * 64;
+
+    // ---- 1. every request of the launch, back to back: pair i of this wave = tiles 2 (wave + 8 i), + 1
+    u32x4 wR[NP][SPW][WPP], xR[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+#pragma unroll
+        for (int s = 0; s < SPW; ++s)
+#pragma unroll
+            for (int h = 0; h < WPP; ++h) wR[i][s][h] = skinny_wload(wb[s] + (size_t)i * (NW * FS * 8) + h * 64);
+        xR[i] = *reinterpret_cast<const u32x4*>(xb + i * (NW * 64));
+    }
+    // epilogue operands (used by wave 0 only; requested by every wave so that no branch surrounds a load)
+    const int colq = lq * 4 < FS ? lq * 4 : 0;
+    const int rowc = lj < p.M ? lj : 0;
+    f32x4 resv[SPW], biasv[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * FS) + colq;
+        const float* bp = p.bias ? p.bias + (strip0 + s) * FS + colq : reinterpret_cast<const float*>(p.x);
+        const float* rp = p.res ? p.res + (size_t)rowc * p.ldr + col : reinterpret_cast<const float*>(p.x);
+        biasv[s] = *reinterpret_cast<const f32x4*>(bp);
+        resv[s] = *reinterpret_cast<const f32x4*>(rp);
+    }
+    const int done = p.done_flag ? *p.done_flag : 0;
+    QTTS_TS(1);
+    if (done) return;
+    QTTS_TS_DRAINED(2);
+
+    // ---- 2. consume in request order
+    f32x4 acc[SPW], acc_ss = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        bf16x8 xe, xo;
+        *reinterpret_cast<u32x4*>(&xe) = xR[i];
+        *reinterpret_cast<u32x4*>(&xo) = dpp_ror8(xR[i]);
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+            bf16x8 we, wo;
+            *reinterpret_cast<u32x4*>(&we) = wR[i][s][0];
+            if constexpr (FS == 16) *reinterpret_cast<u32x4*>(&wo) = wR[i][s][WPP - 1];
+            else *reinterpret_cast<u32x4*>(&wo) = dpp_ror8(wR[i][s][0]);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(we, xe, acc[s], 0, 0, 0);
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo, xo, acc[s], 0, 0, 0);
+        }
+        if constexpr (NORM) {
+            acc_ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xe, xe, acc_ss, 0, 0, 0);
+            acc_ss = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xo, xo, acc_ss, 0, 0, 0);
+        }
+    }
+
+    // ---- 3. cross-wave combine (fixed order) and epilogue by wave 0: the kernel's only barrier
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) red[(wave * NS + s) * 64 + lane] = acc[s];
+    if constexpr (NORM) red[(wave * NS + SPW) * 64 + lane] = acc_ss;
+    QTTS_TS_DRAINED(3);
+    __syncthreads();
+    QTTS_TS(4);
+    if (wave != 0) return;
+
+    float rstd = 1.f;
+    if constexpr (NORM) {        // diagonal of X.X^T: row lj sits in lane (lj, lj >> 2), component lj & 3
+        const float* rf = reinterpret_cast<const float*>(red);
+        const int src = (((lj >> 2) * 16 + lj) << 2) + (lj & 3);
+        float ssum = rf[((0 * NS + SPW) * 64) * 4 + src];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) ssum += rf[((w2 * NS + SPW) * 64) * 4 + src];
+        rstd = rsqrtf(ssum / (float)p.K + p.eps);
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        f32x4 t = red[(0 * NS + s) * 64 + lane];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) t += red[(w2 * NS + s) * 64 + lane];
+        v[s] = t * rstd + (p.bias ? biasv[s] : zero4);
+    }
+    if (lj < p.M && lq * 4 < FS) {
+        if (p.act == ACT_SWIGLU) {
+            if constexpr (SPW == 2) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (v[0][r] / (1.f + expf(-v[0][r]))) * v[1][r];
+                o += p.res ? resv[0] : zero4;
+                skinny_store4(p, lj, blockIdx.x * 16 + lq * 4, o, false);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) skinny_store4(p, lj, (strip0 + s) * FS + lq * 4, v[s] + (p.res ? resv[s] : zero4), true);
+        }
+    }
+    QTTS_TS_DRAINED(5);
+    QTTS_TS_END(skinny, 0, p.K, p.N);
+}
+
 // ------------------------------------------------------------------------------------------ fp32 (exact parity mode)
 // x fragments are loaded per k-tile from global/L2 and the row sums of squares come from `ss_in` (row_ss_kernel): this is the
 // arithmetic the reference goldens were validated against bit for bit; it is not the benchmarked mode and is left as it was.
@@ -497,6 +640,36 @@ static int skinny_spw(int N, int fs, bool swiglu) {
     return (fs == 16 && N / 16 >= 1024 && (N / 16) % 2 == 0) ? 2 : 1;
 }
 
+// batch <= 8, bf16 x, K a multiple of 512 (whole tile pairs for 8 waves): the frame step's kernel.  QTTS_SKINNY8=0 falls back to
+// skinny2_kernel (A/B; read per launch so that one process can compare both).
+template <int SPW, int FS, int NP>
+static void launch8_n(const SkinnyParams& p, hipStream_t st) {
+    const int grid = p.N / (FS * SPW);
+    const size_t lds = (size_t)8 * (SPW + 1) * 64 * 16;
+    if (p.norm) hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, true>), dim3(grid), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, false>), dim3(grid), dim3(512), lds, st, p);
+}
+template <int SPW, int FS>
+static bool launch8_fs(const SkinnyParams& p, hipStream_t st) {
+    switch (p.K / 512) {
+        case 2: launch8_n<SPW, FS, 2>(p, st); return true;
+        case 4: launch8_n<SPW, FS, 4>(p, st); return true;
+        case 6: launch8_n<SPW, FS, 6>(p, st); return true;
+        case 12:
+            if constexpr (SPW == 1) { launch8_n<SPW, FS, 12>(p, st); return true; }     // (strip pairs at K = 6144 would spill)
+            return false;
+        default: return false;
+    }
+}
+static bool launch_skinny8(const SkinnyParams& p, int spw, int fs, hipStream_t st) {
+    const char* e = getenv("QTTS_SKINNY8");
+    if (e && e[0] == '0') return false;
+    if (!p.x_bf16 || p.M > 8 || p.K % 512 != 0 || p.ablate) return false;
+    if (fs == 16) return spw == 2 ? launch8_fs<2, 16>(p, st) : launch8_fs<1, 16>(p, st);
+    if (fs == 8 && spw == 1) return launch8_fs<1, 8>(p, st);
+    return false;
+}
+
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int KT = bf16 ? 32 : 16;
     const int fs = p.fs ? p.fs : 16;
@@ -513,6 +686,7 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int spw = skinny_spw(p.N, fs, p.act == ACT_SWIGLU);
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
+    if (bf16 && nw == 8 && mt == 1 && launch_skinny8(p, spw, fs, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
     if (bf16) {
         if (nw == 8) { if (mt == 1) launch2_mt<1, 8>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 8>(p, spw, fs, st); else launch2_mt<4, 8>(p, spw, fs, st); }
         else         { if (mt == 1) launch2_mt<1, 4>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 4>(p, spw, fs, st); else launch2_mt<4, 4>(p, spw, fs, st); }

@@ -252,8 +252,16 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
              (8, 32, 6144, 8, 0, ACT_NONE, 1, 1, 0),      # talker down: three chunks of 8, 8-feature strips
              (24, 64, 1024, 16, 1, ACT_NONE, 0, 0, 1),    # two m-tiles
              (40, 32, 2048, 8, 1, ACT_NONE, 0, 1, 0),     # four m-tiles
-             (3, 48, 160, 16, 1, ACT_NONE, 1, 0, 0)]      # odd K: generic (guarded) instantiation, 4 waves
-    for (M, N, K, fs, norm, act, hb, hr, sh) in cases:
+             (3, 48, 160, 16, 1, ACT_NONE, 1, 0, 0),      # odd K: generic (guarded) instantiation, 4 waves
+             # skinny8_kernel (batch <= 8: tile pairs, whole-line x requests, DPP-rotated odd tiles) beyond the cases above
+             (5, 32, 2048, 8, 1, ACT_NONE, 1, 1, 1),      # 5 rows (rows 5..7 re-read row 0), 8-feature strips, norm + bias + res + shadow
+             (8, 32, 3072, 8, 0, ACT_NONE, 0, 1, 0),      # six pairs per wave, rotated weights
+             (1, 64, 3072, 16, 1, ACT_SWIGLU, 0, 1, 0),   # one row, strip pairs, six pairs per wave
+             (8, 48, 2048, 16, 0, ACT_NONE, 1, 0, 1)]     # talker o-proj-like, 16-feature strips, no norm
+    for (M, N, K, fs, norm, act, hb, hr, sh), s8 in [(c, v) for c in cases for v in ("1", "0")]:
+        if s8 == "0" and not (M <= 8 and K % 512 == 0 and fs >= 8):
+            continue                                      # (QTTS_SKINNY8=0: the same shapes through skinny2_kernel)
+        os.environ["QTTS_SKINNY8"] = s8
         x = (g.standard_normal((M, K + 8)) * 0.7).astype(np.float32)
         W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
         gw = (1 + 0.1 * g.standard_normal(K)).astype(np.float32) if norm else None
@@ -285,6 +293,7 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
             got = (out16[:, :No].astype(np.uint32) << 16).view(np.float32)
             assert np.abs(got - out[:, :No]).max() <= 8e-3 * max(1.0, float(np.abs(out).max())), "bf16 shadow differs from the fp32 output"
             assert np.all(out16[:, No:] == 0x4242)
+    os.environ.pop("QTTS_SKINNY8", None)
 
 
 @pytest.mark.parametrize("bf16", [0, 1])

@@ -25,6 +25,8 @@ def cheap(shapes, std_of):
         n = int(np.prod(shp))
         v = np.resize(base, n).reshape(shp) * np.float32(std_of(k, shp))
         if "norm" in k and k.endswith("weight"): v = v * 0 + 1
+        if "head" in k:      # the tiled base repeats every 2^20 values: identical head rows = tied logits, which the sampler sees
+            v = np.random.default_rng(__import__("zlib").crc32(k.encode())).standard_normal(shp, dtype=np.float32) * np.float32(std_of(k, shp))
         if k.endswith("cluster_usage"): v = np.abs(v) + 0.5
         out[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
     return out
