@@ -199,7 +199,12 @@ void launch_qknorm_rope_store(const QkNormRopeParams& p, hipStream_t st) {
 #ifndef QTTS_ATTN_TAIL_BATCH
 #define QTTS_ATTN_TAIL_BATCH 0
 #endif
-template <typename KVT, int NQ>
+// CT (all decode kernels): the pool is laid out contiguously (page = b * pages_per_seq + s / 16 -- what the engine allocates): a
+// compile-time fact, because with `CT ? ... : page_table[...]` decided at run time every K / V request sat behind a
+// control-flow join at which the compiler waits for ALL outstanding loads (`s_waitcnt vmcnt(0)`: one side of the join has a
+// page-table load pending) -- the speculative chunk requests of attn_tk went out ONE AT A TIME, a memory round trip each
+// (round-2 in-kernel timestamps: 5.1 of its 9.5 us; found in the ISA, profiles/r02_tstamp_frame.md).
+template <typename KVT, int NQ, bool CT>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     constexpr int HD = 128;
     constexpr int CH = 4;                      // keys per lane group per chunk (64 keys per workgroup chunk)
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 
     auto kv_off = [&](int s) -> size_t {       // element offset of key s, this lane's 8 dims
         s = s < pool_keys ? s : pool_keys - 1;  // speculative loads stay inside the sequence's pages
-        const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+        const int page = CT ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
         return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD + li * 8;
     };
     auto load_chunk = [&](u32x4 (&r)[CH][KW], const KVT* base, int c) {
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
         }
         if (vi >= NQ) {  // K or V of a new token: round through the cache type, append
             const int s = S0 + t;
-            const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+            const int page = CT ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
             const size_t o = ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD;
             KVT* cdst = reinterpret_cast<KVT*>(vi < NQ + p.n_new ? p.kv.k : p.kv.v);
             const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
 //                       cache at kernel entry, before the new row is even read.
 //   stage 2 (wave = query): 32-dim partial dot + quad reduction, fp32 softmax across the 16 key slots (DPP), then
 //                       out[d] = sum_k e_k * v[k][d] with e_k broadcast from its lane -- no cross-lane reduction for PV.
-template <typename KVT>
+template <typename KVT, bool CT>
 __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     constexpr int HD = 128, MAXK = 16;
     constexpr int KW = sizeof(KVT) == 2 ? 4 : 8;          // 16-B vectors per 32-dim quarter of a key
@@ -505,31 +510,11 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     const KVT* kc = reinterpret_cast<const KVT*>(p.kv.k);
     const KVT* vc = reinterpret_cast<const KVT*>(p.kv.v);
     auto key_base = [&](int s) -> size_t {                // element offset of key s (dim 0) in this sequence's pages
-        const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+        const int page = CT ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
         return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD;
     };
-    // ---- 0. cache reads (do not depend on this step's qkv row); only the query waves need them
-    u32x4 kr[KW];
-    KVT vr[MAXK][2];
-#pragma unroll
-    for (int w = 0; w < KW; ++w) kr[w] = (u32x4){0u, 0u, 0u, 0u};
-    if (wave < GQ) {
-        if (kk < S0) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(kc + key_base(kk) + qq * 32);
-#pragma unroll
-            for (int w = 0; w < KW; ++w) kr[w] = src[w];
-        }
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k) {
-            vr[k][0] = vr[k][1] = kv_cast<KVT>(0.f);
-            if (k < S0) {
-                const size_t o = key_base(k);
-                vr[k][0] = vc[o + lane];
-                vr[k][1] = vc[o + lane + 64];
-            }
-        }
-    }
-    // this step's row: wave 0 / 1 -> q heads, wave 2 -> k, wave 3 -> v (with GQ == 1 wave 1 has nothing to do)
+    // ---- 0. this step's row FIRST (loads return in request order: the norm / RoPE stage then runs while the cache rows are still
+    // on their way): wave 0 / 1 -> q heads, wave 2 -> k, wave 3 -> v (with GQ == 1 wave 1 has nothing to do)
     const bool has_vec = wave >= 2 || wave < GQ;
     float x0 = 0.f, x1 = 0.f;
     if (has_vec) {
@@ -537,19 +522,38 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
         const float* src = p.qkv + (size_t)b * p.ld + col;
         x0 = src[lane]; x1 = src[lane + 64];
     }
+    // (norm weights and RoPE frequencies requested here, unconditionally: behind the early-exit test they would cost stage 1 a
+    // second memory round trip)
+    const float* nw = wave == 2 ? p.kw : p.qw;
+    const float nw0 = nw[lane], nw1 = nw[lane + 64], invf = p.inv_freq[lane];
+    // cache reads (do not depend on this step's qkv row); only the query waves need them.  Straight-line and unconditional
+    // inside the (wave-uniform) branch: key slots >= S0 re-read key 0 and are dropped at the point of use -- a conditional load
+    // is merged with the register's previous value, and the compiler waited for each of the 32 V loads before issuing the next
+    // (round 2: the kernel's time grew with the pass number, 2.5 us to first data on average).  V: lane <- dims 2 lane, 2 lane + 1
+    // of every key (one 256-B row per request instead of two 128-B halves).
+    struct alignas(2 * sizeof(KVT)) VPair { KVT a, b; };
+    u32x4 kr[KW];
+    VPair vr[MAXK];
+    if (wave < GQ) {
+        const u32x4* ksrc = reinterpret_cast<const u32x4*>(kc + key_base(kk < S0 ? kk : 0) + qq * 32);
+#pragma unroll
+        for (int w = 0; w < KW; ++w) kr[w] = ksrc[w];
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            vr[k] = *reinterpret_cast<const VPair*>(vc + key_base(k < S0 ? k : 0) + 2 * lane);
+    }
     const int done = p.done_flag ? *p.done_flag : 0;
     QTTS_TS(1);
     if (done) return;
     QTTS_TS_DRAINED(2);                    // cache rows and this step's qkv row have arrived
     // ---- 1. q/k RMSNorm + RoPE at position S0, K/V append
     if (has_vec) {
-        const float* w = wave < 2 ? p.qw : (wave == 2 ? p.kw : nullptr);
-        if (w) {
+        if (wave <= 2) {
             const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
             const float rs = rsqrtf(ss / (float)HD + p.eps);
-            x0 = w[lane] * (x0 * rs);
-            x1 = w[lane + 64] * (x1 * rs);
-            const float ang = (float)S0 * p.inv_freq[lane];
+            x0 = nw0 * (x0 * rs);
+            x1 = nw1 * (x1 * rs);
+            const float ang = (float)S0 * invf;
             const float c = cosf(ang), sn = sinf(ang);
             const float o0 = x0 * c - x1 * sn, o1 = x1 * c + x0 * sn;
             x0 = o0; x1 = o1;
@@ -603,24 +607,21 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     for (int k = 0; k < MAXK; ++k) {
         if (k < S0) {
             const float ek = __shfl(e, k * 4);
-            acc0 += ek * kv_load(&vr[k][0]);
-            acc1 += ek * kv_load(&vr[k][1]);
+            acc0 += ek * kv_load(&vr[k].a);
+            acc1 += ek * kv_load(&vr[k].b);
         }
     }
     {
         const float ek = __shfl(e, S0 * 4);
-        acc0 += ek * vn[lane];
-        acc1 += ek * vn[lane + 64];
+        acc0 += ek * vn[2 * lane];
+        acc1 += ek * vn[2 * lane + 1];
     }
     const float inv = 1.f / l;
-    const size_t o = (size_t)b * p.ldo + (kvh * GQ + wave) * HD;
+    const size_t o = (size_t)b * p.ldo + (kvh * GQ + wave) * HD + 2 * lane;      // this lane's two dims
     if (p.out_bf16) {
-        reinterpret_cast<bf16_t*>(p.out)[o + lane] = f32_to_bf16(acc0 * inv);
-        reinterpret_cast<bf16_t*>(p.out)[o + lane + 64] = f32_to_bf16(acc1 * inv);
-    } else {
-        p.out[o + lane] = acc0 * inv;
-        p.out[o + lane + 64] = acc1 * inv;
-    }
+        const unsigned pk = (unsigned)f32_to_bf16(acc0 * inv) | ((unsigned)f32_to_bf16(acc1 * inv) << 16);
+        *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(p.out) + o) = pk;
+    } else { p.out[o] = acc0 * inv; p.out[o + 1] = acc1 * inv; }
     QTTS_TS_DRAINED(5);
     QTTS_TS_END(attn, 1, S0, 0);
 }
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
 // it); token 1 attends to both.  One workgroup per (sequence, kv head): 8 vectors (q of 2 tokens x up to 2 heads, k and v of
 // both tokens) get RMSNorm + RoPE at positions 0 / 1 two per wave, k / v are appended, then wave gq < GQ forms the two-key
 // softmax of query (token 1, head gq).
-template <typename KVT>
+template <typename KVT, bool CT>
 __global__ __launch_bounds__(256) void attn_cp0_kernel(AttnDecodeParams p) {
     constexpr int HD = 128;
     __shared__ float q1[2][HD];            // normed + roped q of token 1, per head
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256) void attn_cp0_kernel(AttnDecodeParams p) {
             x0 = o0; x1 = o1;
         }
         if (vi >= 4) {                      // K or V of token t: round through the cache type, append at slot t of page 0
-            const int page = p.kv.contig ? b * p.kv.pages_per_seq : p.kv.page_table[b * p.kv.pages_per_seq];
+            const int page = CT ? b * p.kv.pages_per_seq : p.kv.page_table[b * p.kv.pages_per_seq];
             const size_t o = ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + t) * HD;
             KVT* cdst = reinterpret_cast<KVT*>(vi < 6 ? p.kv.k : p.kv.v);
             const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
@@ -727,7 +728,7 @@ __global__ __launch_bounds__(256) void attn_cp0_kernel(AttnDecodeParams p) {
 //   * ONE workgroup barrier (in front of the merge) instead of four;
 //   * beyond the register window (256 keys bf16 / 128 fp32) K and V chunks are read TOGETHER, NPRE chunks per latency round,
 //     and folded into the running statistics -- a long utterance costs one round trip per 256 keys, not two per 64.
-template <typename KVT, int GQ>
+template <typename KVT, int GQ, bool CT>
 __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     constexpr int HD = 128, CH = 4;
     constexpr int KW = sizeof(KVT) == 2 ? 1 : 2;          // 16-B vectors per key per lane (8 dims)
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
 
     auto kv_off = [&](int s) -> size_t {       // element offset of key s, this lane's 8 dims
         s = s < pool_keys ? s : pool_keys - 1;  // speculative loads stay inside the sequence's pages
-        const int page = p.kv.contig ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
+        const int page = CT ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
         return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (s & 15)) * HD + li * 8;
     };
     auto load_chunk = [&](u32x4 (&r)[CH][KW], const KVT* base, int c) {
@@ -775,13 +776,8 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     const int nsplit = gridDim.y, split = blockIdx.y;
     const int cps = ((p.max_len + 16 * CH - 1) / (16 * CH) + nsplit - 1) / nsplit;     // chunks per split
     const int c0s = split * cps, cend_static = c0s + cps;
-    // ---- 0. loads that do not depend on this step's qkv row or on the length: the first K and V chunk(s)
-    u32x4 kR[NPRE][CH][KW], vR[NPRE][CH][KW];
-    load_chunk(kR[0], kc, c0s);
-    load_chunk(vR[0], vc, c0s);
-    const bool deep = p.max_len > 64 && cps > 1;
-    if (deep) { load_chunk(kR[1], kc, c0s + 1); load_chunk(vR[1], vc, c0s + 1); }
-    // this step's row: EVERY wave fetches the GQ query heads, k and v of the new token (lane <- dims lane, lane + 64)
+    // ---- 0. this step's row FIRST (loads return in request order: norm / RoPE of the new token then overlap the K / V stream):
+    // EVERY wave fetches the GQ query heads, k and v of the new token (lane <- dims lane, lane + 64) and the norm weights
     float x0v[GQ + 2], x1v[GQ + 2];
 #pragma unroll
     for (int vi = 0; vi < GQ + 2; ++vi) {
@@ -789,6 +785,14 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         const float* src = p.qkv + (size_t)b * p.ld + col;
         x0v[vi] = src[lane]; x1v[vi] = src[lane + 64];
     }
+    const float wq0 = p.qw[lane], wq1 = p.qw[lane + 64], wk0 = p.kw[lane], wk1 = p.kw[lane + 64];
+    const float invf = p.inv_freq[lane];
+    // loads that do not depend on this step's qkv row or on the length: the first K and V chunk(s)
+    u32x4 kR[NPRE][CH][KW], vR[NPRE][CH][KW];
+    load_chunk(kR[0], kc, c0s);
+    load_chunk(vR[0], vc, c0s);
+    const bool deep = p.max_len > 64 && cps > 1;
+    if (deep) { load_chunk(kR[1], kc, c0s + 1); load_chunk(vR[1], vc, c0s + 1); }
     const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step
     const int npad = p.n_pad ? p.n_pad[b] : 0;
     const int done = p.done_flag ? *p.done_flag : 0;
@@ -802,8 +806,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
 
     // ---- 1. q / k RMSNorm + RoPE of the new token, per wave; K / V append by wave 0 (rounded through the cache type: every
     // wave uses the rounded values, exactly what a later step will read back)
-    const float wq0 = p.qw[lane], wq1 = p.qw[lane + 64], wk0 = p.kw[lane], wk1 = p.kw[lane + 64];
-    const float ang = (float)(S0 - npad) * p.inv_freq[lane];
+    const float ang = (float)(S0 - npad) * invf;
     const float cs = cosf(ang), sn = sinf(ang);
 #pragma unroll
     for (int vi = 0; vi < GQ + 2; ++vi) {
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         if (vi >= GQ) {
             const KVT h0 = kv_cast<KVT>(x0), h1 = kv_cast<KVT>(x1);
             if (wave == 0 && split == 0) {
-                const int page = p.kv.contig ? b * p.kv.pages_per_seq + (S0 >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (S0 >> 4)];
+                const int page = CT ? b * p.kv.pages_per_seq + (S0 >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (S0 >> 4)];
                 const size_t o = ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * 16 + (S0 & 15)) * HD;
                 KVT* cdst = reinterpret_cast<KVT*>(vi == GQ ? p.kv.k : p.kv.v);
                 cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
@@ -998,9 +1001,25 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnDecodeParams p) {
     else p.out[o] = r;
 }
 
+template <typename KVT, int GQ>
+static void launch_attn_tk_c(const AttnDecodeParams& p, dim3 grid, hipStream_t st) {
+    if (p.kv.contig) hipLaunchKernelGGL((attn_tk_kernel<KVT, GQ, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_tk_kernel<KVT, GQ, false>), grid, dim3(256), 0, st, p);
+}
+static void launch_attn_tk(const AttnDecodeParams& p, int GQ, dim3 grid, hipStream_t st) {
+    if (p.kv.bf16) { if (GQ == 1) launch_attn_tk_c<bf16_t, 1>(p, grid, st); else launch_attn_tk_c<bf16_t, 2>(p, grid, st); }
+    else { if (GQ == 1) launch_attn_tk_c<float, 1>(p, grid, st); else launch_attn_tk_c<float, 2>(p, grid, st); }
+}
+template <typename KVT, int NQ, bool CT>
+static void launch_attn_decode_c(const AttnDecodeParams& p, size_t lds, hipStream_t st);
 template <typename KVT, int NQ>
 static void launch_attn_decode_t(const AttnDecodeParams& p, size_t lds, hipStream_t st) {
-    auto kern = attn_decode_kernel<KVT, NQ>;
+    if (p.kv.contig) launch_attn_decode_c<KVT, NQ, true>(p, lds, st);
+    else launch_attn_decode_c<KVT, NQ, false>(p, lds, st);
+}
+template <typename KVT, int NQ, bool CT>
+static void launch_attn_decode_c(const AttnDecodeParams& p, size_t lds, hipStream_t st) {
+    auto kern = attn_decode_kernel<KVT, NQ, CT>;
     static bool attr_set = false;      // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1015,14 +1034,20 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
     const int GQ = p.nh / p.nkv, NQ = p.n_new * GQ;
     QTTS_REQUIRE((NQ == 1 || NQ == 2 || NQ == 4) && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: 1, 2 or 4 queries per kv head");
     if (p.n_new == 2 && !p.len_dev && !p.n_pad && p.len_static == 0 && GQ <= 2) {          // the code predictor's pass 0
-        if (p.kv.bf16) hipLaunchKernelGGL(attn_cp0_kernel<bf16_t>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(attn_cp0_kernel<float>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        const dim3 grid(p.B * p.nkv);
+        if (p.kv.bf16) { if (p.kv.contig) hipLaunchKernelGGL((attn_cp0_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);
+                         else hipLaunchKernelGGL((attn_cp0_kernel<bf16_t, false>), grid, dim3(256), 0, st, p); }
+        else { if (p.kv.contig) hipLaunchKernelGGL((attn_cp0_kernel<float, true>), grid, dim3(256), 0, st, p);
+               else hipLaunchKernelGGL((attn_cp0_kernel<float, false>), grid, dim3(256), 0, st, p); }
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }
     if (p.n_new == 1 && !p.len_dev && !p.n_pad && p.len_static + 1 <= 16 && GQ <= 2) {     // the code predictor's passes >= 1
-        if (p.kv.bf16) hipLaunchKernelGGL(attn_cp_kernel<bf16_t>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(attn_cp_kernel<float>, dim3(p.B * p.nkv), dim3(256), 0, st, p);
+        const dim3 grid(p.B * p.nkv);
+        if (p.kv.bf16) { if (p.kv.contig) hipLaunchKernelGGL((attn_cp_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);
+                         else hipLaunchKernelGGL((attn_cp_kernel<bf16_t, false>), grid, dim3(256), 0, st, p); }
+        else { if (p.kv.contig) hipLaunchKernelGGL((attn_cp_kernel<float, true>), grid, dim3(256), 0, st, p);
+               else hipLaunchKernelGGL((attn_cp_kernel<float, false>), grid, dim3(256), 0, st, p); }
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }
@@ -1030,10 +1055,7 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
         const int ns = p.nsplit > 1 ? p.nsplit : 1;
         QTTS_REQUIRE(ns == 1 || p.part, QTTS_ERR_ARG, "attn_decode: split-KV needs the partial-result buffer");
         const dim3 grid(p.B * p.nkv, ns);
-        if (p.kv.bf16) { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 1>), grid, dim3(256), 0, st, p);
-                         else hipLaunchKernelGGL((attn_tk_kernel<bf16_t, 2>), grid, dim3(256), 0, st, p); }
-        else { if (GQ == 1) hipLaunchKernelGGL((attn_tk_kernel<float, 1>), grid, dim3(256), 0, st, p);
-               else hipLaunchKernelGGL((attn_tk_kernel<float, 2>), grid, dim3(256), 0, st, p); }
+        launch_attn_tk(p, GQ, grid, st);
         if (ns > 1) {
             if (GQ == 1) hipLaunchKernelGGL((attn_merge_kernel<1>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((attn_merge_kernel<2>), dim3(p.B * p.nkv), dim3(256), 0, st, p);
