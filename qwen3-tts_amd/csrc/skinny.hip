@@ -319,10 +319,10 @@ __device__ inline u32x4 dpp_ror8(const u32x4& v) {
     return r;
 }
 
-template <int SPW, int FS, int NP, bool NORM>
-__global__ __launch_bounds__(512) void skinny8_kernel(SkinnyParams p) {
+template <int SPW, int FS, int NP, bool NORM, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void skinny8_kernel(SkinnyParams p) {
     static_assert(FS == 16 || (FS == 8 && SPW == 1), "skinny8: strips of 16 features, or single strips of 8");
-    constexpr int NW = 8, NS = SPW + 1;
+    constexpr int NS = SPW + 1;
     constexpr int WPP = FS == 16 ? 2 : 1;                        // weight requests per pair and strip (1 KiB each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
     f32x4* red = reinterpret_cast<f32x4*>(smem_sk);              // [NW][NS][64]
@@ -642,15 +642,35 @@ static int skinny_spw(int N, int fs, bool swiglu) {
 
 // batch <= 8, bf16 x, K a multiple of 512 (whole tile pairs for 8 waves): the frame step's kernel.  QTTS_SKINNY8=0 falls back to
 // skinny2_kernel (A/B; read per launch so that one process can compare both).
-template <int SPW, int FS, int NP>
+template <int SPW, int FS, int NP, int NW = 8>
 static void launch8_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
-    const size_t lds = (size_t)8 * (SPW + 1) * 64 * 16;
-    if (p.norm) hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, true>), dim3(grid), dim3(512), lds, st, p);
-    else hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, false>), dim3(grid), dim3(512), lds, st, p);
+    const size_t lds = (size_t)NW * (SPW + 1) * 64 * 16;
+    if (p.norm) hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, true, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
+    else hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, false, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
 }
 template <int SPW, int FS>
 static bool launch8_fs(const SkinnyParams& p, hipStream_t st) {
+    // K <= 3072: 4 waves per workgroup with twice the tile pairs each -- half the partial sums to combine, a shorter barrier
+    // (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame, both repetitions); QTTS_SKINNY8_NW=8 restores 8 waves
+    const char* e_nw = getenv("QTTS_SKINNY8_NW");
+    if (!(e_nw && e_nw[0] == '8')) {
+        {
+            if constexpr (SPW == 1) {
+                switch (p.K / 512) {
+                    case 2: launch8_n<SPW, FS, 4, 4>(p, st); return true;
+                    case 4: launch8_n<SPW, FS, 8, 4>(p, st); return true;
+                    case 6: launch8_n<SPW, FS, 12, 4>(p, st); return true;
+                    default: break;
+                }
+            } else {
+                switch (p.K / 512) {
+                    case 2: launch8_n<SPW, FS, 4, 4>(p, st); return true;
+                    default: break;
+                }
+            }
+        }
+    }
     switch (p.K / 512) {
         case 2: launch8_n<SPW, FS, 2>(p, st); return true;
         case 4: launch8_n<SPW, FS, 4>(p, st); return true;

@@ -14,7 +14,9 @@ from qwen3_tts_amd.talker import TalkerEngine
 
 CONFIGS = {
     "default": {},
-    "skinny8_off": {"QTTS_SKINNY8": "0"},        # batch <= 8 decode GEMM back on skinny2_kernel
+    "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},     # 8 waves per workgroup for every K (default: 4 waves up to K = 3072)
+    "fs_min_wgs_48": {"QTTS_FS_MIN_WGS": "48"},  # cp o / down projections in 64 workgroups of 16-feature strips
+    "fs_min_wgs_128": {"QTTS_FS_MIN_WGS": "128"},  # talker o projection / heads in 8-feature strips
 }
 KEYS = sorted({k for c in CONFIGS.values() for k in c})
 
