@@ -649,37 +649,33 @@ static void launch8_n(const SkinnyParams& p, hipStream_t st) {
     if (p.norm) hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, true, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
     else hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, false, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
 }
-template <int SPW, int FS>
-static bool launch8_fs(const SkinnyParams& p, hipStream_t st) {
-    // K <= 3072: 4 waves per workgroup with twice the tile pairs each -- half the partial sums to combine, a shorter barrier
-    // (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame, both repetitions); QTTS_SKINNY8_NW=8 restores 8 waves
-    const char* e_nw = getenv("QTTS_SKINNY8_NW");
-    if (!(e_nw && e_nw[0] == '8')) {
-        {
-            if constexpr (SPW == 1) {
-                switch (p.K / 512) {
-                    case 2: launch8_n<SPW, FS, 4, 4>(p, st); return true;
-                    case 4: launch8_n<SPW, FS, 8, 4>(p, st); return true;
-                    case 6: launch8_n<SPW, FS, 12, 4>(p, st); return true;
-                    default: break;
-                }
-            } else {
-                switch (p.K / 512) {
-                    case 2: launch8_n<SPW, FS, 4, 4>(p, st); return true;
-                    default: break;
-                }
-            }
-        }
-    }
+// waves per workgroup: fewer waves = fewer partial sums to combine and a shorter barrier, more tile pairs (registers) per wave.
+// Default 4 up to K = 3072 (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame with 8, both repetitions), 8 for K = 6144;
+// QTTS_SKINNY8_NW = 8 | 4 | 2 | 1 asks for another count where that instantiation exists (A/B; read per launch).
+template <int SPW, int FS, int NW>
+static bool launch8_nw(const SkinnyParams& p, hipStream_t st) {
+    constexpr int REGS_PER_PAIR = (FS == 16 ? 8 : 4) * SPW + 4;          // operand VGPRs per tile pair
     switch (p.K / 512) {
-        case 2: launch8_n<SPW, FS, 2>(p, st); return true;
-        case 4: launch8_n<SPW, FS, 4>(p, st); return true;
-        case 6: launch8_n<SPW, FS, 6>(p, st); return true;
-        case 12:
-            if constexpr (SPW == 1) { launch8_n<SPW, FS, 12>(p, st); return true; }     // (strip pairs at K = 6144 would spill)
+#define QTTS_S8_CASE(KQ)                                                                                         \
+        case KQ:                                                                                                 \
+            if constexpr ((KQ * 8) % NW == 0 && (KQ * 8 / NW) * REGS_PER_PAIR <= 200) {                           \
+                launch8_n<SPW, FS, KQ * 8 / NW, NW>(p, st);                                                      \
+                return true;                                                                                     \
+            }                                                                                                    \
             return false;
+        QTTS_S8_CASE(2) QTTS_S8_CASE(4) QTTS_S8_CASE(6) QTTS_S8_CASE(12)
+#undef QTTS_S8_CASE
         default: return false;
     }
+}
+template <int SPW, int FS>
+static bool launch8_fs(const SkinnyParams& p, hipStream_t st) {
+    const char* e = getenv("QTTS_SKINNY8_NW");
+    const int want = (e && (e[0] == '8' || e[0] == '4' || e[0] == '2' || e[0] == '1')) ? e[0] - '0' : 4;
+    if (want <= 1 && launch8_nw<SPW, FS, 1>(p, st)) return true;
+    if (want <= 2 && launch8_nw<SPW, FS, 2>(p, st)) return true;
+    if (want <= 4 && launch8_nw<SPW, FS, 4>(p, st)) return true;
+    return launch8_nw<SPW, FS, 8>(p, st);
 }
 static bool launch_skinny8(const SkinnyParams& p, int spw, int fs, hipStream_t st) {
     const char* e = getenv("QTTS_SKINNY8");

@@ -13,10 +13,10 @@ import synth
 from qwen3_tts_amd.talker import TalkerEngine
 
 CONFIGS = {
-    "default": {},
-    "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},     # 8 waves per workgroup for every K (default: 4 waves up to K = 3072)
-    "fs_min_wgs_48": {"QTTS_FS_MIN_WGS": "48"},  # cp o / down projections in 64 workgroups of 16-feature strips
-    "fs_min_wgs_128": {"QTTS_FS_MIN_WGS": "128"},  # talker o projection / heads in 8-feature strips
+    "default": {},                               # 4 waves per workgroup wherever the registers allow it
+    "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
+    "skinny8_nw2": {"QTTS_SKINNY8_NW": "2"},
+    "skinny8_nw1": {"QTTS_SKINNY8_NW": "1"},
 }
 KEYS = sorted({k for c in CONFIGS.values() for k in c})
 
