@@ -266,7 +266,7 @@ def main():
                                    + str(tj.get(args.model, {}).get("source", tj.get("source", "see profiles/"))) + "), not measured by this run")
                 except Exception:
                     pass
-                res["roofline"] = {"bound": "hbm", "kernel": "skinny_kernel (weight-streaming decode GEMM)",
+                res["roofline"] = {"bound": "hbm", "kernel": "skinny8_kernel (weight-streaming decode GEMM, batch <= 8 instantiations)",
                                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                    "launches_per_frame": per_frame, "avg_launch_us": round(1000 * avg_ms, 3),

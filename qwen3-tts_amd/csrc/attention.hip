@@ -113,6 +113,14 @@ template <> __device__ inline float kv_cast<float>(float v) { return v; }
 template <> __device__ inline bf16_t kv_cast<bf16_t>(float v) { return f32_to_bf16(v); }
 __device__ inline float kv_load(const float* p) { return *p; }
 __device__ inline float kv_load(const bf16_t* p) { return bf16_to_f32(*p); }
+// softmax exponential of the decode attentions.  bf16 cache (the benchmarked mode): v_exp_f32 on x * log2(e), 2 instructions
+// (~1e-7 relative: far inside what the bf16 K / V carry); fp32 cache (the parity mode): the library expf the goldens were taken with
+// -- 10 instructions, and the key loop of attn_tk spends a fifth of its VALU time in them.
+template <typename KVT>
+__device__ inline float att_exp(float x) {
+    if constexpr (sizeof(KVT) == 2) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    else return expf(x);
+}
 
 // element offset of (layer, sequence b, position s, kv head) in a pool [layer][page][kvh][16][hd]
 __device__ inline size_t kv_offset(const KvCache& c, int layer, int b, int s, int kvh) {
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     a += __shfl_xor(a, 2);
     const float s = kk < S1 ? a * rsqrtf((float)HD) : -INFINITY;
     const float m = wave_max64_dpp(s);
-    const float e = kk < S1 ? expf(s - m) : 0.f;
+    const float e = kk < S1 ? att_exp<KVT>(s - m) : 0.f;
     const float l = wave_sum64_dpp(qq == 0 ? e : 0.f);
     float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
@@ -856,10 +864,10 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
             for (int i = 1; i < CH; ++i) mc = fmaxf(mc, sc[i][qi]);
             const float mn = fmaxf(m[qi], mc);
             if (mn == -INFINITY) continue;                   // nothing valid so far in this group
-            const float f = expf(m[qi] - mn);                // (m = -inf -> 0)
+            const float f = att_exp<KVT>(m[qi] - mn);        // (m = -inf -> 0)
             float pr[CH], ps = 0.f;
 #pragma unroll
-            for (int i = 0; i < CH; ++i) { pr[i] = expf(sc[i][qi] - mn); ps += pr[i]; }
+            for (int i = 0; i < CH; ++i) { pr[i] = att_exp<KVT>(sc[i][qi] - mn); ps += pr[i]; }
             l[qi] = l[qi] * f + ps;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -954,7 +962,7 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int gg = 0; gg < 16; ++gg) {
-            const float f = gm[gg][qi] > -INFINITY ? expf(gm[gg][qi] - mm) : 0.f;
+            const float f = gm[gg][qi] > -INFINITY ? att_exp<KVT>(gm[gg][qi] - mm) : 0.f;
             num += red[gg][qi][dd] * f;
             den += gl[gg][qi] * f;
         }

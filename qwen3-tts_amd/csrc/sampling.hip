@@ -367,15 +367,21 @@ __device__ inline float topk_softmax_wave(int n_c, int top_k, int lane, float* c
         kq[q] = i < n_c ? ckey[i] : 0u;
         vq[q] = i < n_c ? cval[i] : -INFINITY;
     }
+    // (two bits per round: the three candidates' counts are independent, so a round costs one vector-compare -> scalar-popcount
+    // round trip instead of two)
     uint32_t thr = 0u;
 #pragma unroll 1
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = thr | (1u << bit);
-        int cnt = 0;
+    for (int lo = 30; lo >= 0; lo -= 2) {
+        const uint32_t c1 = thr | (1u << lo), c2 = thr | (2u << lo), c3 = thr | (3u << lo);
+        int n1 = 0, n2 = 0, n3 = 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            if (NQ <= 2 || q < nq) cnt += __popcll(__ballot(kq[q] >= cand));     // (nq: wave-uniform, a scalar branch)
-        if (cnt >= top_k) thr = cand;
+            if (NQ <= 2 || q < nq) {                                              // (nq: wave-uniform, a scalar branch)
+                n1 += __popcll(__ballot(kq[q] >= c1));
+                n2 += __popcll(__ballot(kq[q] >= c2));
+                n3 += __popcll(__ballot(kq[q] >= c3));
+            }
+        thr = n3 >= top_k ? c3 : (n2 >= top_k ? c2 : (n1 >= top_k ? c1 : thr));
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -479,9 +485,10 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
     {
         const uint32_t mk = gkey[lane];
 #pragma unroll 1
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t cand = T0 | (1u << bit);
-            if (__popcll(__ballot(mk >= cand)) >= p.top_k) T0 = cand;
+        for (int lo = 30; lo >= 0; lo -= 2) {                  // two bits per round (see topk_softmax_wave)
+            const uint32_t c1 = T0 | (1u << lo), c2 = T0 | (2u << lo), c3 = T0 | (3u << lo);
+            const int n1 = __popcll(__ballot(mk >= c1)), n2 = __popcll(__ballot(mk >= c2)), n3 = __popcll(__ballot(mk >= c3));
+            T0 = n3 >= p.top_k ? c3 : (n2 >= p.top_k ? c2 : (n1 >= p.top_k ? c1 : T0));
         }
     }
     // ---- 3. compaction in sample_kernel's slot order (wave, slice, lane)

@@ -10,7 +10,10 @@
 // says when the data HAS ARRIVED; that wait also changes the schedule after it, so the variant measures latencies, not the
 // product's throughput.  In the product build every macro below expands to nothing.
 #pragma once
-#ifdef QTTS_TSTAMP
+#ifndef QTTS_TSTAMP
+#define QTTS_TSTAMP 0
+#endif
+#if QTTS_TSTAMP
 namespace qtts {
 struct TsRec { unsigned long long t[6]; int kind, a, b, blk; };
 constexpr unsigned TS_CAP = 1u << 15;

@@ -367,6 +367,7 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clzll(long long v) { return v == 0 ? 64 : __builtin_clzll((unsigned long long)v); }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) simt::update_dpp((old), (src), (ctrl), __COUNTER__ + 1)
 #define __builtin_amdgcn_wave_barrier() ((void)simt::ballot(1, __COUNTER__ + 1))   /* a wave-level sync point for the emulator: lanes exchange data through LDS around it */
+#define __builtin_amdgcn_exp2f(x) exp2f(x)                                  /* v_exp_f32 */
 #define __builtin_amdgcn_sinf(x) sinf((x) * 6.283185307179586f)        /* v_sin_f32: input in revolutions */
 #define __builtin_amdgcn_readfirstlane(v) (v)     /* only ever applied to wave-uniform values */
 #define __builtin_amdgcn_readlane(v, l) simt::shfl_any((v), (l), __COUNTER__ + 1)
