@@ -650,7 +650,7 @@ static void launch8_n(const SkinnyParams& p, hipStream_t st) {
     else hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, false, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
 }
 // waves per workgroup: fewer waves = fewer partial sums to combine and a shorter barrier, more tile pairs (registers) per wave.
-// Default 4 up to K = 3072 (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame with 8, both repetitions), 8 for K = 6144;
+// Default 4 for matrices below 16 MB (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame with 8, both repetitions), 8 above;
 // QTTS_SKINNY8_NW = 8 | 4 | 2 | 1 asks for another count where that instantiation exists (A/B; read per launch).
 template <int SPW, int FS, int NW>
 static bool launch8_nw(const SkinnyParams& p, hipStream_t st) {
@@ -671,7 +671,10 @@ static bool launch8_nw(const SkinnyParams& p, hipStream_t st) {
 template <int SPW, int FS>
 static bool launch8_fs(const SkinnyParams& p, hipStream_t st) {
     const char* e = getenv("QTTS_SKINNY8_NW");
-    const int want = (e && (e[0] == '8' || e[0] == '4' || e[0] == '2' || e[0] == '1')) ? e[0] - '0' : 4;
+    // (matrices of 16 MB and more -- the talker's qkv, gate/up and down projections -- are bound by the stream itself and keep 8
+    // waves: in-kernel timestamps of GPU call 18, 8 vs 4 waves: 3.83 vs 4.15, 8.5 vs 9.4, 5.95 vs 6.6 us)
+    const int dflt = (size_t)p.N * p.K * 2 >= ((size_t)16 << 20) ? 8 : 4;
+    const int want = (e && (e[0] == '8' || e[0] == '4' || e[0] == '2' || e[0] == '1')) ? e[0] - '0' : dflt;
     if (want <= 1 && launch8_nw<SPW, FS, 1>(p, st)) return true;
     if (want <= 2 && launch8_nw<SPW, FS, 2>(p, st)) return true;
     if (want <= 4 && launch8_nw<SPW, FS, 4>(p, st)) return true;

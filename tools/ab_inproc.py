@@ -13,10 +13,9 @@ import synth
 from qwen3_tts_amd.talker import TalkerEngine
 
 CONFIGS = {
-    "default": {},                               # 4 waves per workgroup wherever the registers allow it
+    "default": {},                               # 4 waves per workgroup below 16 MB, 8 above
     "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
-    "skinny8_nw2": {"QTTS_SKINNY8_NW": "2"},
-    "skinny8_nw1": {"QTTS_SKINNY8_NW": "1"},
+    "skinny8_nw4": {"QTTS_SKINNY8_NW": "4"},
 }
 KEYS = sorted({k for c in CONFIGS.values() for k in c})
 

@@ -10,5 +10,5 @@ run() { local name=$1 lim=$2; shift 2; local t0=$(date +%s)
         echo "$name rc=$rc $(( $(date +%s) - t0 ))s" | tee -a "$OUT/summary.txt"; tail -n ${TAILN:-12} "$OUT/$name.log" | cut -c1-400 | sed "s/^/    /"; }
 : > "$OUT/summary.txt"
 run ab 600 python tools/ab_inproc.py --frames 40 --reps 3
-run pytest_subset 600 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "bf16 or metric"
+run pytest_subset 600 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "metric"
 cat "$OUT/summary.txt"
