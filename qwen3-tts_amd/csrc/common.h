@@ -88,6 +88,19 @@ __device__ __forceinline__ float wave_max64_dpp(float v) {
     v = row16_max(v);
     return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each 16-lane row on DPP rotations (what a rotation wraps around
+// is masked by the lane index), then the running totals of the rows below via readlane -- ~16 VALU instructions instead of six
+// ds_bpermute round trips
+__device__ __forceinline__ float wave_incl_scan64_dpp(float v, int lane) {
+    const int li = lane & 15, row = lane >> 4;
+    float t;
+    t = dpp_mov<0x121>(v); v += li >= 1 ? t : 0.f;
+    t = dpp_mov<0x122>(v); v += li >= 2 ? t : 0.f;
+    t = dpp_mov<0x124>(v); v += li >= 4 ? t : 0.f;
+    t = dpp_mov<0x128>(v); v += li >= 8 ? t : 0.f;
+    const float r0 = lane_bcast(v, 15), r1 = lane_bcast(v, 31), r2 = lane_bcast(v, 47);
+    return v + (row == 0 ? 0.f : (row == 1 ? r0 : (row == 2 ? r0 + r1 : (r0 + r1) + r2)));
+}
 
 
 // ------------------------------------------------------------------------------------------ device memory

@@ -386,8 +386,7 @@ __device__ inline float topk_softmax_wave(int n_c, int top_k, int lane, float* c
     float mx = -INFINITY;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) mx = fmaxf(mx, vq[q]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max64_dpp(mx);
     float tot = 0.f;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -398,9 +397,7 @@ __device__ inline float topk_softmax_wave(int n_c, int top_k, int lane, float* c
             tot += e;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-    return tot;
+    return wave_sum64_dpp(tot);           // (rows summed on DPP rotations, the four row sums in a fixed order)
 }
 
 // Round 2 (measured 1.1 % faster per frame, profiles/r02_ab_variants.md, now the default): the sampling path for 0 < top_k <= 64 and V <= 4096 (the
@@ -556,14 +553,12 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
             for (int i0 = 0; i0 < n_c && pick < 0; i0 += 64) {
                 const int i = i0 + lane;
                 const float e = i < n_c ? cval[i] : 0.f;
-                float inc = e;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+                const float inc = wave_incl_scan64_dpp(e, lane);
                 const unsigned long long nz = __ballot(e > 0.f);
                 if (nz) last = i0 + 63 - __clzll((long long)nz);
                 const unsigned long long hit = __ballot(e > 0.f && run + inc > target);
                 if (hit) pick = i0 + __ffsll((long long)hit) - 1;
-                run += __shfl(inc, 63);
+                run += lane_bcast(inc, 63);
             }
             if (pick < 0) pick = last;
             if (lane == 0) pick_lo = cidx[pick];
