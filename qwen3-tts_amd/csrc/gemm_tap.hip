@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
 //     the activated copy goes out as bf16 (C16), and the stand-alone snake passes disappear from the decoder blocks.
 // Tile 128 x BN, 4 waves (2 x 2), each wave 64 x BN/2 as 4 x BN/32 MFMA 16x16x32 tiles per 32 of k.
 template <int BN, int BK>
-__global__ __launch_bounds__(256) void gemm_tap2_kernel(GemmTapParams p, int halo, int cap /* rows of one A buffer: 128 + halo, rounded up */) {
+__global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int halo, int cap /* rows of one A buffer: 128 + halo, rounded up */) {
     constexpr int BM = 128;
     constexpr int TM = 4, TN = BN / 32;
     constexpr int STR = BK + 8;                        // LDS row stride (bf16 elements): 16-B aligned, rows shift by 4 banks
