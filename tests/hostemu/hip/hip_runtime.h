@@ -31,7 +31,7 @@ inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 // `__shared__` -> `static` (one workgroup runs at a time) in the copies of the kernel sources it compiles.
 #include <cmath>
 #define __global__
-#define __launch_bounds__(n)
+#define __launch_bounds__(...)
 struct alignas(16) float4 { float x, y, z, w; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct alignas(8) float2 { float x, y; };
