@@ -739,6 +739,33 @@ def test_build_variants_are_opt_in_only():
             assert re.search(r"#ifndef %s\s*\n#define %s 0" % (macro, macro), text), macro
 
 
+def test_frame_step_kernels_issue_their_requests_back_to_back(libqtts):
+    """Round 2 found the frame step's latency in the compiler's wait placement, not in the algorithm: a conditional load (or a
+    load behind a run-time `contiguous ? arithmetic : page_table[...]`) makes the compiler wait for ALL outstanding loads before
+    the next request (profiles/r02_isa_serialized_waits.md; attn_tk 9.2 -> 6.2 us once fixed).  This pins the fix in the gfx950
+    code objects of the built library: the decode GEMM of batch <= 8 issues every request before its first `s_waitcnt vmcnt`,
+    the two decode attentions issue their whole first burst (this step's row, norm weights, cache rows / speculative chunks)."""
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_waits
+    ks = isa_waits.kernels(os.path.join(ROOT, "qwen3-tts_amd", "libqtts.so"))
+    s8 = {n: ins for n, ins in ks.items() if "skinny8_kernel<" in n}
+    assert len(s8) >= 30, len(s8)
+    for n, ins in s8.items():
+        n_loads = sum(isa_waits.is_load(i) for i in ins)
+        assert n_loads >= 6, (n, n_loads)
+        assert isa_waits.waits_inside_burst(ins, n_loads) == [], (n, "a wait between the requests of the launch")
+    first_burst = {"attn_cp_kernel<unsigned short, true>": 25,       # 2 row + 3 norm / rope + 4 K + 16 V requests
+                   "attn_tk_kernel<unsigned short, 2, true>": 29,    # 8 row + 5 norm / rope + 16 speculative K / V chunk requests
+                   "attn_tk_kernel<unsigned short, 1, true>": 27}
+    for key, n_first in first_burst.items():
+        hit = [ins for n, ins in ks.items() if key in n]
+        assert len(hit) == 1, key
+        assert isa_waits.waits_inside_burst(hit[0], n_first) == [], (key, "a wait inside the first request burst")
+
+
 def test_ctypes_argtypes_match_the_header(libqtts):
     """Every entry point's ctypes signature in qwen3-tts_amd/_lib.py against its prototype in include/qtts.h: same number of
     parameters and the same class of each (pointer / int32 / int64 / float).  The emulator tests declare their own
