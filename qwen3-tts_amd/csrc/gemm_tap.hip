@@ -426,8 +426,12 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
     constexpr int CPR = BK / 8;                        // 16-B chunks per row
     constexpr int MAXROWS = BM + 56;                   // 7 taps x dilation 9 -> halo 54
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_t2[];
-    bf16_t* As = reinterpret_cast<bf16_t*>(smem_t2);                       // [2][cap][STR]  (LDS is sized for the actual halo:
-    bf16_t* Ws = As + 2 * cap * STR;                                       // [2][BN][STR]    occupancy 2-3 workgroups per CU)
+    // The staged input tile is needed in TWO buffers only when every step changes the k-slab (1 tap).  With several taps a slab
+    // lives for `taps` steps: one buffer and one extra barrier per slab change, and the smaller LDS footprint keeps one more
+    // workgroup per CU resident (C = 96, halo 54: 44.8 -> 30.1 KB) -- occupancy is what hides this kernel's latency.
+    const int abufs = p.taps > 1 ? 1 : 2;
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem_t2);                       // [abufs][cap][STR]  (LDS is sized for the actual halo)
+    bf16_t* Ws = As + abufs * cap * STR;                                   // [2][BN][STR]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
         }
     };
     auto store_a = [&](int buf) {
-        bf16_t* dst = As + buf * cap * STR;
+        bf16_t* dst = As + (abufs == 2 ? buf : 0) * cap * STR;
 #pragma unroll
         for (int i = 0; i < AREG; ++i) {
             const int idx = tid + 256 * i;
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
         if (more) load_w(ks2, tap2);                   // global loads stay in flight under the MFMAs
         if (new_slab) load_a(ks2);
         {
-            const bf16_t* Ab = As + (ks & 1) * cap * STR;
+            const bf16_t* Ab = As + (abufs == 2 ? (ks & 1) : 0) * cap * STR;
             const bf16_t* Wb = Ws + (s & 1) * BN * STR;
             const int sh = p.shift[tap];               // <= 0: output row m reads staged row (m - m0) + halo + sh
 #pragma unroll
@@ -536,7 +540,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
         }
         if (more) {                                    // the other buffers were last read one step (W) / one slab (A) ago
             store_w((s + 1) & 1);
-            if (new_slab) store_a(ks2 & 1);
+            if (new_slab) {
+                if (abufs == 1) __syncthreads();       // every wave is done with the slab that is about to be overwritten
+                store_a(ks2 & 1);
+            }
         }
         __syncthreads();
     }
@@ -547,7 +554,7 @@ template <int BN, int BK>
 static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
     const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
     const int cap = (128 + halo + 7) & ~7;
-    const size_t lds = ((size_t)2 * cap + 2 * BN) * (BK + 8) * 2;
+    const size_t lds = ((size_t)(p.taps > 1 ? 1 : 2) * cap + 2 * BN) * (BK + 8) * 2;
     auto kern = gemm_tap2_kernel<BN, BK>;
     static bool attr_set = false;
     if (!attr_set) {
