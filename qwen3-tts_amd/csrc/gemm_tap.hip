@@ -22,6 +22,9 @@
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
+#include "tstamp.h"
+
+QTTS_TS_UNIT(tap)
 
 namespace qtts {
 
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
     const int abufs = p.taps > 1 ? 1 : 2;
     bf16_t* As = reinterpret_cast<bf16_t*>(smem_t2);                       // [abufs][cap][STR]  (LDS is sized for the actual halo)
     bf16_t* Ws = As + abufs * cap * STR;                                   // [2][BN][STR]
+    QTTS_TS_BEGIN();                       // (tstamp build: 1 = prologue done, 2 / 3 = after step 1 / step 1 + 2 taps, 4 = k-loop done, 5 = stored)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
     load_a(0); load_w(0, 0);
     store_a(0); store_w(0);
     __syncthreads();
+    QTTS_TS(1);
     for (int s = 0; s < nsteps; ++s) {
         const int ks = s / p.taps, tap = s - ks * p.taps;
         const bool more = s + 1 < nsteps;
@@ -546,8 +551,15 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
             }
         }
         __syncthreads();
+#if QTTS_TSTAMP
+        if (s == 0) QTTS_TS(2);
+        if (s == 2 * p.taps) QTTS_TS(3);
+#endif
     }
+    QTTS_TS(4);
     tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);
+    QTTS_TS_DRAINED(5);
+    QTTS_TS_END(tap, 4, p.K * p.taps, p.N);
 }
 
 template <int BN, int BK>
