@@ -154,7 +154,8 @@ struct qtts_codec {
     // bf16 mode, decoder blocks: the same GEMM with a bf16 input (A16, selects gemm_tap2) and / or a bf16 copy of the result
     // (C16) that already carries the next consumer's SnakeBeta (sn16); C may be null when only the bf16 copy is consumed
     void gemm16(const Lin& l, const float* A, const bf16_t* A16, int lda, int M, int T, float* C, int ldc, int act, const float* res,
-                int ldr, const Snake* sn, bf16_t* C16, const Snake* sn16, hipStream_t st, int sn16_period = 0) {
+                int ldr, const Snake* sn, bf16_t* C16, const Snake* sn16, hipStream_t st, int sn16_period = 0,
+                const bf16_t* res16 = nullptr, bf16_t* R16 = nullptr) {
         GemmTapParams p{};
         p.A = A; p.A16 = A16; p.lda = lda; p.M = M; p.T = T; p.W = l.W.p; p.N = l.N; p.K = l.K; p.taps = l.taps;
         for (int i = 0; i < 8; ++i) p.shift[i] = l.shift[i];
@@ -165,6 +166,7 @@ struct qtts_codec {
         p.C16 = C16; p.ldc16 = ldc; p.act16 = sn16 ? ACT_SNAKE : ACT_NONE;
         p.snake16_ea = sn16 ? sn16->ea.as<float>() : nullptr; p.snake16_ib = sn16 ? sn16->ib.as<float>() : nullptr;
         p.snake16_period = sn16_period;
+        p.res16 = res16; p.ldres16 = ldr; p.R16 = R16; p.ldR16 = ldc;
         launch_gemm_tap(p, bf16, st);
     }
 
@@ -467,6 +469,14 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     for (auto& bk : blocks) fast16 = fast16 && bk.cin % 32 == 0 && bk.cout % 32 == 0;
     bf16_t* h16a = fast16 ? buf16[0].as<bf16_t>() : nullptr;
     bf16_t* h16b = fast16 ? buf16[1].as<bf16_t>() : nullptr;
+    // ... and (second half of round 2) the residual stream inside the blocks travels as bf16 too, as in the reference's own bf16
+    // mode: the 1x1 convolution of a residual unit is HBM-bound, and 98 of its 148 KB per tile were the fp32 residual read + write
+    // (profiles/r02_tstamp_codec_gemm.md).  fp32 again where a tensor leaves the blocks (the last unit; any requested stage).
+    // Measured (GPU call 28, 8 x 10 s): 13.38 ms with, 13.54 ms without, relative RMS against the reference's fp32 waveform 0.052
+    // vs 0.049 -- the 1x1 convolutions turned out not to be HBM-bound after all, so the fp32 residual stream stays the default and
+    // QTTS_CODEC_RES16=1 selects the bf16 one.
+    static const bool res16_env = [] { const char* e = getenv("QTTS_CODEC_RES16"); return e && atoi(e) != 0; }();
+    const bool res16 = fast16 && res16_env && !stage;
     // ---- decoder.0: conv k=7 latent -> decoder_dim (v2:857)
     {
         float *a, *b, *cc; scratch3(a, b, cc);
@@ -482,7 +492,9 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
         if (fast16) {
             // h16a = SnakeBeta_block(x) in bf16 (from the previous producer).  tconv -> b (fp32, the first unit's residual) and
             // h16a' = SnakeBeta_unit0.act1(b)
-            gemm16(bk.tconv, nullptr, h16a, C, B * L, L, b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st, bk.cout);
+            // (res16: the residual goes out as bf16 into b's storage instead)
+            gemm16(bk.tconv, nullptr, h16a, C, B * L, L, res16 ? nullptr : b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st,
+                   bk.cout, nullptr, res16 ? reinterpret_cast<bf16_t*>(b) : nullptr);
             std::swap(h16a, h16b);                 // h16a: activated input of unit 0; h16b: free
             L *= bk.r; C = bk.cout;
             float* cur = b; float* alt = a;        // (a was only the stand-alone snake's output in the fp32 path: free here)
@@ -490,7 +502,15 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
                 auto& un = bk.u[j];
                 const Snake* next = j < 2 ? &bk.u[j + 1].a1 : (i + 1 < blocks.size() ? &blocks[i + 1].act : nullptr);
                 gemm16(un.c1, nullptr, h16a, C, B * L, L, nullptr, C, ACT_SNAKE, nullptr, 0, &un.a2, h16b, nullptr, st);   // conv7 + act2 -> bf16
-                gemm16(un.c2, nullptr, h16b, C, B * L, L, alt, C, ACT_NONE, cur, C, nullptr, next ? h16a : nullptr, next, st);  // 1x1 + residual
+                // the last unit of a block feeds only the next block's transposed conv (the activated bf16 copy): its residual-stream
+                // output is written only where the tensor leaves the blocks (last block) or a stage was asked for
+                const bool leaves = j == 2 && i + 1 == blocks.size();
+                const bool dead = j == 2 && !leaves && !stage;
+                if (res16) {                       // 1x1 + bf16 residual -> bf16 residual (fp32 where the tensor leaves the blocks)
+                    gemm16(un.c2, nullptr, h16b, C, B * L, L, leaves ? alt : nullptr, C, ACT_NONE, nullptr, C, nullptr, next ? h16a : nullptr, next, st, 0,
+                           reinterpret_cast<const bf16_t*>(cur), (leaves || dead) ? nullptr : reinterpret_cast<bf16_t*>(alt));
+                } else
+                gemm16(un.c2, nullptr, h16b, C, B * L, L, dead ? nullptr : alt, C, ACT_NONE, cur, C, nullptr, next ? h16a : nullptr, next, st);  // 1x1 + residual
                 std::swap(cur, alt);               // ping-pong between a and b: the residual input is never the output
             }
             x = cur;

@@ -91,7 +91,9 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
                     else if (p.act == ACT_SILU) v = v / (1.f + expf(-v));
                     v *= p.scale ? p.scale[n] : 1.f;
                     if (p.res) v += p.res[(size_t)m * p.ldr + n];
+                    else if (p.res16) v += bf16_to_f32(reinterpret_cast<const bf16_t*>(p.res16)[(size_t)m * p.ldres16 + n]);
                     if (p.C) p.C[(size_t)m * p.ldc + n] = v;
+                    if (p.R16) reinterpret_cast<bf16_t*>(p.R16)[(size_t)m * p.ldR16 + n] = f32_to_bf16(v);
                     if (p.C16) {
                         if (p.act16 == ACT_SNAKE) { const int n16 = p.snake16_period > 0 ? n % p.snake16_period : n; v = snake1<FAST>(v, p.snake16_ea[n16], p.snake16_ib[n16]); }
                         reinterpret_cast<bf16_t*>(p.C16)[(size_t)m * p.ldc16 + n] = f32_to_bf16(v);
@@ -100,47 +102,65 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
             }
         return;
     }
+    // Everything a column quad needs from memory -- parameters, then the TM residual vectors -- is requested UNCONDITIONALLY and
+    // back to back (absent operands read W, rows past M re-read row M - 1; selected afterwards).  With `ptr ? *ptr : 0` every one
+    // of these loads was merged with a constant and waited for before the next one was issued: the epilogue of a 1x1 convolution
+    // tile spent 17.6 us in 12 serialized residual round trips (profiles/r02_tstamp_codec_gemm.md).
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    const float* dummy = reinterpret_cast<const float*>(p.W);        // any readable, 16-byte aligned address
+    const bool snake = p.act == ACT_SNAKE, snake16 = p.C16 && p.act16 == ACT_SNAKE;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {                                   // one column quad of this lane at a time
         const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4;
         if (n >= p.N) continue;                                      // (N % 4 == 0: a quad is in or out as a whole)
-        // everything this quad needs from memory is requested first: parameters, then the TM residual vectors
-        const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
-        const f32x4 scale = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : one4;
-        f32x4 ea = zero4, ib = zero4, ea16 = zero4, ib16 = zero4;
-        if (p.act == ACT_SNAKE) { ea = *reinterpret_cast<const f32x4*>(p.snake_ea + n); ib = *reinterpret_cast<const f32x4*>(p.snake_ib + n); }
-        if (p.C16 && p.act16 == ACT_SNAKE) {
-            const int n16 = p.snake16_period > 0 ? n % p.snake16_period : n;       // (period % 4 == 0)
-            ea16 = *reinterpret_cast<const f32x4*>(p.snake16_ea + n16); ib16 = *reinterpret_cast<const f32x4*>(p.snake16_ib + n16);
-        }
+        const int n16 = p.snake16_period > 0 ? n % p.snake16_period : n;       // (period % 4 == 0)
+        f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias ? p.bias + n : dummy);
+        f32x4 scale = *reinterpret_cast<const f32x4*>(p.scale ? p.scale + n : dummy);
+        const f32x4 ea = *reinterpret_cast<const f32x4*>(snake ? p.snake_ea + n : dummy);
+        const f32x4 ib = *reinterpret_cast<const f32x4*>(snake ? p.snake_ib + n : dummy);
+        const f32x4 ea16 = *reinterpret_cast<const f32x4*>(snake16 ? p.snake16_ea + n16 : dummy);
+        const f32x4 ib16 = *reinterpret_cast<const f32x4*>(snake16 ? p.snake16_ib + n16 : dummy);
         f32x4 res[TM];
+        uint2 rh[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + li;
-            res[i] = (p.res && m < p.M) ? *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + n) : zero4;
+            const int m = m0 + wm * 64 + i * 16 + li, mc = m < p.M ? m : p.M - 1;
+            res[i] = *reinterpret_cast<const f32x4*>(p.res ? p.res + (size_t)mc * p.ldr + n : dummy);
+            rh[i] = *reinterpret_cast<const uint2*>(p.res16 ? reinterpret_cast<const bf16_t*>(p.res16) + (size_t)mc * p.ldres16 + n
+                                                            : reinterpret_cast<const bf16_t*>(dummy));
         }
+        if (!p.bias) bias = zero4;
+        if (!p.scale) scale = one4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * 64 + i * 16 + li;
             if (m >= p.M) continue;
+            f32x4 r = zero4;
+            if (p.res) r = res[i];
+            else if (p.res16) r = (f32x4){__uint_as_float(rh[i].x << 16), __uint_as_float(rh[i].x & 0xffff0000u),
+                                          __uint_as_float(rh[i].y << 16), __uint_as_float(rh[i].y & 0xffff0000u)};
             f32x4 v = acc[i][j] + bias;
             if (p.act == ACT_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752440f));
+                for (int r2 = 0; r2 < 4; ++r2) v[r2] = 0.5f * v[r2] * (1.f + erff(v[r2] * 0.70710678118654752440f));
             } else if (p.act == ACT_SNAKE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = snake1<FAST>(v[r], ea[r], ib[r]);
+                for (int r2 = 0; r2 < 4; ++r2) v[r2] = snake1<FAST>(v[r2], ea[r2], ib[r2]);
             } else if (p.act == ACT_SILU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + expf(-v[r]));
+                for (int r2 = 0; r2 < 4; ++r2) v[r2] = v[r2] / (1.f + expf(-v[r2]));
             }
-            v = v * scale + res[i];
+            v = v * scale + r;
             if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            if (p.R16) {               // the residual stream in bf16 (before the consumer's activation)
+                uint2 h;
+                h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.R16) + (size_t)m * p.ldR16 + n) = h;
+            }
             if (p.C16) {               // bf16 copy for a GEMM consumer, with that consumer's SnakeBeta folded in
                 if (p.act16 == ACT_SNAKE) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = snake1<FAST>(v[r], ea16[r], ib16[r]);
+                    for (int r2 = 0; r2 < 4; ++r2) v[r2] = snake1<FAST>(v[r2], ea16[r2], ib16[r2]);
                 }
                 uint2 h;
                 h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);
@@ -606,6 +626,8 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
     // the epilogue moves 4-column vectors (16 B fp32 / 8 B bf16) whenever shapes and pointers allow it
     auto al16 = [](const void* q) { return reinterpret_cast<uintptr_t>(q) % 16 == 0; };
     p.vec4 = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.res || p.ldr % 4 == 0) && (!p.C16 || (p.ldc16 % 4 == 0 && reinterpret_cast<uintptr_t>(p.C16) % 8 == 0)) &&
+             (!p.res16 || (p.ldres16 % 4 == 0 && reinterpret_cast<uintptr_t>(p.res16) % 8 == 0)) &&
+             (!p.R16 || (p.ldR16 % 4 == 0 && reinterpret_cast<uintptr_t>(p.R16) % 8 == 0)) &&
              al16(p.C) && al16(p.res) && al16(p.bias) && al16(p.scale) && al16(p.snake_ea) && al16(p.snake_ib) && al16(p.snake16_ea) &&
              al16(p.snake16_ib) && (p.snake16_period % 4 == 0);
     if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.ldc % 4 == 0 && al16(p.C), QTTS_ERR_ARG, "gemm_tap: swiglu output must be 16-byte aligned with ldc % 4 == 0");
@@ -613,7 +635,8 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         QTTS_REQUIRE(bf16, QTTS_ERR_ARG, "gemm_tap: A16 needs bf16 weights");
         QTTS_REQUIRE(p.act != ACT_SWIGLU, QTTS_ERR_ARG, "gemm_tap: the A16 kernel has no SwiGLU epilogue");
         QTTS_REQUIRE(p.lda % 8 == 0, QTTS_ERR_ARG, "gemm_tap: bf16 A needs lda % 8 == 0");
-        QTTS_REQUIRE(p.C || p.C16, QTTS_ERR_ARG, "gemm_tap: no output");
+        QTTS_REQUIRE(p.C || p.C16 || p.R16, QTTS_ERR_ARG, "gemm_tap: no output");
+        QTTS_REQUIRE(!(p.res && p.res16), QTTS_ERR_ARG, "gemm_tap: residual given twice");
         int halo = 0;
         for (int i = 0; i < p.taps; ++i) { QTTS_REQUIRE(p.shift[i] <= 0, QTTS_ERR_ARG, "gemm_tap: shift > 0"); halo = std::max(halo, -p.shift[i]); }
         QTTS_REQUIRE(halo <= 56, QTTS_ERR_LIMIT, "gemm_tap: tap reach > 56 rows");
@@ -625,6 +648,7 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         return;
     }
     QTTS_REQUIRE(p.C, QTTS_ERR_ARG, "gemm_tap: null output");
+    QTTS_REQUIRE(!p.res16 && !p.R16, QTTS_ERR_ARG, "gemm_tap: the bf16 residual stream needs the A16 kernel");
     int bn;
     if (p.act == ACT_SWIGLU) {
         QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "gemm_tap: swiglu needs N % 32 == 0");

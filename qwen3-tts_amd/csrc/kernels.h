@@ -29,6 +29,10 @@ struct GemmTapParams {
     const float* snake16_ea; const float* snake16_ib;
     int snake16_period;          // > 0: the act16 parameters repeat with this period over the N columns (transposed conv: N = r * Cout)
     int vec4;                    // set by launch_gemm_tap: N / leading dimensions / pointers allow 4-column vector epilogue accesses
+    // ---- bf16 residual stream (codec decoder blocks): the 1x1 convolutions of the residual units are HBM-bound and most of their
+    // bytes were the fp32 residual tile read + written (profiles/r02_tstamp_codec_gemm.md)
+    const void* res16; int ldres16;   // residual as bf16 [M][ldres16] (alternative to res)
+    void* R16; int ldR16;             // optional bf16 output of v BEFORE act16 = the residual stream of the next unit
 };
 void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
 
