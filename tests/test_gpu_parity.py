@@ -491,6 +491,43 @@ def test_bf16_mode_pinned_at_the_metric_config_teacher_forced(dev, golden_dir):
     assert a0 >= 0.93 and asub >= 0.85 and np.mean(rmse32) <= 0.035
 
 
+def test_pair_kernel_equals_the_generic_decode_gemm_on_the_frame_step(dev, golden_dir):
+    """`skinny8_kernel` (round 2: tile pairs, whole-line requests, DPP-rotated odd tiles, 4 or 8 waves) against `skinny2_kernel`
+    (QTTS_SKINNY8=0) on the hardware, through the whole frame step: 0.6B dims, batch 8, bf16, 40 frames teacher-forced with the
+    reference's golden codes, eager launches (the switch is read per launch).  Both kernels compute the same sums in a different
+    order: the raw cb-0 logits must agree to 0.5 % relative RMS and the teacher-forced cb-0 decisions to 97 %.  (The 15
+    sub-codebooks run free inside a frame on seeded random weights with near-flat logits: a rounding-level flip in one pass
+    changes the passes after it, so their agreement -- 0.91 measured; cb-0 0.988, logits 0.31 % -- is reported, not asserted.)"""
+    from qwen3_tts_amd.talker import TalkerEngine
+    cfg = synth.talker_06b()
+    g = np.load(os.path.join(golden_dir, "talker_06b_b8.npz"))
+    wn = synth.talker_weights(cfg, with_text=False)
+    lens = [int(x) for x in g["lens"]]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+    gc = torch.from_numpy(g["codes"][:, :40].copy())
+    steps = [0, 1, 7, 20, 39]
+    res = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["QTTS_SKINNY8"] = flag
+            eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=False)
+            out = eng.generate(emb, mask, tr, pad, teacher_codes=gc, logit_steps=steps, suppress_tokens=_suppress(cfg))
+            res[flag] = (out.own.cpu().numpy(), out.logits_trace.cpu().numpy())
+            del eng
+            torch.cuda.empty_cache()
+    finally:
+        os.environ.pop("QTTS_SKINNY8", None)
+    own8, lt8 = res["1"]
+    own2, lt2 = res["0"]
+    agree0 = float((own8[:, :, 0] == own2[:, :, 0]).mean())
+    agree = float((own8 == own2).mean())
+    rel = float(np.sqrt(((lt8 - lt2) ** 2).mean()) / np.sqrt((lt2.astype(np.float64) ** 2).mean()))
+    print(f"skinny8 vs skinny2 on the frame step (0.6B, 8 x 40 frames, teacher-forced): cb-0 decisions agree {agree0:.4f}, all 16 codebooks "
+          f"{agree:.4f}, cb-0 logit rel. RMS {rel:.5f}")
+    assert not np.array_equal(lt8, lt2), "QTTS_SKINNY8=0 did not select another kernel"
+    assert agree0 >= 0.97 and rel <= 5e-3
+
+
 def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
     """Sampling cannot be bit-compared (torch's RNG stream is not portable): check the first sampled token's
     empirical distribution over many Philox seeds against the oracle's processed softmax (chi-square), and that
