@@ -534,6 +534,9 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     // second memory round trip)
     const float* nw = wave == 2 ? p.kw : p.qw;
     const float nw0 = nw[lane], nw1 = nw[lane + 64], invf = p.inv_freq[lane];
+    const bool rtab = p.rope_cs && S0 < p.rope_cs_n;                  // (kernel-uniform; the row is requested either way)
+    const float* rrow = rtab ? p.rope_cs + (size_t)S0 * 128 : p.inv_freq;
+    const float ctab = rrow[lane], stab = rrow[rtab ? 64 + lane : lane];
     // cache reads (do not depend on this step's qkv row); only the query waves need them.  Straight-line and unconditional
     // inside the (wave-uniform) branch: key slots >= S0 re-read key 0 and are dropped at the point of use -- a conditional load
     // is merged with the register's previous value, and the compiler waited for each of the 32 V loads before issuing the next
@@ -561,8 +564,8 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
             const float rs = rsqrtf(ss / (float)HD + p.eps);
             x0 = nw0 * (x0 * rs);
             x1 = nw1 * (x1 * rs);
-            const float ang = (float)S0 * invf;
-            const float c = cosf(ang), sn = sinf(ang);
+            float c = ctab, sn = stab;
+            if (!rtab) { const float ang = (float)S0 * invf; c = cosf(ang); sn = sinf(ang); }
             const float o0 = x0 * c - x1 * sn, o1 = x1 * c + x0 * sn;
             x0 = o0; x1 = o1;
         }
@@ -1018,6 +1021,20 @@ static void launch_attn_tk(const AttnDecodeParams& p, int GQ, dim3 grid, hipStre
     if (p.kv.bf16) { if (GQ == 1) launch_attn_tk_c<bf16_t, 1>(p, grid, st); else launch_attn_tk_c<bf16_t, 2>(p, grid, st); }
     else { if (GQ == 1) launch_attn_tk_c<float, 1>(p, grid, st); else launch_attn_tk_c<float, 2>(p, grid, st); }
 }
+// cos | sin table for launch-time-known positions: out[pos][0][i] = cosf(pos * inv_freq[i]), out[pos][1][i] = sinf(...), i < 64 -- the
+// same expression, compiled by the same compiler, as in the attention kernels
+__global__ void rope_table_kernel(const float* inv_freq, int n_pos, float* out) {
+    const int pos = blockIdx.x, i = threadIdx.x;
+    if (pos >= n_pos || i >= 64) return;
+    const float ang = (float)pos * inv_freq[i];
+    out[(size_t)pos * 128 + i] = cosf(ang);
+    out[(size_t)pos * 128 + 64 + i] = sinf(ang);
+}
+void launch_rope_table(const float* inv_freq, int n_pos, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3(n_pos), dim3(64), 0, st, inv_freq, n_pos, out);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
 template <typename KVT, int NQ, bool CT>
 static void launch_attn_decode_c(const AttnDecodeParams& p, size_t lds, hipStream_t st);
 template <typename KVT, int NQ>

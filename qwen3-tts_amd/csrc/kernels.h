@@ -175,8 +175,13 @@ struct AttnDecodeParams {
     // split-KV (talker, long sequences): nsplit > 1 workgroups per (sequence, kv head), each over max_len / nsplit keys, partial
     // results in `part` [B*nkv][nsplit][GQ][128 + 2] fp32 (numerator | max | denominator), merged by a second tiny kernel
     int nsplit; float* part;
+    // optional [rope_cs_n][2][64]: cos | sin of pos * inv_freq for positions < rope_cs_n, filled by launch_rope_table with the very
+    // expression the kernels evaluate (bit-identical); attn_cp (static position, known at launch) requests its row at kernel entry
+    // instead of running sinf / cosf behind the arrival of the qkv row
+    const float* rope_cs; int rope_cs_n;
 };
 void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st);
+void launch_rope_table(const float* inv_freq, int n_pos, float* out, hipStream_t st);
 inline size_t attn_part_floats(int B, int nkv, int nsplit, int gq) { return (size_t)B * nkv * nsplit * gq * 130; }
 
 // --------------------------------------------------------------------------------- sampling.hip

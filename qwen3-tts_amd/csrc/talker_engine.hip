@@ -41,6 +41,7 @@ struct qtts_talker {
     StackDims td, cd;
     std::vector<LayerW> tl, cl;
     DevBuf t_norm, c_norm, head_p, emb_talker, emb_cp, proj_p, proj_b, inv_freq_t, inv_freq_c;
+    DevBuf rope_cs_c;                   // code predictor: cos | sin of its 17 possible positions (launch_rope_table)
     DevBuf cp_qkv0_tab;   // [G-2][cp_vocab][q|k|v width] = layer-0 qkv GEMM (norm folded) of the pass input row of every token
     bool skip_qkv = false;
     DevBuf emb_cp_proj;   // [G-2][cp_vocab][cp H] = small_to_mtp_projection(codec_embedding[g](v)), built at finalize by the decode GEMM itself
@@ -201,7 +202,7 @@ struct qtts_talker {
     // one decoder layer on `M = n_new * B` rows of `xs` (in place)
     void decode_layer(const LayerW& L, const StackDims& d, float* xs, unsigned short* xs16, float* qkvb, float* attb,
                       float* actb, int M, int n_new, KvCache& kv, int layer, const int* len_dev, int len_static,
-                      const int* npad, const float* inv_freq, int max_len, hipStream_t st) {
+                      const int* npad, const float* inv_freq, int max_len, hipStream_t st, const float* rope_cs = nullptr, int rope_cs_n = 0) {
         // xs16: bf16 copy of the hidden state kept in step with xs by every producer (bf16 mode, M <= 16), or null
         const bool h16 = xs16 && skinny_takes_bf16_x(M, d.H, bf16);
         SkinnyParams p{};
@@ -217,6 +218,7 @@ struct qtts_talker {
         a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
         a.len_dev = len_dev; a.len_static = len_static; a.kv = kv; a.layer = layer; a.out = attb; a.ldo = d.qd;
         a.max_len = max_len; a.done_flag = ss.done;
+        a.rope_cs = rope_cs; a.rope_cs_n = rope_cs_n;
         if (len_dev && attn_nsplit_active > 1) { a.nsplit = attn_nsplit_active; a.part = attn_part.as<float>(); }   // talker, long sequences: split-KV
         // bf16 mode: attention output and SwiGLU output travel as bf16 (as in the reference's bf16 path) and are
         // staged into the consuming GEMM by LDS-DMA
@@ -369,6 +371,11 @@ void qtts_talker::finalize() {
     };
     mk_freq(inv_freq_t, "model.rotary_emb.inv_freq", c.rope_theta, td.hd);
     mk_freq(inv_freq_c, "code_predictor.model.rotary_emb.inv_freq", c.cp_rope_theta, cd.hd);
+    if (cd.hd == 128) {                 // (attn_cp's head_dim; positions 0 .. G)
+        rope_cs_c.alloc((size_t)(G + 1) * 128 * sizeof(float));
+        launch_rope_table(inv_freq_c.as<float>(), G + 1, rope_cs_c.as<float>(), nullptr);
+        QTTS_CHECK_HIP(hipDeviceSynchronize());
+    }
 
     // bytes of packed weights one frame step streams (bench.py's roofline numerator)
     const double eb = bf16 ? 2.0 : 4.0;
@@ -562,7 +569,8 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         for (int l = 0; l < c.cp_num_hidden_layers; ++l) {
             skip_qkv = j >= 1 && l == 0;
             decode_layer(cl[l], cd, cp_x.as<float>(), c16, cp_qkv.as<float>(), cp_att.as<float>(), cp_act.as<float>(), M, n_new,
-                         kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st);
+                         kv_c, l, nullptr, j == 0 ? 0 : j + 1, nullptr, inv_freq_c.as<float>(), 32, st, rope_cs_c.as<float>(),
+                         rope_cs_c.p ? G + 1 : 0);
         }
         skip_qkv = false;
         // final norm folded into lm_head[j]; only the LAST token's rows are needed (pass 0: rows [B, 2B))
