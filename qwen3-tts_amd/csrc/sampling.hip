@@ -432,6 +432,10 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
     const int n_gen = p.n_generated_dev ? *p.n_generated_dev : 0;
     const uint32_t step = p.step_dev ? (uint32_t)*p.step_dev : 0u;
     const unsigned long long seed = p.seed_dev ? *p.seed_dev : p.seed;
+    // the first 256 entries of this row's token history (repetition penalty; the talker's call only) are requested here, before the
+    // count is known: behind the flag-clearing barrier below the load was a memory round trip of its own (2-6 us by box)
+    const int* gsrc = p.generated ? p.generated + (size_t)b * p.gen_stride + (tid < p.gen_stride ? tid : 0) : reinterpret_cast<const int*>(lg);
+    const int gtok0 = *gsrc;
     float x[EPT];
     unsigned char sup[EPT];
 #pragma unroll
@@ -447,7 +451,8 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
 #pragma unroll
         for (int it = 0; it < EPT; ++it) sc[it * 256 + tid] = 0.f;
         __syncthreads();
-        for (int i = tid; i < n_gen; i += 256) {
+        if (tid < n_gen && gtok0 >= 0 && gtok0 < V) sc[gtok0] = 1.f;          // entries 0..255: prefetched at entry
+        for (int i = tid + 256; i < n_gen; i += 256) {
             const int tok = p.generated[(size_t)b * p.gen_stride + i];
             if (tok >= 0 && tok < V) sc[tok] = 1.f;
         }
