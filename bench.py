@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--talker-dtype", default="bf16", choices=["bf16", "f32"],
                     help="bf16 = the benchmarked mode (the reference examples' dtype); f32 = the exact-fp32 parity mode")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--overlap-codec", type=int, default=0, metavar="FRAMES",
+                    help="EXPERIMENT (off by default, not the reported configuration): decode packets of FRAMES frames through the "
+                         "state-carrying stream decoder while the talker generates the next ones (streaming-output orchestration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the bounded CPU-baseline sample")
@@ -154,7 +157,21 @@ def main():
         gen_kw.update(do_sample=True, top_k=50, top_p=1.0, temperature=0.9, subtalker_dosample=True, subtalker_top_k=50,
                       subtalker_top_p=1.0, subtalker_temperature=0.9)
 
+    def step_overlapped(seed):
+        # streaming-output orchestration: the talker (own stream) yields packets of codes, each packet goes through the
+        # state-carrying codec stream (concatenated packets == whole-sequence decode) while the next frames are generated
+        codec.stream_begin(B)
+        parts, n = [], 0
+        for pk in talker.generate_stream(emb, mask, trailing, pad, packet_frames=args.overlap_codec, seed=seed, **gen_kw):
+            parts.append(codec.stream_push(pk.transpose(1, 2).contiguous())[:, 0])
+            n += pk.shape[1]
+        assert n == F, f"expected {F} frames, got {n}"
+        wav = torch.cat(parts, dim=1)
+        return None, wav, [wav.shape[1]] * B
+
     def step(seed):
+        if args.overlap_codec > 0:
+            return step_overlapped(seed)
         out = talker.generate(emb, mask, trailing, pad, seed=seed, **gen_kw)
         assert out.n_frames == F, f"expected {F} frames, got {out.n_frames}"
         wav, wl = codec.decode_padded(out.codes)
@@ -176,6 +193,11 @@ def main():
     t1 = time.perf_counter()
     for i in range(args.steps):
         ta = time.perf_counter()
+        if args.overlap_codec > 0:          # (no per-leg split in this mode: the legs overlap)
+            out, wav, wl = step_overlapped(2000 + i)
+            torch.cuda.synchronize()
+            t_ar += time.perf_counter() - ta
+            continue
         out = talker.generate(emb, mask, trailing, pad, seed=2000 + i, **gen_kw)
         torch.cuda.synchronize()
         tb = time.perf_counter()
@@ -233,6 +255,9 @@ def main():
     if world > 1:
         res["gather_ms_per_step"] = round(1000 * t_gather / args.steps, 3)
         res["backend"] = args.backend
+    if args.overlap_codec > 0:
+        res["experiment"] = (f"--overlap-codec {args.overlap_codec}: codec packets of {args.overlap_codec} frames decoded by the state-carrying "
+                             "stream decoder while the talker generates the next frames; NOT the reported configuration")
     if hostemu:
         res["INVALID"] = "host emulation build (QTTS_BENCH_HOSTEMU=1): launcher test only, not a measurement"
 
