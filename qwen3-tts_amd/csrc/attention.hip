@@ -490,15 +490,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeParams p) {
     }
 }
 
-// =================================================================================== attn_cp (A/B variant, build.py VARIANTS)
+// =================================================================================== attn_cp (promoted in round 2)
 // The code predictor's single-token passes (70 of the 103 attention launches of a frame) attend over at most 16 keys, yet
 // go through the general kernel above: 64-key speculative chunks, five workgroup barriers, 16 key groups combined through
 // LDS.  This kernel does the same arithmetic for exactly that case -- one new token, a static cache length S0 <= 15, no
 // left padding, 1 or 2 query heads per kv head, head_dim 128 -- with one barrier:
 //   stage 1 (4 waves):  q head 0 | q head 1 | k | v of the new token: RMSNorm + RoPE (q, k), round through the cache type and
-//                       append (k, v), results to LDS.  The old K rows (key-major: lane = key * 4 + quarter, 32 dims each)
-//                       and old V rows (dim-major: lane owns dims lane and lane + 64 of every key) are requested from the
-//                       cache at kernel entry, before the new row is even read.
+//                       append (k, v), results to LDS.  This step's row, the norm weights and the cos | sin row of the (launch-time
+//                       known) position are requested first, then the old K rows (key-major: lane = key * 4 + quarter, 32
+//                       dims each) and the old V rows (lane owns dims 2 lane, 2 lane + 1 of every key: one 256-B row per
+//                       request) of all 16 key slots, straight-line and unconditional (slots >= S0 re-read key 0).
 //   stage 2 (wave = query): 32-dim partial dot + quad reduction, fp32 softmax across the 16 key slots (DPP), then
 //                       out[d] = sum_k e_k * v[k][d] with e_k broadcast from its lane -- no cross-lane reduction for PV.
 template <typename KVT, bool CT>
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(256) void attn_cp0_kernel(AttnDecodeParams p) {
 
 // =================================================================================== attn_tk (round 2)
 // The talker's single-token decode attention (28 launches per frame; 12.7 us each in the general kernel above, ~60 us at 800
-// keys).  Same loads, same key ownership (key s -> 16-lane group s % 16, 8 dims per lane, 64 keys per chunk, the first chunks
+// keys; 6.5 us after the second half of round 2: contiguous-pool page index as a template parameter CT, v_exp_f32).  Same loads, same key ownership (key s -> 16-lane group s % 16, 8 dims per lane, 64 keys per chunk, the first chunks
 // requested speculatively at kernel entry), but flash-decoding INSIDE the workgroup:
 //   * no workgroup-wide score buffer and no softmax phase: every 16-lane group keeps its own running (max, sum, PV accumulator)
 //     over its keys in registers (online softmax: a chunk of 4 keys costs one rescale); the 16 partial results are merged once,
