@@ -45,7 +45,7 @@ const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
  * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
  * 6: + qtts_talker_stream_*). */
-#define QTTS_ABI_VERSION 7
+#define QTTS_ABI_VERSION 8
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -364,8 +364,23 @@ typedef struct {
     double weight_bytes_per_frame; /* bytes of packed weights one frame step streams              */
     double gemm_ms_last;      /* HIP-event time of the dominant kernel class over the call, if enabled */
     int64_t gemm_launches_last;
+    int32_t long_graphs;      /* long-sequence frame graphs captured so far (one per KV-length bucket, ABI v8) */
+    int32_t attn_nsplit_last; /* split-KV workgroups per (sequence, kv head) of the last launched frame step (1 = short mode) */
+    int32_t attn_span_last;   /* the key span those workgroups partition (the live length's bucket; 0 = short mode) */
+    int32_t reserved_;
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
+/* Per-class result of the profile mode (qtts_talker_set_profile(t, 1), ABI v8): every launch of the decode GEMM in frames 1..6
+ * of the last generate call, timed on its own with the kernel's begin / end timestamps, grouped by (stack, N, K). */
+typedef struct {
+    int32_t stack;            /* 0 talker layers, 1 code predictor (layers, projection, lm_head), 2 talker codec_head */
+    int32_t N, K;             /* GEMM shape: out[M <= 64][N] = x[M][K] . W[N][K]^T */
+    int64_t launches;
+    double total_ms;          /* sum of the launches' kernel durations */
+    double min_us, max_us;
+    double bytes_per_launch;  /* algorithmic bytes: the packed weight matrix, N * K * element size */
+} qtts_gemm_class;
+int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n);
 /* Teacher forcing (diagnostic mode for parity measurements; no reference counterpart -- it is how a whole utterance of the
  * bf16 mode is compared decision by decision with the reference's greedy run, SURVEY.md 7 "teacher-forced per-step logits"):
  * until disabled (forced_codes_dev = NULL) every following qtts_talker_generate call -- greedy, min_new_tokens ==
@@ -378,8 +393,11 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
  * NULL.  All pointers are device pointers owned by the caller and must stay valid while the mode is on. */
 int qtts_talker_set_teacher(qtts_talker* t, const int64_t* forced_codes_dev, int32_t n_frames, int32_t* own_dev,
                             const int32_t* logit_slots_dev, float* logits_trace_dev);
-/* Enable per-launch HIP-event timing of the dominant kernel (skinny weight-streaming GEMM) in
- * eager mode; used by bench.py's roofline leg only. */
+/* bench.py's roofline leg.  enable = 1: the next qtts_talker_generate runs its frame steps eagerly and times EVERY launch of the
+ * dominant kernel (skinny weight-streaming decode GEMM) of frames 1..6 of the REAL frame step on its own (kernel begin / end
+ * timestamps through hipExtLaunchKernelGGL events); results per GEMM class from qtts_talker_get_gemm_profile.  enable = 2:
+ * round 2's measurement (the GEMM launches of one frame step replayed in isolation as a hipGraph; the call produces no
+ * usable codes).  0 = off. */
 int qtts_talker_set_profile(qtts_talker* t, int32_t enable);
 
 #ifdef __cplusplus

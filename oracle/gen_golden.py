@@ -308,6 +308,9 @@ def _gen_talker_real(name, t, lens, n_trail, max_new, seed, min_new=2, logit_ste
            "margin": torch.stack(tr["margin"], 1).numpy(), "logits0": tr["logits"][0].numpy(),
            "hidden_last": hidden[:, -1].numpy(), "ref_cpu_seconds": dt,
            "ref_cpu_threads": torch.get_num_threads()}
+    hs = [f for f in (0, 3, 7, 15, 23, 31, 39, 63, 95) if f < hidden.shape[1]]      # hidden states of selected frames: a run that a low-margin
+    out["hidden_steps"] = np.array(hs)                                              # flip shortens is still compared up to where it agrees
+    out["hidden_sel"] = torch.stack([hidden[:, f] for f in hs], 0).numpy()
     if logit_steps is not None:      # raw cb-0 logits (before the HF processors) of selected token steps, for teacher-forced comparisons
         out["logit_steps"] = np.array(logit_steps)
         out["logits_sel"] = torch.stack([tr["logits"][i] for i in logit_steps], 0).numpy()
@@ -333,8 +336,9 @@ def gen_talker_06b_b8():
 
 def gen_talker_17b_b32():
     # BASELINE config 4 shape: 1.7B dims, batch 32, streaming text input (24 trailing text rows fed one per frame,
-    # M:2229-2232), ragged prompts, greedy, 12 frames
-    _gen_talker_real("talker_17b_b32", synth.talker_17b(), [40 + (7 * i) % 32 for i in range(32)], 24, 13, 10)
+    # M:2229-2232), ragged prompts, greedy, 43 frames: the trailing text runs out at frame 24 and the remaining 19 frames take
+    # the tts_pad branch (M:1689-1692) at batch 32 / real dims (round 2's fixture stopped at 12 frames)
+    _gen_talker_real("talker_17b_b32", synth.talker_17b(), [40 + (7 * i) % 32 for i in range(32)], 24, 44, 10)
 
 
 BENCH_LENS = [36, 40, 44, 48, 52, 56, 60, 64]          # bench.py: 24 + 4 * (i % 8) + 12
@@ -673,10 +677,109 @@ def gen_codec_enc_tiny():
     print("codec_enc_tiny:", {k: v.shape for k, v in out.items() if k.startswith(("codes", "batch_codes"))})
 
 
+def gen_codec_real_bf16():
+    """The reference's OWN decoder run in **bfloat16** (V2:869-896; the dtype of its examples) on codec_real.npz's 10 s of codes:
+    the yardstick for the MI355X bf16 codec engine -- how far does bf16 move the reference's own waveform from its fp32 waveform,
+    and is the engine inside that distance?  Stored: the bf16 waveform (float16 is enough for a yardstick) and its relative RMS
+    distance to the fp32 golden."""
+    import torch
+    c = synth.codec_real()
+    w = synth.codec_weights(c)
+    g = np.load(os.path.join(GOLDEN, "codec_real.npz"))
+    assert abs(synth.weights_checksum(w) - float(g["weights_checksum"])) < 1e-3
+    dec = ref_codec_decoder(c, w).to(torch.bfloat16)
+    for mod in dec.modules():             # rotary inv_freq is a non-persistent fp32 buffer in the reference: keep it fp32
+        if hasattr(mod, "rope_init_fn") and hasattr(mod, "inv_freq"):
+            inv, _ = mod.rope_init_fn(mod.config, "cpu")
+            mod.inv_freq = inv
+            mod.original_inv_freq = inv
+    codes = torch.from_numpy(g["t125_codes"].astype(np.int64))
+    t = time.time()
+    with torch.no_grad():
+        wav = ref_model_decode(dec, c, codes)[0].float().numpy()
+    dt = time.time() - t
+    ref = g["t125_wav"].astype(np.float64)
+    rel = float(np.sqrt(((wav - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+    np.savez_compressed(os.path.join(GOLDEN, "codec_real_bf16.npz"), t125_wav_bf16=wav.astype(np.float16), rel_rms_vs_fp32=rel,
+                        ref_cpu_seconds=dt, weights_checksum=float(g["weights_checksum"]))
+    print(f"codec_real_bf16: reference-in-bf16 vs reference-in-fp32 waveform, relative RMS {rel:.4f} ({dt:.0f}s)")
+
+
+ICL_TEXT_LENS = [20, 34, 12, 27, 41, 16, 30, 23]       # body ids of the 8 requests
+ICL_REF_TEXT = [16, 12, 16, 20, 16, 9, 16, 14]         # ref-text ids
+ICL_REF_FRAMES = [38, 30, 38, 45, 38, 25, 52, 38]      # ref_code frames (3 s of reference audio = 38 frames)
+
+
+def gen_talker_17b_base_icl_b8():
+    """BASELINE config 5's request shape at REAL dims: Qwen3-TTS-12Hz-1.7B **Base** (voice clone), ICL prompt = ref text ids +
+    `ref_code` (38 x 16 and ragged neighbours) + x-vector speaker embedding (M:1968-2019 `generate_icl_prompt`, M:2188-2197;
+    wrapper IM:470-631), batch 8, streaming text input (the wrapper's default), greedy, 48 frames.  The reference's own
+    `Qwen3TTSForConditionalGeneration.generate` assembles the prompt (full 151 936-row text embedding, text_projection, the
+    16-codebook embedding sum of every reference frame) and hands it to `talker.generate`, which is the restated HF-4.57.3 loop
+    around the reference's talker.forward as in every other talker fixture.  Stored: the request (ids / ref ids / ref codes /
+    x-vectors are regenerated from the seed by the test through `icl_requests`), a strided sample + per-row sums of the assembled
+    embeddings, and the greedy codes."""
+    import torch
+    t = synth.talker_17b()
+    w = synth.talker_weights(t, with_text=True)
+    TalkerConfig, TopConfig, tk = ref_talker_cfgs(t)
+    from qwen_tts.core.models.modeling_qwen3_tts import Qwen3TTSForConditionalGeneration
+    top = TopConfig(talker_config=tk, tts_model_type="base", tts_model_size="1b7", tokenizer_type="12hz",
+                    im_start_token_id=t.im_start_token_id, im_end_token_id=t.im_end_token_id,
+                    tts_pad_token_id=t.tts_pad_token_id, tts_bos_token_id=t.tts_bos_token_id,
+                    tts_eos_token_id=t.tts_eos_token_id)
+    top.talker_config._attn_implementation = "eager"
+    top.talker_config.code_predictor_config._attn_implementation = "eager"
+    with torch.device("meta"):
+        model = Qwen3TTSForConditionalGeneration(top)
+    model = model.to_empty(device="cpu").eval()
+    for mod in model.modules():
+        if hasattr(mod, "rope_init_fn") and hasattr(mod, "inv_freq"):
+            inv, _ = mod.rope_init_fn(mod.config, "cpu")
+            mod.inv_freq = inv
+            mod.original_inv_freq = inv
+    _load(model.talker, w)
+    model.talker.config._attn_implementation = "eager"
+    req = synth.icl_requests(t, 200, ICL_TEXT_LENS, ICL_REF_TEXT, ICL_REF_FRAMES)
+    rec = {}
+    MAX_NEW = 49
+
+    def talker_generate(inputs_embeds=None, attention_mask=None, trailing_text_hidden=None, tts_pad_embed=None, **kw):
+        rec.update(embeds=inputs_embeds, mask=attention_mask, trailing=trailing_text_hidden, tts_pad=tts_pad_embed, kw=kw)
+        tr = {}
+        codes, toks, hidden = restated_sample_loop(model.talker, t, inputs_embeds, attention_mask, trailing_text_hidden,
+                                                   tts_pad_embed, max_new_tokens=MAX_NEW, min_new_tokens=kw["min_new_tokens"],
+                                                   eos_token_id=kw["eos_token_id"], repetition_penalty=kw["repetition_penalty"],
+                                                   trace=tr)
+        rec.update(codes=codes, tokens=toks, hidden=hidden, margin=torch.stack(tr["margin"], 1))
+        raise StopIteration
+    model.talker.generate = talker_generate
+    t1 = time.time()
+    try:
+        model.generate(input_ids=req["ids"], instruct_ids=[None] * 8, ref_ids=req["ref_ids"], voice_clone_prompt=req["vcp"],
+                       languages=req["languages"], speakers=None, non_streaming_mode=False, max_new_tokens=MAX_NEW,
+                       do_sample=False, subtalker_dosample=False)
+    except StopIteration:
+        pass
+    dt = time.time() - t1
+    e = rec["embeds"].numpy()
+    out = {"weights_checksum": synth.weights_checksum(w),
+           "seed": 200, "text_lens": np.array(ICL_TEXT_LENS), "ref_text": np.array(ICL_REF_TEXT), "ref_frames": np.array(ICL_REF_FRAMES),
+           "max_new": MAX_NEW, "min_new": rec["kw"]["min_new_tokens"], "mask": rec["mask"].numpy(),
+           "embeds_strided": e[:, :, ::64].copy(), "embeds_rowsum": e.astype(np.float64).sum(-1),
+           "trailing_strided": rec["trailing"].numpy()[:, :, ::64].copy(), "trailing_rowsum": rec["trailing"].numpy().astype(np.float64).sum(-1),
+           "tts_pad": rec["tts_pad"].numpy(), "codes": rec["codes"].numpy(), "tokens": rec["tokens"].numpy(),
+           "margin": rec["margin"].numpy(), "hidden_last": rec["hidden"][:, -1].numpy(), "ref_cpu_seconds": dt}
+    np.savez_compressed(os.path.join(GOLDEN, "talker_17b_base_icl_b8.npz"), **out)
+    print(f"talker_17b_base_icl_b8: prompt {tuple(e.shape)} trailing {tuple(rec['trailing'].shape)} codes {tuple(rec['codes'].shape)} "
+          f"min margin {float(rec['margin'].min()):.5f} ({dt:.0f}s)")
+
+
 ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny": gen_talker_tiny,
        "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
        "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "talker_17b_b8": gen_talker_17b_b8, "talker_06b_long": gen_talker_06b_long,
-       "talker_17b_b8_bf16": gen_talker_17b_b8_bf16, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny, "codec_enc_small": gen_codec_enc_small}
+       "talker_17b_b8_bf16": gen_talker_17b_b8_bf16, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny, "codec_enc_small": gen_codec_enc_small,
+       "codec_real_bf16": gen_codec_real_bf16, "talker_17b_base_icl_b8": gen_talker_17b_base_icl_b8}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -67,10 +67,16 @@ class SpeakerConfigC(C.Structure):
 
 class TalkerStatsC(C.Structure):
     _fields_ = [("frames_run", C.c_int32), ("graph_nodes", C.c_int32), ("weight_bytes_per_frame", C.c_double),
-                ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64)]
+                ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64), ("long_graphs", C.c_int32),
+                ("attn_nsplit_last", C.c_int32), ("attn_span_last", C.c_int32), ("reserved_", C.c_int32)]
 
 
-ABI_VERSION = 7           # include/qtts.h; bumped on any signature change
+class GemmClassC(C.Structure):
+    _fields_ = [("stack", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("min_us", C.c_double), ("max_us", C.c_double), ("bytes_per_launch", C.c_double)]
+
+
+ABI_VERSION = 8           # include/qtts.h; bumped on any signature change
 
 # every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
@@ -83,7 +89,8 @@ SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_cod
            "qtts_talker_create", "qtts_talker_destroy", "qtts_talker_bind", "qtts_talker_finalize",
            "qtts_talker_text_projection", "qtts_talker_text_embed", "qtts_talker_assemble_rows", "qtts_talker_prefill",
            "qtts_talker_generate", "qtts_talker_stream_begin", "qtts_talker_stream_step", "qtts_talker_stream_end",
-           "qtts_talker_debug_logits", "qtts_talker_get_stats", "qtts_talker_set_teacher", "qtts_talker_set_profile"]
+           "qtts_talker_debug_logits", "qtts_talker_get_stats", "qtts_talker_get_gemm_profile", "qtts_talker_set_teacher",
+           "qtts_talker_set_profile"]
 
 
 def library_path() -> str:
@@ -142,6 +149,7 @@ def load_library():
     lib.qtts_talker_stream_end.argtypes = [vp, vp, C.POINTER(C.c_int32), vp]
     lib.qtts_talker_debug_logits.argtypes = [vp, f32p, vp]
     lib.qtts_talker_get_stats.argtypes = [vp, C.POINTER(TalkerStatsC)]
+    lib.qtts_talker_get_gemm_profile.argtypes = [vp, C.POINTER(GemmClassC), i32, C.POINTER(C.c_int32)]
     lib.qtts_talker_set_teacher.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.qtts_talker_set_profile.argtypes = [vp, i32]
     for s in SYMBOLS:

@@ -469,14 +469,9 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     for (auto& bk : blocks) fast16 = fast16 && bk.cin % 32 == 0 && bk.cout % 32 == 0;
     bf16_t* h16a = fast16 ? buf16[0].as<bf16_t>() : nullptr;
     bf16_t* h16b = fast16 ? buf16[1].as<bf16_t>() : nullptr;
-    // ... and (second half of round 2) the residual stream inside the blocks travels as bf16 too, as in the reference's own bf16
-    // mode: the 1x1 convolution of a residual unit is HBM-bound, and 98 of its 148 KB per tile were the fp32 residual read + write
-    // (profiles/r02_tstamp_codec_gemm.md).  fp32 again where a tensor leaves the blocks (the last unit; any requested stage).
-    // Measured (GPU call 28, 8 x 10 s): 13.38 ms with, 13.54 ms without, relative RMS against the reference's fp32 waveform 0.052
-    // vs 0.049 -- the 1x1 convolutions turned out not to be HBM-bound after all, so the fp32 residual stream stays the default and
-    // QTTS_CODEC_RES16=1 selects the bf16 one.
-    static const bool res16_env = [] { const char* e = getenv("QTTS_CODEC_RES16"); return e && atoi(e) != 0; }();
-    const bool res16 = fast16 && res16_env && !stage;
+    // (A bf16 residual stream inside the blocks was measured in round 2 -- 13.38 vs 13.54 ms per 8 x 10 s, relative RMS 0.052 vs
+    // 0.049 -- and removed in round 3: the 1x1 convolutions are not HBM-bound, and an env-selected numeric mode nobody tests is a
+    // liability.)
     // ---- decoder.0: conv k=7 latent -> decoder_dim (v2:857)
     {
         float *a, *b, *cc; scratch3(a, b, cc);
@@ -492,9 +487,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
         if (fast16) {
             // h16a = SnakeBeta_block(x) in bf16 (from the previous producer).  tconv -> b (fp32, the first unit's residual) and
             // h16a' = SnakeBeta_unit0.act1(b)
-            // (res16: the residual goes out as bf16 into b's storage instead)
-            gemm16(bk.tconv, nullptr, h16a, C, B * L, L, res16 ? nullptr : b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st,
-                   bk.cout, nullptr, res16 ? reinterpret_cast<bf16_t*>(b) : nullptr);
+            gemm16(bk.tconv, nullptr, h16a, C, B * L, L, b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st, bk.cout);
             std::swap(h16a, h16b);                 // h16a: activated input of unit 0; h16b: free
             L *= bk.r; C = bk.cout;
             float* cur = b; float* alt = a;        // (a was only the stand-alone snake's output in the fp32 path: free here)
@@ -506,10 +499,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
                 // output is written only where the tensor leaves the blocks (last block) or a stage was asked for
                 const bool leaves = j == 2 && i + 1 == blocks.size();
                 const bool dead = j == 2 && !leaves && !stage;
-                if (res16) {                       // 1x1 + bf16 residual -> bf16 residual (fp32 where the tensor leaves the blocks)
-                    gemm16(un.c2, nullptr, h16b, C, B * L, L, leaves ? alt : nullptr, C, ACT_NONE, nullptr, C, nullptr, next ? h16a : nullptr, next, st, 0,
-                           reinterpret_cast<const bf16_t*>(cur), (leaves || dead) ? nullptr : reinterpret_cast<bf16_t*>(alt));
-                } else
+                (void)leaves;
                 gemm16(un.c2, nullptr, h16b, C, B * L, L, dead ? nullptr : alt, C, ACT_NONE, cur, C, nullptr, next ? h16a : nullptr, next, st);  // 1x1 + residual
                 std::swap(cur, alt);               // ping-pong between a and b: the residual input is never the output
             }
@@ -804,6 +794,7 @@ int qtts_codec_forward_stage(qtts_codec* c, const int64_t* codes_dev, int32_t B,
     int64_t l = -1, ch = -1;
     c->forward(codes_dev, B, (int64_t)Q * T, T, 1, 0, T, nullptr, nullptr, 0, 0, stage, out_dev, cap, &l, &ch,
                (hipStream_t)stream);
+    c->check_codes_flag((hipStream_t)stream);
     QTTS_REQUIRE(ch > 1 || strcmp(stage, "none") == 0, QTTS_ERR_NAME, std::string("unknown stage: ") + stage);
     if (L) *L = l;
     if (C) *C = ch;
@@ -851,6 +842,7 @@ int qtts_codec_stream_push(qtts_codec* c, const int64_t* codes_dev, int32_t n_fr
     QTTS_API_BEGIN
     QTTS_REQUIRE(c && codes_dev && wav_dev, QTTS_ERR_ARG, "null argument");
     c->stream_push(codes_dev, n_frames, wav_dev, (hipStream_t)stream);
+    c->check_codes_flag((hipStream_t)stream);      // a bad code must fail THIS call (and not poison the next one through a stale flag)
     QTTS_API_END
 }
 

@@ -58,6 +58,7 @@ struct SkinnyParams {
     int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
 };
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);
+void skinny_set_launch_events(hipEvent_t start, hipEvent_t stop);   // (bench.py's roofline leg: time the NEXT launch on its own; null = off)
 bool skinny_takes_bf16_x(int M, int K, bool bf16);   // bf16 mode: any M <= 64, K % 32 == 0
 size_t skinny_packed_bytes(int N, int K, bool bf16);
 // Pack W[N][K] (row-major f32), optionally scaled per input column by g[K], into the streaming tile layout;

@@ -312,6 +312,39 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleParams p) {
                 sc[v] = e;
                 mine += e;
             }
+            if (p.top_p < 1.0f) {
+                // ---- general top-p (HF TopPLogitsWarper, IM:287-352 forwards any top_p): with no top-k bound, or one beyond the
+                // candidate buffers above, the nucleus is cut on the whole vocabulary.  A token stays iff the softmax mass of everything
+                // ranked strictly above it is < top_p (ascending cumulative probability > 1 - top_p; the top token always stays), so
+                // the kept set is {e >= e*}: e* comes from a bit-by-bit search over the 32-bit key space for the LARGEST key c whose
+                // strictly-above mass S(c) is still >= top_p * total -- 32 block-wide masked sums, one barrier each (exp is
+                // monotone: keys of the numerators order like keys of the scores).  Equal scores are kept or cut together.
+                float* pred = scan;                          // [2][4] partial sums, double-buffered by round parity
+                auto block_sum = [&](float v, int slot) -> float {
+                    v = wave_sum64_dpp(v);
+                    if (lane == 0) pred[slot * 4 + wave] = v;
+                    __syncthreads();
+                    return (pred[slot * 4 + 0] + pred[slot * 4 + 1]) + (pred[slot * 4 + 2] + pred[slot * 4 + 3]);
+                };
+                const float total0 = block_sum(mine, 0);
+                const float P = p.top_p * total0;
+                uint32_t cut = 0u;                           // largest key with S(key) >= P found so far
+                bool any_cut = false;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t cand = cut | (1u << bit);
+                    float above = 0.f;
+                    for (int v = v0; v < v1; ++v) above += float_key(sc[v]) > cand ? sc[v] : 0.f;
+                    const float S = block_sum(above, 1 + (bit & 1));
+                    if (S >= P) { cut = cand; any_cut = true; }
+                }
+                // (no candidate passed: only key 0 could still be cut, and a numerator e >= 0 has a key >= 2^31)
+                __syncthreads();                             // `pred` aliases `scan`, which is rewritten below
+                mine = 0.f;
+                for (int v = v0; v < v1; ++v) {
+                    if (any_cut && float_key(sc[v]) <= cut) sc[v] = 0.f;
+                    mine += sc[v];
+                }
+            }
             scan[tid] = mine;
             if (tid == 0) { pick_lo = 0x7fffffff; pick_hi = -1; }
             __syncthreads();
@@ -646,8 +679,7 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
 
 void launch_sample(const SampleParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.V <= SAMPLE_MAX_V, QTTS_ERR_LIMIT, "sample: vocab too large");
-    QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f) || (p.top_k > 0 && p.top_k <= 256), QTTS_ERR_ARG,
-                 "sample: top_p < 1 on device needs 0 < top_k <= 256 (the reference default is top_k = 50)");
+    QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f) || p.top_p > 0.0f, QTTS_ERR_ARG, "sample: top_p must be in (0, 1]");
     if (p.do_sample && p.top_k > 0 && p.top_k <= 64 && p.top_k < p.V && p.V <= 4096) {
         if (p.V <= 2048) hipLaunchKernelGGL(sample_kernel_v2<8>, dim3(p.B), dim3(256), 0, st, p);
         else if (p.V <= 3072) hipLaunchKernelGGL(sample_kernel_v2<12>, dim3(p.B), dim3(256), 0, st, p);

@@ -26,10 +26,22 @@
 #include "common.h"
 #include "kernels.h"
 #include "tstamp.h"
+#include <hip/hip_ext.h>
 
 QTTS_TS_UNIT(skinny)
 
 namespace qtts {
+
+// Roofline leg of bench.py (qtts_talker_set_profile): when an event pair is set, the next decode-GEMM launch goes out through
+// hipExtLaunchKernelGGL, which stamps the events with THIS kernel's own begin / end timestamps (the dispatch's completion-signal
+// times -- what rocprofv3's kernel trace reports), so that every launch of the REAL frame step is timed on its own.
+static thread_local hipEvent_t tl_ev_start = nullptr, tl_ev_stop = nullptr;
+void skinny_set_launch_events(hipEvent_t start, hipEvent_t stop) { tl_ev_start = start; tl_ev_stop = stop; }
+#define QTTS_SK_LAUNCH(kern, grid, block, lds, st, p)                                                       \
+    do {                                                                                                    \
+        if (tl_ev_start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, tl_ev_start, tl_ev_stop, 0, p);  \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                             \
+    } while (0)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
@@ -585,7 +597,7 @@ static void launch2_n(const SkinnyParams& p, hipStream_t st) {
                                            160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, p);
+    QTTS_SK_LAUNCH(kern, dim3(grid), dim3(NW * 64), lds, st, p);
 }
 template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT>
 static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
@@ -627,7 +639,7 @@ template <int MT, int SPW, int NW>
 static void launch_f32_one(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (16 * SPW);
     const size_t lds = (size_t)NW * SPW * MT * 64 * 16;
-    hipLaunchKernelGGL((skinny_f32_kernel<MT, SPW, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
+    QTTS_SK_LAUNCH((skinny_f32_kernel<MT, SPW, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
 }
 template <int MT>
 static void launch_f32_mt(const SkinnyParams& p, int spw, int nw, hipStream_t st) {
@@ -646,8 +658,8 @@ template <int SPW, int FS, int NP, int NW = 8>
 static void launch8_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
     const size_t lds = (size_t)NW * (SPW + 1) * 64 * 16;
-    if (p.norm) hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, true, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
-    else hipLaunchKernelGGL((skinny8_kernel<SPW, FS, NP, false, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
+    if (p.norm) QTTS_SK_LAUNCH((skinny8_kernel<SPW, FS, NP, true, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
+    else QTTS_SK_LAUNCH((skinny8_kernel<SPW, FS, NP, false, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
 }
 // waves per workgroup: fewer waves = fewer partial sums to combine and a shorter barrier, more tile pairs (registers) per wave.
 // Default 4 for matrices below 16 MB (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame with 8, both repetitions), 8 above;

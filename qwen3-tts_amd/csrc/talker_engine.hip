@@ -94,11 +94,46 @@ struct qtts_talker {
         p.sub_stride = cfg.num_code_groups; p.generated = generated.as<int>(); p.gen_stride = gen_cap; p.st = ss;
         return p;
     }
-    // profiling of the dominant kernel
-    bool profile = false, timing_now = false, skinny_only = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    // profiling of the dominant kernel (bench.py's roofline leg).  profile = 1: real frame steps run eagerly and EVERY decode-GEMM
+    // launch of frames 1..PROF_FRAMES carries its own start / stop event pair (hipExtLaunchKernelGGL: the kernel's own begin / end
+    // timestamps, what rocprofv3's kernel trace reports), aggregated per GEMM class afterwards.  profile = 2: round 2's measurement
+    // -- only the decode-GEMM launches of one frame step re-captured as a hipGraph and replayed in isolation (kept for continuity).
+    int profile = 0;
+    bool timing_now = false, skinny_only = false;
+    static constexpr int PROF_FRAMES = 6;
+    struct LaunchEv { hipEvent_t a, b; int stack, N, K; };
+    std::vector<LaunchEv> ev;
+    int cur_stack = 0;                 // which part of the frame step is being launched: 0 talker layers, 1 code predictor, 2 talker head
+    std::vector<qtts_gemm_class> prof_classes;
     double prof_ms = 0; int64_t prof_launches = 0;
     int frames_run = 0;
+    void release_events() {
+        for (auto& e : ev) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        ev.clear();
+    }
+    // after the stream has drained: per-class totals of the per-launch times
+    void aggregate_profile() {
+        prof_classes.clear();
+        prof_ms = 0; prof_launches = 0;
+        const double eb = bf16 ? 2.0 : 4.0;
+        for (auto& e : ev) {
+            float ms = 0.f;
+            QTTS_CHECK_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+            qtts_gemm_class* c = nullptr;
+            for (auto& q : prof_classes) if (q.stack == e.stack && q.N == e.N && q.K == e.K) { c = &q; break; }
+            if (!c) {
+                qtts_gemm_class q{};
+                q.stack = e.stack; q.N = e.N; q.K = e.K; q.bytes_per_launch = eb * (double)e.N * e.K;
+                q.min_us = 1e30;
+                prof_classes.push_back(q);
+                c = &prof_classes.back();
+            }
+            c->launches += 1; c->total_ms += ms;
+            c->min_us = std::min(c->min_us, 1000.0 * ms); c->max_us = std::max(c->max_us, 1000.0 * ms);
+            prof_ms += ms; prof_launches += 1;
+        }
+        release_events();
+    }
 
     std::vector<float>& P(const std::string& n) {
         auto it = host.find(n);
@@ -184,7 +219,17 @@ struct qtts_talker {
 
     float* ssbuf() { return ss_rows.as<float>(); }     // row sums of squares for GEMMs that cannot stage x (M > 32 / fp32)
 
-    void skinny(const SkinnyParams& p, hipStream_t st) { launch_skinny(p, bf16, st); ++skinny_count; }
+    void skinny(const SkinnyParams& p, hipStream_t st) {
+        if (timing_now) {
+            LaunchEv e{nullptr, nullptr, cur_stack, p.N, p.K};
+            QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
+            ev.push_back(e);
+            skinny_set_launch_events(e.a, e.b);
+            try { launch_skinny(p, bf16, st); } catch (...) { skinny_set_launch_events(nullptr, nullptr); throw; }
+            skinny_set_launch_events(nullptr, nullptr);
+        } else launch_skinny(p, bf16, st);
+        ++skinny_count;
+    }
     int64_t skinny_count = 0;
 
     // x-side handling of a GEMM whose input is RMS-normalised: the bf16 kernel takes the row variances on the matrix pipe
@@ -219,7 +264,9 @@ struct qtts_talker {
         a.len_dev = len_dev; a.len_static = len_static; a.kv = kv; a.layer = layer; a.out = attb; a.ldo = d.qd;
         a.max_len = max_len; a.done_flag = ss.done;
         a.rope_cs = rope_cs; a.rope_cs_n = rope_cs_n;
-        if (len_dev && attn_nsplit_active > 1) { a.nsplit = attn_nsplit_active; a.part = attn_part.as<float>(); }   // talker, long sequences: split-KV
+        if (len_dev && attn_nsplit_active > 1) {     // talker, long sequences: split-KV over the LIVE length's bucket, not the capacity
+            a.nsplit = attn_nsplit_active; a.part = attn_part.as<float>(); a.max_len = attn_span_active;
+        }
         // bf16 mode: attention output and SwiGLU output travel as bf16 (as in the reference's bf16 path) and are
         // staged into the consuming GEMM by LDS-DMA
         const bool att16 = bf16 && skinny_takes_bf16_x(M, d.qd, true), act16 = bf16 && skinny_takes_bf16_x(M, d.I, true);
@@ -254,18 +301,41 @@ struct qtts_talker {
     // for engines whose max_seq exceeds 512, the long-sequence one (split-KV attention + merge kernel, 28 more nodes): measured
     // on MI355X the split costs +0.29 ms per frame at 100-200 keys and saves 0.9 ms at 800 (profiles/r02_long_utterance_*),
     // so a generation switches graphs when its KV length passes SPLIT_FROM keys.
+    // The key range is partitioned by the LIVE length (round 3): the host knows the KV length a burst of frame steps
+    // will reach, picks the power-of-two bucket that holds it (512, 1024, 2048, ...) and launches the graph captured for that
+    // bucket -- SPLIT_KEYS keys per workgroup, at most attn_nsplit workgroups per (sequence, kv head).  Partitioning the static
+    // capacity instead (round 2) left an engine created with max_seq = 4096 / 9216 (attach() / from_pretrained defaults) with 1-2
+    // non-empty splits at 800 keys: the merge nodes' cost without the split's gain.
     int SPLIT_FROM = [] { const char* e = getenv("QTTS_ATTN_SPLIT_FROM"); return e && atoi(e) > 0 ? atoi(e) : 320; }();   // (env: tests)
-    hipGraph_t graph_long = nullptr;
-    hipGraphExec_t graph_exec_long = nullptr;
+    int SPLIT_KEYS = [] { const char* e = getenv("QTTS_ATTN_SPLIT_KEYS"); return e && atoi(e) >= 64 ? atoi(e) / 64 * 64 : 256; }();   // (env: tests)
+    std::map<int, std::pair<hipGraph_t, hipGraphExec_t>> graph_long;      // bucket (keys) -> captured long-sequence frame step
     int attn_nsplit_active = 1;        // what decode_layer launches (and what a capture in progress bakes in)
+    int attn_span_active = 0;          // ... and the key span those workgroups partition (the bucket)
+    int long_graphs_captured = 0;      // (stats: tests assert that a long generation walks through the buckets)
     bool long_mode(int kv_len_after) const { return attn_nsplit > 1 && kv_len_after > SPLIT_FROM; }
-    // the captured graph for this mode, capturing `step` (which is NOT executed by the capture) on first use
+    // bucket of a KV length in long mode: the smallest power of two >= kv_len, at least 2 * SPLIT_KEYS, at most the capacity's bucket
+    int span_bucket(int kv_len) const {
+        int b = 2 * SPLIT_KEYS;
+        while (b < kv_len) b *= 2;
+        return b;
+    }
+    int nsplit_for(int bucket) const { return std::max(2, std::min(attn_nsplit, bucket / SPLIT_KEYS)); }
+    void set_attn_mode(int kv_len_after) {
+        if (long_mode(kv_len_after)) { attn_span_active = span_bucket(kv_len_after); attn_nsplit_active = nsplit_for(attn_span_active); }
+        else { attn_span_active = 0; attn_nsplit_active = 1; }
+    }
+    bool any_graph() const { return graph_exec != nullptr || !graph_long.empty(); }
+    // the captured graph for the mode a burst ending at `kv_len_after` keys runs in, capturing `step` (which is NOT executed by
+    // the capture) on first use
     template <class F>
-    hipGraphExec_t ensure_graph(bool lng, hipStream_t st, F&& step) {
-        hipGraph_t& g = lng ? graph_long : graph;
-        hipGraphExec_t& ge = lng ? graph_exec_long : graph_exec;
+    hipGraphExec_t ensure_graph(int kv_len_after, hipStream_t st, F&& step) {
+        set_attn_mode(kv_len_after);
+        const bool lng = attn_nsplit_active > 1;
+        std::pair<hipGraph_t, hipGraphExec_t> none{nullptr, nullptr};
+        auto& slot = lng ? graph_long[attn_span_active] : none;
+        hipGraph_t& g = lng ? slot.first : graph;
+        hipGraphExec_t& ge = lng ? slot.second : graph_exec;
         if (!ge) {
-            attn_nsplit_active = lng ? attn_nsplit : 1;
             QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             try { step(); }
             catch (...) {
@@ -279,16 +349,20 @@ struct qtts_talker {
             QTTS_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
             graph_nodes = (int)nn;
             QTTS_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            if (lng) ++long_graphs_captured;
         }
         return ge;
     }
     void destroy_graph() {
-        if (graph_exec_long) { (void)hipGraphExecDestroy(graph_exec_long); graph_exec_long = nullptr; }
-        if (graph_long) { (void)hipGraphDestroy(graph_long); graph_long = nullptr; }
+        for (auto& kv : graph_long) {
+            if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+            if (kv.second.first) (void)hipGraphDestroy(kv.second.first);
+        }
+        graph_long.clear();
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
         if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
     }
-    ~qtts_talker() { destroy_graph(); }
+    ~qtts_talker() { destroy_graph(); release_events(); }
 };
 
 void qtts_talker::finalize() {
@@ -407,7 +481,7 @@ void qtts_talker::finalize() {
     // a sequence that can grow past 512 keys is read by several workgroups per (sequence, kv head): one CU pulls ~25 GB/s, and a
     // 60 s utterance has 0.4 MB of K / V per head and layer (measured 52 us per layer at 800 keys with one workgroup)
     if (const char* e = getenv("QTTS_ATTN_NSPLIT")) attn_nsplit = std::max(1, std::min(16, atoi(e)));
-    else attn_nsplit = c.max_seq > 512 ? std::min(8, cdiv(c.max_seq, 256)) : 1;
+    else attn_nsplit = c.max_seq > 512 ? std::min(16, cdiv(c.max_seq, SPLIT_KEYS)) : 1;
     if (attn_nsplit > 1) attn_part.alloc(attn_part_floats(c.max_batch, td.nkv, attn_nsplit, td.nh / td.nkv) * sizeof(float));
     kv_t.k = kpool_t.p; kv_t.v = vpool_t.p; kv_t.page_table = ptab_t.as<int>();
     kv_c.k = kpool_c.p; kv_c.v = vpool_c.p; kv_c.page_table = ptab_c.as<int>();
@@ -541,6 +615,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     const auto& c = cfg;
     const int G = c.num_code_groups;
     // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
+    cur_stack = 1;
     for (int j = 0; j < G - 1; ++j) {
         const int n_new = j == 0 ? 2 : 1, M = n_new * B;
         CpGatherParams gp{};
@@ -611,6 +686,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     e.x_out = x.as<float>(); e.x_out16 = bf16 ? x16.as<unsigned short>() : nullptr; e.codes_out = codes; e.hidden_out = hidden; e.max_frames = max_frames; e.st = ss;
     if (!skinny_only) launch_embed_sum(e, st);
     // ---- talker decode forward (M:1706-1727)
+    cur_stack = 0;
     for (int l = 0; l < c.num_hidden_layers; ++l)
         decode_layer(tl[l], td, x.as<float>(), bf16 ? x16.as<unsigned short>() : nullptr, qkv.as<float>(), att.as<float>(), act.as<float>(), B, 1, kv_t, l, ss.kv_len, 0,
                      n_pad_d.as<int>(), inv_freq_t.as<float>(), c.max_seq, st);
@@ -621,6 +697,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     h.x = past_hidden.as<float>(); h.ldx = td.H; h.M = B; h.Wp = head_p.p; h.N = c.vocab_size; h.K = td.H;
     if (bf16) { h.x = reinterpret_cast<const float*>(ph16.as<unsigned short>()); h.x_bf16 = 1; }
     h.out = logits.as<float>(); h.ldo = c.vocab_size; h.act = ACT_NONE; h.fs = fs_head;
+    cur_stack = 2;
     skinny(h, st);
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
 }
@@ -777,7 +854,8 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     t->generated.ensure((size_t)B * max_new_tokens * 4);
     const int max_frames = std::max(1, max_new_tokens - 1);
     t->frames_run = 0;
-    if (!t->profile) { t->prof_ms = 0; t->prof_launches = 0; }
+    if (!t->profile) { t->prof_ms = 0; t->prof_launches = 0; t->prof_classes.clear(); }
+    t->release_events();
 
     t->sample_talker(*sp, eos_token_id, min_new_tokens, max_new_tokens, st);      // token 0
     int done = 0;
@@ -796,12 +874,13 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     key.sub_top_k = sp->subtalker_top_k; key.top_p = sp->top_p; key.temperature = sp->temperature; key.rep = sp->repetition_penalty;
     key.sub_top_p = sp->subtalker_top_p; key.sub_temperature = sp->subtalker_temperature; key.codes = codes_dev;
     key.hidden = hidden_dev; key.trailing = t->trailing.p; key.tts_pad = t->tts_pad.p; key.generated = t->generated.p;
-    if (!use_graph || !t->graph_exec || !(key == t->graph_key)) { t->destroy_graph(); t->graph_nodes = 0; }
+    if (!use_graph || !t->any_graph() || !(key == t->graph_key)) { t->destroy_graph(); t->graph_nodes = 0; }
     while (!done && f < total) {
-        if (t->profile && f == 1) {
+        if (t->profile == 2 && f == 1) {
             // roofline leg: ONLY the dominant kernel (every skinny GEMM of one frame step, same shapes/order) as a
             // hipGraph, replayed back-to-back between two HIP events on this stream.
             const int REPS = 20;
+            t->set_attn_mode(t->T0 + f + 1);
             t->skinny_only = true;
             hipGraph_t g2 = nullptr; hipGraphExec_t ge2 = nullptr;
             QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -829,16 +908,18 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
             done = 1;
             break;
         }
-        if (!use_graph || (f == 0 && !t->graph_exec)) {      // (a capture does not execute: frame 0 runs eagerly once)
-            t->attn_nsplit_active = t->long_mode(t->T0 + f + 1) ? t->attn_nsplit : 1;
-            t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st);
+        if (!use_graph) {
+            t->set_attn_mode(t->T0 + f + 1);
+            t->timing_now = t->profile == 1 && f >= 1 && f <= qtts_talker::PROF_FRAMES;     // (frame 0 warms the code up)
+            try { t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st); }
+            catch (...) { t->timing_now = false; throw; }
+            t->timing_now = false;
             ++f;
-            if (!use_graph && (f % 8 == 0)) poll();
-            if (use_graph) poll();
+            if (f % 8 == 0) poll();
             continue;
         }
         const int burst = std::min(8, total - f);
-        hipGraphExec_t ge = t->ensure_graph(t->long_mode(t->T0 + f + burst), st, [&] {
+        hipGraphExec_t ge = t->ensure_graph(t->T0 + f + burst, st, [&] {
             t->frame_step(*sp, eos_token_id, min_new_tokens, max_new_tokens, codes_dev, hidden_dev, max_frames, st); });
         t->graph_key = key;
         for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(ge, st));
@@ -847,6 +928,7 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     }
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
     t->frames_run = f;
+    if (t->profile == 1) t->aggregate_profile();
     int fin[5];
     QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
     QTTS_REQUIRE(fin[3] == 1, QTTS_ERR_STATE, "generate: loop ended without the stop condition being latched");
@@ -877,15 +959,15 @@ static void stream_launch_frames(qtts_talker* t, int n, hipStream_t st) {
     const int total = g.max_new - 1;
     int left = std::min(n, total - g.launched);
     while (!g.done && left > 0) {
-        if (!use_graph || (g.launched == 0 && !t->graph_exec)) {      // (a capture does not execute: the first frame runs eagerly once)
-            t->attn_nsplit_active = t->long_mode(t->T0 + g.launched + 1) ? t->attn_nsplit : 1;
+        if (!use_graph) {
+            t->set_attn_mode(t->T0 + g.launched + 1);
             t->frame_step(g.sp, g.eos, g.min_new, g.max_new, g.codes, g.hidden, g.max_frames, st);
             ++g.launched; --left;
             poll();
             continue;
         }
         const int burst = std::min(8, left);
-        hipGraphExec_t ge = t->ensure_graph(t->long_mode(t->T0 + g.launched + burst), st, [&] {
+        hipGraphExec_t ge = t->ensure_graph(t->T0 + g.launched + burst, st, [&] {
             t->frame_step(g.sp, g.eos, g.min_new, g.max_new, g.codes, g.hidden, g.max_frames, st); });
         for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(ge, st));
         g.launched += burst; left -= burst;
@@ -900,6 +982,7 @@ int qtts_talker_stream_begin(qtts_talker* t, const qtts_sampling* sp, int32_t ma
     QTTS_REQUIRE(t && sp && codes_dev, QTTS_ERR_ARG, "null argument");
     QTTS_REQUIRE(t->prefilled, QTTS_ERR_STATE, "stream_begin: prefill() first");
     QTTS_REQUIRE(!t->profile, QTTS_ERR_STATE, "stream_begin: not available in profile mode");
+    QTTS_REQUIRE(!t->tf.codes, QTTS_ERR_STATE, "stream_begin: teacher forcing is a qtts_talker_generate mode (clear it with set_teacher(NULL))");
     QTTS_REQUIRE(max_new_tokens >= 1, QTTS_ERR_ARG, "max_new_tokens >= 1");
     QTTS_REQUIRE(t->T0 + max_new_tokens <= t->cfg.max_seq, QTTS_ERR_LIMIT, "prompt + max_new_tokens exceeds max_seq");
     QTTS_REQUIRE(eos_token_id >= 0 && eos_token_id < t->cfg.vocab_size, QTTS_ERR_ARG, "eos_token_id");
@@ -935,7 +1018,7 @@ int qtts_talker_stream_begin(qtts_talker* t, const qtts_sampling* sp, int32_t ma
     key.sub_top_k = sp->subtalker_top_k; key.top_p = sp->top_p; key.temperature = sp->temperature; key.rep = sp->repetition_penalty;
     key.sub_top_p = sp->subtalker_top_p; key.sub_temperature = sp->subtalker_temperature; key.codes = codes_dev;
     key.hidden = hidden_dev; key.trailing = t->trailing.p; key.tts_pad = t->tts_pad.p; key.generated = t->generated.p;
-    if (!t->cfg.use_graph || !t->graph_exec || !(key == t->graph_key)) { t->destroy_graph(); t->graph_nodes = 0; }
+    if (!t->cfg.use_graph || !t->any_graph() || !(key == t->graph_key)) { t->destroy_graph(); t->graph_nodes = 0; }
     t->graph_key = key;
     g.active = true;
     QTTS_API_END
@@ -998,6 +1081,14 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     QTTS_REQUIRE(t && out, QTTS_ERR_ARG, "null argument");
     out->frames_run = t->frames_run; out->graph_nodes = t->graph_nodes; out->weight_bytes_per_frame = t->weight_bytes_frame;
     out->gemm_ms_last = t->prof_ms; out->gemm_launches_last = t->prof_launches;
+    out->long_graphs = t->long_graphs_captured; out->attn_nsplit_last = t->attn_nsplit_active; out->attn_span_last = t->attn_span_active;
+    QTTS_API_END
+}
+int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && n && (out || cap == 0), QTTS_ERR_ARG, "null argument");
+    *n = (int32_t)t->prof_classes.size();
+    for (int i = 0; i < *n && i < cap; ++i) out[i] = t->prof_classes[i];
     QTTS_API_END
 }
 __global__ void null_kernel(int* p, int mode) {
@@ -1099,7 +1190,8 @@ int qtts_talker_set_teacher(qtts_talker* t, const int64_t* forced_codes_dev, int
 int qtts_talker_set_profile(qtts_talker* t, int32_t enable) {
     QTTS_API_BEGIN
     QTTS_REQUIRE(t, QTTS_ERR_ARG, "null handle");
-    t->profile = enable != 0;
+    QTTS_REQUIRE(enable >= 0 && enable <= 2, QTTS_ERR_ARG, "set_profile: 0 off, 1 per-launch events on the real frame step, 2 isolated GEMM-only graph");
+    t->profile = enable;
     QTTS_API_END
 }
 

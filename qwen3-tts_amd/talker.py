@@ -41,6 +41,23 @@ class TalkerGenerateOutput:
 _SKIP_PREFIXES = ("speaker_encoder.",)
 
 
+
+def _check_warpers(**kw):
+    """HF's own argument checks (transformers generation/logits_process.py: TopKLogitsWarper / TopPLogitsWarper /
+    TemperatureLogitsWarper constructors), so that a bad value fails like the reference instead of reaching the kernel."""
+    for name in ("top_k", "subtalker_top_k"):
+        v = kw.get(name)
+        if v is not None and v != 0 and (not isinstance(v, int) or v < 0):
+            raise ValueError(f"`{name}` has to be a strictly positive integer, but is {v}")
+    for name in ("top_p", "subtalker_top_p"):
+        v = kw.get(name)
+        if v is not None and not (0.0 < float(v) <= 1.0):
+            raise ValueError(f"`{name}` has to be a float > 0 and <= 1, but is {v}")
+    for name in ("temperature", "subtalker_temperature"):
+        v = kw.get(name)
+        if v is not None and not float(v) > 0.0:
+            raise ValueError(f"`{name}` (={v}) has to be a strictly positive float")
+
 class TalkerEngine:
     """Owns one `qtts_talker` handle."""
 
@@ -92,8 +109,18 @@ class TalkerEngine:
         return C.c_void_p(self._stream.cuda_stream)
 
     @_lib.locked
-    def set_profile(self, enable: bool):
-        _lib.check(self._lib.qtts_talker_set_profile(self._h, 1 if enable else 0))
+    def set_profile(self, enable):
+        """0 / False: off.  1 / True: time every decode-GEMM launch of the real frame step on its own (see `gemm_profile`).
+        2: round 2's measurement, the GEMM launches of one frame step replayed in isolation (that call yields no codes)."""
+        _lib.check(self._lib.qtts_talker_set_profile(self._h, int(enable)))
+
+    @_lib.locked
+    def gemm_profile(self) -> List[dict]:
+        """Per-class result of the last generate call made under `set_profile(1)` (include/qtts.h `qtts_gemm_class`)."""
+        buf = (_lib.GemmClassC * 64)()
+        n = C.c_int32(0)
+        _lib.check(self._lib.qtts_talker_get_gemm_profile(self._h, buf, 64, C.byref(n)))
+        return [{f[0]: getattr(buf[i], f[0]) for f in buf[i]._fields_} for i in range(min(64, n.value))]
 
     @_lib.locked
     def stats(self) -> dict:
@@ -212,6 +239,8 @@ class TalkerEngine:
         eos = c.codec_eos_token_id if eos_token_id is None else int(eos_token_id)
         if suppress_tokens is None:
             suppress_tokens = []
+        _check_warpers(top_k=top_k, top_p=top_p, temperature=temperature, subtalker_top_k=subtalker_top_k,
+                       subtalker_top_p=subtalker_top_p, subtalker_temperature=subtalker_temperature)
         sp = _lib.SamplingC()
         sp.do_sample = 1 if do_sample else 0
         sp.top_k = int(top_k) if top_k else 0
@@ -244,6 +273,9 @@ class TalkerEngine:
             if F_t != max_new_tokens - 1:
                 raise ValueError("teacher_codes: the forced frames do not fit max_seq")
             tc = teacher_codes.to(dev, torch.long).contiguous()
+            # forced codes index embedding tables on the device: range-check them here (cb-0 < vocab, sub-codes < cp vocab)
+            if int(tc.min()) < 0 or int(tc[..., 0].max()) >= c.vocab_size or (tc.shape[2] > 1 and int(tc[..., 1:].max()) >= c.cp_vocab_size):
+                raise ValueError("teacher_codes: code index out of range")
             own = torch.full((B, F_t + 1, c.num_code_groups), -1, dtype=torch.int32, device=dev)
             slots = trace = None
             if logit_steps:
@@ -306,6 +338,8 @@ class TalkerEngine:
         max_new_tokens = self._clamp_new_tokens(T, int(max_new_tokens))
         eos = c.codec_eos_token_id if eos_token_id is None else int(eos_token_id)
         suppress_tokens = list(suppress_tokens or [])
+        _check_warpers(top_k=top_k, top_p=top_p, temperature=temperature, subtalker_top_k=subtalker_top_k,
+                       subtalker_top_p=subtalker_top_p, subtalker_temperature=subtalker_temperature)
         sp = _lib.SamplingC()
         sp.do_sample = 1 if do_sample else 0
         sp.top_k = int(top_k) if top_k else 0

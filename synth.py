@@ -545,3 +545,28 @@ def rand_prompt(g: np.random.Generator, t: TalkerCfg, lens, n_trail: int, scale:
     trailing = g.standard_normal((B, n_trail, H), dtype=np.float32) * scale
     pad = g.standard_normal((1, 1, H), dtype=np.float32) * scale
     return torch.from_numpy(emb), torch.from_numpy(mask), torch.from_numpy(trailing), torch.from_numpy(pad)
+
+
+def icl_requests(t: TalkerCfg, seed: int, text_lens, ref_text_lens, ref_frames, languages=None):
+    """A batch of voice-clone (Base model, ICL) requests at the `Qwen3TTSForConditionalGeneration.generate` seam, as the wrapper
+    builds them (inference/qwen3_tts_model.py:470-631): assistant-wrapped text ids, `<|im_start|>assistant\n ref text <|im_end|>\n`
+    ref ids, `ref_code` (frames x 16: codebook 0 below the talker's special range, the rest below the code predictor's vocab) and
+    an x-vector per request.  Shared by oracle/gen_golden.py and the GPU test so that both sides see identical requests."""
+    import torch
+    g = np.random.default_rng(seed)
+    a, n = 77, 198
+    B = len(text_lens)
+    hi = min(t.text_vocab_size, t.im_start_token_id) - 1
+    ids, ref_ids, ref_code, spk = [], [], [], []
+    for i in range(B):
+        body = g.integers(0, hi, (text_lens[i],)).tolist()
+        ids.append(torch.tensor([[t.im_start_token_id, a, n] + body + [t.im_end_token_id, n, t.im_start_token_id, a, n]]))
+        rbody = g.integers(0, hi, (ref_text_lens[i],)).tolist()
+        ref_ids.append(torch.tensor([[t.im_start_token_id, a, n] + rbody + [t.im_end_token_id, n]]))
+        nf = ref_frames[i]
+        rc = np.concatenate([g.integers(0, t.vocab_size - 1024, (nf, 1)), g.integers(0, t.cp_vocab_size, (nf, t.num_code_groups - 1))], 1)
+        ref_code.append(torch.from_numpy(rc))
+        spk.append(torch.from_numpy(g.standard_normal(t.hidden_size).astype(np.float32) * 0.1))
+    langs = languages or [("english", "auto", "chinese")[i % 3] for i in range(B)]
+    vcp = dict(ref_code=ref_code, ref_spk_embedding=spk, x_vector_only_mode=[False] * B, icl_mode=[True] * B)
+    return dict(ids=ids, ref_ids=ref_ids, vcp=vcp, languages=langs)

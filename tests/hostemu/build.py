@@ -41,7 +41,7 @@ SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}
 EXTRA_DEFS = {"gemm_tap.hip": ["-Dlaunch_gemm_tap=launch_gemm_tap_real"]}
 STANDIN = ["cpu_gemm_tap.cpp", "test_entries.cpp", "lds_arrays.cpp"]
 HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h")] + [
-    os.path.join(ROOT, "include", "qtts.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "simt.h")]
+    os.path.join(ROOT, "include", "qtts.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "hip", "hip_ext.h"), os.path.join(HERE, "simt.h")]
 
 
 def _compiler():

@@ -357,6 +357,8 @@ inline void global_load_lds(uintptr_t src, uintptr_t dst, int size) {
 #define gridDim (simt::M().grid_dim)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     (simt::check_launch((grid), (block), (size_t)(shmem), #kern), simt::launch_kernel((grid), (block), kern, ##__VA_ARGS__))
+#define hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, ev_start, ev_stop, flags, ...) \
+    ((void)(ev_start), (void)(ev_stop), hipLaunchKernelGGL(kern, grid, block, shmem, stream, ##__VA_ARGS__))
 inline void __syncthreads() { simt::barrier(); }
 #define __shfl_xor(v, mask) simt::shfl_any((v), simt::lane_id() ^ (mask), __COUNTER__ + 1)
 #define __shfl_up(v, delta) simt::shfl_any((v), simt::lane_id() - (delta), __COUNTER__ + 1)

@@ -643,8 +643,10 @@ def test_sampler_kernel_real_source_vs_hf_processors(emu):
         for min_new in (0, 9):
             want = talker_ref.process_logits(lt, gt, repetition_penalty=1.3, eos_id=eos, min_new_tokens=min_new, suppress=sup_list)
             assert np.array_equal(launch(0, 0, 1.0, 1.0, 0, 0, min_new), want.argmax(-1).numpy()), (V, min_new)
-        for top_k, top_p, temp in ((6, 1.0, 0.8), (50, 1.0, 0.9), (12, 0.7, 1.0), (0, 1.0, 1.3)):
-            if top_k == 0 and V > 300:
+        # (0, 0.9) and (280, 0.75): the reference forwards ANY top_k / top_p to HF (IM:287-352) -- top-p with no top-k bound, and a
+        # top-k beyond the 256-candidate fast path followed by top-p, both cut on the whole vocabulary (round 3)
+        for top_k, top_p, temp in ((6, 1.0, 0.8), (50, 1.0, 0.9), (12, 0.7, 1.0), (0, 1.0, 1.3), (0, 0.9, 1.1), (280, 0.75, 1.0)):
+            if (top_k == 0 or top_k > 256) and V > 300:
                 continue                                                      # full-vocabulary multinomial: small case only
             sc = talker_ref.process_logits(lt, gt, repetition_penalty=1.3, eos_id=eos, min_new_tokens=9, suppress=sup_list,
                                            do_sample=True, temperature=temp, top_k=top_k, top_p=top_p)
@@ -758,10 +760,16 @@ def test_talker_split_kv_attention_and_graph_switch(emu, golden_dir, monkeypatch
     try:
         args = [g[k] for k in ("embeds", "mask", "trailing", "tts_pad")]
         assert args[0].shape[1] < 20 < args[0].shape[1] + 13, "the switch point must fall inside the generation"
+        emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
         for _ in range(2):                      # second call: both graphs come from the cache
             codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=14)
             assert np.array_equal(tokens, g["tokens"]) and np.array_equal(codes, g["codes"])
             assert np.abs(hidden - g["hidden"]).max() <= 2e-3
+            st = _lib.TalkerStatsC()
+            _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+            # the key range is partitioned by the LIVE length's bucket (512 keys = 2 x 256 here), not by max_seq; one long graph,
+            # captured once and reused by the second call
+            assert (st.long_graphs, st.attn_nsplit_last, st.attn_span_last) == (1, 2, 512)
     finally:
         emu.qtts_talker_destroy(h)
 
