@@ -33,6 +33,9 @@ VARIANTS = {
     # csrc/tstamp.h: phase timestamps inside the frame step's kernels (decode GEMM, both decode attentions, sampler); a
     # measuring build for tools/ts_frame.py, never the product.
     "tstamp": ["-DQTTS_TSTAMP=1"],
+    # skinny.hip: the decode GEMM's address operands as leading scalar kernel arguments, preloaded into user SGPRs by the
+    # dispatcher (no kernarg `s_load` round trip in front of the first request); A/B with tools/ab_variants.py.
+    "kpre": ["-DQTTS_KARG_PRELOAD=1", "-mllvm", "-amdgpu-kernarg-preload-count=16"],
 }
 # Round 2 (profiles/r02_ab_variants.md): cp_pretable, cp_qkvtable, attn_cp and sampler_v2 were measured faster and are now the
 # default code; attn_t1, wtemporal, late_norm, embed_sum_v2 and gu8 were measured slower or neutral and are deleted.

@@ -37,10 +37,10 @@ namespace qtts {
 // times -- what rocprofv3's kernel trace reports), so that every launch of the REAL frame step is timed on its own.
 static thread_local hipEvent_t tl_ev_start = nullptr, tl_ev_stop = nullptr;
 void skinny_set_launch_events(hipEvent_t start, hipEvent_t stop) { tl_ev_start = start; tl_ev_stop = stop; }
-#define QTTS_SK_LAUNCH(kern, grid, block, lds, st, p)                                                       \
-    do {                                                                                                    \
-        if (tl_ev_start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, tl_ev_start, tl_ev_stop, 0, p);  \
-        else hipLaunchKernelGGL(kern, grid, block, lds, st, p);                                             \
+#define QTTS_SK_LAUNCH(kern, grid, block, lds, st, ...)                                                               \
+    do {                                                                                                              \
+        if (tl_ev_start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, tl_ev_start, tl_ev_stop, 0, __VA_ARGS__);  \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                             \
     } while (0)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -331,8 +331,26 @@ __device__ inline u32x4 dpp_ror8(const u32x4& v) {
     return r;
 }
 
+// QTTS_KARG_PRELOAD (build variant `kpre`, round 3): a by-value struct argument is never preloaded into SGPRs by the compiler's
+// kernarg-preload feature (`-mllvm -amdgpu-kernarg-preload-count=16`: the first 16 dwords of SCALAR arguments arrive in user SGPRs
+// with the wave, no `s_load` round trip in front of the first address computation).  In the variant the operands every request of
+// the launch depends on travel as leading scalar arguments; the struct follows and is only read by the epilogue.
+#ifndef QTTS_KARG_PRELOAD
+#define QTTS_KARG_PRELOAD 0
+#endif
+#if QTTS_KARG_PRELOAD
+#define QTTS_SK8_PARAMS const void* kWp, const float* kx, const int* kdone, const float* kres, const float* kbias, int kldx, int kM, int kK, int kldr, \
+                        int kact, int kN, SkinnyParams p
+#define QTTS_SK8_ARGS(p) (p).Wp, (p).x, (p).done_flag, (p).res, (p).bias, (p).ldx, (p).M, (p).K, (p).ldr, (p).act, (p).N, (p)
+#else
+#define QTTS_SK8_PARAMS SkinnyParams p
+#define QTTS_SK8_ARGS(p) (p)
+#endif
 template <int SPW, int FS, int NP, bool NORM, int NW = 8>
-__global__ __launch_bounds__(NW * 64) void skinny8_kernel(SkinnyParams p) {
+__global__ __launch_bounds__(NW * 64) void skinny8_kernel(QTTS_SK8_PARAMS) {
+#if QTTS_KARG_PRELOAD
+    p.Wp = kWp; p.x = kx; p.done_flag = kdone; p.res = kres; p.bias = kbias; p.ldx = kldx; p.M = kM; p.K = kK; p.ldr = kldr; p.act = kact; p.N = kN;
+#endif
     static_assert(FS == 16 || (FS == 8 && SPW == 1), "skinny8: strips of 16 features, or single strips of 8");
     constexpr int NS = SPW + 1;
     constexpr int WPP = FS == 16 ? 2 : 1;                        // weight requests per pair and strip (1 KiB each)
@@ -658,8 +676,8 @@ template <int SPW, int FS, int NP, int NW = 8>
 static void launch8_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
     const size_t lds = (size_t)NW * (SPW + 1) * 64 * 16;
-    if (p.norm) QTTS_SK_LAUNCH((skinny8_kernel<SPW, FS, NP, true, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
-    else QTTS_SK_LAUNCH((skinny8_kernel<SPW, FS, NP, false, NW>), dim3(grid), dim3(NW * 64), lds, st, p);
+    if (p.norm) QTTS_SK_LAUNCH((skinny8_kernel<SPW, FS, NP, true, NW>), dim3(grid), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
+    else QTTS_SK_LAUNCH((skinny8_kernel<SPW, FS, NP, false, NW>), dim3(grid), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
 }
 // waves per workgroup: fewer waves = fewer partial sums to combine and a shorter barrier, more tile pairs (registers) per wave.
 // Default 4 for matrices below 16 MB (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame with 8, both repetitions), 8 above;

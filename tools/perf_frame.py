@@ -58,12 +58,14 @@ if a.talker:
               f"weights {st['weight_bytes_per_frame']/1e9:.2f} GB/frame -> {st['weight_bytes_per_frame']/ms/1e6:.0f} GB/s, "
               f"{B*16/ms*1000:.0f} tok/s, RTFx {B*0.08/ms*1000:.0f}", flush=True)
     if a.prof:
-        eng.set_profile(True)
-        eng.generate(emb, mask, tr, pad, seed=0, **dict(kw, max_new_tokens=9, min_new_tokens=9)); eng.set_profile(False)
-        st = eng.stats()
-        avg = 1000 * st['gemm_ms_last'] / st['gemm_launches_last']
-        print(f"skinny-only graph: {st['graph_nodes']} launches/frame, avg {avg:.2f} us/launch, "
-              f"{st['weight_bytes_per_frame'] / st['graph_nodes'] / avg / 1e3:.0f} GB/s")
+        eng.set_profile(1)
+        eng.generate(emb, mask, tr, pad, seed=0, **dict(kw, max_new_tokens=9, min_new_tokens=9)); eng.set_profile(0)
+        cls = eng.gemm_profile()
+        tot = sum(c["total_ms"] for c in cls); n = sum(c["launches"] for c in cls); b = sum(c["launches"] * c["bytes_per_launch"] for c in cls)
+        for c in sorted(cls, key=lambda c: (c["stack"], -c["bytes_per_launch"])):
+            us = 1e3 * c["total_ms"] / c["launches"]
+            print(f"  stack {c['stack']} N={c['N']:5d} K={c['K']:5d} x{c['launches'] // 6:3d}/frame  {us:6.2f} us  {c['bytes_per_launch'] / us / 1e3:6.0f} GB/s")
+        print(f"decode GEMM in the real frame step: {n // 6} launches/frame, avg {1e3 * tot / n:.2f} us/launch, {b / tot / 1e6:.0f} GB/s")
 if a.codec:
     c = synth.codec_real()
     t0 = time.time()

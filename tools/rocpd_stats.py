@@ -24,6 +24,26 @@ g = [x for x in gaps if 0 <= x < 1000]
 import statistics
 lines.append("")
 lines.append(f"kernels: {len(rows)}, busy {tot/1000:.3f} ms; inter-kernel gaps (<1 ms): n={len(g)}, median {statistics.median(g):.2f} us, mean {sum(g)/len(g):.2f} us, total {sum(g)/1000:.3f} ms")
+# the decode GEMM by shape (N, K), reconstructed from the instantiation and the grid: skinny8_kernel<SPW, FS, NP, NORM, NW> covers
+# N = workgroups * FS * SPW output features and K = NP * NW * 64; bytes = N * K * 2 (bf16 weights, read once) -> fraction of the
+# 8 TB/s HBM peak per class.  The same classes as bench.py's `roofline.classes` (measured live with per-launch events).
+shape = {}
+for n, s, e, g, w in rows:
+    m = re.search(r"skinny8_kernel<(\d+), (\d+), (\d+), (true|false), (\d+)>", n)
+    if not m or not w:
+        continue
+    spw, fs, np_, _, nw = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4), int(m.group(5))
+    N, K = (g // w) * fs * spw, np_ * nw * 64
+    a = shape.setdefault((N, K), [0, 0.0])
+    a[0] += 1; a[1] += (e - s) / 1000.0
+if shape:
+    lines += ["", "| decode GEMM class (skinny8_kernel) | launches | avg us | MB (N*K*2) | GB/s | frac of 8 TB/s |", "|---|---|---|---|---|---|"]
+    tb = tt = tn = 0
+    for (N, K), a in sorted(shape.items(), key=lambda kv: -kv[1][1]):
+        us = a[1] / a[0]; b = N * K * 2.0
+        lines.append(f"| N={N} K={K} | {a[0]} | {us:.2f} | {b/1e6:.2f} | {b/us/1e3:.0f} | {b/us/1e3/8000:.4f} |")
+        tb += b * a[0]; tt += a[1]; tn += a[0]
+    lines.append(f"| all (launch-weighted) | {tn} | {tt/tn:.2f} | {tb/tn/1e6:.2f} | {tb/tt/1e3:.0f} | {tb/tt/1e3/8000:.4f} |")
 out = "\n".join(lines)
 print(out)
 if "--out" in sys.argv:
