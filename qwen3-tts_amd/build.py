@@ -21,8 +21,10 @@ SOURCES = ["gemm_tap.hip", "skinny.hip", "elementwise.hip", "attention.hip", "sa
            "codec_engine.hip", "talker_engine.hip", "encoder_kernels.hip", "encoder_engine.hip",
            "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip"]
 HEADERS = ["common.h", "kernels.h", "glue.h", os.path.join("..", "..", "include", "qtts.h")]
+# -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (14 dwords on gfx950) arrive in user SGPRs with the wave instead
+# of behind an `s_load` round trip; the frame step's decode GEMM passes its address operands that way (skinny.hip).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 # name -> extra compiler flags; what each one tests is written next to the macro in the source.
@@ -33,10 +35,8 @@ VARIANTS = {
     # csrc/tstamp.h: phase timestamps inside the frame step's kernels (decode GEMM, both decode attentions, sampler); a
     # measuring build for tools/ts_frame.py, never the product.
     "tstamp": ["-DQTTS_TSTAMP=1"],
-    # skinny.hip: the decode GEMM's address operands as leading scalar kernel arguments, preloaded into user SGPRs by the
-    # dispatcher (no kernarg `s_load` round trip in front of the first request); A/B with tools/ab_variants.py.
-    "kpre": ["-DQTTS_KARG_PRELOAD=1", "-mllvm", "-amdgpu-kernarg-preload-count=16"],
 }
+# Round 3: kpre (kernarg preload for the decode GEMM) measured 0.973x per frame (profiles/r03_ab_kpre.md) and is now the default code.
 # Round 2 (profiles/r02_ab_variants.md): cp_pretable, cp_qkvtable, attn_cp and sampler_v2 were measured faster and are now the
 # default code; attn_t1, wtemporal, late_norm, embed_sum_v2 and gu8 were measured slower or neutral and are deleted.
 

@@ -146,9 +146,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(QkNormRopeParams
     float* v = p.qkv + ((size_t)b * p.T + t) * p.ld + hh * hd;
     KVT* kc = reinterpret_cast<KVT*>(p.kv.k);
     KVT* vc = reinterpret_cast<KVT*>(p.kv.v);
-    if (hh >= p.nh + p.nkv) {  // value head: straight copy
+    if (hh >= p.nh + p.nkv) {  // value head: straight copy (or, for a transposed-V cache, dim-major inside the page)
         const int kvh = hh - p.nh - p.nkv;
         const size_t o = kv_offset(p.kv, p.layer, b, t, kvh);
+        if (p.kv.vt) {
+            const size_t pg = o - (size_t)(t & 15) * hd;              // start of this (page, kv head) block
+            for (int d = lane; d < hd; d += 64) vc[pg + (size_t)d * 16 + (t & 15)] = kv_cast<KVT>(v[d]);
+        } else
         for (int d = lane; d < hd; d += 64) vc[o + d] = kv_cast<KVT>(v[d]);
         return;
     }
@@ -618,13 +622,14 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
         if (k < S0) {
-            const float ek = __shfl(e, k * 4);
+            // (v_readlane with a compile-time lane: a few cycles, where the __shfl this replaces was a ds_bpermute round trip each)
+            const float ek = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), k * 4));
             acc0 += ek * kv_load(&vr[k].a);
             acc1 += ek * kv_load(&vr[k].b);
         }
     }
     {
-        const float ek = __shfl(e, S0 * 4);
+        const float ek = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), S0 * 4));
         acc0 += ek * vn[2 * lane];
         acc1 += ek * vn[2 * lane + 1];
     }
@@ -987,6 +992,252 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
     QTTS_TS_END(attn, 2, S0, nsplit);
 }
 
+// =================================================================================== attn_tk16 (round 3)
+// The talker's single-token decode attention ON THE MATRIX PIPE (bf16 cache).  attn_tk above spends its key loop on the VALU:
+// an 8-dim partial dot per lane and a 4-step DPP row reduction per key and query head (0.9 us per 64 keys per workgroup; 1.7 of
+// its 5.3 us in-kernel at 130 keys, and what bounds a 60 s utterance).  Here both products are `v_mfma_f32_16x16x32_bf16`:
+//   S = K q^T   A = 16 keys x 32 dims of a K page (row-major [key][dim]: a lane's 8 consecutive dims are one 16-B load),
+//               B = q (query heads as columns; columns >= GQ are zero), 4 k-steps over the 128 dims;
+//   O^T = V^T P A = 16 dims x 32 keys of the V pages, which this cache stores TRANSPOSED ([dim][16 keys], KvCache::vt): a
+//               lane's 8 consecutive keys are one 16-B load as well -- no LDS transpose, no LDS at all before the final merge;
+//               B = P (softmax numerators of 32 keys as bf16, heads as columns).
+// The rows of the two S tiles of a 32-key block are PERMUTED keys: tile A row 4q + r = key 8q + r, tile B row 4q + r = key
+// 8q + 4 + r, so that lane (head j, q) ends up with the scores of keys 8q .. 8q + 7 -- exactly the fragment the PV product wants
+// from it as its B operand.  The softmax is the online one (running max / sum per head, accumulators rescaled per block), its
+// statistics live in the lanes of a column (4 lanes per head, two xor-shuffles per block).  A workgroup is 4 waves, wave w
+// takes the 32-key blocks w, w + 4, ... of its split; the new token's key (position S0) is folded in at the merge from this
+// step's own row (fp32 q . k, as before).  Arithmetic: q, K, P, V enter the matrix pipe as bf16, accumulation fp32 -- the
+// precision of the reference's own bf16 attention (M:634-657: bf16 q k^T, fp32 softmax cast to bf16, bf16 P V).
+template <int GQ, bool CT>
+__global__ __launch_bounds__(256) void attn_tk16_kernel(AttnDecodeParams p) {
+    constexpr int HD = 128, NB = 2;            // NB: 32-key blocks per wave requested at kernel entry (4 waves x 2 x 32 = 256 keys)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float xw[4][GQ + 2][HD];      // per wave: q heads, k, v of the new token (fp32)
+    __shared__ __attribute__((aligned(16))) float red[4][GQ][HD];          // per wave: un-normalised output
+    __shared__ float gm[4][GQ], gl[4][GQ], snew[GQ];
+
+    QTTS_TS_BEGIN();
+    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const bf16_t* kc = reinterpret_cast<const bf16_t*>(p.kv.k);
+    const bf16_t* vc = reinterpret_cast<const bf16_t*>(p.kv.v);
+    const int pps = p.kv.pages_per_seq;
+
+    // element offset of (page pg of this sequence, this kv head) -- the same for the K pool ([16][128]) and the V pool ([128][16])
+    auto page_base = [&](int pg) -> size_t {
+        pg = pg < pps ? pg : pps - 1;                                      // speculative requests stay inside the sequence's pages
+        const int page = CT ? b * pps + pg : p.kv.page_table[b * pps + pg];
+        return (((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * (16 * HD);
+    };
+    // K fragments of block `blk`: tile A rows = keys {0-3, 8-11} of both pages, tile B rows = keys {4-7, 12-15}; lane (row lj, lq)
+    // holds dims 32 t + 8 lq .. + 8 for k-step t.  V fragments: dim block d (16 dims), lane (dim 16 d + lj, lq) holds keys
+    // 8 lq .. 8 lq + 7 of the block = keys 8 (lq & 1) .. + 8 of page 2 blk + (lq >> 1).
+    auto load_block = [&](u32x4 (&kA)[4], u32x4 (&kB)[4], u32x4 (&vT)[8], int blk) {
+        const size_t pk = page_base(2 * blk + (lj >> 3));                  // rows 0-7: first page, rows 8-15: second page
+        const int kin = ((lj >> 2) & 1) * 8 + (lj & 3);                    // key inside the page for tile A (tile B: + 4)
+        const u32x4* ka = reinterpret_cast<const u32x4*>(kc + pk + (size_t)kin * HD + lq * 8);
+        const u32x4* kb = reinterpret_cast<const u32x4*>(kc + pk + (size_t)(kin + 4) * HD + lq * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { kA[t] = ka[t * 4]; kB[t] = kb[t * 4]; }     // (32 dims = 64 B = 4 x 16-B units per k-step)
+        const size_t pv = page_base(2 * blk + (lq >> 1));
+        const u32x4* vb = reinterpret_cast<const u32x4*>(vc + pv + (size_t)lj * 16 + (lq & 1) * 8);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) vT[d] = vb[d * 32];                    // (16 dims x 16 keys x 2 B = 512 B = 32 units per dim block)
+    };
+
+    // split-KV: workgroup y of gridDim.y handles the 32-key blocks [b0s, b0s + bps) of the key span p.max_len
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int bps = (((p.max_len + 31) >> 5) + nsplit - 1) / nsplit;
+    const int b0s = split * bps;
+    // ---- 0. this step's row first (loads return in request order), then the K / V blocks of the register window, speculatively
+    float x0v[GQ + 2], x1v[GQ + 2];
+#pragma unroll
+    for (int vi = 0; vi < GQ + 2; ++vi) {
+        const int col = vi < GQ ? (kvh * GQ + vi) * HD : (vi == GQ ? (p.nh + kvh) * HD : (p.nh + p.nkv + kvh) * HD);
+        const float* src = p.qkv + (size_t)b * p.ld + col;
+        x0v[vi] = src[lane]; x1v[vi] = src[lane + 64];
+    }
+    const float wq0 = p.qw[lane], wq1 = p.qw[lane + 64], wk0 = p.kw[lane], wk1 = p.kw[lane + 64];
+    const float invf = p.inv_freq[lane];
+    u32x4 kA[NB][4], kB[NB][4], vT[NB][8];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) load_block(kA[n], kB[n], vT[n], b0s + wave + 4 * n);
+    const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step = position of the new key
+    const int npad = p.n_pad ? p.n_pad[b] : 0;
+    const int done = p.done_flag ? *p.done_flag : 0;
+    if (done) return;
+    QTTS_TS_DRAINED(1);
+    const int bend = min(b0s + bps, (S0 + 31) >> 5);         // blocks of CACHED keys of this split end here
+
+    // ---- 1. q / k RMSNorm + RoPE of the new token, per wave; K / V append by wave 0 of split 0 (V dim-major inside its page)
+    const float ang = (float)(S0 - npad) * invf;
+    const float cs = cosf(ang), sn = sinf(ang);
+    float sq[GQ > 0 ? GQ : 1];
+    float kx0 = 0.f, kx1 = 0.f;
+#pragma unroll
+    for (int vi = GQ; vi >= 0; --vi) {                       // k first (vi == GQ), then the query heads: the scores of the new key need it
+        float x0 = x0v[vi], x1 = x1v[vi];
+        const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
+        const float rs = rsqrtf(ss / (float)HD + p.eps);
+        x0 = (vi < GQ ? wq0 : wk0) * (x0 * rs);
+        x1 = (vi < GQ ? wq1 : wk1) * (x1 * rs);
+        const float o0 = x0 * cs - x1 * sn, o1 = x1 * cs + x0 * sn;
+        x0 = o0; x1 = o1;
+        if (vi == GQ) {
+            const bf16_t h0 = f32_to_bf16(x0), h1 = f32_to_bf16(x1);
+            if (wave == 0 && split == 0) {
+                bf16_t* cdst = reinterpret_cast<bf16_t*>(p.kv.k);
+                const size_t o = page_base(S0 >> 4) + (size_t)(S0 & 15) * HD;
+                cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
+            }
+            kx0 = bf16_to_f32(h0); kx1 = bf16_to_f32(h1);    // every wave uses the rounded key, what a later step reads back
+        } else {
+            xw[wave][vi][lane] = x0; xw[wave][vi][lane + 64] = x1;
+            sq[vi] = wave_sum64_dpp(x0 * kx0 + x1 * kx1) * rsqrtf((float)HD);        // score of the new key (fp32 q . k)
+        }
+    }
+    {
+        const bf16_t h0 = f32_to_bf16(x0v[GQ + 1]), h1 = f32_to_bf16(x1v[GQ + 1]);
+        if (wave == 0 && split == 0) {
+            bf16_t* cdst = reinterpret_cast<bf16_t*>(p.kv.v);
+            const size_t o = page_base(S0 >> 4) + (S0 & 15);
+            cdst[o + (size_t)lane * 16] = h0; cdst[o + (size_t)(lane + 64) * 16] = h1;
+        }
+        xw[wave][GQ + 1][lane] = bf16_to_f32(h0); xw[wave][GQ + 1][lane + 64] = bf16_to_f32(h1);
+    }
+    __builtin_amdgcn_wave_barrier();             // wave-private LDS slice: program order within the wave is all that is needed
+    // B operand of S = K q^T: lane (head lj, lq) <- q[lj][32 t + 8 lq .. + 8] as bf16; columns >= GQ are zero
+    u32x4 qB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float4 a = *reinterpret_cast<const float4*>(&xw[wave][lj < GQ ? lj : 0][32 * t + 8 * lq]);
+        const float4 c = *reinterpret_cast<const float4*>(&xw[wave][lj < GQ ? lj : 0][32 * t + 8 * lq + 4]);
+        u32x4 v;
+        v[0] = pack_bf16(a.x, a.y); v[1] = pack_bf16(a.z, a.w); v[2] = pack_bf16(c.x, c.y); v[3] = pack_bf16(c.z, c.w);
+        qB[t] = lj < GQ ? v : (u32x4){0u, 0u, 0u, 0u};
+    }
+    QTTS_TS_DRAINED(2);
+
+    // ---- 2. online softmax over this wave's blocks; everything in registers
+    const float scale = rsqrtf((float)HD);
+    float m = -INFINITY, l = 0.f;                // of head lj (meaningful for lj < GQ); l: this lane's keys only until the end
+    f32x4 acc[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto process = [&](const u32x4 (&ka)[4], const u32x4 (&kb)[4], const u32x4 (&vt)[8], int blk) {
+        f32x4 sA = {0.f, 0.f, 0.f, 0.f}, sB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x8 a, bq, c;
+            *reinterpret_cast<u32x4*>(&a) = ka[t]; *reinterpret_cast<u32x4*>(&c) = kb[t]; *reinterpret_cast<u32x4*>(&bq) = qB[t];
+            sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, sA, 0, 0, 0);
+            sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c, bq, sB, 0, 0, 0);
+        }
+        // this lane: keys key0 + e, e = 0..7 (tile A: e = 0..3, tile B: e = 4..7) of head lj
+        const int key0 = 32 * blk + 8 * lq;
+        float sc[8];
+        float mc = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int key = key0 + e;
+            const bool valid = key < S0 && key >= npad;      // left-pad slots were never written; slots >= S0 hold nothing yet
+            const float v = (e < 4 ? sA[e] : sB[e - 4]) * scale;
+            sc[e] = valid ? v : -INFINITY;
+            mc = fmaxf(mc, sc[e]);
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 16));
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float mn = fmaxf(m, mc);
+        // (mn == -inf: no valid key so far in this column; every exponent below is then exp(-inf - (-inf)) = NaN -> forced to 0)
+        const float f = m > -INFINITY ? att_exp<bf16_t>(m - mn) : 0.f;
+        float pr[8], ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pr[e] = sc[e] > -INFINITY ? att_exp<bf16_t>(sc[e] - mn) : 0.f; ps += pr[e]; }
+        l = l * f + ps;
+        m = mn;
+        u32x4 pb;
+        pb[0] = pack_bf16(pr[0], pr[1]); pb[1] = pack_bf16(pr[2], pr[3]); pb[2] = pack_bf16(pr[4], pr[5]); pb[3] = pack_bf16(pr[6], pr[7]);
+        // V fragments of never-written / not-yet-written keys may hold anything (NaN x 0 = NaN): mask them to zero.  The 8 keys of a
+        // V fragment are keys 32 blk + 8 lq + e as well (same lq), so one mask serves all 8 dim blocks.
+        u32x4 vm;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int k0 = key0 + 2 * e2;
+            vm[e2] = ((k0 < S0 && k0 >= npad) ? 0x0000ffffu : 0u) | ((k0 + 1 < S0 && k0 + 1 >= npad) ? 0xffff0000u : 0u);
+        }
+        bf16x8 pB;
+        *reinterpret_cast<u32x4*>(&pB) = pb;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            bf16x8 va;
+            *reinterpret_cast<u32x4*>(&va) = vt[d] & vm;
+            acc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pB, acc[d] * f, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+        if (b0s + wave + 4 * n < bend) process(kA[n], kB[n], vT[n], b0s + wave + 4 * n);
+    for (int blk = b0s + wave + 4 * NB; blk < bend; blk += 4 * NB) {        // beyond the register window: NB blocks per latency round
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+            if (blk + 4 * n < bend) load_block(kA[n], kB[n], vT[n], blk + 4 * n);
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+            if (blk + 4 * n < bend) process(kA[n], kB[n], vT[n], blk + 4 * n);
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    // ---- 3. merge of the 4 waves and of the new key (fixed order).  acc[d][r] of lane (head lj, lq) = dim 16 d + 4 lq + r
+    if (lj < GQ) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) *reinterpret_cast<f32x4*>(&red[wave][lj][16 * d + 4 * lq]) = acc[d];
+        if (lq == 0) { gm[wave][lj] = m; gl[wave][lj] = l; }
+    }
+    if (wave == 0 && lane == 0) {
+#pragma unroll
+        for (int qi = 0; qi < GQ; ++qi) snew[qi] = sq[qi];
+    }
+    QTTS_TS_DRAINED(3);
+    __syncthreads();
+    QTTS_TS(4);
+    if (tid < GQ * HD) {
+        const int qi = tid / HD, dd = tid % HD;
+        // the split whose key range holds position S0 also owns the new key
+        const bool has_new = split == min(nsplit - 1, (S0 >> 5) / bps);
+        float mm = has_new ? snew[qi] : -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, gm[w][qi]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = gm[w][qi] > -INFINITY ? att_exp<bf16_t>(gm[w][qi] - mm) : 0.f;
+            num += red[w][qi][dd] * f;
+            den += gl[w][qi] * f;
+        }
+        if (has_new) {
+            const float f = att_exp<bf16_t>(snew[qi] - mm);
+            num += xw[0][GQ + 1][dd] * f;
+            den += f;
+        }
+        if (nsplit > 1) {                                    // partial result of this split: numerator | max | denominator
+            float* pp = p.part + (((size_t)blockIdx.x * nsplit + split) * GQ + qi) * (HD + 2);
+            pp[dd] = num;
+            if (dd == 0) { pp[HD] = mm; pp[HD + 1] = den; }
+            QTTS_TS_DRAINED(5);
+            QTTS_TS_END(attn, 2, S0, nsplit);
+            return;
+        }
+        const size_t o = (size_t)b * p.ldo + (kvh * GQ + qi) * HD + dd;
+        const float r = num / den;
+        if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(r);
+        else p.out[o] = r;
+    }
+    QTTS_TS_DRAINED(5);
+    QTTS_TS_END(attn, 2, S0, nsplit);
+}
+
 // merge of the split-KV partial results (fixed order): out = sum_s num_s e^(m_s - m) / sum_s den_s e^(m_s - m)
 template <int GQ>
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnDecodeParams p) {
@@ -1019,6 +1270,14 @@ static void launch_attn_tk_c(const AttnDecodeParams& p, dim3 grid, hipStream_t s
     else hipLaunchKernelGGL((attn_tk_kernel<KVT, GQ, false>), grid, dim3(256), 0, st, p);
 }
 static void launch_attn_tk(const AttnDecodeParams& p, int GQ, dim3 grid, hipStream_t st) {
+    if (p.kv.vt) {               // bf16 cache with transposed V pages: both products on the matrix pipe
+        QTTS_REQUIRE(p.kv.bf16, QTTS_ERR_ARG, "attn_decode: transposed V pages are a bf16-cache layout");
+        if (p.kv.contig) { if (GQ == 1) hipLaunchKernelGGL((attn_tk16_kernel<1, true>), grid, dim3(256), 0, st, p);
+                           else hipLaunchKernelGGL((attn_tk16_kernel<2, true>), grid, dim3(256), 0, st, p); }
+        else { if (GQ == 1) hipLaunchKernelGGL((attn_tk16_kernel<1, false>), grid, dim3(256), 0, st, p);
+               else hipLaunchKernelGGL((attn_tk16_kernel<2, false>), grid, dim3(256), 0, st, p); }
+        return;
+    }
     if (p.kv.bf16) { if (GQ == 1) launch_attn_tk_c<bf16_t, 1>(p, grid, st); else launch_attn_tk_c<bf16_t, 2>(p, grid, st); }
     else { if (GQ == 1) launch_attn_tk_c<float, 1>(p, grid, st); else launch_attn_tk_c<float, 2>(p, grid, st); }
 }
@@ -1059,6 +1318,8 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.hd == 128, QTTS_ERR_ARG, "attn_decode: head_dim must be 128");
     const int GQ = p.nh / p.nkv, NQ = p.n_new * GQ;
     QTTS_REQUIRE((NQ == 1 || NQ == 2 || NQ == 4) && p.n_new <= 2, QTTS_ERR_ARG, "attn_decode: 1, 2 or 4 queries per kv head");
+    QTTS_REQUIRE(!p.kv.vt || (p.n_new == 1 && GQ <= 2 && (p.len_dev || p.n_pad || p.len_static + 1 > 16)), QTTS_ERR_ARG,
+                 "attn_decode: a transposed-V cache is read by the talker's single-token kernel only");
     if (p.n_new == 2 && !p.len_dev && !p.n_pad && p.len_static == 0 && GQ <= 2) {          // the code predictor's pass 0
         const dim3 grid(p.B * p.nkv);
         if (p.kv.bf16) { if (p.kv.contig) hipLaunchKernelGGL((attn_cp0_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);

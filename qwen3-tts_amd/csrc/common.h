@@ -53,6 +53,11 @@ __host__ __device__ inline float bf16_to_f32(bf16_t h) {
     return v.f;
 }
 
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+__device__ inline unsigned pack_bf16(float a, float b) {   // two floats -> one dword of bf16 (a low, b high): v_cvt_pk_bf16_f32 (RNE)
+    hwbf16x2 v = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<unsigned*>(&v);
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));  // 8 bf16 = 4 VGPRs (MFMA operand type)
 typedef short bf16x4 __attribute__((ext_vector_type(4)));

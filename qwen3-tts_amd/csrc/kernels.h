@@ -149,6 +149,8 @@ struct KvCache {
     int pages_per_seq, n_pages, nkv, hd;
     int bf16;
     int contig;                  // 1: page_table[b][i] == b*pages_per_seq + i (skip the indirection load)
+    int vt;                      // 1: V pages are stored TRANSPOSED, [layer][page][kvh][hd][16] -- the A-operand image of the PV product on
+                                 // the matrix pipe (attn_tk16_kernel, bf16 talker cache only); K pages stay [16][hd]
 };
 struct QkNormRopeParams {
     float* qkv; int ld; int B, T, nh, nkv, hd;

@@ -44,12 +44,6 @@ void skinny_set_launch_events(hipEvent_t start, hipEvent_t stop) { tl_ev_start =
     } while (0)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ inline unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE)
-    hwbf16x2 v = {(__bf16)a, (__bf16)b};
-    return *reinterpret_cast<unsigned*>(&v);
-}
 
 template <class T>
 __device__ inline T skinny_wload(const T* ptr) { return __builtin_nontemporal_load(ptr); }
@@ -331,26 +325,16 @@ __device__ inline u32x4 dpp_ror8(const u32x4& v) {
     return r;
 }
 
-// QTTS_KARG_PRELOAD (build variant `kpre`, round 3): a by-value struct argument is never preloaded into SGPRs by the compiler's
-// kernarg-preload feature (`-mllvm -amdgpu-kernarg-preload-count=16`: the first 16 dwords of SCALAR arguments arrive in user SGPRs
-// with the wave, no `s_load` round trip in front of the first address computation).  In the variant the operands every request of
-// the launch depends on travel as leading scalar arguments; the struct follows and is only read by the epilogue.
-#ifndef QTTS_KARG_PRELOAD
-#define QTTS_KARG_PRELOAD 0
-#endif
-#if QTTS_KARG_PRELOAD
-#define QTTS_SK8_PARAMS const void* kWp, const float* kx, const int* kdone, const float* kres, const float* kbias, int kldx, int kM, int kK, int kldr, \
-                        int kact, int kN, SkinnyParams p
-#define QTTS_SK8_ARGS(p) (p).Wp, (p).x, (p).done_flag, (p).res, (p).bias, (p).ldx, (p).M, (p).K, (p).ldr, (p).act, (p).N, (p)
-#else
-#define QTTS_SK8_PARAMS SkinnyParams p
-#define QTTS_SK8_ARGS(p) (p)
-#endif
+// Kernel arguments (round 3, measured -2.7 % per frame, profiles/r03_ab_kpre.md): a by-value struct argument is never preloaded into
+// SGPRs by the compiler's kernarg-preload feature (`-mllvm -amdgpu-kernarg-preload-count=16`, build.py FLAGS: the first 14 dwords
+// of SCALAR arguments arrive in user SGPRs with the wave -- no `s_load` round trip in front of the first address computation).
+// So the operands every request of the launch depends on travel as leading scalar arguments (5 pointers + 4 ints = 14 dwords);
+// the struct follows and is only read by the epilogue.
+#define QTTS_SK8_ARGS(p) (p).Wp, (p).x, (p).done_flag, (p).res, (p).bias, (p).ldx, (p).M, (p).K, (p).ldr, (p)
 template <int SPW, int FS, int NP, bool NORM, int NW = 8>
-__global__ __launch_bounds__(NW * 64) void skinny8_kernel(QTTS_SK8_PARAMS) {
-#if QTTS_KARG_PRELOAD
-    p.Wp = kWp; p.x = kx; p.done_flag = kdone; p.res = kres; p.bias = kbias; p.ldx = kldx; p.M = kM; p.K = kK; p.ldr = kldr; p.act = kact; p.N = kN;
-#endif
+__global__ __launch_bounds__(NW * 64) void skinny8_kernel(const void* kWp, const float* kx, const int* kdone, const float* kres, const float* kbias,
+                                                          int kldx, int kM, int kK, int kldr, SkinnyParams p) {
+    p.Wp = kWp; p.x = kx; p.done_flag = kdone; p.res = kres; p.bias = kbias; p.ldx = kldx; p.M = kM; p.K = kK; p.ldr = kldr;
     static_assert(FS == 16 || (FS == 8 && SPW == 1), "skinny8: strips of 16 features, or single strips of 8");
     constexpr int NS = SPW + 1;
     constexpr int WPP = FS == 16 ? 2 : 1;                        // weight requests per pair and strip (1 KiB each)

@@ -463,12 +463,15 @@ void qtts_talker::finalize() {
     // ---- KV caches (pages of 16 tokens, reserved up front)
     const size_t esz = bf16 ? 2 : 4;
     const int pps = cdiv(c.max_seq, 16);
-    kv_t = {nullptr, nullptr, nullptr, pps, pps * c.max_batch, td.nkv, td.hd, bf16 ? 1 : 0, 1};
+    // bf16 talker cache: V pages transposed ([dim][16 keys]) -- the A-operand image of the PV product of attn_tk16_kernel, which runs
+    // both attention products on the matrix pipe (QTTS_ATTN_MFMA=0: the VALU kernel attn_tk on row-major V pages, for A/B runs)
+    const bool attn_mfma = bf16 && !(getenv("QTTS_ATTN_MFMA") && getenv("QTTS_ATTN_MFMA")[0] == '0');
+    kv_t = {nullptr, nullptr, nullptr, pps, pps * c.max_batch, td.nkv, td.hd, bf16 ? 1 : 0, 1, attn_mfma ? 1 : 0};
     const size_t tb = (size_t)c.num_hidden_layers * kv_t.n_pages * td.nkv * 16 * td.hd * esz;
     kpool_t.alloc(tb); vpool_t.alloc(tb);
     QTTS_CHECK_HIP(hipMemset(kpool_t.p, 0, tb)); QTTS_CHECK_HIP(hipMemset(vpool_t.p, 0, tb));
     const int cpps = cdiv(G + 1, 16);
-    kv_c = {nullptr, nullptr, nullptr, cpps, cpps * c.max_batch, cd.nkv, cd.hd, bf16 ? 1 : 0, 1};
+    kv_c = {nullptr, nullptr, nullptr, cpps, cpps * c.max_batch, cd.nkv, cd.hd, bf16 ? 1 : 0, 1, 0};
     const size_t cb = (size_t)c.cp_num_hidden_layers * kv_c.n_pages * cd.nkv * 16 * cd.hd * esz;
     kpool_c.alloc(cb); vpool_c.alloc(cb);
     QTTS_CHECK_HIP(hipMemset(kpool_c.p, 0, cb)); QTTS_CHECK_HIP(hipMemset(vpool_c.p, 0, cb));

@@ -115,6 +115,7 @@ extern "C" int hostemu_attn_decode(const float* qkv, int ld, int B, int n_new, i
         p.kv.k = kpool; p.kv.v = vpool; p.kv.page_table = page_table; p.kv.pages_per_seq = pages_per_seq;
         p.kv.n_pages = B * pages_per_seq; p.kv.nkv = nkv; p.kv.hd = 128; p.kv.bf16 = bf16; p.kv.contig = page_table ? 0 : 1;
         p.layer = 0; p.out = out; p.ldo = ldo; p.out_bf16 = 0; p.max_len = max_len; p.done_flag = nullptr;
+        if (const char* e = getenv("QTTS_DEBUG_ATTN_VT")) p.kv.vt = atoi(e) != 0;        // V pool given dim-major inside its pages (attn_tk16)
         std::vector<float> part;
         if (const char* e = getenv("QTTS_DEBUG_ATTN_NSPLIT")) {      // split-KV variant of the talker call shape
             if (atoi(e) > 1 && n_new == 1 && p.len_dev) {

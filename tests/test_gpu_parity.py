@@ -403,11 +403,19 @@ def test_talker_17b_batch32_streaming_text_greedy_vs_reference_golden(dev, golde
     out = eng.generate(emb, mask, tr, pad, teacher_codes=torch.from_numpy(gc), suppress_tokens=_suppress(cfg))
     own = out.own.cpu().numpy()
     F = gc.shape[1]
-    bad0 = np.argwhere(own[:, :, 0] != gt)
-    late = float((own[:, 24:F, :] == gc[:, 24:]).mean())
-    agree = float((own[:, :F, :] == gc).mean())
+    # Row 15 of the fixture samples EOS at token step 23 and is FINISHED from then on (HF keeps feeding it eos, M / HF `_sample`: the
+    # free-running comparison above covers that path at batch 32).  Teacher forcing blocks EOS (min_new_tokens = max_new_tokens), so
+    # the cb-0 decisions of that row from its EOS on are not comparable and are left out; its sub-codebooks still are.
+    eos = cfg.codec_eos_token_id
+    fin = gt == eos
+    assert fin.any() and fin.sum() < 64, "the fixture has one early-finished row"
+    bad0 = np.argwhere((own[:, :, 0] != gt) & ~fin)
+    ok = own[:, :F, :] == gc
+    ok[:, :, 0] |= fin[:, :F]
+    late = float(ok[:, 24:].mean())
+    agree = float(ok.mean())
     print(f"talker_17b_b32 teacher-forced: {F} frames x 16 x 32 rows, agreement {agree:.6f} (frames past the trailing text: {late:.6f}), "
-          f"cb-0 mismatches {len(bad0)}")
+          f"cb-0 mismatches {len(bad0)} outside the {int(fin.sum())} post-EOS steps of the finished row")
     assert all(g["margin"][b, i] < MARGIN_EXEMPT for b, i in bad0), "a cb-0 decision with a clear reference margin differs"
     assert agree >= 0.9995 and late >= 0.9995
 
@@ -624,7 +632,9 @@ def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
     eng = TalkerEngine(t, w, weight_dtype=torch.float32, device=dev, max_batch=4, max_seq=64, use_graph=False)
     args = [torch.from_numpy(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
     N = 600
-    for top_k, top_p in ((6, 1.0), (12, 0.7)):
+    # (0, 0.9): top-p WITHOUT a top-k bound, (300, 0.8): a top-k beyond the 256-candidate fast path followed by top-p -- both cut on
+    # the whole vocabulary by the general path (round 3; the reference forwards any top_k / top_p to HF, IM:287-352)
+    for top_k, top_p in ((6, 1.0), (12, 0.7), (0, 0.9), (300, 0.8)):
         sc = talker_ref.process_logits(torch.from_numpy(g["logits"][:, 0]), torch.zeros(3, 0, dtype=torch.long),
                                        eos_id=t.codec_eos_token_id, min_new_tokens=2, suppress=_suppress(t), do_sample=True,
                                        temperature=0.8, top_k=top_k, top_p=top_p)
@@ -638,15 +648,16 @@ def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
         for b in range(3):
             assert (counts[b][p[b] == 0] == 0).all(), "sampled a token outside HF's top-k / top-p support"
             sup = p[b] > 0
-            assert sup.sum() == top_k if top_p >= 1.0 else 1 <= sup.sum() < top_k
+            if top_k:
+                assert sup.sum() == top_k if top_p >= 1.0 else 1 <= sup.sum() < top_k
             e, o = N * p[b][sup], counts[b][sup]
             small = e < 5.0                                  # pool sparse cells so the statistic is chi-square-like
             if small.sum() > 1:
                 e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
-            chi2 = float((((o - e) ** 2) / e).sum())
-            assert chi2 < 35.0, f"top_k={top_k} top_p={top_p} row {b}: chi-square {chi2:.1f} with {len(e) - 1} dof"
-    with pytest.raises(Exception, match="top_p"):            # top_p without a top-k bound is rejected, not ignored
-        eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=0, top_p=0.9, suppress_tokens=_suppress(t))
+            chi2, dof = float((((o - e) ** 2) / e).sum()), len(e) - 1
+            assert chi2 < dof + 5.0 * np.sqrt(2.0 * max(dof, 1)) + 10.0, f"top_k={top_k} top_p={top_p} row {b}: chi-square {chi2:.1f} with {dof} dof"
+    with pytest.raises(ValueError, match="top_p"):           # HF's own argument check (TopPLogitsWarper): top_p in (0, 1]
+        eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=0, top_p=0.0, suppress_tokens=_suppress(t))
     # same seed -> same draw; different seed -> (almost surely) a different sequence
     kw = dict(max_new_tokens=8, suppress_tokens=_suppress(t))
     a = eng.generate(*args, seed=11, **kw).codes.cpu().numpy()

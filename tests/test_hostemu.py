@@ -391,6 +391,91 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("nsplit", [1, 3])
+def test_attn_tk16_matrix_pipe_kernel_real_source(emu, nsplit, monkeypatch):
+    """attention.hip's `attn_tk16_kernel` (round 3: the talker's single-token decode attention with BOTH products on the matrix
+    pipe; bf16 cache, V pages stored dim-major [128][16 keys]) from its real source against float64 numpy: q / k RMSNorm + RoPE,
+    K row-major / V transposed append, left-pad mask, never-written slots holding NaN, GQA 2:1 and 1:1, cache lengths from 1 key
+    to past the 256-key register window, contiguous and permuted page tables, alone and as split-KV partials + merge.  q, K, P, V
+    enter the MFMA as bf16 (the precision of the reference's own bf16 attention), so the bar is bf16-sized: 2 % of the largest
+    output and 0.4 % RMS; bit-identical across wave scheduling orders."""
+    monkeypatch.setenv("QTTS_DEBUG_ATTN_VT", "1")
+    if nsplit > 1:
+        monkeypatch.setenv("QTTS_DEBUG_ATTN_NSPLIT", str(nsplit))
+    g = np.random.default_rng(91 + nsplit)
+    HD, eps = 128, 1e-6
+    inv_freq = (1.0 / (10000.0 ** (np.arange(64) / 64.0))).astype(np.float32)
+    qw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+    kw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+    rnd = lambda a: _bf16_round(a)[0]
+
+    def normrope(x, w, pos):
+        x = x.astype(np.float64)
+        x = w * (x / np.sqrt((x ** 2).mean() + eps))
+        ang = np.float32(pos) * inv_freq
+        c, s_ = np.cos(ang.astype(np.float64)), np.sin(ang.astype(np.float64))
+        return np.concatenate([x[:64] * c - x[64:] * s_, x[64:] * c + x[:64] * s_])
+
+    for (B, nh, nkv, S0, npads, permute) in [(2, 4, 2, 37, [0, 5], False), (2, 4, 2, 1, [0, 0], False), (3, 4, 2, 130, [0, 17, 64], True),
+                                             (2, 2, 2, 200, [3, 0], False), (2, 4, 2, 300, [0, 40], True), (1, 4, 2, 701, [9], False),
+                                             (2, 4, 2, 32, [0, 31], False), (2, 4, 2, 255, [0, 100], False)]:
+        GQ = nh // nkv
+        pps = (S0 + 1 + 15) // 16 + 1
+        n_pages = B * pps
+        table = g.permutation(n_pages).astype(np.int32).reshape(B, pps) if permute else np.arange(n_pages, dtype=np.int32).reshape(B, pps)
+        ld = (nh + 2 * nkv) * HD
+        qkv = g.standard_normal((B, ld)).astype(np.float32)
+        K = rnd((g.standard_normal((B, nkv, S0, HD)) * 0.7).astype(np.float32))
+        V = rnd(g.standard_normal((B, nkv, S0, HD)).astype(np.float32))
+        kp = np.full((n_pages, nkv, 16, HD), np.nan, np.float32)      # never-written slots must never reach the result
+        vp_ = np.full((n_pages, nkv, HD, 16), np.nan, np.float32)      # V pages: [dim][key]
+        npad = np.asarray(npads, np.int32)
+        for b in range(B):
+            for s_ in range(npad[b], S0):
+                kp[table[b, s_ // 16], :, s_ % 16] = K[b, :, s_]
+                vp_[table[b, s_ // 16], :, :, s_ % 16] = V[b, :, s_]
+        kpool, vpool = _bf16_round(np.nan_to_num(kp, nan=0.0))[1].copy(), _bf16_round(np.nan_to_num(vp_, nan=0.0))[1].copy()
+        kpool[np.isnan(kp)] = 0x7FC0; vpool[np.isnan(vp_)] = 0x7FC0
+        ref = np.zeros((B, nh * HD))
+        newk = np.zeros((B, nkv, HD)); newv = np.zeros((B, nkv, HD))
+        for b in range(B):
+            for h in range(nkv):
+                row = qkv[b]
+                newk[b, h] = rnd(normrope(row[(nh + h) * HD:(nh + h + 1) * HD], kw, S0 - npad[b]).astype(np.float32))
+                newv[b, h] = rnd(row[(nh + nkv + h) * HD:(nh + nkv + h + 1) * HD])
+                keys = np.concatenate([K[b, h].astype(np.float64), newk[b, h][None]], 0)
+                vals = np.concatenate([V[b, h].astype(np.float64), newv[b, h][None]], 0)
+                for gq in range(GQ):
+                    hq = h * GQ + gq
+                    q = normrope(row[hq * HD:(hq + 1) * HD], qw, S0 - npad[b])
+                    sc = keys @ q / np.sqrt(HD)
+                    sc[np.arange(S0 + 1) < npad[b]] = -np.inf
+                    pr = np.exp(sc - sc.max()); pr /= pr.sum()
+                    ref[b, hq * HD:(hq + 1) * HD] = pr @ np.where(np.isfinite(sc)[:, None], vals, 0.0)
+        outs = []
+        for order in (0, 1, 2):
+            kk, vv = kpool.copy(), vpool.copy()
+            out = np.full((B, nh * HD + 4), 5.0, np.float32)
+            emu.hostemu_set_fiber_order(order)
+            try:
+                rc = emu.hostemu_attn_decode(_ptr(qkv), ld, B, 1, nh, nkv, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), _ptr(npad), S0,
+                                             _ptr(kk), _ptr(vv), _ptr(table) if permute else None, pps, 1, _ptr(out), nh * HD + 4, S0 + 4)
+            finally:
+                emu.hostemu_set_fiber_order(0)
+            assert rc == 0, ((B, S0), (emu.qtts_last_error() or b"").decode())
+            outs.append(out)
+            d = out[:, :nh * HD] - ref
+            assert np.isfinite(out).all(), (B, S0, nsplit)
+            assert float(np.abs(d).max()) <= 2e-2 * max(1.0, float(np.abs(ref).max())), (B, nh, S0, nsplit, order, float(np.abs(d).max()))
+            assert float(np.sqrt((d ** 2).mean())) <= 4e-3 * float(np.sqrt((ref ** 2).mean())) + 1e-4, (B, S0, nsplit)
+            assert np.all(out[:, nh * HD:] == 5.0)
+            for b in range(B):                                          # the new K row (row-major) and V row (dim-major) landed in the cache
+                gotk = (kk[table[b, S0 // 16], :, S0 % 16].astype(np.uint32) << 16).view(np.float32)
+                gotv = (vv[table[b, S0 // 16], :, :, S0 % 16].astype(np.uint32) << 16).view(np.float32)
+                assert np.abs(gotk - newk[b]).max() <= 2e-2 and np.abs(gotv - newv[b]).max() <= 1e-6, b
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def _ok(lib, rc):
     assert rc == 0, (rc, (lib.qtts_last_error() or b"").decode())
 

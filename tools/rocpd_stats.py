@@ -4,8 +4,14 @@ import re, sqlite3, sys
 db = sys.argv[1]
 con = sqlite3.connect(db); cur = con.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
-rows = cur.execute("select name, start, end, grid_size_x, workgroup_size_x from kernels order by start").fetchall() if "grid_size_x" in cols else \
-       cur.execute("select name, start, end, 0, 0 from kernels order by start").fetchall()
+# grid (work-items) and workgroup size in x: the column names differ between rocpd schema versions
+gcol = next((c for c in ("grid_size_x", "grid_x", "grid_size") if c in cols), None)
+wcol = next((c for c in ("workgroup_size_x", "workgroup_x", "workgroup_size") if c in cols), None)
+if gcol and wcol:
+    rows = cur.execute(f"select name, start, end, {gcol}, {wcol} from kernels order by start").fetchall()
+else:
+    print("rocpd_stats: no grid / workgroup columns in `kernels` (have: " + ", ".join(cols) + "): no per-shape table", file=sys.stderr)
+    rows = cur.execute("select name, start, end, 0, 0 from kernels order by start").fetchall()
 def short(n):
     n = re.sub(r"\(.*", "", n)
     n = n.replace("qtts::", "")
