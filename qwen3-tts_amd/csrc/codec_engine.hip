@@ -38,7 +38,7 @@ struct qtts_codec {
     std::vector<TLayer> tl;
     struct Up { Lin tconv, pw1, pw2; DevBuf dw_w, dw_b, ln_w, ln_b, gamma; };
     std::vector<Up> ups;
-    struct Unit { Snake a1, a2; Lin c1, c2; };
+    struct Unit { Snake a1, a2; Lin c1, c2; DevBuf w1p, w2p; int dil = 1; bool fused = false; };   // w1p / w2p: resunit.hip's fragment-packed weights
     struct Block { Snake act; Lin tconv; Unit u[3]; int r, cin, cout; };
     std::vector<Block> blocks;
     Snake final_act;
@@ -345,6 +345,24 @@ void qtts_codec::finalize() {
             make_snake(b.u[j].a2, up + "act2");
             make_conv(b.u[j].c1, up + "conv1.conv", dil[j]);
             make_conv(b.u[j].c2, up + "conv2.conv", 1);
+            // bf16 mode, C = 96 | 192 (the two blocks with the most rows): the unit runs as ONE kernel (resunit.hip) on weights
+            // packed into MFMA fragments here.  QTTS_CODEC_FUSED=0 keeps the two tap-GEMM launches (A/B runs).
+            static const bool fused_env = [] { const char* e = getenv("QTTS_CODEC_FUSED"); return !e || atoi(e) != 0; }();
+            b.u[j].dil = dil[j];
+            if (bf16 && fused_env && resunit_supported(b.cout)) {
+                const int Cc = b.cout;
+                auto& w1 = P(up + "conv1.conv.weight");            // (Cout, Cin, 7) -> [tap][n][k]
+                std::vector<float> r1((size_t)7 * Cc * Cc);
+                for (int t = 0; t < 7; ++t)
+                    for (int n2 = 0; n2 < Cc; ++n2)
+                        for (int k = 0; k < Cc; ++k) r1[((size_t)t * Cc + n2) * Cc + k] = w1[((size_t)n2 * Cc + k) * 7 + t];
+                std::vector<bf16_t> h1(resunit_packed_elems(Cc, 7)), h2(resunit_packed_elems(Cc, 1));
+                pack_resunit_weight(r1.data(), Cc, 7, true, h1.data());
+                pack_resunit_weight(P(up + "conv2.conv.weight").data(), Cc, 1, false, h2.data());     // (Cout, Cin, 1) == [n][k]
+                b.u[j].w1p.upload(h1.data(), h1.size() * 2);
+                b.u[j].w2p.upload(h2.data(), h2.size() * 2);
+                b.u[j].fused = true;
+            }
         }
     }
     const int n = c.n_upsample_rates;
@@ -494,11 +512,25 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
             for (int j = 0; j < 3; ++j) {
                 auto& un = bk.u[j];
                 const Snake* next = j < 2 ? &bk.u[j + 1].a1 : (i + 1 < blocks.size() ? &blocks[i + 1].act : nullptr);
-                gemm16(un.c1, nullptr, h16a, C, B * L, L, nullptr, C, ACT_SNAKE, nullptr, 0, &un.a2, h16b, nullptr, st);   // conv7 + act2 -> bf16
                 // the last unit of a block feeds only the next block's transposed conv (the activated bf16 copy): its residual-stream
                 // output is written only where the tensor leaves the blocks (last block) or a stage was asked for
                 const bool leaves = j == 2 && i + 1 == blocks.size();
                 const bool dead = j == 2 && !leaves && !stage;
+                if (un.fused) {                    // conv7 -> SnakeBeta_2 -> conv1x1 -> + residual in one kernel (resunit.hip)
+                    ResUnitParams rp{};
+                    rp.A16 = h16a; rp.lda = C; rp.res = cur; rp.ldr = C; rp.M = B * L; rp.T = L; rp.dil = un.dil; rp.Cch = C;
+                    rp.W1p = un.w1p.p; rp.b1 = un.c1.bias.as<float>(); rp.ea2 = un.a2.ea.as<float>(); rp.ib2 = un.a2.ib.as<float>();
+                    rp.W2p = un.w2p.p; rp.b2 = un.c2.bias.as<float>();
+                    rp.C = dead ? nullptr : alt; rp.ldc = C;
+                    // (its bf16 output must not alias its bf16 input: a tile's halo rows are other tiles' output rows)
+                    rp.C16 = next ? h16b : nullptr; rp.ldc16 = C;
+                    rp.ea16 = next ? next->ea.as<float>() : nullptr; rp.ib16 = next ? next->ib.as<float>() : nullptr;
+                    launch_resunit(rp, st);
+                    std::swap(h16a, h16b);         // h16a: the next unit's (or next block's) activated input
+                    std::swap(cur, alt);
+                    continue;
+                }
+                gemm16(un.c1, nullptr, h16a, C, B * L, L, nullptr, C, ACT_SNAKE, nullptr, 0, &un.a2, h16b, nullptr, st);   // conv7 + act2 -> bf16
                 (void)leaves;
                 gemm16(un.c2, nullptr, h16b, C, B * L, L, dead ? nullptr : alt, C, ACT_NONE, cur, C, nullptr, next ? h16a : nullptr, next, st);  // 1x1 + residual
                 std::swap(cur, alt);               // ping-pong between a and b: the residual input is never the output

@@ -1,0 +1,274 @@
+// resunit.hip -- ONE kernel per residual unit of the codec decoder's blocks (gfx950, bf16 mode).
+//
+//   y = x + conv1x1( SnakeBeta_2( conv7_dil( SnakeBeta_1(x) ) ) )          Qwen3TTSTokenizerV2DecoderDecoderResidualUnit, V2:619-635
+//
+// 78 % of the codec decoder's FLOPs are these units (SURVEY.md 8a').  Until round 3 a unit was two tap-GEMM launches with the
+// activated tile round-tripping through HBM in between, 128-row tiles, one barrier per 32-wide k-step and tap (21 barriers per
+// conv7 tile at C = 96) and a 64 x 48 register tile per wave (two LDS operand reads per four MFMAs): 13.7 % MFMA-busy on the
+// C = 96 / 192 instantiation, and the 1x1 convolution's time was its fp32 residual tile (profiles/r02_pmc_mfma_codec.md,
+// r02_tstamp_codec_gemm.md).  Here, for C = 96 and C = 192 (the two blocks with the most rows):
+//   * the unit's input tile -- SnakeBeta_1(x) as bf16, written by its producer -- is staged ONCE per workgroup with its causal halo
+//     (6 x dilation rows) by LDS-DMA; all 7 taps read it with a row offset (zeroed in the operand registers where a row would come
+//     from before the start of its sequence);
+//   * weights are pre-packed at finalize into MFMA A-operand fragments (96 x 96 chunks of 18 KB) and streamed through a two-deep
+//     LDS ring by LDS-DMA, one chunk per step, ONE barrier per step (7 per conv7 tile at C = 96);
+//   * a wave owns a 64-row x 96-column register tile (24 accumulators): per 32 of k it reads 4 activation + 6 weight fragments for
+//     24 MFMAs -- 2.4 MFMAs per LDS operand read instead of 2, and 72 MFMAs between barriers instead of 12;
+//   * conv7's accumulators never leave the registers: bias + SnakeBeta_2 are applied in place and the result IS the B operand of
+//     the 1x1 convolution -- the output channels of conv7 are assigned to MFMA columns in a permuted order (tile j, column 4 q + r
+//     = channel 32 (j / 2) + 8 q + 4 (j % 2) + r) so that lane (row, q) ends up holding channels 32 kk + 8 q .. + 8: exactly the
+//     fragment the next MFMA wants from it.  No LDS round trip, no HBM round trip (C = 192: the two column halves of a row tile
+//     live in two waves and swap their halves through LDS once);
+//   * epilogue: + bias + fp32 residual -> fp32 residual stream out, and the NEXT consumer's SnakeBeta folded in for its bf16 copy.
+// Arithmetic: bf16 operands, fp32 accumulation, v_sin_f32 SnakeBeta -- the same as gemm_tap2 + tap_epilogue<FAST>.
+#include "common.h"
+#include "kernels.h"
+
+namespace qtts {
+
+namespace {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ru_snake(float v, float ea, float ib) {      // y = v + ib * sin^2(v * ea), v_sin_f32 takes revolutions
+    const float sn = __builtin_amdgcn_sinf(v * ea * 0.15915494309189535f);
+    return v + ib * (sn * sn);
+}
+// MFMA column (tile j, feature f = 4 q + r) of conv7's output <-> channel inside the wave's 96-channel chunk
+__host__ __device__ inline int ru_chan(int j, int f) { return 32 * (j >> 1) + 8 * (f >> 2) + 4 * (j & 1) + (f & 3); }
+
+__device__ __forceinline__ void ru_dma16(const void* src, void* lds_dst) {       // 64 lanes x 16 B -> 1 KiB of LDS, lane-linear
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+}  // namespace
+
+constexpr int RU_CH = 96;                          // channels per chunk
+constexpr int RU_FRAG = 3 * 6 * 64 * 8;            // bf16 elements of one packed 96 x 96 chunk: [kk 3][j 6][lane 64][8]
+
+// NC = C / 96.  Workgroup = 4 waves: NC = 1 -> 4 row groups of 64 rows (256-row tile); NC = 2 -> 2 row groups x 2 column halves
+// (128-row tile).  LDS: the activated input tile [(RW + halo)][C + 8] bf16 (rows 16 B apart from a bank-conflict-free stride),
+// then the weight ring [2][NC][RU_FRAG] bf16.
+template <int NC>
+__global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo, int a_bytes /* LDS bytes reserved for the input tile (multiple of 1024) */) {
+    constexpr int C = RU_CH * NC, WR = 4 / NC, RW = 64 * WR, STR = C + 8, RS = STR * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ru[];
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem_ru);
+    bf16_t* Wst = reinterpret_cast<bf16_t*>(smem_ru + a_bytes);                // [2][NC][RU_FRAG]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave % WR, wc = wave / WR;
+    const int li = lane & 15, lq = lane >> 4;
+    const int m0 = blockIdx.x * RW;
+    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(p.A16);
+    const bf16_t* W1p = reinterpret_cast<const bf16_t*>(p.W1p);
+    const bf16_t* W2p = reinterpret_cast<const bf16_t*>(p.W2p);
+
+    // ---- 0. stage the input tile (rows m0 - halo .. m0 + RW - 1) and weight chunk 0.  LDS byte o -> (row, col) = divmod(o, RS);
+    // the 16-B row pad and rows outside [0, M) fetch some valid address: such rows only ever feed output rows that are not stored
+    // (rows >= M) or are zeroed at the operand (rows before the start of a sequence).
+    const int a_need = (RW + halo) * RS;
+    for (int c = wave; c * 1024 < a_need; c += 4) {
+        const int o = c * 1024 + lane * 16;
+        const int row = o / RS, col = o - row * RS;
+        int gr = m0 - halo + row;
+        gr = gr < 0 ? 0 : (gr >= p.M ? p.M - 1 : gr);
+        const unsigned char* src = A16 + (size_t)gr * p.lda * 2 + (col < C * 2 ? col : 0);
+        ru_dma16(src, smem_ru + c * 1024);
+    }
+    auto stage_w = [&](const bf16_t* chunk, int buf) {                         // NC x 18 KB, fragment order: a linear copy
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(chunk);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(Wst + (size_t)buf * NC * RU_FRAG);
+        for (int c = wave; c < NC * RU_FRAG * 2 / 1024; c += 4) ru_dma16(src + c * 1024 + lane * 16, dst + c * 1024);
+    };
+    stage_w(W1p, 0);
+
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int tpos[4];                                       // position of this lane's rows inside their sequence
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tpos[i] = (m0 + wr * 64 + i * 16 + li) % p.T;
+    __syncthreads();
+
+    // ---- 1. conv7: steps (tap, kc); the chunk of step s + 1 (or the first 1x1 chunk) lands in the other ring slot meanwhile
+    constexpr int NSTEP = 7 * NC;
+#pragma unroll 1
+    for (int s = 0; s < NSTEP; ++s) {
+        const int tap = s / NC, kc = s - tap * NC;
+        if (s + 1 < NSTEP) stage_w(W1p + (size_t)(s + 1) * NC * RU_FRAG, (s + 1) & 1);
+        else stage_w(W2p, (s + 1) & 1);
+        const bf16_t* Wb = Wst + ((size_t)(s & 1) * NC + wc) * RU_FRAG;
+        const int sh = -(6 - tap) * p.dil;             // output row m reads staged row (m - m0) + halo + sh
+        u32x4 wf[3][6];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) wf[kk][j] = *reinterpret_cast<const u32x4*>(&Wb[((kk * 6 + j) * 64 + lane) * 8]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t* ar = &As[(wr * 64 + i * 16 + li + halo + sh) * STR + kc * RU_CH + lq * 8];
+            const bool zero = tpos[i] + sh < 0;        // before the start of its own sequence: the causal left padding
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                u32x4 a = *reinterpret_cast<const u32x4*>(ar + kk * 32);
+                if (zero) a = (u32x4){0u, 0u, 0u, 0u};
+                bf16x8 ab;
+                *reinterpret_cast<u32x4*>(&ab) = a;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    bf16x8 wb;
+                    *reinterpret_cast<u32x4*>(&wb) = wf[kk][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, ab, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                               // (drains the DMA of the next chunk as well: it is complete for step s + 1)
+    }
+
+    // ---- 2. bias + SnakeBeta_2 in place; the result is the B operand of the 1x1 convolution (this wave's 96 channels, 3 k-steps)
+    u32x4 a2[4][3];
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+        const int c0 = wc * RU_CH + 32 * kk + 8 * lq;              // channels c0 .. c0 + 7 of this lane
+        const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + c0), bB = *reinterpret_cast<const f32x4*>(p.b1 + c0 + 4);
+        const f32x4 eA = *reinterpret_cast<const f32x4*>(p.ea2 + c0), eB = *reinterpret_cast<const f32x4*>(p.ea2 + c0 + 4);
+        const f32x4 iA = *reinterpret_cast<const f32x4*>(p.ib2 + c0), iB = *reinterpret_cast<const f32x4*>(p.ib2 + c0 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = ru_snake(acc[i][2 * kk][r] + bA[r], eA[r], iA[r]);
+                v[4 + r] = ru_snake(acc[i][2 * kk + 1][r] + bB[r], eB[r], iB[r]);
+            }
+            a2[i][kk][0] = pack_bf16(v[0], v[1]); a2[i][kk][1] = pack_bf16(v[2], v[3]);
+            a2[i][kk][2] = pack_bf16(v[4], v[5]); a2[i][kk][3] = pack_bf16(v[6], v[7]);
+        }
+    }
+    if constexpr (NC == 2) {
+        // the 1x1 convolution contracts over all 192 channels: the other half of this row tile lives in the wave with the same row
+        // group and the other column half.  Every wave publishes its half as [row][channel] bf16 in the (now free) input-tile area.
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk)
+                *reinterpret_cast<u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + wc * RU_CH + 32 * kk + 8 * lq]) = a2[i][kk];
+        __syncthreads();
+    }
+
+    // ---- 3. 1x1 convolution: chunk kc of the contraction; its weights are in ring slot (NSTEP + kc) & 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kc = 0; kc < NC; ++kc) {
+        if (kc + 1 < NC) stage_w(W2p + (size_t)(kc + 1) * NC * RU_FRAG, (NSTEP + kc + 1) & 1);
+        const bf16_t* Wb = Wst + ((size_t)((NSTEP + kc) & 1) * NC + wc) * RU_FRAG;
+        u32x4 wf[3][6];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) wf[kk][j] = *reinterpret_cast<const u32x4*>(&Wb[((kk * 6 + j) * 64 + lane) * 8]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                u32x4 a = a2[i][kk];
+                if (NC == 2 && kc != wc) a = *reinterpret_cast<const u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + kc * RU_CH + 32 * kk + 8 * lq]);
+                bf16x8 ab;
+                *reinterpret_cast<u32x4*>(&ab) = a;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    bf16x8 wb;
+                    *reinterpret_cast<u32x4*>(&wb) = wf[kk][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, ab, acc[i][j], 0, 0, 0);
+                }
+            }
+        if (kc + 1 < NC) __syncthreads();
+    }
+
+    // ---- 4. epilogue: + bias + residual -> fp32 stream; the next consumer's SnakeBeta folded into its bf16 copy.  All operand vectors
+    // of a column quad are requested unconditionally and back to back (rows past M re-read row M - 1; selected at the store).
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int n = wc * RU_CH + 16 * j + 4 * lq;
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + n);
+        const f32x4 e16 = *reinterpret_cast<const f32x4*>((p.ea16 ? p.ea16 : p.b2) + n);
+        const f32x4 i16 = *reinterpret_cast<const f32x4*>((p.ib16 ? p.ib16 : p.b2) + n);
+        f32x4 res[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + li, mc = m < p.M ? m : p.M - 1;
+            res[i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.ldr + n);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wr * 64 + i * 16 + li;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + b2 + res[i];
+            if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            if (p.C16) {
+                if (p.ea16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = ru_snake(v[r], e16[r], i16[r]);
+                }
+                uint2 h;
+                h.x = pack_bf16(v[0], v[1]); h.y = pack_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C16) + (size_t)m * p.ldc16 + n) = h;
+            }
+        }
+    }
+}
+
+bool resunit_supported(int C) { return C == 96 || C == 192; }
+size_t resunit_packed_elems(int C, int taps) { return (size_t)taps * (C / RU_CH) * (C / RU_CH) * RU_FRAG; }
+
+// W[taps][N = C][K = C] (row-major f32) -> [tap][kc][wc][kk 3][j 6][lane 64][8] bf16: the fragment of lane (f = lane & 15, q = lane >> 4)
+// is W[tap][96 wc + col(j, f)][96 kc + 32 kk + 8 q .. + 8], col = the permuted channel order for conv7's weights (permute_cols),
+// the plain order 16 j + f for the 1x1 convolution.
+void pack_resunit_weight(const float* W, int C, int taps, bool permute_cols, bf16_t* out) {
+    const int NC = C / RU_CH;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int kc = 0; kc < NC; ++kc)
+            for (int wc = 0; wc < NC; ++wc)
+                for (int kk = 0; kk < 3; ++kk)
+                    for (int j = 0; j < 6; ++j)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int f = lane & 15, q = lane >> 4;
+                            const int n = RU_CH * wc + (permute_cols ? ru_chan(j, f) : 16 * j + f);
+                            const float* src = W + ((size_t)tap * C + n) * C + RU_CH * kc + 32 * kk + 8 * q;
+                            bf16_t* dst = out + ((((((size_t)tap * NC + kc) * NC + wc) * 3 + kk) * 6 + j) * 64 + lane) * 8;
+                            for (int e = 0; e < 8; ++e) dst[e] = f32_to_bf16(src[e]);
+                        }
+}
+
+template <int NC>
+static void launch_ru(const ResUnitParams& p, hipStream_t st) {
+    constexpr int C = RU_CH * NC, RW = 64 * (4 / NC);
+    const int halo = 6 * p.dil;
+    const int a_bytes = ((RW + halo) * (C + 8) * 2 + 1023) & ~1023;
+    const size_t lds = (size_t)a_bytes + 2 * NC * RU_FRAG * 2;
+    QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "resunit: LDS budget exceeded");
+    auto kern = resunit_kernel<NC>;
+    static bool attr_set = false;          // one flag per instantiation
+    if (!attr_set) {
+        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(p.M, RW)), dim3(256), lds, st, p, halo, a_bytes);
+}
+
+void launch_resunit(const ResUnitParams& p, hipStream_t st) {
+    QTTS_REQUIRE(resunit_supported(p.Cch), QTTS_ERR_ARG, "resunit: C must be 96 or 192");
+    QTTS_REQUIRE(p.A16 && p.res && p.W1p && p.W2p && p.b1 && p.b2 && p.ea2 && p.ib2 && (p.C || p.C16), QTTS_ERR_ARG, "resunit: null operand");
+    QTTS_REQUIRE(p.M > 0 && p.T > 0 && p.dil >= 1 && 6 * p.dil <= 56, QTTS_ERR_ARG, "resunit: shape");
+    QTTS_REQUIRE(p.lda % 8 == 0 && p.ldr % 4 == 0 && (!p.C || p.ldc % 4 == 0) && (!p.C16 || p.ldc16 % 4 == 0), QTTS_ERR_ARG, "resunit: leading dimensions");
+    QTTS_REQUIRE((p.ea16 == nullptr) == (p.ib16 == nullptr), QTTS_ERR_ARG, "resunit: snake16 parameters go together");
+    if (p.Cch == 96) launch_ru<1>(p, st); else launch_ru<2>(p, st);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace qtts

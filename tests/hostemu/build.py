@@ -34,7 +34,7 @@ OUT = os.path.join(HERE, f"libqtts_hostemu{_TAG}.so")
 GEN = os.path.join(HERE, "gen" + _TAG)
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
 SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "sampling.hip",
-                "elementwise.hip", "skinny.hip", "gemm_tap.hip"]
+                "elementwise.hip", "skinny.hip", "gemm_tap.hip", "resunit.hip"]
 # kernels without barriers / cross-lane ops run as plain per-thread calls (no fibers): much faster for large grids
 SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}
 # gemm_tap.hip is built as launch_gemm_tap_real; cpu_gemm_tap.cpp owns launch_gemm_tap and forwards to it on request

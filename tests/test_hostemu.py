@@ -57,6 +57,7 @@ def emu():
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
     lib.hostemu_skinny_bf16x.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32, vp]
+    lib.hostemu_resunit.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.hostemu_sample.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_float, i32, i32, vp, i32, i32, C.c_float, C.c_float,
                                    C.c_uint64, C.c_uint32, i32, vp]
     lib.hostemu_attn_decode.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, C.c_float, vp, vp, i32, vp, vp, vp, i32, i32, vp,
@@ -200,6 +201,46 @@ def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
             got = (out16[:, :N].astype(np.uint32) << 16).view(np.float32)
             assert np.abs(got - want16).max() <= 1e-2 * max(1.0, float(np.abs(want16).max())), (M, N, K, shift, float(np.abs(got - want16).max()))
             assert np.all(out16[:, N:] == 0x4242)
+
+
+@pytest.mark.parametrize("C,M,T,dil", [(96, 600, 300, 1), (96, 300, 100, 9), (96, 77, 77, 3), (192, 300, 150, 9), (192, 130, 65, 1)])
+def test_resunit_fused_kernel_real_source(emu, C, M, T, dil):
+    """resunit.hip's fused residual unit (round 3: conv7 -> SnakeBeta -> conv1x1 -> + residual in ONE kernel, weights pre-packed into
+    MFMA fragments, conv7's output channels permuted so that its accumulators are the next MFMA's operand) from its real source
+    against float64 numpy on bf16-rounded operands: several sequences per tile (causal zero rows inside a tile), partial last
+    tile, all three dilations, both channel counts (C = 192 runs the two-wave column split with the LDS half swap)."""
+    g = np.random.default_rng(C + M + dil)
+    x = g.standard_normal((M, C)).astype(np.float32)
+    a1e, a1i = np.exp(0.3 * g.standard_normal(C)).astype(np.float32), (1.0 / (np.exp(0.3 * g.standard_normal(C)) + 1e-9)).astype(np.float32)
+    a16f, a16 = _bf16_round((x + a1i * np.sin(x * a1e) ** 2).astype(np.float32))
+    W1 = (g.standard_normal((7, C, C)) / np.sqrt(7 * C)).astype(np.float32)
+    W2 = (g.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)
+    b1, b2 = (0.1 * g.standard_normal(C)).astype(np.float32), (0.1 * g.standard_normal(C)).astype(np.float32)
+    ea2, ib2 = np.exp(0.3 * g.standard_normal(C)).astype(np.float32), (1.0 / (np.exp(0.3 * g.standard_normal(C)) + 1e-9)).astype(np.float32)
+    ea16, ib16 = np.exp(0.3 * g.standard_normal(C)).astype(np.float32), (1.0 / (np.exp(0.3 * g.standard_normal(C)) + 1e-9)).astype(np.float32)
+    W1r, W2r = _bf16_round(W1)[0].astype(np.float64), _bf16_round(W2)[0].astype(np.float64)
+    y1 = np.tile(b1.astype(np.float64), (M, 1))
+    for tap in range(7):
+        sh = -(6 - tap) * dil
+        for m in range(M):
+            if (m % T) + sh >= 0:
+                y1[m] += W1r[tap] @ a16f[m + sh].astype(np.float64)
+    act = _bf16_round((y1 + ib2 * np.sin(y1 * ea2) ** 2).astype(np.float32))[0].astype(np.float64)
+    y2 = act @ W2r.T + b2 + x
+    want16 = y2 + ib16 * np.sin(y2 * ea16) ** 2
+    for with16 in (True, False):
+        out = np.full((M, C + 4), 7.0, np.float32)
+        c16 = np.zeros((M, C + 4), np.uint16)
+        rc = emu.hostemu_resunit(_ptr(a16), C, _ptr(x), C, M, T, dil, C, _ptr(W1), _ptr(b1), _ptr(ea2), _ptr(ib2), _ptr(W2), _ptr(b2),
+                                 _ptr(out), C + 4, _ptr(c16), _ptr(ea16) if with16 else None, _ptr(ib16) if with16 else None)
+        assert rc == 0, (emu.qtts_last_error() or b"").decode()
+        assert np.all(out[:, C:] == 7.0) and np.all(c16[:, C:] == 0)
+        err = float(np.abs(out[:, :C] - y2).max())
+        assert err <= 4e-3 * max(1.0, float(np.abs(y2).max())), (C, M, T, dil, err)      # (a bf16 flip of one activation moves a sum by ~1e-3)
+        assert float(np.sqrt(((out[:, :C] - y2) ** 2).mean())) <= 4e-4 * float(np.sqrt((y2 ** 2).mean()))
+        got16 = (c16[:, :C].astype(np.uint32) << 16).view(np.float32)
+        ref16 = want16 if with16 else y2
+        assert float(np.abs(got16 - ref16).max()) <= 1.2e-2 * max(1.0, float(np.abs(ref16).max()))
 
 
 @pytest.mark.parametrize("bf16", [0, 1])
