@@ -657,6 +657,10 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
     else if (p.N % 96 == 0) bn = 96;
     else if (p.N <= 64) bn = 64;
     else bn = 128;
+    // A grid that leaves most of the 256 CUs idle (the talker prefill's o / down projections: 512 rows x 2048 columns = 64 tiles of
+    // 128 x 128) runs 64-column tiles instead: twice the workgroups pulling the same weights (QTTS_GEMM_NARROW=0: A/B).
+    static const bool narrow_env = [] { const char* e = getenv("QTTS_GEMM_NARROW"); return !e || atoi(e) != 0; }();
+    if (narrow_env && bf16 && bn == 128 && p.act != ACT_SWIGLU && p.taps == 1 && cdiv(p.M, 128) * cdiv(p.N, 128) < 128 && p.N % 64 == 0) bn = 64;
     // small grids are latency-bound per k-step: use the deep-k kernel (bf16, plain Linear)
     const int nb = cdiv(p.M, 128) * cdiv(p.N, bn);
     if (bf16 && p.taps == 1 && p.shift[0] == 0 && p.K % 128 == 0 && p.K >= 512 && nb <= 1024 && (bn == 128 || bn == 64)) {
