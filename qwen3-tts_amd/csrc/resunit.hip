@@ -10,8 +10,9 @@
 //   * the unit's input tile -- SnakeBeta_1(x) as bf16, written by its producer -- is staged ONCE per workgroup with its causal halo
 //     (6 x dilation rows) by LDS-DMA; all 7 taps read it with a row offset (zeroed in the operand registers where a row would come
 //     from before the start of its sequence);
-//   * weights are pre-packed at finalize into MFMA A-operand fragments (96 x 96 chunks of 18 KB) and streamed through a two-deep
-//     LDS ring by LDS-DMA, one chunk per step, ONE barrier per step (7 per conv7 tile at C = 96);
+//   * weights are pre-packed at finalize into MFMA A-operand fragments (96 x 96 chunks of 18 KB) and streamed through a two-slot
+//     LDS ring, one chunk per step, ONE barrier per step (7 per conv7 tile at C = 96); a chunk is requested into registers
+//     three steps before its use, so no step waits for memory;
 //   * a wave owns a 64-row x 96-column register tile (24 accumulators): per 32 of k it reads 4 activation + 6 weight fragments for
 //     24 MFMAs -- 2.4 MFMAs per LDS operand read instead of 2, and 72 MFMAs between barriers instead of 12;
 //   * conv7's accumulators never leave the registers: bias + SnakeBeta_2 are applied in place and the result IS the B operand of
@@ -63,9 +64,34 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
     const bf16_t* W1p = reinterpret_cast<const bf16_t*>(p.W1p);
     const bf16_t* W2p = reinterpret_cast<const bf16_t*>(p.W2p);
 
-    // ---- 0. stage the input tile (rows m0 - halo .. m0 + RW - 1) and weight chunk 0.  LDS byte o -> (row, col) = divmod(o, RS);
-    // the 16-B row pad and rows outside [0, M) fetch some valid address: such rows only ever feed output rows that are not stored
-    // (rows >= M) or are zeroed at the operand (rows before the start of a sequence).
+    // ---- 0. weight stages 0..2 are requested first (global -> registers), then the input tile (rows m0 - halo .. m0 + RW - 1) by
+    // LDS-DMA.  LDS byte o -> (row, col) = divmod(o, RS); the 16-B row pad and rows outside [0, M) fetch some valid address: such
+    // rows only ever feed output rows that are not stored (rows >= M) or are zeroed at the operand (rows before a sequence start).
+    //
+    // The weight stream: stage k = 96 x 96 chunk(s) (tap, kc) of conv7 for k < 7 NC, then the NC chunks of the 1x1 convolution --
+    // NC x 18 KB each, fragment order, so a stage is a linear copy.  A stage travels global -> registers THREE steps ahead of its
+    // use and registers -> LDS ring slot one step ahead (first measurement of this kernel, profiles/r03_codec_*call3*: with the
+    // stage requested by LDS-DMA at the top of the step before its use, a step -- 72 MFMAs per wave, 0.5 us -- waited ~2.4 us for
+    // the DMA at its closing barrier: 16-20 % MFMA-busy.  Register staging lets the compiler wait for exactly the three-steps-old
+    // loads; nothing is in flight towards LDS at a barrier).
+    constexpr int TS = 8 * NC;                                   // stages = steps: 7 NC of conv7 + NC of the 1x1 convolution
+    constexpr int NCHUNK = NC * RU_FRAG * 2 / 16;                // 16-B chunks per stage
+    constexpr int NR = (NCHUNK + 255) / 256;
+    u32x4 wreg[3][NR];
+    auto stage_ptr = [&](int k) -> const u32x4* {
+        return reinterpret_cast<const u32x4*>(k < 7 * NC ? W1p + (size_t)k * NC * RU_FRAG : W2p + (size_t)(k - 7 * NC) * NC * RU_FRAG);
+    };
+    auto load_stage = [&](u32x4 (&r)[NR], int k) {
+        const u32x4* src = stage_ptr(k);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { const int idx = tid + 256 * i; r[i] = src[idx < NCHUNK ? idx : 0]; }
+    };
+    auto store_stage = [&](const u32x4 (&r)[NR], int slot) {
+        u32x4* dst = reinterpret_cast<u32x4*>(Wst + (size_t)slot * NC * RU_FRAG);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { const int idx = tid + 256 * i; if (idx < NCHUNK) dst[idx] = r[i]; }
+    };
+    load_stage(wreg[0], 0); load_stage(wreg[1], 1); load_stage(wreg[2], 2);
     const int a_need = (RW + halo) * RS;
     for (int c = wave; c * 1024 < a_need; c += 4) {
         const int o = c * 1024 + lane * 16;
@@ -75,12 +101,8 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
         const unsigned char* src = A16 + (size_t)gr * p.lda * 2 + (col < C * 2 ? col : 0);
         ru_dma16(src, smem_ru + c * 1024);
     }
-    auto stage_w = [&](const bf16_t* chunk, int buf) {                         // NC x 18 KB, fragment order: a linear copy
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(chunk);
-        unsigned char* dst = reinterpret_cast<unsigned char*>(Wst + (size_t)buf * NC * RU_FRAG);
-        for (int c = wave; c < NC * RU_FRAG * 2 / 1024; c += 4) ru_dma16(src + c * 1024 + lane * 16, dst + c * 1024);
-    };
-    stage_w(W1p, 0);
+    store_stage(wreg[0], 0);
+    load_stage(wreg[0], 3);
 
     f32x4 acc[4][6];
 #pragma unroll
@@ -90,104 +112,96 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
     int tpos[4];                                       // position of this lane's rows inside their sequence
 #pragma unroll
     for (int i = 0; i < 4; ++i) tpos[i] = (m0 + wr * 64 + i * 16 + li) % p.T;
-    __syncthreads();
+    u32x4 a2[4][3];                                    // SnakeBeta_2(conv7) of this wave's 64 rows x 96 channels: B operand of the 1x1
+    __syncthreads();                                   // (the input tile's DMA has landed)
 
-    // ---- 1. conv7: steps (tap, kc); the chunk of step s + 1 (or the first 1x1 chunk) lands in the other ring slot meanwhile
-    constexpr int NSTEP = 7 * NC;
-#pragma unroll 1
-    for (int s = 0; s < NSTEP; ++s) {
-        const int tap = s / NC, kc = s - tap * NC;
-        if (s + 1 < NSTEP) stage_w(W1p + (size_t)(s + 1) * NC * RU_FRAG, (s + 1) & 1);
-        else stage_w(W2p, (s + 1) & 1);
+    // ---- 1..3. the steps, fully unrolled (register sets and ring slots are compile-time): conv7 (tap, kc), then the 1x1 (kc)
+#pragma unroll
+    for (int s = 0; s < TS; ++s) {
+        if (s + 1 < TS) store_stage(wreg[(s + 1) % 3], (s + 1) & 1);       // stage s + 1: requested >= 2 steps ago; its slot was last read in step s - 1
+        if (s + 4 < TS) load_stage(wreg[(s + 1) % 3], s + 4);
         const bf16_t* Wb = Wst + ((size_t)(s & 1) * NC + wc) * RU_FRAG;
-        const int sh = -(6 - tap) * p.dil;             // output row m reads staged row (m - m0) + halo + sh
+        if (s == 7 * NC) {
+            // ---- 2. bias + SnakeBeta_2 in place; the result is the B operand of the 1x1 convolution (this wave's 96 channels, 3 k-steps)
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int c0 = wc * RU_CH + 32 * kk + 8 * lq;              // channels c0 .. c0 + 7 of this lane
+                const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + c0), bB = *reinterpret_cast<const f32x4*>(p.b1 + c0 + 4);
+                const f32x4 eA = *reinterpret_cast<const f32x4*>(p.ea2 + c0), eB = *reinterpret_cast<const f32x4*>(p.ea2 + c0 + 4);
+                const f32x4 iA = *reinterpret_cast<const f32x4*>(p.ib2 + c0), iB = *reinterpret_cast<const f32x4*>(p.ib2 + c0 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = ru_snake(acc[i][2 * kk][r] + bA[r], eA[r], iA[r]);
+                        v[4 + r] = ru_snake(acc[i][2 * kk + 1][r] + bB[r], eB[r], iB[r]);
+                    }
+                    a2[i][kk][0] = pack_bf16(v[0], v[1]); a2[i][kk][1] = pack_bf16(v[2], v[3]);
+                    a2[i][kk][2] = pack_bf16(v[4], v[5]); a2[i][kk][3] = pack_bf16(v[6], v[7]);
+                }
+            }
+            if constexpr (NC == 2) {
+                // the 1x1 convolution contracts over all 192 channels: the other half of this row tile lives in the wave with the same
+                // row group and the other column half.  Every wave publishes its half as [row][channel] bf16 in the (now free: the
+                // barrier that closed step s - 1 is behind every wave) input-tile area.
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk)
+                        *reinterpret_cast<u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + wc * RU_CH + 32 * kk + 8 * lq]) = a2[i][kk];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         u32x4 wf[3][6];
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
             for (int j = 0; j < 6; ++j) wf[kk][j] = *reinterpret_cast<const u32x4*>(&Wb[((kk * 6 + j) * 64 + lane) * 8]);
+        if (s < 7 * NC) {                              // conv7, step (tap, kc)
+            const int tap = s / NC, kc = s - tap * NC;
+            const int sh = -(6 - tap) * p.dil;         // output row m reads staged row (m - m0) + halo + sh
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16_t* ar = &As[(wr * 64 + i * 16 + li + halo + sh) * STR + kc * RU_CH + lq * 8];
-            const bool zero = tpos[i] + sh < 0;        // before the start of its own sequence: the causal left padding
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* ar = &As[(wr * 64 + i * 16 + li + halo + sh) * STR + kc * RU_CH + lq * 8];
+                const bool zero = tpos[i] + sh < 0;    // before the start of its own sequence: the causal left padding
 #pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                u32x4 a = *reinterpret_cast<const u32x4*>(ar + kk * 32);
-                if (zero) a = (u32x4){0u, 0u, 0u, 0u};
-                bf16x8 ab;
-                *reinterpret_cast<u32x4*>(&ab) = a;
+                for (int kk = 0; kk < 3; ++kk) {
+                    u32x4 a = *reinterpret_cast<const u32x4*>(ar + kk * 32);
+                    if (zero) a = (u32x4){0u, 0u, 0u, 0u};
+                    bf16x8 ab;
+                    *reinterpret_cast<u32x4*>(&ab) = a;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    bf16x8 wb;
-                    *reinterpret_cast<u32x4*>(&wb) = wf[kk][j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, ab, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 6; ++j) {
+                        bf16x8 wb;
+                        *reinterpret_cast<u32x4*>(&wb) = wf[kk][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, ab, acc[i][j], 0, 0, 0);
+                    }
                 }
             }
-        }
-        __syncthreads();                               // (drains the DMA of the next chunk as well: it is complete for step s + 1)
-    }
-
-    // ---- 2. bias + SnakeBeta_2 in place; the result is the B operand of the 1x1 convolution (this wave's 96 channels, 3 k-steps)
-    u32x4 a2[4][3];
+        } else {                                       // the 1x1 convolution, chunk kc of its contraction
+            const int kc = s - 7 * NC;
 #pragma unroll
-    for (int kk = 0; kk < 3; ++kk) {
-        const int c0 = wc * RU_CH + 32 * kk + 8 * lq;              // channels c0 .. c0 + 7 of this lane
-        const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + c0), bB = *reinterpret_cast<const f32x4*>(p.b1 + c0 + 4);
-        const f32x4 eA = *reinterpret_cast<const f32x4*>(p.ea2 + c0), eB = *reinterpret_cast<const f32x4*>(p.ea2 + c0 + 4);
-        const f32x4 iA = *reinterpret_cast<const f32x4*>(p.ib2 + c0), iB = *reinterpret_cast<const f32x4*>(p.ib2 + c0 + 4);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v[8];
+                for (int kk = 0; kk < 3; ++kk) {
+                    u32x4 a = a2[i][kk];
+                    if (NC == 2 && kc != wc) a = *reinterpret_cast<const u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + kc * RU_CH + 32 * kk + 8 * lq]);
+                    bf16x8 ab;
+                    *reinterpret_cast<u32x4*>(&ab) = a;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = ru_snake(acc[i][2 * kk][r] + bA[r], eA[r], iA[r]);
-                v[4 + r] = ru_snake(acc[i][2 * kk + 1][r] + bB[r], eB[r], iB[r]);
-            }
-            a2[i][kk][0] = pack_bf16(v[0], v[1]); a2[i][kk][1] = pack_bf16(v[2], v[3]);
-            a2[i][kk][2] = pack_bf16(v[4], v[5]); a2[i][kk][3] = pack_bf16(v[6], v[7]);
-        }
-    }
-    if constexpr (NC == 2) {
-        // the 1x1 convolution contracts over all 192 channels: the other half of this row tile lives in the wave with the same row
-        // group and the other column half.  Every wave publishes its half as [row][channel] bf16 in the (now free) input-tile area.
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk)
-                *reinterpret_cast<u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + wc * RU_CH + 32 * kk + 8 * lq]) = a2[i][kk];
-        __syncthreads();
-    }
-
-    // ---- 3. 1x1 convolution: chunk kc of the contraction; its weights are in ring slot (NSTEP + kc) & 1
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int kc = 0; kc < NC; ++kc) {
-        if (kc + 1 < NC) stage_w(W2p + (size_t)(kc + 1) * NC * RU_FRAG, (NSTEP + kc + 1) & 1);
-        const bf16_t* Wb = Wst + ((size_t)((NSTEP + kc) & 1) * NC + wc) * RU_FRAG;
-        u32x4 wf[3][6];
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) wf[kk][j] = *reinterpret_cast<const u32x4*>(&Wb[((kk * 6 + j) * 64 + lane) * 8]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                u32x4 a = a2[i][kk];
-                if (NC == 2 && kc != wc) a = *reinterpret_cast<const u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + kc * RU_CH + 32 * kk + 8 * lq]);
-                bf16x8 ab;
-                *reinterpret_cast<u32x4*>(&ab) = a;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    bf16x8 wb;
-                    *reinterpret_cast<u32x4*>(&wb) = wf[kk][j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, ab, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 6; ++j) {
+                        bf16x8 wb;
+                        *reinterpret_cast<u32x4*>(&wb) = wf[kk][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, ab, acc[i][j], 0, 0, 0);
+                    }
                 }
-            }
-        if (kc + 1 < NC) __syncthreads();
+        }
+        if (s + 1 < TS) __syncthreads();               // slot (s + 1) & 1 is complete for step s + 1; slot s & 1 may be overwritten in step s + 1
     }
 
     // ---- 4. epilogue: + bias + residual -> fp32 stream; the next consumer's SnakeBeta folded into its bf16 copy.  All operand vectors
