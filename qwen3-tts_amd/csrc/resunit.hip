@@ -45,12 +45,16 @@ __device__ __forceinline__ void ru_dma16(const void* src, void* lds_dst) {      
 constexpr int RU_CH = 96;                          // channels per chunk
 constexpr int RU_FRAG = 3 * 6 * 64 * 8;            // bf16 elements of one packed 96 x 96 chunk: [kk 3][j 6][lane 64][8]
 
-// NC = C / 96.  Workgroup = 4 waves: NC = 1 -> 4 row groups of 64 rows (256-row tile); NC = 2 -> 2 row groups x 2 column halves
-// (128-row tile).  LDS: the activated input tile [(RW + halo)][C + 8] bf16 (rows 16 B apart from a bank-conflict-free stride),
-// then the weight ring [2][NC][RU_FRAG] bf16.
-template <int NC>
-__global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo, int a_bytes /* LDS bytes reserved for the input tile (multiple of 1024) */) {
-    constexpr int C = RU_CH * NC, WR = 4 / NC, RW = 64 * WR, STR = C + 8, RS = STR * 2;
+// NC = C / 96, TM = 16-row tiles per wave.  Workgroup = 4 waves: NC = 1 -> 4 row groups; NC = 2 -> 2 row groups x 2 column halves.
+// LDS: the activated input tile [(RW + halo)][C + 8] bf16 (rows 16 B apart from a bank-conflict-free stride), then the weight ring
+// [2][NC][RU_FRAG] bf16.
+// C = 96 runs TM = 2 (128-row tiles, 74 KB of LDS, TWO workgroups per CU): measured on the first build (TM = 4, 256-row tiles, one
+// workgroup per CU) a tile took 24 us for 4 us of MFMA work, with or without the deeper weight prefetch -- a CU pulls its 300 KB of
+// tile traffic (bf16 input with halo, fp32 residual in, fp32 + bf16 out) at the ~30 GB/s one CU gets, and with ONE resident
+// workgroup that time adds to the compute time instead of hiding under another workgroup's MFMAs.
+template <int NC, int TM>
+__global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnitParams p, int halo, int a_bytes /* LDS bytes reserved for the input tile (multiple of 1024) */) {
+    constexpr int C = RU_CH * NC, WR = 4 / NC, RPW = 16 * TM, RW = RPW * WR, STR = C + 8, RS = STR * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ru[];
     bf16_t* As = reinterpret_cast<bf16_t*>(smem_ru);
     bf16_t* Wst = reinterpret_cast<bf16_t*>(smem_ru + a_bytes);                // [2][NC][RU_FRAG]
@@ -104,15 +108,15 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
     store_stage(wreg[0], 0);
     load_stage(wreg[0], 3);
 
-    f32x4 acc[4][6];
+    f32x4 acc[TM][6];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int tpos[4];                                       // position of this lane's rows inside their sequence
+    int tpos[TM];                                       // position of this lane's rows inside their sequence
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tpos[i] = (m0 + wr * 64 + i * 16 + li) % p.T;
-    u32x4 a2[4][3];                                    // SnakeBeta_2(conv7) of this wave's 64 rows x 96 channels: B operand of the 1x1
+    for (int i = 0; i < TM; ++i) tpos[i] = (m0 + wr * RPW + i * 16 + li) % p.T;
+    u32x4 a2[TM][3];                                    // SnakeBeta_2(conv7) of this wave's 64 rows x 96 channels: B operand of the 1x1
     __syncthreads();                                   // (the input tile's DMA has landed)
 
     // ---- 1..3. the steps, fully unrolled (register sets and ring slots are compile-time): conv7 (tap, kc), then the 1x1 (kc)
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
                 const f32x4 eA = *reinterpret_cast<const f32x4*>(p.ea2 + c0), eB = *reinterpret_cast<const f32x4*>(p.ea2 + c0 + 4);
                 const f32x4 iA = *reinterpret_cast<const f32x4*>(p.ib2 + c0), iB = *reinterpret_cast<const f32x4*>(p.ib2 + c0 + 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < TM; ++i) {
                     float v[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -146,14 +150,14 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
                 // row group and the other column half.  Every wave publishes its half as [row][channel] bf16 in the (now free: the
                 // barrier that closed step s - 1 is behind every wave) input-tile area.
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int kk = 0; kk < 3; ++kk)
-                        *reinterpret_cast<u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + wc * RU_CH + 32 * kk + 8 * lq]) = a2[i][kk];
+                        *reinterpret_cast<u32x4*>(&As[(wr * RPW + i * 16 + li) * STR + wc * RU_CH + 32 * kk + 8 * lq]) = a2[i][kk];
                 __syncthreads();
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
             const int tap = s / NC, kc = s - tap * NC;
             const int sh = -(6 - tap) * p.dil;         // output row m reads staged row (m - m0) + halo + sh
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16_t* ar = &As[(wr * 64 + i * 16 + li + halo + sh) * STR + kc * RU_CH + lq * 8];
+            for (int i = 0; i < TM; ++i) {
+                const bf16_t* ar = &As[(wr * RPW + i * 16 + li + halo + sh) * STR + kc * RU_CH + lq * 8];
                 const bool zero = tpos[i] + sh < 0;    // before the start of its own sequence: the causal left padding
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
@@ -186,11 +190,11 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
         } else {                                       // the 1x1 convolution, chunk kc of its contraction
             const int kc = s - 7 * NC;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int kk = 0; kk < 3; ++kk) {
                     u32x4 a = a2[i][kk];
-                    if (NC == 2 && kc != wc) a = *reinterpret_cast<const u32x4*>(&As[(wr * 64 + i * 16 + li) * STR + kc * RU_CH + 32 * kk + 8 * lq]);
+                    if (NC == 2 && kc != wc) a = *reinterpret_cast<const u32x4*>(&As[(wr * RPW + i * 16 + li) * STR + kc * RU_CH + 32 * kk + 8 * lq]);
                     bf16x8 ab;
                     *reinterpret_cast<u32x4*>(&ab) = a;
 #pragma unroll
@@ -212,15 +216,15 @@ __global__ __launch_bounds__(256) void resunit_kernel(ResUnitParams p, int halo,
         const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + n);
         const f32x4 e16 = *reinterpret_cast<const f32x4*>((p.ea16 ? p.ea16 : p.b2) + n);
         const f32x4 i16 = *reinterpret_cast<const f32x4*>((p.ib16 ? p.ib16 : p.b2) + n);
-        f32x4 res[4];
+        f32x4 res[TM];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + li, mc = m < p.M ? m : p.M - 1;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wr * RPW + i * 16 + li, mc = m < p.M ? m : p.M - 1;
             res[i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.ldr + n);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + li;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wr * RPW + i * 16 + li;
             if (m >= p.M) continue;
             f32x4 v = acc[i][j] + b2 + res[i];
             if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
@@ -259,14 +263,14 @@ void pack_resunit_weight(const float* W, int C, int taps, bool permute_cols, bf1
                         }
 }
 
-template <int NC>
+template <int NC, int TM>
 static void launch_ru(const ResUnitParams& p, hipStream_t st) {
-    constexpr int C = RU_CH * NC, RW = 64 * (4 / NC);
+    constexpr int C = RU_CH * NC, RW = 16 * TM * (4 / NC);
     const int halo = 6 * p.dil;
     const int a_bytes = ((RW + halo) * (C + 8) * 2 + 1023) & ~1023;
     const size_t lds = (size_t)a_bytes + 2 * NC * RU_FRAG * 2;
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "resunit: LDS budget exceeded");
-    auto kern = resunit_kernel<NC>;
+    auto kern = resunit_kernel<NC, TM>;
     static bool attr_set = false;          // one flag per instantiation
     if (!attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -281,7 +285,10 @@ void launch_resunit(const ResUnitParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.M > 0 && p.T > 0 && p.dil >= 1 && 6 * p.dil <= 56, QTTS_ERR_ARG, "resunit: shape");
     QTTS_REQUIRE(p.lda % 8 == 0 && p.ldr % 4 == 0 && (!p.C || p.ldc % 4 == 0) && (!p.C16 || p.ldc16 % 4 == 0), QTTS_ERR_ARG, "resunit: leading dimensions");
     QTTS_REQUIRE((p.ea16 == nullptr) == (p.ib16 == nullptr), QTTS_ERR_ARG, "resunit: snake16 parameters go together");
-    if (p.Cch == 96) launch_ru<1>(p, st); else launch_ru<2>(p, st);
+    // rows per wave: QTTS_RESUNIT_TM = 2 | 4 overrides the C = 96 default of 2 (A/B runs; read per launch)
+    const char* e = getenv("QTTS_RESUNIT_TM");
+    if (p.Cch == 96) { if (e && e[0] == '4') launch_ru<1, 4>(p, st); else launch_ru<1, 2>(p, st); }
+    else launch_ru<2, 4>(p, st);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
