@@ -505,7 +505,15 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
         if (fast16) {
             // h16a = SnakeBeta_block(x) in bf16 (from the previous producer).  tconv -> b (fp32, the first unit's residual) and
             // h16a' = SnakeBeta_unit0.act1(b)
-            gemm16(bk.tconv, nullptr, h16a, C, B * L, L, b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st, bk.cout);
+            // Round 3: inside a block whose units run fused (C = 96 / 192) the residual stream travels as bf16, as in the reference's
+            // own bfloat16 mode: the fused unit is bound by its tile's HBM bytes (profiles/r03_pmc_mfma_codec.md), and 768 of its
+            // 1236 B per row were the fp32 residual in and out.  It lives in the storage of the fp32 buffers `a` / `b`; fp32 comes
+            // back where a tensor leaves the blocks (last unit of the last block) or a stage is asked for.
+            // QTTS_CODEC_RES16=0: fp32 residual stream (A/B runs).
+            static const bool res16_env = [] { const char* e = getenv("QTTS_CODEC_RES16"); return !e || atoi(e) != 0; }();
+            const bool r16 = res16_env && !stage && bk.u[0].fused && bk.u[1].fused && bk.u[2].fused;
+            gemm16(bk.tconv, nullptr, h16a, C, B * L, L, r16 ? nullptr : b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st, bk.cout,
+                   nullptr, r16 ? reinterpret_cast<bf16_t*>(b) : nullptr);
             std::swap(h16a, h16b);                 // h16a: activated input of unit 0; h16b: free
             L *= bk.r; C = bk.cout;
             float* cur = b; float* alt = a;        // (a was only the stand-alone snake's output in the fp32 path: free here)
@@ -518,10 +526,13 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
                 const bool dead = j == 2 && !leaves && !stage;
                 if (un.fused) {                    // conv7 -> SnakeBeta_2 -> conv1x1 -> + residual in one kernel (resunit.hip)
                     ResUnitParams rp{};
-                    rp.A16 = h16a; rp.lda = C; rp.res = cur; rp.ldr = C; rp.M = B * L; rp.T = L; rp.dil = un.dil; rp.Cch = C;
+                    rp.A16 = h16a; rp.lda = C; rp.ldr = C; rp.M = B * L; rp.T = L; rp.dil = un.dil; rp.Cch = C;
+                    if (r16) rp.res16 = cur; else rp.res = cur;
                     rp.W1p = un.w1p.p; rp.b1 = un.c1.bias.as<float>(); rp.ea2 = un.a2.ea.as<float>(); rp.ib2 = un.a2.ib.as<float>();
                     rp.W2p = un.w2p.p; rp.b2 = un.c2.bias.as<float>();
-                    rp.C = dead ? nullptr : alt; rp.ldc = C;
+                    rp.ldc = C;
+                    if (r16 && !leaves) rp.R16 = dead ? nullptr : alt;       // bf16 stream on to the next unit ...
+                    else rp.C = dead ? nullptr : alt;                        // ... fp32 where the tensor leaves the blocks
                     // (its bf16 output must not alias its bf16 input: a tile's halo rows are other tiles' output rows)
                     rp.C16 = next ? h16b : nullptr; rp.ldc16 = C;
                     rp.ea16 = next ? next->ea.as<float>() : nullptr; rp.ib16 = next ? next->ib.as<float>() : nullptr;

@@ -41,12 +41,14 @@ void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st);
 //   out = x + conv1x1(SnakeBeta_2(conv7_dil(A16))) with A16 = bf16(SnakeBeta_1(x)) written by the unit's producer (V2:619-635).
 struct ResUnitParams {
     const void* A16; int lda;            // bf16 [M][lda]: the unit's activated input
-    const float* res; int ldr;           // fp32 [M][ldr]: x, the residual
+    const float* res; int ldr;           // fp32 [M][ldr]: x, the residual ...
+    const void* res16;                   // ... or the same as bf16 [M][ldr] (the bf16 residual stream inside a decoder block)
     int M, T, dil, Cch;                  // rows, rows per sequence (causal left padding), dilation of the 7-tap conv, channels
     const void* W1p; const float* b1;    // conv7: weights packed by pack_resunit_weight(permute_cols = true), bias [C]
     const float* ea2; const float* ib2;  // SnakeBeta_2: exp(alpha)[C], 1 / (exp(beta) + 1e-9)[C]
     const void* W2p; const float* b2;    // conv1x1: packed (permute_cols = false), bias [C]
     float* C; int ldc;                   // fp32 output (the residual stream) or null
+    void* R16;                           // bf16 output of the same values [M][ldc] (the bf16 residual stream) or null
     void* C16; int ldc16;                // bf16 output for the next GEMM consumer or null, ...
     const float* ea16; const float* ib16;    // ... with that consumer's SnakeBeta folded in (null: plain bf16 copy)
 };

@@ -20,7 +20,8 @@
 //     = channel 32 (j / 2) + 8 q + 4 (j % 2) + r) so that lane (row, q) ends up holding channels 32 kk + 8 q .. + 8: exactly the
 //     fragment the next MFMA wants from it.  No LDS round trip, no HBM round trip (C = 192: the two column halves of a row tile
 //     live in two waves and swap their halves through LDS once);
-//   * epilogue: + bias + fp32 residual -> fp32 residual stream out, and the NEXT consumer's SnakeBeta folded in for its bf16 copy.
+//   * epilogue: + bias + residual (fp32, or bf16 inside a block) -> residual stream out (fp32 and / or bf16), and the NEXT consumer's
+//     SnakeBeta folded in for its bf16 copy.
 // Arithmetic: bf16 operands, fp32 accumulation, v_sin_f32 SnakeBeta -- the same as gemm_tap2 + tap_epilogue<FAST>.
 #include "common.h"
 #include "kernels.h"
@@ -217,17 +218,28 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
         const f32x4 e16 = *reinterpret_cast<const f32x4*>((p.ea16 ? p.ea16 : p.b2) + n);
         const f32x4 i16 = *reinterpret_cast<const f32x4*>((p.ib16 ? p.ib16 : p.b2) + n);
         f32x4 res[TM];
+        uint2 rh[TM];
+        const float* dummy = p.b2;                      // (any readable 16-byte aligned address for the operand that is absent)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * RPW + i * 16 + li, mc = m < p.M ? m : p.M - 1;
-            res[i] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.ldr + n);
+            res[i] = *reinterpret_cast<const f32x4*>(p.res ? p.res + (size_t)mc * p.ldr + n : dummy);
+            rh[i] = *reinterpret_cast<const uint2*>(p.res16 ? reinterpret_cast<const bf16_t*>(p.res16) + (size_t)mc * p.ldr + n
+                                                            : reinterpret_cast<const bf16_t*>(dummy));
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * RPW + i * 16 + li;
             if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + b2 + res[i];
+            const f32x4 r = p.res ? res[i] : (f32x4){__uint_as_float(rh[i].x << 16), __uint_as_float(rh[i].x & 0xffff0000u),
+                                                     __uint_as_float(rh[i].y << 16), __uint_as_float(rh[i].y & 0xffff0000u)};
+            f32x4 v = acc[i][j] + b2 + r;
             if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            if (p.R16) {
+                uint2 h;
+                h.x = pack_bf16(v[0], v[1]); h.y = pack_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.R16) + (size_t)m * p.ldc + n) = h;
+            }
             if (p.C16) {
                 if (p.ea16) {
 #pragma unroll
@@ -281,7 +293,8 @@ static void launch_ru(const ResUnitParams& p, hipStream_t st) {
 
 void launch_resunit(const ResUnitParams& p, hipStream_t st) {
     QTTS_REQUIRE(resunit_supported(p.Cch), QTTS_ERR_ARG, "resunit: C must be 96 or 192");
-    QTTS_REQUIRE(p.A16 && p.res && p.W1p && p.W2p && p.b1 && p.b2 && p.ea2 && p.ib2 && (p.C || p.C16), QTTS_ERR_ARG, "resunit: null operand");
+    QTTS_REQUIRE(p.A16 && ((p.res != nullptr) != (p.res16 != nullptr)) && p.W1p && p.W2p && p.b1 && p.b2 && p.ea2 && p.ib2 && (p.C || p.C16 || p.R16),
+                 QTTS_ERR_ARG, "resunit: null operand (exactly one of res / res16; at least one output)");
     QTTS_REQUIRE(p.M > 0 && p.T > 0 && p.dil >= 1 && 6 * p.dil <= 56, QTTS_ERR_ARG, "resunit: shape");
     QTTS_REQUIRE(p.lda % 8 == 0 && p.ldr % 4 == 0 && (!p.C || p.ldc % 4 == 0) && (!p.C16 || p.ldc16 % 4 == 0), QTTS_ERR_ARG, "resunit: leading dimensions");
     QTTS_REQUIRE((p.ea16 == nullptr) == (p.ib16 == nullptr), QTTS_ERR_ARG, "resunit: snake16 parameters go together");

@@ -50,13 +50,14 @@ extern "C" int hostemu_gemm_tap16(const unsigned short* A16, int lda, int M, int
 // the fused residual unit (resunit.hip): W1 [7][C][C], W2 [C][C] row-major fp32, packed here exactly as the codec engine packs them
 extern "C" int hostemu_resunit(const unsigned short* A16, int lda, const float* res, int ldr, int M, int T, int dil, int C,
                                const float* W1, const float* b1, const float* ea2, const float* ib2, const float* W2, const float* b2,
-                               float* out, int ldc, unsigned short* C16, const float* ea16, const float* ib16) {
+                               float* out, int ldc, unsigned short* C16, const float* ea16, const float* ib16,
+                               const unsigned short* res16, unsigned short* R16) {
     try {
         std::vector<uint16_t> w1(qtts::resunit_packed_elems(C, 7)), w2(qtts::resunit_packed_elems(C, 1));
         qtts::pack_resunit_weight(W1, C, 7, true, w1.data());
         qtts::pack_resunit_weight(W2, C, 1, false, w2.data());
         qtts::ResUnitParams p{};
-        p.A16 = A16; p.lda = lda; p.res = res; p.ldr = ldr; p.M = M; p.T = T; p.dil = dil; p.Cch = C;
+        p.A16 = A16; p.lda = lda; p.res = res16 ? nullptr : res; p.res16 = res16; p.R16 = R16; p.ldr = ldr; p.M = M; p.T = T; p.dil = dil; p.Cch = C;
         p.W1p = w1.data(); p.b1 = b1; p.ea2 = ea2; p.ib2 = ib2; p.W2p = w2.data(); p.b2 = b2;
         p.C = out; p.ldc = ldc; p.C16 = C16; p.ldc16 = ldc; p.ea16 = ea16; p.ib16 = ib16;
         qtts::launch_resunit(p, nullptr);

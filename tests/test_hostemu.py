@@ -57,7 +57,7 @@ def emu():
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
     lib.hostemu_skinny_bf16x.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32, vp]
-    lib.hostemu_resunit.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.hostemu_resunit.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.hostemu_sample.argtypes = [vp, i32, i32, i32, vp, i32, i32, C.c_float, i32, i32, vp, i32, i32, C.c_float, C.c_float,
                                    C.c_uint64, C.c_uint32, i32, vp]
     lib.hostemu_attn_decode.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, C.c_float, vp, vp, i32, vp, vp, vp, i32, i32, vp,
@@ -232,7 +232,7 @@ def test_resunit_fused_kernel_real_source(emu, C, M, T, dil):
         out = np.full((M, C + 4), 7.0, np.float32)
         c16 = np.zeros((M, C + 4), np.uint16)
         rc = emu.hostemu_resunit(_ptr(a16), C, _ptr(x), C, M, T, dil, C, _ptr(W1), _ptr(b1), _ptr(ea2), _ptr(ib2), _ptr(W2), _ptr(b2),
-                                 _ptr(out), C + 4, _ptr(c16), _ptr(ea16) if with16 else None, _ptr(ib16) if with16 else None)
+                                 _ptr(out), C + 4, _ptr(c16), _ptr(ea16) if with16 else None, _ptr(ib16) if with16 else None, None, None)
         assert rc == 0, (emu.qtts_last_error() or b"").decode()
         assert np.all(out[:, C:] == 7.0) and np.all(c16[:, C:] == 0)
         err = float(np.abs(out[:, :C] - y2).max())
@@ -241,6 +241,20 @@ def test_resunit_fused_kernel_real_source(emu, C, M, T, dil):
         got16 = (c16[:, :C].astype(np.uint32) << 16).view(np.float32)
         ref16 = want16 if with16 else y2
         assert float(np.abs(got16 - ref16).max()) <= 1.2e-2 * max(1.0, float(np.abs(ref16).max()))
+    # the bf16 residual stream inside a decoder block: residual in as bf16 (stride C + 4 like the outputs), stream out as bf16
+    xr, xr16 = _bf16_round(x)
+    x16p = np.zeros((M, C + 4), np.uint16); x16p[:, :C] = xr16
+    r16 = np.zeros((M, C + 4), np.uint16)
+    c16 = np.zeros((M, C + 4), np.uint16)
+    rc = emu.hostemu_resunit(_ptr(a16), C, None, C + 4, M, T, dil, C, _ptr(W1), _ptr(b1), _ptr(ea2), _ptr(ib2), _ptr(W2), _ptr(b2),
+                             None, C + 4, _ptr(c16), _ptr(ea16), _ptr(ib16), _ptr(x16p), _ptr(r16))
+    assert rc == 0, (emu.qtts_last_error() or b"").decode()
+    y2r = act @ W2r.T + b2 + xr
+    gotr = (r16[:, :C].astype(np.uint32) << 16).view(np.float32)
+    assert np.all(r16[:, C:] == 0) and float(np.abs(gotr - y2r).max()) <= 1.2e-2 * max(1.0, float(np.abs(y2r).max()))
+    got16 = (c16[:, :C].astype(np.uint32) << 16).view(np.float32)
+    w16 = y2r + ib16 * np.sin(y2r * ea16) ** 2
+    assert float(np.abs(got16 - w16).max()) <= 1.2e-2 * max(1.0, float(np.abs(w16).max()))
 
 
 @pytest.mark.parametrize("bf16", [0, 1])
