@@ -23,8 +23,12 @@
 //   * epilogue: + bias + residual (fp32, or bf16 inside a block) -> residual stream out (fp32 and / or bf16), and the NEXT consumer's
 //     SnakeBeta folded in for its bf16 copy.
 // Arithmetic: bf16 operands, fp32 accumulation, v_sin_f32 SnakeBeta -- the same as gemm_tap2 + tap_epilogue<FAST>.
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
+#include "tstamp.h"
+
+QTTS_TS_UNIT(ru)
 
 namespace qtts {
 
@@ -53,13 +57,18 @@ constexpr int RU_FRAG = 3 * 6 * 64 * 8;            // bf16 elements of one packe
 // workgroup per CU) a tile took 24 us for 4 us of MFMA work, with or without the deeper weight prefetch -- a CU pulls its 300 KB of
 // tile traffic (bf16 input with halo, fp32 residual in, fp32 + bf16 out) at the ~30 GB/s one CU gets, and with ONE resident
 // workgroup that time adds to the compute time instead of hiding under another workgroup's MFMAs.
-template <int NC, int TM>
+template <int NC, int TM, bool RES16>
 __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnitParams p, int halo, int a_bytes /* LDS bytes reserved for the input tile (multiple of 1024) */) {
     constexpr int C = RU_CH * NC, WR = 4 / NC, RPW = 16 * TM, RW = RPW * WR, STR = C + 8, RS = STR * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ru[];
     bf16_t* As = reinterpret_cast<bf16_t*>(smem_ru);
     bf16_t* Wst = reinterpret_cast<bf16_t*>(smem_ru + a_bytes);                // [2][NC][RU_FRAG]
+    // per-channel parameters, staged once: b1 | ea2 | ib2 | b2 | ea16 | ib16 ([6][C] floats).  Read from global at their points of use
+    // they cost a memory round trip each in the middle of the tile (in-kernel timestamps, profiles/r03_tstamp_codec_resunit.md:
+    // 2.1 us for the 0.3 us 1x1 step, 8.7 us for the epilogue of a 19 us tile).
+    float* Pst = reinterpret_cast<float*>(smem_ru + a_bytes + 2 * NC * RU_FRAG * 2);
 
+    QTTS_TS_BEGIN();                                   // (tstamp build: 1 = tile staged, 2 = step 0 done, 3 = conv7 done, 4 = 1x1 done, 5 = stored)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave % WR, wc = wave / WR;
@@ -106,6 +115,12 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
         const unsigned char* src = A16 + (size_t)gr * p.lda * 2 + (col < C * 2 ? col : 0);
         ru_dma16(src, smem_ru + c * 1024);
     }
+    {
+        const float* srcs[6] = {p.b1, p.ea2, p.ib2, p.b2, p.ea16 ? p.ea16 : p.b2, p.ib16 ? p.ib16 : p.b2};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            for (int c4 = tid; c4 < C / 4; c4 += 256) *reinterpret_cast<f32x4*>(&Pst[q * C + c4 * 4]) = *reinterpret_cast<const f32x4*>(srcs[q] + c4 * 4);
+    }
     store_stage(wreg[0], 0);
     load_stage(wreg[0], 3);
 
@@ -117,8 +132,11 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
     int tpos[TM];                                       // position of this lane's rows inside their sequence
 #pragma unroll
     for (int i = 0; i < TM; ++i) tpos[i] = (m0 + wr * RPW + i * 16 + li) % p.T;
-    u32x4 a2[TM][3];                                    // SnakeBeta_2(conv7) of this wave's 64 rows x 96 channels: B operand of the 1x1
+    u32x4 a2[TM][3];                                    // SnakeBeta_2(conv7) of this wave's rows x 96 channels: B operand of the 1x1
+    // the residual tile of the epilogue, requested at the top of the LAST step so that it arrives under that step's MFMAs
+    typename std::conditional<RES16, uint2, f32x4>::type resv[TM][6];
     __syncthreads();                                   // (the input tile's DMA has landed)
+    QTTS_TS(1);
 
     // ---- 1..3. the steps, fully unrolled (register sets and ring slots are compile-time): conv7 (tap, kc), then the 1x1 (kc)
 #pragma unroll
@@ -131,9 +149,9 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
                 const int c0 = wc * RU_CH + 32 * kk + 8 * lq;              // channels c0 .. c0 + 7 of this lane
-                const f32x4 bA = *reinterpret_cast<const f32x4*>(p.b1 + c0), bB = *reinterpret_cast<const f32x4*>(p.b1 + c0 + 4);
-                const f32x4 eA = *reinterpret_cast<const f32x4*>(p.ea2 + c0), eB = *reinterpret_cast<const f32x4*>(p.ea2 + c0 + 4);
-                const f32x4 iA = *reinterpret_cast<const f32x4*>(p.ib2 + c0), iB = *reinterpret_cast<const f32x4*>(p.ib2 + c0 + 4);
+                const f32x4 bA = *reinterpret_cast<const f32x4*>(&Pst[c0]), bB = *reinterpret_cast<const f32x4*>(&Pst[c0 + 4]);
+                const f32x4 eA = *reinterpret_cast<const f32x4*>(&Pst[C + c0]), eB = *reinterpret_cast<const f32x4*>(&Pst[C + c0 + 4]);
+                const f32x4 iA = *reinterpret_cast<const f32x4*>(&Pst[2 * C + c0]), iB = *reinterpret_cast<const f32x4*>(&Pst[2 * C + c0 + 4]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     float v[8];
@@ -161,6 +179,17 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 6; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (s == TS - 1) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = m0 + wr * RPW + i * 16 + li, mc = m < p.M ? m : p.M - 1;
+                    const int n = wc * RU_CH + 16 * j + 4 * lq;
+                    if constexpr (RES16) resv[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.res16) + (size_t)mc * p.ldr + n);
+                    else resv[i][j] = *reinterpret_cast<const f32x4*>(p.res + (size_t)mc * p.ldr + n);
+                }
         }
         u32x4 wf[3][6];
 #pragma unroll
@@ -207,32 +236,29 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
                 }
         }
         if (s + 1 < TS) __syncthreads();               // slot (s + 1) & 1 is complete for step s + 1; slot s & 1 may be overwritten in step s + 1
+#if QTTS_TSTAMP
+        if (s == 0) QTTS_TS(2);
+        if (s == 7 * NC - 1) QTTS_TS(3);
+        if (s == TS - 1) QTTS_TS(4);
+#endif
     }
 
-    // ---- 4. epilogue: + bias + residual -> fp32 stream; the next consumer's SnakeBeta folded into its bf16 copy.  All operand vectors
-    // of a column quad are requested unconditionally and back to back (rows past M re-read row M - 1; selected at the store).
+    // ---- 4. epilogue: + bias + residual -> residual stream out (fp32 and / or bf16); the next consumer's SnakeBeta folded into its
+    // bf16 copy.  Parameters come from LDS, the residual tile is already in registers: nothing here waits for memory but the stores.
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int n = wc * RU_CH + 16 * j + 4 * lq;
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + n);
-        const f32x4 e16 = *reinterpret_cast<const f32x4*>((p.ea16 ? p.ea16 : p.b2) + n);
-        const f32x4 i16 = *reinterpret_cast<const f32x4*>((p.ib16 ? p.ib16 : p.b2) + n);
-        f32x4 res[TM];
-        uint2 rh[TM];
-        const float* dummy = p.b2;                      // (any readable 16-byte aligned address for the operand that is absent)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wr * RPW + i * 16 + li, mc = m < p.M ? m : p.M - 1;
-            res[i] = *reinterpret_cast<const f32x4*>(p.res ? p.res + (size_t)mc * p.ldr + n : dummy);
-            rh[i] = *reinterpret_cast<const uint2*>(p.res16 ? reinterpret_cast<const bf16_t*>(p.res16) + (size_t)mc * p.ldr + n
-                                                            : reinterpret_cast<const bf16_t*>(dummy));
-        }
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(&Pst[3 * C + n]);
+        const f32x4 e16 = *reinterpret_cast<const f32x4*>(&Pst[4 * C + n]);
+        const f32x4 i16 = *reinterpret_cast<const f32x4*>(&Pst[5 * C + n]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wr * RPW + i * 16 + li;
             if (m >= p.M) continue;
-            const f32x4 r = p.res ? res[i] : (f32x4){__uint_as_float(rh[i].x << 16), __uint_as_float(rh[i].x & 0xffff0000u),
-                                                     __uint_as_float(rh[i].y << 16), __uint_as_float(rh[i].y & 0xffff0000u)};
+            f32x4 r;
+            if constexpr (RES16) r = (f32x4){__uint_as_float(resv[i][j].x << 16), __uint_as_float(resv[i][j].x & 0xffff0000u),
+                                             __uint_as_float(resv[i][j].y << 16), __uint_as_float(resv[i][j].y & 0xffff0000u)};
+            else r = resv[i][j];
             f32x4 v = acc[i][j] + b2 + r;
             if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
             if (p.R16) {
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
             if (p.C16) {
                 if (p.ea16) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = ru_snake(v[r], e16[r], i16[r]);
+                    for (int r2 = 0; r2 < 4; ++r2) v[r2] = ru_snake(v[r2], e16[r2], i16[r2]);
                 }
                 uint2 h;
                 h.x = pack_bf16(v[0], v[1]); h.y = pack_bf16(v[2], v[3]);
@@ -251,6 +277,18 @@ __global__ __launch_bounds__(256, (TM <= 2 ? 2 : 1)) void resunit_kernel(ResUnit
             }
         }
     }
+#if QTTS_TSTAMP
+    ts_[5] = qtts::ts_drained();
+    if (threadIdx.x == 0 && blockIdx.x % 499 == 7) {   // a sample of workgroups across the whole launch (the shared macro takes first / last only)
+        const unsigned i_ = atomicAdd(&qtts::ts_cnt_ru, 1u);
+        if (i_ < qtts::TS_CAP) {
+            qtts::TsRec r_;
+            for (int k_ = 0; k_ < 6; ++k_) r_.t[k_] = ts_[k_];
+            r_.kind = 5; r_.a = NC * 100 + TM; r_.b = p.dil; r_.blk = (int)blockIdx.x;
+            qtts::ts_log_ru[i_] = r_;
+        }
+    }
+#endif
 }
 
 bool resunit_supported(int C) { return C == 96 || C == 192; }
@@ -275,20 +313,24 @@ void pack_resunit_weight(const float* W, int C, int taps, bool permute_cols, bf1
                         }
 }
 
-template <int NC, int TM>
-static void launch_ru(const ResUnitParams& p, hipStream_t st) {
+template <int NC, int TM, bool RES16>
+static void launch_ru_r(const ResUnitParams& p, hipStream_t st) {
     constexpr int C = RU_CH * NC, RW = 16 * TM * (4 / NC);
     const int halo = 6 * p.dil;
     const int a_bytes = ((RW + halo) * (C + 8) * 2 + 1023) & ~1023;
-    const size_t lds = (size_t)a_bytes + 2 * NC * RU_FRAG * 2;
+    const size_t lds = (size_t)a_bytes + 2 * NC * RU_FRAG * 2 + 6 * C * sizeof(float);
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "resunit: LDS budget exceeded");
-    auto kern = resunit_kernel<NC, TM>;
+    auto kern = resunit_kernel<NC, TM, RES16>;
     static bool attr_set = false;          // one flag per instantiation
     if (!attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(cdiv(p.M, RW)), dim3(256), lds, st, p, halo, a_bytes);
+}
+template <int NC, int TM>
+static void launch_ru(const ResUnitParams& p, hipStream_t st) {
+    if (p.res16) launch_ru_r<NC, TM, true>(p, st); else launch_ru_r<NC, TM, false>(p, st);
 }
 
 void launch_resunit(const ResUnitParams& p, hipStream_t st) {

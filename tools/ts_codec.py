@@ -60,3 +60,20 @@ for key in sorted({(int(x), int(y)) for x, y in zip(r["a"], r["b"])}):
                      loop_us=round(loop, 1), epilogue_us=round(epi, 1), in_kernel_us=round(tot, 1)))
     print(f"{key[0]:9d} {key[1]:5d} {len(rr):4d} {steps:6d} {pro:9.2f} {loop / steps:8.3f} {loop:8.1f} {epi:9.1f} {tot:10.1f}")
 if a.json: json.dump(dict(batch=a.batch, frames=a.frames, rows=rows), open(a.json, "w"), indent=1)
+
+# ---- the fused residual unit (resunit.hip): a sample of workgroups of every launch
+fr = lib.qtts_debug_tslog_ru; fr.argtypes = [C.c_void_p, C.c_int]; fr.restype = C.c_int
+buf = np.zeros(1 << 15, dtype=REC)
+n = fr(buf.ctypes.data, 1 << 15)
+r = buf[:max(n, 0)]
+print(f"\nresunit_kernel: {len(r)} sampled workgroups (both decodes)")
+print(f"{'NC,TM':>6s} {'dil':>4s} {'n':>4s} {'staged':>8s} {'step 0':>8s} {'conv7 (rest)':>13s} {'1x1':>7s} {'epilogue':>9s} {'in-kernel':>10s}  us")
+ru_rows = []
+for key in sorted({(int(x), int(y)) for x, y in zip(r["a"], r["b"])}):
+    rr = r[(r["a"] == key[0]) & (r["b"] == key[1])]
+    t = rr["t"].astype(np.float64) * US
+    d = [(t[:, i + 1] - t[:, i]).mean() for i in range(5)]
+    ru_rows.append(dict(nc_tm=key[0], dil=key[1], records=len(rr), staged_us=round(d[0], 2), step0_us=round(d[1], 2), conv7_rest_us=round(d[2], 2),
+                        conv1x1_us=round(d[3], 2), epilogue_us=round(d[4], 2), in_kernel_us=round(sum(d), 2)))
+    print(f"{key[0]:6d} {key[1]:4d} {len(rr):4d} {d[0]:8.2f} {d[1]:8.2f} {d[2]:13.2f} {d[3]:7.2f} {d[4]:9.2f} {sum(d):10.2f}")
+if a.json: json.dump(dict(batch=a.batch, frames=a.frames, rows=rows, resunit=ru_rows), open(a.json, "w"), indent=1)
