@@ -364,7 +364,7 @@ typedef struct {
     double weight_bytes_per_frame; /* bytes of packed weights one frame step streams              */
     double gemm_ms_last;      /* HIP-event time of the dominant kernel class over the call, if enabled */
     int64_t gemm_launches_last;
-    int32_t long_graphs;      /* long-sequence frame graphs captured so far (one per KV-length bucket, ABI v8) */
+    int32_t long_graphs;      /* long-sequence frame graphs currently cached (one per KV-length bucket the generation reached, ABI v8) */
     int32_t attn_nsplit_last; /* split-KV workgroups per (sequence, kv head) of the last launched frame step (1 = short mode) */
     int32_t attn_span_last;   /* the key span those workgroups partition (the live length's bucket; 0 = short mode) */
     int32_t reserved_;

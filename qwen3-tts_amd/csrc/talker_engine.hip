@@ -311,7 +311,6 @@ struct qtts_talker {
     std::map<int, std::pair<hipGraph_t, hipGraphExec_t>> graph_long;      // bucket (keys) -> captured long-sequence frame step
     int attn_nsplit_active = 1;        // what decode_layer launches (and what a capture in progress bakes in)
     int attn_span_active = 0;          // ... and the key span those workgroups partition (the bucket)
-    int long_graphs_captured = 0;      // (stats: tests assert that a long generation walks through the buckets)
     bool long_mode(int kv_len_after) const { return attn_nsplit > 1 && kv_len_after > SPLIT_FROM; }
     // bucket of a KV length in long mode: the smallest power of two >= kv_len, at least 2 * SPLIT_KEYS, at most the capacity's bucket
     int span_bucket(int kv_len) const {
@@ -349,7 +348,6 @@ struct qtts_talker {
             QTTS_CHECK_HIP(hipGraphGetNodes(g, nullptr, &nn));
             graph_nodes = (int)nn;
             QTTS_CHECK_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            if (lng) ++long_graphs_captured;
         }
         return ge;
     }
@@ -1084,7 +1082,7 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     QTTS_REQUIRE(t && out, QTTS_ERR_ARG, "null argument");
     out->frames_run = t->frames_run; out->graph_nodes = t->graph_nodes; out->weight_bytes_per_frame = t->weight_bytes_frame;
     out->gemm_ms_last = t->prof_ms; out->gemm_launches_last = t->prof_launches;
-    out->long_graphs = t->long_graphs_captured; out->attn_nsplit_last = t->attn_nsplit_active; out->attn_span_last = t->attn_span_active;
+    out->long_graphs = (int32_t)t->graph_long.size(); out->attn_nsplit_last = t->attn_nsplit_active; out->attn_span_last = t->attn_span_active;
     QTTS_API_END
 }
 int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n) {
