@@ -40,26 +40,25 @@ constexpr int CAND_MAX = 1024;          // top-k candidates (scores >= the k-th 
 // The next pass's input rows (tabulated projected embedding, tabulated layer-0 q|k|v) are random rows of 117 / 470 MB tables:
 // every request is an HBM round trip (~1 us), so ALL of a thread's requests are issued before the first store -- the round-1
 // loops waited for each 16-byte piece in turn (up to 5 dependent round trips at the end of every code-predictor pass).
-template <int BS = 256>
 __device__ __forceinline__ void gather_next_rows(const SampleParams& p, int token, int b, int tid) {
-    constexpr int G1 = 2 * (256 / BS), G2 = 4 * (256 / BS);   // 16-byte pieces per thread: rows of <= 2048 / <= 4096 floats
+    constexpr int G1 = 2, G2 = 4;                           // 16-byte pieces per thread: rows of <= 2048 / <= 4096 floats
     float4 v1[G1], v2[G2];
     const float* src = p.gather_emb ? p.gather_emb + (size_t)token * p.gather_C : nullptr;
     const float* src2 = p.gather2_emb ? p.gather2_emb + (size_t)token * p.gather2_C : nullptr;
 #pragma unroll
     for (int it = 0; it < G1; ++it) {
-        const int c = tid * 4 + it * (BS * 4);
+        const int c = tid * 4 + it * 1024;
         v1[it] = (src && c < p.gather_C) ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int it = 0; it < G2; ++it) {
-        const int c = tid * 4 + it * (BS * 4);
+        const int c = tid * 4 + it * 1024;
         v2[it] = (src2 && c < p.gather2_C) ? *reinterpret_cast<const float4*>(src2 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (src) {
 #pragma unroll
         for (int it = 0; it < G1; ++it) {
-            const int c = tid * 4 + it * (BS * 4);
+            const int c = tid * 4 + it * 1024;
             if (c >= p.gather_C) continue;
             *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v1[it];
             if (p.gather_out16) {
@@ -67,7 +66,7 @@ __device__ __forceinline__ void gather_next_rows(const SampleParams& p, int toke
                 *reinterpret_cast<ushort4*>(p.gather_out16 + (size_t)b * p.gather_C + c) = h;
             }
         }
-        for (int c = tid * 4 + G1 * (BS * 4); c < p.gather_C; c += BS * 4) {          // (wider rows: the plain loop)
+        for (int c = tid * 4 + G1 * 1024; c < p.gather_C; c += 1024) {          // (wider rows: the plain loop)
             const float4 v = *reinterpret_cast<const float4*>(src + c);
             *reinterpret_cast<float4*>(p.gather_out + (size_t)b * p.gather_C + c) = v;
             if (p.gather_out16) {
@@ -79,10 +78,10 @@ __device__ __forceinline__ void gather_next_rows(const SampleParams& p, int toke
     if (src2) {
 #pragma unroll
         for (int it = 0; it < G2; ++it) {
-            const int c = tid * 4 + it * (BS * 4);
+            const int c = tid * 4 + it * 1024;
             if (c < p.gather2_C) *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = v2[it];
         }
-        for (int c = tid * 4 + G2 * (BS * 4); c < p.gather2_C; c += BS * 4)
+        for (int c = tid * 4 + G2 * 1024; c < p.gather2_C; c += 1024)
             *reinterpret_cast<float4*>(p.gather2_out + (size_t)b * p.gather2_C + c) = *reinterpret_cast<const float4*>(src2 + c);
     }
 }
@@ -678,131 +677,13 @@ __global__ __launch_bounds__(256) void sample_kernel_v2(SampleParams p) {
     QTTS_TS_END(sample, 3, V, 0);
 }
 
-// Round 3: the code predictor's sampler call (15 of the 16 samplers of a frame: V = 2048 logits, top-k <= 64, no repetition penalty,
-// no suppress mask, no EOS handling) on ONE WAVE per row.  sample_kernel_v2 spends its 7.7 us in-kernel in a chain of phases
-// separated by workgroup barriers (profiles/r03_tstamp_frame_call2.txt: logits arrived 1.2 | bound 1.9 | candidates ranked 4.1 | drawn
-// 6.0 | rows out 7.7); with the whole row in one wave (32 logits per lane, in registers) there is no barrier at all: the candidate
-// bound is the k-th largest of the 64 LANE maxima (bit-wise selection, as before on quad maxima), the candidates (a few per lane) are
-// compacted by ballots into LDS in (slice, lane) order, and the exact top-k threshold, the softmax, top-p and the inverse-CDF draw run
-// on them exactly as in v2's single-wave tail.  Same processors in HF's order (temperature -> top-k -> top-p), same Philox draw.
-template <int EPL>              // logits per lane (V <= 64 * EPL)
-__global__ __launch_bounds__(64) void sample_kernel_w1(SampleParams p) {
-    constexpr int CMAX = 64 * EPL;                          // every score can be a candidate (all-equal logits): no fallback path
-    __shared__ float cval[CMAX];
-    __shared__ int cidx[CMAX];
-    __shared__ __attribute__((aligned(16))) uint32_t ckey[CMAX + 4];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int V = p.V;
-    const float* lg = p.logits + (size_t)b * p.ld;
-    const int done = p.done_in ? *p.done_in : 0;
-    const uint32_t step = p.step_dev ? (uint32_t)*p.step_dev : 0u;
-    const unsigned long long seed = p.seed_dev ? *p.seed_dev : p.seed;
-    float x[EPL];
-#pragma unroll
-    for (int it = 0; it < EPL / 4; ++it) {                  // lane <- logits [it * 256 + 4 lane, + 4): whole 1-KiB requests
-        const int v = it * 256 + lane * 4;
-        const float4 q = v + 3 < V ? *reinterpret_cast<const float4*>(lg + v) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        x[4 * it] = q.x; x[4 * it + 1] = q.y; x[4 * it + 2] = q.z; x[4 * it + 3] = q.w;
-    }
-    if (done) return;
-    float tm = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        if (p.temperature != 1.0f) x[e] = x[e] / p.temperature;
-        tm = fmaxf(tm, x[e]);
-    }
-    uint32_t rnd[4];
-    philox4x32_10(step, (uint32_t)b, p.stream_id, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
-    const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
-    // candidate bound: the k-th largest of the 64 lane maxima is <= the k-th largest score
-    uint32_t T0 = 0u;
-    {
-        const uint32_t mk = float_key(tm);
-#pragma unroll 1
-        for (int lo = 30; lo >= 0; lo -= 2) {
-            const uint32_t c1 = T0 | (1u << lo), c2 = T0 | (2u << lo), c3 = T0 | (3u << lo);
-            const int n1 = __popcll(__ballot(mk >= c1)), n2 = __popcll(__ballot(mk >= c2)), n3 = __popcll(__ballot(mk >= c3));
-            T0 = n3 >= p.top_k ? c3 : (n2 >= p.top_k ? c2 : (n1 >= p.top_k ? c1 : T0));
-        }
-    }
-    // compaction in (element, lane) order
-    int base = 0;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-        const int v = (e >> 2) * 256 + lane * 4 + (e & 3);
-        const bool keep = v < V && float_key(x[e]) >= T0;
-        const unsigned long long m = __ballot(keep);
-        if (keep) {
-            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            cval[slot] = x[e]; cidx[slot] = v; ckey[slot] = float_key(x[e]);
-        }
-        base += __popcll(m);
-    }
-    const int n_c = base;
-    __builtin_amdgcn_wave_barrier();                        // one wave: program order is all the LDS hand-over needs
-    float tot = n_c <= 128 ? topk_softmax_wave<2>(n_c, p.top_k, lane, cval, ckey) : topk_softmax_wave<EPL>(n_c, p.top_k, lane, cval, ckey);
-    __builtin_amdgcn_wave_barrier();
-    if (p.top_p < 1.0f) {                                   // HF TopPLogitsWarper after TopK (as sample_kernel_v2)
-        float keep_e[EPL];
-        float tot2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < EPL; ++q) {
-            const int i = q * 64 + lane;
-            keep_e[q] = 0.f;
-            if (i < n_c && cval[i] > 0.f) {
-                const uint32_t mk = ckey[i];
-                float above = 0.f;
-                for (int j = 0; j < n_c; ++j) {
-                    const uint32_t kj = ckey[j];
-                    if (kj > mk || (kj == mk && j < i)) above += cval[j];
-                }
-                if (above < p.top_p * tot) keep_e[q] = cval[i];
-            }
-            tot2 += keep_e[q];
-        }
-        tot2 = wave_sum64_dpp(tot2);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < EPL; ++q) {
-            const int i = q * 64 + lane;
-            if (i < n_c) cval[i] = keep_e[q];
-        }
-        __builtin_amdgcn_wave_barrier();
-        tot = tot2;
-    }
-    const float target = u * tot;
-    float run = 0.f;
-    int pick = -1, last = 0;
-    for (int i0 = 0; i0 < n_c && pick < 0; i0 += 64) {
-        const int i = i0 + lane;
-        const float e = i < n_c ? cval[i] : 0.f;
-        const float inc = wave_incl_scan64_dpp(e, lane);
-        const unsigned long long nz = __ballot(e > 0.f);
-        if (nz) last = i0 + 63 - __clzll((long long)nz);
-        const unsigned long long hit = __ballot(e > 0.f && run + inc > target);
-        if (hit) pick = i0 + __ffsll((long long)hit) - 1;
-        run += lane_bcast(inc, 63);
-    }
-    if (pick < 0) pick = last;
-    int token = cidx[pick];                                 // (every lane reads the same slot)
-    if (token < 0 || token >= V) token = 0;
-    gather_next_rows<64>(p, token, b, lane);
-    if (lane == 0) p.tok_out[(size_t)b * p.tok_stride] = token;
-}
-
+// (Round 3 measured a ONE-WAVE-per-row sampler for the code predictor's call shape -- 32 logits per lane in registers, no workgroup
+// barrier, candidates compacted by 32 ballots: 14.2 us per launch against 8.5 us for sample_kernel_v2, frame 2.76 vs 2.68 ms
+// (profiles/r03_ab_sampler_w1.md).  One wave issuing every load, ballot and row gather of the launch is slower than four waves with
+// three barriers; deleted.)
 void launch_sample(const SampleParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.V <= SAMPLE_MAX_V, QTTS_ERR_LIMIT, "sample: vocab too large");
     QTTS_REQUIRE(!(p.do_sample && p.top_p < 1.0f) || p.top_p > 0.0f, QTTS_ERR_ARG, "sample: top_p must be in (0, 1]");
-    // the code predictor's call: one wave per row (QTTS_SAMPLER_W1=0: sample_kernel_v2, for A/B runs; read per launch)
-    if (p.do_sample && p.top_k > 0 && p.top_k <= 64 && p.top_k < p.V && p.V <= 2048 && p.V % 4 == 0 && p.ld % 4 == 0 &&
-        !(p.generated && p.repetition_penalty != 1.0f) && !p.suppress_mask && p.eos < 0 && !p.unfinished) {
-        const char* e = getenv("QTTS_SAMPLER_W1");
-        if (!(e && e[0] == '0')) {
-            hipLaunchKernelGGL(sample_kernel_w1<32>, dim3(p.B), dim3(64), 0, st, p);
-            QTTS_CHECK_HIP(hipGetLastError());
-            return;
-        }
-    }
     if (p.do_sample && p.top_k > 0 && p.top_k <= 64 && p.top_k < p.V && p.V <= 4096) {
         if (p.V <= 2048) hipLaunchKernelGGL(sample_kernel_v2<8>, dim3(p.B), dim3(256), 0, st, p);
         else if (p.V <= 3072) hipLaunchKernelGGL(sample_kernel_v2<12>, dim3(p.B), dim3(256), 0, st, p);

@@ -810,11 +810,11 @@ def test_sampler_kernel_real_source_vs_hf_processors(emu):
         assert np.array_equal(launch(1, 50, 1.0, 0.9, 42, 3, 9), launch(1, 50, 1.0, 0.9, 42, 3, 9))       # same key -> same draw
 
 
-def test_sampler_single_wave_kernel_code_predictor_call_shape(emu, monkeypatch):
-    """sampling.hip's `sample_kernel_w1` (round 3: the code predictor's sampler call -- 2048 logits, top-k <= 64, no repetition
-    penalty / suppress mask / EOS -- on ONE wave per row, no workgroup barrier) against the oracle's HF processor chain: support
-    exactly HF's top-k / top-p set, chi-square of the empirical distribution over Philox (seed, step) pairs; an all-equal row (every
-    score a candidate) and a ragged leading dimension; and the same statistics from `sample_kernel_v2` (QTTS_SAMPLER_W1=0)."""
+def test_sampler_code_predictor_call_shape(emu):
+    """The code predictor's sampler call (15 of a frame's 16 samplers: 2048 logits, top-k <= 64, no repetition penalty / suppress mask /
+    EOS) through `sample_kernel_v2` against the oracle's HF processor chain: support exactly HF's top-k / top-p set, chi-square of the
+    empirical distribution over Philox (seed, step) pairs, an all-equal row (every score a candidate: the general path) and a ragged
+    leading dimension."""
     import talker_ref
     g = np.random.default_rng(123)
     V, B = 2048, 3
@@ -828,36 +828,33 @@ def test_sampler_single_wave_kernel_code_predictor_call_shape(emu, monkeypatch):
         assert rc == 0, (emu.qtts_last_error() or b"").decode()
         return tok.copy()
 
-    for w1 in ("1", "0"):
-        monkeypatch.setenv("QTTS_SAMPLER_W1", w1)
-        for top_k, top_p, temp in ((50, 1.0, 0.9), (12, 0.7, 1.0)) if w1 == "1" else ((50, 1.0, 0.9),):
-            sc = talker_ref.process_logits(lt, torch.zeros(B, 0, dtype=torch.long), do_sample=True, temperature=temp, top_k=top_k, top_p=top_p)
-            pr = torch.softmax(sc, -1).numpy()
-            N = 1500
-            counts = np.zeros_like(pr)
-            for i in range(N):
-                for b, tk in enumerate(launch(top_k, top_p, temp, 500 + i // 5, i % 5)):
-                    counts[b, tk] += 1
-            for b in range(B):
-                if b == 2 and top_p < 1.0:
-                    # all-equal scores under top-p: WHICH of the tied tokens survive is decided by the sort order (torch.sort in HF, slot
-                    # order here) -- only the size of the surviving set is comparable
-                    ns, nd = int((pr[b] > 0).sum()), int((counts[b] > 0).sum())          # N uniform draws from ns tokens see ns (1 - e^(-N / ns)) of them
-                    assert 0.8 * ns * (1 - np.exp(-N / ns)) <= nd <= ns, (nd, ns)
-                    continue
-                assert (counts[b][pr[b] == 0] == 0).all(), (w1, top_k, top_p, b)
-                supp = pr[b] > 0
-                if b < 2:
-                    assert supp.sum() == top_k if top_p >= 1.0 else 1 <= supp.sum() <= top_k
-                else:
-                    assert supp.sum() == V                                       # the tied row keeps everything
-                e, o = N * pr[b][supp], counts[b][supp]
-                small = e < 5.0
-                if small.sum() > 1:
-                    e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
-                chi2, dof = float((((o - e) ** 2) / e).sum()), len(e) - 1
-                assert chi2 < dof + 5.0 * np.sqrt(2.0 * max(dof, 1)) + 10.0, (w1, top_k, top_p, b, chi2, dof)
-    monkeypatch.setenv("QTTS_SAMPLER_W1", "1")
+    for top_k, top_p, temp in ((50, 1.0, 0.9), (12, 0.7, 1.0)):
+        sc = talker_ref.process_logits(lt, torch.zeros(B, 0, dtype=torch.long), do_sample=True, temperature=temp, top_k=top_k, top_p=top_p)
+        pr = torch.softmax(sc, -1).numpy()
+        N = 1500
+        counts = np.zeros_like(pr)
+        for i in range(N):
+            for b, tk in enumerate(launch(top_k, top_p, temp, 500 + i // 5, i % 5)):
+                counts[b, tk] += 1
+        for b in range(B):
+            if b == 2 and top_p < 1.0:
+                # all-equal scores under top-p: WHICH of the tied tokens survive is decided by the sort order (torch.sort in HF, slot
+                # order here) -- only the size of the surviving set is comparable
+                ns, nd = int((pr[b] > 0).sum()), int((counts[b] > 0).sum())          # N uniform draws from ns tokens see ns (1 - e^(-N / ns)) of them
+                assert 0.8 * ns * (1 - np.exp(-N / ns)) <= nd <= ns, (nd, ns)
+                continue
+            assert (counts[b][pr[b] == 0] == 0).all(), (top_k, top_p, b)
+            supp = pr[b] > 0
+            if b < 2:
+                assert supp.sum() == top_k if top_p >= 1.0 else 1 <= supp.sum() <= top_k
+            else:
+                assert supp.sum() == V                                       # the tied row keeps everything
+            e, o = N * pr[b][supp], counts[b][supp]
+            small = e < 5.0
+            if small.sum() > 1:
+                e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
+            chi2, dof = float((((o - e) ** 2) / e).sum()), len(e) - 1
+            assert chi2 < dof + 5.0 * np.sqrt(2.0 * max(dof, 1)) + 10.0, (top_k, top_p, b, chi2, dof)
     assert np.array_equal(launch(50, 1.0, 0.9, 42, 3), launch(50, 1.0, 0.9, 42, 3))
 
 
