@@ -925,7 +925,10 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
         t->graph_key = key;
         for (int i = 0; i < burst; ++i) QTTS_CHECK_HIP(hipGraphLaunch(ge, st));
         f += burst;
-        poll();
+        // The stop condition cannot latch while EOS is still blocked by MinNewTokensLength (frame step i samples token i + 1; EOS is
+        // -inf until min_new_tokens tokens exist) and max_new_tokens is not reached: such bursts need no host round trip -- the
+        // queue stays fed (each poll idles the GPU for the host's wake-up + the next launch, ~50 us).
+        if (f + 1 >= min_new_tokens || f >= total) poll();
     }
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
     t->frames_run = f;
