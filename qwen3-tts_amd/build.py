@@ -19,7 +19,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libqtts.so")
 SOURCES = ["gemm_tap.hip", "resunit.hip", "skinny.hip", "elementwise.hip", "attention.hip", "sampling.hip",
            "codec_engine.hip", "talker_engine.hip", "encoder_kernels.hip", "encoder_engine.hip",
-           "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip"]
+           "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip",
+           "persist_probe.hip"]            # (last: measuring tool, tools/persist_probe.py)
 HEADERS = ["common.h", "kernels.h", "glue.h", os.path.join("..", "..", "include", "qtts.h")]
 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (14 dwords on gfx950) arrive in user SGPRs with the wave instead
 # of behind an `s_load` round trip; the frame step's decode GEMM passes its address operands that way (skinny.hip).

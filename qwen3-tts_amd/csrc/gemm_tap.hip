@@ -487,11 +487,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
     const int nsteps = kslabs * p.taps;
     constexpr int AREG = (MAXROWS * CPR + 255) / 256;
     constexpr int WREG = (BN * CPR + 255) / 256;
-    // Round 3: the weight tile of step s + 3 is requested at step s (three register sets, the loop unrolled by three so that the
-    // set index is static) and goes to LDS one step ahead as before.  With the request only ONE step ahead a step -- 16 MFMAs per wave,
-    // 0.11 us -- ended up as long as an L2 round trip (in-kernel timestamps: 0.9-1.5 us per step, profiles/r03_tstamp_codec_resunit.md);
-    // the staged input slab of a multi-tap convolution is requested at the FIRST tap of the slab before it (taps - 1 steps ahead).
-    uint4 ra[AREG], rw[3][WREG];
+    uint4 ra[AREG], rw[WREG];
 
     auto load_a = [&](int ks) {
 #pragma unroll
@@ -513,8 +509,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
             if (r < arows) *reinterpret_cast<uint4*>(&dst[r * STR + c * 8]) = ra[i];
         }
     };
-    auto load_w = [&](uint4 (&rwk)[WREG], int step) {
-        const int ks = step / p.taps, tap = step - ks * p.taps;
+    auto load_w = [&](int ks, int tap) {
         const bf16_t* W = Wg + (size_t)tap * p.N * p.K;
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
@@ -522,72 +517,64 @@ __global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int 
             const int r = idx / CPR, c = idx - r * CPR;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < BN && n0 + r < p.N) v = *reinterpret_cast<const uint4*>(W + (size_t)(n0 + r) * p.K + ks * BK + c * 8);
-            rwk[i] = v;
+            rw[i] = v;
         }
     };
-    auto store_w = [&](const uint4 (&rwk)[WREG], int buf) {
+    auto store_w = [&](int buf) {
         bf16_t* dst = Ws + buf * BN * STR;
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
             const int idx = tid + 256 * i;
             const int r = idx / CPR, c = idx - r * CPR;
-            if (r < BN) *reinterpret_cast<uint4*>(&dst[r * STR + c * 8]) = rwk[i];
+            if (r < BN) *reinterpret_cast<uint4*>(&dst[r * STR + c * 8]) = rw[i];
         }
     };
 
-    const bool a_early = p.taps > 1;                   // the next slab is requested at tap 0 of this one (else: one step ahead, as the weights were)
-    load_a(0); load_w(rw[0], 0);
-    if (nsteps > 1) load_w(rw[1], 1);
-    if (nsteps > 2) load_w(rw[2], 2);
-    store_a(0); store_w(rw[0], 0);
+    load_a(0); load_w(0, 0);
+    store_a(0); store_w(0);
     __syncthreads();
     QTTS_TS(1);
-    for (int s0 = 0; s0 < nsteps; s0 += 3) {
+    for (int s = 0; s < nsteps; ++s) {
+        const int ks = s / p.taps, tap = s - ks * p.taps;
+        const bool more = s + 1 < nsteps;
+        const int ks2 = (s + 1) / p.taps, tap2 = (s + 1) - ks2 * p.taps;
+        const bool new_slab = more && ks2 != ks;
+        if (more) load_w(ks2, tap2);                   // global loads stay in flight under the MFMAs
+        if (new_slab) load_a(ks2);
+        {
+            const bf16_t* Ab = As + (abufs == 2 ? (ks & 1) : 0) * cap * STR;
+            const bf16_t* Wb = Ws + (s & 1) * BN * STR;
+            const int sh = p.shift[tap];               // <= 0: output row m reads staged row (m - m0) + halo + sh
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int s = s0 + u;
-            if (s >= nsteps) break;
-            const int ks = s / p.taps, tap = s - ks * p.taps;
-            const bool more = s + 1 < nsteps;
-            const int ks2 = (s + 1) / p.taps;
-            const bool new_slab = more && ks2 != ks;
-            if (s + 3 < nsteps) load_w(rw[u], s + 3);      // (set u held step s: it went to LDS at the end of step s - 1)
-            if (a_early ? (tap == 0 && ks + 1 < kslabs) : new_slab) load_a(ks + 1);
-            {
-                const bf16_t* Ab = As + (abufs == 2 ? (ks & 1) : 0) * cap * STR;
-                const bf16_t* Wb = Ws + (s & 1) * BN * STR;
-                const int sh = p.shift[tap];               // <= 0: output row m reads staged row (m - m0) + halo + sh
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 a[TM], b[TN];
 #pragma unroll
-                for (int kk = 0; kk < BK / 32; ++kk) {
-                    bf16x8 a[TM], b[TN];
+                for (int i = 0; i < TM; ++i) {
+                    a[i] = *reinterpret_cast<const bf16x8*>(&Ab[(wm * 64 + i * 16 + li + halo + sh) * STR + kk * 32 + lq * 8]);
+                    if (tpos[i] + sh < 0) a[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // before the start of its own sequence
+                }
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        a[i] = *reinterpret_cast<const bf16x8*>(&Ab[(wm * 64 + i * 16 + li + halo + sh) * STR + kk * 32 + lq * 8]);
-                        if (tpos[i] + sh < 0) a[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // before the start of its own sequence
-                    }
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const bf16x8*>(&Wb[(wn * (BN / 2) + j * 16 + li) * STR + kk * 32 + lq * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        b[j] = *reinterpret_cast<const bf16x8*>(&Wb[(wn * (BN / 2) + j * 16 + li) * STR + kk * 32 + lq * 8]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-                }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
-            if (more) {                                    // the other buffers were last read one step (W) / one slab (A) ago
-                store_w(rw[(u + 1) % 3], (s + 1) & 1);
-                if (new_slab) {
-                    if (abufs == 1) __syncthreads();       // every wave is done with the slab that is about to be overwritten
-                    store_a(ks2 & 1);
-                }
-            }
-            __syncthreads();
-#if QTTS_TSTAMP
-            if (s == 0) QTTS_TS(2);
-            if (s == 2 * p.taps) QTTS_TS(3);
-#endif
         }
+        if (more) {                                    // the other buffers were last read one step (W) / one slab (A) ago
+            store_w((s + 1) & 1);
+            if (new_slab) {
+                if (abufs == 1) __syncthreads();       // every wave is done with the slab that is about to be overwritten
+                store_a(ks2 & 1);
+            }
+        }
+        __syncthreads();
+#if QTTS_TSTAMP
+        if (s == 0) QTTS_TS(2);
+        if (s == 2 * p.taps) QTTS_TS(3);
+#endif
     }
     QTTS_TS(4);
     tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);

@@ -1,0 +1,337 @@
+// persist_probe.hip -- MEASURING TOOL (tools/persist_probe.py; not on the product path, no C-ABI entry in include/qtts.h).
+//
+// Question: would the code predictor's layers run faster as ONE persistent launch whose stages hand over through
+// grid barriers, with every stage's weights requested BEFORE the barrier wait, than as the chain of hipGraph kernel nodes the engine
+// uses?  DESIGN.md argues "no" from the guide's price list (a grid barrier costs more than a kernel boundary, and 4-13 MB operators
+// leave little stream to hide behind it); this probe measures it on the box instead.
+//
+// Both sides run the same GEMM chain of one code-predictor layer -- q|k|v (4096 x 1024) -> o (1024 x 2048) -> gate|up (6144 x 1024) ->
+// down (1024 x 3072), batch 8, bf16, L layers back to back (attention, norm, SwiGLU and residuals left out on both sides: the probe
+// times the hand-offs and the weight streams, the outputs only have to agree with each other) -- on weights packed as the engine packs
+// them (pack_skinny_weight, 16-feature strips):
+//   launches    4 L launches of the engine's own decode GEMM (launch_skinny -> skinny8_kernel), captured in one hipGraph;
+//   persistent  ONE launch of 256 workgroups x 4 waves (one per CU, all co-resident).  A stage: every workgroup owns N / 256 output
+//               features (1, 1, 3, 1 strips of 16, 4, 8, 4 features), its 4 waves split K; the workgroup's WHOLE share of the next
+//               operator (16-48 KB) is requested into registers between its arrival at the barrier and its wait, x (written by all other workgroups)
+//               is read after it.  Barrier = XCD-hierarchical counters (8 groups of 32 workgroups, one top counter), release fence
+//               before the arrival, acquire fence after the wait, EVERY spin bounded (give-up flag after 2 ms, reported to the host).
+#include <cmath>
+#include <vector>
+#include "common.h"
+#include "kernels.h"
+
+namespace qtts {
+
+namespace {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct PStage { const void* Wp; int N, K; int in, out; int fs, spw, jsh; };   // in / out: activation buffer index (bf16 [8][ACT_LD]); fs: features per
+                                                                         // strip of THIS side's packing; spw = N / fs / 256 strips per workgroup; jsh = log2(K / 128) where spw > 1, else 31
+struct PersistParams {
+    const PStage* st;                // [4 n_layers] (device memory; every layer has its own operators)
+    unsigned short* act[5];          // activation buffers bf16 [8][ACT_LD]
+    int n_layers;
+    unsigned* counters;              // [32 g] arrivals of XCD g, [256] XCDs complete, [512 + 32 g] generation word of XCD g; monotonic over the launch
+    int* abort_flag;
+    unsigned long long* phase;       // [4] ticks of the 100 MHz clock summed over the stages, workgroup 0: body | arrive | operator request | wait
+};
+constexpr int ACT_LD = 6144;
+constexpr int MAXT = 24;             // 16-byte weight chunks per lane and stage: spw x (K / 32 / 4 waves) -- 8 (q|k|v), 16 (o), 3 x 8 (gate|up), 24 (down)
+
+__device__ inline unsigned long long probe_clock() {        // 100 MHz constant clock
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+
+// XCD-hierarchical grid barrier (the guide's "barrier-xcd" form), all 256 workgroups, epoch = barriers passed so far + 1:
+//   every workgroup: its stores have left the CU (vmcnt(0)) -> arrive on its XCD's counter (workgroup b runs on XCD b % 8);
+//   the LAST arriver of an XCD (the leader of this epoch): release fence = write-back of the XCD's L2 -> arrive on the top counter ->
+//   poll it until all 8 XCDs are in -> store the epoch into its XCD's generation word;
+//   everyone else polls its XCD's generation word (one lane, relaxed loads, s_sleep); then ONE acquire fence per workgroup.
+// Every spin is bounded by a poll count (~2 ms); a give-up raises abort_flag and the kernel returns.
+constexpr unsigned SPIN_POLLS = 20000;
+__device__ inline bool poll_ge(const unsigned* w, unsigned v, int* abort_flag) {
+    for (unsigned n = 0; n < SPIN_POLLS; ++n) {
+        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+__device__ inline unsigned barrier_arrive(const PersistParams& p) {          // returns the arrival index on this XCD's counter (thread 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's stores have left the CU
+    __syncthreads();
+    unsigned c = 0;
+    if (threadIdx.x == 0) c = __hip_atomic_fetch_add(p.counters + (blockIdx.x & 7u) * 32u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return c;
+}
+__device__ inline bool barrier_wait(const PersistParams& p, unsigned epoch, unsigned c) {
+    if (threadIdx.x == 0) {
+        const unsigned g = blockIdx.x & 7u;
+        unsigned* gen = p.counters + 512u + g * 32u;             // (words 128 B apart)
+        unsigned* top = p.counters + 256u;
+        if (c + 1u == 32u * epoch) {                             // leader of this XCD for this epoch
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            poll_ge(top, 8u * epoch, p.abort_flag);
+            __hip_atomic_store(gen, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            poll_ge(gen, epoch, p.abort_flag);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+// This wave's share of the workgroup's spw strips of stage s: chunk i = (strip j = i / nkw, k-tile wave + 4 (i % nkw)), nkw = K / 128.
+// Packed layout (pack_skinny_weight): [strip][k-tile][k-slice 4][feature fs][16 B]; lane (lj, lq) takes (k-slice lq, feature lj % fs).
+__device__ inline void load_w(const PStage& s, int wave, int lane, u32x4 (&w)[MAXT]) {
+    const int nkt = s.K >> 5, nkw = nkt >> 2, lj = lane & 15, lq = lane >> 4;
+    const int cnt = s.spw * nkw;
+    const u32x4* base = reinterpret_cast<const u32x4*>(s.Wp) + lq * s.fs + (lj & (s.fs - 1));
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i)
+        if (i < cnt) {
+            const int j = i >> s.jsh, kt = wave + 4 * (i - (j << s.jsh));
+            const int strip = blockIdx.x * s.spw + j;
+            w[i] = __builtin_nontemporal_load(base + ((size_t)strip * nkt + kt) * (s.fs * 4));
+        }
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void persist_layer_kernel(PersistParams p) {
+    __shared__ __attribute__((aligned(16))) f32x4 red[3][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int n_stages = 4 * p.n_layers;
+    u32x4 w[MAXT];
+    unsigned epoch = 0;
+    unsigned long long ph[4] = {0, 0, 0, 0};
+    load_w(p.st[0], wave, lane, w);
+    for (int si = 0; si < n_stages; ++si) {
+        const PStage s = p.st[si];
+        const unsigned long long t0 = probe_clock();
+        const int nkw = s.K >> 7;
+        const unsigned short* x = p.act[s.in];
+        unsigned short* out = p.act[s.out];
+        // B operand: lane (batch row lj & 7, lq) <- x[row][kt * 32 + lq * 8 .. + 8]; columns 8..15 duplicate 0..7 (never stored)
+        const unsigned short* xr = x + (size_t)(lj & 7) * ACT_LD + lq * 8;
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+            if (i < s.spw * nkw) {
+                const int j = i >> s.jsh, kt = wave + 4 * (i - (j << s.jsh));
+                bf16x8 xb, wb;
+                *reinterpret_cast<u32x4*>(&xb) = *reinterpret_cast<const u32x4*>(xr + kt * 32);
+                *reinterpret_cast<u32x4*>(&wb) = w[i];
+                if (j == 0) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc[0], 0, 0, 0);
+                else if (j == 1) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc[1], 0, 0, 0);
+                else acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc[2], 0, 0, 0);
+            }
+        for (int j = 0; j < s.spw; ++j) red[j][wave][lane] = acc[j];
+        __syncthreads();
+        if (wave < s.spw) {                                       // wave j finishes strip j: D lane (batch row lj, lq) holds features 4 lq .. 4 lq + 3
+            const f32x4 t = (red[wave][0][lane] + red[wave][1][lane]) + (red[wave][2][lane] + red[wave][3][lane]);
+            if (lj < 8 && lq * 4 < s.fs) {
+                const int strip = blockIdx.x * s.spw + wave;
+                uint2 h;                                          // (x 1/32: keeps a 20-stage chain of random operators finite; exact in bf16)
+                h.x = pack_bf16(t[0] * 0.03125f, t[1] * 0.03125f); h.y = pack_bf16(t[2] * 0.03125f, t[3] * 0.03125f);
+                *reinterpret_cast<uint2*>(out + (size_t)lj * ACT_LD + strip * s.fs + lq * 4) = h;
+            }
+        }
+        if (si + 1 < n_stages) {
+            const unsigned long long t1 = probe_clock();
+            const unsigned c = barrier_arrive(p);
+            const unsigned long long t2 = probe_clock();
+            load_w(p.st[si + 1], wave, lane, w);                // the whole next operator: requested between arrival and wait
+            const unsigned long long t3 = probe_clock();
+            if (!barrier_wait(p, ++epoch, c)) return;
+            const unsigned long long t4 = probe_clock();
+            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 4; ++i) p.phase[i] = ph[i];
+}
+
+// Variant 3: the launches, plus a second graph branch that pulls the operator of stage n + 1 into the XCDs' L2s while stage n runs.
+// Workgroup b of the decode GEMM reads the contiguous bytes [b S, (b + 1) S) of its packed operator and runs on XCD b % 8; this kernel
+// uses the same grid, so its workgroup b leaves exactly those lines in the L2 that GEMM workgroup b will ask.
+__global__ __launch_bounds__(256) void operator_prefetch_kernel(const u32x4* W, int units_per_wg, unsigned* sink) {
+    const u32x4* p = W + (size_t)blockIdx.x * units_per_wg + threadIdx.x;
+    u32x4 a = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < units_per_wg; i += 256 * 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (i + j * 256 + (int)threadIdx.x < units_per_wg) ? p[i + j * 256] : a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a ^= v[j];
+    }
+    if ((a[0] ^ a[1] ^ a[2] ^ a[3]) == 0x9e3779b9u && sink) *sink = 1u;       // (keeps the loads; never true for these operators)
+}
+
+extern "C" __attribute__((visibility("default")))
+int qtts_debug_persist_layer(int32_t n_layers, int32_t reps, double* us_per_stage_persistent, double* us_per_stage_launches,
+                             double* max_rel_diff, int32_t* aborted, double* phase_us /* [4]: body, arrive, request, wait; per stage, workgroup 0 */,
+                             double* us_per_stage_prefetch /* launches + operator-prefetch branch */) {
+    try {
+        QTTS_REQUIRE(n_layers >= 1 && n_layers <= 16 && reps >= 1 && us_per_stage_persistent && us_per_stage_launches && max_rel_diff && aborted,
+                     QTTS_ERR_ARG, "bad argument");
+        const int shapes[4][2] = {{4096, 1024}, {1024, 2048}, {6144, 1024}, {1024, 3072}};
+        //            in -> out buffers: act0 (1024 wide) -> act1 (4096; the o stage reads its first 2048) -> act2 (1024) -> act3 (6144; first 3072) -> act0
+        const int io[4][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}};
+        const int pfs[4] = {16, 4, 8, 4};          // persistent side: 256 x {1, 1, 3, 1} strips
+        const int lfs[4] = {16, 8, 16, 8};         // launches: the engine's own choice (choose_fs: at least 96 workgroups)
+        std::vector<DevBuf> W(4 * n_layers), Wl(4 * n_layers);
+        DevBuf act[5], cnt, abortf, stab, phase;
+        uint32_t r = 777;
+        for (int i = 0; i < 4; ++i) {
+            const int N = shapes[i][0], K = shapes[i][1];
+            std::vector<float> w((size_t)N * K);
+            for (auto& v : w) { r = r * 1664525u + 1013904223u; v = ((int)(r >> 9) % 2001 - 1000) * 1e-3f; }
+            std::vector<char> packed(skinny_packed_bytes(N, K, true));
+            pack_skinny_weight(w.data(), N, K, true, packed.data(), nullptr, pfs[i]);
+            for (int l = 0; l < n_layers; ++l) W[4 * l + i].upload(packed.data(), packed.size());        // (same values, own memory: 30 MB per layer)
+            pack_skinny_weight(w.data(), N, K, true, packed.data(), nullptr, lfs[i]);
+            for (int l = 0; l < n_layers; ++l) Wl[4 * l + i].upload(packed.data(), packed.size());
+        }
+        std::vector<bf16_t> x0((size_t)8 * ACT_LD);
+        for (auto& v : x0) { r = r * 1664525u + 1013904223u; v = f32_to_bf16(((int)(r >> 9) % 2001 - 1000) * 1e-3f); }
+        for (int i = 0; i < 5; ++i) act[i].upload(x0.data(), x0.size() * 2);
+        cnt.alloc(4096); abortf.alloc(4); phase.alloc(32);
+        hipStream_t st;
+        QTTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        hipEvent_t ea, eb;
+        QTTS_CHECK_HIP(hipEventCreate(&ea)); QTTS_CHECK_HIP(hipEventCreate(&eb));
+        const int n_stages = 4 * n_layers;
+        // ---- launches: the engine's decode GEMM, 4 L nodes in one graph
+        auto chain = [&](hipStream_t s2) {
+            for (int si = 0; si < n_stages; ++si) {
+                const int k = si & 3;
+                SkinnyParams p{};
+                p.x = reinterpret_cast<const float*>(act[io[k][0]].p); p.x_bf16 = 1; p.ldx = ACT_LD; p.M = 8;
+                p.Wp = Wl[si].p; p.N = shapes[k][0]; p.K = shapes[k][1]; p.fs = lfs[k];
+                p.out = reinterpret_cast<float*>(act[io[k][1]].p); p.out_bf16 = 1; p.ldo = ACT_LD; p.act = ACT_NONE;
+                launch_skinny(p, true, s2);
+            }
+        };
+        QTTS_CHECK_HIP(hipMemcpy(act[0].p, x0.data(), x0.size() * 2, hipMemcpyHostToDevice));
+        hipGraph_t gr; hipGraphExec_t ge;
+        QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        chain(st);
+        QTTS_CHECK_HIP(hipStreamEndCapture(st, &gr));
+        QTTS_CHECK_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        float best = 1e30f;
+        for (int i = 0; i < reps; ++i) {
+            QTTS_CHECK_HIP(hipMemcpyAsync(act[0].p, x0.data(), x0.size() * 2, hipMemcpyHostToDevice, st));
+            QTTS_CHECK_HIP(hipEventRecord(ea, st)); QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipEventRecord(eb, st));
+            QTTS_CHECK_HIP(hipStreamSynchronize(st));
+            float ms = 0; QTTS_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); best = std::min(best, ms);
+        }
+        *us_per_stage_launches = 1000.0 * best / n_stages;
+        // ---- launches + prefetch branch: stage n + 1's operator is requested on a second stream as soon as stage n - 1 has ended
+        if (us_per_stage_prefetch) {
+            hipStream_t sp;
+            QTTS_CHECK_HIP(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+            std::vector<hipEvent_t> ev(n_stages + 3);
+            for (auto& e : ev) QTTS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            auto prefetch = [&](int si) {
+                const int k = si & 3;
+                const int grid = shapes[k][0] / lfs[k];
+                const int units = (int)((size_t)shapes[k][0] * shapes[k][1] * 2 / 16 / grid);
+                hipLaunchKernelGGL(operator_prefetch_kernel, dim3(grid), dim3(256), 0, sp, reinterpret_cast<const u32x4*>(Wl[si].p), units,
+                                   reinterpret_cast<unsigned*>(abortf.p));
+            };
+            hipGraph_t g2; hipGraphExec_t ge2;
+            QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            QTTS_CHECK_HIP(hipEventRecord(ev[n_stages], st));
+            QTTS_CHECK_HIP(hipStreamWaitEvent(sp, ev[n_stages], 0));
+            prefetch(0);
+            if (n_stages > 1) prefetch(1);
+            QTTS_CHECK_HIP(hipEventRecord(ev[n_stages + 1], sp));
+            QTTS_CHECK_HIP(hipStreamWaitEvent(st, ev[n_stages + 1], 0));             // (the first two operators are in before the chain starts)
+            for (int si = 0; si < n_stages; ++si) {
+                const int k = si & 3;
+                SkinnyParams p{};
+                p.x = reinterpret_cast<const float*>(act[io[k][0]].p); p.x_bf16 = 1; p.ldx = ACT_LD; p.M = 8;
+                p.Wp = Wl[si].p; p.N = shapes[k][0]; p.K = shapes[k][1]; p.fs = lfs[k];
+                p.out = reinterpret_cast<float*>(act[io[k][1]].p); p.out_bf16 = 1; p.ldo = ACT_LD; p.act = ACT_NONE;
+                launch_skinny(p, true, st);
+                if (si + 2 < n_stages) {
+                    QTTS_CHECK_HIP(hipEventRecord(ev[si], st));
+                    QTTS_CHECK_HIP(hipStreamWaitEvent(sp, ev[si], 0));
+                    prefetch(si + 2);
+                }
+            }
+            QTTS_CHECK_HIP(hipEventRecord(ev[n_stages + 2], sp));
+            QTTS_CHECK_HIP(hipStreamWaitEvent(st, ev[n_stages + 2], 0));
+            QTTS_CHECK_HIP(hipStreamEndCapture(st, &g2));
+            QTTS_CHECK_HIP(hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0));
+            QTTS_CHECK_HIP(hipGraphLaunch(ge2, st)); QTTS_CHECK_HIP(hipStreamSynchronize(st));
+            best = 1e30f;
+            for (int i = 0; i < reps; ++i) {
+                QTTS_CHECK_HIP(hipMemcpyAsync(act[0].p, x0.data(), x0.size() * 2, hipMemcpyHostToDevice, st));
+                QTTS_CHECK_HIP(hipEventRecord(ea, st)); QTTS_CHECK_HIP(hipGraphLaunch(ge2, st)); QTTS_CHECK_HIP(hipEventRecord(eb, st));
+                QTTS_CHECK_HIP(hipStreamSynchronize(st));
+                float ms = 0; QTTS_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb)); best = std::min(best, ms);
+            }
+            *us_per_stage_prefetch = 1000.0 * best / n_stages;
+            (void)hipGraphExecDestroy(ge2); (void)hipGraphDestroy(g2); (void)hipStreamDestroy(sp);
+            for (auto& e : ev) (void)hipEventDestroy(e);
+        }
+        std::vector<bf16_t> ref((size_t)8 * ACT_LD);
+        QTTS_CHECK_HIP(hipMemcpy(ref.data(), act[0].p, ref.size() * 2, hipMemcpyDeviceToHost));
+        // ---- persistent: one launch
+        PersistParams pp{};
+        std::vector<PStage> tab(n_stages);
+        for (int si = 0; si < n_stages; ++si) {
+            const int k = si & 3;
+            tab[si] = {W[si].p, shapes[k][0], shapes[k][1], io[k][0], io[k][1], pfs[k], shapes[k][0] / pfs[k] / 256, k == 2 ? 3 : 31};
+        }
+        stab.upload(tab.data(), tab.size() * sizeof(PStage));
+        pp.st = stab.as<PStage>();
+        for (int i = 0; i < 5; ++i) pp.act[i] = act[i].as<unsigned short>();
+        pp.n_layers = n_layers; pp.counters = cnt.as<unsigned>(); pp.abort_flag = abortf.as<int>(); pp.phase = phase.as<unsigned long long>();
+        best = 1e30f;
+        int ab = 0;
+        for (int i = 0; i < reps + 1 && !ab; ++i) {
+            QTTS_CHECK_HIP(hipMemsetAsync(cnt.p, 0, 4096, st)); QTTS_CHECK_HIP(hipMemsetAsync(abortf.p, 0, 4, st));
+            QTTS_CHECK_HIP(hipMemcpyAsync(act[0].p, x0.data(), x0.size() * 2, hipMemcpyHostToDevice, st));
+            QTTS_CHECK_HIP(hipEventRecord(ea, st));
+            hipLaunchKernelGGL(persist_layer_kernel, dim3(256), dim3(256), 0, st, pp);
+            QTTS_CHECK_HIP(hipGetLastError());
+            QTTS_CHECK_HIP(hipEventRecord(eb, st));
+            QTTS_CHECK_HIP(hipStreamSynchronize(st));
+            QTTS_CHECK_HIP(hipMemcpy(&ab, abortf.p, 4, hipMemcpyDeviceToHost));
+            float ms = 0; QTTS_CHECK_HIP(hipEventElapsedTime(&ms, ea, eb));
+            if (i > 0) best = std::min(best, ms);                    // (first run warms the code up)
+        }
+        *aborted = ab;
+        if (phase_us) {
+            unsigned long long ph[4];
+            QTTS_CHECK_HIP(hipMemcpy(ph, phase.p, 32, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 4; ++i) phase_us[i] = ph[i] * 0.01 / std::max(1, n_stages - 1);
+        }
+        *us_per_stage_persistent = 1000.0 * best / n_stages;
+        // agreement of the two sides: the persistent kernel's output after the chain x 32^stages == the launch chain's (same sums, other order)
+        std::vector<bf16_t> got((size_t)8 * ACT_LD);
+        QTTS_CHECK_HIP(hipMemcpy(got.data(), act[0].p, got.size() * 2, hipMemcpyDeviceToHost));
+        double num = 0, den = 0;
+        const double sc = std::pow(32.0, n_stages);
+        for (int m = 0; m < 8; ++m)
+            for (int c = 0; c < 1024; ++c) {
+                const double a = bf16_to_f32(got[(size_t)m * ACT_LD + c]) * sc, b = bf16_to_f32(ref[(size_t)m * ACT_LD + c]);
+                num = std::max(num, std::fabs(a - b)); den = std::max(den, std::fabs(b));
+            }
+        *max_rel_diff = den > 0 ? num / den : -1.0;
+        (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr); (void)hipStreamDestroy(st);
+        return QTTS_OK;
+    } catch (const qtts::Error& e) { qtts::set_last_error(e.what()); return e.code; }
+    catch (const std::exception& e) { qtts::set_last_error(e.what()); return QTTS_ERR_ARG; }
+}
+
+}  // namespace qtts
