@@ -35,11 +35,13 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
     const int h = (int)((item / p.T) % p.nh);
     const int b = (int)(item / ((int64_t)p.T * p.nh));
     const int npad = p.n_pad ? p.n_pad[b] : 0;
-    float* orow = p.out + ((size_t)b * p.T + tq) * p.ldo + h * HD + li * DPL;
+    const size_t ooff = ((size_t)b * p.T + tq) * p.ldo + h * HD + li * DPL;
+    float* orow = p.out + ooff;
+    bf16_t* orow16 = reinterpret_cast<bf16_t*>(p.out16) + ooff;
     if (tq < npad) {  // left-pad query row: never read downstream
         if (g == 0)
 #pragma unroll
-            for (int d = 0; d < DPL; ++d) orow[d] = 0.f;
+            for (int d = 0; d < DPL; ++d) { if (p.out16) orow16[d] = 0; else orow[d] = 0.f; }
         return;
     }
     const int kvh = h / (p.nh / p.nkv);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
     if (g == 0) {
         const float inv = 1.f / l;
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) orow[e] = acc[e] * inv;
+        for (int e = 0; e < DPL; ++e) { if (p.out16) orow16[e] = f32_to_bf16(acc[e] * inv); else orow[e] = acc[e] * inv; }
     }
 }
 

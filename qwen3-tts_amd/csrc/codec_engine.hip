@@ -439,7 +439,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
             gemm(Ly.qkv, a, H, M, L, b2, qd + 2 * kvd, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
             launch_rope_inplace(b2, qd + 2 * kvd, M, L, c.num_attention_heads + c.num_key_value_heads, c.head_dim,
                                 inv_freq.as<float>(), st);
-            AttnRowsParams ap;
+            AttnRowsParams ap{};
             ap.qkv = b2; ap.ld = qd + 2 * kvd; ap.q_off = 0; ap.k_off = qd; ap.v_off = qd + kvd;
             ap.B = B; ap.T = L; ap.nh = c.num_attention_heads; ap.nkv = c.num_key_value_heads; ap.hd = c.head_dim;
             ap.window = c.sliding_window; ap.n_pad = nullptr; ap.out = a; ap.ldo = qd;
@@ -485,6 +485,9 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     static const bool fast16_env = [] { const char* e = getenv("QTTS_CODEC_FAST16"); return !e || atoi(e) != 0; }();   // (=0: A/B)
     bool fast16 = bf16 && !blocks.empty() && fast16_env;
     for (auto& bk : blocks) fast16 = fast16 && bk.cin % 32 == 0 && bk.cout % 32 == 0;
+    // QTTS_CODEC_FINAL16=0: fp32 tensor out of the last unit + stand-alone SnakeBeta + fp32 final conv (A/B runs)
+    static const bool final16_env = [] { const char* e = getenv("QTTS_CODEC_FINAL16"); return !e || atoi(e) != 0; }();
+    const bool final16 = fast16 && final16_env && !stage && wav && final_c % 8 == 0 && (size_t)262 * (final_c / 2 + 1) * 4 <= 64 * 1024;
     bf16_t* h16a = fast16 ? buf16[0].as<bf16_t>() : nullptr;
     bf16_t* h16b = fast16 ? buf16[1].as<bf16_t>() : nullptr;
     // (A bf16 residual stream inside the blocks was measured in round 2 -- 13.38 vs 13.54 ms per 8 x 10 s, relative RMS 0.052 vs
@@ -519,11 +522,14 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
             float* cur = b; float* alt = a;        // (a was only the stand-alone snake's output in the fp32 path: free here)
             for (int j = 0; j < 3; ++j) {
                 auto& un = bk.u[j];
-                const Snake* next = j < 2 ? &bk.u[j + 1].a1 : (i + 1 < blocks.size() ? &blocks[i + 1].act : nullptr);
                 // the last unit of a block feeds only the next block's transposed conv (the activated bf16 copy): its residual-stream
-                // output is written only where the tensor leaves the blocks (last block) or a stage was asked for
+                // output is written only where a stage was asked for.  The last unit of the last block feeds only the final
+                // SnakeBeta + conv (C -> 1): the same bf16 copy with the final activation (final16; the fp32 tensor, the stand-alone
+                // SnakeBeta pass over it and the fp32 read of the final conv were 16 C of the tail's 18 C bytes per output sample).
                 const bool leaves = j == 2 && i + 1 == blocks.size();
-                const bool dead = j == 2 && !leaves && !stage;
+                const bool to_final16 = leaves && final16;
+                const Snake* next = j < 2 ? &bk.u[j + 1].a1 : (i + 1 < blocks.size() ? &blocks[i + 1].act : (to_final16 ? &final_act : nullptr));
+                const bool dead = j == 2 && !stage && (!leaves || to_final16);
                 if (un.fused) {                    // conv7 -> SnakeBeta_2 -> conv1x1 -> + residual in one kernel (resunit.hip)
                     ResUnitParams rp{};
                     rp.A16 = h16a; rp.lda = C; rp.ldr = C; rp.M = B * L; rp.T = L; rp.dil = un.dil; rp.Cch = C;
@@ -532,7 +538,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
                     rp.W2p = un.w2p.p; rp.b2 = un.c2.bias.as<float>();
                     rp.ldc = C;
                     if (r16 && !leaves) rp.R16 = dead ? nullptr : alt;       // bf16 stream on to the next unit ...
-                    else rp.C = dead ? nullptr : alt;                        // ... fp32 where the tensor leaves the blocks
+                    else rp.C = dead ? nullptr : alt;                        // ... fp32 where the tensor leaves the blocks as such
                     // (its bf16 output must not alias its bf16 input: a tile's halo rows are other tiles' output rows)
                     rp.C16 = next ? h16b : nullptr; rp.ldc16 = C;
                     rp.ea16 = next ? next->ea.as<float>() : nullptr; rp.ib16 = next ? next->ib.as<float>() : nullptr;
@@ -566,10 +572,12 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
         if (want(nm.c_str())) { emit(x); return; }
     }
     // ---- final SnakeBeta + conv(C -> 1, k=7) + clamp (v2:861-864, 884)
-    {
+    QTTS_REQUIRE(C == final_c, QTTS_ERR_ARG, "final conv channel mismatch");
+    if (final16) {                 // h16a = SnakeBeta_final(x) in bf16, written by the last unit
+        launch_final_conv16(h16a, final_w.as<float>(), final_b, wav, pre, (int64_t)B * L, L, C, wav_stride_b, skip_samples, st);
+    } else {
         float *a, *b, *cc; scratch3(a, b, cc);
         launch_snake(x, final_act.ea.as<float>(), final_act.ib.as<float>(), a, (int64_t)B * L, C, st);
-        QTTS_REQUIRE(C == final_c, QTTS_ERR_ARG, "final conv channel mismatch");
         if (wav)
             launch_final_conv(a, final_w.as<float>(), final_b, wav, pre, (int64_t)B * L, L, C, wav_stride_b, skip_samples, st);
     }
@@ -690,7 +698,7 @@ void qtts_codec::stream_push(const int64_t* codes, int n, float* wav, hipStream_
             QTTS_REQUIRE(k.C == qw && k.h == W1, QTTS_ERR_STATE, "codec stream: KV carry mismatch");
             launch_stage_rows(b2, n, 0, n, k.d.as<float>(), W1, a, B, qw, st);
             launch_save_tail(a, W1 + n, k.d.as<float>(), W1, B, qw, st);
-            AttnRowsParams ap;
+            AttnRowsParams ap{};
             ap.qkv = a; ap.ld = qw; ap.q_off = 0; ap.k_off = qd; ap.v_off = qd + kvd;
             ap.B = B; ap.T = W1 + n; ap.nh = c.num_attention_heads; ap.nkv = c.num_key_value_heads; ap.hd = c.head_dim;
             ap.window = c.sliding_window; ap.n_pad = stream_npad.as<int>(); ap.out = b2; ap.ldo = qd;

@@ -20,11 +20,11 @@ __device__ inline float block_sum(float v, float* sm) {
 
 // ---------------------------------------------------------------------------------- RMSNorm
 // Qwen3TTS(TokenizerV2Decoder)RMSNorm: y = w * (x * rsqrt(mean(x^2) + eps)), fp32 throughout.
+template <bool OUT16>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, const float* w, float eps, float* y,
                                                       int ldy, int C) {
     __shared__ float sm[4];
     const float* xr = x + (size_t)blockIdx.x * ldx;
-    float* yr = y + (size_t)blockIdx.x * ldy;
     float s = 0.f;
     for (int c = threadIdx.x * 4; c < C; c += 1024) {
         const float4 v = *reinterpret_cast<const float4*>(xr + c);
@@ -37,13 +37,24 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int ldx, c
         const float4 g = *reinterpret_cast<const float4*>(w + c);
         float4 o;
         o.x = g.x * (v.x * r); o.y = g.y * (v.y * r); o.z = g.z * (v.z * r); o.w = g.w * (v.w * r);
-        *reinterpret_cast<float4*>(yr + c) = o;
+        if constexpr (OUT16) {           // y is a bf16 [rows][ldy] buffer: the consumer is a bf16 GEMM that would round the same way
+            uint2 h; h.x = pack_bf16(o.x, o.y); h.y = pack_bf16(o.z, o.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (size_t)blockIdx.x * ldy + c) = h;
+        } else {
+            *reinterpret_cast<float4*>(y + (size_t)blockIdx.x * ldy + c) = o;
+        }
     }
 }
 void launch_rmsnorm(const float* x, int ldx, const float* w, float eps, float* y, int ldy, int rows, int C,
                     hipStream_t st) {
     QTTS_REQUIRE(C % 4 == 0, QTTS_ERR_ARG, "rmsnorm: C % 4");
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, st, x, ldx, w, eps, y, ldy, C);
+    hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(rows), dim3(256), 0, st, x, ldx, w, eps, y, ldy, C);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+void launch_rmsnorm16(const float* x, int ldx, const float* w, float eps, void* y16, int ldy, int rows, int C,
+                      hipStream_t st) {
+    QTTS_REQUIRE(C % 4 == 0 && ldy % 4 == 0, QTTS_ERR_ARG, "rmsnorm16: C % 4, ldy % 4");
+    hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(rows), dim3(256), 0, st, x, ldx, w, eps, reinterpret_cast<float*>(y16), ldy, C);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
@@ -185,6 +196,60 @@ void launch_final_conv(const float* x, const float* w, float bias, float* wav, f
     const size_t lds = (70 * (C + 1) + 7 * C) * sizeof(float);
     QTTS_REQUIRE(lds <= 64 * 1024, QTTS_ERR_ARG, "final_conv: C too large");
     hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)((T + 63) / 64), B), dim3(256), lds, st, x, w, bias, wav,
+                       pre_clamp, T, C, out_stride_b, skip);
+    QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// bf16 mode: x is the bf16 copy the last residual unit's epilogue leaves, the final SnakeBeta already applied ([B*T][C], C % 8 == 0).
+// One output per thread, 256 per workgroup; the 262 input rows are staged once as bf16 pairs, row stride C / 2 + 1 words (odd for
+// C = 96: a wave's column reads fall into 64 different banks); the taps are uniform per instruction and come through the scalar cache.
+// HBM: 2 C bytes per output instead of the fp32 path's 4 C (fp32 tensor out of the unit) + 8 C (stand-alone SnakeBeta) + 4 C.
+__global__ __launch_bounds__(256) void final_conv16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, float bias,
+                                                           float* wav, float* pre, int64_t T, int C, int64_t out_stride_b,
+                                                           int64_t skip) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float sm_fc[];
+    unsigned* xs = reinterpret_cast<unsigned*>(sm_fc);           // [262][C / 2 + 1]
+    const int LW = C / 2 + 1, upr = C / 8;
+    const int b = blockIdx.y;
+    const int64_t t0 = (int64_t)blockIdx.x * 256;
+    const bf16_t* xb = x + (size_t)b * T * C;
+    for (int i = threadIdx.x; i < 262 * upr; i += 256) {
+        const int r = i / upr, u = i - r * upr;
+        const int64_t t = t0 - 6 + r;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t >= 0 && t < T) v = *reinterpret_cast<const u32x4*>(xb + (size_t)t * C + u * 8);
+        unsigned* d = xs + r * LW + u * 4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+    const unsigned* xr = xs + threadIdx.x * LW;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int k = 0; k < 7; ++k) {
+        const float* wk = w + k * C;
+        const unsigned* xk = xr + k * LW;
+#pragma unroll 8
+        for (int c2 = 0; c2 < C / 2; ++c2) {
+            const unsigned pr = xk[c2];
+            acc0 += wk[2 * c2] * __uint_as_float(pr << 16);
+            acc1 += wk[2 * c2 + 1] * __uint_as_float(pr & 0xffff0000u);
+        }
+    }
+    const int64_t t = t0 + threadIdx.x;
+    if (t < T && t >= skip) {
+        const float v = acc0 + acc1 + bias;
+        const size_t o = (size_t)b * out_stride_b + (size_t)(t - skip);
+        if (pre) pre[o] = v;
+        wav[o] = fminf(fmaxf(v, -1.f), 1.f);
+    }
+}
+void launch_final_conv16(const bf16_t* x, const float* w, float bias, float* wav, float* pre_clamp, int64_t rows,
+                         int64_t T, int C, int64_t out_stride_b, int64_t skip, hipStream_t st) {
+    const int B = (int)(rows / T);
+    QTTS_REQUIRE(C % 8 == 0, QTTS_ERR_ARG, "final_conv16: C % 8");
+    const size_t lds = (size_t)262 * (C / 2 + 1) * 4;
+    QTTS_REQUIRE(lds <= 64 * 1024, QTTS_ERR_ARG, "final_conv16: C too large");
+    hipLaunchKernelGGL(final_conv16_kernel, dim3((unsigned)((T + 255) / 256), B), dim3(256), lds, st, x, w, bias, wav,
                        pre_clamp, T, C, out_stride_b, skip);
     QTTS_CHECK_HIP(hipGetLastError());
 }

@@ -294,7 +294,7 @@ void qtts_encoder::encode(const float* wav, int B, int L, int64_t* codes, hipStr
             launch_layernorm(h, H, Ly.n1w.as<float>(), Ly.n1b.as<float>(), c.norm_eps, a, H, M, H, st);
             gemm(Ly.qkv, a, H, M, T, b2, qw, ACT_NONE, nullptr, 0, nullptr, st);
             launch_rope_inplace(b2, qw, M, T, c.num_attention_heads + c.num_key_value_heads, c.head_dim, inv_freq.as<float>(), st);
-            AttnRowsParams ap;
+            AttnRowsParams ap{};
             ap.qkv = b2; ap.ld = qw; ap.q_off = 0; ap.k_off = qd; ap.v_off = qd + kvd;
             ap.B = B; ap.T = T; ap.nh = c.num_attention_heads; ap.nkv = c.num_key_value_heads; ap.hd = c.head_dim;
             ap.window = c.sliding_window; ap.n_pad = nullptr; ap.out = a; ap.ldo = qd;

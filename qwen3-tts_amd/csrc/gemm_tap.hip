@@ -59,7 +59,7 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
         if constexpr (TN % 2 == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wm * 64 + i * 16 + li;
+                const int m = m0 + wm * (TM * 16) + i * 16 + li;
 #pragma unroll
                 for (int j = 0; j < TN; j += 2) {
                     const int n_packed = n0 + wn * (BN / 2) + j * 16 + lq * 4;
@@ -68,7 +68,11 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
                         f32x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float g = acc[i][j][r], u = acc[i][j + 1][r]; o[r] = (g / (1.f + expf(-g))) * u; }
-                        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + no) = o;
+                        if (p.C) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + no) = o;
+                        if (p.C16) {     // bf16 copy for a bf16-GEMM consumer (ldc16 % 4 == 0, 8-byte aligned: checked at launch)
+                            uint2 hv; hv.x = cvt_pk_bf16(o[0], o[1]); hv.y = cvt_pk_bf16(o[2], o[3]);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C16) + (size_t)m * p.ldc16 + no) = hv;
+                        }
                     }
                 }
             }
@@ -80,7 +84,7 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int m = m0 + wm * 64 + i * 16 + li;
+                const int m = m0 + wm * (TM * 16) + i * 16 + li;
 #pragma unroll 1
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0 + wn * (BN / 2) + j * 16 + lq * 4 + r;
@@ -124,7 +128,7 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
         uint2 rh[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + li, mc = m < p.M ? m : p.M - 1;
+            const int m = m0 + wm * (TM * 16) + i * 16 + li, mc = m < p.M ? m : p.M - 1;
             res[i] = *reinterpret_cast<const f32x4*>(p.res ? p.res + (size_t)mc * p.ldr + n : dummy);
             rh[i] = *reinterpret_cast<const uint2*>(p.res16 ? reinterpret_cast<const bf16_t*>(p.res16) + (size_t)mc * p.ldres16 + n
                                                             : reinterpret_cast<const bf16_t*>(dummy));
@@ -133,7 +137,7 @@ __device__ __forceinline__ void tap_epilogue(const GemmTapParams& p, f32x4 (&acc
         if (!p.scale) scale = one4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + li;
+            const int m = m0 + wm * (TM * 16) + i * 16 + li;
             if (m >= p.M) continue;
             f32x4 r = zero4;
             if (p.res) r = res[i];
@@ -328,14 +332,18 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmTapParams p) {
     tap_epilogue<BN, TM, TN, BF16>(p, acc, m0, n0, wm, wn, li, lq);
 }
 
-// ---- wide-K variant for SMALL grids (talker prefill, text projection): bf16, 1 tap, BK = 128.
+// ---- wide-K variant for SMALL grids (talker prefill, text projection, the codec's transformer): bf16, 1 tap, BK = 128.
 // With fewer workgroups than CUs nothing hides the global-load latency of a k-step (~0.9 us measured per step with
 // BK = 32), so the step is made 4x deeper instead: 4x fewer exposed round trips, 16 + 8 16-B loads in flight per
-// thread.  128 x BN tile, 4 waves (2x2) as above; LDS rows are 128 + 8 bf16.
-template <int BN>
+// thread.  BM x BN tile, 4 waves (2x2), LDS rows are 128 + 8 bf16.
+// Round 3: what bounds these launches is what ONE CU can pull -- a k-step of a 128 x 128 tile moves 96 KB (64 KB of it the fp32
+// activation tile) in ~2 us = 0.53 us + bytes / 65 GB/s, whatever the prefetch depth -- so the time of a launch is
+// (bytes all workgroups pull) / (CUs with a workgroup x 65 GB/s).  Hence
+//   * BM = 64 tiles where the 128-row grid leaves CUs idle (launch_gemm_tap picks the tile by that estimate), and
+//   * A16: the activation tile read as bf16 when the producer left a bf16 copy (same rounding as converting here, half the bytes).
+template <int BM, int BN, bool A16, int BK>
 __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
-    constexpr int BM = 128, BK = 128;
-    constexpr int TM = 4, TN = BN / 32;
+    constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int STR = BK + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_gw[];
     bf16_t* As = reinterpret_cast<bf16_t*>(smem_gw);
@@ -362,39 +370,56 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = p.K / BK;
-    constexpr int AREG = 16;                 // 128 rows x 32 float4 / 256 threads
-    constexpr int WREG = BN * 16 / 256;      // BN rows x 16 uint4 / 256 threads
-    float4 ra[AREG];
+    constexpr int CH = BK / 8;                        // 16-B units of bf16 per row and k-step; fp32 rows have 2 CH
+    constexpr int AREG = A16 ? BM * CH / 256 : BM * 2 * CH / 256;
+    constexpr int WREG = BN * CH / 256;
+    float4 ra[A16 ? 1 : AREG];
+    uint4 ra16[A16 ? AREG : 1];
     uint4 rw[WREG];
-    const int a_c4 = tid & 31, a_r = tid >> 5;      // rows a_r + 8*i
-    const int w_c = tid & 15, w_r = tid >> 4;       // rows w_r + 16*i
+    constexpr int AROWS = 256 / (2 * CH), WROWS = 256 / CH;
+    const int a_c4 = tid % (2 * CH), a_r = tid / (2 * CH);      // fp32 A: rows a_r + AROWS * i
+    const int w_c = tid % CH, w_r = tid / CH;                   // W (and bf16 A): rows w_r + WROWS * i
     const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W);
+    const bf16_t* Ah = reinterpret_cast<const bf16_t*>(p.A16);
 
     auto load_tiles = [&](int s) {
         const int k0 = s * BK;
+        if constexpr (A16) {
 #pragma unroll
-        for (int i = 0; i < AREG; ++i) {
-            const int m = m0 + a_r + 8 * i;
-            ra[i] = m < p.M ? *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + k0 + a_c4 * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < AREG; ++i) {
+                const int m = m0 + w_r + WROWS * i;
+                ra16[i] = m < p.M ? *reinterpret_cast<const uint4*>(Ah + (size_t)m * p.lda + k0 + w_c * 8) : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AREG; ++i) {
+                const int m = m0 + a_r + AROWS * i;
+                ra[i] = m < p.M ? *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + k0 + a_c4 * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
-            const int r = w_r + 16 * i;
+            const int r = w_r + WROWS * i;
             rw[i] = (n0 + r < p.N) ? *reinterpret_cast<const uint4*>(W + (size_t)(n0 + r) * p.K + k0 + w_c * 8)
                                    : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&]() {
+        if constexpr (A16) {
 #pragma unroll
-        for (int i = 0; i < AREG; ++i) {
-            uint2 h;
-            h.x = cvt_pk_bf16(ra[i].x, ra[i].y);
-            h.y = cvt_pk_bf16(ra[i].z, ra[i].w);
-            *reinterpret_cast<uint2*>(&As[(a_r + 8 * i) * STR + a_c4 * 4]) = h;
+            for (int i = 0; i < AREG; ++i) *reinterpret_cast<uint4*>(&As[(w_r + WROWS * i) * STR + w_c * 8]) = ra16[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < AREG; ++i) {
+                uint2 h;
+                h.x = cvt_pk_bf16(ra[i].x, ra[i].y);
+                h.y = cvt_pk_bf16(ra[i].z, ra[i].w);
+                *reinterpret_cast<uint2*>(&As[(a_r + AROWS * i) * STR + a_c4 * 4]) = h;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < WREG; ++i) *reinterpret_cast<uint4*>(&Ws[(w_r + 16 * i) * STR + w_c * 8]) = rw[i];
+        for (int i = 0; i < WREG; ++i) *reinterpret_cast<uint4*>(&Ws[(w_r + WROWS * i) * STR + w_c * 8]) = rw[i];
     };
 
     load_tiles(0);
@@ -407,7 +432,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
             bf16x8 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 16 + li) * STR + kk * 32 + lq * 8]);
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * (BM / 2) + i * 16 + li) * STR + kk * 32 + lq * 8]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 b[j] = *reinterpret_cast<const bf16x8*>(&Ws[(wn * (BN / 2) + j * 16 + li) * STR + kk * 32 + lq * 8]);
@@ -597,11 +622,11 @@ static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo, cap);
 }
 
-template <int BN>
-static void launch_wide(const GemmTapParams& p, hipStream_t st) {
-    const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
-    const size_t lds = (size_t)(128 + BN) * (128 + 8) * 2;
-    auto kern = gemm_wide_kernel<BN>;
+template <int BM, int BN, bool A16, int BK>
+static void launch_wide_k(const GemmTapParams& p, hipStream_t st) {
+    const int nb = cdiv(p.M, BM) * cdiv(p.N, BN);
+    const size_t lds = (size_t)(BM + BN) * (BK + 8) * 2;
+    auto kern = gemm_wide_kernel<BM, BN, A16, BK>;
     static bool attr_set = false;
     if (!attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -609,6 +634,50 @@ static void launch_wide(const GemmTapParams& p, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p);
+}
+// Tile of the wide-K kernel.  Three bounds, all measured on the prefill's and the codec transformer's shapes
+// (profiles/r03_gemm_small_tiles.md); the launch takes about the largest:
+//   a workgroup's own chain: k-steps x (0.53 us + step bytes / 65 GB/s)      (one CU, one workgroup's loads in flight)
+//   a CU's share:            workgroups per CU x the bytes each pulls / 80 GB/s
+//   the operator itself:     row tiles x N K 2 bytes / 6 TB/s                 (every row tile streams the whole operator)
+// 64-row tiles double the workgroups where 128 rows leave CUs idle; a 256-wide k-step (64-row tiles only: registers) halves the
+// exposed round trips of a long K.
+struct WideTile { int bm, bn, bk; };
+static int g_wide_force = -1;                    // tests / A-B tooling: bm bn bk as digits (64064256), 0 = the chooser, -1 = QTTS_GEMM_WIDE_TILE
+static WideTile wide_tile(const GemmTapParams& p, bool a16, int bn_max) {
+    static const int force_env = [] { const char* e = getenv("QTTS_GEMM_WIDE_TILE"); return e ? atoi(e) : 0; }();
+    const int force = g_wide_force >= 0 ? g_wide_force : force_env;
+    static const bool legacy = [] { const char* e = getenv("QTTS_GEMM_NARROW"); return e && atoi(e) == 0; }();   // round 2's rule
+    WideTile best{128, bn_max, 128};
+    if (legacy) {
+        if (!a16 && bn_max == 128 && p.act != ACT_SWIGLU && cdiv(p.M, 128) * cdiv(p.N, 128) < 128 && p.N % 64 == 0) best.bn = 64;
+        return best;
+    }
+    double tb = 1e30;
+    const double ab = a16 ? 2.0 : 4.0;
+    for (int cm : {128, 64})
+        for (int cn : {128, 64})
+            for (int ck : {128, 256}) {
+                if (cn > bn_max || p.N % cn != 0 || p.K % ck != 0) continue;
+                if (ck == 256 && (cm != 64 || (!a16 && cn != 64))) continue;       // (registers: 64 x 128 fp32 at 256 would spill)
+                if (force && force != (cm * 1000 + cn) * 1000 + ck) continue;
+                const int wgs = cdiv(p.M, cm) * cdiv(p.N, cn), steps = p.K / ck;
+                const double sb = ck * (cm * ab + cn * 2.0) * 1e-3;                    // KB per k-step
+                const double chain = steps * (0.53 + sb / 65.0);
+                const double cu = cdiv(wgs, 256) * steps * sb / 80.0;
+                const double op = (double)cdiv(p.M, cm) * p.N * p.K * 2.0 / 6e6;
+                const double t = std::max(chain, std::max(cu, op)) * (1.0 + 0.01 * (cm * cn < 128 * 128));   // (ties go to the larger tile)
+                if (t < tb) { tb = t; best = {cm, cn, ck}; }
+            }
+    return best;
+}
+template <bool A16>
+static void launch_wide(const GemmTapParams& p, int bn_max, hipStream_t st) {
+    const WideTile t = wide_tile(p, A16, bn_max);
+    if (t.bm == 128) { if (t.bn == 128) launch_wide_k<128, 128, A16, 128>(p, st); else launch_wide_k<128, 64, A16, 128>(p, st); }
+    else if (t.bk == 128) { if (t.bn == 128) launch_wide_k<64, 128, A16, 128>(p, st); else launch_wide_k<64, 64, A16, 128>(p, st); }
+    else if (t.bn == 128) { if constexpr (A16) launch_wide_k<64, 128, true, 256>(p, st); else launch_wide_k<64, 128, false, 128>(p, st); }
+    else launch_wide_k<64, 64, A16, 256>(p, st);
 }
 
 template <int BN, bool BF16>
@@ -619,6 +688,8 @@ static void launch_t(const GemmTapParams& p, hipStream_t st) {
 
 void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
     GemmTapParams p = p_in;
+    static const int wide_max_tiles = [] { const char* e = getenv("QTTS_GEMM_WIDE_MAX"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
+    // (grids up to 2048 tiles of 128 x 128: the batch-32 prefill's gate|up GEMM, 1536 tiles, runs 150 us here, 187 us in the BK = 32 kernel)
     QTTS_REQUIRE(p.K % 32 == 0, QTTS_ERR_ARG, "gemm_tap: K must be a multiple of 32");
     QTTS_REQUIRE(p.taps >= 1 && p.taps <= 8, QTTS_ERR_ARG, "gemm_tap: 1..8 taps");
     QTTS_REQUIRE(p.M > 0 && p.N > 0, QTTS_ERR_ARG, "gemm_tap: empty problem");
@@ -630,7 +701,16 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
              (!p.R16 || (p.ldR16 % 4 == 0 && reinterpret_cast<uintptr_t>(p.R16) % 8 == 0)) &&
              al16(p.C) && al16(p.res) && al16(p.bias) && al16(p.scale) && al16(p.snake_ea) && al16(p.snake_ib) && al16(p.snake16_ea) &&
              al16(p.snake16_ib) && (p.snake16_period % 4 == 0);
-    if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.ldc % 4 == 0 && al16(p.C), QTTS_ERR_ARG, "gemm_tap: swiglu output must be 16-byte aligned with ldc % 4 == 0");
+    if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.ldc % 4 == 0 && al16(p.C) && (!p.C16 || (p.ldc16 % 4 == 0 && reinterpret_cast<uintptr_t>(p.C16) % 8 == 0)),
+                                          QTTS_ERR_ARG, "gemm_tap: swiglu outputs must be 16-byte (fp32) / 8-byte (bf16) aligned with ldc % 4 == 0");
+    if (p.A16 && bf16 && p.taps == 1 && p.shift[0] == 0 && p.K % 128 == 0 && p.K >= 512 && p.N % 64 == 0 && p.lda % 8 == 0 && (p.C || p.C16) && !p.res16 &&
+        !p.R16 && (cdiv(p.M, 128) * cdiv(p.N, 128) <= wide_max_tiles || p.act == ACT_SWIGLU)) {       // (the tap-reuse kernel has no SwiGLU epilogue)
+        // bf16 activations into a SMALL grid (the talker prefill): the deep-k kernel reading the bf16 copy
+        if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "gemm_tap: swiglu needs N % 32 == 0");
+        launch_wide<true>(p, p.N % 128 == 0 ? 128 : 64, st);
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     if (p.A16) {                           // bf16 activations: the tap-reuse kernel (bf16 mode only)
         QTTS_REQUIRE(bf16, QTTS_ERR_ARG, "gemm_tap: A16 needs bf16 weights");
         QTTS_REQUIRE(p.act != ACT_SWIGLU, QTTS_ERR_ARG, "gemm_tap: the A16 kernel has no SwiGLU epilogue");
@@ -647,7 +727,7 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }
-    QTTS_REQUIRE(p.C, QTTS_ERR_ARG, "gemm_tap: null output");
+    QTTS_REQUIRE(p.C || (p.C16 && p.act == ACT_SWIGLU), QTTS_ERR_ARG, "gemm_tap: null output");
     QTTS_REQUIRE(!p.res16 && !p.R16, QTTS_ERR_ARG, "gemm_tap: the bf16 residual stream needs the A16 kernel");
     int bn;
     if (p.act == ACT_SWIGLU) {
@@ -657,14 +737,11 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
     else if (p.N % 96 == 0) bn = 96;
     else if (p.N <= 64) bn = 64;
     else bn = 128;
-    // A grid that leaves most of the 256 CUs idle (the talker prefill's o / down projections: 512 rows x 2048 columns = 64 tiles of
-    // 128 x 128) runs 64-column tiles instead: twice the workgroups pulling the same weights (QTTS_GEMM_NARROW=0: A/B).
-    static const bool narrow_env = [] { const char* e = getenv("QTTS_GEMM_NARROW"); return !e || atoi(e) != 0; }();
-    if (narrow_env && bf16 && bn == 128 && p.act != ACT_SWIGLU && p.taps == 1 && cdiv(p.M, 128) * cdiv(p.N, 128) < 128 && p.N % 64 == 0) bn = 64;
-    // small grids are latency-bound per k-step: use the deep-k kernel (bf16, plain Linear)
-    const int nb = cdiv(p.M, 128) * cdiv(p.N, bn);
-    if (bf16 && p.taps == 1 && p.shift[0] == 0 && p.K % 128 == 0 && p.K >= 512 && nb <= 1024 && (bn == 128 || bn == 64)) {
-        if (bn == 128) launch_wide<128>(p, st); else launch_wide<64>(p, st);
+    // small grids are bound by what the CUs holding a workgroup can pull: the deep-k kernel (bf16, plain Linear), tile by wide_tile()
+    // (QTTS_GEMM_NARROW=0: always 128 rows, and 64 columns only where N asks for it -- round 2's rule, for A/B runs)
+    if (bf16 && p.taps == 1 && p.shift[0] == 0 && p.K % 128 == 0 && p.K >= 512 && (bn == 128 || bn == 64) &&
+        cdiv(p.M, 128) * cdiv(p.N, bn) <= wide_max_tiles) {
+        launch_wide<false>(p, bn, st);
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }
@@ -678,6 +755,50 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         else launch_t<64, false>(p, st);
     }
     QTTS_CHECK_HIP(hipGetLastError());
+}
+
+// DEBUG/test hook: force the tile of the wide-K kernel (a forced tile the shape does not admit falls back to 128 x 128).
+extern "C" __attribute__((visibility("default"))) void qtts_debug_gemm_wide_tile(int32_t code) { g_wide_force = code; }
+
+// DEBUG/perf tooling (tools/bench_gemm_small.py; not part of the product surface): a hipGraph chain of `iters` identical
+// launch_gemm_tap calls on an [M][K] activation (fp32, or bf16 when a16) and a bf16 [N][K] operator; microseconds per launch.
+extern "C" __attribute__((visibility("default")))
+int qtts_debug_gemm_tap(int32_t M, int32_t N, int32_t K, int32_t act, int32_t with_res, int32_t a16, int32_t iters, int32_t reps,
+                        double* us_per_launch) {
+    try {
+        QTTS_REQUIRE(us_per_launch && iters > 0 && reps > 0 && M > 0, QTTS_ERR_ARG, "bad argument");
+        DevBuf A, W, Cb, R;
+        A.alloc((size_t)M * K * 4); W.alloc((size_t)N * K * 2); Cb.alloc((size_t)M * N * 4); R.alloc((size_t)M * N * 4);
+        QTTS_CHECK_HIP(hipMemset(A.p, 0x3c, A.bytes)); QTTS_CHECK_HIP(hipMemset(W.p, 0x3c, W.bytes)); QTTS_CHECK_HIP(hipMemset(R.p, 0, R.bytes));
+        GemmTapParams p{};
+        if (a16) p.A16 = A.p; else p.A = A.as<float>();
+        p.lda = K; p.M = M; p.T = M; p.W = W.p; p.N = N; p.K = K; p.taps = 1; p.act = act;
+        const int No = act == ACT_SWIGLU ? N / 2 : N;
+        if (with_res) { p.res = R.as<float>(); p.ldr = No; }
+        p.C = Cb.as<float>(); p.ldc = No;
+        hipStream_t st;
+        QTTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        launch_gemm_tap(p, true, st);
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        hipGraph_t gr; hipGraphExec_t ge;
+        QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < iters; ++i) launch_gemm_tap(p, true, st);
+        QTTS_CHECK_HIP(hipStreamEndCapture(st, &gr));
+        QTTS_CHECK_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+        QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        hipEvent_t a, b;
+        QTTS_CHECK_HIP(hipEventCreate(&a)); QTTS_CHECK_HIP(hipEventCreate(&b));
+        float best = 1e30f;
+        for (int r = 0; r < reps; ++r) {
+            QTTS_CHECK_HIP(hipEventRecord(a, st)); QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipEventRecord(b, st));
+            QTTS_CHECK_HIP(hipStreamSynchronize(st));
+            float ms = 0; QTTS_CHECK_HIP(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
+        }
+        *us_per_launch = 1000.0 * best / iters;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr); (void)hipStreamDestroy(st);
+        return QTTS_OK;
+    } catch (const qtts::Error& e) { qtts::set_last_error(e.what()); return e.code; }
+    catch (const std::exception& e) { qtts::set_last_error(e.what()); return QTTS_ERR_ARG; }
 }
 
 }  // namespace qtts

@@ -89,6 +89,8 @@ void pack_skinny_weight(const float* W, int N, int K, bool bf16, void* out_host,
 // --------------------------------------------------------------------------------- elementwise.hip
 void launch_rmsnorm(const float* x, int ldx, const float* w, float eps, float* y, int ldy, int rows, int C,
                     hipStream_t st);
+// the same with a bf16 output [rows][ldy] (the only consumer is a bf16 GEMM: identical rounding, half the bytes it reads)
+void launch_rmsnorm16(const float* x, int ldx, const float* w, float eps, void* y16, int ldy, int rows, int C, hipStream_t st);
 void launch_snake(const float* x, const float* ea, const float* ib, float* y, int64_t rows, int C, hipStream_t st);
 // y[t][c] = LayerNorm_c(sum_k w[c][k] x[t-6+k][c] + b[c]) (ConvNeXt dwconv k=7 + LN eps)
 void launch_dwconv_ln(const float* x, const float* w7, const float* b, const float* ln_w, const float* ln_b,
@@ -100,6 +102,9 @@ void launch_rvq_gather(const int64_t* codes, int B, int Q, int T, int64_t stride
 // final conv (C -> 1, k = 7, causal) + clamp; x already snake-activated, channel-last
 void launch_final_conv(const float* x, const float* w /*[7][C]*/, float bias, float* wav, float* pre_clamp,
                        int64_t rows, int64_t T, int C, int64_t out_stride_b, int64_t skip, hipStream_t st);
+// bf16 mode: x = the producer's bf16 copy with the final SnakeBeta applied
+void launch_final_conv16(const bf16_t* x, const float* w /*[7][C]*/, float bias, float* wav, float* pre_clamp,
+                         int64_t rows, int64_t T, int C, int64_t out_stride_b, int64_t skip, hipStream_t st);
 // in-place rotate-half RoPE on the q and k parts of a fused qkv buffer (codec transformer: no q/k norm)
 void launch_rope_inplace(float* qkv, int ld, int rows, int T, int n_heads_total /* q + k heads */, int hd,
                          const float* inv_freq, hipStream_t st);
@@ -160,6 +165,7 @@ struct AttnRowsParams {
     int window;                  // 0 = full causal; else keys in (tq - window, tq]
     const int* n_pad;            // optional [B]: keys < n_pad masked, query rows < n_pad skipped
     float* out; int ldo;
+    void* out16 = nullptr;       // optional: write bf16 [rows][ldo] here INSTEAD of the fp32 `out` (the consumer is a bf16 GEMM)
 };
 void launch_attn_rows(const AttnRowsParams& p, hipStream_t st);
 

@@ -551,15 +551,25 @@ void qtts_talker::prefill(const float* embeds, int B_, int T, const int32_t* n_p
     QTTS_CHECK_HIP(hipMemcpyAsync(tts_pad.p, tts_pad_dev, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
     QTTS_CHECK_HIP(hipMemcpyAsync(n_pad_d.p, n_pad_host, (size_t)B * 4, hipMemcpyHostToDevice, st));
     float *xs = pf_x.as<float>(), *nb = pf_n.as<float>(), *qb = pf_qkv.as<float>(), *ab = pf_att.as<float>(), *mb = pf_act.as<float>();
-    auto gemm = [&](const DevBuf& Wr, int N, int K, const float* A, int lda, float* C, int ldc, int act_, const float* res) {
+    // bf16 mode (round 3): a tensor whose only consumer is a GEMM -- the normed rows, the attention output, the SwiGLU product -- is
+    // written as bf16 by its producer (the GEMM rounded it the same way while staging: bit-identical results) and read at half the
+    // bytes; these small-grid GEMMs are bound by what a CU can pull (gemm_tap.hip, gemm_wide_kernel).  The bf16 tensors live in the
+    // fp32 buffers' storage.  QTTS_PREFILL_A16=0: fp32 hand-over (A/B runs and the equality test).
+    const bool a16_env = [] { const char* e = getenv("QTTS_PREFILL_A16"); return !e || atoi(e) != 0; }();   // (read per call: the test runs both)
+    // (the SwiGLU GEMM with bf16 input exists in the wide-K kernel only: K = H a multiple of 128, at least 512)
+    const bool a16 = bf16 && a16_env && H >= 512 && H % 128 == 0 && td.qd % 8 == 0 && td.I % 32 == 0;
+    auto gemm = [&](const DevBuf& Wr, int N, int K, const float* A, int lda, float* C, int ldc, int act_, const float* res, bool out16 = false) {
         GemmTapParams p{};
-        p.A = A; p.lda = lda; p.M = M; p.T = T; p.W = Wr.p; p.N = N; p.K = K; p.taps = 1; p.act = act_;
-        p.res = res; p.ldr = H; p.C = C; p.ldc = ldc;
+        if (a16) p.A16 = A; else p.A = A;
+        p.lda = lda; p.M = M; p.T = T; p.W = Wr.p; p.N = N; p.K = K; p.taps = 1; p.act = act_;
+        p.res = res; p.ldr = H;
+        if (out16) { p.C16 = C; p.ldc16 = ldc; p.ldc = ldc; } else { p.C = C; p.ldc = ldc; }
         launch_gemm_tap(p, bf16, st);
     };
     for (int l = 0; l < c.num_hidden_layers; ++l) {
         auto& L = tl[l];
-        launch_rmsnorm(xs, H, L.g1.as<float>(), td.eps, nb, H, M, H, st);
+        if (a16) launch_rmsnorm16(xs, H, L.g1.as<float>(), td.eps, nb, H, M, H, st);
+        else launch_rmsnorm(xs, H, L.g1.as<float>(), td.eps, nb, H, M, H, st);
         gemm(L.qkv_r, W, H, nb, H, qb, W, ACT_NONE, nullptr);
         QkNormRopeParams q{};
         q.qkv = qb; q.ld = W; q.B = B; q.T = T; q.nh = td.nh; q.nkv = td.nkv; q.hd = td.hd; q.qw = L.qn.as<float>();
@@ -569,10 +579,12 @@ void qtts_talker::prefill(const float* embeds, int B_, int T, const int32_t* n_p
         AttnRowsParams a{};
         a.qkv = qb; a.ld = W; a.q_off = 0; a.k_off = td.qd; a.v_off = td.qd + td.kvd; a.B = B; a.T = T; a.nh = td.nh;
         a.nkv = td.nkv; a.hd = td.hd; a.window = 0; a.n_pad = n_pad_d.as<int>(); a.out = ab; a.ldo = td.qd;
+        if (a16) a.out16 = ab;
         launch_attn_rows(a, st);
         gemm(L.o_r, H, td.qd, ab, td.qd, xs, H, ACT_NONE, xs);
-        launch_rmsnorm(xs, H, L.g2.as<float>(), td.eps, nb, H, M, H, st);
-        gemm(L.gu_r, 2 * td.I, H, nb, H, mb, td.I, ACT_SWIGLU, nullptr);
+        if (a16) launch_rmsnorm16(xs, H, L.g2.as<float>(), td.eps, nb, H, M, H, st);
+        else launch_rmsnorm(xs, H, L.g2.as<float>(), td.eps, nb, H, M, H, st);
+        gemm(L.gu_r, 2 * td.I, H, nb, H, mb, td.I, ACT_SWIGLU, nullptr, a16);
         gemm(L.d_r, H, td.I, mb, td.I, xs, H, ACT_NONE, xs);
     }
     // last position of every (left-padded) row -> final norm -> past_hidden, logits (M:1726-1740)
@@ -1129,12 +1141,16 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     QTTS_API_BEGIN
     QTTS_REQUIRE(us_per_launch && iters > 0 && reps > 0, QTTS_ERR_ARG, "bad argument");
     DevBuf W, x, out, res, ssin, done;
-    W.alloc(skinny_packed_bytes(N, K, true));
+    // QTTS_DEBUG_WBUFS=n: the launches of the chain rotate through n copies of the operator (n x bytes beyond the caches = every launch
+    // streams from HBM / the Infinity Cache, as in the frame step; 1 = the same L2-resident operator every time)
+    const int wbufs = [] { const char* e = getenv("QTTS_DEBUG_WBUFS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    const size_t wbytes = skinny_packed_bytes(N, K, true);
+    W.alloc(wbytes * wbufs);
     {
         std::vector<uint16_t> h((size_t)N * K);
         uint32_t r = 12345;
         for (auto& v : h) { r = r * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((r >> 16) & 0x3ff) - 0x200 + ((r >> 31) << 15)); }
-        W.upload(h.data(), h.size() * 2);
+        for (int i = 0; i < wbufs; ++i) QTTS_CHECK_HIP(hipMemcpy(static_cast<char*>(W.p) + i * wbytes, h.data(), wbytes, hipMemcpyHostToDevice));
     }
     const int No = act == ACT_SWIGLU ? N / 2 : N;
     x.alloc((size_t)64 * K * 4); out.alloc((size_t)64 * No * 4); res.alloc((size_t)64 * No * 4);
@@ -1156,7 +1172,7 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
     hipGraph_t gr; hipGraphExec_t ge;
     QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < iters; ++i) launch_skinny(p, true, st);
+    for (int i = 0; i < iters; ++i) { p.Wp = static_cast<const char*>(W.p) + (size_t)(i % wbufs) * wbytes; launch_skinny(p, true, st); }
     QTTS_CHECK_HIP(hipStreamEndCapture(st, &gr));
     QTTS_CHECK_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
     QTTS_CHECK_HIP(hipGraphLaunch(ge, st));

@@ -159,6 +159,44 @@ def test_gemm_tap_kernel_real_source(emu, bf16):
         assert np.all(out[:, No:] == 7.0), "wrote outside its columns"
 
 
+@pytest.mark.parametrize("tile", [128128128, 128064128, 64128128, 64064128, 64064256, 64128256])
+def test_gemm_wide_kernel_every_tile_real_source(emu, tile):
+    """The small-grid GEMM of the talker prefill and the codec transformer (gemm_wide_kernel, round 3: 64-row tiles, 256-wide k-steps,
+    bf16 activations): every tile instantiation, forced through the test hook, with fp32 and with bf16 activations, ragged M, a
+    residual / bias epilogue and the SwiGLU epilogue, against float64 numpy.  (A tile the shape or the registers do not admit -- the
+    256-wide step with 128 fp32 columns -- runs as 128 x 128, which the first parameter covers.)"""
+    g = np.random.default_rng(tile % 1000 + tile // 1000000)
+    emu.qtts_debug_gemm_wide_tile.argtypes = [C.c_int32]; emu.qtts_debug_gemm_wide_tile.restype = None
+    emu.qtts_debug_gemm_wide_tile(tile)
+    try:
+        for (M, N, K, act, hb, hr) in ((150, 192, 512, ACT_NONE, 1, 1), (70, 128, 1024, ACT_SWIGLU, 0, 0)):
+            A = (g.standard_normal((M, K)) * 0.5).astype(np.float32)
+            W = (g.standard_normal((1, N, K)) / np.sqrt(K)).astype(np.float32)
+            bias = g.standard_normal(N).astype(np.float32) if hb else None
+            No = N // 2 if act == ACT_SWIGLU else N
+            res = g.standard_normal((M, No + 4)).astype(np.float32) if hr else None
+            Wv, Wbits = _bf16_round(W)
+            Av, Abits = _bf16_round(A)
+            want = _gemm_tap_ref(Av, M, Wv, [0], bias, None, res[:, :No] if hr else None, None, None, act)
+            ldc = No + 8
+            sh = (C.c_int32 * 1)(0)
+            tol = 2e-3 * max(1.0, float(np.abs(want).max()))
+            out = np.full((M, ldc), 7.0, np.float32)
+            rc = emu.hostemu_gemm_tap(_ptr(A), K, M, M, _ptr(Wbits), N, K, 1, sh, _ptr(bias) if hb else None, None,
+                                      _ptr(res) if hr else None, No + 4, None, None, act, _ptr(out), ldc, 1)
+            assert rc == 0, (emu.qtts_last_error() or b"").decode()
+            assert np.abs(out[:, :No] - want).max() <= tol and np.all(out[:, No:] == 7.0), (tile, M, N, K, "fp32 activations")
+            out16 = np.full((M, ldc), 7.0, np.float32)
+            rc = emu.hostemu_gemm_tap16(_ptr(Abits), K, M, M, _ptr(Wbits), N, K, 1, sh, _ptr(bias) if hb else None,
+                                        _ptr(res) if hr else None, No + 4, None, None, act, _ptr(out16), ldc, None, None, None)
+            assert rc == 0, (emu.qtts_last_error() or b"").decode()
+            assert np.abs(out16[:, :No] - want).max() <= tol and np.all(out16[:, No:] == 7.0), (tile, M, N, K, "bf16 activations")
+            if tile == 128128128:                                   # the same rounding either way: bf16 activations change nothing
+                assert np.array_equal(out16[:, :No], out[:, :No])
+    finally:
+        emu.qtts_debug_gemm_wide_tile(-1)
+
+
 def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
     """gemm_tap2 (round 2, the codec decoder's bf16 GEMM): bf16 input tile staged once per k-slab with its causal halo and reused
     by every tap, sequence-start zeroing applied in the operand registers (tiles that span two sequences included), k-slabs of
@@ -1160,6 +1198,27 @@ def test_talker_bf16_small_batch_staged_path(emu, golden_dir):
     finally:
         emu.hostemu_set_real_gemm(1 if FULL else 0)
         emu.qtts_talker_destroy(h)
+
+
+def test_talker_bf16_prefill_bf16_handover_changes_nothing(emu, monkeypatch):
+    """Round 3: in bf16 mode the prefill's GEMM-only tensors (normed rows, attention output, SwiGLU product) are written as bf16 by
+    their producers (rmsnorm16, attn_rows out16, the SwiGLU epilogue's C16) and read by the wide-K GEMM's bf16-activation
+    instantiations.  The GEMM rounded them the same way while staging, so every code and every hidden state must come out
+    bit-identical to the fp32 hand-over (QTTS_PREFILL_A16=0), at dims where the path is taken (hidden >= 512)."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), hidden_size=512, intermediate_size=512, num_hidden_layers=1)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = [x.numpy() for x in synth.rand_prompt(np.random.default_rng(5), t, [9, 6, 7], 2, scale=0.05)]
+    outs = []
+    for a16 in ("1", "0"):
+        monkeypatch.setenv("QTTS_PREFILL_A16", a16)
+        h = _talker_emu(emu, t, w, max_batch=4, max_seq=32, dtype=_lib.QTTS_BF16)
+        try:
+            outs.append(_talker_generate(emu, h, t, emb, mask, tr, pad, max_new=3))
+        finally:
+            emu.qtts_talker_destroy(h)
+    (c1, k1, h1), (c0, k0, h0) = outs
+    assert c1.shape[1] >= 1 and np.array_equal(c1, c0) and np.array_equal(k1, k0) and np.array_equal(h1, h0)
 
 
 @pytest.mark.skipif(not FULL, reason="QTTS_HOSTEMU_FULL=1 (2 min; a hardening pass of the emulator, not a parity gate)")
