@@ -608,6 +608,21 @@ static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
         if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2>(p, st); return; }
         if (nchunks == 3) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 3>(p, st); return; }
     }
+    // Round 3: the same for batch 17..32 (two 16-row tiles; chunks of 4 / SPW k-tiles, so K <= 3072 at 8 waves: every code-predictor
+    // GEMM and the talker's q|k|v, o and gate|up).  In the generic loop the waves of a launch drift apart by a memory round trip per
+    // chunk pair -- in-kernel timestamps at batch 32: 1.0-2.4 us between the first wave's last MFMA and the barrier
+    // (profiles/r03_skinny_b32_straight.md).  QTTS_SKINNY2_STRAIGHT_MT2=0 keeps the loop (A/B; read per launch).
+    if constexpr (EXACT && MT == 2 && XB16 && NW == 8) {
+        const char* e = getenv("QTTS_SKINNY2_STRAIGHT_MT2");
+        if (!(e && e[0] == '0')) {
+            if (nchunks == 1) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 1>(p, st); return; }
+            if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2>(p, st); return; }
+            if (nchunks == 3) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 3>(p, st); return; }
+            if constexpr (SPW == 2) {      // (chunks of 2 k-tiles: the talker's gate|up, K = 2048, is 4 of them)
+                if (nchunks == 4) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 4>(p, st); return; }
+            }
+        }
+    }
     launch2_n<MT, SPW, NW, FS, XB16, U, EXACT, 0>(p, st);
 }
 template <int MT, int SPW, int NW, int FS, bool XB16>

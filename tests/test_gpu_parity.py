@@ -532,6 +532,32 @@ def test_teacher_forcing_tiny_reproduces_golden(talker_tiny, dev):
     assert np.array_equal(out3.codes.cpu().numpy(), gc) and out3.own is None, "teacher mode must switch itself off"
 
 
+def test_prefill_bf16_handover_is_bit_identical_on_the_gpu(dev, golden_dir, monkeypatch):
+    """Round 3: in bf16 mode the prefill's GEMM-only tensors travel as bf16 from their producers to the wide-K GEMM's bf16-activation
+    instantiations (QTTS_PREFILL_A16, default on).  The GEMM rounded them the same way while staging, so at the metric config's dims
+    (1.7B, batch 8, bench.py's prompts) the greedy codes, tokens and hidden states of the first frames -- which rest entirely on the
+    prefill's KV cache -- must come out bit-identical with the fp32 hand-over, and so must the tile the chooser picks (the same launch
+    either way apart from the activation dtype).  The emulator pins the same at test dims."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    cfg = synth.talker_17b()
+    g = np.load(os.path.join(golden_dir, "talker_17b_b8.npz"))
+    lens = [int(x) for x in g["lens"]]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+    eng = TalkerEngine(cfg, _td(synth.talker_weights(cfg, with_text=False)), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens),
+                       max_seq=256, use_graph=True)
+    outs = []
+    for a16 in ("1", "0", "1"):
+        monkeypatch.setenv("QTTS_PREFILL_A16", a16)
+        o = eng.generate(emb, mask, tr, pad, max_new_tokens=7, min_new_tokens=7, do_sample=False, subtalker_dosample=False,
+                         suppress_tokens=_suppress(cfg))          # greedy: the default is seeded sampling
+        assert o.hidden is not None
+        outs.append((o.codes.cpu().numpy().copy(), o.tokens.cpu().numpy().copy(), o.hidden.cpu().numpy().copy()))
+    assert outs[0][0].shape[1] == 6
+    for k in (1, 2):
+        for x, y in zip(outs[0], outs[k]):
+            assert np.array_equal(x, y), "bf16 hand-over in the prefill changed a result"
+
+
 def test_bf16_mode_pinned_at_the_metric_config_teacher_forced(dev, golden_dir):
     """THE BENCHMARKED MODE AT THE BENCHMARKED SIZE: Qwen3-TTS-12Hz-1.7B dims, batch 8, bench.py's prompts,
     125 frames.  (1) fp32 engine, free-running greedy: bit-exact with the reference's fp32 golden `talker_17b_b8.npz`.

@@ -345,6 +345,11 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
              (8, 32, 6144, 8, 0, ACT_NONE, 1, 1, 0),      # talker down: three chunks of 8, 8-feature strips
              (24, 64, 1024, 16, 1, ACT_NONE, 0, 0, 1),    # two m-tiles
              (40, 32, 2048, 8, 1, ACT_NONE, 0, 1, 0),     # four m-tiles
+             # round 3: batch 17..32 through the straight-line instantiations (1..3 chunks of 4 k-tiles; strip pairs: 2 / 4 chunks of 2)
+             (32, 32, 2048, 8, 0, ACT_NONE, 0, 1, 1),     # cp o-proj at batch 32: two chunks, 8-feature strips, residual + shadow
+             (20, 32, 3072, 8, 0, ACT_NONE, 1, 1, 0),     # cp down at batch 20: three chunks, ragged second m-tile
+             (32, 64, 1024, 16, 1, ACT_SWIGLU, 0, 0, 0),  # cp gate|up at batch 32: strip pairs, two chunks of 2
+             (27, 64, 2048, 16, 1, ACT_SWIGLU, 0, 1, 0),  # talker gate|up: strip pairs, four chunks of 2
              (3, 48, 160, 16, 1, ACT_NONE, 1, 0, 0),      # odd K: generic (guarded) instantiation, 4 waves
              # skinny8_kernel (batch <= 8: tile pairs, whole-line x requests, DPP-rotated odd tiles) beyond the cases above
              (5, 32, 2048, 8, 1, ACT_NONE, 1, 1, 1),      # 5 rows (rows 5..7 re-read row 0), 8-feature strips, norm + bias + res + shadow
