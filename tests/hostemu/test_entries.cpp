@@ -14,6 +14,17 @@ extern "C" void hostemu_set_fiber_order(int order) { simt::M().order = order; }
 
 extern "C" void hostemu_set_real_gemm(int on) { qtts::g_real_gemm = on ? 1 : 0; }
 
+// the codec's final convolution (C -> 1, k = 7, causal) + clamp: x fp32 [B*T][C] through final_conv_kernel, or x16 bf16 bits through
+// final_conv16_kernel (round 3); wav / pre [B][out_stride], the first `skip` samples of every sequence dropped
+extern "C" int hostemu_final_conv(const float* x, const unsigned short* x16, const float* w, float bias, float* wav, float* pre, int B, int T,
+                                  int C, int out_stride, int skip) {
+    try {
+        if (x16) qtts::launch_final_conv16(x16, w, bias, wav, pre, (int64_t)B * T, T, C, out_stride, skip, nullptr);
+        else qtts::launch_final_conv(x, w, bias, wav, pre, (int64_t)B * T, T, C, out_stride, skip, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
 // C[M][ldc] = epilogue(sum_tap A[m + shift[tap]] . W[tap]^T) through the REAL gemm_tap.hip kernels; returns 0 / QTTS_ERR_*
 extern "C" int hostemu_gemm_tap(const float* A, int lda, int M, int T, const void* W, int N, int K, int taps, const int* shift,
                                 const float* bias, const float* scale, const float* res, int ldr, const float* snake_ea,

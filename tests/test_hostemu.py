@@ -197,6 +197,37 @@ def test_gemm_wide_kernel_every_tile_real_source(emu, tile):
         emu.qtts_debug_gemm_wide_tile(-1)
 
 
+@pytest.mark.parametrize("C_, T, skip", [(96, 300, 0), (96, 517, 40), (32, 70, 0)])
+def test_final_conv_kernels_real_source(emu, C_, T, skip):
+    """The codec's last layer (V2:884: causal Conv1d(C -> 1, k = 7) + clamp), both kernels: `final_conv_kernel` on the fp32 tensor and
+    round 3's `final_conv16_kernel` on the bf16 copy the last residual unit leaves -- two sequences (the causal left padding must not
+    read the previous sequence's tail), T not a multiple of the 64 / 256 outputs per workgroup, the first `skip` samples dropped (chunked
+    decode), pre-clamp output returned, values beyond +-1 present so that the clamp is exercised -- against float64 numpy."""
+    g = np.random.default_rng(C_ + T)
+    B = 2
+    x = (g.standard_normal((B, T, C_)) * 0.8).astype(np.float32)
+    w = (g.standard_normal((7, C_)) / np.sqrt(C_)).astype(np.float32)
+    bias = 0.05
+    xb, xbits = _bf16_round(x)
+    emu.hostemu_final_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p] + [C.c_int] * 5
+    for name, xin, tol in (("fp32", x, 2e-5), ("bf16", xb, 2e-5)):
+        want = np.zeros((B, T), np.float64)
+        xp = np.concatenate([np.zeros((B, 6, C_)), xin.astype(np.float64)], axis=1)
+        for k in range(7):
+            want += (xp[:, k:k + T] * w[k].astype(np.float64)).sum(-1)
+        want += bias
+        stride = T - skip + 3
+        wav = np.full((B, stride), 7.0, np.float32)
+        pre = np.full((B, stride), 7.0, np.float32)
+        rc = emu.hostemu_final_conv(_ptr(x) if name == "fp32" else None, _ptr(xbits) if name == "bf16" else None, _ptr(w), bias,
+                                    _ptr(wav), _ptr(pre), B, T, C_, stride, skip)
+        assert rc == 0, (emu.qtts_last_error() or b"").decode()
+        n = T - skip
+        assert np.abs(pre[:, :n] - want[:, skip:]).max() <= tol * max(1.0, float(np.abs(want).max())), name
+        assert np.array_equal(wav[:, :n], np.clip(pre[:, :n], -1.0, 1.0)) and float(np.abs(pre[:, :n]).max()) > 1.0, name
+        assert np.all(wav[:, n:] == 7.0) and np.all(pre[:, n:] == 7.0), "wrote outside its samples"
+
+
 def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
     """gemm_tap2 (round 2, the codec decoder's bf16 GEMM): bf16 input tile staged once per k-slab with its causal halo and reused
     by every tap, sequence-start zeroing applied in the operand registers (tiles that span two sequences included), k-slabs of
