@@ -4,7 +4,8 @@
 
 namespace qtts {
 
-enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SWIGLU = 2, ACT_SNAKE = 3, ACT_SILU = 4 };
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SWIGLU = 2, ACT_SNAKE = 3, ACT_SILU = 4,
+           ACT_SWIGLU8 = 5 };   // decode GEMM at batch <= 8 only: W rows interleaved [8 gate | 8 up] per 16-feature strip (see SkinnyParams::act)
 
 // --------------------------------------------------------------------------------- gemm_tap.hip
 struct GemmTapParams {
@@ -74,13 +75,15 @@ struct SkinnyParams {
     const float* bias;           // [N] or null
     const float* res; int ldr;   // residual [M][ldr] or null
     float* out; int ldo;
-    int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns)
+    int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns) | ACT_SWIGLU8 (round 3, skinny8_kernel:
+                                 // ONE strip = 8 gate + 8 up rows of the same 8 output columns -> N/16 workgroups instead of N/32)
     const int* done_flag;        // optional device flag: when non-zero the kernel exits early
     int ablate;                  // DEBUG ONLY (perf ablation): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
 };
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);
 void skinny_set_launch_events(hipEvent_t start, hipEvent_t stop);   // (bench.py's roofline leg: time the NEXT launch on its own; null = off)
 bool skinny_takes_bf16_x(int M, int K, bool bf16);   // bf16 mode: any M <= 64, K % 32 == 0
+bool skinny_swiglu8_takes(int K);                     // ACT_SWIGLU8 (batch <= 8 kernel): K = 1024 | 2048 | 3072 | 6144
 size_t skinny_packed_bytes(int N, int K, bool bf16);
 // Pack W[N][K] (row-major f32), optionally scaled per input column by g[K], into the streaming tile layout;
 // gate/up interleaving is the caller's.

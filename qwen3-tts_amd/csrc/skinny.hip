@@ -373,7 +373,8 @@ __global__ __launch_bounds__(NW * 64) void skinny8_kernel(const void* kWp, const
     f32x4 resv[SPW], biasv[SPW];
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
-        const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * FS) + colq;
+        const int col = p.act == ACT_SWIGLU8 ? blockIdx.x * 8 + (lq & 1) * 4
+                                             : (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * FS) + colq;
         const float* bp = p.bias ? p.bias + (strip0 + s) * FS + colq : reinterpret_cast<const float*>(p.x);
         const float* rp = p.res ? p.res + (size_t)rowc * p.ldr + col : reinterpret_cast<const float*>(p.x);
         biasv[s] = *reinterpret_cast<const f32x4*>(bp);
@@ -434,6 +435,23 @@ __global__ __launch_bounds__(NW * 64) void skinny8_kernel(const void* kWp, const
 #pragma unroll
         for (int w2 = 1; w2 < NW; ++w2) t += red[(w2 * NS + s) * 64 + lane];
         v[s] = t * rstd + (p.bias ? biasv[s] : zero4);
+    }
+    if constexpr (SPW == 1 && FS == 16) {
+        if (p.act == ACT_SWIGLU8) {      // rows 0..7 of the strip = gate, rows 8..15 = up of output columns 8 b .. 8 b + 7: the up quad of
+            f32x4 up;                    // lane (lj, lq < 2) sits in lane (lj, lq + 2) = lane + 32
+#pragma unroll
+            for (int r = 0; r < 4; ++r) up[r] = __shfl(v[0][r], (lane + 32) & 63);
+            if (lj < p.M && lq < 2) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (v[0][r] / (1.f + expf(-v[0][r]))) * up[r];
+                o += p.res ? resv[0] : zero4;
+                skinny_store4(p, lj, blockIdx.x * 8 + lq * 4, o, false);
+            }
+            QTTS_TS_DRAINED(5);
+            QTTS_TS_END(skinny, 0, p.K, p.N);
+            return;
+        }
     }
     if (lj < p.M && lq * 4 < FS) {
         if (p.act == ACT_SWIGLU) {
@@ -586,6 +604,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
 // bf16 mode: a GEMM input may arrive as the producer's bf16 copy (x_bf16) for any M <= 64 -- nothing is staged through LDS any
 // more, so there is no capacity condition left (round 1: M <= 16 up to K = 7096, M <= 32 up to K = 2344).
 bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <= 64 && K % 32 == 0; }
+// ACT_SWIGLU8 lives in skinny8_kernel only: the K for which that kernel is instantiated (launch8_nw)
+bool skinny_swiglu8_takes(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
 
 template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
 static void launch2_n(const SkinnyParams& p, hipStream_t st) {
@@ -731,6 +751,14 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(!p.out_bf16 || bf16, QTTS_ERR_ARG, "skinny: bf16 output only in bf16 mode");
     QTTS_REQUIRE(bf16 || !p.norm || p.ss_in, QTTS_ERR_ARG, "skinny: the fp32 kernel takes the row sums of squares from ss_in");
     if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.N % 32 == 0 && fs == 16, QTTS_ERR_ARG, "skinny: swiglu needs N % 32 and fs == 16");
+    if (p.act == ACT_SWIGLU8) {          // one 16-feature strip = 8 gate + 8 up rows: only the batch <= 8 kernel has this epilogue
+        QTTS_REQUIRE(bf16 && fs == 16 && p.x_bf16 && p.M <= 8 && p.K % 512 == 0 && !p.bias && !p.ablate, QTTS_ERR_ARG,
+                     "skinny: ACT_SWIGLU8 needs the bf16 batch <= 8 kernel (bf16 x, K % 512 == 0, 16-feature strips, no bias)");
+        const char* e8 = getenv("QTTS_SKINNY8");
+        QTTS_REQUIRE(!(e8 && e8[0] == '0'), QTTS_ERR_ARG, "skinny: ACT_SWIGLU8 with QTTS_SKINNY8=0");
+        if (launch8_fs<1, 16>(p, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
+        throw Error(QTTS_ERR_ARG, "skinny: no batch <= 8 instantiation for this K");
+    }
     const int spw = skinny_spw(p.N, fs, p.act == ACT_SWIGLU);
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);

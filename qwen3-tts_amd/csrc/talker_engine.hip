@@ -25,6 +25,7 @@ namespace {
 struct LayerW {
     int fs_o = 16, fs_d = 16;         // features per strip of o_p / d_p
     DevBuf qkv_p, o_p, gu_p, d_p;     // packed (decode)
+    DevBuf gu_p8;                     // gate|up packed with 8-row interleave (ACT_SWIGLU8: the batch <= 8 kernel, twice the workgroups); bf16 only
     DevBuf qkv_r, o_r, gu_r, d_r;     // row-major (prefill, talker only)
     DevBuf g1, g2, qn, kn;
 };
@@ -193,6 +194,19 @@ struct qtts_talker {
         }
         return w;
     }
+    // the same with 8-row blocks: strip j of the packed operator = gate rows 8 j .. 8 j + 7, then up rows 8 j .. 8 j + 7 (ACT_SWIGLU8)
+    static std::vector<float> interleave_gu8(const std::vector<float>& g, const std::vector<float>& u, int I, int H) {
+        std::vector<float> w((size_t)2 * I * H);
+        for (int f = 0; f < I; ++f) {
+            memcpy(&w[((size_t)(f / 8) * 16 + f % 8) * H], &g[(size_t)f * H], (size_t)H * 4);
+            memcpy(&w[((size_t)(f / 8) * 16 + 8 + f % 8) * H], &u[(size_t)f * H], (size_t)H * 4);
+        }
+        return w;
+    }
+    // Round 3 (profiles/r03_ab_swiglu8.md): at batch <= 8 the gate|up GEMM runs as N / 16 workgroups of ONE strip (8 gate + 8 up rows)
+    // instead of N / 32 strip pairs -- 768 instead of 384 for the talker: three per CU instead of 1.5, 9.5 vs 10.7 us streamed.
+    // Bit-identical results (the same per-element accumulation), a second packed copy of the operator.  QTTS_SWIGLU8=0: strip pairs.
+    bool swiglu8_env = [] { const char* e = getenv("QTTS_SWIGLU8"); return !e || atoi(e) != 0; }();
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
                          PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
@@ -203,6 +217,9 @@ struct qtts_talker {
         L.fs_o = choose_fs(d.H, d.qd); L.fs_d = choose_fs(d.H, d.I);
         upload_packed(L.o_p, ow, d.H, d.qd, nullptr, L.fs_o);
         upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
+        if (bf16 && swiglu8_env && d.I % 8 == 0 && skinny_swiglu8_takes(d.H))
+            upload_packed(L.gu_p8, interleave_gu8(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H),
+                          2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
@@ -231,6 +248,7 @@ struct qtts_talker {
         ++skinny_count;
     }
     int64_t skinny_count = 0;
+    static bool skinny_ablate_or_off() { const char* e = getenv("QTTS_SKINNY8"); return e && e[0] == '0'; }   // (A/B switch of skinny.hip, read per launch)
 
     // x-side handling of a GEMM whose input is RMS-normalised: the bf16 kernel takes the row variances on the matrix pipe
     // (skinny.hip) from the producer's bf16 copy of x; the fp32 parity kernel gets the row sums of squares from one extra
@@ -283,6 +301,7 @@ struct qtts_talker {
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
         g.out_bf16 = act16;
         norm_input(g, d, h16 ? xs16 : nullptr, st);
+        if (L.gu_p8.p && g.x_bf16 && M <= 8 && !skinny_ablate_or_off()) { g.Wp = L.gu_p8.p; g.act = ACT_SWIGLU8; }
         skinny(g, st);
         SkinnyParams dn{};
         dn.done_flag = ss.done;
@@ -1152,7 +1171,8 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
         for (auto& v : h) { r = r * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((r >> 16) & 0x3ff) - 0x200 + ((r >> 31) << 15)); }
         for (int i = 0; i < wbufs; ++i) QTTS_CHECK_HIP(hipMemcpy(static_cast<char*>(W.p) + i * wbytes, h.data(), wbytes, hipMemcpyHostToDevice));
     }
-    const int No = act == ACT_SWIGLU ? N / 2 : N;
+    const bool glu = act == ACT_SWIGLU || act == ACT_SWIGLU8;
+    const int No = glu ? N / 2 : N;
     x.alloc((size_t)64 * K * 4); out.alloc((size_t)64 * No * 4); res.alloc((size_t)64 * No * 4);
     ssin.alloc(64 * 8); done.alloc(64);
     QTTS_CHECK_HIP(hipMemset(x.p, 0x3c, x.bytes));
@@ -1161,8 +1181,8 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     SkinnyParams p{};
     p.x = x.as<float>(); p.ldx = K; p.M = M; p.Wp = W.p; p.N = N; p.K = K; p.eps = 1e-6f; p.act = act;
     p.x_bf16 = 1;                                   // as in the frame step: the producer's bf16 copy of x
-    if (act != ACT_SWIGLU) { int fs = 16; while (fs > 4 && N / fs < 192) fs /= 2; p.fs = fs; }     // the engine's choose_fs
-    if (const char* e = getenv("QTTS_DEBUG_FS")) { if (act != ACT_SWIGLU && atoi(e) > 0) p.fs = atoi(e); }
+    if (!glu) { int fs = 16; while (fs > 4 && N / fs < 192) fs /= 2; p.fs = fs; }     // the engine's choose_fs
+    if (const char* e = getenv("QTTS_DEBUG_FS")) { if (!glu && atoi(e) > 0) p.fs = atoi(e); }
     if (with_norm) { p.norm = 1; p.ss_in = ssin.as<float>(); }
     if (with_res) { p.res = res.as<float>(); p.ldr = No; }
     p.out = out.as<float>(); p.ldo = No; p.done_flag = done.as<int>(); p.ablate = ablate;

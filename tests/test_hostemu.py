@@ -88,7 +88,7 @@ def _bf16_round(x):
     return (r << 16).astype(np.uint32).view(np.float32).reshape(x.shape), r.astype(np.uint16).reshape(x.shape)
 
 
-ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SNAKE, ACT_SILU = 0, 1, 2, 3, 4            # csrc/kernels.h enum Act
+ACT_NONE, ACT_GELU, ACT_SWIGLU, ACT_SNAKE, ACT_SILU, ACT_SWIGLU8 = 0, 1, 2, 3, 4, 5     # csrc/kernels.h enum Act
 
 
 def _gemm_tap_ref(A, T, W, shift, bias, scale, res, ea, ib, act):
@@ -386,16 +386,19 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
              (5, 32, 2048, 8, 1, ACT_NONE, 1, 1, 1),      # 5 rows (rows 5..7 re-read row 0), 8-feature strips, norm + bias + res + shadow
              (8, 32, 3072, 8, 0, ACT_NONE, 0, 1, 0),      # six pairs per wave, rotated weights
              (1, 64, 3072, 16, 1, ACT_SWIGLU, 0, 1, 0),   # one row, strip pairs, six pairs per wave
-             (8, 48, 2048, 16, 0, ACT_NONE, 1, 0, 1)]     # talker o-proj-like, 16-feature strips, no norm
+             (8, 48, 2048, 16, 0, ACT_NONE, 1, 0, 1),     # talker o-proj-like, 16-feature strips, no norm
+             # round 3: SwiGLU in ONE strip (8 gate + 8 up rows; twice the workgroups of the strip pairs), batch <= 8 only
+             (8, 64, 2048, 16, 1, ACT_SWIGLU8, 0, 0, 0),  # talker gate|up-like
+             (3, 48, 1024, 16, 1, ACT_SWIGLU8, 0, 1, 0)]  # code-predictor-like, 3 rows, with a residual
     for (M, N, K, fs, norm, act, hb, hr, sh), s8 in [(c, v) for c in cases for v in ("1", "0")]:
-        if s8 == "0" and not (M <= 8 and K % 512 == 0 and fs >= 8):
+        if s8 == "0" and (act == ACT_SWIGLU8 or not (M <= 8 and K % 512 == 0 and fs >= 8)):
             continue                                      # (QTTS_SKINNY8=0: the same shapes through skinny2_kernel)
         os.environ["QTTS_SKINNY8"] = s8
         x = (g.standard_normal((M, K + 8)) * 0.7).astype(np.float32)
         W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
         gw = (1 + 0.1 * g.standard_normal(K)).astype(np.float32) if norm else None
         bias = g.standard_normal(N).astype(np.float32) if hb else None
-        No = N // 2 if act == ACT_SWIGLU else N
+        No = N // 2 if act in (ACT_SWIGLU, ACT_SWIGLU8) else N
         res = g.standard_normal((M, No)).astype(np.float32) if hr else None
         Wf = _bf16_round(W * gw if norm else W)[0]
         xv = _bf16_round(x[:, :K])[0]
@@ -404,8 +407,9 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
             acc *= 1 / np.sqrt((xv.astype(np.float64) ** 2).mean(1, keepdims=True) + 1e-6)
         if hb:
             acc += bias
-        if act == ACT_SWIGLU:
-            a = acc.reshape(M, N // 32, 2, 16)
+        if act in (ACT_SWIGLU, ACT_SWIGLU8):                  # W rows: blocks of 16 (8) gate rows, then 16 (8) up rows of the same columns
+            blk = 16 if act == ACT_SWIGLU else 8
+            a = acc.reshape(M, N // (2 * blk), 2, blk)
             acc = ((a[:, :, 0] / (1 + np.exp(-a[:, :, 0]))) * a[:, :, 1]).reshape(M, No)
         if hr:
             acc = acc + res
@@ -1234,6 +1238,27 @@ def test_talker_bf16_small_batch_staged_path(emu, golden_dir):
     finally:
         emu.hostemu_set_real_gemm(1 if FULL else 0)
         emu.qtts_talker_destroy(h)
+
+
+def test_talker_bf16_swiglu_single_strip_changes_nothing(emu, monkeypatch):
+    """Round 3: at batch <= 8 the frame step's gate|up GEMM runs from a second packed copy of the operator -- 8 gate + 8 up rows per
+    strip, one strip per workgroup (ACT_SWIGLU8), twice the workgroups of the strip pairs.  Every output element is accumulated by the
+    same MFMA sequence either way, so codes, tokens and hidden states must be bit-identical with QTTS_SWIGLU8=0 (strip pairs), at dims
+    where the copy exists (hidden = 1024 | 2048 | 3072 | 6144, the K the batch <= 8 kernel is instantiated for)."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), hidden_size=1024, intermediate_size=256, num_hidden_layers=1)     # (K = 1024: an instantiated K)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = [x.numpy() for x in synth.rand_prompt(np.random.default_rng(8), t, [7, 5, 9], 2, scale=0.05)]
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("QTTS_SWIGLU8", on)
+        h = _talker_emu(emu, t, w, max_batch=4, max_seq=32, dtype=_lib.QTTS_BF16)
+        try:
+            outs.append(_talker_generate(emu, h, t, emb, mask, tr, pad, max_new=4))
+        finally:
+            emu.qtts_talker_destroy(h)
+    (c1, k1, h1), (c0, k0, h0) = outs
+    assert c1.shape[1] >= 2 and np.array_equal(c1, c0) and np.array_equal(k1, k0) and np.array_equal(h1, h0)
 
 
 def test_talker_bf16_prefill_bf16_handover_changes_nothing(emu, monkeypatch):
