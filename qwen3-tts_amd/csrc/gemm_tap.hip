@@ -759,6 +759,15 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
 
 // DEBUG/test hook: force the tile of the wide-K kernel (a forced tile the shape does not admit falls back to 128 x 128).
 extern "C" __attribute__((visibility("default"))) void qtts_debug_gemm_wide_tile(int32_t code) { g_wide_force = code; }
+// DEBUG/test hook (host code only, no device): the tile wide_tile() picks for a plain Linear of this shape -- pins the chooser's
+// documented behaviour in the CPU suite (tests/test_hostemu.py).
+extern "C" __attribute__((visibility("default")))
+void qtts_debug_gemm_wide_choice(int32_t M, int32_t N, int32_t K, int32_t a16, int32_t* bm, int32_t* bn, int32_t* bk) {
+    GemmTapParams p{};
+    p.M = M; p.N = N; p.K = K; p.taps = 1;
+    const WideTile t = wide_tile(p, a16 != 0, N % 128 == 0 ? 128 : 64);
+    *bm = t.bm; *bn = t.bn; *bk = t.bk;
+}
 
 // DEBUG/perf tooling (tools/bench_gemm_small.py; not part of the product surface): a hipGraph chain of `iters` identical
 // launch_gemm_tap calls on an [M][K] activation (fp32, or bf16 when a16) and a bf16 [N][K] operator; microseconds per launch.

@@ -228,6 +228,41 @@ def test_final_conv_kernels_real_source(emu, C_, T, skip):
         assert np.all(wav[:, n:] == 7.0) and np.all(pre[:, n:] == 7.0), "wrote outside its samples"
 
 
+def test_gemm_wide_tile_chooser_follows_its_three_bounds(emu):
+    """`wide_tile()` (gemm_tap.hip) picks the small-grid GEMM's tile from three measured bounds (profiles/r03_gemm_small_tiles.md).  Host
+    code only.  Pinned here: every choice is an instantiation that exists for the shape; where 128-row tiles would leave most CUs idle
+    (the prefill's q|k|v, o and down projections at 512 rows, the codec transformer's at 125 / 1000 rows) it at least doubles the workgroups; where every
+    row tile streams a 50 MB operator (gate|up) or the grid already fills the chip (2048 rows) it keeps 128 x 128; a 256-wide k-step
+    only with 64 rows, and with fp32 activations only on 64 columns (registers)."""
+    f = emu.qtts_debug_gemm_wide_choice
+    f.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_int32)] * 3; f.restype = None
+    emu.qtts_debug_gemm_wide_tile.argtypes = [C.c_int32]; emu.qtts_debug_gemm_wide_tile.restype = None
+    emu.qtts_debug_gemm_wide_tile(0)                                     # the chooser itself, whatever QTTS_GEMM_WIDE_TILE says
+    def pick(M, N, K, a16):
+        bm, bn, bk = C.c_int32(), C.c_int32(), C.c_int32()
+        f(M, N, K, a16, C.byref(bm), C.byref(bn), C.byref(bk))
+        return bm.value, bn.value, bk.value
+    try:
+        for a16 in (0, 1):
+            for (M, N, K) in ((512, 4096, 2048), (512, 2048, 2048), (512, 12288, 2048), (512, 2048, 6144), (2048, 4096, 2048), (2048, 12288, 2048),
+                              (1000, 3072, 1024), (1000, 1024, 3072), (125, 3072, 1024), (125, 1024, 3072), (37, 192, 512), (8, 2048, 1024)):
+                bm, bn, bk = pick(M, N, K, a16)
+                assert bm in (64, 128) and bn in (64, 128) and bk in (128, 256) and N % bn == 0 and K % bk == 0, (M, N, K, a16, bm, bn, bk)
+                assert bk == 128 or (bm == 64 and (a16 or bn == 64)), (M, N, K, a16, bm, bn, bk)
+            for (M, N, K) in ((512, 4096, 2048), (512, 2048, 2048), (512, 2048, 6144), (1000, 1024, 3072), (125, 3072, 1024), (125, 1024, 3072)):
+                bm, bn, bk = pick(M, N, K, a16)                              # 128 x 128 would hold 128 workgroups or fewer: at least twice as many
+                cd = lambda a, b: -(-a // b)
+                assert cd(M, bm) * cd(N, bn) >= 2 * cd(M, 128) * cd(N, 128), ((M, N, K), a16, (bm, bn, bk))
+            for shape in ((512, 2048, 2048), (512, 2048, 6144), (125, 1024, 3072)):
+                assert pick(*shape, a16)[:2] == (64, 64), (shape, a16, pick(*shape, a16))     # 64 tiles of 128 x 128: four times as many
+            for shape in ((2048, 4096, 2048), (2048, 12288, 2048)):
+                assert pick(*shape, a16)[:2] == (128, 128), (shape, a16, pick(*shape, a16))
+            assert pick(512, 12288, 2048, a16)[0] == 128                    # row tiles x 50 MB is the bound: 64-row tiles would double it
+        assert pick(512, 2048, 6144, 0) == (64, 64, 256)                     # long K: half the exposed round trips
+    finally:
+        emu.qtts_debug_gemm_wide_tile(-1)
+
+
 def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
     """gemm_tap2 (round 2, the codec decoder's bf16 GEMM): bf16 input tile staged once per k-slab with its causal halo and reused
     by every tap, sequence-start zeroing applied in the operand registers (tiles that span two sequences included), k-slabs of
