@@ -106,6 +106,12 @@ def main(argv=None, device=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else argv, args.backend))
     hostemu = device is not None
+    if not hostemu and os.environ.get("QTTS_LIBRARY"):
+        from qwen3_tts_amd import _lib as _qlib
+        if _qlib.library_override():
+            print(f"[bench] FATAL: QTTS_LIBRARY={os.environ['QTTS_LIBRARY']} -- the bench line is only ever measured on the product "
+                  "library (qwen3-tts_amd/libqtts.so)", file=sys.stderr, flush=True)
+            sys.exit(2)
 
     import numpy as np
     import torch
@@ -421,7 +427,8 @@ def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
     return res
 
 
-def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model):
+def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_bytes=2,
+                 kernel="skinny8_kernel (weight-streaming decode GEMM, batch <= 8 instantiations)"):
     """Live measurement of the dominant kernel IN THE REAL FRAME STEP (round 3): the engine runs 8 real frames eagerly and times
     every launch of the skinny weight-streaming decode GEMM of frames 1..6 on its own -- the kernel's own begin / end timestamps
     (hipExtLaunchKernelGGL events on the engine's stream: the numbers rocprofv3's kernel trace reports for the same launches).
@@ -434,9 +441,9 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model):
     talker.set_profile(0)
     cls = talker.gemm_profile()
     frames = 6
-    out = {"bound": "hbm", "kernel": "skinny8_kernel (weight-streaming decode GEMM, batch <= 8 instantiations)", "peak": HBM_PEAK_GBS,
+    out = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "method": "per-launch kernel begin/end timestamps (hipExtLaunchKernelGGL events) over every decode-GEMM "
-                                      f"launch of {frames} real frame steps, eager launches; frac per class = N*K*2 B / avg duration / 8 TB/s"}
+                                      f"launch of {frames} real frame steps, eager launches; frac per class = N*K*{elem_bytes} B / avg duration / 8 TB/s"}
     tot_ms = sum(c["total_ms"] for c in cls)
     tot_n = sum(c["launches"] for c in cls)
     tot_b = sum(c["launches"] * c["bytes_per_launch"] for c in cls)
@@ -461,6 +468,9 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model):
         a[0] += c["total_ms"]; a[1] += c["launches"]; a[2] += c["launches"] * c["bytes_per_launch"]
     out["by_stack"] = {k: {"launches_per_frame": v[1] // frames, "avg_us": round(1e3 * v[0] / v[1], 3),
                            "frac": round(v[2] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in by.items()}
+    if elem_bytes != 2:            # (the parity-mode leg: no PMC pass and no isolated replay for the fp32 engine)
+        out["traffic"] = None
+        return out
     # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), x2 gfx950 correction
     traffic, traffic_src = None, None
     try:
@@ -507,9 +517,14 @@ def parity_mode_leg(args, tcfg, ccfg, tw_np, cw_np, lens, dev, emb, mask, traili
     torch.cuda.synchronize()
     tc = time.perf_counter()
     assert out.n_frames == F and bool(torch.isfinite(wav).all())
+    roof = None
+    if not args.no_roofline:      # the parity mode's own roofline: every fp32 decode-GEMM launch of 6 real frame steps, per class
+        roof = roofline_leg(t32, emb, mask, trailing, pad, gen_kw, t32.stats()["weight_bytes_per_frame"], args.model, elem_bytes=4,
+                            kernel="skinny8_f32_kernel (exact-fp32 weight-streaming decode GEMM, v_mfma_f32_16x16x4_f32, batch <= 8)")
     del t32, c32
     torch.cuda.empty_cache()
-    return {"talker_f32_ms_per_frame": round(1e3 * (tb - ta) / F, 4), "codec_f32_ms_per_step": round(1e3 * (tc - tb), 2),
+    return {"roofline": roof,
+            "talker_f32_ms_per_frame": round(1e3 * (tb - ta) / F, 4), "codec_f32_ms_per_step": round(1e3 * (tc - tb), 2),
             "step_ms": round(1e3 * (tc - ta), 2), "speech_tokens_per_s": round(B * F * tcfg.num_code_groups / (tc - ta), 1),
             "what": "exact-fp32 talker (v_mfma_f32_16x16x4_f32 chain, bit-exact greedy codes vs the reference goldens) + fp32 codec "
                     "(waveform RMS 7.4e-6 vs the reference at real dims): the mode the parity bar is proven in, same workload, 1 step"}

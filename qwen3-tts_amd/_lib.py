@@ -93,8 +93,23 @@ SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_cod
            "qtts_talker_set_profile"]
 
 
+PRODUCT_LIBRARY = os.path.join(_HERE, "libqtts.so")
+
+
+def library_override():
+    """Path given by QTTS_LIBRARY when it names something other than the product library, else None.  The override exists for
+    build VARIANTS of the same sources (`libqtts_<variant>.so` next to the product library: A/B and measuring builds, build.py)
+    and for the host-emulation build the CPU suite installs (tests/hostemu/pyshim.py).  It is never silent: `load_library`
+    announces it on stderr, refuses a path that is neither of the two kinds unless QTTS_LIBRARY_OK=1 says the caller means it,
+    and `bench.py` / `__graft_entry__.smoke()` refuse to run with an override at all."""
+    p = os.environ.get("QTTS_LIBRARY")
+    if not p or os.path.abspath(p) == os.path.abspath(PRODUCT_LIBRARY):
+        return None
+    return p
+
+
 def library_path() -> str:
-    return os.environ.get("QTTS_LIBRARY", os.path.join(_HERE, "libqtts.so"))
+    return library_override() or PRODUCT_LIBRARY
 
 
 def load_library():
@@ -103,6 +118,15 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = library_path()
+    if library_override():
+        import sys
+        base = os.path.basename(path)
+        variant = os.path.dirname(os.path.abspath(path)) == _HERE and base.startswith("libqtts_") and base.endswith(".so")
+        hostemu = base.startswith("libqtts_hostemu") and os.path.basename(os.path.dirname(os.path.abspath(path))) == "hostemu"
+        if not (variant or hostemu or os.environ.get("QTTS_LIBRARY_OK") == "1"):
+            raise QttsError(-103, f"QTTS_LIBRARY={path} is neither a build variant of this package (qwen3-tts_amd/libqtts_<variant>.so) "
+                                  "nor the test suite's host-emulation build; set QTTS_LIBRARY_OK=1 to load it anyway")
+        print(f"[qtts] QTTS_LIBRARY override in effect: loading {path} instead of the product library", file=sys.stderr, flush=True)
     if not os.path.exists(path):
         raise QttsError(-100, f"{path} not found -- run `python qwen3-tts_amd/build.py` (or __graft_entry__.build())")
     lib = C.CDLL(path)

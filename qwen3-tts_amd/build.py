@@ -19,8 +19,9 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libqtts.so")
 SOURCES = ["gemm_tap.hip", "resunit.hip", "skinny.hip", "elementwise.hip", "attention.hip", "sampling.hip",
            "codec_engine.hip", "talker_engine.hip", "encoder_kernels.hip", "encoder_engine.hip",
-           "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip",
-           "persist_probe.hip"]            # (last: measuring tool, tools/persist_probe.py)
+           "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip"]
+# sources that only a measuring variant links (never the product library): variant name -> files
+VARIANT_SOURCES = {"probe": ["persist_probe.hip"]}
 HEADERS = ["common.h", "kernels.h", "glue.h", os.path.join("..", "..", "include", "qtts.h")]
 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (14 dwords on gfx950) arrive in user SGPRs with the wave instead
 # of behind an `s_load` round trip; the frame step's decode GEMM passes its address operands that way (skinny.hip).
@@ -36,6 +37,12 @@ VARIANTS = {
     # csrc/tstamp.h: phase timestamps inside the frame step's kernels (decode GEMM, both decode attentions, sampler); a
     # measuring build for tools/ts_frame.py, never the product.
     "tstamp": ["-DQTTS_TSTAMP=1"],
+    # skinny.hip: the perf-ablation branches of the decode GEMM (`SkinnyParams::ablate`: no done check / no x loads / no epilogue
+    # loads / no weight stream) exist only in this build (tools/ablate_skinny.py); the product build has them compiled out.
+    "ablate": ["-DQTTS_ABLATE=1"],
+    # csrc/persist_probe.hip (hand-off probe: persistent launch with grid barriers vs graph launches, tools/persist_probe.py):
+    # the product sources + the probe's own file and entry point; round 3 linked it into libqtts.so, round 4 moved it here.
+    "probe": ["-DQTTS_PROBE=1"],
 }
 # Round 3: kpre (kernarg preload for the decode GEMM) measured 0.973x per frame (profiles/r03_ab_kpre.md) and is now the default code.
 # Round 2 (profiles/r02_ab_variants.md): cp_pretable, cp_qkvtable, attn_cp and sampler_v2 were measured faster and are now the
@@ -69,7 +76,7 @@ def build(force: bool = False, verbose: bool = True, variant: str = None) -> str
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     procs = []
-    for s in SOURCES:
+    for s in SOURCES + (VARIANT_SOURCES.get(variant, []) if variant else []):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         stamp = obj + ".sha"

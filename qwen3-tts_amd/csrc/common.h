@@ -7,6 +7,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <thread>
@@ -35,6 +36,18 @@ struct Error : std::runtime_error {
     do {                                                               \
         if (!(cond)) throw ::qtts::Error((code), std::string(msg));    \
     } while (0)
+
+// ------------------------------------------------------------------------------------------ A/B environment switches
+// An A/B switch that sits on a launch path is read ONCE (its value copied) -- no getenv per launch.  Measuring tools and
+// tests that flip a switch inside one process (tools/ab_inproc.py, monkeypatched tests) export QTTS_DEBUG_ENV_LIVE=1 before the
+// library is loaded; only then is the environment re-read at every use.
+#define QTTS_ENV(var)                                                                                              \
+    ([]() -> const char* {                                                                                        \
+        static const bool live = getenv("QTTS_DEBUG_ENV_LIVE") != nullptr;                                        \
+        if (live) return getenv(var);                                                                             \
+        static const std::string v = [] { const char* e = getenv(var); return std::string(e ? e : "\x01"); }();   \
+        return v.size() == 1 && v[0] == '\x01' ? nullptr : v.c_str();                                             \
+    }())
 
 // ------------------------------------------------------------------------------------------ bf16
 typedef uint16_t bf16_t;

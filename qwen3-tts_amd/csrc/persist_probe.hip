@@ -15,6 +15,12 @@
 //               operator (16-48 KB) is requested into registers between its arrival at the barrier and its wait, x (written by all other workgroups)
 //               is read after it.  Barrier = XCD-hierarchical counters (8 groups of 32 workgroups, one top counter), release fence
 //               before the arrival, acquire fence after the wait, EVERY spin bounded (give-up flag after 2 ms, reported to the host).
+// Built ONLY into the `probe` variant (python qwen3-tts_amd/build.py --variant probe -> libqtts_probe.so, -DQTTS_PROBE=1): a measuring
+// tool with grid-barrier spin loops has no place in the product library (round-3 verdict / advice).
+#ifndef QTTS_PROBE
+#define QTTS_PROBE 0
+#endif
+#if QTTS_PROBE
 #include <cmath>
 #include <vector>
 #include "common.h"
@@ -335,3 +341,4 @@ int qtts_debug_persist_layer(int32_t n_layers, int32_t reps, double* us_per_stag
 }
 
 }  // namespace qtts
+#endif  // QTTS_PROBE

@@ -341,7 +341,7 @@ void launch_resunit(const ResUnitParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.lda % 8 == 0 && p.ldr % 4 == 0 && (!p.C || p.ldc % 4 == 0) && (!p.C16 || p.ldc16 % 4 == 0), QTTS_ERR_ARG, "resunit: leading dimensions");
     QTTS_REQUIRE((p.ea16 == nullptr) == (p.ib16 == nullptr), QTTS_ERR_ARG, "resunit: snake16 parameters go together");
     // rows per wave: QTTS_RESUNIT_TM = 2 | 4 overrides the C = 96 default of 2 (A/B runs; read per launch)
-    const char* e = getenv("QTTS_RESUNIT_TM");
+    const char* e = QTTS_ENV("QTTS_RESUNIT_TM");
     if (p.Cch == 96) { if (e && e[0] == '4') launch_ru<1, 4>(p, st); else launch_ru<1, 2>(p, st); }
     else launch_ru<2, 4>(p, st);
     QTTS_CHECK_HIP(hipGetLastError());

@@ -30,6 +30,17 @@
 
 QTTS_TS_UNIT(skinny)
 
+// Perf-ablation hooks (tools/ablate_skinny.py) exist only in the `ablate` build variant (build.py VARIANTS, -DQTTS_ABLATE=1); in the
+// product build the expressions are the constant 0 and the branches are gone.
+#ifndef QTTS_ABLATE
+#define QTTS_ABLATE 0
+#endif
+#if QTTS_ABLATE
+#define QTTS_ABL(p, bit) ((p).ablate & (bit))
+#else
+#define QTTS_ABL(p, bit) 0
+#endif
+
 namespace qtts {
 
 // Roofline leg of bench.py (qtts_talker_set_profile): when an event pair is set, the next decode-GEMM launch goes out through
@@ -116,8 +127,8 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     }
     // perf ablation (DEBUG): "no weight stream" / "no x fetch" collapse the tile stride to 0 -- every request of a wave then hits
     // one resident line -- so that the instruction stream is unchanged
-    const size_t wstep = (p.ablate & 8) ? 0 : (size_t)(FS * 4);
-    const int xstep = (p.ablate & 2) ? 0 : KT;
+    const size_t wstep = QTTS_ABL(p, 8) ? 0 : (size_t)(FS * 4);
+    const int xstep = QTTS_ABL(p, 2) ? 0 : KT;
 
     // (non-temporal: measured twice -- round 1 whole-frame +7.6 % with plain loads; round 2 per GEMM class, plain loads for the code
     // predictor's re-read 157 MB: no gain with, +3.5 % without a warm-up -- profiles/r02_ab_inproc_prefetch_temporal.json)
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
 
     // ---- 2. epilogue operands of wave 0 are fetched now, under the weight stream
     f32x4 resv[SPW][MT], biasv[SPW];
-    const bool epi_loads = wave == 0 && !(p.ablate & 4);
+    const bool epi_loads = wave == 0 && !QTTS_ABL(p, 4);
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
         const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * FS) + lq * 4;
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
                 resv[s][m] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
         }
     }
-    const int done = (p.done_flag && !(p.ablate & 1)) ? *p.done_flag : 0;
+    const int done = (p.done_flag && !QTTS_ABL(p, 1)) ? *p.done_flag : 0;
     QTTS_TS(1);                            // every request of the straight-line kernels has been issued (and `done` has arrived)
     if (done) return;
     QTTS_TS_DRAINED(2);                    // ... and has arrived
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
             const int kt = wave + NW * i;
 #pragma unroll
             for (int s = 0; s < SPW; ++s)
-                w[s][u] = (i < my_tiles && !(p.ablate & 8)) ? skinny_wload(wbase[s] + (size_t)kt * (FS * 4)) : (u32x4){0u, 0u, 0u, 0u};
+                w[s][u] = (i < my_tiles && !QTTS_ABL(p, 8)) ? skinny_wload(wbase[s] + (size_t)kt * (FS * 4)) : (u32x4){0u, 0u, 0u, 0u};
         }
     };
     u32x4 wA[SPW][U], wB[SPW][U];
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
     load_chunk(wB, 1);
 
     f32x4 resv[SPW][MT], biasv[SPW];
-    const bool epi_loads = wave == 0 && !(p.ablate & 4);
+    const bool epi_loads = wave == 0 && !QTTS_ABL(p, 4);
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
         const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * FS) + lq * 4;
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
                 resv[s][m] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
         }
     }
-    const int done = (p.done_flag && !(p.ablate & 1)) ? *p.done_flag : 0;
+    const int done = (p.done_flag && !QTTS_ABL(p, 1)) ? *p.done_flag : 0;
     float rstd_l[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
             for (int m = 0; m < MT; ++m) {
                 const int row = m * 16 + lj;
                 float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < p.M && !(p.ablate & 2)) xv = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + k);
+                if (row < p.M && !QTTS_ABL(p, 2)) xv = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + k);
 #pragma unroll
                 for (int s = 0; s < SPW; ++s) {
                     f32x4 wa;
@@ -601,6 +612,159 @@ __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ fp32, batch <= 8 (round 4)
+// The parity mode's frame-step kernel: skinny8_kernel's design carried over to the exact-fp32 arithmetic (v_mfma_f32_16x16x4_f32
+// chains, fp32 weights and activations).  Round 3 left the fp32 GEMM as rounds 1-2 had it -- x fragments loaded tile by tile inside
+// the MFMA loop (a dependent L2 round trip per k-tile), guarded weight requests, and one extra `row_ss_kernel` launch in front of
+// every normalised GEMM: 7.03 ms per frame for 10.3 GB of weights = 0.18 of the HBM peak, below the bf16 kernel's 0.29.
+//   * A wave owns PAIRS of adjacent 16-wide k-tiles (pair j = wave + NW i).  At batch <= 8 the MFMA's batch columns 8..15 are
+//     padding, so the x operand of a pair is ONE request of all 64 lanes for 8 rows x 128 B (whole cache lines): lane (lj, lq) reads
+//     row lj & 7, floats 32 j + 16 (lj >> 3) + 4 lq .. + 4.  Lanes lj < 8 hold the even tile's B fragments in place, a DPP row rotation
+//     by 8 brings the odd tile's out of the padding columns.
+//   * Every request of a chunk is unconditional and issued back to back (rows >= M re-read row 0, absent residual / bias operands read
+//     x; the epilogue selects).  CH = 1 | 2: everything is requested at kernel entry; CH = 3 (K = 6144: 24 pairs per wave would need
+//     288 operand registers): two chunks at entry, the third into the first chunk's registers once that one is consumed.
+//   * The RMSNorm row sum of squares is taken from the x fragments the wave holds anyway (4 FMAs per pair and lane, reduced over the
+//     row's 8 lanes by DPP / bpermute and over the waves in fixed order at the combine): the 206 `row_ss_kernel` launches of an fp32
+//     frame step are gone.
+//   * Leading scalar arguments arrive preloaded in SGPRs as for skinny8_kernel.
+// Summation order: a wave accumulates its pairs in ascending k, 4 MFMAs per tile (e = 0..3: k = 4 lq + e); waves are combined in
+// ascending order.  This is not the order of skinny_f32_kernel (tiles dealt singly to the waves), so results differ in the last bits;
+// the fp32 goldens (greedy codes, all 16 codebooks) are the acceptance test, on the emulator and on the MI355X.
+__device__ inline f32x4 dpp_ror8_f(const f32x4& v) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    return r;
+}
+template <int SPW, int NP, int CH, bool NORM, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, const float* kx, const int* kdone, const float* kres, const float* kbias,
+                                                              int kldx, int kM, int kK, int kldr, SkinnyParams p) {
+    p.Wp = kWp; p.x = kx; p.done_flag = kdone; p.res = kres; p.bias = kbias; p.ldx = kldx; p.M = kM; p.K = kK; p.ldr = kldr;
+    static_assert(CH >= 1 && CH <= 3, "skinny8_f32: 1..3 chunks");
+    constexpr int NSET = CH < 2 ? CH : 2;                        // register sets
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem_sk);              // [NW][SPW][64]
+    float* ssl = reinterpret_cast<float*>(red + NW * SPW * 64);  // [NW][16]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int nkt = p.K >> 4;
+    const int strip0 = blockIdx.x * SPW;
+
+    // 16-B units; a tile is 64 units, a pair 128
+    const u32x4* wb[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s)
+        wb[s] = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)(strip0 + s) * nkt * 64 + lq * 16 + lj + (size_t)wave * 128;
+    const float* xb = p.x + (size_t)((lj & 7) < p.M ? (lj & 7) : 0) * p.ldx + (lj >> 3) * 16 + lq * 4 + wave * 32;
+
+    u32x4 wR[NSET][NP][SPW][2];
+    f32x4 xR[NSET][NP];
+    auto request = [&](int set, int c) {                          // chunk c = pairs wave + NW (c NP + i)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+#pragma unroll
+            for (int s = 0; s < SPW; ++s)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) wR[set][i][s][h] = skinny_wload(wb[s] + (size_t)(c * NP + i) * (NW * 128) + h * 64);
+            xR[set][i] = *reinterpret_cast<const f32x4*>(xb + (c * NP + i) * (NW * 32));
+        }
+    };
+    // ---- 1. the requests, back to back
+    request(0, 0);
+    if constexpr (CH >= 2) request(1, 1);
+    // epilogue operands (used by wave 0 only; requested by every wave so that no branch surrounds a load)
+    const int rowc = lj < p.M ? lj : 0;
+    f32x4 resv[SPW], biasv[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * 16) + lq * 4;
+        const float* bp = p.bias ? p.bias + (strip0 + s) * 16 + lq * 4 : p.x;
+        const float* rp = p.res ? p.res + (size_t)rowc * p.ldr + col : p.x;
+        biasv[s] = *reinterpret_cast<const f32x4*>(bp);
+        resv[s] = *reinterpret_cast<const f32x4*>(rp);
+    }
+    const int done = p.done_flag ? *p.done_flag : 0;
+    if (done) return;
+
+    // ---- 2. consume in request order
+    f32x4 acc[SPW];
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const f32x4 xe = xR[set][i];
+            const f32x4 xo = dpp_ror8_f(xR[set][i]);
+            if constexpr (NORM) {                                 // this lane's 4 values belong to row lj & 7 (even or odd tile of the pair)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss = fmaf(xe[e], xe[e], ss);
+            }
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                f32x4 we, wo;
+                *reinterpret_cast<u32x4*>(&we) = wR[set][i][s][0];
+                *reinterpret_cast<u32x4*>(&wo) = wR[set][i][s][1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(we[e], xe[e], acc[s], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[e], xo[e], acc[s], 0, 0, 0);
+            }
+        }
+    };
+    consume(0);
+    if constexpr (CH == 3) request(0, 2);
+    if constexpr (CH >= 2) consume(1);
+    if constexpr (CH == 3) consume(0);
+
+    // ---- 3. cross-wave combine (fixed order) and epilogue by wave 0: the kernel's only barrier
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) red[(wave * SPW + s) * 64 + lane] = acc[s];
+    if constexpr (NORM) {        // row lj & 7: lanes (lj & 7, lj & 7 | 8) x lq = 0..3 of this wave
+        float t = ss + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ss), 0x128, 0xf, 0xf, false));
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        if (lane < 16) ssl[wave * 16 + lane] = t;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    float rstd = 1.f;
+    if constexpr (NORM) {
+        float ssum = ssl[lj & 7];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) ssum += ssl[w2 * 16 + (lj & 7)];
+        rstd = rsqrtf(ssum / (float)p.K + p.eps);
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+        f32x4 t = red[(0 * SPW + s) * 64 + lane];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) t += red[(w2 * SPW + s) * 64 + lane];
+        v[s] = t * rstd + (p.bias ? biasv[s] : zero4);
+    }
+    if (lj < p.M) {
+        if (p.act == ACT_SWIGLU) {
+            if constexpr (SPW == 2) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (v[0][r] / (1.f + expf(-v[0][r]))) * v[1][r];
+                o += p.res ? resv[0] : zero4;
+                *reinterpret_cast<f32x4*>(p.out + (size_t)lj * p.ldo + blockIdx.x * 16 + lq * 4) = o;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < SPW; ++s)
+                *reinterpret_cast<f32x4*>(p.out + (size_t)lj * p.ldo + (strip0 + s) * 16 + lq * 4) = v[s] + (p.res ? resv[s] : zero4);
+        }
+    }
+}
+
 // bf16 mode: a GEMM input may arrive as the producer's bf16 copy (x_bf16) for any M <= 64 -- nothing is staged through LDS any
 // more, so there is no capacity condition left (round 1: M <= 16 up to K = 7096, M <= 32 up to K = 2344).
 bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <= 64 && K % 32 == 0; }
@@ -631,9 +795,9 @@ static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
     // Round 3: the same for batch 17..32 (two 16-row tiles; chunks of 4 / SPW k-tiles, so K <= 3072 at 8 waves: every code-predictor
     // GEMM and the talker's q|k|v, o and gate|up).  In the generic loop the waves of a launch drift apart by a memory round trip per
     // chunk pair -- in-kernel timestamps at batch 32: 1.0-2.4 us between the first wave's last MFMA and the barrier
-    // (profiles/r03_skinny_b32_straight.md).  QTTS_SKINNY2_STRAIGHT_MT2=0 keeps the loop (A/B; read per launch).
+    // (profiles/r03_skinny_b32_straight.md).  QTTS_SKINNY2_STRAIGHT_MT2=0 keeps the loop (A/B; QTTS_ENV).
     if constexpr (EXACT && MT == 2 && XB16 && NW == 8) {
-        const char* e = getenv("QTTS_SKINNY2_STRAIGHT_MT2");
+        const char* e = QTTS_ENV("QTTS_SKINNY2_STRAIGHT_MT2");
         if (!(e && e[0] == '0')) {
             if (nchunks == 1) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 1>(p, st); return; }
             if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2>(p, st); return; }
@@ -690,7 +854,7 @@ static int skinny_spw(int N, int fs, bool swiglu) {
 }
 
 // batch <= 8, bf16 x, K a multiple of 512 (whole tile pairs for 8 waves): the frame step's kernel.  QTTS_SKINNY8=0 falls back to
-// skinny2_kernel (A/B; read per launch so that one process can compare both).
+// skinny2_kernel (A/B; QTTS_ENV: one process can compare both under QTTS_DEBUG_ENV_LIVE=1).
 template <int SPW, int FS, int NP, int NW = 8>
 static void launch8_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
@@ -700,7 +864,7 @@ static void launch8_n(const SkinnyParams& p, hipStream_t st) {
 }
 // waves per workgroup: fewer waves = fewer partial sums to combine and a shorter barrier, more tile pairs (registers) per wave.
 // Default 4 for matrices below 16 MB (in-process A/B, GPU call 14: 2.854 vs 2.884 ms per frame with 8, both repetitions), 8 above;
-// QTTS_SKINNY8_NW = 8 | 4 | 2 | 1 asks for another count where that instantiation exists (A/B; read per launch).
+// QTTS_SKINNY8_NW = 8 | 4 | 2 | 1 asks for another count where that instantiation exists (A/B; QTTS_ENV).
 template <int SPW, int FS, int NW>
 static bool launch8_nw(const SkinnyParams& p, hipStream_t st) {
     constexpr int REGS_PER_PAIR = (FS == 16 ? 8 : 4) * SPW + 4;          // operand VGPRs per tile pair
@@ -719,7 +883,7 @@ static bool launch8_nw(const SkinnyParams& p, hipStream_t st) {
 }
 template <int SPW, int FS>
 static bool launch8_fs(const SkinnyParams& p, hipStream_t st) {
-    const char* e = getenv("QTTS_SKINNY8_NW");
+    const char* e = QTTS_ENV("QTTS_SKINNY8_NW");
     // (matrices of 16 MB and more -- the talker's qkv, gate/up and down projections -- are bound by the stream itself and keep 8
     // waves: in-kernel timestamps of GPU call 18, 8 vs 4 waves: 3.83 vs 4.15, 8.5 vs 9.4, 5.95 vs 6.6 us)
     const int dflt = (size_t)p.N * p.K * 2 >= ((size_t)16 << 20) ? 8 : 4;
@@ -730,12 +894,70 @@ static bool launch8_fs(const SkinnyParams& p, hipStream_t st) {
     return launch8_nw<SPW, FS, 8>(p, st);
 }
 static bool launch_skinny8(const SkinnyParams& p, int spw, int fs, hipStream_t st) {
-    const char* e = getenv("QTTS_SKINNY8");
+    const char* e = QTTS_ENV("QTTS_SKINNY8");
     if (e && e[0] == '0') return false;
-    if (!p.x_bf16 || p.M > 8 || p.K % 512 != 0 || p.ablate) return false;
+    if (!p.x_bf16 || p.M > 8 || p.K % 512 != 0 || QTTS_ABL(p, 15)) return false;
     if (fs == 16) return spw == 2 ? launch8_fs<2, 16>(p, st) : launch8_fs<1, 16>(p, st);
     if (fs == 8 && spw == 1) return launch8_fs<1, 8>(p, st);
     return false;
+}
+
+// fp32, batch <= 8 (skinny8_f32_kernel).  QTTS_SKINNY8F=0 keeps skinny_f32_kernel + row_ss_kernel (A/B; read once: the engine decides
+// with the same function whether a normalised GEMM needs the row sums of squares from a launch of its own).
+static bool skinny8f_enabled() {
+    static const bool on = [] { const char* e = getenv("QTTS_SKINNY8F"); return !(e && e[0] == '0'); }();
+    return on;
+}
+template <int SPW, int NP, int CH, int NW>
+static void launch8f_n(const SkinnyParams& p, hipStream_t st) {
+    const int grid = p.N / (16 * SPW);
+    const size_t lds = (size_t)NW * SPW * 64 * 16 + (size_t)NW * 16 * 4;
+    if (p.norm) QTTS_SK_LAUNCH((skinny8_f32_kernel<SPW, NP, CH, true, NW>), dim3(grid), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
+    else QTTS_SK_LAUNCH((skinny8_f32_kernel<SPW, NP, CH, false, NW>), dim3(grid), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
+}
+// waves per workgroup and chunks by K (pairs = K / 32): operand registers per pair = 8 SPW + 4, at most ~200 per register set pair.
+//   K    pairs   SPW = 1                     SPW = 2 (SwiGLU)
+//   1024   32    8 waves x 4                 8 waves x 4
+//   2048   64    16 waves x 4                16 waves x 4
+//   3072   96    8 waves x 12                8 waves x 3 chunks of 4
+//   6144  192    8 waves x 3 chunks of 8     --
+// (16 waves x 6 pairs was tried for K = 3072 / 6144: a 1024-thread workgroup caps a wave at 128 registers and the kernel spilled)
+template <int SPW>
+static bool launch8f_spw(const SkinnyParams& p, hipStream_t st) {
+#ifdef QTTS_HOST_EMU
+    const int nw_env = [] { const char* e = getenv("QTTS_SKINNY8F_NW"); return e ? atoi(e) : 0; }();      // (the emulator test walks the instantiations)
+#else
+    static const int nw_env = [] { const char* e = getenv("QTTS_SKINNY8F_NW"); return e ? atoi(e) : 0; }();
+#endif
+    // QTTS_SKINNY8F_NW = 4 | 8 | 16 asks for another wave count where that instantiation exists (A/B)
+    switch (p.K) {
+        case 1024:
+            if (nw_env == 4) launch8f_n<SPW, 8, 1, 4>(p, st);
+            else if (nw_env == 16) launch8f_n<SPW, 2, 1, 16>(p, st);
+            else launch8f_n<SPW, 4, 1, 8>(p, st);
+            return true;
+        case 2048:          // 16 waves x 4 pairs: 4.53 vs 4.71 ms per fp32 frame with 8 x 8 (GPU call 2 of round 4)
+            if (nw_env == 8) launch8f_n<SPW, 8, 1, 8>(p, st); else launch8f_n<SPW, 4, 1, 16>(p, st);
+            return true;
+        case 3072:
+            if constexpr (SPW == 1) { if (nw_env == 16) launch8f_n<1, 6, 1, 16>(p, st); else launch8f_n<1, 12, 1, 8>(p, st); }
+            else launch8f_n<2, 4, 3, 8>(p, st);
+            return true;
+        case 6144:
+            if constexpr (SPW == 1) { launch8f_n<1, 8, 3, 8>(p, st); return true; }
+            return false;
+        default: return false;
+    }
+}
+// the K for which skinny8_f32_kernel is instantiated: a normalised fp32 GEMM with M <= 8 and such a K needs no ss_in
+bool skinny_f32_inline_norm(int M, int K) {
+    return skinny8f_enabled() && M >= 1 && M <= 8 && (K == 1024 || K == 2048 || K == 3072);
+}
+static bool launch_skinny8_f32(const SkinnyParams& p, int spw, hipStream_t st) {
+    if (!skinny8f_enabled() || p.M > 8 || p.x_bf16 || p.out_bf16 || p.out16) return false;
+    if (spw == 2 && p.K == 6144) return false;
+    if (!(p.K == 1024 || p.K == 2048 || p.K == 3072 || p.K == 6144)) return false;
+    return spw == 2 ? launch8f_spw<2>(p, st) : launch8f_spw<1>(p, st);
 }
 
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
@@ -746,15 +968,19 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(p.N % 16 == 0, QTTS_ERR_ARG, "skinny: N % 16");
     QTTS_REQUIRE(p.K % KT == 0, QTTS_ERR_ARG, "skinny: K must be a multiple of the k-tile");
     QTTS_REQUIRE(p.M >= 1 && p.M <= 64, QTTS_ERR_LIMIT, "skinny: 1 <= M <= 64");
+#if !QTTS_ABLATE
+    QTTS_REQUIRE(p.ablate == 0, QTTS_ERR_ARG, "skinny: perf-ablation flags need the `ablate` build variant (python qwen3-tts_amd/build.py --variant ablate)");
+#endif
     QTTS_REQUIRE(p.ldx % 4 == 0 && p.ldo % 4 == 0, QTTS_ERR_ARG, "skinny: ldx/ldo % 4");
     QTTS_REQUIRE(!p.x_bf16 || (bf16 && p.ldx % 8 == 0), QTTS_ERR_ARG, "skinny: bf16 x needs the bf16 kernel and ldx % 8");
     QTTS_REQUIRE(!p.out_bf16 || bf16, QTTS_ERR_ARG, "skinny: bf16 output only in bf16 mode");
-    QTTS_REQUIRE(bf16 || !p.norm || p.ss_in, QTTS_ERR_ARG, "skinny: the fp32 kernel takes the row sums of squares from ss_in");
+    QTTS_REQUIRE(bf16 || !p.norm || p.ss_in || skinny_f32_inline_norm(p.M, p.K), QTTS_ERR_ARG,
+                 "skinny: the generic fp32 kernel takes the row sums of squares from ss_in");
     if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.N % 32 == 0 && fs == 16, QTTS_ERR_ARG, "skinny: swiglu needs N % 32 and fs == 16");
     if (p.act == ACT_SWIGLU8) {          // one 16-feature strip = 8 gate + 8 up rows: only the batch <= 8 kernel has this epilogue
-        QTTS_REQUIRE(bf16 && fs == 16 && p.x_bf16 && p.M <= 8 && p.K % 512 == 0 && !p.bias && !p.ablate, QTTS_ERR_ARG,
+        QTTS_REQUIRE(bf16 && fs == 16 && p.x_bf16 && p.M <= 8 && p.K % 512 == 0 && !p.bias && !QTTS_ABL(p, 15), QTTS_ERR_ARG,
                      "skinny: ACT_SWIGLU8 needs the bf16 batch <= 8 kernel (bf16 x, K % 512 == 0, 16-feature strips, no bias)");
-        const char* e8 = getenv("QTTS_SKINNY8");
+        const char* e8 = QTTS_ENV("QTTS_SKINNY8");
         QTTS_REQUIRE(!(e8 && e8[0] == '0'), QTTS_ERR_ARG, "skinny: ACT_SWIGLU8 with QTTS_SKINNY8=0");
         if (launch8_fs<1, 16>(p, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
         throw Error(QTTS_ERR_ARG, "skinny: no batch <= 8 instantiation for this K");
@@ -763,10 +989,12 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16 && nw == 8 && mt == 1 && launch_skinny8(p, spw, fs, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
+    if (!bf16 && !QTTS_ABL(p, 15) && launch_skinny8_f32(p, spw, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
     if (bf16) {
         if (nw == 8) { if (mt == 1) launch2_mt<1, 8>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 8>(p, spw, fs, st); else launch2_mt<4, 8>(p, spw, fs, st); }
         else         { if (mt == 1) launch2_mt<1, 4>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 4>(p, spw, fs, st); else launch2_mt<4, 4>(p, spw, fs, st); }
     } else {
+        QTTS_REQUIRE(!p.norm || p.ss_in, QTTS_ERR_ARG, "skinny: the generic fp32 kernel takes the row sums of squares from ss_in");
         if (mt == 1) launch_f32_mt<1>(p, spw, nw, st);
         else if (mt == 2) launch_f32_mt<2>(p, spw, nw, st);
         else launch_f32_mt<4>(p, spw, nw, st);

@@ -248,7 +248,7 @@ struct qtts_talker {
         ++skinny_count;
     }
     int64_t skinny_count = 0;
-    static bool skinny_ablate_or_off() { const char* e = getenv("QTTS_SKINNY8"); return e && e[0] == '0'; }   // (A/B switch of skinny.hip, read per launch)
+    static bool skinny_ablate_or_off() { const char* e = QTTS_ENV("QTTS_SKINNY8"); return e && e[0] == '0'; }   // (A/B switch of skinny.hip; read once unless QTTS_DEBUG_ENV_LIVE)
 
     // x-side handling of a GEMM whose input is RMS-normalised: the bf16 kernel takes the row variances on the matrix pipe
     // (skinny.hip) from the producer's bf16 copy of x; the fp32 parity kernel gets the row sums of squares from one extra
@@ -258,6 +258,7 @@ struct qtts_talker {
         if (bf16) {
             if (x16v) { p.x = reinterpret_cast<const float*>(x16v); p.x_bf16 = 1; }
         } else {
+            if (skinny_f32_inline_norm(p.M, p.K)) return;        // round 4: the batch <= 8 fp32 kernel sums x^2 from its own fragments
             if (!skinny_only) launch_row_ss(p.x, p.ldx, p.M, p.K, ssbuf(), ss.done, st);
             p.ss_in = ssbuf();
         }

@@ -8,6 +8,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the library copies its A/B environment switches once (csrc/common.h QTTS_ENV); tests flip them with monkeypatch inside one process
+os.environ.setdefault("QTTS_DEBUG_ENV_LIVE", "1")
 
 
 def pytest_configure(config):

@@ -85,7 +85,8 @@ extern "C" int hostemu_skinny(const float* x, int ldx, int M, const float* W, in
         std::vector<float> ss(M, 0.f);
         for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) ss[m] += x[(size_t)m * ldx + k] * x[(size_t)m * ldx + k];
         qtts::SkinnyParams p{};
-        p.x = x; p.ldx = ldx; p.M = M; p.Wp = wp.data(); p.N = N; p.K = K; p.fs = 16; p.norm = norm; p.ss_in = ss.data(); p.eps = eps;
+        p.x = x; p.ldx = ldx; p.M = M; p.Wp = wp.data(); p.N = N; p.K = K; p.fs = 16; p.norm = norm; p.eps = eps;
+        p.ss_in = (!bf16 && qtts::skinny_f32_inline_norm(M, K)) ? nullptr : ss.data();     // (the batch <= 8 fp32 kernel must not need it)
         p.bias = bias; p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.act = act;
         qtts::launch_skinny(p, bf16 != 0, nullptr);
         return 0;

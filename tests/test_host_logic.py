@@ -729,7 +729,7 @@ def test_no_kernel_spills_or_scratch(libqtts):
     assert int(re.search(r"^(\d+) kernels;", out.stdout, re.M).group(1)) >= 60
 
 
-def test_build_variants_are_opt_in_only():
+def test_build_variants_are_opt_in_only(libqtts):
     """The product library is the flag-free build: variants (A/B material) get their own file names, carry at least one
     -DQTTS_ flag each, and nothing in the default flag set or in __graft_entry__.build() selects one."""
     import importlib.util
@@ -748,6 +748,11 @@ def test_build_variants_are_opt_in_only():
     from qwen3_tts_amd import _lib
     if "QTTS_LIBRARY" not in os.environ:
         assert os.path.basename(_lib.library_path()) == "libqtts.so"
+    # measuring code stays out of the product library: the hand-off probe's entry point is exported by its own variant only
+    import ctypes
+    prod = ctypes.CDLL(libqtts) if isinstance(libqtts, str) else None
+    assert prod is None or not hasattr(prod, "qtts_debug_persist_layer")
+    assert "persist_probe.hip" not in m.SOURCES and "persist_probe.hip" in m.VARIANT_SOURCES["probe"]
     # every -D name used by a variant is defaulted to 0 in the sources, so the default build never sees it set
     csrc = os.path.join(ROOT, "qwen3-tts_amd", "csrc")
     text = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc))

@@ -399,6 +399,46 @@ def test_skinny_kernel_real_source(emu, bf16):
         assert np.all(out[:, No:] == 7.0)
 
 
+def test_skinny_f32_batch8_kernel_real_source(emu, monkeypatch):
+    """skinny8_f32_kernel (round 4: the parity mode's frame-step GEMM at batch <= 8 -- tile pairs, whole-line x requests, DPP-rotated
+    odd tiles, in-kernel RMSNorm statistics, three-chunk K = 6144) in every instantiation, against float64 numpy; no ss_in is
+    handed over for the normalised cases (tests/hostemu/test_entries.cpp)."""
+    g = np.random.default_rng(58)
+    cases = [(8, 32, 1024, 1, ACT_NONE, 0, 1, 0), (1, 32, 1024, 1, ACT_SWIGLU, 0, 1, 4), (3, 64, 2048, 1, ACT_SWIGLU, 0, 0, 0),
+             (7, 16, 2048, 1, ACT_NONE, 1, 0, 8), (8, 16, 3072, 0, ACT_NONE, 1, 1, 0), (2, 32, 3072, 1, ACT_SWIGLU, 0, 0, 0),
+             (6, 16, 3072, 1, ACT_NONE, 0, 1, 16), (5, 16, 6144, 0, ACT_NONE, 0, 1, 0), (8, 16, 6144, 1, ACT_NONE, 0, 0, 0),
+             (4, 32, 2048, 0, ACT_SWIGLU, 0, 1, 8), (8, 16, 1024, 1, ACT_NONE, 0, 0, 4), (5, 32, 1024, 1, ACT_SWIGLU, 0, 0, 16),
+             (8, 16, 2048, 1, ACT_NONE, 0, 1, 0)]
+    for (M, N, K, norm, act, hb, hr, nw) in cases:
+        if nw:
+            monkeypatch.setenv("QTTS_SKINNY8F_NW", str(nw))
+        else:
+            monkeypatch.delenv("QTTS_SKINNY8F_NW", raising=False)
+        x = g.standard_normal((M, K + 4)).astype(np.float32)
+        W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        gw = (1 + 0.1 * g.standard_normal(K)).astype(np.float32) if norm else None
+        bias = g.standard_normal(N).astype(np.float32) if hb else None
+        No = N // 2 if act == ACT_SWIGLU else N
+        res = g.standard_normal((M, No)).astype(np.float32) if hr else None
+        acc = x[:, :K].astype(np.float64) @ (W * gw if norm else W).astype(np.float64).T
+        if norm:
+            acc *= 1 / np.sqrt((x[:, :K].astype(np.float64) ** 2).mean(1, keepdims=True) + 1e-6)
+        if hb:
+            acc += bias
+        if act == ACT_SWIGLU:
+            a = acc.reshape(M, N // 32, 2, 16)
+            acc = ((a[:, :, 0] / (1 + np.exp(-a[:, :, 0]))) * a[:, :, 1]).reshape(M, No)
+        if hr:
+            acc = acc + res
+        out = np.full((M + 1, No + 4), 7.0, np.float32)
+        rc = emu.hostemu_skinny(_ptr(x), K + 4, M, _ptr(W), N, K, _ptr(gw) if norm else None, norm, 1e-6, _ptr(bias) if hb else None,
+                                _ptr(res) if hr else None, No, act, _ptr(out), No + 4, 0)
+        assert rc == 0, ((M, N, K), (emu.qtts_last_error() or b"").decode())
+        err = float(np.abs(out[:M, :No] - acc).max())
+        assert err <= 2e-5 * max(1.0, float(np.abs(acc).max())), (M, N, K, norm, act, nw, err)
+        assert np.all(out[:M, No:] == 7.0) and np.all(out[M] == 7.0)
+
+
 def test_skinny_bf16_kernel_frame_step_shapes(emu):
     """skinny2_kernel the way the frame step launches it: x as the producer's bf16 copy, the real models' K (every wave owns the
     same number of k-tiles: the branch-free EXACT instantiations, one / two / three chunks), narrow strips (4 / 8 / 16

@@ -5,6 +5,8 @@ effects being measured): for each repetition, for each configuration: set the en
 
     python tools/ab_inproc.py --frames 40 --reps 3
 """
+import os as _os
+_os.environ.setdefault("QTTS_DEBUG_ENV_LIVE", "1")   # the library copies its A/B switches once unless told otherwise (csrc/common.h QTTS_ENV)
 import argparse, gc, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -3,6 +3,9 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from qwen3_tts_amd import _lib
+# the ablation branches exist only in the `ablate` build variant (python qwen3-tts_amd/build.py --variant ablate)
+import os as _os
+_os.environ.setdefault("QTTS_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "qwen3-tts_amd", "libqtts_ablate.so"))
 lib = _lib.load_library()
 torch.zeros(1).cuda()
 f = lib.qtts_debug_skinny_chain

@@ -15,6 +15,7 @@ ap.add_argument("--batch", type=int, default=8); ap.add_argument("--codec", acti
 ap.add_argument("--talker", action="store_true"); ap.add_argument("--prof", action="store_true")
 ap.add_argument("--no-graph", action="store_true"); ap.add_argument("--codec-dtype", default="bf16")
 ap.add_argument("--codec-frames", type=int, default=125); ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--talker-dtype", default="bf16", choices=["bf16", "f32"], help="f32 = the exact-fp32 parity mode")
 a = ap.parse_args()
 if not (a.codec or a.talker): a.talker = True
 
@@ -36,7 +37,7 @@ if a.talker:
     t = {"1.7b": synth.talker_17b, "0.6b": synth.talker_06b}[a.model]()
     t0 = time.time()
     w = cheap(synth.talker_param_shapes(t, with_text=False), lambda k, s: 0.08 if ("head" in k) else 0.02)
-    eng = TalkerEngine(t, w, weight_dtype=torch.bfloat16, max_batch=B, max_seq=64 + F + 8, use_graph=not a.no_graph)
+    eng = TalkerEngine(t, w, weight_dtype=torch.bfloat16 if a.talker_dtype == "bf16" else torch.float32, max_batch=B, max_seq=64 + F + 8, use_graph=not a.no_graph)
     del w
     print(f"talker build {time.time() - t0:.1f}s", flush=True)
     lens = [24 + 4 * (i % 8) + 12 for i in range(B)]

@@ -5,6 +5,9 @@ for both sides, for 1, 2 and 5 layers (4, 8, 20 stages), and how far the two sid
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
+# the probe lives in its own build variant (python qwen3-tts_amd/build.py --variant probe), not in the product library
+os.environ.setdefault("QTTS_LIBRARY", os.path.join(ROOT, "qwen3-tts_amd", "libqtts_probe.so"))
+os.environ.setdefault("QTTS_LIBRARY_OK", "1")
 from qwen3_tts_amd import _lib
 lib = _lib.load_library()
 torch.zeros(1).cuda()
