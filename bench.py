@@ -78,7 +78,8 @@ def main(argv=None, device=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="1.7b", choices=["1.7b", "0.6b", "tiny"])
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=None, help="requests per engine batch: 8 for the metric workload, 32 (waves) for clone-shard")
+    ap.add_argument("--engines", type=int, default=None, help="clone-shard: engine pairs per GPU running waves concurrently (default 2)")
     ap.add_argument("--frames", type=int, default=125, help="codec frames per utterance (125 = 10 s)")
     ap.add_argument("--greedy", action="store_true", help="greedy decode instead of the default sampling")
     ap.add_argument("--codec-dtype", default="bf16", choices=["bf16", "f32"])
@@ -96,6 +97,8 @@ def main(argv=None, device=None):
                     help="torch.distributed backend of the N > 1 job (nccl = RCCL; gloo only for the CPU launcher test)")
     ap.add_argument("--no-parity-mode", action="store_true",
                     help="skip the fp32 parity-mode timing leg (fp32 talker frame step + fp32 codec decode, N = 1 only)")
+    ap.add_argument("--no-api-e2e", action="store_true",
+                    help="skip the api_e2e leg (Qwen3TTSModel.generate_custom_voice: text -> host numpy, N = 1 only)")
     ap.add_argument("--workload", default="metric", choices=["metric", "clone-shard"],
                     help="metric = BASELINE.json's metric config (weak scaling: one batch per GPU); clone-shard = BASELINE "
                          "config 5, a FIXED job of --requests voice-clone requests dealt to the ranks (strong scaling)")
@@ -103,6 +106,10 @@ def main(argv=None, device=None):
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.batch is None:
+        args.batch = 32 if args.workload == "clone-shard" else 8
+    if args.engines is None:
+        args.engines = 2 if args.workload == "clone-shard" else 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else argv, args.backend))
     hostemu = device is not None
@@ -301,6 +308,11 @@ def main(argv=None, device=None):
         if not args.no_parity_mode and world == 1 and not hostemu:
             res["parity_mode"] = parity_mode_leg(args, tcfg, ccfg, tw_np, cw_np, lens, dev, emb, mask, trailing, pad, gen_kw, None)
             log("parity-mode leg done")
+        if not args.no_api_e2e and world == 1:
+            del talker, codec                 # (the leg builds its own engines behind the API; free the bench's first)
+            torch.cuda.empty_cache()
+            res["api_e2e"] = api_e2e_leg(args, tcfg, ccfg, cw_np, dev, res["ms_per_step"])
+            log("api_e2e leg done")
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(tcfg, ccfg, tw_np, cw_np, lens, args.cpu_frames, args.cpu_budget_s)
             log("cpu baseline done")
@@ -318,66 +330,95 @@ def main(argv=None, device=None):
 
 def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
     """BASELINE config 5 under the bench launcher, STRONG scaling: a fixed job of `--requests` voice-clone (ICL-shaped: 38
-    reference frames + 16 ref-text rows in the prompt) requests of different lengths, dealt to the N ranks longest-first
-    (`sharding.lpt_partition`, every rank computes the same partition), run in waves of `--batch`, every rank's variable-length
-    waveforms gathered on rank 0 (`sharding.gather_waveforms`: the shard's one exchange).  A step = the whole job; the timed
-    region is bracketed by barriers and the maximum over ranks is reported, as for the metric workload."""
+    reference frames + 16 ref-text rows in the prompt) requests of different lengths, dealt longest-first to the (rank, engine)
+    bins (`sharding.engine_partition`, every rank computes the same partition), each engine running waves of `--batch` requests of
+    similar length, every rank's variable-length waveforms gathered on rank 0 (`sharding.gather_waveforms_device`: the shard's one
+    exchange, device to device).  A step = the whole job; the timed region is bracketed by barriers and the maximum over ranks is
+    reported, as for the metric workload.
+
+    Round 4 defaults (VERDICT r3 item 4 -- the configuration a scaling run should measure): waves of 32 (a batch-32 frame step is
+    4.4 ms against 2.7 ms at batch 8: 2.4x the tokens per second) and TWO engines per GPU, each with its own weights, HIP stream
+    and host thread (a frame step leaves most CUs idle: +47 % measured in round 3)."""
+    import threading
     import numpy as np
     import torch
     import synth
     from qwen3_tts_amd import sharding
     from qwen3_tts_amd.codec import CodecDecoderEngine
     from qwen3_tts_amd.talker import TalkerEngine
-    NREQ, B, REF = args.requests, args.batch, 38
+    hostemu = not str(dev).startswith("cuda")
+    NREQ, B, REF, E = args.requests, args.batch, 38, max(1, args.engines)
     rq = np.random.default_rng(5)
     text = rq.integers(16, 72, NREQ).tolist()                                   # text tokens per request
     frames = [max(2, int(round(t * args.frames / 57.0))) for t in text]         # synthetic length model: ~2.2 frames per text token at --frames 125
-    parts = sharding.lpt_partition(text, world)
-    my_waves = sharding.waves(sorted(parts[rank], key=lambda i: -text[i]), B)   # similar lengths share a wave
+    parts = sharding.engine_partition(text, world, E)                           # parts[rank][engine] -> request indices
+    my_waves = [sharding.waves(sorted(p, key=lambda i: -text[i]), B) for p in parts[rank]]   # similar lengths share a wave
     Fmax = max(frames)
     td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
     tdt = torch.bfloat16 if args.talker_dtype == "bf16" else torch.float32
     cdt = torch.bfloat16 if args.codec_dtype == "bf16" else torch.float32
-    talker = TalkerEngine(tcfg, td(synth.talker_weights(tcfg, with_text=False)), weight_dtype=tdt, device=dev, max_batch=B,
-                          max_seq=12 + REF + 16 + 8 + Fmax + 8, use_graph=not args.no_graph)
-    codec = CodecDecoderEngine(ccfg, td(synth.codec_weights(ccfg)), compute_dtype=cdt, device=dev, max_batch=B,
-                               max_frames=min(Fmax, 300) + 25)
+    tw, cw = td(synth.talker_weights(tcfg, with_text=False)), td(synth.codec_weights(ccfg))
+    talkers = [TalkerEngine(tcfg, tw, weight_dtype=tdt, device=dev, max_batch=B, max_seq=12 + REF + 16 + 8 + Fmax + 8,
+                            use_graph=not args.no_graph) for _ in range(E)]
+    codecs = [CodecDecoderEngine(ccfg, cw, compute_dtype=cdt, device=dev, max_batch=B, max_frames=min(Fmax, 300) + 25) for _ in range(E)]
+    del tw, cw
     sup = [i for i in range(tcfg.vocab_size - 1024, tcfg.vocab_size) if i != tcfg.codec_eos_token_id]
     base = dict(suppress_tokens=sup, repetition_penalty=1.05, output_hidden_states=False, do_sample=True, top_k=50, top_p=1.0,
                 temperature=0.9, subtalker_dosample=True, subtalker_top_k=50, subtalker_top_p=1.0, subtalker_temperature=0.9)
 
-    def run_wave(w, seed):
+    def run_wave(w, seed, e):
         lens = [12 + REF + 16 + (text[i] % 7) for i in w]        # role + codec prefix + [ref text + text] over [ref codes]
         g = np.random.default_rng(1000 + w[0])
         emb, mask, trailing, pad = [x.to(dev) for x in synth.rand_prompt(g, tcfg, lens, max(text[i] for i in w), 0.05)]
         F = max(frames[i] for i in w)
-        out = talker.generate(emb, mask, trailing, pad, seed=seed, max_new_tokens=F + 1, min_new_tokens=F + 1, **base)
+        out = talkers[e].generate(emb, mask, trailing, pad, seed=seed, max_new_tokens=F + 1, min_new_tokens=F + 1, **base)
         codes = out.codes.clone()
         for j, i in enumerate(w):                                # each request keeps its own length (rest = -1 padding)
             codes[j, frames[i]:] = -1
-        wav, wl = codec.decode_padded(codes)
+        wav, wl = codecs[e].decode_padded(codes)
         return [wav[j, :int(wl[j])] for j in range(len(w))]
 
+    def engine_loop(e, seed0, results, errors):
+        try:
+            torch.cuda.set_device(torch.device(dev))
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):       # per-thread current stream: copies and the codec stay off the
+                for k, w in enumerate(my_waves[e]):                      # shared default stream
+                    results[e].append(run_wave(w, seed0 + 64 * e + k, e))
+                torch.cuda.current_stream().synchronize()
+        except Exception as ex:                                          # surface worker failures on the main thread
+            errors.append(ex)
+
     def job(seed0):
+        results, errors = [[] for _ in range(E)], []
+        if E == 1 or hostemu:                                            # (the emulator's SIMT state is process-global: its engines take turns)
+            for e in range(E):
+                engine_loop(e, seed0, results, errors)
+        else:                                                            # ctypes releases the GIL inside the C calls
+            th = [threading.Thread(target=engine_loop, args=(e, seed0, results, errors)) for e in range(E)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        if errors:
+            raise errors[0]
         wavs, idx = [], []
-        for k, w in enumerate(my_waves):
-            for i, x in zip(w, run_wave(w, seed0 + k)):
-                idx.append(i)
-                wavs.append(x)
+        for e in range(E):
+            for w, r in zip(my_waves[e], results[e]):
+                idx += list(w)
+                wavs += r
         torch.cuda.synchronize()
         tg = time.perf_counter()
         if dist is not None:
-            allw = sharding.gather_waveforms([x.cpu().numpy() for x in wavs], idx, NREQ,
-                                             device=torch.device(dev) if args.backend == "nccl" else torch.device("cpu"))
+            allw = sharding.gather_waveforms_device(wavs, idx, NREQ)     # device -> device (nccl = RCCL); no host round trip
         else:
             allw = [None] * NREQ
             for i, x in zip(idx, wavs):
-                allw[i] = x.cpu().numpy()
+                allw[i] = x
+        torch.cuda.synchronize()
         return allw, time.perf_counter() - tg
 
-    for i in range(max(1, args.warmup)):                         # (at least one warm-up: graph capture per wave shape)
-        if my_waves:
-            run_wave(my_waves[0], 1 + i)
+    for i in range(max(1, args.warmup)):                         # (at least one warm-up: graph capture per wave shape, on every engine)
+        for e in range(E):
+            if my_waves[e]:
+                run_wave(my_waves[e][0], 1 + i, e)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -393,9 +434,10 @@ def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     per_rank = None
+    n_mine = sum(len(p) for p in parts[rank])
     if dist is not None:
         gdev = dev if args.backend == "nccl" else "cpu"
-        mine = torch.tensor([float(rank), elapsed, t_gather, float(len(parts[rank]))], dtype=torch.float64, device=gdev)
+        mine = torch.tensor([float(rank), elapsed, t_gather, float(n_mine)], dtype=torch.float64, device=gdev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = sorted([float(x) for x in r.cpu()] for r in allr)
@@ -403,22 +445,26 @@ def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
     if rank != 0:
         return None
     assert all(allw[i] is not None and allw[i].shape[0] == frames[i] * ccfg.total_upsample for i in range(NREQ))
+    assert all(bool(torch.isfinite(allw[i]).all()) for i in range(0, NREQ, max(1, NREQ // 16)))
     G = tcfg.num_code_groups
     tok = sum(frames) * G * args.steps
     audio_s = sum(frames) * ccfg.total_upsample / 24000.0 * args.steps
+    all_waves = [w for pr in parts for pe in pr for w in sharding.waves(sorted(pe, key=lambda i: -text[i]), B)]
+    load = [sum(text[i] for i in pe) for pr in parts for pe in pr]
     res = {"metric": "speech-tokens/sec (+ audio RTF), Qwen3-TTS-12Hz-1.7B Base voice-clone job sharded over the GPUs (BASELINE config 5)",
            "value": round(tok / elapsed, 1), "unit": "speech-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": args.talker_dtype, "data": "synthetic",
            "config": {"workload": f"clone-shard: {NREQ} voice-clone requests (ICL-shaped prompts: 38 reference frames + 16 ref-text rows, "
                                   f"16..71 text tokens, {min(frames)}..{max(frames)} frames each), Qwen3-TTS-12Hz-{args.model} dims, seeded random "
-                                  f"weights, waves of {B}, LPT partition over the ranks, waveforms gathered on rank 0",
-                      "requests": NREQ, "wave_batch": B, "parallelism": f"request-shard x{world}"},
+                                  f"weights, {E} engine(s) per GPU, waves of {B}, LPT partition over (rank, engine), waveforms gathered on rank 0 (device)",
+                      "requests": NREQ, "wave_batch": B, "engines_per_gpu": E, "parallelism": f"request-shard x{world} x {E} engines"},
+           "wave_batch": B, "engines_per_gpu": E,
            "rtf_x": round(audio_s / elapsed, 2), "gather_ms_per_step": round(1e3 * t_gather / args.steps, 3),
-           "requests_by_rank": [len(p) for p in parts],
-           "rank_load_imbalance": round(max(sum(text[i] for i in p) for p in parts) / (sum(text) / world), 3),
-           "padding_waste": round(1.0 - sum(frames) / sum(max(frames[i] for i in w) * len(w) for p in parts
-                                                        for w in sharding.waves(sorted(p, key=lambda i: -text[i]), B)), 3)}
+           "requests_by_rank": [sum(len(pe) for pe in pr) for pr in parts],
+           "rank_load_imbalance": round(max(sum(text[i] for pe in pr for i in pe) for pr in parts) / (sum(text) / world), 3),
+           "engine_load_imbalance": round(max(load) / (sum(text) / (world * E)), 3),
+           "padding_waste": round(1.0 - sum(frames) / sum(max(frames[i] for i in w) * len(w) for w in all_waves), 3)}
     if per_rank is not None:
         res["backend"] = args.backend
         res["ranks_seen"] = [int(r[0]) for r in per_rank]
@@ -528,6 +574,108 @@ def parity_mode_leg(args, tcfg, ccfg, tw_np, cw_np, lens, dev, emb, mask, traili
             "step_ms": round(1e3 * (tc - ta), 2), "speech_tokens_per_s": round(B * F * tcfg.num_code_groups / (tc - ta), 1),
             "what": "exact-fp32 talker (v_mfma_f32_16x16x4_f32 chain, bit-exact greedy codes vs the reference goldens) + fp32 codec "
                     "(waveform RMS 7.4e-6 vs the reference at real dims): the mode the parity bar is proven in, same workload, 1 step"}
+
+
+class _BenchProcessor:
+    """Deterministic stand-in for the HF text tokenizer (no Qwen vocabulary offline): one id per 4 characters of the body, the chat
+    template's special strings mapped to the ids the model config names (as the reference's processor does, IM:263-285)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __call__(self, text=None, return_tensors="pt", padding=True, **kw):
+        import torch
+        t = self.t
+        a, u, n = 77, 78, 198
+        body = text
+        for tag in ("<|im_start|>assistant\n", "<|im_start|>user\n", "<|im_end|>\n", "<|im_start|>", "<|im_end|>"):
+            body = body.replace(tag, "")
+        V = int(t.text_vocab_size)
+        lo = min(1000, V // 2)                         # (plain text ids; the special ids sit outside this range at real dims)
+        toks = [lo + (sum(ord(ch) * (i + 1) for i, ch in enumerate(body[k:k + 4])) % min(40000, V - lo)) for k in range(0, len(body), 4)]
+        if text.startswith("<|im_start|>user"):
+            ids = [t.im_start_token_id, u, n] + toks + [t.im_end_token_id, n]
+        else:
+            ids = [t.im_start_token_id, a, n] + toks + [t.im_end_token_id, n, t.im_start_token_id, a, n]
+        return {"input_ids": torch.tensor([ids])}
+
+
+def api_e2e_leg(args, tcfg, ccfg, cw_np, dev, s2_ms_per_step):
+    """The step at the API the north_star says to keep (IM:732-840): `Qwen3TTSModel.generate_custom_voice(texts, speakers,
+    language=...)` from Python strings to host numpy waveforms -- tokenise, prompt assembly on the device (a1 / f1), prefill + AR
+    decode, codec decode, D2H and list building -- on the same model dims, batch, sampling and frame count as the S2 step above,
+    timed end to end on the host clock.  The parts that are NOT in the S2 number are timed on their own so that the gap is itemised."""
+    import numpy as np
+    import torch
+    import synth
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    from qwen3_tts_amd.model import Qwen3TTSForConditionalGeneration, Qwen3TTSModel
+    B, F = args.batch, args.frames
+    td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
+    t0 = time.time()
+    tw = synth.talker_weights(tcfg, with_text=True)                 # + text embedding (151 936 rows at 1.7B dims) and projection
+    cfgd = dict(synth.cfg_dict(tcfg), tts_model_type="custom_voice", tts_model_size="1b7", tokenizer_type="12hz")
+    ntext = [24 + 4 * (i % 8) for i in range(B)]                     # text tokens per request, as the S2 step's prompt rows
+    model = Qwen3TTSForConditionalGeneration(cfgd, td(tw), device=dev, dtype=torch.bfloat16 if args.talker_dtype == "bf16" else torch.float32, max_batch=B,
+                                             max_seq=max(ntext) + 32 + F + 8, use_graph=not args.no_graph)
+    del tw
+    cdt = torch.bfloat16 if args.codec_dtype == "bf16" else torch.float32
+    model.load_speech_tokenizer(Qwen3TTSTokenizer.from_state_dict(synth.cfg_dict(ccfg), td(cw_np), device=dev, dtype=cdt, max_batch=B,
+                                                                  max_frames=min(F, 300) + 25))
+    tts = Qwen3TTSModel(model, _BenchProcessor(tcfg), generate_defaults={})
+    build_s = time.time() - t0
+    rng = np.random.default_rng(7)
+    alphabet = np.array(list("abcdefghijklmnopqrstuvwxyz    ,."))
+    texts = ["".join(rng.choice(alphabet, 4 * n)) for n in ntext]   # 96..208 characters ("128-char synthetic prompts", BASELINE config 3)
+    speakers = [sorted(tcfg.spk_id)[i % len(tcfg.spk_id)] for i in range(B)]
+    langs = [sorted(tcfg.codec_language_id)[i % len(tcfg.codec_language_id)] for i in range(B)]
+    # a fixed number of frames, as in the S2 step: the stop id handed to generate() is one the suppress list never lets through
+    # (M:2059-2063 suppresses the top 1024 ids except the real EOS); a row that samples the real EOS id is still cut there (M:2283-2289)
+    never = tcfg.vocab_size - 1
+    assert never != tcfg.codec_eos_token_id
+    kw = dict(language=langs, max_new_tokens=F + 1, eos_token_id=never) if not args.greedy else dict(
+        language=langs, max_new_tokens=F + 1, eos_token_id=never, do_sample=False, subtalker_dosample=False)
+    for i in range(max(1, args.warmup)):
+        tts.generate_custom_voice(texts, speakers, seed=500 + i, **kw)
+    torch.cuda.synchronize()
+    K = max(3, min(args.steps, 10))
+    ts, frames_out = [], []
+    for i in range(K):
+        ta = time.perf_counter()
+        wavs, sr = tts.generate_custom_voice(texts, speakers, seed=600 + i, **kw)
+        ts.append(time.perf_counter() - ta)            # the call returns host numpy arrays: nothing is left in flight
+        frames_out.append(sum(w.shape[0] for w in wavs) // ccfg.total_upsample)
+        assert sr == 24000 and len(wavs) == B and all(isinstance(w, np.ndarray) and w.dtype == np.float32 for w in wavs)
+    ms = 1e3 * float(np.mean(ts))
+    # the parts the S2 step does not contain, each on its own
+    def timed(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t) / n, r
+    tok_ms, ids = timed(lambda: tts._tokenize_texts([tts._build_assistant_text(x) for x in texts]))
+    asm_ms, _ = timed(lambda: model.assemble_prompts(ids, langs, speakers, [None] * B, True))
+    codes = torch.randint(0, ccfg.codebook_size, (B, F, ccfg.num_quantizers), device=dev)
+    dec_ms, _ = timed(lambda: model.speech_tokenizer.decode([{"audio_codes": c} for c in codes]))
+    pad_ms, _ = timed(lambda: model.speech_tokenizer.model.decoder.decode_padded(codes))
+    G = tcfg.num_code_groups
+    tok_s = B * F * G / (ms * 1e-3)
+    out = {"api": "Qwen3TTSModel.generate_custom_voice(texts[8], speakers[8], language=...) -> (list of host numpy waveforms, 24000)",
+           "ms_per_call": round(ms, 2), "ms_min": round(1e3 * min(ts), 2), "calls": K,
+           "speech_tokens_per_s": round(tok_s, 1), "rtf_x": round(B * F * 0.08 / (ms * 1e-3), 2),
+           "frames_generated_per_row": F, "frames_returned_mean": round(float(np.mean(frames_out)) / B, 2),
+           "s2_ms_per_step": s2_ms_per_step, "gap_ms": round(ms - s2_ms_per_step, 2), "gap_pct": round(100.0 * (ms / s2_ms_per_step - 1.0), 2),
+           "not_in_s2_ms": {"tokenise (stand-in processor)": round(tok_ms, 3), "assemble_prompts (build_prompt_plan + text_embed + assemble_rows)": round(asm_ms, 3),
+                            "wrapper decode: D2H + per-request numpy list, over decode_padded": round(dec_ms - pad_ms, 3)},
+           "build_seconds": round(build_s, 1),
+           "note": "same dims / batch / sampling / frame count as the S2 step; text 24..52 tokens per request (96..208 characters); prompt rows come from the "
+                   "real chat template + codec prefix instead of synthetic embeddings; EOS trimming (M:2283-2289) applies, so a row may return fewer frames than were generated"}
+    del tts, model
+    torch.cuda.empty_cache()
+    return out
 
 
 def _host_threads():

@@ -13,8 +13,9 @@ restates what those calls do for RIFF/WAVE files (the format the reference's exa
     (ceil(n * target / orig)) and agrees with an ideal band-limited resampler to ~1e-4 on in-band content, but it is not
     sample-identical to soxr.  Audio already at the target rate never passes through it.
 
-Other containers (flac / ogg / mp3) need libsndfile / audioread and raise ValueError here.  Pure host code: no device
-work, nothing on the hot path."""
+Other containers (flac / ogg / ...) go to `soundfile.read` -- the reference's own reader (IM:207-223) -- when that package is
+importable (`read_audio_bytes`); where it is not (this image), they raise ValueError as before.  Pure host code: no device work,
+nothing on the hot path."""
 import base64
 import math
 import struct
@@ -97,16 +98,31 @@ def read_wav_bytes(data: bytes) -> Tuple[np.ndarray, int]:
     return (x if channels == 1 else x.reshape(-1, channels)), int(rate)
 
 
+def read_audio_bytes(data: bytes) -> Tuple[np.ndarray, int]:
+    """Any container the reference reads (IM:207-223: `soundfile.read(io.BytesIO(bytes), dtype="float32", always_2d=False)`):
+    RIFF/WAVE by this module's own exact reader; everything else (FLAC, OGG/Vorbis, AIFF, ...) by `soundfile` when it is importable;
+    without it, the ValueError `read_wav_bytes` raises for a non-WAVE container."""
+    if len(data) >= 12 and data[:4] == b"RIFF" and data[8:12] == b"WAVE":
+        return read_wav_bytes(data)
+    try:
+        import soundfile
+    except ImportError:
+        return read_wav_bytes(data)                                      # raises: "only RIFF/WAVE is readable without libsndfile"
+    import io
+    audio, sr = soundfile.read(io.BytesIO(data), dtype="float32", always_2d=False)
+    return np.asarray(audio, dtype=np.float32), int(sr)
+
+
 def load_audio_to_np(x: str) -> Tuple[np.ndarray, int]:
     """IM:207-222: path / URL / base64 -> (mono float32 waveform, its own sample rate)."""
     if is_url(x):
         with urllib.request.urlopen(x) as resp:
-            audio, sr = read_wav_bytes(resp.read())
+            audio, sr = read_audio_bytes(resp.read())
     elif is_probably_base64(x):
-        audio, sr = read_wav_bytes(decode_base64_to_wav_bytes(x))
+        audio, sr = read_audio_bytes(decode_base64_to_wav_bytes(x))
     else:
         with open(x, "rb") as f:                                         # FileNotFoundError like librosa.load
-            audio, sr = read_wav_bytes(f.read())
+            audio, sr = read_audio_bytes(f.read())
     if audio.ndim > 1:
         audio = np.mean(audio, axis=-1)
     return audio.astype(np.float32), int(sr)

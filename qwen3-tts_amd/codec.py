@@ -316,9 +316,8 @@ class Qwen3TTSTokenizer:
         """Loads `config.json` + `*.safetensors` of a Qwen3-TTS-Tokenizer-12Hz directory.  kwargs follow the
         reference (`device_map`, `dtype`, `attn_implementation` accepted and ignored)."""
         from safetensors.torch import load_file
-        path = pretrained_model_name_or_path
-        if not os.path.isdir(path):
-            raise OSError(f"{path} is not a local directory (this build has no hub access)")
+        from .model import resolve_checkpoint_dir
+        path = resolve_checkpoint_dir(pretrained_model_name_or_path, **kwargs)      # local directory, or a hub id (IT:62-99)
         with open(os.path.join(path, "config.json")) as f:
             cfg = json.load(f)
         sd = {}

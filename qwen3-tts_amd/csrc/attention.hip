@@ -1029,7 +1029,11 @@ __global__ __launch_bounds__(256) void attn_tk16_kernel(AttnDecodeParams p) {
 
     // element offset of (page pg of this sequence, this kv head) -- the same for the K pool ([16][128]) and the V pool ([128][16])
     auto page_base = [&](int pg) -> size_t {
-        pg = pg < pps ? pg : pps - 1;                                      // speculative requests stay inside the sequence's pages
+        // speculative READS stay inside the sequence's pages (what they fetch beyond the live length is dropped at use).  With a page
+        // table (CT = false) every entry (b, pg < pps) must therefore be populated at create -- the engine reserves all pages of a
+        // sequence up front.  The APPEND below never goes through the clamp: a step at capacity writes nothing (`fits`), it does not
+        // overwrite the last page (the host refuses such a step first: max_seq check in qtts_talker_generate).
+        pg = pg < pps ? pg : pps - 1;
         const int page = CT ? b * pps + pg : p.kv.page_table[b * pps + pg];
         return (((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + kvh) * (16 * HD);
     };
@@ -1089,7 +1093,7 @@ __global__ __launch_bounds__(256) void attn_tk16_kernel(AttnDecodeParams p) {
         x0 = o0; x1 = o1;
         if (vi == GQ) {
             const bf16_t h0 = f32_to_bf16(x0), h1 = f32_to_bf16(x1);
-            if (wave == 0 && split == 0) {
+            if (wave == 0 && split == 0 && (S0 >> 4) < pps) {
                 bf16_t* cdst = reinterpret_cast<bf16_t*>(p.kv.k);
                 const size_t o = page_base(S0 >> 4) + (size_t)(S0 & 15) * HD;
                 cdst[o + lane] = h0; cdst[o + lane + 64] = h1;
@@ -1102,7 +1106,7 @@ __global__ __launch_bounds__(256) void attn_tk16_kernel(AttnDecodeParams p) {
     }
     {
         const bf16_t h0 = f32_to_bf16(x0v[GQ + 1]), h1 = f32_to_bf16(x1v[GQ + 1]);
-        if (wave == 0 && split == 0) {
+        if (wave == 0 && split == 0 && (S0 >> 4) < pps) {
             bf16_t* cdst = reinterpret_cast<bf16_t*>(p.kv.v);
             const size_t o = page_base(S0 >> 4) + (S0 & 15);
             cdst[o + (size_t)lane * 16] = h0; cdst[o + (size_t)(lane + 64) * 16] = h1;

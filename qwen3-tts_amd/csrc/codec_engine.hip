@@ -490,9 +490,8 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     const bool final16 = fast16 && final16_env && !stage && wav && final_c % 8 == 0 && (size_t)262 * (final_c / 2 + 1) * 4 <= 64 * 1024;
     bf16_t* h16a = fast16 ? buf16[0].as<bf16_t>() : nullptr;
     bf16_t* h16b = fast16 ? buf16[1].as<bf16_t>() : nullptr;
-    // (A bf16 residual stream inside the blocks was measured in round 2 -- 13.38 vs 13.54 ms per 8 x 10 s, relative RMS 0.052 vs
-    // 0.049 -- and removed in round 3: the 1x1 convolutions are not HBM-bound, and an env-selected numeric mode nobody tests is a
-    // liability.)
+    // (Residual stream: fp32 between the tap-GEMM launches of the C = 768 / 384 blocks; bf16 inside blocks whose units run fused
+    // (round 3, `r16` below: on by default, relative RMS 0.0497 vs 0.0493 at real dims, pinned by the GPU test's 0.060 bar).)
     // ---- decoder.0: conv k=7 latent -> decoder_dim (v2:857)
     {
         float *a, *b, *cc; scratch3(a, b, cc);

@@ -653,6 +653,12 @@ static WideTile wide_tile(const GemmTapParams& p, bool a16, int bn_max) {
         if (!a16 && bn_max == 128 && p.act != ACT_SWIGLU && cdiv(p.M, 128) * cdiv(p.N, 128) < 128 && p.N % 64 == 0) best.bn = 64;
         return best;
     }
+    // CU count of the device the launch goes to (256 on MI355X; the three rates in the cost model above are MI355X measurements)
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
     double tb = 1e30;
     const double ab = a16 ? 2.0 : 4.0;
     for (int cm : {128, 64})
@@ -664,7 +670,7 @@ static WideTile wide_tile(const GemmTapParams& p, bool a16, int bn_max) {
                 const int wgs = cdiv(p.M, cm) * cdiv(p.N, cn), steps = p.K / ck;
                 const double sb = ck * (cm * ab + cn * 2.0) * 1e-3;                    // KB per k-step
                 const double chain = steps * (0.53 + sb / 65.0);
-                const double cu = cdiv(wgs, 256) * steps * sb / 80.0;
+                const double cu = cdiv(wgs, n_cu) * steps * sb / 80.0;
                 const double op = (double)cdiv(p.M, cm) * p.N * p.K * 2.0 / 6e6;
                 const double t = std::max(chain, std::max(cu, op)) * (1.0 + 0.01 * (cm * cn < 128 * 128));   // (ties go to the larger tile)
                 if (t < tb) { tb = t; best = {cm, cn, ck}; }

@@ -217,7 +217,9 @@ struct qtts_talker {
         L.fs_o = choose_fs(d.H, d.qd); L.fs_d = choose_fs(d.H, d.I);
         upload_packed(L.o_p, ow, d.H, d.qd, nullptr, L.fs_o);
         upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
-        if (bf16 && swiglu8_env && d.I % 8 == 0 && skinny_swiglu8_takes(d.H))
+        // (only engines that can run at batch <= 8 at all pay for the second copy -- 1.46 GB at 1.7B dims; an engine created for waves
+        // of 9..32 rows keeps the strip-pair kernel for a short last wave: ADVICE r3)
+        if (bf16 && swiglu8_env && cfg.max_batch <= 8 && d.I % 8 == 0 && skinny_swiglu8_takes(d.H))
             upload_packed(L.gu_p8, interleave_gu8(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H),
                           2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);

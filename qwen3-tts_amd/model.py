@@ -325,6 +325,31 @@ class Qwen3TTSForConditionalGeneration:
 
 
 # ====================================================================================== inference wrapper
+_HUB_KWARGS = ("cache_dir", "revision", "token", "local_files_only", "force_download", "proxies")
+
+
+def resolve_checkpoint_dir(name_or_path: str, **kwargs) -> str:
+    """The directory `from_pretrained` reads.  The reference forwards its argument to `AutoModel.from_pretrained`
+    (qwen3_tts_model.py:82-121), so the examples pass hub ids ("Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice/"): a local directory is used
+    as it is; anything else is resolved with `huggingface_hub.snapshot_download` (same cache, `revision` / `cache_dir` / `token` /
+    `local_files_only` forwarded) when that package is importable.  A name that is neither raises OSError, as HF does -- with the
+    hub's own error attached when the download was attempted (no network on a build box: a cached snapshot still resolves)."""
+    path = str(name_or_path)
+    if os.path.isdir(path):
+        return path
+    try:
+        from huggingface_hub import snapshot_download
+    except ImportError as e:
+        raise OSError(f"{path} is not a local directory and huggingface_hub is not importable to resolve it as a hub id") from e
+    repo_id = path.strip("/")
+    if repo_id.count("/") > 1 or not repo_id or repo_id.startswith("."):
+        raise OSError(f"{path} is neither a local directory nor a hub id of the form 'namespace/name'")
+    try:
+        return snapshot_download(repo_id=repo_id, **{k: kwargs[k] for k in _HUB_KWARGS if k in kwargs})
+    except Exception as e:                      # offline, unknown repo, gated, ...: surface as the OSError HF's from_pretrained raises
+        raise OSError(f"{path} is not a local directory and could not be resolved as a hub id ({type(e).__name__}: {e})") from e
+
+
 class _TextProcessor:
     """The reference's processor is a thin wrapper over the HF Qwen2 tokenizer
     (core/models/processing_qwen3_tts.py:27); this is the same call surface on AutoTokenizer."""
@@ -355,9 +380,7 @@ class Qwen3TTSModel:
         `attn_implementation` (accepted; the HIP engine has one attention path)."""
         from safetensors.torch import load_file
         from .codec import Qwen3TTSTokenizer
-        path = pretrained_model_name_or_path
-        if not os.path.isdir(path):
-            raise OSError(f"{path} is not a local directory (this build has no hub access)")
+        path = resolve_checkpoint_dir(pretrained_model_name_or_path, **kwargs)
         with open(os.path.join(path, "config.json")) as f:
             cfg = json.load(f)
         sd = {}

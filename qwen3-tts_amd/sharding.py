@@ -31,42 +31,65 @@ def waves(indices: Sequence[int], batch: int) -> List[List[int]]:
     return [list(indices[i:i + batch]) for i in range(0, len(indices), batch)]
 
 
-def gather_waveforms(local_wavs: List[np.ndarray], local_indices: List[int], n_total: int,
-                     device: Optional[torch.device] = None, group=None) -> Optional[List[np.ndarray]]:
-    """Gather every rank's (index, waveform) pairs on rank 0 and return them in request order there
-    (None elsewhere).  Two collectives: lengths, then one padded float tensor per rank."""
+def gather_waveforms_device(local_wavs: Sequence[torch.Tensor], local_indices: Sequence[int], n_total: int, group=None
+                            ) -> Optional[List[torch.Tensor]]:
+    """The request shard's exchange for VARIABLE-length, device-resident results: every rank holds its own requests' waveforms as
+    1-D float32 tensors on its device (what `decode_padded` returns, cut to length); rank 0 receives all of them and returns a list
+    of `n_total` tensors in request order (views of the gathered buffers, still on the device); other ranks return None.  Nothing
+    passes through host memory: the rows are packed into one padded (n_max, L_max) tensor per rank by `pad_sequence` on the device
+    and travel in ONE `torch.distributed.gather` (nccl = RCCL over xGMI; gloo on CPU tensors in the tests); two small collectives
+    agree on n_max / L_max first, one carries the (index, length) table."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if device is None:
+    if len(local_wavs):
+        device = local_wavs[0].device
+    else:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    # every rank owns at most ceil(n_total / 1) entries; meta row i = (request index, length), -1 = unused
-    cap = n_total
-    meta = torch.full((cap, 2), -1, dtype=torch.int64, device=device)
+    dims = torch.tensor([len(local_wavs), max([int(w.shape[0]) for w in local_wavs], default=0)], dtype=torch.int64, device=device)
+    dist.all_reduce(dims, op=dist.ReduceOp.MAX, group=group)
+    n, L = max(1, int(dims[0])), max(1, int(dims[1]))
+    meta = torch.full((n, 2), -1, dtype=torch.int64)
     for j, (idx, w) in enumerate(zip(local_indices, local_wavs)):
         meta[j, 0], meta[j, 1] = int(idx), int(w.shape[0])
-    metas = [torch.empty_like(meta) for _ in range(world)] if rank == 0 else None
-    dist.gather(meta, metas, dst=0, group=group)
-    mx = torch.tensor([max([int(w.shape[0]) for w in local_wavs], default=0)], dtype=torch.int64, device=device)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-    L = max(1, int(mx.item()))
-    nmax = torch.tensor([len(local_wavs)], dtype=torch.int64, device=device)
-    dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=group)
-    n = max(1, int(nmax.item()))
+    meta = meta.to(device)
     buf = torch.zeros(n, L, dtype=torch.float32, device=device)
-    for j, w in enumerate(local_wavs):
-        buf[j, : w.shape[0]] = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(device)
+    if len(local_wavs):
+        packed = torch.nn.utils.rnn.pad_sequence([w.to(torch.float32) for w in local_wavs], batch_first=True)   # one device op
+        buf[: packed.shape[0], : packed.shape[1]] = packed
+    metas = [torch.empty_like(meta) for _ in range(world)] if rank == 0 else None
     bufs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(meta, metas, dst=0, group=group)
     dist.gather(buf, bufs, dst=0, group=group)
     if rank != 0:
         return None
-    out: List[Optional[np.ndarray]] = [None] * n_total
+    out: List[Optional[torch.Tensor]] = [None] * n_total
     for r in range(world):
         m = metas[r].cpu().numpy()
-        b = bufs[r].cpu().numpy()
-        for j in range(cap):
+        for j in range(n):
             idx, ln = int(m[j, 0]), int(m[j, 1])
             if idx >= 0:
-                out[idx] = b[j, :ln].copy()
+                out[idx] = bufs[r][j, :ln]
     return out
+
+
+def gather_waveforms(local_wavs: List[np.ndarray], local_indices: List[int], n_total: int,
+                     device: Optional[torch.device] = None, group=None) -> Optional[List[np.ndarray]]:
+    """`gather_waveforms_device` for callers that hold host numpy waveforms (what the API returns, IM:840) and want numpy back on
+    rank 0: the arrays are staged on `device` (nccl needs device tensors), gathered, and copied back once."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    dev_wavs = [torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(device) for w in local_wavs]
+    out = gather_waveforms_device(dev_wavs, local_indices, n_total, group)
+    if out is None:
+        return None
+    return [None if w is None else w.cpu().numpy().copy() for w in out]
+
+
+def engine_partition(costs: Sequence[float], world_size: int, engines_per_rank: int) -> List[List[List[int]]]:
+    """LPT over (rank, engine) bins: `parts[r][e]` = the requests engine e of rank r runs.  With E engines per GPU (each its own
+    weights, stream and host thread -- a frame step leaves most CUs idle, so a second stream fills the gaps) the balancing unit is
+    the engine, not the rank."""
+    flat = lpt_partition(costs, world_size * engines_per_rank)
+    return [[flat[r * engines_per_rank + e] for e in range(engines_per_rank)] for r in range(world_size)]
 
 
 def gather_padded(wav: torch.Tensor, lengths: torch.Tensor, group=None):

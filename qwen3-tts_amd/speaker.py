@@ -3,7 +3,7 @@
 Host mirror of `Qwen3TTSForConditionalGeneration.extract_speaker_embedding` (modeling_qwen3_tts.py:1941-1954) over
 `qtts_speaker_*` (include/qtts.h): log-mel front end + ECAPA-TDNN.  The Slaney mel filterbank the reference takes from
 `librosa.filters.mel` (absent here) is computed by `mel_filterbank_slaney` below -- a restatement of librosa's published
-algorithm (htk=False, norm="slaney"); its values are unpinned against librosa itself.
+algorithm (htk=False, norm="slaney"), pinned against the values librosa's documentation publishes (round 4; CPU test).
 STATUS round 1: HIP side compiled, orchestration executed on CPU stand-ins (tests/test_hostemu.py), hardware run pending.
 """
 import ctypes as C
@@ -49,24 +49,36 @@ class SpeakerEncoderConfig:
         return cls(**kw)
 
 
+_F_SP, _MIN_LOG_HZ = 200.0 / 3, 1000.0
+_MIN_LOG_MEL, _LOGSTEP = _MIN_LOG_HZ / _F_SP, np.log(6.4) / 27.0
+
+
+def hz_to_mel_slaney(f):
+    """`librosa.hz_to_mel(f, htk=False)`: linear below 1 kHz (200/3 Hz per mel), logarithmic above (27 mels per factor 6.4)."""
+    f = np.asarray(f, dtype=np.float64)
+    return np.where(f >= _MIN_LOG_HZ, _MIN_LOG_MEL + np.log(np.maximum(f, 1e-10) / _MIN_LOG_HZ) / _LOGSTEP, f / _F_SP)
+
+
+def mel_to_hz_slaney(m):
+    """`librosa.mel_to_hz(m, htk=False)`."""
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= _MIN_LOG_MEL, _MIN_LOG_HZ * np.exp(_LOGSTEP * (m - _MIN_LOG_MEL)), _F_SP * m)
+
+
+def mel_frequencies_slaney(n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """`librosa.mel_frequencies(n_mels, fmin=fmin, fmax=fmax, htk=False)`: n_mels points evenly spaced on the Slaney mel scale."""
+    return mel_to_hz_slaney(np.linspace(hz_to_mel_slaney(fmin), hz_to_mel_slaney(fmax), n_mels))
+
+
 def mel_filterbank_slaney(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
-    """`librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)` with its defaults (htk=False, norm="slaney"): Slaney's mel
-    scale (linear below 1 kHz at 200/3 Hz per mel, logarithmic above with step log(6.4)/27), triangular filters between
-    consecutive mel points, each scaled by 2 / (f[i+2] - f[i]).  Returns (n_mels, 1 + n_fft//2) float32."""
+    """`librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)` with its defaults (htk=False, norm="slaney"), the filterbank of the
+    reference's `mel_spectrogram` (M:399-464): triangular filters between consecutive points of `mel_frequencies(n_mels + 2)`, each
+    scaled by 2 / (f[i+2] - f[i]).  Returns (n_mels, 1 + n_fft//2) float32.  librosa is not in this image; the scale and the
+    filterbank are pinned against the values librosa's own documentation publishes (tests/test_host_logic.py:
+    `test_slaney_mel_filterbank_matches_librosa_published_values`)."""
     fmax = float(sr) / 2 if fmax is None else float(fmax)
-    f_sp, min_log_hz = 200.0 / 3, 1000.0
-    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
-
-    def hz_to_mel(f):
-        f = np.asarray(f, dtype=np.float64)
-        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
-
-    def mel_to_hz(m):
-        m = np.asarray(m, dtype=np.float64)
-        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
-
     fft_f = np.linspace(0.0, float(sr) / 2, 1 + n_fft // 2)
-    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    mel_f = mel_frequencies_slaney(n_mels + 2, fmin, fmax)
     fdiff = np.diff(mel_f)
     ramps = mel_f[:, None] - fft_f[None, :]
     wts = np.zeros((n_mels, 1 + n_fft // 2), dtype=np.float64)

@@ -42,21 +42,46 @@ _SKIP_PREFIXES = ("speaker_encoder.",)
 
 
 
+def _as_index(v):
+    """An integer-like scalar (int, numpy / torch integer) as int, else None (bool is not an index here)."""
+    import operator
+    if isinstance(v, bool):
+        return None
+    try:
+        return operator.index(v)
+    except TypeError:
+        return None
+
+
 def _check_warpers(**kw):
     """HF's own argument checks (transformers generation/logits_process.py: TopKLogitsWarper / TopPLogitsWarper /
-    TemperatureLogitsWarper constructors), so that a bad value fails like the reference instead of reaching the kernel."""
+    TemperatureLogitsWarper constructors), so that a bad value fails like the reference instead of reaching the kernel.
+    `top_p` follows HF literally: only values < 0 or > 1 raise; `top_p == 0` is legal there (the sorted cumulative mass cut removes
+    everything and `min_tokens_to_keep = 1` puts the top token back) and is run here as `top_k = 1` (`_resolve_top`).  Integer-like
+    scalars (numpy / torch integers) are accepted for `top_k`, which is more lenient than HF's `isinstance(top_k, int)`."""
     for name in ("top_k", "subtalker_top_k"):
         v = kw.get(name)
-        if v is not None and v != 0 and (not isinstance(v, int) or v < 0):
+        if v is not None and v != 0 and (_as_index(v) is None or _as_index(v) < 0):
             raise ValueError(f"`{name}` has to be a strictly positive integer, but is {v}")
     for name in ("top_p", "subtalker_top_p"):
         v = kw.get(name)
-        if v is not None and not (0.0 < float(v) <= 1.0):
-            raise ValueError(f"`{name}` has to be a float > 0 and <= 1, but is {v}")
+        if v is not None and not (0.0 <= float(v) <= 1.0):
+            raise ValueError(f"`{name}` has to be a float > 0 and < 1, but is {v}")
     for name in ("temperature", "subtalker_temperature"):
         v = kw.get(name)
         if v is not None and not float(v) > 0.0:
             raise ValueError(f"`{name}` (={v}) has to be a strictly positive float")
+
+
+def _resolve_top(top_k, top_p):
+    """(top_k, top_p) as the kernel takes them: `top_p == 0` keeps exactly the top token under HF's rule (see `_check_warpers`),
+    which is `top_k = 1` with no nucleus cut."""
+    k = _as_index(top_k) if top_k else 0
+    p = float(top_p) if top_p is not None else 1.0
+    if p == 0.0:
+        return 1, 1.0
+    return int(k or 0), p
+
 
 class TalkerEngine:
     """Owns one `qtts_talker` handle."""
@@ -243,13 +268,11 @@ class TalkerEngine:
                        subtalker_top_p=subtalker_top_p, subtalker_temperature=subtalker_temperature)
         sp = _lib.SamplingC()
         sp.do_sample = 1 if do_sample else 0
-        sp.top_k = int(top_k) if top_k else 0
-        sp.top_p = float(top_p) if top_p is not None else 1.0
+        sp.top_k, sp.top_p = _resolve_top(top_k, top_p)
         sp.temperature = float(temperature) if temperature is not None else 1.0
         sp.repetition_penalty = float(repetition_penalty) if repetition_penalty is not None else 1.0
         sp.subtalker_dosample = 1 if subtalker_dosample else 0
-        sp.subtalker_top_k = int(subtalker_top_k) if subtalker_top_k else 0
-        sp.subtalker_top_p = float(subtalker_top_p) if subtalker_top_p is not None else 1.0
+        sp.subtalker_top_k, sp.subtalker_top_p = _resolve_top(subtalker_top_k, subtalker_top_p)
         sp.subtalker_temperature = float(subtalker_temperature) if subtalker_temperature is not None else 1.0
         sp.seed = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else _fresh_seed()
 
@@ -342,13 +365,11 @@ class TalkerEngine:
                        subtalker_top_p=subtalker_top_p, subtalker_temperature=subtalker_temperature)
         sp = _lib.SamplingC()
         sp.do_sample = 1 if do_sample else 0
-        sp.top_k = int(top_k) if top_k else 0
-        sp.top_p = float(top_p) if top_p is not None else 1.0
+        sp.top_k, sp.top_p = _resolve_top(top_k, top_p)
         sp.temperature = float(temperature) if temperature is not None else 1.0
         sp.repetition_penalty = float(repetition_penalty) if repetition_penalty is not None else 1.0
         sp.subtalker_dosample = 1 if subtalker_dosample else 0
-        sp.subtalker_top_k = int(subtalker_top_k) if subtalker_top_k else 0
-        sp.subtalker_top_p = float(subtalker_top_p) if subtalker_top_p is not None else 1.0
+        sp.subtalker_top_k, sp.subtalker_top_p = _resolve_top(subtalker_top_k, subtalker_top_p)
         sp.subtalker_temperature = float(subtalker_temperature) if subtalker_temperature is not None else 1.0
         sp.seed = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else _fresh_seed()
         dev = self.device

@@ -23,6 +23,9 @@ inline hipError_t hipMalloc(void** p, size_t n) {
 }
 inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return 0; }     // (an MI355X's CU count: the tile chooser's test pins its picks)
 inline hipError_t hipGetLastError() { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
 

@@ -106,3 +106,22 @@ def test_round1_advice_fixes_python_path(glue, golden_dir):
 def test_teacher_forcing_python_path(glue, golden_dir):
     """`TalkerEngine.generate(teacher_codes=...)` / `qtts_talker_set_teacher`: the GPU test body on the emulator."""
     glue.test_teacher_forcing_tiny_reproduces_golden(_talker_tiny(glue, golden_dir), "cpu")
+
+
+def test_top_p_zero_and_integer_like_top_k_python_path(glue, golden_dir):
+    """HF's TopPLogitsWarper accepts `top_p == 0` (the nucleus cut removes everything, `min_tokens_to_keep = 1` puts the
+    top token back): the sampled token is the greedy one whatever the seed; only `top_p < 0` or `> 1` raises; numpy integers are
+    accepted for `top_k`."""
+    from qwen3_tts_amd.talker import TalkerEngine, _resolve_top
+    assert _resolve_top(50, 0.0) == (1, 1.0) and _resolve_top(np.int64(7), 0.5) == (7, 0.5) and _resolve_top(None, None) == (0, 1.0)
+    t, w, g = _talker_tiny(glue, golden_dir)
+    eng = TalkerEngine(t, w, weight_dtype=torch.float32, device="cpu", max_batch=4, max_seq=64, use_graph=False)
+    args = [torch.from_numpy(g[k]) for k in ("embeds", "mask", "trailing", "tts_pad")]
+    sup = glue._suppress(t)
+    greedy = eng.generate(*args, max_new_tokens=1, do_sample=False, suppress_tokens=sup).tokens[:, 0].numpy()
+    for seed in (1, 2):
+        o = eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=np.int64(0), top_p=0.0, temperature=0.8, suppress_tokens=sup, seed=seed)
+        assert np.array_equal(o.tokens[:, 0].numpy(), greedy)
+    for bad in (dict(top_p=1.5), dict(top_p=-0.1), dict(top_k=2.5), dict(subtalker_top_k=-3)):
+        with pytest.raises(ValueError):
+            eng.generate(*args, max_new_tokens=1, do_sample=True, suppress_tokens=sup, **bad)

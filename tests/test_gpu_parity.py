@@ -190,7 +190,9 @@ def test_codec_bf16_mode_tracks_fp32(codec_tiny, dev):
 
 def test_codec_bf16_mode_at_real_dims_vs_reference_golden(dev, golden_dir):
     """The benchmarked codec mode at the benchmarked size: real dims, 10 s (125 frames) of random codes,
-    bf16 engine (tap-reuse GEMM, bf16 activations inside the decoder blocks) against the REFERENCE's fp32 waveform
+    bf16 engine (tap-reuse GEMM, bf16 activations inside the decoder blocks; since round 3 the fused residual units of the C = 96 /
+    192 blocks also carry their RESIDUAL STREAM in bf16 -- `QTTS_CODEC_RES16`, on by default, as the reference's own bfloat16 mode
+    does -- and hand bf16 to the final convolution) against the REFERENCE's fp32 waveform
     (`codec_real.npz`), as relative RMS; and the round-1 activation path (QTTS_CODEC_FAST16=0 is a process-wide switch, so
     that comparison lives in tools/bench_configs.py) -- the bar is a doubling of the measured error."""
     from qwen3_tts_amd.codec import Qwen3TTSTokenizerV2Model
@@ -203,7 +205,9 @@ def test_codec_bf16_mode_at_real_dims_vs_reference_golden(dev, golden_dir):
     ref = g["t125_wav"].astype(np.float64)
     rel = _rms(out[0].cpu().numpy(), g["t125_wav"]) / float(np.sqrt((ref ** 2).mean()))
     print(f"bf16 codec at real dims, 125 frames: relative rms error {rel:.4f} vs the reference's fp32 waveform")
-    assert np.isfinite(rel) and rel <= 0.10
+    # measured on MI355X with the round-3 default (bf16 residual stream inside fused blocks + final16): 0.0497 (fp32 residual
+    # stream, QTTS_CODEC_RES16=0: 0.0493).  The bar pins that: a 20 % growth of the error fails, well inside the yardstick.
+    assert np.isfinite(rel) and rel <= 0.060
     # The yardstick for the benchmarked codec mode: the REFERENCE'S OWN decoder run in bfloat16 on the same
     # codes (`codec_real_bf16.npz`, oracle/gen_golden.py:gen_codec_real_bf16, V2:869-896) sits at relative RMS 0.088 from its fp32
     # waveform.  The engine (bf16 GEMM operands, fp32 accumulation and residual stream) must be no further from fp32 than that.
@@ -682,8 +686,14 @@ def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
                 e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
             chi2, dof = float((((o - e) ** 2) / e).sum()), len(e) - 1
             assert chi2 < dof + 5.0 * np.sqrt(2.0 * max(dof, 1)) + 10.0, f"top_k={top_k} top_p={top_p} row {b}: chi-square {chi2:.1f} with {dof} dof"
-    with pytest.raises(ValueError, match="top_p"):           # HF's own argument check (TopPLogitsWarper): top_p in (0, 1]
-        eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=0, top_p=0.0, suppress_tokens=_suppress(t))
+    with pytest.raises(ValueError, match="top_p"):           # HF's own argument check (TopPLogitsWarper): top_p < 0 or > 1 raises
+        eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=0, top_p=1.5, suppress_tokens=_suppress(t))
+    # top_p == 0 is legal in HF: the nucleus cut removes everything and min_tokens_to_keep = 1 puts the top token back -> the greedy
+    # token, whatever the seed; numpy integers are accepted for top_k
+    greedy = eng.generate(*args, max_new_tokens=1, do_sample=False, suppress_tokens=_suppress(t)).tokens[:, 0].cpu().numpy()
+    for seed in (1, 2, 3):
+        o = eng.generate(*args, max_new_tokens=1, do_sample=True, top_k=np.int64(0), top_p=0.0, temperature=0.8, suppress_tokens=_suppress(t), seed=seed)
+        assert np.array_equal(o.tokens[:, 0].cpu().numpy(), greedy)
     # same seed -> same draw; different seed -> (almost surely) a different sequence
     kw = dict(max_new_tokens=8, suppress_tokens=_suppress(t))
     a = eng.generate(*args, seed=11, **kw).codes.cpu().numpy()

@@ -133,6 +133,16 @@ def test_bench_self_launches_two_ranks_gloo_on_the_emulator():
     assert max(j["ms_per_step_by_rank"]) <= j["ms_per_step"] * 1.001 + 1e-6
 
 
+def test_bench_api_e2e_leg_on_the_emulator():
+    """bench.py's `api_e2e` leg (round 4): `Qwen3TTSModel.generate_custom_voice` from Python strings to host numpy waveforms, timed
+    end to end next to the S2 step, with the parts the S2 step does not contain itemised.  Here: tiny dims on the emulator."""
+    j = _bench_on_emulator("--gpus", "1", "--model", "tiny", "--batch", "2", "--frames", "3", "--steps", "1", "--warmup", "0",
+                           "--no-roofline", "--no-cpu-baseline", "--no-parity-mode", "--talker-dtype", "f32", "--codec-dtype", "f32")
+    a = j["api_e2e"]
+    assert "INVALID" in j and a["calls"] >= 1 and a["ms_per_call"] > 0 and a["frames_generated_per_row"] == 3
+    assert 0 < a["frames_returned_mean"] <= 3 and set(a["not_in_s2_ms"]) and a["s2_ms_per_step"] == j["ms_per_step"]
+
+
 def test_bench_clone_shard_strong_scaling_two_ranks_gloo_on_the_emulator():
     """BASELINE config 5 under the bench launcher (`--workload clone-shard`): a FIXED job of 6 voice-clone-shaped requests dealt
     to 2 ranks by `lpt_partition`, waves of 2, every rank's variable-length waveforms gathered on rank 0 -- strong scaling."""
@@ -142,6 +152,22 @@ def test_bench_clone_shard_strong_scaling_two_ranks_gloo_on_the_emulator():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["requests"] == 6 and "INVALID" in j
     assert j["ranks_seen"] == [0, 1] and sum(j["requests_by_rank"]) == 6 and min(j["requests_by_rank"]) >= 2
     assert j["value"] > 0 and j["gather_ms_per_step"] > 0
+    assert j["wave_batch"] == 2 and j["engines_per_gpu"] == 2          # round 4: two engines per GPU by default, LPT over (rank, engine)
+
+
+def test_bench_clone_shard_defaults_are_the_fast_configuration():
+    """`--workload clone-shard` with no --batch / --engines runs waves of 32 on two engines per GPU, and the
+    (rank, engine) partition covers every request exactly once."""
+    import importlib
+    from qwen3_tts_amd import sharding
+    parts = sharding.engine_partition(list(range(16, 72)) * 4, 4, 2)
+    flat = sorted(i for pr in parts for pe in pr for i in pe)
+    assert flat == list(range(56 * 4)) and len(parts) == 4 and all(len(pr) == 2 for pr in parts)
+    loads = [sum((list(range(16, 72)) * 4)[i] for i in pe) for pr in parts for pe in pr]
+    assert max(loads) / (sum(loads) / len(loads)) < 1.02
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.batch = 32 if args.workload == "clone-shard" else 8' in src
+    assert 'args.engines = 2 if args.workload == "clone-shard" else 1' in src
 
 
 def test_gather_padded_gloo_world2(tmp_path):
@@ -881,3 +907,108 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
         assert C.sizeof(cls) == got[name]["size"], (name, C.sizeof(cls), got[name]["size"])
         for f in py_fields:
             assert getattr(cls, f).offset == got[name][f], (name, f)
+
+
+def test_slaney_mel_filterbank_matches_librosa_published_values():
+    """f4's audio front end (M:399-464 builds its filterbank with `librosa.filters.mel`, absent here): the Slaney scale and the
+    filterbank restated in qwen3_tts_amd/speaker.py reproduce the numbers librosa's own documentation prints -- the examples of
+    `librosa.hz_to_mel` (60 Hz -> 0.9; [110, 220, 440] -> [1.65, 3.3, 6.6]), `librosa.mel_to_hz` (3 -> 200; [1..5] -> 66.667 ...
+    333.333), `librosa.mel_frequencies(n_mels=40)` (fmin = 0, fmax = 11025: the 40-entry table below, printed to 3 decimals) and
+    `librosa.filters.mel(sr=22050, n_fft=2048)` (first row `[0., 0.016, ...]`) -- plus the closed-form anchors of the scale
+    (1 kHz = 15 mel, 6.4 kHz = 42 mel) and the properties the "slaney" normalisation is defined by."""
+    from qwen3_tts_amd.speaker import hz_to_mel_slaney, mel_filterbank_slaney, mel_frequencies_slaney, mel_to_hz_slaney
+    assert abs(float(hz_to_mel_slaney(60)) - 0.9) < 1e-12
+    assert np.allclose(hz_to_mel_slaney([110, 220, 440]), [1.65, 3.3, 6.6], atol=1e-12)
+    assert abs(float(mel_to_hz_slaney(3)) - 200.0) < 1e-9
+    assert np.allclose(mel_to_hz_slaney([1, 2, 3, 4, 5]), [66.667, 133.333, 200.0, 266.667, 333.333], atol=5e-4)
+    assert abs(float(hz_to_mel_slaney(1000.0)) - 15.0) < 1e-12 and abs(float(hz_to_mel_slaney(6400.0)) - 42.0) < 1e-9
+    published = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856,
+                 1119.114, 1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686, 2945.799,
+                 3216.731, 3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009, 7754.107, 8467.272,
+                 9246.028, 10096.408, 11025.]
+    assert np.abs(mel_frequencies_slaney(40, 0.0, 11025.0) - np.array(published)).max() < 6e-4          # (3 printed decimals)
+    fb = mel_filterbank_slaney(22050, 2048, 128, 0.0, 11025.0)
+    assert fb.shape == (128, 1025) and fb.dtype == np.float32
+    assert abs(float(fb[0, 1]) - 0.016) < 5e-4 and float(fb[0, 0]) == 0.0 and float(fb[-1, -1]) == 0.0
+    # "slaney" normalisation: every triangle has unit area in Hz (2 / width x peak 1 x width / 2), up to the FFT grid's sampling
+    df = 22050.0 / 2048
+    area = fb.astype(np.float64).sum(1) * df
+    assert np.all(np.abs(area[8:] - 1.0) < 0.06), (area.min(), area.max())
+    # each filter peaks between its neighbours' peaks, and the un-normalised triangles sum to 1 between the first and last centre
+    mf = mel_frequencies_slaney(130, 0.0, 11025.0)
+    tri = fb.astype(np.float64) / (2.0 / (mf[2:] - mf[:-2]))[:, None]
+    grid = np.linspace(0.0, 11025.0, 1025)
+    inner = (grid >= mf[1]) & (grid <= mf[-2])
+    assert np.abs(tri.sum(0)[inner] - 1.0).max() < 1e-6
+    # the configuration the speaker encoder uses (M:1944-1952): 24 kHz, n_fft 1024, 128 mels, fmin 0, fmax 12 kHz
+    fb2 = mel_filterbank_slaney(24000, 1024, 128, 0.0, 12000.0)
+    assert fb2.shape == (128, 513) and np.all(fb2 >= 0) and np.all(fb2.sum(1) > 0)
+
+
+def test_from_pretrained_resolves_hub_ids_like_the_reference(monkeypatch, tmp_path):
+    """IM:82-121 forwards its argument to `AutoModel.from_pretrained`, so the examples pass hub ids
+    ("Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice/"): a local directory is used as it is, a hub id goes through
+    `huggingface_hub.snapshot_download` (revision / cache_dir forwarded), and anything that cannot be resolved -- offline, unknown
+    repo, a malformed name -- is the OSError HF raises."""
+    import huggingface_hub
+    from qwen3_tts_amd.model import resolve_checkpoint_dir
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    assert resolve_checkpoint_dir(str(d)) == str(d)
+    calls = []
+
+    def fake_snapshot(repo_id, **kw):
+        calls.append((repo_id, kw))
+        return str(d)
+    monkeypatch.setattr(huggingface_hub, "snapshot_download", fake_snapshot)
+    assert resolve_checkpoint_dir("Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice/", revision="main", device_map="cuda:0", dtype="x") == str(d)
+    assert calls == [("Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice", {"revision": "main"})]       # only hub kwargs are forwarded
+
+    def offline(repo_id, **kw):
+        raise ConnectionError("no route to huggingface.co")
+    monkeypatch.setattr(huggingface_hub, "snapshot_download", offline)
+    with pytest.raises(OSError, match="could not be resolved as a hub id"):
+        resolve_checkpoint_dir("Qwen/Qwen3-TTS-12Hz-0.6B-Base")
+    with pytest.raises(OSError, match="neither a local directory nor a hub id"):
+        resolve_checkpoint_dir(str(tmp_path / "a" / "b" / "missing"))
+    # both loaders go through it (no engine is built: the error comes first)
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    from qwen3_tts_amd.model import Qwen3TTSModel
+    for cls in (Qwen3TTSModel, Qwen3TTSTokenizer):
+        with pytest.raises(OSError):
+            cls.from_pretrained("Qwen/Qwen3-TTS-Tokenizer-12Hz", device_map="cuda:0")
+
+
+def test_audio_containers_other_than_wave_go_to_soundfile_when_present(monkeypatch):
+    """IM:207-223 reads bytes with `soundfile.read(io.BytesIO(..), dtype="float32", always_2d=False)`: FLAC / OGG reach that call when
+    the package is importable; without it (this image) a non-WAVE container is the ValueError it always was; RIFF/WAVE never leaves
+    the module's own exact reader."""
+    import io
+    import types
+    from qwen3_tts_amd import audio_io
+    flac = b"fLaC" + bytes(64)
+    monkeypatch.setitem(sys.modules, "soundfile", None)                  # import soundfile -> ImportError
+    with pytest.raises(ValueError, match="RIFF/WAVE"):
+        audio_io.read_audio_bytes(flac)
+    seen = []
+    fake = types.ModuleType("soundfile")
+
+    def read(f, dtype=None, always_2d=None):
+        seen.append((f.read(4), dtype, always_2d))
+        return np.stack([np.linspace(-1, 1, 8), np.zeros(8)], 1).astype(np.float32), 16000
+    fake.read = read
+    monkeypatch.setitem(sys.modules, "soundfile", fake)
+    a, sr = audio_io.read_audio_bytes(flac)
+    assert seen == [(b"fLaC", "float32", False)] and sr == 16000 and a.shape == (8, 2) and a.dtype == np.float32
+    # through the public path: base64 of a FLAC stream, down-mixed to mono like the reference (IM:218-219)
+    import base64
+    b64 = "data:audio/flac;base64," + base64.b64encode(flac).decode()
+    mono, sr2 = audio_io.load_audio_to_np(b64)
+    assert sr2 == 16000 and mono.shape == (8,) and np.allclose(mono, np.linspace(-1, 1, 8) / 2, atol=1e-6)
+    # a WAVE file is still read by the exact in-module reader even when soundfile is there
+    import struct
+    pcm = np.array([0, 16384, -32768], "<i2").tobytes()
+    wav = b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 8000, 16000, 2, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm
+    n_before = len(seen)
+    x, sr3 = audio_io.read_audio_bytes(wav)
+    assert len(seen) == n_before and sr3 == 8000 and np.allclose(x, [0.0, 0.5, -1.0])
