@@ -44,8 +44,9 @@ extern "C" {
 const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
  * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
- * 6: + qtts_talker_stream_*). */
-#define QTTS_ABI_VERSION 8
+ * 6: + qtts_talker_stream_*; 7: + qtts_talker_set_teacher; 8: + qtts_talker_set_profile / get_gemm_profile;
+ * 9: + qtts_codec_get_stats). */
+#define QTTS_ABI_VERSION 9
 int qtts_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -118,6 +119,17 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
  * codes_dev int64 (batch, num_quantizers, n_frames) into wav_dev float (batch, n_frames * total_upsample).
  * STATUS: validated on MI355X (round 2): any packetisation == `forward` on the whole sequence
  * (tests/test_gpu_parity.py::test_codec_incremental_stream_equals_forward). */
+/* Bookkeeping of the decode-call graph cache (round 4): `qtts_codec_forward` / `qtts_codec_decode` replay a captured hipGraph from
+ * the second call with the same (codes pointer, output pointer, B, T, chunking) on -- the reference's decode is a Python loop of
+ * eager PyTorch ops (tokenizer v2:869-896); there is nothing to mirror, this only reports what happened. */
+typedef struct qtts_codec_stats {
+    int32_t graph_captures;  /* decode shapes captured so far                                   */
+    int32_t graph_replays;   /* calls served by hipGraphLaunch                                  */
+    int32_t graphs_cached;   /* captured graphs alive (LRU of 8)                                */
+    int32_t graph_nodes_last; /* nodes of the most recently used graph (0: last call ran eagerly) */
+} qtts_codec_stats;
+int qtts_codec_get_stats(qtts_codec* c, qtts_codec_stats* out);
+
 int qtts_codec_stream_begin(qtts_codec* c, int32_t batch);
 int qtts_codec_stream_push(qtts_codec* c, const int64_t* codes_dev, int32_t n_frames, float* wav_dev, void* stream);
 

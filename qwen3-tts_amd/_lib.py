@@ -71,17 +71,21 @@ class TalkerStatsC(C.Structure):
                 ("attn_nsplit_last", C.c_int32), ("attn_span_last", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class CodecStatsC(C.Structure):
+    _fields_ = [("graph_captures", C.c_int32), ("graph_replays", C.c_int32), ("graphs_cached", C.c_int32), ("graph_nodes_last", C.c_int32)]
+
+
 class GemmClassC(C.Structure):
     _fields_ = [("stack", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("min_us", C.c_double), ("max_us", C.c_double), ("bytes_per_launch", C.c_double)]
 
 
-ABI_VERSION = 8           # include/qtts.h; bumped on any signature change
+ABI_VERSION = 9           # include/qtts.h; bumped on any signature change
 
 # every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
            "qtts_codec_finalize", "qtts_codec_forward", "qtts_codec_decode", "qtts_codec_forward_stage",
-           "qtts_codec_stream_begin", "qtts_codec_stream_push",
+           "qtts_codec_stream_begin", "qtts_codec_stream_push", "qtts_codec_get_stats",
            "qtts_encoder_create", "qtts_encoder_destroy", "qtts_encoder_bind", "qtts_encoder_finalize", "qtts_encoder_frames",
            "qtts_encoder_encode",
            "qtts_speaker_create", "qtts_speaker_destroy", "qtts_speaker_bind", "qtts_speaker_finalize", "qtts_speaker_mel_frames",
@@ -141,6 +145,7 @@ def load_library():
     lib.qtts_codec_forward.argtypes = [vp, vp, i32, i32, f32p, f32p, vp]
     lib.qtts_codec_decode.argtypes = [vp, vp, i32, i32, i32, i32, f32p, i64p, vp]
     lib.qtts_codec_forward_stage.argtypes = [vp, vp, i32, i32, C.c_char_p, f32p, C.c_int64, i64p, i64p, vp]
+    lib.qtts_codec_get_stats.argtypes = [vp, C.POINTER(CodecStatsC)]
     lib.qtts_codec_stream_begin.argtypes = [vp, i32]
     lib.qtts_codec_stream_push.argtypes = [vp, vp, i32, f32p, vp]
     lib.qtts_encoder_create.argtypes = [C.POINTER(EncoderConfigC), C.POINTER(vp)]

@@ -144,6 +144,12 @@ class CodecDecoderEngine:
                                                    int(left_context_size), C.c_void_p(wav.data_ptr()), lens, self._stream()))
         return wav, [int(x) for x in lens]
 
+    def stats(self) -> Dict[str, int]:
+        """Graph-cache bookkeeping of this engine (include/qtts.h `qtts_codec_get_stats`)."""
+        st = _lib.CodecStatsC()
+        _lib.check(self._lib.qtts_codec_get_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in _lib.CodecStatsC._fields_}
+
     @_lib.locked
     def stream_begin(self, batch: int):
         """Start a state-carrying streaming session for `batch` sequences (include/qtts.h `qtts_codec_stream_begin`).

@@ -5,6 +5,7 @@
 // is one `gemm_tap` launch (see gemm_tap.hip).  Stage order follows Qwen3TTSTokenizerV2Decoder.forward
 // (tokenizer v2:869-884); chunking follows chunked_decode (v2:886-896).
 #include <map>
+#include <tuple>
 #include <functional>
 #include <algorithm>
 #include "common.h"
@@ -48,6 +49,79 @@ struct qtts_codec {
     DevBuf buf16[2];                    // bf16 mode: activations that are only a GEMM input (decoder blocks)
     size_t buf_elems = 0;
     DevBuf err_flag;                    // device int: a code index >= codebook_size was seen (checked by the entry points)
+
+    // ---- hipGraph replay of whole decode calls (round 4).  A decode is ~140 launches whose arguments are fixed by (codes pointer,
+    // output pointer, B, T, chunking): the SECOND call with the same key captures the launch sequence (on a private stream -- a
+    // capture executes nothing, and the caller's stream may be the legacy default stream, which cannot be captured) and this and
+    // every later call replay it with one hipGraphLaunch on the caller's stream.  Every other address in the graph is engine-owned
+    // workspace.  A caller that allocates fresh buffers per call (PyTorch's caching allocator hands the same blocks back in a steady
+    // loop) simply never hits the cache and runs eagerly, as before.  QTTS_CODEC_GRAPH=0: always eager (A/B).
+    struct GraphKey {
+        const void* codes; void* wav; void* pre; int B, T, chunk, left;
+        bool operator<(const GraphKey& o) const {
+            return std::tie(codes, wav, pre, B, T, chunk, left) < std::tie(o.codes, o.wav, o.pre, o.B, o.T, o.chunk, o.left);
+        }
+    };
+    struct GraphSlot { hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; uint64_t last_use = 0; int seen = 0; int nodes = 0; };
+    std::map<GraphKey, GraphSlot> graphs;
+    hipStream_t cap_stream = nullptr;
+    uint64_t graph_clock = 0;
+    int graph_replays = 0, graph_captures = 0;
+    static constexpr size_t GRAPH_SLOTS = 8;
+    static bool graph_enabled() { static const bool on = [] { const char* e = getenv("QTTS_CODEC_GRAPH"); return !e || atoi(e) != 0; }(); return on; }
+    void drop_graphs() {
+        for (auto& kv : graphs) {
+            if (kv.second.ge) (void)hipGraphExecDestroy(kv.second.ge);
+            if (kv.second.g) (void)hipGraphDestroy(kv.second.g);
+        }
+        graphs.clear();
+    }
+    ~qtts_codec() {
+        drop_graphs();
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    }
+    // run `body(stream)` -- a launch sequence without host synchronisation -- eagerly on `st`, or as a cached graph
+    template <class F>
+    void run_graphed(const GraphKey& key, hipStream_t st, F&& body) {
+        if (!graph_enabled()) { body(st); return; }
+        GraphSlot& slot = graphs[key];
+        slot.last_use = ++graph_clock;
+        if (!slot.ge) {
+            if (++slot.seen < 2) {                                   // first sight: eager (also loads every code object lazily loaded)
+                body(st);
+                evict();
+                return;
+            }
+            if (!cap_stream) QTTS_CHECK_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+            QTTS_CHECK_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+            try { body(cap_stream); }
+            catch (...) {
+                hipGraph_t gx = nullptr;
+                (void)hipStreamEndCapture(cap_stream, &gx);
+                if (gx) (void)hipGraphDestroy(gx);
+                graphs.erase(key);
+                throw;
+            }
+            QTTS_CHECK_HIP(hipStreamEndCapture(cap_stream, &slot.g));
+            size_t nn = 0;
+            QTTS_CHECK_HIP(hipGraphGetNodes(slot.g, nullptr, &nn));
+            slot.nodes = (int)nn;
+            QTTS_CHECK_HIP(hipGraphInstantiate(&slot.ge, slot.g, nullptr, nullptr, 0));
+            ++graph_captures;
+        }
+        QTTS_CHECK_HIP(hipGraphLaunch(slot.ge, st));
+        ++graph_replays;
+        evict();
+    }
+    void evict() {
+        while (graphs.size() > GRAPH_SLOTS) {
+            auto lru = graphs.begin();
+            for (auto it = graphs.begin(); it != graphs.end(); ++it) if (it->second.last_use < lru->second.last_use) lru = it;
+            if (lru->second.ge) (void)hipGraphExecDestroy(lru->second.ge);
+            if (lru->second.g) (void)hipGraphDestroy(lru->second.g);
+            graphs.erase(lru);
+        }
+    }
     void check_codes_flag(hipStream_t st) {
         int e = 0;
         QTTS_CHECK_HIP(hipMemcpyAsync(&e, err_flag.p, 4, hipMemcpyDeviceToHost, st));
@@ -831,8 +905,10 @@ int qtts_codec_forward(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32
     QTTS_API_BEGIN
     QTTS_REQUIRE(c && codes_dev && wav_dev, QTTS_ERR_ARG, "null argument");
     const int Q = c->cfg.num_quantizers;
-    c->forward(codes_dev, B, (int64_t)Q * T, T, 1, 0, T, wav_dev, pre_clamp_dev, (int64_t)T * c->up_total, 0, nullptr,
-               nullptr, 0, nullptr, nullptr, (hipStream_t)stream);
+    c->run_graphed({codes_dev, wav_dev, pre_clamp_dev, B, T, 0, -1}, (hipStream_t)stream, [&](hipStream_t s) {
+        c->forward(codes_dev, B, (int64_t)Q * T, T, 1, 0, T, wav_dev, pre_clamp_dev, (int64_t)T * c->up_total, 0, nullptr,
+                   nullptr, 0, nullptr, nullptr, s);
+    });
     c->check_codes_flag((hipStream_t)stream);
     QTTS_API_END
 }
@@ -870,15 +946,30 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
         for (int64_t v : h)   // the reference's embedding lookup raises on an index past the codebook
             QTTS_REQUIRE(v < c->cfg.codebook_size, QTTS_ERR_ARG, "codec: code index out of range (>= codebook_size)");
     }
-    int start = 0;
-    while (start < T) {  // chunked_decode (v2:886-896)
-        const int end = std::min(start + chunk_size, T);
-        const int ctx = (start - left_context > 0) ? left_context : start;
-        c->forward(codes_dev, B, (int64_t)T * Q, 1, Q, start - ctx, end - (start - ctx), wav_dev + (int64_t)start * up, nullptr,
-                   (int64_t)T * up, (int64_t)ctx * up, nullptr, nullptr, 0, nullptr, nullptr, st);
-        start = end;
-    }
+    c->run_graphed({codes_dev, wav_dev, nullptr, B, T, chunk_size, left_context}, st, [&](hipStream_t s) {
+        int start = 0;
+        while (start < T) {  // chunked_decode (v2:886-896)
+            const int end = std::min(start + chunk_size, T);
+            const int ctx = (start - left_context > 0) ? left_context : start;
+            c->forward(codes_dev, B, (int64_t)T * Q, 1, Q, start - ctx, end - (start - ctx), wav_dev + (int64_t)start * up, nullptr,
+                       (int64_t)T * up, (int64_t)ctx * up, nullptr, nullptr, 0, nullptr, nullptr, s);
+            start = end;
+        }
+    });
     if (!lengths_host) c->check_codes_flag(st);      // (with lengths the codes were validated on the host above)
+    QTTS_API_END
+}
+
+int qtts_codec_get_stats(qtts_codec* c, qtts_codec_stats* out) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(c && out, QTTS_ERR_ARG, "null argument");
+    out->graph_captures = c->graph_captures; out->graph_replays = c->graph_replays;
+    out->graphs_cached = 0; out->graph_nodes_last = 0;
+    uint64_t newest = 0;
+    for (auto& kv : c->graphs) {
+        if (kv.second.ge) ++out->graphs_cached;
+        if (kv.second.last_use > newest) { newest = kv.second.last_use; out->graph_nodes_last = kv.second.ge ? kv.second.nodes : 0; }
+    }
     QTTS_API_END
 }
 

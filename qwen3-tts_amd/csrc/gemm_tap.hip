@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmTapParams p) {
 //     the activated copy goes out as bf16 (C16), and the stand-alone snake passes disappear from the decoder blocks.
 // Tile 128 x BN, 4 waves (2 x 2), each wave 64 x BN/2 as 4 x BN/32 MFMA 16x16x32 tiles per 32 of k.
 template <int BN, int BK>
-__global__ __launch_bounds__(256, 3) void gemm_tap2_kernel(GemmTapParams p, int halo, int cap /* rows of one A buffer: 128 + halo, rounded up */) {
+__global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gemm_tap2_kernel(GemmTapParams p, int halo, int cap /* rows of one A buffer: 128 + halo, rounded up */) {
     constexpr int BM = 128;
     constexpr int TM = 4, TN = BN / 32;
     constexpr int STR = BK + 8;                        // LDS row stride (bf16 elements): 16-B aligned, rows shift by 4 banks
@@ -729,7 +729,19 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         const int bn2 = (p.N % 128 == 0) ? 128 : (p.N % 96 == 0 ? 96 : (p.N <= 64 ? 64 : 128));
         // k-slab of 32: measured 7 % faster than 64 / 96 on the codec (14.8 vs 15.95 ms per 8 x 10 s,
         // profiles/r02_config2_codec_tap2*.json) -- the smaller LDS footprint (<= 50 KB) keeps 3 workgroups per CU resident
-        if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st);
+        // Round 4: a grid that leaves every CU at most one workgroup (the C = 768 / 384 units of a B = 1 x 10 s or 32 x 4-frame decode: 192
+        // tiles, 168 k-steps each) is bound by its workgroups' own step chains, not by occupancy: 64-wide k-slabs halve the steps.
+        // QTTS_TAP2_BK = 32 | 64 forces one side (A/B); default: 64 when the grid has at most `n_cu` tiles and K % 64 == 0.
+        static const int bk_env = [] { const char* e = getenv("QTTS_TAP2_BK"); return e ? atoi(e) : 0; }();
+        static const int n_cu2 = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return n;
+        }();
+        const int tiles = cdiv(p.M, 128) * cdiv(p.N, bn2);
+        const bool bk64 = p.K % 64 == 0 && bn2 == 128 && (bk_env == 64 || (bk_env == 0 && tiles <= n_cu2));
+        if (bk64) launch_tap2<128, 64>(p, halo, st);
+        else if (bn2 == 128) launch_tap2<128, 32>(p, halo, st); else if (bn2 == 96) launch_tap2<96, 32>(p, halo, st); else launch_tap2<64, 32>(p, halo, st);
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }

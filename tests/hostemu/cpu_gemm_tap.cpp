@@ -24,8 +24,14 @@ static bool real_gemm() {
 }
 
 // gemm_tap.hip: C[m][n] = epi( sum_tap sum_k A[m + shift[tap]][k] * W[tap][n][k] ), zero row when (m % T) + shift < 0
+static void gemm_tap_loops(const GemmTapParams& p);
 void launch_gemm_tap(const GemmTapParams& p, bool bf16, hipStream_t st) {
     if (real_gemm() || bf16) return launch_gemm_tap_real(p, bf16, st);     // bf16 engines: always the real kernels (small test dims only)
+    // like a real launch: while a stream capture is open the work becomes a graph node (arguments by value) and runs at replay
+    if (simt::capture().open) { const GemmTapParams q = p; simt::capture().open->nodes.push_back([q] { gemm_tap_loops(q); }); return; }
+    gemm_tap_loops(p);
+}
+static void gemm_tap_loops(const GemmTapParams& p) {
     QTTS_REQUIRE(p.K % 32 == 0, QTTS_ERR_ARG, "gemm_tap: K must be a multiple of 32");
     QTTS_REQUIRE(p.taps >= 1 && p.taps <= 8, QTTS_ERR_ARG, "gemm_tap: 1..8 taps");
     QTTS_REQUIRE(p.M > 0 && p.N > 0, QTTS_ERR_ARG, "gemm_tap: empty problem");

@@ -780,6 +780,58 @@ def test_decoder_orchestration_forward_and_chunked(emu, codec):
     assert np.sqrt(((out - chunked) ** 2).mean()) <= 1e-5
 
 
+def test_decode_call_graph_replay_equals_eager(emu, codec):
+    """Round 4: `qtts_codec_forward` / `qtts_codec_decode` replay a captured graph from the second call with the same (codes pointer,
+    output pointer, B, T, chunking) on.  Same buffers, new contents -> the replay must see the new contents (the graph bakes
+    addresses, not data); another buffer or shape runs eagerly; the cache is an LRU of 8."""
+    c, w, h = codec
+
+    class St(C.Structure):
+        _fields_ = [("cap", C.c_int32), ("rep", C.c_int32), ("cached", C.c_int32), ("nodes", C.c_int32)]
+    emu.qtts_codec_get_stats.argtypes = [C.c_void_p, C.POINTER(St)]
+
+    def stats():
+        st = St()
+        _ok(emu, emu.qtts_codec_get_stats(h, C.byref(st)))
+        return st.cap, st.rep, st.cached, st.nodes
+    c0, r0, _, _ = stats()
+    rng = np.random.default_rng(31)
+    T = 9
+    padded = np.ascontiguousarray(rng.integers(0, c.codebook_size, (2, T, c.num_quantizers)))
+    out = np.zeros((2, T * c.total_upsample), np.float32)
+    lens = (C.c_int64 * 2)()
+    refs = []
+    for it in range(4):                      # call 0: eager; call 1: capture + replay; calls 2, 3: replay -- each on fresh codes
+        padded[...] = rng.integers(0, c.codebook_size, padded.shape)
+        if it == 3:
+            padded[1, 5:] = -1               # padding rides through the graph like any other code value
+        _ok(emu, emu.qtts_codec_decode(h, _ptr(padded), 2, T, 4, 3, _ptr(out), lens, None))
+        with torch.no_grad():
+            chunked = codec_ref.chunked_decode(w, c, torch.clamp(torch.from_numpy(padded), min=0).transpose(1, 2), 4, 3)[:, 0].numpy()
+        assert np.sqrt(((out - chunked) ** 2).mean()) <= 1e-5, it
+    cap, rep, cached, nodes = stats()
+    assert (cap - c0, rep - r0) == (1, 3) and cached >= 1 and nodes > 20
+    assert [int(x) for x in lens] == [T * c.total_upsample, 5 * c.total_upsample]
+    # an out-of-range code fails the replayed call too (device flag), and the next call is clean again
+    padded[0, 0, 0] = c.codebook_size
+    assert emu.qtts_codec_decode(h, _ptr(padded), 2, T, 4, 3, _ptr(out), None, None) != 0
+    padded[0, 0, 0] = 0
+    _ok(emu, emu.qtts_codec_decode(h, _ptr(padded), 2, T, 4, 3, _ptr(out), None, None))
+    # forward(): its own key space (pre-clamp pointer included)
+    codes = np.ascontiguousarray(rng.integers(0, c.codebook_size, (1, c.num_quantizers, 5)))
+    w1, w2, pre = (np.zeros((1, 5 * c.total_upsample), np.float32) for _ in range(3))
+    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w1), None, None))
+    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w1), None, None))        # captured here
+    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w2), _ptr(pre), None))   # other outputs: eager
+    assert np.array_equal(w1, w2) and np.abs(pre).max() > 0
+    # LRU: ten more keys (distinct output buffers), each seen twice -> at most 8 graphs stay cached, all results still right
+    bufs = [np.zeros((1, 5 * c.total_upsample), np.float32) for _ in range(10)]
+    for _ in range(2):
+        for b in bufs:
+            _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(b), None, None))
+    assert all(np.array_equal(b, w1) for b in bufs) and stats()[2] <= 8
+
+
 def test_stream_push_equals_whole_sequence_forward(emu, codec):
     """qtts_codec_stream_begin / _push (state-carrying streaming decode): the product's C++ orchestration,
     run here on the emulated kernels, reproduces the whole-sequence forward for ragged packets, single frames and streams several
