@@ -77,13 +77,20 @@ struct SkinnyParams {
     float* out; int ldo;
     int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns) | ACT_SWIGLU8 (round 3, skinny8_kernel:
                                  // ONE strip = 8 gate + 8 up rows of the same 8 output columns -> N/16 workgroups instead of N/32)
+    // fp32 batch <= 8 kernel only (round 4): split-K with the combine in the consumer's prologue
+    int ksplit;                  // 2: producer -- workgroup (strip, half) writes raw partial sums to out + half * part_stride (plain GEMM only)
+    size_t part_stride;          //    floats between the two halves' [M][ldo] partial buffers
+    const float* xp;             // consumer: x is formed as (x + xp[0]) + xp[1], the halves at xp and xp + xp_stride, laid out like x ([M][ldx])
+    size_t xp_stride;
+    float* x_out;                //    ... and workgroup 0 writes the combined rows here (!= x)
     const int* done_flag;        // optional device flag: when non-zero the kernel exits early
     int ablate;                  // `ablate` build variant only (-DQTTS_ABLATE; must be 0 in the product build): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
 };
 void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st);
 void skinny_set_launch_events(hipEvent_t start, hipEvent_t stop);   // (bench.py's roofline leg: time the NEXT launch on its own; null = off)
 bool skinny_takes_bf16_x(int M, int K, bool bf16);   // bf16 mode: any M <= 64, K % 32 == 0
-bool skinny_f32_inline_norm(int M, int K);            // fp32 mode: the batch <= 8 kernel takes the RMSNorm row statistics itself (no ss_in)
+bool skinny_f32_inline_norm(int M, int K);
+bool skinny_f32_splitk_takes(int M, int K_producer, int K_consumer);   // fp32 mode: producer may split K in two, its consumer combines            // fp32 mode: the batch <= 8 kernel takes the RMSNorm row statistics itself (no ss_in)
 bool skinny_swiglu8_takes(int K);                     // ACT_SWIGLU8 (batch <= 8 kernel): K = 1024 | 2048 | 3072 | 6144
 size_t skinny_packed_bytes(int N, int K, bool bf16);
 // Pack W[N][K] (row-major f32), optionally scaled per input column by g[K], into the streaming tile layout;

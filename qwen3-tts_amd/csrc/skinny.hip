@@ -637,11 +637,23 @@ __device__ inline f32x4 dpp_ror8_f(const f32x4& v) {
     for (int e = 0; e < 4; ++e) r[e] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[e]), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
     return r;
 }
-template <int SPW, int NP, int CH, bool NORM, int NW>
+// Split-K with the combine in the CONSUMER's prologue (round 4, second step).  The N = 1024 / 2048 operators (o-proj, down-proj) are 64 /
+// 128 strips of 16 features: 64 workgroups pulling 128-196 KB each ran at 1.1-1.4 TB/s (profiles/r04_f32_skinny8.md), and narrower
+// strips would spend 3/4 of an fp32 16x16x4 MFMA on padding.  Instead:
+//   KS = 2  (producer): workgroup (strip, half) accumulates its half of K and writes the raw partial sums to `out + half * part_stride`
+//           -- no residual, no bias, no activation, no normalisation; twice the workgroups, half the chain each;
+//   COMB    (consumer: the NEXT decode GEMM, which reads that output as its x anyway): every x fragment is formed as
+//           (x + xp[0]) + xp[1] from three requests instead of one -- the launch-boundary reduce costs no launch and no barrier -- and
+//           workgroup 0 writes the combined rows to `x_out` (another buffer than x: the other workgroups are still reading x), which
+//           is the residual stream from here on.  The RMSNorm statistics come from the combined fragments.
+// Fixed summation order (half 0 + half 1 on top of x), so results are run-to-run identical; they differ in the last bits from the
+// unsplit kernel -- the fp32 goldens are the acceptance test.
+template <int SPW, int NP, int CH, bool NORM, int NW, int KS = 1, bool COMB = false>
 __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, const float* kx, const int* kdone, const float* kres, const float* kbias,
                                                               int kldx, int kM, int kK, int kldr, SkinnyParams p) {
     p.Wp = kWp; p.x = kx; p.done_flag = kdone; p.res = kres; p.bias = kbias; p.ldx = kldx; p.M = kM; p.K = kK; p.ldr = kldr;
     static_assert(CH >= 1 && CH <= 3, "skinny8_f32: 1..3 chunks");
+    static_assert(KS == 1 || (KS == 2 && !NORM && !COMB && SPW == 1), "skinny8_f32: the split-K producer is a plain single-strip GEMM");
     constexpr int NSET = CH < 2 ? CH : 2;                        // register sets
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
     f32x4* red = reinterpret_cast<f32x4*>(smem_sk);              // [NW][SPW][64]
@@ -650,18 +662,21 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
-    const int nkt = p.K >> 4;
-    const int strip0 = blockIdx.x * SPW;
+    const int nkt = p.K >> 4;                                    // k-tiles of the whole operator (a strip's stride)
+    const int bidx = KS == 1 ? blockIdx.x : blockIdx.x / KS;     // strip (pair) index
+    const int kh = KS == 1 ? 0 : blockIdx.x % KS;                // which half of K
+    const int strip0 = bidx * SPW;
 
     // 16-B units; a tile is 64 units, a pair 128
     const u32x4* wb[SPW];
 #pragma unroll
     for (int s = 0; s < SPW; ++s)
-        wb[s] = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)(strip0 + s) * nkt * 64 + lq * 16 + lj + (size_t)wave * 128;
-    const float* xb = p.x + (size_t)((lj & 7) < p.M ? (lj & 7) : 0) * p.ldx + (lj >> 3) * 16 + lq * 4 + wave * 32;
+        wb[s] = reinterpret_cast<const u32x4*>(p.Wp) + (size_t)(strip0 + s) * nkt * 64 + (size_t)kh * (nkt / KS) * 64 + lq * 16 + lj + (size_t)wave * 128;
+    const size_t xoff = (size_t)((lj & 7) < p.M ? (lj & 7) : 0) * p.ldx + kh * (p.K / KS) + (lj >> 3) * 16 + lq * 4 + wave * 32;
+    const float* xb = p.x + xoff;
 
     u32x4 wR[NSET][NP][SPW][2];
-    f32x4 xR[NSET][NP];
+    f32x4 xR[NSET][NP], pR[COMB ? NSET : 1][COMB ? NP : 1][2];
     auto request = [&](int set, int c) {                          // chunk c = pairs wave + NW (c NP + i)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -670,6 +685,11 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
 #pragma unroll
                 for (int h = 0; h < 2; ++h) wR[set][i][s][h] = skinny_wload(wb[s] + (size_t)(c * NP + i) * (NW * 128) + h * 64);
             xR[set][i] = *reinterpret_cast<const f32x4*>(xb + (c * NP + i) * (NW * 32));
+            if constexpr (COMB) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    pR[set][i][h] = *reinterpret_cast<const f32x4*>(p.xp + h * p.xp_stride + xoff + (c * NP + i) * (NW * 32));
+            }
         }
     };
     // ---- 1. the requests, back to back
@@ -677,14 +697,20 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
     if constexpr (CH >= 2) request(1, 1);
     // epilogue operands (used by wave 0 only; requested by every wave so that no branch surrounds a load)
     const int rowc = lj < p.M ? lj : 0;
+    constexpr bool EPI = KS == 1 && !COMB;                       // (a split-K producer and a combining consumer take neither bias nor residual)
     f32x4 resv[SPW], biasv[SPW];
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
-        const int col = (p.act == ACT_SWIGLU ? blockIdx.x * 16 : (strip0 + s) * 16) + lq * 4;
-        const float* bp = p.bias ? p.bias + (strip0 + s) * 16 + lq * 4 : p.x;
-        const float* rp = p.res ? p.res + (size_t)rowc * p.ldr + col : p.x;
-        biasv[s] = *reinterpret_cast<const f32x4*>(bp);
-        resv[s] = *reinterpret_cast<const f32x4*>(rp);
+        if constexpr (EPI) {
+            const int col = (p.act == ACT_SWIGLU ? bidx * 16 : (strip0 + s) * 16) + lq * 4;
+            const float* bp = p.bias ? p.bias + (strip0 + s) * 16 + lq * 4 : p.x;
+            const float* rp = p.res ? p.res + (size_t)rowc * p.ldr + col : p.x;
+            biasv[s] = *reinterpret_cast<const f32x4*>(bp);
+            resv[s] = *reinterpret_cast<const f32x4*>(rp);
+        } else {
+            biasv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            resv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     const int done = p.done_flag ? *p.done_flag : 0;
     if (done) return;
@@ -694,11 +720,16 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
     float ss = 0.f;
 #pragma unroll
     for (int s = 0; s < SPW; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto consume = [&](int set) {
+    auto consume = [&](int set, int c) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const f32x4 xe = xR[set][i];
-            const f32x4 xo = dpp_ror8_f(xR[set][i]);
+            f32x4 xe = xR[set][i];
+            if constexpr (COMB) {
+                xe = (xe + pR[set][i][0]) + pR[set][i][1];        // the launch-boundary reduce: x + half 0 + half 1, in this order
+                if (blockIdx.x == 0 && (lj & 7) < p.M)            // one workgroup writes the combined rows: the residual stream from here on
+                    *reinterpret_cast<f32x4*>(p.x_out + xoff + (c * NP + i) * (NW * 32)) = xe;
+            }
+            const f32x4 xo = dpp_ror8_f(xe);
             if constexpr (NORM) {                                 // this lane's 4 values belong to row lj & 7 (even or odd tile of the pair)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ss = fmaf(xe[e], xe[e], ss);
@@ -715,10 +746,10 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
             }
         }
     };
-    consume(0);
+    consume(0, 0);
     if constexpr (CH == 3) request(0, 2);
-    if constexpr (CH >= 2) consume(1);
-    if constexpr (CH == 3) consume(0);
+    if constexpr (CH >= 2) consume(1, 1);
+    if constexpr (CH == 3) consume(0, 2);
 
     // ---- 3. cross-wave combine (fixed order) and epilogue by wave 0: the kernel's only barrier
 #pragma unroll
@@ -746,21 +777,23 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
         f32x4 t = red[(0 * SPW + s) * 64 + lane];
 #pragma unroll
         for (int w2 = 1; w2 < NW; ++w2) t += red[(w2 * SPW + s) * 64 + lane];
-        v[s] = t * rstd + (p.bias ? biasv[s] : zero4);
+        v[s] = t * rstd + (EPI && p.bias ? biasv[s] : zero4);
     }
     if (lj < p.M) {
-        if (p.act == ACT_SWIGLU) {
+        if constexpr (KS > 1) {              // raw partial sums of this half (no bias / residual / activation: the consumer adds them to x)
+            *reinterpret_cast<f32x4*>(p.out + (size_t)kh * p.part_stride + (size_t)lj * p.ldo + strip0 * 16 + lq * 4) = v[0];
+        } else if (p.act == ACT_SWIGLU) {
             if constexpr (SPW == 2) {
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (v[0][r] / (1.f + expf(-v[0][r]))) * v[1][r];
-                o += p.res ? resv[0] : zero4;
-                *reinterpret_cast<f32x4*>(p.out + (size_t)lj * p.ldo + blockIdx.x * 16 + lq * 4) = o;
+                o += EPI && p.res ? resv[0] : zero4;
+                *reinterpret_cast<f32x4*>(p.out + (size_t)lj * p.ldo + bidx * 16 + lq * 4) = o;
             }
         } else {
 #pragma unroll
             for (int s = 0; s < SPW; ++s)
-                *reinterpret_cast<f32x4*>(p.out + (size_t)lj * p.ldo + (strip0 + s) * 16 + lq * 4) = v[s] + (p.res ? resv[s] : zero4);
+                *reinterpret_cast<f32x4*>(p.out + (size_t)lj * p.ldo + (strip0 + s) * 16 + lq * 4) = v[s] + (EPI && p.res ? resv[s] : zero4);
         }
     }
 }
@@ -915,6 +948,17 @@ static void launch8f_n(const SkinnyParams& p, hipStream_t st) {
     if (p.norm) QTTS_SK_LAUNCH((skinny8_f32_kernel<SPW, NP, CH, true, NW>), dim3(grid), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
     else QTTS_SK_LAUNCH((skinny8_f32_kernel<SPW, NP, CH, false, NW>), dim3(grid), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
 }
+// split-K producer (two workgroups per strip) and combining consumer (x = x + xp[0] + xp[1]; always a normalised GEMM: q|k|v, gate|up)
+template <int NP, int NW>
+static void launch8f_split(const SkinnyParams& p, hipStream_t st) {
+    const size_t lds = (size_t)NW * 64 * 16 + (size_t)NW * 16 * 4;
+    QTTS_SK_LAUNCH((skinny8_f32_kernel<1, NP, 1, false, NW, 2, false>), dim3(p.N / 16 * 2), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
+}
+template <int SPW, int NP, int NW>
+static void launch8f_comb(const SkinnyParams& p, hipStream_t st) {
+    const size_t lds = (size_t)NW * SPW * 64 * 16 + (size_t)NW * 16 * 4;
+    QTTS_SK_LAUNCH((skinny8_f32_kernel<SPW, NP, 1, true, NW, 1, true>), dim3(p.N / (16 * SPW)), dim3(NW * 64), lds, st, QTTS_SK8_ARGS(p));
+}
 // waves per workgroup and chunks by K (pairs = K / 32): operand registers per pair = 8 SPW + 4, at most ~200 per register set pair.
 //   K    pairs   SPW = 1                     SPW = 2 (SwiGLU)
 //   1024   32    8 waves x 4                 8 waves x 4
@@ -929,6 +973,24 @@ static bool launch8f_spw(const SkinnyParams& p, hipStream_t st) {
 #else
     static const int nw_env = [] { const char* e = getenv("QTTS_SKINNY8F_NW"); return e ? atoi(e) : 0; }();
 #endif
+    if (p.ksplit == 2) {                   // producer: K / 2 per workgroup
+        if constexpr (SPW == 1) {
+            switch (p.K) {
+                case 2048: launch8f_split<4, 8>(p, st); return true;
+                case 3072: launch8f_split<6, 8>(p, st); return true;
+                case 6144: launch8f_split<12, 8>(p, st); return true;
+                default: return false;
+            }
+        }
+        return false;
+    }
+    if (p.xp) {                            // consumer of a split producer
+        switch (p.K) {
+            case 1024: launch8f_comb<SPW, 4, 8>(p, st); return true;
+            case 2048: launch8f_comb<SPW, 4, 16>(p, st); return true;
+            default: return false;
+        }
+    }
     // QTTS_SKINNY8F_NW = 4 | 8 | 16 asks for another wave count where that instantiation exists (A/B)
     switch (p.K) {
         case 1024:
@@ -953,7 +1015,23 @@ static bool launch8f_spw(const SkinnyParams& p, hipStream_t st) {
 bool skinny_f32_inline_norm(int M, int K) {
     return skinny8f_enabled() && M >= 1 && M <= 8 && (K == 1024 || K == 2048 || K == 3072);
 }
+// split-K producer / combining consumer shapes (the engine asks before it plans a layer that way)
+bool skinny_f32_splitk_takes(int M, int K_producer, int K_consumer) {
+    static const bool on = [] { const char* e = getenv("QTTS_SKINNY8F_SPLITK"); return !(e && e[0] == '0'); }();     // (=0: A/B)
+    return on && skinny8f_enabled() && M >= 1 && M <= 8 && (K_producer == 2048 || K_producer == 3072 || K_producer == 6144) &&
+           (K_consumer == 1024 || K_consumer == 2048);
+}
 static bool launch_skinny8_f32(const SkinnyParams& p, int spw, hipStream_t st) {
+    if (p.ksplit == 2 || p.xp) {           // no other kernel implements these: refuse loudly instead of falling through
+        QTTS_REQUIRE(skinny8f_enabled() && p.M <= 8 && !p.x_bf16 && !p.out_bf16 && !p.out16, QTTS_ERR_ARG, "skinny: split-K / combine need the fp32 batch <= 8 kernel");
+        QTTS_REQUIRE(!(p.ksplit == 2 && p.xp), QTTS_ERR_ARG, "skinny: a split-K producer cannot also combine");
+        if (p.ksplit == 2) QTTS_REQUIRE(!p.norm && !p.bias && !p.res && p.act == ACT_NONE && spw == 1, QTTS_ERR_ARG, "skinny: the split-K producer is a plain GEMM");
+        if (p.xp) QTTS_REQUIRE(p.norm && p.x_out && p.x_out != p.x && !p.bias && !p.res, QTTS_ERR_ARG,
+                               "skinny: the combining consumer is a normalised GEMM without bias / residual, writing x_out != x");
+        const bool ok = spw == 2 ? launch8f_spw<2>(p, st) : launch8f_spw<1>(p, st);
+        QTTS_REQUIRE(ok, QTTS_ERR_ARG, "skinny: no split-K / combine instantiation for this K");
+        return true;
+    }
     if (!skinny8f_enabled() || p.M > 8 || p.x_bf16 || p.out_bf16 || p.out16) return false;
     if (spw == 2 && p.K == 6144) return false;
     if (!(p.K == 1024 || p.K == 2048 || p.K == 3072 || p.K == 6144)) return false;

@@ -93,6 +93,27 @@ extern "C" int hostemu_skinny(const float* x, int ldx, int M, const float* W, in
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
+// fp32 batch <= 8, round 4: y = x . W1^T as a split-K PRODUCER (two halves into parts[2][8][N1]), then
+// z = act( rmsnorm(res + half 0 + half 1) . (g (.) W2)^T ) by the COMBINING consumer, which also writes the combined rows to x_out.
+extern "C" int hostemu_skinny_splitk(const float* x, int M, const float* W1, int N1, int K1, const float* res, const float* W2, int N2,
+                                     const float* g, float eps, int act, float* parts, float* x_out, float* z, int ldz) {
+    try {
+        std::vector<unsigned char> w1(qtts::skinny_packed_bytes(N1, K1, false)), w2(qtts::skinny_packed_bytes(N2, N1, false));
+        qtts::pack_skinny_weight(W1, N1, K1, false, w1.data(), nullptr, 16);
+        qtts::pack_skinny_weight(W2, N2, N1, false, w2.data(), g, 16);
+        if (!qtts::skinny_f32_splitk_takes(M, K1, N1)) return -7;
+        qtts::SkinnyParams a{};
+        a.x = x; a.ldx = K1; a.M = M; a.Wp = w1.data(); a.N = N1; a.K = K1; a.fs = 16; a.out = parts; a.ldo = N1; a.act = qtts::ACT_NONE;
+        a.ksplit = 2; a.part_stride = (size_t)8 * N1;
+        qtts::launch_skinny(a, false, nullptr);
+        qtts::SkinnyParams b{};
+        b.x = res; b.ldx = N1; b.M = M; b.Wp = w2.data(); b.N = N2; b.K = N1; b.fs = 16; b.norm = 1; b.eps = eps; b.out = z; b.ldo = ldz; b.act = act;
+        b.xp = parts; b.xp_stride = (size_t)8 * N1; b.x_out = x_out;
+        qtts::launch_skinny(b, false, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { qtts::set_last_error(e.what()); return e.code; } catch (...) { return -1; }
+}
+
 // The bf16 decode GEMM as the frame step launches it: x handed over as the producer's bf16 copy (x_bf16), narrow strips
 // (fs = 16 | 8 | 4), optional bf16 shadow output (out16, same leading dimension as out).
 extern "C" int hostemu_skinny_bf16x(const float* x, int ldx, int M, const float* W, int N, int K, const float* g, int norm, float eps,

@@ -439,6 +439,44 @@ def test_skinny_f32_batch8_kernel_real_source(emu, monkeypatch):
         assert np.all(out[:M, No:] == 7.0) and np.all(out[M] == 7.0)
 
 
+def test_skinny_f32_split_k_producer_and_combining_consumer(emu):
+    """Round 4: the fp32 batch <= 8 o- / down-projections split K over two workgroups per strip (raw halves, no residual) and the
+    next GEMM of the chain forms its x as residual + half 0 + half 1 on the way in, writes the combined rows to another buffer and
+    takes the RMSNorm statistics from them -- against float64 numpy, for the producer K of both stacks (2048, 3072, 6144) and both
+    consumer shapes (K = 1024: 8 waves, K = 2048: 16 waves; plain and SwiGLU)."""
+    g = np.random.default_rng(77)
+    i32, vp = C.c_int32, C.c_void_p
+    emu.hostemu_skinny_splitk.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, C.c_float, i32, vp, vp, vp, i32]
+    for (M, K1, N1, N2, act) in [(8, 2048, 1024, 32, ACT_SWIGLU), (5, 3072, 1024, 16, ACT_NONE), (3, 6144, 2048, 32, ACT_SWIGLU),
+                                 (8, 2048, 2048, 16, ACT_NONE), (1, 3072, 1024, 64, ACT_SWIGLU)]:
+        x = g.standard_normal((M, K1)).astype(np.float32)
+        W1 = (g.standard_normal((N1, K1)) / np.sqrt(K1)).astype(np.float32)
+        res = g.standard_normal((M, N1)).astype(np.float32)
+        W2 = (g.standard_normal((N2, N1)) / np.sqrt(N1)).astype(np.float32)
+        gw = (1 + 0.1 * g.standard_normal(N1)).astype(np.float32)
+        No = N2 // 2 if act == ACT_SWIGLU else N2
+        parts = np.full((2, 8, N1), 3.0, np.float32)
+        x_out = np.full((M + 1, N1), 7.0, np.float32)
+        z = np.full((M + 1, No + 4), 7.0, np.float32)
+        rc = emu.hostemu_skinny_splitk(_ptr(x), M, _ptr(W1), N1, K1, _ptr(res), _ptr(W2), N2, _ptr(gw), 1e-6, act, _ptr(parts), _ptr(x_out), _ptr(z), No + 4)
+        assert rc == 0, ((M, K1, N1), rc, (emu.qtts_last_error() or b"").decode())
+        y64 = x.astype(np.float64) @ W1.astype(np.float64).T
+        h0 = x[:, :K1 // 2].astype(np.float64) @ W1[:, :K1 // 2].astype(np.float64).T
+        assert np.abs(parts[0, :M] - h0).max() <= 2e-5 and np.abs(parts[0, :M] + parts[1, :M] - y64).max() <= 4e-5
+        assert np.all(parts[:, M:] == 3.0)                                   # rows >= M are nobody's
+        h = res.astype(np.float64) + y64
+        assert np.abs(x_out[:M] - h).max() <= 4e-5 and np.all(x_out[M] == 7.0)
+        # bit-level: the combined row IS (res + half 0) + half 1 in fp32, in that order
+        assert np.array_equal(x_out[:M], (res + parts[0, :M]) + parts[1, :M])
+        acc = (h / np.sqrt((h ** 2).mean(1, keepdims=True) + 1e-6)) @ (W2 * gw).astype(np.float64).T
+        if act == ACT_SWIGLU:
+            a = acc.reshape(M, N2 // 32, 2, 16)
+            acc = ((a[:, :, 0] / (1 + np.exp(-a[:, :, 0]))) * a[:, :, 1]).reshape(M, No)
+        err = float(np.abs(z[:M, :No] - acc).max())
+        assert err <= 3e-5 * max(1.0, float(np.abs(acc).max())), (M, K1, N1, N2, act, err)
+        assert np.all(z[:M, No:] == 7.0) and np.all(z[M] == 7.0)
+
+
 def test_skinny_bf16_kernel_frame_step_shapes(emu):
     """skinny2_kernel the way the frame step launches it: x as the producer's bf16 copy, the real models' K (every wave owns the
     same number of k-tiles: the branch-free EXACT instantiations, one / two / three chunks), narrow strips (4 / 8 / 16
@@ -1299,6 +1337,38 @@ def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
             assert np.array_equal(part, whole[half])
     finally:
         emu.hostemu_set_real_gemm(1 if FULL else 0)
+        emu.qtts_talker_destroy(h)
+
+
+def test_talker_fp32_split_k_layer_chain_vs_oracle(emu):
+    """Round 4: the ENGINE side of the fp32 split-K plan -- which GEMM of a layer splits, which one combines, which of the two
+    residual buffers is current, the unsplit last layer writing where the caller reads -- at the real layer widths (hidden 1024,
+    intermediate 3072, q width 2048: the 0.6B talker's and the code predictor's), which is where the plan engages; three layers per
+    stack (first / middle / last take different branches), three code groups (pass 0 with two new tokens, pass 1 with its q|k|v row
+    from the table).  Greedy fp32 against the oracle, and the same with QTTS_SKINNY8F_SPLITK=0 semantics checked by the oracle."""
+    import talker_ref
+    t = synth.TalkerCfg(vocab_size=1280, hidden_size=1024, intermediate_size=3072, num_hidden_layers=3, num_attention_heads=16,
+                        num_key_value_heads=8, head_dim=128, num_code_groups=3, text_hidden_size=64, text_vocab_size=512,
+                        cp_vocab_size=64, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=3,
+                        cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128,
+                        codec_eos_token_id=358, codec_think_id=362, codec_nothink_id=363, codec_think_bos_id=364, codec_think_eos_id=365,
+                        codec_pad_id=356, codec_bos_id=357, im_start_token_id=500, im_end_token_id=501, tts_pad_token_id=502,
+                        tts_bos_token_id=503, tts_eos_token_id=504, spk_id={"vivian": 1200}, spk_is_dialect={"vivian": False},
+                        codec_language_id={"english": 301})
+    wn = synth.talker_weights(t, with_text=False)
+    w = {k: torch.from_numpy(v) for k, v in wn.items()}
+    lens = [4, 2, 3]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(19), t, lens, 2, scale=0.5)
+    sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
+    with torch.no_grad():
+        r = talker_ref.talker_generate(w, t, emb, mask, tr, pad, max_new_tokens=4, sp=sp)
+    h = _talker_emu(emu, t, w, max_batch=3, max_seq=32)
+    try:
+        codes, tokens, hidden = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=4)
+        assert np.array_equal(tokens, r["tokens"].numpy()) and np.array_equal(codes, r["codes"].numpy())
+        ref_h = r["hidden"].numpy()
+        assert np.abs(hidden - ref_h).max() <= 2e-4 * max(1.0, float(np.abs(ref_h).max()))
+    finally:
         emu.qtts_talker_destroy(h)
 
 
