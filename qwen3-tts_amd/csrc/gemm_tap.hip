@@ -622,6 +622,146 @@ static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo, cap);
 }
 
+// ---- round 4: gemm_dma -- the bf16-activation tap GEMM with BOTH operands staged by LDS-DMA (global_load_lds, 16 B per lane).
+// gemm_tap2 / gemm_wide move every tile global -> VGPRs -> ds_write -> LDS: the staging registers, the write pass and (gemm_wide) a
+// second barrier per k-step are what the guide's "128 x 128, two barriers per step" structure spends its time on (~25 % MFMA-busy
+// on the codec's C = 768 / 384 units and on the batch-32 prefill, profiles/r03_pmc_mfma_codec.md).  Here a k-step is
+//     __syncthreads()            -- step s's tiles have landed (the barrier's fence drains the DMA queue), step s - 1 is consumed
+//     request step s + 1's tiles -- W [BN][64] of (slab, tap), and the A tile [128 + halo][64] when the slab changes
+//     32 MFMAs per wave from the tiles of step s
+// -- one barrier, no staging registers, the next step's bytes in flight under this step's MFMAs.  LDS rows keep gemm_tap2's
+// 144-byte stride (64 bf16 + 16 B: consecutive rows shift by 4 banks); an LDS-DMA writes lane-linear (wave-uniform base + 16 lane),
+// so the padded image is produced by giving every lane the SOURCE address of the LDS byte it fills (resunit.hip's scheme): byte o
+// of a buffer is (row, col) = divmod(o, 144), pad bytes and rows past the tile re-fetch a valid element that nobody reads.
+// Sequence-start zeroing, tap offsets, epilogue: exactly gemm_tap2's.
+__device__ __forceinline__ void gd_dma16(const void* src, void* lds_dst) {       // 64 lanes x 16 B -> 1 KiB of LDS, lane-linear
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmTapParams p, int halo, int a_stride /* bytes of one A buffer, multiple of 1024 */) {
+    constexpr int BM = 128, BK = 64;
+    constexpr int TM = 4, TN = BN / 32;
+    constexpr int STR = BK + 8, RS = STR * 2;          // LDS row: 72 bf16 = 144 B
+    constexpr int W_BYTES = (BN * RS + 1023) / 1024 * 1024;
+    constexpr int NWC = W_BYTES / 1024;                // 1-KiB chunks of a W buffer
+    constexpr int WPW = (NWC + 3) / 4;                 // ... per wave
+    constexpr int APW = ((BM + 56) * RS / 1024 + 1 + 3) / 4;      // A chunks per wave at the largest halo
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gd[];
+    unsigned char* Abuf = smem_gd;                     // [2][a_stride]
+    unsigned char* Wbuf = smem_gd + 2 * a_stride;      // [2][W_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n_tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {   // XCD-aware tile order (as gemm_tap_kernel)
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / n_tiles_n) * BM;
+    const int n0 = (bid % n_tiles_n) * BN;
+    const int arows = BM + halo;
+    const int nac = (arows * RS + 1023) / 1024;        // chunks of an A buffer actually filled
+    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(p.A16);
+    const unsigned char* Wg = reinterpret_cast<const unsigned char*>(p.W);
+
+    // per-lane source offsets (bytes, without the k-slab / tap terms) of the chunks this wave requests: chunk c = wave + 4 i
+    size_t a_off[APW], w_off[WPW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int o = (wave + 4 * i) * 1024 + lane * 16;
+        int row = o / RS;
+        const int col = o - row * RS;
+        row = row < arows ? row : arows - 1;
+        int gr = m0 - halo + row;
+        gr = gr < 0 ? 0 : (gr >= p.M ? p.M - 1 : gr);
+        a_off[i] = (size_t)gr * p.lda * 2 + (col < BK * 2 ? col : 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int o = (wave + 4 * i) * 1024 + lane * 16;
+        int row = o / RS;
+        const int col = o - row * RS;
+        row = row < BN ? row : BN - 1;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        w_off[i] = (size_t)gn * p.K * 2 + (col < BK * 2 ? col : 0);
+    }
+    auto dma_a = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < APW; ++i)
+            if (wave + 4 * i < nac) gd_dma16(A16 + a_off[i] + (size_t)ks * (BK * 2), Abuf + buf * a_stride + (wave + 4 * i) * 1024);
+    };
+    auto dma_w = [&](int ks, int tap, int buf) {
+        const unsigned char* W = Wg + ((size_t)tap * p.N * p.K + (size_t)ks * BK) * 2;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i)
+            if (wave + 4 * i < NWC) gd_dma16(W + w_off[i], Wbuf + buf * W_BYTES + (wave + 4 * i) * 1024);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int tpos[TM];                                      // position of this lane's output rows inside their sequence
+#pragma unroll
+    for (int i = 0; i < TM; ++i) tpos[i] = (m0 + wm * 64 + i * 16 + li) % p.T;
+
+    const int kslabs = p.K / BK;
+    const int nsteps = kslabs * p.taps;
+    dma_a(0, 0);
+    dma_w(0, 0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int ks = s / p.taps, tap = s - ks * p.taps;
+        __syncthreads();                               // step s's tiles are in LDS; every wave is done with step s - 1's
+        if (s + 1 < nsteps) {
+            const int ks2 = (s + 1) / p.taps, tap2 = (s + 1) - ks2 * p.taps;
+            dma_w(ks2, tap2, (s + 1) & 1);             // (last read in step s - 1)
+            if (ks2 != ks) dma_a(ks2, ks2 & 1);        // (last read in the last step of slab ks - 1)
+        }
+        const bf16_t* Ab = reinterpret_cast<const bf16_t*>(Abuf + (ks & 1) * a_stride);
+        const bf16_t* Wb = reinterpret_cast<const bf16_t*>(Wbuf + (s & 1) * W_BYTES);
+        const int sh = p.shift[tap];                   // <= 0: output row m reads staged row (m - m0) + halo + sh
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(&Ab[(wm * 64 + i * 16 + li + halo + sh) * STR + kk * 32 + lq * 8]);
+                if (tpos[i] + sh < 0) a[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};      // before the start of its own sequence
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(&Wb[(wn * (BN / 2) + j * 16 + li) * STR + kk * 32 + lq * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);
+}
+
+template <int BN>
+static void launch_dma(const GemmTapParams& p, int halo, hipStream_t st) {
+    const int nb = cdiv(p.M, 128) * cdiv(p.N, BN);
+    const int a_stride = ((128 + halo) * 144 + 1023) / 1024 * 1024;
+    const size_t lds = 2 * (size_t)a_stride + 2 * (size_t)((BN * 144 + 1023) / 1024 * 1024);
+    auto kern = gemm_dma_kernel<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo, a_stride);
+}
+
 template <int BM, int BN, bool A16, int BK>
 static void launch_wide_k(const GemmTapParams& p, hipStream_t st) {
     const int nb = cdiv(p.M, BM) * cdiv(p.N, BN);
@@ -713,6 +853,14 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         !p.R16 && (cdiv(p.M, 128) * cdiv(p.N, 128) <= wide_max_tiles || p.act == ACT_SWIGLU)) {       // (the tap-reuse kernel has no SwiGLU epilogue)
         // bf16 activations into a SMALL grid (the talker prefill): the deep-k kernel reading the bf16 copy
         if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "gemm_tap: swiglu needs N % 32 == 0");
+        {   // QTTS_GEMM_DMA=1 | 2: the LDS-DMA kernel for the plain bf16 Linear too (2: only here) -- A/B
+            const int dma_env2 = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : 0; }();
+            if ((dma_env2 == 1 || dma_env2 == 2) && p.N % 128 == 0 && p.K % 64 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 128) {
+                launch_dma<128>(p, 0, st);
+                QTTS_CHECK_HIP(hipGetLastError());
+                return;
+            }
+        }
         launch_wide<true>(p, p.N % 128 == 0 ? 128 : 64, st);
         QTTS_CHECK_HIP(hipGetLastError());
         return;
@@ -738,6 +886,9 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
             return n;
         }();
+        // QTTS_GEMM_DMA=1: the LDS-DMA kernel for every 128-column launch of this path (A/B; default off until measured)
+        const int dma_env = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : 0; }();
+        if (dma_env == 1 && bn2 == 128 && p.K % 64 == 0) { launch_dma<128>(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
         const int tiles = cdiv(p.M, 128) * cdiv(p.N, bn2);
         const bool bk64 = p.K % 64 == 0 && bn2 == 128 && (bk_env == 64 || (bk_env == 0 && tiles <= n_cu2));
         if (bk64) launch_tap2<128, 64>(p, halo, st);

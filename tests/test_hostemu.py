@@ -307,6 +307,52 @@ def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
             assert np.all(out16[:, N:] == 0x4242)
 
 
+def test_gemm_dma_lds_dma_staged_kernel_real_source(emu, monkeypatch):
+    """gemm_dma (round 4): gemm_tap2's arithmetic with both operands staged by LDS-DMA into two buffers -- per-lane source addresses
+    that produce the padded 144-byte-row LDS image, 64-wide k-slabs, one barrier per step, the A tile re-staged only when the slab
+    changes -- against float64 numpy: 7-tap convolutions at dilation 1 and 9 (halo 54, several sequences per tile, ragged last
+    tile), the two-tap transposed-conv form, a plain Linear with residual and both outputs.  (The emulator completes a DMA at
+    once: what it checks is addressing and bookkeeping; the barrier / DMA ordering is checked on the MI355X.)"""
+    monkeypatch.setenv("QTTS_GEMM_DMA", "1")
+    g = np.random.default_rng(48)
+    cases = [  # M, T, N, K, shifts, act, bias, res, out32, out16, snake16
+        (300, 100, 128, 128, [-6, -5, -4, -3, -2, -1, 0], ACT_SNAKE, 1, 0, 0, 1, 0),
+        (200, 50, 128, 192, [-54, -45, -36, -27, -18, -9, 0], ACT_SNAKE, 1, 0, 0, 1, 0),
+        (260, 130, 256, 64, [0], ACT_NONE, 1, 1, 1, 1, 1),
+        (150, 75, 256, 128, [-1, 0], ACT_NONE, 1, 0, 1, 1, 1),
+        (129, 43, 128, 320, [-18, -15, -12, -9, -6, -3, 0], ACT_NONE, 0, 0, 1, 0, 0),
+    ]
+    for (M, T, N, K, shift, act, hb, hr, o32, o16, s16) in cases:
+        A = (g.standard_normal((M, K + 8)) * 0.5).astype(np.float32)
+        Av, Abits = _bf16_round(A)
+        W = (g.standard_normal((len(shift), N, K)) / np.sqrt(K * len(shift))).astype(np.float32)
+        Wv, Wbits = _bf16_round(W)
+        bias = g.standard_normal(N).astype(np.float32) if hb else None
+        res = g.standard_normal((M, N)).astype(np.float32) if hr else None
+        ea = np.exp(g.standard_normal(N) * 0.3).astype(np.float32)
+        ib = (1 / (np.exp(g.standard_normal(N) * 0.3) + 1e-9)).astype(np.float32)
+        ea16 = np.exp(g.standard_normal(N) * 0.3).astype(np.float32)
+        ib16 = (1 / (np.exp(g.standard_normal(N) * 0.3) + 1e-9)).astype(np.float32)
+        want = _gemm_tap_ref(Av[:, :K], T, Wv, shift, bias, None, res, ea, ib, act)
+        want16 = want + ib16 * np.sin(want * ea16) ** 2 if s16 else want
+        out = np.full((M, N + 8), 7.0, np.float32)
+        out16 = np.full((M, N + 8), 0x4242, np.uint16)
+        sh = (C.c_int32 * len(shift))(*shift)
+        rc = emu.hostemu_gemm_tap16(Abits.ctypes.data_as(C.c_void_p), K + 8, M, T, _ptr(Wbits), N, K, len(shift), sh,
+                                    _ptr(bias) if hb else None, _ptr(res) if hr else None, N, _ptr(ea), _ptr(ib), act,
+                                    _ptr(out) if o32 else None, N + 8, out16.ctypes.data_as(C.c_void_p) if o16 else None,
+                                    _ptr(ea16) if s16 else None, _ptr(ib16) if s16 else None)
+        assert rc == 0, ((M, N, K, shift, act), (emu.qtts_last_error() or b"").decode())
+        tol = 2e-3 * max(1.0, float(np.abs(want).max()))
+        if o32:
+            assert np.abs(out[:, :N] - want).max() <= tol, (M, N, K, shift, act, float(np.abs(out[:, :N] - want).max()))
+            assert np.all(out[:, N:] == 7.0)
+        if o16:
+            got = (out16[:, :N].astype(np.uint32) << 16).view(np.float32)
+            assert np.abs(got - want16).max() <= 1e-2 * max(1.0, float(np.abs(want16).max())), (M, N, K, shift, float(np.abs(got - want16).max()))
+            assert np.all(out16[:, N:] == 0x4242)
+
+
 @pytest.mark.parametrize("C,M,T,dil", [(96, 600, 300, 1), (96, 300, 100, 9), (96, 77, 77, 3), (192, 300, 150, 9), (192, 130, 65, 1)])
 def test_resunit_fused_kernel_real_source(emu, C, M, T, dil):
     """resunit.hip's fused residual unit (round 3: conv7 -> SnakeBeta -> conv1x1 -> + residual in ONE kernel, weights pre-packed into
