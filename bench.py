@@ -517,17 +517,33 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
     if elem_bytes != 2:            # (the parity-mode leg: no PMC pass and no isolated replay for the fp32 engine)
         out["traffic"] = None
         return out
-    # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), x2 gfx950 correction
+    # HBM bytes per launch: the round's own rocprofv3 --pmc FETCH_SIZE pass (separate pass, x1024 x2: MI355X_MICROARCH.md), reduced by
+    # tools/pmc_traffic.py to a traffic / algorithmic ratio over the skinny8_kernel dispatches and STAMPED with a digest of the kernel
+    # and engine sources: a tree whose digest differs reports `traffic: null` instead of a stale number.  The same
+    # file carries `frac_rocprof`, the fraction rocprofv3's kernel trace of the bench command gives for the same launches.
     traffic, traffic_src = None, None
     try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_traffic
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             tj = json.load(f)
-        traffic = tj.get(model, {}).get("bytes_per_launch")
-        traffic_src = ("profiles/pmc_traffic.json (builder-run rocprofv3 --pmc FETCH_SIZE pass: "
-                       + str(tj.get(model, {}).get("source", tj.get("source", "see profiles/"))) + "), not measured by this run")
-    except Exception:
-        pass
+        rec = tj.get(model, {})
+        if tj.get("kernel_digest") != pmc_traffic.kernel_digest():
+            traffic_src = (f"profiles/pmc_traffic.json is STALE (taken on kernel digest {tj.get('kernel_digest')}, this tree is "
+                           f"{pmc_traffic.kernel_digest()}): re-run the PMC pass (tools/pmc_traffic.py)")
+        elif "ratio_traffic_over_algorithmic" in rec:
+            traffic = round(out["algorithmic_bytes_per_launch"] * rec["ratio_traffic_over_algorithmic"])
+            traffic_src = (f"builder-run rocprofv3 --pmc FETCH_SIZE pass on this tree's kernels ({rec.get('source')}; digest "
+                           f"{tj['kernel_digest']}): traffic / algorithmic = {rec['ratio_traffic_over_algorithmic']} over {rec['dispatches']} "
+                           "skinny8_kernel dispatches; not measured by this run")
+            if "frac_rocprof" in rec:
+                out["frac_rocprof"] = rec["frac_rocprof"]
+                out["rocprof_avg_launch_us"] = rec["rocprof_avg_launch_us"]
+                out["frac_live_over_rocprof"] = round(out["frac"] / rec["frac_rocprof"], 4)
+    except Exception as e:
+        traffic_src = f"unavailable ({type(e).__name__}: {e})"
     out["traffic"], out["traffic_source"] = traffic, traffic_src
+    out["frac_live"] = out["frac"]
     try:          # continuity with rounds 1-2: the same launches replayed in isolation (no attention / sampler / glue nodes between them)
         talker.set_profile(2)
         talker.generate(emb, mask, trailing, pad, seed=7, **dict(gen_kw, max_new_tokens=9, min_new_tokens=9))

@@ -853,7 +853,9 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         !p.R16 && (cdiv(p.M, 128) * cdiv(p.N, 128) <= wide_max_tiles || p.act == ACT_SWIGLU)) {       // (the tap-reuse kernel has no SwiGLU epilogue)
         // bf16 activations into a SMALL grid (the talker prefill): the deep-k kernel reading the bf16 copy
         if (p.act == ACT_SWIGLU) QTTS_REQUIRE(p.N % 32 == 0, QTTS_ERR_ARG, "gemm_tap: swiglu needs N % 32 == 0");
-        {   // QTTS_GEMM_DMA=1 | 2: the LDS-DMA kernel for the plain bf16 Linear too (2: only here) -- A/B
+        {   // QTTS_GEMM_DMA=1 | 2: the LDS-DMA kernel for the plain bf16 Linear too (2: only here) -- A/B only: on the prefill's shapes it wins
+            // where N is wide (q|k|v 0.87x, 4096^3 0.90x) and loses where K is deep and the grid small (o 1.13x, down 1.11x); first packet
+            // 31.9 -> 32.6 ms with it (profiles/r04_gemm_dma.md), so the tile chooser's kernel stays
             const int dma_env2 = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : 0; }();
             if ((dma_env2 == 1 || dma_env2 == 2) && p.N % 128 == 0 && p.K % 64 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 128) {
                 launch_dma<128>(p, 0, st);
@@ -886,9 +888,10 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
             return n;
         }();
-        // QTTS_GEMM_DMA=1: the LDS-DMA kernel for every 128-column launch of this path (A/B; default off until measured)
-        const int dma_env = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : 0; }();
-        if (dma_env == 1 && bn2 == 128 && p.K % 64 == 0) { launch_dma<128>(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
+        // The LDS-DMA kernel for every 128-column launch of this path (the codec's C = 768 / 384 units and transposed convolutions):
+        // measured 2.70 -> 2.54 ms at B = 1 x 10 s and 10.23 -> 9.96 ms at 8 x 10 s (profiles/r04_gemm_dma.md).  QTTS_GEMM_DMA=0: gemm_tap2.
+        const int dma_env = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : -1; }();
+        if (dma_env != 0 && bn2 == 128 && p.K % 64 == 0) { launch_dma<128>(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
         const int tiles = cdiv(p.M, 128) * cdiv(p.N, bn2);
         const bool bk64 = p.K % 64 == 0 && bn2 == 128 && (bk_env == 64 || (bk_env == 0 && tiles <= n_cu2));
         if (bk64) launch_tap2<128, 64>(p, halo, st);
