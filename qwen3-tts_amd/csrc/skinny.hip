@@ -70,14 +70,6 @@ __device__ inline void skinny_store4(const SkinnyParams& p, int row, int col, co
     } else *reinterpret_cast<f32x4*>(p.out + (size_t)row * p.ldo + col) = o;
 }
 
-// DPP row rotation by 8 lanes of a 4-register operand (lane lj <- lane lj ^ 8 of its 16-lane row)
-__device__ inline u32x4 dpp_ror8(const u32x4& v) {
-    u32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[e], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
-    return r;
-}
-
 // ------------------------------------------------------------------------------------------ bf16 (the benchmarked mode)
 // FS = output features per strip (16 | 8 | 4).  Narrow strips put GEMMs with few output features on all 256 CUs (a CU pulls
 // only ~25 GB/s); lanes with (lane & 15) >= FS carry no weights and their MFMA rows are ignored.
@@ -87,15 +79,8 @@ __device__ inline u32x4 dpp_ror8(const u32x4& v) {
 // requests; the generic variant guards the tail tile by tile (tiny test dimensions, odd K).
 // NCH > 0 (EXACT only): the number of chunks is a compile-time constant (1..3) and the whole kernel is straight-line code -- no
 // branch, hence no register merge (a merge copy of a load result waits for that load) between the request bursts.
-// PAIRX (round 4; EXACT, bf16 x, U even, M > 16): at batch 17..64 the x rows are what a workgroup pulls (32 rows x K x 2 B against 8-32 x K x 2 B
-// of weights) and a B-operand-shaped request -- 16 rows x 64 B -- touches 16 HALF cache lines.  Here a wave owns PAIRS of adjacent k-tiles
-// (tiles 2 P, 2 P + 1 with P = wave + NW i) and requests the x rows of a pair as WHOLE 128-byte lines: per m-tile one request for rows 0..7
-// and one for rows 8..15, lane (lj, lq) reading row (lj & 7), 16-B piece lq + 4 (lj >> 3).  The two B fragments of the pair are put together
-// from the two registers by a DPP row rotation and a select (16 VALU instructions per pair and m-tile).  Same bytes, same number of requests,
-// half the cache lines touched per request (MI355X guide: fragment-shaped activation loads cost +18..45 % at M = 256).
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH, bool PAIRX = false>
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
 __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
-    static_assert(!PAIRX || (XB16 && EXACT && U % 2 == 0), "PAIRX: bf16 x, exact tile counts, whole pairs per chunk");
     constexpr int KT = 32;                                       // k per tile
     constexpr int NS = SPW * MT + MT;                            // accumulators per wave: the GEMM's + one X.X^T per m-tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
@@ -109,8 +94,6 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     const int my_tiles = (nkt - wave + NW - 1) / NW;             // tile = wave + NW*i  (0: this wave has nothing to do)
     const int nchunks = (my_tiles + U - 1) / U;
     const int strip0 = blockIdx.x * SPW;
-    // k-tile owned by this wave as its i-th: round-robin singles, or (PAIRX) round-robin PAIRS of adjacent tiles
-    auto tile_of = [&](int i) -> int { return PAIRX ? 2 * (wave + NW * (i >> 1)) + (i & 1) : wave + NW * i; };
 
     f32x4 acc[SPW][MT], acc_ss[MT];
 #pragma unroll
@@ -135,21 +118,12 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     const unsigned short* xp16[MT];
     const float* xp32[MT];
     bool xlane[MT];
-    // PAIRX: the two whole-line requests of m-tile m (rows 16 m + (lj & 7) and + 8), piece lq + 4 (lj >> 3) of the pair's 128 B
-    const unsigned short* xpl[MT][2];
-    bool xll[MT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         xlane[m] = m * 16 + lj < p.M;
         const int row = xlane[m] ? m * 16 + lj : 0;
         xp16[m] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)row * p.ldx + lq * 8;
         xp32[m] = p.x + (size_t)row * p.ldx + lq * 8;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r2 = m * 16 + 8 * h + (lj & 7);
-            xll[m][h] = r2 < p.M;
-            xpl[m][h] = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(xll[m][h] ? r2 : 0) * p.ldx + (lq + 4 * (lj >> 3)) * 8;
-        }
     }
     // perf ablation (DEBUG): "no weight stream" / "no x fetch" collapse the tile stride to 0 -- every request of a wave then hits
     // one resident line -- so that the instruction stream is unchanged
@@ -178,26 +152,14 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int s = 0; s < SPW; ++s) w[s][u] = wload(wbase[s] + (size_t)tile_of(c * U + u) * wstep);
+                    for (int s = 0; s < SPW; ++s) w[s][u] = wload(wbase[s] + (size_t)(wave + NW * (c * U + u)) * wstep);
             }
-            if constexpr (PAIRX) {                               // xq[m][2 v] = rows 0..7, xq[m][2 v + 1] = rows 8..15 of pair v, whole lines
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        if (xll[m][h]) {
-#pragma unroll
-                            for (int v = 0; v < U / 2; ++v)
-                                xq[m][2 * v + h] = *reinterpret_cast<const u32x4*>(xpl[m][h] + tile_of(c * U + 2 * v) * xstep);
-                        }
-            } else {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 if (xlane[m]) {                                  // one exec mask per m-tile for its x requests
 #pragma unroll
-                    for (int u = 0; u < U; ++u) xq[m][u] = load_x(m, tile_of(c * U + u));
+                    for (int u = 0; u < U; ++u) xq[m][u] = load_x(m, wave + NW * (c * U + u));
                 }
-            }
         } else {
             const int n = my_tiles - c * U;                      // wave-uniform: tiles of this chunk that exist
 #pragma unroll
@@ -273,35 +235,8 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
             if (p.norm) acc_ss[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, xb, acc_ss[m], 0, 0, 0);
         }
     };
-    // PAIRX: B fragments of the pair's two tiles from the two whole-line registers: even tile = rows 0..7 in place | rows 8..15 rotated up,
-    // odd tile = rows 0..7 rotated down | rows 8..15 in place
-    auto compute_pair = [&](u32x4 (&w)[SPW][U], u32x4 (&xq)[MT][U], int v) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const u32x4 lo = xq[m][2 * v], hi = xq[m][2 * v + 1];
-            const u32x4 lor = dpp_ror8(lo), hir = dpp_ror8(hi);
-            u32x4 xe, xo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { xe[e] = lj < 8 ? lo[e] : hir[e]; xo[e] = lj < 8 ? lor[e] : hi[e]; }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                bf16x8 xb;
-                *reinterpret_cast<u32x4*>(&xb) = t == 0 ? xe : xo;
-#pragma unroll
-                for (int s = 0; s < SPW; ++s) {
-                    bf16x8 wa;
-                    *reinterpret_cast<u32x4*>(&wa) = w[s][2 * v + t];
-                    acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[s][m], 0, 0, 0);
-                }
-                if (p.norm) acc_ss[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, xb, acc_ss[m], 0, 0, 0);
-            }
-        }
-    };
     auto compute_chunk = [&](u32x4 (&w)[SPW][U], u32x4 (&xq)[MT][U], int c) {
-        if constexpr (PAIRX) {
-#pragma unroll
-            for (int v = 0; v < U / 2; ++v) compute_pair(w, xq, v);
-        } else if constexpr (EXACT) {
+        if constexpr (EXACT) {
 #pragma unroll
             for (int u = 0; u < U; ++u) compute_tile(w, xq, u);
         } else {
@@ -394,6 +329,12 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
 //     skinny2_kernel, different ones after every edit).  Rows >= M re-read row 0, absent residual / bias operands read x; the
 //     epilogue selects.
 // NP = pairs per wave (K = 512 NP), NORM: RMSNorm folded in (acc_ss rides on the matrix pipe as in skinny2_kernel).
+__device__ inline u32x4 dpp_ror8(const u32x4& v) {
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[e], 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+    return r;
+}
 
 // Kernel arguments (round 3, measured -2.7 % per frame, profiles/r03_ab_kpre.md): a by-value struct argument is never preloaded into
 // SGPRs by the compiler's kernarg-preload feature (`-mllvm -amdgpu-kernarg-preload-count=16`, build.py FLAGS: the first 14 dwords
@@ -863,12 +804,12 @@ bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <
 // ACT_SWIGLU8 lives in skinny8_kernel only: the K for which that kernel is instantiated (launch8_nw)
 bool skinny_swiglu8_takes(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
 
-template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH, bool PAIRX = false>
+template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT, int NCH>
 static void launch2_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);
     const size_t lds = (size_t)NW * (SPW * MT + MT) * 64 * 16;
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "skinny: LDS budget exceeded");
-    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH, PAIRX>;
+    auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH>;
     static bool attr_set = false;          // one flag per instantiation
     if (lds > 48 * 1024 && !attr_set) {
         QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -891,19 +832,6 @@ static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
     if constexpr (EXACT && MT == 2 && XB16 && NW == 8) {
         const char* e = QTTS_ENV("QTTS_SKINNY2_STRAIGHT_MT2");
         if (!(e && e[0] == '0')) {
-            // Round 4: whole-line x requests over pairs of adjacent k-tiles (PAIRX; chunks hold whole pairs: U even).  QTTS_SKINNY2_PAIRX=0:
-            // fragment-shaped requests (A/B).
-            const char* ep = QTTS_ENV("QTTS_SKINNY2_PAIRX");
-            if constexpr (U % 2 == 0) {
-                if (!(ep && ep[0] == '0')) {
-                    if (nchunks == 1) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 1, true>(p, st); return; }
-                    if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2, true>(p, st); return; }
-                    if (nchunks == 3) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 3, true>(p, st); return; }
-                    if constexpr (SPW == 2) {
-                        if (nchunks == 4) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 4, true>(p, st); return; }
-                    }
-                }
-            }
             if (nchunks == 1) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 1>(p, st); return; }
             if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2>(p, st); return; }
             if (nchunks == 3) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 3>(p, st); return; }
@@ -911,10 +839,6 @@ static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
                 if (nchunks == 4) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 4>(p, st); return; }
             }
         }
-    }
-    if constexpr (EXACT && MT == 2 && XB16 && NW == 8 && U % 2 == 0) {      // (more chunks than the straight-line kernels hold: K = 6144)
-        const char* ep = QTTS_ENV("QTTS_SKINNY2_PAIRX");
-        if (!(ep && ep[0] == '0')) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 0, true>(p, st); return; }
     }
     launch2_n<MT, SPW, NW, FS, XB16, U, EXACT, 0>(p, st);
 }

@@ -263,11 +263,10 @@ def test_gemm_wide_tile_chooser_follows_its_three_bounds(emu):
         emu.qtts_debug_gemm_wide_tile(-1)
 
 
-def test_gemm_tap2_tap_reuse_kernel_real_source(emu, monkeypatch):
+def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
     """gemm_tap2 (round 2, the codec decoder's bf16 GEMM): bf16 input tile staged once per k-slab with its causal halo and reused
     by every tap, sequence-start zeroing applied in the operand registers (tiles that span two sequences included), k-slabs of
     64 and 96, two LDS buffers, fp32 and / or bf16 output with the consumer's SnakeBeta folded in -- against float64 numpy."""
-    monkeypatch.setenv("QTTS_GEMM_DMA", "0")          # (round 4: 128-column launches default to gemm_dma_kernel, tested below)
     g = np.random.default_rng(47)
     cases = [  # M, T, N, K, shifts, act, bias, res, out32, out16, snake16
         (300, 100, 96, 96, [-6, -5, -4, -3, -2, -1, 0], ACT_SNAKE, 1, 0, 0, 1, 0),       # conv7 (d = 1) + act2 -> bf16 only
@@ -541,10 +540,6 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
              (20, 32, 3072, 8, 0, ACT_NONE, 1, 1, 0),     # cp down at batch 20: three chunks, ragged second m-tile
              (32, 64, 1024, 16, 1, ACT_SWIGLU, 0, 0, 0),  # cp gate|up at batch 32: strip pairs, two chunks of 2
              (27, 64, 2048, 16, 1, ACT_SWIGLU, 0, 1, 0),  # talker gate|up: strip pairs, four chunks of 2
-             # round 4: the same four + the talker's down-projection (six chunks: the loop kernel) also run with whole-line x requests over
-             # pairs of adjacent k-tiles (PAIRX, the default at batch 17..32; QTTS_SKINNY2_PAIRX=0 below = the fragment-shaped requests)
-             (32, 32, 6144, 8, 0, ACT_NONE, 0, 1, 1),     # talker down at batch 32: six chunks of 4
-             (19, 32, 6144, 16, 1, ACT_NONE, 1, 0, 0),    # ... ragged second m-tile, normalised, bias
              (3, 48, 160, 16, 1, ACT_NONE, 1, 0, 0),      # odd K: generic (guarded) instantiation, 4 waves
              # skinny8_kernel (batch <= 8: tile pairs, whole-line x requests, DPP-rotated odd tiles) beyond the cases above
              (5, 32, 2048, 8, 1, ACT_NONE, 1, 1, 1),      # 5 rows (rows 5..7 re-read row 0), 8-feature strips, norm + bias + res + shadow
@@ -554,13 +549,7 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
              # round 3: SwiGLU in ONE strip (8 gate + 8 up rows; twice the workgroups of the strip pairs), batch <= 8 only
              (8, 64, 2048, 16, 1, ACT_SWIGLU8, 0, 0, 0),  # talker gate|up-like
              (3, 48, 1024, 16, 1, ACT_SWIGLU8, 0, 1, 0)]  # code-predictor-like, 3 rows, with a residual
-    for (M, N, K, fs, norm, act, hb, hr, sh), s8 in [(c, v) for c in cases for v in ("1", "0", "p0")]:
-        os.environ.pop("QTTS_SKINNY2_PAIRX", None)
-        if s8 == "p0":                                    # batch 17..32 once more without the whole-line x requests
-            if not (16 < M <= 32):
-                continue
-            os.environ["QTTS_SKINNY2_PAIRX"] = "0"
-            s8 = "1"
+    for (M, N, K, fs, norm, act, hb, hr, sh), s8 in [(c, v) for c in cases for v in ("1", "0")]:
         if s8 == "0" and (act == ACT_SWIGLU8 or not (M <= 8 and K % 512 == 0 and fs >= 8)):
             continue                                      # (QTTS_SKINNY8=0: the same shapes through skinny2_kernel)
         os.environ["QTTS_SKINNY8"] = s8
