@@ -45,44 +45,6 @@ struct qtts_codec {
     Snake final_act;
     DevBuf final_w; float final_b = 0.f; int final_c = 0;
 
-    // ---- round 4: the pre_transformer at <= 128 rows (a B = 1 x 10 s decode, the 32-stream first packet) as WEIGHT-STREAMING strips.
-    // Its 40 GEMMs are 125-128 rows x 512-3072 columns x 512-1024 deep: as 64 x 64 tiles they were 16-48 workgroups walking 2-8 k-steps
-    // each, 17 us per launch (profiles/r04_codec_kernel_trace_b1x125.md) for 1-6 MB of weights.  The decode GEMM of the talker
-    // (skinny.hip, eight m-tiles) runs them as N / 16..4 strips with every request of a strip in flight at once; the RMSNorm weights
-    // fold into W and the row statistics ride on the matrix pipe (two rmsnorm launches per layer gone), the layer scales fold into
-    // the rows of the o- / down-projection, activations travel as bf16 between the launches.  bf16 engines only; QTTS_CODEC_SKINNY=0: off.
-    struct SkLin { DevBuf Wp, bias; int N = 0, K = 0, fs = 16; bool has_bias = false; };
-    struct SkLayer { SkLin qkv, o, gu, down; };
-    std::vector<SkLayer> sk_tl;
-    SkLin sk_in, sk_out;
-    bool sk_ready = false;
-    DevBuf sk_pre16, sk_h16, sk_att16, sk_act16;     // bf16 [128][latent | hidden | q width | intermediate]
-    static constexpr int SK_MAX_ROWS = 128;
-    static int sk_fs(int N) { int fs = 16; while (fs > 4 && N / fs < 96) fs /= 2; return fs; }
-    void sk_pack(SkLin& l, const std::vector<float>& W, int N, int K, const float* g_cols, const float* s_rows, const std::vector<float>* bias,
-                 int fs_force = 0) {
-        std::vector<float> w2;
-        const float* src = W.data();
-        if (s_rows) {                    // out = res + s[n] * (x . W[n]): the layer scale folded into the operator's rows
-            w2.resize(W.size());
-            for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) w2[(size_t)n * K + k] = W[(size_t)n * K + k] * s_rows[n];
-            src = w2.data();
-        }
-        l.N = N; l.K = K; l.fs = fs_force ? fs_force : sk_fs(N);
-        std::vector<char> h(skinny_packed_bytes(N, K, true));
-        pack_skinny_weight(src, N, K, true, h.data(), g_cols, l.fs);
-        l.Wp.upload(h.data(), h.size());
-        if (bias) { upload_f(l.bias, *bias); l.has_bias = true; }
-    }
-    void sk_gemm(const SkLin& l, const void* x16, int ldx, int M, bool norm, float* out, int ldo, int act, const float* res, int ldr,
-                 void* out16, bool out_is_bf16, hipStream_t st) {
-        SkinnyParams p{};
-        p.x = reinterpret_cast<const float*>(x16); p.x_bf16 = 1; p.ldx = ldx; p.M = M; p.Wp = l.Wp.p; p.N = l.N; p.K = l.K; p.fs = l.fs;
-        p.norm = norm ? 1 : 0; p.eps = cfg.rms_norm_eps; p.bias = l.has_bias ? l.bias.as<float>() : nullptr;
-        p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.act = act; p.out16 = out16; p.out_bf16 = out_is_bf16 ? 1 : 0;
-        launch_skinny(p, true, st);
-    }
-
     DevBuf buf[4];
     DevBuf buf16[2];                    // bf16 mode: activations that are only a GEMM input (decoder blocks)
     size_t buf_elems = 0;
@@ -431,37 +393,6 @@ void qtts_codec::finalize() {
         upload_f(L.ls1, P(p + "self_attn_layer_scale.scale"));
         upload_f(L.ls2, P(p + "mlp_layer_scale.scale"));
     }
-    {   // the strip-GEMM copy of the transformer for decodes of <= 128 rows (see SkLin above)
-        const char* sk_e = getenv("QTTS_CODEC_SKINNY");        // (read when an engine is built)
-        const bool sk_env = !sk_e || atoi(sk_e) != 0;
-        const int qd = c.num_attention_heads * c.head_dim, kvd = c.num_key_value_heads * c.head_dim, qw = qd + 2 * kvd, Ld = c.latent_dim;
-        const bool shapes_ok = H % 32 == 0 && qd % 32 == 0 && I % 32 == 0 && Ld % 32 == 0 && H % 16 == 0 && qw % 16 == 0 && Ld % 16 == 0;
-        if (bf16 && sk_env && shapes_ok) {
-            sk_pack(sk_in, P("pre_transformer.input_proj.weight"), H, Ld, nullptr, nullptr, &P("pre_transformer.input_proj.bias"));
-            sk_pack(sk_out, P("pre_transformer.output_proj.weight"), Ld, H, P("pre_transformer.norm.weight").data(), nullptr,
-                    &P("pre_transformer.output_proj.bias"));
-            sk_tl.resize(c.num_hidden_layers);
-            for (int l = 0; l < c.num_hidden_layers; ++l) {
-                const std::string p = "pre_transformer.layers." + std::to_string(l) + ".";
-                auto& q = P(p + "self_attn.q_proj.weight"); auto& k = P(p + "self_attn.k_proj.weight"); auto& v = P(p + "self_attn.v_proj.weight");
-                std::vector<float> w; w.reserve(q.size() + k.size() + v.size());
-                w.insert(w.end(), q.begin(), q.end()); w.insert(w.end(), k.begin(), k.end()); w.insert(w.end(), v.begin(), v.end());
-                sk_pack(sk_tl[l].qkv, w, qw, H, P(p + "input_layernorm.weight").data(), nullptr, nullptr);
-                sk_pack(sk_tl[l].o, P(p + "self_attn.o_proj.weight"), H, qd, nullptr, P(p + "self_attn_layer_scale.scale").data(), nullptr);
-                auto& g = P(p + "mlp.gate_proj.weight"); auto& u = P(p + "mlp.up_proj.weight");
-                std::vector<float> gu((size_t)2 * I * H);
-                for (int f = 0; f < I; ++f) {
-                    memcpy(&gu[((size_t)(f / 16) * 32 + f % 16) * H], &g[(size_t)f * H], (size_t)H * 4);
-                    memcpy(&gu[((size_t)(f / 16) * 32 + 16 + f % 16) * H], &u[(size_t)f * H], (size_t)H * 4);
-                }
-                sk_pack(sk_tl[l].gu, gu, 2 * I, H, P(p + "post_attention_layernorm.weight").data(), nullptr, nullptr, 16);   // (SwiGLU strip pairs)
-                sk_pack(sk_tl[l].down, P(p + "mlp.down_proj.weight"), H, I, nullptr, P(p + "mlp_layer_scale.scale").data(), nullptr);
-            }
-            sk_pre16.alloc((size_t)SK_MAX_ROWS * Ld * 2); sk_h16.alloc((size_t)SK_MAX_ROWS * H * 2);
-            sk_att16.alloc((size_t)SK_MAX_ROWS * qd * 2); sk_act16.alloc((size_t)SK_MAX_ROWS * I * 2);
-            sk_ready = true;
-        }
-    }
     ups.resize(c.n_upsampling_ratios);
     for (int u = 0; u < c.n_upsampling_ratios; ++u) {
         const std::string p = "upsample." + std::to_string(u) + ".";
@@ -567,37 +498,14 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     C = c.codebook_dim;
     if (want("rvq")) { emit(x); return; }
     // ---- pre_conv (k=3 causal) (v2:874)
-    const bool sk_path = sk_ready && B * L <= SK_MAX_ROWS;        // (<= 128 rows: the transformer below runs as weight-streaming strips)
-    if (sk_path) gemm16(pre_conv, x, nullptr, C, B * L, L, s1, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, sk_pre16.as<bf16_t>(), nullptr, st);
-    else gemm(pre_conv, x, C, B * L, L, s1, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
+    gemm(pre_conv, x, C, B * L, L, s1, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, nullptr, st);
     std::swap(x, s1); C = c.latent_dim;
     if (want("pre_conv")) { emit(x); return; }
     // ---- pre_transformer (v2:501-575)
-    if (sk_path) {
-        const int H = c.hidden_size, I = c.intermediate_size;
-        const int qd = c.num_attention_heads * c.head_dim, kvd = c.num_key_value_heads * c.head_dim, qw = qd + 2 * kvd;
-        const int M = B * L;
-        float* h = s1;                            // the residual stream [M][H] (fp32) with its bf16 shadow sk_h16
-        float* qkvb = s2;                         // [M][qw] fp32 (RoPE in place, attention reads it)
-        bf16_t *h16 = sk_h16.as<bf16_t>(), *att16 = sk_att16.as<bf16_t>(), *act16 = sk_act16.as<bf16_t>();
-        sk_gemm(sk_in, sk_pre16.p, C, M, false, h, H, ACT_NONE, nullptr, 0, h16, false, st);
-        for (auto& Ly : sk_tl) {
-            sk_gemm(Ly.qkv, h16, H, M, true, qkvb, qw, ACT_NONE, nullptr, 0, nullptr, false, st);
-            launch_rope_inplace(qkvb, qw, M, L, c.num_attention_heads + c.num_key_value_heads, c.head_dim, inv_freq.as<float>(), st);
-            AttnRowsParams ap{};
-            ap.qkv = qkvb; ap.ld = qw; ap.q_off = 0; ap.k_off = qd; ap.v_off = qd + kvd;
-            ap.B = B; ap.T = L; ap.nh = c.num_attention_heads; ap.nkv = c.num_key_value_heads; ap.hd = c.head_dim;
-            ap.window = c.sliding_window; ap.n_pad = nullptr; ap.out = qkvb /* unused: out16 is written instead */; ap.ldo = qd; ap.out16 = att16;
-            launch_attn_rows(ap, st);
-            sk_gemm(Ly.o, att16, qd, M, false, h, H, ACT_NONE, h, H, h16, false, st);                 // h += ls1 * o(att)
-            sk_gemm(Ly.gu, h16, H, M, true, reinterpret_cast<float*>(act16), I, ACT_SWIGLU, nullptr, 0, nullptr, true, st);
-            sk_gemm(Ly.down, act16, I, M, false, h, H, ACT_NONE, h, H, h16, false, st);               // h += ls2 * down(act)
-        }
-        float* outp = s3;
-        sk_gemm(sk_out, h16, H, M, true, outp, c.latent_dim, ACT_NONE, nullptr, 0, nullptr, false, st);   // final norm folded
-        // rotate so that x points at the stage output and the scratch names stay distinct
-        float* old_x = x; x = outp; s3 = old_x; C = c.latent_dim;
-    } else {
+    // (Round 4 ran this stage's GEMMs as weight-streaming strips for decodes of <= 128 rows -- the talker's decode GEMM with eight
+    // m-tiles, norms and layer scales folded: 2.52 vs 2.44 ms at B = 1 x 10 s, i.e. slower than the tile GEMMs below; removed,
+    // profiles/r04_codec_small_rows.md.)
+    {
         const int H = c.hidden_size, I = c.intermediate_size;
         const int qd = c.num_attention_heads * c.head_dim, kvd = c.num_key_value_heads * c.head_dim;
         const int M = B * L;

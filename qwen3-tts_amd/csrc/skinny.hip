@@ -800,7 +800,7 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
 
 // bf16 mode: a GEMM input may arrive as the producer's bf16 copy (x_bf16) for any M <= 64 -- nothing is staged through LDS any
 // more, so there is no capacity condition left (round 1: M <= 16 up to K = 7096, M <= 32 up to K = 2344).
-bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <= 128 && K % 32 == 0; }
+bool skinny_takes_bf16_x(int M, int K, bool bf16) { return bf16 && M >= 1 && M <= 64 && K % 32 == 0; }
 // ACT_SWIGLU8 lives in skinny8_kernel only: the K for which that kernel is instantiated (launch8_nw)
 bool skinny_swiglu8_takes(int K) { return K == 1024 || K == 2048 || K == 3072 || K == 6144; }
 
@@ -844,8 +844,7 @@ static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
 }
 template <int MT, int SPW, int NW, int FS, bool XB16>
 static void launch2_x(const SkinnyParams& p, hipStream_t st) {
-    constexpr int UBASE = (MT == 1 ? 8 : (MT == 2 ? 4 : (MT == 4 ? 2 : 1))) / SPW;
-    constexpr int UMAX = UBASE < 1 ? 1 : UBASE;          // (MT = 8, round 4: one k-tile per chunk -- 8 x fragments of 4 registers per tile)
+    constexpr int UMAX = (MT == 1 ? 8 : (MT == 2 ? 4 : 2)) / SPW;
     if constexpr (XB16 && NW == 8) {       // the frame step's shapes: K / 32 tiles dealt evenly to 8 waves
         const int nkt = p.K / 32;
         if (nkt % NW == 0) {
@@ -1046,8 +1045,7 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     QTTS_REQUIRE(fs == 16 || bf16, QTTS_ERR_ARG, "skinny: narrow strips (fs < 16) are only built for the bf16 kernel");
     QTTS_REQUIRE(p.N % 16 == 0, QTTS_ERR_ARG, "skinny: N % 16");
     QTTS_REQUIRE(p.K % KT == 0, QTTS_ERR_ARG, "skinny: K must be a multiple of the k-tile");
-    // (M 65..128: bf16 only, round 4 -- the codec transformer's GEMMs at <= 128 rows run as weight-streaming strips, codec_engine.hip)
-    QTTS_REQUIRE(p.M >= 1 && p.M <= (bf16 ? 128 : 64), QTTS_ERR_LIMIT, "skinny: 1 <= M <= 64 (128 in bf16 mode)");
+    QTTS_REQUIRE(p.M >= 1 && p.M <= 64, QTTS_ERR_LIMIT, "skinny: 1 <= M <= 64");
 #if !QTTS_ABLATE
     QTTS_REQUIRE(p.ablate == 0, QTTS_ERR_ARG, "skinny: perf-ablation flags need the `ablate` build variant (python qwen3-tts_amd/build.py --variant ablate)");
 #endif
@@ -1066,21 +1064,12 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
         throw Error(QTTS_ERR_ARG, "skinny: no batch <= 8 instantiation for this K");
     }
     const int spw = skinny_spw(p.N, fs, p.act == ACT_SWIGLU);
-    const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : (p.M <= 64 ? 4 : 8));
-    // 8 waves split K unless K is tiny; eight m-tiles keep 16-24 accumulators + 8 x fragments per k-tile per wave (~360 registers: one
-    // wave per SIMD) and combine through 16-24 KiB of LDS per wave: 4 waves
-    const int nw = (p.K / KT >= 16 && mt != 8) ? 8 : 4;
+    const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
+    const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16 && nw == 8 && mt == 1 && launch_skinny8(p, spw, fs, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
     if (!bf16 && !QTTS_ABL(p, 15) && launch_skinny8_f32(p, spw, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
     if (bf16) {
-        if (mt == 8) {
-            QTTS_REQUIRE(p.x_bf16, QTTS_ERR_ARG, "skinny: M > 64 takes x as the producer's bf16 copy");
-            if (spw == 2) launch2_x<8, 2, 4, 16, true>(p, st);
-            else if (fs == 16) launch2_x<8, 1, 4, 16, true>(p, st);
-            else if (fs == 8) launch2_x<8, 1, 4, 8, true>(p, st);
-            else launch2_x<8, 1, 4, 4, true>(p, st);
-        }
-        else if (nw == 8) { if (mt == 1) launch2_mt<1, 8>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 8>(p, spw, fs, st); else launch2_mt<4, 8>(p, spw, fs, st); }
+        if (nw == 8) { if (mt == 1) launch2_mt<1, 8>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 8>(p, spw, fs, st); else launch2_mt<4, 8>(p, spw, fs, st); }
         else         { if (mt == 1) launch2_mt<1, 4>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 4>(p, spw, fs, st); else launch2_mt<4, 4>(p, spw, fs, st); }
     } else {
         QTTS_REQUIRE(!p.norm || p.ss_in, QTTS_ERR_ARG, "skinny: the generic fp32 kernel takes the row sums of squares from ss_in");

@@ -541,11 +541,6 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
              (32, 64, 1024, 16, 1, ACT_SWIGLU, 0, 0, 0),  # cp gate|up at batch 32: strip pairs, two chunks of 2
              (27, 64, 2048, 16, 1, ACT_SWIGLU, 0, 1, 0),  # talker gate|up: strip pairs, four chunks of 2
              (3, 48, 160, 16, 1, ACT_NONE, 1, 0, 0),      # odd K: generic (guarded) instantiation, 4 waves
-             # round 4: 65..128 rows (eight m-tiles, 4 waves) -- the codec transformer's GEMMs of a <= 128-row decode
-             (100, 64, 512, 16, 1, ACT_NONE, 0, 1, 1),    # q|k|v-like: normalised, residual + shadow, ragged seventh m-tile
-             (128, 32, 1024, 8, 0, ACT_NONE, 1, 1, 0),    # o / down-like: 8-feature strips, bias + residual
-             (77, 64, 512, 16, 1, ACT_SWIGLU, 0, 0, 0),   # gate|up strip pairs
-             (65, 32, 160, 4, 1, ACT_NONE, 1, 0, 0),      # odd K, 4-feature strips
              # skinny8_kernel (batch <= 8: tile pairs, whole-line x requests, DPP-rotated odd tiles) beyond the cases above
              (5, 32, 2048, 8, 1, ACT_NONE, 1, 1, 1),      # 5 rows (rows 5..7 re-read row 0), 8-feature strips, norm + bias + res + shadow
              (8, 32, 3072, 8, 0, ACT_NONE, 0, 1, 0),      # six pairs per wave, rotated weights
@@ -835,42 +830,9 @@ def test_decoder_bf16_forward_and_stream(emu):
                 _ok(emu, emu.qtts_codec_stream_push(h, _ptr(np.ascontiguousarray(codes[..., a:b])), b - a, _ptr(o), None))
                 outs.append(o)
             st_wav = np.concatenate(outs, axis=1)
-            # round 4: `forward` at <= 128 rows runs the transformer as weight-streaming strips (bf16 hand-overs, norm statistics from
-            # the bf16 rows) while `stream_push` keeps the tile GEMMs with fp32 activations between layers: two bf16 realisations of
-            # one fp32 function, each ~5 % from fp32 and 4.2 % from each other (1.3 % when both ran the tile GEMMs).  The exact
-            # stream == forward property is pinned in fp32 (test_stream_push_equals_whole_sequence_forward).
-            assert np.sqrt(((st_wav - wav) ** 2).mean()) <= 0.06 * np.sqrt((wav ** 2).mean())
+            assert np.sqrt(((st_wav - wav) ** 2).mean()) <= 0.03 * np.sqrt((wav ** 2).mean())     # measured 1.3 %
     finally:
         emu.qtts_codec_destroy(h)
-
-
-def test_decoder_bf16_strip_gemm_transformer_at_up_to_128_rows(emu, monkeypatch):
-    """Round 4: a bf16 decode of <= 128 rows runs the pre_transformer's GEMMs through the talker's weight-streaming decode GEMM
-    (eight m-tiles at 65..128 rows): RMSNorm weights folded into the operators, layer scales folded into the o- / down-projection's
-    rows, bf16 hand-over between the launches.  80 rows (two sequences of 40 frames: several attention windows) against the fp32
-    oracle, and against the same engine with the path switched off (the tile-GEMM path) -- the two bf16 paths must agree much more
-    closely than either agrees with fp32."""
-    T, B = 40, 2
-    codes = np.random.default_rng(5).integers(0, 64, (B, 16, T))
-    outs = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("QTTS_CODEC_SKINNY", mode)
-        c, w, h = _codec_emu(emu, _lib.QTTS_BF16)
-        try:
-            with real_gemm(emu):
-                wav = np.zeros((B, T * c.total_upsample), np.float32)
-                _ok(emu, emu.qtts_codec_forward(h, _ptr(np.ascontiguousarray(codes[:, :c.num_quantizers])), B, T, _ptr(wav), None, None))
-            outs[mode] = wav
-        finally:
-            emu.qtts_codec_destroy(h)
-    with torch.no_grad():
-        ref = codec_ref.decoder_forward(w, c, torch.from_numpy(codes[:, :c.num_quantizers]))[:, 0].numpy()
-    rms = lambda a: float(np.sqrt((a.astype(np.float64) ** 2).mean()))
-    print(f"strip path vs fp32 oracle {rms(outs['1'] - ref) / rms(ref):.4f}, tile path vs fp32 oracle {rms(outs['0'] - ref) / rms(ref):.4f}, "
-          f"strip vs tile {rms(outs['1'] - outs['0']) / rms(ref):.4f}")
-    assert rms(outs["1"] - ref) <= 0.08 * rms(ref) and rms(outs["0"] - ref) <= 0.08 * rms(ref)
-    assert not np.array_equal(outs["1"], outs["0"]), "QTTS_CODEC_SKINNY=0 did not select the other path"
-    assert rms(outs["1"] - outs["0"]) <= 0.05 * rms(ref)
 
 
 def test_decoder_orchestration_forward_and_chunked(emu, codec):
