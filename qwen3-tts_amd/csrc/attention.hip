@@ -58,15 +58,31 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
     const int hi = tq;
     const float* kb = base + p.k_off + kvh * HD + li * DPL;
     const float* vb = base + p.v_off + kvh * HD + li * DPL;
+    // Round 4: UN keys per 16-lane group and loop trip (16 per wave), their K (and V) rows requested together and unconditionally (keys past
+    // `hi` re-read key `hi` and are skipped at use): the loop was one dependent L2 round trip per 4 keys -- 48 us per layer for the
+    // batch-32 prefill's 50-key rows (profiles/r03_config4_kernel_trace.md).  Keys are still folded in ascending order per group, so the
+    // sums are bit-identical to the one-key-per-trip loop.
+    constexpr int UN = 4;
     // pass 1: row max
     float m = -INFINITY;
-    for (int s = lo + g; s <= hi; s += 4) {
-        const float* kp = kb + (size_t)s * p.ld;
-        float d = 0.f;
+    for (int s0 = lo + g; s0 <= hi; s0 += 4 * UN) {
+        float kr[UN][DPL];
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) d += q[e] * kp[e];
-        d = group16_sum(d) * scale;
-        m = fmaxf(m, d);
+        for (int u = 0; u < UN; ++u) {
+            const int sc = s0 + 4 * u <= hi ? s0 + 4 * u : hi;
+            const float* kp = kb + (size_t)sc * p.ld;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) kr[u][e] = kp[e];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (s0 + 4 * u > hi) continue;
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) d += q[e] * kr[u][e];
+            d = group16_sum(d) * scale;
+            m = fmaxf(m, d);
+        }
     }
     m = fmaxf(m, __shfl_xor(m, 16));
     m = fmaxf(m, __shfl_xor(m, 32));
@@ -74,17 +90,28 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
     float l = 0.f, acc[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) acc[e] = 0.f;
-    for (int s = lo + g; s <= hi; s += 4) {
-        const float* kp = kb + (size_t)s * p.ld;
-        const float* vp = vb + (size_t)s * p.ld;
-        float d = 0.f;
+    for (int s0 = lo + g; s0 <= hi; s0 += 4 * UN) {
+        float kr[UN][DPL], vr[UN][DPL];
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) d += q[e] * kp[e];
-        d = group16_sum(d) * scale;
-        const float pr = expf(d - m);
-        l += pr;
+        for (int u = 0; u < UN; ++u) {
+            const int sc = s0 + 4 * u <= hi ? s0 + 4 * u : hi;
+            const float* kp = kb + (size_t)sc * p.ld;
+            const float* vp = vb + (size_t)sc * p.ld;
 #pragma unroll
-        for (int e = 0; e < DPL; ++e) acc[e] += pr * vp[e];
+            for (int e = 0; e < DPL; ++e) { kr[u][e] = kp[e]; vr[u][e] = vp[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (s0 + 4 * u > hi) continue;
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) d += q[e] * kr[u][e];
+            d = group16_sum(d) * scale;
+            const float pr = expf(d - m);
+            l += pr;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) acc[e] += pr * vr[u][e];
+        }
     }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
