@@ -24,7 +24,9 @@ SOURCES = ["gemm_tap.hip", "resunit.hip", "skinny.hip", "elementwise.hip", "atte
 VARIANT_SOURCES = {"probe": ["persist_probe.hip"]}
 HEADERS = ["common.h", "kernels.h", "glue.h", os.path.join("..", "..", "include", "qtts.h")]
 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (14 dwords on gfx950) arrive in user SGPRs with the wave instead
-# of behind an `s_load` round trip; the frame step's decode GEMM passes its address operands that way (skinny.hip).
+# of behind an `s_load` round trip; the frame step's decode GEMMs (skinny8_kernel, skinny8_f32_kernel) pass their address operands that way.
+# The flag applies to every kernel of the library (only leading SCALAR arguments are ever preloaded; a kernel whose first argument is a
+# by-value struct is unaffected) and needs a gfx940+ firmware / ROCm >= 6.1 that implements kernarg preload -- true of every MI355X stack.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 

@@ -320,7 +320,7 @@ def test_gemm_dma_lds_dma_staged_kernel_real_source(emu, monkeypatch):
         (200, 50, 128, 192, [-54, -45, -36, -27, -18, -9, 0], ACT_SNAKE, 1, 0, 0, 1, 0),
         (260, 130, 256, 64, [0], ACT_NONE, 1, 1, 1, 1, 1),
         (150, 75, 256, 128, [-1, 0], ACT_NONE, 1, 0, 1, 1, 1),
-        (129, 43, 128, 320, [-18, -15, -12, -9, -6, -3, 0], ACT_NONE, 0, 0, 1, 0, 0),
+        (129, 43, 128, 192, [-18, -15, -12, -9, -6, -3, 0], ACT_NONE, 0, 0, 1, 0, 0),
     ]
     for (M, T, N, K, shift, act, hb, hr, o32, o16, s16) in cases:
         A = (g.standard_normal((M, K + 8)) * 0.5).astype(np.float32)
@@ -450,11 +450,10 @@ def test_skinny_f32_batch8_kernel_real_source(emu, monkeypatch):
     odd tiles, in-kernel RMSNorm statistics, three-chunk K = 6144) in every instantiation, against float64 numpy; no ss_in is
     handed over for the normalised cases (tests/hostemu/test_entries.cpp)."""
     g = np.random.default_rng(58)
-    cases = [(8, 32, 1024, 1, ACT_NONE, 0, 1, 0), (1, 32, 1024, 1, ACT_SWIGLU, 0, 1, 4), (3, 64, 2048, 1, ACT_SWIGLU, 0, 0, 0),
+    cases = [(8, 32, 1024, 1, ACT_NONE, 0, 1, 0), (1, 32, 1024, 1, ACT_SWIGLU, 0, 1, 4), (3, 32, 2048, 1, ACT_SWIGLU, 0, 0, 0),
              (7, 16, 2048, 1, ACT_NONE, 1, 0, 8), (8, 16, 3072, 0, ACT_NONE, 1, 1, 0), (2, 32, 3072, 1, ACT_SWIGLU, 0, 0, 0),
-             (6, 16, 3072, 1, ACT_NONE, 0, 1, 16), (5, 16, 6144, 0, ACT_NONE, 0, 1, 0), (8, 16, 6144, 1, ACT_NONE, 0, 0, 0),
-             (4, 32, 2048, 0, ACT_SWIGLU, 0, 1, 8), (8, 16, 1024, 1, ACT_NONE, 0, 0, 4), (5, 32, 1024, 1, ACT_SWIGLU, 0, 0, 16),
-             (8, 16, 2048, 1, ACT_NONE, 0, 1, 0)]
+             (6, 16, 3072, 1, ACT_NONE, 0, 1, 16), (8, 16, 6144, 1, ACT_NONE, 0, 1, 0),
+             (4, 32, 2048, 0, ACT_SWIGLU, 0, 1, 8), (5, 32, 1024, 1, ACT_SWIGLU, 0, 0, 16)]
     for (M, N, K, norm, act, hb, hr, nw) in cases:
         if nw:
             monkeypatch.setenv("QTTS_SKINNY8F_NW", str(nw))
@@ -494,7 +493,7 @@ def test_skinny_f32_split_k_producer_and_combining_consumer(emu):
     i32, vp = C.c_int32, C.c_void_p
     emu.hostemu_skinny_splitk.argtypes = [vp, i32, vp, i32, i32, vp, vp, i32, vp, C.c_float, i32, vp, vp, vp, i32]
     for (M, K1, N1, N2, act) in [(8, 2048, 1024, 32, ACT_SWIGLU), (5, 3072, 1024, 16, ACT_NONE), (3, 6144, 2048, 32, ACT_SWIGLU),
-                                 (8, 2048, 2048, 16, ACT_NONE), (1, 3072, 1024, 64, ACT_SWIGLU)]:
+                                 (8, 2048, 2048, 16, ACT_NONE)]:
         x = g.standard_normal((M, K1)).astype(np.float32)
         W1 = (g.standard_normal((N1, K1)) / np.sqrt(K1)).astype(np.float32)
         res = g.standard_normal((M, N1)).astype(np.float32)
