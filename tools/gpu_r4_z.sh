@@ -33,4 +33,6 @@ run codec_only 200 python tools/bench_configs.py codec_only --trials 10
 run first_packet 200 python tools/bench_configs.py first_packet --trials 20
 run clone 600 python bench.py --workload clone-shard --steps 1 --warmup 1
 grep -h '^{' "$OUT/clone.log" > "$OUT/clone.json"
+run clone_e3 600 python bench.py --workload clone-shard --steps 1 --warmup 1 --engines 3
+run clone_e4 600 python bench.py --workload clone-shard --steps 1 --warmup 1 --engines 4
 cat "$OUT/summary.txt"
