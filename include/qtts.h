@@ -126,7 +126,7 @@ typedef struct qtts_codec_stats {
     int32_t graph_captures;  /* decode shapes captured so far                                   */
     int32_t graph_replays;   /* calls served by hipGraphLaunch                                  */
     int32_t graphs_cached;   /* captured graphs alive (LRU of 8)                                */
-    int32_t graph_nodes_last; /* nodes of the most recently used graph (0: last call ran eagerly) */
+    int32_t graph_nodes_last; /* nodes of the most recently REPLAYED graph (0: nothing replayed yet)      */
 } qtts_codec_stats;
 int qtts_codec_get_stats(qtts_codec* c, qtts_codec_stats* out);
 

@@ -66,7 +66,7 @@ struct qtts_codec {
     std::map<GraphKey, GraphSlot> graphs;
     hipStream_t cap_stream = nullptr;
     uint64_t graph_clock = 0;
-    int graph_replays = 0, graph_captures = 0;
+    int graph_replays = 0, graph_captures = 0, graph_nodes_replayed = 0;
     static constexpr size_t GRAPH_SLOTS = 8;
     static bool graph_enabled() { static const bool on = [] { const char* e = getenv("QTTS_CODEC_GRAPH"); return !e || atoi(e) != 0; }(); return on; }
     void drop_graphs() {
@@ -111,6 +111,7 @@ struct qtts_codec {
         }
         QTTS_CHECK_HIP(hipGraphLaunch(slot.ge, st));
         ++graph_replays;
+        graph_nodes_replayed = slot.nodes;
         evict();
     }
     void evict() {
@@ -977,12 +978,8 @@ int qtts_codec_get_stats(qtts_codec* c, qtts_codec_stats* out) {
     QTTS_API_BEGIN
     QTTS_REQUIRE(c && out, QTTS_ERR_ARG, "null argument");
     out->graph_captures = c->graph_captures; out->graph_replays = c->graph_replays;
-    out->graphs_cached = 0; out->graph_nodes_last = 0;
-    uint64_t newest = 0;
-    for (auto& kv : c->graphs) {
-        if (kv.second.ge) ++out->graphs_cached;
-        if (kv.second.last_use > newest) { newest = kv.second.last_use; out->graph_nodes_last = kv.second.ge ? kv.second.nodes : 0; }
-    }
+    out->graphs_cached = 0; out->graph_nodes_last = c->graph_nodes_replayed;
+    for (auto& kv : c->graphs) if (kv.second.ge) ++out->graphs_cached;
     QTTS_API_END
 }
 

@@ -484,7 +484,8 @@ __global__ __launch_bounds__(NW * 64) void skinny8_kernel(const void* kWp, const
 
 // ------------------------------------------------------------------------------------------ fp32 (exact parity mode)
 // x fragments are loaded per k-tile from global/L2 and the row sums of squares come from `ss_in` (row_ss_kernel): this is the
-// arithmetic the reference goldens were validated against bit for bit; it is not the benchmarked mode and is left as it was.
+// arithmetic of rounds 1-3.  Since round 4 the frame step at batch <= 8 runs skinny8_f32_kernel (below) instead; this kernel serves batch
+// 9..64, odd K and the finalize-time tabulation of the code predictor's layer-0 rows.
 template <int MT, int SPW, int NW>
 __global__ __launch_bounds__(NW * 64) void skinny_f32_kernel(SkinnyParams p) {
     constexpr int KT = 16, FS = 16;

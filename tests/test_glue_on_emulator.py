@@ -125,3 +125,9 @@ def test_top_p_zero_and_integer_like_top_k_python_path(glue, golden_dir):
     for bad in (dict(top_p=1.5), dict(top_p=-0.1), dict(top_k=2.5), dict(subtalker_top_k=-3)):
         with pytest.raises(ValueError):
             eng.generate(*args, max_new_tokens=1, do_sample=True, suppress_tokens=sup, **bad)
+
+
+def test_codec_graph_replay_python_path(glue):
+    """`CodecDecoderEngine.decode_padded` called repeatedly on the same buffers + `stats()`: the GPU test body on the emulator (whether a
+    call hits the graph cache depends on the allocator handing the output block back; both outcomes are checked for equal results)."""
+    glue.test_codec_decode_calls_replay_as_graphs_on_the_gpu("cpu")
