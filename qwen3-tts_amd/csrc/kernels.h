@@ -78,11 +78,11 @@ struct SkinnyParams {
     int act;                     // ACT_NONE | ACT_SWIGLU (strip pairs gate/up -> N/2 output columns) | ACT_SWIGLU8 (round 3, skinny8_kernel:
                                  // ONE strip = 8 gate + 8 up rows of the same 8 output columns -> N/16 workgroups instead of N/32)
     // fp32 batch <= 8 kernel only (round 4): split-K with the combine in the consumer's prologue
-    int ksplit;                  // 2: producer -- workgroup (strip, half) writes raw partial sums to out + half * part_stride (plain GEMM only)
+    int ksplit;                  // 2: producer -- workgroup (strip, half) writes its sums to out + half * part_stride; half 0 adds `res` (plain GEMM only)
     size_t part_stride;          //    floats between the two halves' [M][ldo] partial buffers
-    const float* xp;             // consumer: x is formed as (x + xp[0]) + xp[1], the halves at xp and xp + xp_stride, laid out like x ([M][ldx])
+    const float* xp;             // consumer: x is formed as xp[0] + xp[1] (= residual + half 0, half 1), at xp and xp + xp_stride, [M][ldx]; `x` is not read
     size_t xp_stride;
-    float* x_out;                //    ... and workgroup 0 writes the combined rows here (!= x)
+    float* x_out;                //    ... and workgroup 0 writes the combined rows here (outside the halves)
     const int* done_flag;        // optional device flag: when non-zero the kernel exits early
     int ablate;                  // `ablate` build variant only (-DQTTS_ABLATE; must be 0 in the product build): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
 };

@@ -641,13 +641,16 @@ __device__ inline f32x4 dpp_ror8_f(const f32x4& v) {
 // Split-K with the combine in the CONSUMER's prologue (round 4, second step).  The N = 1024 / 2048 operators (o-proj, down-proj) are 64 /
 // 128 strips of 16 features: 64 workgroups pulling 128-196 KB each ran at 1.1-1.4 TB/s (profiles/r04_f32_skinny8.md), and narrower
 // strips would spend 3/4 of an fp32 16x16x4 MFMA on padding.  Instead:
-//   KS = 2  (producer): workgroup (strip, half) accumulates its half of K and writes the raw partial sums to `out + half * part_stride`
-//           -- no residual, no bias, no activation, no normalisation; twice the workgroups, half the chain each;
+//   KS = 2  (producer): workgroup (strip, half) accumulates its half of K and writes its partial sums to `out + half * part_stride`
+//           -- no bias, no activation, no normalisation; half 0 adds the residual to its sums (8 x 16 floats it reads anyway), half 1
+//           writes raw sums; twice the workgroups, half the chain each;
 //   COMB    (consumer: the NEXT decode GEMM, which reads that output as its x anyway): every x fragment is formed as
-//           (x + xp[0]) + xp[1] from three requests instead of one -- the launch-boundary reduce costs no launch and no barrier -- and
-//           workgroup 0 writes the combined rows to `x_out` (another buffer than x: the other workgroups are still reading x), which
-//           is the residual stream from here on.  The RMSNorm statistics come from the combined fragments.
-// Fixed summation order (half 0 + half 1 on top of x), so results are run-to-run identical; they differ in the last bits from the
+//           xp[0] + xp[1] = (residual + half 0) + half 1 from two requests instead of one -- the launch-boundary reduce costs no launch
+//           and no barrier -- and workgroup 0 writes the combined rows to `x_out`, which is the residual stream from here on.  The
+//           RMSNorm statistics come from the combined fragments.  (First version of this round: the consumer read residual, half 0 and
+//           half 1 -- three requests; moving the residual into half 0 is the same sum in the same order, bit for bit, for two thirds of
+//           the consumer's x traffic.)
+// Fixed summation order ((residual + half 0) + half 1), so results are run-to-run identical; they differ in the last bits from the
 // unsplit kernel -- the fp32 goldens are the acceptance test.
 template <int SPW, int NP, int CH, bool NORM, int NW, int KS = 1, bool COMB = false>
 __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, const float* kx, const int* kdone, const float* kres, const float* kbias,
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
     const float* xb = p.x + xoff;
 
     u32x4 wR[NSET][NP][SPW][2];
-    f32x4 xR[NSET][NP], pR[COMB ? NSET : 1][COMB ? NP : 1][2];
+    f32x4 xR[NSET][NP], pR[COMB ? NSET : 1][COMB ? NP : 1];
     auto request = [&](int set, int c) {                          // chunk c = pairs wave + NW (c NP + i)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -685,12 +688,10 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
             for (int s = 0; s < SPW; ++s)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) wR[set][i][s][h] = skinny_wload(wb[s] + (size_t)(c * NP + i) * (NW * 128) + h * 64);
-            xR[set][i] = *reinterpret_cast<const f32x4*>(xb + (c * NP + i) * (NW * 32));
             if constexpr (COMB) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    pR[set][i][h] = *reinterpret_cast<const f32x4*>(p.xp + h * p.xp_stride + xoff + (c * NP + i) * (NW * 32));
-            }
+                xR[set][i] = *reinterpret_cast<const f32x4*>(p.xp + xoff + (c * NP + i) * (NW * 32));                      // residual + half 0
+                pR[set][i] = *reinterpret_cast<const f32x4*>(p.xp + p.xp_stride + xoff + (c * NP + i) * (NW * 32));       // half 1
+            } else xR[set][i] = *reinterpret_cast<const f32x4*>(xb + (c * NP + i) * (NW * 32));
         }
     };
     // ---- 1. the requests, back to back
@@ -698,19 +699,21 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
     if constexpr (CH >= 2) request(1, 1);
     // epilogue operands (used by wave 0 only; requested by every wave so that no branch surrounds a load)
     const int rowc = lj < p.M ? lj : 0;
-    constexpr bool EPI = KS == 1 && !COMB;                       // (a split-K producer and a combining consumer take neither bias nor residual)
+    constexpr bool EPI = KS == 1 && !COMB;                       // (a combining consumer takes neither bias nor residual; a split-K producer no bias)
+    constexpr bool EPI_RES = !COMB;
     f32x4 resv[SPW], biasv[SPW];
 #pragma unroll
     for (int s = 0; s < SPW; ++s) {
+        biasv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        resv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int col = (p.act == ACT_SWIGLU ? bidx * 16 : (strip0 + s) * 16) + lq * 4;
         if constexpr (EPI) {
-            const int col = (p.act == ACT_SWIGLU ? bidx * 16 : (strip0 + s) * 16) + lq * 4;
             const float* bp = p.bias ? p.bias + (strip0 + s) * 16 + lq * 4 : p.x;
-            const float* rp = p.res ? p.res + (size_t)rowc * p.ldr + col : p.x;
             biasv[s] = *reinterpret_cast<const f32x4*>(bp);
+        }
+        if constexpr (EPI_RES) {
+            const float* rp = p.res ? p.res + (size_t)rowc * p.ldr + col : p.x;
             resv[s] = *reinterpret_cast<const f32x4*>(rp);
-        } else {
-            biasv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            resv[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
     const int done = p.done_flag ? *p.done_flag : 0;
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
         for (int i = 0; i < NP; ++i) {
             f32x4 xe = xR[set][i];
             if constexpr (COMB) {
-                xe = (xe + pR[set][i][0]) + pR[set][i][1];        // the launch-boundary reduce: x + half 0 + half 1, in this order
+                xe = xe + pR[set][i];                             // the launch-boundary reduce: (residual + half 0) + half 1
                 if (blockIdx.x == 0 && (lj & 7) < p.M)            // one workgroup writes the combined rows: the residual stream from here on
                     *reinterpret_cast<f32x4*>(p.x_out + xoff + (c * NP + i) * (NW * 32)) = xe;
             }
@@ -781,8 +784,9 @@ __global__ __launch_bounds__(NW * 64) void skinny8_f32_kernel(const void* kWp, c
         v[s] = t * rstd + (EPI && p.bias ? biasv[s] : zero4);
     }
     if (lj < p.M) {
-        if constexpr (KS > 1) {              // raw partial sums of this half (no bias / residual / activation: the consumer adds them to x)
-            *reinterpret_cast<f32x4*>(p.out + (size_t)kh * p.part_stride + (size_t)lj * p.ldo + strip0 * 16 + lq * 4) = v[0];
+        if constexpr (KS > 1) {              // this half's sums; half 0 carries the residual (the consumer adds the two halves)
+            *reinterpret_cast<f32x4*>(p.out + (size_t)kh * p.part_stride + (size_t)lj * p.ldo + strip0 * 16 + lq * 4) =
+                v[0] + (kh == 0 && p.res ? resv[0] : zero4);
         } else if (p.act == ACT_SWIGLU) {
             if constexpr (SPW == 2) {
                 f32x4 o;
@@ -1026,9 +1030,9 @@ static bool launch_skinny8_f32(const SkinnyParams& p, int spw, hipStream_t st) {
     if (p.ksplit == 2 || p.xp) {           // no other kernel implements these: refuse loudly instead of falling through
         QTTS_REQUIRE(skinny8f_enabled() && p.M <= 8 && !p.x_bf16 && !p.out_bf16 && !p.out16, QTTS_ERR_ARG, "skinny: split-K / combine need the fp32 batch <= 8 kernel");
         QTTS_REQUIRE(!(p.ksplit == 2 && p.xp), QTTS_ERR_ARG, "skinny: a split-K producer cannot also combine");
-        if (p.ksplit == 2) QTTS_REQUIRE(!p.norm && !p.bias && !p.res && p.act == ACT_NONE && spw == 1, QTTS_ERR_ARG, "skinny: the split-K producer is a plain GEMM");
-        if (p.xp) QTTS_REQUIRE(p.norm && p.x_out && p.x_out != p.x && !p.bias && !p.res, QTTS_ERR_ARG,
-                               "skinny: the combining consumer is a normalised GEMM without bias / residual, writing x_out != x");
+        if (p.ksplit == 2) QTTS_REQUIRE(!p.norm && !p.bias && p.act == ACT_NONE && spw == 1, QTTS_ERR_ARG, "skinny: the split-K producer is a plain GEMM (+ residual)");
+        if (p.xp) QTTS_REQUIRE(p.norm && p.x_out && p.x_out != p.xp && p.x_out != p.xp + p.xp_stride && !p.bias && !p.res, QTTS_ERR_ARG,
+                               "skinny: the combining consumer is a normalised GEMM without bias / residual, writing x_out outside the halves");
         const bool ok = spw == 2 ? launch8f_spw<2>(p, st) : launch8f_spw<1>(p, st);
         QTTS_REQUIRE(ok, QTTS_ERR_ARG, "skinny: no split-K / combine instantiation for this K");
         return true;

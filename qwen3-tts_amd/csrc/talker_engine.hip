@@ -265,23 +265,20 @@ struct qtts_talker {
             p.ss_in = ssbuf();
         }
     }
-    // fp32 mode, batch <= 8 (round 4): the o- and down-projections split K over two workgroups per strip and the NEXT GEMM of the chain
-    // (gate|up, the next layer's q|k|v) forms its x as residual + half 0 + half 1 while it loads it, writing the combined rows to the
-    // other of two residual buffers (skinny.hip: KS / COMB).  `sk_cur` is the buffer that holds the residual stream right now,
-    // `sk_pending` says that the two halves in `sk_part` still have to be added to it.  The last layer of a stack does not split its
-    // down-projection and writes the stack's output where the caller expects it (xs).
-    DevBuf sk_alt, sk_part;            // [8][H_max] and [2][8][H_max] floats (fp32 engines only)
-    float* sk_cur = nullptr;
+    // fp32 mode, batch <= 8 (round 4): the o- and down-projections split K over two workgroups per strip -- half 0 adds the residual to its
+    // sums, half 1 writes raw sums, both into `sk_part` -- and the NEXT GEMM of the chain (gate|up, the next layer's q|k|v) forms its x as
+    // half 0 + half 1 while it loads it and writes the combined rows back to the residual buffer (skinny.hip: KS / COMB; nobody else reads
+    // the residual buffer during that launch).  `sk_pending` says that the halves of a down-projection still wait for the next q|k|v.  The
+    // last layer of a stack does not split its down-projection: the stack's output is complete where the caller reads it.
+    DevBuf sk_part;                    // [2][8][H_max] floats (fp32 engines only)
     bool sk_pending = false;
     // one decoder layer on `M = n_new * B` rows of `xs` (in place)
     void decode_layer(const LayerW& L, const StackDims& d, float* xs, unsigned short* xs16, float* qkvb, float* attb,
                       float* actb, int M, int n_new, KvCache& kv, int layer, const int* len_dev, int len_static,
                       const int* npad, const float* inv_freq, int max_len, hipStream_t st, const float* rope_cs = nullptr, int rope_cs_n = 0,
                       bool last_layer = true) {
-        const bool splitk = !bf16 && sk_alt.p && M <= 8 && skinny_f32_splitk_takes(M, d.qd, d.H) && skinny_f32_splitk_takes(M, d.I, d.H);
-        if (layer == 0 || !splitk) { sk_cur = xs; sk_pending = false; }
-        float* const alt = sk_alt.as<float>();
-        auto other = [&](float* b) { return b == xs ? alt : xs; };
+        const bool splitk = !bf16 && sk_part.p && M <= 8 && skinny_f32_splitk_takes(M, d.qd, d.H) && skinny_f32_splitk_takes(M, d.I, d.H);
+        if (layer == 0 || !splitk) sk_pending = false;
         const size_t pstride = (size_t)8 * d.H;
         // xs16: bf16 copy of the hidden state kept in step with xs by every producer (bf16 mode, M <= 16), or null
         const bool h16 = xs16 && skinny_takes_bf16_x(M, d.H, bf16);
@@ -290,12 +287,9 @@ struct qtts_talker {
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
         if (!skip_qkv) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
-            if (splitk) {
-                p.x = sk_cur;
-                if (sk_pending) {    // the previous layer's down-projection left two halves: combine them into the other buffer on the way in
-                    p.xp = sk_part.as<float>(); p.xp_stride = pstride; p.x_out = other(sk_cur);
-                    sk_cur = p.x_out; sk_pending = false;
-                }
+            if (splitk && sk_pending) {    // the previous layer's down-projection left (residual + half 0, half 1): added on the way in
+                p.xp = sk_part.as<float>(); p.xp_stride = pstride; p.x_out = xs;
+                sk_pending = false;
             }
             norm_input(p, d, h16 ? xs16 : nullptr, st);
             skinny(p, st);
@@ -319,16 +313,13 @@ struct qtts_talker {
         o.x_bf16 = att16;
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
         o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr; o.fs = L.fs_o;
-        if (splitk) { o.res = nullptr; o.out = sk_part.as<float>(); o.ksplit = 2; o.part_stride = pstride; }
+        if (splitk) { o.out = sk_part.as<float>(); o.ksplit = 2; o.part_stride = pstride; }     // (o.res = xs: half 0 = residual + its sums)
         skinny(o, st);
         SkinnyParams g{};
         g.done_flag = ss.done;
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
         g.out_bf16 = act16;
-        if (splitk) {               // residual + the o-projection's two halves, combined into the other buffer
-            g.x = sk_cur; g.xp = sk_part.as<float>(); g.xp_stride = pstride; g.x_out = other(sk_cur);
-            sk_cur = g.x_out;
-        }
+        if (splitk) { g.xp = sk_part.as<float>(); g.xp_stride = pstride; g.x_out = xs; }     // (residual + half 0) + half 1 of the o-projection
         norm_input(g, d, h16 ? xs16 : nullptr, st);
         if (L.gu_p8.p && g.x_bf16 && M <= 8 && !skinny_ablate_or_off()) { g.Wp = L.gu_p8.p; g.act = ACT_SWIGLU8; }
         skinny(g, st);
@@ -337,10 +328,7 @@ struct qtts_talker {
         dn.x_bf16 = act16;
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
         dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE; dn.out16 = h16 ? xs16 : nullptr; dn.fs = L.fs_d;
-        if (splitk) {
-            if (!last_layer) { dn.res = nullptr; dn.out = sk_part.as<float>(); dn.ksplit = 2; dn.part_stride = pstride; sk_pending = true; }
-            else { dn.res = sk_cur; dn.out = xs; sk_cur = xs; }          // the stack's output lands where the caller reads it
-        }
+        if (splitk && !last_layer) { dn.out = sk_part.as<float>(); dn.ksplit = 2; dn.part_stride = pstride; sk_pending = true; }   // (dn.res = xs)
         skinny(dn, st);
     }
 
@@ -547,10 +535,10 @@ void qtts_talker::finalize() {
     cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
     cp_att.alloc((size_t)R * cd.qd * 4); cp_act.alloc((size_t)R * cd.I * 4); cp_logits.alloc((size_t)R * c.cp_vocab_size * 4);
     cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_rows.alloc(64 * 8); ints.alloc(64 * 4 + R * 4);
-    if (!bf16) {                      // split-K residual ping-pong + the two halves (decode_layer)
+    if (!bf16) {                      // the two halves of a split-K o- / down-projection (decode_layer)
         const size_t hmax = (size_t)std::max(td.H, cd.H);
-        sk_alt.alloc(8 * hmax * 4); sk_part.alloc(2 * 8 * hmax * 4);
-        QTTS_CHECK_HIP(hipMemset(sk_alt.p, 0, sk_alt.bytes)); QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
+        sk_part.alloc(2 * 8 * hmax * 4);
+        QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
     }
     n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size); seed_d.alloc(8);
     QTTS_CHECK_HIP(hipMemset(ss_rows.p, 0, ss_rows.bytes));

@@ -93,8 +93,8 @@ extern "C" int hostemu_skinny(const float* x, int ldx, int M, const float* W, in
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
-// fp32 batch <= 8, round 4: y = x . W1^T as a split-K PRODUCER (two halves into parts[2][8][N1]), then
-// z = act( rmsnorm(res + half 0 + half 1) . (g (.) W2)^T ) by the COMBINING consumer, which also writes the combined rows to x_out.
+// fp32 batch <= 8, round 4: y = x . W1^T as a split-K PRODUCER (parts[0] = res + first half of K, parts[1] = second half), then
+// z = act( rmsnorm(parts[0] + parts[1]) . (g (.) W2)^T ) by the COMBINING consumer, which also writes the combined rows to x_out.
 extern "C" int hostemu_skinny_splitk(const float* x, int M, const float* W1, int N1, int K1, const float* res, const float* W2, int N2,
                                      const float* g, float eps, int act, float* parts, float* x_out, float* z, int ldz) {
     try {
@@ -104,10 +104,11 @@ extern "C" int hostemu_skinny_splitk(const float* x, int M, const float* W1, int
         if (!qtts::skinny_f32_splitk_takes(M, K1, N1)) return -7;
         qtts::SkinnyParams a{};
         a.x = x; a.ldx = K1; a.M = M; a.Wp = w1.data(); a.N = N1; a.K = K1; a.fs = 16; a.out = parts; a.ldo = N1; a.act = qtts::ACT_NONE;
-        a.ksplit = 2; a.part_stride = (size_t)8 * N1;
+        a.ksplit = 2; a.part_stride = (size_t)8 * N1; a.res = res; a.ldr = N1;          // half 0 = residual + its sums
         qtts::launch_skinny(a, false, nullptr);
         qtts::SkinnyParams b{};
-        b.x = res; b.ldx = N1; b.M = M; b.Wp = w2.data(); b.N = N2; b.K = N1; b.fs = 16; b.norm = 1; b.eps = eps; b.out = z; b.ldo = ldz; b.act = act;
+        b.x = parts; b.ldx = N1; b.M = M;                                            // (x is not read: the halves are)
+        b.Wp = w2.data(); b.N = N2; b.K = N1; b.fs = 16; b.norm = 1; b.eps = eps; b.out = z; b.ldo = ldz; b.act = act;
         b.xp = parts; b.xp_stride = (size_t)8 * N1; b.x_out = x_out;
         qtts::launch_skinny(b, false, nullptr);
         return 0;

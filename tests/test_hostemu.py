@@ -485,8 +485,8 @@ def test_skinny_f32_batch8_kernel_real_source(emu, monkeypatch):
 
 
 def test_skinny_f32_split_k_producer_and_combining_consumer(emu):
-    """Round 4: the fp32 batch <= 8 o- / down-projections split K over two workgroups per strip (raw halves, no residual) and the
-    next GEMM of the chain forms its x as residual + half 0 + half 1 on the way in, writes the combined rows to another buffer and
+    """Round 4: the fp32 batch <= 8 o- / down-projections split K over two workgroups per strip (half 0 carries the residual) and the
+    next GEMM of the chain forms its x as half 0 + half 1 on the way in, writes the combined rows out and
     takes the RMSNorm statistics from them -- against float64 numpy, for the producer K of both stacks (2048, 3072, 6144) and both
     consumer shapes (K = 1024: 8 waves, K = 2048: 16 waves; plain and SwiGLU)."""
     g = np.random.default_rng(77)
@@ -507,12 +507,12 @@ def test_skinny_f32_split_k_producer_and_combining_consumer(emu):
         assert rc == 0, ((M, K1, N1), rc, (emu.qtts_last_error() or b"").decode())
         y64 = x.astype(np.float64) @ W1.astype(np.float64).T
         h0 = x[:, :K1 // 2].astype(np.float64) @ W1[:, :K1 // 2].astype(np.float64).T
-        assert np.abs(parts[0, :M] - h0).max() <= 2e-5 and np.abs(parts[0, :M] + parts[1, :M] - y64).max() <= 4e-5
+        assert np.abs(parts[0, :M] - (res + h0)).max() <= 2e-5 and np.abs(parts[0, :M] + parts[1, :M] - (res + y64)).max() <= 4e-5
         assert np.all(parts[:, M:] == 3.0)                                   # rows >= M are nobody's
         h = res.astype(np.float64) + y64
         assert np.abs(x_out[:M] - h).max() <= 4e-5 and np.all(x_out[M] == 7.0)
-        # bit-level: the combined row IS (res + half 0) + half 1 in fp32, in that order
-        assert np.array_equal(x_out[:M], (res + parts[0, :M]) + parts[1, :M])
+        # bit-level: the combined row IS (res + half 0) + half 1 in fp32, in that order (half 0 arrives with the residual in it)
+        assert np.array_equal(x_out[:M], parts[0, :M] + parts[1, :M])
         acc = (h / np.sqrt((h ** 2).mean(1, keepdims=True) + 1e-6)) @ (W2 * gw).astype(np.float64).T
         if act == ACT_SWIGLU:
             a = acc.reshape(M, N2 // 32, 2, 16)
