@@ -120,7 +120,7 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
  * STATUS: validated on MI355X (round 2): any packetisation == `forward` on the whole sequence
  * (tests/test_gpu_parity.py::test_codec_incremental_stream_equals_forward). */
 /* Bookkeeping of the decode-call graph cache (round 4): `qtts_codec_forward` / `qtts_codec_decode` replay a captured hipGraph from
- * the second call with the same (codes pointer, output pointer, B, T, chunking) on -- the reference's decode is a Python loop of
+ * the second call with the same shape (B, T, chunking) on, staging codes and waveform in engine-owned buffers -- the reference's decode is a Python loop of
  * eager PyTorch ops (tokenizer v2:869-896); there is nothing to mirror, this only reports what happened. */
 typedef struct qtts_codec_stats {
     int32_t graph_captures;  /* decode shapes captured so far                                   */

@@ -50,18 +50,31 @@ struct qtts_codec {
     size_t buf_elems = 0;
     DevBuf err_flag;                    // device int: a code index >= codebook_size was seen (checked by the entry points)
 
-    // ---- hipGraph replay of whole decode calls (round 4).  A decode is ~140 launches whose arguments are fixed by (codes pointer,
-    // output pointer, B, T, chunking): the SECOND call with the same key captures the launch sequence (on a private stream -- a
-    // capture executes nothing, and the caller's stream may be the legacy default stream, which cannot be captured) and this and
-    // every later call replay it with one hipGraphLaunch on the caller's stream.  Every other address in the graph is engine-owned
-    // workspace.  A caller that allocates fresh buffers per call (PyTorch's caching allocator hands the same blocks back in a steady
-    // loop) simply never hits the cache and runs eagerly, as before.  QTTS_CODEC_GRAPH=0: always eager (A/B).
+    // ---- hipGraph replay of whole decode calls (round 4).  A decode is ~140 launches whose arguments are fixed by (B, T, chunking) once
+    // the codes and the waveform live at fixed addresses: the engine owns a staging buffer for each (`g_codes`, `g_wav`, `g_pre`); a
+    // call copies its codes in (device to device, a few KB to a few hundred KB), replays the graph captured for its shape, and copies
+    // the waveform out to the caller's buffer.  The SECOND call with a shape captures the launch sequence (on a private stream -- a capture
+    // executes nothing, and the caller's stream may be the legacy default stream, which cannot be captured); this and every later call
+    // replay it with one hipGraphLaunch on the caller's stream.  Keyed on the SHAPE only: a caller that allocates fresh tensors per
+    // call (PyTorch does) still replays, and no call pays a capture because its addresses changed (first version of this round: keyed
+    // on the caller's pointers -- a first-packet p99 of 37-58 ms where round 3 had 32.4, every new address pair a 5-25 ms
+    // capture + instantiate inside a request).  QTTS_CODEC_GRAPH=0: always eager, no staging (A/B).
     struct GraphKey {
-        const void* codes; void* wav; void* pre; int B, T, chunk, left;
+        int B, T, chunk, left, has_pre;
         bool operator<(const GraphKey& o) const {
-            return std::tie(codes, wav, pre, B, T, chunk, left) < std::tie(o.codes, o.wav, o.pre, o.B, o.T, o.chunk, o.left);
+            return std::tie(B, T, chunk, left, has_pre) < std::tie(o.B, o.T, o.chunk, o.left, o.has_pre);
         }
     };
+    DevBuf g_codes, g_wav, g_pre;
+    // staging sized for this call; growing a buffer moves it, so every captured graph (they bake the old address) is dropped first
+    void ensure_staging(size_t codes_bytes, size_t wav_bytes, bool pre) {
+        if (codes_bytes > g_codes.bytes || wav_bytes > g_wav.bytes || (pre && wav_bytes > g_pre.bytes)) {
+            drop_graphs();
+            if (codes_bytes > g_codes.bytes) g_codes.alloc(codes_bytes);
+            if (wav_bytes > g_wav.bytes) g_wav.alloc(wav_bytes);
+            if (pre && wav_bytes > g_pre.bytes) g_pre.alloc(wav_bytes);
+        }
+    }
     struct GraphSlot { hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; uint64_t last_use = 0; int seen = 0; int nodes = 0; };
     std::map<GraphKey, GraphSlot> graphs;
     hipStream_t cap_stream = nullptr;
@@ -81,14 +94,17 @@ struct qtts_codec {
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
     }
     // run `body(stream)` -- a launch sequence without host synchronisation -- eagerly on `st`, or as a cached graph
-    template <class F>
-    void run_graphed(const GraphKey& key, hipStream_t st, F&& body) {
-        if (!graph_enabled()) { body(st); return; }
+    // `eager(stream)` runs the launch sequence on the caller's buffers; `staged(stream)` the same sequence on the staging buffers (that is
+    // what a capture records); `copy_in` / `copy_out` move the caller's data to / from the staging buffers around a replay.
+    template <class FE, class FS, class FI, class FO>
+    void run_graphed(const GraphKey& key, hipStream_t st, FE&& eager, FS&& staged, FI&& copy_in, FO&& copy_out) {
+        if (!graph_enabled()) { eager(st); return; }
         GraphSlot& slot = graphs[key];
         slot.last_use = ++graph_clock;
+        auto body = [&](hipStream_t s) { staged(s); };
         if (!slot.ge) {
             if (++slot.seen < 2) {                                   // first sight: eager (also loads every code object lazily loaded)
-                body(st);
+                eager(st);
                 evict();
                 return;
             }
@@ -109,7 +125,9 @@ struct qtts_codec {
             QTTS_CHECK_HIP(hipGraphInstantiate(&slot.ge, slot.g, nullptr, nullptr, 0));
             ++graph_captures;
         }
+        copy_in(st);
         QTTS_CHECK_HIP(hipGraphLaunch(slot.ge, st));
+        copy_out(st);
         ++graph_replays;
         graph_nodes_replayed = slot.nodes;
         evict();
@@ -919,10 +937,19 @@ int qtts_codec_forward(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32
     QTTS_API_BEGIN
     QTTS_REQUIRE(c && codes_dev && wav_dev, QTTS_ERR_ARG, "null argument");
     const int Q = c->cfg.num_quantizers;
-    c->run_graphed({codes_dev, wav_dev, pre_clamp_dev, B, T, 0, -1}, (hipStream_t)stream, [&](hipStream_t s) {
-        c->forward(codes_dev, B, (int64_t)Q * T, T, 1, 0, T, wav_dev, pre_clamp_dev, (int64_t)T * c->up_total, 0, nullptr,
-                   nullptr, 0, nullptr, nullptr, s);
-    });
+    const size_t cbytes = (size_t)B * Q * T * sizeof(int64_t), wbytes = (size_t)B * T * c->up_total * sizeof(float);
+    if (qtts_codec::graph_enabled()) c->ensure_staging(cbytes, wbytes, pre_clamp_dev != nullptr);
+    auto run = [&](const int64_t* cd, float* wv, float* pr, hipStream_t s) {
+        c->forward(cd, B, (int64_t)Q * T, T, 1, 0, T, wv, pr, (int64_t)T * c->up_total, 0, nullptr, nullptr, 0, nullptr, nullptr, s);
+    };
+    c->run_graphed({B, T, 0, -1, pre_clamp_dev ? 1 : 0}, (hipStream_t)stream,
+        [&](hipStream_t s) { run(codes_dev, wav_dev, pre_clamp_dev, s); },
+        [&](hipStream_t s) { run(c->g_codes.as<int64_t>(), c->g_wav.as<float>(), pre_clamp_dev ? c->g_pre.as<float>() : nullptr, s); },
+        [&](hipStream_t s) { QTTS_CHECK_HIP(hipMemcpyAsync(c->g_codes.p, codes_dev, cbytes, hipMemcpyDeviceToDevice, s)); },
+        [&](hipStream_t s) {
+            QTTS_CHECK_HIP(hipMemcpyAsync(wav_dev, c->g_wav.p, wbytes, hipMemcpyDeviceToDevice, s));
+            if (pre_clamp_dev) QTTS_CHECK_HIP(hipMemcpyAsync(pre_clamp_dev, c->g_pre.p, wbytes, hipMemcpyDeviceToDevice, s));
+        });
     c->check_codes_flag((hipStream_t)stream);
     QTTS_API_END
 }
@@ -960,16 +987,23 @@ int qtts_codec_decode(qtts_codec* c, const int64_t* codes_dev, int32_t B, int32_
         for (int64_t v : h)   // the reference's embedding lookup raises on an index past the codebook
             QTTS_REQUIRE(v < c->cfg.codebook_size, QTTS_ERR_ARG, "codec: code index out of range (>= codebook_size)");
     }
-    c->run_graphed({codes_dev, wav_dev, nullptr, B, T, chunk_size, left_context}, st, [&](hipStream_t s) {
+    const size_t cbytes = (size_t)B * T * Q * sizeof(int64_t), wbytes = (size_t)B * T * up * sizeof(float);
+    if (qtts_codec::graph_enabled()) c->ensure_staging(cbytes, wbytes, false);
+    auto run = [&](const int64_t* cd, float* wv, hipStream_t s) {
         int start = 0;
         while (start < T) {  // chunked_decode (v2:886-896)
             const int end = std::min(start + chunk_size, T);
             const int ctx = (start - left_context > 0) ? left_context : start;
-            c->forward(codes_dev, B, (int64_t)T * Q, 1, Q, start - ctx, end - (start - ctx), wav_dev + (int64_t)start * up, nullptr,
+            c->forward(cd, B, (int64_t)T * Q, 1, Q, start - ctx, end - (start - ctx), wv + (int64_t)start * up, nullptr,
                        (int64_t)T * up, (int64_t)ctx * up, nullptr, nullptr, 0, nullptr, nullptr, s);
             start = end;
         }
-    });
+    };
+    c->run_graphed({B, T, chunk_size, left_context, 0}, st,
+        [&](hipStream_t s) { run(codes_dev, wav_dev, s); },
+        [&](hipStream_t s) { run(c->g_codes.as<int64_t>(), c->g_wav.as<float>(), s); },
+        [&](hipStream_t s) { QTTS_CHECK_HIP(hipMemcpyAsync(c->g_codes.p, codes_dev, cbytes, hipMemcpyDeviceToDevice, s)); },
+        [&](hipStream_t s) { QTTS_CHECK_HIP(hipMemcpyAsync(wav_dev, c->g_wav.p, wbytes, hipMemcpyDeviceToDevice, s)); });
     if (!lengths_host) c->check_codes_flag(st);      // (with lengths the codes were validated on the host above)
     QTTS_API_END
 }

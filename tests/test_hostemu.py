@@ -864,9 +864,9 @@ def test_decoder_orchestration_forward_and_chunked(emu, codec):
 
 
 def test_decode_call_graph_replay_equals_eager(emu, codec):
-    """Round 4: `qtts_codec_forward` / `qtts_codec_decode` replay a captured graph from the second call with the same (codes pointer,
-    output pointer, B, T, chunking) on.  Same buffers, new contents -> the replay must see the new contents (the graph bakes
-    addresses, not data); another buffer or shape runs eagerly; the cache is an LRU of 8."""
+    """Round 4: `qtts_codec_forward` / `qtts_codec_decode` replay a captured graph from the second call with the same SHAPE (B, T,
+    chunking) on: the engine copies the codes into its own staging buffer, replays, and copies the waveform out, so the caller's
+    addresses do not matter (new tensors per call still replay) and new contents are seen; the cache is an LRU of 8 shapes."""
     c, w, h = codec
 
     class St(C.Structure):
@@ -900,19 +900,29 @@ def test_decode_call_graph_replay_equals_eager(emu, codec):
     assert emu.qtts_codec_decode(h, _ptr(padded), 2, T, 4, 3, _ptr(out), None, None) != 0
     padded[0, 0, 0] = 0
     _ok(emu, emu.qtts_codec_decode(h, _ptr(padded), 2, T, 4, 3, _ptr(out), None, None))
-    # forward(): its own key space (pre-clamp pointer included)
+    # forward(): its own key space (with / without the pre-clamp output); OTHER buffers of the same shape replay the same graph
     codes = np.ascontiguousarray(rng.integers(0, c.codebook_size, (1, c.num_quantizers, 5)))
-    w1, w2, pre = (np.zeros((1, 5 * c.total_upsample), np.float32) for _ in range(3))
+    w1, w2, w3, pre = (np.zeros((1, 5 * c.total_upsample), np.float32) for _ in range(4))
     _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w1), None, None))
+    cap0, rep0 = stats()[:2]
     _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w1), None, None))        # captured here
-    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w2), _ptr(pre), None))   # other outputs: eager
-    assert np.array_equal(w1, w2) and np.abs(pre).max() > 0
-    # LRU: ten more keys (distinct output buffers), each seen twice -> at most 8 graphs stay cached, all results still right
-    bufs = [np.zeros((1, 5 * c.total_upsample), np.float32) for _ in range(10)]
-    for _ in range(2):
-        for b in bufs:
-            _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(b), None, None))
-    assert all(np.array_equal(b, w1) for b in bufs) and stats()[2] <= 8
+    codes2 = codes.copy()
+    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes2), 1, 5, _ptr(w2), None, None))       # other addresses, same shape: replay
+    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w3), _ptr(pre), None))   # with the pre-clamp output: another key, eager
+    cap1, rep1 = stats()[:2]
+    assert (cap1 - cap0, rep1 - rep0) == (1, 2)
+    assert np.array_equal(w1, w2) and np.array_equal(w1, w3) and np.abs(pre).max() > 0
+    # LRU: ten more shapes, each seen twice -> at most 8 graphs stay cached, results still right; growing the staging buffers
+    # (a larger shape) drops the graphs that baked the old addresses, and the small shape captures again
+    for T2 in range(6, 16):
+        cd = np.ascontiguousarray(rng.integers(0, c.codebook_size, (1, c.num_quantizers, T2)))
+        a, b = (np.zeros((1, T2 * c.total_upsample), np.float32) for _ in range(2))
+        _ok(emu, emu.qtts_codec_forward(h, _ptr(cd), 1, T2, _ptr(a), None, None))
+        _ok(emu, emu.qtts_codec_forward(h, _ptr(cd), 1, T2, _ptr(b), None, None))
+        assert np.array_equal(a, b)
+    assert stats()[2] <= 8
+    _ok(emu, emu.qtts_codec_forward(h, _ptr(codes), 1, 5, _ptr(w2), None, None))
+    assert np.array_equal(w1, w2)
 
 
 def test_stream_push_equals_whole_sequence_forward(emu, codec):
