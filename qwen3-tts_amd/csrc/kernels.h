@@ -225,6 +225,21 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st);
 void launch_rope_table(const float* inv_freq, int n_pos, float* out, hipStream_t st);
 inline size_t attn_part_floats(int B, int nkv, int nsplit, int gq) { return (size_t)B * nkv * nsplit * gq * 130; }
 
+// The code predictor's passes >= 1, attention + o-projection in one launch (attention.hip: cp_attn_o_kernel).  `a` as for
+// launch_attn_decode (its out / ldo / out_bf16 are not used); the o-projection's operator packed by pack_skinny_weight(bf16, fs = 16).
+struct CpAttnOParams {
+    AttnDecodeParams a;
+    const void* Wo;               // [H / 16 strips][nh * hd / 32 k-tiles][4][16][8] bf16
+    const float* res;             // residual rows [B][H] (may be `out`)
+    float* out;                   // hidden rows [B][H] fp32
+    unsigned short* out16;        // optional bf16 copy [B][H]
+    float* part;                  // scratch [nkv][8][H] fp32: one partial sum per kv head
+    unsigned* cnt;                // [H / 128] arrival counters, zero between launches
+    int H;
+};
+bool cp_attn_o_takes(const AttnDecodeParams& a, int H);
+void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st);
+
 // --------------------------------------------------------------------------------- sampling.hip
 struct SampleParams {
     const float* logits; int ld; int V; int B;

@@ -26,6 +26,7 @@ struct LayerW {
     int fs_o = 16, fs_d = 16;         // features per strip of o_p / d_p
     DevBuf qkv_p, o_p, gu_p, d_p;     // packed (decode)
     DevBuf gu_p8;                     // gate|up packed with 8-row interleave (ACT_SWIGLU8: the batch <= 8 kernel, twice the workgroups); bf16 only
+    DevBuf o_p16;                     // o-projection in 16-feature strips for the fused attention + o-projection launch (code predictor, bf16 only)
     DevBuf qkv_r, o_r, gu_r, d_r;     // row-major (prefill, talker only)
     DevBuf g1, g2, qn, kn;
 };
@@ -207,6 +208,11 @@ struct qtts_talker {
     // instead of N / 32 strip pairs -- 768 instead of 384 for the talker: three per CU instead of 1.5, 9.5 vs 10.7 us streamed.
     // Bit-identical results (the same per-element accumulation), a second packed copy of the operator.  QTTS_SWIGLU8=0: strip pairs.
     bool swiglu8_env = [] { const char* e = getenv("QTTS_SWIGLU8"); return !e || atoi(e) != 0; }();
+    // QTTS_CP_ATTN_O=0: attn_cp + the decode GEMM as two launches (A/B; read at engine creation and, for the launch choice, per QTTS_ENV)
+    bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
+    static bool cp_attn_o_off() { const char* e = QTTS_ENV("QTTS_CP_ATTN_O"); return e && e[0] == '0'; }
+    DevBuf ao_part, ao_cnt;            // cp_attn_o: [8 kv heads][8 rows][H] fp32 partial sums; [H / 128] arrival counters (zero between launches)
+    int64_t cp_attn_o_count = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
                          PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
@@ -223,6 +229,10 @@ struct qtts_talker {
             upload_packed(L.gu_p8, interleave_gu8(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H),
                           2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);
+        // code predictor, bf16: passes >= 1 run attention + o-projection as ONE launch (attention.hip: cp_attn_o_kernel), whose waves
+        // own 16-feature strips of the operator (a second packed copy when the decode GEMM's strips are narrower: 4 MB per layer)
+        if (bf16 && !rows && cp_attn_o_env && d.nh == 16 && d.nkv == 8 && d.hd == 128 && d.H % 128 == 0)
+            upload_packed(L.o_p16, ow, d.H, d.qd, nullptr, 16);
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
             upload_rows(L.o_r, ow);
@@ -307,6 +317,15 @@ struct qtts_talker {
         // staged into the consuming GEMM by LDS-DMA
         const bool att16 = bf16 && skinny_takes_bf16_x(M, d.qd, true), act16 = bf16 && skinny_takes_bf16_x(M, d.I, true);
         a.out_bf16 = att16;
+        // bf16 engines, code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k by kv head,
+        // partial sums combined by the last arriver of each 128-feature chunk in kv-head order; profiles/r04_cp_attn_o.md)
+        if (L.o_p16.p && ao_part.p && att16 && !skinny_only && !cp_attn_o_off() && cp_attn_o_takes(a, d.H)) {
+            CpAttnOParams f{};
+            f.a = a; f.Wo = L.o_p16.p; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
+            f.part = ao_part.as<float>(); f.cnt = ao_cnt.as<unsigned>(); f.H = d.H;
+            launch_cp_attn_o(f, st);
+            ++cp_attn_o_count;
+        } else {
         if (!skinny_only) launch_attn_decode(a, st);
         SkinnyParams o{};
         o.done_flag = ss.done;
@@ -315,6 +334,7 @@ struct qtts_talker {
         o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr; o.fs = L.fs_o;
         if (splitk) { o.out = sk_part.as<float>(); o.ksplit = 2; o.part_stride = pstride; }     // (o.res = xs: half 0 = residual + its sums)
         skinny(o, st);
+        }
         SkinnyParams g{};
         g.done_flag = ss.done;
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
@@ -539,6 +559,11 @@ void qtts_talker::finalize() {
         const size_t hmax = (size_t)std::max(td.H, cd.H);
         sk_part.alloc(2 * 8 * hmax * 4);
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
+    }
+    if (bf16 && !cl.empty() && cl[0].o_p16.p) {
+        ao_part.alloc((size_t)8 * 8 * cd.H * 4); ao_cnt.alloc((size_t)(cd.H / 128) * 4);
+        QTTS_CHECK_HIP(hipMemset(ao_part.p, 0, ao_part.bytes));
+        QTTS_CHECK_HIP(hipMemset(ao_cnt.p, 0, ao_cnt.bytes));
     }
     n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size); seed_d.alloc(8);
     QTTS_CHECK_HIP(hipMemset(ss_rows.p, 0, ss_rows.bytes));

@@ -77,6 +77,7 @@ struct Machine {
     dim3 block_idx, block_dim, grid_dim;
     const std::function<void()>* body = nullptr;
     int order = 0;                    // fiber scheduling order: 0 ascending thread id, 1 descending, >= 2 seeded shuffle of waves
+    int block_order = 0;              // workgroup execution order of a launch: 0 ascending blockIdx, 1 descending, >= 2 seeded shuffle
 };
 inline Machine& M() { static Machine m; return m; }
 
@@ -253,9 +254,21 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
 template <class F>
 inline void launch(dim3 grid, dim3 block, F&& body) {
     std::function<void()> fn = body;
+    // The hardware starts the workgroups of a launch in no promised order and runs them concurrently; a kernel whose workgroups talk to
+    // each other (arrival tickets, last-arriver reductions) must give the same result for every order: hostemu_set_block_order.
+    const int bo = M().block_order;
+    std::vector<unsigned> xs(grid.x);
+    for (unsigned i = 0; i < grid.x; ++i) xs[i] = bo == 1 ? grid.x - 1 - i : i;
+    if (bo >= 2) {
+        uint64_t st = 0x9E3779B97F4A7C15ull * (uint64_t)bo + grid.x;
+        for (unsigned w = grid.x; w > 1; --w) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(xs[w - 1], xs[(st >> 33) % w]);
+        }
+    }
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) run_block(fn, dim3(bx, by, bz), block, grid);
+            for (unsigned bi = 0; bi < grid.x; ++bi) run_block(fn, dim3(xs[bi], by, bz), block, grid);
 }
 
 // Thread-independent kernels (no barrier, no cross-lane op) do not need fibers: translation units compiled with
@@ -385,4 +398,10 @@ inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+// agent-scope atomics between workgroups (arrival tickets): one workgroup runs at a time, so plain operations
+#define __HIP_MEMORY_SCOPE_AGENT 4
+namespace simt { template <class T, class V> inline T atomic_fetch_add(T* p, V v) { const T o = *p; *p = (T)(o + v); return o; } }
+#define __hip_atomic_fetch_add(p, v, order, scope) simt::atomic_fetch_add((p), (v))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+#define __hip_atomic_load(p, order, scope) (*(p))
 inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }

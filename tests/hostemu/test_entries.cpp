@@ -12,6 +12,9 @@ namespace qtts { extern int g_real_gemm; void launch_gemm_tap_real(const GemmTap
 // 0: fibers resume in ascending thread order, 1: descending, >= 2: seeded shuffle of the waves (see simt::run_block)
 extern "C" void hostemu_set_fiber_order(int order) { simt::M().order = order; }
 
+// 0: the workgroups of a launch run in ascending blockIdx.x order, 1: descending, >= 2: seeded shuffle (see simt::launch)
+extern "C" void hostemu_set_block_order(int order) { simt::M().block_order = order; }
+
 extern "C" void hostemu_set_real_gemm(int on) { qtts::g_real_gemm = on ? 1 : 0; }
 
 // the codec's final convolution (C -> 1, k = 7, causal) + clamp: x fp32 [B*T][C] through final_conv_kernel, or x16 bf16 bits through
@@ -177,6 +180,45 @@ extern "C" int hostemu_attn_decode(const float* qkv, int ld, int B, int n_new, i
             }
         }
         qtts::launch_attn_decode(p, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
+// The code predictor's attention + o-projection of one single-token pass (bf16 cache, 16 query / 8 kv heads of 128) on B rows:
+// fused = 0: attn_cp (bf16 output) followed by the decode GEMM (bf16 x, strips of `fs_unfused` features, + residual), as the engine ran it
+// through round 3; fused = 1: cp_attn_o_kernel.  Same inputs, K / V pools updated in place, hidden rows to out (fp32) and out16 (bf16).
+extern "C" int hostemu_cp_attn_o(const float* qkv, int ld, int B, const float* qw, const float* kw, float eps, const float* inv_freq, int S0,
+                                 void* kpool, void* vpool, const int* page_table, int pages_per_seq, const float* Wo, int H,
+                                 const float* res, float* out, unsigned short* out16, int fused, int fs_unfused, const float* rope_cs, int rope_cs_n) {
+    try {
+        const int nh = 16, nkv = 8, qd = nh * 128;
+        qtts::AttnDecodeParams a{};
+        a.qkv = qkv; a.ld = ld; a.B = B; a.n_new = 1; a.nh = nh; a.nkv = nkv; a.hd = 128;
+        a.qw = qw; a.kw = kw; a.eps = eps; a.inv_freq = inv_freq; a.len_static = S0;
+        a.kv.k = kpool; a.kv.v = vpool; a.kv.page_table = page_table; a.kv.pages_per_seq = pages_per_seq;
+        a.kv.n_pages = B * pages_per_seq; a.kv.nkv = nkv; a.kv.hd = 128; a.kv.bf16 = 1; a.kv.contig = page_table ? 0 : 1;
+        a.layer = 0; a.max_len = 32; a.rope_cs = rope_cs; a.rope_cs_n = rope_cs_n;
+        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(H, qd, true));
+        for (int i = 0; i < B * H; ++i) out[i] = res[i];            // the engine's residual stream is updated in place
+        if (fused) {
+            qtts::pack_skinny_weight(Wo, H, qd, true, wp.data(), nullptr, 16);
+            std::vector<float> part((size_t)8 * 8 * H, NAN);
+            std::vector<unsigned> cnt(H / 128, 0u);
+            qtts::CpAttnOParams f{};
+            f.a = a; f.Wo = wp.data(); f.res = out; f.out = out; f.out16 = out16; f.part = part.data(); f.cnt = cnt.data(); f.H = H;
+            if (!qtts::cp_attn_o_takes(a, H)) return -2;
+            qtts::launch_cp_attn_o(f, nullptr);
+            for (unsigned c : cnt) if (c != 0u) return -3;           // every counter is back at zero for the next launch
+            return 0;
+        }
+        std::vector<qtts::bf16_t> att((size_t)B * qd, (qtts::bf16_t)0x7FC0);
+        a.out = reinterpret_cast<float*>(att.data()); a.ldo = qd; a.out_bf16 = 1;
+        qtts::launch_attn_decode(a, nullptr);
+        qtts::pack_skinny_weight(Wo, H, qd, true, wp.data(), nullptr, fs_unfused);
+        qtts::SkinnyParams p{};
+        p.x = reinterpret_cast<const float*>(att.data()); p.x_bf16 = 1; p.ldx = qd; p.M = B; p.Wp = wp.data(); p.N = H; p.K = qd;
+        p.fs = fs_unfused; p.res = out; p.ldr = H; p.out = out; p.ldo = H; p.act = qtts::ACT_NONE; p.out16 = out16;
+        qtts::launch_skinny(p, true, nullptr);
         return 0;
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }

@@ -686,6 +686,45 @@ def test_pair_kernel_equals_the_generic_decode_gemm_on_the_frame_step(dev, golde
     assert agree0 >= 0.97 and rel <= 5e-3
 
 
+def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(dev, golden_dir):
+    """`cp_attn_o_kernel` (round 4: the code predictor's attention + o-projection of passes >= 1 in ONE launch, split over k by kv head,
+    partial sums published write-through and combined by the last arriver of every 128-feature chunk) against the two launches it
+    replaces (QTTS_CP_ATTN_O=0) on the hardware, through the whole frame step: 0.6B dims, batch 8, bf16, 40 frames teacher-forced with the
+    reference's golden codes, captured frame graph.  (1) The fused engine run three times gives the same 8 x 40 x 16 codes bit for bit:
+    every one of its 40 x 14 x 5 x 8 cross-workgroup hand-offs delivered complete partial sums, whoever arrived last.  (2) Both forms
+    compute the same bf16 products in a different fp32 summation order; the 15 sub-codebooks run free inside a frame on seeded random
+    weights with near-flat logits (a rounding-level flip in one pass changes the passes after it: 0.91 between the two decode-GEMM
+    kernels of the test above), so the bar on their agreement is 0.85.  (3) The graph of the fused engine has 70 fewer kernel nodes."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    cfg = synth.talker_06b()
+    g = np.load(os.path.join(golden_dir, "talker_06b_b8.npz"))
+    wn = synth.talker_weights(cfg, with_text=False)
+    lens = [int(x) for x in g["lens"]]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+    gc = torch.from_numpy(g["codes"][:, :40].copy())
+    res, nodes = {}, {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["QTTS_CP_ATTN_O"] = flag
+            eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=True)
+            runs = [eng.generate(emb, mask, tr, pad, teacher_codes=gc, suppress_tokens=_suppress(cfg)).own.cpu().numpy() for _ in range(3 if flag == "1" else 1)]
+            res[flag] = runs
+            nodes[flag] = int(eng.stats()["graph_nodes"])
+            del eng
+            torch.cuda.empty_cache()
+    finally:
+        os.environ.pop("QTTS_CP_ATTN_O", None)
+    f = res["1"]
+    assert np.array_equal(f[0], f[1]) and np.array_equal(f[0], f[2]), "the fused launch is not run-to-run identical (a stale or partial hand-off)"
+    agree = float((f[0][:, :, 1:] == res["0"][0][:, :, 1:]).mean())
+    agree_gold = float((f[0][:, :40, 1:] == g["codes"][:, :40, 1:]).mean())
+    plain_gold = float((res["0"][0][:, :40, 1:] == g["codes"][:, :40, 1:]).mean())
+    print(f"cp_attn_o vs attn_cp + decode GEMM (0.6B, 8 x 40 frames, teacher-forced): sub-codebooks agree {agree:.4f}; against the fp32 golden: "
+          f"fused {agree_gold:.4f}, two launches {plain_gold:.4f}; graph nodes {nodes['1']} vs {nodes['0']}")
+    assert nodes["0"] - nodes["1"] == 14 * cfg.cp_num_hidden_layers, nodes
+    assert agree >= 0.85 and agree_gold >= plain_gold - 0.03
+
+
 def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
     """Sampling cannot be bit-compared (torch's RNG stream is not portable): check the first sampled token's
     empirical distribution over many Philox seeds against the oracle's processed softmax (chi-square), and that

@@ -53,6 +53,8 @@ def emu():
     fp = C.POINTER(C.c_float)
     lib.hostemu_set_real_gemm.argtypes = [i32]; lib.hostemu_set_real_gemm.restype = None
     lib.hostemu_set_fiber_order.argtypes = [i32]; lib.hostemu_set_fiber_order.restype = None
+    lib.hostemu_set_block_order.argtypes = [i32]; lib.hostemu_set_block_order.restype = None
+    lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
@@ -680,6 +682,97 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
                     gotk = (gotk.astype(np.uint32) << 16).view(np.float32) if bf16 else gotk
                     assert np.abs(gotk - newk[b, :, t]).max() <= (2e-2 if bf16 else 1e-5), (b, t)
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_cp_attn_o_fused_launch_real_source(emu):
+    """attention.hip's `cp_attn_o_kernel` (round 4: the code predictor's attention AND o-projection of a single-token pass in one
+    launch -- the GEMM split over k by kv head, 64 workgroups publishing 8 x 128 partial sums, the last arriver of every 128-feature
+    chunk adding them in kv-head order + the residual) from its real source at the code predictor's real dimensions (16 / 8 heads of
+    128, hidden 1024), against (a) the two launches it replaces -- `attn_cp_kernel` + the decode GEMM -- on the same inputs: the K / V
+    rows appended to the cache are BIT-identical (the attention stage is attn_cp's arithmetic statement for statement), the hidden
+    rows agree to fp32 summation order (the same bf16 products, 8 partial sums of 256 instead of the decode GEMM's tile order);
+    (b) float64 numpy; for every workgroup execution order (ascending, descending, two shuffles: who is the last arriver changes,
+    the result may not) and two fiber orders, batch 8 / 5 / 1, cache lengths 1..15, contiguous and permuted page tables, with and
+    without the RoPE table, and with the arrival counters back at zero after every launch."""
+    g = np.random.default_rng(404)
+    HD, nh, nkv, H, eps = 128, 16, 8, 1024, 1e-6
+    qd, ld = nh * HD, (nh + 2 * nkv) * HD
+    inv_freq = (1.0 / (10000.0 ** (np.arange(64) / 64.0))).astype(np.float32)
+    qw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+    kw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+    Wo = (g.standard_normal((H, qd)) * 0.03).astype(np.float32)
+    Wo_r = _bf16_round(Wo)[0].astype(np.float64)
+    rope = np.zeros((17, 2, 64), np.float32)                       # launch_rope_table's layout, from the same fp32 angle
+    for pos in range(17):
+        ang = (np.float32(pos) * inv_freq).astype(np.float32)
+        rope[pos, 0], rope[pos, 1] = np.cos(ang), np.sin(ang)
+
+    def normrope(x, w, pos):
+        x = x.astype(np.float64)
+        x = w * (x / np.sqrt((x ** 2).mean() + eps))
+        ang = np.float32(pos) * inv_freq
+        c, s = np.cos(ang.astype(np.float64)), np.sin(ang.astype(np.float64))
+        return np.concatenate([x[:64] * c - x[64:] * s, x[64:] * c + x[:64] * s])
+
+    for (B, S0, permute, use_tab) in [(8, 7, False, True), (5, 15, True, False), (1, 1, False, True), (8, 2, True, True)]:
+        pps = 2
+        n_pages = B * pps
+        table = (g.permutation(n_pages) if permute else np.arange(n_pages)).astype(np.int32).reshape(B, pps)
+        qkv = g.standard_normal((B, ld)).astype(np.float32)
+        res = g.standard_normal((B, H)).astype(np.float32)
+        K = _bf16_round((g.standard_normal((B, nkv, S0, HD)) * 0.7).astype(np.float32))[0]
+        V = _bf16_round(g.standard_normal((B, nkv, S0, HD)).astype(np.float32))[0]
+        kpool = np.full((n_pages, nkv, 16, HD), 0x7FC0, np.uint16)  # never-written slots hold bf16 NaN
+        vpool = kpool.copy()
+        for b in range(B):
+            for s in range(S0):
+                kpool[table[b, s // 16], :, s % 16] = _bf16_round(K[b, :, s])[1]
+                vpool[table[b, s // 16], :, s % 16] = _bf16_round(V[b, :, s])[1]
+        # float64 reference: attention (bf16 K / V, new key through bf16), output through bf16, o-projection with bf16 weights
+        ref = np.zeros((B, H))
+        for b in range(B):
+            att = np.zeros(qd)
+            for h in range(nkv):
+                row = qkv[b]
+                nk = _bf16_round(normrope(row[(nh + h) * HD:(nh + h + 1) * HD], kw, S0).astype(np.float32))[0]
+                nv = _bf16_round(row[(nh + nkv + h) * HD:(nh + nkv + h + 1) * HD])[0]
+                keys = np.concatenate([K[b, h].astype(np.float64), nk[None].astype(np.float64)], 0)
+                vals = np.concatenate([V[b, h].astype(np.float64), nv[None].astype(np.float64)], 0)
+                for gq in range(2):
+                    hq = 2 * h + gq
+                    q = normrope(row[hq * HD:(hq + 1) * HD], qw, S0)
+                    sc = keys @ q / np.sqrt(HD)
+                    pr = np.exp(sc - sc.max()); pr /= pr.sum()
+                    att[hq * HD:(hq + 1) * HD] = pr @ vals
+            ref[b] = Wo_r @ _bf16_round(att.astype(np.float32))[0].astype(np.float64) + res[b]
+
+        def run(fused, block_order=0, fiber_order=0):
+            kk, vv = kpool.copy(), vpool.copy()
+            out = np.full((B, H), np.nan, np.float32)
+            out16 = np.full((B, H), 0x4242, np.uint16)
+            emu.hostemu_set_block_order(block_order); emu.hostemu_set_fiber_order(fiber_order)
+            try:
+                rc = emu.hostemu_cp_attn_o(_ptr(qkv), ld, B, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), S0, _ptr(kk), _ptr(vv),
+                                           _ptr(table) if permute else None, pps, _ptr(Wo), H, _ptr(res), _ptr(out), _ptr(out16), fused, 8,
+                                           _ptr(rope) if use_tab else None, 17 if use_tab else 0)
+            finally:
+                emu.hostemu_set_block_order(0); emu.hostemu_set_fiber_order(0)
+            assert rc == 0, ((B, S0, fused), rc, (emu.qtts_last_error() or b"").decode())
+            return out, out16, kk, vv
+
+        o0, h0, k0, v0 = run(0)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(o0 - ref).max()) <= 2e-2 * scale, "the unfused pair is off its own reference"
+        first = None
+        for (bo, fo) in [(0, 0), (1, 0), (2, 1), (3, 2)]:
+            o1, h1, k1, v1 = run(1, bo, fo)
+            assert np.array_equal(k1, k0) and np.array_equal(v1, v0), ("K / V append differs from attn_cp", B, S0, bo)
+            assert float(np.abs(o1 - o0).max()) <= 2e-5 * scale, (B, S0, bo, float(np.abs(o1 - o0).max()))
+            assert float(np.abs(o1 - ref).max()) <= 2e-2 * scale
+            assert np.array_equal(h1, _bf16_round(o1)[1]), "bf16 copy of the hidden rows"
+            if first is None:
+                first = o1
+            assert np.array_equal(o1, first), ("result depends on the arrival order", B, S0, bo, fo)
 
 
 @pytest.mark.parametrize("nsplit", [1, 3])
@@ -1425,6 +1518,50 @@ def test_talker_fp32_split_k_layer_chain_vs_oracle(emu):
         assert np.abs(hidden - ref_h).max() <= 2e-4 * max(1.0, float(np.abs(ref_h).max()))
     finally:
         emu.qtts_talker_destroy(h)
+
+
+def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeypatch):
+    """Round 4: the ENGINE side of `cp_attn_o_kernel` -- the second packed copy of the o-projection (16-feature strips), the partial-sum
+    and counter buffers, which passes take the fused launch (passes >= 1 of a bf16 engine at batch <= 8; pass 0 with its two new tokens
+    keeps attn_cp0 + the decode GEMM) -- on a predictor with the real head geometry (16 query / 8 kv heads of 128) and a 256-wide hidden
+    state (two 128-feature chunks), greedy bf16, eager and through the captured frame graph: the codes and hidden states equal those of
+    the same engine with QTTS_CP_ATTN_O=0 (two launches) up to bf16 noise, the captured graph has (passes - 1) x layers fewer kernel
+    nodes, and a second generation on the same handle (counters re-used) repeats the first bit for bit."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=256, cp_intermediate_size=256, cp_num_hidden_layers=2,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(23), t, [5, 3, 6], 2, scale=0.5)
+    args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
+    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+    emu.hostemu_set_real_gemm(1)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("QTTS_CP_ATTN_O", mode)
+            for use_graph in (0, 1):
+                h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=use_graph)
+                try:
+                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=5)
+                    codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=5)
+                    assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2), (mode, use_graph)
+                    st = _lib.TalkerStatsC()
+                    _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+                    res[(mode, use_graph)] = (codes, hidden, int(st.graph_nodes))
+                finally:
+                    emu.qtts_talker_destroy(h)
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
+    for mode in ("1", "0"):                                          # eager == graph, as for every other path of the engine
+        assert np.array_equal(res[(mode, 0)][0], res[(mode, 1)][0]) and np.array_equal(res[(mode, 0)][1], res[(mode, 1)][1]), mode
+    fused, plain = res[("1", 1)], res[("0", 1)]
+    assert plain[2] - fused[2] == (t.num_code_groups - 2) * t.cp_num_hidden_layers, (plain[2], fused[2])
+    n = min(fused[0].shape[1], plain[0].shape[1])
+    assert n >= 2 and float((fused[0][:, :n] == plain[0][:, :n]).mean()) >= 0.9
+    same = (fused[0][:, :n] == plain[0][:, :n]).all(axis=(0, 2))      # frames up to the first differing code see the same inputs
+    k = int(np.argmin(same)) if not same.all() else n
+    assert k >= 1
+    assert np.abs(fused[1][:, :k] - plain[1][:, :k]).max() <= 2e-2 * max(1.0, float(np.abs(plain[1][:, :k]).max()))
 
 
 def test_talker_orchestration_no_projection_vs_oracle(emu):
