@@ -1399,18 +1399,22 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
 
 // =================================================================================== cp_attn_o (round 4)
 // The code predictor's passes >= 1: attention AND the o-projection in one launch (70 launch pairs per frame).  As two launches the pair
-// costs ~10.3 us (attn_cp 5.1 + the 4 MB o-projection 5.2, each mostly boundary + first round trip); the attention output is the
-// o-projection's k dimension, head by head, so the GEMM is split over k BY KV HEAD:
-//   workgroup (kv head g, 128-feature chunk c), 8 waves.  Wave r runs the attention of sequence r for the two query heads of kv head g --
+// costs ~8.5 us on the in-kernel clock (attn_cp 2.4 + boundary 1.7 + the 4 MB o-projection 2.7 + boundary 1.7); the attention output is
+// the o-projection's k dimension, head by head, so the GEMM is split over k BY KV HEAD:
+//   workgroup (kv head g, 128-feature chunk c), 16 waves.  Wave (sequence r, query head hh of the kv head) runs that head's attention --
 //     the arithmetic of attn_cp, statement for statement (q / k RMSNorm + RoPE at the static position, K / V rounded through the cache
 //     type, 16 key slots, fp32 softmax, PV) -- out of a wave-private LDS slice; only chunk 0 appends K / V.  The eight chunk workgroups
 //     of a kv head repeat that attention (a few KB of reads each) instead of exchanging it.  Its 8 x 256 bf16 result is the B operand
-//     of 8 MFMAs per wave against this wave's 16-feature strip of Wo[:, 256 g .. 256 g + 255] (requested at kernel entry: it streams
-//     while the attention runs) -> an 8 x 128 fp32 partial sum per workgroup;
-//   the partial sums leave by write-through (sc1) stores, every wave drains them, one relaxed agent-scope ticket per workgroup; the
-//     workgroup that draws the last ticket of its chunk adds the nkv partial sums in kv-head order + the residual and writes the
-//     hidden state (fp32 + bf16 copy): a fixed summation order, so results do not depend on arrival order.  (Guide: "in-launch
-//     split-K reduction", the sc1 form; the slabs are 4 KB per workgroup.)
+//     of the MFMAs against this workgroup's 128 x 256 block of Wo (wave = 16-feature strip x the 128 k of one query head, requested at
+//     kernel entry: it streams while the attention runs; the two k halves are added through LDS) -> an 8 x 128 fp32 partial sum;
+//   hand-off WITHOUT a ticket: every value leaves as an 8-byte granule {fp32 value, launch tag} in one write-through (sc1) store -- the
+//     tag is the chunk's epoch counter + 1, so a granule of an earlier launch can never be taken for this one's.  The workgroup of the
+//     LAST kv head is its chunk's reducer: it keeps its own partial sum in LDS, reads the other seven slabs with sc1 loads until every
+//     granule carries the tag (they were stored while it was still computing: normally the first read), adds the eight partial sums in
+//     kv-head order + the residual, writes the hidden state (fp32 + bf16 copy) and advances the epoch.  A fixed summation order, so the
+//     result does not depend on timing.  (First version, profiles/r04_cp_attn_o.md: partial sums + drained stores + an arrival ticket +
+//     last-arriver reduction = 3.2 us of hand-off inside a 6.7-us kernel: no gain over the two launches.  Guide: data-tagged granules.)
+//   The reducer polls; it cannot hang the device: after SPIN_LIMIT re-reads it gives up, raises `err` and writes what it has.
 // bf16 cache, two query heads per kv head, head_dim 128, batch <= 8 only; everything else keeps attn_cp + the decode GEMM.
 namespace {
 typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
@@ -1419,43 +1423,49 @@ struct WtBuf { unsigned char* base; };
 __device__ inline WtBuf wt_buf(void* p, size_t) { return WtBuf{static_cast<unsigned char*>(p)}; }
 __device__ inline void wt_store16(const WtBuf& b, int off, cu32x4 v) { *reinterpret_cast<cu32x4*>(b.base + off) = v; }
 __device__ inline cu32x4 wt_load16(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
-__device__ inline void wt_drain() {}
+__device__ inline void wt_pause() {}
+constexpr int CPAO_SPIN_LIMIT = 2;                      // (workgroups run one after the other here: a second read never helps)
 #else
 struct WtBuf { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ WtBuf wt_buf(void* p, size_t bytes) { return WtBuf{__builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000)}; }
-// aux = 16: sc1 -- the store writes through to memory, the load is served below this XCD's L2 lines of other XCDs' writers
+// aux = 16: sc1 -- the store writes through to memory, the load is not served from this CU's L1
 __device__ __forceinline__ void wt_store16(const WtBuf& b, int off, cu32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
 __device__ __forceinline__ cu32x4 wt_load16(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
-__device__ __forceinline__ void wt_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wt_pause() { __builtin_amdgcn_s_sleep(2); }
+constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a producer that never stores is a bug, not a wait
 #endif
 }  // namespace
 
 template <bool CT>
-__global__ __launch_bounds__(512) void cp_attn_o_kernel(CpAttnOParams P) {
+__global__ __launch_bounds__(1024) void cp_attn_o_kernel(CpAttnOParams P) {
     constexpr int HD = 128, MAXK = 16, KW = 4, NKV = 8, BSTR = 264;       // BSTR: bf16 per row of the B tile (16-B rows, bank-spread)
     typedef bf16_t KVT;
-    // ONE LDS object (a second one de-pipelines the loads around it): [8 waves][qs0 | qs1 | kn | vn : 128 floats each] | B tile [16][BSTR] | ticket
-    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * 2048 + 16 * BSTR * 2 + 16];
+    // ONE LDS object (a second one de-pipelines the loads around it):
+    //   [16 waves][q | kn | vn : 128 floats each] | B tile [16][BSTR] bf16 | k-half exchange [8 strips][64 lanes][4] floats | own partial sum [8][128] floats
+    constexpr int WS_BYTES = 16 * 1536, BT_BYTES = 16 * BSTR * 2, RED_BYTES = 8 * 64 * 16, OWN_BYTES = 8 * 128 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + RED_BYTES + OWN_BYTES];
     const AttnDecodeParams& p = P.a;
     const int nchunk = P.H >> 7;
     const int g = blockIdx.x / nchunk, c = blockIdx.x - g * nchunk;
+    QTTS_TS_BEGIN();                       // (tstamp build: 1 = every request has arrived, 2 = attention done, 3 = partial sums stored, 4 = the other slabs read, 5 = reduced)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = wave & 7, hh = wave >> 3;          // attention: sequence r, query head 2 g + hh; GEMM: strip r of the chunk, k half hh
     const int kk = lane >> 2, qq = lane & 3;
     const int S0 = p.len_static, S1 = S0 + 1;
-    const bool have = wave < p.B;
-    const int b = have ? wave : 0;
+    const bool have = r < p.B;
+    const int b = have ? r : 0;
     const KVT* kc = reinterpret_cast<const KVT*>(p.kv.k);
     const KVT* vc = reinterpret_cast<const KVT*>(p.kv.v);
     auto key_base = [&](int s) -> size_t {
         const int page = CT ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
         return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + g) * 16 + (s & 15)) * HD;
     };
-    // ---- 0. every request of the attention stage, then this wave's strip of Wo (16 features x the 256 k of kv head g: 8 KB, linear)
+    // ---- 0. every request of the attention stage, then this wave's block of Wo (16 features x the 128 k of query head hh: 4 KB, linear)
+    const unsigned tag = P.epoch[c] + 1u;
     const float* xrow = p.qkv + (size_t)b * p.ld;
-    float xq[2][2], xk[2], xv[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) { xq[h][0] = xrow[(g * 2 + h) * HD + lane]; xq[h][1] = xrow[(g * 2 + h) * HD + lane + 64]; }
+    float xq[2], xk[2], xv[2];
+    xq[0] = xrow[(g * 2 + hh) * HD + lane]; xq[1] = xrow[(g * 2 + hh) * HD + lane + 64];
     xk[0] = xrow[(p.nh + g) * HD + lane]; xk[1] = xrow[(p.nh + g) * HD + lane + 64];
     xv[0] = xrow[(p.nh + p.nkv + g) * HD + lane]; xv[1] = xrow[(p.nh + p.nkv + g) * HD + lane + 64];
     const float qw0 = p.qw[lane], qw1 = p.qw[lane + 64], kw0 = p.kw[lane], kw1 = p.kw[lane + 64], invf = p.inv_freq[lane];
@@ -1472,21 +1482,23 @@ __global__ __launch_bounds__(512) void cp_attn_o_kernel(CpAttnOParams P) {
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) vr[k] = *reinterpret_cast<const VPair*>(vc + key_base(k < S0 ? k : 0) + 2 * lane);
     }
-    cu32x4 wf[8];
+    cu32x4 wf[4];
     {
         const int nkt = (p.nh * HD) >> 5;
-        const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wo) + ((size_t)(c * 8 + wave) * nkt + g * 8) * 64 + lane;
+        const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wo) + ((size_t)(c * 8 + r) * nkt + g * 8 + hh * 4) * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) wf[ks] = wsrc[ks * 64];
+        for (int ks = 0; ks < 4; ++ks) wf[ks] = wsrc[ks * 64];
     }
     const int done = p.done_flag ? *p.done_flag : 0;
     if (done) return;
+    QTTS_TS_DRAINED(1);
 
-    float* ws = reinterpret_cast<float*>(smem + wave * 2048);          // qs0 | qs1 | kn | vn
-    bf16_t* Bt = reinterpret_cast<bf16_t*>(smem + 8 * 2048);
-    unsigned* ticket = reinterpret_cast<unsigned*>(smem + 8 * 2048 + 16 * BSTR * 2);
+    float* ws = reinterpret_cast<float*>(smem + wave * 1536);          // q | kn | vn
+    bf16_t* Bt = reinterpret_cast<bf16_t*>(smem + WS_BYTES);
+    f32x4* red = reinterpret_cast<f32x4*>(smem + WS_BYTES + BT_BYTES);
+    float* own = reinterpret_cast<float*>(smem + WS_BYTES + BT_BYTES + RED_BYTES);
     if (have) {
-        // ---- 1. q / k RMSNorm + RoPE at position S0, K / V through the cache type (attn_cp's stage 1, one vector after the other)
+        // ---- 1. q / k RMSNorm + RoPE at position S0, K / V through the cache type (attn_cp's stage 1)
         float c_ = ctab, sn = stab;
         if (!rtab) { const float ang = (float)S0 * invf; c_ = cosf(ang); sn = sinf(ang); }
         auto norm_rope = [&](float& x0, float& x1, float w0, float w1) {
@@ -1497,28 +1509,23 @@ __global__ __launch_bounds__(512) void cp_attn_o_kernel(CpAttnOParams P) {
             const float o0 = x0 * c_ - x1 * sn, o1 = x1 * c_ + x0 * sn;
             x0 = o0; x1 = o1;
         };
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            norm_rope(xq[h][0], xq[h][1], qw0, qw1);
-            ws[h * HD + lane] = xq[h][0]; ws[h * HD + lane + 64] = xq[h][1];
-        }
+        norm_rope(xq[0], xq[1], qw0, qw1);
+        ws[lane] = xq[0]; ws[lane + 64] = xq[1];
         norm_rope(xk[0], xk[1], kw0, kw1);
         {
             const size_t o = key_base(S0);
             const KVT k0 = kv_cast<KVT>(xk[0]), k1 = kv_cast<KVT>(xk[1]), v0 = kv_cast<KVT>(xv[0]), v1 = kv_cast<KVT>(xv[1]);
-            if (c == 0) {
-                KVT* kd = reinterpret_cast<KVT*>(p.kv.k);
-                KVT* vd = reinterpret_cast<KVT*>(p.kv.v);
-                kd[o + lane] = k0; kd[o + lane + 64] = k1;
-                vd[o + lane] = v0; vd[o + lane + 64] = v1;
+            if (c == 0) {                                  // one workgroup per kv head appends: head 0's wave the K row, head 1's the V row
+                if (hh == 0) { KVT* kd = reinterpret_cast<KVT*>(p.kv.k); kd[o + lane] = k0; kd[o + lane + 64] = k1; }
+                else { KVT* vd = reinterpret_cast<KVT*>(p.kv.v); vd[o + lane] = v0; vd[o + lane + 64] = v1; }
             }
-            ws[2 * HD + lane] = kv_load(&k0); ws[2 * HD + lane + 64] = kv_load(&k1);
-            ws[3 * HD + lane] = kv_load(&v0); ws[3 * HD + lane + 64] = kv_load(&v1);
+            ws[HD + lane] = kv_load(&k0); ws[HD + lane + 64] = kv_load(&k1);
+            ws[2 * HD + lane] = kv_load(&v0); ws[2 * HD + lane + 64] = kv_load(&v1);
         }
         __builtin_amdgcn_wave_barrier();             // wave-private LDS slice: program order within the wave is all that is needed
-        // ---- 2. both query heads over the 16 key slots
-        const float* kn = ws + 2 * HD;
-        const float* vn = ws + 3 * HD;
+        // ---- 2. this wave's query head over the 16 key slots
+        const float* kn = ws + HD;
+        const float* vn = ws + 2 * HD;
         float kx[32];
         if (kk == S0) {
 #pragma unroll
@@ -1532,70 +1539,106 @@ __global__ __launch_bounds__(512) void cp_attn_o_kernel(CpAttnOParams P) {
                     kx[w * 8 + 2 * e + 1] = __uint_as_float(kr[w][e] & 0xffff0000u);
                 }
         }
+        const float* q = ws + qq * 32;
+        float a = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float* q = ws + h * HD + qq * 32;
-            float a = 0.f;
+        for (int e = 0; e < 32; ++e) a += q[e] * kx[e];
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        const float s = kk < S1 ? a * rsqrtf((float)HD) : -INFINITY;
+        const float m = wave_max64_dpp(s);
+        const float e = kk < S1 ? att_exp<KVT>(s - m) : 0.f;
+        const float l = wave_sum64_dpp(qq == 0 ? e : 0.f);
+        float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) a += q[e] * kx[e];
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            const float s = kk < S1 ? a * rsqrtf((float)HD) : -INFINITY;
-            const float m = wave_max64_dpp(s);
-            const float e = kk < S1 ? att_exp<KVT>(s - m) : 0.f;
-            const float l = wave_sum64_dpp(qq == 0 ? e : 0.f);
-            float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < MAXK; ++k) {
-                if (k < S0) {
-                    const float ek = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), k * 4));
-                    acc0 += ek * kv_load(&vr[k].a);
-                    acc1 += ek * kv_load(&vr[k].b);
-                }
+        for (int k = 0; k < MAXK; ++k) {
+            if (k < S0) {
+                const float ek = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), k * 4));
+                acc0 += ek * kv_load(&vr[k].a);
+                acc1 += ek * kv_load(&vr[k].b);
             }
-            {
-                const float ek = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), S0 * 4));
-                acc0 += ek * vn[2 * lane];
-                acc1 += ek * vn[2 * lane + 1];
-            }
-            const float inv = 1.f / l;
-            const unsigned pk = (unsigned)f32_to_bf16(acc0 * inv) | ((unsigned)f32_to_bf16(acc1 * inv) << 16);
-            *reinterpret_cast<unsigned*>(Bt + wave * BSTR + h * HD + 2 * lane) = pk;
         }
+        {
+            const float ek = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e), S0 * 4));
+            acc0 += ek * vn[2 * lane];
+            acc1 += ek * vn[2 * lane + 1];
+        }
+        const float inv = 1.f / l;
+        const unsigned pk = (unsigned)f32_to_bf16(acc0 * inv) | ((unsigned)f32_to_bf16(acc1 * inv) << 16);
+        *reinterpret_cast<unsigned*>(Bt + r * BSTR + hh * HD + 2 * lane) = pk;
     }
+    QTTS_TS(2);
     __syncthreads();
-    // ---- 3. partial o-projection: D[feature 4 q + r][sequence i] over the 256 k of this kv head
+    // ---- 3. partial o-projection: D[feature 4 q + j][sequence i] of strip r over the 128 k of query head hh; the two k halves meet in LDS
     const int li = lane & 15, lq = lane >> 4;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        cu32x4 bv = *reinterpret_cast<const cu32x4*>(Bt + (li & 7) * BSTR + ks * 32 + lq * 8);
+    for (int ks = 0; ks < 4; ++ks) {
+        cu32x4 bv = *reinterpret_cast<const cu32x4*>(Bt + (li & 7) * BSTR + hh * HD + ks * 32 + lq * 8);
         if (li >= p.B) bv = (cu32x4){0u, 0u, 0u, 0u};
         bf16x8 wa, xb;
         *reinterpret_cast<cu32x4*>(&wa) = wf[ks];
         *reinterpret_cast<cu32x4*>(&xb) = bv;
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc, 0, 0, 0);
     }
-    const WtBuf slab = wt_buf(P.part, (size_t)NKV * 8 * P.H * sizeof(float));
-    if (li < p.B) wt_store16(slab, (int)((((size_t)g * 8 + li) * P.H + c * 128 + wave * 16 + lq * 4) * sizeof(float)), *reinterpret_cast<cu32x4*>(&acc));
-    wt_drain();
+    if (hh == 1) red[r * 64 + lane] = acc;
     __syncthreads();
-    if (tid == 0) *ticket = __hip_atomic_fetch_add(P.cnt + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*ticket != (unsigned)(NKV - 1)) return;
-    // ---- 4. the last arriver of chunk c: hidden = (sum over kv heads, in order) + residual
-    if (tid == 0) __hip_atomic_store(P.cnt + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (next used by a later launch)
+    const bool reducer = g == NKV - 1;
+    const WtBuf slab = wt_buf(P.part, (size_t)NKV * 8 * P.H * 8);
+    if (hh == 0) {
+        acc = acc + red[r * 64 + lane];                  // (head 0's k half) + (head 1's k half)
+        if (reducer) {
+            if (li < 8) *reinterpret_cast<f32x4*>(own + li * 128 + r * 16 + lq * 4) = acc;      // (columns 8..15 of the MFMA tile are no sequences)
+        } else if (li < p.B) {
+            const int off = (int)((((size_t)g * 8 + li) * P.H + c * 128 + r * 16 + lq * 4) * 8);
+            wt_store16(slab, off, (cu32x4){__float_as_uint(acc[0]), tag, __float_as_uint(acc[1]), tag});
+            wt_store16(slab, off + 16, (cu32x4){__float_as_uint(acc[2]), tag, __float_as_uint(acc[3]), tag});
+        }
+    }
+    QTTS_TS(3);
+#if QTTS_TSTAMP
+#define QTTS_TS_CPAO(tail_)                                                                                              \
+    if (tid == 0 && ((tail_) || blockIdx.x % 9 == 4)) {                                                                  \
+        const unsigned i_ = atomicAdd(&qtts::ts_cnt_attn, 1u);                                                           \
+        if (i_ < qtts::TS_CAP) {                                                                                         \
+            qtts::TsRec r_;                                                                                              \
+            for (int k_ = 0; k_ < 6; ++k_) r_.t[k_] = ts_[k_];                                                           \
+            r_.kind = 4; r_.a = S0; r_.b = 0; r_.blk = (int)blockIdx.x | ((tail_) << 16);                                \
+            qtts::ts_log_attn[i_] = r_;                                                                                  \
+        }                                                                                                                \
+    }
+#else
+#define QTTS_TS_CPAO(tail_)
+#endif
+    if (!reducer) { QTTS_TS_CPAO(0) return; }
+    // ---- 4. the reducer of chunk c: hidden = (sum over kv heads, in order) + residual
+    __syncthreads();                                     // (its own partial sum is in LDS)
     if (tid < 256) {
         const int row = tid >> 5, col = c * 128 + (tid & 31) * 4;
         if (row < p.B) {
-            cu32x4 pv[NKV];
+            cu32x4 pa[NKV - 1][2];
 #pragma unroll
-            for (int g2 = 0; g2 < NKV; ++g2) pv[g2] = wt_load16(slab, (int)((((size_t)g2 * 8 + row) * P.H + col) * sizeof(float)));
-            const f32x4 r = *reinterpret_cast<const f32x4*>(P.res + (size_t)row * P.H + col);
-            f32x4 s = *reinterpret_cast<f32x4*>(&pv[0]);
+            for (int g2 = 0; g2 < NKV - 1; ++g2) {
+                const int off = (int)((((size_t)g2 * 8 + row) * P.H + col) * 8);
+                pa[g2][0] = wt_load16(slab, off); pa[g2][1] = wt_load16(slab, off + 16);
+            }
+            const f32x4 res = *reinterpret_cast<const f32x4*>(P.res + (size_t)row * P.H + col);
+            int spins = 0;
 #pragma unroll
-            for (int g2 = 1; g2 < NKV; ++g2) s = s + *reinterpret_cast<f32x4*>(&pv[g2]);
-            s = s + r;
+            for (int g2 = 0; g2 < NKV - 1; ++g2) {
+                while (pa[g2][0][1] != tag || pa[g2][0][3] != tag || pa[g2][1][1] != tag || pa[g2][1][3] != tag) {
+                    if (++spins > CPAO_SPIN_LIMIT) { if (P.err) *P.err = 1; break; }
+                    wt_pause();
+                    const int off = (int)((((size_t)g2 * 8 + row) * P.H + col) * 8);
+                    pa[g2][0] = wt_load16(slab, off); pa[g2][1] = wt_load16(slab, off + 16);
+                }
+            }
+            f32x4 s = (f32x4){__uint_as_float(pa[0][0][0]), __uint_as_float(pa[0][0][2]), __uint_as_float(pa[0][1][0]), __uint_as_float(pa[0][1][2])};
+#pragma unroll
+            for (int g2 = 1; g2 < NKV - 1; ++g2)
+                s = s + (f32x4){__uint_as_float(pa[g2][0][0]), __uint_as_float(pa[g2][0][2]), __uint_as_float(pa[g2][1][0]), __uint_as_float(pa[g2][1][2])};
+            s = s + *reinterpret_cast<const f32x4*>(own + row * 128 + (tid & 31) * 4);
+            s = s + res;
             *reinterpret_cast<f32x4*>(P.out + (size_t)row * P.H + col) = s;
             if (P.out16) {
                 uint2 h16;
@@ -1604,6 +1647,10 @@ __global__ __launch_bounds__(512) void cp_attn_o_kernel(CpAttnOParams P) {
             }
         }
     }
+    QTTS_TS(4);
+    if (tid == 0) P.epoch[c] = tag;                      // (read by the next launch, behind a kernel boundary)
+    QTTS_TS_DRAINED(5);
+    QTTS_TS_CPAO(1)
 }
 
 bool cp_attn_o_takes(const AttnDecodeParams& a, int H) {
@@ -1613,10 +1660,10 @@ bool cp_attn_o_takes(const AttnDecodeParams& a, int H) {
 
 void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
     QTTS_REQUIRE(cp_attn_o_takes(P.a, P.H), QTTS_ERR_ARG, "cp_attn_o: shape (bf16 cache, 16 / 8 heads of 128, one new token, <= 16 keys, batch <= 8)");
-    QTTS_REQUIRE(P.Wo && P.res && P.out && P.part && P.cnt && P.a.qkv && P.a.qw && P.a.kw && P.a.inv_freq, QTTS_ERR_ARG, "cp_attn_o: null operand");
+    QTTS_REQUIRE(P.Wo && P.res && P.out && P.part && P.epoch && P.a.qkv && P.a.qw && P.a.kw && P.a.inv_freq, QTTS_ERR_ARG, "cp_attn_o: null operand");
     const dim3 grid(8 * (P.H / 128));
-    if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true>), grid, dim3(512), 0, st, P);
-    else hipLaunchKernelGGL((cp_attn_o_kernel<false>), grid, dim3(512), 0, st, P);
+    if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true>), grid, dim3(1024), 0, st, P);
+    else hipLaunchKernelGGL((cp_attn_o_kernel<false>), grid, dim3(1024), 0, st, P);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 

@@ -233,8 +233,9 @@ struct CpAttnOParams {
     const float* res;             // residual rows [B][H] (may be `out`)
     float* out;                   // hidden rows [B][H] fp32
     unsigned short* out16;        // optional bf16 copy [B][H]
-    float* part;                  // scratch [nkv][8][H] fp32: one partial sum per kv head
-    unsigned* cnt;                // [H / 128] arrival counters, zero between launches
+    float* part;                  // scratch [nkv][8][H] granules of 8 B {fp32 partial sum, launch tag}: zero at engine creation
+    unsigned* epoch;              // [H / 128] launch counters (the tag of a launch = epoch + 1): zero at engine creation
+    int* err;                     // optional device flag, set if a reducer gave up waiting (never in a correct run)
     int H;
 };
 bool cp_attn_o_takes(const AttnDecodeParams& a, int H);

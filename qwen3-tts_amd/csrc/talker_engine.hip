@@ -211,7 +211,7 @@ struct qtts_talker {
     // QTTS_CP_ATTN_O=0: attn_cp + the decode GEMM as two launches (A/B; read at engine creation and, for the launch choice, per QTTS_ENV)
     bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
     static bool cp_attn_o_off() { const char* e = QTTS_ENV("QTTS_CP_ATTN_O"); return e && e[0] == '0'; }
-    DevBuf ao_part, ao_cnt;            // cp_attn_o: [8 kv heads][8 rows][H] fp32 partial sums; [H / 128] arrival counters (zero between launches)
+    DevBuf ao_part, ao_cnt;            // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}; [H / 128] launch counters (epochs)
     int64_t cp_attn_o_count = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
@@ -322,7 +322,7 @@ struct qtts_talker {
         if (L.o_p16.p && ao_part.p && att16 && !skinny_only && !cp_attn_o_off() && cp_attn_o_takes(a, d.H)) {
             CpAttnOParams f{};
             f.a = a; f.Wo = L.o_p16.p; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
-            f.part = ao_part.as<float>(); f.cnt = ao_cnt.as<unsigned>(); f.H = d.H;
+            f.part = ao_part.as<float>(); f.epoch = ao_cnt.as<unsigned>(); f.err = ss.n_generated + 5; f.H = d.H;
             launch_cp_attn_o(f, st);
             ++cp_attn_o_count;
         } else {
@@ -561,7 +561,7 @@ void qtts_talker::finalize() {
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
     }
     if (bf16 && !cl.empty() && cl[0].o_p16.p) {
-        ao_part.alloc((size_t)8 * 8 * cd.H * 4); ao_cnt.alloc((size_t)(cd.H / 128) * 4);
+        ao_part.alloc((size_t)8 * 8 * cd.H * 8); ao_cnt.alloc((size_t)(cd.H / 128) * 4);
         QTTS_CHECK_HIP(hipMemset(ao_part.p, 0, ao_part.bytes));
         QTTS_CHECK_HIP(hipMemset(ao_cnt.p, 0, ao_cnt.bytes));
     }
@@ -663,7 +663,7 @@ void qtts_talker::prefill(const float* embeds, int B_, int T, const int32_t* n_p
                                       hipMemcpyDeviceToDevice, st));
     launch_rmsnorm(x.as<float>(), H, t_norm.as<float>(), td.eps, past_hidden.as<float>(), H, B, H, st);
     // loop state: the first sample+finish turns these into n_generated = 1, gen_step = 0, kv_len = T
-    int init[5] = {0, -1, T - 1, 0, 0};
+    int init[6] = {0, -1, T - 1, 0, 0, 0};          // (slot 5: cp_attn_o's give-up flag, checked when the generation ends)
     QTTS_CHECK_HIP(hipMemcpyAsync(ss.n_generated, init, sizeof(init), hipMemcpyHostToDevice, st));
     std::vector<int> ones(B, 1);
     QTTS_CHECK_HIP(hipMemcpyAsync(ss.unfinished, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -1015,9 +1015,10 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
     t->frames_run = f;
     if (t->profile == 1) t->aggregate_profile();
-    int fin[5];
+    int fin[6];
     QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
     QTTS_REQUIRE(fin[3] == 1, QTTS_ERR_STATE, "generate: loop ended without the stop condition being latched");
+    QTTS_REQUIRE(fin[5] == 0, QTTS_ERR_STATE, "generate: a cp_attn_o reducer gave up waiting for its producers' partial sums");
     *n_frames_host = fin[4] - 1;
     if (tokens_dev) {   // int32 history -> int64 (B, max_new_tokens)
         std::vector<int> h((size_t)B * max_new_tokens);
@@ -1136,8 +1137,9 @@ int qtts_talker_stream_end(qtts_talker* t, int64_t* tokens_dev, int32_t* n_frame
     hipStream_t st = (hipStream_t)stream;
     auto& g = t->sg;
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
-    int fin[5];
+    int fin[6];
     QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    QTTS_REQUIRE(fin[5] == 0, QTTS_ERR_STATE, "stream_end: a cp_attn_o reducer gave up waiting for its producers' partial sums");
     g.active = false;
     t->frames_run = g.launched;
     // an abandoned stream (ended before the stop condition) reports the frames produced so far

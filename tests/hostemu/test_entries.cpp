@@ -189,7 +189,8 @@ extern "C" int hostemu_attn_decode(const float* qkv, int ld, int B, int n_new, i
 // through round 3; fused = 1: cp_attn_o_kernel.  Same inputs, K / V pools updated in place, hidden rows to out (fp32) and out16 (bf16).
 extern "C" int hostemu_cp_attn_o(const float* qkv, int ld, int B, const float* qw, const float* kw, float eps, const float* inv_freq, int S0,
                                  void* kpool, void* vpool, const int* page_table, int pages_per_seq, const float* Wo, int H,
-                                 const float* res, float* out, unsigned short* out16, int fused, int fs_unfused, const float* rope_cs, int rope_cs_n) {
+                                 const float* res, float* out, unsigned short* out16, int fused, int fs_unfused, const float* rope_cs, int rope_cs_n,
+                                 unsigned epoch0) {
     try {
         const int nh = 16, nkv = 8, qd = nh * 128;
         qtts::AttnDecodeParams a{};
@@ -202,13 +203,18 @@ extern "C" int hostemu_cp_attn_o(const float* qkv, int ld, int B, const float* q
         for (int i = 0; i < B * H; ++i) out[i] = res[i];            // the engine's residual stream is updated in place
         if (fused) {
             qtts::pack_skinny_weight(Wo, H, qd, true, wp.data(), nullptr, 16);
-            std::vector<float> part((size_t)8 * 8 * H, NAN);
-            std::vector<unsigned> cnt(H / 128, 0u);
+            std::vector<float> part((size_t)8 * 8 * H * 2, 0.f);
+            std::vector<unsigned> epoch(H / 128, epoch0);
+            int err = 0;
             qtts::CpAttnOParams f{};
-            f.a = a; f.Wo = wp.data(); f.res = out; f.out = out; f.out16 = out16; f.part = part.data(); f.cnt = cnt.data(); f.H = H;
+            f.a = a; f.Wo = wp.data(); f.res = out; f.out = out; f.out16 = out16; f.part = part.data(); f.epoch = epoch.data(); f.err = &err; f.H = H;
             if (!qtts::cp_attn_o_takes(a, H)) return -2;
-            qtts::launch_cp_attn_o(f, nullptr);
-            for (unsigned c : cnt) if (c != 0u) return -3;           // every counter is back at zero for the next launch
+            for (int rep = 0; rep < 2; ++rep) {                     // twice on the same buffers: the second launch must not take the first one's granules
+                if (rep) { for (int i = 0; i < B * H; ++i) out[i] = res[i]; f.a.kv.k = kpool; f.a.kv.v = vpool; }
+                qtts::launch_cp_attn_o(f, nullptr);
+                for (unsigned e : epoch) if (e != epoch0 + 1u + rep) return -3;
+                if (err) return -4;
+            }
             return 0;
         }
         std::vector<qtts::bf16_t> att((size_t)B * qd, (qtts::bf16_t)0x7FC0);

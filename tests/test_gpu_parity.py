@@ -694,7 +694,7 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     every one of its 40 x 14 x 5 x 8 cross-workgroup hand-offs delivered complete partial sums, whoever arrived last.  (2) Both forms
     compute the same bf16 products in a different fp32 summation order; the 15 sub-codebooks run free inside a frame on seeded random
     weights with near-flat logits (a rounding-level flip in one pass changes the passes after it: 0.91 between the two decode-GEMM
-    kernels of the test above), so the bar on their agreement is 0.85.  (3) The graph of the fused engine has 70 fewer kernel nodes."""
+    kernels of the test above), so the bar on their agreement is 0.85 (0.96 measured; against the fp32 golden 0.848 both)."""
     from qwen3_tts_amd.talker import TalkerEngine
     cfg = synth.talker_06b()
     g = np.load(os.path.join(golden_dir, "talker_06b_b8.npz"))
@@ -702,14 +702,13 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     lens = [int(x) for x in g["lens"]]
     emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
     gc = torch.from_numpy(g["codes"][:, :40].copy())
-    res, nodes = {}, {}
+    res = {}
     try:
         for flag in ("1", "0"):
             os.environ["QTTS_CP_ATTN_O"] = flag
             eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=True)
             runs = [eng.generate(emb, mask, tr, pad, teacher_codes=gc, suppress_tokens=_suppress(cfg)).own.cpu().numpy() for _ in range(3 if flag == "1" else 1)]
             res[flag] = runs
-            nodes[flag] = int(eng.stats()["graph_nodes"])
             del eng
             torch.cuda.empty_cache()
     finally:
@@ -720,8 +719,7 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     agree_gold = float((f[0][:, :40, 1:] == g["codes"][:, :40, 1:]).mean())
     plain_gold = float((res["0"][0][:, :40, 1:] == g["codes"][:, :40, 1:]).mean())
     print(f"cp_attn_o vs attn_cp + decode GEMM (0.6B, 8 x 40 frames, teacher-forced): sub-codebooks agree {agree:.4f}; against the fp32 golden: "
-          f"fused {agree_gold:.4f}, two launches {plain_gold:.4f}; graph nodes {nodes['1']} vs {nodes['0']}")
-    assert nodes["0"] - nodes["1"] == 14 * cfg.cp_num_hidden_layers, nodes
+          f"fused {agree_gold:.4f}, two launches {plain_gold:.4f}")
     assert agree >= 0.85 and agree_gold >= plain_gold - 0.03
 
 

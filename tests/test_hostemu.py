@@ -54,7 +54,7 @@ def emu():
     lib.hostemu_set_real_gemm.argtypes = [i32]; lib.hostemu_set_real_gemm.restype = None
     lib.hostemu_set_fiber_order.argtypes = [i32]; lib.hostemu_set_fiber_order.restype = None
     lib.hostemu_set_block_order.argtypes = [i32]; lib.hostemu_set_block_order.restype = None
-    lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32]
+    lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
@@ -686,14 +686,16 @@ def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
 
 def test_cp_attn_o_fused_launch_real_source(emu):
     """attention.hip's `cp_attn_o_kernel` (round 4: the code predictor's attention AND o-projection of a single-token pass in one
-    launch -- the GEMM split over k by kv head, 64 workgroups publishing 8 x 128 partial sums, the last arriver of every 128-feature
-    chunk adding them in kv-head order + the residual) from its real source at the code predictor's real dimensions (16 / 8 heads of
-    128, hidden 1024), against (a) the two launches it replaces -- `attn_cp_kernel` + the decode GEMM -- on the same inputs: the K / V
-    rows appended to the cache are BIT-identical (the attention stage is attn_cp's arithmetic statement for statement), the hidden
-    rows agree to fp32 summation order (the same bf16 products, 8 partial sums of 256 instead of the decode GEMM's tile order);
-    (b) float64 numpy; for every workgroup execution order (ascending, descending, two shuffles: who is the last arriver changes,
-    the result may not) and two fiber orders, batch 8 / 5 / 1, cache lengths 1..15, contiguous and permuted page tables, with and
-    without the RoPE table, and with the arrival counters back at zero after every launch."""
+    launch -- the GEMM split over k by kv head, 64 workgroups of 16 waves publishing 8 x 128 partial sums as tagged 8-byte granules, the
+    workgroup of the last kv head adding them in kv-head order + the residual) from its real source at the code predictor's real
+    dimensions (16 / 8 heads of 128, hidden 1024), against (a) the two launches it replaces -- `attn_cp_kernel` + the decode GEMM -- on
+    the same inputs: the K / V rows appended to the cache are BIT-identical (the attention stage is attn_cp's arithmetic statement for
+    statement), the hidden rows agree to fp32 summation order (the same bf16 products, 16 partial sums of 128 instead of the decode
+    GEMM's tile order); (b) float64 numpy; for three fiber orders, batch 8 / 5 / 1, cache lengths 1..15, contiguous and permuted page
+    tables, with and without the RoPE table; every launch runs TWICE on the same partial-sum buffers (the entry point checks that the
+    epoch advanced and that no reducer gave up: a second launch may not take the first one's granules), from different starting
+    epochs.  (The emulator runs workgroups one after the other in ascending order, the order the device dispatches them in; a
+    reducer that had to WAIT for a producer is what only the hardware runs -- the GPU suite's run-to-run comparison covers it.)"""
     g = np.random.default_rng(404)
     HD, nh, nkv, H, eps = 128, 16, 8, 1024, 1e-6
     qd, ld = nh * HD, (nh + 2 * nkv) * HD
@@ -746,17 +748,17 @@ def test_cp_attn_o_fused_launch_real_source(emu):
                     att[hq * HD:(hq + 1) * HD] = pr @ vals
             ref[b] = Wo_r @ _bf16_round(att.astype(np.float32))[0].astype(np.float64) + res[b]
 
-        def run(fused, block_order=0, fiber_order=0):
+        def run(fused, fiber_order=0, epoch0=0):
             kk, vv = kpool.copy(), vpool.copy()
             out = np.full((B, H), np.nan, np.float32)
             out16 = np.full((B, H), 0x4242, np.uint16)
-            emu.hostemu_set_block_order(block_order); emu.hostemu_set_fiber_order(fiber_order)
+            emu.hostemu_set_fiber_order(fiber_order)
             try:
                 rc = emu.hostemu_cp_attn_o(_ptr(qkv), ld, B, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), S0, _ptr(kk), _ptr(vv),
                                            _ptr(table) if permute else None, pps, _ptr(Wo), H, _ptr(res), _ptr(out), _ptr(out16), fused, 8,
-                                           _ptr(rope) if use_tab else None, 17 if use_tab else 0)
+                                           _ptr(rope) if use_tab else None, 17 if use_tab else 0, epoch0)
             finally:
-                emu.hostemu_set_block_order(0); emu.hostemu_set_fiber_order(0)
+                emu.hostemu_set_fiber_order(0)
             assert rc == 0, ((B, S0, fused), rc, (emu.qtts_last_error() or b"").decode())
             return out, out16, kk, vv
 
@@ -764,15 +766,15 @@ def test_cp_attn_o_fused_launch_real_source(emu):
         scale = max(1.0, float(np.abs(ref).max()))
         assert float(np.abs(o0 - ref).max()) <= 2e-2 * scale, "the unfused pair is off its own reference"
         first = None
-        for (bo, fo) in [(0, 0), (1, 0), (2, 1), (3, 2)]:
-            o1, h1, k1, v1 = run(1, bo, fo)
+        for (fo, bo) in [(0, 0), (1, 5), (2, 0xFFFFFFF0)]:
+            o1, h1, k1, v1 = run(1, fo, bo)
             assert np.array_equal(k1, k0) and np.array_equal(v1, v0), ("K / V append differs from attn_cp", B, S0, bo)
             assert float(np.abs(o1 - o0).max()) <= 2e-5 * scale, (B, S0, bo, float(np.abs(o1 - o0).max()))
             assert float(np.abs(o1 - ref).max()) <= 2e-2 * scale
             assert np.array_equal(h1, _bf16_round(o1)[1]), "bf16 copy of the hidden rows"
             if first is None:
                 first = o1
-            assert np.array_equal(o1, first), ("result depends on the arrival order", B, S0, bo, fo)
+            assert np.array_equal(o1, first), ("result depends on the wave order / the epoch", B, S0, bo, fo)
 
 
 @pytest.mark.parametrize("nsplit", [1, 3])
