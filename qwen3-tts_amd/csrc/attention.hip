@@ -1401,19 +1401,21 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
 // The code predictor's passes >= 1: attention AND the o-projection in one launch (70 launch pairs per frame).  As two launches the pair
 // costs ~8.5 us on the in-kernel clock (attn_cp 2.4 + boundary 1.7 + the 4 MB o-projection 2.7 + boundary 1.7); the attention output is
 // the o-projection's k dimension, head by head, so the GEMM is split over k BY KV HEAD:
-//   workgroup (kv head g, 128-feature chunk c), 16 waves.  Wave (sequence r, query head hh of the kv head) runs that head's attention --
-//     the arithmetic of attn_cp, statement for statement (q / k RMSNorm + RoPE at the static position, K / V rounded through the cache
-//     type, 16 key slots, fp32 softmax, PV) -- out of a wave-private LDS slice; only chunk 0 appends K / V.  The eight chunk workgroups
-//     of a kv head repeat that attention (a few KB of reads each) instead of exchanging it.  Its 8 x 256 bf16 result is the B operand
-//     of the MFMAs against this workgroup's 128 x 256 block of Wo (wave = 16-feature strip x the 128 k of one query head, requested at
-//     kernel entry: it streams while the attention runs; the two k halves are added through LDS) -> an 8 x 128 fp32 partial sum;
+//   workgroup (row pair, kv head g, 128-feature chunk c), 4 waves = 256 workgroups at batch 8: one wave per SIMD of the chip.  Wave
+//     (sequence, query head hh of the kv head) runs that head's attention -- the arithmetic of attn_cp, statement for statement (q / k
+//     RMSNorm + RoPE at the static position, K / V rounded through the cache type, 16 key slots, fp32 softmax, PV) -- out of a
+//     wave-private LDS slice; only chunk 0 appends K / V.  The eight chunk workgroups of a (row pair, kv head) repeat that attention (a
+//     few KB of reads each) instead of exchanging it: the attention stage is ~400 VALU instructions per (sequence, head), so the
+//     repeats must not share a SIMD (second version, 16 waves per workgroup on 64 CUs: 2.3 us of VALU queueing behind the barrier).
+//     Its 2 x 256 bf16 result is the B operand (two columns of the MFMA tile) of 16 MFMAs per wave against this workgroup's 128 x 256
+//     block of Wo (wave = two 16-feature strips, requested at kernel entry: they stream while the attention runs);
 //   hand-off WITHOUT a ticket: every value leaves as an 8-byte granule {fp32 value, launch tag} in one write-through (sc1) store -- the
-//     tag is the chunk's epoch counter + 1, so a granule of an earlier launch can never be taken for this one's.  The workgroup of the
-//     LAST kv head is its chunk's reducer: it keeps its own partial sum in LDS, reads the other seven slabs with sc1 loads until every
-//     granule carries the tag (they were stored while it was still computing: normally the first read), adds the eight partial sums in
-//     kv-head order + the residual, writes the hidden state (fp32 + bf16 copy) and advances the epoch.  A fixed summation order, so the
-//     result does not depend on timing.  (First version, profiles/r04_cp_attn_o.md: partial sums + drained stores + an arrival ticket +
-//     last-arriver reduction = 3.2 us of hand-off inside a 6.7-us kernel: no gain over the two launches.  Guide: data-tagged granules.)
+//     tag is the (row pair, chunk)'s epoch counter + 1, so a granule of an earlier launch can never be taken for this one's.  The
+//     workgroup of the LAST kv head is the reducer of its (row pair, chunk): it keeps its own partial sum in LDS, reads the other seven
+//     slabs with sc1 loads until every granule carries the tag, adds the eight partial sums in kv-head order + the residual, writes
+//     the hidden state (fp32 + bf16 copy) and advances the epoch.  A fixed summation order, so the result does not depend on timing.
+//     (First version, profiles/r04_cp_attn_o.md: partial sums + drained stores + an arrival ticket + last-arriver reduction = 3.2 us
+//     of hand-off inside a 6.7-us kernel: no gain over the two launches.  Guide: data-tagged granules.)
 //   The reducer polls; it cannot hang the device: after SPIN_LIMIT re-reads it gives up, raises `err` and writes what it has.
 // bf16 cache, two query heads per kv head, head_dim 128, batch <= 8 only; everything else keeps attn_cp + the decode GEMM.
 namespace {
@@ -1437,32 +1439,37 @@ constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a
 }  // namespace
 
 template <bool CT>
-__global__ __launch_bounds__(1024) void cp_attn_o_kernel(CpAttnOParams P) {
+__global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
     constexpr int HD = 128, MAXK = 16, KW = 4, NKV = 8, BSTR = 264;       // BSTR: bf16 per row of the B tile (16-B rows, bank-spread)
     typedef bf16_t KVT;
     // ONE LDS object (a second one de-pipelines the loads around it):
-    //   [16 waves][q | kn | vn : 128 floats each] | B tile [16][BSTR] bf16 | k-half exchange [8 strips][64 lanes][4] floats | own partial sum [8][128] floats
-    constexpr int WS_BYTES = 16 * 1536, BT_BYTES = 16 * BSTR * 2, RED_BYTES = 8 * 64 * 16, OWN_BYTES = 8 * 128 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + RED_BYTES + OWN_BYTES];
+    //   [4 waves][q | kn | vn : 128 floats each] | B tile [2][BSTR] bf16 | the reducer's own partial sum [2][128] floats
+    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES];
     const AttnDecodeParams& p = P.a;
     const int nchunk = P.H >> 7;
-    const int g = blockIdx.x / nchunk, c = blockIdx.x - g * nchunk;
+    // blockIdx = (row pair, kv head, chunk), chunk fastest: with 8 chunks the 32 workgroups that read one chunk's columns of Wo share an XCD's L2
+    const int rq = blockIdx.x / (NKV * nchunk), gc = blockIdx.x - rq * (NKV * nchunk);
+    const int g = gc / nchunk, c = gc - g * nchunk;
+    if (rq * 2 >= p.B) return;                         // (no sequence in this row pair: nobody waits for this workgroup either)
     QTTS_TS_BEGIN();                       // (tstamp build: 1 = every request has arrived, 2 = attention done, 3 = partial sums stored, 4 = the other slabs read, 5 = reduced)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = wave & 7, hh = wave >> 3;          // attention: sequence r, query head 2 g + hh; GEMM: strip r of the chunk, k half hh
+    const int rr = wave & 1, hh = wave >> 1;         // attention: sequence 2 rq + rr, query head 2 g + hh; GEMM: strips 2 wave, 2 wave + 1 of the chunk
     const int kk = lane >> 2, qq = lane & 3;
     const int S0 = p.len_static, S1 = S0 + 1;
-    const bool have = r < p.B;
-    const int b = have ? r : 0;
+    const int row_w = rq * 2 + rr;
+    const bool have = row_w < p.B;
+    const int b = have ? row_w : 0;
     const KVT* kc = reinterpret_cast<const KVT*>(p.kv.k);
     const KVT* vc = reinterpret_cast<const KVT*>(p.kv.v);
     auto key_base = [&](int s) -> size_t {
         const int page = CT ? b * p.kv.pages_per_seq + (s >> 4) : p.kv.page_table[b * p.kv.pages_per_seq + (s >> 4)];
         return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + g) * 16 + (s & 15)) * HD;
     };
-    // ---- 0. every request of the attention stage, then this wave's block of Wo (16 features x the 128 k of query head hh: 4 KB, linear)
-    const unsigned tag = P.epoch[c] + 1u;
+    // ---- 0. every request of the attention stage, then this wave's block of Wo (two 16-feature strips x the 256 k of kv head g: 16 KB)
+    unsigned* epoch = P.epoch + rq * nchunk + c;
+    const unsigned tag = *epoch + 1u;
     const float* xrow = p.qkv + (size_t)b * p.ld;
     float xq[2], xk[2], xv[2];
     xq[0] = xrow[(g * 2 + hh) * HD + lane]; xq[1] = xrow[(g * 2 + hh) * HD + lane + 64];
@@ -1482,12 +1489,15 @@ __global__ __launch_bounds__(1024) void cp_attn_o_kernel(CpAttnOParams P) {
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) vr[k] = *reinterpret_cast<const VPair*>(vc + key_base(k < S0 ? k : 0) + 2 * lane);
     }
-    cu32x4 wf[4];
+    cu32x4 wf[2][8];
     {
         const int nkt = (p.nh * HD) >> 5;
-        const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wo) + ((size_t)(c * 8 + r) * nkt + g * 8 + hh * 4) * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wf[ks] = wsrc[ks * 64];
+        for (int s = 0; s < 2; ++s) {
+            const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wo) + ((size_t)(c * 8 + wave * 2 + s) * nkt + g * 8) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) wf[s][ks] = wsrc[ks * 64];
+        }
     }
     const int done = p.done_flag ? *p.done_flag : 0;
     if (done) return;
@@ -1495,8 +1505,7 @@ __global__ __launch_bounds__(1024) void cp_attn_o_kernel(CpAttnOParams P) {
 
     float* ws = reinterpret_cast<float*>(smem + wave * 1536);          // q | kn | vn
     bf16_t* Bt = reinterpret_cast<bf16_t*>(smem + WS_BYTES);
-    f32x4* red = reinterpret_cast<f32x4*>(smem + WS_BYTES + BT_BYTES);
-    float* own = reinterpret_cast<float*>(smem + WS_BYTES + BT_BYTES + RED_BYTES);
+    float* own = reinterpret_cast<float*>(smem + WS_BYTES + BT_BYTES);
     if (have) {
         // ---- 1. q / k RMSNorm + RoPE at position S0, K / V through the cache type (attn_cp's stage 1)
         float c_ = ctab, sn = stab;
@@ -1515,7 +1524,7 @@ __global__ __launch_bounds__(1024) void cp_attn_o_kernel(CpAttnOParams P) {
         {
             const size_t o = key_base(S0);
             const KVT k0 = kv_cast<KVT>(xk[0]), k1 = kv_cast<KVT>(xk[1]), v0 = kv_cast<KVT>(xv[0]), v1 = kv_cast<KVT>(xv[1]);
-            if (c == 0) {                                  // one workgroup per kv head appends: head 0's wave the K row, head 1's the V row
+            if (c == 0) {                                  // one workgroup per (row pair, kv head) appends: head 0's wave the K row, head 1's the V row
                 if (hh == 0) { KVT* kd = reinterpret_cast<KVT*>(p.kv.k); kd[o + lane] = k0; kd[o + lane + 64] = k1; }
                 else { KVT* vd = reinterpret_cast<KVT*>(p.kv.v); vd[o + lane] = v0; vd[o + lane + 64] = v1; }
             }
@@ -1565,34 +1574,43 @@ __global__ __launch_bounds__(1024) void cp_attn_o_kernel(CpAttnOParams P) {
         }
         const float inv = 1.f / l;
         const unsigned pk = (unsigned)f32_to_bf16(acc0 * inv) | ((unsigned)f32_to_bf16(acc1 * inv) << 16);
-        *reinterpret_cast<unsigned*>(Bt + r * BSTR + hh * HD + 2 * lane) = pk;
+        *reinterpret_cast<unsigned*>(Bt + rr * BSTR + hh * HD + 2 * lane) = pk;
     }
     QTTS_TS(2);
     __syncthreads();
-    // ---- 3. partial o-projection: D[feature 4 q + j][sequence i] of strip r over the 128 k of query head hh; the two k halves meet in LDS
+    // ---- 3. partial o-projection: D[feature 4 q + j][sequence li] of two strips over the 256 k of this kv head (columns 0 / 1 of the MFMA tile)
     const int li = lane & 15, lq = lane >> 4;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int row = rq * 2 + li;                        // (meaningful for li < 2)
+    const bool col_ok = li < 2 && row < p.B;
+    f32x4 acc[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        cu32x4 bv = *reinterpret_cast<const cu32x4*>(Bt + (li & 7) * BSTR + hh * HD + ks * 32 + lq * 8);
-        if (li >= p.B) bv = (cu32x4){0u, 0u, 0u, 0u};
-        bf16x8 wa, xb;
-        *reinterpret_cast<cu32x4*>(&wa) = wf[ks];
+    for (int s = 0; s < 2; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        cu32x4 bv = *reinterpret_cast<const cu32x4*>(Bt + (li & 1) * BSTR + ks * 32 + lq * 8);
+        if (!col_ok) bv = (cu32x4){0u, 0u, 0u, 0u};
+        bf16x8 xb;
         *reinterpret_cast<cu32x4*>(&xb) = bv;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 wa;
+            *reinterpret_cast<cu32x4*>(&wa) = wf[s][ks];
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[s], 0, 0, 0);
+        }
     }
-    if (hh == 1) red[r * 64 + lane] = acc;
-    __syncthreads();
     const bool reducer = g == NKV - 1;
     const WtBuf slab = wt_buf(P.part, (size_t)NKV * 8 * P.H * 8);
-    if (hh == 0) {
-        acc = acc + red[r * 64 + lane];                  // (head 0's k half) + (head 1's k half)
-        if (reducer) {
-            if (li < 8) *reinterpret_cast<f32x4*>(own + li * 128 + r * 16 + lq * 4) = acc;      // (columns 8..15 of the MFMA tile are no sequences)
-        } else if (li < p.B) {
-            const int off = (int)((((size_t)g * 8 + li) * P.H + c * 128 + r * 16 + lq * 4) * 8);
-            wt_store16(slab, off, (cu32x4){__float_as_uint(acc[0]), tag, __float_as_uint(acc[1]), tag});
-            wt_store16(slab, off + 16, (cu32x4){__float_as_uint(acc[2]), tag, __float_as_uint(acc[3]), tag});
+    if (reducer) {
+        if (li < 2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(own + li * 128 + (wave * 2 + s) * 16 + lq * 4) = acc[s];
+        }
+    } else if (col_ok) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = (int)((((size_t)g * 8 + row) * P.H + c * 128 + (wave * 2 + s) * 16 + lq * 4) * 8);
+            wt_store16(slab, off, (cu32x4){__float_as_uint(acc[s][0]), tag, __float_as_uint(acc[s][1]), tag});
+            wt_store16(slab, off + 16, (cu32x4){__float_as_uint(acc[s][2]), tag, __float_as_uint(acc[s][3]), tag});
         }
     }
     QTTS_TS(3);
@@ -1611,44 +1629,36 @@ __global__ __launch_bounds__(1024) void cp_attn_o_kernel(CpAttnOParams P) {
 #define QTTS_TS_CPAO(tail_)
 #endif
     if (!reducer) { QTTS_TS_CPAO(0) return; }
-    // ---- 4. the reducer of chunk c: hidden = (sum over kv heads, in order) + residual
+    // ---- 4. the reducer of (row pair, chunk c): hidden = (sum over kv heads, in order) + residual
     __syncthreads();                                     // (its own partial sum is in LDS)
-    if (tid < 256) {
-        const int row = tid >> 5, col = c * 128 + (tid & 31) * 4;
-        if (row < p.B) {
-            cu32x4 pa[NKV - 1][2];
+    if (tid < 128) {
+        const int rw = rq * 2 + (tid >> 6), c2 = (tid & 63) * 2, col = c * 128 + c2;
+        if (rw < p.B) {
+            cu32x4 pa[NKV - 1];
 #pragma unroll
-            for (int g2 = 0; g2 < NKV - 1; ++g2) {
-                const int off = (int)((((size_t)g2 * 8 + row) * P.H + col) * 8);
-                pa[g2][0] = wt_load16(slab, off); pa[g2][1] = wt_load16(slab, off + 16);
-            }
-            const f32x4 res = *reinterpret_cast<const f32x4*>(P.res + (size_t)row * P.H + col);
+            for (int g2 = 0; g2 < NKV - 1; ++g2) pa[g2] = wt_load16(slab, (int)((((size_t)g2 * 8 + rw) * P.H + col) * 8));
+            const float2 res = *reinterpret_cast<const float2*>(P.res + (size_t)rw * P.H + col);
             int spins = 0;
 #pragma unroll
             for (int g2 = 0; g2 < NKV - 1; ++g2) {
-                while (pa[g2][0][1] != tag || pa[g2][0][3] != tag || pa[g2][1][1] != tag || pa[g2][1][3] != tag) {
+                while (pa[g2][1] != tag || pa[g2][3] != tag) {
                     if (++spins > CPAO_SPIN_LIMIT) { if (P.err) *P.err = 1; break; }
                     wt_pause();
-                    const int off = (int)((((size_t)g2 * 8 + row) * P.H + col) * 8);
-                    pa[g2][0] = wt_load16(slab, off); pa[g2][1] = wt_load16(slab, off + 16);
+                    pa[g2] = wt_load16(slab, (int)((((size_t)g2 * 8 + rw) * P.H + col) * 8));
                 }
             }
-            f32x4 s = (f32x4){__uint_as_float(pa[0][0][0]), __uint_as_float(pa[0][0][2]), __uint_as_float(pa[0][1][0]), __uint_as_float(pa[0][1][2])};
+            float s0 = __uint_as_float(pa[0][0]), s1 = __uint_as_float(pa[0][2]);
 #pragma unroll
-            for (int g2 = 1; g2 < NKV - 1; ++g2)
-                s = s + (f32x4){__uint_as_float(pa[g2][0][0]), __uint_as_float(pa[g2][0][2]), __uint_as_float(pa[g2][1][0]), __uint_as_float(pa[g2][1][2])};
-            s = s + *reinterpret_cast<const f32x4*>(own + row * 128 + (tid & 31) * 4);
-            s = s + res;
-            *reinterpret_cast<f32x4*>(P.out + (size_t)row * P.H + col) = s;
-            if (P.out16) {
-                uint2 h16;
-                h16.x = pack_bf16(s[0], s[1]); h16.y = pack_bf16(s[2], s[3]);
-                *reinterpret_cast<uint2*>(P.out16 + (size_t)row * P.H + col) = h16;
-            }
+            for (int g2 = 1; g2 < NKV - 1; ++g2) { s0 += __uint_as_float(pa[g2][0]); s1 += __uint_as_float(pa[g2][2]); }
+            s0 += own[(tid >> 6) * 128 + c2]; s1 += own[(tid >> 6) * 128 + c2 + 1];
+            s0 += res.x; s1 += res.y;
+            float2 o2; o2.x = s0; o2.y = s1;
+            *reinterpret_cast<float2*>(P.out + (size_t)rw * P.H + col) = o2;
+            if (P.out16) *reinterpret_cast<unsigned*>(P.out16 + (size_t)rw * P.H + col) = pack_bf16(s0, s1);
         }
     }
     QTTS_TS(4);
-    if (tid == 0) P.epoch[c] = tag;                      // (read by the next launch, behind a kernel boundary)
+    if (tid == 0) *epoch = tag;                          // (read by the next launch, behind a kernel boundary)
     QTTS_TS_DRAINED(5);
     QTTS_TS_CPAO(1)
 }
@@ -1661,9 +1671,9 @@ bool cp_attn_o_takes(const AttnDecodeParams& a, int H) {
 void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
     QTTS_REQUIRE(cp_attn_o_takes(P.a, P.H), QTTS_ERR_ARG, "cp_attn_o: shape (bf16 cache, 16 / 8 heads of 128, one new token, <= 16 keys, batch <= 8)");
     QTTS_REQUIRE(P.Wo && P.res && P.out && P.part && P.epoch && P.a.qkv && P.a.qw && P.a.kw && P.a.inv_freq, QTTS_ERR_ARG, "cp_attn_o: null operand");
-    const dim3 grid(8 * (P.H / 128));
-    if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true>), grid, dim3(1024), 0, st, P);
-    else hipLaunchKernelGGL((cp_attn_o_kernel<false>), grid, dim3(1024), 0, st, P);
+    const dim3 grid(4 * 8 * (P.H / 128));                // (row pair, kv head, chunk)
+    if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((cp_attn_o_kernel<false>), grid, dim3(256), 0, st, P);
     QTTS_CHECK_HIP(hipGetLastError());
 }
 

@@ -234,7 +234,7 @@ struct CpAttnOParams {
     float* out;                   // hidden rows [B][H] fp32
     unsigned short* out16;        // optional bf16 copy [B][H]
     float* part;                  // scratch [nkv][8][H] granules of 8 B {fp32 partial sum, launch tag}: zero at engine creation
-    unsigned* epoch;              // [H / 128] launch counters (the tag of a launch = epoch + 1): zero at engine creation
+    unsigned* epoch;              // [4 row pairs][H / 128] launch counters (the tag of a launch = epoch + 1): zero at engine creation
     int* err;                     // optional device flag, set if a reducer gave up waiting (never in a correct run)
     int H;
 };

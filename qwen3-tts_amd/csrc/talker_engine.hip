@@ -211,7 +211,7 @@ struct qtts_talker {
     // QTTS_CP_ATTN_O=0: attn_cp + the decode GEMM as two launches (A/B; read at engine creation and, for the launch choice, per QTTS_ENV)
     bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
     static bool cp_attn_o_off() { const char* e = QTTS_ENV("QTTS_CP_ATTN_O"); return e && e[0] == '0'; }
-    DevBuf ao_part, ao_cnt;            // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}; [H / 128] launch counters (epochs)
+    DevBuf ao_part, ao_cnt;            // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}; [4 row pairs][H / 128] launch counters (epochs)
     int64_t cp_attn_o_count = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
@@ -561,7 +561,7 @@ void qtts_talker::finalize() {
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
     }
     if (bf16 && !cl.empty() && cl[0].o_p16.p) {
-        ao_part.alloc((size_t)8 * 8 * cd.H * 8); ao_cnt.alloc((size_t)(cd.H / 128) * 4);
+        ao_part.alloc((size_t)8 * 8 * cd.H * 8); ao_cnt.alloc((size_t)4 * (cd.H / 128) * 4);
         QTTS_CHECK_HIP(hipMemset(ao_part.p, 0, ao_part.bytes));
         QTTS_CHECK_HIP(hipMemset(ao_cnt.p, 0, ao_cnt.bytes));
     }
