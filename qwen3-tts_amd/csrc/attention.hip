@@ -1426,6 +1426,7 @@ __device__ inline WtBuf wt_buf(void* p, size_t) { return WtBuf{static_cast<unsig
 __device__ inline void wt_store16(const WtBuf& b, int off, cu32x4 v) { *reinterpret_cast<cu32x4*>(b.base + off) = v; }
 __device__ inline cu32x4 wt_load16(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
 __device__ inline void wt_pause() {}
+__device__ inline void wt_first_pause() {}
 constexpr int CPAO_SPIN_LIMIT = 2;                      // (workgroups run one after the other here: a second read never helps)
 #else
 struct WtBuf { __amdgpu_buffer_rsrc_t r; };
@@ -1434,6 +1435,7 @@ __device__ __forceinline__ WtBuf wt_buf(void* p, size_t bytes) { return WtBuf{__
 __device__ __forceinline__ void wt_store16(const WtBuf& b, int off, cu32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
 __device__ __forceinline__ cu32x4 wt_load16(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
 __device__ __forceinline__ void wt_pause() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ void wt_first_pause() { __builtin_amdgcn_s_sleep(20); }        // 20 x 64 clocks ~ 0.5 us
 constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a producer that never stores is a bug, not a wait
 #endif
 }  // namespace
@@ -1634,10 +1636,13 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
     if (tid < 128) {
         const int rw = rq * 2 + (tid >> 6), c2 = (tid & 63) * 2, col = c * 128 + c2;
         if (rw < p.B) {
+            const float2 res = *reinterpret_cast<const float2*>(P.res + (size_t)rw * P.H + col);
+            // the other workgroups stored when this one did, and a write-through store takes ~1 us to become readable: a read issued now
+            // would come back stale and cost a second round trip (third version's timeline: reduced 2.7 us after its own partial sum)
+            wt_first_pause();
             cu32x4 pa[NKV - 1];
 #pragma unroll
             for (int g2 = 0; g2 < NKV - 1; ++g2) pa[g2] = wt_load16(slab, (int)((((size_t)g2 * 8 + rw) * P.H + col) * 8));
-            const float2 res = *reinterpret_cast<const float2*>(P.res + (size_t)rw * P.H + col);
             int spins = 0;
 #pragma unroll
             for (int g2 = 0; g2 < NKV - 1; ++g2) {

@@ -208,9 +208,11 @@ struct qtts_talker {
     // instead of N / 32 strip pairs -- 768 instead of 384 for the talker: three per CU instead of 1.5, 9.5 vs 10.7 us streamed.
     // Bit-identical results (the same per-element accumulation), a second packed copy of the operator.  QTTS_SWIGLU8=0: strip pairs.
     bool swiglu8_env = [] { const char* e = getenv("QTTS_SWIGLU8"); return !e || atoi(e) != 0; }();
-    // QTTS_CP_ATTN_O=0: attn_cp + the decode GEMM as two launches (A/B; read at engine creation and, for the launch choice, per QTTS_ENV)
-    bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
-    static bool cp_attn_o_off() { const char* e = QTTS_ENV("QTTS_CP_ATTN_O"); return e && e[0] == '0'; }
+    // QTTS_CP_ATTN_O=1 (A/B only, read at engine creation): the code predictor's attention + o-projection of passes >= 1 as ONE launch
+    // (attention.hip: cp_attn_o_kernel).  Three versions were measured on the MI355X (profiles/r04_cp_attn_o.md): 2.74-2.87 ms per frame
+    // against 2.67 ms with the two launches -- the in-launch hand-off of the partial sums costs what the boundary it replaces costs -- so
+    // the default stays attn_cp + the decode GEMM.
+    bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return e && atoi(e) != 0; }();
     DevBuf ao_part, ao_cnt;            // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}; [4 row pairs][H / 128] launch counters (epochs)
     int64_t cp_attn_o_count = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
@@ -229,8 +231,8 @@ struct qtts_talker {
             upload_packed(L.gu_p8, interleave_gu8(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H),
                           2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);
-        // code predictor, bf16: passes >= 1 run attention + o-projection as ONE launch (attention.hip: cp_attn_o_kernel), whose waves
-        // own 16-feature strips of the operator (a second packed copy when the decode GEMM's strips are narrower: 4 MB per layer)
+        // QTTS_CP_ATTN_O=1, code predictor, bf16: passes >= 1 run attention + o-projection as ONE launch (attention.hip: cp_attn_o_kernel),
+        // whose waves own 16-feature strips of the operator (a second packed copy: 4 MB per layer)
         if (bf16 && !rows && cp_attn_o_env && d.nh == 16 && d.nkv == 8 && d.hd == 128 && d.H % 128 == 0)
             upload_packed(L.o_p16, ow, d.H, d.qd, nullptr, 16);
         if (rows) {
@@ -317,9 +319,9 @@ struct qtts_talker {
         // staged into the consuming GEMM by LDS-DMA
         const bool att16 = bf16 && skinny_takes_bf16_x(M, d.qd, true), act16 = bf16 && skinny_takes_bf16_x(M, d.I, true);
         a.out_bf16 = att16;
-        // bf16 engines, code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k by kv head,
-        // partial sums combined by the last arriver of each 128-feature chunk in kv-head order; profiles/r04_cp_attn_o.md)
-        if (L.o_p16.p && ao_part.p && att16 && !skinny_only && !cp_attn_o_off() && cp_attn_o_takes(a, d.H)) {
+        // QTTS_CP_ATTN_O=1 engines (bf16), code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k
+        // by kv head, partial sums handed over as tagged granules and added in kv-head order; profiles/r04_cp_attn_o.md)
+        if (L.o_p16.p && ao_part.p && att16 && !skinny_only && cp_attn_o_takes(a, d.H)) {
             CpAttnOParams f{};
             f.a = a; f.Wo = L.o_p16.p; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
             f.part = ao_part.as<float>(); f.epoch = ao_cnt.as<unsigned>(); f.err = ss.n_generated + 5; f.H = d.H;

@@ -116,6 +116,11 @@ print(f"{'kernel':34s} {'n':>5s}  " + "  ".join(f"{'phase'+str(j+1):>11s}" for j
 for x in rows:
     print(f"{x['kernel']:34s} {x['records']:5d}  " + "  ".join(f"{n[:6]:>6s}{v:5.2f}" for n, v in x["phases_us"].items())
           + f"  {x['in_kernel_us']:9.2f} {x['boundary_us_median'] if x['boundary_us_median'] is not None else float('nan'):8.2f}")
+l_kind = np.array([r["kind"][launch_id == k][0] for k in range(n_l)])
+if (l_kind == 4).any():       # the fused launch ends with its slowest reducer: the launch's length, not the mean of its workgroups, is what the next node waits for
+    ln = (l_end - l_entry)[l_kind == 4] * TICK_US
+    print(f"cp_attn_o launch length (first logged entry -> last stamp of any logged workgroup): mean {ln.mean():.2f} us, median {np.median(ln):.2f}, "
+          f"p90 {np.percentile(ln, 90):.2f}, max {ln.max():.2f}, n={len(ln)}")
 fin = l_pitch[np.isfinite(l_pitch) & (l_pitch < 30)]
 print(f"launch pitch (entry to entry, instrumented launches that follow one another): median {np.median(fin):.2f} us, mean {fin.mean():.2f} us, n={len(fin)}")
 if a.json:
