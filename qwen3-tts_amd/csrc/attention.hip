@@ -1410,10 +1410,10 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
 //     Its 2 x 256 bf16 result is the B operand (two columns of the MFMA tile) of 16 MFMAs per wave against this workgroup's 128 x 256
 //     block of Wo (wave = two 16-feature strips, requested at kernel entry: they stream while the attention runs);
 //   hand-off WITHOUT a ticket: every value leaves as an 8-byte granule {fp32 value, launch tag} in one write-through (sc1) store -- the
-//     tag is the (row pair, chunk)'s epoch counter + 1, so a granule of an earlier launch can never be taken for this one's.  The
+//     tag is (frame serial << 7 | launch slot), different from that of every launch that wrote the buffer shortly before.  The
 //     workgroup of the LAST kv head is the reducer of its (row pair, chunk): it keeps its own partial sum in LDS, reads the other seven
 //     slabs with sc1 loads until every granule carries the tag, adds the eight partial sums in kv-head order + the residual, writes
-//     the hidden state (fp32 + bf16 copy) and advances the epoch.  A fixed summation order, so the result does not depend on timing.
+//     the hidden state (fp32 + bf16 copy).  A fixed summation order, so the result does not depend on timing.
 //     (First version, profiles/r04_cp_attn_o.md: partial sums + drained stores + an arrival ticket + last-arriver reduction = 3.2 us
 //     of hand-off inside a 6.7-us kernel: no gain over the two launches.  Guide: data-tagged granules.)
 //   The reducer polls; it cannot hang the device: after SPIN_LIMIT re-reads it gives up, raises `err` and writes what it has.
@@ -1425,8 +1425,9 @@ struct WtBuf { unsigned char* base; };
 __device__ inline WtBuf wt_buf(void* p, size_t) { return WtBuf{static_cast<unsigned char*>(p)}; }
 __device__ inline void wt_store16(const WtBuf& b, int off, cu32x4 v) { *reinterpret_cast<cu32x4*>(b.base + off) = v; }
 __device__ inline cu32x4 wt_load16(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
+__device__ inline uint2 wt_load8(const WtBuf& b, int off) { return *reinterpret_cast<const uint2*>(b.base + off); }
 __device__ inline void wt_pause() {}
-__device__ inline void wt_first_pause() {}
+__device__ inline void wt_first_pause(int) {}
 constexpr int CPAO_SPIN_LIMIT = 2;                      // (workgroups run one after the other here: a second read never helps)
 #else
 struct WtBuf { __amdgpu_buffer_rsrc_t r; };
@@ -1434,26 +1435,33 @@ __device__ __forceinline__ WtBuf wt_buf(void* p, size_t bytes) { return WtBuf{__
 // aux = 16: sc1 -- the store writes through to memory, the load is not served from this CU's L1
 __device__ __forceinline__ void wt_store16(const WtBuf& b, int off, cu32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
 __device__ __forceinline__ cu32x4 wt_load16(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
+__device__ __forceinline__ uint2 wt_load8(const WtBuf& b, int off) {
+    typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
+    const cu32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, off, 0, 16);
+    uint2 r; r.x = v[0]; r.y = v[1];
+    return r;
+}
 __device__ __forceinline__ void wt_pause() { __builtin_amdgcn_s_sleep(2); }
-__device__ __forceinline__ void wt_first_pause() { __builtin_amdgcn_s_sleep(20); }        // 20 x 64 clocks ~ 0.5 us
+__device__ __forceinline__ void wt_first_pause(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // n x 64 clocks (20 ~ 0.5 us)
 constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a producer that never stores is a bug, not a wait
 #endif
 }  // namespace
 
-template <bool CT>
+template <bool CT, bool QKV>
 __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
     constexpr int HD = 128, MAXK = 16, KW = 4, NKV = 8, BSTR = 264;       // BSTR: bf16 per row of the B tile (16-B rows, bank-spread)
     typedef bf16_t KVT;
     // ONE LDS object (a second one de-pipelines the loads around it):
     //   [4 waves][q | kn | vn : 128 floats each] | B tile [2][BSTR] bf16 | the reducer's own partial sum [2][128] floats
-    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES];
+    //   | QKV: the four k quarters of the q|k|v strip [4 waves][64 lanes][4] floats and of the row sums of squares [4][16]
+    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4, QP_BYTES = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES];
     const AttnDecodeParams& p = P.a;
     const int nchunk = P.H >> 7;
     // blockIdx = (row pair, kv head, chunk), chunk fastest: with 8 chunks the 32 workgroups that read one chunk's columns of Wo share an XCD's L2
     const int rq = blockIdx.x / (NKV * nchunk), gc = blockIdx.x - rq * (NKV * nchunk);
     const int g = gc / nchunk, c = gc - g * nchunk;
-    if (rq * 2 >= p.B) return;                         // (no sequence in this row pair: nobody waits for this workgroup either)
+    if (!QKV && rq * 2 >= p.B) return;                 // (no sequence in this row pair: nobody waits for this workgroup either)
     QTTS_TS_BEGIN();                       // (tstamp build: 1 = every request has arrived, 2 = attention done, 3 = partial sums stored, 4 = the other slabs read, 5 = reduced)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1470,13 +1478,27 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
         return ((((size_t)p.layer * p.kv.n_pages + page) * p.kv.nkv + g) * 16 + (s & 15)) * HD;
     };
     // ---- 0. every request of the attention stage, then this wave's block of Wo (two 16-feature strips x the 256 k of kv head g: 16 KB)
-    unsigned* epoch = P.epoch + rq * nchunk + c;
-    const unsigned tag = *epoch + 1u;
+    // the launch tag: nobody in this launch writes the word it derives from, and the launches that wrote the granule buffers before this
+    // one had another (serial, slot) pair -- a granule that carries the tag is this launch's
+    const unsigned tag = ((unsigned)*P.serial << 7) | (unsigned)P.slot;
+    const int li = lane & 15, lq = lane >> 4;
+    // ---- 0a (QKV). this workgroup's strip of the layer's q|k|v GEMM: 16 features x K, the four waves take a quarter of k each.  Requested
+    // first: every other workgroup's attention waits for these sums.
+    cu32x4 gw[8], gx[8];
+    if (QKV && P.phase != 1) {
+        const int nkt = P.K >> 5, kq = nkt >> 2;           // k-tiles of 32; per wave kq of them (8 at K = 1024)
+        const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wqkv) + ((size_t)blockIdx.x * nkt + wave * kq) * 64 + lane;
+        const cu32x4* xsrc = reinterpret_cast<const cu32x4*>(P.x16 + (size_t)(li < p.B ? li : 0) * P.ldx16 + wave * kq * 32 + lq * 8);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { gw[ks] = wsrc[ks * 64]; gx[ks] = xsrc[ks * 4]; }
+    }
     const float* xrow = p.qkv + (size_t)b * p.ld;
     float xq[2], xk[2], xv[2];
-    xq[0] = xrow[(g * 2 + hh) * HD + lane]; xq[1] = xrow[(g * 2 + hh) * HD + lane + 64];
-    xk[0] = xrow[(p.nh + g) * HD + lane]; xk[1] = xrow[(p.nh + g) * HD + lane + 64];
-    xv[0] = xrow[(p.nh + p.nkv + g) * HD + lane]; xv[1] = xrow[(p.nh + p.nkv + g) * HD + lane + 64];
+    if constexpr (!QKV) {
+        xq[0] = xrow[(g * 2 + hh) * HD + lane]; xq[1] = xrow[(g * 2 + hh) * HD + lane + 64];
+        xk[0] = xrow[(p.nh + g) * HD + lane]; xk[1] = xrow[(p.nh + g) * HD + lane + 64];
+        xv[0] = xrow[(p.nh + p.nkv + g) * HD + lane]; xv[1] = xrow[(p.nh + p.nkv + g) * HD + lane + 64];
+    }
     const float qw0 = p.qw[lane], qw1 = p.qw[lane + 64], kw0 = p.kw[lane], kw1 = p.kw[lane + 64], invf = p.inv_freq[lane];
     const bool rtab = p.rope_cs && S0 < p.rope_cs_n;
     const float* rrow = rtab ? p.rope_cs + (size_t)S0 * 128 : p.inv_freq;
@@ -1503,7 +1525,72 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
     }
     const int done = p.done_flag ? *p.done_flag : 0;
     if (done) return;
-    QTTS_TS_DRAINED(1);
+    if (QKV && P.phase != 1) {
+        // ---- 0b. 8 MFMAs per wave (D[feature 4 q + j][sequence i]), the row sums of squares from the same x fragments (the RMSNorm weight is
+        // folded into Wqkv, so out = rsqrt(mean x^2 + eps) * W' x as in the decode GEMM), the four k quarters added in wave order
+        f32x4 qa = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float ssq = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            cu32x4 xv4 = gx[ks];
+            if (li >= p.B) xv4 = (cu32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(xv4[e] << 16), hi = __uint_as_float(xv4[e] & 0xffff0000u);
+                ssq += lo * lo; ssq += hi * hi;
+            }
+            bf16x8 wa, xb;
+            *reinterpret_cast<cu32x4*>(&wa) = gw[ks];
+            *reinterpret_cast<cu32x4*>(&xb) = xv4;
+            qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, qa, 0, 0, 0);
+        }
+        ssq += __shfl_xor(ssq, 16);
+        ssq += __shfl_xor(ssq, 32);                      // every lane: its row's sum over this wave's k quarter
+        f32x4* qpart = reinterpret_cast<f32x4*>(smem + WS_BYTES + BT_BYTES + OWN_BYTES);
+        float* qss = reinterpret_cast<float*>(smem + WS_BYTES + BT_BYTES + OWN_BYTES + 4 * 64 * 16);
+        qpart[wave * 64 + lane] = qa;
+        if (lq == 0) qss[wave * 16 + li] = ssq;
+        __syncthreads();
+        if (wave == 0 && li < p.B) {
+            const f32x4 s4 = ((qpart[lane] + qpart[64 + lane]) + qpart[128 + lane]) + qpart[192 + lane];
+            const float ss = ((qss[li] + qss[16 + li]) + qss[32 + li]) + qss[48 + li];
+            const float rs = rsqrtf(ss / (float)P.K + P.eps_in);
+            const WtBuf qg = wt_buf(P.qkv_gran, (size_t)8 * p.ld * 8);
+            const int off = (int)(((size_t)li * p.ld + blockIdx.x * 16 + lq * 4) * 8);
+            wt_store16(qg, off, (cu32x4){__float_as_uint(s4[0] * rs), tag, __float_as_uint(s4[1] * rs), tag});
+            wt_store16(qg, off + 16, (cu32x4){__float_as_uint(s4[2] * rs), tag, __float_as_uint(s4[3] * rs), tag});
+        }
+        if (P.phase == 0) return;
+    }
+    if constexpr (QKV) {
+        if (rq * 2 >= p.B) return;                     // (no sequence in this row pair: nothing to attend to, nobody waits for more)
+        QTTS_TS(1);
+        // ---- 0c. this wave's rows of q | k | v, from the strips of 6 other workgroups: wait ~0.5 us before the first read (as the reducer
+        // below: a read issued right away comes back stale), then until every granule carries this launch's tag
+        const WtBuf qg = wt_buf(P.qkv_gran, (size_t)8 * p.ld * 8);
+        int cols[3] = {(g * 2 + hh) * HD, (p.nh + g) * HD, (p.nh + p.nkv + g) * HD};
+        uint2 gq[3][2];
+        wt_first_pause(P.first_pause);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) gq[v][h2] = wt_load8(qg, (int)(((size_t)b * p.ld + cols[v] + lane + 64 * h2) * 8));
+        int spins = 0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                while (gq[v][h2].y != tag) {
+                    if (++spins > CPAO_SPIN_LIMIT) { if (P.err) *P.err = 1; break; }
+                    wt_pause();
+                    gq[v][h2] = wt_load8(qg, (int)(((size_t)b * p.ld + cols[v] + lane + 64 * h2) * 8));
+                }
+        xq[0] = __uint_as_float(gq[0][0].x); xq[1] = __uint_as_float(gq[0][1].x);
+        xk[0] = __uint_as_float(gq[1][0].x); xk[1] = __uint_as_float(gq[1][1].x);
+        xv[0] = __uint_as_float(gq[2][0].x); xv[1] = __uint_as_float(gq[2][1].x);
+    } else {
+        QTTS_TS_DRAINED(1);
+    }
 
     float* ws = reinterpret_cast<float*>(smem + wave * 1536);          // q | kn | vn
     bf16_t* Bt = reinterpret_cast<bf16_t*>(smem + WS_BYTES);
@@ -1581,7 +1668,6 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
     QTTS_TS(2);
     __syncthreads();
     // ---- 3. partial o-projection: D[feature 4 q + j][sequence li] of two strips over the 256 k of this kv head (columns 0 / 1 of the MFMA tile)
-    const int li = lane & 15, lq = lane >> 4;
     const int row = rq * 2 + li;                        // (meaningful for li < 2)
     const bool col_ok = li < 2 && row < p.B;
     f32x4 acc[2];
@@ -1639,7 +1725,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
             const float2 res = *reinterpret_cast<const float2*>(P.res + (size_t)rw * P.H + col);
             // the other workgroups stored when this one did, and a write-through store takes ~1 us to become readable: a read issued now
             // would come back stale and cost a second round trip (third version's timeline: reduced 2.7 us after its own partial sum)
-            wt_first_pause();
+            wt_first_pause(P.first_pause);
             cu32x4 pa[NKV - 1];
 #pragma unroll
             for (int g2 = 0; g2 < NKV - 1; ++g2) pa[g2] = wt_load16(slab, (int)((((size_t)g2 * 8 + rw) * P.H + col) * 8));
@@ -1663,7 +1749,6 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
         }
     }
     QTTS_TS(4);
-    if (tid == 0) *epoch = tag;                          // (read by the next launch, behind a kernel boundary)
     QTTS_TS_DRAINED(5);
     QTTS_TS_CPAO(1)
 }
@@ -1675,10 +1760,30 @@ bool cp_attn_o_takes(const AttnDecodeParams& a, int H) {
 
 void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
     QTTS_REQUIRE(cp_attn_o_takes(P.a, P.H), QTTS_ERR_ARG, "cp_attn_o: shape (bf16 cache, 16 / 8 heads of 128, one new token, <= 16 keys, batch <= 8)");
-    QTTS_REQUIRE(P.Wo && P.res && P.out && P.part && P.epoch && P.a.qkv && P.a.qw && P.a.kw && P.a.inv_freq, QTTS_ERR_ARG, "cp_attn_o: null operand");
+    QTTS_REQUIRE(P.Wo && P.res && P.out && P.part && P.serial && P.a.qw && P.a.kw && P.a.inv_freq, QTTS_ERR_ARG, "cp_attn_o: null operand");
+    QTTS_REQUIRE(P.slot >= 0 && P.slot < 128, QTTS_ERR_ARG, "cp_attn_o: slot must be 0..127");
     const dim3 grid(4 * 8 * (P.H / 128));                // (row pair, kv head, chunk)
-    if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true>), grid, dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((cp_attn_o_kernel<false>), grid, dim3(256), 0, st, P);
+    if (P.Wqkv) {      // with the layer's q|k|v GEMM in front: workgroup = one 16-feature strip of it, so the two grids must coincide
+        QTTS_REQUIRE((int)grid.x * 16 == P.a.ld && P.K == 1024 && P.x16 && P.qkv_gran && P.ldx16 % 8 == 0, QTTS_ERR_ARG,
+                     "cp_attn_o: the q|k|v front needs K = 1024, (nh + 2 nkv) * 128 == 16 * workgroups, bf16 x and the granule buffer");
+        CpAttnOParams Q = P;
+#ifdef QTTS_HOST_EMU
+        // The emulator runs the workgroups of a launch one after the other; here every workgroup first produces and then waits for
+        // other workgroups' strips, so the emulated launch runs as its two halves (the same code, both launches read the same tag).
+        for (int ph = 0; ph < 2; ++ph) {
+            Q.phase = ph;
+#else
+        {
+            Q.phase = 2;
+#endif
+            if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, true>), grid, dim3(256), 0, st, Q);
+            else hipLaunchKernelGGL((cp_attn_o_kernel<false, true>), grid, dim3(256), 0, st, Q);
+        }
+    } else {
+        QTTS_REQUIRE(P.a.qkv, QTTS_ERR_ARG, "cp_attn_o: null q|k|v rows");
+        if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, false>), grid, dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((cp_attn_o_kernel<false, false>), grid, dim3(256), 0, st, P);
+    }
     QTTS_CHECK_HIP(hipGetLastError());
 }
 

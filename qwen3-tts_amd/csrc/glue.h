@@ -12,6 +12,7 @@ struct StepState {
     int* done;          // latched when HF's stopping criteria would break
     int* final_count;   // n_generated at that moment
     int* unfinished;    // [B]
+    int* frame_serial;  // optional: +1 per frame step, never reset (the hand-off tags of attention.hip's cp_attn_o_kernel derive from it)
 };
 void launch_sample_finish(const StepState& s, int B, int max_new_tokens, hipStream_t st);
 

@@ -233,9 +233,18 @@ struct CpAttnOParams {
     const float* res;             // residual rows [B][H] (may be `out`)
     float* out;                   // hidden rows [B][H] fp32
     unsigned short* out16;        // optional bf16 copy [B][H]
-    float* part;                  // scratch [nkv][8][H] granules of 8 B {fp32 partial sum, launch tag}: zero at engine creation
-    unsigned* epoch;              // [4 row pairs][H / 128] launch counters (the tag of a launch = epoch + 1): zero at engine creation
+    float* part;                  // scratch [nkv][8][H] granules of 8 B {fp32 partial sum, launch tag}: zero at engine creation (tag 0 is never used)
+    const int* serial;            // device word that changes between two launches with the same `slot` (the engine: +1 per frame step)
+    int slot;                     // < 128, different for launches that share a value of *serial (the engine: pass * layers + layer):
+                                  // the launch tag = (*serial << 7) | slot differs from that of the launches before it
+    int phase;                    // 2: the whole kernel.  0 / 1 (host emulator only, with Wqkv): the q|k|v strips only / everything after them
     int* err;                     // optional device flag, set if a reducer gave up waiting (never in a correct run)
+    int first_pause;              // the reducer's wait before its first read of the other slabs, in units of 64 clocks (the engine passes 20)
+    // optional: the layer's q|k|v GEMM in front, in the same launch (workgroup i = 16-feature strip i of it; `a.qkv` is then unused)
+    const void* Wqkv;             // packed by pack_skinny_weight(bf16, fs = 16, RMSNorm weight folded): [(nh + 2 nkv) * hd / 16][K / 32][4][16][8] bf16
+    const unsigned short* x16;    // the layer's input rows [B][ldx16] bf16 (un-normalised: the kernel takes the row variances itself)
+    int ldx16, K; float eps_in;
+    float* qkv_gran;              // scratch [8][a.ld] granules of 8 B {fp32 q|k|v value, launch tag}: zero at engine creation
     int H;
 };
 bool cp_attn_o_takes(const AttnDecodeParams& a, int H);

@@ -705,6 +705,7 @@ __global__ void sample_finish_kernel(StepState st, int B, int max_new_tokens) {
         *st.n_generated = n;
         *st.gen_step += 1;
         *st.kv_len += 1;
+        if (st.frame_serial) *st.frame_serial += 1;
         int any = 0;
         for (int b = 0; b < B; ++b) any |= st.unfinished[b];
         if (n >= max_new_tokens || !any) { *st.done = 1; *st.final_count = n; }

@@ -208,13 +208,16 @@ struct qtts_talker {
     // instead of N / 32 strip pairs -- 768 instead of 384 for the talker: three per CU instead of 1.5, 9.5 vs 10.7 us streamed.
     // Bit-identical results (the same per-element accumulation), a second packed copy of the operator.  QTTS_SWIGLU8=0: strip pairs.
     bool swiglu8_env = [] { const char* e = getenv("QTTS_SWIGLU8"); return !e || atoi(e) != 0; }();
-    // QTTS_CP_ATTN_O=1 (A/B only, read at engine creation): the code predictor's attention + o-projection of passes >= 1 as ONE launch
-    // (attention.hip: cp_attn_o_kernel).  Three versions were measured on the MI355X (profiles/r04_cp_attn_o.md): 2.74-2.87 ms per frame
-    // against 2.67 ms with the two launches -- the in-launch hand-off of the partial sums costs what the boundary it replaces costs -- so
-    // the default stays attn_cp + the decode GEMM.
-    bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return e && atoi(e) != 0; }();
-    DevBuf ao_part, ao_cnt;            // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}; [4 row pairs][H / 128] launch counters (epochs)
-    int64_t cp_attn_o_count = 0;
+    // The code predictor's attention + o-projection of passes >= 1 as ONE launch (attention.hip: cp_attn_o_kernel; bf16 engines, batch <= 8):
+    // 2.60 vs 2.68 ms per frame on the MI355X in its fourth version (profiles/r04_cp_attn_o.md; the first three were slower than the two
+    // launches).  QTTS_CP_ATTN_O=0 (read at engine creation): attn_cp + the decode GEMM.
+    bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
+    int cp_attn_o_pause = [] { const char* e = getenv("QTTS_CP_ATTN_O_PAUSE"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 20; }();   // (A/B: x 64 clocks)
+    DevBuf ao_part;                    // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}
+    int64_t cp_attn_o_count = 0, cp_front_count = 0;
+    // ... with the layer's own q|k|v GEMM in front of it in the same launch (layers >= 1).  QTTS_CP_FRONT=0: the decode GEMM, then cp_attn_o.
+    bool cp_front_env = [] { const char* e = getenv("QTTS_CP_FRONT"); return !e || atoi(e) != 0; }();
+    DevBuf ao_qkv;                     // [8 rows][q|k|v width] granules {value, tag}
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
                          PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
@@ -231,8 +234,8 @@ struct qtts_talker {
             upload_packed(L.gu_p8, interleave_gu8(PS(p + "mlp.gate_proj.weight", {d.I, d.H}), PS(p + "mlp.up_proj.weight", {d.I, d.H}), d.I, d.H),
                           2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         upload_packed(L.d_p, dw, d.H, d.I, nullptr, L.fs_d);
-        // QTTS_CP_ATTN_O=1, code predictor, bf16: passes >= 1 run attention + o-projection as ONE launch (attention.hip: cp_attn_o_kernel),
-        // whose waves own 16-feature strips of the operator (a second packed copy: 4 MB per layer)
+        // code predictor, bf16: passes >= 1 run attention + o-projection as ONE launch (attention.hip: cp_attn_o_kernel), whose waves own
+        // 16-feature strips of the operator (a second packed copy: 4 MB per layer)
         if (bf16 && !rows && cp_attn_o_env && d.nh == 16 && d.nkv == 8 && d.hd == 128 && d.H % 128 == 0)
             upload_packed(L.o_p16, ow, d.H, d.qd, nullptr, 16);
         if (rows) {
@@ -298,14 +301,6 @@ struct qtts_talker {
         p.done_flag = ss.done;
         p.x = xs; p.ldx = d.H; p.M = M; p.Wp = L.qkv_p.p; p.N = d.qd + 2 * d.kvd; p.K = d.H;
         p.out = qkvb; p.ldo = d.qd + 2 * d.kvd; p.act = ACT_NONE;
-        if (!skip_qkv) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
-            if (splitk && sk_pending) {    // the previous layer's down-projection left (residual + half 0, half 1): added on the way in
-                p.xp = sk_part.as<float>(); p.xp_stride = pstride; p.x_out = xs;
-                sk_pending = false;
-            }
-            norm_input(p, d, h16 ? xs16 : nullptr, st);
-            skinny(p, st);
-        }
         AttnDecodeParams a{};
         a.qkv = qkvb; a.ld = d.qd + 2 * d.kvd; a.B = B; a.n_new = n_new; a.nh = d.nh; a.nkv = d.nkv; a.hd = d.hd;
         a.qw = L.qn.as<float>(); a.kw = L.kn.as<float>(); a.eps = d.eps; a.inv_freq = inv_freq; a.n_pad = npad;
@@ -319,12 +314,28 @@ struct qtts_talker {
         // staged into the consuming GEMM by LDS-DMA
         const bool att16 = bf16 && skinny_takes_bf16_x(M, d.qd, true), act16 = bf16 && skinny_takes_bf16_x(M, d.I, true);
         a.out_bf16 = att16;
-        // QTTS_CP_ATTN_O=1 engines (bf16), code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k
-        // by kv head, partial sums handed over as tagged granules and added in kv-head order; profiles/r04_cp_attn_o.md)
-        if (L.o_p16.p && ao_part.p && att16 && !skinny_only && cp_attn_o_takes(a, d.H)) {
+        // bf16 engines, code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k by kv head, partial
+        // sums handed over as tagged granules and added in kv-head order; profiles/r04_cp_attn_o.md) -- and, where the layer has a q|k|v
+        // GEMM of its own (layers >= 1: layer 0's row comes from the table), that GEMM in front of them in the same launch
+        const bool fuse_ao = L.o_p16.p && ao_part.p && att16 && !skinny_only && cp_attn_o_takes(a, d.H) && layer < 5 && len_static * 5 + layer < 128;
+        const bool front = fuse_ao && !skip_qkv && h16 && cp_front_env && d.H == 1024 && a.ld == 4 * 8 * (d.H / 128) * 16;
+        if (!skip_qkv && !front) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
+            if (splitk && sk_pending) {    // the previous layer's down-projection left (residual + half 0, half 1): added on the way in
+                p.xp = sk_part.as<float>(); p.xp_stride = pstride; p.x_out = xs;
+                sk_pending = false;
+            }
+            norm_input(p, d, h16 ? xs16 : nullptr, st);
+            skinny(p, st);
+        }
+        if (fuse_ao) {
             CpAttnOParams f{};
             f.a = a; f.Wo = L.o_p16.p; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
-            f.part = ao_part.as<float>(); f.epoch = ao_cnt.as<unsigned>(); f.err = ss.n_generated + 5; f.H = d.H;
+            f.part = ao_part.as<float>(); f.serial = ss.frame_serial; f.slot = len_static * 5 + layer; f.phase = 2;
+            f.err = ss.n_generated + 5; f.H = d.H; f.first_pause = cp_attn_o_pause;
+            if (front) {
+                f.Wqkv = L.qkv_p.p; f.x16 = xs16; f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = ao_qkv.as<float>();
+                ++cp_front_count;
+            }
             launch_cp_attn_o(f, st);
             ++cp_attn_o_count;
         } else {
@@ -563,14 +574,16 @@ void qtts_talker::finalize() {
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
     }
     if (bf16 && !cl.empty() && cl[0].o_p16.p) {
-        ao_part.alloc((size_t)8 * 8 * cd.H * 8); ao_cnt.alloc((size_t)4 * (cd.H / 128) * 4);
+        ao_part.alloc((size_t)8 * 8 * cd.H * 8);
+        ao_qkv.alloc((size_t)8 * (cd.qd + 2 * cd.kvd) * 8);
+        QTTS_CHECK_HIP(hipMemset(ao_qkv.p, 0, ao_qkv.bytes));
         QTTS_CHECK_HIP(hipMemset(ao_part.p, 0, ao_part.bytes));
-        QTTS_CHECK_HIP(hipMemset(ao_cnt.p, 0, ao_cnt.bytes));
     }
     n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size); seed_d.alloc(8);
     QTTS_CHECK_HIP(hipMemset(ss_rows.p, 0, ss_rows.bytes));
     int* ip = ints.as<int>();
-    ss = {ip + 0, ip + 1, ip + 2, ip + 3, ip + 4, ip + 64};
+    ss = {ip + 0, ip + 1, ip + 2, ip + 3, ip + 4, ip + 64, ip + 6};
+    { const int one = 1; QTTS_CHECK_HIP(hipMemcpy(ss.frame_serial, &one, 4, hipMemcpyHostToDevice)); }       // (0 is the tag of a never-written granule)
     // A/B variant (build.py VARIANTS): in passes 1 .. G-2 the code predictor's layer-0 q|k|v GEMM sees only the pass input row,
     // a function of the previous token alone (has_proj: the projected embedding above; otherwise codec_embedding itself).
     // Tabulate it with the same launches the frame step makes -- bf16 mode: LDS-staged from the bf16 image of the row with the

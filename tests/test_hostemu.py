@@ -54,6 +54,7 @@ def emu():
     lib.hostemu_set_real_gemm.argtypes = [i32]; lib.hostemu_set_real_gemm.restype = None
     lib.hostemu_set_fiber_order.argtypes = [i32]; lib.hostemu_set_fiber_order.restype = None
     lib.hostemu_set_block_order.argtypes = [i32]; lib.hostemu_set_block_order.restype = None
+    lib.hostemu_cp_layer_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.c_uint32]
     lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
@@ -775,6 +776,96 @@ def test_cp_attn_o_fused_launch_real_source(emu):
             if first is None:
                 first = o1
             assert np.array_equal(o1, first), ("result depends on the wave order / the epoch", B, S0, bo, fo)
+
+
+def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
+    """`cp_attn_o_kernel` with the layer's q|k|v GEMM in front (round 4): 256 workgroups, each first computes a 16-feature strip of
+    q|k|v = rsqrt(mean x^2 + eps) * W' x (RMSNorm weight folded into W', row variances from the same bf16 x fragments, four k quarters
+    added in wave order), hands it over as tagged granules, then attends with the rows it reads back from six other workgroups' strips,
+    and goes on as the attention + o-projection launch.  Real source, real dimensions (hidden 1024, 16 / 8 heads of 128), against the
+    three launches it replaces (decode GEMM, attn_cp, decode GEMM: agreement to fp32 summation order of the two GEMMs + the bf16
+    rounding of K / V / the attention output that a last-bit difference in q|k|v can flip) and against float64 numpy; batch 8 / 3,
+    contiguous and permuted page tables, three fiber orders, two launches per call on the same granule buffers from two epochs."""
+    g = np.random.default_rng(505)
+    HD, nh, nkv, H, eps, eps_in = 128, 16, 8, 1024, 1e-6, 1e-6
+    qd, ld = nh * HD, (nh + 2 * nkv) * HD
+    inv_freq = (1.0 / (10000.0 ** (np.arange(64) / 64.0))).astype(np.float32)
+    qw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+    kw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
+    gn = (1 + 0.1 * g.standard_normal(H)).astype(np.float32)
+    Wqkv = (g.standard_normal((ld, H)) * 0.04).astype(np.float32)
+    Wo = (g.standard_normal((H, qd)) * 0.03).astype(np.float32)
+    Wq_r = _bf16_round(Wqkv * gn[None, :])[0].astype(np.float64)
+    Wo_r = _bf16_round(Wo)[0].astype(np.float64)
+
+    def normrope(x, w, pos):
+        x = x.astype(np.float64)
+        x = w * (x / np.sqrt((x ** 2).mean() + eps))
+        ang = np.float32(pos) * inv_freq
+        c, s = np.cos(ang.astype(np.float64)), np.sin(ang.astype(np.float64))
+        return np.concatenate([x[:64] * c - x[64:] * s, x[64:] * c + x[:64] * s])
+
+    for (B, S0, permute) in [(8, 6, False), (3, 14, True)]:
+        pps = 2
+        n_pages = B * pps
+        table = (g.permutation(n_pages) if permute else np.arange(n_pages)).astype(np.int32).reshape(B, pps)
+        x = g.standard_normal((B, H)).astype(np.float32)
+        res = g.standard_normal((B, H)).astype(np.float32)
+        K = _bf16_round((g.standard_normal((B, nkv, S0, HD)) * 0.7).astype(np.float32))[0]
+        V = _bf16_round(g.standard_normal((B, nkv, S0, HD)).astype(np.float32))[0]
+        kpool = np.full((n_pages, nkv, 16, HD), 0x7FC0, np.uint16)
+        vpool = kpool.copy()
+        for b in range(B):
+            for s in range(S0):
+                kpool[table[b, s // 16], :, s % 16] = _bf16_round(K[b, :, s])[1]
+                vpool[table[b, s // 16], :, s % 16] = _bf16_round(V[b, :, s])[1]
+        x_r = _bf16_round(x)[0].astype(np.float64)
+        ref = np.zeros((B, H))
+        for b in range(B):
+            row = (Wq_r @ x_r[b]) / np.sqrt((x_r[b] ** 2).mean() + eps_in)
+            att = np.zeros(qd)
+            for h in range(nkv):
+                nk = _bf16_round(normrope(row[(nh + h) * HD:(nh + h + 1) * HD], kw, S0).astype(np.float32))[0]
+                nv = _bf16_round(row[(nh + nkv + h) * HD:(nh + nkv + h + 1) * HD].astype(np.float32))[0]
+                keys = np.concatenate([K[b, h].astype(np.float64), nk[None].astype(np.float64)], 0)
+                vals = np.concatenate([V[b, h].astype(np.float64), nv[None].astype(np.float64)], 0)
+                for gq in range(2):
+                    hq = 2 * h + gq
+                    q = normrope(row[hq * HD:(hq + 1) * HD], qw, S0)
+                    sc = keys @ q / np.sqrt(HD)
+                    pr = np.exp(sc - sc.max()); pr /= pr.sum()
+                    att[hq * HD:(hq + 1) * HD] = pr @ vals
+            ref[b] = Wo_r @ _bf16_round(att.astype(np.float32))[0].astype(np.float64) + res[b]
+
+        def run(mode, fiber_order=0, epoch0=0):
+            kk, vv = kpool.copy(), vpool.copy()
+            out = np.full((B, H), np.nan, np.float32)
+            out16 = np.full((B, H), 0x4242, np.uint16)
+            emu.hostemu_set_fiber_order(fiber_order)
+            try:
+                rc = emu.hostemu_cp_layer_front(_ptr(x), B, _ptr(Wqkv), _ptr(gn), eps_in, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), S0, _ptr(kk),
+                                                _ptr(vv), _ptr(table) if permute else None, pps, _ptr(Wo), H, _ptr(res), _ptr(out), _ptr(out16),
+                                                mode, None, 0, epoch0)
+            finally:
+                emu.hostemu_set_fiber_order(0)
+            assert rc == 0, ((B, S0, mode), rc, (emu.qtts_last_error() or b"").decode())
+            return out, out16, kk, vv
+
+        o0, h0, k0, v0 = run(0)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(o0 - ref).max()) <= 3e-2 * scale, "the three launches are off their own reference"
+        first = None
+        for (fo, e0) in [(0, 0), (1, 7), (2, 0xFFFFFFF0)]:
+            o2, h2, k2, v2 = run(2, fo, e0)
+            assert float(np.abs(o2 - ref).max()) <= 3e-2 * scale, (B, S0, float(np.abs(o2 - ref).max()))
+            assert float(np.sqrt(((o2 - o0) ** 2).mean())) <= 2e-3 * float(np.sqrt((o0 ** 2).mean())), (B, S0)
+            # the appended K / V rows: equal up to a bf16 last-bit flip where the two q|k|v GEMMs' fp32 sums straddle a rounding boundary
+            kd = (k2.astype(np.int32) - k0.astype(np.int32)); vd = (v2.astype(np.int32) - v0.astype(np.int32))
+            assert np.abs(kd).max() <= 1 and np.abs(vd).max() <= 1 and (kd != 0).mean() < 0.02 and (vd != 0).mean() < 0.02
+            assert np.array_equal(h2, _bf16_round(o2)[1]), "bf16 copy of the hidden rows"
+            if first is None:
+                first = o2
+            assert np.array_equal(o2, first), ("result depends on the wave order / the epoch", B, S0, fo)
 
 
 @pytest.mark.parametrize("nsplit", [1, 3])
@@ -1522,15 +1613,19 @@ def test_talker_fp32_split_k_layer_chain_vs_oracle(emu):
         emu.qtts_talker_destroy(h)
 
 
-def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeypatch):
-    """Round 4: the ENGINE side of `cp_attn_o_kernel` -- the second packed copy of the o-projection (16-feature strips), the partial-sum
-    and counter buffers, which passes take the fused launch (passes >= 1 of a bf16 engine at batch <= 8; pass 0 with its two new tokens
-    keeps attn_cp0 + the decode GEMM) -- on a predictor with the real head geometry (16 query / 8 kv heads of 128) and a 256-wide hidden
-    state (two 128-feature chunks), greedy bf16, eager and through the captured frame graph: the codes and hidden states equal those of
-    the same engine with QTTS_CP_ATTN_O=0 (two launches) up to bf16 noise, the captured graph has (passes - 1) x layers fewer kernel
-    nodes, and a second generation on the same handle (counters re-used) repeats the first bit for bit."""
+@pytest.mark.parametrize("cp_hidden", [256, 1024])
+def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeypatch, cp_hidden):
+    """Round 4: the ENGINE side of `cp_attn_o_kernel` -- the second packed copy of the o-projection (16-feature strips), the granule
+    buffers and the frame serial the launch tags derive from, which passes take the fused launch (passes >= 1 of a bf16 engine at batch
+    <= 8; pass 0 with its two new tokens keeps attn_cp0 + the decode GEMM) and which layers also take their q|k|v GEMM into it (layers
+    >= 1 of a 1024-wide predictor: layer 0's row comes from the table) -- on a predictor with the real head geometry (16 query / 8 kv
+    heads of 128) and a 256-wide (two 128-feature chunks; no q|k|v front) or 1024-wide (the real width; with the front) hidden state,
+    greedy bf16, eager and through the captured frame graph: the codes and hidden states equal those of the same engine with
+    QTTS_CP_ATTN_O=0 (separate launches) up to bf16 noise, the captured graph has (passes - 1) x layers fewer kernel nodes (the emulator
+    runs a launch with the front as its two halves: one node less per fused layer either way), and a second generation on the same
+    handle (granule buffers re-used, serial advanced) repeats the first bit for bit."""
     import dataclasses
-    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=256, cp_intermediate_size=256, cp_num_hidden_layers=2,
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=cp_hidden, cp_intermediate_size=256, cp_num_hidden_layers=2,
                             cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
     w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
     emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(23), t, [5, 3, 6], 2, scale=0.5)
