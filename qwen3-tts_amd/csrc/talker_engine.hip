@@ -212,7 +212,8 @@ struct qtts_talker {
     // 2.60 vs 2.68 ms per frame on the MI355X in its fourth version (profiles/r04_cp_attn_o.md; the first three were slower than the two
     // launches).  QTTS_CP_ATTN_O=0 (read at engine creation): attn_cp + the decode GEMM.
     bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
-    int cp_attn_o_pause = [] { const char* e = getenv("QTTS_CP_ATTN_O_PAUSE"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 20; }();   // (A/B: x 64 clocks)
+    int cp_attn_o_pause = [] { const char* e = getenv("QTTS_CP_ATTN_O_PAUSE"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 16; }();   // (A/B: x 64 clocks)
+    int cp_attn_o_step = [] { const char* e = getenv("QTTS_CP_ATTN_O_STEP"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 8; }();
     DevBuf ao_part;                    // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}
     int64_t cp_attn_o_count = 0, cp_front_count = 0;
     // ... with the layer's own q|k|v GEMM in front of it in the same launch (layers >= 1).  QTTS_CP_FRONT=0: the decode GEMM, then cp_attn_o.
@@ -331,7 +332,7 @@ struct qtts_talker {
             CpAttnOParams f{};
             f.a = a; f.Wo = L.o_p16.p; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
             f.part = ao_part.as<float>(); f.serial = ss.frame_serial; f.slot = len_static * 5 + layer; f.phase = 2;
-            f.err = ss.n_generated + 5; f.H = d.H; f.first_pause = cp_attn_o_pause;
+            f.err = ss.n_generated + 5; f.H = d.H; f.first_pause = cp_attn_o_pause; f.poll_step = cp_attn_o_step;
             if (front) {
                 f.Wqkv = L.qkv_p.p; f.x16 = xs16; f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = ao_qkv.as<float>();
                 ++cp_front_count;

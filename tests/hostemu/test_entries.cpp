@@ -207,7 +207,7 @@ extern "C" int hostemu_cp_attn_o(const float* qkv, int ld, int B, const float* q
             int serial = (int)epoch0, err = 0;
             qtts::CpAttnOParams f{};
             f.a = a; f.Wo = wp.data(); f.res = out; f.out = out; f.out16 = out16; f.part = part.data(); f.serial = &serial; f.slot = 3; f.phase = 2;
-            f.err = &err; f.H = H; f.first_pause = 20;
+            f.err = &err; f.H = H; f.first_pause = 16; f.poll_step = 8;
             if (!qtts::cp_attn_o_takes(a, H)) return -2;
             for (int rep = 0; rep < 2; ++rep) {                     // twice on the same buffers: the second launch must not take the first one's granules
                 if (rep) { for (int i = 0; i < B * H; ++i) out[i] = res[i]; f.a.kv.k = kpool; f.a.kv.v = vpool; f.slot = 4; }
@@ -257,7 +257,7 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
             int serial = (int)epoch0, err = 0;
             qtts::CpAttnOParams f{};
             f.a = a; f.a.qkv = nullptr; f.Wo = wp.data(); f.res = out; f.out = out; f.out16 = out16; f.part = part.data(); f.serial = &serial; f.slot = 9;
-            f.phase = 2; f.err = &err; f.H = H; f.first_pause = 20;
+            f.phase = 2; f.err = &err; f.H = H; f.first_pause = 16; f.poll_step = 8;
             f.Wqkv = wq.data(); f.x16 = x16.data(); f.ldx16 = H; f.K = H; f.eps_in = eps_in; f.qkv_gran = gran.data();
             for (int rep = 0; rep < 2; ++rep) {                     // twice on the same granule buffers
                 if (rep) { for (int i = 0; i < B * H; ++i) out[i] = res[i]; ++serial; }
