@@ -1514,7 +1514,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
         for (int k = 0; k < MAXK; ++k) vr[k] = *reinterpret_cast<const VPair*>(vc + key_base(k < S0 ? k : 0) + 2 * lane);
     }
     cu32x4 wf[2][8];
-    {
+    auto load_wo = [&] {
         const int nkt = (p.nh * HD) >> 5;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -1522,7 +1522,8 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) wf[s][ks] = wsrc[ks * 64];
         }
-    }
+    };
+    if constexpr (!QKV) load_wo();                      // (with the q|k|v front: requested behind the strip's store -- 64 KB that would delay the strip)
     const int done = p.done_flag ? *p.done_flag : 0;
     if (done) return;
     if (QKV && P.phase != 1) {
@@ -1564,6 +1565,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
     }
     if constexpr (QKV) {
         if (rq * 2 >= p.B) return;                     // (no sequence in this row pair: nothing to attend to, nobody waits for more)
+        load_wo();                                     // arrives while this workgroup waits for its rows and attends
         QTTS_TS(1);
         // ---- 0c. this wave's rows of q | k | v, from the strips of 6 other workgroups: wait ~0.5 us before the first read (as the reducer
         // below: a read issued right away comes back stale), then until every granule carries this launch's tag

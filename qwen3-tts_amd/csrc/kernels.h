@@ -240,7 +240,7 @@ struct CpAttnOParams {
     int phase;                    // 2: the whole kernel.  0 / 1 (host emulator only, with Wqkv): the q|k|v strips only / everything after them
     int* err;                     // optional device flag, set if a reducer gave up waiting (never in a correct run)
     int first_pause, poll_step;   // x 64 clocks: a consumer's wait before its first read of other workgroups' granules, and between the
-                                  // reads it keeps in flight after that (the engine passes 16 and 8: ~0.4 and ~0.2 us)
+                                  // reads it keeps in flight after that (the engine passes 16 and 4: ~0.4 and ~0.1 us)
     // optional: the layer's q|k|v GEMM in front, in the same launch (workgroup i = 16-feature strip i of it; `a.qkv` is then unused)
     const void* Wqkv;             // packed by pack_skinny_weight(bf16, fs = 16, RMSNorm weight folded): [(nh + 2 nkv) * hd / 16][K / 32][4][16][8] bf16
     const unsigned short* x16;    // the layer's input rows [B][ldx16] bf16 (un-normalised: the kernel takes the row variances itself)

@@ -213,7 +213,7 @@ struct qtts_talker {
     // launches).  QTTS_CP_ATTN_O=0 (read at engine creation): attn_cp + the decode GEMM.
     bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
     int cp_attn_o_pause = [] { const char* e = getenv("QTTS_CP_ATTN_O_PAUSE"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 16; }();   // (A/B: x 64 clocks)
-    int cp_attn_o_step = [] { const char* e = getenv("QTTS_CP_ATTN_O_STEP"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 8; }();
+    int cp_attn_o_step = [] { const char* e = getenv("QTTS_CP_ATTN_O_STEP"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 4; }();
     DevBuf ao_part;                    // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}
     int64_t cp_attn_o_count = 0, cp_front_count = 0;
     // ... with the layer's own q|k|v GEMM in front of it in the same launch (layers >= 1).  QTTS_CP_FRONT=0: the decode GEMM, then cp_attn_o.
