@@ -540,6 +540,25 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
                 out["frac_rocprof"] = rec["frac_rocprof"]
                 out["rocprof_avg_launch_us"] = rec["rocprof_avg_launch_us"]
                 out["frac_live_over_rocprof"] = round(out["frac"] / rec["frac_rocprof"], 4)
+            if "fused" in rec and out["weight_bytes_per_frame_timed"] < wbytes:
+                # Round 4: in passes >= 1 of the code predictor the q|k|v GEMM, the attention and the o-projection run as ONE launch
+                # (attention.hip: cp_attn_o_kernel) -- weight bytes that left the decode GEMM's launches.  Not timed by the per-launch events
+                # above: durations and FETCH_SIZE bytes from the same stamped rocprofv3 passes, algorithmic bytes = the two operators.
+                c = talker.config
+                qd, kvd, H = c.cp_num_attention_heads * c.cp_head_dim, c.cp_num_key_value_heads * c.cp_head_dim, c.cp_hidden_size
+                G, L = c.num_code_groups, c.cp_num_hidden_layers
+                alg = {"front": ((qd + 2 * kvd) * H + H * qd) * elem_bytes, "attn_o": H * qd * elem_bytes}
+                per_frame = {"front": (G - 2) * (L - 1), "attn_o": G - 2}
+                fl = {}
+                for k, f in rec["fused"].items():
+                    if k in alg and f.get("rocprof_avg_launch_us"):
+                        fl[k] = {"launches_per_frame": per_frame[k], "algorithmic_bytes_per_launch": alg[k], "rocprof_avg_launch_us": f["rocprof_avg_launch_us"],
+                                 "frac_rocprof": round(alg[k] / (f["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "traffic": f.get("fetch_bytes_per_launch")}
+                if fl:
+                    fl["kernel"] = "cp_attn_o_kernel (front: q|k|v GEMM + attention + o-projection of a code-predictor layer in one launch; attn_o: layer 0, whose q|k|v row comes from the table)"
+                    fl["weight_bytes_per_frame"] = sum(v["launches_per_frame"] * v["algorithmic_bytes_per_launch"] for v in fl.values() if isinstance(v, dict))
+                    out["fused_cp_launch"] = fl
     except Exception as e:
         traffic_src = f"unavailable ({type(e).__name__}: {e})"
     out["traffic"], out["traffic_source"] = traffic, traffic_src

@@ -721,6 +721,23 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     print(f"cp_attn_o vs attn_cp + decode GEMM (0.6B, 8 x 40 frames, teacher-forced): sub-codebooks agree {agree:.4f}; against the fp32 golden: "
           f"fused {agree_gold:.4f}, two launches {plain_gold:.4f}")
     assert agree >= 0.85 and agree_gold >= plain_gold - 0.03
+    # a batch that does not fill the row pairs (3 sequences: the second pair has one, the last two have none), free-running greedy
+    sub = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["QTTS_CP_ATTN_O"] = flag
+            eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=3, max_seq=256, use_graph=True)
+            kw = dict(max_new_tokens=21, min_new_tokens=21, do_sample=False, subtalker_dosample=False, suppress_tokens=_suppress(cfg))
+            sub[flag] = [eng.generate(emb[:3], mask[:3], tr[:3], pad, **kw).codes.cpu().numpy() for _ in range(2)]
+            del eng
+            torch.cuda.empty_cache()
+    finally:
+        os.environ.pop("QTTS_CP_ATTN_O", None)
+    assert np.array_equal(sub["1"][0], sub["1"][1]), "batch 3: the fused launch is not run-to-run identical"
+    n = min(sub["1"][0].shape[1], sub["0"][0].shape[1], 4)            # (free-running: the first frames, before a flipped code changes the inputs)
+    a3 = float((sub["1"][0][:, :n] == sub["0"][0][:, :n]).mean())
+    print(f"batch 3, free-running greedy, first {n} frames: fused vs separate launches agree {a3:.4f}")
+    assert a3 >= 0.8
 
 
 def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):

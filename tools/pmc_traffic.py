@@ -9,7 +9,9 @@ the pass (410 of the frame step's 415 decode-GEMM launches; the other five share
 ratio = sum(FETCH_SIZE bytes) / sum(algorithmic bytes), where the algorithmic bytes of a dispatch are N x K x 2 with N and K reconstructed
 from the instantiation and the grid (as tools/rocpd_stats.py does).  bench.py multiplies ITS algorithmic bytes per launch by that ratio.
 With --trace-db the same classes' launch-weighted duration from the kernel trace gives `frac_rocprof` (the roofline fraction rocprofv3 sees).
-The JSON carries a digest of csrc/skinny.hip + csrc/talker_engine.hip; bench.py reports `traffic: null` when the tree's digest differs."""
+The JSON carries a digest of csrc/skinny.hip + csrc/talker_engine.hip; bench.py reports `traffic: null` when the tree's digest differs.
+The code predictor's fused launches (attention.hip: cp_attn_o_kernel, with / without the q|k|v front) ride along under "fused": dispatches,
+FETCH_SIZE bytes and trace duration per launch -- bench.py prints them beside the decode GEMM's numbers (`roofline.fused_cp_launch`)."""
 import argparse, hashlib, json, os, re, sqlite3, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -42,8 +44,16 @@ if __name__ == "__main__":
     rows = cur.execute("select kernel_name, counter_name, value, grid_size_x, workgroup_size_x from counters_collection").fetchall()
     fetch = alg = 0.0
     n = 0
+    fused = {}                                   # "front" | "attn_o" -> [dispatches, fetch bytes, trace launches, trace us]
+    def fused_key(name):
+        m = re.search(r"cp_attn_o_kernel<(true|false), (true|false)>", name)
+        return None if not m else ("front" if m.group(2) == "true" else "attn_o")
     for name, cname, v, g, w in rows:
         if cname != "FETCH_SIZE":
+            continue
+        fk = fused_key(name)
+        if fk:
+            f = fused.setdefault(fk, [0, 0.0, 0, 0.0]); f[0] += 1; f[1] += v * 1024.0 * 2.0
             continue
         s = shape_of(name, g, w)
         if s is None:
@@ -61,6 +71,10 @@ if __name__ == "__main__":
         wcol = next(c for c in ("workgroup_size_x", "workgroup_x", "workgroup_size") if c in cols)
         tb = tt = tn = 0.0
         for name, s0, e0, g, w in c2.execute(f"select name, start, end, {gcol}, {wcol} from kernels"):
+            fk = fused_key(name)
+            if fk:
+                f = fused.setdefault(fk, [0, 0.0, 0, 0.0]); f[2] += 1; f[3] += (e0 - s0) / 1000.0
+                continue
             s = shape_of(name, g, w)
             if s is None:
                 continue
@@ -68,6 +82,9 @@ if __name__ == "__main__":
         rec["rocprof_avg_launch_us"] = round(tt / tn, 3)
         rec["frac_rocprof"] = round(tb / tt / 1e3 / 8000.0, 4)
         rec["rocprof_launches"] = int(tn)
+    if fused:
+        rec["fused"] = {k: {"dispatches": f[0], "fetch_bytes_per_launch": round(f[1] / f[0]) if f[0] else None, "rocprof_launches": f[2],
+                            "rocprof_avg_launch_us": round(f[3] / f[2], 3) if f[2] else None} for k, f in fused.items()}
     out = {"_doc": __doc__.split("\n\n")[1].replace("\n", " "), "kernel_digest": kernel_digest(), a.model: rec}
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
