@@ -721,23 +721,26 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     print(f"cp_attn_o vs attn_cp + decode GEMM (0.6B, 8 x 40 frames, teacher-forced): sub-codebooks agree {agree:.4f}; against the fp32 golden: "
           f"fused {agree_gold:.4f}, two launches {plain_gold:.4f}")
     assert agree >= 0.85 and agree_gold >= plain_gold - 0.03
-    # a batch that does not fill the row pairs (3 sequences: the second pair has one, the last two have none), free-running greedy
+    # a batch that does not fill the row pairs (3 sequences: the second pair has one, the last two have none), teacher-forced like the
+    # first part (free-running greedy is no measure here: on these seeded random weights one rounding-level flip in frame 0 changes every
+    # code after it -- measured: 0.27 agreement in frame 0, 0.04 after, between two CORRECT builds)
     sub = {}
     try:
         for flag in ("1", "0"):
             os.environ["QTTS_CP_ATTN_O"] = flag
             eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=3, max_seq=256, use_graph=True)
-            kw = dict(max_new_tokens=21, min_new_tokens=21, do_sample=False, subtalker_dosample=False, suppress_tokens=_suppress(cfg))
-            sub[flag] = [eng.generate(emb[:3], mask[:3], tr[:3], pad, **kw).codes.cpu().numpy() for _ in range(2)]
+            sub[flag] = [eng.generate(emb[:3], mask[:3], tr[:3], pad, teacher_codes=gc[:3], suppress_tokens=_suppress(cfg)).own.cpu().numpy()
+                         for _ in range(2)]
             del eng
             torch.cuda.empty_cache()
     finally:
         os.environ.pop("QTTS_CP_ATTN_O", None)
     assert np.array_equal(sub["1"][0], sub["1"][1]), "batch 3: the fused launch is not run-to-run identical"
-    n = min(sub["1"][0].shape[1], sub["0"][0].shape[1], 4)            # (free-running: the first frames, before a flipped code changes the inputs)
-    a3 = float((sub["1"][0][:, :n] == sub["0"][0][:, :n]).mean())
-    print(f"batch 3, free-running greedy, first {n} frames: fused vs separate launches agree {a3:.4f}")
-    assert a3 >= 0.8
+    a3 = float((sub["1"][0][:, :, 1:] == sub["0"][0][:, :, 1:]).mean())
+    g3 = float((sub["1"][0][:, :40, 1:] == g["codes"][:3, :40, 1:]).mean())
+    p3 = float((sub["0"][0][:, :40, 1:] == g["codes"][:3, :40, 1:]).mean())
+    print(f"batch 3, teacher-forced: sub-codebooks agree {a3:.4f}; against the fp32 golden: fused {g3:.4f}, separate launches {p3:.4f}")
+    assert a3 >= 0.85 and g3 >= p3 - 0.04
 
 
 def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):
