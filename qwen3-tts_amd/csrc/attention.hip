@@ -1447,8 +1447,14 @@ constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a
 #endif
 }  // namespace
 
+// The operands of the FIRST requests are leading scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave
+// instead of behind an s_load round trip of the by-value struct (as the decode GEMM's, profiles/r03_ab_kpre.md).
+#define QTTS_CPAO_ARGS(P) ((P).Wqkv ? (P).Wqkv : static_cast<const void*>((P).a.qkv)), (P).x16, (P).serial, (P).a.done_flag, (P).a.B, (P).ldx16, (P).K, (P).slot, (P)
 template <bool CT, bool QKV>
-__global__ __launch_bounds__(256) void cp_attn_o_kernel(CpAttnOParams P) {
+__global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const unsigned short* kx16, const int* kserial, const int* kdone, int kB, int kldx16,
+                                                        int kK, int kslot, CpAttnOParams P) {
+    if constexpr (QKV) P.Wqkv = k0; else P.a.qkv = static_cast<const float*>(k0);
+    P.x16 = kx16; P.serial = kserial; P.a.done_flag = kdone; P.a.B = kB; P.ldx16 = kldx16; P.K = kK; P.slot = kslot;
     constexpr int HD = 128, MAXK = 16, KW = 4, NKV = 8, BSTR = 264;       // BSTR: bf16 per row of the B tile (16-B rows, bank-spread)
     typedef bf16_t KVT;
     // ONE LDS object (a second one de-pipelines the loads around it):
@@ -1793,13 +1799,13 @@ void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
         {
             Q.phase = 2;
 #endif
-            if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, true>), grid, dim3(256), 0, st, Q);
-            else hipLaunchKernelGGL((cp_attn_o_kernel<false, true>), grid, dim3(256), 0, st, Q);
+            if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, true>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(Q));
+            else hipLaunchKernelGGL((cp_attn_o_kernel<false, true>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(Q));
         }
     } else {
         QTTS_REQUIRE(P.a.qkv, QTTS_ERR_ARG, "cp_attn_o: null q|k|v rows");
-        if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, false>), grid, dim3(256), 0, st, P);
-        else hipLaunchKernelGGL((cp_attn_o_kernel<false, false>), grid, dim3(256), 0, st, P);
+        if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, false>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(P));
+        else hipLaunchKernelGGL((cp_attn_o_kernel<false, false>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(P));
     }
     QTTS_CHECK_HIP(hipGetLastError());
 }
