@@ -11,6 +11,7 @@
 //   KV cache  paged, 16 tokens per page: pool[layer][page][kv_head][16][128] (fp32 or bf16), page table per
 //             sequence reserved at create for max_seq tokens (no growth inside the captured step)
 //   state     residual stream / qkv / mlp activations fp32 [rows <= 64][dim]; rows = t*B + b
+#include <atomic>
 #include <map>
 #include <algorithm>
 #include "common.h"
@@ -434,7 +435,17 @@ struct qtts_talker {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
         if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
     }
-    ~qtts_talker() { destroy_graph(); release_events(); }
+    ~qtts_talker() {
+        destroy_graph(); release_events();
+        if (cp_fused_slot) fused_engines().fetch_sub(1);
+    }
+    // The fused code-predictor launch keeps 256 workgroups of 4 waves resident, every one of which may wait for six others: two such
+    // launches (two engines feeding one GPU, bench.py --workload clone-shard) fit beside each other on 256 CUs with room to spare
+    // (163 VGPRs: three workgroups per CU), four would not -- and partially resident launches that wait for their missing workgroups
+    // would hold each other's slots until the consumers give up.  So at most two engines of a process take the fused launch; a third
+    // keeps the separate launches (no performance claim is made for more than two engines per GPU at batch <= 8).
+    static std::atomic<int>& fused_engines() { static std::atomic<int> n{0}; return n; }
+    bool cp_fused_slot = false;
 };
 
 void qtts_talker::finalize() {
@@ -448,6 +459,10 @@ void qtts_talker::finalize() {
     QTTS_REQUIRE(c.max_batch >= 1 && c.max_batch <= 32, QTTS_ERR_LIMIT, "max_batch must be 1..32");
     QTTS_REQUIRE(td.I % 16 == 0 && cd.I % 16 == 0, QTTS_ERR_ARG, "intermediate sizes % 16");
     const int G = c.num_code_groups;
+    if (bf16 && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0) {
+        if (fused_engines().fetch_add(1) < 2) cp_fused_slot = true;
+        else { fused_engines().fetch_sub(1); cp_attn_o_env = false; }
+    } else cp_attn_o_env = false;
     tl.resize(c.num_hidden_layers);
     for (int l = 0; l < c.num_hidden_layers; ++l) build_layer(tl[l], "model.layers." + std::to_string(l) + ".", td, true);
     cl.resize(c.cp_num_hidden_layers);

@@ -1661,6 +1661,38 @@ def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeyp
     assert np.abs(fused[1][:, :k] - plain[1][:, :k]).max() <= 2e-2 * max(1.0, float(np.abs(plain[1][:, :k]).max()))
 
 
+def test_at_most_two_engines_of_a_process_take_the_fused_code_predictor_launch(emu, monkeypatch):
+    """The fused code-predictor launch keeps 256 workgroups resident that wait for each other; two such launches fit on the chip side by
+    side, four would not.  The engine therefore hands out two process-wide slots: a third bf16 engine alive at the same time keeps the
+    separate launches (more kernel nodes in its captured frame step), and a slot comes back when its engine is destroyed."""
+    import dataclasses
+    monkeypatch.delenv("QTTS_CP_ATTN_O", raising=False)
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=256, cp_intermediate_size=256, cp_num_hidden_layers=2,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(29), t, [4, 3], 2, scale=0.5)
+    args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
+    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+
+    def nodes(h):
+        _talker_generate(emu, h, t, *args, max_new=3)
+        st = _lib.TalkerStatsC()
+        _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+        return int(st.graph_nodes)
+
+    hs = [_talker_emu(emu, t, w, max_batch=2, max_seq=32, dtype=_lib.QTTS_BF16, use_graph=1) for _ in range(3)]
+    try:
+        n = [nodes(h) for h in hs]
+        fused_less = (t.num_code_groups - 2) * t.cp_num_hidden_layers
+        assert n[0] == n[1] and n[2] - n[0] == fused_less, n
+        emu.qtts_talker_destroy(hs.pop(0))
+        hs.append(_talker_emu(emu, t, w, max_batch=2, max_seq=32, dtype=_lib.QTTS_BF16, use_graph=1))
+        assert nodes(hs[-1]) == n[0], "the slot of a destroyed engine was not handed out again"
+    finally:
+        for h in hs:
+            emu.qtts_talker_destroy(h)
+
+
 def test_talker_orchestration_no_projection_vs_oracle(emu):
     """The 0.6B models' shape of the code predictor: talker hidden == predictor hidden, so small_to_mtp_projection is the
     identity (M:1171-1174) and the pass input row is the codec embedding itself.  Greedy fp32 against the oracle, then the bf16
