@@ -1636,7 +1636,7 @@ def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeyp
     try:
         for mode in ("1", "0"):
             monkeypatch.setenv("QTTS_CP_ATTN_O", mode)
-            for use_graph in (0, 1):
+            for use_graph in ((0, 1) if cp_hidden == 256 else (1,)):     # (eager == graph: the 256-wide case; the 1024-wide one is 4x the emulation time)
                 h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=use_graph)
                 try:
                     codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=5)
@@ -1650,7 +1650,8 @@ def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeyp
     finally:
         emu.hostemu_set_real_gemm(1 if FULL else 0)
     for mode in ("1", "0"):                                          # eager == graph, as for every other path of the engine
-        assert np.array_equal(res[(mode, 0)][0], res[(mode, 1)][0]) and np.array_equal(res[(mode, 0)][1], res[(mode, 1)][1]), mode
+        if (mode, 0) in res:
+            assert np.array_equal(res[(mode, 0)][0], res[(mode, 1)][0]) and np.array_equal(res[(mode, 0)][1], res[(mode, 1)][1]), mode
     fused, plain = res[("1", 1)], res[("0", 1)]
     assert plain[2] - fused[2] == (t.num_code_groups - 2) * t.cp_num_hidden_layers, (plain[2], fused[2])
     n = min(fused[0].shape[1], plain[0].shape[1])
