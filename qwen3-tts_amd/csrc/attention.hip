@@ -1793,7 +1793,7 @@ void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
 #ifdef QTTS_HOST_EMU
         // The emulator runs the workgroups of a launch one after the other; here every workgroup first produces and then waits for
         // other workgroups' strips, so the emulated launch runs as its two halves (the same code, both launches read the same tag).
-        for (int ph = 0; ph < 2; ++ph) {
+        for (int ph = P.phase == 1 ? 1 : 0; ph < 2; ++ph) {     // (phase == 1 given: the consuming half alone -- the stale-granule test)
             Q.phase = ph;
 #else
         {

@@ -3,6 +3,7 @@
 // SIMT emulator without an engine around them.  Not part of the product ABI (include/qtts.h).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "common.h"
 #include "kernels.h"
@@ -264,6 +265,24 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
                 qtts::launch_cp_attn_o(f, nullptr);
                 if (err) return -4;
             }
+            // the consuming half ALONE on the buffers the launches above filled: under the same (serial, slot) it finds every granule; under
+            // another slot or another serial every granule is a stale one -- the consumers must give up and say so, not take them
+            std::vector<float> keep(out, out + (size_t)B * H);
+            std::vector<unsigned short> keep16(out16, out16 + (size_t)B * H);
+            for (int variant = 0; variant < 3; ++variant) {
+                for (int i = 0; i < B * H; ++i) out[i] = res[i];
+                qtts::CpAttnOParams c2 = f;
+                c2.phase = 1;
+                if (variant == 1) c2.slot = f.slot + 1;
+                int serial2 = serial + 1;
+                if (variant == 2) c2.serial = &serial2;
+                err = 0;
+                qtts::launch_cp_attn_o(c2, nullptr);
+                if ((variant == 0) != (err == 0)) return -5 - variant;
+                if (variant == 0 && memcmp(out, keep.data(), keep.size() * 4) != 0) return -8;
+            }
+            memcpy(out, keep.data(), keep.size() * 4);
+            memcpy(out16, keep16.data(), keep16.size() * 2);
             return 0;
         }
         qtts::SkinnyParams q{};

@@ -785,7 +785,10 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
     and goes on as the attention + o-projection launch.  Real source, real dimensions (hidden 1024, 16 / 8 heads of 128), against the
     three launches it replaces (decode GEMM, attn_cp, decode GEMM: agreement to fp32 summation order of the two GEMMs + the bf16
     rounding of K / V / the attention output that a last-bit difference in q|k|v can flip) and against float64 numpy; batch 8 / 3,
-    contiguous and permuted page tables, three fiber orders, two launches per call on the same granule buffers from two epochs."""
+    contiguous and permuted page tables, three fiber orders, two launches per call on the same granule buffers under two serials.  The
+    entry point then runs the CONSUMING half alone on those buffers: with the launch's own (serial, slot) it finds every granule and
+    reproduces the result bit for bit; with another slot or another serial every granule is stale and the consumers give up and raise
+    the error flag instead of taking them (what `generate` turns into QTTS_ERR_STATE)."""
     g = np.random.default_rng(505)
     HD, nh, nkv, H, eps, eps_in = 128, 16, 8, 1024, 1e-6, 1e-6
     qd, ld = nh * HD, (nh + 2 * nkv) * HD
