@@ -720,6 +720,7 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     plain_gold = float((res["0"][0][:, :40, 1:] == g["codes"][:, :40, 1:]).mean())
     print(f"cp_attn_o vs attn_cp + decode GEMM (0.6B, 8 x 40 frames, teacher-forced): sub-codebooks agree {agree:.4f}; against the fp32 golden: "
           f"fused {agree_gold:.4f}, two launches {plain_gold:.4f}")
+    assert not np.array_equal(f[0], res["0"][0]), "QTTS_CP_ATTN_O=1 did not select the fused launch (no slot left? see talker_engine.hip: fused_engines)"
     assert agree >= 0.85 and agree_gold >= plain_gold - 0.03
     # a batch that does not fill the row pairs (3 sequences: the second pair has one, the last two have none), teacher-forced like the
     # first part (free-running greedy is no measure here: on these seeded random weights one rounding-level flip in frame 0 changes every
