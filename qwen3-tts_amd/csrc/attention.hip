@@ -1398,25 +1398,35 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
 }
 
 // =================================================================================== cp_attn_o (round 4)
-// The code predictor's passes >= 1: attention AND the o-projection in one launch (70 launch pairs per frame).  As two launches the pair
-// costs ~8.5 us on the in-kernel clock (attn_cp 2.4 + boundary 1.7 + the 4 MB o-projection 2.7 + boundary 1.7); the attention output is
-// the o-projection's k dimension, head by head, so the GEMM is split over k BY KV HEAD:
-//   workgroup (row pair, kv head g, 128-feature chunk c), 4 waves = 256 workgroups at batch 8: one wave per SIMD of the chip.  Wave
-//     (sequence, query head hh of the kv head) runs that head's attention -- the arithmetic of attn_cp, statement for statement (q / k
-//     RMSNorm + RoPE at the static position, K / V rounded through the cache type, 16 key slots, fp32 softmax, PV) -- out of a
-//     wave-private LDS slice; only chunk 0 appends K / V.  The eight chunk workgroups of a (row pair, kv head) repeat that attention (a
-//     few KB of reads each) instead of exchanging it: the attention stage is ~400 VALU instructions per (sequence, head), so the
-//     repeats must not share a SIMD (second version, 16 waves per workgroup on 64 CUs: 2.3 us of VALU queueing behind the barrier).
-//     Its 2 x 256 bf16 result is the B operand (two columns of the MFMA tile) of 16 MFMAs per wave against this workgroup's 128 x 256
-//     block of Wo (wave = two 16-feature strips, requested at kernel entry: they stream while the attention runs);
-//   hand-off WITHOUT a ticket: every value leaves as an 8-byte granule {fp32 value, launch tag} in one write-through (sc1) store -- the
-//     tag is (frame serial << 7 | launch slot), different from that of every launch that wrote the buffer shortly before.  The
-//     workgroup of the LAST kv head is the reducer of its (row pair, chunk): it keeps its own partial sum in LDS, reads the other seven
-//     slabs with sc1 loads until every granule carries the tag, adds the eight partial sums in kv-head order + the residual, writes
-//     the hidden state (fp32 + bf16 copy).  A fixed summation order, so the result does not depend on timing.
-//     (First version, profiles/r04_cp_attn_o.md: partial sums + drained stores + an arrival ticket + last-arriver reduction = 3.2 us
-//     of hand-off inside a 6.7-us kernel: no gain over the two launches.  Guide: data-tagged granules.)
-//   The reducer polls; it cannot hang the device: after SPIN_LIMIT re-reads it gives up, raises `err` and writes what it has.
+// The code predictor's passes >= 1: a layer's q|k|v GEMM (template QKV; layers >= 1 -- layer 0's row comes from the table), attention AND
+// o-projection in one launch (70 launches per frame, 56 of them with the GEMM in front).  As separate launches they cost, on the in-kernel
+// clock, q|k|v 2.7 + attn_cp 2.4 + the 4 MB o-projection 2.7 us and a 1.7-us boundary each = 13.0 us; here ~7.6 + 1.6 us
+// (profiles/r04_cp_attn_o.md: eight builds, what each timeline said).  The attention output is the o-projection's k dimension, head by
+// head, so the GEMM is split over k BY KV HEAD and every edge between workgroups is narrow:
+//   workgroup (row pair, kv head g, 128-feature chunk c), 4 waves = 256 workgroups at batch 8: one wave per SIMD of the chip.
+//   QKV front: the workgroup first computes 16-feature strip `blockIdx` of q|k|v = rsqrt(mean x^2 + eps) W' x (RMSNorm weight folded into W';
+//     each wave a quarter of k: 8 MFMAs, the row variances from the same bf16 x fragments; quarters added in wave order) and stores it as
+//     tagged granules.  Then wave (sequence, query head hh of the kv head) reads its q / k / v rows back -- parts of six other workgroups'
+//     strips -- and
+//   attention: runs that head's attention -- the arithmetic of attn_cp, statement for statement (q / k RMSNorm + RoPE at the static
+//     position, K / V rounded through the cache type, 16 key slots, fp32 softmax, PV) -- out of a wave-private LDS slice; only chunk 0
+//     appends K / V.  The eight chunk workgroups of a (row pair, kv head) repeat that attention (a few KB of reads each) instead of
+//     exchanging it: the attention stage is ~400 VALU instructions per (sequence, head), so the repeats must not share a SIMD (second
+//     build, 16 waves per workgroup on 64 CUs: 2.3 us of VALU queueing behind the barrier).
+//   o-projection: the 2 x 256 bf16 result is the B operand (two columns of the MFMA tile) of 16 MFMAs per wave against this workgroup's
+//     128 x 256 block of Wo (wave = two 16-feature strips; requested at kernel entry, or behind the strip's store with the front: they
+//     stream while the workgroup waits and attends); the partial sums leave as tagged granules; the workgroup of the LAST kv head is the
+//     reducer of its (row pair, chunk): its own partial sum stays in LDS, it reads the other seven slabs, adds the eight in kv-head order
+//     + the residual and writes the hidden state (fp32 + bf16 copy).  Fixed summation orders: the result does not depend on timing.
+//   hand-off WITHOUT a ticket or a fence: every value is an 8-byte granule {fp32 value, launch tag}, stored write-through (sc1), read with
+//     sc1 loads until it carries the tag.  Tag = (frame serial << 7 | launch slot): nobody in the launch writes the word it derives from,
+//     and no launch that wrote the buffers shortly before had the same pair.  A consumer waits ~0.4 us before its first read (a read
+//     issued at once comes back stale and costs a round trip: third build) and keeps TWO reads in flight ~0.1 us apart (the producers
+//     do not store at the same instant: with single reads the frame time moved 5 % with the delay).  (First build: partial sums +
+//     drained stores + an arrival ticket + last-arriver reduction = 3.2 us of hand-off: what a boundary costs.)
+//   A consumer cannot hang the device: after SPIN_LIMIT re-reads it gives up, raises `err` and writes what it has.  All 256 workgroups
+//   are resident from the start and producers never wait, so there is no circular wait inside a launch; across concurrent launches see
+//   talker_engine.hip (two engines per process take this kernel).
 // bf16 cache, two query heads per kv head, head_dim 128, batch <= 8 only; everything else keeps attn_cp + the decode GEMM.
 namespace {
 typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
@@ -1426,7 +1436,6 @@ __device__ inline WtBuf wt_buf(void* p, size_t) { return WtBuf{static_cast<unsig
 __device__ inline void wt_store16(const WtBuf& b, int off, cu32x4 v) { *reinterpret_cast<cu32x4*>(b.base + off) = v; }
 __device__ inline cu32x4 wt_load16(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
 __device__ inline uint2 wt_load8(const WtBuf& b, int off) { return *reinterpret_cast<const uint2*>(b.base + off); }
-__device__ inline void wt_pause() {}
 __device__ inline void wt_first_pause(int) {}
 constexpr int CPAO_SPIN_LIMIT = 2;                      // (workgroups run one after the other here: a second read never helps)
 #else
@@ -1441,8 +1450,7 @@ __device__ __forceinline__ uint2 wt_load8(const WtBuf& b, int off) {
     uint2 r; r.x = v[0]; r.y = v[1];
     return r;
 }
-__device__ __forceinline__ void wt_pause() { __builtin_amdgcn_s_sleep(2); }
-__device__ __forceinline__ void wt_first_pause(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // n x 64 clocks (20 ~ 0.5 us)
+__device__ __forceinline__ void wt_first_pause(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // n x 64 clocks (16 ~ 0.4 us)
 constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a producer that never stores is a bug, not a wait
 #endif
 }  // namespace
