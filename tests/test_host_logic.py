@@ -1012,3 +1012,41 @@ def test_audio_containers_other_than_wave_go_to_soundfile_when_present(monkeypat
     n_before = len(seen)
     x, sr3 = audio_io.read_audio_bytes(wav)
     assert len(seen) == n_before and sr3 == 8000 and np.allclose(x, [0.0, 0.5, -1.0])
+
+
+def test_pmc_traffic_tool_reduces_two_rocprofv3_passes_and_stamps_the_sources(tmp_path):
+    """tools/pmc_traffic.py (what `bench.py`'s `roofline.traffic`, `frac_rocprof` and `fused_cp_launch` are read from): given a rocprofv3
+    `--pmc FETCH_SIZE` database and a kernel-trace database it (1) reconstructs (N, K) of every `skinny8_kernel` dispatch from the
+    instantiation and the grid, sums FETCH_SIZE x 1024 x 2 bytes against N x K x 2, (2) takes the launch-weighted duration of the same
+    classes from the trace, (3) keeps the code predictor's fused launches apart (with / without the q|k|v front), and (4) stamps the JSON
+    with the digest of csrc/skinny.hip + csrc/talker_engine.hip that `bench.py` compares before it uses the numbers."""
+    import json, sqlite3, subprocess
+    fetch_db, trace_db, out = str(tmp_path / "pmc.db"), str(tmp_path / "trace.db"), str(tmp_path / "pmc_traffic.json")
+    sk = "void qtts::skinny8_kernel<1, 16, 4, true, 4>(void const*, float const*)"      # FS 16, NP 4, NW 4 -> K = 1024; 256 workgroups -> N = 4096
+    fr = "void qtts::cp_attn_o_kernel<true, true>(qtts::CpAttnOParams)"
+    ao = "void qtts::cp_attn_o_kernel<true, false>(qtts::CpAttnOParams)"
+    con = sqlite3.connect(fetch_db)
+    con.execute("create table counters_collection (kernel_name text, counter_name text, value real, grid_size_x int, workgroup_size_x int)")
+    alg = 4096 * 1024 * 2
+    rows = [(sk, "FETCH_SIZE", 1.05 * alg / 2048.0, 256 * 256, 256)] * 4 + [(sk, "OTHER", 1e9, 256 * 256, 256)]
+    rows += [(fr, "FETCH_SIZE", 17.0e6 / 2048.0, 256 * 256, 256)] * 2 + [(ao, "FETCH_SIZE", 8.0e6 / 2048.0, 256 * 256, 256)]
+    con.executemany("insert into counters_collection values (?, ?, ?, ?, ?)", rows); con.commit(); con.close()
+    con = sqlite3.connect(trace_db)
+    con.execute("create table kernels (name text, start int, end int, grid_size_x int, workgroup_size_x int)")
+    con.executemany("insert into kernels values (?, ?, ?, ?, ?)",
+                    [(sk, 0, 5000, 256 * 256, 256), (sk, 10000, 16000, 256 * 256, 256), (fr, 20000, 28000, 256 * 256, 256), (ao, 30000, 36000, 256 * 256, 256)])
+    con.commit(); con.close()
+    tool = os.path.join(ROOT, "tools", "pmc_traffic.py")
+    r = subprocess.run([sys.executable, tool, "--fetch-db", fetch_db, "--trace-db", trace_db, "--source", "unit test", "--out", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.load(open(out))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    assert d["kernel_digest"] == pmc_traffic.kernel_digest() and len(d["kernel_digest"]) == 16
+    rec = d["1.7b"]
+    assert rec["dispatches"] == 4 and abs(rec["ratio_traffic_over_algorithmic"] - 1.05) < 1e-3 and rec["algorithmic_bytes_per_launch_skinny8"] == alg
+    assert rec["rocprof_launches"] == 2 and abs(rec["rocprof_avg_launch_us"] - 5.5) < 1e-6
+    assert abs(rec["frac_rocprof"] - alg / 5.5e-6 / 1e9 / 8000.0) < 1e-3
+    assert rec["fused"]["front"] == {"dispatches": 2, "fetch_bytes_per_launch": 17000000, "rocprof_launches": 1, "rocprof_avg_launch_us": 8.0}
+    assert rec["fused"]["attn_o"] == {"dispatches": 1, "fetch_bytes_per_launch": 8000000, "rocprof_launches": 1, "rocprof_avg_launch_us": 6.0}
