@@ -473,6 +473,29 @@ def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
     return res
 
 
+def fused_cp_report(c, fused_rec, elem_bytes=2):
+    """`roofline.fused_cp_launch`.  Round 4: in passes >= 1 of the code predictor the q|k|v GEMM, the attention and the o-projection run as ONE
+    launch (attention.hip: cp_attn_o_kernel) -- weight bytes that left the decode GEMM's launches and are reported beside them.  Not timed by
+    the per-launch events of `roofline_leg`: durations and FETCH_SIZE bytes come from the stamped rocprofv3 passes (`fused_rec` = the "fused"
+    section of profiles/pmc_traffic.json), algorithmic bytes = the two operators of a layer (`front`) or the o-projection alone (`attn_o`:
+    layer 0, whose q|k|v row comes from the table)."""
+    qd, kvd, H = c.cp_num_attention_heads * c.cp_head_dim, c.cp_num_key_value_heads * c.cp_head_dim, c.cp_hidden_size
+    G, L = c.num_code_groups, c.cp_num_hidden_layers
+    alg = {"front": ((qd + 2 * kvd) * H + H * qd) * elem_bytes, "attn_o": H * qd * elem_bytes}
+    per_frame = {"front": (G - 2) * (L - 1), "attn_o": G - 2}
+    fl = {}
+    for k, f in fused_rec.items():
+        if k in alg and isinstance(f, dict) and f.get("rocprof_avg_launch_us"):
+            fl[k] = {"launches_per_frame": per_frame[k], "algorithmic_bytes_per_launch": alg[k], "rocprof_avg_launch_us": f["rocprof_avg_launch_us"],
+                     "frac_rocprof": round(alg[k] / (f["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": f.get("fetch_bytes_per_launch")}
+    if fl:
+        fl["weight_bytes_per_frame"] = sum(v["launches_per_frame"] * v["algorithmic_bytes_per_launch"] for v in fl.values())
+        fl["kernel"] = ("cp_attn_o_kernel (front: q|k|v GEMM + attention + o-projection of a code-predictor layer in one launch; attn_o: layer 0, "
+                        "whose q|k|v row comes from the table)")
+    return fl
+
+
 def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_bytes=2,
                  kernel="skinny8_kernel (weight-streaming decode GEMM, batch <= 8 instantiations)"):
     """Live measurement of the dominant kernel IN THE REAL FRAME STEP (round 3): the engine runs 8 real frames eagerly and times
@@ -541,23 +564,8 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
                 out["rocprof_avg_launch_us"] = rec["rocprof_avg_launch_us"]
                 out["frac_live_over_rocprof"] = round(out["frac"] / rec["frac_rocprof"], 4)
             if "fused" in rec and out["weight_bytes_per_frame_timed"] < wbytes:
-                # Round 4: in passes >= 1 of the code predictor the q|k|v GEMM, the attention and the o-projection run as ONE launch
-                # (attention.hip: cp_attn_o_kernel) -- weight bytes that left the decode GEMM's launches.  Not timed by the per-launch events
-                # above: durations and FETCH_SIZE bytes from the same stamped rocprofv3 passes, algorithmic bytes = the two operators.
-                c = talker.config
-                qd, kvd, H = c.cp_num_attention_heads * c.cp_head_dim, c.cp_num_key_value_heads * c.cp_head_dim, c.cp_hidden_size
-                G, L = c.num_code_groups, c.cp_num_hidden_layers
-                alg = {"front": ((qd + 2 * kvd) * H + H * qd) * elem_bytes, "attn_o": H * qd * elem_bytes}
-                per_frame = {"front": (G - 2) * (L - 1), "attn_o": G - 2}
-                fl = {}
-                for k, f in rec["fused"].items():
-                    if k in alg and f.get("rocprof_avg_launch_us"):
-                        fl[k] = {"launches_per_frame": per_frame[k], "algorithmic_bytes_per_launch": alg[k], "rocprof_avg_launch_us": f["rocprof_avg_launch_us"],
-                                 "frac_rocprof": round(alg[k] / (f["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                 "traffic": f.get("fetch_bytes_per_launch")}
+                fl = fused_cp_report(talker.config, rec["fused"], elem_bytes)
                 if fl:
-                    fl["kernel"] = "cp_attn_o_kernel (front: q|k|v GEMM + attention + o-projection of a code-predictor layer in one launch; attn_o: layer 0, whose q|k|v row comes from the table)"
-                    fl["weight_bytes_per_frame"] = sum(v["launches_per_frame"] * v["algorithmic_bytes_per_launch"] for v in fl.values() if isinstance(v, dict))
                     out["fused_cp_launch"] = fl
     except Exception as e:
         traffic_src = f"unavailable ({type(e).__name__}: {e})"

@@ -1050,3 +1050,24 @@ def test_pmc_traffic_tool_reduces_two_rocprofv3_passes_and_stamps_the_sources(tm
     assert abs(rec["frac_rocprof"] - alg / 5.5e-6 / 1e9 / 8000.0) < 1e-3
     assert rec["fused"]["front"] == {"dispatches": 2, "fetch_bytes_per_launch": 17000000, "rocprof_launches": 1, "rocprof_avg_launch_us": 8.0}
     assert rec["fused"]["attn_o"] == {"dispatches": 1, "fetch_bytes_per_launch": 8000000, "rocprof_launches": 1, "rocprof_avg_launch_us": 6.0}
+
+
+def test_bench_fused_launch_report_accounts_for_the_bytes_that_left_the_decode_gemm():
+    """`bench.fused_cp_report` (the `roofline.fused_cp_launch` object): at the 1.7B model's code-predictor dims, 14 passes x 4 layers take the
+    launch with the q|k|v front (12.58 MB of operators each) and 14 x 1 the attention + o-projection launch (4.19 MB): 763 363 328 bytes per
+    frame -- exactly what the GPU bench's `weight_bytes_per_frame_timed` is short of `weight_bytes_per_frame_model` (profiles/r04_bench_n1.json)."""
+    import bench
+    from qwen3_tts_amd.config import TalkerConfig
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    c = TalkerConfig.from_any(synth.cfg_dict(synth.talker_17b()))
+    rec = {"front": {"rocprof_avg_launch_us": 8.475, "fetch_bytes_per_launch": 17972871}, "attn_o": {"rocprof_avg_launch_us": 6.229, "fetch_bytes_per_launch": 8135703},
+           "_note": "ignored"}
+    r = bench.fused_cp_report(c, rec)
+    assert r["front"]["launches_per_frame"] == 56 and r["front"]["algorithmic_bytes_per_launch"] == 12582912
+    assert r["attn_o"]["launches_per_frame"] == 14 and r["attn_o"]["algorithmic_bytes_per_launch"] == 4194304
+    assert r["weight_bytes_per_frame"] == 763363328
+    assert abs(r["front"]["frac_rocprof"] - 12582912 / 8.475e-6 / 1e9 / 8000.0) < 1e-3 and r["front"]["traffic"] == 17972871
+    line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))["roofline"]
+    assert line["weight_bytes_per_frame_model"] - line["weight_bytes_per_frame_timed"] == r["weight_bytes_per_frame"]
+    assert bench.fused_cp_report(c, {}) == {}
