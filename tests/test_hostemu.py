@@ -1642,9 +1642,10 @@ def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeyp
             for use_graph in ((0, 1) if cp_hidden == 256 else (1,)):     # (eager == graph: the 256-wide case; the 1024-wide one is 4x the emulation time)
                 h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=use_graph)
                 try:
-                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=5)
-                    codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=5)
-                    assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2), (mode, use_graph)
+                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=4)
+                    if mode == "1":                                  # (granule buffers re-used, serial advanced)
+                        codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=4)
+                        assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2), (mode, use_graph)
                     st = _lib.TalkerStatsC()
                     _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
                     res[(mode, use_graph)] = (codes, hidden, int(st.graph_nodes))
