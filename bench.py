@@ -97,6 +97,8 @@ def main(argv=None, device=None):
                     help="torch.distributed backend of the N > 1 job (nccl = RCCL; gloo only for the CPU launcher test)")
     ap.add_argument("--no-parity-mode", action="store_true",
                     help="skip the fp32 parity-mode timing leg (fp32 talker frame step + fp32 codec decode, N = 1 only)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the configs leg (BASELINE configs 2-5 on the line: codec-only, 0.6B b8, first packet b32, clone-shard at N = 1; N = 1 only)")
     ap.add_argument("--no-api-e2e", action="store_true",
                     help="skip the api_e2e leg (Qwen3TTSModel.generate_custom_voice: text -> host numpy, N = 1 only)")
     ap.add_argument("--workload", default="metric", choices=["metric", "clone-shard"],
@@ -152,6 +154,7 @@ def main(argv=None, device=None):
     if args.workload == "clone-shard":
         res = clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist)
         if rank == 0:
+            res["frame_steps_in_job"] = sum(res.pop("_wave_frames"))
             if hostemu:
                 res["INVALID"] = f"run by a test wrapper on device {device!r}: launcher test only, not a measurement"
             print(json.dumps(res), flush=True)
@@ -308,9 +311,23 @@ def main(argv=None, device=None):
         if not args.no_parity_mode and world == 1 and not hostemu:
             res["parity_mode"] = parity_mode_leg(args, tcfg, ccfg, tw_np, cw_np, lens, dev, emb, mask, trailing, pad, gen_kw, None)
             log("parity-mode leg done")
-        if not args.no_api_e2e and world == 1:
-            del talker, codec                 # (the leg builds its own engines behind the API; free the bench's first)
+        if (not args.no_api_e2e or not args.no_configs) and world == 1:
+            del talker, codec                 # (the legs below build their own engines; free the bench's first)
             torch.cuda.empty_cache()
+        if not args.no_configs and world == 1 and args.model in ("1.7b", "tiny"):
+            try:                              # (an extra leg must never cost the run its metric line)
+                res["configs"] = configs_leg(args, tcfg, ccfg, tw_np, cw_np, dev)
+            except Exception as e:            # noqa: BLE001
+                res["configs"] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+            log("configs leg done")
+        if not args.no_configs and world == 1 and args.model in ("1.7b", "tiny"):
+            try:
+                res["voice_clone_prompt"] = voice_clone_prompt_leg(args, tcfg, dev)
+            except Exception as e:            # noqa: BLE001
+                res["voice_clone_prompt"] = {"error": f"{type(e).__name__}: {e}"}
+            log("voice_clone_prompt leg done")
+        if not args.no_api_e2e and world == 1:
             res["api_e2e"] = api_e2e_leg(args, tcfg, ccfg, cw_np, dev, res["ms_per_step"])
             log("api_e2e leg done")
         if not args.no_cpu_baseline and world == 1:
@@ -328,7 +345,7 @@ def main(argv=None, device=None):
         dist.destroy_process_group()
 
 
-def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
+def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist, weights=None, keep=None):
     """BASELINE config 5 under the bench launcher, STRONG scaling: a fixed job of `--requests` voice-clone (ICL-shaped: 38
     reference frames + 16 ref-text rows in the prompt) requests of different lengths, dealt longest-first to the (rank, engine)
     bins (`sharding.engine_partition`, every rank computes the same partition), each engine running waves of `--batch` requests of
@@ -357,11 +374,14 @@ def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
     td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
     tdt = torch.bfloat16 if args.talker_dtype == "bf16" else torch.float32
     cdt = torch.bfloat16 if args.codec_dtype == "bf16" else torch.float32
-    tw, cw = td(synth.talker_weights(tcfg, with_text=False)), td(synth.codec_weights(ccfg))
+    # (`weights` = (talker, codec) numpy dicts a caller already holds -- the `configs` leg of the metric run; `keep`: a dict that receives the engines)
+    tw, cw = (td(weights[0]), td(weights[1])) if weights is not None else (td(synth.talker_weights(tcfg, with_text=False)), td(synth.codec_weights(ccfg)))
     talkers = [TalkerEngine(tcfg, tw, weight_dtype=tdt, device=dev, max_batch=B, max_seq=12 + REF + 16 + 8 + Fmax + 8,
                             use_graph=not args.no_graph) for _ in range(E)]
     codecs = [CodecDecoderEngine(ccfg, cw, compute_dtype=cdt, device=dev, max_batch=B, max_frames=min(Fmax, 300) + 25) for _ in range(E)]
     del tw, cw
+    if keep is not None:
+        keep.update(talkers=talkers, codecs=codecs, frames=frames)
     sup = [i for i in range(tcfg.vocab_size - 1024, tcfg.vocab_size) if i != tcfg.codec_eos_token_id]
     base = dict(suppress_tokens=sup, repetition_penalty=1.05, output_hidden_states=False, do_sample=True, top_k=50, top_p=1.0,
                 temperature=0.9, subtalker_dosample=True, subtalker_top_k=50, subtalker_top_p=1.0, subtalker_temperature=0.9)
@@ -464,13 +484,229 @@ def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist):
            "requests_by_rank": [sum(len(pe) for pe in pr) for pr in parts],
            "rank_load_imbalance": round(max(sum(text[i] for pe in pr for i in pe) for pr in parts) / (sum(text) / world), 3),
            "engine_load_imbalance": round(max(load) / (sum(text) / (world * E)), 3),
-           "padding_waste": round(1.0 - sum(frames) / sum(max(frames[i] for i in w) * len(w) for w in all_waves), 3)}
+           "padding_waste": round(1.0 - sum(frames) / sum(max(frames[i] for i in w) * len(w) for w in all_waves), 3),
+           "_wave_frames": [max(frames[i] for i in w) * args.steps for w in all_waves]}
     if per_rank is not None:
         res["backend"] = args.backend
         res["ranks_seen"] = [int(r[0]) for r in per_rank]
         res["ms_per_step_by_rank"] = [round(1e3 * r[1] / args.steps, 2) for r in per_rank]
         res["gather_ms_per_step_by_rank"] = [round(1e3 * r[2] / args.steps, 3) for r in per_rank]
     return res
+
+
+def configs_leg(args, tcfg, ccfg, tw_np, cw_np, dev):
+    """BASELINE.json's OTHER configurations on the driver's line, outside the timed region, N = 1 only:
+      config2  Tokenizer-12Hz decode-only, 10 s of random codes -> waveform, batch 1: ms + fraction of the MFMA peak (5.12 GFLOP per
+               frame, SURVEY 8d), in bf16 (the serving mode) and fp32 (the mode that meets RMS <= 1e-4);
+      config3  0.6B dims, batch 8, 125 frames: the metric step at the small model (prefill + AR decode + codec decode);
+      config4  1.7B dims, batch 32, streaming text input: first packet = call -> 4 frames of PCM on the host, p50 / p99 over 10 trials;
+      config5  the 256-request voice-clone job at N = 1 (2 engines x waves of 32; `--workload clone-shard` runs it at N > 1).
+    Synthetic seeded weights and prompts as everywhere; every sub-object names its roofline denominator."""
+    import argparse as _ap
+    import numpy as np
+    import torch
+    import synth
+    from qwen3_tts_amd.codec import CodecDecoderEngine
+    from qwen3_tts_amd.talker import TalkerEngine
+    td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
+    out = {}
+    t_leg = time.perf_counter()
+    small = args.model == "tiny"            # (tests/hostemu/bench_emu.py: the same leg at test dims on the emulator)
+    # ---- config 2
+    F = 3 if small else 125
+    c2 = {"workload": "Qwen3-TTS-Tokenizer-12Hz decode-only, 125 frames (10 s) of random codes -> 24 kHz waveform, batch 1", "runs": []}
+    rng = np.random.default_rng(2)
+    for dt, peak, name in ((torch.bfloat16, 2500.0, "bf16"), (torch.float32, 157.3, "f32")):
+        if small and name == "bf16":
+            continue                         # (the emulator's bf16 matrix path is slow; the leg's plumbing does not depend on the dtype)
+        eng = CodecDecoderEngine(ccfg, td(cw_np), compute_dtype=dt, device=dev, max_batch=1, max_frames=F + 25)
+        codes = torch.from_numpy(rng.integers(0, ccfg.codebook_size, (1, F, ccfg.num_quantizers))).to(dev)
+        for _ in range(1 if small else 3):
+            wav, wl = eng.decode_padded(codes)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(1 if small else 10):
+            t0 = time.perf_counter()
+            wav, wl = eng.decode_padded(codes)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        assert bool(torch.isfinite(wav).all()) and int(wl[0]) == F * ccfg.total_upsample
+        ms = 1e3 * float(np.median(ts))
+        tf = 5.12 * F / ms
+        c2["runs"].append({"dtype": name, "ms_p50": round(ms, 3), "ms_min": round(1e3 * min(ts), 3), "tflops": round(tf, 1),
+                           "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
+                           "rtf_x": round(F * 0.08 / (ms * 1e-3), 1)})
+        del eng
+    out["config2_codec_only"] = c2
+    log(f"configs: config 2 done (+{time.perf_counter() - t_leg:.1f}s)")
+    # ---- config 3
+    t6 = tcfg if small else synth.talker_06b()
+    B = 2 if small else 8
+    lens = [24 + 4 * (i % 8) + 12 for i in range(B)] if not small else [5, 7]
+    sdt = torch.float32 if small else torch.bfloat16
+    tk = TalkerEngine(t6, td(synth.talker_weights(t6, with_text=False)), weight_dtype=sdt, device=dev, max_batch=B, max_seq=max(lens) + F + 8,
+                      use_graph=not args.no_graph)
+    cd = CodecDecoderEngine(ccfg, td(cw_np), compute_dtype=sdt, device=dev, max_batch=B, max_frames=F + 25)
+    emb, mask, trailing, pad = [x.to(dev) for x in synth_prompt(np.random.default_rng(100), t6, lens, 1)]
+    sup = [i for i in range(t6.vocab_size - 1024, t6.vocab_size) if i != t6.codec_eos_token_id]
+    kw = dict(max_new_tokens=F + 1, min_new_tokens=F + 1, suppress_tokens=sup, repetition_penalty=1.05, output_hidden_states=False, do_sample=True,
+              top_k=50, top_p=1.0, temperature=0.9, subtalker_dosample=True, subtalker_top_k=50, subtalker_top_p=1.0, subtalker_temperature=0.9)
+
+    def step6(seed):
+        o = tk.generate(emb, mask, trailing, pad, seed=seed, **kw)
+        assert o.n_frames == F
+        return cd.decode_padded(o.codes)
+    step6(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    K3 = 1 if small else 5
+    for i in range(K3):
+        wav, wl = step6(10 + i)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / K3
+    t0 = time.perf_counter()
+    tk.generate(emb, mask, trailing, pad, seed=3, **kw)
+    torch.cuda.synchronize()
+    ar = time.perf_counter() - t0
+    wb = tk.stats()["weight_bytes_per_frame"]
+    kvb = 2.0 * B * t6.num_hidden_layers * 2 * t6.num_key_value_heads * t6.head_dim * (np.mean(lens) + F / 2)
+    out["config3_06b_b8"] = {"workload": "Qwen3-TTS-12Hz-0.6B dims, batch 8, ragged prompts 36..64 rows, 125 frames, sampling; prefill + AR decode (hipGraph) + codec decode (bf16)",
+                             "value": round(B * F * t6.num_code_groups / el, 1), "unit": "speech-tokens/s", "ms_per_step": round(1e3 * el, 2), "steps": K3,
+                             "ar_ms_per_frame": round(1e3 * ar / F, 4), "rtf_x": round(B * F * 0.08 / el, 1),
+                             "roofline": {"bound": "hbm", "what": "whole AR frame: (packed weights + average KV) bytes / ar_ms_per_frame", "achieved": round((wb + kvb) / (ar / F) / 1e9, 1),
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((wb + kvb) / (ar / F) / 1e9 / HBM_PEAK_GBS, 4)},
+                             "cp_fused": {k: tk.stats()[k] for k in ("cp_fused_active", "cp_fused_per_step")}}
+    del tk, cd
+    torch.cuda.empty_cache()
+    log(f"configs: config 3 done (+{time.perf_counter() - t_leg:.1f}s)")
+    # ---- config 5 at N = 1 (its engines, batch 32, serve config 4 too)
+    a5 = _ap.Namespace(**vars(args))
+    a5.requests, a5.batch, a5.engines, a5.steps, a5.warmup, a5.workload = (6, 2, 2, 1, 1, "clone-shard") if small else (256, 32, 2, 1, 1, "clone-shard")
+    keep = {}
+    r5 = clone_shard_job(a5, tcfg, ccfg, dev, 0, 1, None, weights=(tw_np, cw_np), keep=keep)
+    wb17 = keep["talkers"][0].stats()["weight_bytes_per_frame"]
+    waves_frames = r5.pop("_wave_frames", None)
+    out["config5_clone_shard_n1"] = {"workload": r5["config"]["workload"], "value": r5["value"], "unit": r5["unit"], "ms_per_job": r5["ms_per_step"],
+                                     "rtf_x": r5["rtf_x"], "wave_batch": a5.batch, "engines_per_gpu": 2, "padding_waste": r5["padding_waste"],
+                                     "engine_load_imbalance": r5["engine_load_imbalance"], "n_gpus": 1,
+                                     "note": "the N = 1 point of the strong-scaling job; `bench.py --workload clone-shard --gpus N` runs the same job over N ranks"}
+    if waves_frames:
+        streamed = wb17 * sum(waves_frames)                  # every frame step of every wave streams the packed weights once
+        out["config5_clone_shard_n1"]["roofline"] = {"bound": "hbm", "what": "packed-weight bytes streamed by all frame steps of the job (both engines) / job time",
+                                                      "achieved": round(streamed / (r5["ms_per_step"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                      "frac": round(streamed / (r5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    log(f"configs: config 5 done (+{time.perf_counter() - t_leg:.1f}s)")
+    # ---- config 4: first packet at batch 32 on one of those engines
+    talker, codec = keep["talkers"][0], keep["codecs"][0]
+    B, NF = (2 if small else 32), (2 if small else 4)
+    text = [24 + 4 * (i % 8) for i in range(B)] if not small else [3, 4]     # text tokens, fed one per frame (streaming text input, M:2229-2232)
+    lens = [32 + 12 + (i % 5) for i in range(B)] if not small else [6, 5]    # instruct (32) + role / codec prefix rows, ragged
+    emb, mask, trailing, pad = [x.to(dev) for x in synth.rand_prompt(np.random.default_rng(4), tcfg, lens, max(text), 0.05)]
+    sup = [i for i in range(tcfg.vocab_size - 1024, tcfg.vocab_size) if i != tcfg.codec_eos_token_id]
+    kw = dict(kw, suppress_tokens=sup, max_new_tokens=NF + 1, min_new_tokens=NF + 1)
+    lat, legs = [], []
+    for trial in range(3 if small else 12):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = talker.generate(emb, mask, trailing, pad, seed=50 + trial, **kw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        wav, wl = codec.decode_padded(o.codes[:, :NF])
+        pcm = wav.cpu()                                        # the first packet is on the host here
+        t2 = time.perf_counter()
+        assert o.n_frames == NF and pcm.shape[1] == NF * ccfg.total_upsample
+        if trial >= 2:
+            lat.append(1e3 * (t2 - t0))
+            legs.append((1e3 * (t1 - t0), 1e3 * (t2 - t1)))
+    lat = np.array(lat)
+    qd, kvd = tcfg.num_attention_heads * tcfg.head_dim, tcfg.num_key_value_heads * tcfg.head_dim
+    talker_w = 2.0 * tcfg.num_hidden_layers * (tcfg.hidden_size * (2 * qd + 2 * kvd) + 3 * tcfg.hidden_size * tcfg.intermediate_size)   # bf16 layer weights: one pass = the prefill
+    floor_b = talker_w + NF * wb17
+    talker_ms = float(np.median([a for a, _ in legs]))
+    out["config4_first_packet_b32"] = {"workload": "Qwen3-TTS-12Hz-1.7B dims, VoiceDesign-shaped batch of 32 (32 instruct rows + prefix), streaming text input, sampling; "
+                                                   "first packet = generate() call -> 4 frames (320 ms) of PCM on the host",
+                                       "trials": len(lat), "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
+                                       "min_ms": round(float(lat.min()), 3), "prefill_plus_ar_ms_p50": round(float(np.median([a for a, _ in legs])), 3),
+                                       "codec_plus_d2h_ms_p50": round(float(np.median([b for _, b in legs])), 3),
+                                       "roofline": {"bound": "hbm", "what": "weight bytes the talker leg must stream (one pass of the talker layers for the prefill + 4 frame "
+                                                                           "steps incl. the code predictor's 15 passes each) / prefill_plus_ar_ms_p50",
+                                                    "achieved": round(floor_b / (talker_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                    "unit": "GB/s", "frac": round(floor_b / (talker_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    log(f"configs: config 4 done (+{time.perf_counter() - t_leg:.1f}s)")
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    return out
+
+
+def voice_clone_prompt_leg(args, tcfg, dev):
+    """`Qwen3TTSModel.create_voice_clone_prompt` (IM:356-458) for 8 and for 32 reference clips of 3 s: audio normalisation, the codec
+    ENCODER (f3: waveform -> 16 codebooks, batched) and the SPEAKER encoder (f4: log-mel + ECAPA-TDNN, one clip at a time as the reference
+    loops, IM:440-455) at the RELEASED dimensions (synth.mimi_enc_real / speaker_real; parity at these dims: tests/test_gpu_parity.py), the
+    real wrapper around a model stand-in that owns the two engines (the talker is not involved in this call)."""
+    import numpy as np
+    import torch
+    import synth
+    from qwen3_tts_amd.codec import Qwen3TTSTokenizer
+    from qwen3_tts_amd.model import Qwen3TTSModel
+    from qwen3_tts_amd.speaker import SpeakerEncoderEngine
+    small = args.model == "tiny"
+    td = lambda w: {k: torch.from_numpy(v) for k, v in w.items()}
+    t0 = time.time()
+    enc = synth.mimi_enc_small() if small else synth.mimi_enc_real()
+    spk = synth.speaker_small() if small else synth.speaker_real(tcfg.hidden_size if tcfg.hidden_size >= 1024 else 2048)
+    dec = synth.codec_tiny() if small else synth.codec_real()
+    n = 2048 if small else 72000
+    counts = (2,) if small else (8, 32)
+    tok_sd = dict(synth.codec_weights(dec))
+    tok_sd.update({"encoder." + k: v for k, v in synth.mimi_enc_weights(enc).items()})
+    tok_cfg = dict(synth.cfg_dict(dec), encoder_config=synth.cfg_dict(enc), encoder_valid_num_quantizers=enc.encoder_valid_num_quantizers,
+                   encode_downsample_rate=enc.encode_downsample_rate, input_sample_rate=24000)
+    out = {"api": "Qwen3TTSModel.create_voice_clone_prompt(ref_audio=[(waveform, 24000)] * N, ref_text=[...]) -> N VoiceClonePromptItem",
+           "clip_seconds": round(n / 24000.0, 3), "runs": []}
+    for dt, name in ((torch.float32, "f32"),) if small else ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        tok = Qwen3TTSTokenizer.from_state_dict(tok_cfg, td(tok_sd), device=dev, dtype=dt, max_batch=max(counts), max_frames=32)
+        se = SpeakerEncoderEngine(synth.cfg_dict(spk), td(synth.speaker_weights(spk)), compute_dtype=dt, device=dev, max_batch=1, max_samples=n)
+
+        class _BaseModel:                      # what the wrapper touches for this call (IM:356-458)
+            tts_model_type = "base"
+            speaker_encoder_sample_rate = 24000
+            speech_tokenizer = tok
+            device = tok.device
+
+            def extract_speaker_embedding(self, audio, sr):
+                return se.extract_speaker_embedding(audio, sr)
+        tts = Qwen3TTSModel(_BaseModel(), _BenchProcessor(tcfg), generate_defaults={})
+        for N in counts:
+            clips = [(a, 24000) for a in synth.rand_audio(300 + N, N, n)]
+            texts = ["reference words"] * N
+            items = tts.create_voice_clone_prompt(ref_audio=clips, ref_text=texts)            # warm-up: builds the encoder engine, fills caches
+            assert len(items) == N and items[0].ref_code.shape == (-(-n // enc.encode_downsample_rate), enc.encoder_valid_num_quantizers)
+            assert items[0].ref_spk_embedding.shape == (spk.enc_dim,) and bool(torch.isfinite(items[0].ref_spk_embedding).all())
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(1 if small else 5):
+                ta = time.perf_counter()
+                tts.create_voice_clone_prompt(ref_audio=clips, ref_text=texts)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - ta)
+            wavs = torch.from_numpy(np.stack([a for a, _ in clips])).to(dev)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            tok.model._encoder.encode_padded(wavs)
+            torch.cuda.synchronize()
+            enc_ms = 1e3 * (time.perf_counter() - ta)
+            ta = time.perf_counter()
+            for i in range(N):
+                se.embed(wavs[i:i + 1])
+            torch.cuda.synchronize()
+            spk_ms = 1e3 * (time.perf_counter() - ta)
+            out["runs"].append({"dtype": name, "clips": N, "ms_per_call": round(1e3 * float(np.median(ts)), 2), "ms_min": round(1e3 * min(ts), 2),
+                                "ms_per_clip": round(1e3 * float(np.median(ts)) / N, 3), "encoder_batched_ms": round(enc_ms, 2),
+                                "speaker_clip_by_clip_ms": round(spk_ms, 2),
+                                "audio_seconds_per_wall_second": round(N * n / 24000.0 / float(np.median(ts)), 1)})
+        del tts, tok, se
+        torch.cuda.empty_cache()
+    out["build_seconds"] = round(time.time() - t0, 1)
+    return out
 
 
 def fused_cp_report(c, fused_rec, elem_bytes=2):
@@ -508,7 +744,11 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
     talker.set_profile(1)
     talker.generate(emb, mask, trailing, pad, seed=7, **dict(gen_kw, max_new_tokens=9, min_new_tokens=9))
     talker.set_profile(0)
-    cls = talker.gemm_profile()
+    cls_all = talker.gemm_profile()
+    # stack 3 = the code predictor's fused launch (cp_attn_o_kernel: q|k|v GEMM + attention + o-projection of a layer), timed by the
+    # same per-launch events in the same run (round 5); the dominant-kernel figure stays the decode GEMM's own launches
+    cls = [c for c in cls_all if c["stack"] != 3]
+    cls_fused = [c for c in cls_all if c["stack"] == 3]
     frames = 6
     out = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "method": "per-launch kernel begin/end timestamps (hipExtLaunchKernelGGL events) over every decode-GEMM "
@@ -537,6 +777,27 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
         a[0] += c["total_ms"]; a[1] += c["launches"]; a[2] += c["launches"] * c["bytes_per_launch"]
     out["by_stack"] = {k: {"launches_per_frame": v[1] // frames, "avg_us": round(1e3 * v[0] / v[1], 3),
                            "frac": round(v[2] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in by.items()}
+    if cls_fused:
+        # measured IN THIS RUN: the fused launches' own begin / end timestamps, and the like-for-like figure over
+        # EVERY weight-streaming launch of the frame (decode GEMMs + fused launches)
+        fl = {}
+        for c in cls_fused:
+            us = 1e3 * c["total_ms"] / c["launches"]
+            key = "front" if c["N"] > talker.config.cp_hidden_size else "attn_o"
+            fl[key] = {"launches_per_frame": c["launches"] // frames, "algorithmic_bytes_per_launch": round(c["bytes_per_launch"]),
+                       "avg_us": round(us, 3), "min_us": round(c["min_us"], 3),
+                       "frac": round(c["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        fl["weight_bytes_per_frame"] = round(sum(c["launches"] * c["bytes_per_launch"] for c in cls_fused) / frames)
+        fl["kernel"] = ("cp_attn_o_kernel (front: q|k|v GEMM + attention + o-projection of a code-predictor layer in one launch; attn_o: layer 0, "
+                        "whose q|k|v row comes from the table); per-launch events of this run")
+        out["fused_cp_launch"] = fl
+        ms_all = tot_ms + sum(c["total_ms"] for c in cls_fused)
+        b_all = tot_b + sum(c["launches"] * c["bytes_per_launch"] for c in cls_fused)
+        out["frac_all_weight_launches"] = round(b_all / (ms_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["weight_launches_per_frame"] = (tot_n + sum(c["launches"] for c in cls_fused)) // frames
+        out["weight_bytes_per_frame_timed_all"] = round(b_all / frames)
+    st_f = talker.stats()
+    out["cp_fused"] = {k: st_f[k] for k in ("cp_fused_active", "cp_fused_capacity", "cp_fused_per_step", "cp_fused_giveups") if k in st_f}
     if elem_bytes != 2:            # (the parity-mode leg: no PMC pass and no isolated replay for the fp32 engine)
         out["traffic"] = None
         return out
@@ -565,8 +826,13 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
                 out["frac_live_over_rocprof"] = round(out["frac"] / rec["frac_rocprof"], 4)
             if "fused" in rec and out["weight_bytes_per_frame_timed"] < wbytes:
                 fl = fused_cp_report(talker.config, rec["fused"], elem_bytes)
-                if fl:
-                    out["fused_cp_launch"] = fl
+                if fl:                         # the stamped rocprofv3 / FETCH_SIZE pass rides beside the live numbers
+                    for k in ("front", "attn_o"):
+                        if k in fl and k in out.get("fused_cp_launch", {}):
+                            out["fused_cp_launch"][k].update(rocprof_avg_launch_us=fl[k]["rocprof_avg_launch_us"], frac_rocprof=fl[k]["frac_rocprof"],
+                                                             traffic=fl[k]["traffic"])
+                    if "fused_cp_launch" not in out:
+                        out["fused_cp_launch"] = fl
     except Exception as e:
         traffic_src = f"unavailable ({type(e).__name__}: {e})"
     out["traffic"], out["traffic_source"] = traffic, traffic_src

@@ -45,9 +45,19 @@ const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
  * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
  * 6: + qtts_talker_stream_*; 7: + qtts_talker_set_teacher; 8: + qtts_talker_set_profile / get_gemm_profile;
- * 9: + qtts_codec_get_stats). */
-#define QTTS_ABI_VERSION 9
+ * 9: + qtts_codec_get_stats; 10: + qtts_set_option / qtts_get_option, qtts_talker_stats grew the fused-launch fields). */
+#define QTTS_ABI_VERSION 10
 int qtts_abi_version(void);
+
+/* A/B switches of the library (measuring tools and tests; a deployment sets none).  Every switch has a name of the form
+ * "QTTS_..." (the list: DESIGN.md "switches"); its value is, in this order, what qtts_set_option last gave it, else the
+ * environment variable of the same name as it was when the library first looked, else the built-in default.  Engine-level
+ * switches are copied into a handle when it is CREATED (qtts_*_create): later changes do not touch existing handles.
+ * Launcher-level switches (kernel selection inside csrc/) are looked up per launch and follow the table at once.
+ * value = NULL removes the override.  No reference counterpart (the reference has no native code to switch). */
+int qtts_set_option(const char* name, const char* value);
+/* -> the current value ("" + return 1 when the switch is unset), copied into buf (cap bytes incl. the terminator). */
+int qtts_get_option(const char* name, char* buf, int32_t cap);
 
 /* ------------------------------------------------------------------------------------------
  * Codec decoder: Qwen3-TTS-Tokenizer-12Hz  codes -> 24 kHz waveform.
@@ -379,7 +389,13 @@ typedef struct {
     int32_t long_graphs;      /* long-sequence frame graphs currently cached (one per KV-length bucket the generation reached, ABI v8) */
     int32_t attn_nsplit_last; /* split-KV workgroups per (sequence, kv head) of the last launched frame step (1 = short mode) */
     int32_t attn_span_last;   /* the key span those workgroups partition (the live length's bucket; 0 = short mode) */
-    int32_t reserved_;
+    /* the code predictor's fused launch (q|k|v + attention + o-projection of a layer in one launch; ABI v10) */
+    int32_t cp_fused_per_step;      /* fused launches in the frame step last launched / captured (0: this engine runs the separate launches) */
+    int64_t cp_fused_launches_last; /* = cp_fused_per_step x frames_run of the last generation                                              */
+    int32_t cp_fused_giveups;       /* generations that ended with QTTS_ERR_STATE because a consumer gave up (the engine then left the fused launch) */
+    int32_t cp_fused_capacity;      /* fused launches of this engine's grid the DEVICE holds resident at once (occupancy x compute units / grid) */
+    int32_t cp_fused_active;        /* 1: this engine holds one of those places                                                             */
+    int32_t reserved2_;
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
 /* Per-class result of the profile mode (qtts_talker_set_profile(t, 1), ABI v8): every launch of the decode GEMM in frames 1..6

@@ -104,7 +104,7 @@ def encoder_transformer(w, cfg, x):
     return h
 
 
-def rvq_encode(w, prefix, x, n_layers):
+def rvq_encode(w, prefix, x, n_layers, margins=None):
     """MimiResidualVectorQuantizer.encode (TM:1050-1068): 1x1 input_proj, then per layer nearest codebook entry
     (Euclidean, argmin of cdist; embed = embed_sum / clamp(cluster_usage, 1e-5), TM:964-1007) and residual update."""
     r = F.conv1d(x, _t(w, prefix + "input_proj.weight"))
@@ -114,13 +114,17 @@ def rvq_encode(w, prefix, x, n_layers):
         cu = _t(w, f"{prefix}layers.{i}.codebook.cluster_usage")
         table = es / cu.clamp(min=1e-5)[:, None]
         flat = r.permute(0, 2, 1).reshape(-1, r.shape[1])
-        ind = torch.cdist(flat[None].float(), table[None].float(), p=2)[0].argmin(dim=-1).view(r.shape[0], r.shape[2])
+        dist = torch.cdist(flat[None].float(), table[None].float(), p=2)[0]
+        ind = dist.argmin(dim=-1).view(r.shape[0], r.shape[2])
+        if margins is not None:          # (test infrastructure: how far the runner-up entry is, relative to the winner -- the near-tie exemption of the parity tests)
+            d2 = torch.topk(dist, 2, dim=-1, largest=False).values
+            margins.append(((d2[:, 1] - d2[:, 0]) / d2[:, 0].clamp(min=1e-12)).view(r.shape[0], r.shape[2]))
         r = r - F.embedding(ind, table).permute(0, 2, 1)
         out.append(ind)
     return torch.stack(out)                                        # (layers, B, T)
 
 
-def mimi_encode(w, cfg, wav: torch.Tensor, num_quantizers: int = None) -> torch.Tensor:
+def mimi_encode(w, cfg, wav: torch.Tensor, num_quantizers: int = None, margins=None) -> torch.Tensor:
     """MimiModel.encode / _encode_frame (TM:1230-1262, 1297-1394), non-streaming.  wav (B, 1, samples) ->
     codes (B, num_quantizers, frames) int64."""
     nq = cfg.num_quantizers if num_quantizers is None else num_quantizers
@@ -128,10 +132,10 @@ def mimi_encode(w, cfg, wav: torch.Tensor, num_quantizers: int = None) -> torch.
     h = encoder_transformer(w, cfg, h.transpose(1, 2)).transpose(1, 2)
     h = mimi_conv1d(h, _t(w, "downsample.conv.weight"), None, stride=2, pad_mode="replicate")
     ns = cfg.num_semantic_quantizers
-    codes = rvq_encode(w, "quantizer.semantic_residual_vector_quantizer.", h, ns)
+    codes = rvq_encode(w, "quantizer.semantic_residual_vector_quantizer.", h, ns, margins)
     if nq > ns:
-        codes = torch.cat([codes, rvq_encode(w, "quantizer.acoustic_residual_vector_quantizer.", h, nq - ns)], dim=0)
-    return codes.transpose(0, 1)
+        codes = torch.cat([codes, rvq_encode(w, "quantizer.acoustic_residual_vector_quantizer.", h, nq - ns, margins)], dim=0)
+    return codes.transpose(0, 1)                                   # (margins: a list of nq tensors (B, T), in codebook order)
 
 
 def model_encode(w, cfg, input_values: torch.Tensor, padding_mask: torch.Tensor) -> List[torch.Tensor]:

@@ -677,6 +677,63 @@ def gen_codec_enc_tiny():
     print("codec_enc_tiny:", {k: v.shape for k, v in out.items() if k.startswith(("codes", "batch_codes"))})
 
 
+def gen_codec_enc_real():
+    """f3 at the RELEASED dimensions: the reference's encoder class (tokenizer v2:897-908; Mimi: hidden 512, 8 layers,
+    32 codebooks of 2048 x 256) on 3 s of audio (72 000 samples), batch 2.  The waveform is synth.rand_audio(seed) (not stored); stored are
+    the reference's codes, and -- from the oracle restatement, which must reproduce those codes here -- the relative gap between the nearest
+    and the second-nearest codebook entry of every index (the near-tie exemption of the GPU test)."""
+    import torch
+    import codec_enc_ref
+    c = synth.mimi_enc_real()
+    w = synth.mimi_enc_weights(c)
+    m = ref_mimi_encoder(c, w)
+    seed, n = 77, 72000
+    x = torch.from_numpy(synth.rand_audio(seed, 2, n))[:, None]
+    with torch.no_grad():
+        codes = m.encode(input_values=x, return_dict=True).audio_codes.numpy()
+        mg = []
+        oc = codec_enc_ref.mimi_encode({k: torch.from_numpy(v) for k, v in w.items()}, c, x, margins=mg).numpy()
+    margin = torch.stack(mg, 1).numpy().astype(np.float32)          # (B, Q, T)
+    agree = float((oc == codes).mean())
+    print(f"codec_enc_real: codes {codes.shape}, oracle == reference on {agree:.4f} of the indices, smallest margin {margin.min():.2e}")
+    assert agree >= 0.999
+    np.savez_compressed(os.path.join(GOLDEN, "codec_enc_real.npz"), weights_checksum=synth.weights_checksum(w), seed=seed, samples=n,
+                        codes=codes.astype(np.int16), margin=margin, oracle_agree=agree)
+
+
+def gen_speaker_real():
+    """f4 at the RELEASED dimensions: the reference's Qwen3TTSSpeakerEncoder (M:95-393; ECAPA-TDNN 512/512/512/512/1536, enc_dim 2048)
+    and its mel_spectrogram (M:402-464, with the restated Slaney filterbank as in speaker_tiny) on 3 s of audio, batch 2."""
+    ref_shims.install()
+    import torch
+    import speaker_ref
+    from qwen_tts.core.models import modeling_qwen3_tts as M
+    from qwen_tts.core.models.configuration_qwen3_tts import Qwen3TTSSpeakerEncoderConfig
+    c = synth.speaker_real()
+    w = synth.speaker_weights(c)
+    cfg = Qwen3TTSSpeakerEncoderConfig(mel_dim=c.mel_dim, enc_dim=c.enc_dim, enc_channels=list(c.enc_channels),
+                                       enc_kernel_sizes=list(c.enc_kernel_sizes), enc_dilations=list(c.enc_dilations),
+                                       enc_attention_channels=c.enc_attention_channels, enc_res2net_scale=c.enc_res2net_scale,
+                                       enc_se_channels=c.enc_se_channels)
+    m = M.Qwen3TTSSpeakerEncoder(cfg).eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == synth.speaker_param_shapes(c)
+    _load(m, w)
+    seed, n = 78, 72000
+    audio = torch.from_numpy(synth.rand_audio(seed, 2, n))
+    fb = speaker_ref.mel_filterbank_slaney(24000, 1024, 128, 0, 12000)
+    M.librosa_mel_fn = lambda sr, n_fft, n_mels, fmin, fmax: fb
+    with torch.no_grad():
+        mel = M.mel_spectrogram(audio, n_fft=1024, num_mels=128, sampling_rate=24000, hop_size=256, win_size=1024, fmin=0, fmax=12000)
+        emb = m(mel.transpose(1, 2))                               # M:1951: mels (B, frames, 128)
+        oemb = speaker_ref.speaker_encoder_forward({k: torch.from_numpy(v) for k, v in w.items()}, c,
+                                                   speaker_ref.mel_spectrogram(audio).transpose(1, 2))
+    d = float((emb - oemb).abs().max())
+    print(f"speaker_real: embedding {tuple(emb.shape)} |max| {float(emb.abs().max()):.3f}, mel {tuple(mel.shape)}, oracle - reference max {d:.2e}")
+    assert d <= 1e-4 * max(1.0, float(emb.abs().max()))
+    np.savez_compressed(os.path.join(GOLDEN, "speaker_real.npz"), weights_checksum=synth.weights_checksum(w), seed=seed, samples=n,
+                        embedding=emb.numpy(), mel_sum=float(mel.double().sum()), mel_frames=mel.shape[-1])
+
+
 def gen_codec_real_bf16():
     """The reference's OWN decoder run in **bfloat16** (V2:869-896; the dtype of its examples) on codec_real.npz's 10 s of codes:
     the yardstick for the MI355X bf16 codec engine -- how far does bf16 move the reference's own waveform from its fp32 waveform,
@@ -779,7 +836,8 @@ ALL = {"codec_tiny": gen_codec_tiny, "codec_real": gen_codec_real, "talker_tiny"
        "talker_06b": gen_talker_06b, "talker_17b": gen_talker_17b, "prompt_tiny": gen_prompt_tiny,
        "talker_06b_b8": gen_talker_06b_b8, "talker_17b_b32": gen_talker_17b_b32, "talker_17b_b8": gen_talker_17b_b8, "talker_06b_long": gen_talker_06b_long,
        "talker_17b_b8_bf16": gen_talker_17b_b8_bf16, "ckpt_tiny": gen_ckpt_tiny, "speaker_tiny": gen_speaker_tiny, "codec_enc_tiny": gen_codec_enc_tiny, "codec_enc_small": gen_codec_enc_small,
-       "codec_real_bf16": gen_codec_real_bf16, "talker_17b_base_icl_b8": gen_talker_17b_base_icl_b8}
+       "codec_real_bf16": gen_codec_real_bf16, "talker_17b_base_icl_b8": gen_talker_17b_base_icl_b8,
+       "codec_enc_real": gen_codec_enc_real, "speaker_real": gen_speaker_real}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

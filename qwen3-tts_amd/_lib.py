@@ -68,7 +68,9 @@ class SpeakerConfigC(C.Structure):
 class TalkerStatsC(C.Structure):
     _fields_ = [("frames_run", C.c_int32), ("graph_nodes", C.c_int32), ("weight_bytes_per_frame", C.c_double),
                 ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64), ("long_graphs", C.c_int32),
-                ("attn_nsplit_last", C.c_int32), ("attn_span_last", C.c_int32), ("reserved_", C.c_int32)]
+                ("attn_nsplit_last", C.c_int32), ("attn_span_last", C.c_int32), ("cp_fused_per_step", C.c_int32),
+                ("cp_fused_launches_last", C.c_int64), ("cp_fused_giveups", C.c_int32), ("cp_fused_capacity", C.c_int32),
+                ("cp_fused_active", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 class CodecStatsC(C.Structure):
@@ -80,10 +82,10 @@ class GemmClassC(C.Structure):
                 ("min_us", C.c_double), ("max_us", C.c_double), ("bytes_per_launch", C.c_double)]
 
 
-ABI_VERSION = 9           # include/qtts.h; bumped on any signature change
+ABI_VERSION = 10          # include/qtts.h; bumped on any signature change
 
-# every symbol include/qtts.h declares (checked by tests/test_abi.py without a GPU)
-SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
+# every symbol include/qtts.h declares (checked by tests/test_host_logic.py::test_abi_exports_every_declared_symbol without a GPU)
+SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_set_option", "qtts_get_option", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
            "qtts_codec_finalize", "qtts_codec_forward", "qtts_codec_decode", "qtts_codec_forward_stage",
            "qtts_codec_stream_begin", "qtts_codec_stream_push", "qtts_codec_get_stats",
            "qtts_encoder_create", "qtts_encoder_destroy", "qtts_encoder_bind", "qtts_encoder_finalize", "qtts_encoder_frames",
@@ -137,6 +139,8 @@ def load_library():
     vp, i32, i64p, f32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p
     lib.qtts_last_error.restype = C.c_char_p
     lib.qtts_abi_version.restype = C.c_int
+    lib.qtts_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    lib.qtts_get_option.argtypes = [C.c_char_p, C.c_char_p, i32]
     lib.qtts_codec_create.argtypes = [C.POINTER(CodecConfigC), C.POINTER(vp)]
     lib.qtts_codec_destroy.argtypes = [vp]
     lib.qtts_codec_destroy.restype = None
@@ -189,6 +193,32 @@ def load_library():
         raise QttsError(-101, "libqtts.so ABI version mismatch; rebuild")
     _LIB = lib
     return lib
+
+
+def set_option(name: str, value=None, lib=None) -> None:
+    """An A/B switch of the library through its C ABI (include/qtts.h qtts_set_option): measuring tools and tests only.
+    value None removes the override (the switch falls back to the environment variable of the same name, then to its default)."""
+    lib = lib or load_library()
+    lib.qtts_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    check(lib.qtts_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+class options:
+    """`with _lib.options(QTTS_SKINNY8="0"): ...` -- switches set for the block and removed after it.  Engine-level switches are copied
+    into an engine when it is CREATED: build the engine inside the block."""
+
+    def __init__(self, lib=None, **kw):
+        self.lib, self.kw = lib, kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v, self.lib)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, None, self.lib)
+        return False
 
 
 def locked(fn):

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "tstamp.h"
+#include <hip/hip_ext.h>
 
 QTTS_TS_UNIT(attn)
 
@@ -1455,6 +1456,16 @@ constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a
 #endif
 }  // namespace
 
+// A consumer that never saw its producers' tag: raise the engine's flag AND latch the generation's stop flag -- every later kernel of
+// the frame chain (and every later frame step of the burst) returns at its `done` check, so one lost launch costs one give-up and the
+// host finds the flag at its next poll (talker_engine.hip: generate / stream_step / stream_end raise QTTS_ERR_STATE).
+__device__ __forceinline__ void cpao_give_up(const CpAttnOParams& P) {
+    if (P.err) __hip_atomic_store(P.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (P.done_latch) __hip_atomic_store(P.done_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (bit 31 is never set in a launch tag -- the serial stays below 2^24: a granule stored under this tag is fresh for nobody)
+constexpr unsigned CPAO_POISON = 0x80000000u;
+
 // The operands of the FIRST requests are leading scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave
 // instead of behind an s_load round trip of the by-value struct (as the decode GEMM's, profiles/r03_ab_kpre.md).
 #define QTTS_CPAO_ARGS(P) ((P).Wqkv ? (P).Wqkv : static_cast<const void*>((P).a.qkv)), (P).x16, (P).serial, (P).a.done_flag, (P).a.B, (P).ldx16, (P).K, (P).slot, (P)
@@ -1468,8 +1479,9 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
     // ONE LDS object (a second one de-pipelines the loads around it):
     //   [4 waves][q | kn | vn : 128 floats each] | B tile [2][BSTR] bf16 | the reducer's own partial sum [2][128] floats
     //   | QKV: the four k quarters of the q|k|v strip [4 waves][64 lanes][4] floats and of the row sums of squares [4][16]
-    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4, QP_BYTES = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES];
+    //   | one word per wave: "a lane of this wave gave up waiting for its q|k|v rows"
+    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4, QP_BYTES = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0, GU_BYTES = 16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES + GU_BYTES];
     const AttnDecodeParams& p = P.a;
     const int nchunk = P.H >> 7;
     // blockIdx = (row pair, kv head, chunk), chunk fastest: with 8 chunks the 32 workgroups that read one chunk's columns of Wo share an XCD's L2
@@ -1508,6 +1520,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
     }
     const float* xrow = p.qkv + (size_t)b * p.ld;
     float xq[2], xk[2], xv[2];
+    bool lane_gave_up = false;                          // (QKV: this lane's q|k|v granules never carried the tag)
     if constexpr (!QKV) {
         xq[0] = xrow[(g * 2 + hh) * HD + lane]; xq[1] = xrow[(g * 2 + hh) * HD + lane + 64];
         xk[0] = xrow[(p.nh + g) * HD + lane]; xk[1] = xrow[(p.nh + g) * HD + lane + 64];
@@ -1603,7 +1616,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 #pragma unroll
             for (int v = 0; v < 3; ++v) fresh = fresh && gq[v][0].y == tag && gq[v][1].y == tag;
             if (fresh) break;
-            if (spins > CPAO_SPIN_LIMIT) { if (P.err) *P.err = 1; break; }
+            if (spins > CPAO_SPIN_LIMIT) { cpao_give_up(P); lane_gave_up = true; break; }
 #pragma unroll
             for (int v = 0; v < 3; ++v) { gq[v][0] = gn[v][0]; gq[v][1] = gn[v][1]; }
             wt_first_pause(P.poll_step);
@@ -1690,7 +1703,17 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
         *reinterpret_cast<unsigned*>(Bt + rr * BSTR + hh * HD + 2 * lane) = pk;
     }
     QTTS_TS(2);
+    // a workgroup one of whose lanes gave up has no attention output worth handing on: its partial sums leave under a tag nobody waits
+    // for (so its reducer gives up in turn instead of adding garbage), and as a reducer it writes nothing
+    int* gu = reinterpret_cast<int*>(smem + WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES);
+    if constexpr (QKV) {
+        const bool wave_bad = __ballot(lane_gave_up) != 0;
+        if (lane == 0) gu[wave] = wave_bad ? 1 : 0;
+    }
     __syncthreads();
+    bool wg_bad = false;
+    if constexpr (QKV) wg_bad = (gu[0] | gu[1] | gu[2] | gu[3]) != 0;
+    const unsigned tag_out = wg_bad ? (tag | CPAO_POISON) : tag;
     // ---- 3. partial o-projection: D[feature 4 q + j][sequence li] of two strips over the 256 k of this kv head (columns 0 / 1 of the MFMA tile)
     const int row = rq * 2 + li;                        // (meaningful for li < 2)
     const bool col_ok = li < 2 && row < p.B;
@@ -1721,8 +1744,8 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int off = (int)((((size_t)g * 8 + row) * P.H + c * 128 + (wave * 2 + s) * 16 + lq * 4) * 8);
-            wt_store16(slab, off, (cu32x4){__float_as_uint(acc[s][0]), tag, __float_as_uint(acc[s][1]), tag});
-            wt_store16(slab, off + 16, (cu32x4){__float_as_uint(acc[s][2]), tag, __float_as_uint(acc[s][3]), tag});
+            wt_store16(slab, off, (cu32x4){__float_as_uint(acc[s][0]), tag_out, __float_as_uint(acc[s][1]), tag_out});
+            wt_store16(slab, off + 16, (cu32x4){__float_as_uint(acc[s][2]), tag_out, __float_as_uint(acc[s][3]), tag_out});
         }
     }
     QTTS_TS(3);
@@ -1758,12 +1781,15 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
             load_slabs(pa);
             wt_first_pause(P.poll_step);
             load_slabs(pn);
-            for (int spins = 0;; ++spins) {                 // (two reads in flight, as for the q | k | v rows)
+            bool gave_up = wg_bad;
+            for (int spins = 0; !wg_bad; ++spins) {         // (two reads in flight, as for the q | k | v rows)
                 bool fresh = true;
 #pragma unroll
                 for (int g2 = 0; g2 < NKV - 1; ++g2) fresh = fresh && pa[g2][1] == tag && pa[g2][3] == tag;
                 if (fresh) break;
-                if (spins > CPAO_SPIN_LIMIT) { if (P.err) *P.err = 1; break; }
+                if (spins > CPAO_SPIN_LIMIT) { cpao_give_up(P); gave_up = true; break; }
+                // somebody else of this launch gave up (its slab will never carry the tag): do not wait the limit out a second time
+                if ((spins & 1023) == 1023 && P.done_latch && __hip_atomic_load(P.done_latch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gave_up = true; break; }
 #pragma unroll
                 for (int g2 = 0; g2 < NKV - 1; ++g2) pa[g2] = pn[g2];
                 wt_first_pause(P.poll_step);
@@ -1774,9 +1800,11 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
             for (int g2 = 1; g2 < NKV - 1; ++g2) { s0 += __uint_as_float(pa[g2][0]); s1 += __uint_as_float(pa[g2][2]); }
             s0 += own[(tid >> 6) * 128 + c2]; s1 += own[(tid >> 6) * 128 + c2 + 1];
             s0 += res.x; s1 += res.y;
-            float2 o2; o2.x = s0; o2.y = s1;
-            *reinterpret_cast<float2*>(P.out + (size_t)rw * P.H + col) = o2;
-            if (P.out16) *reinterpret_cast<unsigned*>(P.out16 + (size_t)rw * P.H + col) = pack_bf16(s0, s1);
+            if (!gave_up) {                                 // (a reducer that gave up leaves the hidden state as it was: the latch stops the chain)
+                float2 o2; o2.x = s0; o2.y = s1;
+                *reinterpret_cast<float2*>(P.out + (size_t)rw * P.H + col) = o2;
+                if (P.out16) *reinterpret_cast<unsigned*>(P.out16 + (size_t)rw * P.H + col) = pack_bf16(s0, s1);
+            }
         }
     }
     QTTS_TS(4);
@@ -1789,11 +1817,40 @@ bool cp_attn_o_takes(const AttnDecodeParams& a, int H) {
            a.B >= 1 && a.B <= 8 && a.kv.bf16 && !a.kv.vt && H % 128 == 0 && H >= 128;
 }
 
+// bench.py's roofline leg (qtts_talker_set_profile(1)): the next launch goes out through hipExtLaunchKernelGGL with the caller's event
+// pair -- the kernel's own begin / end timestamps, as for the decode GEMM (skinny.hip: skinny_set_launch_events)
+static thread_local hipEvent_t tl_cpao_ev_start = nullptr, tl_cpao_ev_stop = nullptr;
+void cp_attn_o_set_launch_events(hipEvent_t start, hipEvent_t stop) { tl_cpao_ev_start = start; tl_cpao_ev_stop = stop; }
+#define QTTS_CPAO_LAUNCH(kern, grid, st, ...)                                                                                  \
+    do {                                                                                                                       \
+        if (tl_cpao_ev_start) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, st, tl_cpao_ev_start, tl_cpao_ev_stop, 0, __VA_ARGS__);  \
+        else hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, __VA_ARGS__);                                                    \
+    } while (0)
+
+int cp_attn_o_grid(int H) { return 4 * 8 * (H / 128); }
+
+int cp_attn_o_blocks_per_cu() {
+#ifdef QTTS_HOST_EMU
+    if (const char* e = QTTS_ENV("QTTS_HOSTEMU_CPAO_BLOCKS_PER_CU")) return atoi(e);      // (tests of the admission rule)
+    return 2;                                           // what the gfx950 build reports (the q|k|v-front instantiations: 176-180 registers, two waves per SIMD)
+#else
+    int best = 1 << 30;
+    auto probe = [&](auto kern) {
+        int n = 0;
+        QTTS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, 0));
+        best = std::min(best, n);
+    };
+    probe(cp_attn_o_kernel<true, true>); probe(cp_attn_o_kernel<false, true>);
+    probe(cp_attn_o_kernel<true, false>); probe(cp_attn_o_kernel<false, false>);
+    return best;
+#endif
+}
+
 void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
     QTTS_REQUIRE(cp_attn_o_takes(P.a, P.H), QTTS_ERR_ARG, "cp_attn_o: shape (bf16 cache, 16 / 8 heads of 128, one new token, <= 16 keys, batch <= 8)");
     QTTS_REQUIRE(P.Wo && P.res && P.out && P.part && P.serial && P.a.qw && P.a.kw && P.a.inv_freq, QTTS_ERR_ARG, "cp_attn_o: null operand");
     QTTS_REQUIRE(P.slot >= 0 && P.slot < 128, QTTS_ERR_ARG, "cp_attn_o: slot must be 0..127");
-    const dim3 grid(4 * 8 * (P.H / 128));                // (row pair, kv head, chunk)
+    const dim3 grid(cp_attn_o_grid(P.H));                // (row pair, kv head, chunk)
     if (P.Wqkv) {      // with the layer's q|k|v GEMM in front: workgroup = one 16-feature strip of it, so the two grids must coincide
         QTTS_REQUIRE((int)grid.x * 16 == P.a.ld && P.K == 1024 && P.x16 && P.qkv_gran && P.ldx16 % 8 == 0, QTTS_ERR_ARG,
                      "cp_attn_o: the q|k|v front needs K = 1024, (nh + 2 nkv) * 128 == 16 * workgroups, bf16 x and the granule buffer");
@@ -1807,13 +1864,13 @@ void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
         {
             Q.phase = 2;
 #endif
-            if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, true>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(Q));
-            else hipLaunchKernelGGL((cp_attn_o_kernel<false, true>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(Q));
+            if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, true>), grid, st, QTTS_CPAO_ARGS(Q));
+            else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, true>), grid, st, QTTS_CPAO_ARGS(Q));
         }
     } else {
         QTTS_REQUIRE(P.a.qkv, QTTS_ERR_ARG, "cp_attn_o: null q|k|v rows");
-        if (P.a.kv.contig) hipLaunchKernelGGL((cp_attn_o_kernel<true, false>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(P));
-        else hipLaunchKernelGGL((cp_attn_o_kernel<false, false>), grid, dim3(256), 0, st, QTTS_CPAO_ARGS(P));
+        if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, false>), grid, st, QTTS_CPAO_ARGS(P));
+        else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, false>), grid, st, QTTS_CPAO_ARGS(P));
     }
     QTTS_CHECK_HIP(hipGetLastError());
 }

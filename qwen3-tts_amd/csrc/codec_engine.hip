@@ -5,6 +5,8 @@
 // is one `gemm_tap` launch (see gemm_tap.hip).  Stage order follows Qwen3TTSTokenizerV2Decoder.forward
 // (tokenizer v2:869-884); chunking follows chunked_decode (v2:886-896).
 #include <map>
+#include <mutex>
+#include <atomic>
 #include <tuple>
 #include <functional>
 #include <algorithm>
@@ -81,7 +83,7 @@ struct qtts_codec {
     uint64_t graph_clock = 0;
     int graph_replays = 0, graph_captures = 0, graph_nodes_replayed = 0;
     static constexpr size_t GRAPH_SLOTS = 8;
-    static bool graph_enabled() { static const bool on = [] { const char* e = getenv("QTTS_CODEC_GRAPH"); return !e || atoi(e) != 0; }(); return on; }
+    static bool graph_enabled() { return QTTS_OPT_ON("QTTS_CODEC_GRAPH"); }
     void drop_graphs() {
         for (auto& kv : graphs) {
             if (kv.second.ge) (void)hipGraphExecDestroy(kv.second.ge);
@@ -441,7 +443,7 @@ void qtts_codec::finalize() {
             make_conv(b.u[j].c2, up + "conv2.conv", 1);
             // bf16 mode, C = 96 | 192 (the two blocks with the most rows): the unit runs as ONE kernel (resunit.hip) on weights
             // packed into MFMA fragments here.  QTTS_CODEC_FUSED=0 keeps the two tap-GEMM launches (A/B runs).
-            static const bool fused_env = [] { const char* e = getenv("QTTS_CODEC_FUSED"); return !e || atoi(e) != 0; }();
+            const bool fused_env = QTTS_OPT_ON("QTTS_CODEC_FUSED");
             b.u[j].dil = dil[j];
             if (bf16 && fused_env && resunit_supported(b.cout)) {
                 const int Cc = b.cout;
@@ -553,7 +555,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     }
     if (want("pre_transformer")) { emit(x); return; }
     // ---- upsample: ConvTranspose(k = s = f) + ConvNeXt (v2:878-880)
-    static const bool dec0_a16_env = [] { const char* e = getenv("QTTS_CODEC_DEC0_A16"); return !e || atoi(e) != 0; }();
+    const bool dec0_a16_env = QTTS_OPT_ON("QTTS_CODEC_DEC0_A16");
     const bool dec0_a16 = bf16 && dec0_a16_env && !stage && c.n_upsampling_ratios > 0 && !blocks.empty() && c.latent_dim % 64 == 0 && c.decoder_dim % 32 == 0;
     for (int u = 0; u < c.n_upsampling_ratios; ++u) {
         const int f = c.upsampling_ratios[u];
@@ -587,11 +589,11 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
     };
     // bf16 mode (round 2): inside the decoder blocks every tensor that is only a GEMM input travels as bf16 with the consumer's
     // SnakeBeta already applied by its producer's epilogue; the residual stream stays fp32.
-    static const bool fast16_env = [] { const char* e = getenv("QTTS_CODEC_FAST16"); return !e || atoi(e) != 0; }();   // (=0: A/B)
+    const bool fast16_env = QTTS_OPT_ON("QTTS_CODEC_FAST16");   // (=0: A/B)
     bool fast16 = bf16 && !blocks.empty() && fast16_env;
     for (auto& bk : blocks) fast16 = fast16 && bk.cin % 32 == 0 && bk.cout % 32 == 0;
     // QTTS_CODEC_FINAL16=0: fp32 tensor out of the last unit + stand-alone SnakeBeta + fp32 final conv (A/B runs)
-    static const bool final16_env = [] { const char* e = getenv("QTTS_CODEC_FINAL16"); return !e || atoi(e) != 0; }();
+    const bool final16_env = QTTS_OPT_ON("QTTS_CODEC_FINAL16");
     const bool final16 = fast16 && final16_env && !stage && wav && final_c % 8 == 0 && (size_t)262 * (final_c / 2 + 1) * 4 <= 64 * 1024;
     bf16_t* h16a = fast16 ? buf16[0].as<bf16_t>() : nullptr;
     bf16_t* h16b = fast16 ? buf16[1].as<bf16_t>() : nullptr;
@@ -618,7 +620,7 @@ void qtts_codec::forward(const int64_t* codes, int B, int64_t sb, int64_t sq, in
             // 1236 B per row were the fp32 residual in and out.  It lives in the storage of the fp32 buffers `a` / `b`; fp32 comes
             // back where a tensor leaves the blocks (last unit of the last block) or a stage is asked for.
             // QTTS_CODEC_RES16=0: fp32 residual stream (A/B runs).
-            static const bool res16_env = [] { const char* e = getenv("QTTS_CODEC_RES16"); return !e || atoi(e) != 0; }();
+            const bool res16_env = QTTS_OPT_ON("QTTS_CODEC_RES16");
             const bool r16 = res16_env && !stage && bk.u[0].fused && bk.u[1].fused && bk.u[2].fused;
             gemm16(bk.tconv, nullptr, h16a, C, B * L, L, r16 ? nullptr : b, bk.r * bk.cout, ACT_NONE, nullptr, 0, nullptr, h16b, &bk.u[0].a1, st, bk.cout,
                    nullptr, r16 ? reinterpret_cast<bf16_t*>(b) : nullptr);
@@ -881,6 +883,29 @@ void qtts_codec::stream_push(const int64_t* codes, int n, float* wav, hipStream_
 namespace qtts {
 thread_local std::string g_last_error;
 void set_last_error(const std::string& s) { g_last_error = s; }
+
+// the A/B switch table (common.h: QTTS_ENV; include/qtts.h: qtts_set_option)
+namespace {
+struct OptTable {
+    std::mutex m;
+    std::map<std::string, std::string> kv;
+    std::atomic<unsigned> gen{1};
+};
+OptTable& opt_table() { static OptTable t; return t; }
+}  // namespace
+const char* opt_lookup(const char* var, unsigned& gen_seen, std::string& cache, bool& has) {
+    auto& t = opt_table();
+    const unsigned cur = t.gen.load(std::memory_order_acquire);
+    if (cur != gen_seen) {
+        std::lock_guard<std::mutex> lk(t.m);
+        auto it = t.kv.find(var);
+        if (it != t.kv.end()) { cache = it->second; has = true; }
+        else if (const char* e = getenv(var)) { cache = e; has = true; }
+        else { cache.clear(); has = false; }
+        gen_seen = t.gen.load(std::memory_order_relaxed);
+    }
+    return has ? cache.c_str() : nullptr;
+}
 }  // namespace qtts
 
 #define QTTS_API_BEGIN try {
@@ -894,6 +919,25 @@ extern "C" {
 
 const char* qtts_last_error(void) { return qtts::g_last_error.c_str(); }
 int qtts_abi_version(void) { return QTTS_ABI_VERSION; }
+
+int qtts_set_option(const char* name, const char* value) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(name && strncmp(name, "QTTS_", 5) == 0 && strlen(name) < 64, QTTS_ERR_ARG, "set_option: the switch names start with QTTS_");
+    auto& t = qtts::opt_table();
+    std::lock_guard<std::mutex> lk(t.m);
+    if (value) t.kv[name] = value; else t.kv.erase(name);
+    t.gen.fetch_add(1, std::memory_order_release);
+    QTTS_API_END
+}
+int qtts_get_option(const char* name, char* buf, int32_t cap) {
+        if (!name || !buf || cap < 1) { qtts::set_last_error("get_option: null argument"); return QTTS_ERR_ARG; }
+    auto& t = qtts::opt_table();
+    std::lock_guard<std::mutex> lk(t.m);
+    auto it = t.kv.find(name);
+    const char* v = it != t.kv.end() ? it->second.c_str() : getenv(name);
+    snprintf(buf, (size_t)cap, "%s", v ? v : "");
+    return v ? QTTS_OK : 1;
+}
 
 int qtts_codec_create(const qtts_codec_config* cfg, qtts_codec** out) {
     QTTS_API_BEGIN

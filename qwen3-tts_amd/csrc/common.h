@@ -37,17 +37,24 @@ struct Error : std::runtime_error {
         if (!(cond)) throw ::qtts::Error((code), std::string(msg));    \
     } while (0)
 
-// ------------------------------------------------------------------------------------------ A/B environment switches
-// An A/B switch that sits on a launch path is read ONCE (its value copied) -- no getenv per launch.  Measuring tools and
-// tests that flip a switch inside one process (tools/ab_inproc.py, monkeypatched tests) export QTTS_DEBUG_ENV_LIVE=1 before the
-// library is loaded; only then is the environment re-read at every use.
-#define QTTS_ENV(var)                                                                                              \
-    ([]() -> const char* {                                                                                        \
-        static const bool live = getenv("QTTS_DEBUG_ENV_LIVE") != nullptr;                                        \
-        if (live) return getenv(var);                                                                             \
-        static const std::string v = [] { const char* e = getenv(var); return std::string(e ? e : "\x01"); }();   \
-        return v.size() == 1 && v[0] == '\x01' ? nullptr : v.c_str();                                             \
+// ------------------------------------------------------------------------------------------ A/B switches
+// One table for every A/B switch of the library (include/qtts.h: qtts_set_option).  QTTS_ENV("QTTS_X") = the value qtts_set_option last
+// gave the switch, else the environment variable of that name, else null.  The lookup is cached per call site and thread and repeated
+// only when the table's generation has moved (one relaxed atomic load per use: nothing a launch path notices).
+// Engine-level switches are copied into the handle when it is created; launcher-level switches follow the table at once.  Tests
+// flip switches through the C ABI -- never through os.environ inside a process.
+const char* opt_lookup(const char* var, unsigned& gen_seen, std::string& cache, bool& has);     // (codec_engine.hip)
+#define QTTS_ENV(var)                                                                  \
+    ([]() -> const char* {                                                            \
+        static thread_local unsigned gen_ = 0;                                        \
+        static thread_local std::string val_;                                         \
+        static thread_local bool has_ = false;                                        \
+        return ::qtts::opt_lookup(var, gen_, val_, has_);                             \
     }())
+// integer / boolean forms: QTTS_OPT_INT("QTTS_X", default), QTTS_OPT_ON("QTTS_X") (unset = on), QTTS_OPT_SET("QTTS_X") (unset = off)
+#define QTTS_OPT_INT(var, dflt) ([&]() -> int { const char* e_ = QTTS_ENV(var); return e_ ? atoi(e_) : (dflt); }())
+#define QTTS_OPT_ON(var) ([]() -> bool { const char* e_ = QTTS_ENV(var); return !e_ || atoi(e_) != 0; }())
+#define QTTS_OPT_SET(var) ([]() -> bool { const char* e_ = QTTS_ENV(var); return e_ && atoi(e_) != 0; }())
 
 // ------------------------------------------------------------------------------------------ bf16
 typedef uint16_t bf16_t;

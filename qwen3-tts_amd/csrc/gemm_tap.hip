@@ -785,9 +785,9 @@ static void launch_wide_k(const GemmTapParams& p, hipStream_t st) {
 struct WideTile { int bm, bn, bk; };
 static int g_wide_force = -1;                    // tests / A-B tooling: bm bn bk as digits (64064256), 0 = the chooser, -1 = QTTS_GEMM_WIDE_TILE
 static WideTile wide_tile(const GemmTapParams& p, bool a16, int bn_max) {
-    static const int force_env = [] { const char* e = getenv("QTTS_GEMM_WIDE_TILE"); return e ? atoi(e) : 0; }();
+    const int force_env = QTTS_OPT_INT("QTTS_GEMM_WIDE_TILE", 0);
     const int force = g_wide_force >= 0 ? g_wide_force : force_env;
-    static const bool legacy = [] { const char* e = getenv("QTTS_GEMM_NARROW"); return e && atoi(e) == 0; }();   // round 2's rule
+    const bool legacy = [] { const char* e = QTTS_ENV("QTTS_GEMM_NARROW"); return e && atoi(e) == 0; }();   // round 2's rule
     WideTile best{128, bn_max, 128};
     if (legacy) {
         if (!a16 && bn_max == 128 && p.act != ACT_SWIGLU && cdiv(p.M, 128) * cdiv(p.N, 128) < 128 && p.N % 64 == 0) best.bn = 64;
@@ -834,7 +834,7 @@ static void launch_t(const GemmTapParams& p, hipStream_t st) {
 
 void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
     GemmTapParams p = p_in;
-    static const int wide_max_tiles = [] { const char* e = getenv("QTTS_GEMM_WIDE_MAX"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
+    const int wide_max_tiles = [] { const char* e = QTTS_ENV("QTTS_GEMM_WIDE_MAX"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
     // (grids up to 2048 tiles of 128 x 128: the batch-32 prefill's gate|up GEMM, 1536 tiles, runs 150 us here, 187 us in the BK = 32 kernel)
     QTTS_REQUIRE(p.K % 32 == 0, QTTS_ERR_ARG, "gemm_tap: K must be a multiple of 32");
     QTTS_REQUIRE(p.taps >= 1 && p.taps <= 8, QTTS_ERR_ARG, "gemm_tap: 1..8 taps");
@@ -882,7 +882,7 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         // Round 4: a grid that leaves every CU at most one workgroup (the C = 768 / 384 units of a B = 1 x 10 s or 32 x 4-frame decode: 192
         // tiles, 168 k-steps each) is bound by its workgroups' own step chains, not by occupancy: 64-wide k-slabs halve the steps.
         // QTTS_TAP2_BK = 32 | 64 forces one side (A/B); default: 64 when the grid has at most `n_cu` tiles and K % 64 == 0.
-        static const int bk_env = [] { const char* e = getenv("QTTS_TAP2_BK"); return e ? atoi(e) : 0; }();
+        const int bk_env = QTTS_OPT_INT("QTTS_TAP2_BK", 0);
         static const int n_cu2 = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;

@@ -239,6 +239,8 @@ struct CpAttnOParams {
                                   // the launch tag = (*serial << 7) | slot differs from that of the launches before it
     int phase;                    // 2: the whole kernel.  0 / 1 (host emulator only, with Wqkv): the q|k|v strips only / everything after them
     int* err;                     // optional device flag, set if a reducer gave up waiting (never in a correct run)
+    int* done_latch;              // optional: the generation's stop latch, SET by a consumer that gives up -- every later kernel of the frame
+                                  // chain honours it, so a launch that lost its producers costs ONE give-up, not one per launch
     int first_pause, poll_step;   // x 64 clocks: a consumer's wait before its first read of other workgroups' granules, and between the
                                   // reads it keeps in flight after that (the engine passes 16 and 4: ~0.4 and ~0.1 us)
     // optional: the layer's q|k|v GEMM in front, in the same launch (workgroup i = 16-feature strip i of it; `a.qkv` is then unused)
@@ -250,6 +252,13 @@ struct CpAttnOParams {
 };
 bool cp_attn_o_takes(const AttnDecodeParams& a, int H);
 void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st);
+// Residency of the fused launch: workgroups of cp_attn_o_kernel (256 threads, its static LDS, its registers) one compute unit holds at
+// once -- hipOccupancyMaxActiveBlocksPerMultiprocessor, the minimum over the instantiations an engine can launch.  A launch whose
+// workgroups wait for each other's granules is only correct when ALL of them are resident: the engine admits a fused launch per
+// device only while (fused engines on the device) x grid <= this x the device's compute units (talker_engine.hip: fused_admit).
+int cp_attn_o_blocks_per_cu();
+int cp_attn_o_grid(int H);                                        // workgroups of one launch
+void cp_attn_o_set_launch_events(hipEvent_t start, hipEvent_t stop);   // bench.py's roofline leg: time the NEXT launch on its own (as skinny_set_launch_events)
 
 // --------------------------------------------------------------------------------- sampling.hip
 struct SampleParams {

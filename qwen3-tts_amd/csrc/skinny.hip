@@ -943,7 +943,7 @@ static bool launch_skinny8(const SkinnyParams& p, int spw, int fs, hipStream_t s
 // fp32, batch <= 8 (skinny8_f32_kernel).  QTTS_SKINNY8F=0 keeps skinny_f32_kernel + row_ss_kernel (A/B; read once: the engine decides
 // with the same function whether a normalised GEMM needs the row sums of squares from a launch of its own).
 static bool skinny8f_enabled() {
-    static const bool on = [] { const char* e = getenv("QTTS_SKINNY8F"); return !(e && e[0] == '0'); }();
+    const bool on = QTTS_OPT_ON("QTTS_SKINNY8F");
     return on;
 }
 template <int SPW, int NP, int CH, int NW>
@@ -973,11 +973,7 @@ static void launch8f_comb(const SkinnyParams& p, hipStream_t st) {
 // (16 waves x 6 pairs was tried for K = 3072 / 6144: a 1024-thread workgroup caps a wave at 128 registers and the kernel spilled)
 template <int SPW>
 static bool launch8f_spw(const SkinnyParams& p, hipStream_t st) {
-#ifdef QTTS_HOST_EMU
-    const int nw_env = [] { const char* e = getenv("QTTS_SKINNY8F_NW"); return e ? atoi(e) : 0; }();      // (the emulator test walks the instantiations)
-#else
-    static const int nw_env = [] { const char* e = getenv("QTTS_SKINNY8F_NW"); return e ? atoi(e) : 0; }();
-#endif
+    const int nw_env = QTTS_OPT_INT("QTTS_SKINNY8F_NW", 0);      // (the emulator test walks the instantiations)
     if (p.ksplit == 2) {                   // producer: K / 2 per workgroup
         if constexpr (SPW == 1) {
             switch (p.K) {
@@ -1022,7 +1018,7 @@ bool skinny_f32_inline_norm(int M, int K) {
 }
 // split-K producer / combining consumer shapes (the engine asks before it plans a layer that way)
 bool skinny_f32_splitk_takes(int M, int K_producer, int K_consumer) {
-    static const bool on = [] { const char* e = getenv("QTTS_SKINNY8F_SPLITK"); return !(e && e[0] == '0'); }();     // (=0: A/B)
+    const bool on = QTTS_OPT_ON("QTTS_SKINNY8F_SPLITK");     // (=0: A/B)
     return on && skinny8f_enabled() && M >= 1 && M <= 8 && (K_producer == 2048 || K_producer == 3072 || K_producer == 6144) &&
            (K_consumer == 1024 || K_consumer == 2048);
 }

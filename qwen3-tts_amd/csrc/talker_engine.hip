@@ -13,6 +13,7 @@
 //   state     residual stream / qkv / mlp activations fp32 [rows <= 64][dim]; rows = t*B + b
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <algorithm>
 #include "common.h"
 #include "kernels.h"
@@ -104,7 +105,7 @@ struct qtts_talker {
     int profile = 0;
     bool timing_now = false, skinny_only = false;
     static constexpr int PROF_FRAMES = 6;
-    struct LaunchEv { hipEvent_t a, b; int stack, N, K; };
+    struct LaunchEv { hipEvent_t a, b; int stack, N, K; double bytes = 0; };      // bytes: algorithmic bytes when N * K * element size is not it (the fused launch: two operators)
     std::vector<LaunchEv> ev;
     int cur_stack = 0;                 // which part of the frame step is being launched: 0 talker layers, 1 code predictor, 2 talker head
     std::vector<qtts_gemm_class> prof_classes;
@@ -126,7 +127,7 @@ struct qtts_talker {
             for (auto& q : prof_classes) if (q.stack == e.stack && q.N == e.N && q.K == e.K) { c = &q; break; }
             if (!c) {
                 qtts_gemm_class q{};
-                q.stack = e.stack; q.N = e.N; q.K = e.K; q.bytes_per_launch = eb * (double)e.N * e.K;
+                q.stack = e.stack; q.N = e.N; q.K = e.K; q.bytes_per_launch = e.bytes > 0 ? e.bytes : eb * (double)e.N * e.K;
                 q.min_us = 1e30;
                 prof_classes.push_back(q);
                 c = &prof_classes.back();
@@ -172,7 +173,7 @@ struct qtts_talker {
     // workgroup re-reads the whole x (M x K bf16) through its XCD's L2, so MORE workgroups also cost more (round-2 sweep,
     // profiles/r02_skinny_sweep_fs_M_temporal.txt).  Floor of 96 workgroups: measured 1.2 % faster per frame than 192 and than 48
     // (profiles/r02_ab_inproc_fs_floor.txt); QTTS_FS_MIN_WGS overrides it for A/B runs.
-    int fs_min_wgs = [] { const char* e = getenv("QTTS_FS_MIN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
+    int fs_min_wgs = [] { const char* e = QTTS_ENV("QTTS_FS_MIN_WGS"); return e && atoi(e) > 0 ? atoi(e) : 96; }();
     int choose_fs(int N, int K) const {
         if (!bf16) return 16;
         // a matrix of 16 MB or more is bound by what a CU can pull (~25 GB/s): it gets the full 192-workgroup floor (talker down,
@@ -208,17 +209,17 @@ struct qtts_talker {
     // Round 3 (profiles/r03_ab_swiglu8.md): at batch <= 8 the gate|up GEMM runs as N / 16 workgroups of ONE strip (8 gate + 8 up rows)
     // instead of N / 32 strip pairs -- 768 instead of 384 for the talker: three per CU instead of 1.5, 9.5 vs 10.7 us streamed.
     // Bit-identical results (the same per-element accumulation), a second packed copy of the operator.  QTTS_SWIGLU8=0: strip pairs.
-    bool swiglu8_env = [] { const char* e = getenv("QTTS_SWIGLU8"); return !e || atoi(e) != 0; }();
+    bool swiglu8_env = QTTS_OPT_ON("QTTS_SWIGLU8");
     // The code predictor's attention + o-projection of passes >= 1 as ONE launch (attention.hip: cp_attn_o_kernel; bf16 engines, batch <= 8):
     // 2.60 vs 2.68 ms per frame on the MI355X in its fourth version (profiles/r04_cp_attn_o.md; the first three were slower than the two
     // launches).  QTTS_CP_ATTN_O=0 (read at engine creation): attn_cp + the decode GEMM.
-    bool cp_attn_o_env = [] { const char* e = getenv("QTTS_CP_ATTN_O"); return !e || atoi(e) != 0; }();
-    int cp_attn_o_pause = [] { const char* e = getenv("QTTS_CP_ATTN_O_PAUSE"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 16; }();   // (A/B: x 64 clocks)
-    int cp_attn_o_step = [] { const char* e = getenv("QTTS_CP_ATTN_O_STEP"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 4; }();
+    bool cp_attn_o_env = QTTS_OPT_ON("QTTS_CP_ATTN_O");
+    int cp_attn_o_pause = [] { const char* e = QTTS_ENV("QTTS_CP_ATTN_O_PAUSE"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 16; }();   // (A/B: x 64 clocks)
+    int cp_attn_o_step = [] { const char* e = QTTS_ENV("QTTS_CP_ATTN_O_STEP"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 4; }();
     DevBuf ao_part;                    // cp_attn_o: [8 kv heads][8 rows][H] granules {partial sum, tag}
     int64_t cp_attn_o_count = 0, cp_front_count = 0;
     // ... with the layer's own q|k|v GEMM in front of it in the same launch (layers >= 1).  QTTS_CP_FRONT=0: the decode GEMM, then cp_attn_o.
-    bool cp_front_env = [] { const char* e = getenv("QTTS_CP_FRONT"); return !e || atoi(e) != 0; }();
+    bool cp_front_env = QTTS_OPT_ON("QTTS_CP_FRONT");
     DevBuf ao_qkv;                     // [8 rows][q|k|v width] granules {value, tag}
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
@@ -257,7 +258,7 @@ struct qtts_talker {
 
     void skinny(const SkinnyParams& p, hipStream_t st) {
         if (timing_now) {
-            LaunchEv e{nullptr, nullptr, cur_stack, p.N, p.K};
+            LaunchEv e{nullptr, nullptr, cur_stack, p.N, p.K, 0.0};
             QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
             ev.push_back(e);
             skinny_set_launch_events(e.a, e.b);
@@ -319,7 +320,7 @@ struct qtts_talker {
         // bf16 engines, code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k by kv head, partial
         // sums handed over as tagged granules and added in kv-head order; profiles/r04_cp_attn_o.md) -- and, where the layer has a q|k|v
         // GEMM of its own (layers >= 1: layer 0's row comes from the table), that GEMM in front of them in the same launch
-        const bool fuse_ao = L.o_p16.p && ao_part.p && att16 && !skinny_only && cp_attn_o_takes(a, d.H) && layer < 5 && len_static * 5 + layer < 128;
+        const bool fuse_ao = cp_attn_o_env && L.o_p16.p && ao_part.p && att16 && !skinny_only && cp_attn_o_takes(a, d.H) && layer < 5 && len_static * 5 + layer < 128;
         const bool front = fuse_ao && !skip_qkv && h16 && cp_front_env && d.H == 1024 && a.ld == 4 * 8 * (d.H / 128) * 16;
         if (!skip_qkv && !front) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
             if (splitk && sk_pending) {    // the previous layer's down-projection left (residual + half 0, half 1): added on the way in
@@ -333,12 +334,21 @@ struct qtts_talker {
             CpAttnOParams f{};
             f.a = a; f.Wo = L.o_p16.p; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
             f.part = ao_part.as<float>(); f.serial = ss.frame_serial; f.slot = len_static * 5 + layer; f.phase = 2;
-            f.err = ss.n_generated + 5; f.H = d.H; f.first_pause = cp_attn_o_pause; f.poll_step = cp_attn_o_step;
+            f.err = ss.n_generated + 5; f.done_latch = ss.done; f.H = d.H; f.first_pause = cp_attn_o_pause; f.poll_step = cp_attn_o_step;
             if (front) {
                 f.Wqkv = L.qkv_p.p; f.x16 = xs16; f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = ao_qkv.as<float>();
                 ++cp_front_count;
             }
-            launch_cp_attn_o(f, st);
+            if (timing_now) {          // bench.py's roofline leg: this launch timed on its own, as the decode GEMM's (stack 3: the fused launch)
+                const double eb = 2.0;
+                LaunchEv e{nullptr, nullptr, 3, front ? a.ld + d.H : d.H, front ? d.H : d.qd,
+                           eb * ((double)d.H * d.qd + (front ? (double)a.ld * d.H : 0.0))};
+                QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
+                ev.push_back(e);
+                cp_attn_o_set_launch_events(e.a, e.b);
+                try { launch_cp_attn_o(f, st); } catch (...) { cp_attn_o_set_launch_events(nullptr, nullptr); throw; }
+                cp_attn_o_set_launch_events(nullptr, nullptr);
+            } else launch_cp_attn_o(f, st);
             ++cp_attn_o_count;
         } else {
         if (!skinny_only) launch_attn_decode(a, st);
@@ -381,8 +391,8 @@ struct qtts_talker {
     // bucket -- SPLIT_KEYS keys per workgroup, at most attn_nsplit workgroups per (sequence, kv head).  Partitioning the static
     // capacity instead (round 2) left an engine created with max_seq = 4096 / 9216 (attach() / from_pretrained defaults) with 1-2
     // non-empty splits at 800 keys: the merge nodes' cost without the split's gain.
-    int SPLIT_FROM = [] { const char* e = getenv("QTTS_ATTN_SPLIT_FROM"); return e && atoi(e) > 0 ? atoi(e) : 320; }();   // (env: tests)
-    int SPLIT_KEYS = [] { const char* e = getenv("QTTS_ATTN_SPLIT_KEYS"); return e && atoi(e) >= 64 ? atoi(e) / 64 * 64 : 256; }();   // (env: tests)
+    int SPLIT_FROM = [] { const char* e = QTTS_ENV("QTTS_ATTN_SPLIT_FROM"); return e && atoi(e) > 0 ? atoi(e) : 320; }();   // (env: tests)
+    int SPLIT_KEYS = [] { const char* e = QTTS_ENV("QTTS_ATTN_SPLIT_KEYS"); return e && atoi(e) >= 64 ? atoi(e) / 64 * 64 : 256; }();   // (env: tests)
     std::map<int, std::pair<hipGraph_t, hipGraphExec_t>> graph_long;      // bucket (keys) -> captured long-sequence frame step
     int attn_nsplit_active = 1;        // what decode_layer launches (and what a capture in progress bakes in)
     int attn_span_active = 0;          // ... and the key span those workgroups partition (the bucket)
@@ -437,15 +447,58 @@ struct qtts_talker {
     }
     ~qtts_talker() {
         destroy_graph(); release_events();
-        if (cp_fused_slot) fused_engines().fetch_sub(1);
+        fused_release();
     }
-    // The fused code-predictor launch keeps 256 workgroups of 4 waves resident, every one of which may wait for six others: two such
-    // launches (two engines feeding one GPU, bench.py --workload clone-shard) fit beside each other on 256 CUs with room to spare
-    // (163 VGPRs: three workgroups per CU), four would not -- and partially resident launches that wait for their missing workgroups
-    // would hold each other's slots until the consumers give up.  So at most two engines of a process take the fused launch; a third
-    // keeps the separate launches (no performance claim is made for more than two engines per GPU at batch <= 8).
-    static std::atomic<int>& fused_engines() { static std::atomic<int> n{0}; return n; }
+    // The fused code-predictor launch (attention.hip: cp_attn_o_kernel) is correct only when ALL its workgroups are resident at once: every
+    // workgroup waits for granules that other workgroups of the same launch produce.  Residency is a property of the DEVICE, so the
+    // admission is per device (round 5): an engine takes the fused launch only while
+    //     (fused engines on its device, itself included) x grid  <=  hipOccupancyMaxActiveBlocksPerMultiprocessor(kernel) x compute units
+    // -- on a whole MI355X 3 x 256 = 768 slots for 256 workgroups per launch (three engines: bench.py --workload clone-shard runs two),
+    // on a CPX partition (32 CUs, 96 slots) none: those engines keep the separate launches.  Kernels that do not wait for anybody (the
+    // codec on another stream, another engine's GEMMs) only DELAY a fused launch: they drain, their slots go to the launch's pending
+    // workgroups (dispatch is in order), and the wait is bounded by their duration, far below the give-up limit.  What the rule cannot
+    // see is another PROCESS on the same device; a consumer that loses its producers there gives up after ~0.3 s, latches the stop flag
+    // (one give-up per generation, not per launch), the call fails with QTTS_ERR_STATE and the engine leaves the fused launch for good
+    // (`fused_retire`): the caller's retry runs on the separate launches.
+    struct FusedRegistry { std::mutex m; std::map<int, int> engines; };
+    static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
     bool cp_fused_slot = false;
+    int fused_device = -1, fused_capacity = 0;         // capacity: fused launches of this engine's grid the device holds at once
+    int cp_fused_per_step = 0;                         // fused launches in the frame step last launched / captured
+    int cp_fused_giveups = 0;                          // generations of this engine that ended on the give-up flag
+    // QTTS_CP_FUSED_MAX (A/B, tests): cap on fused engines per device below what residency allows
+    void fused_admit(int grid) {
+        QTTS_CHECK_HIP(hipGetDevice(&fused_device));
+        int cus = 0;
+        QTTS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fused_device));
+        fused_capacity = grid > 0 ? cp_attn_o_blocks_per_cu() * cus / grid : 0;
+        if (const char* e = QTTS_ENV("QTTS_CP_FUSED_MAX")) fused_capacity = std::min(fused_capacity, std::max(0, atoi(e)));
+        auto& r = fused_registry();
+        std::lock_guard<std::mutex> lk(r.m);
+        int& n = r.engines[fused_device];
+        if (n + 1 <= fused_capacity) { ++n; cp_fused_slot = true; }
+    }
+    void fused_release() {
+        if (!cp_fused_slot) return;
+        auto& r = fused_registry();
+        std::lock_guard<std::mutex> lk(r.m);
+        --r.engines[fused_device];
+        cp_fused_slot = false;
+    }
+    // after a give-up: this engine runs the separate launches from now on (graphs that baked the fused launch in are dropped)
+    void fused_retire() {
+        ++cp_fused_giveups;
+        cp_attn_o_env = false;
+        fused_release();
+        destroy_graph();
+        graph_nodes = 0;
+    }
+    void check_fused_flag(int flag, const char* where) {
+        if (!flag) return;
+        fused_retire();
+        throw Error(QTTS_ERR_STATE, std::string(where) + ": a cp_attn_o consumer gave up waiting for its producers' granules (the fused launch was not "
+                                    "fully resident: another process on the device?); this engine now uses the separate launches -- retry the request");
+    }
 };
 
 void qtts_talker::finalize() {
@@ -460,8 +513,8 @@ void qtts_talker::finalize() {
     QTTS_REQUIRE(td.I % 16 == 0 && cd.I % 16 == 0, QTTS_ERR_ARG, "intermediate sizes % 16");
     const int G = c.num_code_groups;
     if (bf16 && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0) {
-        if (fused_engines().fetch_add(1) < 2) cp_fused_slot = true;
-        else { fused_engines().fetch_sub(1); cp_attn_o_env = false; }
+        fused_admit(cp_attn_o_grid(cd.H));
+        if (!cp_fused_slot) cp_attn_o_env = false;
     } else cp_attn_o_env = false;
     tl.resize(c.num_hidden_layers);
     for (int l = 0; l < c.num_hidden_layers; ++l) build_layer(tl[l], "model.layers." + std::to_string(l) + ".", td, true);
@@ -552,7 +605,7 @@ void qtts_talker::finalize() {
     const int pps = cdiv(c.max_seq, 16);
     // bf16 talker cache: V pages transposed ([dim][16 keys]) -- the A-operand image of the PV product of attn_tk16_kernel, which runs
     // both attention products on the matrix pipe (QTTS_ATTN_MFMA=0: the VALU kernel attn_tk on row-major V pages, for A/B runs)
-    const bool attn_mfma = bf16 && !(getenv("QTTS_ATTN_MFMA") && getenv("QTTS_ATTN_MFMA")[0] == '0');
+    const bool attn_mfma = bf16 && QTTS_OPT_ON("QTTS_ATTN_MFMA");
     kv_t = {nullptr, nullptr, nullptr, pps, pps * c.max_batch, td.nkv, td.hd, bf16 ? 1 : 0, 1, attn_mfma ? 1 : 0};
     const size_t tb = (size_t)c.num_hidden_layers * kv_t.n_pages * td.nkv * 16 * td.hd * esz;
     kpool_t.alloc(tb); vpool_t.alloc(tb);
@@ -570,7 +623,7 @@ void qtts_talker::finalize() {
     }
     // a sequence that can grow past 512 keys is read by several workgroups per (sequence, kv head): one CU pulls ~25 GB/s, and a
     // 60 s utterance has 0.4 MB of K / V per head and layer (measured 52 us per layer at 800 keys with one workgroup)
-    if (const char* e = getenv("QTTS_ATTN_NSPLIT")) attn_nsplit = std::max(1, std::min(16, atoi(e)));
+    if (const char* e = QTTS_ENV("QTTS_ATTN_NSPLIT")) attn_nsplit = std::max(1, std::min(16, atoi(e)));
     else attn_nsplit = c.max_seq > 512 ? std::min(16, cdiv(c.max_seq, SPLIT_KEYS)) : 1;
     if (attn_nsplit > 1) attn_part.alloc(attn_part_floats(c.max_batch, td.nkv, attn_nsplit, td.nh / td.nkv) * sizeof(float));
     kv_t.k = kpool_t.p; kv_t.v = vpool_t.p; kv_t.page_table = ptab_t.as<int>();
@@ -656,7 +709,7 @@ void qtts_talker::prefill(const float* embeds, int B_, int T, const int32_t* n_p
     // written as bf16 by its producer (the GEMM rounded it the same way while staging: bit-identical results) and read at half the
     // bytes; these small-grid GEMMs are bound by what a CU can pull (gemm_tap.hip, gemm_wide_kernel).  The bf16 tensors live in the
     // fp32 buffers' storage.  QTTS_PREFILL_A16=0: fp32 hand-over (A/B runs and the equality test).
-    const bool a16_env = [] { const char* e = getenv("QTTS_PREFILL_A16"); return !e || atoi(e) != 0; }();   // (read per call: the test runs both)
+    const bool a16_env = QTTS_OPT_ON("QTTS_PREFILL_A16");   // (read per call: the test runs both)
     // (the SwiGLU GEMM with bf16 input exists in the wide-K kernel only: K = H a multiple of 128, at least 512)
     const bool a16 = bf16 && a16_env && H >= 512 && H % 128 == 0 && td.qd % 8 == 0 && td.I % 32 == 0;
     auto gemm = [&](const DevBuf& Wr, int N, int K, const float* A, int lda, float* C, int ldc, int act_, const float* res, bool out16 = false) {
@@ -728,6 +781,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
                              int max_frames, hipStream_t st) {
     const auto& c = cfg;
     const int G = c.num_code_groups;
+    const int64_t fused_before = cp_attn_o_count;
     // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
     cur_stack = 1;
     for (int j = 0; j < G - 1; ++j) {
@@ -814,6 +868,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     cur_stack = 2;
     skinny(h, st);
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
+    cp_fused_per_step = (int)(cp_attn_o_count - fused_before);      // (a captured step replays exactly these launches)
 }
 
 // ============================================================================================ C ABI
@@ -1048,8 +1103,8 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     if (t->profile == 1) t->aggregate_profile();
     int fin[6];
     QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    t->check_fused_flag(fin[5], "generate");
     QTTS_REQUIRE(fin[3] == 1, QTTS_ERR_STATE, "generate: loop ended without the stop condition being latched");
-    QTTS_REQUIRE(fin[5] == 0, QTTS_ERR_STATE, "generate: a cp_attn_o reducer gave up waiting for its producers' partial sums");
     *n_frames_host = fin[4] - 1;
     if (tokens_dev) {   // int32 history -> int64 (B, max_new_tokens)
         std::vector<int> h((size_t)B * max_new_tokens);
@@ -1152,8 +1207,10 @@ int qtts_talker_stream_step(qtts_talker* t, int32_t max_frames_now, int32_t* fra
     auto& g = t->sg;
     stream_launch_frames(t, max_frames_now, st);
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
-    int fin[5];
+    int fin[6];
     QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    if (fin[5]) g.active = false;                        // (no packet of a burst that lost a fused launch is handed out)
+    t->check_fused_flag(fin[5], "stream_step");
     // frames whose codes are final: every launched step that ran before the latch; after the latch exactly final_count - 1
     const int valid = fin[3] ? fin[4] - 1 : g.launched;
     *frames_total_host = std::min(valid, g.launched);
@@ -1170,8 +1227,8 @@ int qtts_talker_stream_end(qtts_talker* t, int64_t* tokens_dev, int32_t* n_frame
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
     int fin[6];
     QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
-    QTTS_REQUIRE(fin[5] == 0, QTTS_ERR_STATE, "stream_end: a cp_attn_o reducer gave up waiting for its producers' partial sums");
     g.active = false;
+    t->check_fused_flag(fin[5], "stream_end");
     t->frames_run = g.launched;
     // an abandoned stream (ended before the stop condition) reports the frames produced so far
     const int n_tok = fin[3] ? fin[4] : fin[0];
@@ -1201,6 +1258,10 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     out->frames_run = t->frames_run; out->graph_nodes = t->graph_nodes; out->weight_bytes_per_frame = t->weight_bytes_frame;
     out->gemm_ms_last = t->prof_ms; out->gemm_launches_last = t->prof_launches;
     out->long_graphs = (int32_t)t->graph_long.size(); out->attn_nsplit_last = t->attn_nsplit_active; out->attn_span_last = t->attn_span_active;
+    out->cp_fused_per_step = t->cp_fused_slot ? t->cp_fused_per_step : 0;
+    out->cp_fused_launches_last = (int64_t)out->cp_fused_per_step * t->frames_run;
+    out->cp_fused_giveups = t->cp_fused_giveups; out->cp_fused_capacity = t->fused_capacity; out->cp_fused_active = t->cp_fused_slot ? 1 : 0;
+    out->reserved2_ = 0;
     QTTS_API_END
 }
 int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n) {
@@ -1246,7 +1307,7 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     DevBuf W, x, out, res, ssin, done;
     // QTTS_DEBUG_WBUFS=n: the launches of the chain rotate through n copies of the operator (n x bytes beyond the caches = every launch
     // streams from HBM / the Infinity Cache, as in the frame step; 1 = the same L2-resident operator every time)
-    const int wbufs = [] { const char* e = getenv("QTTS_DEBUG_WBUFS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    const int wbufs = [] { const char* e = QTTS_ENV("QTTS_DEBUG_WBUFS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
     const size_t wbytes = skinny_packed_bytes(N, K, true);
     W.alloc(wbytes * wbufs);
     {
@@ -1266,7 +1327,7 @@ int qtts_debug_skinny_chain(int32_t N, int32_t K, int32_t M, int32_t act, int32_
     p.x = x.as<float>(); p.ldx = K; p.M = M; p.Wp = W.p; p.N = N; p.K = K; p.eps = 1e-6f; p.act = act;
     p.x_bf16 = 1;                                   // as in the frame step: the producer's bf16 copy of x
     if (!glu) { int fs = 16; while (fs > 4 && N / fs < 192) fs /= 2; p.fs = fs; }     // the engine's choose_fs
-    if (const char* e = getenv("QTTS_DEBUG_FS")) { if (!glu && atoi(e) > 0) p.fs = atoi(e); }
+    if (const char* e = QTTS_ENV("QTTS_DEBUG_FS")) { if (!glu && atoi(e) > 0) p.fs = atoi(e); }
     if (with_norm) { p.norm = 1; p.ss_in = ssin.as<float>(); }
     if (with_res) { p.res = res.as<float>(); p.ldr = No; }
     p.out = out.as<float>(); p.ldo = No; p.done_flag = done.as<int>(); p.ablate = ablate;

@@ -532,6 +532,22 @@ def cfg_dict(c) -> dict:
     return asdict(c)
 
 
+def rand_audio(seed: int, batch: int, samples: int, sr: int = 24000) -> np.ndarray:
+    """Seeded speech-shaped test audio (batch, samples) float32 in (-1, 1): a few harmonics of a drifting f0 under a slow amplitude
+    envelope plus a little noise.  Shared by oracle/gen_golden.py (reference run) and the tests, so the waveform itself is never stored."""
+    g = np.random.default_rng(seed)
+    t = np.arange(samples, dtype=np.float64) / sr
+    out = np.zeros((batch, samples), np.float64)
+    for b in range(batch):
+        f0 = g.uniform(100.0, 280.0) * (1.0 + 0.08 * np.sin(2 * np.pi * g.uniform(1.0, 3.0) * t + g.uniform(0, 6.28)))
+        ph = 2 * np.pi * np.cumsum(f0) / sr
+        x = sum(g.uniform(0.2, 1.0) / (h + 1) * np.sin((h + 1) * ph + g.uniform(0, 6.28)) for h in range(6))
+        env = 0.55 + 0.45 * np.sin(2 * np.pi * g.uniform(2.0, 5.0) * t + g.uniform(0, 6.28))
+        x = 0.25 * x * env + 0.01 * g.standard_normal(samples)
+        out[b] = x
+    return np.clip(out, -0.99, 0.99).astype(np.float32)
+
+
 def rand_prompt(g: np.random.Generator, t: TalkerCfg, lens, n_trail: int, scale: float = 0.05):
     """Synthetic inputs at the `talker.generate` seam: ragged LEFT-padded embeds (B,T,H), mask (B,T),
     trailing text (B,n_trail,H), tts_pad (1,1,H) as torch tensors.  Shared by gen_golden / tests / bench."""

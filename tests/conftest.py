@@ -8,8 +8,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-# the library copies its A/B environment switches once (csrc/common.h QTTS_ENV); tests flip them with monkeypatch inside one process
-os.environ.setdefault("QTTS_DEBUG_ENV_LIVE", "1")
+# A/B switches of the library are flipped through its C ABI (qtts_set_option, include/qtts.h) -- the `qopt` fixture below -- never through
+# os.environ inside the process: the library looks at the environment once per switch.
 
 
 def pytest_configure(config):
@@ -29,3 +29,22 @@ def libqtts():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m.build(verbose=False)
+
+
+@pytest.fixture
+def qopt():
+    """qopt(lib, "QTTS_X", value): set an A/B switch of `lib` (a ctypes handle of libqtts / the host-emulation build) through the C ABI;
+    value None removes the override.  Every switch set through the fixture is cleared again when the test ends."""
+    import ctypes as C
+    touched = []
+
+    def set_(lib, name, value):
+        lib.qtts_set_option.argtypes = [C.c_char_p, C.c_char_p]
+        lib.qtts_set_option.restype = C.c_int
+        rc = lib.qtts_set_option(name.encode(), None if value is None else str(value).encode())
+        assert rc == 0, (name, value, rc)
+        touched.append((lib, name))
+
+    yield set_
+    for lib, name in touched:
+        lib.qtts_set_option(name.encode(), None)

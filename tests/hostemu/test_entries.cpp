@@ -171,9 +171,9 @@ extern "C" int hostemu_attn_decode(const float* qkv, int ld, int B, int n_new, i
         p.kv.k = kpool; p.kv.v = vpool; p.kv.page_table = page_table; p.kv.pages_per_seq = pages_per_seq;
         p.kv.n_pages = B * pages_per_seq; p.kv.nkv = nkv; p.kv.hd = 128; p.kv.bf16 = bf16; p.kv.contig = page_table ? 0 : 1;
         p.layer = 0; p.out = out; p.ldo = ldo; p.out_bf16 = 0; p.max_len = max_len; p.done_flag = nullptr;
-        if (const char* e = getenv("QTTS_DEBUG_ATTN_VT")) p.kv.vt = atoi(e) != 0;        // V pool given dim-major inside its pages (attn_tk16)
+        if (const char* e = QTTS_ENV("QTTS_DEBUG_ATTN_VT")) p.kv.vt = atoi(e) != 0;        // V pool given dim-major inside its pages (attn_tk16)
         std::vector<float> part;
-        if (const char* e = getenv("QTTS_DEBUG_ATTN_NSPLIT")) {      // split-KV variant of the talker call shape
+        if (const char* e = QTTS_ENV("QTTS_DEBUG_ATTN_NSPLIT")) {      // split-KV variant of the talker call shape
             if (atoi(e) > 1 && n_new == 1 && p.len_dev) {
                 p.nsplit = atoi(e);
                 part.assign(qtts::attn_part_floats(B, nkv, p.nsplit, nh / nkv), NAN);
@@ -277,9 +277,13 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
                 int serial2 = serial + 1;
                 if (variant == 2) c2.serial = &serial2;
                 err = 0;
+                int latch = 0;
+                c2.done_latch = &latch;
                 qtts::launch_cp_attn_o(c2, nullptr);
                 if ((variant == 0) != (err == 0)) return -5 - variant;
+                if ((err != 0) != (latch != 0)) return -9;                         // a give-up latches the generation's stop flag ...
                 if (variant == 0 && memcmp(out, keep.data(), keep.size() * 4) != 0) return -8;
+                if (variant != 0 && memcmp(out, res, (size_t)B * H * 4) != 0) return -10;      // ... and leaves the hidden state as it was
             }
             memcpy(out, keep.data(), keep.size() * 4);
             memcpy(out16, keep16.data(), keep16.size() * 2);

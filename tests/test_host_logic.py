@@ -125,7 +125,7 @@ def test_bench_self_launches_two_ranks_gloo_on_the_emulator():
     tests/hostemu/bench_emu.py, which calls bench.main(device="cpu") (bench.py itself cannot load anything but the HIP
     library; the line is marked INVALID as a measurement); on an N-GPU box the same path runs nccl = RCCL."""
     j = _bench_on_emulator("--gpus", "2", "--backend", "gloo", "--model", "tiny", "--batch", "2", "--frames", "3", "--steps", "1",
-                           "--warmup", "0", "--no-roofline", "--no-cpu-baseline", "--talker-dtype", "f32", "--codec-dtype", "f32")
+                           "--warmup", "0", "--no-roofline", "--no-cpu-baseline", "--no-configs", "--talker-dtype", "f32", "--codec-dtype", "f32")
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 4 and j["backend"] == "gloo"
     assert j["gather_ms_per_step"] > 0 and "INVALID" in j and j["scaling"] == "weak"
     # what the ranks report through the process group (VERDICT r2 item 8)
@@ -137,10 +137,28 @@ def test_bench_api_e2e_leg_on_the_emulator():
     """bench.py's `api_e2e` leg (round 4): `Qwen3TTSModel.generate_custom_voice` from Python strings to host numpy waveforms, timed
     end to end next to the S2 step, with the parts the S2 step does not contain itemised.  Here: tiny dims on the emulator."""
     j = _bench_on_emulator("--gpus", "1", "--model", "tiny", "--batch", "2", "--frames", "3", "--steps", "1", "--warmup", "0",
-                           "--no-roofline", "--no-cpu-baseline", "--no-parity-mode", "--talker-dtype", "f32", "--codec-dtype", "f32")
+                           "--no-roofline", "--no-cpu-baseline", "--no-parity-mode", "--no-configs", "--talker-dtype", "f32", "--codec-dtype", "f32")
     a = j["api_e2e"]
     assert "INVALID" in j and a["calls"] >= 1 and a["ms_per_call"] > 0 and a["frames_generated_per_row"] == 3
     assert 0 < a["frames_returned_mean"] <= 3 and set(a["not_in_s2_ms"]) and a["s2_ms_per_step"] == j["ms_per_step"]
+
+
+def test_bench_configs_and_voice_clone_prompt_legs_on_the_emulator():
+    """bench.py's `configs` leg (round 5: BASELINE configs 2-5 on the driver's line -- codec-only, the small model at batch 8, first packet
+    at batch 32, the clone-shard job at N = 1) and its `voice_clone_prompt` leg (create_voice_clone_prompt through the real wrapper, the two
+    encoders behind it), at test dims on the emulator: every sub-object is there, carries its numbers and its roofline denominator."""
+    j = _bench_on_emulator("--gpus", "1", "--model", "tiny", "--batch", "2", "--frames", "3", "--steps", "1", "--warmup", "0",
+                           "--no-roofline", "--no-cpu-baseline", "--no-parity-mode", "--no-api-e2e", "--talker-dtype", "f32", "--codec-dtype", "f32")
+    c = j["configs"]
+    assert "error" not in c, c
+    assert set(c) >= {"config2_codec_only", "config3_06b_b8", "config4_first_packet_b32", "config5_clone_shard_n1", "leg_seconds"}
+    assert [r["dtype"] for r in c["config2_codec_only"]["runs"]] == ["f32"] and all(r["ms_p50"] > 0 and r["roofline"]["bound"] == "mfma" for r in c["config2_codec_only"]["runs"])
+    assert c["config3_06b_b8"]["value"] > 0 and c["config3_06b_b8"]["roofline"]["bound"] == "hbm" and c["config3_06b_b8"]["roofline"]["achieved"] >= 0
+    assert c["config4_first_packet_b32"]["p50_ms"] > 0 and c["config4_first_packet_b32"]["p99_ms"] >= c["config4_first_packet_b32"]["p50_ms"]
+    assert c["config5_clone_shard_n1"]["value"] > 0 and c["config5_clone_shard_n1"]["engines_per_gpu"] == 2 and c["config5_clone_shard_n1"]["roofline"]["achieved"] >= 0
+    v = j["voice_clone_prompt"]
+    assert "error" not in v, v
+    assert v["runs"] and all(r["ms_per_call"] > 0 and r["encoder_batched_ms"] > 0 and r["speaker_clip_by_clip_ms"] > 0 for r in v["runs"])
 
 
 def test_bench_clone_shard_strong_scaling_two_ranks_gloo_on_the_emulator():

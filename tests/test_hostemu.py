@@ -310,13 +310,13 @@ def test_gemm_tap2_tap_reuse_kernel_real_source(emu):
             assert np.all(out16[:, N:] == 0x4242)
 
 
-def test_gemm_dma_lds_dma_staged_kernel_real_source(emu, monkeypatch):
+def test_gemm_dma_lds_dma_staged_kernel_real_source(emu, qopt):
     """gemm_dma (round 4): gemm_tap2's arithmetic with both operands staged by LDS-DMA into two buffers -- per-lane source addresses
     that produce the padded 144-byte-row LDS image, 64-wide k-slabs, one barrier per step, the A tile re-staged only when the slab
     changes -- against float64 numpy: 7-tap convolutions at dilation 1 and 9 (halo 54, several sequences per tile, ragged last
     tile), the two-tap transposed-conv form, a plain Linear with residual and both outputs.  (The emulator completes a DMA at
     once: what it checks is addressing and bookkeeping; the barrier / DMA ordering is checked on the MI355X.)"""
-    monkeypatch.setenv("QTTS_GEMM_DMA", "1")
+    qopt(emu, "QTTS_GEMM_DMA", "1")
     g = np.random.default_rng(48)
     cases = [  # M, T, N, K, shifts, act, bias, res, out32, out16, snake16
         (300, 100, 128, 128, [-6, -5, -4, -3, -2, -1, 0], ACT_SNAKE, 1, 0, 0, 1, 0),
@@ -448,7 +448,7 @@ def test_skinny_kernel_real_source(emu, bf16):
         assert np.all(out[:, No:] == 7.0)
 
 
-def test_skinny_f32_batch8_kernel_real_source(emu, monkeypatch):
+def test_skinny_f32_batch8_kernel_real_source(emu, qopt):
     """skinny8_f32_kernel (round 4: the parity mode's frame-step GEMM at batch <= 8 -- tile pairs, whole-line x requests, DPP-rotated
     odd tiles, in-kernel RMSNorm statistics, three-chunk K = 6144) in every instantiation, against float64 numpy; no ss_in is
     handed over for the normalised cases (tests/hostemu/test_entries.cpp)."""
@@ -459,9 +459,9 @@ def test_skinny_f32_batch8_kernel_real_source(emu, monkeypatch):
              (4, 32, 2048, 0, ACT_SWIGLU, 0, 1, 8), (5, 32, 1024, 1, ACT_SWIGLU, 0, 0, 16)]
     for (M, N, K, norm, act, hb, hr, nw) in cases:
         if nw:
-            monkeypatch.setenv("QTTS_SKINNY8F_NW", str(nw))
+            qopt(emu, "QTTS_SKINNY8F_NW", str(nw))
         else:
-            monkeypatch.delenv("QTTS_SKINNY8F_NW", raising=False)
+            qopt(emu, "QTTS_SKINNY8F_NW", None)
         x = g.standard_normal((M, K + 4)).astype(np.float32)
         W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
         gw = (1 + 0.1 * g.standard_normal(K)).astype(np.float32) if norm else None
@@ -525,7 +525,7 @@ def test_skinny_f32_split_k_producer_and_combining_consumer(emu):
         assert np.all(z[:M, No:] == 7.0) and np.all(z[M] == 7.0)
 
 
-def test_skinny_bf16_kernel_frame_step_shapes(emu):
+def test_skinny_bf16_kernel_frame_step_shapes(emu, qopt):
     """skinny2_kernel the way the frame step launches it: x as the producer's bf16 copy, the real models' K (every wave owns the
     same number of k-tiles: the branch-free EXACT instantiations, one / two / three chunks), narrow strips (4 / 8 / 16
     features), M <= 16 / 32 / 64 rows, row variances from the X.X^T MFMA, bf16 shadow output -- against float64 numpy."""
@@ -554,7 +554,7 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
     for (M, N, K, fs, norm, act, hb, hr, sh), s8 in [(c, v) for c in cases for v in ("1", "0")]:
         if s8 == "0" and (act == ACT_SWIGLU8 or not (M <= 8 and K % 512 == 0 and fs >= 8)):
             continue                                      # (QTTS_SKINNY8=0: the same shapes through skinny2_kernel)
-        os.environ["QTTS_SKINNY8"] = s8
+        qopt(emu, "QTTS_SKINNY8", s8)
         x = (g.standard_normal((M, K + 8)) * 0.7).astype(np.float32)
         W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
         gw = (1 + 0.1 * g.standard_normal(K)).astype(np.float32) if norm else None
@@ -587,7 +587,6 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu):
             got = (out16[:, :No].astype(np.uint32) << 16).view(np.float32)
             assert np.abs(got - out[:, :No]).max() <= 8e-3 * max(1.0, float(np.abs(out).max())), "bf16 shadow differs from the fp32 output"
             assert np.all(out16[:, No:] == 0x4242)
-    os.environ.pop("QTTS_SKINNY8", None)
 
 
 @pytest.mark.parametrize("bf16", [0, 1])
@@ -872,16 +871,16 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
 
 
 @pytest.mark.parametrize("nsplit", [1, 3])
-def test_attn_tk16_matrix_pipe_kernel_real_source(emu, nsplit, monkeypatch):
+def test_attn_tk16_matrix_pipe_kernel_real_source(emu, nsplit, qopt):
     """attention.hip's `attn_tk16_kernel` (round 3: the talker's single-token decode attention with BOTH products on the matrix
     pipe; bf16 cache, V pages stored dim-major [128][16 keys]) from its real source against float64 numpy: q / k RMSNorm + RoPE,
     K row-major / V transposed append, left-pad mask, never-written slots holding NaN, GQA 2:1 and 1:1, cache lengths from 1 key
     to past the 256-key register window, contiguous and permuted page tables, alone and as split-KV partials + merge.  q, K, P, V
     enter the MFMA as bf16 (the precision of the reference's own bf16 attention), so the bar is bf16-sized: 2 % of the largest
     output and 0.4 % RMS; bit-identical across wave scheduling orders."""
-    monkeypatch.setenv("QTTS_DEBUG_ATTN_VT", "1")
+    qopt(emu, "QTTS_DEBUG_ATTN_VT", "1")
     if nsplit > 1:
-        monkeypatch.setenv("QTTS_DEBUG_ATTN_NSPLIT", str(nsplit))
+        qopt(emu, "QTTS_DEBUG_ATTN_NSPLIT", str(nsplit))
     g = np.random.default_rng(91 + nsplit)
     HD, eps = 128, 1e-6
     inv_freq = (1.0 / (10000.0 ** (np.arange(64) / 64.0))).astype(np.float32)
@@ -1421,13 +1420,13 @@ def test_talker_orchestration_greedy_vs_reference_golden(emu, golden_dir, use_gr
         emu.qtts_talker_destroy(h)
 
 
-def test_talker_split_kv_attention_and_graph_switch(emu, golden_dir, monkeypatch):
+def test_talker_split_kv_attention_and_graph_switch(emu, golden_dir, qopt):
     """Long-sequence mode of the talker's decode attention: an engine told to use split-KV (two attention workgroups per
     (sequence, kv head) + merge kernel) from 20 keys on starts a generation on the short-sequence frame graph and SWITCHES to the
     long-sequence graph mid-way (the knobs default to max_seq > 512 / 320 keys; QTTS_ATTN_NSPLIT / QTTS_ATTN_SPLIT_FROM bring the
     switch into the range of the tiny golden).  The reference's greedy codes must still come out bit for bit."""
-    monkeypatch.setenv("QTTS_ATTN_NSPLIT", "2")
-    monkeypatch.setenv("QTTS_ATTN_SPLIT_FROM", "20")
+    qopt(emu, "QTTS_ATTN_NSPLIT", "2")
+    qopt(emu, "QTTS_ATTN_SPLIT_FROM", "20")
     g = np.load(os.path.join(golden_dir, "talker_tiny.npz"))
     t = synth.talker_tiny()
     w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
@@ -1617,7 +1616,7 @@ def test_talker_fp32_split_k_layer_chain_vs_oracle(emu):
 
 
 @pytest.mark.parametrize("cp_hidden", [256, 1024])
-def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeypatch, cp_hidden):
+def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, qopt, cp_hidden):
     """Round 4: the ENGINE side of `cp_attn_o_kernel` -- the second packed copy of the o-projection (16-feature strips), the granule
     buffers and the frame serial the launch tags derive from, which passes take the fused launch (passes >= 1 of a bf16 engine at batch
     <= 8; pass 0 with its two new tokens keeps attn_cp0 + the decode GEMM) and which layers also take their q|k|v GEMM into it (layers
@@ -1638,7 +1637,7 @@ def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeyp
     res = {}
     try:
         for mode in ("1", "0"):
-            monkeypatch.setenv("QTTS_CP_ATTN_O", mode)
+            qopt(emu, "QTTS_CP_ATTN_O", mode)
             for use_graph in ((0, 1) if cp_hidden == 256 else (1,)):     # (eager == graph: the 256-wide case; the 1024-wide one is 4x the emulation time)
                 h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=use_graph)
                 try:
@@ -1666,36 +1665,61 @@ def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, monkeyp
     assert np.abs(fused[1][:, :k] - plain[1][:, :k]).max() <= 2e-2 * max(1.0, float(np.abs(plain[1][:, :k]).max()))
 
 
-def test_at_most_two_engines_of_a_process_take_the_fused_code_predictor_launch(emu, monkeypatch):
-    """The fused code-predictor launch keeps 256 workgroups resident that wait for each other; two such launches fit on the chip side by
-    side, four would not.  The engine therefore hands out two process-wide slots: a third bf16 engine alive at the same time keeps the
-    separate launches (more kernel nodes in its captured frame step), and a slot comes back when its engine is destroyed."""
+def test_fused_code_predictor_launch_is_admitted_per_device_by_residency(emu, qopt):
+    """The fused code-predictor launch keeps all its workgroups resident, every one of which waits for others of the same launch.  The
+    engine therefore asks the DEVICE at finalize (round 5): (fused engines on the device) x grid <= occupancy x compute units, counted
+    per device; an engine beyond that keeps the separate launches (more kernel nodes in its captured frame step), a place comes back when
+    its engine is destroyed, a device that cannot hold one launch (a CPX partition: here occupancy 0) admits nobody -- and
+    qtts_talker_stats says which path an engine took (cp_fused_per_step / cp_fused_launches_last / cp_fused_active / cp_fused_capacity)."""
     import dataclasses
-    monkeypatch.delenv("QTTS_CP_ATTN_O", raising=False)
     t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=256, cp_intermediate_size=256, cp_num_hidden_layers=2,
                             cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
     w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
     emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(29), t, [4, 3], 2, scale=0.5)
     args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
     emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+    fused_per_step = (t.num_code_groups - 2) * t.cp_num_hidden_layers
 
-    def nodes(h):
+    def run(h):
         _talker_generate(emu, h, t, *args, max_new=3)
         st = _lib.TalkerStatsC()
         _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
-        return int(st.graph_nodes)
+        return st
 
-    hs = [_talker_emu(emu, t, w, max_batch=2, max_seq=32, dtype=_lib.QTTS_BF16, use_graph=1) for _ in range(3)]
+    mk = lambda: _talker_emu(emu, t, w, max_batch=2, max_seq=32, dtype=_lib.QTTS_BF16, use_graph=1)
+    # (1) the emulated device: 256 compute units x 2 workgroups, 64 workgroups per launch at this width -> 8 places
+    h = mk()
     try:
-        n = [nodes(h) for h in hs]
-        fused_less = (t.num_code_groups - 2) * t.cp_num_hidden_layers
-        assert n[0] == n[1] and n[2] - n[0] == fused_less, n
+        st = run(h)
+        assert st.cp_fused_capacity == 2 * 256 // 64 and st.cp_fused_active == 1 and st.cp_fused_giveups == 0
+        assert st.cp_fused_per_step == fused_per_step and st.cp_fused_launches_last == fused_per_step * st.frames_run and st.frames_run >= 2
+        n_fused = int(st.graph_nodes)
+    finally:
+        emu.qtts_talker_destroy(h)
+    # (2) a cap of two places: the third engine alive at the same time keeps the separate launches; a destroyed engine's place is handed out again
+    qopt(emu, "QTTS_CP_FUSED_MAX", "2")
+    hs = [mk() for _ in range(3)]
+    try:
+        sts = [run(h) for h in hs]
+        assert [s.cp_fused_active for s in sts] == [1, 1, 0] and [s.cp_fused_per_step for s in sts] == [fused_per_step, fused_per_step, 0]
+        assert sts[2].cp_fused_launches_last == 0 and sts[2].cp_fused_capacity == 2
+        assert sts[0].graph_nodes == n_fused and sts[2].graph_nodes - n_fused == fused_per_step, [s.graph_nodes for s in sts]
         emu.qtts_talker_destroy(hs.pop(0))
-        hs.append(_talker_emu(emu, t, w, max_batch=2, max_seq=32, dtype=_lib.QTTS_BF16, use_graph=1))
-        assert nodes(hs[-1]) == n[0], "the slot of a destroyed engine was not handed out again"
+        hs.append(mk())
+        st = run(hs[-1])
+        assert st.cp_fused_active == 1 and st.graph_nodes == n_fused, "the place of a destroyed engine was not handed out again"
     finally:
         for h in hs:
             emu.qtts_talker_destroy(h)
+    qopt(emu, "QTTS_CP_FUSED_MAX", None)
+    # (3) a device that cannot keep one launch resident admits nobody
+    qopt(emu, "QTTS_HOSTEMU_CPAO_BLOCKS_PER_CU", "0")
+    h = mk()
+    try:
+        st = run(h)
+        assert st.cp_fused_capacity == 0 and st.cp_fused_active == 0 and st.cp_fused_per_step == 0 and st.graph_nodes - n_fused == fused_per_step
+    finally:
+        emu.qtts_talker_destroy(h)
 
 
 def test_talker_orchestration_no_projection_vs_oracle(emu):
@@ -1763,7 +1787,7 @@ def test_talker_bf16_small_batch_staged_path(emu, golden_dir):
         emu.qtts_talker_destroy(h)
 
 
-def test_talker_bf16_swiglu_single_strip_changes_nothing(emu, monkeypatch):
+def test_talker_bf16_swiglu_single_strip_changes_nothing(emu, qopt):
     """Round 3: at batch <= 8 the frame step's gate|up GEMM runs from a second packed copy of the operator -- 8 gate + 8 up rows per
     strip, one strip per workgroup (ACT_SWIGLU8), twice the workgroups of the strip pairs.  Every output element is accumulated by the
     same MFMA sequence either way, so codes, tokens and hidden states must be bit-identical with QTTS_SWIGLU8=0 (strip pairs), at dims
@@ -1774,7 +1798,7 @@ def test_talker_bf16_swiglu_single_strip_changes_nothing(emu, monkeypatch):
     emb, mask, tr, pad = [x.numpy() for x in synth.rand_prompt(np.random.default_rng(8), t, [7, 5, 9], 2, scale=0.05)]
     outs = []
     for on in ("1", "0"):
-        monkeypatch.setenv("QTTS_SWIGLU8", on)
+        qopt(emu, "QTTS_SWIGLU8", on)
         h = _talker_emu(emu, t, w, max_batch=4, max_seq=32, dtype=_lib.QTTS_BF16)
         try:
             outs.append(_talker_generate(emu, h, t, emb, mask, tr, pad, max_new=4))
@@ -1784,7 +1808,7 @@ def test_talker_bf16_swiglu_single_strip_changes_nothing(emu, monkeypatch):
     assert c1.shape[1] >= 2 and np.array_equal(c1, c0) and np.array_equal(k1, k0) and np.array_equal(h1, h0)
 
 
-def test_talker_bf16_prefill_bf16_handover_changes_nothing(emu, monkeypatch):
+def test_talker_bf16_prefill_bf16_handover_changes_nothing(emu, qopt):
     """Round 3: in bf16 mode the prefill's GEMM-only tensors (normed rows, attention output, SwiGLU product) are written as bf16 by
     their producers (rmsnorm16, attn_rows out16, the SwiGLU epilogue's C16) and read by the wide-K GEMM's bf16-activation
     instantiations.  The GEMM rounded them the same way while staging, so every code and every hidden state must come out
@@ -1795,7 +1819,7 @@ def test_talker_bf16_prefill_bf16_handover_changes_nothing(emu, monkeypatch):
     emb, mask, tr, pad = [x.numpy() for x in synth.rand_prompt(np.random.default_rng(5), t, [9, 6, 7], 2, scale=0.05)]
     outs = []
     for a16 in ("1", "0"):
-        monkeypatch.setenv("QTTS_PREFILL_A16", a16)
+        qopt(emu, "QTTS_PREFILL_A16", a16)
         h = _talker_emu(emu, t, w, max_batch=4, max_seq=32, dtype=_lib.QTTS_BF16)
         try:
             outs.append(_talker_generate(emu, h, t, emb, mask, tr, pad, max_new=3))

@@ -257,6 +257,42 @@ def test_codec_encoder_oracle_vs_reference_golden(golden_dir):
     assert [r.shape[0] for r in rows] == [21, 11]          # ceil(331 / 16), ceil(170 / 16)
 
 
+def test_encoders_at_released_dims_oracle_vs_reference_golden(golden_dir):
+    """f3 / f4 at the RELEASED dimensions: the oracle restatements against what the reference's own classes produced
+    for 3 s of audio, batch 2 -- `codec_enc_real.npz` (Qwen3TTSTokenizerV2Encoder: Mimi hidden 512, 8 layers, 32 codebooks of 2048 x 256)
+    and `speaker_real.npz` (Qwen3TTSSpeakerEncoder + mel_spectrogram, enc_dim 2048).  The waveforms are regenerated from the stored seed
+    (synth.rand_audio), as on the GPU box; the GPU suite runs the HIP engines against the same two fixtures."""
+    import codec_enc_ref
+    import speaker_ref
+    g = np.load(os.path.join(golden_dir, "codec_enc_real.npz"))
+    c = synth.mimi_enc_real()
+    w = synth.mimi_enc_weights(c)
+    assert abs(synth.weights_checksum(w) - float(g["weights_checksum"])) < 1e-6 * max(1.0, abs(float(g["weights_checksum"])))
+    x = torch.from_numpy(synth.rand_audio(int(g["seed"]), 2, int(g["samples"])))[:, None]
+    with torch.no_grad():
+        mg = []
+        codes = codec_enc_ref.mimi_encode(_td(w), c, x, margins=mg).numpy()
+    want = g["codes"].astype(np.int64)
+    assert codes.shape == want.shape == (2, c.num_quantizers, 38)
+    # bit-exact except behind a near-tie (the stored margin of the reference's own winner): the first differing codebook of a frame, if any
+    bad = codes != want
+    for b, t in zip(*np.nonzero(bad.any(1))):
+        q = int(np.argmax(bad[b, :, t]))
+        assert g["margin"][b, q, t] < 1e-4, (b, q, t, float(g["margin"][b, q, t]))
+    assert float(bad.mean()) <= 0.001
+    assert np.abs(torch.stack(mg, 1).numpy() - g["margin"])[~bad].max() <= 1e-3
+    gs = np.load(os.path.join(golden_dir, "speaker_real.npz"))
+    cs = synth.speaker_real()
+    ws = synth.speaker_weights(cs)
+    assert abs(synth.weights_checksum(ws) - float(gs["weights_checksum"])) < 1e-6 * max(1.0, abs(float(gs["weights_checksum"])))
+    a = torch.from_numpy(synth.rand_audio(int(gs["seed"]), 2, int(gs["samples"])))
+    with torch.no_grad():
+        mel = speaker_ref.mel_spectrogram(a)
+        emb = speaker_ref.speaker_encoder_forward(_td(ws), cs, mel.transpose(1, 2)).numpy()
+    assert mel.shape[-1] == int(gs["mel_frames"]) and abs(float(mel.double().sum()) - float(gs["mel_sum"])) <= 1e-6 * abs(float(gs["mel_sum"]))
+    assert emb.shape == (2, 2048) and np.abs(emb - gs["embedding"]).max() <= 1e-4
+
+
 def test_staged_stream_bookkeeping_matches_full_forward(codec_tiny):
     """oracle/codec_stage_emul.py mirrors the staging / skip / carry bookkeeping of the C++ `stream_push`
     (codec_engine.hip) with whole-buffer oracle ops: any packetisation must reproduce the whole-sequence forward."""
