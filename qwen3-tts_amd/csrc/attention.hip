@@ -1339,12 +1339,7 @@ static void launch_attn_decode_t(const AttnDecodeParams& p, size_t lds, hipStrea
 template <typename KVT, int NQ, bool CT>
 static void launch_attn_decode_c(const AttnDecodeParams& p, size_t lds, hipStream_t st) {
     auto kern = attn_decode_kernel<KVT, NQ, CT>;
-    static bool attr_set = false;      // one flag per instantiation
-    if (lds > 48 * 1024 && !attr_set) {
-        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024));
-        attr_set = true;
-    }
+    if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 150 * 1024);
     hipLaunchKernelGGL(kern, dim3(p.B * p.nkv), dim3(256), lds, st, p);
 }
 

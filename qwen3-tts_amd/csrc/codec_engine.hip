@@ -5,6 +5,7 @@
 // is one `gemm_tap` launch (see gemm_tap.hip).  Stage order follows Qwen3TTSTokenizerV2Decoder.forward
 // (tokenizer v2:869-884); chunking follows chunked_decode (v2:886-896).
 #include <map>
+#include <set>
 #include <mutex>
 #include <atomic>
 #include <tuple>
@@ -124,7 +125,11 @@ struct qtts_codec {
             size_t nn = 0;
             QTTS_CHECK_HIP(hipGraphGetNodes(slot.g, nullptr, &nn));
             slot.nodes = (int)nn;
-            QTTS_CHECK_HIP(hipGraphInstantiate(&slot.ge, slot.g, nullptr, nullptr, 0));
+            if (hipGraphInstantiate(&slot.ge, slot.g, nullptr, nullptr, 0) != hipSuccess) {      // (no half-built slot survives a failure)
+                (void)hipGraphDestroy(slot.g);
+                graphs.erase(key);
+                throw Error(QTTS_ERR_HIP, "codec: hipGraphInstantiate failed");
+            }
             ++graph_captures;
         }
         copy_in(st);
@@ -134,14 +139,27 @@ struct qtts_codec {
         graph_nodes_replayed = slot.nodes;
         evict();
     }
+    // Captured graphs and shapes that were merely SEEN once are bounded separately: a run of one-off shapes (variable-length
+    // non-streaming decode) can push out neither a captured graph nor -- before SEEN_SLOTS of them -- the memory of a shape's first sighting.
+    static constexpr size_t SEEN_SLOTS = 64;
     void evict() {
-        while (graphs.size() > GRAPH_SLOTS) {
-            auto lru = graphs.begin();
-            for (auto it = graphs.begin(); it != graphs.end(); ++it) if (it->second.last_use < lru->second.last_use) lru = it;
-            if (lru->second.ge) (void)hipGraphExecDestroy(lru->second.ge);
-            if (lru->second.g) (void)hipGraphDestroy(lru->second.g);
-            graphs.erase(lru);
-        }
+        auto drop_lru = [&](bool captured, size_t cap) {
+            for (;;) {
+                size_t n = 0;
+                auto lru = graphs.end();
+                for (auto it = graphs.begin(); it != graphs.end(); ++it) {
+                    if ((it->second.ge != nullptr) != captured) continue;
+                    ++n;
+                    if (lru == graphs.end() || it->second.last_use < lru->second.last_use) lru = it;
+                }
+                if (n <= cap) return;
+                if (lru->second.ge) (void)hipGraphExecDestroy(lru->second.ge);
+                if (lru->second.g) (void)hipGraphDestroy(lru->second.g);
+                graphs.erase(lru);
+            }
+        };
+        drop_lru(true, GRAPH_SLOTS);
+        drop_lru(false, SEEN_SLOTS);
     }
     void check_codes_flag(hipStream_t st) {
         int e = 0;
@@ -893,6 +911,16 @@ struct OptTable {
 };
 OptTable& opt_table() { static OptTable t; return t; }
 }  // namespace
+void ensure_dynamic_lds(const void* kern, int bytes) {
+    static std::mutex m;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    QTTS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(m);
+    if (done.count({kern, dev})) return;
+    QTTS_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({kern, dev});
+}
 const char* opt_lookup(const char* var, unsigned& gen_seen, std::string& cache, bool& has) {
     auto& t = opt_table();
     const unsigned cur = t.gen.load(std::memory_order_acquire);

@@ -56,6 +56,10 @@ const char* opt_lookup(const char* var, unsigned& gen_seen, std::string& cache, 
 #define QTTS_OPT_ON(var) ([]() -> bool { const char* e_ = QTTS_ENV(var); return !e_ || atoi(e_) != 0; }())
 #define QTTS_OPT_SET(var) ([]() -> bool { const char* e_ = QTTS_ENV(var); return e_ && atoi(e_) != 0; }())
 
+// hipFuncSetAttribute(kern, MaxDynamicSharedMemorySize, bytes) once per (kernel, DEVICE), thread-safe: a process-wide `static bool`
+// would leave a second device of the process without the attribute and is shared between engine threads.  (codec_engine.hip)
+void ensure_dynamic_lds(const void* kern, int bytes);
+
 // ------------------------------------------------------------------------------------------ bf16
 typedef uint16_t bf16_t;
 

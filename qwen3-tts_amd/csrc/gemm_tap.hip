@@ -613,12 +613,7 @@ static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
     const int cap = (128 + halo + 7) & ~7;
     const size_t lds = ((size_t)(p.taps > 1 ? 1 : 2) * cap + 2 * BN) * (BK + 8) * 2;
     auto kern = gemm_tap2_kernel<BN, BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo, cap);
 }
 
@@ -636,6 +631,14 @@ static void launch_tap2(const GemmTapParams& p, int halo, hipStream_t st) {
 // Sequence-start zeroing, tap offsets, epilogue: exactly gemm_tap2's.
 __device__ __forceinline__ void gd_dma16(const void* src, void* lds_dst) {       // 64 lanes x 16 B -> 1 KiB of LDS, lane-linear
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// The barrier alone does not order another wave's reads behind this wave's LDS-DMA: the data is in LDS when the REQUESTING wave's vmcnt
+// says so.  The compiler's barrier fence emits the wait today (tools/isa_waits.py dma_barriers pins that for every kernel that uses
+// global_load_lds); the kernel whose loop depends on it says it itself.
+__device__ __forceinline__ void gd_dma_wait() {
+#ifndef QTTS_HOST_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 template <int BN>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmTapParams p, int halo, int a_stride /* bytes of one A buffer, multiple of 1024 */) {
@@ -718,7 +721,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(GemmTapParams p, int h
     dma_w(0, 0, 0);
     for (int s = 0; s < nsteps; ++s) {
         const int ks = s / p.taps, tap = s - ks * p.taps;
-        __syncthreads();                               // step s's tiles are in LDS; every wave is done with step s - 1's
+        gd_dma_wait();                                 // this wave's DMA requests of step s have landed (explicit: ADVICE r4) ...
+        __syncthreads();                               // ... and every other wave's: step s's tiles are in LDS; every wave is done with step s - 1's
         if (s + 1 < nsteps) {
             const int ks2 = (s + 1) / p.taps, tap2 = (s + 1) - ks2 * p.taps;
             dma_w(ks2, tap2, (s + 1) & 1);             // (last read in step s - 1)
@@ -754,11 +758,7 @@ static void launch_dma(const GemmTapParams& p, int halo, hipStream_t st) {
     const int a_stride = ((128 + halo) * 144 + 1023) / 1024 * 1024;
     const size_t lds = 2 * (size_t)a_stride + 2 * (size_t)((BN * 144 + 1023) / 1024 * 1024);
     auto kern = gemm_dma_kernel<BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo, a_stride);
 }
 
@@ -767,12 +767,7 @@ static void launch_wide_k(const GemmTapParams& p, hipStream_t st) {
     const int nb = cdiv(p.M, BM) * cdiv(p.N, BN);
     const size_t lds = (size_t)(BM + BN) * (BK + 8) * 2;
     auto kern = gemm_wide_kernel<BM, BN, A16, BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p);
 }
 // Tile of the wide-K kernel.  Three bounds, all measured on the prefill's and the codec transformer's shapes

@@ -321,11 +321,7 @@ static void launch_ru_r(const ResUnitParams& p, hipStream_t st) {
     const size_t lds = (size_t)a_bytes + 2 * NC * RU_FRAG * 2 + 6 * C * sizeof(float);
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "resunit: LDS budget exceeded");
     auto kern = resunit_kernel<NC, TM, RES16>;
-    static bool attr_set = false;          // one flag per instantiation
-    if (!attr_set) {
-        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(cdiv(p.M, RW)), dim3(256), lds, st, p, halo, a_bytes);
 }
 template <int NC, int TM>

@@ -815,12 +815,7 @@ static void launch2_n(const SkinnyParams& p, hipStream_t st) {
     const size_t lds = (size_t)NW * (SPW * MT + MT) * 64 * 16;
     QTTS_REQUIRE(lds <= 160 * 1024, QTTS_ERR_LIMIT, "skinny: LDS budget exceeded");
     auto kern = skinny2_kernel<MT, SPW, NW, FS, XB16, U, EXACT, NCH>;
-    static bool attr_set = false;          // one flag per instantiation
-    if (lds > 48 * 1024 && !attr_set) {
-        QTTS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
-        attr_set = true;
-    }
+    if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
     QTTS_SK_LAUNCH(kern, dim3(grid), dim3(NW * 64), lds, st, p);
 }
 template <int MT, int SPW, int NW, int FS, bool XB16, int U, bool EXACT>

@@ -833,6 +833,48 @@ def test_frame_step_kernels_issue_their_requests_back_to_back(libqtts):
         assert isa_waits.waits_inside_burst(hit[0], n_first) == [], (key, "a wait inside the first request burst")
 
 
+def test_lds_dma_kernels_wait_for_their_requests_before_the_barrier(libqtts):
+    """a workgroup barrier orders the waves, not the LDS-DMA data -- a tile staged with `global_load_lds` is in LDS once the
+    REQUESTING wave's vmcnt has drained.  In the gfx950 code objects of the built library every `s_barrier` that follows a DMA request in
+    program-text order has a `s_waitcnt vmcnt(0)` between the two (gemm_dma_kernel says so in its source; for the others this pins the
+    compiler's fence placement)."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_waits
+    d = isa_waits.dma_barriers(os.path.join(ROOT, "qwen3-tts_amd", "libqtts.so"))
+    assert any("gemm_dma_kernel" in k for k in d) and any("resunit_kernel" in k for k in d), sorted(d)
+    for k, (tot, bad) in d.items():
+        assert tot >= 1 and bad == 0, (k, tot, bad)
+
+
+def test_option_table_through_the_c_abi(libqtts):
+    """qtts_set_option / qtts_get_option (include/qtts.h, ABI v10): the A/B switches of the library are set through the C ABI -- the
+    environment is looked at once per switch (the product path of QTTS_ENV: ADVICE r4), an override wins over it, removing the override
+    falls back to it, names outside QTTS_* are refused."""
+    import ctypes as C
+    import subprocess
+    code = r"""
+import ctypes as C, os, sys
+os.environ["QTTS_TEST_SWITCH_A"] = "env"
+lib = C.CDLL(sys.argv[1])
+lib.qtts_set_option.argtypes = [C.c_char_p, C.c_char_p]; lib.qtts_get_option.argtypes = [C.c_char_p, C.c_char_p, C.c_int32]
+lib.qtts_last_error.restype = C.c_char_p
+buf = C.create_string_buffer(64)
+assert lib.qtts_get_option(b"QTTS_TEST_SWITCH_A", buf, 64) == 0 and buf.value == b"env"
+assert lib.qtts_get_option(b"QTTS_TEST_SWITCH_B", buf, 64) == 1 and buf.value == b""
+assert lib.qtts_set_option(b"QTTS_TEST_SWITCH_A", b"abi") == 0
+assert lib.qtts_get_option(b"QTTS_TEST_SWITCH_A", buf, 64) == 0 and buf.value == b"abi"
+assert lib.qtts_set_option(b"QTTS_TEST_SWITCH_A", None) == 0
+assert lib.qtts_get_option(b"QTTS_TEST_SWITCH_A", buf, 64) == 0 and buf.value == b"env"
+assert lib.qtts_set_option(b"PATH", b"x") != 0 and b"QTTS_" in lib.qtts_last_error()
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code, libqtts], capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if not k.startswith("QTTS_")})
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_ctypes_argtypes_match_the_header(libqtts):
     """Every entry point's ctypes signature in qwen3-tts_amd/_lib.py against its prototype in include/qtts.h: same number of
     parameters and the same class of each (pointer / int32 / int64 / float).  The emulator tests declare their own

@@ -37,6 +37,30 @@ def kernels(lib):
     return out
 
 
+def dma_barriers(lib):
+    """Kernels that stage tiles by LDS-DMA (`global_load_lds` / `buffer_load ... lds`): {kernel: (barriers, barriers reached in
+    program-text order after a DMA request without a `s_waitcnt vmcnt(0)` in between)}.  The second number must be 0: a barrier
+    orders the WAVES, the DMA data is in LDS only once the requesting wave's vmcnt has drained."""
+    out = {}
+    for name, ins in kernels(lib).items():
+        is_dma = lambda i: "global_load_lds" in i or (i.startswith("buffer_load") and i.rstrip().endswith(" lds"))
+        if not any(is_dma(i) for i in ins):
+            continue
+        tot = bad = 0
+        waited = True
+        for i in ins:
+            if is_dma(i):
+                waited = False
+            m = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", i)
+            if m and int(m.group(1)) == 0:
+                waited = True
+            if i.startswith("s_barrier"):
+                tot += 1
+                bad += 0 if waited else 1
+        out[name] = (tot, bad)
+    return out
+
+
 def is_load(ins):
     return ins.startswith(("global_load", "buffer_load", "flat_load"))
 
