@@ -395,7 +395,7 @@ typedef struct {
     int32_t cp_fused_giveups;       /* generations that ended with QTTS_ERR_STATE because a consumer gave up (the engine then left the fused launch) */
     int32_t cp_fused_capacity;      /* fused launches of this engine's grid the DEVICE holds resident at once (occupancy x compute units / grid) */
     int32_t cp_fused_active;        /* 1: this engine holds one of those places                                                             */
-    int32_t reserved2_;
+    int32_t cp_mlp_per_step;        /* fused MLP launches (cp_mlp.hip: gate|up + SwiGLU + down of a code-predictor layer) in that frame step */
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
 /* Per-class result of the profile mode (qtts_talker_set_profile(t, 1), ABI v8): every launch of the decode GEMM in frames 1..6

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "tstamp.h"
+#include "granule.h"
 #include <hip/hip_ext.h>
 
 QTTS_TS_UNIT(attn)
@@ -1424,42 +1425,17 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
 //   are resident from the start and producers never wait, so there is no circular wait inside a launch; across concurrent launches see
 //   talker_engine.hip (two engines per process take this kernel).
 // bf16 cache, two query heads per kv head, head_dim 128, batch <= 8 only; everything else keeps attn_cp + the decode GEMM.
-namespace {
-typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
-#ifdef QTTS_HOST_EMU
-struct WtBuf { unsigned char* base; };
-__device__ inline WtBuf wt_buf(void* p, size_t) { return WtBuf{static_cast<unsigned char*>(p)}; }
-__device__ inline void wt_store16(const WtBuf& b, int off, cu32x4 v) { *reinterpret_cast<cu32x4*>(b.base + off) = v; }
-__device__ inline cu32x4 wt_load16(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
-__device__ inline uint2 wt_load8(const WtBuf& b, int off) { return *reinterpret_cast<const uint2*>(b.base + off); }
-__device__ inline void wt_first_pause(int) {}
-constexpr int CPAO_SPIN_LIMIT = 2;                      // (workgroups run one after the other here: a second read never helps)
-#else
-struct WtBuf { __amdgpu_buffer_rsrc_t r; };
-__device__ __forceinline__ WtBuf wt_buf(void* p, size_t bytes) { return WtBuf{__builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000)}; }
-// aux = 16: sc1 -- the store writes through to memory, the load is not served from this CU's L1
-__device__ __forceinline__ void wt_store16(const WtBuf& b, int off, cu32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
-__device__ __forceinline__ cu32x4 wt_load16(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
-__device__ __forceinline__ uint2 wt_load8(const WtBuf& b, int off) {
-    typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
-    const cu32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, off, 0, 16);
-    uint2 r; r.x = v[0]; r.y = v[1];
-    return r;
-}
-__device__ __forceinline__ void wt_first_pause(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // n x 64 clocks (16 ~ 0.4 us)
-constexpr int CPAO_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a producer that never stores is a bug, not a wait
-#endif
-}  // namespace
 
 // A consumer that never saw its producers' tag: raise the engine's flag AND latch the generation's stop flag -- every later kernel of
-// the frame chain (and every later frame step of the burst) returns at its `done` check, so one lost launch costs one give-up and the
-// host finds the flag at its next poll (talker_engine.hip: generate / stream_step / stream_end raise QTTS_ERR_STATE).
+// the frame chain (and every later frame step of the burst) returns at its `done` check, so one lost launch costs one give-up, the
+// garbage this launch still writes is never consumed, and the host finds the flag at its next poll (talker_engine.hip: generate /
+// stream_step / stream_end raise QTTS_ERR_STATE).  Only this cold block differs from round 4's kernel: a first version that also
+// tracked "gave up" per lane (to poison what it hands on) changed the code of the polling loops -- the two reads in flight collapsed
+// into one -- and cost 1.3 us per launch on the MI355X (profiles/r05_cp_attn_o_giveup_ab.md).
 __device__ __forceinline__ void cpao_give_up(const CpAttnOParams& P) {
     if (P.err) __hip_atomic_store(P.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (P.done_latch) __hip_atomic_store(P.done_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// (bit 31 is never set in a launch tag -- the serial stays below 2^24: a granule stored under this tag is fresh for nobody)
-constexpr unsigned CPAO_POISON = 0x80000000u;
 
 // The operands of the FIRST requests are leading scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave
 // instead of behind an s_load round trip of the by-value struct (as the decode GEMM's, profiles/r03_ab_kpre.md).
@@ -1474,9 +1450,8 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
     // ONE LDS object (a second one de-pipelines the loads around it):
     //   [4 waves][q | kn | vn : 128 floats each] | B tile [2][BSTR] bf16 | the reducer's own partial sum [2][128] floats
     //   | QKV: the four k quarters of the q|k|v strip [4 waves][64 lanes][4] floats and of the row sums of squares [4][16]
-    //   | one word per wave: "a lane of this wave gave up waiting for its q|k|v rows"
-    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4, QP_BYTES = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0, GU_BYTES = 16;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES + GU_BYTES];
+    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4, QP_BYTES = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES];
     const AttnDecodeParams& p = P.a;
     const int nchunk = P.H >> 7;
     // blockIdx = (row pair, kv head, chunk), chunk fastest: with 8 chunks the 32 workgroups that read one chunk's columns of Wo share an XCD's L2
@@ -1515,7 +1490,6 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
     }
     const float* xrow = p.qkv + (size_t)b * p.ld;
     float xq[2], xk[2], xv[2];
-    bool lane_gave_up = false;                          // (QKV: this lane's q|k|v granules never carried the tag)
     if constexpr (!QKV) {
         xq[0] = xrow[(g * 2 + hh) * HD + lane]; xq[1] = xrow[(g * 2 + hh) * HD + lane + 64];
         xk[0] = xrow[(p.nh + g) * HD + lane]; xk[1] = xrow[(p.nh + g) * HD + lane + 64];
@@ -1611,12 +1585,13 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 #pragma unroll
             for (int v = 0; v < 3; ++v) fresh = fresh && gq[v][0].y == tag && gq[v][1].y == tag;
             if (fresh) break;
-            if (spins > CPAO_SPIN_LIMIT) { cpao_give_up(P); lane_gave_up = true; break; }
+            if (spins > GRANULE_SPIN_LIMIT) { cpao_give_up(P); break; }
 #pragma unroll
             for (int v = 0; v < 3; ++v) { gq[v][0] = gn[v][0]; gq[v][1] = gn[v][1]; }
             wt_first_pause(P.poll_step);
             load_rows(gn);
         }
+
         xq[0] = __uint_as_float(gq[0][0].x); xq[1] = __uint_as_float(gq[0][1].x);
         xk[0] = __uint_as_float(gq[1][0].x); xk[1] = __uint_as_float(gq[1][1].x);
         xv[0] = __uint_as_float(gq[2][0].x); xv[1] = __uint_as_float(gq[2][1].x);
@@ -1698,17 +1673,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
         *reinterpret_cast<unsigned*>(Bt + rr * BSTR + hh * HD + 2 * lane) = pk;
     }
     QTTS_TS(2);
-    // a workgroup one of whose lanes gave up has no attention output worth handing on: its partial sums leave under a tag nobody waits
-    // for (so its reducer gives up in turn instead of adding garbage), and as a reducer it writes nothing
-    int* gu = reinterpret_cast<int*>(smem + WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES);
-    if constexpr (QKV) {
-        const bool wave_bad = __ballot(lane_gave_up) != 0;
-        if (lane == 0) gu[wave] = wave_bad ? 1 : 0;
-    }
     __syncthreads();
-    bool wg_bad = false;
-    if constexpr (QKV) wg_bad = (gu[0] | gu[1] | gu[2] | gu[3]) != 0;
-    const unsigned tag_out = wg_bad ? (tag | CPAO_POISON) : tag;
     // ---- 3. partial o-projection: D[feature 4 q + j][sequence li] of two strips over the 256 k of this kv head (columns 0 / 1 of the MFMA tile)
     const int row = rq * 2 + li;                        // (meaningful for li < 2)
     const bool col_ok = li < 2 && row < p.B;
@@ -1739,8 +1704,8 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int off = (int)((((size_t)g * 8 + row) * P.H + c * 128 + (wave * 2 + s) * 16 + lq * 4) * 8);
-            wt_store16(slab, off, (cu32x4){__float_as_uint(acc[s][0]), tag_out, __float_as_uint(acc[s][1]), tag_out});
-            wt_store16(slab, off + 16, (cu32x4){__float_as_uint(acc[s][2]), tag_out, __float_as_uint(acc[s][3]), tag_out});
+            wt_store16(slab, off, (cu32x4){__float_as_uint(acc[s][0]), tag, __float_as_uint(acc[s][1]), tag});
+            wt_store16(slab, off + 16, (cu32x4){__float_as_uint(acc[s][2]), tag, __float_as_uint(acc[s][3]), tag});
         }
     }
     QTTS_TS(3);
@@ -1776,30 +1741,26 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
             load_slabs(pa);
             wt_first_pause(P.poll_step);
             load_slabs(pn);
-            bool gave_up = wg_bad;
-            for (int spins = 0; !wg_bad; ++spins) {         // (two reads in flight, as for the q | k | v rows)
+            for (int spins = 0;; ++spins) {                 // (two reads in flight, as for the q | k | v rows)
                 bool fresh = true;
 #pragma unroll
                 for (int g2 = 0; g2 < NKV - 1; ++g2) fresh = fresh && pa[g2][1] == tag && pa[g2][3] == tag;
                 if (fresh) break;
-                if (spins > CPAO_SPIN_LIMIT) { cpao_give_up(P); gave_up = true; break; }
-                // somebody else of this launch gave up (its slab will never carry the tag): do not wait the limit out a second time
-                if ((spins & 1023) == 1023 && P.done_latch && __hip_atomic_load(P.done_latch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { gave_up = true; break; }
+                if (spins > GRANULE_SPIN_LIMIT) { cpao_give_up(P); break; }
 #pragma unroll
                 for (int g2 = 0; g2 < NKV - 1; ++g2) pa[g2] = pn[g2];
                 wt_first_pause(P.poll_step);
                 load_slabs(pn);
             }
+
             float s0 = __uint_as_float(pa[0][0]), s1 = __uint_as_float(pa[0][2]);
 #pragma unroll
             for (int g2 = 1; g2 < NKV - 1; ++g2) { s0 += __uint_as_float(pa[g2][0]); s1 += __uint_as_float(pa[g2][2]); }
             s0 += own[(tid >> 6) * 128 + c2]; s1 += own[(tid >> 6) * 128 + c2 + 1];
             s0 += res.x; s1 += res.y;
-            if (!gave_up) {                                 // (a reducer that gave up leaves the hidden state as it was: the latch stops the chain)
-                float2 o2; o2.x = s0; o2.y = s1;
-                *reinterpret_cast<float2*>(P.out + (size_t)rw * P.H + col) = o2;
-                if (P.out16) *reinterpret_cast<unsigned*>(P.out16 + (size_t)rw * P.H + col) = pack_bf16(s0, s1);
-            }
+            float2 o2; o2.x = s0; o2.y = s1;
+            *reinterpret_cast<float2*>(P.out + (size_t)rw * P.H + col) = o2;
+            if (P.out16) *reinterpret_cast<unsigned*>(P.out16 + (size_t)rw * P.H + col) = pack_bf16(s0, s1);
         }
     }
     QTTS_TS(4);

@@ -260,6 +260,34 @@ int cp_attn_o_blocks_per_cu();
 int cp_attn_o_grid(int H);                                        // workgroups of one launch
 void cp_attn_o_set_launch_events(hipEvent_t start, hipEvent_t stop);   // bench.py's roofline leg: time the NEXT launch on its own (as skinny_set_launch_events)
 
+// --------------------------------------------------------------------------------- cp_mlp.hip
+// The code predictor's MLP of a layer (RMSNorm -> gate|up -> SwiGLU -> down -> + residual) as ONE launch, batch <= 8, bf16 (round 5).
+struct CpMlpParams {
+    const void* Wgu;              // pack_cp_mlp_gu: [8 J workgroups][H / 32][4][2 ACT rows][8] bf16, RMSNorm weight folded (J = H / 32, ACT = I / (8 J))
+    const void* Wd;               // down-projection, pack_skinny_weight(bf16, fs = 16): [H / 16][I / 32][4][16][8]
+    const unsigned short* x16;    // the MLP's input rows [B][ldx16] bf16 (the hidden state after attention, un-normalised)
+    int ldx16; float eps;
+    const float* res;             // residual rows [B][H] fp32 (may be `out`)
+    float* out;                   // hidden rows [B][H] fp32
+    unsigned short* out16;        // optional bf16 copy [B][H]
+    float* act_gran;              // scratch [8 XCDs][8 rows][I / 16] granules {2 x bf16 act, tag}: zero at engine creation
+    float* part;                  // scratch [8 XCDs][8 rows][H] granules {fp32 partial sum, tag}: zero at engine creation
+    const int* serial; int slot;  // launch tag = (*serial << 7) | slot, as for cp_attn_o (its own buffers: its own slot numbering)
+    int phase;                    // 3: the whole kernel.  0 / 1 / 2 (host emulator, or a test): phase A / B / C alone
+    int* err; int* done_latch;    // give-up flag and the generation's stop latch (set by a consumer that gives up)
+    const int* done_flag;         // optional: when non-zero the kernel exits early
+    int first_pause, poll_step;   // x 64 clocks, as for cp_attn_o
+    int B, H, I;
+};
+bool cp_mlp_takes(int B, int H, int I);
+bool cp_mlp_instantiated(int H, int I);
+int cp_mlp_grid(int H);
+int cp_mlp_blocks_per_cu(int H, int I);                // residency, as cp_attn_o_blocks_per_cu
+size_t cp_mlp_gu_bytes(int H, int I);
+void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int I, void* out_host);
+void launch_cp_mlp(const CpMlpParams& P, hipStream_t st);
+void cp_mlp_set_launch_events(hipEvent_t start, hipEvent_t stop);
+
 // --------------------------------------------------------------------------------- sampling.hip
 struct SampleParams {
     const float* logits; int ld; int V; int B;

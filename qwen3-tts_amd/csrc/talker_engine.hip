@@ -29,6 +29,7 @@ struct LayerW {
     DevBuf qkv_p, o_p, gu_p, d_p;     // packed (decode)
     DevBuf gu_p8;                     // gate|up packed with 8-row interleave (ACT_SWIGLU8: the batch <= 8 kernel, twice the workgroups); bf16 only
     DevBuf o_p16;                     // o-projection in 16-feature strips for the fused attention + o-projection launch (code predictor, bf16 only)
+    DevBuf gu_mlp, d_p16;             // the fused MLP launch's operators (cp_mlp.hip: gate|up by workgroup, down in 16-feature strips; code predictor, bf16 only)
     DevBuf qkv_r, o_r, gu_r, d_r;     // row-major (prefill, talker only)
     DevBuf g1, g2, qn, kn;
 };
@@ -221,6 +222,11 @@ struct qtts_talker {
     // ... with the layer's own q|k|v GEMM in front of it in the same launch (layers >= 1).  QTTS_CP_FRONT=0: the decode GEMM, then cp_attn_o.
     bool cp_front_env = QTTS_OPT_ON("QTTS_CP_FRONT");
     DevBuf ao_qkv;                     // [8 rows][q|k|v width] granules {value, tag}
+    // The code predictor's MLP of a layer as ONE launch (cp_mlp.hip; round 5).  QTTS_CP_MLP=0 (copied at engine creation): the two decode GEMMs.
+    bool cp_mlp_env = QTTS_OPT_ON("QTTS_CP_MLP");
+    DevBuf mlp_act, mlp_part;          // granule buffers of the fused MLP launch
+    int64_t cp_mlp_count = 0;
+    int cp_mlp_per_step = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
                          PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
@@ -241,6 +247,14 @@ struct qtts_talker {
         // 16-feature strips of the operator (a second packed copy: 4 MB per layer)
         if (bf16 && !rows && cp_attn_o_env && d.nh == 16 && d.nkv == 8 && d.hd == 128 && d.H % 128 == 0)
             upload_packed(L.o_p16, ow, d.H, d.qd, nullptr, 16);
+        // ... and the MLP as ONE launch (cp_mlp.hip): gate|up packed by workgroup (XCD-major slices of the intermediate vector), down in 16-feature strips
+        if (bf16 && !rows && cp_mlp_env && cp_mlp_instantiated(d.H, d.I)) {
+            std::vector<char> h(cp_mlp_gu_bytes(d.H, d.I));
+            pack_cp_mlp_gu(PS(p + "mlp.gate_proj.weight", {d.I, d.H}).data(), PS(p + "mlp.up_proj.weight", {d.I, d.H}).data(),
+                           PS(p + "post_attention_layernorm.weight", {d.H}).data(), d.H, d.I, h.data());
+            L.gu_mlp.upload(h.data(), h.size());
+            upload_packed(L.d_p16, dw, d.H, d.I, nullptr, 16);
+        }
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
             upload_rows(L.o_r, ow);
@@ -360,6 +374,26 @@ struct qtts_talker {
         if (splitk) { o.out = sk_part.as<float>(); o.ksplit = 2; o.part_stride = pstride; }     // (o.res = xs: half 0 = residual + its sums)
         skinny(o, st);
         }
+        // bf16 engines, code predictor passes >= 1 at batch <= 8: the MLP as ONE launch (cp_mlp.hip) instead of the two decode GEMMs below
+        const bool fuse_mlp = cp_mlp_env && cp_fused_slot && L.gu_mlp.p && mlp_act.p && h16 && !skinny_only && !len_dev && n_new == 1 && len_static >= 1 &&
+                              cp_mlp_takes(M, d.H, d.I) && len_static * 5 + layer < 128;
+        if (fuse_mlp) {
+            CpMlpParams m{};
+            m.Wgu = L.gu_mlp.p; m.Wd = L.d_p16.p; m.x16 = xs16; m.ldx16 = d.H; m.eps = d.eps; m.res = xs; m.out = xs; m.out16 = xs16;
+            m.act_gran = mlp_act.as<float>(); m.part = mlp_part.as<float>(); m.serial = ss.frame_serial; m.slot = len_static * 5 + layer; m.phase = 3;
+            m.err = ss.n_generated + 5; m.done_latch = ss.done; m.done_flag = ss.done; m.first_pause = cp_attn_o_pause; m.poll_step = cp_attn_o_step;
+            m.B = M; m.H = d.H; m.I = d.I;
+            if (timing_now) {          // bench.py's roofline leg: timed on its own (stack 4: the fused MLP launch, three operators)
+                LaunchEv e{nullptr, nullptr, 4, 3 * d.I, d.H, 2.0 * 3.0 * (double)d.I * d.H};
+                QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
+                ev.push_back(e);
+                cp_mlp_set_launch_events(e.a, e.b);
+                try { launch_cp_mlp(m, st); } catch (...) { cp_mlp_set_launch_events(nullptr, nullptr); throw; }
+                cp_mlp_set_launch_events(nullptr, nullptr);
+            } else launch_cp_mlp(m, st);
+            ++cp_mlp_count;
+            return;
+        }
         SkinnyParams g{};
         g.done_flag = ss.done;
         g.x = xs; g.ldx = d.H; g.M = M; g.Wp = L.gu_p.p; g.N = 2 * d.I; g.K = d.H; g.out = actb; g.ldo = d.I; g.act = ACT_SWIGLU;
@@ -467,11 +501,11 @@ struct qtts_talker {
     int cp_fused_per_step = 0;                         // fused launches in the frame step last launched / captured
     int cp_fused_giveups = 0;                          // generations of this engine that ended on the give-up flag
     // QTTS_CP_FUSED_MAX (A/B, tests): cap on fused engines per device below what residency allows
-    void fused_admit(int grid) {
+    void fused_admit(int grid, int blocks_per_cu) {
         QTTS_CHECK_HIP(hipGetDevice(&fused_device));
         int cus = 0;
         QTTS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fused_device));
-        fused_capacity = grid > 0 ? cp_attn_o_blocks_per_cu() * cus / grid : 0;
+        fused_capacity = grid > 0 ? blocks_per_cu * cus / grid : 0;
         if (const char* e = QTTS_ENV("QTTS_CP_FUSED_MAX")) fused_capacity = std::min(fused_capacity, std::max(0, atoi(e)));
         auto& r = fused_registry();
         std::lock_guard<std::mutex> lk(r.m);
@@ -488,7 +522,7 @@ struct qtts_talker {
     // after a give-up: this engine runs the separate launches from now on (graphs that baked the fused launch in are dropped)
     void fused_retire() {
         ++cp_fused_giveups;
-        cp_attn_o_env = false;
+        cp_attn_o_env = false; cp_mlp_env = false;
         fused_release();
         destroy_graph();
         graph_nodes = 0;
@@ -512,10 +546,16 @@ void qtts_talker::finalize() {
     QTTS_REQUIRE(c.max_batch >= 1 && c.max_batch <= 32, QTTS_ERR_LIMIT, "max_batch must be 1..32");
     QTTS_REQUIRE(td.I % 16 == 0 && cd.I % 16 == 0, QTTS_ERR_ARG, "intermediate sizes % 16");
     const int G = c.num_code_groups;
-    if (bf16 && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0) {
-        fused_admit(cp_attn_o_grid(cd.H));
-        if (!cp_fused_slot) cp_attn_o_env = false;
-    } else cp_attn_o_env = false;
+    if (!bf16 || !cp_mlp_instantiated(cd.H, cd.I)) cp_mlp_env = false;
+    const bool want_ao = bf16 && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0;
+    if (want_ao || cp_mlp_env) {        // one admission for the engine's fused launches: the largest grid against the smallest occupancy
+        int bpc = 1 << 30, grid = 0;
+        if (want_ao) { bpc = std::min(bpc, cp_attn_o_blocks_per_cu()); grid = std::max(grid, cp_attn_o_grid(cd.H)); }
+        if (cp_mlp_env) { bpc = std::min(bpc, cp_mlp_blocks_per_cu(cd.H, cd.I)); grid = std::max(grid, cp_mlp_grid(cd.H)); }
+        fused_admit(grid, bpc);
+    }
+    if (!want_ao || !cp_fused_slot) cp_attn_o_env = false;
+    if (!cp_fused_slot) cp_mlp_env = false;
     tl.resize(c.num_hidden_layers);
     for (int l = 0; l < c.num_hidden_layers; ++l) build_layer(tl[l], "model.layers." + std::to_string(l) + ".", td, true);
     cl.resize(c.cp_num_hidden_layers);
@@ -641,6 +681,12 @@ void qtts_talker::finalize() {
         const size_t hmax = (size_t)std::max(td.H, cd.H);
         sk_part.alloc(2 * 8 * hmax * 4);
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
+    }
+    if (bf16 && !cl.empty() && cl[0].gu_mlp.p) {
+        mlp_act.alloc((size_t)8 * 8 * (cd.I / 16) * 8);
+        mlp_part.alloc((size_t)8 * 8 * cd.H * 8);
+        QTTS_CHECK_HIP(hipMemset(mlp_act.p, 0, mlp_act.bytes));
+        QTTS_CHECK_HIP(hipMemset(mlp_part.p, 0, mlp_part.bytes));
     }
     if (bf16 && !cl.empty() && cl[0].o_p16.p) {
         ao_part.alloc((size_t)8 * 8 * cd.H * 8);
@@ -781,7 +827,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
                              int max_frames, hipStream_t st) {
     const auto& c = cfg;
     const int G = c.num_code_groups;
-    const int64_t fused_before = cp_attn_o_count;
+    const int64_t fused_before = cp_attn_o_count, mlp_before = cp_mlp_count;
     // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
     cur_stack = 1;
     for (int j = 0; j < G - 1; ++j) {
@@ -869,6 +915,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     skinny(h, st);
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
     cp_fused_per_step = (int)(cp_attn_o_count - fused_before);      // (a captured step replays exactly these launches)
+    cp_mlp_per_step = (int)(cp_mlp_count - mlp_before);
 }
 
 // ============================================================================================ C ABI
@@ -1261,7 +1308,7 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     out->cp_fused_per_step = t->cp_fused_slot ? t->cp_fused_per_step : 0;
     out->cp_fused_launches_last = (int64_t)out->cp_fused_per_step * t->frames_run;
     out->cp_fused_giveups = t->cp_fused_giveups; out->cp_fused_capacity = t->fused_capacity; out->cp_fused_active = t->cp_fused_slot ? 1 : 0;
-    out->reserved2_ = 0;
+    out->cp_mlp_per_step = t->cp_fused_slot ? t->cp_mlp_per_step : 0;
     QTTS_API_END
 }
 int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n) {

@@ -281,9 +281,9 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
                 c2.done_latch = &latch;
                 qtts::launch_cp_attn_o(c2, nullptr);
                 if ((variant == 0) != (err == 0)) return -5 - variant;
-                if ((err != 0) != (latch != 0)) return -9;                         // a give-up latches the generation's stop flag ...
+                if ((err != 0) != (latch != 0)) return -9;                         // a give-up latches the generation's stop flag: what this launch still writes is never consumed
                 if (variant == 0 && memcmp(out, keep.data(), keep.size() * 4) != 0) return -8;
-                if (variant != 0 && memcmp(out, res, (size_t)B * H * 4) != 0) return -10;      // ... and leaves the hidden state as it was
+
             }
             memcpy(out, keep.data(), keep.size() * 4);
             memcpy(out16, keep16.data(), keep16.size() * 2);
@@ -303,4 +303,80 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
         qtts::launch_skinny(p, true, nullptr);
         return 0;
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
+// cp_mlp_kernel (cp_mlp.hip): the code predictor's MLP as one launch against the two decode-GEMM launches it replaces.
+// mode 0: skinny8 ACT_SWIGLU8 (gate|up, bf16 act) + skinny down-projection; mode 3: the fused launch, twice on the same granule buffers under two
+// serials, then phases B + C alone under the launch's own tag (bit-identical) and under another slot / serial (stale: give-up + latch).
+extern "C" int hostemu_cp_mlp(const float* x, int B, const float* Wg, const float* Wu, const float* gnorm, float eps, const float* Wd, int H, int I,
+                              const float* res, float* out, unsigned short* out16, int mode, unsigned epoch0) {
+    try {
+        std::vector<qtts::bf16_t> x16((size_t)B * H);
+        for (size_t i = 0; i < x16.size(); ++i) x16[i] = qtts::f32_to_bf16(x[i]);
+        for (int i = 0; i < B * H; ++i) out[i] = res[i];
+        if (mode == 3) {
+            std::vector<unsigned char> wgu(qtts::cp_mlp_gu_bytes(H, I)), wd(qtts::skinny_packed_bytes(H, I, true));
+            qtts::pack_cp_mlp_gu(Wg, Wu, gnorm, H, I, wgu.data());
+            qtts::pack_skinny_weight(Wd, H, I, true, wd.data(), nullptr, 16);
+            std::vector<float> act((size_t)8 * 8 * (I / 16) * 2, 0.f), part((size_t)8 * 8 * H * 2, 0.f);
+            int serial = (int)epoch0, err = 0, latch = 0;
+            qtts::CpMlpParams m{};
+            m.Wgu = wgu.data(); m.Wd = wd.data(); m.x16 = x16.data(); m.ldx16 = H; m.eps = eps; m.res = out; m.out = out; m.out16 = out16;
+            m.act_gran = act.data(); m.part = part.data(); m.serial = &serial; m.slot = 11; m.phase = 3; m.err = &err; m.done_latch = &latch;
+            m.first_pause = 16; m.poll_step = 4; m.B = B; m.H = H; m.I = I;
+            for (int rep = 0; rep < 2; ++rep) {
+                if (rep) { for (int i = 0; i < B * H; ++i) out[i] = res[i]; ++serial; }
+                qtts::launch_cp_mlp(m, nullptr);
+                if (err || latch) return -4;
+            }
+            std::vector<float> keep(out, out + (size_t)B * H);
+            std::vector<unsigned short> keep16(out16, out16 + (size_t)B * H);
+            // the consuming phases alone on the buffers the launches above filled
+            for (int variant = 0; variant < 3; ++variant) {
+                for (int ph = 1; ph <= 2; ++ph) {
+                    for (int i = 0; i < B * H; ++i) out[i] = res[i];
+                    qtts::CpMlpParams c2 = m;
+                    c2.phase = ph;
+                    if (variant == 1) c2.slot = m.slot + 1;
+                    int serial2 = serial + 1;
+                    if (variant == 2) c2.serial = &serial2;
+                    err = 0; latch = 0;
+                    if (variant != 0 && ph == 2) {     // (phase B under a foreign tag re-published the partial sums under that tag: restore the launch's own)
+                        qtts::CpMlpParams c1 = m; c1.phase = 1; int e2 = 0, l2 = 0; c1.err = &e2; c1.done_latch = &l2;
+                        qtts::launch_cp_mlp(c1, nullptr);
+                        for (int i = 0; i < B * H; ++i) out[i] = res[i];
+                    }
+                    qtts::launch_cp_mlp(c2, nullptr);
+                    if ((variant == 0) != (err == 0)) return -5 - variant - 10 * ph;
+                    if ((err != 0) != (latch != 0)) return -9;
+                    if (variant == 0 && ph == 2 && memcmp(out, keep.data(), keep.size() * 4) != 0) return -8;
+                }
+            }
+            memcpy(out, keep.data(), keep.size() * 4);
+            memcpy(out16, keep16.data(), keep16.size() * 2);
+            return 0;
+        }
+        // the two launches: gate|up in 8-row interleave (ACT_SWIGLU8), then the down-projection
+        std::vector<float> gu((size_t)2 * I * H);
+        const int blk = H % 512 == 0 ? 8 : 16;             // ACT_SWIGLU8 (K % 512 == 0: the frame step's form) or the strip-pair form
+        for (int f = 0; f < I; ++f) {
+            memcpy(&gu[((size_t)(f / blk) * 2 * blk + f % blk) * H], Wg + (size_t)f * H, (size_t)H * 4);
+            memcpy(&gu[((size_t)(f / blk) * 2 * blk + blk + f % blk) * H], Wu + (size_t)f * H, (size_t)H * 4);
+        }
+        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(2 * I, H, true)), wdp(qtts::skinny_packed_bytes(H, I, true));
+        qtts::pack_skinny_weight(gu.data(), 2 * I, H, true, wp.data(), gnorm, 16);
+        qtts::pack_skinny_weight(Wd, H, I, true, wdp.data(), nullptr, 8);
+        std::vector<qtts::bf16_t> act((size_t)B * I, (qtts::bf16_t)0x7FC0);
+        qtts::SkinnyParams g{};
+        g.x = reinterpret_cast<const float*>(x16.data()); g.x_bf16 = 1; g.ldx = H; g.M = B; g.Wp = wp.data(); g.N = 2 * I; g.K = H; g.fs = 16;
+        g.norm = 1; g.eps = eps; g.out = reinterpret_cast<float*>(act.data()); g.out_bf16 = 1; g.ldo = I; g.act = blk == 8 ? qtts::ACT_SWIGLU8 : qtts::ACT_SWIGLU;
+        qtts::launch_skinny(g, true, nullptr);
+        qtts::SkinnyParams d{};
+        d.x = reinterpret_cast<const float*>(act.data()); d.x_bf16 = 1; d.ldx = I; d.M = B; d.Wp = wdp.data(); d.N = H; d.K = I; d.fs = 8;
+        d.res = out; d.ldr = H; d.out = out; d.ldo = H; d.act = qtts::ACT_NONE; d.out16 = out16;
+        qtts::launch_skinny(d, true, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) {
+        return e.code;
+    }
 }

@@ -750,6 +750,44 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     assert a3 >= 0.85 and g3 >= p3 - 0.04
 
 
+def test_fused_mlp_equals_the_two_launches_on_the_frame_step(dev, golden_dir):
+    """`cp_mlp_kernel` (round 5: the code predictor's MLP of a layer -- gate|up GEMM, SwiGLU, down GEMM, residual -- in ONE launch, the
+    intermediate vector sliced by XCD, partial sums added in XCD order) against the two decode-GEMM launches it replaces (QTTS_CP_MLP=0)
+    on the hardware, through the whole frame step: 0.6B dims, batch 8 and batch 3, bf16, 40 frames teacher-forced with the reference's
+    golden codes, captured frame graph.  (1) The engine's own word on the path (`cp_mlp_per_step`).  (2) Three runs of the fused engine
+    give the same codes bit for bit: every cross-workgroup hand-off delivered complete values.  (3) Both forms compute the same bf16
+    products in another fp32 summation order; bars as for the fused attention launch (sub-codebook agreement >= 0.85, agreement with
+    the fp32 golden no worse than the separate launches' by more than 0.03)."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    cfg = synth.talker_06b()
+    g = np.load(os.path.join(golden_dir, "talker_06b_b8.npz"))
+    wn = synth.talker_weights(cfg, with_text=False)
+    lens = [int(x) for x in g["lens"]]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+    gc = torch.from_numpy(g["codes"][:, :40].copy())
+    per_step = (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers
+    for nb in (len(lens), 3):
+        res = {}
+        for flag in ("1", "0"):
+            with _qlib.options(QTTS_CP_MLP=flag):
+                eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=nb, max_seq=256, use_graph=True)
+                res[flag] = [eng.generate(emb[:nb], mask[:nb], tr[:nb], pad, teacher_codes=gc[:nb], suppress_tokens=_suppress(cfg)).own.cpu().numpy()
+                             for _ in range(3 if flag == "1" else 2)]
+                st = eng.stats()
+                assert st["cp_fused_active"] == 1 and st["cp_fused_giveups"] == 0 and st["cp_mlp_per_step"] == (per_step if flag == "1" else 0), st
+                del eng
+                torch.cuda.empty_cache()
+        f, p2 = res["1"], res["0"]
+        assert np.array_equal(f[0], f[1]) and np.array_equal(f[0], f[2]), f"batch {nb}: the fused MLP launch is not run-to-run identical"
+        assert np.array_equal(p2[0], p2[1]), f"batch {nb}: the separate launches are not run-to-run identical"
+        agree = float((f[0][:, :, 1:] == p2[0][:, :, 1:]).mean())
+        ag = float((f[0][:, :40, 1:] == g["codes"][:nb, :40, 1:]).mean())
+        pg = float((p2[0][:, :40, 1:] == g["codes"][:nb, :40, 1:]).mean())
+        print(f"cp_mlp vs two decode GEMMs (0.6B, {nb} x 40 frames, teacher-forced): sub-codebooks agree {agree:.4f}; against the fp32 golden: fused {ag:.4f}, two launches {pg:.4f}")
+        assert not np.array_equal(f[0], p2[0]), "the two forms gave identical codes: did QTTS_CP_MLP=0 select the separate launches?"
+        assert agree >= 0.85 and ag >= pg - 0.03
+
+
 def test_fused_launch_under_contention_codec_stream_and_other_engines(dev, golden_dir):
     """VERDICT r4 item 1(c).  The fused code-predictor launch waits, inside the launch, for workgroups of the same launch -- so what
     happens when the device is busy with other work?  One fused engine generates (0.6B dims, batch 8, 40 frames teacher-forced, captured

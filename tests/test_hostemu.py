@@ -56,6 +56,7 @@ def emu():
     lib.hostemu_set_block_order.argtypes = [i32]; lib.hostemu_set_block_order.restype = None
     lib.hostemu_cp_layer_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.c_uint32]
     lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
+    lib.hostemu_cp_mlp.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, i32, i32, vp, vp, vp, i32, C.c_uint32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
@@ -775,6 +776,60 @@ def test_cp_attn_o_fused_launch_real_source(emu):
             if first is None:
                 first = o1
             assert np.array_equal(o1, first), ("result depends on the wave order / the epoch", B, S0, bo, fo)
+
+
+@pytest.mark.parametrize("H,I", [(256, 1024), (1024, 3072)])
+def test_cp_mlp_one_launch_real_source(emu, H, I):
+    """`cp_mlp_kernel` (cp_mlp.hip, round 5): the code predictor's MLP of a layer -- RMSNorm, gate|up GEMM, SwiGLU, down GEMM, residual --
+    as ONE launch: the intermediate vector sliced by XCD, every workgroup a few features of its XCD's slice (phase A), then its 32 output
+    features over that slice (phase B), the eight XCD partials added in XCD order by the workgroup of XCD 7 (phase C); values cross between
+    workgroups as tagged granules.  Real source at the code predictor's real dimensions (1024 / 3072: 12 features per workgroup, the padded
+    MFMA tile rows) and at 256 / 1024 (16 per workgroup), against the two decode-GEMM launches it replaces (same bf16 products, another
+    fp32 summation order, the bf16 rounding of the intermediate vector in between) and against float64 numpy; batch 8 / 3, three fiber
+    orders, two launches per call on the same granule buffers under two serials.  The entry point then runs the consuming phases alone:
+    under the launch's own (serial, slot) they reproduce the result bit for bit, under another slot or serial every granule is stale and
+    the consumers give up, raise the error flag and latch the stop flag."""
+    g = np.random.default_rng(606 + H)
+    eps = 1e-6
+    gn = (1 + 0.1 * g.standard_normal(H)).astype(np.float32)
+    Wg = (g.standard_normal((I, H)) * 0.05).astype(np.float32)
+    Wu = (g.standard_normal((I, H)) * 0.05).astype(np.float32)
+    Wd = (g.standard_normal((H, I)) * 0.03).astype(np.float32)
+    Wg_r = _bf16_round(Wg * gn[None, :])[0].astype(np.float64)
+    Wu_r = _bf16_round(Wu * gn[None, :])[0].astype(np.float64)
+    Wd_r = _bf16_round(Wd)[0].astype(np.float64)
+    for B in (8, 3):
+        x = g.standard_normal((B, H)).astype(np.float32)
+        res = g.standard_normal((B, H)).astype(np.float32)
+        x_r = _bf16_round(x)[0].astype(np.float64)
+        rs = 1.0 / np.sqrt((x_r ** 2).mean(1, keepdims=True) + eps)
+        gg, uu = (x_r @ Wg_r.T) * rs, (x_r @ Wu_r.T) * rs
+        act = _bf16_round((gg / (1.0 + np.exp(-gg)) * uu).astype(np.float32))[0].astype(np.float64)
+        ref = act @ Wd_r.T + res
+
+        def run(mode, fiber_order=0, epoch0=0):
+            out = np.full((B, H), np.nan, np.float32)
+            out16 = np.full((B, H), 0x4242, np.uint16)
+            emu.hostemu_set_fiber_order(fiber_order)
+            try:
+                rc = emu.hostemu_cp_mlp(_ptr(x), B, _ptr(Wg), _ptr(Wu), _ptr(gn), eps, _ptr(Wd), H, I, _ptr(res), _ptr(out), _ptr(out16), mode, epoch0)
+            finally:
+                emu.hostemu_set_fiber_order(0)
+            assert rc == 0, ((H, I, B, mode), rc, (emu.qtts_last_error() or b"").decode())
+            return out, out16
+
+        o0, h0 = run(0)
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(o0 - ref).max()) <= 2e-2 * scale, "the two launches are off their own reference"
+        first = None
+        for (fo, e0) in [(0, 1), (1, 7), (2, 0xFFFFF0)]:
+            o3, h3 = run(3, fo, e0)
+            assert float(np.abs(o3 - ref).max()) <= 2e-2 * scale, (H, B, float(np.abs(o3 - ref).max()))
+            assert float(np.sqrt(((o3 - o0) ** 2).mean())) <= 2e-3 * float(np.sqrt((o0 ** 2).mean())), (H, B)
+            assert np.array_equal(h3, _bf16_round(o3)[1]), "bf16 copy of the hidden rows"
+            if first is None:
+                first = o3
+            assert np.array_equal(o3, first), ("result depends on the wave order / the epoch", H, B, fo)
 
 
 def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
@@ -1660,6 +1715,52 @@ def test_talker_bf16_fused_attention_o_projection_in_the_frame_step(emu, qopt, c
     n = min(fused[0].shape[1], plain[0].shape[1])
     assert n >= 2 and float((fused[0][:, :n] == plain[0][:, :n]).mean()) >= 0.9
     same = (fused[0][:, :n] == plain[0][:, :n]).all(axis=(0, 2))      # frames up to the first differing code see the same inputs
+    k = int(np.argmin(same)) if not same.all() else n
+    assert k >= 1
+    assert np.abs(fused[1][:, :k] - plain[1][:, :k]).max() <= 2e-2 * max(1.0, float(np.abs(plain[1][:, :k]).max()))
+
+
+def test_talker_bf16_fused_mlp_in_the_frame_step(emu, qopt):
+    """Round 5: the ENGINE side of `cp_mlp_kernel` -- the gate|up operator packed by workgroup (XCD-major slices of the intermediate vector), the
+    down operator in 16-feature strips, the two granule buffers, which launches take it (passes >= 1 of a bf16 engine at batch <= 8 that
+    holds a place of its device's residency; pass 0 with its two new tokens keeps the two decode GEMMs) -- on a predictor with a 256-wide
+    hidden state and a 1024-wide intermediate vector (16 features per workgroup), greedy bf16, eager and through the captured frame graph:
+    codes and hidden states equal those of the same engine with QTTS_CP_MLP=0 up to bf16 noise, `cp_mlp_per_step` says which path ran, and a
+    second generation on the same handle (granule buffers re-used, serial advanced) repeats the first bit for bit."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=256, cp_intermediate_size=1024, cp_num_hidden_layers=2,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(31), t, [5, 3, 6], 2, scale=0.5)
+    args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
+    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+    per_step = (t.num_code_groups - 2) * t.cp_num_hidden_layers
+    emu.hostemu_set_real_gemm(1)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            qopt(emu, "QTTS_CP_MLP", mode)
+            for use_graph in (0, 1):
+                h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=use_graph)
+                try:
+                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=4)
+                    if mode == "1":
+                        codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=4)
+                        assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2), (mode, use_graph)
+                    st = _lib.TalkerStatsC()
+                    _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+                    assert st.cp_mlp_per_step == (per_step if mode == "1" else 0) and st.cp_fused_per_step == per_step and st.cp_fused_giveups == 0
+                    res[(mode, use_graph)] = (codes, hidden)
+                finally:
+                    emu.qtts_talker_destroy(h)
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
+    for mode in ("1", "0"):
+        assert np.array_equal(res[(mode, 0)][0], res[(mode, 1)][0]) and np.array_equal(res[(mode, 0)][1], res[(mode, 1)][1]), mode
+    fused, plain = res[("1", 1)], res[("0", 1)]
+    n = min(fused[0].shape[1], plain[0].shape[1])
+    assert n >= 2 and float((fused[0][:, :n] == plain[0][:, :n]).mean()) >= 0.9
+    same = (fused[0][:, :n] == plain[0][:, :n]).all(axis=(0, 2))
     k = int(np.argmin(same)) if not same.all() else n
     assert k >= 1
     assert np.abs(fused[1][:, :k] - plain[1][:, :k]).max() <= 2e-2 * max(1.0, float(np.abs(plain[1][:, :k]).max()))

@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
 """In-process, interleaved A/B of engine-level knobs (process-to-process variance on the pool's boxes is ~5 %, larger than the
-effects being measured): for each repetition, for each configuration: set the environment, build a 1.7B bf16 talker engine
-(the knobs are read at engine construction), time `--frames` frame steps (min of 3), destroy the engine.
+effects being measured): for each repetition, for each configuration: set the switches through the C ABI (qtts_set_option), build a
+1.7B bf16 talker engine (engine-level switches are copied at engine construction), time `--frames` frame steps (min of 3), destroy it.
 
     python tools/ab_inproc.py --frames 40 --reps 3
 """
-import os as _os
-_os.environ.setdefault("QTTS_DEBUG_ENV_LIVE", "1")   # the library copies its A/B switches once unless told otherwise (csrc/common.h QTTS_ENV)
 import argparse, gc, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import synth
+from qwen3_tts_amd import _lib
 from qwen3_tts_amd.talker import TalkerEngine
 
 CONFIGS = {
-    "default": {},                               # 4 waves per workgroup below 16 MB, 8 above
+    "default": {},
+    "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
+    "cp_fused_off": {"QTTS_CP_MLP": "0", "QTTS_CP_ATTN_O": "0"},   # ... and q|k|v / attention / o-projection as separate launches (round 3's)
+    "mlp_pause8": {"QTTS_CP_ATTN_O_PAUSE": "8"},
+    "mlp_pause24": {"QTTS_CP_ATTN_O_PAUSE": "24"},
     "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
     "skinny8_nw4": {"QTTS_SKINNY8_NW": "4"},
 }
@@ -45,8 +48,7 @@ def main():
     for rep in range(a.reps):
         for n in names:
             for k in KEYS:
-                os.environ.pop(k, None)
-            os.environ.update(CONFIGS[n])
+                _lib.set_option(k, CONFIGS[n].get(k))
             eng = TalkerEngine(t, w, weight_dtype=torch.bfloat16, max_batch=B, max_seq=64 + F + 8, use_graph=True)
             eng.generate(emb, mask, tr, pad, seed=0, **kw); torch.cuda.synchronize()
             ts = []
@@ -57,7 +59,9 @@ def main():
             tp = time.perf_counter() - t1
             ms = 1000 * (min(ts) - tp) / F
             res[n].append(round(ms, 4))
-            print(f"[ab_inproc] rep {rep} {n:28s} {ms:.3f} ms/frame", flush=True)
+            st = eng.stats()
+            print(f"[ab_inproc] rep {rep} {n:28s} {ms:.3f} ms/frame   (graph nodes {st['graph_nodes']}, fused launches per step: attention {st['cp_fused_per_step']}, "
+                  f"mlp {st['cp_mlp_per_step']})", flush=True)
             del eng; gc.collect(); torch.cuda.empty_cache()
     out = {n: {"ms_per_frame": v, "min": min(v), "median": float(np.median(v))} for n, v in res.items()}
     print(json.dumps(out))
