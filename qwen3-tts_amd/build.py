@@ -27,8 +27,17 @@ HEADERS = ["common.h", "kernels.h", "glue.h", "granule.h", "tstamp.h", os.path.j
 # of behind an `s_load` round trip; the frame step's decode GEMMs (skinny8_kernel, skinny8_f32_kernel) pass their address operands that way.
 # The flag applies to every kernel of the library (only leading SCALAR arguments are ever preloaded; a kernel whose first argument is a
 # by-value struct is unaffected) and needs a gfx940+ firmware / ROCm >= 6.1 that implements kernarg preload -- true of every MI355X stack.
+# -target-feature -packed-fp32-ops (round 5): NO packed fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) in the device code.
+# With them, a sequence the compiler forms out of scalar source -- attn_cp's RoPE: `v_pk_mul_f32 v[8:9], v[8:9], v[6:7] op_sel:[0,1]
+# op_sel_hi:[0,0]` ... `v_sub_f32 v2, v14, v8` -- returned, in lanes 48-63 of the wave and only while another stream's kernels shared the
+# compute units, x0' c instead of x0' c - x1' sn: identical inputs, operands long arrived (`s_waitcnt vmcnt(0)` thirty instructions before),
+# 13 of 32 generations affected; 0 of 32 with this flag (profiles/r05_packed_fp32_hazard.md: the bisection from "codes differ under a
+# concurrent codec decode" down to the instruction pair).  The library had 16 275 such instructions in 318 kernels; none of the hot loops
+# is VALU-bound (the frame step is launch-latency-bound, the codec MFMA- and LDS-bound): the measured cost is on the same page.
+# (The host pass of hipcc reports the feature as unknown for x86 and ignores it.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 # name -> extra compiler flags; what each one tests is written next to the macro in the source.
@@ -45,6 +54,9 @@ VARIANTS = {
     # csrc/persist_probe.hip (hand-off probe: persistent launch with grid barriers vs graph launches, tools/persist_probe.py):
     # the product sources + the probe's own file and entry point; round 3 linked it into libqtts.so, round 4 moved it here.
     "probe": ["-DQTTS_PROBE=1"],
+    # Round 5 diagnosis (profiles/r05_packed_fp32_hazard.md): the same sources WITH packed fp32 instructions (the compiler's default for gfx950;
+    # the product build disables them, FLAGS above) -- the build that reproduces the run-to-run differences under a concurrent codec decode.
+    "pk": ["-Xclang", "-target-feature", "-Xclang", "+packed-fp32-ops"],
 }
 # Round 3: kpre (kernarg preload for the decode GEMM) measured 0.973x per frame (profiles/r03_ab_kpre.md) and is now the default code.
 # Round 2 (profiles/r02_ab_variants.md): cp_pretable, cp_qkvtable, attn_cp and sampler_v2 were measured faster and are now the

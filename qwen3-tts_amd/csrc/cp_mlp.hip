@@ -65,6 +65,20 @@ bool cp_mlp_takes(int B, int H, int I) {
 }
 int cp_mlp_grid(int H) { return 8 * (H / 32); }
 
+#if QTTS_TSTAMP
+#define QTTS_TS_CPMLP(tail_)                                                                                             \
+    if (threadIdx.x == 0 && ((tail_) || blockIdx.x % 9 == 4)) {                                                          \
+        const unsigned i_ = atomicAdd(&qtts::ts_cnt_cpmlp, 1u);                                                          \
+        if (i_ < qtts::TS_CAP) {                                                                                         \
+            qtts::TsRec r_;                                                                                              \
+            for (int k_ = 0; k_ < 6; ++k_) r_.t[k_] = ts_[k_];                                                           \
+            r_.kind = 5; r_.a = P.slot; r_.b = 0; r_.blk = (int)blockIdx.x | ((tail_) << 16);                            \
+            qtts::ts_log_cpmlp[i_] = r_;                                                                                 \
+        }                                                                                                                \
+    }
+#else
+#define QTTS_TS_CPMLP(tail_)
+#endif
 #define QTTS_CPMLP_ARGS(P) (P).Wgu, (P).Wd, (P).x16, (P).serial, (P).done_flag, (P).ldx16, (P).slot, (P)
 // ACT: intermediate features per workgroup; KQ: k-tiles (of 32) per wave in phase A (H / 128); KTW: k-tiles of the XCD slice per wave in phase B
 template <int ACT, int KQ, int KTW>
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
         }
         QTTS_TS(4);
     }
-    if (!run_c || xcd != 7) return;
+    if (!run_c || xcd != 7) { QTTS_TS_CPMLP(0) return; }
     // ---- C. the reducer of output features [32 j, 32 j + 32): the 8 XCD partials in XCD order + the residual
     if (r_t < P.B) {
         const int col = j * 32 + f_t;
@@ -261,6 +275,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
         if (P.out16) P.out16[(size_t)r_t * P.H + col] = f32_to_bf16(s);
     }
     QTTS_TS_DRAINED(5);
+    QTTS_TS_CPMLP(1)
 }
 
 static thread_local hipEvent_t tl_mlp_ev_start = nullptr, tl_mlp_ev_stop = nullptr;

@@ -225,6 +225,13 @@ struct qtts_talker {
     // The code predictor's MLP of a layer as ONE launch (cp_mlp.hip; round 5).  QTTS_CP_MLP=0 (copied at engine creation): the two decode GEMMs.
     bool cp_mlp_env = QTTS_OPT_ON("QTTS_CP_MLP");
     DevBuf mlp_act, mlp_part;          // granule buffers of the fused MLP launch
+    // DIAGNOSTIC (QTTS_DEBUG_ATT_TRACE=1, eager launches only): the code predictor's attention input rows and output of every separate
+    // attention launch, copied aside in launch order (tools/diag_att_trace.py)
+    bool dbg_trace = QTTS_OPT_SET("QTTS_DEBUG_ATT_TRACE");
+    DevBuf dbg_att, dbg_qkv, dbg_k, dbg_v, dbg_s1;
+    static constexpr size_t DBG_S1 = (size_t)64 * 3 * 516;       // floats per launch (attn_cp's stage-1 dump, QTTS_DEBUG_ATTN_CP bit 16)
+    int64_t dbg_idx = 0, dbg_cap = 0;
+    size_t dbg_layer_bytes(const KvCache& kv) const { return (size_t)kv.n_pages * kv.nkv * 16 * kv.hd * (kv.bf16 ? 2 : 4); }
     int64_t cp_mlp_count = 0;
     int cp_mlp_per_step = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
@@ -235,6 +242,8 @@ struct qtts_talker {
         auto& dw = PS(p + "mlp.down_proj.weight", {d.H, d.I});
         upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H, &PS(p + "input_layernorm.weight", {d.H}));
         L.fs_o = choose_fs(d.H, d.qd); L.fs_d = choose_fs(d.H, d.I);
+        if (const char* e = QTTS_ENV("QTTS_DEBUG_FS_O")) { if (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4) L.fs_o = atoi(e); }     // (diagnostics)
+        if (const char* e = QTTS_ENV("QTTS_DEBUG_FS_D")) { if (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4) L.fs_d = atoi(e); }
         upload_packed(L.o_p, ow, d.H, d.qd, nullptr, L.fs_o);
         upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         // (only engines that can run at batch <= 8 at all pay for the second copy -- 1.46 GB at 1.7B dims; an engine created for waves
@@ -365,7 +374,17 @@ struct qtts_talker {
             } else launch_cp_attn_o(f, st);
             ++cp_attn_o_count;
         } else {
+        if (dbg_trace && !len_dev && n_new == 1 && dbg_att.p && dbg_idx < dbg_cap) a.part = dbg_s1.as<float>() + (size_t)dbg_idx * DBG_S1;
         if (!skinny_only) launch_attn_decode(a, st);
+        if (dbg_trace && !len_dev && n_new == 1 && dbg_att.p && dbg_idx < dbg_cap) {
+            const size_t ab = (size_t)8 * d.qd * 2, qb = (size_t)8 * a.ld * 4;
+            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_att.p) + dbg_idx * ab, attb, (size_t)M * d.qd * 2, hipMemcpyDeviceToDevice, st));
+            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_qkv.p) + dbg_idx * qb, qkvb, (size_t)M * a.ld * 4, hipMemcpyDeviceToDevice, st));
+            const size_t lb = dbg_layer_bytes(kv);              // this layer's K / V pages as the launch left them
+            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_k.p) + dbg_idx * lb, static_cast<const char*>(kv.k) + (size_t)layer * lb, lb, hipMemcpyDeviceToDevice, st));
+            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_v.p) + dbg_idx * lb, static_cast<const char*>(kv.v) + (size_t)layer * lb, lb, hipMemcpyDeviceToDevice, st));
+            ++dbg_idx;
+        }
         SkinnyParams o{};
         o.done_flag = ss.done;
         o.x_bf16 = att16;
@@ -494,6 +513,7 @@ struct qtts_talker {
     // see is another PROCESS on the same device; a consumer that loses its producers there gives up after ~0.3 s, latches the stop flag
     // (one give-up per generation, not per launch), the call fails with QTTS_ERR_STATE and the engine leaves the fused launch for good
     // (`fused_retire`): the caller's retry runs on the separate launches.
+    static constexpr int FUSED_WGS_PER_CU = 2;
     struct FusedRegistry { std::mutex m; std::map<int, int> engines; };
     static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
     bool cp_fused_slot = false;
@@ -505,6 +525,10 @@ struct qtts_talker {
         QTTS_CHECK_HIP(hipGetDevice(&fused_device));
         int cus = 0;
         QTTS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fused_device));
+        // (at most the FUSED_WGS_PER_CU the kernels are built for: the occupancy API left the accumulator registers out for one of them --
+        // 3 reported where vgpr + agpr allow 2 -- and an over-estimate is the one error this rule must not make; the code objects' own
+        // numbers are pinned by tests/test_host_logic.py::test_fused_launches_fit_two_workgroups_per_compute_unit)
+        blocks_per_cu = std::min(blocks_per_cu, FUSED_WGS_PER_CU);
         fused_capacity = grid > 0 ? blocks_per_cu * cus / grid : 0;
         if (const char* e = QTTS_ENV("QTTS_CP_FUSED_MAX")) fused_capacity = std::min(fused_capacity, std::max(0, atoi(e)));
         auto& r = fused_registry();
@@ -1297,6 +1321,39 @@ int qtts_talker_debug_logits(qtts_talker* t, float* logits_dev, void* stream) {
     QTTS_REQUIRE(t && logits_dev, QTTS_ERR_ARG, "null argument");
     QTTS_CHECK_HIP(hipMemcpyAsync(logits_dev, t->logits.p, (size_t)t->B * t->cfg.vocab_size * 4, hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
+    QTTS_API_END
+}
+// DIAGNOSTIC (not in include/qtts.h): arm the attention trace for `cap` launches / read it back (device buffers of cap x 8 x qd bf16 and cap x 8 x ld fp32)
+int qtts_debug_att_s1(qtts_talker* t, void* out_dev) {          // the stage-1 dumps of the traced launches (DBG_S1 floats each)
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && t->dbg_trace && out_dev, QTTS_ERR_STATE, "att trace off");
+    QTTS_CHECK_HIP(hipDeviceSynchronize());
+    QTTS_CHECK_HIP(hipMemcpy(out_dev, t->dbg_s1.p, (size_t)t->dbg_idx * qtts_talker::DBG_S1 * 4, hipMemcpyDeviceToDevice));
+    QTTS_API_END
+}
+int qtts_debug_att_trace(qtts_talker* t, int64_t cap, void* att_out_dev, void* qkv_out_dev, void* k_out_dev, void* v_out_dev, int64_t* n, int64_t* layer_bytes) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && t->dbg_trace, QTTS_ERR_STATE, "att trace: create the engine with QTTS_DEBUG_ATT_TRACE=1");
+    const size_t ab = (size_t)8 * t->cd.qd * 2, qb = (size_t)8 * (t->cd.qd + 2 * t->cd.kvd) * 4;
+    if (att_out_dev) {
+        QTTS_CHECK_HIP(hipDeviceSynchronize());
+        QTTS_CHECK_HIP(hipMemcpy(att_out_dev, t->dbg_att.p, (size_t)t->dbg_idx * ab, hipMemcpyDeviceToDevice));
+        QTTS_CHECK_HIP(hipMemcpy(qkv_out_dev, t->dbg_qkv.p, (size_t)t->dbg_idx * qb, hipMemcpyDeviceToDevice));
+        const size_t lb2 = t->dbg_layer_bytes(t->kv_c);
+        if (k_out_dev) QTTS_CHECK_HIP(hipMemcpy(k_out_dev, t->dbg_k.p, (size_t)t->dbg_idx * lb2, hipMemcpyDeviceToDevice));
+        if (v_out_dev) QTTS_CHECK_HIP(hipMemcpy(v_out_dev, t->dbg_v.p, (size_t)t->dbg_idx * lb2, hipMemcpyDeviceToDevice));
+        if (n) *n = t->dbg_idx;
+    }
+    if (layer_bytes) *layer_bytes = (int64_t)t->dbg_layer_bytes(t->kv_c);
+    if (cap > 0) {
+        if (cap > t->dbg_cap) {
+            const size_t lb2 = t->dbg_layer_bytes(t->kv_c);
+            t->dbg_att.alloc((size_t)cap * ab); t->dbg_qkv.alloc((size_t)cap * qb); t->dbg_k.alloc((size_t)cap * lb2); t->dbg_v.alloc((size_t)cap * lb2);
+            t->dbg_s1.alloc((size_t)cap * qtts_talker::DBG_S1 * 4);
+            t->dbg_cap = cap;
+        }
+        t->dbg_idx = 0;
+    }
     QTTS_API_END
 }
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {

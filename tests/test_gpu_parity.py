@@ -708,7 +708,7 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     res = {}
     per_step = (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers
     for flag in ("1", "0"):
-        with _qlib.options(QTTS_CP_ATTN_O=flag):          # (an engine-level switch: copied when the engine is created)
+        with _qlib.options(QTTS_CP_ATTN_O=flag, QTTS_CP_MLP="0"):          # (engine-level switches: copied when the engine is created; the fused MLP has its own test)
             eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=True)
             runs = [eng.generate(emb, mask, tr, pad, teacher_codes=gc, suppress_tokens=_suppress(cfg)).own.cpu().numpy() for _ in range(3 if flag == "1" else 1)]
             res[flag] = runs
@@ -735,7 +735,7 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     # code after it -- measured: 0.27 agreement in frame 0, 0.04 after, between two CORRECT builds)
     sub = {}
     for flag in ("1", "0"):
-        with _qlib.options(QTTS_CP_ATTN_O=flag):
+        with _qlib.options(QTTS_CP_ATTN_O=flag, QTTS_CP_MLP="0"):
             eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=3, max_seq=256, use_graph=True)
             sub[flag] = [eng.generate(emb[:3], mask[:3], tr[:3], pad, teacher_codes=gc[:3], suppress_tokens=_suppress(cfg)).own.cpu().numpy()
                          for _ in range(2)]

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Where does the separate-launch attention (attn_cp) first differ under a concurrent codec decode?  Eager engine with the attention
+trace (QTTS_DEBUG_ATT_TRACE): per attn_cp launch, the q|k|v input rows and the attention output; quiet run vs runs with a codec neighbour."""
+import ctypes as C, os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import synth
+from qwen3_tts_amd import _lib
+from qwen3_tts_amd.talker import TalkerEngine
+from qwen3_tts_amd.codec import CodecDecoderEngine
+
+dev = "cuda:0"
+cfg = synth.talker_06b()
+g = np.load(os.path.join(ROOT, "tests", "golden", "talker_06b_b8.npz"))
+wn = {k: torch.from_numpy(v) for k, v in synth.talker_weights(cfg, with_text=False).items()}
+lens = [int(x) for x in g["lens"]]
+emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+sup = [i for i in range(cfg.vocab_size - 1024, cfg.vocab_size) if i != cfg.codec_eos_token_id]
+ccfg = synth.codec_real()
+cw = {k: torch.from_numpy(v) for k, v in synth.codec_weights(ccfg).items()}
+cstream = torch.cuda.Stream(device=dev)
+codec = CodecDecoderEngine(ccfg, cw, compute_dtype=torch.bfloat16, device=dev, max_batch=8, max_frames=150)
+codes8s = torch.from_numpy(np.random.default_rng(3).integers(0, ccfg.codebook_size, (8, ccfg.num_quantizers, 12))).to(dev)
+F = 20
+G, L = cfg.num_code_groups, cfg.cp_num_hidden_layers
+PER = (G - 2) * L                       # separate attention launches of passes >= 1 per frame
+CAP = F * PER
+qd, ld = cfg.cp_num_attention_heads * cfg.cp_head_dim, (cfg.cp_num_attention_heads + 2 * cfg.cp_num_key_value_heads) * cfg.cp_head_dim
+lib = _lib.load_library()
+lib.qtts_debug_att_trace.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+lib.qtts_debug_att_s1.argtypes = [C.c_void_p, C.c_void_p]
+_lib.set_option("QTTS_DEBUG_ATTN_CP", "16")
+S1 = 64 * 3 * 516
+with _lib.options(QTTS_CP_ATTN_O="0", QTTS_CP_MLP="0", QTTS_DEBUG_ATT_TRACE="1"):
+    e = TalkerEngine(cfg, wn, weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=False)
+
+
+def run():
+    lb = C.c_int64(0)
+    _lib.check(lib.qtts_debug_att_trace(e._h, CAP, None, None, None, None, None, C.byref(lb)))
+    o = e.generate(emb, mask, tr, pad, max_new_tokens=F + 1, min_new_tokens=F + 1, do_sample=False, subtalker_dosample=False, suppress_tokens=sup)
+    att = torch.empty(CAP, 8, qd, dtype=torch.bfloat16, device=dev)
+    qkv = torch.empty(CAP, 8, ld, dtype=torch.float32, device=dev)
+    kk = torch.empty(CAP, lb.value // 2, dtype=torch.int16, device=dev)
+    vv = torch.empty(CAP, lb.value // 2, dtype=torch.int16, device=dev)
+    n = C.c_int64(0)
+    _lib.check(lib.qtts_debug_att_trace(e._h, 0, C.c_void_p(att.data_ptr()), C.c_void_p(qkv.data_ptr()), C.c_void_p(kk.data_ptr()), C.c_void_p(vv.data_ptr()), C.byref(n), None))
+    s1 = torch.empty(CAP, 64, 3, 516, dtype=torch.float32, device=dev)
+    _lib.check(lib.qtts_debug_att_s1(e._h, C.c_void_p(s1.data_ptr())))
+    global last_s1
+    last_s1 = s1[:n.value].cpu().numpy().view(np.uint32)
+    return o.codes.cpu().numpy(), att[:n.value].float().cpu().numpy(), qkv[:n.value].cpu().numpy(), kk[:n.value].cpu().numpy(), vv[:n.value].cpu().numpy()
+
+
+c0, a0, q0, k0, v0 = run()
+s1_0 = last_s1
+c1, a1, q1, k1, v1 = run()
+print(f"[trace] {a0.shape[0]} traced launches; quiet repeat: codes equal {np.array_equal(c0, c1)}, att equal {np.array_equal(a0, a1)}, qkv equal {np.array_equal(q0, q1)}", flush=True)
+stop = threading.Event()
+def loop():
+    with torch.cuda.stream(cstream):
+        while not stop.is_set():
+            codec.forward(codes8s); cstream.synchronize()
+t = threading.Thread(target=loop); t.start(); time.sleep(0.2)
+try:
+    for rep in range(6):
+        c, a, q, kc, vc = run()
+        if np.array_equal(a, a0) and np.array_equal(q, q0):
+            print(f"[trace] run {rep}: identical", flush=True)
+            continue
+        n = min(len(a), len(a0))
+        da = np.array([not np.array_equal(a[i], a0[i]) for i in range(n)])
+        dq = np.array([not np.array_equal(q[i], q0[i]) for i in range(n)])
+        ia = int(np.argmax(da)) if da.any() else -1
+        iq = int(np.argmax(dq)) if dq.any() else -1
+        msg = f"[trace] run {rep}: first differing attention OUTPUT at launch {ia} (frame {ia // PER}, pass {1 + (ia % PER) // L}, layer {ia % L}); first differing q|k|v INPUT at launch {iq}"
+        if ia >= 0 and (iq < 0 or ia <= iq):
+            d = np.argwhere(a[ia] != a0[ia])
+            rows = sorted(set(int(x[0]) for x in d)); heads = sorted(set(int(x[1]) // 128 for x in d))
+            mag = float(np.abs(a[ia] - a0[ia]).max()); ref = float(np.abs(a0[ia]).max())
+            msg += f"; INPUT of that launch identical: {np.array_equal(q[ia], q0[ia])}; differing rows {rows} heads {heads} ({len(d)} values), max |diff| {mag:.4g} (|ref| max {ref:.4g})"
+            r, hd = rows[0], heads[0]
+            msg += f"; sample: run {a[ia][r, hd * 128:hd * 128 + 4]} vs quiet {a0[ia][r, hd * 128:hd * 128 + 4]}"
+        # the cache pages as each launch left them: [page 16][kvh 8][key 16][dim 128] bf16 bit patterns
+        for nm, cur, ref in (("K", kc, k0), ("V", vc, v0)):
+            cur4 = cur.reshape(n, -1, 8, 16, 128); ref4 = ref.reshape(n, -1, 8, 16, 128)        # [launch][page][kv head][key][dim]
+            found = None
+            for i in range(n):
+                nk = 3 + (i % PER) // L                      # valid keys after this launch: 0 .. pass + 1
+                if not np.array_equal(cur4[i, :, :, :nk], ref4[i, :, :, :nk]):
+                    found = i
+                    break
+            if found is None:
+                msg += f"\n        {nm}: every VALID key row identical after every launch"
+                continue
+            i0 = found
+            nk = 3 + (i0 % PER) // L
+            w = np.argwhere(cur4[i0, :, :, :nk] != ref4[i0, :, :, :nk])
+            msg += (f"\n        first differing valid {nm} rows after launch {i0} (frame {i0 // PER}, pass {1 + (i0 % PER) // L}, layer {i0 % L}; it appended key {nk - 1}): {len(w)} elements "
+                    f"(page, kv head, key, dim) {[tuple(int(y) for y in x) for x in w[:6]]}; bits run {[hex(int(cur4[i0][tuple(x)]) & 0xffff) for x in w[:6]]} vs quiet {[hex(int(ref4[i0][tuple(x)]) & 0xffff) for x in w[:6]]}")
+        # stage 1 of attn_cp: per (launch, workgroup, wave): [0:128] normed+roped, [128:256] norm weight, [256:384] cos|sin, [384:512] the raw row, [512] ss, [513] rs
+        s1 = last_s1
+        NAMES = [("result", 0, 128), ("norm weight", 128, 256), ("cos|sin", 256, 384), ("raw row (second load)", 384, 512), ("ss", 512, 513), ("rs", 513, 514)]
+        for i in range(n):
+            if not np.array_equal(s1[i], s1_0[i]):
+                w = np.argwhere(s1[i] != s1_0[i])
+                what = {}
+                for (wg, wv, off) in w:
+                    nm = [x[0] for x in NAMES if x[1] <= off < x[2]][0]
+                    what.setdefault((int(wg), int(wv)), {}).setdefault(nm, []).append(int(off))
+                msg += f"\n        stage 1 first differs at launch {i} (frame {i // PER}, pass {1 + (i % PER) // L}, layer {i % L}): " + "; ".join(
+                    f"workgroup {wg} (row {wg // 8}, kv head {wg % 8}) wave {wv} ({'q0 q1 k'.split()[wv]}): " + ", ".join(f"{nm} x{len(v)}" + (f" [{hex(int(s1[i][wg, wv, v[0]]))} vs {hex(int(s1_0[i][wg, wv, v[0]]))}]") for nm, v in d.items())
+                    for (wg, wv), d in list(what.items())[:4])
+                # which lanes, and does a neighbouring launch's cos|sin row (another position) explain them?
+                (wg, wv), d = list(what.items())[0]
+                offs = np.array(d.get("result", []))
+                f32 = lambda a: a.view(np.float32)
+                cur, ref = f32(s1[i][wg, wv]), f32(s1_0[i][wg, wv])
+                msg += f"\n        differing result offsets {offs.tolist()}"
+                xr, nw, cs, rs = ref[384:512].astype(np.float32), ref[128:256], ref[256:384], ref[513]
+                xn0 = nw[:64] * (xr[:64] * rs); xn1 = nw[64:] * (xr[64:] * rs)
+                def rope(c, sn):
+                    return np.concatenate([xn0 * c - xn1 * sn, xn1 * c + xn0 * sn]).astype(np.float32)
+                base = rope(cs[:64], cs[64:])
+                msg += f"; host recomputation with this launch's table row reproduces the quiet result in {int((base.view(np.uint32) == s1_0[i][wg, wv][:128]).sum())}/128 lanes"
+                # hypothesis: in the last 16-lane pass, o0 kept the LOW result of `v_pk_fma_f32 v[18:19] = x0' c + x1' sn | x0' sn + x1' c` instead of
+                # the `v_sub_f32 v18 = x0' c - x1' sn` that follows it (a write-after-write reordering): x0', x1' recovered from the quiet (o0, o1)
+                o0, o1 = ref[:64].astype(np.float64), ref[64:128].astype(np.float64)
+                c64, s64 = cs[:64].astype(np.float64), cs[64:].astype(np.float64)
+                x0p, x1p = o0 * c64 + o1 * s64, o1 * c64 - o0 * s64
+                waw = (x0p * c64 + x1p * s64).astype(np.float32)
+                lanes = offs[offs < 64]
+                msg += (f"\n          WAW hypothesis (o0 = x0' c + x1' sn in those lanes): max |predicted - observed| {float(np.abs(waw[lanes] - cur[lanes]).max()):.3g} "
+                        f"against a perturbation of {float(np.abs(cur[lanes] - ref[lanes]).max()):.3g}; observed {cur[lanes][:4]} predicted {waw[lanes][:4]} quiet {ref[lanes][:4]}")
+                for dl in ():
+                    j = i + dl
+                    if 0 <= j < n:
+                        cj = f32(s1_0[j][wg, wv])[256:384]
+                        alt = rope(cj[:64], cj[64:])
+                        hit = int((alt.view(np.uint32)[offs] == s1[i][wg, wv][offs]).sum()) if len(offs) else 0
+                        near = float(np.abs(alt[offs] - cur[offs]).max()) if len(offs) else 0.0
+                        msg += f"\n          with the cos|sin row of launch {j:+d}: {hit}/{len(offs)} of the perturbed lanes reproduced bit for bit (max |diff| {near:.3g}; perturbation itself {float(np.abs(cur[offs] - ref[offs]).max()):.3g})".replace(f"launch {j:+d}", f"launch i{dl:+d}")
+                break
+        print(msg, flush=True)
+finally:
+    stop.set(); t.join()
