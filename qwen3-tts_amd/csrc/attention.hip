@@ -547,8 +547,6 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     __shared__ float vn[HD];
     const int GQ = p.nh / p.nkv;
     QTTS_TS_BEGIN();
-    const int dbg = p.nsplit;              // DIAGNOSTIC bits (QTTS_DEBUG_ATTN_CP; 0 in the product): see launch_attn_decode
-    if (dbg & 4) __syncthreads();
     const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kk = lane >> 2, qq = lane & 3;
@@ -596,26 +594,16 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     if (done) return;
     QTTS_TS_DRAINED(2);                    // cache rows and this step's qkv row have arrived
     // ---- 1. q/k RMSNorm + RoPE at position S0, K/V append
-    float dbg_ss = 0.f, dbg_rs = 0.f;
     if (has_vec) {
         if (wave <= 2) {
             const float ss = wave_sum64_dpp(x0 * x0 + x1 * x1);
             const float rs = rsqrtf(ss / (float)HD + p.eps);
-            dbg_ss = ss; dbg_rs = rs;
             x0 = nw0 * (x0 * rs);
             x1 = nw1 * (x1 * rs);
             float c = ctab, sn = stab;
             if (!rtab) { const float ang = (float)S0 * invf; c = cosf(ang); sn = sinf(ang); }
             const float o0 = x0 * c - x1 * sn, o1 = x1 * c + x0 * sn;
             x0 = o0; x1 = o1;
-        }
-        if ((dbg & 16) && p.part && wave <= 2) {        // DIAGNOSTIC: stage 1's operands and results of this (workgroup, wave), fp32
-            float* t = p.part + ((size_t)blockIdx.x * 3 + wave) * 516;
-            t[lane] = x0; t[64 + lane] = x1;                                    // normed + roped
-            t[128 + lane] = nw0; t[192 + lane] = nw1; t[256 + lane] = ctab; t[320 + lane] = stab;
-            const float* src = p.qkv + (size_t)b * p.ld + (wave < 2 ? (kvh * GQ + wave) * HD : (p.nh + kvh) * HD);
-            t[384 + lane] = src[lane]; t[448 + lane] = src[lane + 64];          // the row as a second load sees it
-            if (lane == 0) { t[512] = dbg_ss; t[513] = dbg_rs; }
         }
         if (wave >= 2) {
             const size_t o = key_base(S0);
@@ -630,18 +618,7 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
     QTTS_TS_DRAINED(3);                    // norm + RoPE + append done
     __syncthreads();
     QTTS_TS(4);
-    if (wave >= GQ) {
-        if (dbg & 1) { __threadfence(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        return;
-    }
-    if (dbg & 8) {                         // the cache rows again, after the barrier
-        const u32x4* ksrc = reinterpret_cast<const u32x4*>(kc + key_base(kk < S0 ? kk : 0) + qq * 32);
-#pragma unroll
-        for (int w = 0; w < KW; ++w) kr[w] = ksrc[w];
-#pragma unroll
-        for (int k = 0; k < MAXK; ++k)
-            vr[k] = *reinterpret_cast<const VPair*>(vc + key_base(k < S0 ? k : 0) + 2 * lane);
-    }
+    if (wave >= GQ) return;
     // ---- 2. one wave per query head
     const float* q = qs[wave] + qq * 32;
     float kx[32];
@@ -693,7 +670,6 @@ __global__ __launch_bounds__(256) void attn_cp_kernel(AttnDecodeParams p) {
         const unsigned pk = (unsigned)f32_to_bf16(acc0 * inv) | ((unsigned)f32_to_bf16(acc1 * inv) << 16);
         *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(p.out) + o) = pk;
     } else { p.out[o] = acc0 * inv; p.out[o + 1] = acc1 * inv; }
-    if (dbg & 1) { __threadfence(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     QTTS_TS_DRAINED(5);
     QTTS_TS_END(attn, 1, S0, 0);
 }
@@ -1383,14 +1359,12 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }
-    if (p.n_new == 1 && !p.len_dev && !p.n_pad && p.len_static + 1 <= 16 && GQ <= 2 && !p.kv.vt && !QTTS_OPT_SET("QTTS_DEBUG_NO_ATTN_CP")) {     // the code predictor's passes >= 1
+    if (p.n_new == 1 && !p.len_dev && !p.n_pad && p.len_static + 1 <= 16 && GQ <= 2) {     // the code predictor's passes >= 1
         const dim3 grid(p.B * p.nkv);
-        AttnDecodeParams q = p;
-        q.nsplit = QTTS_OPT_INT("QTTS_DEBUG_ATTN_CP", 0);      // (diagnostic bits: 1 fence before exit, 4 barrier at entry, 8 cache rows re-read behind the barrier)
-        if (p.kv.bf16) { if (p.kv.contig) hipLaunchKernelGGL((attn_cp_kernel<bf16_t, true>), grid, dim3(256), 0, st, q);
-                         else hipLaunchKernelGGL((attn_cp_kernel<bf16_t, false>), grid, dim3(256), 0, st, q); }
-        else { if (p.kv.contig) hipLaunchKernelGGL((attn_cp_kernel<float, true>), grid, dim3(256), 0, st, q);
-               else hipLaunchKernelGGL((attn_cp_kernel<float, false>), grid, dim3(256), 0, st, q); }
+        if (p.kv.bf16) { if (p.kv.contig) hipLaunchKernelGGL((attn_cp_kernel<bf16_t, true>), grid, dim3(256), 0, st, p);
+                         else hipLaunchKernelGGL((attn_cp_kernel<bf16_t, false>), grid, dim3(256), 0, st, p); }
+        else { if (p.kv.contig) hipLaunchKernelGGL((attn_cp_kernel<float, true>), grid, dim3(256), 0, st, p);
+               else hipLaunchKernelGGL((attn_cp_kernel<float, false>), grid, dim3(256), 0, st, p); }
         QTTS_CHECK_HIP(hipGetLastError());
         return;
     }

@@ -175,14 +175,22 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
 #pragma unroll
         for (int t = 0; t < KTW; ++t) offs[t] = (int)((((size_t)xcd * 8 + row) * spairs + (wave * KTW + t) * 16 + lq * 4) * 8);
         cu32x4 cur[KTW][2], nxt[KTW][2];
-        auto load_slice = [&](cu32x4 (&d)[KTW][2]) {
+        // (l2_local: the slice was written by workgroups of THIS XCD -- reads served by the shared L2 (sc0) see it first; every fourth round
+        // reads at memory scope (sc1), which is what guarantees progress should a producer ever sit on another XCD)
+        auto load_slice = [&](cu32x4 (&d)[KTW][2], bool l2) {
+            if (l2) {
 #pragma unroll
-            for (int t = 0; t < KTW; ++t) { d[t][0] = wt_load16(ag, offs[t]); d[t][1] = wt_load16(ag, offs[t] + 16); }
+                for (int t = 0; t < KTW; ++t) { d[t][0] = wt_load16_l2(ag, offs[t]); d[t][1] = wt_load16_l2(ag, offs[t] + 16); }
+            } else {
+#pragma unroll
+                for (int t = 0; t < KTW; ++t) { d[t][0] = wt_load16(ag, offs[t]); d[t][1] = wt_load16(ag, offs[t] + 16); }
+            }
         };
-        wt_first_pause(P.first_pause);
-        load_slice(cur);
+        const bool l2l = P.l2_local != 0;
+        wt_first_pause(l2l ? P.l2_pause : P.first_pause);
+        load_slice(cur, l2l);
         wt_first_pause(P.poll_step);
-        load_slice(nxt);
+        load_slice(nxt, l2l);
         for (int spins = 0;; ++spins) {
             bool fresh = true;
 #pragma unroll
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
 #pragma unroll
             for (int t = 0; t < KTW; ++t) { cur[t][0] = nxt[t][0]; cur[t][1] = nxt[t][1]; }
             wt_first_pause(P.poll_step);
-            load_slice(nxt);
+            load_slice(nxt, l2l && (spins & 3) != 3);
         }
         QTTS_TS(3);
         f32x4 acc[2];

@@ -277,6 +277,7 @@ struct CpMlpParams {
     int* err; int* done_latch;    // give-up flag and the generation's stop latch (set by a consumer that gives up)
     const int* done_flag;         // optional: when non-zero the kernel exits early
     int first_pause, poll_step;   // x 64 clocks, as for cp_attn_o
+    int l2_local, l2_pause;       // 1: phase B polls its XCD's slice through the shared L2 first (sc0 reads; every fourth round at memory scope), after l2_pause x 64 clocks
     int B, H, I;
 };
 bool cp_mlp_takes(int B, int H, int I);

@@ -224,14 +224,8 @@ struct qtts_talker {
     DevBuf ao_qkv;                     // [8 rows][q|k|v width] granules {value, tag}
     // The code predictor's MLP of a layer as ONE launch (cp_mlp.hip; round 5).  QTTS_CP_MLP=0 (copied at engine creation): the two decode GEMMs.
     bool cp_mlp_env = QTTS_OPT_ON("QTTS_CP_MLP");
+    int cp_mlp_l2 = QTTS_OPT_INT("QTTS_CP_MLP_L2", 0), cp_mlp_l2_pause = QTTS_OPT_INT("QTTS_CP_MLP_L2_PAUSE", 6);      // (A/B: phase B's reads through the XCD's L2)
     DevBuf mlp_act, mlp_part;          // granule buffers of the fused MLP launch
-    // DIAGNOSTIC (QTTS_DEBUG_ATT_TRACE=1, eager launches only): the code predictor's attention input rows and output of every separate
-    // attention launch, copied aside in launch order (tools/diag_att_trace.py)
-    bool dbg_trace = QTTS_OPT_SET("QTTS_DEBUG_ATT_TRACE");
-    DevBuf dbg_att, dbg_qkv, dbg_k, dbg_v, dbg_s1;
-    static constexpr size_t DBG_S1 = (size_t)64 * 3 * 516;       // floats per launch (attn_cp's stage-1 dump, QTTS_DEBUG_ATTN_CP bit 16)
-    int64_t dbg_idx = 0, dbg_cap = 0;
-    size_t dbg_layer_bytes(const KvCache& kv) const { return (size_t)kv.n_pages * kv.nkv * 16 * kv.hd * (kv.bf16 ? 2 : 4); }
     int64_t cp_mlp_count = 0;
     int cp_mlp_per_step = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
@@ -242,8 +236,6 @@ struct qtts_talker {
         auto& dw = PS(p + "mlp.down_proj.weight", {d.H, d.I});
         upload_packed(L.qkv_p, qkvw, d.qd + 2 * d.kvd, d.H, &PS(p + "input_layernorm.weight", {d.H}));
         L.fs_o = choose_fs(d.H, d.qd); L.fs_d = choose_fs(d.H, d.I);
-        if (const char* e = QTTS_ENV("QTTS_DEBUG_FS_O")) { if (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4) L.fs_o = atoi(e); }     // (diagnostics)
-        if (const char* e = QTTS_ENV("QTTS_DEBUG_FS_D")) { if (atoi(e) == 16 || atoi(e) == 8 || atoi(e) == 4) L.fs_d = atoi(e); }
         upload_packed(L.o_p, ow, d.H, d.qd, nullptr, L.fs_o);
         upload_packed(L.gu_p, guw, 2 * d.I, d.H, &PS(p + "post_attention_layernorm.weight", {d.H}));
         // (only engines that can run at batch <= 8 at all pay for the second copy -- 1.46 GB at 1.7B dims; an engine created for waves
@@ -374,17 +366,7 @@ struct qtts_talker {
             } else launch_cp_attn_o(f, st);
             ++cp_attn_o_count;
         } else {
-        if (dbg_trace && !len_dev && n_new == 1 && dbg_att.p && dbg_idx < dbg_cap) a.part = dbg_s1.as<float>() + (size_t)dbg_idx * DBG_S1;
         if (!skinny_only) launch_attn_decode(a, st);
-        if (dbg_trace && !len_dev && n_new == 1 && dbg_att.p && dbg_idx < dbg_cap) {
-            const size_t ab = (size_t)8 * d.qd * 2, qb = (size_t)8 * a.ld * 4;
-            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_att.p) + dbg_idx * ab, attb, (size_t)M * d.qd * 2, hipMemcpyDeviceToDevice, st));
-            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_qkv.p) + dbg_idx * qb, qkvb, (size_t)M * a.ld * 4, hipMemcpyDeviceToDevice, st));
-            const size_t lb = dbg_layer_bytes(kv);              // this layer's K / V pages as the launch left them
-            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_k.p) + dbg_idx * lb, static_cast<const char*>(kv.k) + (size_t)layer * lb, lb, hipMemcpyDeviceToDevice, st));
-            QTTS_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(dbg_v.p) + dbg_idx * lb, static_cast<const char*>(kv.v) + (size_t)layer * lb, lb, hipMemcpyDeviceToDevice, st));
-            ++dbg_idx;
-        }
         SkinnyParams o{};
         o.done_flag = ss.done;
         o.x_bf16 = att16;
@@ -401,7 +383,7 @@ struct qtts_talker {
             m.Wgu = L.gu_mlp.p; m.Wd = L.d_p16.p; m.x16 = xs16; m.ldx16 = d.H; m.eps = d.eps; m.res = xs; m.out = xs; m.out16 = xs16;
             m.act_gran = mlp_act.as<float>(); m.part = mlp_part.as<float>(); m.serial = ss.frame_serial; m.slot = len_static * 5 + layer; m.phase = 3;
             m.err = ss.n_generated + 5; m.done_latch = ss.done; m.done_flag = ss.done; m.first_pause = cp_attn_o_pause; m.poll_step = cp_attn_o_step;
-            m.B = M; m.H = d.H; m.I = d.I;
+            m.B = M; m.H = d.H; m.I = d.I; m.l2_local = cp_mlp_l2; m.l2_pause = cp_mlp_l2_pause;
             if (timing_now) {          // bench.py's roofline leg: timed on its own (stack 4: the fused MLP launch, three operators)
                 LaunchEv e{nullptr, nullptr, 4, 3 * d.I, d.H, 2.0 * 3.0 * (double)d.I * d.H};
                 QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
@@ -1323,37 +1305,21 @@ int qtts_talker_debug_logits(qtts_talker* t, float* logits_dev, void* stream) {
                                   (hipStream_t)stream));
     QTTS_API_END
 }
-// DIAGNOSTIC (not in include/qtts.h): arm the attention trace for `cap` launches / read it back (device buffers of cap x 8 x qd bf16 and cap x 8 x ld fp32)
-int qtts_debug_att_s1(qtts_talker* t, void* out_dev) {          // the stage-1 dumps of the traced launches (DBG_S1 floats each)
-    QTTS_API_BEGIN
-    QTTS_REQUIRE(t && t->dbg_trace && out_dev, QTTS_ERR_STATE, "att trace off");
-    QTTS_CHECK_HIP(hipDeviceSynchronize());
-    QTTS_CHECK_HIP(hipMemcpy(out_dev, t->dbg_s1.p, (size_t)t->dbg_idx * qtts_talker::DBG_S1 * 4, hipMemcpyDeviceToDevice));
-    QTTS_API_END
+// DIAGNOSTIC (not in include/qtts.h): which XCD runs workgroup i of a launch?  (cp_mlp.hip slices its exchange by `blockIdx % 8`.)
+__global__ void xcc_probe_kernel(int* out) {
+#ifndef QTTS_HOST_EMU
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;       // HW_REG_XCC_ID
+#else
+    if (threadIdx.x == 0) out[blockIdx.x] = blockIdx.x & 7;
+#endif
 }
-int qtts_debug_att_trace(qtts_talker* t, int64_t cap, void* att_out_dev, void* qkv_out_dev, void* k_out_dev, void* v_out_dev, int64_t* n, int64_t* layer_bytes) {
+int qtts_debug_xcc_map(int32_t grid, int32_t* out_host, void* stream) {
     QTTS_API_BEGIN
-    QTTS_REQUIRE(t && t->dbg_trace, QTTS_ERR_STATE, "att trace: create the engine with QTTS_DEBUG_ATT_TRACE=1");
-    const size_t ab = (size_t)8 * t->cd.qd * 2, qb = (size_t)8 * (t->cd.qd + 2 * t->cd.kvd) * 4;
-    if (att_out_dev) {
-        QTTS_CHECK_HIP(hipDeviceSynchronize());
-        QTTS_CHECK_HIP(hipMemcpy(att_out_dev, t->dbg_att.p, (size_t)t->dbg_idx * ab, hipMemcpyDeviceToDevice));
-        QTTS_CHECK_HIP(hipMemcpy(qkv_out_dev, t->dbg_qkv.p, (size_t)t->dbg_idx * qb, hipMemcpyDeviceToDevice));
-        const size_t lb2 = t->dbg_layer_bytes(t->kv_c);
-        if (k_out_dev) QTTS_CHECK_HIP(hipMemcpy(k_out_dev, t->dbg_k.p, (size_t)t->dbg_idx * lb2, hipMemcpyDeviceToDevice));
-        if (v_out_dev) QTTS_CHECK_HIP(hipMemcpy(v_out_dev, t->dbg_v.p, (size_t)t->dbg_idx * lb2, hipMemcpyDeviceToDevice));
-        if (n) *n = t->dbg_idx;
-    }
-    if (layer_bytes) *layer_bytes = (int64_t)t->dbg_layer_bytes(t->kv_c);
-    if (cap > 0) {
-        if (cap > t->dbg_cap) {
-            const size_t lb2 = t->dbg_layer_bytes(t->kv_c);
-            t->dbg_att.alloc((size_t)cap * ab); t->dbg_qkv.alloc((size_t)cap * qb); t->dbg_k.alloc((size_t)cap * lb2); t->dbg_v.alloc((size_t)cap * lb2);
-            t->dbg_s1.alloc((size_t)cap * qtts_talker::DBG_S1 * 4);
-            t->dbg_cap = cap;
-        }
-        t->dbg_idx = 0;
-    }
+    QTTS_REQUIRE(grid >= 1 && grid <= 65536 && out_host, QTTS_ERR_ARG, "xcc_map: grid 1..65536");
+    DevBuf d; d.alloc((size_t)grid * 4);
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d.as<int>());
+    QTTS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    QTTS_CHECK_HIP(hipMemcpy(out_host, d.p, (size_t)grid * 4, hipMemcpyDeviceToHost));
     QTTS_API_END
 }
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {

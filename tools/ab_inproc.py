@@ -17,8 +17,9 @@ CONFIGS = {
     "default": {},
     "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
     "cp_fused_off": {"QTTS_CP_MLP": "0", "QTTS_CP_ATTN_O": "0"},   # ... and q|k|v / attention / o-projection as separate launches (round 3's)
-    "mlp_pause8": {"QTTS_CP_ATTN_O_PAUSE": "8"},
-    "mlp_pause24": {"QTTS_CP_ATTN_O_PAUSE": "24"},
+    "mlp_l2": {"QTTS_CP_MLP_L2": "1"},                              # phase B of the fused MLP polls through the XCD's L2 first
+    "mlp_l2_p3": {"QTTS_CP_MLP_L2": "1", "QTTS_CP_MLP_L2_PAUSE": "3"},
+    "mlp_l2_p10": {"QTTS_CP_MLP_L2": "1", "QTTS_CP_MLP_L2_PAUSE": "10"},
     "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
     "skinny8_nw4": {"QTTS_SKINNY8_NW": "4"},
 }
