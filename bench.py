@@ -717,8 +717,8 @@ def fused_cp_report(c, fused_rec, elem_bytes=2):
     layer 0, whose q|k|v row comes from the table)."""
     qd, kvd, H = c.cp_num_attention_heads * c.cp_head_dim, c.cp_num_key_value_heads * c.cp_head_dim, c.cp_hidden_size
     G, L = c.num_code_groups, c.cp_num_hidden_layers
-    alg = {"front": ((qd + 2 * kvd) * H + H * qd) * elem_bytes, "attn_o": H * qd * elem_bytes}
-    per_frame = {"front": (G - 2) * (L - 1), "attn_o": G - 2}
+    alg = {"front": ((qd + 2 * kvd) * H + H * qd) * elem_bytes, "attn_o": H * qd * elem_bytes, "mlp": 3 * c.cp_intermediate_size * H * elem_bytes}
+    per_frame = {"front": (G - 2) * (L - 1), "attn_o": G - 2, "mlp": (G - 2) * L}
     fl = {}
     for k, f in fused_rec.items():
         if k in alg and isinstance(f, dict) and f.get("rocprof_avg_launch_us"):
@@ -747,8 +747,8 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
     cls_all = talker.gemm_profile()
     # stack 3 = the code predictor's fused launch (cp_attn_o_kernel: q|k|v GEMM + attention + o-projection of a layer), timed by the
     # same per-launch events in the same run (round 5); the dominant-kernel figure stays the decode GEMM's own launches
-    cls = [c for c in cls_all if c["stack"] != 3]
-    cls_fused = [c for c in cls_all if c["stack"] == 3]
+    cls = [c for c in cls_all if c["stack"] in (0, 1, 2)]
+    cls_fused = [c for c in cls_all if c["stack"] in (3, 4)]          # 3: cp_attn_o_kernel; 4: cp_mlp_kernel (gate|up + SwiGLU + down of a code-predictor layer)
     frames = 6
     out = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "method": "per-launch kernel begin/end timestamps (hipExtLaunchKernelGGL events) over every decode-GEMM "
@@ -783,13 +783,14 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
         fl = {}
         for c in cls_fused:
             us = 1e3 * c["total_ms"] / c["launches"]
-            key = "front" if c["N"] > talker.config.cp_hidden_size else "attn_o"
+            key = "mlp" if c["stack"] == 4 else ("front" if c["N"] > talker.config.cp_hidden_size else "attn_o")
             fl[key] = {"launches_per_frame": c["launches"] // frames, "algorithmic_bytes_per_launch": round(c["bytes_per_launch"]),
                        "avg_us": round(us, 3), "min_us": round(c["min_us"], 3),
                        "frac": round(c["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         fl["weight_bytes_per_frame"] = round(sum(c["launches"] * c["bytes_per_launch"] for c in cls_fused) / frames)
         fl["kernel"] = ("cp_attn_o_kernel (front: q|k|v GEMM + attention + o-projection of a code-predictor layer in one launch; attn_o: layer 0, "
-                        "whose q|k|v row comes from the table); per-launch events of this run")
+                        "whose q|k|v row comes from the table) and cp_mlp_kernel (mlp: RMSNorm + gate|up GEMM + SwiGLU + down GEMM + residual of a layer in "
+                        "one launch); per-launch events of this run")
         out["fused_cp_launch"] = fl
         ms_all = tot_ms + sum(c["total_ms"] for c in cls_fused)
         b_all = tot_b + sum(c["launches"] * c["bytes_per_launch"] for c in cls_fused)
@@ -797,7 +798,7 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
         out["weight_launches_per_frame"] = (tot_n + sum(c["launches"] for c in cls_fused)) // frames
         out["weight_bytes_per_frame_timed_all"] = round(b_all / frames)
     st_f = talker.stats()
-    out["cp_fused"] = {k: st_f[k] for k in ("cp_fused_active", "cp_fused_capacity", "cp_fused_per_step", "cp_fused_giveups") if k in st_f}
+    out["cp_fused"] = {k: st_f[k] for k in ("cp_fused_active", "cp_fused_capacity", "cp_fused_per_step", "cp_mlp_per_step", "cp_fused_giveups") if k in st_f}
     if elem_bytes != 2:            # (the parity-mode leg: no PMC pass and no isolated replay for the fp32 engine)
         out["traffic"] = None
         return out
@@ -827,7 +828,7 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
             if "fused" in rec and out["weight_bytes_per_frame_timed"] < wbytes:
                 fl = fused_cp_report(talker.config, rec["fused"], elem_bytes)
                 if fl:                         # the stamped rocprofv3 / FETCH_SIZE pass rides beside the live numbers
-                    for k in ("front", "attn_o"):
+                    for k in ("front", "attn_o", "mlp"):
                         if k in fl and k in out.get("fused_cp_launch", {}):
                             out["fused_cp_launch"][k].update(rocprof_avg_launch_us=fl[k]["rocprof_avg_launch_us"], frac_rocprof=fl[k]["frac_rocprof"],
                                                              traffic=fl[k]["traffic"])

@@ -107,13 +107,18 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
             wu[ks] = wsrc[(size_t)ks * 4 * 2 * ACT + ACT];
             gx[ks] = xsrc[ks * 4];
         }
+    }
+    // phase B's block of the down operator: requested BEHIND phase A's operands are consumed (its 24 KB would share the workgroup's memory
+    // pipe with the 48 KB phase A waits for; it streams while the quarters are combined and the granules travel) -- or at entry (wd_early, A/B)
+    auto load_wd = [&] {
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             const cu32x4* dsrc = reinterpret_cast<const cu32x4*>(P.Wd) + ((size_t)(j * 2 + t2) * nktI + xcd * (slice >> 5) + wave * KTW) * 64 + lane;
 #pragma unroll
             for (int t = 0; t < KTW; ++t) wd[t2][t] = dsrc[t * 64];
         }
-    }
+    };
+    if (P.wd_early || !run_a) load_wd();
     const int done = P.done_flag ? *P.done_flag : 0;
     if (done) return;
     f32x4* qa = reinterpret_cast<f32x4*>(smem);
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
             ag4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, ag4, 0, 0, 0);
             au4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb2, xb, au4, 0, 0, 0);
         }
+        if (!P.wd_early) load_wd();
         ssq += __shfl_xor(ssq, 16);
         ssq += __shfl_xor(ssq, 32);                      // every lane: its row's sum over this wave's k quarter
         qa[(wave * 64 + lane) * 2] = ag4;
@@ -175,22 +181,14 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
 #pragma unroll
         for (int t = 0; t < KTW; ++t) offs[t] = (int)((((size_t)xcd * 8 + row) * spairs + (wave * KTW + t) * 16 + lq * 4) * 8);
         cu32x4 cur[KTW][2], nxt[KTW][2];
-        // (l2_local: the slice was written by workgroups of THIS XCD -- reads served by the shared L2 (sc0) see it first; every fourth round
-        // reads at memory scope (sc1), which is what guarantees progress should a producer ever sit on another XCD)
-        auto load_slice = [&](cu32x4 (&d)[KTW][2], bool l2) {
-            if (l2) {
+        auto load_slice = [&](cu32x4 (&d)[KTW][2]) {
 #pragma unroll
-                for (int t = 0; t < KTW; ++t) { d[t][0] = wt_load16_l2(ag, offs[t]); d[t][1] = wt_load16_l2(ag, offs[t] + 16); }
-            } else {
-#pragma unroll
-                for (int t = 0; t < KTW; ++t) { d[t][0] = wt_load16(ag, offs[t]); d[t][1] = wt_load16(ag, offs[t] + 16); }
-            }
+            for (int t = 0; t < KTW; ++t) { d[t][0] = wt_load16(ag, offs[t]); d[t][1] = wt_load16(ag, offs[t] + 16); }
         };
-        const bool l2l = P.l2_local != 0;
-        wt_first_pause(l2l ? P.l2_pause : P.first_pause);
-        load_slice(cur, l2l);
+        wt_first_pause(P.first_pause);
+        load_slice(cur);
         wt_first_pause(P.poll_step);
-        load_slice(nxt, l2l);
+        load_slice(nxt);
         for (int spins = 0;; ++spins) {
             bool fresh = true;
 #pragma unroll
@@ -206,7 +204,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
 #pragma unroll
             for (int t = 0; t < KTW; ++t) { cur[t][0] = nxt[t][0]; cur[t][1] = nxt[t][1]; }
             wt_first_pause(P.poll_step);
-            load_slice(nxt, l2l && (spins & 3) != 3);
+            load_slice(nxt);
         }
         QTTS_TS(3);
         f32x4 acc[2];
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
 #pragma unroll
             for (int x2 = 0; x2 < NP; ++x2) d[x2] = wt_load8(slab, (int)((((size_t)(x2 < nwait ? x2 : 0) * 8 + r_t) * P.H + col) * 8));
         };
-        wt_first_pause(P.first_pause);
+        wt_first_pause(P.pause_c);
         load_slabs(pa);
         wt_first_pause(P.poll_step);
         load_slabs(pn);

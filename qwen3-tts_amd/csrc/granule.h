@@ -16,7 +16,6 @@ __device__ inline WtBuf wt_buf(void* p, size_t) { return WtBuf{static_cast<unsig
 __device__ inline void wt_store16(const WtBuf& b, int off, cu32x4 v) { *reinterpret_cast<cu32x4*>(b.base + off) = v; }
 __device__ inline cu32x4 wt_load16(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
 __device__ inline uint2 wt_load8(const WtBuf& b, int off) { return *reinterpret_cast<const uint2*>(b.base + off); }
-__device__ inline cu32x4 wt_load16_l2(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
 __device__ inline void wt_first_pause(int) {}
 constexpr int GRANULE_SPIN_LIMIT = 2;                      // (workgroups run one after the other here: a second read never helps)
 #else
@@ -25,10 +24,6 @@ __device__ __forceinline__ WtBuf wt_buf(void* p, size_t bytes) { return WtBuf{__
 // aux = 16: sc1 -- the store writes through to memory, the load is not served from this CU's L1
 __device__ __forceinline__ void wt_store16(const WtBuf& b, int off, cu32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
 __device__ __forceinline__ cu32x4 wt_load16(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
-// aux = 1: sc0 -- not served from this CU's L1 but from the XCD's L2: a granule stored by a workgroup of the SAME XCD is there as soon as
-// the write-through store has passed the L2, long before a memory-scope (sc1) read returns it.  Only a hint of locality: a consumer that
-// polls with it must also poll with wt_load16 (a workgroup of another XCD never sees the line change in its own L2).
-__device__ __forceinline__ cu32x4 wt_load16_l2(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 1); }
 __device__ __forceinline__ uint2 wt_load8(const WtBuf& b, int off) {
     typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
     const cu32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, off, 0, 16);

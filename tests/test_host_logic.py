@@ -848,20 +848,24 @@ def test_lds_dma_kernels_wait_for_their_requests_before_the_barrier(libqtts):
         assert tot >= 1 and bad == 0, (k, tot, bad)
 
 
-def test_fused_launches_fit_two_workgroups_per_compute_unit(libqtts):
-    """The admission rule of the fused code-predictor launches (talker_engine.hip: fused_admit) counts on two workgroups of every fused kernel
-    fitting on a compute unit (FUSED_WGS_PER_CU = 2, the minimum with what the occupancy API reports).  Pinned from the code objects of the
-    built library: registers (vgpr rounded to 4, + agpr, in granules of 8) <= 256 per lane, static LDS <= 80 KB, no scratch."""
+def test_fused_launches_fit_their_register_shares(libqtts):
+    """The admission rule of the fused launches (talker_engine.hip: fused_admit) is an account of the register file: CP_SHARE = 184 registers
+    per lane and SIMD for a workgroup of cp_attn_o_kernel / cp_mlp_kernel (4 waves, one per SIMD), TK_SHARE = 416 for tk_front_kernel (8
+    waves, two per SIMD).  Pinned from the code objects of the built library (`.vgpr_count` = arch + accumulator registers, allocated in
+    granules of 8): every fused kernel within its share, LDS far from the limit, no scratch."""
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("llvm-objdump not available")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
-    rows = [k for k in kernel_resources.kernels_of(libqtts) if "cp_attn_o_kernel" in k[".name"] or "cp_mlp_kernel" in k[".name"]]
-    assert len(rows) >= 5, [k[".name"] for k in rows]
+    ks = kernel_resources.kernels_of(libqtts)
+    rows = [k for k in ks if any(n in k[".name"] for n in ("cp_attn_o_kernel", "cp_mlp_kernel", "tk_front_kernel"))]
+    assert len(rows) >= 9, [k[".name"] for k in rows]
     for k in rows:
-        regs = (k[".vgpr_count"] + 3) // 4 * 4 + k.get(".agpr_count", 0)
-        regs = (regs + 7) // 8 * 8
-        assert 2 * regs <= 512 and 2 * k[".group_segment_fixed_size"] <= 160 * 1024 and k.get(".private_segment_fixed_size", 0) == 0, k[".name"]
+        regs = (k[".vgpr_count"] + 7) // 8 * 8
+        waves_per_simd = k[".max_flat_workgroup_size"] // 256
+        share = 416 if "tk_front_kernel" in k[".name"] else 184
+        assert waves_per_simd in (1, 2) and regs * waves_per_simd <= share, (k[".name"], regs, waves_per_simd)
+        assert 2 * k[".group_segment_fixed_size"] <= 160 * 1024 and k.get(".private_segment_fixed_size", 0) == 0, k[".name"]
 
 
 def test_option_table_through_the_c_abi(libqtts):

@@ -17,9 +17,14 @@ CONFIGS = {
     "default": {},
     "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
     "cp_fused_off": {"QTTS_CP_MLP": "0", "QTTS_CP_ATTN_O": "0"},   # ... and q|k|v / attention / o-projection as separate launches (round 3's)
-    "mlp_l2": {"QTTS_CP_MLP_L2": "1"},                              # phase B of the fused MLP polls through the XCD's L2 first
-    "mlp_l2_p3": {"QTTS_CP_MLP_L2": "1", "QTTS_CP_MLP_L2_PAUSE": "3"},
-    "mlp_l2_p10": {"QTTS_CP_MLP_L2": "1", "QTTS_CP_MLP_L2_PAUSE": "10"},
+    "tk_front_off": {"QTTS_TK_FRONT": "0"},                         # round 5: the talker's q|k|v GEMM and attention as two launches
+    "tk_pause12": {"QTTS_TK_FRONT_PAUSE": "12"}, "tk_pause16": {"QTTS_TK_FRONT_PAUSE": "16"}, "tk_pause32": {"QTTS_TK_FRONT_PAUSE": "32"}, "tk_pause40": {"QTTS_TK_FRONT_PAUSE": "40"},
+    "mlp_wd_early": {"QTTS_CP_MLP_WD_EARLY": "1"},                  # the fused MLP's down block requested at kernel entry (round 5's first version)
+    "mlp_b16_c24": {"QTTS_CP_MLP_PAUSE_B": "16"}, "mlp_b20_c24": {"QTTS_CP_MLP_PAUSE_B": "20"}, "mlp_b28_c24": {"QTTS_CP_MLP_PAUSE_B": "28"},
+    "mlp_b24_c16": {"QTTS_CP_MLP_PAUSE_C": "16"}, "mlp_b24_c20": {"QTTS_CP_MLP_PAUSE_C": "20"}, "mlp_b24_c28": {"QTTS_CP_MLP_PAUSE_C": "28"},
+    "mlp_b24_c32": {"QTTS_CP_MLP_PAUSE_C": "32"}, "mlp_b28_c28": {"QTTS_CP_MLP_PAUSE_B": "28", "QTTS_CP_MLP_PAUSE_C": "28"},
+    "mlp_step2": {"QTTS_CP_MLP_STEP": "2"}, "mlp_step8": {"QTTS_CP_MLP_STEP": "8"},
+    "ao_pause20": {"QTTS_CP_ATTN_O_PAUSE": "20"}, "ao_pause24": {"QTTS_CP_ATTN_O_PAUSE": "24"}, "ao_pause12": {"QTTS_CP_ATTN_O_PAUSE": "12"},
     "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
     "skinny8_nw4": {"QTTS_SKINNY8_NW": "4"},
 }
@@ -62,7 +67,7 @@ def main():
             res[n].append(round(ms, 4))
             st = eng.stats()
             print(f"[ab_inproc] rep {rep} {n:28s} {ms:.3f} ms/frame   (graph nodes {st['graph_nodes']}, fused launches per step: attention {st['cp_fused_per_step']}, "
-                  f"mlp {st['cp_mlp_per_step']})", flush=True)
+                  f"mlp {st['cp_mlp_per_step']}, talker {st['tk_front_per_step']})", flush=True)
             del eng; gc.collect(); torch.cuda.empty_cache()
     out = {n: {"ms_per_frame": v, "min": min(v), "median": float(np.median(v))} for n, v in res.items()}
     print(json.dumps(out))
