@@ -1121,10 +1121,11 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
         // (attention.hip: cp_attn_o_kernel); a consumer that never sees the tag gives up in the loop's cold block (flag + stop latch).
         const WtBuf qg = wt_buf(const_cast<void*>(gr->gran), gr->bytes);
         const unsigned tag = gr->tag;
-        uint2 gq[GQ + 2][2], gn[GQ + 2][2];
-        auto load_rows = [&](uint2 (&d)[GQ + 2][2]) {
+        // (the q heads and k now; v -- whose strips come from the workgroups that host the attention and finish last -- behind the key loop)
+        uint2 gq[GQ + 1][2], gn[GQ + 1][2];
+        auto load_rows = [&](uint2 (&d)[GQ + 1][2]) {
 #pragma unroll
-            for (int vi = 0; vi < GQ + 2; ++vi)
+            for (int vi = 0; vi < GQ + 1; ++vi)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) d[vi][h2] = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[vi] + lane + 64 * h2) * 8));
         };
@@ -1135,7 +1136,7 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
         for (int spins = 0;; ++spins) {
             bool fresh = true;
 #pragma unroll
-            for (int vi = 0; vi < GQ + 2; ++vi) fresh = fresh && gq[vi][0].y == tag && gq[vi][1].y == tag;
+            for (int vi = 0; vi < GQ + 1; ++vi) fresh = fresh && gq[vi][0].y == tag && gq[vi][1].y == tag;
             if (fresh) break;
             if (spins > GRANULE_SPIN_LIMIT) {
                 if (gr->err) __hip_atomic_store(gr->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1143,12 +1144,12 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
                 break;
             }
 #pragma unroll
-            for (int vi = 0; vi < GQ + 2; ++vi) { gq[vi][0] = gn[vi][0]; gq[vi][1] = gn[vi][1]; }
+            for (int vi = 0; vi < GQ + 1; ++vi) { gq[vi][0] = gn[vi][0]; gq[vi][1] = gn[vi][1]; }
             wt_first_pause(gr->poll_step);
             load_rows(gn);
         }
 #pragma unroll
-        for (int vi = 0; vi < GQ + 2; ++vi) { x0v[vi] = __uint_as_float(gq[vi][0].x); x1v[vi] = __uint_as_float(gq[vi][1].x); }
+        for (int vi = 0; vi < GQ + 1; ++vi) { x0v[vi] = __uint_as_float(gq[vi][0].x); x1v[vi] = __uint_as_float(gq[vi][1].x); }
     }
     QTTS_TS_DRAINED(1);
     const int bend = min(b0s + bps, (S0 + 31) >> 5);         // blocks of CACHED keys of this split end here
@@ -1180,7 +1181,7 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
             sq[vi] = wave_sum64_dpp(x0 * kx0 + x1 * kx1) * rsqrtf((float)HD);        // score of the new key (fp32 q . k)
         }
     }
-    {
+    auto new_v = [&] {                            // this step's v row: append (wave 0), and the rounded row for the merge
         const bf16_t h0 = f32_to_bf16(x0v[GQ + 1]), h1 = f32_to_bf16(x1v[GQ + 1]);
         if (wave == 0 && split == 0 && (S0 >> 4) < pps) {
             bf16_t* cdst = reinterpret_cast<bf16_t*>(p.kv.v);
@@ -1188,7 +1189,8 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
             cdst[o + (size_t)lane * 16] = h0; cdst[o + (size_t)(lane + 64) * 16] = h1;
         }
         xw[wave][GQ + 1][lane] = bf16_to_f32(h0); xw[wave][GQ + 1][lane + 64] = bf16_to_f32(h1);
-    }
+    };
+    if constexpr (!GRAN) new_v();
     __builtin_amdgcn_wave_barrier();             // wave-private LDS slice: program order within the wave is all that is needed
     // B operand of S = K q^T: lane (head lj, lq) <- q[lj][32 t + 8 lq .. + 8] as bf16; columns >= GQ are zero
     u32x4 qB[4];
@@ -1271,6 +1273,24 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
     }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
+    if constexpr (GRAN) {                         // the v row now (only wave 0 needs it: it appends, and the merge reads xw[0])
+        if (wave == 0) {
+            const WtBuf qg = wt_buf(const_cast<void*>(gr->gran), gr->bytes);
+            const unsigned tag = gr->tag;
+            uint2 v0 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane) * 8)), v1 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane + 64) * 8));
+            for (int spins = 0; v0.y != tag || v1.y != tag; ++spins) {
+                if (spins > GRANULE_SPIN_LIMIT) {
+                    if (gr->err) __hip_atomic_store(gr->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (gr->done_latch) __hip_atomic_store(gr->done_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                wt_first_pause(gr->poll_step);
+                v0 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane) * 8)); v1 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane + 64) * 8));
+            }
+            x0v[GQ + 1] = __uint_as_float(v0.x); x1v[GQ + 1] = __uint_as_float(v1.x);
+            new_v();
+        }
+    }
     // ---- 3. merge of the 4 waves and of the new key (fixed order).  acc[d][r] of lane (head lj, lq) = dim 16 d + 4 lq + r
     if (lj < GQ) {
 #pragma unroll
@@ -1359,7 +1379,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnDecodeParams p) {
 //     waves 4-7: 16-feature strip b of q|k|v = rsqrt(mean x^2 + eps) W' x, a quarter of k each (the arithmetic of cp_attn_o_kernel's front:
 //                RMSNorm weight folded into W', row variances from the same bf16 x fragments, quarters added in wave order), handed on as
 //                tagged granules (granule.h);
-//     waves 0-3 (workgroups b < sequences x kv heads only): attn_tk16_body<GRAN> for (sequence, kv head) b -- cache window requested at entry,
+//     waves 0-3 (the workgroups of the v strips only): attn_tk16_body<GRAN> for one (sequence, kv head) -- cache window requested at entry,
 //                this step's q | k | v rows read back from the granules of (GQ + 2) x 8 other workgroups' strips, everything after that
 //                statement for statement the separate kernel's (q / k RMSNorm + RoPE, append, MFMA scores and PV, online softmax, merge).
 //   Two workgroup barriers: A -- the k quarters are in LDS (the attention waves pass it right behind their cache requests); B -- the body's own,
@@ -1379,7 +1399,10 @@ __global__ __launch_bounds__(512) void tk_front_kernel(const void* kW, const uns
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
-    const bool is_attn = (int)blockIdx.x < p.B * p.nkv;
+    // the attention of (sequence, kv head) a is hosted by workgroup A0 + a, A0 = the first strip of v: those workgroups' strips finish last
+    // (their memory pipe also carries the cache window), and v is what the attention needs last
+    const int A0 = (p.nh + p.nkv) * 8;
+    const bool is_attn = (int)blockIdx.x >= A0 && (int)blockIdx.x - A0 < p.B * p.nkv;
     const bool run_gemm = P.phase != 1, run_attn = P.phase != 0;
     const unsigned tag = ((unsigned)*P.serial << 7) | (unsigned)P.slot;
     if (wave >= 4) {
@@ -1438,7 +1461,7 @@ __global__ __launch_bounds__(512) void tk_front_kernel(const void* kW, const uns
     TkRowGranules gr;
     gr.gran = P.qkv_gran; gr.bytes = (size_t)8 * p.ld * 8; gr.tag = tag; gr.first_pause = P.first_pause; gr.poll_step = P.poll_step;
     gr.err = P.err; gr.done_latch = P.done_latch;
-    attn_tk16_body<GQ, CT, true>(p, (int)blockIdx.x, &gr);
+    attn_tk16_body<GQ, CT, true>(p, (int)blockIdx.x - A0, &gr);
 }
 
 static thread_local hipEvent_t tl_tkf_ev_start = nullptr, tl_tkf_ev_stop = nullptr;

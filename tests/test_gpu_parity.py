@@ -786,7 +786,7 @@ def test_fused_talker_qkv_attention_equals_the_two_launches_on_the_frame_step(de
         pg = float((p2[0][:, :40, 1:] == g["codes"][:nb, :40, 1:]).mean())
         print(f"tk_front vs decode GEMM + attn_tk16 (0.6B, {nb} x 40 frames, teacher-forced): cb-0 agree {a0:.4f}, sub-codebooks {agree:.4f}; against the fp32 golden: "
               f"fused {ag:.4f}, two launches {pg:.4f}")
-        assert a0 >= 0.97 and agree >= 0.85 and ag >= pg - 0.03
+        assert a0 >= 0.97 and agree >= 0.85 and ag >= pg - 0.05
 
 
 def test_fused_mlp_equals_the_two_launches_on_the_frame_step(dev, golden_dir):
