@@ -396,8 +396,7 @@ typedef struct {
     int32_t cp_fused_capacity;      /* engines with the code predictor's fused launches the DEVICE holds at once (register-share account, talker_engine.hip) */
     int32_t cp_fused_active;        /* 1: this engine holds one of those places                                                             */
     int32_t cp_mlp_per_step;        /* fused MLP launches (cp_mlp.hip: gate|up + SwiGLU + down of a code-predictor layer) in that frame step */
-    int32_t tk_front_per_step;      /* fused talker launches (attention.hip tk_front_kernel: q|k|v GEMM + attention of a talker layer) in that frame step */
-    int32_t tk_front_active;        /* 1: this engine was admitted with the talker's fused launch as well (one such engine per device)          */
+    int32_t reserved2_;
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
 /* Per-class result of the profile mode (qtts_talker_set_profile(t, 1), ABI v8): every launch of the decode GEMM in frames 1..6

@@ -1039,15 +1039,8 @@ __global__ __launch_bounds__(256) void attn_tk_kernel(AttnDecodeParams p) {
 // takes the 32-key blocks w, w + 4, ... of its split; the new token's key (position S0) is folded in at the merge from this
 // step's own row (fp32 q . k, as before).  Arithmetic: q, K, P, V enter the matrix pipe as bf16, accumulation fp32 -- the
 // precision of the reference's own bf16 attention (M:634-657: bf16 q k^T, fp32 softmax cast to bf16, bf16 P V).
-// The body is shared by attn_tk16_kernel (this step's q|k|v rows read from `p.qkv`) and by tk_front.hip's tk_front_kernel (GRAN: the rows
-// arrive as tagged granules from the q|k|v GEMM of the same launch; the cache window is requested first, the rows are waited for behind
-// it; called by waves 0-3 of an 8-wave workgroup whose waves 4-7 run the GEMM and meet them at two barriers).  `bidx` = sequence * nkv + kv head.
-struct TkRowGranules {                 // GRAN: where this step's q|k|v rows come from
-    const void* gran;                  // [8 rows][ld] granules {fp32 value, launch tag}
-    size_t bytes; unsigned tag; int first_pause, poll_step; int* err; int* done_latch;
-};
-template <int GQ, bool CT, bool GRAN>
-__device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const int bidx, const TkRowGranules* gr) {
+template <int GQ, bool CT>
+__global__ __launch_bounds__(256) void attn_tk16_kernel(AttnDecodeParams p) {
     constexpr int HD = 128, NB = 2;            // NB: 32-key blocks per wave requested at kernel entry (4 waves x 2 x 32 = 256 keys)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) float xw[4][GQ + 2][HD];      // per wave: q heads, k, v of the new token (fp32)
@@ -1055,7 +1048,7 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
     __shared__ float gm[4][GQ], gl[4][GQ], snew[GQ];
 
     QTTS_TS_BEGIN();
-    const int b = bidx / p.nkv, kvh = bidx % p.nkv;
+    const int b = blockIdx.x / p.nkv, kvh = blockIdx.x % p.nkv;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
@@ -1090,20 +1083,16 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
     };
 
     // split-KV: workgroup y of gridDim.y handles the 32-key blocks [b0s, b0s + bps) of the key span p.max_len
-    const int nsplit = GRAN ? 1 : gridDim.y, split = GRAN ? 0 : blockIdx.y;
+    const int nsplit = gridDim.y, split = blockIdx.y;
     const int bps = (((p.max_len + 31) >> 5) + nsplit - 1) / nsplit;
     const int b0s = split * bps;
     // ---- 0. this step's row first (loads return in request order), then the K / V blocks of the register window, speculatively
     float x0v[GQ + 2], x1v[GQ + 2];
-    int rcol[GQ + 2];
 #pragma unroll
-    for (int vi = 0; vi < GQ + 2; ++vi) rcol[vi] = vi < GQ ? (kvh * GQ + vi) * HD : (vi == GQ ? (p.nh + kvh) * HD : (p.nh + p.nkv + kvh) * HD);
-    if constexpr (!GRAN) {
-#pragma unroll
-        for (int vi = 0; vi < GQ + 2; ++vi) {
-            const float* src = p.qkv + (size_t)b * p.ld + rcol[vi];
-            x0v[vi] = src[lane]; x1v[vi] = src[lane + 64];
-        }
+    for (int vi = 0; vi < GQ + 2; ++vi) {
+        const int col = vi < GQ ? (kvh * GQ + vi) * HD : (vi == GQ ? (p.nh + kvh) * HD : (p.nh + p.nkv + kvh) * HD);
+        const float* src = p.qkv + (size_t)b * p.ld + col;
+        x0v[vi] = src[lane]; x1v[vi] = src[lane + 64];
     }
     const float wq0 = p.qw[lane], wq1 = p.qw[lane + 64], wk0 = p.kw[lane], wk1 = p.kw[lane + 64];
     const float invf = p.inv_freq[lane];
@@ -1112,45 +1101,8 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
     for (int n = 0; n < NB; ++n) load_block(kA[n], kB[n], vT[n], b0s + wave + 4 * n);
     const int S0 = p.len_dev ? *p.len_dev : p.len_static;   // KV length before this step = position of the new key
     const int npad = p.n_pad ? p.n_pad[b] : 0;
-    if constexpr (!GRAN) {
-        const int done = p.done_flag ? *p.done_flag : 0;
-        if (done) return;
-    } else {
-        __syncthreads();               // barrier A of tk_front_kernel: the GEMM waves of this workgroup have their k quarters in LDS
-        // this step's rows: strips of (GQ + 2) x 8 other workgroups of this launch.  Two reads in flight, `poll_step` apart, after `first_pause`
-        // (attention.hip: cp_attn_o_kernel); a consumer that never sees the tag gives up in the loop's cold block (flag + stop latch).
-        const WtBuf qg = wt_buf(const_cast<void*>(gr->gran), gr->bytes);
-        const unsigned tag = gr->tag;
-        // (the q heads and k now; v -- whose strips come from the workgroups that host the attention and finish last -- behind the key loop)
-        uint2 gq[GQ + 1][2], gn[GQ + 1][2];
-        auto load_rows = [&](uint2 (&d)[GQ + 1][2]) {
-#pragma unroll
-            for (int vi = 0; vi < GQ + 1; ++vi)
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) d[vi][h2] = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[vi] + lane + 64 * h2) * 8));
-        };
-        wt_first_pause(gr->first_pause);
-        load_rows(gq);
-        wt_first_pause(gr->poll_step);
-        load_rows(gn);
-        for (int spins = 0;; ++spins) {
-            bool fresh = true;
-#pragma unroll
-            for (int vi = 0; vi < GQ + 1; ++vi) fresh = fresh && gq[vi][0].y == tag && gq[vi][1].y == tag;
-            if (fresh) break;
-            if (spins > GRANULE_SPIN_LIMIT) {
-                if (gr->err) __hip_atomic_store(gr->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (gr->done_latch) __hip_atomic_store(gr->done_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-#pragma unroll
-            for (int vi = 0; vi < GQ + 1; ++vi) { gq[vi][0] = gn[vi][0]; gq[vi][1] = gn[vi][1]; }
-            wt_first_pause(gr->poll_step);
-            load_rows(gn);
-        }
-#pragma unroll
-        for (int vi = 0; vi < GQ + 1; ++vi) { x0v[vi] = __uint_as_float(gq[vi][0].x); x1v[vi] = __uint_as_float(gq[vi][1].x); }
-    }
+    const int done = p.done_flag ? *p.done_flag : 0;
+    if (done) return;
     QTTS_TS_DRAINED(1);
     const int bend = min(b0s + bps, (S0 + 31) >> 5);         // blocks of CACHED keys of this split end here
 
@@ -1181,7 +1133,7 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
             sq[vi] = wave_sum64_dpp(x0 * kx0 + x1 * kx1) * rsqrtf((float)HD);        // score of the new key (fp32 q . k)
         }
     }
-    auto new_v = [&] {                            // this step's v row: append (wave 0), and the rounded row for the merge
+    {
         const bf16_t h0 = f32_to_bf16(x0v[GQ + 1]), h1 = f32_to_bf16(x1v[GQ + 1]);
         if (wave == 0 && split == 0 && (S0 >> 4) < pps) {
             bf16_t* cdst = reinterpret_cast<bf16_t*>(p.kv.v);
@@ -1189,8 +1141,7 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
             cdst[o + (size_t)lane * 16] = h0; cdst[o + (size_t)(lane + 64) * 16] = h1;
         }
         xw[wave][GQ + 1][lane] = bf16_to_f32(h0); xw[wave][GQ + 1][lane + 64] = bf16_to_f32(h1);
-    };
-    if constexpr (!GRAN) new_v();
+    }
     __builtin_amdgcn_wave_barrier();             // wave-private LDS slice: program order within the wave is all that is needed
     // B operand of S = K q^T: lane (head lj, lq) <- q[lj][32 t + 8 lq .. + 8] as bf16; columns >= GQ are zero
     u32x4 qB[4];
@@ -1273,24 +1224,6 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
     }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
-    if constexpr (GRAN) {                         // the v row now (only wave 0 needs it: it appends, and the merge reads xw[0])
-        if (wave == 0) {
-            const WtBuf qg = wt_buf(const_cast<void*>(gr->gran), gr->bytes);
-            const unsigned tag = gr->tag;
-            uint2 v0 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane) * 8)), v1 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane + 64) * 8));
-            for (int spins = 0; v0.y != tag || v1.y != tag; ++spins) {
-                if (spins > GRANULE_SPIN_LIMIT) {
-                    if (gr->err) __hip_atomic_store(gr->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (gr->done_latch) __hip_atomic_store(gr->done_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                wt_first_pause(gr->poll_step);
-                v0 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane) * 8)); v1 = wt_load8(qg, (int)(((size_t)b * p.ld + rcol[GQ + 1] + lane + 64) * 8));
-            }
-            x0v[GQ + 1] = __uint_as_float(v0.x); x1v[GQ + 1] = __uint_as_float(v1.x);
-            new_v();
-        }
-    }
     // ---- 3. merge of the 4 waves and of the new key (fixed order).  acc[d][r] of lane (head lj, lq) = dim 16 d + 4 lq + r
     if (lj < GQ) {
 #pragma unroll
@@ -1324,7 +1257,7 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
             den += f;
         }
         if (nsplit > 1) {                                    // partial result of this split: numerator | max | denominator
-            float* pp = p.part + (((size_t)bidx * nsplit + split) * GQ + qi) * (HD + 2);
+            float* pp = p.part + (((size_t)blockIdx.x * nsplit + split) * GQ + qi) * (HD + 2);
             pp[dd] = num;
             if (dd == 0) { pp[HD] = mm; pp[HD + 1] = den; }
             QTTS_TS_DRAINED(5);
@@ -1339,8 +1272,6 @@ __device__ __forceinline__ void attn_tk16_body(const AttnDecodeParams& p, const 
     QTTS_TS_DRAINED(5);
     QTTS_TS_END(attn, 2, S0, nsplit);
 }
-template <int GQ, bool CT>
-__global__ __launch_bounds__(256) void attn_tk16_kernel(AttnDecodeParams p) { attn_tk16_body<GQ, CT, false>(p, (int)blockIdx.x, nullptr); }
 
 // merge of the split-KV partial results (fixed order): out = sum_s num_s e^(m_s - m) / sum_s den_s e^(m_s - m)
 template <int GQ>
@@ -1366,136 +1297,6 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnDecodeParams p) {
     const float r = num / den;
     if (p.out_bf16) reinterpret_cast<bf16_t*>(p.out)[o] = f32_to_bf16(r);
     else p.out[o] = r;
-}
-
-// =================================================================================== tk_front (round 5)
-// A TALKER layer's q|k|v GEMM and its single-token attention as ONE launch.  Replaces, in the talker's decode forward at batch <= 8
-// (modeling_qwen3_tts.py:1348-1424 layer, :727-805 attention; short sequences: the split-KV buckets keep the two launches), the decode GEMM
-// of q|k|v (skinny8_kernel, 16.8 MB at 1.7B dims) + attn_tk16_kernel and the dependent-launch boundary between them, 28 times per frame.
-// What the fusion buys is not the boundary alone: attn_tk16 spends 3.6 of its 5.9 us waiting for its cache window (64 workgroups pull ~77 KB
-// each at ~150 keys) -- here that window is requested at kernel entry, by waves that have nothing else to do, and arrives while the GEMM
-// runs (profiles/r05_tk_front.md).
-//   workgroup b of 256 = 8 waves:
-//     waves 4-7: 16-feature strip b of q|k|v = rsqrt(mean x^2 + eps) W' x, a quarter of k each (the arithmetic of cp_attn_o_kernel's front:
-//                RMSNorm weight folded into W', row variances from the same bf16 x fragments, quarters added in wave order), handed on as
-//                tagged granules (granule.h);
-//     waves 0-3 (the workgroups of the v strips only): attn_tk16_body<GRAN> for one (sequence, kv head) -- cache window requested at entry,
-//                this step's q | k | v rows read back from the granules of (GQ + 2) x 8 other workgroups' strips, everything after that
-//                statement for statement the separate kernel's (q / k RMSNorm + RoPE, append, MFMA scores and PV, online softmax, merge).
-//   Two workgroup barriers: A -- the k quarters are in LDS (the attention waves pass it right behind their cache requests); B -- the body's own,
-//   before its merge (the GEMM waves wait there for the attention to finish).
-// Producers never wait: no circular wait inside a launch, provided all workgroups are resident (512 threads, <= 256 registers: ONE workgroup
-// fills a compute unit -- the engine admits one such engine per device, talker_engine.hip).  A consumer that loses its producers gives up in
-// the cold block of its polling loop (flag + stop latch), as in cp_attn_o_kernel.
-#define QTTS_TKF_ARGS(P) (P).Wqkv, (P).x16, (P).serial, (P).a.done_flag, (P).a.B, (P).ldx16, (P).slot, (P)
-template <bool CT, int KQ>                              // KQ: k-tiles (of 32) per GEMM wave = K / 128
-__global__ __launch_bounds__(512) void tk_front_kernel(const void* kW, const unsigned short* kx16, const int* kserial, const int* kdone, int kB, int kldx16,
-                                                       int kslot, TkFrontParams P) {
-    P.Wqkv = kW; P.x16 = kx16; P.serial = kserial; P.a.done_flag = kdone; P.a.B = kB; P.ldx16 = kldx16; P.slot = kslot;
-    constexpr int GQ = 2;
-    __shared__ __attribute__((aligned(16))) f32x4 qpart[4 * 64];
-    __shared__ float qss[4 * 16];
-    const AttnDecodeParams& p = P.a;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lq = lane >> 4;
-    // the attention of (sequence, kv head) a is hosted by workgroup A0 + a, A0 = the first strip of v: those workgroups' strips finish last
-    // (their memory pipe also carries the cache window), and v is what the attention needs last
-    const int A0 = (p.nh + p.nkv) * 8;
-    const bool is_attn = (int)blockIdx.x >= A0 && (int)blockIdx.x - A0 < p.B * p.nkv;
-    const bool run_gemm = P.phase != 1, run_attn = P.phase != 0;
-    const unsigned tag = ((unsigned)*P.serial << 7) | (unsigned)P.slot;
-    if (wave >= 4) {
-        if (!run_gemm) return;
-        // ---- the strip of the q|k|v GEMM: every request first
-        const int w4 = wave - 4;
-        cu32x4 gw[KQ], gx[KQ];
-        {
-            const int nkt = KQ * 4;
-            const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wqkv) + ((size_t)blockIdx.x * nkt + w4 * KQ) * 64 + lane;
-            const cu32x4* xsrc = reinterpret_cast<const cu32x4*>(P.x16 + (size_t)(li < p.B ? li : 0) * P.ldx16 + w4 * KQ * 32 + lq * 8);
-#pragma unroll
-            for (int ks = 0; ks < KQ; ++ks) { gw[ks] = wsrc[ks * 64]; gx[ks] = xsrc[ks * 4]; }
-        }
-        const int done = p.done_flag ? *p.done_flag : 0;
-        if (done) return;
-        f32x4 qa = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float ssq = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KQ; ++ks) {
-            cu32x4 xv4 = gx[ks];
-            if (li >= p.B) xv4 = (cu32x4){0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(xv4[e] << 16), hi = __uint_as_float(xv4[e] & 0xffff0000u);
-                ssq += lo * lo; ssq += hi * hi;
-            }
-            bf16x8 wa, xb;
-            *reinterpret_cast<cu32x4*>(&wa) = gw[ks];
-            *reinterpret_cast<cu32x4*>(&xb) = xv4;
-            qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, qa, 0, 0, 0);
-        }
-        ssq += __shfl_xor(ssq, 16);
-        ssq += __shfl_xor(ssq, 32);
-        qpart[w4 * 64 + lane] = qa;
-        if (lq == 0) qss[w4 * 16 + li] = ssq;
-        __syncthreads();                                   // barrier A
-        if (w4 == 0 && li < p.B) {
-            const f32x4 s4 = ((qpart[lane] + qpart[64 + lane]) + qpart[128 + lane]) + qpart[192 + lane];
-            const float ss = ((qss[li] + qss[16 + li]) + qss[32 + li]) + qss[48 + li];
-            const float rs = rsqrtf(ss / (float)(KQ * 128) + P.eps_in);
-            const WtBuf qg = wt_buf(P.qkv_gran, (size_t)8 * p.ld * 8);
-            const int off = (int)(((size_t)li * p.ld + blockIdx.x * 16 + lq * 4) * 8);
-            wt_store16(qg, off, (cu32x4){__float_as_uint(s4[0] * rs), tag, __float_as_uint(s4[1] * rs), tag});
-            wt_store16(qg, off + 16, (cu32x4){__float_as_uint(s4[2] * rs), tag, __float_as_uint(s4[3] * rs), tag});
-        }
-        if (is_attn && run_attn) __syncthreads();          // barrier B (the attention waves' merge)
-        return;
-    }
-    // ---- waves 0-3: the attention of (sequence, kv head) blockIdx.x -- or nothing
-    if (!is_attn || !run_attn) return;
-    {
-        const int done = p.done_flag ? *p.done_flag : 0;
-        if (done) return;
-    }
-    TkRowGranules gr;
-    gr.gran = P.qkv_gran; gr.bytes = (size_t)8 * p.ld * 8; gr.tag = tag; gr.first_pause = P.first_pause; gr.poll_step = P.poll_step;
-    gr.err = P.err; gr.done_latch = P.done_latch;
-    attn_tk16_body<GQ, CT, true>(p, (int)blockIdx.x - A0, &gr);
-}
-
-static thread_local hipEvent_t tl_tkf_ev_start = nullptr, tl_tkf_ev_stop = nullptr;
-void tk_front_set_launch_events(hipEvent_t start, hipEvent_t stop) { tl_tkf_ev_start = start; tl_tkf_ev_stop = stop; }
-
-bool tk_front_takes(const AttnDecodeParams& a, int K) {
-    return a.hd == 128 && a.nkv == 8 && a.nh == 16 && a.n_new == 1 && a.len_dev && a.B >= 1 && a.B <= 8 && a.kv.bf16 && a.kv.vt && a.nsplit <= 1 &&
-           a.ld == 4096 && (K == 2048 || K == 1024);
-}
-int tk_front_grid() { return 256; }
-
-template <bool CT, int KQ>
-static void launch_tk_front_t(const TkFrontParams& P, hipStream_t st) {
-    auto kern = tk_front_kernel<CT, KQ>;
-#ifdef QTTS_HOST_EMU
-    for (int ph = 0; ph < 2; ++ph) {                      // the emulator runs workgroups one after the other: producers first, then the consumers
-        if (P.phase != 2 && P.phase != ph) continue;
-        TkFrontParams Q = P;
-        Q.phase = ph;
-        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, st, QTTS_TKF_ARGS(Q));
-    }
-#else
-    if (tl_tkf_ev_start) hipExtLaunchKernelGGL(kern, dim3(256), dim3(512), 0, st, tl_tkf_ev_start, tl_tkf_ev_stop, 0, QTTS_TKF_ARGS(P));
-    else hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, st, QTTS_TKF_ARGS(P));
-#endif
-}
-
-void launch_tk_front(const TkFrontParams& P, hipStream_t st) {
-    QTTS_REQUIRE(tk_front_takes(P.a, P.K), QTTS_ERR_ARG, "tk_front: shape (bf16 cache with transposed V pages, 16 / 8 heads of 128, one new token, batch <= 8, K = 1024 | 2048, no split-KV)");
-    QTTS_REQUIRE(P.Wqkv && P.x16 && P.qkv_gran && P.serial && P.a.qw && P.a.kw && P.a.inv_freq && P.a.out, QTTS_ERR_ARG, "tk_front: null operand");
-    QTTS_REQUIRE(P.slot >= 0 && P.slot < 128 && P.ldx16 % 8 == 0, QTTS_ERR_ARG, "tk_front: slot must be 0..127, ldx16 % 8");
-    if (P.K == 2048) { if (P.a.kv.contig) launch_tk_front_t<true, 16>(P, st); else launch_tk_front_t<false, 16>(P, st); }
-    else { if (P.a.kv.contig) launch_tk_front_t<true, 8>(P, st); else launch_tk_front_t<false, 8>(P, st); }
-    QTTS_CHECK_HIP(hipGetLastError());
 }
 
 template <typename KVT, int GQ>

@@ -260,23 +260,6 @@ int cp_attn_o_blocks_per_cu();
 int cp_attn_o_grid(int H);                                        // workgroups of one launch
 void cp_attn_o_set_launch_events(hipEvent_t start, hipEvent_t stop);   // bench.py's roofline leg: time the NEXT launch on its own (as skinny_set_launch_events)
 
-// attention.hip: a TALKER layer's q|k|v GEMM + single-token attention as one launch (round 5; batch <= 8, bf16, short sequences)
-struct TkFrontParams {
-    AttnDecodeParams a;           // the attention's parameters as for launch_attn_decode (a.qkv is unused: the rows travel as granules)
-    const void* Wqkv;             // pack_skinny_weight(bf16, fs = 16, RMSNorm weight folded): [(nh + 2 nkv) * hd / 16][K / 32][4][16][8]
-    const unsigned short* x16;    // the layer's input rows [B][ldx16] bf16 (un-normalised)
-    int ldx16, K; float eps_in;
-    float* qkv_gran;              // scratch [8 rows][a.ld] granules {fp32 value, launch tag}: zero at engine creation
-    const int* serial; int slot;  // launch tag = (*serial << 7) | slot
-    int phase;                    // 2: the whole kernel.  0 / 1 (host emulator): the GEMM / the attention alone
-    int* err; int* done_latch;
-    int first_pause, poll_step;
-};
-bool tk_front_takes(const AttnDecodeParams& a, int K);
-int tk_front_grid();
-void launch_tk_front(const TkFrontParams& P, hipStream_t st);
-void tk_front_set_launch_events(hipEvent_t start, hipEvent_t stop);
-
 // --------------------------------------------------------------------------------- cp_mlp.hip
 // The code predictor's MLP of a layer (RMSNorm -> gate|up -> SwiGLU -> down -> + residual) as ONE launch, batch <= 8, bf16 (round 5).
 struct CpMlpParams {

@@ -231,13 +231,6 @@ struct qtts_talker {
     int cp_mlp_pause_c = [] { const char* e = QTTS_ENV("QTTS_CP_MLP_PAUSE_C"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 24; }();
     int cp_mlp_step = [] { const char* e = QTTS_ENV("QTTS_CP_MLP_STEP"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 4; }();
     DevBuf mlp_act, mlp_part;          // granule buffers of the fused MLP launch
-    // A talker layer's q|k|v GEMM + attention as ONE launch (attention.hip: tk_front_kernel; round 5).  QTTS_TK_FRONT=0 (copied at engine
-    // creation): the decode GEMM, then attn_tk16.
-    bool tk_front_env = QTTS_OPT_ON("QTTS_TK_FRONT");
-    int tk_front_pause = [] { const char* e = QTTS_ENV("QTTS_TK_FRONT_PAUSE"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 24; }();
-    DevBuf tk_gran;                    // [8 rows][q|k|v width] granules {value, tag}
-    int64_t tk_front_count = 0;
-    int tk_front_per_step = 0;
     int64_t cp_mlp_count = 0;
     int cp_mlp_per_step = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
@@ -347,26 +340,9 @@ struct qtts_talker {
         // bf16 engines, code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k by kv head, partial
         // sums handed over as tagged granules and added in kv-head order; profiles/r04_cp_attn_o.md) -- and, where the layer has a q|k|v
         // GEMM of its own (layers >= 1: layer 0's row comes from the table), that GEMM in front of them in the same launch
-        // bf16 engines, talker layers at batch <= 8, short sequences: q|k|v GEMM + attention in one launch (attention.hip: tk_front_kernel)
-        const bool fuse_tk = tk_front_env && tk_gran.p && len_dev && h16 && att16 && !skinny_only && a.nsplit <= 1 && tk_front_takes(a, d.H) && layer < 128;
-        if (fuse_tk) {
-            TkFrontParams f{};
-            f.a = a; f.Wqkv = L.qkv_p.p; f.x16 = xs16; f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = tk_gran.as<float>();
-            f.serial = ss.frame_serial; f.slot = layer; f.phase = 2; f.err = ss.n_generated + 5; f.done_latch = ss.done;
-            f.first_pause = tk_front_pause; f.poll_step = cp_attn_o_step;
-            if (timing_now) {          // bench.py's roofline leg (stack 5: the talker's fused q|k|v + attention launch)
-                LaunchEv e{nullptr, nullptr, 5, a.ld, d.H, 2.0 * (double)a.ld * d.H};
-                QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
-                ev.push_back(e);
-                tk_front_set_launch_events(e.a, e.b);
-                try { launch_tk_front(f, st); } catch (...) { tk_front_set_launch_events(nullptr, nullptr); throw; }
-                tk_front_set_launch_events(nullptr, nullptr);
-            } else launch_tk_front(f, st);
-            ++tk_front_count;
-        }
         const bool fuse_ao = cp_attn_o_env && L.o_p16.p && ao_part.p && att16 && !skinny_only && cp_attn_o_takes(a, d.H) && layer < 5 && len_static * 5 + layer < 128;
         const bool front = fuse_ao && !skip_qkv && h16 && cp_front_env && d.H == 1024 && a.ld == 4 * 8 * (d.H / 128) * 16;
-        if (!skip_qkv && !front && !fuse_tk) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
+        if (!skip_qkv && !front) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
             if (splitk && sk_pending) {    // the previous layer's down-projection left (residual + half 0, half 1): added on the way in
                 p.xp = sk_part.as<float>(); p.xp_stride = pstride; p.x_out = xs;
                 sk_pending = false;
@@ -395,7 +371,7 @@ struct qtts_talker {
             } else launch_cp_attn_o(f, st);
             ++cp_attn_o_count;
         } else {
-        if (!skinny_only && !fuse_tk) launch_attn_decode(a, st);
+        if (!skinny_only) launch_attn_decode(a, st);
         SkinnyParams o{};
         o.done_flag = ss.done;
         o.x_bf16 = att16;
@@ -514,64 +490,57 @@ struct qtts_talker {
         destroy_graph(); release_events();
         fused_release();
     }
-    // The fused launches (attention.hip: cp_attn_o_kernel, tk_front_kernel; cp_mlp.hip: cp_mlp_kernel) are correct only when ALL workgroups of a
-    // launch are resident at once: workgroups wait for granules that other workgroups of the same launch produce.  Residency is a property of
-    // the DEVICE, so the admission is per device (round 5), and it is an account of the one resource that limits it here, the
+    // The fused launches (attention.hip: cp_attn_o_kernel; cp_mlp.hip: cp_mlp_kernel) are correct only when ALL workgroups of a launch are
+    // resident at once: workgroups wait for granules that other workgroups of the same launch produce.  Residency is a property of the
+    // DEVICE, so the admission is per device (round 5), and it is an account of the one resource that limits it here, the
     // register file: a compute unit has 512 registers per lane and SIMD; a launch of `grid` workgroups on `cus` compute units puts
-    // ceil(grid / cus) workgroups on a compute unit, each with (waves per SIMD) x (registers per wave) of that budget --
-    //     cp_attn_o / cp_mlp   4 waves of <= 184 registers, one per SIMD      -> CP_SHARE  = 184 per workgroup
-    //     tk_front             8 waves of <= 208 registers, two per SIMD      -> TK_SHARE  = 416 per workgroup
+    // ceil(grid / cus) workgroups on a compute unit, each -- 4 waves, one per SIMD, of <= 184 registers -- with CP_SHARE = 184 of that budget
     // (the code objects' own numbers are pinned by tests/test_host_logic.py::test_fused_launches_fit_their_register_shares).  An engine's
     // share is that of its LARGEST fused launch (its launches run one after the other on one stream); engines are admitted while the shares
-    // of the fused engines of a device add up to <= 512: on a whole MI355X one engine with every fusion (416), or two with the code
-    // predictor's (2 x 184; the first engine is asked first and takes all it can -- QTTS_TK_FRONT=0 leaves room for a second), on a CPX
-    // partition (32 compute units: 8 workgroups of a 256-workgroup launch per unit) none.  Kernels that do not wait for anybody (the codec
-    // on another stream, another engine's GEMMs) only DELAY a fused launch: they drain, their places go to the launch's pending workgroups
-    // (dispatch is in order), and the wait is bounded by their duration, far below the give-up limit.  What the rule cannot see is another
-    // PROCESS on the same device: a consumer that loses its producers there gives up after ~0.3 s, latches the stop flag (one give-up per
-    // generation, not per launch), the call fails with QTTS_ERR_STATE and the engine leaves the fused launches for good (`fused_retire`):
-    // the caller's retry runs on the separate launches.
-    static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184, TK_SHARE = 416;
+    // of the fused engines of a device add up to <= 512: two on a whole MI355X (bench.py --workload clone-shard at batch 8 runs two), none
+    // on a CPX partition (32 compute units: 8 workgroups of a 256-workgroup launch per unit).  Kernels that do not wait for anybody (the
+    // codec on another stream, another engine's GEMMs) only DELAY a fused launch: they drain, their places go to the launch's pending
+    // workgroups (dispatch is in order), and the wait is bounded by their duration, far below the give-up limit.  What the rule cannot see
+    // is another PROCESS on the same device: a consumer that loses its producers there gives up after ~0.3 s, latches the stop flag (one
+    // give-up per generation, not per launch), the call fails with QTTS_ERR_STATE and the engine leaves the fused launches for good
+    // (`fused_retire`): the caller's retry runs on the separate launches.
+    static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184;
     struct FusedRegistry { std::mutex m; std::map<int, std::pair<int, int>> dev; };        // device -> (share in use, fused engines)
     static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
-    bool cp_fused_slot = false, tk_fused_slot = false;
+    bool cp_fused_slot = false;
     int fused_device = -1, fused_capacity = 0, fused_share = 0;     // capacity: engines with this engine's share the device holds at once
     int cp_fused_per_step = 0;                         // fused launches in the frame step last launched / captured
     int cp_fused_giveups = 0;                          // generations of this engine that ended on the give-up flag
     // QTTS_CP_FUSED_MAX (A/B, tests): cap on fused engines per device below what residency allows
-    // grid_cp / grid_tk: workgroups per launch of the code predictor's / the talker's fused kernels (0: not wanted); occ_ok: the occupancy API
-    // finds room for at least one workgroup of every wanted kernel on a compute unit
-    void fused_admit(int grid_cp, int grid_tk, bool occ_ok) {
+    // grid_cp: workgroups per launch of the engine's largest fused kernel; occ_ok: the occupancy API finds room for at least one workgroup of
+    // every wanted kernel on a compute unit
+    void fused_admit(int grid_cp, bool occ_ok) {
         QTTS_CHECK_HIP(hipGetDevice(&fused_device));
         int cus = 0;
         QTTS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fused_device));
-        const int need_cp = grid_cp > 0 ? CP_SHARE * cdiv(grid_cp, std::max(1, cus)) : 0;
-        const int need_tk = grid_tk > 0 ? TK_SHARE * cdiv(grid_tk, std::max(1, cus)) : 0;
+        const int need = grid_cp > 0 ? CP_SHARE * cdiv(grid_cp, std::max(1, cus)) : 0;
         int max_engines = 1 << 20;
         if (const char* e = QTTS_ENV("QTTS_CP_FUSED_MAX")) max_engines = std::max(0, atoi(e));
         auto& r = fused_registry();
         std::lock_guard<std::mutex> lk(r.m);
         auto& d = r.dev[fused_device];
-        const int full = std::max(need_cp, need_tk);
-        fused_capacity = need_cp > 0 && occ_ok ? std::min(max_engines, CU_REG_BUDGET / need_cp) : 0;
-        if (!occ_ok || d.second + 1 > max_engines) return;
-        if (need_tk > 0 && d.first + full <= CU_REG_BUDGET) { fused_share = full; tk_fused_slot = true; cp_fused_slot = need_cp > 0; }
-        else if (need_cp > 0 && d.first + need_cp <= CU_REG_BUDGET) { fused_share = need_cp; cp_fused_slot = true; }
-        else return;
+        fused_capacity = need > 0 && occ_ok ? std::min(max_engines, CU_REG_BUDGET / need) : 0;
+        if (!occ_ok || need <= 0 || d.second + 1 > max_engines || d.first + need > CU_REG_BUDGET) return;
+        fused_share = need; cp_fused_slot = true;
         d.first += fused_share; d.second += 1;
     }
     void fused_release() {
-        if (!cp_fused_slot && !tk_fused_slot) return;
+        if (!cp_fused_slot) return;
         auto& r = fused_registry();
         std::lock_guard<std::mutex> lk(r.m);
         auto& d = r.dev[fused_device];
         d.first -= fused_share; d.second -= 1;
-        cp_fused_slot = tk_fused_slot = false; fused_share = 0;
+        cp_fused_slot = false; fused_share = 0;
     }
     // after a give-up: this engine runs the separate launches from now on (graphs that baked the fused launch in are dropped)
     void fused_retire() {
         ++cp_fused_giveups;
-        cp_attn_o_env = false; cp_mlp_env = false; tk_front_env = false;
+        cp_attn_o_env = false; cp_mlp_env = false;
         fused_release();
         destroy_graph();
         graph_nodes = 0;
@@ -597,18 +566,15 @@ void qtts_talker::finalize() {
     const int G = c.num_code_groups;
     if (!bf16 || !cp_mlp_instantiated(cd.H, cd.I)) cp_mlp_env = false;
     const bool want_ao = bf16 && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0;
-    const bool want_tk = bf16 && tk_front_env && c.max_batch <= 8 && td.nh == 16 && td.nkv == 8 && td.hd == 128 && (td.H == 1024 || td.H == 2048) &&
-                         QTTS_OPT_ON("QTTS_ATTN_MFMA");
-    if (want_ao || cp_mlp_env || want_tk) {      // one admission for the engine's fused launches
+    if (want_ao || cp_mlp_env) {      // one admission for the engine's fused launches
         int grid_cp = 0;
         bool occ_ok = true;
         if (want_ao) { grid_cp = std::max(grid_cp, cp_attn_o_grid(cd.H)); occ_ok = occ_ok && cp_attn_o_blocks_per_cu() >= 1; }
         if (cp_mlp_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp_blocks_per_cu(cd.H, cd.I) >= 1; }
-        fused_admit(grid_cp, want_tk ? tk_front_grid() : 0, occ_ok);
+        fused_admit(grid_cp, occ_ok);
     }
     if (!want_ao || !cp_fused_slot) cp_attn_o_env = false;
     if (!cp_fused_slot) cp_mlp_env = false;
-    if (!want_tk || !tk_fused_slot) tk_front_env = false;
     tl.resize(c.num_hidden_layers);
     for (int l = 0; l < c.num_hidden_layers; ++l) build_layer(tl[l], "model.layers." + std::to_string(l) + ".", td, true);
     cl.resize(c.cp_num_hidden_layers);
@@ -734,10 +700,6 @@ void qtts_talker::finalize() {
         const size_t hmax = (size_t)std::max(td.H, cd.H);
         sk_part.alloc(2 * 8 * hmax * 4);
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
-    }
-    if (tk_front_env) {
-        tk_gran.alloc((size_t)8 * (td.qd + 2 * td.kvd) * 8);
-        QTTS_CHECK_HIP(hipMemset(tk_gran.p, 0, tk_gran.bytes));
     }
     if (bf16 && !cl.empty() && cl[0].gu_mlp.p) {
         mlp_act.alloc((size_t)8 * 8 * (cd.I / 16) * 8);
@@ -884,7 +846,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
                              int max_frames, hipStream_t st) {
     const auto& c = cfg;
     const int G = c.num_code_groups;
-    const int64_t fused_before = cp_attn_o_count, mlp_before = cp_mlp_count, tk_before = tk_front_count;
+    const int64_t fused_before = cp_attn_o_count, mlp_before = cp_mlp_count;
     // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
     cur_stack = 1;
     for (int j = 0; j < G - 1; ++j) {
@@ -973,7 +935,6 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
     cp_fused_per_step = (int)(cp_attn_o_count - fused_before);      // (a captured step replays exactly these launches)
     cp_mlp_per_step = (int)(cp_mlp_count - mlp_before);
-    tk_front_per_step = (int)(tk_front_count - tk_before);
 }
 
 // ============================================================================================ C ABI
@@ -1384,7 +1345,7 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     out->cp_fused_launches_last = (int64_t)out->cp_fused_per_step * t->frames_run;
     out->cp_fused_giveups = t->cp_fused_giveups; out->cp_fused_capacity = t->fused_capacity; out->cp_fused_active = t->cp_fused_slot ? 1 : 0;
     out->cp_mlp_per_step = t->cp_fused_slot ? t->cp_mlp_per_step : 0;
-    out->tk_front_per_step = t->tk_fused_slot ? t->tk_front_per_step : 0; out->tk_front_active = t->tk_fused_slot ? 1 : 0;
+    out->reserved2_ = 0;
     QTTS_API_END
 }
 int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n) {

@@ -380,62 +380,3 @@ extern "C" int hostemu_cp_mlp(const float* x, int B, const float* Wg, const floa
         return e.code;
     }
 }
-
-// tk_front_kernel (attention.hip): a talker layer's q|k|v GEMM + single-token attention as one launch against the two launches it replaces
-// (decode GEMM with the RMSNorm folded in, then attn_tk16 on a bf16 cache with transposed V pages).  16 / 8 heads of 128, K = hidden.
-// mode 0: the two launches; mode 2: the fused launch, twice on the same granule buffer under two serials, then the consuming half alone under the
-// launch's own tag (bit-identical) and under another slot / serial (stale: give-up + latch).  The attention output (bf16) lands in out16.
-extern "C" int hostemu_tk_front(const float* x, int B, const float* Wqkv, const float* gnorm, float eps_in, const float* qw, const float* kw, float eps,
-                                const float* inv_freq, const int* n_pad, int S0, void* kpool, void* vpool, const int* page_table, int pages_per_seq,
-                                int H, unsigned short* out16, int mode, unsigned epoch0) {
-    try {
-        const int nh = 16, nkv = 8, qd = nh * 128, ld = (nh + 2 * nkv) * 128;
-        std::vector<qtts::bf16_t> x16((size_t)B * H);
-        for (size_t i = 0; i < x16.size(); ++i) x16[i] = qtts::f32_to_bf16(x[i]);
-        std::vector<unsigned char> wq(qtts::skinny_packed_bytes(ld, H, true));
-        qtts::pack_skinny_weight(Wqkv, ld, H, true, wq.data(), gnorm, 16);
-        std::vector<float> qkv((size_t)B * ld, NAN);
-        qtts::AttnDecodeParams a{};
-        a.qkv = qkv.data(); a.ld = ld; a.B = B; a.n_new = 1; a.nh = nh; a.nkv = nkv; a.hd = 128;
-        a.qw = qw; a.kw = kw; a.eps = eps; a.inv_freq = inv_freq; a.n_pad = n_pad; a.len_dev = &S0; a.len_static = S0;
-        a.kv.k = kpool; a.kv.v = vpool; a.kv.page_table = page_table; a.kv.pages_per_seq = pages_per_seq;
-        a.kv.n_pages = B * pages_per_seq; a.kv.nkv = nkv; a.kv.hd = 128; a.kv.bf16 = 1; a.kv.contig = page_table ? 0 : 1; a.kv.vt = 1;
-        a.layer = 0; a.max_len = S0 + 4; a.out = reinterpret_cast<float*>(out16); a.ldo = qd; a.out_bf16 = 1;
-        if (mode == 2) {
-            std::vector<float> gran((size_t)8 * ld * 2, 0.f);
-            int serial = (int)epoch0, err = 0, latch = 0;
-            qtts::TkFrontParams f{};
-            f.a = a; f.a.qkv = nullptr; f.Wqkv = wq.data(); f.x16 = x16.data(); f.ldx16 = H; f.K = H; f.eps_in = eps_in; f.qkv_gran = gran.data();
-            f.serial = &serial; f.slot = 5; f.phase = 2; f.err = &err; f.done_latch = &latch; f.first_pause = 16; f.poll_step = 4;
-            if (!qtts::tk_front_takes(f.a, H)) return -2;
-            for (int rep = 0; rep < 2; ++rep) {
-                if (rep) ++serial;                              // (the second launch appends the same K / V row again: idempotent)
-                qtts::launch_tk_front(f, nullptr);
-                if (err || latch) return -4;
-            }
-            std::vector<unsigned short> keep(out16, out16 + (size_t)B * qd);
-            for (int variant = 0; variant < 3; ++variant) {
-                qtts::TkFrontParams c2 = f;
-                c2.phase = 1;
-                if (variant == 1) c2.slot = f.slot + 1;
-                int serial2 = serial + 1;
-                if (variant == 2) c2.serial = &serial2;
-                err = 0; latch = 0;
-                qtts::launch_tk_front(c2, nullptr);
-                if ((variant == 0) != (err == 0)) return -5 - variant;
-                if ((err != 0) != (latch != 0)) return -9;
-                if (variant == 0 && memcmp(out16, keep.data(), keep.size() * 2) != 0) return -8;
-            }
-            memcpy(out16, keep.data(), keep.size() * 2);
-            return 0;
-        }
-        qtts::SkinnyParams q{};
-        q.x = reinterpret_cast<const float*>(x16.data()); q.x_bf16 = 1; q.ldx = H; q.M = B; q.Wp = wq.data(); q.N = ld; q.K = H;
-        q.fs = 16; q.norm = 1; q.eps = eps_in; q.out = qkv.data(); q.ldo = ld; q.act = qtts::ACT_NONE;
-        qtts::launch_skinny(q, true, nullptr);
-        qtts::launch_attn_decode(a, nullptr);
-        return 0;
-    } catch (const qtts::Error& e) {
-        return e.code;
-    } catch (...) { return -1; }
-}

@@ -627,7 +627,7 @@ def test_bf16_mode_pinned_at_the_metric_config_teacher_forced(dev, golden_dir):
     # the pin is a pin of the BENCHMARKED construction: every frame went through the fused code-predictor launch
     assert st["cp_fused_active"] == 1 and st["cp_fused_giveups"] == 0, st
     assert st["cp_fused_per_step"] == (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers and st["cp_fused_launches_last"] == st["cp_fused_per_step"] * st["frames_run"] > 0, st
-    assert st["cp_mlp_per_step"] == st["cp_fused_per_step"] and st["tk_front_active"] == 1 and st["tk_front_per_step"] == cfg.num_hidden_layers, st
+    assert st["cp_mlp_per_step"] == st["cp_fused_per_step"], st
     own = out.own.cpu().numpy()
     lt = out.logits_trace.cpu().numpy()                     # (n_steps, B, V)
     rel = lambda a, b: float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b.astype(np.float64) ** 2).mean()))
@@ -751,44 +751,6 @@ def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(
     assert a3 >= 0.85 and g3 >= p3 - 0.04
 
 
-def test_fused_talker_qkv_attention_equals_the_two_launches_on_the_frame_step(dev, golden_dir):
-    """`tk_front_kernel` (round 5: a talker layer's q|k|v GEMM and its single-token attention in ONE launch -- 256 workgroups x 8 waves, the
-    strips handed to the attention waves as tagged granules, the cache window requested at kernel entry) against the two launches it replaces
-    (QTTS_TK_FRONT=0) on the hardware, through the whole frame step: 0.6B dims, batch 8 and batch 3, bf16, 40 frames teacher-forced with the
-    reference's golden codes, captured frame graph, ragged left padding.  (1) The engine's own word on the path (`tk_front_per_step`).
-    (2) Three runs of the fused engine give the same codes bit for bit.  (3) Both forms compute the same bf16 products in another fp32
-    summation order (the GEMM's k split: four quarters here, eight waves there): cb-0 decisions agree >= 0.97, sub-codebooks >= 0.85,
-    agreement with the fp32 golden no worse than the separate launches' by more than 0.03."""
-    from qwen3_tts_amd.talker import TalkerEngine
-    cfg = synth.talker_06b()
-    g = np.load(os.path.join(golden_dir, "talker_06b_b8.npz"))
-    wn = synth.talker_weights(cfg, with_text=False)
-    lens = [int(x) for x in g["lens"]]
-    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
-    gc = torch.from_numpy(g["codes"][:, :40].copy())
-    for nb in (len(lens), 3):
-        res = {}
-        for flag in ("1", "0"):
-            with _qlib.options(QTTS_TK_FRONT=flag):
-                eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=nb, max_seq=256, use_graph=True)
-                res[flag] = [eng.generate(emb[:nb], mask[:nb], tr[:nb], pad, teacher_codes=gc[:nb], suppress_tokens=_suppress(cfg)).own.cpu().numpy()
-                             for _ in range(3 if flag == "1" else 2)]
-                st = eng.stats()
-                assert st["tk_front_active"] == int(flag) and st["tk_front_per_step"] == (cfg.num_hidden_layers if flag == "1" else 0) and st["cp_fused_giveups"] == 0, st
-                del eng
-                torch.cuda.empty_cache()
-        f, p2 = res["1"], res["0"]
-        assert np.array_equal(f[0], f[1]) and np.array_equal(f[0], f[2]), f"batch {nb}: the fused talker launch is not run-to-run identical"
-        assert np.array_equal(p2[0], p2[1]), f"batch {nb}: the separate launches are not run-to-run identical"
-        a0 = float((f[0][:, :, 0] == p2[0][:, :, 0]).mean())
-        agree = float((f[0][:, :, 1:] == p2[0][:, :, 1:]).mean())
-        ag = float((f[0][:, :40, 1:] == g["codes"][:nb, :40, 1:]).mean())
-        pg = float((p2[0][:, :40, 1:] == g["codes"][:nb, :40, 1:]).mean())
-        print(f"tk_front vs decode GEMM + attn_tk16 (0.6B, {nb} x 40 frames, teacher-forced): cb-0 agree {a0:.4f}, sub-codebooks {agree:.4f}; against the fp32 golden: "
-              f"fused {ag:.4f}, two launches {pg:.4f}")
-        assert a0 >= 0.97 and agree >= 0.85 and ag >= pg - 0.05
-
-
 def test_fused_mlp_equals_the_two_launches_on_the_frame_step(dev, golden_dir):
     """`cp_mlp_kernel` (round 5: the code predictor's MLP of a layer -- gate|up GEMM, SwiGLU, down GEMM, residual -- in ONE launch, the
     intermediate vector sliced by XCD, partial sums added in XCD order) against the two decode-GEMM launches it replaces (QTTS_CP_MLP=0)
@@ -831,10 +793,8 @@ def test_fused_launch_under_contention_codec_stream_and_other_engines(dev, golde
     """VERDICT r4 item 1(c).  The fused launches wait, inside a launch, for workgroups of the same launch -- so what happens when the device
     is busy with other work?  0.6B dims, batch 8, 40 frames teacher-forced, captured frame graphs; the engine under test generates (a)
     alone, then (b) three times while, from other host threads and on other streams, a codec engine decodes in a loop and two more talker
-    engines generate in a loop.  Twice: first with the code predictor's fused launches only (QTTS_TK_FRONT=0: two such engines fit a device
-    side by side -- the second one runs as a neighbour, the third is beyond the account and runs the separate launches), then with an
-    engine that holds the talker's fused launch too (it fills the account: its neighbours run the separate launches).  Kernels that wait
-    for nobody only delay a fused launch, so: no give-up (no QTTS_ERR_STATE, `cp_fused_giveups` 0 on every engine), the codes of (b) are
+    engines generate in a loop: a second fused engine (two fit a device side by side) and a third that is beyond the device's account
+    and runs the separate launches.  Kernels that wait for nobody only delay a fused launch, so: no give-up (no QTTS_ERR_STATE, `cp_fused_giveups` 0 on every engine), the codes of (b) are
     those of (a) bit for bit, and every neighbour is run-to-run identical as well -- the check that caught, in this round, a packed-fp32
     instruction sequence returning wrong lanes under contention (qwen3-tts_amd/build.py FLAGS; profiles/r05_packed_fp32_hazard.md)."""
     import threading
@@ -897,22 +857,12 @@ def test_fused_launch_under_contention_codec_stream_and_other_engines(dev, golde
             assert e.stats()["cp_fused_giveups"] == 0, (tag, name, e.stats())
         print(f"contention ({tag}): background loops {loops}; 3 contended runs == the quiet run")
 
-    with _qlib.options(QTTS_TK_FRONT="0"):
-        a, b, c = mk(), mk(), mk()
+    a, b, c = mk(), mk(), mk()
     st = [e.stats() for e in (a, b, c)]
     assert st[0]["cp_fused_capacity"] == 2, f"an MI355X holds two launches of the code predictor's fused kernels side by side, the engine says {st[0]['cp_fused_capacity']}"
-    assert [x["cp_fused_active"] for x in st] == [1, 1, 0] and [x["tk_front_active"] for x in st] == [0, 0, 0], st
-    contended(a, [("b", b), ("c", c)], "code predictor's fused launches, two engines + a third on the separate launches")
+    assert [x["cp_fused_active"] for x in st] == [1, 1, 0], st
+    contended(a, [("b", b), ("c", c)], "two fused engines + a third on the separate launches")
     assert a.stats()["cp_fused_launches_last"] > 0 and b.stats()["cp_fused_launches_last"] > 0 and c.stats()["cp_fused_launches_last"] == 0
-    del a, b, c
-    import gc as _gc
-    _gc.collect()              # (the account is per device: the three engines above must be gone before the next one is admitted)
-    torch.cuda.empty_cache()
-    d, e2, f2 = mk(), mk(), mk()
-    st = [x.stats() for x in (d, e2, f2)]
-    assert [x["tk_front_active"] for x in st] == [1, 0, 0] and [x["cp_fused_active"] for x in st] == [1, 0, 0], st
-    contended(d, [("e", e2), ("f", f2)], "every fused launch on one engine, two neighbours on the separate launches")
-    assert d.stats()["tk_front_per_step"] == cfg.num_hidden_layers and d.stats()["cp_fused_launches_last"] > 0
 
 
 def test_sampler_distribution_matches_hf_processors(talker_tiny, dev):

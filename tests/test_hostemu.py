@@ -56,7 +56,6 @@ def emu():
     lib.hostemu_set_block_order.argtypes = [i32]; lib.hostemu_set_block_order.restype = None
     lib.hostemu_cp_layer_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.c_uint32]
     lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
-    lib.hostemu_tk_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
     lib.hostemu_cp_mlp.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, i32, i32, vp, vp, vp, i32, C.c_uint32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
@@ -777,72 +776,6 @@ def test_cp_attn_o_fused_launch_real_source(emu):
             if first is None:
                 first = o1
             assert np.array_equal(o1, first), ("result depends on the wave order / the epoch", B, S0, bo, fo)
-
-
-def test_tk_front_qkv_gemm_and_talker_attention_one_launch_real_source(emu):
-    """`tk_front_kernel` (attention.hip, round 5): a TALKER layer's q|k|v GEMM and its single-token attention as ONE launch of 256 workgroups x
-    8 waves -- waves 4-7 the 16-feature strip of q|k|v (RMSNorm folded, k quarters added in wave order, handed on as tagged granules), waves
-    0-3 of the first (sequences x kv heads) workgroups attn_tk16's body with its rows read back from those granules (cache window requested
-    first).  Real source at the 0.6B talker's width (hidden 1024, 16 / 8 heads of 128), bf16 cache with transposed V pages, ragged left
-    padding, 40 and 150 cached keys (inside / across the 128-key blocks of the four waves), contiguous and permuted page tables, batch 8 / 3,
-    against the two launches it replaces: the appended K / V rows equal up to a bf16 last-bit flip (the two GEMMs sum their k in another
-    order), the attention output to bf16 noise; three fiber orders give the same bits; two launches per call on the same granule buffer
-    under two serials; the consuming half alone reproduces the result under the launch's own tag and gives up (flag + stop latch) under a
-    foreign one."""
-    g = np.random.default_rng(707)
-    HD, nh, nkv, H, eps, eps_in = 128, 16, 8, 1024, 1e-6, 1e-6
-    qd, ld = nh * HD, (nh + 2 * nkv) * HD
-    inv_freq = (1.0 / (10000.0 ** (np.arange(64) / 64.0))).astype(np.float32)
-    qw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
-    kw = (1 + 0.1 * g.standard_normal(HD)).astype(np.float32)
-    gn = (1 + 0.1 * g.standard_normal(H)).astype(np.float32)
-    Wqkv = (g.standard_normal((ld, H)) * 0.04).astype(np.float32)
-    for (B, S0, npads, permute) in [(8, 40, [0, 3, 0, 7, 1, 0, 12, 5], False), (3, 150, [0, 21, 64], True)]:
-        pps = (S0 + 1 + 15) // 16 + 1
-        n_pages = B * pps
-        table = (g.permutation(n_pages) if permute else np.arange(n_pages)).astype(np.int32).reshape(B, pps)
-        npad = np.asarray(npads, np.int32)
-        x = g.standard_normal((B, H)).astype(np.float32)
-        K = _bf16_round((g.standard_normal((B, nkv, S0, HD)) * 0.7).astype(np.float32))[0]
-        V = _bf16_round(g.standard_normal((B, nkv, S0, HD)).astype(np.float32))[0]
-        kp = np.full((n_pages, nkv, 16, HD), np.nan, np.float32)
-        vp_ = np.full((n_pages, nkv, HD, 16), np.nan, np.float32)
-        for b in range(B):
-            for s_ in range(npad[b], S0):
-                kp[table[b, s_ // 16], :, s_ % 16] = K[b, :, s_]
-                vp_[table[b, s_ // 16], :, :, s_ % 16] = V[b, :, s_]
-        kpool, vpool = _bf16_round(np.nan_to_num(kp, nan=0.0))[1].copy(), _bf16_round(np.nan_to_num(vp_, nan=0.0))[1].copy()
-        kpool[np.isnan(kp)] = 0x7FC0; vpool[np.isnan(vp_)] = 0x7FC0
-
-        def run(mode, fiber_order=0, epoch0=1):
-            kk, vv = kpool.copy(), vpool.copy()
-            out16 = np.full((B, qd), 0x4242, np.uint16)
-            emu.hostemu_set_fiber_order(fiber_order)
-            try:
-                rc = emu.hostemu_tk_front(_ptr(x), B, _ptr(Wqkv), _ptr(gn), eps_in, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), _ptr(npad), S0, _ptr(kk),
-                                          _ptr(vv), _ptr(table) if permute else None, pps, H, _ptr(out16), mode, epoch0)
-            finally:
-                emu.hostemu_set_fiber_order(0)
-            assert rc == 0, ((B, S0, mode), rc, (emu.qtts_last_error() or b"").decode())
-            return (out16.astype(np.uint32) << 16).view(np.float32), out16, kk, vv
-
-        o0, h0, k0, v0 = run(0)
-        assert np.isfinite(o0).all()
-        first = None
-        for (fo, e0) in [(0, 1), (1, 9), (2, 0xFFFFF0)]:
-            o2, h2, k2, v2 = run(2, fo, e0)
-            assert np.isfinite(o2).all()
-            assert float(np.sqrt(((o2 - o0) ** 2).mean())) <= 6e-3 * float(np.sqrt((o0 ** 2).mean())), (B, S0)
-            assert float(np.abs(o2 - o0).max()) <= 3e-2 * max(1.0, float(np.abs(o0).max())), (B, S0)
-            # the appended rows: the same values up to the fp32 summation order of the two GEMMs, i.e. a last-place flip of the bf16 rounding
-            # (more than one place only where the sum cancels to nearly nothing)
-            f32 = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
-            for cur, ref in ((k2, k0), (v2, v0)):
-                w = cur != ref
-                assert w.mean() < 0.02 and float(np.abs(f32(cur)[w] - f32(ref)[w]).max(initial=0.0)) <= 2e-2, (B, S0, float(w.mean()))
-            if first is None:
-                first = h2
-            assert np.array_equal(h2, first), ("result depends on the wave order / the epoch", B, S0, fo)
 
 
 @pytest.mark.parametrize("H,I", [(256, 1024), (1024, 3072)])
@@ -1817,60 +1750,6 @@ def test_talker_bf16_fused_mlp_in_the_frame_step(emu, qopt):
                     st = _lib.TalkerStatsC()
                     _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
                     assert st.cp_mlp_per_step == (per_step if mode == "1" else 0) and st.cp_fused_per_step == per_step and st.cp_fused_giveups == 0
-                    res[(mode, use_graph)] = (codes, hidden)
-                finally:
-                    emu.qtts_talker_destroy(h)
-    finally:
-        emu.hostemu_set_real_gemm(1 if FULL else 0)
-    for mode in ("1", "0"):
-        assert np.array_equal(res[(mode, 0)][0], res[(mode, 1)][0]) and np.array_equal(res[(mode, 0)][1], res[(mode, 1)][1]), mode
-    fused, plain = res[("1", 1)], res[("0", 1)]
-    n = min(fused[0].shape[1], plain[0].shape[1])
-    assert n >= 2 and float((fused[0][:, :n] == plain[0][:, :n]).mean()) >= 0.9
-    same = (fused[0][:, :n] == plain[0][:, :n]).all(axis=(0, 2))
-    k = int(np.argmin(same)) if not same.all() else n
-    assert k >= 1
-    assert np.abs(fused[1][:, :k] - plain[1][:, :k]).max() <= 2e-2 * max(1.0, float(np.abs(plain[1][:, :k]).max()))
-
-
-def test_talker_bf16_fused_qkv_attention_in_the_frame_step(emu, qopt):
-    """Round 5: the ENGINE side of `tk_front_kernel` -- which talker layers take it (bf16 engines created for batch <= 8 whose device had the
-    register share left for it; short sequences only: the split-KV buckets keep the two launches), the granule buffer, the slot per layer --
-    on a talker with the real head geometry (16 query / 8 kv heads of 128) and a 1024-wide hidden state, two layers, greedy bf16, eager and
-    through the captured frame graph: codes and hidden states equal those of the same engine with QTTS_TK_FRONT=0 up to bf16 noise (the two
-    q|k|v GEMMs sum their k in another order), `tk_front_per_step` says which path ran, a second generation on the same handle repeats the
-    first bit for bit, and a second engine on the same device is told that the share is taken (`tk_front_active` 0)."""
-    import dataclasses
-    t = dataclasses.replace(synth.talker_tiny(), hidden_size=1024, intermediate_size=256, num_hidden_layers=2, num_attention_heads=16,
-                            num_key_value_heads=8, head_dim=128)
-    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
-    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(37), t, [6, 3, 5], 2, scale=0.5)
-    args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
-    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
-    emu.hostemu_set_real_gemm(1)
-    res = {}
-    try:
-        for mode in ("1", "0"):
-            qopt(emu, "QTTS_TK_FRONT", mode)
-            for use_graph in (0, 1):
-                h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=use_graph)
-                try:
-                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=4)
-                    if mode == "1":
-                        codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=4)
-                        assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2), (mode, use_graph)
-                    st = _lib.TalkerStatsC()
-                    _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
-                    assert st.tk_front_per_step == (t.num_hidden_layers if mode == "1" else 0) and st.tk_front_active == int(mode) and st.cp_fused_giveups == 0
-                    if mode == "1" and use_graph:
-                        h2 = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=1)
-                        try:
-                            _talker_generate(emu, h2, t, *args, max_new=3)
-                            st2 = _lib.TalkerStatsC()
-                            _ok(emu, emu.qtts_talker_get_stats(h2, C.byref(st2)))
-                            assert st2.tk_front_active == 0 and st2.tk_front_per_step == 0, "a second engine was given the talker's fused launch beside the first"
-                        finally:
-                            emu.qtts_talker_destroy(h2)
                     res[(mode, use_graph)] = (codes, hidden)
                 finally:
                     emu.qtts_talker_destroy(h)

@@ -17,8 +17,6 @@ CONFIGS = {
     "default": {},
     "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
     "cp_fused_off": {"QTTS_CP_MLP": "0", "QTTS_CP_ATTN_O": "0"},   # ... and q|k|v / attention / o-projection as separate launches (round 3's)
-    "tk_front_off": {"QTTS_TK_FRONT": "0"},                         # round 5: the talker's q|k|v GEMM and attention as two launches
-    "tk_pause12": {"QTTS_TK_FRONT_PAUSE": "12"}, "tk_pause16": {"QTTS_TK_FRONT_PAUSE": "16"}, "tk_pause32": {"QTTS_TK_FRONT_PAUSE": "32"}, "tk_pause40": {"QTTS_TK_FRONT_PAUSE": "40"},
     "mlp_wd_early": {"QTTS_CP_MLP_WD_EARLY": "1"},                  # the fused MLP's down block requested at kernel entry (round 5's first version)
     "mlp_b16_c24": {"QTTS_CP_MLP_PAUSE_B": "16"}, "mlp_b20_c24": {"QTTS_CP_MLP_PAUSE_B": "20"}, "mlp_b28_c24": {"QTTS_CP_MLP_PAUSE_B": "28"},
     "mlp_b24_c16": {"QTTS_CP_MLP_PAUSE_C": "16"}, "mlp_b24_c20": {"QTTS_CP_MLP_PAUSE_C": "20"}, "mlp_b24_c28": {"QTTS_CP_MLP_PAUSE_C": "28"},
@@ -67,7 +65,7 @@ def main():
             res[n].append(round(ms, 4))
             st = eng.stats()
             print(f"[ab_inproc] rep {rep} {n:28s} {ms:.3f} ms/frame   (graph nodes {st['graph_nodes']}, fused launches per step: attention {st['cp_fused_per_step']}, "
-                  f"mlp {st['cp_mlp_per_step']}, talker {st['tk_front_per_step']})", flush=True)
+                  f"mlp {st['cp_mlp_per_step']})", flush=True)
             del eng; gc.collect(); torch.cuda.empty_cache()
     out = {n: {"ms_per_frame": v, "min": min(v), "median": float(np.median(v))} for n, v in res.items()}
     print(json.dumps(out))
