@@ -390,12 +390,12 @@ typedef struct {
     int32_t attn_nsplit_last; /* split-KV workgroups per (sequence, kv head) of the last launched frame step (1 = short mode) */
     int32_t attn_span_last;   /* the key span those workgroups partition (the live length's bucket; 0 = short mode) */
     /* the code predictor's fused launch (q|k|v + attention + o-projection of a layer in one launch; ABI v10) */
-    int32_t cp_fused_per_step;      /* fused launches in the frame step last launched / captured (0: this engine runs the separate launches) */
+    int32_t cp_fused_per_step;      /* fused attention + o-projection launches in the frame step last launched / captured (0: separate launches; bf16 only) */
     int64_t cp_fused_launches_last; /* = cp_fused_per_step x frames_run of the last generation                                              */
     int32_t cp_fused_giveups;       /* generations that ended with QTTS_ERR_STATE because a consumer gave up (the engine then left the fused launch) */
     int32_t cp_fused_capacity;      /* engines with the code predictor's fused launches the DEVICE holds at once (register-share account, talker_engine.hip) */
     int32_t cp_fused_active;        /* 1: this engine holds one of those places                                                             */
-    int32_t cp_mlp_per_step;        /* fused MLP launches (cp_mlp.hip: gate|up + SwiGLU + down of a code-predictor layer) in that frame step */
+    int32_t cp_mlp_per_step;        /* fused MLP launches (cp_mlp.hip: gate|up + SwiGLU + down of a code-predictor layer; bf16 and fp32) in that frame step */
     int32_t reserved2_;
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);

@@ -37,10 +37,10 @@ namespace qtts {
 
 // Packed gate|up operator of the fused launch: [workgroup b = xcd + 8 j][H / 32 k-tiles][4 k-slices][2 ACT rows: ACT gate | ACT up][8 bf16],
 // RMSNorm weight g folded in.  Workgroup (xcd, j) owns intermediate features xcd * (I / 8) + j * ACT + r.
-size_t cp_mlp_gu_bytes(int H, int I) { return (size_t)2 * I * H * 2; }
-void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int I, void* out_host) {
-    const int J = H / 32, ACT = I / (8 * J), nkt = H / 32;
-    bf16_t* o = reinterpret_cast<bf16_t*>(out_host);
+// fp32 engines (the exact parity mode): the same with k-tiles of 16 and 4 floats per 16-byte unit.
+size_t cp_mlp_gu_bytes(int H, int I, bool bf16) { return (size_t)2 * I * H * (bf16 ? 2 : 4); }
+void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int I, bool bf16, void* out_host) {
+    const int J = H / 32, ACT = I / (8 * J), KT = bf16 ? 32 : 16, E = bf16 ? 8 : 4, nkt = H / KT;
     parallel_for(8 * J, [&](int64_t b0, int64_t b1) {
         for (int64_t b = b0; b < b1; ++b) {
             const int xcd = (int)(b & 7), j = (int)(b >> 3);
@@ -48,9 +48,13 @@ void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int
                 for (int q = 0; q < 4; ++q)
                     for (int r2 = 0; r2 < 2 * ACT; ++r2) {
                         const int f = xcd * (I / 8) + j * ACT + (r2 % ACT);
-                        const float* src = (r2 < ACT ? Wg : Wu) + (size_t)f * H + kt * 32 + q * 8;
-                        bf16_t* d = o + ((((size_t)b * nkt + kt) * 4 + q) * (2 * ACT) + r2) * 8;
-                        for (int e = 0; e < 8; ++e) d[e] = f32_to_bf16(g ? src[e] * g[kt * 32 + q * 8 + e] : src[e]);
+                        const float* src = (r2 < ACT ? Wg : Wu) + (size_t)f * H + kt * KT + q * E;
+                        const size_t unit = (((size_t)b * nkt + kt) * 4 + q) * (2 * ACT) + r2;
+                        for (int e = 0; e < E; ++e) {
+                            const float v = g ? src[e] * g[kt * KT + q * E + e] : src[e];
+                            if (bf16) reinterpret_cast<bf16_t*>(out_host)[unit * 8 + e] = f32_to_bf16(v);
+                            else reinterpret_cast<float*>(out_host)[unit * 4 + e] = v;
+                        }
                     }
         }
     });
@@ -80,11 +84,14 @@ int cp_mlp_grid(int H) { return 8 * (H / 32); }
 #define QTTS_TS_CPMLP(tail_)
 #endif
 #define QTTS_CPMLP_ARGS(P) (P).Wgu, (P).Wd, (P).x16, (P).serial, (P).done_flag, (P).ldx16, (P).slot, (P)
-// ACT: intermediate features per workgroup; KQ: k-tiles (of 32) per wave in phase A (H / 128); KTW: k-tiles of the XCD slice per wave in phase B
-template <int ACT, int KQ, int KTW>
+// ACT: intermediate features per workgroup; KQ: k-tiles per wave in phase A; KTW: k-tiles of the XCD slice per wave in phase B.
+// F32 (the exact parity mode): fp32 operators and fp32 x rows (`x16` then points to floats), k-tiles of 16 consumed by four
+// v_mfma_f32_16x16x4_f32 each, the intermediate vector travels as fp32 (one value per granule) -- as between the fp32 engines' separate launches.
+template <bool F32, int ACT, int KQ, int KTW>
 __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const void* kWd, const unsigned short* kx16, const int* kserial, const int* kdone,
                                                      int kldx16, int kslot, CpMlpParams P) {
     P.Wgu = kWgu; P.Wd = kWd; P.x16 = kx16; P.serial = kserial; P.done_flag = kdone; P.ldx16 = kldx16; P.slot = kslot;
+    constexpr int KT = F32 ? 16 : 32;                   // k per tile
     // ONE LDS object: phase A's k quarters [4 waves][64 lanes][gate, up] f32x4 + row sums of squares [4][16] | phase B's quarters [4][2 tiles][64] f32x4
     constexpr int QA_BYTES = 4 * 64 * 2 * 16 + 4 * 16 * 4, QB_BYTES = 4 * 2 * 64 * 16;
     __shared__ __attribute__((aligned(16))) unsigned char smem[QA_BYTES + QB_BYTES];
@@ -93,14 +100,16 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int nktH = P.H >> 5, nktI = P.I >> 5, slice = P.I >> 3, spairs = slice >> 1;      // spairs: granules (pairs of bf16) per row of an XCD's slice
+    const int nktH = P.H / KT, nktI = P.I / KT, slice = P.I >> 3;
+    const int spairs = F32 ? slice : slice >> 1;      // granules per row of an XCD's slice (bf16: a pair of values each; fp32: one)
     const bool run_a = P.phase == 3 || P.phase == 0, run_b = P.phase == 3 || P.phase == 1, run_c = P.phase == 3 || P.phase == 2;
     const unsigned tag = ((unsigned)*P.serial << 7) | (unsigned)P.slot;
     // ---- 0. every weight request of the launch: phase A's gate / up tiles of this wave's k quarter, then phase B's block of the down operator
     cu32x4 wg[KQ], wu[KQ], gx[KQ], wd[2][KTW];
     {
         const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wgu) + (((size_t)b * nktH + wave * KQ) * 4 + lq) * (2 * ACT) + (li < ACT ? li : 0);
-        const cu32x4* xsrc = reinterpret_cast<const cu32x4*>(P.x16 + (size_t)(li < P.B ? li : 0) * P.ldx16 + wave * KQ * 32 + lq * 8);
+        const cu32x4* xsrc = F32 ? reinterpret_cast<const cu32x4*>(reinterpret_cast<const float*>(P.x16) + (size_t)(li < P.B ? li : 0) * P.ldx16 + wave * KQ * 16 + lq * 4)
+                                 : reinterpret_cast<const cu32x4*>(P.x16 + (size_t)(li < P.B ? li : 0) * P.ldx16 + wave * KQ * 32 + lq * 8);
 #pragma unroll
         for (int ks = 0; ks < KQ; ++ks) {
             wg[ks] = wsrc[(size_t)ks * 4 * 2 * ACT];
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
     auto load_wd = [&] {
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-            const cu32x4* dsrc = reinterpret_cast<const cu32x4*>(P.Wd) + ((size_t)(j * 2 + t2) * nktI + xcd * (slice >> 5) + wave * KTW) * 64 + lane;
+            const cu32x4* dsrc = reinterpret_cast<const cu32x4*>(P.Wd) + ((size_t)(j * 2 + t2) * nktI + xcd * (slice / KT) + wave * KTW) * 64 + lane;
 #pragma unroll
             for (int t = 0; t < KTW; ++t) wd[t2][t] = dsrc[t * 64];
         }
@@ -134,17 +143,27 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
             cu32x4 xv4 = gx[ks], g4 = wg[ks], u4 = wu[ks];
             if (li >= P.B) xv4 = (cu32x4){0u, 0u, 0u, 0u};
             if (li >= ACT) { g4 = (cu32x4){0u, 0u, 0u, 0u}; u4 = g4; }
+            if constexpr (F32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(xv4[e] << 16), hi = __uint_as_float(xv4[e] & 0xffff0000u);
-                ssq += lo * lo; ssq += hi * hi;
+                for (int e = 0; e < 4; ++e) {
+                    const float xe = __uint_as_float(xv4[e]);
+                    ssq += xe * xe;
+                    ag4 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(g4[e]), xe, ag4, 0, 0, 0);
+                    au4 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(u4[e]), xe, au4, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(xv4[e] << 16), hi = __uint_as_float(xv4[e] & 0xffff0000u);
+                    ssq += lo * lo; ssq += hi * hi;
+                }
+                bf16x8 wa, wb2, xb;
+                *reinterpret_cast<cu32x4*>(&wa) = g4;
+                *reinterpret_cast<cu32x4*>(&wb2) = u4;
+                *reinterpret_cast<cu32x4*>(&xb) = xv4;
+                ag4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, ag4, 0, 0, 0);
+                au4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb2, xb, au4, 0, 0, 0);
             }
-            bf16x8 wa, wb2, xb;
-            *reinterpret_cast<cu32x4*>(&wa) = g4;
-            *reinterpret_cast<cu32x4*>(&wb2) = u4;
-            *reinterpret_cast<cu32x4*>(&xb) = xv4;
-            ag4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, ag4, 0, 0, 0);
-            au4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb2, xb, au4, 0, 0, 0);
         }
         if (!P.wd_early) load_wd();
         ssq += __shfl_xor(ssq, 16);
@@ -165,8 +184,14 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
                 const float vg = sg[r] * rs, vu = su[r] * rs;
                 a4[r] = (vg / (1.f + expf(-vg))) * vu;
             }
-            const int off = (int)((((size_t)xcd * 8 + li) * spairs + ((j * ACT + lq * 4) >> 1)) * 8);
-            wt_store16(ag, off, (cu32x4){pack_bf16(a4[0], a4[1]), tag, pack_bf16(a4[2], a4[3]), tag});
+            if constexpr (F32) {
+                const int off = (int)((((size_t)xcd * 8 + li) * spairs + j * ACT + lq * 4) * 8);
+                wt_store16(ag, off, (cu32x4){__float_as_uint(a4[0]), tag, __float_as_uint(a4[1]), tag});
+                wt_store16(ag, off + 16, (cu32x4){__float_as_uint(a4[2]), tag, __float_as_uint(a4[3]), tag});
+            } else {
+                const int off = (int)((((size_t)xcd * 8 + li) * spairs + ((j * ACT + lq * 4) >> 1)) * 8);
+                wt_store16(ag, off, (cu32x4){pack_bf16(a4[0], a4[1]), tag, pack_bf16(a4[2], a4[3]), tag});
+            }
         }
         QTTS_TS(2);
     }
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
         const int row = li < P.B ? li : 0;
         int offs[KTW];
 #pragma unroll
-        for (int t = 0; t < KTW; ++t) offs[t] = (int)((((size_t)xcd * 8 + row) * spairs + (wave * KTW + t) * 16 + lq * 4) * 8);
+        for (int t = 0; t < KTW; ++t) offs[t] = (int)((((size_t)xcd * 8 + row) * spairs + (wave * KTW + t) * 16 + lq * 4) * 8);       // (bf16: 16 pairs = 32 k per tile; fp32: 16 values)
         cu32x4 cur[KTW][2], nxt[KTW][2];
         auto load_slice = [&](cu32x4 (&d)[KTW][2]) {
 #pragma unroll
@@ -213,13 +238,21 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
         for (int t = 0; t < KTW; ++t) {
             cu32x4 xv4 = (cu32x4){cur[t][0][0], cur[t][0][2], cur[t][1][0], cur[t][1][2]};
             if (li >= P.B) xv4 = (cu32x4){0u, 0u, 0u, 0u};
-            bf16x8 xb;
-            *reinterpret_cast<cu32x4*>(&xb) = xv4;
+            if constexpr (F32) {
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                bf16x8 wa;
-                *reinterpret_cast<cu32x4*>(&wa) = wd[t2][t];
-                acc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[t2], 0, 0, 0);
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wd[t2][t][e]), __uint_as_float(xv4[e]), acc[t2], 0, 0, 0);
+            } else {
+                bf16x8 xb;
+                *reinterpret_cast<cu32x4*>(&xb) = xv4;
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    bf16x8 wa;
+                    *reinterpret_cast<cu32x4*>(&wa) = wd[t2][t];
+                    acc[t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[t2], 0, 0, 0);
+                }
             }
         }
         qb[(wave * 2 + 0) * 64 + lane] = acc[0];
@@ -287,10 +320,10 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
 static thread_local hipEvent_t tl_mlp_ev_start = nullptr, tl_mlp_ev_stop = nullptr;
 void cp_mlp_set_launch_events(hipEvent_t start, hipEvent_t stop) { tl_mlp_ev_start = start; tl_mlp_ev_stop = stop; }
 
-template <int ACT, int KQ, int KTW>
+template <bool F32, int ACT, int KQ, int KTW>
 static void launch_cp_mlp_t(const CpMlpParams& P, hipStream_t st) {
     const dim3 grid(cp_mlp_grid(P.H));
-    auto kern = cp_mlp_kernel<ACT, KQ, KTW>;
+    auto kern = cp_mlp_kernel<F32, ACT, KQ, KTW>;
 #ifdef QTTS_HOST_EMU
     // The emulator runs the workgroups of a launch one after the other: the launch runs as its three phases (the same code, the same tag).
     for (int ph = 0; ph < 3; ++ph) {
@@ -305,36 +338,49 @@ static void launch_cp_mlp_t(const CpMlpParams& P, hipStream_t st) {
 #endif
 }
 
-#define QTTS_CPMLP_CASES(X) X(12, 8, 3) X(16, 2, 1) X(16, 8, 4) X(8, 8, 2) X(4, 8, 1) X(16, 4, 2) X(8, 4, 1)
+// (bf16: k-tiles of 32, KQ = H / 128, KTW = I / 1024; fp32: k-tiles of 16, KQ = H / 64, KTW = I / 512)
+#define QTTS_CPMLP_CASES(X) X(false, 12, 8, 3) X(false, 16, 2, 1) X(false, 16, 8, 4) X(false, 8, 8, 2) X(false, 4, 8, 1) X(false, 16, 4, 2) X(false, 8, 4, 1) \
+                            X(true, 12, 16, 6) X(true, 16, 4, 2)
+
+static bool cp_mlp_shape(int H, int I, bool f32, int& act, int& kq, int& ktw) {
+    if (!cp_mlp_takes(1, H, I)) return false;
+    act = I / (H / 4); kq = H / (f32 ? 64 : 128); ktw = I / 8 / (f32 ? 16 : 32) / 4;
+    return true;
+}
 
 void launch_cp_mlp(const CpMlpParams& P, hipStream_t st) {
     QTTS_REQUIRE(cp_mlp_takes(P.B, P.H, P.I), QTTS_ERR_ARG, "cp_mlp: shape (batch <= 8, H % 128, I / (H / 4) in {4, 8, 12, 16})");
     QTTS_REQUIRE(P.Wgu && P.Wd && P.x16 && P.res && P.out && P.act_gran && P.part && P.serial, QTTS_ERR_ARG, "cp_mlp: null operand");
-    QTTS_REQUIRE(P.slot >= 0 && P.slot < 128 && P.ldx16 % 8 == 0, QTTS_ERR_ARG, "cp_mlp: slot must be 0..127, ldx16 % 8");
-    const int act = P.I / (P.H / 4), kq = P.H / 128, ktw = P.I / 8 / 32 / 4;
-#define QTTS_CPMLP_X(A, Q, T) if (act == A && kq == Q && ktw == T) { launch_cp_mlp_t<A, Q, T>(P, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
+    QTTS_REQUIRE(P.slot >= 0 && P.slot < 128 && P.ldx16 % 8 == 0 && (!P.f32 || !P.out16), QTTS_ERR_ARG, "cp_mlp: slot must be 0..127, ldx16 % 8, no bf16 copy in fp32 mode");
+    int act = 0, kq = 0, ktw = 0;
+    cp_mlp_shape(P.H, P.I, P.f32 != 0, act, kq, ktw);
+    const bool f32 = P.f32 != 0;
+#define QTTS_CPMLP_X(F, A, Q, T) if (f32 == F && act == A && kq == Q && ktw == T) { launch_cp_mlp_t<F, A, Q, T>(P, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
     QTTS_CPMLP_CASES(QTTS_CPMLP_X)
 #undef QTTS_CPMLP_X
-    throw Error(QTTS_ERR_ARG, "cp_mlp: no instantiation for this (H, I)");
+    throw Error(QTTS_ERR_ARG, "cp_mlp: no instantiation for this (H, I, dtype)");
 }
 
-bool cp_mlp_instantiated(int H, int I) {
-    if (!cp_mlp_takes(1, H, I)) return false;
-    const int act = I / (H / 4), kq = H / 128, ktw = I / 8 / 32 / 4;
-#define QTTS_CPMLP_X(A, Q, T) if (act == A && kq == Q && ktw == T) return true;
+bool cp_mlp_instantiated(int H, int I, bool bf16) {
+    int act = 0, kq = 0, ktw = 0;
+    if (!cp_mlp_shape(H, I, !bf16, act, kq, ktw)) return false;
+    const bool f32 = !bf16;
+#define QTTS_CPMLP_X(F, A, Q, T) if (f32 == F && act == A && kq == Q && ktw == T) return true;
     QTTS_CPMLP_CASES(QTTS_CPMLP_X)
 #undef QTTS_CPMLP_X
     return false;
 }
 
-int cp_mlp_blocks_per_cu(int H, int I) {
+int cp_mlp_blocks_per_cu(int H, int I, bool bf16) {
 #ifdef QTTS_HOST_EMU
     if (const char* e = QTTS_ENV("QTTS_HOSTEMU_CPAO_BLOCKS_PER_CU")) return atoi(e);
     return 2;
 #else
-    const int act = I / (H / 4), kq = H / 128, ktw = I / 8 / 32 / 4;
+    int act = 0, kq = 0, ktw = 0;
+    if (!cp_mlp_shape(H, I, !bf16, act, kq, ktw)) return 0;
+    const bool f32 = !bf16;
     int n = 0;
-#define QTTS_CPMLP_X(A, Q, T) if (act == A && kq == Q && ktw == T) { QTTS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cp_mlp_kernel<A, Q, T>, 256, 0)); return n; }
+#define QTTS_CPMLP_X(F, A, Q, T) if (f32 == F && act == A && kq == Q && ktw == T) { QTTS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cp_mlp_kernel<F, A, Q, T>, 256, 0)); return n; }
     QTTS_CPMLP_CASES(QTTS_CPMLP_X)
 #undef QTTS_CPMLP_X
     return 0;

@@ -263,6 +263,7 @@ void cp_attn_o_set_launch_events(hipEvent_t start, hipEvent_t stop);   // bench.
 // --------------------------------------------------------------------------------- cp_mlp.hip
 // The code predictor's MLP of a layer (RMSNorm -> gate|up -> SwiGLU -> down -> + residual) as ONE launch, batch <= 8, bf16 (round 5).
 struct CpMlpParams {
+    int f32;                      // 1: the exact parity mode -- fp32 operators, `x16` points to fp32 rows, no bf16 copy (out16 null)
     const void* Wgu;              // pack_cp_mlp_gu: [8 J workgroups][H / 32][4][2 ACT rows][8] bf16, RMSNorm weight folded (J = H / 32, ACT = I / (8 J))
     const void* Wd;               // down-projection, pack_skinny_weight(bf16, fs = 16): [H / 16][I / 32][4][16][8]
     const unsigned short* x16;    // the MLP's input rows [B][ldx16] bf16 (the hidden state after attention, un-normalised)
@@ -282,11 +283,11 @@ struct CpMlpParams {
     int B, H, I;
 };
 bool cp_mlp_takes(int B, int H, int I);
-bool cp_mlp_instantiated(int H, int I);
+bool cp_mlp_instantiated(int H, int I, bool bf16);
 int cp_mlp_grid(int H);
-int cp_mlp_blocks_per_cu(int H, int I);                // residency, as cp_attn_o_blocks_per_cu
-size_t cp_mlp_gu_bytes(int H, int I);
-void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int I, void* out_host);
+int cp_mlp_blocks_per_cu(int H, int I, bool bf16);     // residency, as cp_attn_o_blocks_per_cu
+size_t cp_mlp_gu_bytes(int H, int I, bool bf16);
+void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int I, bool bf16, void* out_host);
 void launch_cp_mlp(const CpMlpParams& P, hipStream_t st);
 void cp_mlp_set_launch_events(hipEvent_t start, hipEvent_t stop);
 

@@ -254,12 +254,13 @@ struct qtts_talker {
         if (bf16 && !rows && cp_attn_o_env && d.nh == 16 && d.nkv == 8 && d.hd == 128 && d.H % 128 == 0)
             upload_packed(L.o_p16, ow, d.H, d.qd, nullptr, 16);
         // ... and the MLP as ONE launch (cp_mlp.hip): gate|up packed by workgroup (XCD-major slices of the intermediate vector), down in 16-feature strips
-        if (bf16 && !rows && cp_mlp_env && cp_mlp_instantiated(d.H, d.I)) {
-            std::vector<char> h(cp_mlp_gu_bytes(d.H, d.I));
+        // (fp32 engines too, round 5: the exact parity mode runs through the same construction; their down operator is in 16-feature strips already)
+        if (!rows && cp_mlp_env && cp_mlp_instantiated(d.H, d.I, bf16)) {
+            std::vector<char> h(cp_mlp_gu_bytes(d.H, d.I, bf16));
             pack_cp_mlp_gu(PS(p + "mlp.gate_proj.weight", {d.I, d.H}).data(), PS(p + "mlp.up_proj.weight", {d.I, d.H}).data(),
-                           PS(p + "post_attention_layernorm.weight", {d.H}).data(), d.H, d.I, h.data());
+                           PS(p + "post_attention_layernorm.weight", {d.H}).data(), d.H, d.I, bf16, h.data());
             L.gu_mlp.upload(h.data(), h.size());
-            upload_packed(L.d_p16, dw, d.H, d.I, nullptr, 16);
+            if (bf16) upload_packed(L.d_p16, dw, d.H, d.I, nullptr, 16);
         }
         if (rows) {
             upload_rows(L.qkv_r, qkvw);
@@ -315,7 +316,11 @@ struct qtts_talker {
                       float* actb, int M, int n_new, KvCache& kv, int layer, const int* len_dev, int len_static,
                       const int* npad, const float* inv_freq, int max_len, hipStream_t st, const float* rope_cs = nullptr, int rope_cs_n = 0,
                       bool last_layer = true) {
-        const bool splitk = !bf16 && sk_part.p && M <= 8 && skinny_f32_splitk_takes(M, d.qd, d.H) && skinny_f32_splitk_takes(M, d.I, d.H);
+        // the MLP of this call as ONE launch (cp_mlp.hip): code predictor passes >= 1 at batch <= 8 of an engine that holds a place of its device's account
+        const bool mlp_fusable = cp_mlp_env && cp_fused_slot && L.gu_mlp.p && mlp_act.p && !skinny_only && !len_dev && n_new == 1 && len_static >= 1 &&
+                                 cp_mlp_takes(M, d.H, d.I) && len_static * 5 + layer < 128 && (!bf16 || (xs16 && skinny_takes_bf16_x(M, d.H, true)));
+        // (fp32: a layer whose MLP is fused keeps its o-projection whole -- the fused launch reads complete rows and writes complete rows)
+        const bool splitk = !bf16 && !mlp_fusable && sk_part.p && M <= 8 && skinny_f32_splitk_takes(M, d.qd, d.H) && skinny_f32_splitk_takes(M, d.I, d.H);
         if (layer == 0 || !splitk) sk_pending = false;
         const size_t pstride = (size_t)8 * d.H;
         // xs16: bf16 copy of the hidden state kept in step with xs by every producer (bf16 mode, M <= 16), or null
@@ -381,17 +386,18 @@ struct qtts_talker {
         skinny(o, st);
         }
         // bf16 engines, code predictor passes >= 1 at batch <= 8: the MLP as ONE launch (cp_mlp.hip) instead of the two decode GEMMs below
-        const bool fuse_mlp = cp_mlp_env && cp_fused_slot && L.gu_mlp.p && mlp_act.p && h16 && !skinny_only && !len_dev && n_new == 1 && len_static >= 1 &&
-                              cp_mlp_takes(M, d.H, d.I) && len_static * 5 + layer < 128;
+        const bool fuse_mlp = mlp_fusable;
         if (fuse_mlp) {
             CpMlpParams m{};
-            m.Wgu = L.gu_mlp.p; m.Wd = L.d_p16.p; m.x16 = xs16; m.ldx16 = d.H; m.eps = d.eps; m.res = xs; m.out = xs; m.out16 = xs16;
+            m.f32 = bf16 ? 0 : 1;
+            m.Wgu = L.gu_mlp.p; m.Wd = bf16 ? L.d_p16.p : L.d_p.p; m.x16 = bf16 ? xs16 : reinterpret_cast<const unsigned short*>(xs); m.ldx16 = d.H; m.eps = d.eps;
+            m.res = xs; m.out = xs; m.out16 = bf16 ? xs16 : nullptr;
             m.act_gran = mlp_act.as<float>(); m.part = mlp_part.as<float>(); m.serial = ss.frame_serial; m.slot = len_static * 5 + layer; m.phase = 3;
             m.err = ss.n_generated + 5; m.done_latch = ss.done; m.done_flag = ss.done; m.first_pause = cp_attn_o_pause; m.poll_step = cp_attn_o_step;
             m.B = M; m.H = d.H; m.I = d.I; m.wd_early = cp_mlp_wd_early;
             m.first_pause = cp_mlp_pause_b; m.pause_c = cp_mlp_pause_c; m.poll_step = cp_mlp_step;
             if (timing_now) {          // bench.py's roofline leg: timed on its own (stack 4: the fused MLP launch, three operators)
-                LaunchEv e{nullptr, nullptr, 4, 3 * d.I, d.H, 2.0 * 3.0 * (double)d.I * d.H};
+                LaunchEv e{nullptr, nullptr, 4, 3 * d.I, d.H, (bf16 ? 2.0 : 4.0) * 3.0 * (double)d.I * d.H};
                 QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
                 ev.push_back(e);
                 cp_mlp_set_launch_events(e.a, e.b);
@@ -399,6 +405,7 @@ struct qtts_talker {
                 cp_mlp_set_launch_events(nullptr, nullptr);
             } else launch_cp_mlp(m, st);
             ++cp_mlp_count;
+            sk_pending = false;
             return;
         }
         SkinnyParams g{};
@@ -494,7 +501,8 @@ struct qtts_talker {
     // resident at once: workgroups wait for granules that other workgroups of the same launch produce.  Residency is a property of the
     // DEVICE, so the admission is per device (round 5), and it is an account of the one resource that limits it here, the
     // register file: a compute unit has 512 registers per lane and SIMD; a launch of `grid` workgroups on `cus` compute units puts
-    // ceil(grid / cus) workgroups on a compute unit, each -- 4 waves, one per SIMD, of <= 184 registers -- with CP_SHARE = 184 of that budget
+    // ceil(grid / cus) workgroups on a compute unit, each -- 4 waves, one per SIMD, of <= 184 registers (bf16 engines; <= 256 for the fp32
+    // instantiation of cp_mlp_kernel: CP_SHARE_F32) -- with CP_SHARE = 184 of that budget
     // (the code objects' own numbers are pinned by tests/test_host_logic.py::test_fused_launches_fit_their_register_shares).  An engine's
     // share is that of its LARGEST fused launch (its launches run one after the other on one stream); engines are admitted while the shares
     // of the fused engines of a device add up to <= 512: two on a whole MI355X (bench.py --workload clone-shard at batch 8 runs two), none
@@ -504,7 +512,7 @@ struct qtts_talker {
     // is another PROCESS on the same device: a consumer that loses its producers there gives up after ~0.3 s, latches the stop flag (one
     // give-up per generation, not per launch), the call fails with QTTS_ERR_STATE and the engine leaves the fused launches for good
     // (`fused_retire`): the caller's retry runs on the separate launches.
-    static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184;
+    static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 256;     // (fp32 engines: cp_mlp_kernel<true, ...> holds twice the operand registers)
     struct FusedRegistry { std::mutex m; std::map<int, std::pair<int, int>> dev; };        // device -> (share in use, fused engines)
     static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
     bool cp_fused_slot = false;
@@ -514,11 +522,11 @@ struct qtts_talker {
     // QTTS_CP_FUSED_MAX (A/B, tests): cap on fused engines per device below what residency allows
     // grid_cp: workgroups per launch of the engine's largest fused kernel; occ_ok: the occupancy API finds room for at least one workgroup of
     // every wanted kernel on a compute unit
-    void fused_admit(int grid_cp, bool occ_ok) {
+    void fused_admit(int grid_cp, bool occ_ok, int share) {
         QTTS_CHECK_HIP(hipGetDevice(&fused_device));
         int cus = 0;
         QTTS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fused_device));
-        const int need = grid_cp > 0 ? CP_SHARE * cdiv(grid_cp, std::max(1, cus)) : 0;
+        const int need = grid_cp > 0 ? share * cdiv(grid_cp, std::max(1, cus)) : 0;
         int max_engines = 1 << 20;
         if (const char* e = QTTS_ENV("QTTS_CP_FUSED_MAX")) max_engines = std::max(0, atoi(e));
         auto& r = fused_registry();
@@ -548,7 +556,7 @@ struct qtts_talker {
     void check_fused_flag(int flag, const char* where) {
         if (!flag) return;
         fused_retire();
-        throw Error(QTTS_ERR_STATE, std::string(where) + ": a cp_attn_o consumer gave up waiting for its producers' granules (the fused launch was not "
+        throw Error(QTTS_ERR_STATE, std::string(where) + ": a consumer of a fused launch gave up waiting for its producers' granules (the fused launch was not "
                                     "fully resident: another process on the device?); this engine now uses the separate launches -- retry the request");
     }
 };
@@ -564,14 +572,19 @@ void qtts_talker::finalize() {
     QTTS_REQUIRE(c.max_batch >= 1 && c.max_batch <= 32, QTTS_ERR_LIMIT, "max_batch must be 1..32");
     QTTS_REQUIRE(td.I % 16 == 0 && cd.I % 16 == 0, QTTS_ERR_ARG, "intermediate sizes % 16");
     const int G = c.num_code_groups;
-    if (!bf16 || !cp_mlp_instantiated(cd.H, cd.I)) cp_mlp_env = false;
+    if (!cp_mlp_instantiated(cd.H, cd.I, bf16) || c.max_batch > 8) cp_mlp_env = false;
+    // fp32 engines (the exact parity mode) take the fused MLP launch only on request (QTTS_CP_MLP_F32=1): cp_mlp_kernel<true, ...> is the fused
+    // construction's bit-exact leg (tests/test_gpu_parity.py runs the reference goldens through it), but with fp32 operators the MLP is
+    // 38 MB per layer and the round-4 plan -- o- and down-projection split over two workgroups per strip -- streams it faster than 256
+    // workgroups of 256 registers do: 4.18 vs 4.30 ms per frame (1.7B, batch 8; profiles/r05_cp_mlp.md)
+    if (!bf16 && !QTTS_OPT_SET("QTTS_CP_MLP_F32")) cp_mlp_env = false;
     const bool want_ao = bf16 && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0;
     if (want_ao || cp_mlp_env) {      // one admission for the engine's fused launches
         int grid_cp = 0;
         bool occ_ok = true;
         if (want_ao) { grid_cp = std::max(grid_cp, cp_attn_o_grid(cd.H)); occ_ok = occ_ok && cp_attn_o_blocks_per_cu() >= 1; }
-        if (cp_mlp_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp_blocks_per_cu(cd.H, cd.I) >= 1; }
-        fused_admit(grid_cp, occ_ok);
+        if (cp_mlp_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp_blocks_per_cu(cd.H, cd.I, bf16) >= 1; }
+        fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE : CP_SHARE_F32);
     }
     if (!want_ao || !cp_fused_slot) cp_attn_o_env = false;
     if (!cp_fused_slot) cp_mlp_env = false;
@@ -701,8 +714,8 @@ void qtts_talker::finalize() {
         sk_part.alloc(2 * 8 * hmax * 4);
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
     }
-    if (bf16 && !cl.empty() && cl[0].gu_mlp.p) {
-        mlp_act.alloc((size_t)8 * 8 * (cd.I / 16) * 8);
+    if (!cl.empty() && cl[0].gu_mlp.p) {
+        mlp_act.alloc((size_t)8 * 8 * (cd.I / (bf16 ? 16 : 8)) * 8);
         mlp_part.alloc((size_t)8 * 8 * cd.H * 8);
         QTTS_CHECK_HIP(hipMemset(mlp_act.p, 0, mlp_act.bytes));
         QTTS_CHECK_HIP(hipMemset(mlp_part.p, 0, mlp_part.bytes));

@@ -305,23 +305,27 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
-// cp_mlp_kernel (cp_mlp.hip): the code predictor's MLP as one launch against the two decode-GEMM launches it replaces.
-// mode 0: skinny8 ACT_SWIGLU8 (gate|up, bf16 act) + skinny down-projection; mode 3: the fused launch, twice on the same granule buffers under two
-// serials, then phases B + C alone under the launch's own tag (bit-identical) and under another slot / serial (stale: give-up + latch).
+// cp_mlp_kernel (cp_mlp.hip): the code predictor's MLP as one launch against the two decode-GEMM launches it replaces, bf16 (f32 = 0) or the
+// exact fp32 mode (f32 = 1: fp32 operators, fp32 rows, fp32 intermediate vector).
+// mode 0: the two launches (bf16: ACT_SWIGLU8 where K % 512 == 0; fp32: strip pairs); mode 3: the fused launch, twice on the same granule buffers
+// under two serials, then phases B + C alone under the launch's own tag (bit-identical) and under another slot / serial (stale: give-up + latch).
 extern "C" int hostemu_cp_mlp(const float* x, int B, const float* Wg, const float* Wu, const float* gnorm, float eps, const float* Wd, int H, int I,
-                              const float* res, float* out, unsigned short* out16, int mode, unsigned epoch0) {
+                              const float* res, float* out, unsigned short* out16, int mode, unsigned epoch0, int f32) {
     try {
+        const bool bf = !f32;
         std::vector<qtts::bf16_t> x16((size_t)B * H);
         for (size_t i = 0; i < x16.size(); ++i) x16[i] = qtts::f32_to_bf16(x[i]);
         for (int i = 0; i < B * H; ++i) out[i] = res[i];
         if (mode == 3) {
-            std::vector<unsigned char> wgu(qtts::cp_mlp_gu_bytes(H, I)), wd(qtts::skinny_packed_bytes(H, I, true));
-            qtts::pack_cp_mlp_gu(Wg, Wu, gnorm, H, I, wgu.data());
-            qtts::pack_skinny_weight(Wd, H, I, true, wd.data(), nullptr, 16);
-            std::vector<float> act((size_t)8 * 8 * (I / 16) * 2, 0.f), part((size_t)8 * 8 * H * 2, 0.f);
+            std::vector<unsigned char> wgu(qtts::cp_mlp_gu_bytes(H, I, bf)), wd(qtts::skinny_packed_bytes(H, I, bf));
+            qtts::pack_cp_mlp_gu(Wg, Wu, gnorm, H, I, bf, wgu.data());
+            qtts::pack_skinny_weight(Wd, H, I, bf, wd.data(), nullptr, 16);
+            std::vector<float> act((size_t)8 * 8 * (I / (bf ? 16 : 8)) * 2, 0.f), part((size_t)8 * 8 * H * 2, 0.f);
             int serial = (int)epoch0, err = 0, latch = 0;
             qtts::CpMlpParams m{};
-            m.Wgu = wgu.data(); m.Wd = wd.data(); m.x16 = x16.data(); m.ldx16 = H; m.eps = eps; m.res = out; m.out = out; m.out16 = out16;
+            m.f32 = f32;
+            m.Wgu = wgu.data(); m.Wd = wd.data(); m.x16 = bf ? x16.data() : reinterpret_cast<const unsigned short*>(x); m.ldx16 = H; m.eps = eps;
+            m.res = out; m.out = out; m.out16 = bf ? out16 : nullptr;
             m.act_gran = act.data(); m.part = part.data(); m.serial = &serial; m.slot = 11; m.phase = 3; m.err = &err; m.done_latch = &latch;
             m.first_pause = 16; m.pause_c = 16; m.poll_step = 4; m.B = B; m.H = H; m.I = I;
             for (int rep = 0; rep < 2; ++rep) {
@@ -331,7 +335,6 @@ extern "C" int hostemu_cp_mlp(const float* x, int B, const float* Wg, const floa
             }
             std::vector<float> keep(out, out + (size_t)B * H);
             std::vector<unsigned short> keep16(out16, out16 + (size_t)B * H);
-            // the consuming phases alone on the buffers the launches above filled
             for (int variant = 0; variant < 3; ++variant) {
                 for (int ph = 1; ph <= 2; ++ph) {
                     for (int i = 0; i < B * H; ++i) out[i] = res[i];
@@ -356,25 +359,32 @@ extern "C" int hostemu_cp_mlp(const float* x, int B, const float* Wg, const floa
             memcpy(out16, keep16.data(), keep16.size() * 2);
             return 0;
         }
-        // the two launches: gate|up in 8-row interleave (ACT_SWIGLU8), then the down-projection
+        // the two launches: gate|up interleaved (8-row blocks for ACT_SWIGLU8, 16-row strip pairs otherwise), then the down-projection
         std::vector<float> gu((size_t)2 * I * H);
-        const int blk = H % 512 == 0 ? 8 : 16;             // ACT_SWIGLU8 (K % 512 == 0: the frame step's form) or the strip-pair form
+        const int blk = (bf && H % 512 == 0) ? 8 : 16;
         for (int f = 0; f < I; ++f) {
             memcpy(&gu[((size_t)(f / blk) * 2 * blk + f % blk) * H], Wg + (size_t)f * H, (size_t)H * 4);
             memcpy(&gu[((size_t)(f / blk) * 2 * blk + blk + f % blk) * H], Wu + (size_t)f * H, (size_t)H * 4);
         }
-        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(2 * I, H, true)), wdp(qtts::skinny_packed_bytes(H, I, true));
-        qtts::pack_skinny_weight(gu.data(), 2 * I, H, true, wp.data(), gnorm, 16);
-        qtts::pack_skinny_weight(Wd, H, I, true, wdp.data(), nullptr, 8);
+        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(2 * I, H, bf)), wdp(qtts::skinny_packed_bytes(H, I, bf));
+        qtts::pack_skinny_weight(gu.data(), 2 * I, H, bf, wp.data(), gnorm, 16);
+        qtts::pack_skinny_weight(Wd, H, I, bf, wdp.data(), nullptr, bf ? 8 : 16);
+        std::vector<float> act32((size_t)B * I, NAN);
         std::vector<qtts::bf16_t> act((size_t)B * I, (qtts::bf16_t)0x7FC0);
         qtts::SkinnyParams g{};
-        g.x = reinterpret_cast<const float*>(x16.data()); g.x_bf16 = 1; g.ldx = H; g.M = B; g.Wp = wp.data(); g.N = 2 * I; g.K = H; g.fs = 16;
-        g.norm = 1; g.eps = eps; g.out = reinterpret_cast<float*>(act.data()); g.out_bf16 = 1; g.ldo = I; g.act = blk == 8 ? qtts::ACT_SWIGLU8 : qtts::ACT_SWIGLU;
-        qtts::launch_skinny(g, true, nullptr);
+        g.x = bf ? reinterpret_cast<const float*>(x16.data()) : x; g.x_bf16 = bf ? 1 : 0; g.ldx = H; g.M = B; g.Wp = wp.data(); g.N = 2 * I; g.K = H; g.fs = 16;
+        std::vector<float> ss(B, 0.f);
+        if (!bf && !qtts::skinny_f32_inline_norm(B, H)) {
+            for (int m = 0; m < B; ++m) { double a = 0; for (int k = 0; k < H; ++k) a += (double)x[(size_t)m * H + k] * x[(size_t)m * H + k]; ss[m] = (float)a; }
+            g.ss_in = ss.data();
+        }
+        g.norm = 1; g.eps = eps; g.out = bf ? reinterpret_cast<float*>(act.data()) : act32.data(); g.out_bf16 = bf ? 1 : 0; g.ldo = I;
+        g.act = blk == 8 ? qtts::ACT_SWIGLU8 : qtts::ACT_SWIGLU;
+        qtts::launch_skinny(g, bf, nullptr);
         qtts::SkinnyParams d{};
-        d.x = reinterpret_cast<const float*>(act.data()); d.x_bf16 = 1; d.ldx = I; d.M = B; d.Wp = wdp.data(); d.N = H; d.K = I; d.fs = 8;
-        d.res = out; d.ldr = H; d.out = out; d.ldo = H; d.act = qtts::ACT_NONE; d.out16 = out16;
-        qtts::launch_skinny(d, true, nullptr);
+        d.x = bf ? reinterpret_cast<const float*>(act.data()) : act32.data(); d.x_bf16 = bf ? 1 : 0; d.ldx = I; d.M = B; d.Wp = wdp.data(); d.N = H; d.K = I;
+        d.fs = bf ? 8 : 16; d.res = out; d.ldr = H; d.out = out; d.ldo = H; d.act = qtts::ACT_NONE; d.out16 = bf ? out16 : nullptr;
+        qtts::launch_skinny(d, bf, nullptr);
         return 0;
     } catch (const qtts::Error& e) {
         return e.code;

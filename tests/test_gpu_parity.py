@@ -376,7 +376,7 @@ def test_talker_vs_oracle_fresh_inputs(talker_tiny, dev):
         _compare_greedy(out.codes.cpu().numpy(), out.tokens.cpu().numpy(), r["codes"].numpy(), r["tokens"].numpy(), margin)
 
 
-def _real_golden(dev, golden_dir, name, cfg, max_seq=256):
+def _real_golden(dev, golden_dir, name, cfg, max_seq=256, fused_f32=False):
     from qwen3_tts_amd.talker import TalkerEngine
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     wn = synth.talker_weights(cfg, with_text=False)
@@ -395,6 +395,9 @@ def _real_golden(dev, golden_dir, name, cfg, max_seq=256):
     if n == g["codes"].shape[1]:          # (a low-margin flip ends the comparison early: the golden stores only the LAST frame's hidden state)
         assert np.abs(out.hidden[:, n - 1].cpu().numpy() - g["hidden_last"]).max() <= 2e-3
     _check_hidden_steps(out, g, n)
+    st = eng.stats()
+    want = (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers if fused_f32 else 0
+    assert st["cp_mlp_per_step"] == want and st["cp_fused_giveups"] == 0, st
     return eng
 
 
@@ -422,6 +425,16 @@ def test_talker_06b_batch8_10s_greedy_vs_reference_golden(dev, golden_dir):
     """BASELINE config 3: 0.6B dims, batch 8, ragged left-padded prompts, length forced to 125 frames (10 s), greedy:
     8 x 125 x 16 codebook indices bit-exact vs the reference CPU path."""
     _real_golden(dev, golden_dir, "talker_06b_b8", synth.talker_06b())
+
+
+@pytest.mark.parametrize("name", ["talker_06b", "talker_17b", "talker_06b_b8"])
+def test_fused_mlp_fp32_instantiation_bit_exact_vs_reference_golden(dev, golden_dir, name):
+    """the fused construction's bit-exact leg.  `cp_mlp_kernel<true, ...>` -- the same kernel source as the bf16 frame
+    step's fused MLP launch (XCD-sliced intermediate vector, granule hand-offs, partial sums added in XCD order) with fp32 operators,
+    rows and intermediate vector -- runs the code predictor's passes >= 1 of an fp32 engine (QTTS_CP_MLP_F32=1; `cp_mlp_per_step` says
+    it did), greedy, against the reference's CPU goldens: every codebook index of every frame, 1 / 3 / 8 utterances, 0.6B and 1.7B dims."""
+    with _qlib.options(QTTS_CP_MLP_F32="1"):
+        _real_golden(dev, golden_dir, name, synth.talker_06b() if "06b" in name else synth.talker_17b(), fused_f32=True)
 
 
 def test_talker_17b_batch32_streaming_text_greedy_vs_reference_golden(dev, golden_dir):

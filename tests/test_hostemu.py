@@ -56,7 +56,7 @@ def emu():
     lib.hostemu_set_block_order.argtypes = [i32]; lib.hostemu_set_block_order.restype = None
     lib.hostemu_cp_layer_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.c_uint32]
     lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
-    lib.hostemu_cp_mlp.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, i32, i32, vp, vp, vp, i32, C.c_uint32]
+    lib.hostemu_cp_mlp.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, i32, i32, vp, vp, vp, i32, C.c_uint32, i32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
@@ -778,8 +778,8 @@ def test_cp_attn_o_fused_launch_real_source(emu):
             assert np.array_equal(o1, first), ("result depends on the wave order / the epoch", B, S0, bo, fo)
 
 
-@pytest.mark.parametrize("H,I", [(256, 1024), (1024, 3072)])
-def test_cp_mlp_one_launch_real_source(emu, H, I):
+@pytest.mark.parametrize("H,I,f32", [(256, 1024, 0), (1024, 3072, 0), (256, 1024, 1), (1024, 3072, 1)])
+def test_cp_mlp_one_launch_real_source(emu, H, I, f32):
     """`cp_mlp_kernel` (cp_mlp.hip, round 5): the code predictor's MLP of a layer -- RMSNorm, gate|up GEMM, SwiGLU, down GEMM, residual --
     as ONE launch: the intermediate vector sliced by XCD, every workgroup a few features of its XCD's slice (phase A), then its 32 output
     features over that slice (phase B), the eight XCD partials added in XCD order by the workgroup of XCD 7 (phase C); values cross between
@@ -788,31 +788,34 @@ def test_cp_mlp_one_launch_real_source(emu, H, I):
     fp32 summation order, the bf16 rounding of the intermediate vector in between) and against float64 numpy; batch 8 / 3, three fiber
     orders, two launches per call on the same granule buffers under two serials.  The entry point then runs the consuming phases alone:
     under the launch's own (serial, slot) they reproduce the result bit for bit, under another slot or serial every granule is stale and
-    the consumers give up, raise the error flag and latch the stop flag."""
+    the consumers give up, raise the error flag and latch the stop flag.  f32 = 1: the instantiation of the exact parity mode (fp32 operators, rows and
+    intermediate vector on v_mfma_f32_16x16x4_f32) against the fp32 engines' two launches and float64 numpy to fp32 precision."""
     g = np.random.default_rng(606 + H)
     eps = 1e-6
     gn = (1 + 0.1 * g.standard_normal(H)).astype(np.float32)
     Wg = (g.standard_normal((I, H)) * 0.05).astype(np.float32)
     Wu = (g.standard_normal((I, H)) * 0.05).astype(np.float32)
     Wd = (g.standard_normal((H, I)) * 0.03).astype(np.float32)
-    Wg_r = _bf16_round(Wg * gn[None, :])[0].astype(np.float64)
-    Wu_r = _bf16_round(Wu * gn[None, :])[0].astype(np.float64)
-    Wd_r = _bf16_round(Wd)[0].astype(np.float64)
+    rw = (lambda a: a) if f32 else (lambda a: _bf16_round(a)[0])
+    Wg_r = rw(Wg * gn[None, :]).astype(np.float64)
+    Wu_r = rw(Wu * gn[None, :]).astype(np.float64)
+    Wd_r = rw(Wd).astype(np.float64)
     for B in (8, 3):
         x = g.standard_normal((B, H)).astype(np.float32)
         res = g.standard_normal((B, H)).astype(np.float32)
-        x_r = _bf16_round(x)[0].astype(np.float64)
+        x_r = rw(x).astype(np.float64)
         rs = 1.0 / np.sqrt((x_r ** 2).mean(1, keepdims=True) + eps)
         gg, uu = (x_r @ Wg_r.T) * rs, (x_r @ Wu_r.T) * rs
-        act = _bf16_round((gg / (1.0 + np.exp(-gg)) * uu).astype(np.float32))[0].astype(np.float64)
+        act = rw((gg / (1.0 + np.exp(-gg)) * uu).astype(np.float32)).astype(np.float64)
         ref = act @ Wd_r.T + res
+        tol, rtol = (2e-5, 2e-6) if f32 else (2e-2, 2e-3)
 
         def run(mode, fiber_order=0, epoch0=0):
             out = np.full((B, H), np.nan, np.float32)
             out16 = np.full((B, H), 0x4242, np.uint16)
             emu.hostemu_set_fiber_order(fiber_order)
             try:
-                rc = emu.hostemu_cp_mlp(_ptr(x), B, _ptr(Wg), _ptr(Wu), _ptr(gn), eps, _ptr(Wd), H, I, _ptr(res), _ptr(out), _ptr(out16), mode, epoch0)
+                rc = emu.hostemu_cp_mlp(_ptr(x), B, _ptr(Wg), _ptr(Wu), _ptr(gn), eps, _ptr(Wd), H, I, _ptr(res), _ptr(out), _ptr(out16), mode, epoch0, f32)
             finally:
                 emu.hostemu_set_fiber_order(0)
             assert rc == 0, ((H, I, B, mode), rc, (emu.qtts_last_error() or b"").decode())
@@ -820,13 +823,14 @@ def test_cp_mlp_one_launch_real_source(emu, H, I):
 
         o0, h0 = run(0)
         scale = max(1.0, float(np.abs(ref).max()))
-        assert float(np.abs(o0 - ref).max()) <= 2e-2 * scale, "the two launches are off their own reference"
+        assert float(np.abs(o0 - ref).max()) <= tol * scale, "the two launches are off their own reference"
         first = None
         for (fo, e0) in [(0, 1), (1, 7), (2, 0xFFFFF0)]:
             o3, h3 = run(3, fo, e0)
-            assert float(np.abs(o3 - ref).max()) <= 2e-2 * scale, (H, B, float(np.abs(o3 - ref).max()))
-            assert float(np.sqrt(((o3 - o0) ** 2).mean())) <= 2e-3 * float(np.sqrt((o0 ** 2).mean())), (H, B)
-            assert np.array_equal(h3, _bf16_round(o3)[1]), "bf16 copy of the hidden rows"
+            assert float(np.abs(o3 - ref).max()) <= tol * scale, (H, B, float(np.abs(o3 - ref).max()))
+            assert float(np.sqrt(((o3 - o0) ** 2).mean())) <= rtol * float(np.sqrt((o0 ** 2).mean())), (H, B)
+            if not f32:
+                assert np.array_equal(h3, _bf16_round(o3)[1]), "bf16 copy of the hidden rows"
             if first is None:
                 first = o3
             assert np.array_equal(o3, first), ("result depends on the wave order / the epoch", H, B, fo)
@@ -1638,8 +1642,12 @@ def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
         emu.qtts_talker_destroy(h)
 
 
-def test_talker_fp32_split_k_layer_chain_vs_oracle(emu):
-    """Round 4: the ENGINE side of the fp32 split-K plan -- which GEMM of a layer splits, which one combines, which of the two
+@pytest.mark.parametrize("cp_mlp", ["1", "0"])
+def test_talker_fp32_split_k_layer_chain_vs_oracle(emu, qopt, cp_mlp):
+    """Round 5 (cp_mlp = "1"): the code predictor's passes >= 1 take the fp32 instantiation of the one-launch MLP (`cp_mlp_kernel<true, ...>`:
+    the exact parity mode's fused leg; the o-projection before it no longer splits K, the talker stack keeps the split-K plan), and
+    `cp_mlp_per_step` says so (QTTS_CP_MLP_F32=1: opt-in, the split-K plan is the faster one in fp32); cp_mlp = "0": round 4's plan on both stacks.
+    Round 4: the ENGINE side of the fp32 split-K plan -- which GEMM of a layer splits, which one combines, which of the two
     residual buffers is current, the unsplit last layer writing where the caller reads -- at the real layer widths (hidden 1024,
     intermediate 3072, q width 2048: the 0.6B talker's and the code predictor's), which is where the plan engages; three layers per
     stack (first / middle / last take different branches), three code groups (pass 0 with two new tokens, pass 1 with its q|k|v row
@@ -1660,12 +1668,19 @@ def test_talker_fp32_split_k_layer_chain_vs_oracle(emu):
     sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
     with torch.no_grad():
         r = talker_ref.talker_generate(w, t, emb, mask, tr, pad, max_new_tokens=4, sp=sp)
+    qopt(emu, "QTTS_CP_MLP_F32", cp_mlp)          # (fp32 engines take the fused MLP launch on request only: talker_engine.hip finalize)
     h = _talker_emu(emu, t, w, max_batch=3, max_seq=32)
     try:
         codes, tokens, hidden = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=4)
         assert np.array_equal(tokens, r["tokens"].numpy()) and np.array_equal(codes, r["codes"].numpy())
         ref_h = r["hidden"].numpy()
         assert np.abs(hidden - ref_h).max() <= 2e-4 * max(1.0, float(np.abs(ref_h).max()))
+        emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+        st = _lib.TalkerStatsC()
+        _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+        want = (t.num_code_groups - 2) * t.cp_num_hidden_layers if cp_mlp == "1" else 0
+        assert st.cp_mlp_per_step == want and st.cp_fused_per_step == 0 and st.cp_fused_giveups == 0, (st.cp_mlp_per_step, st.cp_fused_per_step)
+        assert st.cp_fused_active == (1 if cp_mlp == "1" else 0) and st.cp_fused_capacity == (512 // 256 if cp_mlp == "1" else 0)
     finally:
         emu.qtts_talker_destroy(h)
 

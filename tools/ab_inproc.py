@@ -16,6 +16,7 @@ from qwen3_tts_amd.talker import TalkerEngine
 CONFIGS = {
     "default": {},
     "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
+    "f32_fused_mlp": {"QTTS_CP_MLP_F32": "1"},       # --dtype f32: cp_mlp_kernel<true, ...> against the fp32 split-K plan (the default there)
     "cp_fused_off": {"QTTS_CP_MLP": "0", "QTTS_CP_ATTN_O": "0"},   # ... and q|k|v / attention / o-projection as separate launches (round 3's)
     "mlp_wd_early": {"QTTS_CP_MLP_WD_EARLY": "1"},                  # the fused MLP's down block requested at kernel entry (round 5's first version)
     "mlp_b16_c24": {"QTTS_CP_MLP_PAUSE_B": "16"}, "mlp_b20_c24": {"QTTS_CP_MLP_PAUSE_B": "20"}, "mlp_b28_c24": {"QTTS_CP_MLP_PAUSE_B": "28"},
@@ -33,6 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=40); ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="f32: the exact parity mode (fp32 operators; cp_mlp_kernel<true, ...> against the split-K plan)")
     a = ap.parse_args()
     t = synth.talker_17b()
     base = np.random.default_rng(0).standard_normal(1 << 20, dtype=np.float32)
@@ -53,7 +55,7 @@ def main():
         for n in names:
             for k in KEYS:
                 _lib.set_option(k, CONFIGS[n].get(k))
-            eng = TalkerEngine(t, w, weight_dtype=torch.bfloat16, max_batch=B, max_seq=64 + F + 8, use_graph=True)
+            eng = TalkerEngine(t, w, weight_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32, max_batch=B, max_seq=64 + F + 8, use_graph=True)
             eng.generate(emb, mask, tr, pad, seed=0, **kw); torch.cuda.synchronize()
             ts = []
             for r in range(3):
@@ -70,7 +72,7 @@ def main():
     out = {n: {"ms_per_frame": v, "min": min(v), "median": float(np.median(v))} for n, v in res.items()}
     print(json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab_inproc.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab_inproc.json" if a.dtype == "bf16" else "ab_inproc_f32.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
