@@ -1440,17 +1440,24 @@ __device__ __forceinline__ void cpao_give_up(const CpAttnOParams& P) {
 // The operands of the FIRST requests are leading scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave
 // instead of behind an s_load round trip of the by-value struct (as the decode GEMM's, profiles/r03_ab_kpre.md).
 #define QTTS_CPAO_ARGS(P) ((P).Wqkv ? (P).Wqkv : static_cast<const void*>((P).a.qkv)), (P).x16, (P).serial, (P).a.done_flag, (P).a.B, (P).ldx16, (P).K, (P).slot, (P)
-template <bool CT, bool QKV>
+// F32 (round 5: the exact parity mode's instantiation, the construction's bit-exact leg): fp32 operators in the fp32 decode GEMM's packing
+// (k-tiles of 16, four v_mfma_f32_16x16x4_f32 each), fp32 x rows (`x16` then points to floats), fp32 cache, the attention output stays
+// fp32 in the B tile -- the arithmetic of the fp32 engines' three launches in the fused launch's summation orders.
+template <bool F32> struct CpaoKv { typedef bf16_t type; };
+template <> struct CpaoKv<true> { typedef float type; };
+template <bool CT, bool QKV, bool F32>
 __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const unsigned short* kx16, const int* kserial, const int* kdone, int kB, int kldx16,
                                                         int kK, int kslot, CpAttnOParams P) {
     if constexpr (QKV) P.Wqkv = k0; else P.a.qkv = static_cast<const float*>(k0);
     P.x16 = kx16; P.serial = kserial; P.a.done_flag = kdone; P.a.B = kB; P.ldx16 = kldx16; P.K = kK; P.slot = kslot;
-    constexpr int HD = 128, MAXK = 16, KW = 4, NKV = 8, BSTR = 264;       // BSTR: bf16 per row of the B tile (16-B rows, bank-spread)
-    typedef bf16_t KVT;
+    constexpr int HD = 128, MAXK = 16, KW = F32 ? 8 : 4, NKV = 8, BSTR = 264;       // BSTR: elements per row of the B tile (16-B rows, bank-spread)
+    constexpr int KT = F32 ? 16 : 32;                   // k per tile of the packed operators
+    constexpr int NKS = F32 ? 16 : 8;                   // k-tiles per wave: a quarter of K = 1024 in the front, the 256 k of a kv head in the o-projection
+    typedef typename CpaoKv<F32>::type KVT;
     // ONE LDS object (a second one de-pipelines the loads around it):
     //   [4 waves][q | kn | vn : 128 floats each] | B tile [2][BSTR] bf16 | the reducer's own partial sum [2][128] floats
     //   | QKV: the four k quarters of the q|k|v strip [4 waves][64 lanes][4] floats and of the row sums of squares [4][16]
-    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * 2, OWN_BYTES = 2 * 128 * 4, QP_BYTES = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0;
+    constexpr int WS_BYTES = 4 * 1536, BT_BYTES = 2 * BSTR * (F32 ? 4 : 2), OWN_BYTES = 2 * 128 * 4, QP_BYTES = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[WS_BYTES + BT_BYTES + OWN_BYTES + QP_BYTES];
     const AttnDecodeParams& p = P.a;
     const int nchunk = P.H >> 7;
@@ -1480,13 +1487,14 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
     const int li = lane & 15, lq = lane >> 4;
     // ---- 0a (QKV). this workgroup's strip of the layer's q|k|v GEMM: 16 features x K, the four waves take a quarter of k each.  Requested
     // first: every other workgroup's attention waits for these sums.
-    cu32x4 gw[8], gx[8];
+    cu32x4 gw[NKS], gx[NKS];
     if (QKV && P.phase != 1) {
-        const int nkt = P.K >> 5, kq = nkt >> 2;           // k-tiles of 32; per wave kq of them (8 at K = 1024)
+        const int nkt = P.K / KT, kq = nkt >> 2;           // k-tiles; per wave kq of them (NKS at K = 1024)
         const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wqkv) + ((size_t)blockIdx.x * nkt + wave * kq) * 64 + lane;
-        const cu32x4* xsrc = reinterpret_cast<const cu32x4*>(P.x16 + (size_t)(li < p.B ? li : 0) * P.ldx16 + wave * kq * 32 + lq * 8);
+        const cu32x4* xsrc = F32 ? reinterpret_cast<const cu32x4*>(reinterpret_cast<const float*>(P.x16) + (size_t)(li < p.B ? li : 0) * P.ldx16 + wave * kq * 16 + lq * 4)
+                                 : reinterpret_cast<const cu32x4*>(P.x16 + (size_t)(li < p.B ? li : 0) * P.ldx16 + wave * kq * 32 + lq * 8);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) { gw[ks] = wsrc[ks * 64]; gx[ks] = xsrc[ks * 4]; }
+        for (int ks = 0; ks < NKS; ++ks) { gw[ks] = wsrc[ks * 64]; gx[ks] = xsrc[ks * 4]; }
     }
     const float* xrow = p.qkv + (size_t)b * p.ld;
     float xq[2], xk[2], xv[2];
@@ -1499,7 +1507,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
     const bool rtab = p.rope_cs && S0 < p.rope_cs_n;
     const float* rrow = rtab ? p.rope_cs + (size_t)S0 * 128 : p.inv_freq;
     const float ctab = rrow[lane], stab = rrow[rtab ? 64 + lane : lane];
-    struct alignas(4) VPair { KVT a, b; };
+    struct alignas(2 * sizeof(KVT)) VPair { KVT a, b; };
     cu32x4 kr[KW];
     VPair vr[MAXK];
     {
@@ -1509,14 +1517,14 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) vr[k] = *reinterpret_cast<const VPair*>(vc + key_base(k < S0 ? k : 0) + 2 * lane);
     }
-    cu32x4 wf[2][8];
+    cu32x4 wf[2][NKS];
     auto load_wo = [&] {
-        const int nkt = (p.nh * HD) >> 5;
+        const int nkt = (p.nh * HD) / KT;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wo) + ((size_t)(c * 8 + wave * 2 + s) * nkt + g * 8) * 64 + lane;
+            const cu32x4* wsrc = reinterpret_cast<const cu32x4*>(P.Wo) + ((size_t)(c * 8 + wave * 2 + s) * nkt + g * NKS) * 64 + lane;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) wf[s][ks] = wsrc[ks * 64];
+            for (int ks = 0; ks < NKS; ++ks) wf[s][ks] = wsrc[ks * 64];
         }
     };
     if constexpr (!QKV) load_wo();                      // (with the q|k|v front: requested behind the strip's store -- 64 KB that would delay the strip)
@@ -1528,18 +1536,27 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
         f32x4 qa = (f32x4){0.f, 0.f, 0.f, 0.f};
         float ssq = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             cu32x4 xv4 = gx[ks];
             if (li >= p.B) xv4 = (cu32x4){0u, 0u, 0u, 0u};
+            if constexpr (F32) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float lo = __uint_as_float(xv4[e] << 16), hi = __uint_as_float(xv4[e] & 0xffff0000u);
-                ssq += lo * lo; ssq += hi * hi;
+                for (int e = 0; e < 4; ++e) {
+                    const float xe = __uint_as_float(xv4[e]);
+                    ssq += xe * xe;
+                    qa = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(gw[ks][e]), xe, qa, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(xv4[e] << 16), hi = __uint_as_float(xv4[e] & 0xffff0000u);
+                    ssq += lo * lo; ssq += hi * hi;
+                }
+                bf16x8 wa, xb;
+                *reinterpret_cast<cu32x4*>(&wa) = gw[ks];
+                *reinterpret_cast<cu32x4*>(&xb) = xv4;
+                qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, qa, 0, 0, 0);
             }
-            bf16x8 wa, xb;
-            *reinterpret_cast<cu32x4*>(&wa) = gw[ks];
-            *reinterpret_cast<cu32x4*>(&xb) = xv4;
-            qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, qa, 0, 0, 0);
         }
         ssq += __shfl_xor(ssq, 16);
         ssq += __shfl_xor(ssq, 32);                      // every lane: its row's sum over this wave's k quarter
@@ -1601,6 +1618,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 
     float* ws = reinterpret_cast<float*>(smem + wave * 1536);          // q | kn | vn
     bf16_t* Bt = reinterpret_cast<bf16_t*>(smem + WS_BYTES);
+    float* Btf = reinterpret_cast<float*>(smem + WS_BYTES);             // (F32: the B tile holds floats)
     float* own = reinterpret_cast<float*>(smem + WS_BYTES + BT_BYTES);
     if (have) {
         // ---- 1. q / k RMSNorm + RoPE at position S0, K / V through the cache type (attn_cp's stage 1)
@@ -1640,8 +1658,11 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
             for (int w = 0; w < KW; ++w)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    kx[w * 8 + 2 * e] = __uint_as_float(kr[w][e] << 16);
-                    kx[w * 8 + 2 * e + 1] = __uint_as_float(kr[w][e] & 0xffff0000u);
+                    if constexpr (F32) kx[w * 4 + e] = __uint_as_float(kr[w][e]);
+                    else {
+                        kx[w * 8 + 2 * e] = __uint_as_float(kr[w][e] << 16);
+                        kx[w * 8 + 2 * e + 1] = __uint_as_float(kr[w][e] & 0xffff0000u);
+                    }
                 }
         }
         const float* q = ws + qq * 32;
@@ -1669,8 +1690,13 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
             acc1 += ek * vn[2 * lane + 1];
         }
         const float inv = 1.f / l;
-        const unsigned pk = (unsigned)f32_to_bf16(acc0 * inv) | ((unsigned)f32_to_bf16(acc1 * inv) << 16);
-        *reinterpret_cast<unsigned*>(Bt + rr * BSTR + hh * HD + 2 * lane) = pk;
+        if constexpr (F32) {
+            float2 o2; o2.x = acc0 * inv; o2.y = acc1 * inv;
+            *reinterpret_cast<float2*>(Btf + rr * BSTR + hh * HD + 2 * lane) = o2;
+        } else {
+            const unsigned pk = (unsigned)f32_to_bf16(acc0 * inv) | ((unsigned)f32_to_bf16(acc1 * inv) << 16);
+            *reinterpret_cast<unsigned*>(Bt + rr * BSTR + hh * HD + 2 * lane) = pk;
+        }
     }
     QTTS_TS(2);
     __syncthreads();
@@ -1681,16 +1707,25 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 #pragma unroll
     for (int s = 0; s < 2; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        cu32x4 bv = *reinterpret_cast<const cu32x4*>(Bt + (li & 1) * BSTR + ks * 32 + lq * 8);
+    for (int ks = 0; ks < NKS; ++ks) {
+        cu32x4 bv = F32 ? *reinterpret_cast<const cu32x4*>(Btf + (li & 1) * BSTR + ks * 16 + lq * 4)
+                        : *reinterpret_cast<const cu32x4*>(Bt + (li & 1) * BSTR + ks * 32 + lq * 8);
         if (!col_ok) bv = (cu32x4){0u, 0u, 0u, 0u};
-        bf16x8 xb;
-        *reinterpret_cast<cu32x4*>(&xb) = bv;
+        if constexpr (F32) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 wa;
-            *reinterpret_cast<cu32x4*>(&wa) = wf[s][ks];
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[s], 0, 0, 0);
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[s][ks][e]), __uint_as_float(bv[e]), acc[s], 0, 0, 0);
+        } else {
+            bf16x8 xb;
+            *reinterpret_cast<cu32x4*>(&xb) = bv;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 wa;
+                *reinterpret_cast<cu32x4*>(&wa) = wf[s][ks];
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[s], 0, 0, 0);
+            }
         }
     }
     const bool reducer = g == NKV - 1;
@@ -1770,7 +1805,7 @@ __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const un
 
 bool cp_attn_o_takes(const AttnDecodeParams& a, int H) {
     return a.hd == 128 && a.nkv == 8 && a.nh == 16 && a.n_new == 1 && !a.len_dev && !a.n_pad && a.len_static >= 1 && a.len_static + 1 <= 16 &&
-           a.B >= 1 && a.B <= 8 && a.kv.bf16 && !a.kv.vt && H % 128 == 0 && H >= 128;
+           a.B >= 1 && a.B <= 8 && !a.kv.vt && H % 128 == 0 && H >= 128;          // (bf16 cache: the bf16 instantiations; fp32 cache: the F32 ones)
 }
 
 // bench.py's roofline leg (qtts_talker_set_profile(1)): the next launch goes out through hipExtLaunchKernelGGL with the caller's event
@@ -1785,10 +1820,10 @@ void cp_attn_o_set_launch_events(hipEvent_t start, hipEvent_t stop) { tl_cpao_ev
 
 int cp_attn_o_grid(int H) { return 4 * 8 * (H / 128); }
 
-int cp_attn_o_blocks_per_cu() {
+int cp_attn_o_blocks_per_cu(bool f32) {
 #ifdef QTTS_HOST_EMU
     if (const char* e = QTTS_ENV("QTTS_HOSTEMU_CPAO_BLOCKS_PER_CU")) return atoi(e);      // (tests of the admission rule)
-    return 2;                                           // what the gfx950 build reports (the q|k|v-front instantiations: 176-180 registers, two waves per SIMD)
+    return f32 ? 1 : 2;                                 // what the gfx950 build reports (the q|k|v-front instantiations: 176-180 registers, two waves per SIMD)
 #else
     int best = 1 << 30;
     auto probe = [&](auto kern) {
@@ -1796,20 +1831,27 @@ int cp_attn_o_blocks_per_cu() {
         QTTS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, 0));
         best = std::min(best, n);
     };
-    probe(cp_attn_o_kernel<true, true>); probe(cp_attn_o_kernel<false, true>);
-    probe(cp_attn_o_kernel<true, false>); probe(cp_attn_o_kernel<false, false>);
+    if (f32) {
+        probe(cp_attn_o_kernel<true, true, true>); probe(cp_attn_o_kernel<false, true, true>);
+        probe(cp_attn_o_kernel<true, false, true>); probe(cp_attn_o_kernel<false, false, true>);
+    } else {
+        probe(cp_attn_o_kernel<true, true, false>); probe(cp_attn_o_kernel<false, true, false>);
+        probe(cp_attn_o_kernel<true, false, false>); probe(cp_attn_o_kernel<false, false, false>);
+    }
     return best;
 #endif
 }
 
 void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
-    QTTS_REQUIRE(cp_attn_o_takes(P.a, P.H), QTTS_ERR_ARG, "cp_attn_o: shape (bf16 cache, 16 / 8 heads of 128, one new token, <= 16 keys, batch <= 8)");
+    QTTS_REQUIRE(cp_attn_o_takes(P.a, P.H), QTTS_ERR_ARG, "cp_attn_o: shape (16 / 8 heads of 128, one new token, <= 16 keys, batch <= 8)");
+    const bool f32 = !P.a.kv.bf16;                       // (the cache type says which engine this is: fp32 operators, rows and cache go together)
+    QTTS_REQUIRE(!f32 || !P.out16, QTTS_ERR_ARG, "cp_attn_o: no bf16 copy of the hidden rows in fp32 mode");
     QTTS_REQUIRE(P.Wo && P.res && P.out && P.part && P.serial && P.a.qw && P.a.kw && P.a.inv_freq, QTTS_ERR_ARG, "cp_attn_o: null operand");
     QTTS_REQUIRE(P.slot >= 0 && P.slot < 128, QTTS_ERR_ARG, "cp_attn_o: slot must be 0..127");
     const dim3 grid(cp_attn_o_grid(P.H));                // (row pair, kv head, chunk)
     if (P.Wqkv) {      // with the layer's q|k|v GEMM in front: workgroup = one 16-feature strip of it, so the two grids must coincide
         QTTS_REQUIRE((int)grid.x * 16 == P.a.ld && P.K == 1024 && P.x16 && P.qkv_gran && P.ldx16 % 8 == 0, QTTS_ERR_ARG,
-                     "cp_attn_o: the q|k|v front needs K = 1024, (nh + 2 nkv) * 128 == 16 * workgroups, bf16 x and the granule buffer");
+                     "cp_attn_o: the q|k|v front needs K = 1024, (nh + 2 nkv) * 128 == 16 * workgroups, x rows in the engine's type and the granule buffer");
         CpAttnOParams Q = P;
 #ifdef QTTS_HOST_EMU
         // The emulator runs the workgroups of a launch one after the other; here every workgroup first produces and then waits for
@@ -1820,13 +1862,23 @@ void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st) {
         {
             Q.phase = 2;
 #endif
-            if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, true>), grid, st, QTTS_CPAO_ARGS(Q));
-            else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, true>), grid, st, QTTS_CPAO_ARGS(Q));
+            if (f32) {
+                if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, true, true>), grid, st, QTTS_CPAO_ARGS(Q));
+                else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, true, true>), grid, st, QTTS_CPAO_ARGS(Q));
+            } else {
+                if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, true, false>), grid, st, QTTS_CPAO_ARGS(Q));
+                else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, true, false>), grid, st, QTTS_CPAO_ARGS(Q));
+            }
         }
     } else {
         QTTS_REQUIRE(P.a.qkv, QTTS_ERR_ARG, "cp_attn_o: null q|k|v rows");
-        if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, false>), grid, st, QTTS_CPAO_ARGS(P));
-        else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, false>), grid, st, QTTS_CPAO_ARGS(P));
+        if (f32) {
+            if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, false, true>), grid, st, QTTS_CPAO_ARGS(P));
+            else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, false, true>), grid, st, QTTS_CPAO_ARGS(P));
+        } else {
+            if (P.a.kv.contig) QTTS_CPAO_LAUNCH((cp_attn_o_kernel<true, false, false>), grid, st, QTTS_CPAO_ARGS(P));
+            else QTTS_CPAO_LAUNCH((cp_attn_o_kernel<false, false, false>), grid, st, QTTS_CPAO_ARGS(P));
+        }
     }
     QTTS_CHECK_HIP(hipGetLastError());
 }

@@ -256,7 +256,7 @@ void launch_cp_attn_o(const CpAttnOParams& P, hipStream_t st);
 // once -- hipOccupancyMaxActiveBlocksPerMultiprocessor, the minimum over the instantiations an engine can launch.  A launch whose
 // workgroups wait for each other's granules is only correct when ALL of them are resident: the engine admits a fused launch per
 // device only while (fused engines on the device) x grid <= this x the device's compute units (talker_engine.hip: fused_admit).
-int cp_attn_o_blocks_per_cu();
+int cp_attn_o_blocks_per_cu(bool f32 = false);
 int cp_attn_o_grid(int H);                                        // workgroups of one launch
 void cp_attn_o_set_launch_events(hipEvent_t start, hipEvent_t stop);   // bench.py's roofline leg: time the NEXT launch on its own (as skinny_set_launch_events)
 

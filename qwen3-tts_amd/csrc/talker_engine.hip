@@ -345,8 +345,11 @@ struct qtts_talker {
         // bf16 engines, code predictor passes >= 1 at batch <= 8: attention and o-projection in one launch (split over k by kv head, partial
         // sums handed over as tagged granules and added in kv-head order; profiles/r04_cp_attn_o.md) -- and, where the layer has a q|k|v
         // GEMM of its own (layers >= 1: layer 0's row comes from the table), that GEMM in front of them in the same launch
-        const bool fuse_ao = cp_attn_o_env && L.o_p16.p && ao_part.p && att16 && !skinny_only && cp_attn_o_takes(a, d.H) && layer < 5 && len_static * 5 + layer < 128;
-        const bool front = fuse_ao && !skip_qkv && h16 && cp_front_env && d.H == 1024 && a.ld == 4 * 8 * (d.H / 128) * 16;
+        // (fp32 engines, on request: the F32 instantiation on the fp32 decode GEMM's own packed operators, only in front of a fused MLP)
+        const void* wo_fused = bf16 ? L.o_p16.p : (L.fs_o == 16 ? L.o_p.p : nullptr);
+        const bool fuse_ao = cp_attn_o_env && wo_fused && ao_part.p && (bf16 ? att16 : mlp_fusable) && !skinny_only && cp_attn_o_takes(a, d.H) && layer < 5 &&
+                             len_static * 5 + layer < 128;
+        const bool front = fuse_ao && !skip_qkv && (h16 || !bf16) && cp_front_env && d.H == 1024 && a.ld == 4 * 8 * (d.H / 128) * 16;
         if (!skip_qkv && !front) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
             if (splitk && sk_pending) {    // the previous layer's down-projection left (residual + half 0, half 1): added on the way in
                 p.xp = sk_part.as<float>(); p.xp_stride = pstride; p.x_out = xs;
@@ -357,15 +360,15 @@ struct qtts_talker {
         }
         if (fuse_ao) {
             CpAttnOParams f{};
-            f.a = a; f.Wo = L.o_p16.p; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
+            f.a = a; f.Wo = wo_fused; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
             f.part = ao_part.as<float>(); f.serial = ss.frame_serial; f.slot = len_static * 5 + layer; f.phase = 2;
             f.err = ss.n_generated + 5; f.done_latch = ss.done; f.H = d.H; f.first_pause = cp_attn_o_pause; f.poll_step = cp_attn_o_step;
             if (front) {
-                f.Wqkv = L.qkv_p.p; f.x16 = xs16; f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = ao_qkv.as<float>();
+                f.Wqkv = L.qkv_p.p; f.x16 = bf16 ? xs16 : reinterpret_cast<const unsigned short*>(xs); f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = ao_qkv.as<float>();
                 ++cp_front_count;
             }
             if (timing_now) {          // bench.py's roofline leg: this launch timed on its own, as the decode GEMM's (stack 3: the fused launch)
-                const double eb = 2.0;
+                const double eb = bf16 ? 2.0 : 4.0;
                 LaunchEv e{nullptr, nullptr, 3, front ? a.ld + d.H : d.H, front ? d.H : d.qd,
                            eb * ((double)d.H * d.qd + (front ? (double)a.ld * d.H : 0.0))};
                 QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
@@ -501,8 +504,8 @@ struct qtts_talker {
     // resident at once: workgroups wait for granules that other workgroups of the same launch produce.  Residency is a property of the
     // DEVICE, so the admission is per device (round 5), and it is an account of the one resource that limits it here, the
     // register file: a compute unit has 512 registers per lane and SIMD; a launch of `grid` workgroups on `cus` compute units puts
-    // ceil(grid / cus) workgroups on a compute unit, each -- 4 waves, one per SIMD, of <= 184 registers (bf16 engines; <= 256 for the fp32
-    // instantiation of cp_mlp_kernel: CP_SHARE_F32) -- with CP_SHARE = 184 of that budget
+    // ceil(grid / cus) workgroups on a compute unit, each -- 4 waves, one per SIMD, of <= 184 registers (bf16 engines; <= 272 for the fp32
+    // instantiations of the two kernels: CP_SHARE_F32) -- with CP_SHARE = 184 of that budget
     // (the code objects' own numbers are pinned by tests/test_host_logic.py::test_fused_launches_fit_their_register_shares).  An engine's
     // share is that of its LARGEST fused launch (its launches run one after the other on one stream); engines are admitted while the shares
     // of the fused engines of a device add up to <= 512: two on a whole MI355X (bench.py --workload clone-shard at batch 8 runs two), none
@@ -512,7 +515,7 @@ struct qtts_talker {
     // is another PROCESS on the same device: a consumer that loses its producers there gives up after ~0.3 s, latches the stop flag (one
     // give-up per generation, not per launch), the call fails with QTTS_ERR_STATE and the engine leaves the fused launches for good
     // (`fused_retire`): the caller's retry runs on the separate launches.
-    static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 256;     // (fp32 engines: cp_mlp_kernel<true, ...> holds twice the operand registers)
+    static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 272;     // (fp32 engines: the F32 instantiations hold twice the operand registers -- one engine per device)
     struct FusedRegistry { std::mutex m; std::map<int, std::pair<int, int>> dev; };        // device -> (share in use, fused engines)
     static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
     bool cp_fused_slot = false;
@@ -578,11 +581,14 @@ void qtts_talker::finalize() {
     // 38 MB per layer and the round-4 plan -- o- and down-projection split over two workgroups per strip -- streams it faster than 256
     // workgroups of 256 registers do: 4.18 vs 4.30 ms per frame (1.7B, batch 8; profiles/r05_cp_mlp.md)
     if (!bf16 && !QTTS_OPT_SET("QTTS_CP_MLP_F32")) cp_mlp_env = false;
-    const bool want_ao = bf16 && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0;
+    // ... and the fused attention + o-projection launch likewise (QTTS_CP_ATTN_O_F32=1), together with the fused MLP only: both read and
+    // write complete rows, so no half of a split-K projection is pending anywhere in passes >= 1
+    const bool ao_f32 = !bf16 && cp_mlp_env && QTTS_OPT_SET("QTTS_CP_ATTN_O_F32");
+    const bool want_ao = (bf16 || ao_f32) && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0;
     if (want_ao || cp_mlp_env) {      // one admission for the engine's fused launches
         int grid_cp = 0;
         bool occ_ok = true;
-        if (want_ao) { grid_cp = std::max(grid_cp, cp_attn_o_grid(cd.H)); occ_ok = occ_ok && cp_attn_o_blocks_per_cu() >= 1; }
+        if (want_ao) { grid_cp = std::max(grid_cp, cp_attn_o_grid(cd.H)); occ_ok = occ_ok && cp_attn_o_blocks_per_cu(!bf16) >= 1; }
         if (cp_mlp_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp_blocks_per_cu(cd.H, cd.I, bf16) >= 1; }
         fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE : CP_SHARE_F32);
     }
@@ -720,7 +726,7 @@ void qtts_talker::finalize() {
         QTTS_CHECK_HIP(hipMemset(mlp_act.p, 0, mlp_act.bytes));
         QTTS_CHECK_HIP(hipMemset(mlp_part.p, 0, mlp_part.bytes));
     }
-    if (bf16 && !cl.empty() && cl[0].o_p16.p) {
+    if (!cl.empty() && cp_attn_o_env && (bf16 ? cl[0].o_p16.p != nullptr : true)) {
         ao_part.alloc((size_t)8 * 8 * cd.H * 8);
         ao_qkv.alloc((size_t)8 * (cd.qd + 2 * cd.kvd) * 8);
         QTTS_CHECK_HIP(hipMemset(ao_qkv.p, 0, ao_qkv.bytes));

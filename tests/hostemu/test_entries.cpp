@@ -229,37 +229,39 @@ extern "C" int hostemu_cp_attn_o(const float* qkv, int ld, int B, const float* q
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
-// One code-predictor layer front of a single-token pass (bf16 engine, K = hidden = 1024, 16 / 8 heads of 128) on B rows: q|k|v GEMM with the
+// One code-predictor layer front of a single-token pass (K = hidden = 1024, 16 / 8 heads of 128) on B rows: q|k|v GEMM with the
 // folded RMSNorm + attention + o-projection.  mode 0: three launches (decode GEMM, attn_cp, decode GEMM); mode 2: ONE launch
 // (cp_attn_o_kernel with the q|k|v front: every workgroup produces a strip of q|k|v, hands it over as tagged granules, then attends).
-// x [B][H] fp32 (rounded to bf16 here, as the engine's bf16 copy of the hidden state), Wqkv [(nh + 2 nkv) * 128][H], gnorm [H].
+// x [B][H] fp32 (f32 = 0: rounded to bf16 here, as the engine's bf16 copy of the hidden state), Wqkv [(nh + 2 nkv) * 128][H], gnorm [H].
+// f32 = 1: the exact parity mode -- fp32 operators, rows and cache (kpool / vpool hold floats), cp_attn_o_kernel<.., .., true>.
 extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, const float* gnorm, float eps_in, const float* qw, const float* kw,
                                       float eps, const float* inv_freq, int S0, void* kpool, void* vpool, const int* page_table, int pages_per_seq,
                                       const float* Wo, int H, const float* res, float* out, unsigned short* out16, int mode, const float* rope_cs,
-                                      int rope_cs_n, unsigned epoch0) {
+                                      int rope_cs_n, unsigned epoch0, int f32) {
     try {
+        const bool bf = !f32;
         const int nh = 16, nkv = 8, qd = nh * 128, ld = (nh + 2 * nkv) * 128;
         std::vector<qtts::bf16_t> x16((size_t)B * H);
         for (size_t i = 0; i < x16.size(); ++i) x16[i] = qtts::f32_to_bf16(x[i]);
-        std::vector<unsigned char> wq(qtts::skinny_packed_bytes(ld, H, true));
-        qtts::pack_skinny_weight(Wqkv, ld, H, true, wq.data(), gnorm, 16);
+        std::vector<unsigned char> wq(qtts::skinny_packed_bytes(ld, H, bf));
+        qtts::pack_skinny_weight(Wqkv, ld, H, bf, wq.data(), gnorm, 16);
         std::vector<float> qkv((size_t)B * ld, NAN);
         qtts::AttnDecodeParams a{};
         a.qkv = qkv.data(); a.ld = ld; a.B = B; a.n_new = 1; a.nh = nh; a.nkv = nkv; a.hd = 128;
         a.qw = qw; a.kw = kw; a.eps = eps; a.inv_freq = inv_freq; a.len_static = S0;
         a.kv.k = kpool; a.kv.v = vpool; a.kv.page_table = page_table; a.kv.pages_per_seq = pages_per_seq;
-        a.kv.n_pages = B * pages_per_seq; a.kv.nkv = nkv; a.kv.hd = 128; a.kv.bf16 = 1; a.kv.contig = page_table ? 0 : 1;
+        a.kv.n_pages = B * pages_per_seq; a.kv.nkv = nkv; a.kv.hd = 128; a.kv.bf16 = bf ? 1 : 0; a.kv.contig = page_table ? 0 : 1;
         a.layer = 0; a.max_len = 32; a.rope_cs = rope_cs; a.rope_cs_n = rope_cs_n;
-        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(H, qd, true));
+        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(H, qd, bf));
         for (int i = 0; i < B * H; ++i) out[i] = res[i];
         if (mode == 2) {
-            qtts::pack_skinny_weight(Wo, H, qd, true, wp.data(), nullptr, 16);
+            qtts::pack_skinny_weight(Wo, H, qd, bf, wp.data(), nullptr, 16);
             std::vector<float> part((size_t)8 * 8 * H * 2, 0.f), gran((size_t)8 * ld * 2, 0.f);
             int serial = (int)epoch0, err = 0;
             qtts::CpAttnOParams f{};
-            f.a = a; f.a.qkv = nullptr; f.Wo = wp.data(); f.res = out; f.out = out; f.out16 = out16; f.part = part.data(); f.serial = &serial; f.slot = 9;
+            f.a = a; f.a.qkv = nullptr; f.Wo = wp.data(); f.res = out; f.out = out; f.out16 = bf ? out16 : nullptr; f.part = part.data(); f.serial = &serial; f.slot = 9;
             f.phase = 2; f.err = &err; f.H = H; f.first_pause = 16; f.poll_step = 8;
-            f.Wqkv = wq.data(); f.x16 = x16.data(); f.ldx16 = H; f.K = H; f.eps_in = eps_in; f.qkv_gran = gran.data();
+            f.Wqkv = wq.data(); f.x16 = bf ? x16.data() : reinterpret_cast<const unsigned short*>(x); f.ldx16 = H; f.K = H; f.eps_in = eps_in; f.qkv_gran = gran.data();
             for (int rep = 0; rep < 2; ++rep) {                     // twice on the same granule buffers
                 if (rep) { for (int i = 0; i < B * H; ++i) out[i] = res[i]; ++serial; }
                 qtts::launch_cp_attn_o(f, nullptr);
@@ -290,17 +292,23 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
             return 0;
         }
         qtts::SkinnyParams q{};
-        q.x = reinterpret_cast<const float*>(x16.data()); q.x_bf16 = 1; q.ldx = H; q.M = B; q.Wp = wq.data(); q.N = ld; q.K = H;
+        q.x = bf ? reinterpret_cast<const float*>(x16.data()) : x; q.x_bf16 = bf ? 1 : 0; q.ldx = H; q.M = B; q.Wp = wq.data(); q.N = ld; q.K = H;
         q.fs = 16; q.norm = 1; q.eps = eps_in; q.out = qkv.data(); q.ldo = ld; q.act = qtts::ACT_NONE;
-        qtts::launch_skinny(q, true, nullptr);
+        std::vector<float> ss(B, 0.f);
+        if (!bf && !qtts::skinny_f32_inline_norm(B, H)) {
+            for (int m = 0; m < B; ++m) { double acc = 0; for (int k = 0; k < H; ++k) acc += (double)x[(size_t)m * H + k] * x[(size_t)m * H + k]; ss[m] = (float)acc; }
+            q.ss_in = ss.data();
+        }
+        qtts::launch_skinny(q, bf, nullptr);
         std::vector<qtts::bf16_t> att((size_t)B * qd, (qtts::bf16_t)0x7FC0);
-        a.out = reinterpret_cast<float*>(att.data()); a.ldo = qd; a.out_bf16 = 1;
+        std::vector<float> att32((size_t)B * qd, NAN);
+        a.out = bf ? reinterpret_cast<float*>(att.data()) : att32.data(); a.ldo = qd; a.out_bf16 = bf ? 1 : 0;
         qtts::launch_attn_decode(a, nullptr);
-        qtts::pack_skinny_weight(Wo, H, qd, true, wp.data(), nullptr, 8);
+        qtts::pack_skinny_weight(Wo, H, qd, bf, wp.data(), nullptr, bf ? 8 : 16);
         qtts::SkinnyParams p{};
-        p.x = reinterpret_cast<const float*>(att.data()); p.x_bf16 = 1; p.ldx = qd; p.M = B; p.Wp = wp.data(); p.N = H; p.K = qd;
-        p.fs = 8; p.res = out; p.ldr = H; p.out = out; p.ldo = H; p.act = qtts::ACT_NONE; p.out16 = out16;
-        qtts::launch_skinny(p, true, nullptr);
+        p.x = bf ? reinterpret_cast<const float*>(att.data()) : att32.data(); p.x_bf16 = bf ? 1 : 0; p.ldx = qd; p.M = B; p.Wp = wp.data(); p.N = H; p.K = qd;
+        p.fs = bf ? 8 : 16; p.res = out; p.ldr = H; p.out = out; p.ldo = H; p.act = qtts::ACT_NONE; p.out16 = bf ? out16 : nullptr;
+        qtts::launch_skinny(p, bf, nullptr);
         return 0;
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }

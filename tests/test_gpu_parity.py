@@ -397,7 +397,7 @@ def _real_golden(dev, golden_dir, name, cfg, max_seq=256, fused_f32=False):
     _check_hidden_steps(out, g, n)
     st = eng.stats()
     want = (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers if fused_f32 else 0
-    assert st["cp_mlp_per_step"] == want and st["cp_fused_giveups"] == 0, st
+    assert st["cp_mlp_per_step"] == want and st["cp_fused_per_step"] == want and st["cp_fused_giveups"] == 0, st
     return eng
 
 
@@ -425,16 +425,6 @@ def test_talker_06b_batch8_10s_greedy_vs_reference_golden(dev, golden_dir):
     """BASELINE config 3: 0.6B dims, batch 8, ragged left-padded prompts, length forced to 125 frames (10 s), greedy:
     8 x 125 x 16 codebook indices bit-exact vs the reference CPU path."""
     _real_golden(dev, golden_dir, "talker_06b_b8", synth.talker_06b())
-
-
-@pytest.mark.parametrize("name", ["talker_06b", "talker_17b", "talker_06b_b8"])
-def test_fused_mlp_fp32_instantiation_bit_exact_vs_reference_golden(dev, golden_dir, name):
-    """the fused construction's bit-exact leg.  `cp_mlp_kernel<true, ...>` -- the same kernel source as the bf16 frame
-    step's fused MLP launch (XCD-sliced intermediate vector, granule hand-offs, partial sums added in XCD order) with fp32 operators,
-    rows and intermediate vector -- runs the code predictor's passes >= 1 of an fp32 engine (QTTS_CP_MLP_F32=1; `cp_mlp_per_step` says
-    it did), greedy, against the reference's CPU goldens: every codebook index of every frame, 1 / 3 / 8 utterances, 0.6B and 1.7B dims."""
-    with _qlib.options(QTTS_CP_MLP_F32="1"):
-        _real_golden(dev, golden_dir, name, synth.talker_06b() if "06b" in name else synth.talker_17b(), fused_f32=True)
 
 
 def test_talker_17b_batch32_streaming_text_greedy_vs_reference_golden(dev, golden_dir):
@@ -472,6 +462,10 @@ def test_talker_17b_batch32_streaming_text_greedy_vs_reference_golden(dev, golde
 
 
 def test_talker_17b_base_voice_clone_icl_batch8_vs_reference_golden(dev, golden_dir):
+    _icl_golden(dev, golden_dir, False)
+
+
+def _icl_golden(dev, golden_dir, fused_f32):
     """BASELINE config 5's request shape at REAL dims: Qwen3-TTS-12Hz-1.7B **Base**, 8 voice-clone requests
     with ICL prompts -- ref text ids + `ref_code` (25..52 frames x 16 codebooks) + x-vector, streaming text input -- through
     seam S1.  The fixture was produced by the reference's own `Qwen3TTSForConditionalGeneration.generate` (prompt assembly incl.
@@ -509,6 +503,26 @@ def test_talker_17b_base_voice_clone_icl_batch8_vs_reference_golden(dev, golden_
           f"(min reference margin {float(margin.min()):.5f})")
     assert n == gc.shape[1]
     assert np.abs(hidden[0][n - 1].cpu().numpy() - g["hidden_last"][0]).max() <= 2e-3
+    st = model.talker.stats()
+    want = (t.num_code_groups - 2) * t.cp_num_hidden_layers if fused_f32 else 0
+    assert st["cp_mlp_per_step"] == want and st["cp_fused_per_step"] == want and st["cp_fused_giveups"] == 0, st
+
+
+@pytest.mark.parametrize("name", ["talker_06b", "talker_17b", "talker_06b_b8", "talker_17b_base_icl_b8", "talker_06b_long"])
+def test_fused_launches_fp32_instantiations_bit_exact_vs_reference_golden(dev, golden_dir, name):
+    """the fused construction's bit-exact leg.  `cp_attn_o_kernel<.., .., true>` and `cp_mlp_kernel<true, ...>` -- the kernel
+    sources of the bf16 frame step's two fused launches (q|k|v strips handed over as granules, attention, o-projection split over k by kv
+    head and summed in kv-head order; gate|up / SwiGLU / down with the intermediate vector sliced by XCD and the partial sums added in XCD
+    order) instantiated with fp32 operators, rows, cache and intermediate vector -- run EVERY launch of the code predictor's passes >= 1 of
+    an fp32 engine (QTTS_CP_ATTN_O_F32=1, QTTS_CP_MLP_F32=1; `cp_fused_per_step` and `cp_mlp_per_step` say they did), greedy, against the
+    reference's CPU goldens at batch <= 8: every codebook index of every frame -- 1 / 3 / 8 utterances at 0.6B and 1.7B dims, the 8 Base
+    voice-clone ICL requests through the wrapper, the 820-frame utterance."""
+    with _qlib.options(QTTS_CP_MLP_F32="1", QTTS_CP_ATTN_O_F32="1"):
+        if name == "talker_17b_base_icl_b8":
+            _icl_golden(dev, golden_dir, True)
+        else:
+            _real_golden(dev, golden_dir, name, synth.talker_06b() if "06b" in name else synth.talker_17b(), max_seq=1024 if "long" in name else 256,
+                         fused_f32=True)
 
 
 @pytest.mark.parametrize("max_seq", [1024, 4096])

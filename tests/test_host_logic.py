@@ -850,8 +850,8 @@ def test_lds_dma_kernels_wait_for_their_requests_before_the_barrier(libqtts):
 
 def test_fused_launches_fit_their_register_shares(libqtts):
     """The admission rule of the fused launches (talker_engine.hip: fused_admit) is an account of the register file: CP_SHARE = 184 registers
-    per lane and SIMD for a workgroup of cp_attn_o_kernel / cp_mlp_kernel (4 waves, one per SIMD), CP_SHARE_F32 = 256 for the fp32
-    instantiations of cp_mlp_kernel (the exact parity mode: twice the operand registers).  Pinned from the code objects of the built library
+    per lane and SIMD for a workgroup of cp_attn_o_kernel / cp_mlp_kernel (4 waves, one per SIMD), CP_SHARE_F32 = 272 for the fp32
+    instantiations of the two kernels (the exact parity mode: twice the operand registers).  Pinned from the code objects of the built library
     (`.vgpr_count` = arch + accumulator registers, allocated in granules of 8): every fused kernel within its share, LDS far from the limit, no
     scratch."""
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
@@ -865,13 +865,13 @@ def test_fused_launches_fit_their_register_shares(libqtts):
     for k in rows:
         regs = (k[".vgpr_count"] + 7) // 8 * 8
         waves_per_simd = k[".max_flat_workgroup_size"] // 256
-        f32 = "cp_mlp_kernel" in k[".name"] and "ILb1E" in k[".name"]          # (cp_mlp_kernel<true, ...>)
+        f32 = ("cp_mlp_kernelILb1E" in k[".name"]) or ("cp_attn_o_kernelILb" in k[".name"] and "ELb1EEE" in k[".name"])     # (<true, ...> / <.., .., true>)
         n_f32 += f32
-        assert waves_per_simd == 1 and regs <= (256 if f32 else 184), (k[".name"], regs, waves_per_simd)
+        assert waves_per_simd == 1 and regs <= (272 if f32 else 184), (k[".name"], regs, waves_per_simd)
         assert 2 * k[".group_segment_fixed_size"] <= 160 * 1024 and k.get(".private_segment_fixed_size", 0) == 0, k[".name"]
-    assert n_f32 >= 1
+    assert n_f32 >= 5
     src = open(os.path.join(ROOT, "qwen3-tts_amd", "csrc", "talker_engine.hip")).read()
-    assert "CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 256;" in src
+    assert "CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 272;" in src
 
 
 def test_option_table_through_the_c_abi(libqtts):

@@ -54,7 +54,7 @@ def emu():
     lib.hostemu_set_real_gemm.argtypes = [i32]; lib.hostemu_set_real_gemm.restype = None
     lib.hostemu_set_fiber_order.argtypes = [i32]; lib.hostemu_set_fiber_order.restype = None
     lib.hostemu_set_block_order.argtypes = [i32]; lib.hostemu_set_block_order.restype = None
-    lib.hostemu_cp_layer_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.c_uint32]
+    lib.hostemu_cp_layer_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.c_uint32, i32]
     lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
     lib.hostemu_cp_mlp.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, i32, i32, vp, vp, vp, i32, C.c_uint32, i32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
@@ -836,7 +836,8 @@ def test_cp_mlp_one_launch_real_source(emu, H, I, f32):
             assert np.array_equal(o3, first), ("result depends on the wave order / the epoch", H, B, fo)
 
 
-def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
+@pytest.mark.parametrize("f32", [0, 1])
+def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu, f32):
     """`cp_attn_o_kernel` with the layer's q|k|v GEMM in front (round 4): 256 workgroups, each first computes a 16-feature strip of
     q|k|v = rsqrt(mean x^2 + eps) * W' x (RMSNorm weight folded into W', row variances from the same bf16 x fragments, four k quarters
     added in wave order), hands it over as tagged granules, then attends with the rows it reads back from six other workgroups' strips,
@@ -846,8 +847,12 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
     contiguous and permuted page tables, three fiber orders, two launches per call on the same granule buffers under two serials.  The
     entry point then runs the CONSUMING half alone on those buffers: with the launch's own (serial, slot) it finds every granule and
     reproduces the result bit for bit; with another slot or another serial every granule is stale and the consumers give up and raise
-    the error flag instead of taking them (what `generate` turns into QTTS_ERR_STATE)."""
+    the error flag instead of taking them (what `generate` turns into QTTS_ERR_STATE).
+    f32 = 1 (round 5): the F32 instantiation -- the exact parity mode's operators (fp32, k-tiles of 16 on v_mfma_f32_16x16x4_f32), fp32 rows and
+    fp32 cache through the same launch, against the fp32 engines' three launches and float64 numpy to fp32 precision."""
     g = np.random.default_rng(505)
+    rw = (lambda a_: np.asarray(a_, np.float32)) if f32 else (lambda a_: _bf16_round(np.asarray(a_, np.float32))[0])
+    tol, rtol = (3e-5, 3e-6) if f32 else (3e-2, 2e-3)
     HD, nh, nkv, H, eps, eps_in = 128, 16, 8, 1024, 1e-6, 1e-6
     qd, ld = nh * HD, (nh + 2 * nkv) * HD
     inv_freq = (1.0 / (10000.0 ** (np.arange(64) / 64.0))).astype(np.float32)
@@ -856,8 +861,8 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
     gn = (1 + 0.1 * g.standard_normal(H)).astype(np.float32)
     Wqkv = (g.standard_normal((ld, H)) * 0.04).astype(np.float32)
     Wo = (g.standard_normal((H, qd)) * 0.03).astype(np.float32)
-    Wq_r = _bf16_round(Wqkv * gn[None, :])[0].astype(np.float64)
-    Wo_r = _bf16_round(Wo)[0].astype(np.float64)
+    Wq_r = rw(Wqkv * gn[None, :]).astype(np.float64)
+    Wo_r = rw(Wo).astype(np.float64)
 
     def normrope(x, w, pos):
         x = x.astype(np.float64)
@@ -874,20 +879,20 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
         res = g.standard_normal((B, H)).astype(np.float32)
         K = _bf16_round((g.standard_normal((B, nkv, S0, HD)) * 0.7).astype(np.float32))[0]
         V = _bf16_round(g.standard_normal((B, nkv, S0, HD)).astype(np.float32))[0]
-        kpool = np.full((n_pages, nkv, 16, HD), 0x7FC0, np.uint16)
+        kpool = np.full((n_pages, nkv, 16, HD), np.nan, np.float32) if f32 else np.full((n_pages, nkv, 16, HD), 0x7FC0, np.uint16)
         vpool = kpool.copy()
         for b in range(B):
             for s in range(S0):
-                kpool[table[b, s // 16], :, s % 16] = _bf16_round(K[b, :, s])[1]
-                vpool[table[b, s // 16], :, s % 16] = _bf16_round(V[b, :, s])[1]
-        x_r = _bf16_round(x)[0].astype(np.float64)
+                kpool[table[b, s // 16], :, s % 16] = K[b, :, s] if f32 else _bf16_round(K[b, :, s])[1]
+                vpool[table[b, s // 16], :, s % 16] = V[b, :, s] if f32 else _bf16_round(V[b, :, s])[1]
+        x_r = rw(x).astype(np.float64)
         ref = np.zeros((B, H))
         for b in range(B):
             row = (Wq_r @ x_r[b]) / np.sqrt((x_r[b] ** 2).mean() + eps_in)
             att = np.zeros(qd)
             for h in range(nkv):
-                nk = _bf16_round(normrope(row[(nh + h) * HD:(nh + h + 1) * HD], kw, S0).astype(np.float32))[0]
-                nv = _bf16_round(row[(nh + nkv + h) * HD:(nh + nkv + h + 1) * HD].astype(np.float32))[0]
+                nk = rw(normrope(row[(nh + h) * HD:(nh + h + 1) * HD], kw, S0))
+                nv = rw(row[(nh + nkv + h) * HD:(nh + nkv + h + 1) * HD])
                 keys = np.concatenate([K[b, h].astype(np.float64), nk[None].astype(np.float64)], 0)
                 vals = np.concatenate([V[b, h].astype(np.float64), nv[None].astype(np.float64)], 0)
                 for gq in range(2):
@@ -896,7 +901,7 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
                     sc = keys @ q / np.sqrt(HD)
                     pr = np.exp(sc - sc.max()); pr /= pr.sum()
                     att[hq * HD:(hq + 1) * HD] = pr @ vals
-            ref[b] = Wo_r @ _bf16_round(att.astype(np.float32))[0].astype(np.float64) + res[b]
+            ref[b] = Wo_r @ rw(att).astype(np.float64) + res[b]
 
         def run(mode, fiber_order=0, epoch0=0):
             kk, vv = kpool.copy(), vpool.copy()
@@ -906,7 +911,7 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
             try:
                 rc = emu.hostemu_cp_layer_front(_ptr(x), B, _ptr(Wqkv), _ptr(gn), eps_in, _ptr(qw), _ptr(kw), eps, _ptr(inv_freq), S0, _ptr(kk),
                                                 _ptr(vv), _ptr(table) if permute else None, pps, _ptr(Wo), H, _ptr(res), _ptr(out), _ptr(out16),
-                                                mode, None, 0, epoch0)
+                                                mode, None, 0, epoch0, f32)
             finally:
                 emu.hostemu_set_fiber_order(0)
             assert rc == 0, ((B, S0, mode), rc, (emu.qtts_last_error() or b"").decode())
@@ -914,16 +919,21 @@ def test_cp_layer_front_qkv_attention_o_projection_one_launch_real_source(emu):
 
         o0, h0, k0, v0 = run(0)
         scale = max(1.0, float(np.abs(ref).max()))
-        assert float(np.abs(o0 - ref).max()) <= 3e-2 * scale, "the three launches are off their own reference"
+        assert float(np.abs(o0 - ref).max()) <= tol * scale, "the three launches are off their own reference"
         first = None
         for (fo, e0) in [(0, 0), (1, 7), (2, 0xFFFFFFF0)]:
             o2, h2, k2, v2 = run(2, fo, e0)
-            assert float(np.abs(o2 - ref).max()) <= 3e-2 * scale, (B, S0, float(np.abs(o2 - ref).max()))
-            assert float(np.sqrt(((o2 - o0) ** 2).mean())) <= 2e-3 * float(np.sqrt((o0 ** 2).mean())), (B, S0)
-            # the appended K / V rows: equal up to a bf16 last-bit flip where the two q|k|v GEMMs' fp32 sums straddle a rounding boundary
-            kd = (k2.astype(np.int32) - k0.astype(np.int32)); vd = (v2.astype(np.int32) - v0.astype(np.int32))
-            assert np.abs(kd).max() <= 1 and np.abs(vd).max() <= 1 and (kd != 0).mean() < 0.02 and (vd != 0).mean() < 0.02
-            assert np.array_equal(h2, _bf16_round(o2)[1]), "bf16 copy of the hidden rows"
+            assert float(np.abs(o2 - ref).max()) <= tol * scale, (B, S0, float(np.abs(o2 - ref).max()))
+            assert float(np.sqrt(((o2 - o0) ** 2).mean())) <= rtol * float(np.sqrt((o0 ** 2).mean())), (B, S0)
+            if f32:     # the appended K / V rows: the two q|k|v GEMMs' fp32 sums differ in order only
+                live = ~np.isnan(k0)
+                assert np.array_equal(live, ~np.isnan(k2)) and np.array_equal(~np.isnan(v0), ~np.isnan(v2))
+                assert np.abs(k2[live] - k0[live]).max() <= 2e-5 and np.abs(v2[live] - v0[live]).max() <= 2e-5
+            else:
+                # the appended K / V rows: equal up to a bf16 last-bit flip where the two q|k|v GEMMs' fp32 sums straddle a rounding boundary
+                kd = (k2.astype(np.int32) - k0.astype(np.int32)); vd = (v2.astype(np.int32) - v0.astype(np.int32))
+                assert np.abs(kd).max() <= 1 and np.abs(vd).max() <= 1 and (kd != 0).mean() < 0.02 and (vd != 0).mean() < 0.02
+                assert np.array_equal(h2, _bf16_round(o2)[1]), "bf16 copy of the hidden rows"
             if first is None:
                 first = o2
             assert np.array_equal(o2, first), ("result depends on the wave order / the epoch", B, S0, fo)
@@ -1642,11 +1652,13 @@ def test_talker_orchestration_large_ragged_batch_vs_oracle(emu):
         emu.qtts_talker_destroy(h)
 
 
-@pytest.mark.parametrize("cp_mlp", ["1", "0"])
+@pytest.mark.parametrize("cp_mlp", ["both", "1", "0"])
 def test_talker_fp32_split_k_layer_chain_vs_oracle(emu, qopt, cp_mlp):
     """Round 5 (cp_mlp = "1"): the code predictor's passes >= 1 take the fp32 instantiation of the one-launch MLP (`cp_mlp_kernel<true, ...>`:
     the exact parity mode's fused leg; the o-projection before it no longer splits K, the talker stack keeps the split-K plan), and
-    `cp_mlp_per_step` says so (QTTS_CP_MLP_F32=1: opt-in, the split-K plan is the faster one in fp32); cp_mlp = "0": round 4's plan on both stacks.
+    `cp_mlp_per_step` says so (QTTS_CP_MLP_F32=1: opt-in, the split-K plan is the faster one in fp32); cp_mlp = "both": q|k|v + attention +
+    o-projection of those passes in `cp_attn_o_kernel<.., .., true>` as well (QTTS_CP_ATTN_O_F32=1; layer 0 without, layers >= 1 with the q|k|v
+    front): the whole of a pass >= 1 on the fused construction, greedy fp32 against the oracle; cp_mlp = "0": round 4's plan on both stacks.
     Round 4: the ENGINE side of the fp32 split-K plan -- which GEMM of a layer splits, which one combines, which of the two
     residual buffers is current, the unsplit last layer writing where the caller reads -- at the real layer widths (hidden 1024,
     intermediate 3072, q width 2048: the 0.6B talker's and the code predictor's), which is where the plan engages; three layers per
@@ -1668,7 +1680,8 @@ def test_talker_fp32_split_k_layer_chain_vs_oracle(emu, qopt, cp_mlp):
     sp = talker_ref.SamplingParams(do_sample=False, subtalker_dosample=False)
     with torch.no_grad():
         r = talker_ref.talker_generate(w, t, emb, mask, tr, pad, max_new_tokens=4, sp=sp)
-    qopt(emu, "QTTS_CP_MLP_F32", cp_mlp)          # (fp32 engines take the fused MLP launch on request only: talker_engine.hip finalize)
+    qopt(emu, "QTTS_CP_MLP_F32", "0" if cp_mlp == "0" else "1")          # (fp32 engines take the fused launches on request only: talker_engine.hip finalize)
+    qopt(emu, "QTTS_CP_ATTN_O_F32", "1" if cp_mlp == "both" else "0")
     h = _talker_emu(emu, t, w, max_batch=3, max_seq=32)
     try:
         codes, tokens, hidden = _talker_generate(emu, h, t, emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy(), max_new=4)
@@ -1678,9 +1691,9 @@ def test_talker_fp32_split_k_layer_chain_vs_oracle(emu, qopt, cp_mlp):
         emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
         st = _lib.TalkerStatsC()
         _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
-        want = (t.num_code_groups - 2) * t.cp_num_hidden_layers if cp_mlp == "1" else 0
-        assert st.cp_mlp_per_step == want and st.cp_fused_per_step == 0 and st.cp_fused_giveups == 0, (st.cp_mlp_per_step, st.cp_fused_per_step)
-        assert st.cp_fused_active == (1 if cp_mlp == "1" else 0) and st.cp_fused_capacity == (512 // 256 if cp_mlp == "1" else 0)
+        want = (t.num_code_groups - 2) * t.cp_num_hidden_layers if cp_mlp != "0" else 0
+        assert st.cp_mlp_per_step == want and st.cp_fused_per_step == (want if cp_mlp == "both" else 0) and st.cp_fused_giveups == 0, (st.cp_mlp_per_step, st.cp_fused_per_step)
+        assert st.cp_fused_active == (1 if cp_mlp != "0" else 0) and st.cp_fused_capacity == (512 // 272 if cp_mlp != "0" else 0)
     finally:
         emu.qtts_talker_destroy(h)
 

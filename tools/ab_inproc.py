@@ -16,7 +16,8 @@ from qwen3_tts_amd.talker import TalkerEngine
 CONFIGS = {
     "default": {},
     "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
-    "f32_fused_mlp": {"QTTS_CP_MLP_F32": "1"},       # --dtype f32: cp_mlp_kernel<true, ...> against the fp32 split-K plan (the default there)
+    "f32_fused_mlp": {"QTTS_CP_MLP_F32": "1"},
+    "f32_fused_both": {"QTTS_CP_MLP_F32": "1", "QTTS_CP_ATTN_O_F32": "1"},     # ... and cp_attn_o_kernel<.., .., true>: every launch of passes >= 1 fused       # --dtype f32: cp_mlp_kernel<true, ...> against the fp32 split-K plan (the default there)
     "cp_fused_off": {"QTTS_CP_MLP": "0", "QTTS_CP_ATTN_O": "0"},   # ... and q|k|v / attention / o-projection as separate launches (round 3's)
     "mlp_wd_early": {"QTTS_CP_MLP_WD_EARLY": "1"},                  # the fused MLP's down block requested at kernel entry (round 5's first version)
     "mlp_b16_c24": {"QTTS_CP_MLP_PAUSE_B": "16"}, "mlp_b20_c24": {"QTTS_CP_MLP_PAUSE_B": "20"}, "mlp_b28_c24": {"QTTS_CP_MLP_PAUSE_B": "28"},
