@@ -24,7 +24,11 @@
 // phase B -- no circular wait, provided all workgroups are resident (the engine's admission rule, talker_engine.hip: fused_admit).
 // A consumer that loses its producers gives up and latches the generation's stop flag (the cold block of its polling loop: nothing
 // else of the loop may depend on it -- attention.hip: cpao_give_up): what the launch still writes is never consumed.
-// bf16 engines, batch <= 8, H % 128 == 0, (I / (H / 4)) in {4, 8, 12, 16}; everything else keeps the two launches.
+// bf16 engines, batch <= 8, H % 128 == 0, (I / (H / 4)) in {4, 8, 12, 16}; everything else keeps the two launches.  (24 KB of the down
+// operator: requested behind phase A's MFMAs since the A/B of profiles/r05_cp_mlp.md; `wd_early` is the first version.)
+// fp32 engines (the exact parity mode), on request (QTTS_CP_MLP_F32=1): the F32 instantiation of the same source -- fp32 operators, rows and
+// intermediate vector -- through which the reference's fp32 goldens run bit-exact on the MI355X (tests/test_gpu_parity.py:
+// test_fused_launches_fp32_instantiations_bit_exact_vs_reference_golden); slower there than the split-K plan, hence not the default.
 #include "common.h"
 #include "kernels.h"
 #include "tstamp.h"

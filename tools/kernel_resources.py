@@ -72,7 +72,7 @@ def kernels_of(so):
 
 
 def occupancy(k):
-    regs = k[".vgpr_count"] + k.get(".agpr_count", 0)
+    regs = k[".vgpr_count"]          # (gfx90a+ unified file: the total -- arch registers + the accumulator registers `.agpr_count` reports separately)
     regs = max(VGPR_GRANULE, -(-regs // VGPR_GRANULE) * VGPR_GRANULE)
     by_regs = min(MAX_WAVES_PER_SIMD, VGPR_FILE // regs)
     wg_waves = -(-k[".max_flat_workgroup_size"] // 64)
