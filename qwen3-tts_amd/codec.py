@@ -396,11 +396,16 @@ class Qwen3TTSTokenizer:
         if not wavs:
             raise ValueError("encode(): no audio given")
         L = max(w.shape[0] for w in wavs)
-        x = torch.zeros(len(wavs), L, dtype=torch.float32)
-        m = torch.zeros(len(wavs), L, dtype=torch.long)
-        for i, w in enumerate(wavs):                        # EncodecFeatureExtractor semantics: right zero padding + mask
-            x[i, : w.shape[0]] = torch.from_numpy(w)
-            m[i, : w.shape[0]] = 1
+        # EncodecFeatureExtractor semantics: right zero padding + mask.  Built with numpy, not torch: torch's CPU kernels go parallel above 32 K
+        # elements, and an OpenMP team sized for every core the box SHOWS, inside a container whose CPU quota is a fraction of them, gets
+        # the whole process throttled for the rest of the scheduler period -- 85-100 ms stalls in one call of three on the MI355X box
+        # (profiles/r05_voice_clone_prompt.md).  Host-side preparation on the request path stays single-threaded.
+        x_np = np.zeros((len(wavs), L), np.float32)
+        m_np = np.zeros((len(wavs), L), np.int64)
+        for i, w in enumerate(wavs):
+            x_np[i, : w.shape[0]] = w
+            m_np[i, : w.shape[0]] = 1
+        x, m = torch.from_numpy(x_np), torch.from_numpy(m_np)
         return self.model.encode(x, m, return_dict=return_dict)
 
     def decode(self, encoded) -> Tuple[List[np.ndarray], int]:

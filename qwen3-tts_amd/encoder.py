@@ -86,8 +86,9 @@ class CodecEncoderEngine:
         """Qwen3TTSTokenizerV2Model.encode (tokenizer v2:961-991): per row, the first ceil(valid_samples /
         encode_downsample_rate) frames, transposed to (frames, valid_num_quantizers)."""
         codes = self.encode_padded(input_values)
+        lens = padding_mask.detach().to("cpu").numpy().sum(axis=1)      # (numpy: single-threaded -- see codec.py Qwen3TTSTokenizer.encode)
         out = []
-        for c, m in zip(codes, padding_mask):
-            n = -(-int(m.sum()) // self.config.encode_downsample_rate)
+        for c, n_valid in zip(codes, lens):
+            n = -(-int(n_valid) // self.config.encode_downsample_rate)
             out.append(c[..., :n].transpose(0, 1))
         return out
