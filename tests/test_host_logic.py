@@ -853,6 +853,17 @@ def test_lds_dma_kernels_wait_for_their_requests_before_the_barrier(libqtts):
         assert tot >= 1 and bad == 0, (k, tot, bad)
 
 
+def test_product_library_has_no_packed_fp32_math(libqtts):
+    """Round 5 (profiles/r05_packed_fp32_hazard.md): a `v_pk_mul_f32` / `v_pk_fma_f32` sequence returned wrong lanes 48-63 on the MI355X
+    while another stream shared the device; the product library is built with packed fp32 math off.  Pinned from the code objects."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_waits
+    n, names = isa_waits.packed_fp32(os.path.join(ROOT, "qwen3-tts_amd", "libqtts.so"))
+    assert n == 0, (n, names[:5])
+
+
 def test_fused_launches_fit_their_register_shares(libqtts):
     """The admission rule of the fused launches (talker_engine.hip: fused_admit) is an account of the register file: CP_SHARE = 184 registers
     per lane and SIMD for a workgroup of cp_attn_o_kernel / cp_mlp_kernel (4 waves, one per SIMD), CP_SHARE_F32 = 272 for the fp32

@@ -61,6 +61,17 @@ def dma_barriers(lib):
     return out
 
 
+def packed_fp32(lib):
+    """(number of packed fp32 arithmetic instructions, kernels that hold one) in the gfx950 code objects of `lib`.  The product build
+    carries none (build.py FLAGS: -packed-fp32-ops off; profiles/r05_packed_fp32_hazard.md)."""
+    n, names = 0, []
+    for name, ins in kernels(lib).items():
+        c = sum(1 for i in ins if re.match(r"v_pk_(mul|add|fma)_f32\b", i))
+        if c:
+            n += c; names.append(name)
+    return n, names
+
+
 def is_load(ins):
     return ins.startswith(("global_load", "buffer_load", "flat_load"))
 
