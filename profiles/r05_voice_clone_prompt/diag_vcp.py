@@ -1,5 +1,5 @@
 import sys, time, os, gc
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.getcwd())      # (run from the repository root)
 import numpy as np, torch, synth
 from qwen3_tts_amd.codec import Qwen3TTSTokenizer
 from qwen3_tts_amd.speaker import SpeakerEncoderEngine
