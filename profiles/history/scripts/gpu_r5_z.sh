@@ -4,7 +4,7 @@
 # this tree's digest, frac_rocprof), the codec's kernel trace and MFMA-busy counters at 8 x 10 s, config 5 as its own job.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../../..}"
-OUT=gpurun_out/r5z2
+OUT=gpurun_out/r5z
 mkdir -p "$OUT"
 export PYTHONUNBUFFERED=1
 run() { local name=$1 lim=$2; shift 2; local t0=$(date +%s)
