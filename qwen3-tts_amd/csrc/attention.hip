@@ -1421,9 +1421,9 @@ void launch_attn_decode(const AttnDecodeParams& p, hipStream_t st) {
 //     issued at once comes back stale and costs a round trip: third build) and keeps TWO reads in flight ~0.1 us apart (the producers
 //     do not store at the same instant: with single reads the frame time moved 5 % with the delay).  (First build: partial sums +
 //     drained stores + an arrival ticket + last-arriver reduction = 3.2 us of hand-off: what a boundary costs.)
-//   A consumer cannot hang the device: after SPIN_LIMIT re-reads it gives up, raises `err` and writes what it has.  All 256 workgroups
+//   A consumer cannot hang the device: after GRANULE_SPIN_LIMIT re-reads it gives up (cpao_give_up below).  All 256 workgroups
 //   are resident from the start and producers never wait, so there is no circular wait inside a launch; across concurrent launches see
-//   talker_engine.hip (two engines per process take this kernel).
+//   talker_engine.hip: fused_admit (engines are admitted per device by an account of the register file).
 // bf16 cache, two query heads per kv head, head_dim 128, batch <= 8 only; everything else keeps attn_cp + the decode GEMM.
 
 // A consumer that never saw its producers' tag: raise the engine's flag AND latch the generation's stop flag -- every later kernel of

@@ -887,7 +887,7 @@ static int skinny_spw(int N, int fs, bool swiglu) {
 }
 
 // batch <= 8, bf16 x, K a multiple of 512 (whole tile pairs for 8 waves): the frame step's kernel.  QTTS_SKINNY8=0 falls back to
-// skinny2_kernel (A/B; QTTS_ENV: one process can compare both under QTTS_DEBUG_ENV_LIVE=1).
+// skinny2_kernel (A/B; QTTS_ENV: one process compares both through qtts_set_option).
 template <int SPW, int FS, int NP, int NW = 8>
 static void launch8_n(const SkinnyParams& p, hipStream_t st) {
     const int grid = p.N / (FS * SPW);

@@ -289,7 +289,7 @@ struct qtts_talker {
         ++skinny_count;
     }
     int64_t skinny_count = 0;
-    static bool skinny_ablate_or_off() { const char* e = QTTS_ENV("QTTS_SKINNY8"); return e && e[0] == '0'; }   // (A/B switch of skinny.hip; read once unless QTTS_DEBUG_ENV_LIVE)
+    static bool skinny_ablate_or_off() { const char* e = QTTS_ENV("QTTS_SKINNY8"); return e && e[0] == '0'; }   // (A/B switch of skinny.hip, through the option table)
 
     // x-side handling of a GEMM whose input is RMS-normalised: the bf16 kernel takes the row variances on the matrix pipe
     // (skinny.hip) from the producer's bf16 copy of x; the fp32 parity kernel gets the row sums of squares from one extra

@@ -3,7 +3,6 @@
 bf16 Linear shapes of the batch-32 and batch-8 prefill, interleaved in one process (qtts_debug_gemm_tap: a hipGraph chain of 40
 launches, best of 4); TFLOP/s = 2 M N K / time."""
 import os
-os.environ.setdefault("QTTS_DEBUG_ENV_LIVE", "1")
 import ctypes as C, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 SHAPES = [("prefill b32 q|k|v", 2048, 4096, 2048, 0, 0), ("prefill b32 o", 2048, 2048, 2048, 0, 1), ("prefill b32 gate|up", 2048, 12288, 2048, 2, 0),
@@ -20,7 +19,7 @@ for name, M, N, K, act, rs in SHAPES:
     r = {}
     for rep in range(2):
         for mode in ("0", "2"):
-            os.environ["QTTS_GEMM_DMA"] = mode
+            _lib.set_option("QTTS_GEMM_DMA", mode)
             us = C.c_double()
             rc = f(M, N, K, act, rs, 1, 40, 4, C.byref(us))
             assert rc == 0, lib.qtts_last_error()

@@ -18,7 +18,7 @@ def engine_fs(N, K):                                     # talker_engine.hip cho
     while fs > 4 and N // fs < floor: fs //= 2
     return fs
 def run(N, K, M, act, norm, res, wbufs, iters=240, reps=5):
-    os.environ["QTTS_DEBUG_WBUFS"] = str(wbufs); os.environ["QTTS_DEBUG_FS"] = str(engine_fs(N, K))
+    _lib.set_option("QTTS_DEBUG_WBUFS", str(wbufs)); _lib.set_option("QTTS_DEBUG_FS", str(engine_fs(N, K)))
     us = C.c_double()
     rc = f(N, K, M, act, norm, res, 0, iters, reps, C.byref(us))
     assert rc == 0, lib.qtts_last_error()

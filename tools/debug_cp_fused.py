@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth
 from qwen3_tts_amd.talker import TalkerEngine
+from qwen3_tts_amd import _lib
 
 cfg = synth.talker_06b()
 wn = {k: torch.from_numpy(v) for k, v in synth.talker_weights(cfg, with_text=False).items()}
@@ -17,8 +18,8 @@ for B in (3,):
     res = {}
     for name, env in (("plain", {"QTTS_CP_ATTN_O": "0"}), ("attn_o", {"QTTS_CP_FRONT": "0"}), ("front", {})):
         for graph in (False, True):
-            for k in ("QTTS_CP_ATTN_O", "QTTS_CP_FRONT"): os.environ.pop(k, None)
-            os.environ.update(env)
+            for k in ("QTTS_CP_ATTN_O", "QTTS_CP_FRONT"): _lib.set_option(k, None)
+            for k, v in env.items(): _lib.set_option(k, v)
             eng = TalkerEngine(cfg, wn, weight_dtype=torch.bfloat16, device=dev, max_batch=B, max_seq=256, use_graph=graph)
             out = eng.generate(emb, mask, tr, pad, max_new_tokens=7, min_new_tokens=7, do_sample=False, subtalker_dosample=False, suppress_tokens=sup)
             res[(name, graph)] = out.codes.cpu().numpy()
@@ -39,8 +40,8 @@ lens = [int(x) for x in g["lens"]]
 emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
 out = {}
 for flag in ("1", "0"):
-    for k in ("QTTS_CP_ATTN_O", "QTTS_CP_FRONT"): os.environ.pop(k, None)
-    os.environ["QTTS_CP_ATTN_O"] = flag
+    for k in ("QTTS_CP_ATTN_O", "QTTS_CP_FRONT"): _lib.set_option(k, None)
+    _lib.set_option("QTTS_CP_ATTN_O", flag)
     eng = TalkerEngine(cfg, wn, weight_dtype=torch.bfloat16, device=dev, max_batch=3, max_seq=256, use_graph=True)
     kw = dict(max_new_tokens=21, min_new_tokens=21, do_sample=False, subtalker_dosample=False, suppress_tokens=sup)
     out[flag] = [eng.generate(emb[:3], mask[:3], tr[:3], pad, **kw).codes.cpu().numpy() for _ in range(2)]

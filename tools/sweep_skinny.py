@@ -10,7 +10,7 @@ torch.zeros(1).cuda()
 f = lib.qtts_debug_skinny_chain
 f.argtypes = [C.c_int32] * 9 + [C.POINTER(C.c_double)]; f.restype = C.c_int
 def run(N, K, M, act=0, norm=0, res=1, abl=0, fs=0, temporal=0, iters=200, reps=5):
-    os.environ["QTTS_DEBUG_FS"] = str(fs); os.environ["QTTS_CP_TEMPORAL"] = str(temporal)
+    _lib.set_option("QTTS_DEBUG_FS", str(fs)); _lib.set_option("QTTS_CP_TEMPORAL", str(temporal))
     us = C.c_double()
     rc = f(N, K, M, act, norm, res, abl, iters, reps, C.byref(us))
     assert rc == 0, lib.qtts_last_error()

@@ -25,7 +25,7 @@ def engine_fs(N, K):
     while fs > 4 and N // fs < floor: fs //= 2
     return fs
 def run(N, K, act, norm, res, wbufs, iters=120):
-    os.environ["QTTS_DEBUG_WBUFS"] = str(wbufs); os.environ["QTTS_DEBUG_FS"] = str(engine_fs(N, K))
+    _lib.set_option("QTTS_DEBUG_WBUFS", str(wbufs)); _lib.set_option("QTTS_DEBUG_FS", str(engine_fs(N, K)))
     us = C.c_double()
     drain()
     assert f(N, K, 8, act, norm, res, 0, iters, 1, C.byref(us)) == 0, lib.qtts_last_error()
