@@ -25,6 +25,7 @@ CONFIGS = {
     "mlp_b24_c32": {"QTTS_CP_MLP_PAUSE_C": "32"}, "mlp_b28_c28": {"QTTS_CP_MLP_PAUSE_B": "28", "QTTS_CP_MLP_PAUSE_C": "28"},
     "mlp_step2": {"QTTS_CP_MLP_STEP": "2"}, "mlp_step8": {"QTTS_CP_MLP_STEP": "8"},
     "ao_pause20": {"QTTS_CP_ATTN_O_PAUSE": "20"}, "ao_pause24": {"QTTS_CP_ATTN_O_PAUSE": "24"}, "ao_pause12": {"QTTS_CP_ATTN_O_PAUSE": "12"},
+    "ao_step2": {"QTTS_CP_ATTN_O_STEP": "2"}, "ao_step6": {"QTTS_CP_ATTN_O_STEP": "6"}, "ao_step8": {"QTTS_CP_ATTN_O_STEP": "8"},
     "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
     "skinny8_nw4": {"QTTS_SKINNY8_NW": "4"},
 }
