@@ -508,15 +508,16 @@ def _icl_golden(dev, golden_dir, fused_f32):
     assert st["cp_mlp_per_step"] == want and st["cp_fused_per_step"] == want and st["cp_fused_giveups"] == 0, st
 
 
-@pytest.mark.parametrize("name", ["talker_06b", "talker_17b", "talker_06b_b8", "talker_17b_base_icl_b8", "talker_06b_long"])
+@pytest.mark.parametrize("name", ["talker_06b", "talker_17b", "talker_06b_b8", "talker_17b_b8", "talker_17b_base_icl_b8", "talker_06b_long"])
 def test_fused_launches_fp32_instantiations_bit_exact_vs_reference_golden(dev, golden_dir, name):
     """the fused construction's bit-exact leg.  `cp_attn_o_kernel<.., .., true>` and `cp_mlp_kernel<true, ...>` -- the kernel
     sources of the bf16 frame step's two fused launches (q|k|v strips handed over as granules, attention, o-projection split over k by kv
     head and summed in kv-head order; gate|up / SwiGLU / down with the intermediate vector sliced by XCD and the partial sums added in XCD
     order) instantiated with fp32 operators, rows, cache and intermediate vector -- run EVERY launch of the code predictor's passes >= 1 of
     an fp32 engine (QTTS_CP_ATTN_O_F32=1, QTTS_CP_MLP_F32=1; `cp_fused_per_step` and `cp_mlp_per_step` say they did), greedy, against the
-    reference's CPU goldens at batch <= 8: every codebook index of every frame -- 1 / 3 / 8 utterances at 0.6B and 1.7B dims, the 8 Base
-    voice-clone ICL requests through the wrapper, the 820-frame utterance."""
+    reference's CPU goldens at batch <= 8: every codebook index of every frame -- 1 / 3 / 8 utterances at 0.6B and 1.7B dims (`talker_17b_b8`:
+    THE METRIC CONFIG, 1.7B x batch 8 x 125 frames with bench.py's prompts), the 8 Base voice-clone ICL requests through the wrapper, the
+    820-frame utterance."""
     with _qlib.options(QTTS_CP_MLP_F32="1", QTTS_CP_ATTN_O_F32="1"):
         if name == "talker_17b_base_icl_b8":
             _icl_golden(dev, golden_dir, True)
