@@ -45,8 +45,9 @@ const char* qtts_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: + qtts_talker_text_embed, qtts_talker_assemble_rows;
  * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
  * 6: + qtts_talker_stream_*; 7: + qtts_talker_set_teacher; 8: + qtts_talker_set_profile / get_gemm_profile;
- * 9: + qtts_codec_get_stats; 10: + qtts_set_option / qtts_get_option, qtts_talker_stats grew the fused-launch fields). */
-#define QTTS_ABI_VERSION 10
+ * 9: + qtts_codec_get_stats; 10: + qtts_set_option / qtts_get_option, qtts_talker_stats grew the fused-launch fields;
+ * 11: + qtts_talker_debug_cp_logits). */
+#define QTTS_ABI_VERSION 11
 int qtts_abi_version(void);
 
 /* A/B switches of the library (measuring tools and tests; a deployment sets none).  Every switch has a name of the form
@@ -378,6 +379,10 @@ int qtts_talker_stream_end(qtts_talker* t, int64_t* tokens_dev, int32_t* n_frame
 
 /* Test/diagnostic hooks (device -> caller device buffers, after prefill / a generate call). */
 int qtts_talker_debug_logits(qtts_talker* t, float* logits_dev /* (B, vocab) */, void* stream);
+/* The code predictor's RAW logits of the last frame step that ran, every pass: what `code_predictor.generate`'s lm_head[j] returned
+ * before HF's processors (modeling_qwen3_tts.py:1250-1312; the sampled path is checked against the processed softmax of exactly
+ * these numbers, tests/test_gpu_parity.py).  The frame step keeps one row block per pass, so nothing is added to it.  ABI v11. */
+int qtts_talker_debug_cp_logits(qtts_talker* t, float* logits_dev /* (num_code_groups - 1, B, cp_vocab) */, void* stream);
 
 /* Per-call statistics of the last generate (for bench.py): kernel-side byte model inputs. */
 typedef struct {

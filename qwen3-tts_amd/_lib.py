@@ -82,7 +82,7 @@ class GemmClassC(C.Structure):
                 ("min_us", C.c_double), ("max_us", C.c_double), ("bytes_per_launch", C.c_double)]
 
 
-ABI_VERSION = 10          # include/qtts.h; bumped on any signature change
+ABI_VERSION = 11          # include/qtts.h; bumped on any signature change
 
 # every symbol include/qtts.h declares (checked by tests/test_host_logic.py::test_abi_exports_every_declared_symbol without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_set_option", "qtts_get_option", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",
@@ -95,7 +95,7 @@ SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_set_option", "qtts_get_o
            "qtts_talker_create", "qtts_talker_destroy", "qtts_talker_bind", "qtts_talker_finalize",
            "qtts_talker_text_projection", "qtts_talker_text_embed", "qtts_talker_assemble_rows", "qtts_talker_prefill",
            "qtts_talker_generate", "qtts_talker_stream_begin", "qtts_talker_stream_step", "qtts_talker_stream_end",
-           "qtts_talker_debug_logits", "qtts_talker_get_stats", "qtts_talker_get_gemm_profile", "qtts_talker_set_teacher",
+           "qtts_talker_debug_logits", "qtts_talker_debug_cp_logits", "qtts_talker_get_stats", "qtts_talker_get_gemm_profile", "qtts_talker_set_teacher",
            "qtts_talker_set_profile"]
 
 
@@ -181,6 +181,7 @@ def load_library():
     lib.qtts_talker_stream_step.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), vp]
     lib.qtts_talker_stream_end.argtypes = [vp, vp, C.POINTER(C.c_int32), vp]
     lib.qtts_talker_debug_logits.argtypes = [vp, f32p, vp]
+    lib.qtts_talker_debug_cp_logits.argtypes = [vp, f32p, vp]
     lib.qtts_talker_get_stats.argtypes = [vp, C.POINTER(TalkerStatsC)]
     lib.qtts_talker_get_gemm_profile.argtypes = [vp, C.POINTER(GemmClassC), i32, C.POINTER(C.c_int32)]
     lib.qtts_talker_set_teacher.argtypes = [vp, vp, i32, vp, vp, vp]
@@ -198,26 +199,41 @@ def load_library():
 def set_option(name: str, value=None, lib=None) -> None:
     """An A/B switch of the library through its C ABI (include/qtts.h qtts_set_option): measuring tools and tests only.
     value None removes the override (the switch falls back to the environment variable of the same name, then to its default)."""
+    key = (id(lib) if lib is not None else 0, name)
     lib = lib or load_library()
     lib.qtts_set_option.argtypes = [C.c_char_p, C.c_char_p]
     check(lib.qtts_set_option(name.encode(), None if value is None else str(value).encode()))
+    if value is None:
+        _OVERRIDES.pop(key, None)
+    else:
+        _OVERRIDES[key] = str(value)
+
+
+def get_override(name: str, lib=None):
+    """The value `set_option` last gave the switch, or None when it has no override (the environment's value is not an override)."""
+    return _OVERRIDES.get((id(lib) if lib is not None else 0, name))
+
+
+_OVERRIDES = {}          # (library, name) -> the override in force: the C table answers "override or environment", this says which
 
 
 class options:
-    """`with _lib.options(QTTS_SKINNY8="0"): ...` -- switches set for the block and removed after it.  Engine-level switches are copied
-    into an engine when it is CREATED: build the engine inside the block."""
+    """`with _lib.options(QTTS_SKINNY8="0"): ...` -- switches set for the block; on exit every switch goes back to the override it had
+    BEFORE the block (or to none), so blocks nest.  The table is process-global: do not open blocks from concurrent threads.
+    Engine-level switches are copied into an engine when it is CREATED: build the engine inside the block."""
 
     def __init__(self, lib=None, **kw):
-        self.lib, self.kw = lib, kw
+        self.lib, self.kw, self.prev = lib, kw, {}
 
     def __enter__(self):
         for k, v in self.kw.items():
+            self.prev[k] = get_override(k, self.lib)
             set_option(k, v, self.lib)
         return self
 
     def __exit__(self, *exc):
-        for k in self.kw:
-            set_option(k, None, self.lib)
+        for k in reversed(list(self.kw)):
+            set_option(k, self.prev.get(k), self.lib)
         return False
 
 

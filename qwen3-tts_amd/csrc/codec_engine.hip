@@ -907,7 +907,18 @@ namespace {
 struct OptTable {
     std::mutex m;
     std::map<std::string, std::string> kv;
+    // the environment's value of a switch AS IT WAS WHEN THE LIBRARY FIRST LOOKED (include/qtts.h): one getenv per name for the life of the
+    // process, under the table's lock -- later lookups never touch the environment again (a putenv from another thread cannot race a launch)
+    std::map<std::string, std::pair<bool, std::string>> env;
     std::atomic<unsigned> gen{1};
+    const std::pair<bool, std::string>& env_once(const char* var) {          // (caller holds m)
+        auto it = env.find(var);
+        if (it == env.end()) {
+            const char* e = getenv(var);
+            it = env.emplace(var, std::make_pair(e != nullptr, std::string(e ? e : ""))).first;
+        }
+        return it->second;
+    }
 };
 OptTable& opt_table() { static OptTable t; return t; }
 }  // namespace
@@ -928,8 +939,11 @@ const char* opt_lookup(const char* var, unsigned& gen_seen, std::string& cache, 
         std::lock_guard<std::mutex> lk(t.m);
         auto it = t.kv.find(var);
         if (it != t.kv.end()) { cache = it->second; has = true; }
-        else if (const char* e = getenv(var)) { cache = e; has = true; }
-        else { cache.clear(); has = false; }
+        else {
+            const auto& e = t.env_once(var);
+            if (e.first) { cache = e.second; has = true; }
+            else { cache.clear(); has = false; }
+        }
         gen_seen = t.gen.load(std::memory_order_relaxed);
     }
     return has ? cache.c_str() : nullptr;
@@ -958,13 +972,20 @@ int qtts_set_option(const char* name, const char* value) {
     QTTS_API_END
 }
 int qtts_get_option(const char* name, char* buf, int32_t cap) {
+    bool set = false;
+    try {                                    // (nothing may cross the C ABI: the map lookups allocate)
         if (!name || !buf || cap < 1) { qtts::set_last_error("get_option: null argument"); return QTTS_ERR_ARG; }
-    auto& t = qtts::opt_table();
-    std::lock_guard<std::mutex> lk(t.m);
-    auto it = t.kv.find(name);
-    const char* v = it != t.kv.end() ? it->second.c_str() : getenv(name);
-    snprintf(buf, (size_t)cap, "%s", v ? v : "");
-    return v ? QTTS_OK : 1;
+        auto& t = qtts::opt_table();
+        std::lock_guard<std::mutex> lk(t.m);
+        auto it = t.kv.find(name);
+        const char* v = nullptr;
+        if (it != t.kv.end()) v = it->second.c_str();
+        else { const auto& e = t.env_once(name); if (e.first) v = e.second.c_str(); }
+        snprintf(buf, (size_t)cap, "%s", v ? v : "");
+        set = v != nullptr;
+    }
+    catch (const std::exception& e) { qtts::set_last_error(e.what()); return QTTS_ERR_ARG; }
+    return set ? QTTS_OK : 1;
 }
 
 int qtts_codec_create(const qtts_codec_config* cfg, qtts_codec** out) {

@@ -2,9 +2,12 @@
 // Every value travels as an 8-byte granule {32-bit payload, launch tag}, stored write-through (sc1) and read with sc1 loads until it
 // carries the tag of the running launch: no ticket, no fence, and a consumer can tell a stale granule from a fresh one by the tag alone.
 // Tag = (frame serial << 7 | launch slot) -- nobody in the launch writes the word it derives from, and the launches that wrote the same
-// buffer before had another (serial, slot) pair.  Bit 31 is never set in a tag (the serial stays below 2^24): a granule stored under
-// tag | GRANULE_POISON is fresh for nobody (what a workgroup that gave up hands on).
-// A consumer cannot hang the device: after GRANULE_SPIN_LIMIT re-reads it gives up (talker_engine.hip: the give-up latch).
+// buffer before had another (serial, slot) pair (the engine keeps slot = position * layers + layer below 128 and refuses the fused
+// launches for a code predictor with more than CP_FUSED_MAX_LAYERS layers: talker_engine.hip).
+// A consumer cannot hang the device: after GRANULE_SPIN_LIMIT re-reads it gives up -- it raises the engine's flag and latches the
+// generation's stop flag (talker_engine.hip: the give-up latch).  What a workgroup that gave up still publishes carries a VALID tag and
+// is garbage; nothing consumes it: every later kernel of the chain returns at its `done` check, the host call fails with
+// QTTS_ERR_STATE and the Python wrappers re-run the request once on the separate launches (talker.py: TalkerEngine.generate).
 #pragma once
 #include "common.h"
 
@@ -33,5 +36,4 @@ __device__ __forceinline__ uint2 wt_load8(const WtBuf& b, int off) {
 __device__ __forceinline__ void wt_first_pause(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }        // n x 64 clocks (16 ~ 0.4 us)
 constexpr int GRANULE_SPIN_LIMIT = 1 << 18;                // ~0.3 s of re-reads: a producer that never stores is a bug, not a wait
 #endif
-constexpr unsigned GRANULE_POISON = 0x80000000u;
 }  // namespace qtts

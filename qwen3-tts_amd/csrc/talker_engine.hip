@@ -318,7 +318,7 @@ struct qtts_talker {
                       bool last_layer = true) {
         // the MLP of this call as ONE launch (cp_mlp.hip): code predictor passes >= 1 at batch <= 8 of an engine that holds a place of its device's account
         const bool mlp_fusable = cp_mlp_env && cp_fused_slot && L.gu_mlp.p && mlp_act.p && !skinny_only && !len_dev && n_new == 1 && len_static >= 1 &&
-                                 cp_mlp_takes(M, d.H, d.I) && len_static * 5 + layer < 128 && (!bf16 || (xs16 && skinny_takes_bf16_x(M, d.H, true)));
+                                 cp_mlp_takes(M, d.H, d.I) && layer < CP_FUSED_MAX_LAYERS && len_static * CP_FUSED_MAX_LAYERS + layer < 128 && (!bf16 || (xs16 && skinny_takes_bf16_x(M, d.H, true)));
         // (fp32: a layer whose MLP is fused keeps its o-projection whole -- the fused launch reads complete rows and writes complete rows)
         const bool splitk = !bf16 && !mlp_fusable && sk_part.p && M <= 8 && skinny_f32_splitk_takes(M, d.qd, d.H) && skinny_f32_splitk_takes(M, d.I, d.H);
         if (layer == 0 || !splitk) sk_pending = false;
@@ -347,8 +347,8 @@ struct qtts_talker {
         // GEMM of its own (layers >= 1: layer 0's row comes from the table), that GEMM in front of them in the same launch
         // (fp32 engines, on request: the F32 instantiation on the fp32 decode GEMM's own packed operators, only in front of a fused MLP)
         const void* wo_fused = bf16 ? L.o_p16.p : (L.fs_o == 16 ? L.o_p.p : nullptr);
-        const bool fuse_ao = cp_attn_o_env && wo_fused && ao_part.p && (bf16 ? att16 : mlp_fusable) && !skinny_only && cp_attn_o_takes(a, d.H) && layer < 5 &&
-                             len_static * 5 + layer < 128;
+        const bool fuse_ao = cp_attn_o_env && wo_fused && ao_part.p && (bf16 ? att16 : mlp_fusable) && !skinny_only && cp_attn_o_takes(a, d.H) && layer < CP_FUSED_MAX_LAYERS &&
+                             len_static * CP_FUSED_MAX_LAYERS + layer < 128;
         const bool front = fuse_ao && !skip_qkv && (h16 || !bf16) && cp_front_env && d.H == 1024 && a.ld == 4 * 8 * (d.H / 128) * 16;
         if (!skip_qkv && !front) {        // otherwise the previous pass's sampler gathered this row of qkvb from the table
             if (splitk && sk_pending) {    // the previous layer's down-projection left (residual + half 0, half 1): added on the way in
@@ -361,7 +361,7 @@ struct qtts_talker {
         if (fuse_ao) {
             CpAttnOParams f{};
             f.a = a; f.Wo = wo_fused; f.res = xs; f.out = xs; f.out16 = h16 ? xs16 : nullptr;
-            f.part = ao_part.as<float>(); f.serial = ss.frame_serial; f.slot = len_static * 5 + layer; f.phase = 2;
+            f.part = ao_part.as<float>(); f.serial = ss.frame_serial; f.slot = len_static * CP_FUSED_MAX_LAYERS + layer; f.phase = 2;
             f.err = ss.n_generated + 5; f.done_latch = ss.done; f.H = d.H; f.first_pause = cp_attn_o_pause; f.poll_step = cp_attn_o_step;
             if (front) {
                 f.Wqkv = L.qkv_p.p; f.x16 = bf16 ? xs16 : reinterpret_cast<const unsigned short*>(xs); f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = ao_qkv.as<float>();
@@ -395,7 +395,7 @@ struct qtts_talker {
             m.f32 = bf16 ? 0 : 1;
             m.Wgu = L.gu_mlp.p; m.Wd = bf16 ? L.d_p16.p : L.d_p.p; m.x16 = bf16 ? xs16 : reinterpret_cast<const unsigned short*>(xs); m.ldx16 = d.H; m.eps = d.eps;
             m.res = xs; m.out = xs; m.out16 = bf16 ? xs16 : nullptr;
-            m.act_gran = mlp_act.as<float>(); m.part = mlp_part.as<float>(); m.serial = ss.frame_serial; m.slot = len_static * 5 + layer; m.phase = 3;
+            m.act_gran = mlp_act.as<float>(); m.part = mlp_part.as<float>(); m.serial = ss.frame_serial; m.slot = len_static * CP_FUSED_MAX_LAYERS + layer; m.phase = 3;
             m.err = ss.n_generated + 5; m.done_latch = ss.done; m.done_flag = ss.done; m.first_pause = cp_attn_o_pause; m.poll_step = cp_attn_o_step;
             m.B = M; m.H = d.H; m.I = d.I; m.wd_early = cp_mlp_wd_early;
             m.first_pause = cp_mlp_pause_b; m.pause_c = cp_mlp_pause_c; m.poll_step = cp_mlp_step;
@@ -515,6 +515,11 @@ struct qtts_talker {
     // is another PROCESS on the same device: a consumer that loses its producers there gives up after ~0.3 s, latches the stop flag (one
     // give-up per generation, not per launch), the call fails with QTTS_ERR_STATE and the engine leaves the fused launches for good
     // (`fused_retire`): the caller's retry runs on the separate launches.
+    // The launch tag's slot = position * CP_FUSED_MAX_LAYERS + layer must be unique among the launches of a frame that write one granule
+    // buffer: a code predictor with more layers than this (the reference's default and every released checkpoint have 5;
+    // configuration_qwen3_tts.py:370-454) keeps the separate launches -- finalize() switches both fused launches off (layer 5 of
+    // pass L would otherwise share its tag with layer 0 of pass L + 1 and a consumer could take a stale granule as fresh).
+    static constexpr int CP_FUSED_MAX_LAYERS = 5;
     static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 272;     // (fp32 engines: the F32 instantiations hold twice the operand registers -- one engine per device)
     struct FusedRegistry { std::mutex m; std::map<int, std::pair<int, int>> dev; };        // device -> (share in use, fused engines)
     static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
@@ -575,6 +580,7 @@ void qtts_talker::finalize() {
     QTTS_REQUIRE(c.max_batch >= 1 && c.max_batch <= 32, QTTS_ERR_LIMIT, "max_batch must be 1..32");
     QTTS_REQUIRE(td.I % 16 == 0 && cd.I % 16 == 0, QTTS_ERR_ARG, "intermediate sizes % 16");
     const int G = c.num_code_groups;
+    if (c.cp_num_hidden_layers > CP_FUSED_MAX_LAYERS) { cp_mlp_env = false; cp_attn_o_env = false; }     // (tag uniqueness, see CP_FUSED_MAX_LAYERS)
     if (!cp_mlp_instantiated(cd.H, cd.I, bf16) || c.max_batch > 8) cp_mlp_env = false;
     // fp32 engines (the exact parity mode) take the fused MLP launch only on request (QTTS_CP_MLP_F32=1): cp_mlp_kernel<true, ...> is the fused
     // construction's bit-exact leg (tests/test_gpu_parity.py runs the reference goldens through it), but with fp32 operators the MLP is
@@ -713,7 +719,7 @@ void qtts_talker::finalize() {
     x.alloc((size_t)R * td.H * 4); qkv.alloc((size_t)R * (td.qd + 2 * td.kvd) * 4); att.alloc((size_t)R * td.qd * 4);
     act.alloc((size_t)R * td.I * 4); logits.alloc((size_t)R * c.vocab_size * 4); past_hidden.alloc((size_t)R * td.H * 4);
     cp_in.alloc((size_t)R * td.H * 4); cp_x.alloc((size_t)R * cd.H * 4); cp_qkv.alloc((size_t)R * (cd.qd + 2 * cd.kvd) * 4);
-    cp_att.alloc((size_t)R * cd.qd * 4); cp_act.alloc((size_t)R * cd.I * 4); cp_logits.alloc((size_t)R * c.cp_vocab_size * 4);
+    cp_att.alloc((size_t)R * cd.qd * 4); cp_act.alloc((size_t)R * cd.I * 4); cp_logits.alloc((size_t)(c.num_code_groups - 1) * R * c.cp_vocab_size * 4);     // [pass][row][cp vocab]: every pass keeps its own rows (qtts_talker_debug_cp_logits)
     cur_tok.alloc(R * 4); sub.alloc((size_t)R * G * 4); ss_rows.alloc(64 * 8); ints.alloc(64 * 4 + R * 4);
     if (!bf16) {                      // the two halves of a split-K o- / down-projection (decode_layer)
         const size_t hmax = (size_t)std::max(td.H, cd.H);
@@ -905,11 +911,11 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
         lh.done_flag = ss.done;
         const int off = (n_new - 1) * B;
         lh.x = cp_x.as<float>() + (size_t)off * cd.H; lh.ldx = cd.H; lh.M = B; lh.Wp = lm_head_p[j].p; lh.N = c.cp_vocab_size;
-        lh.K = cd.H; lh.out = cp_logits.as<float>(); lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE; lh.fs = fs_lm;
+        lh.K = cd.H; lh.out = cp_logits.as<float>() + (size_t)j * 64 * c.cp_vocab_size; lh.ldo = c.cp_vocab_size; lh.act = ACT_NONE; lh.fs = fs_lm;
         norm_input(lh, cd, (c16 && skinny_takes_bf16_x(M, cd.H, bf16)) ? c16 + (size_t)off * cd.H : nullptr, st);
         skinny(lh, st);
         SampleParams s{};
-        s.logits = cp_logits.as<float>(); s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
+        s.logits = cp_logits.as<float>() + (size_t)j * 64 * c.cp_vocab_size; s.ld = c.cp_vocab_size; s.V = c.cp_vocab_size; s.B = B;
         s.repetition_penalty = 1.0f; s.eos = -1; s.do_sample = sp.subtalker_dosample; s.top_k = sp.subtalker_top_k;
         s.top_p = sp.subtalker_top_p; s.temperature = sp.subtalker_temperature; s.seed = sp.seed; s.stream_id = 1 + j;
         s.seed_dev = seed_d.as<unsigned long long>();
@@ -1335,6 +1341,15 @@ int qtts_talker_debug_logits(qtts_talker* t, float* logits_dev, void* stream) {
     QTTS_REQUIRE(t && logits_dev, QTTS_ERR_ARG, "null argument");
     QTTS_CHECK_HIP(hipMemcpyAsync(logits_dev, t->logits.p, (size_t)t->B * t->cfg.vocab_size * 4, hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream));
+    QTTS_API_END
+}
+int qtts_talker_debug_cp_logits(qtts_talker* t, float* logits_dev, void* stream) {
+    QTTS_API_BEGIN
+    QTTS_REQUIRE(t && logits_dev, QTTS_ERR_ARG, "null argument");
+    const size_t Vc = (size_t)t->cfg.cp_vocab_size;
+    for (int j = 0; j < t->cfg.num_code_groups - 1; ++j)       // (the engine's rows are [pass][64 rows][cp vocab])
+        QTTS_CHECK_HIP(hipMemcpyAsync(logits_dev + (size_t)j * t->B * Vc, t->cp_logits.as<float>() + (size_t)j * 64 * Vc, (size_t)t->B * Vc * 4,
+                                      hipMemcpyDeviceToDevice, (hipStream_t)stream));
     QTTS_API_END
 }
 // DIAGNOSTIC (not in include/qtts.h): which XCD runs workgroup i of a launch?  (cp_mlp.hip slices its exchange by `blockIdx % 8`.)

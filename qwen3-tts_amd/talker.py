@@ -227,7 +227,25 @@ class TalkerEngine:
         return out
 
     @_lib.locked
-    def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, trailing_text_hidden: torch.Tensor,
+    def generate(self, *args, **kw) -> TalkerGenerateOutput:
+        """Seam S2 (`talker.generate`, M:2272): see `_generate_once` for the arguments.  One thing is added around it: a generation
+        that ended on the fused launches' give-up flag (a consumer workgroup lost its producers -- another PROCESS on the device took
+        the compute units; csrc/talker_engine.hip: check_fused_flag) has produced nothing the caller saw, and the engine has left the
+        fused launches for good, so the request is re-run ONCE here on the separate launches instead of surfacing a bare error.
+        (`generate_stream` cannot do that after it has yielded packets: there the error reaches the caller, whose retry runs on the
+        separate launches.)"""
+        giveups = self.stats()["cp_fused_giveups"]
+        try:
+            return self._generate_once(*args, **kw)
+        except _lib.QttsError:
+            if self.stats()["cp_fused_giveups"] <= giveups:
+                raise
+            import warnings
+            warnings.warn("a fused code-predictor launch gave up waiting for its producers (device shared with another process?); "
+                          "this engine now runs the separate launches and the request is re-run once")
+            return self._generate_once(*args, **kw)
+
+    def _generate_once(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, trailing_text_hidden: torch.Tensor,
                  tts_pad_embed: torch.Tensor, max_new_tokens: int = 2048, min_new_tokens: int = 2,
                  do_sample: bool = True, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,
                  temperature: Optional[float] = 0.9, subtalker_dosample: bool = True,
@@ -412,5 +430,14 @@ class TalkerEngine:
         out = torch.empty(self.max_batch, self.config.vocab_size, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.qtts_talker_debug_logits(self._h, C.c_void_p(out.data_ptr()), self._s()))
+            self._stream.synchronize()
+        return out
+
+    @_lib.locked
+    def debug_cp_logits(self) -> torch.Tensor:
+        """(num_code_groups - 1, max_batch, cp_vocab): the code predictor's raw logits of the last frame step that ran, every pass."""
+        out = torch.empty(self.config.num_code_groups - 1, self.max_batch, self.config.cp_vocab_size, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.qtts_talker_debug_cp_logits(self._h, C.c_void_p(out.data_ptr()), self._s()))
             self._stream.synchronize()
         return out

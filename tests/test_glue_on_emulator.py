@@ -131,3 +131,24 @@ def test_codec_graph_replay_python_path(glue):
     """`CodecDecoderEngine.decode_padded` called repeatedly on the same buffers + `stats()`: the GPU test body on the emulator (whether a
     call hits the graph cache depends on the allocator handing the output block back; both outcomes are checked for equal results)."""
     glue.test_codec_decode_calls_replay_as_graphs_on_the_gpu("cpu")
+
+
+def test_sampled_path_body_on_the_emulator(glue):
+    """The GPU suite's sampled-path test body (`_sampled_path_body`: the engine's own raw logits -> the oracle's HF processors ->
+    rank-bucket chi-square + the per-draw check that u = Philox(seed; step, row, stream) falls into the token's inverse-CDF interval in
+    the kernel's candidate order) on the emulator: a bf16 engine through the captured frame graph with both fused launches, a talker
+    vocabulary of 2304 (`sample_kernel_v2<12>`) and a code-predictor vocabulary of 256 (`<8>`), a few seeds.  What it pins here is the
+    body itself -- the Philox restatement, the counter layout (the code predictor's samplers read the same step counter as the talker's),
+    the slot order -- so that the 2000-seed run on the MI355X starts from a checked test; the draw-by-draw check is exact at any seed count."""
+    import dataclasses
+    import synth
+    t = dataclasses.replace(synth.talker_tiny(), vocab_size=2304, num_code_groups=4, cp_hidden_size=256, cp_intermediate_size=1024,
+                            cp_num_hidden_layers=2, cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = glue._td(synth.talker_weights(t, with_text=False))
+    fused = t.cp_num_hidden_layers * (t.num_code_groups - 2)
+    ev = glue._sampled_path_body("cpu", t, w, torch.bfloat16, True, 5, 3, 3, fused)
+    assert ev["draws"] >= 5 * 3 * t.num_code_groups - 12 and ev["worst_u_gap"] <= 2e-5
+    ev1 = glue._sampled_path_body("cpu", t, w, torch.bfloat16, True, 4, 3, 3, fused, rep=1.5)
+    assert ev1["worst_u_gap"] <= 2e-5
+    ev0 = glue._sampled_path_body("cpu", t, w, torch.float32, False, 4, 1, 3, None)
+    assert ev0["draws"] == 12

@@ -1002,6 +1002,181 @@ def test_code_predictor_sampling_distribution_matches_hf(talker_tiny, dev):
         print(f"code-predictor sampling row {b}: chi2 {c0:.1f} (sub-code 0, {N} draws), {c1:.1f} (sub-code 1 | {v0[b]}, {int(sel.sum())} draws)")
 
 
+# ---- the sampled path AT THE SHAPE THE BENCH RUNS: V = 3072 / 2048, top-k 50, T 0.9, rep 1.05, bf16, graph, fused
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al. 2011, the published constants) on numpy uint64 arrays holding 32-bit words: the counter-based
+    generator csrc/sampling.hip keys by (seed; token step, row, stream) -- restated here so a test can say WHICH uniform a draw used."""
+    M0, M1, W0, W1, MASK = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    c0, c1, c2, c3, k0, k1 = (np.asarray(a, np.uint64) & np.uint64(MASK) for a in (c0, c1, c2, c3, k0, k1))
+    for _ in range(10):
+        p0, p1 = c0 * np.uint64(M0), c2 * np.uint64(M1)
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & np.uint64(MASK), p1 >> np.uint64(32), p1 & np.uint64(MASK)
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + np.uint64(W0)) & np.uint64(MASK), (k1 + np.uint64(W1)) & np.uint64(MASK)
+    return c0, c1, c2, c3
+
+
+def _sampler_slot_order(V):
+    """The order in which sample_kernel_v2 lays its candidates out for the inverse-CDF scan (csrc/sampling.hip, step 3: "(wave, slice,
+    lane)"): thread tid of 256 holds logits v = it * 256 + tid; wave = tid / 64."""
+    v = np.arange(V)
+    return v[np.lexsort((v % 64, v // 256, (v % 256) // 64))]
+
+
+class _RankBuckets:
+    """Order-free distribution check over draws that each have THEIR OWN expected distribution (the histories differ per seed): the
+    observed token's rank in its processed softmax, pooled over draws; the expected count of rank r = the sum of the draws' r-th
+    largest probabilities.  Keeps 64 numbers per draw, not the distribution."""
+    NB = 64
+
+    def __init__(self, what):
+        self.what, self.e, self.o, self.n = what, np.zeros(self.NB), np.zeros(self.NB), 0
+
+    def add(self, P, tok):
+        n = P.shape[0]
+        if n == 0:
+            return
+        assert (P[np.arange(n), tok] > 0).all(), f"{self.what}: sampled a token outside HF's processed support"
+        order = np.argsort(-P, axis=1, kind="stable")[:, :self.NB]
+        rank = (order == tok[:, None]).argmax(1)
+        assert (order[np.arange(n), rank] == tok).all(), f"{self.what}: a sampled token ranks below {self.NB}: outside any top-k 50 support"
+        self.e += np.take_along_axis(P, order, 1).sum(0)
+        self.o += np.bincount(rank, minlength=self.NB)
+        self.n += n
+
+    def check(self):
+        e, o = self.e, self.o
+        small = e < 5.0
+        if small.sum() > 1:
+            e, o = np.append(e[~small], e[small].sum()), np.append(o[~small], o[small].sum())
+        keep = e > 0
+        e, o = e[keep], o[keep]
+        chi2, dof = float((((o - e) ** 2) / e).sum()), len(e) - 1
+        assert chi2 < dof + 5.0 * np.sqrt(2.0 * max(dof, 1)) + 10.0, f"{self.what}: chi-square {chi2:.1f} with {dof} dof over {self.n} draws"
+        return round(chi2, 1), dof, self.n
+
+
+def _u_gap(p, so, pos_of, rows, tok, u):
+    """How far `u` lies outside the inverse-CDF interval of `tok` when the candidates are scanned in the kernel's order (<= 0: inside)."""
+    cdf = np.cumsum(p[rows][:, so], 1)
+    hi = cdf[np.arange(len(rows)), pos_of[tok]]
+    lo = hi - p[rows, tok]
+    return np.maximum(lo - u, u - hi)
+
+
+def _sampled_path_body(dev, t, w, weight_dtype, use_graph, n_seeds, n_tokens, B, expect_fused, rep=1.05, top_k=50, temp=0.9):
+    """Every draw of the LAST token step and of the LAST frame of `n_tokens`-token generations, `n_seeds` Philox seeds x B rows,
+    checked against the engine's OWN raw logits pushed through the oracle's HF processors (talker_ref.process_logits):
+      (1) support: the token is inside HF's processed support;
+      (2) distribution: rank-bucket chi-square per stream (talker token, sub-code 0, sub-code 1, the later sub-codes pooled);
+      (3) WHICH uniform: u = Philox(seed; step, row, stream), restated here, must fall into the token's interval of the inverse CDF in
+          the kernel's candidate order -- for every single draw.  That pins the key / counter layout (the 16 draws of a frame use 16
+          different counters: no shared offset; rows and steps never share one either) AND, draw by draw, the processed distribution
+          itself: an interval moves by more than the tolerance when the penalty, the temperature or the top-k cut is off.
+    Returns the evidence dict."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    G, V, Vc = t.num_code_groups, t.vocab_size, t.cp_vocab_size
+    eng = TalkerEngine(t, w, weight_dtype=weight_dtype, device=dev, max_batch=B, max_seq=64, use_graph=use_graph)
+    lens = [int(x) for x in np.random.default_rng(77).integers(5, 12, B)]
+    args = synth.rand_prompt(np.random.default_rng(78), t, lens, 3, scale=0.5)
+    sup = _suppress(t)
+    kw = dict(max_new_tokens=n_tokens, min_new_tokens=2, do_sample=True, top_k=top_k, top_p=1.0, temperature=temp, subtalker_dosample=True,
+              subtalker_top_k=top_k, subtalker_top_p=1.0, subtalker_temperature=temp, repetition_penalty=rep, suppress_tokens=sup)
+    so_t, so_c = _sampler_slot_order(V), _sampler_slot_order(Vc)
+    pos_t, pos_c = np.argsort(so_t), np.argsort(so_c)
+    rb_t = _RankBuckets(f"talker token at step {n_tokens - 1}")
+    rb_c = {"sub0": _RankBuckets("sub-code 0"), "sub1": _RankBuckets("sub-code 1"), "sub2_14": _RankBuckets("sub-codes 2..14")}
+    worst, worst_nopen, n_draws, hist_hits = -1.0, -1.0, 0, 0
+    TOL = 2e-5                                               # fp32 softmax + scan against the float64 restatement; u has 24 bits
+    step = n_tokens - 1
+    empty = torch.zeros(B, 0, dtype=torch.long)
+    for seed in range(n_seeds):
+        out = eng.generate(*args, seed=seed, **kw)
+        toks = out.tokens.cpu().numpy()
+        if toks.shape[1] < n_tokens:                         # every row sampled EOS early: nothing ran at the last step
+            continue
+        raw = eng.debug_logits()[:B].cpu()
+        pk = dict(eos_id=t.codec_eos_token_id, min_new_tokens=2, suppress=sup, do_sample=True, temperature=temp, top_k=top_k, top_p=1.0)
+        p = torch.softmax(talker_ref.process_logits(raw, torch.from_numpy(toks[:, :step]), repetition_penalty=rep, **pk).double(), -1).numpy()
+        # rows that finished earlier keep receiving EOS whatever was drawn (HF semantics): only live rows carry a draw
+        rows = np.nonzero((toks[:, :step] != t.codec_eos_token_id).all(1))[0]
+        if len(rows) == 0:
+            continue
+        tok = toks[rows, step]
+        rb_t.add(p[rows], tok)
+        c0 = _philox4x32_10(np.full(len(rows), step), rows, 0, 0, seed & 0xFFFFFFFF, seed >> 32)[0]
+        u = (c0 >> np.uint64(8)).astype(np.float64) / 16777216.0
+        worst = max(worst, float(_u_gap(p, so_t, pos_t, rows, tok, u).max()))
+        n_draws += len(rows)
+        if step > 0:
+            hist_hits += int((np.take_along_axis(p[rows], toks[rows, :step], 1) > 0).sum())     # history tokens inside the support: the penalty acts on them
+            if rep != 1.0:                                   # the same draws against "no penalty": the check must be able to tell
+                q = torch.softmax(talker_ref.process_logits(raw, empty, **dict(pk, min_new_tokens=0)).double(), -1).numpy()
+                ok = q[rows, tok] > 0
+                worst_nopen = max(worst_nopen, float(_u_gap(q, so_t, pos_t, rows[ok], tok[ok], u[ok]).max()) if ok.any() else 1.0)
+        if step == 0:
+            continue
+        # ---- the 15 sub-codes of the last frame (frame step - 1; the device's step counter reads `step` while it runs)
+        codes = out.codes.cpu().numpy()
+        cp_raw = eng.debug_cp_logits()[:, :B].cpu()
+        for j in range(G - 1):
+            pj = torch.softmax(talker_ref.process_logits(cp_raw[j], empty, do_sample=True, temperature=temp, top_k=top_k, top_p=1.0).double(), -1).numpy()
+            tk = codes[rows, step - 1, 1 + j]
+            rb_c["sub0" if j == 0 else "sub1" if j == 1 else "sub2_14"].add(pj[rows], tk)
+            c0 = _philox4x32_10(np.full(len(rows), step), rows, 1 + j, 0, seed & 0xFFFFFFFF, seed >> 32)[0]
+            uj = (c0 >> np.uint64(8)).astype(np.float64) / 16777216.0
+            worst = max(worst, float(_u_gap(pj, so_c, pos_c, rows, tk, uj).max()))
+            n_draws += len(rows)
+    st = eng.stats()
+    if expect_fused is not None:
+        assert st["cp_fused_per_step"] == expect_fused and st["cp_mlp_per_step"] == expect_fused and st["cp_fused_giveups"] == 0, st
+    if use_graph and n_tokens > 1:
+        assert st["graph_nodes"] > 0, st
+    assert n_draws > 0
+    assert worst <= TOL, (f"a draw's uniform lies {worst:.2e} outside its token's inverse-CDF interval: the kernel did not use "
+                          f"Philox(seed; step, row, stream) for it (shared offset?) or its processed distribution differs from HF's")
+    ev = {"draws": n_draws, "worst_u_gap": worst, "worst_u_gap_without_penalty": worst_nopen, "history_tokens_in_support": hist_hits,
+          "stats": {k: st[k] for k in ("cp_fused_per_step", "cp_mlp_per_step", "graph_nodes")}, "talker": rb_t.check()}
+    if n_tokens > 1:
+        for name, rb in rb_c.items():
+            if rb.n:
+                ev[name] = rb.check()
+    del eng
+    return ev
+
+
+def test_sampled_path_at_the_benchmarked_shape_distribution_and_philox_keying(dev):
+    """the headline step samples (T 0.9, top-k 50, rep 1.05) with `sample_kernel_v2<12>` on the talker's
+    V = 3072 logits and `sample_kernel_v2<8>` on the code predictor's V = 2048 -- instantiations no distribution test had reached
+    (the older two run vocab 1280 / 256, fp32, eager, first token only).  Here: the REAL vocabulary sizes and the real code-predictor
+    dims (0.6B: hidden 1024, 5 layers, 16 codebooks; the talker keeps its dims and 2 of its 28 layers), a bf16 engine whose frame
+    step is the captured graph with the fused launches (asserted), the reference's defaults incl. suppress [V - 1024, V) \\ {eos} and
+    min_new_tokens 2 (`modeling_qwen3_tts.py:2044-2066`, HF `_sample` + processors), QTTS_TEST_SAMPLER_SEEDS (2000) seeds:
+      (a) the first talker token (empty history, EOS blocked);
+      (b) the talker token at step 4 -- a four-token history the repetition penalty acts on -- and (c) all 15 sub-codes of frame 3;
+      plus (b) with repetition_penalty 1.5, where the test shows its own power: against the expectation WITHOUT the penalty the
+      per-draw check must fail by orders of magnitude."""
+    N = int(os.environ.get("QTTS_TEST_SAMPLER_SEEDS", "2000"))
+    t = synth.talker_06b()
+    t.num_hidden_layers = 2
+    assert t.vocab_size == 3072 and t.cp_vocab_size == 2048           # launch_sample: V <= 2048 -> <8>, 2048 < V <= 3072 -> <12>
+    w = _td(synth.talker_weights(t, with_text=False))
+    fused = 5 * (t.num_code_groups - 2)
+    ev_a = _sampled_path_body(dev, t, w, torch.bfloat16, True, N, 1, 8, None)
+    ev_b = _sampled_path_body(dev, t, w, torch.bfloat16, True, N, 5, 8, fused)
+    assert ev_b["history_tokens_in_support"] > 0, "no history token ever fell inside the top-k support: the penalty was not exercised"
+    print(f"sampled path, bf16 / graph / fused, {N} seeds x 8 rows: sample_kernel_v2<12> (V=3072) first token chi2/dof/n {ev_a['talker']}, "
+          f"step 4 {ev_b['talker']} ({ev_b['history_tokens_in_support']} history tokens inside the support); sample_kernel_v2<8> (V=2048) "
+          f"sub-code 0 {ev_b['sub0']}, 1 {ev_b['sub1']}, 2..14 {ev_b['sub2_14']}; every one of {ev_a['draws'] + ev_b['draws']} draws used "
+          f"u = Philox(seed; step, row, stream) (worst gap {max(ev_a['worst_u_gap'], ev_b['worst_u_gap']):.1e}, against 'no penalty' "
+          f"{ev_b['worst_u_gap_without_penalty']:.1e}); {ev_b['stats']}")
+    assert ev_b["worst_u_gap_without_penalty"] > 1e-3, "the per-draw check cannot tell repetition_penalty 1.05 from none"
+    ev_c = _sampled_path_body(dev, t, w, torch.bfloat16, True, max(100, N // 4), 5, 8, fused, rep=1.5)
+    assert ev_c["worst_u_gap_without_penalty"] > 1e-2
+    print(f"repetition_penalty 1.5: step-4 talker token chi2/dof/n {ev_c['talker']}, {ev_c['history_tokens_in_support']} history tokens inside the "
+          f"support, worst gap {ev_c['worst_u_gap']:.1e} vs {ev_c['worst_u_gap_without_penalty']:.1e} against 'no penalty'")
+
+
 def test_prompt_assembly_and_generate_vs_reference_golden(dev, golden_dir):
     """Seam S1: Qwen3TTSForConditionalGeneration.generate -- prompt assembly (incl. the HIP text_projection) against
     what the reference's generate() hands to talker.generate, then the full generate against the oracle."""

@@ -1173,3 +1173,37 @@ def test_bench_fused_launch_report_accounts_for_the_bytes_that_left_the_decode_g
     line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))["roofline"]
     assert line["weight_bytes_per_frame_model"] - line["weight_bytes_per_frame_timed"] == r["weight_bytes_per_frame"]
     assert bench.fused_cp_report(c, {}) == {}
+
+
+def test_options_blocks_nest_and_restore_the_previous_override(libqtts):
+    """`_lib.options` used to CLEAR its switches on exit, so a nested block dropped the outer block's override.  Now every
+    switch goes back to the override it had before the block (or to none); the C table reads the environment once per name."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import ctypes as C, os, sys
+        sys.path.insert(0, {ROOT!r})
+        os.environ["QTTS_TEST_SWITCH_E"] = "env0"
+        from qwen3_tts_amd import _lib
+        lib = _lib.load_library()
+        def get(n):
+            b = C.create_string_buffer(64)
+            rc = lib.qtts_get_option(n.encode(), b, 64)
+            return (rc, b.value.decode())
+        with _lib.options(QTTS_TEST_SWITCH_N="outer"):
+            assert get("QTTS_TEST_SWITCH_N") == (0, "outer")
+            with _lib.options(QTTS_TEST_SWITCH_N="inner", QTTS_TEST_SWITCH_M="m"):
+                assert get("QTTS_TEST_SWITCH_N") == (0, "inner") and get("QTTS_TEST_SWITCH_M") == (0, "m")
+            assert get("QTTS_TEST_SWITCH_N") == (0, "outer"), "the inner block dropped the outer override"
+            assert get("QTTS_TEST_SWITCH_M")[0] == 1
+        assert get("QTTS_TEST_SWITCH_N")[0] == 1
+        # the environment is looked at ONCE per name: a later change is not seen, an override still wins and falls back to the first value
+        assert get("QTTS_TEST_SWITCH_E") == (0, "env0")
+        os.environ["QTTS_TEST_SWITCH_E"] = "env1"
+        assert get("QTTS_TEST_SWITCH_E") == (0, "env0")
+        with _lib.options(QTTS_TEST_SWITCH_E="ovr"):
+            assert get("QTTS_TEST_SWITCH_E") == (0, "ovr")
+        assert get("QTTS_TEST_SWITCH_E") == (0, "env0")
+        print("ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

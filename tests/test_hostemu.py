@@ -1851,6 +1851,39 @@ def test_fused_code_predictor_launch_is_admitted_per_device_by_residency(emu, qo
         emu.qtts_talker_destroy(h)
 
 
+def test_code_predictor_with_more_than_five_layers_keeps_the_separate_launches(emu):
+    """the fused launches tag their granules with slot = position * 5 + layer.  With a sixth layer, layer 5 of pass L would
+    carry the tag of layer 0 of pass L + 1 in the same frame and the same buffers -- a stale granule would pass for a fresh one.  The
+    reference's `cp_num_hidden_layers` is configurable (configuration_qwen3_tts.py:370-454; every released checkpoint has 5): an engine
+    with six layers must run the separate launches -- stats say so -- and its greedy bf16 frames must be those of the same engine with the
+    fused launches switched off by hand (i.e. nothing of the fused path ran), bit for bit."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=256, cp_intermediate_size=1024, cp_num_hidden_layers=6,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(41), t, [4, 3], 2, scale=0.5)
+    args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
+    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+    emu.qtts_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    res = []
+    for off in (False, True):
+        if off:
+            emu.qtts_set_option(b"QTTS_CP_ATTN_O", b"0"); emu.qtts_set_option(b"QTTS_CP_MLP", b"0")
+        try:
+            h = _talker_emu(emu, t, w, max_batch=2, max_seq=32, dtype=_lib.QTTS_BF16, use_graph=1)
+            try:
+                codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=3)
+                st = _lib.TalkerStatsC()
+                _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+                assert st.cp_fused_per_step == 0 and st.cp_mlp_per_step == 0 and st.cp_fused_active == 0 and st.cp_fused_launches_last == 0
+                res.append((codes, hidden, int(st.graph_nodes)))
+            finally:
+                emu.qtts_talker_destroy(h)
+        finally:
+            emu.qtts_set_option(b"QTTS_CP_ATTN_O", None); emu.qtts_set_option(b"QTTS_CP_MLP", None)
+    assert res[0][2] == res[1][2] and np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_talker_orchestration_no_projection_vs_oracle(emu):
     """The 0.6B models' shape of the code predictor: talker hidden == predictor hidden, so small_to_mtp_projection is the
     identity (M:1171-1174) and the pass input row is the codec embedding itself.  Greedy fp32 against the oracle, then the bf16
