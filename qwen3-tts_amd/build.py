@@ -17,12 +17,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libqtts.so")
-SOURCES = ["gemm_tap.hip", "resunit.hip", "skinny.hip", "elementwise.hip", "attention.hip", "cp_mlp.hip", "sampling.hip",
+SOURCES = ["gemm_tap.hip", "resunit.hip", "skinny.hip", "elementwise.hip", "attention.hip", "cp_mlp.hip", "cp_layer.hip", "sampling.hip",
            "codec_engine.hip", "talker_engine.hip", "encoder_kernels.hip", "encoder_engine.hip",
            "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip"]
 # sources that only a measuring variant links (never the product library): variant name -> files
 VARIANT_SOURCES = {"probe": ["persist_probe.hip"]}
-HEADERS = ["common.h", "kernels.h", "glue.h", "granule.h", "tstamp.h", os.path.join("..", "..", "include", "qtts.h")]
+HEADERS = ["common.h", "kernels.h", "glue.h", "granule.h", "attn_helpers.h", "tstamp.h", os.path.join("..", "..", "include", "qtts.h")]
 # -amdgpu-kernarg-preload-count: the leading scalar kernel arguments (14 dwords on gfx950) arrive in user SGPRs with the wave instead
 # of behind an `s_load` round trip; the frame step's decode GEMMs (skinny8_kernel, skinny8_f32_kernel) pass their address operands that way.
 # The flag applies to every kernel of the library (only leading SCALAR arguments are ever preloaded; a kernel whose first argument is a

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "tstamp.h"
 #include "granule.h"
+#include "attn_helpers.h"
 #include <hip/hip_ext.h>
 
 QTTS_TS_UNIT(attn)
@@ -138,21 +139,7 @@ void launch_attn_rows(const AttnRowsParams& p, hipStream_t st) {
     QTTS_CHECK_HIP(hipGetLastError());
 }
 
-// =================================================================================== KV cache helpers
-template <typename KVT> __device__ inline KVT kv_cast(float v);
-template <> __device__ inline float kv_cast<float>(float v) { return v; }
-template <> __device__ inline bf16_t kv_cast<bf16_t>(float v) { return f32_to_bf16(v); }
-__device__ inline float kv_load(const float* p) { return *p; }
-__device__ inline float kv_load(const bf16_t* p) { return bf16_to_f32(*p); }
-// softmax exponential of the decode attentions.  bf16 cache (the benchmarked mode): v_exp_f32 on x * log2(e), 2 instructions
-// (~1e-7 relative: far inside what the bf16 K / V carry); fp32 cache (the parity mode): the library expf the goldens were taken with
-// -- 10 instructions, and the key loop of attn_tk spends a fifth of its VALU time in them.
-template <typename KVT>
-__device__ inline float att_exp(float x) {
-    if constexpr (sizeof(KVT) == 2) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
-    else return expf(x);
-}
-
+// =================================================================================== KV cache helpers (attn_helpers.h)
 // element offset of (layer, sequence b, position s, kv head) in a pool [layer][page][kvh][16][hd]
 __device__ inline size_t kv_offset(const KvCache& c, int layer, int b, int s, int kvh) {
     const int page = c.page_table[b * c.pages_per_seq + (s >> 4)];
@@ -1443,8 +1430,6 @@ __device__ __forceinline__ void cpao_give_up(const CpAttnOParams& P) {
 // F32 (round 5: the exact parity mode's instantiation, the construction's bit-exact leg): fp32 operators in the fp32 decode GEMM's packing
 // (k-tiles of 16, four v_mfma_f32_16x16x4_f32 each), fp32 x rows (`x16` then points to floats), fp32 cache, the attention output stays
 // fp32 in the B tile -- the arithmetic of the fp32 engines' three launches in the fused launch's summation orders.
-template <bool F32> struct CpaoKv { typedef bf16_t type; };
-template <> struct CpaoKv<true> { typedef float type; };
 template <bool CT, bool QKV, bool F32>
 __global__ __launch_bounds__(256) void cp_attn_o_kernel(const void* k0, const unsigned short* kx16, const int* kserial, const int* kdone, int kB, int kldx16,
                                                         int kK, int kslot, CpAttnOParams P) {

@@ -291,6 +291,27 @@ void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int
 void launch_cp_mlp(const CpMlpParams& P, hipStream_t st);
 void cp_mlp_set_launch_events(hipEvent_t start, hipEvent_t stop);
 
+// --------------------------------------------------------------------------------- cp_layer.hip
+// A whole decoder layer of the code predictor (passes >= 1, batch <= 8) as ONE launch (round 6): cp_attn_o's stages, then cp_mlp's, the
+// launch boundary between them replaced by a granule hand-off of the hidden rows, the gate|up block requested at entry by LDS-DMA.
+// `ao` / `mlp` as for the two launches (`mlp.x16`, `mlp.res`, `ao.out`, `ao.out16` are unused: the rows in between travel as granules
+// and stay in the reducers' registers); one tag = (ao.serial, ao.slot) for all five granule buffers.
+struct CpLayerParams {
+    CpAttnOParams ao;
+    CpMlpParams mlp;
+    float* hid_gran;              // scratch [8 rows][H / 2] granules {2 x bf16 hidden, tag} (fp32 engines: [8][H] {fp32, tag}): zero at engine creation
+    int pause_h;                  // x 64 clocks: a workgroup's wait before its first read of the hidden rows
+    int gu_when;                  // 0: the gate|up block's LDS-DMA at kernel entry; 1 (A/B): behind the o-projection operator's requests
+    int phase;                    // 8: the whole kernel.  0..4 (host emulator, or a test): one stage alone
+};
+bool cp_layer_takes(const AttnDecodeParams& a, int H, int I);
+bool cp_layer_instantiated(int H, int I, bool bf16);
+int cp_layer_grid(int H);
+int cp_layer_lds_bytes(int H, int I, bool bf16);        // dynamic LDS of one workgroup (the admission account's second resource)
+int cp_layer_blocks_per_cu(int H, int I, bool bf16);
+void launch_cp_layer(const CpLayerParams& P, hipStream_t st);
+void cp_layer_set_launch_events(hipEvent_t start, hipEvent_t stop);
+
 // --------------------------------------------------------------------------------- sampling.hip
 struct SampleParams {
     const float* logits; int ld; int V; int B;

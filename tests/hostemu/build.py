@@ -33,14 +33,14 @@ _TAG = ("_asan" if ASAN else "_ubsan" if UBSAN else "") + ("_v" + hashlib.sha256
 OUT = os.path.join(HERE, f"libqtts_hostemu{_TAG}.so")
 GEN = os.path.join(HERE, "gen" + _TAG)
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
-SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "cp_mlp.hip", "sampling.hip",
+SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "cp_mlp.hip", "cp_layer.hip", "sampling.hip",
                 "elementwise.hip", "skinny.hip", "gemm_tap.hip", "resunit.hip"]
 # kernels without barriers / cross-lane ops run as plain per-thread calls (no fibers): much faster for large grids
 SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}
 # gemm_tap.hip is built as launch_gemm_tap_real; cpu_gemm_tap.cpp owns launch_gemm_tap and forwards to it on request
 EXTRA_DEFS = {"gemm_tap.hip": ["-Dlaunch_gemm_tap=launch_gemm_tap_real"]}
 STANDIN = ["cpu_gemm_tap.cpp", "test_entries.cpp", "lds_arrays.cpp"]
-HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h", "granule.h", "tstamp.h")] + [
+HEADERS = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "glue.h", "granule.h", "attn_helpers.h", "tstamp.h")] + [
     os.path.join(ROOT, "include", "qtts.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "hip", "hip_ext.h"), os.path.join(HERE, "simt.h")]
 
 
