@@ -639,8 +639,8 @@ def configs_leg(args, tcfg, ccfg, tw_np, cw_np, dev):
 
 def voice_clone_prompt_leg(args, tcfg, dev):
     """`Qwen3TTSModel.create_voice_clone_prompt` (IM:356-458) for 8 and for 32 reference clips of 3 s: audio normalisation, the codec
-    ENCODER (f3: waveform -> 16 codebooks, batched) and the SPEAKER encoder (f4: log-mel + ECAPA-TDNN, one clip at a time as the reference
-    loops, IM:440-455) at the RELEASED dimensions (synth.mimi_enc_real / speaker_real; parity at these dims: tests/test_gpu_parity.py), the
+    ENCODER (f3: waveform -> 16 codebooks, batched) and the SPEAKER encoder (f4: log-mel + ECAPA-TDNN; the reference loops clip by clip,
+    IM:440-455 -- round 6: equal-length clips in batches of 8, `speaker_batched8_ms` beside `speaker_clip_by_clip_ms`) at the RELEASED dimensions (synth.mimi_enc_real / speaker_real; parity at these dims: tests/test_gpu_parity.py), the
     real wrapper around a model stand-in that owns the two engines (the talker is not involved in this call)."""
     import numpy as np
     import torch
@@ -664,7 +664,7 @@ def voice_clone_prompt_leg(args, tcfg, dev):
            "clip_seconds": round(n / 24000.0, 3), "runs": []}
     for dt, name in ((torch.float32, "f32"),) if small else ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
         tok = Qwen3TTSTokenizer.from_state_dict(tok_cfg, td(tok_sd), device=dev, dtype=dt, max_batch=max(counts), max_frames=32)
-        se = SpeakerEncoderEngine(synth.cfg_dict(spk), td(synth.speaker_weights(spk)), compute_dtype=dt, device=dev, max_batch=1, max_samples=n)
+        se = SpeakerEncoderEngine(synth.cfg_dict(spk), td(synth.speaker_weights(spk)), compute_dtype=dt, device=dev, max_batch=8, max_samples=n)
 
         class _BaseModel:                      # what the wrapper touches for this call (IM:356-458)
             tts_model_type = "base"
@@ -674,6 +674,9 @@ def voice_clone_prompt_leg(args, tcfg, dev):
 
             def extract_speaker_embedding(self, audio, sr):
                 return se.extract_speaker_embedding(audio, sr)
+
+            def extract_speaker_embeddings(self, audios, sr):           # round 6: equal-length clips as batches of 8 (model.py)
+                return se.embed_many(audios)
         tts = Qwen3TTSModel(_BaseModel(), _BenchProcessor(tcfg), generate_defaults={})
         for N in counts:
             clips = [(a, 24000) for a in synth.rand_audio(300 + N, N, n)]
@@ -699,9 +702,14 @@ def voice_clone_prompt_leg(args, tcfg, dev):
                 se.embed(wavs[i:i + 1])
             torch.cuda.synchronize()
             spk_ms = 1e3 * (time.perf_counter() - ta)
+            ta = time.perf_counter()
+            for i in range(0, N, 8):
+                se.embed(wavs[i:i + 8])
+            torch.cuda.synchronize()
+            spk_b_ms = 1e3 * (time.perf_counter() - ta)
             out["runs"].append({"dtype": name, "clips": N, "ms_per_call": round(1e3 * float(np.median(ts)), 2), "ms_min": round(1e3 * min(ts), 2),
                                 "ms_per_clip": round(1e3 * float(np.median(ts)) / N, 3), "encoder_batched_ms": round(enc_ms, 2),
-                                "speaker_clip_by_clip_ms": round(spk_ms, 2),
+                                "speaker_clip_by_clip_ms": round(spk_ms, 2), "speaker_batched8_ms": round(spk_b_ms, 2),
                                 "audio_seconds_per_wall_second": round(N * n / 24000.0 / float(np.median(ts)), 1)})
         del tts, tok, se
         torch.cuda.empty_cache()

@@ -46,7 +46,7 @@ const char* qtts_last_error(void);
  * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
  * 6: + qtts_talker_stream_*; 7: + qtts_talker_set_teacher; 8: + qtts_talker_set_profile / get_gemm_profile;
  * 9: + qtts_codec_get_stats; 10: + qtts_set_option / qtts_get_option, qtts_talker_stats grew the fused-launch fields;
- * 11: + qtts_talker_debug_cp_logits). */
+ * 11: + qtts_talker_debug_cp_logits, qtts_talker_stats.cp_layer_per_step in the reserved word). */
 #define QTTS_ABI_VERSION 11
 int qtts_abi_version(void);
 
@@ -401,7 +401,8 @@ typedef struct {
     int32_t cp_fused_capacity;      /* engines with the code predictor's fused launches the DEVICE holds at once (register-share account, talker_engine.hip) */
     int32_t cp_fused_active;        /* 1: this engine holds one of those places                                                             */
     int32_t cp_mlp_per_step;        /* fused MLP launches (cp_mlp.hip: gate|up + SwiGLU + down of a code-predictor layer; bf16 and fp32) in that frame step */
-    int32_t reserved2_;
+    int32_t cp_layer_per_step;      /* of those, the launches that ran BOTH stages of a layer as one (cp_layer.hip, round 6): they count in cp_fused_per_step
+                                     * and cp_mlp_per_step too.  (ABI v11: the former reserved word.)                                        */
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
 /* Per-class result of the profile mode (qtts_talker_set_profile(t, 1), ABI v8): every launch of the decode GEMM in frames 1..6

@@ -70,7 +70,7 @@ class TalkerStatsC(C.Structure):
                 ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64), ("long_graphs", C.c_int32),
                 ("attn_nsplit_last", C.c_int32), ("attn_span_last", C.c_int32), ("cp_fused_per_step", C.c_int32),
                 ("cp_fused_launches_last", C.c_int64), ("cp_fused_giveups", C.c_int32), ("cp_fused_capacity", C.c_int32),
-                ("cp_fused_active", C.c_int32), ("cp_mlp_per_step", C.c_int32), ("reserved2_", C.c_int32)]
+                ("cp_fused_active", C.c_int32), ("cp_mlp_per_step", C.c_int32), ("cp_layer_per_step", C.c_int32)]
 
 
 class CodecStatsC(C.Structure):

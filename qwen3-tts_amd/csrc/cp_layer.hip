@@ -41,9 +41,16 @@ namespace qtts {
 __device__ __forceinline__ void cl_dma16(const void* src, void* lds_dst) {        // 64 lanes x 16 B -> 1 KiB of LDS, lane-linear
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
-__device__ __forceinline__ void cl_dma_wait() {     // this wave's LDS-DMA has landed when ITS vmcnt says so (each wave reads back only what it requested)
+// This wave's LDS-DMA has landed when ITS vmcnt says so (each wave reads back only what it requested).  Vector loads complete in issue
+// order, so "all but the NEWER newest requests" is enough: the polling loop that runs between the DMA and its use keeps a second round of
+// reads in flight, and vmcnt(0) would wait a memory round trip for reads whose values nobody uses (first timeline of this kernel: 1.1 us).
+template <int NEWER>
+__device__ __forceinline__ void cl_dma_wait() {
 #ifndef QTTS_HOST_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(NEWER >= 0 && NEWER < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+#else
+    __builtin_amdgcn_wave_barrier();                 // (emulator: lanes are fibers -- every lane of the wave has issued its copies before any lane reads them back)
 #endif
 }
 __device__ __forceinline__ void cl_give_up(const CpLayerParams& P) {
@@ -66,7 +73,7 @@ __device__ __forceinline__ void cl_give_up(const CpLayerParams& P) {
 #define QTTS_TS_CPLAYER(tail_)
 #endif
 
-// LDS of one workgroup (dynamic: > 64 KB with the DMA region): [gate|up block (DMA; bf16 only)] | attention stage | MLP stage
+// LDS of one workgroup (dynamic: > 64 KB with the DMA region): [gate|up block (DMA; bf16 only)] | attention stage / MLP stage
 template <bool QKV, bool F32, int ACT, int KQ>
 struct ClLds {
     static constexpr int BSTR = 264;
@@ -74,7 +81,10 @@ struct ClLds {
     static constexpr int WS = 4 * 1536, BT = 2 * BSTR * (F32 ? 4 : 2), OWN = 2 * 128 * 4, QP = QKV ? 4 * 64 * 16 + 4 * 16 * 4 : 0;
     static constexpr int ATT = WS + BT + OWN + QP;
     static constexpr int QA = 4 * 64 * 2 * 16 + 4 * 16 * 4, QB = 4 * 2 * 64 * 16;
-    static constexpr int TOTAL = GU + ATT + QA + QB;
+    static constexpr int MLP = QA + QB;
+    // the MLP stage's quarters lie OVER the attention stage's region (dead by then; one workgroup barrier in between): 64.6 KB per workgroup at the
+    // released dims, two workgroups per compute unit with a fifth of the LDS to spare
+    static constexpr int TOTAL = GU + (ATT > MLP ? ATT : MLP);
 };
 
 #define QTTS_CPLAYER_ARGS(P) ((P).ao.Wqkv ? (P).ao.Wqkv : static_cast<const void*>((P).ao.a.qkv)), (P).mlp.Wgu, (P).ao.x16, (P).ao.serial, (P).ao.a.done_flag, (P).ao.a.B, (P).ao.slot, (P)
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cl[];
     unsigned char* gu_lds = smem_cl;
     unsigned char* att_lds = smem_cl + L::GU;
-    unsigned char* mlp_lds = att_lds + L::ATT;
+    unsigned char* mlp_lds = att_lds;                   // (aliased: see ClLds)
     const AttnDecodeParams& p = P.ao.a;
     const int H = P.ao.H, I = P.mlp.I, B = p.B;
     const int nchunk = H >> 7;
@@ -177,8 +187,11 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             for (int i = 0; i < GU_WAVE / 1024; ++i) cl_dma16(src + i * 1024, gu_lds + wave * GU_WAVE + i * 1024);
         }
     };
-    const bool gu_late = QKV && ph == CL_ALL && P.gu_when == 1 && att_wg;      // (A/B: behind the o-projection's operator instead of at entry)
-    if (run2 && !gu_late) dma_gu();
+    // when: 2 (default) -- behind the attention stage (after the partial o-projection is published / the hidden rows are: the workgroup then
+    // waits >= 1.6 us for the hidden rows, longer than the block takes to arrive); requested at entry (0) or behind the o-projection's
+    // operator (1) the 12.6 MB of a launch compete with the strips and with Wo: the attention stage ran 1.5-2 us late (profiles/r06_cp_layer.md)
+    const int gu_when = (ph == CL_ALL && att_wg) ? P.gu_when : 0;
+    if (run2 && gu_when == 0) dma_gu();
     const int done = p.done_flag ? *p.done_flag : 0;
     if (done) return;
     // ================================================================================================ stage 0: the q|k|v strip
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
     if (run1 && att_wg) {
         if constexpr (QKV) {
             load_wo();                                 // arrives while this workgroup waits for its rows and attends
-            if (gu_late) dma_gu();
+            if (gu_when == 1) dma_gu();
             const WtBuf qg = wt_buf(P.ao.qkv_gran, (size_t)8 * p.ld * 8);
             int cols[3] = {(g * 2 + hh) * HD, (p.nh + g) * HD, (p.nh + p.nkv + g) * HD};
             uint2 gq[3][2], gn[3][2];
@@ -384,6 +397,8 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             }
         }
         QTTS_TS(1);
+        if (gu_when == 1 && !QKV) dma_gu();
+        if (gu_when == 2 && !reducer) dma_gu();
         // ============================================================================================ stage 2: the o-projection's reducers -> hidden rows
         if (reducer) {
             __syncthreads();                                 // (its own partial sum is in LDS)
@@ -418,7 +433,8 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
                     s0 += res.x; s1 += res.y;
                     x1a = s0; x1b = s1;
                     // the hidden rows after attention: to every workgroup's phase A as granules -- {2 x bf16, tag} (fp32 engines: {fp32, tag} x 2)
-                    const WtBuf hg = wt_buf(P.hid_gran, (size_t)8 * (F32 ? H : H / 2) * 8);
+                    const int hid_stride = 8 * (F32 ? H : H / 2) * 8;
+                    const WtBuf hg = wt_buf(reinterpret_cast<unsigned char*>(P.hid_gran) + (size_t)P.hid_slot * hid_stride, (size_t)hid_stride);
                     if constexpr (F32) {
                         wt_store16(hg, (int)(((size_t)rw * H + col) * 8), (cu32x4){__float_as_uint(s0), tag, __float_as_uint(s1), tag});
                     } else {
@@ -429,6 +445,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
                         __builtin_amdgcn_raw_buffer_store_b64((cu32x2){pack_bf16(s0, s1), tag}, hg.r, (int)(((size_t)rw * (H / 2) + (col >> 1)) * 8), 0, 16);
 #endif
                     }
+                    QTTS_TS(1);                              // (reducers: stamp 1 = the hidden rows published)
                     if (ph != CL_ALL) {                      // (emulated stages: the residual of stage 5 travels through the output rows)
                         float2 o2; o2.x = s0; o2.y = s1;
                         *reinterpret_cast<float2*>(P.mlp.out + (size_t)rw * H + col) = o2;
@@ -437,6 +454,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             }
         }
     }
+    if (run2 && gu_when == 2 && reducer) dma_gu();
     if (!run2 && !run3 && !run4) return;
     // ================================================================================================ stage 3: phase A (gate|up over the hidden rows)
     constexpr int KTM = F32 ? 16 : 32;
@@ -457,7 +475,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
         }
     };
     if (run2) {
-        const WtBuf hg = wt_buf(P.hid_gran, (size_t)8 * (F32 ? H : H / 2) * 8);
+        if (ph == CL_ALL) __syncthreads();                 // the attention stage's LDS (B tile, the reducer's own partial sum) is dead: phase A's quarters overwrite it
         const int row = li < B ? li : 0;
         // this wave's k quarter of the hidden rows: per k-tile 8 bf16 = 4 granules = 32 B per lane (fp32: 4 values = 4 granules = 32 B)
         cu32x4 wgr[F32 ? KQ : 1], wur[F32 ? KQ : 1];     // fp32 engines: the gate|up tiles in registers, requested here
@@ -467,39 +485,63 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             for (int ks = 0; ks < KQ; ++ks) { wgr[ks] = wsrc[(size_t)ks * 4 * 2 * ACT]; wur[ks] = wsrc[(size_t)ks * 4 * 2 * ACT + ACT]; }
         }
         if (run3) load_wd();                             // 24 KB: streams while the hidden rows travel
+        // The hidden rows reach 1024 waves from 32 reducers.  First version: every wave polled its whole k quarter (8 KB per wave and round =
+        // 8 MB per round through the fabric) -- the hand-off took 3.7 us in the kernel's timeline.  Now a wave polls one SENTINEL granule per
+        // producer wave it depends on (the first granule of each (row, 128-feature chunk): 16 lanes x 8 B), and reads its quarter once the
+        // sentinels carry the tag -- every granule's own tag is still checked, and re-read (sc1) until fresh: a producer wave's 64 granules
+        // leave in ONE store instruction, so they become readable together, but nothing orders them.
+        // hid_mode 2: that one read may be served by this XCD's L2 (the region of the buffer is this launch slot's own: nobody has read it
+        // since the previous frame): 32 workgroups of an XCD pull each line through the fabric once instead of 32 times.
+        const int hid_stride = 8 * (F32 ? H : H / 2) * 8;                 // bytes of one launch slot's region
+        const WtBuf hgs = wt_buf(reinterpret_cast<unsigned char*>(P.hid_gran) + (size_t)P.hid_slot * hid_stride, (size_t)hid_stride);
         int hoff[KQ];
 #pragma unroll
         for (int ks = 0; ks < KQ; ++ks)
             hoff[ks] = F32 ? (int)(((size_t)row * H + (wave * KQ + ks) * 16 + lq * 4) * 8) : (int)(((size_t)row * (H / 2) + (wave * KQ + ks) * 16 + lq * 4) * 8);
-        constexpr int NB = F32 ? 1 : 2;                   // reads in flight (fp32: the tiles in registers leave room for one)
-        cu32x4 cur[KQ][2], nxt[NB == 2 ? KQ : 1][2];
+        constexpr int NV = KQ * KTM, NCH = (NV + 127) / 128;              // values / 128-feature chunks of this wave's k quarter
+        const int srow = lane / NCH, scc = lane - srow * NCH;
+        const bool s_live = lane < 8 * NCH && srow < B;
+        const int c_s = (wave * NV) / 128 + scc;
+        const int soff = F32 ? (int)(((size_t)(s_live ? srow : 0) * H + c_s * 128) * 8) : (int)(((size_t)(s_live ? srow : 0) * (H / 2) + c_s * 64) * 8);
+        cu32x4 cur[KQ][2];
         auto load_hid = [&](cu32x4 (&d)[KQ][2]) {
 #pragma unroll
-            for (int ks = 0; ks < KQ; ++ks) { d[ks][0] = wt_load16(hg, hoff[ks]); d[ks][1] = wt_load16(hg, hoff[ks] + 16); }
+            for (int ks = 0; ks < KQ; ++ks) { d[ks][0] = wt_load16(hgs, hoff[ks]); d[ks][1] = wt_load16(hgs, hoff[ks] + 16); }
         };
-        wt_first_pause(P.pause_h);
-        load_hid(cur);
-        if constexpr (NB == 2) { wt_first_pause(P.mlp.poll_step); load_hid(nxt); }
-        for (int spins = 0;; ++spins) {
+        auto load_hid_cached = [&](cu32x4 (&d)[KQ][2]) {
+#pragma unroll
+            for (int ks = 0; ks < KQ; ++ks) { d[ks][0] = wt_load16_cached(hgs, hoff[ks]); d[ks][1] = wt_load16_cached(hgs, hoff[ks] + 16); }
+        };
+        auto all_fresh = [&](const cu32x4 (&d)[KQ][2]) {
             bool fresh = true;
 #pragma unroll
             for (int ks = 0; ks < KQ; ++ks)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) fresh = fresh && cur[ks][h2][1] == tag && cur[ks][h2][3] == tag;
-            if (fresh) break;
-            if (spins > GRANULE_SPIN_LIMIT) { cl_give_up(P); break; }
-            if constexpr (NB == 2) {
-#pragma unroll
-                for (int ks = 0; ks < KQ; ++ks) { cur[ks][0] = nxt[ks][0]; cur[ks][1] = nxt[ks][1]; }
+                for (int h2 = 0; h2 < 2; ++h2) fresh = fresh && d[ks][h2][1] == tag && d[ks][h2][3] == tag;
+            return fresh;
+        };
+        wt_first_pause(P.pause_h);
+        if (P.hid_mode != 0) {
+            uint2 sv = wt_load8(hgs, soff);
+            wt_first_pause(P.mlp.poll_step);
+            uint2 sn = wt_load8(hgs, soff);
+            for (int spins = 0;; ++spins) {
+                if (__ballot(s_live && sv.y != tag) == 0ull) break;
+                if (spins > GRANULE_SPIN_LIMIT) { cl_give_up(P); break; }
+                sv = sn;
                 wt_first_pause(P.mlp.poll_step);
-                load_hid(nxt);
-            } else {
-                wt_first_pause(P.mlp.poll_step);
-                load_hid(cur);
+                sn = wt_load8(hgs, soff);
             }
+            if (P.hid_mode == 2) load_hid_cached(cur); else load_hid(cur);
+        } else load_hid(cur);
+        for (int spins = 0;; ++spins) {                   // (hid_mode 0: the polling loop; otherwise it runs through once unless a granule lags its sentinel)
+            if (all_fresh(cur)) break;
+            if (spins > GRANULE_SPIN_LIMIT) { cl_give_up(P); break; }
+            wt_first_pause(P.mlp.poll_step);
+            load_hid(cur);
         }
         QTTS_TS(2);
-        if constexpr (!F32) cl_dma_wait();               // (the gate|up block was requested long ago; this wave reads back its own requests)
+        if constexpr (!F32) cl_dma_wait<0>();            // (the gate|up block was requested long ago and every later read has come back; this wave reads back its own requests)
         f32x4 ag4 = (f32x4){0.f, 0.f, 0.f, 0.f}, au4 = (f32x4){0.f, 0.f, 0.f, 0.f};
         float ssq = 0.f;
 #pragma unroll

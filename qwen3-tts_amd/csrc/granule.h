@@ -18,6 +18,7 @@ struct WtBuf { unsigned char* base; };
 __device__ inline WtBuf wt_buf(void* p, size_t) { return WtBuf{static_cast<unsigned char*>(p)}; }
 __device__ inline void wt_store16(const WtBuf& b, int off, cu32x4 v) { *reinterpret_cast<cu32x4*>(b.base + off) = v; }
 __device__ inline cu32x4 wt_load16(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
+__device__ inline cu32x4 wt_load16_cached(const WtBuf& b, int off) { return *reinterpret_cast<const cu32x4*>(b.base + off); }
 __device__ inline uint2 wt_load8(const WtBuf& b, int off) { return *reinterpret_cast<const uint2*>(b.base + off); }
 __device__ inline void wt_first_pause(int) {}
 constexpr int GRANULE_SPIN_LIMIT = 2;                      // (workgroups run one after the other here: a second read never helps)
@@ -27,6 +28,10 @@ __device__ __forceinline__ WtBuf wt_buf(void* p, size_t bytes) { return WtBuf{__
 // aux = 16: sc1 -- the store writes through to memory, the load is not served from this CU's L1
 __device__ __forceinline__ void wt_store16(const WtBuf& b, int off, cu32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, off, 0, 16); }
 __device__ __forceinline__ cu32x4 wt_load16(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 16); }
+// aux = 0: an ordinary load -- this CU's L1 and this XCD's L2 may serve it.  Only for granules whose buffer region has not been read
+// for a long time (cp_layer.hip rotates its hidden-row regions) AND only behind a fresh sentinel: a line that is stale in a cache comes back
+// with an old tag, which the reader sees and answers with sc1 re-reads.
+__device__ __forceinline__ cu32x4 wt_load16_cached(const WtBuf& b, int off) { return __builtin_amdgcn_raw_buffer_load_b128(b.r, off, 0, 0); }
 __device__ __forceinline__ uint2 wt_load8(const WtBuf& b, int off) {
     typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
     const cu32x2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, off, 0, 16);

@@ -299,9 +299,11 @@ void cp_mlp_set_launch_events(hipEvent_t start, hipEvent_t stop);
 struct CpLayerParams {
     CpAttnOParams ao;
     CpMlpParams mlp;
-    float* hid_gran;              // scratch [8 rows][H / 2] granules {2 x bf16 hidden, tag} (fp32 engines: [8][H] {fp32, tag}): zero at engine creation
+    float* hid_gran;              // scratch [hid_slots][8 rows][H / 2] granules {2 x bf16 hidden, tag} (fp32 engines: [..][8][H] {fp32, tag}): zero at engine creation
+    int hid_slot;                 // which region of hid_gran this launch uses (the engine: ao.slot -- a region is touched once per frame)
+    int hid_mode;                 // 0: every wave polls its whole k quarter; 1: sentinel granules, then one sc1 read; 2: ... one read the L2 may serve
     int pause_h;                  // x 64 clocks: a workgroup's wait before its first read of the hidden rows
-    int gu_when;                  // 0: the gate|up block's LDS-DMA at kernel entry; 1 (A/B): behind the o-projection operator's requests
+    int gu_when;                  // the gate|up block's LDS-DMA: 2 behind the attention stage; 0 at kernel entry, 1 behind the o-projection operator's requests (A/B)
     int phase;                    // 8: the whole kernel.  0..4 (host emulator, or a test): one stage alone
 };
 bool cp_layer_takes(const AttnDecodeParams& a, int H, int I);

@@ -233,6 +233,17 @@ struct qtts_talker {
     DevBuf mlp_act, mlp_part;          // granule buffers of the fused MLP launch
     int64_t cp_mlp_count = 0;
     int cp_mlp_per_step = 0;
+    // Round 6: both fused launches of a layer as ONE (cp_layer.hip: the hidden rows between them travel as granules, the gate|up block is
+    // requested at entry by LDS-DMA).  QTTS_CP_LAYER=0 (copied at engine creation): the two launches.  A launch of it counts in
+    // cp_attn_o_count AND cp_mlp_count (both stages ran fused) and in cp_layer_count.
+    bool cp_layer_env = QTTS_OPT_ON("QTTS_CP_LAYER");
+    int cp_layer_pause_h = [] { const char* e = QTTS_ENV("QTTS_CP_LAYER_PAUSE_H"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 16; }();   // (A/B: x 64 clocks)
+    int cp_layer_gu_when = QTTS_OPT_INT("QTTS_CP_LAYER_GU_WHEN", 2);
+    int cp_layer_hid_mode = QTTS_OPT_INT("QTTS_CP_LAYER_HID_MODE", 1);
+    static constexpr int CP_HID_SLOTS = 128;            // one region of the hidden-row granules per launch slot (position x layer)
+    DevBuf cp_hid;                     // [8 rows][H / 2] granules {2 x bf16 hidden, tag} (fp32 engines: [8][H] {fp32, tag})
+    int64_t cp_layer_count = 0;
+    int cp_layer_per_step = 0;
     void build_layer(LayerW& L, const std::string& p, const StackDims& d, bool rows) {
         auto qkvw = cat3(PS(p + "self_attn.q_proj.weight", {d.qd, d.H}), PS(p + "self_attn.k_proj.weight", {d.kvd, d.H}),
                          PS(p + "self_attn.v_proj.weight", {d.kvd, d.H}));
@@ -357,6 +368,41 @@ struct qtts_talker {
             }
             norm_input(p, d, h16 ? xs16 : nullptr, st);
             skinny(p, st);
+        }
+        const bool fuse_layer = cp_layer_env && fuse_ao && mlp_fusable && cp_hid.p && cp_layer_takes(a, d.H, d.I);
+        if (fuse_layer) {           // the whole layer as ONE launch (cp_layer.hip): both parameter blocks as for the two launches
+            CpLayerParams cl{};
+            CpAttnOParams& f = cl.ao;
+            f.a = a; f.Wo = wo_fused; f.res = xs; f.out = xs; f.out16 = nullptr;
+            f.part = ao_part.as<float>(); f.serial = ss.frame_serial; f.slot = len_static * CP_FUSED_MAX_LAYERS + layer; f.phase = 2;
+            f.err = ss.n_generated + 5; f.done_latch = ss.done; f.H = d.H; f.first_pause = cp_attn_o_pause; f.poll_step = cp_attn_o_step;
+            if (front) {
+                f.Wqkv = L.qkv_p.p; f.x16 = bf16 ? xs16 : reinterpret_cast<const unsigned short*>(xs); f.ldx16 = d.H; f.K = d.H; f.eps_in = d.eps; f.qkv_gran = ao_qkv.as<float>();
+                ++cp_front_count;
+            }
+            CpMlpParams& m = cl.mlp;
+            m.f32 = bf16 ? 0 : 1;
+            m.Wgu = L.gu_mlp.p; m.Wd = bf16 ? L.d_p16.p : L.d_p.p; m.eps = d.eps;
+            m.out = xs; m.out16 = bf16 ? xs16 : nullptr;
+            m.act_gran = mlp_act.as<float>(); m.part = mlp_part.as<float>(); m.serial = ss.frame_serial; m.slot = f.slot; m.phase = 3;
+            m.err = f.err; m.done_latch = ss.done; m.done_flag = ss.done;
+            m.B = M; m.H = d.H; m.I = d.I;
+            m.first_pause = cp_mlp_pause_b; m.pause_c = cp_mlp_pause_c; m.poll_step = cp_mlp_step;
+            cl.hid_gran = cp_hid.as<float>(); cl.hid_slot = f.slot; cl.hid_mode = cp_layer_hid_mode;
+            cl.pause_h = cp_layer_pause_h; cl.gu_when = cp_layer_gu_when; cl.phase = 8;
+            if (timing_now) {          // bench.py's roofline leg: timed on its own (stack 5: the layer launch, every operator of the layer)
+                const double eb = bf16 ? 2.0 : 4.0;
+                LaunchEv e{nullptr, nullptr, 5, front ? a.ld + d.H + 3 * d.I : d.H + 3 * d.I, d.H,
+                           eb * ((double)d.H * d.qd + (front ? (double)a.ld * d.H : 0.0) + 3.0 * (double)d.I * d.H)};
+                QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
+                ev.push_back(e);
+                cp_layer_set_launch_events(e.a, e.b);
+                try { launch_cp_layer(cl, st); } catch (...) { cp_layer_set_launch_events(nullptr, nullptr); throw; }
+                cp_layer_set_launch_events(nullptr, nullptr);
+            } else launch_cp_layer(cl, st);
+            ++cp_attn_o_count; ++cp_mlp_count; ++cp_layer_count;
+            sk_pending = false;
+            return;
         }
         if (fuse_ao) {
             CpAttnOParams f{};
@@ -521,42 +567,53 @@ struct qtts_talker {
     // pass L would otherwise share its tag with layer 0 of pass L + 1 and a consumer could take a stale granule as fresh).
     static constexpr int CP_FUSED_MAX_LAYERS = 5;
     static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 272;     // (fp32 engines: the F32 instantiations hold twice the operand registers -- one engine per device)
-    struct FusedRegistry { std::mutex m; std::map<int, std::pair<int, int>> dev; };        // device -> (share in use, fused engines)
+    // Round 6: the layer launch (cp_layer.hip) runs both stages in the two launches' register share (176 of 184 in bf16; 360 with the operators
+    // in registers in fp32) and holds 65 KB of LDS per workgroup (the gate|up block requested by LDS-DMA): the account has a SECOND resource,
+    // a compute unit's 160 KB of LDS (a register-only account over-admits the moment a fused launch stages operands in LDS).
+    static constexpr int CP_SHARE_LAYER = 184, CP_SHARE_LAYER_F32 = 360, CU_LDS_BUDGET = 160 * 1024, CP_LDS_TWO_LAUNCHES = 17 * 1024;
+    struct FusedDev { int regs = 0, lds = 0, engines = 0; };
+    struct FusedRegistry { std::mutex m; std::map<int, FusedDev> dev; };        // device -> (register share, LDS bytes in use, fused engines)
     static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
     bool cp_fused_slot = false;
-    int fused_device = -1, fused_capacity = 0, fused_share = 0;     // capacity: engines with this engine's share the device holds at once
+    int fused_device = -1, fused_capacity = 0, fused_share = 0, fused_lds = 0;     // capacity: engines with this engine's shares the device holds at once
     int cp_fused_per_step = 0;                         // fused launches in the frame step last launched / captured
     int cp_fused_giveups = 0;                          // generations of this engine that ended on the give-up flag
     // QTTS_CP_FUSED_MAX (A/B, tests): cap on fused engines per device below what residency allows
     // grid_cp: workgroups per launch of the engine's largest fused kernel; occ_ok: the occupancy API finds room for at least one workgroup of
-    // every wanted kernel on a compute unit
-    void fused_admit(int grid_cp, bool occ_ok, int share) {
+    // every wanted kernel on a compute unit; share / lds: registers per lane and LDS bytes of one workgroup of the engine's largest fused launch
+    // `budget_regs` / `budget_lds`: the part of a compute unit fused engines may take together.  The two-launch kernels (184 of 512 registers per
+    // engine) leave room beside two engines for the short waves of other streams.  The first layer kernel (256 registers, 77 KB of LDS) fitted
+    // twice EXACTLY -- and then any short wave that lands on a compute unit keeps a pending workgroup out until it has left, while the resident
+    // workgroups of both launches wait for the pending ones: on the MI355X two such engines beside a codec stream and a third engine ran into
+    // a give-up (profiles/r06_cp_layer.md).  So layer engines are admitted only while an eighth of the register file AND of the LDS stays free.
+    void fused_admit(int grid_cp, bool occ_ok, int share, int lds, int budget_regs = CU_REG_BUDGET, int budget_lds = CU_LDS_BUDGET) {
         QTTS_CHECK_HIP(hipGetDevice(&fused_device));
         int cus = 0;
         QTTS_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, fused_device));
-        const int need = grid_cp > 0 ? share * cdiv(grid_cp, std::max(1, cus)) : 0;
+        const int per_cu = grid_cp > 0 ? cdiv(grid_cp, std::max(1, cus)) : 0;
+        const int need = share * per_cu, need_lds = lds * per_cu;
         int max_engines = 1 << 20;
         if (const char* e = QTTS_ENV("QTTS_CP_FUSED_MAX")) max_engines = std::max(0, atoi(e));
         auto& r = fused_registry();
         std::lock_guard<std::mutex> lk(r.m);
         auto& d = r.dev[fused_device];
-        fused_capacity = need > 0 && occ_ok ? std::min(max_engines, CU_REG_BUDGET / need) : 0;
-        if (!occ_ok || need <= 0 || d.second + 1 > max_engines || d.first + need > CU_REG_BUDGET) return;
-        fused_share = need; cp_fused_slot = true;
-        d.first += fused_share; d.second += 1;
+        fused_capacity = need > 0 && occ_ok ? std::min(max_engines, std::min(budget_regs / need, need_lds > 0 ? budget_lds / need_lds : 1 << 20)) : 0;
+        if (!occ_ok || need <= 0 || d.engines + 1 > max_engines || d.regs + need > budget_regs || d.lds + need_lds > budget_lds) return;
+        fused_share = need; fused_lds = need_lds; cp_fused_slot = true;
+        d.regs += fused_share; d.lds += fused_lds; d.engines += 1;
     }
     void fused_release() {
         if (!cp_fused_slot) return;
         auto& r = fused_registry();
         std::lock_guard<std::mutex> lk(r.m);
         auto& d = r.dev[fused_device];
-        d.first -= fused_share; d.second -= 1;
-        cp_fused_slot = false; fused_share = 0;
+        d.regs -= fused_share; d.lds -= fused_lds; d.engines -= 1;
+        cp_fused_slot = false; fused_share = 0; fused_lds = 0;
     }
     // after a give-up: this engine runs the separate launches from now on (graphs that baked the fused launch in are dropped)
     void fused_retire() {
         ++cp_fused_giveups;
-        cp_attn_o_env = false; cp_mlp_env = false;
+        cp_attn_o_env = false; cp_mlp_env = false; cp_layer_env = false;
         fused_release();
         destroy_graph();
         graph_nodes = 0;
@@ -591,15 +648,24 @@ void qtts_talker::finalize() {
     // write complete rows, so no half of a split-K projection is pending anywhere in passes >= 1
     const bool ao_f32 = !bf16 && cp_mlp_env && QTTS_OPT_SET("QTTS_CP_ATTN_O_F32");
     const bool want_ao = (bf16 || ao_f32) && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0;
+    // the layer launch (cp_layer.hip) needs both fused stages, its instantiation, and a contiguous page table (the engine's always is)
+    bool want_layer = cp_layer_env && want_ao && cp_mlp_env && cp_layer_instantiated(cd.H, cd.I, bf16);
     if (want_ao || cp_mlp_env) {      // one admission for the engine's fused launches
         int grid_cp = 0;
         bool occ_ok = true;
         if (want_ao) { grid_cp = std::max(grid_cp, cp_attn_o_grid(cd.H)); occ_ok = occ_ok && cp_attn_o_blocks_per_cu(!bf16) >= 1; }
         if (cp_mlp_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp_blocks_per_cu(cd.H, cd.I, bf16) >= 1; }
-        fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE : CP_SHARE_F32);
+        if (want_layer && cp_layer_blocks_per_cu(cd.H, cd.I, bf16) < 1) want_layer = false;      // (also sets the kernels' dynamic-LDS attribute, outside any capture)
+        if (want_layer) fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE_LAYER : CP_SHARE_LAYER_F32, cp_layer_lds_bytes(cd.H, cd.I, bf16),
+                                    CU_REG_BUDGET - CU_REG_BUDGET / 8, CU_LDS_BUDGET - CU_LDS_BUDGET / 8);
+        if (!cp_fused_slot) {         // no room for (or no) layer launch: the two launches' smaller shares
+            want_layer = false;
+            fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE : CP_SHARE_F32, CP_LDS_TWO_LAUNCHES);
+        }
     }
     if (!want_ao || !cp_fused_slot) cp_attn_o_env = false;
     if (!cp_fused_slot) cp_mlp_env = false;
+    cp_layer_env = want_layer && cp_fused_slot;
     tl.resize(c.num_hidden_layers);
     for (int l = 0; l < c.num_hidden_layers; ++l) build_layer(tl[l], "model.layers." + std::to_string(l) + ".", td, true);
     cl.resize(c.cp_num_hidden_layers);
@@ -738,6 +804,10 @@ void qtts_talker::finalize() {
         QTTS_CHECK_HIP(hipMemset(ao_qkv.p, 0, ao_qkv.bytes));
         QTTS_CHECK_HIP(hipMemset(ao_part.p, 0, ao_part.bytes));
     }
+    if (cp_layer_env && mlp_act.p && ao_part.p) {
+        cp_hid.alloc((size_t)CP_HID_SLOTS * 8 * (bf16 ? cd.H / 2 : cd.H) * 8);
+        QTTS_CHECK_HIP(hipMemset(cp_hid.p, 0, cp_hid.bytes));
+    }
     n_pad_d.alloc(R * 4); suppress.alloc(c.vocab_size); seed_d.alloc(8);
     QTTS_CHECK_HIP(hipMemset(ss_rows.p, 0, ss_rows.bytes));
     int* ip = ints.as<int>();
@@ -871,7 +941,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
                              int max_frames, hipStream_t st) {
     const auto& c = cfg;
     const int G = c.num_code_groups;
-    const int64_t fused_before = cp_attn_o_count, mlp_before = cp_mlp_count;
+    const int64_t fused_before = cp_attn_o_count, mlp_before = cp_mlp_count, layer_before = cp_layer_count;
     // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
     cur_stack = 1;
     for (int j = 0; j < G - 1; ++j) {
@@ -960,6 +1030,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     if (!skinny_only) sample_talker(sp, eos, min_new, max_new, st);
     cp_fused_per_step = (int)(cp_attn_o_count - fused_before);      // (a captured step replays exactly these launches)
     cp_mlp_per_step = (int)(cp_mlp_count - mlp_before);
+    cp_layer_per_step = (int)(cp_layer_count - layer_before);
 }
 
 // ============================================================================================ C ABI
@@ -1379,7 +1450,7 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     out->cp_fused_launches_last = (int64_t)out->cp_fused_per_step * t->frames_run;
     out->cp_fused_giveups = t->cp_fused_giveups; out->cp_fused_capacity = t->fused_capacity; out->cp_fused_active = t->cp_fused_slot ? 1 : 0;
     out->cp_mlp_per_step = t->cp_fused_slot ? t->cp_mlp_per_step : 0;
-    out->reserved2_ = 0;
+    out->cp_layer_per_step = t->cp_fused_slot ? t->cp_layer_per_step : 0;
     QTTS_API_END
 }
 int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n) {

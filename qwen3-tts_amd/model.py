@@ -181,13 +181,13 @@ class Qwen3TTSForConditionalGeneration:
                  dtype: torch.dtype = torch.bfloat16, max_batch: int = 8, max_seq: int = 4096,
                  use_graph: bool = True):
         self.config = TalkerConfig.from_any(config)
-        self.device = torch.device(device)
         self.dtype = dtype
         sd = state_dict
         if any(k.startswith("talker.") for k in sd):
             sd = {k[len("talker."):]: v for k, v in sd.items() if k.startswith("talker.")}
         self.talker = TalkerEngine(self.config, sd, weight_dtype=dtype, device=device, max_batch=max_batch,
                                    max_seq=max_seq, use_graph=use_graph)
+        self.device = self.talker.device            # (the HIP device the engine accepted: `_lib.hip_device` refuses anything else)
         if "model.text_embedding.weight" not in sd:
             raise KeyError("state_dict has no talker.model.text_embedding.weight (needed by the prompt assembly)")
         self.speech_tokenizer = None
@@ -252,6 +252,30 @@ class Qwen3TTSForConditionalGeneration:
             self.speaker_encoder = SpeakerEncoderEngine(self._speaker_config, self._speaker_state, compute_dtype=torch.float32,
                                                         device=str(self.device), max_samples=cap)
         return self.speaker_encoder.extract_speaker_embedding(audio, sr)
+
+    SPEAKER_BATCH = 8                       # clips per speaker-encoder call (the engine's workspace is sized for it)
+
+    def extract_speaker_embeddings(self, audios: List[np.ndarray], sr: int) -> List[torch.Tensor]:
+        """`extract_speaker_embedding` (M:1941-1954) for a LIST of 24 kHz waveforms -- what `create_voice_clone_prompt` (IM:356-458)
+        computes clip by clip.  Clips of EQUAL length run through the log-mel front end and the ECAPA-TDNN as one batch of up to
+        SPEAKER_BATCH rows, ragged clips are bucketed by exact length (`SpeakerEncoderEngine.embed_many`); the batched rows equal the
+        clip-by-clip ones (GPU test).  The result list is in the order of `audios`."""
+        assert sr == 24000, "Only support 24kHz audio"
+        if not self._speaker_state:
+            raise NotImplementedError("this checkpoint has no `speaker_encoder.*` weights (only the Base model does)")
+        arrs = [np.asarray(a, dtype=np.float32).reshape(-1) for a in audios]
+        if not arrs:
+            return []
+        n = max(a.shape[0] for a in arrs)
+        if self.speaker_encoder is None or n > self.speaker_encoder.max_samples or self.speaker_encoder.max_batch < min(self.SPEAKER_BATCH, len(arrs)):
+            from .speaker import SpeakerEncoderEngine
+            cap = max(30 * 24000, -(-n // 240000) * 240000)
+            if self.speaker_encoder is not None:
+                cap = max(cap, self.speaker_encoder.max_samples)
+            self.speaker_encoder = None
+            self.speaker_encoder = SpeakerEncoderEngine(self._speaker_config, self._speaker_state, compute_dtype=torch.float32,
+                                                        device=str(self.device), max_batch=self.SPEAKER_BATCH, max_samples=cap)
+        return self.speaker_encoder.embed_many(arrs)
 
     # ------------------------------------------------------------------ generate (seam S1)
     @torch.no_grad()
@@ -547,10 +571,15 @@ class Qwen3TTSModel:
             ref_codes = [self.model.speech_tokenizer.encode(w, sr=sr).audio_codes[0] for w, sr in normalized]
         items = []
         spk_sr = int(self.model.speaker_encoder_sample_rate)
-        for (wav, sr), code, rtext, xv in zip(normalized, ref_codes, texts, xvecs):
-            wav24 = wav if sr == spk_sr else audio_io.resample(wav, sr, spk_sr)                      # IM:440-444
-            items.append(VoiceClonePromptItem(ref_code=None if xv else code,
-                                              ref_spk_embedding=self.model.extract_speaker_embedding(audio=wav24, sr=spk_sr),
+        wav24 = [wav if sr == spk_sr else audio_io.resample(wav, sr, spk_sr) for wav, sr in normalized]          # IM:440-444
+        # the reference embeds clip by clip (IM:446-447); here clips of equal length share a launch sequence (round 6: 74 % of this
+        # call was the speaker encoder running eight times) -- a row's embedding does not depend on its neighbours
+        if hasattr(self.model, "extract_speaker_embeddings"):
+            spk = self.model.extract_speaker_embeddings(wav24, spk_sr)
+        else:                                   # (a model object without the batched entry point: `attach()`-style stand-ins)
+            spk = [self.model.extract_speaker_embedding(audio=w, sr=spk_sr) for w in wav24]
+        for code, rtext, xv, emb in zip(ref_codes, texts, xvecs, spk):
+            items.append(VoiceClonePromptItem(ref_code=None if xv else code, ref_spk_embedding=emb,
                                               x_vector_only_mode=bool(xv), icl_mode=bool(not xv), ref_text=rtext))
         return items
 

@@ -131,6 +131,24 @@ class SpeakerEncoderEngine:
                                                     C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return out
 
+    def embed_many(self, audios) -> list:
+        """A LIST of 24 kHz waveforms -> their x-vectors, in order.  Clips of EQUAL length run as one batch of up to `max_batch` rows
+        (every row keeps its own time statistics -- the squeeze-excitation means and the attentive pooling are per row -- so a row's
+        x-vector does not depend on its neighbours); clips of other lengths form their own groups: padding a clip would change its
+        statistics, so ragged clips are bucketed by exact length."""
+        arrs = [np.asarray(a, dtype=np.float32).reshape(-1) for a in audios]
+        groups: Dict[int, list] = {}
+        for i, a in enumerate(arrs):
+            groups.setdefault(a.shape[0], []).append(i)
+        out = [None] * len(arrs)
+        for idx in groups.values():
+            for k in range(0, len(idx), self.max_batch):
+                part = idx[k:k + self.max_batch]
+                emb = self.embed(torch.from_numpy(np.stack([arrs[i] for i in part])))
+                for r, i in enumerate(part):
+                    out[i] = emb[r]
+        return out
+
     def extract_speaker_embedding(self, audio: np.ndarray, sr: int) -> torch.Tensor:
         """M:1941-1954: one waveform -> (enc_dim,)."""
         assert sr == self.config.sample_rate, "Only support 24kHz audio"

@@ -152,3 +152,26 @@ def test_sampled_path_body_on_the_emulator(glue):
     assert ev1["worst_u_gap"] <= 2e-5
     ev0 = glue._sampled_path_body("cpu", t, w, torch.float32, False, 4, 1, 3, None)
     assert ev0["draws"] == 12
+
+
+def test_speaker_embed_many_buckets_by_length_python_path(glue):
+    """Round 6 (`create_voice_clone_prompt`, IM:440-455: the reference embeds clip by clip): `SpeakerEncoderEngine.embed_many` runs clips of
+    equal length as one batch of up to max_batch rows and buckets ragged clips by exact length -- in the callers' order, every row equal to
+    the same clip embedded on its own (a row's x-vector does not depend on its neighbours), and equal to the oracle."""
+    import synth
+    import speaker_ref
+    from qwen3_tts_amd.speaker import SpeakerEncoderEngine
+    c = synth.speaker_small()
+    w = synth.speaker_weights(c)
+    n = 4096
+    eng = SpeakerEncoderEngine(synth.cfg_dict(c), glue._td(w), compute_dtype=torch.float32, device="cpu", max_batch=3, max_samples=n)
+    a = synth.rand_audio(7, 6, n)
+    clips = [a[0], a[1][:3000], a[2], a[3], a[4][:3000], a[5]]          # lengths 4096 x 4 (two calls: 3 + 1) and 3000 x 2
+    many = [e.numpy() for e in eng.embed_many(clips)]
+    assert len(many) == 6
+    for i, clip in enumerate(clips):
+        solo = eng.embed(torch.from_numpy(clip[None])).numpy()[0]
+        assert np.abs(solo - many[i]).max() <= 1e-5, i
+    with torch.no_grad():
+        ref = speaker_ref.extract_speaker_embedding(glue._td(w), c, clips[1], 24000).numpy()
+    assert np.abs(ref - many[1]).max() <= 2e-4 * max(1.0, float(np.abs(ref).max()))

@@ -817,6 +817,46 @@ def test_fused_mlp_equals_the_two_launches_on_the_frame_step(dev, golden_dir):
         assert agree >= 0.85 and ag >= pg - 0.03
 
 
+def test_whole_layer_launch_equals_the_two_fused_launches_bit_for_bit(dev, golden_dir):
+    """`cp_layer_kernel` (round 6, csrc/cp_layer.hip): q|k|v GEMM, attention, o-projection, gate|up, SwiGLU and down-projection of a
+    code-predictor layer in ONE launch -- cp_attn_o's and cp_mlp's stages with the launch boundary between them replaced by a granule
+    hand-off of the hidden rows and the gate|up block requested at kernel entry by LDS-DMA.  The arithmetic and every summation order are
+    those of the two launches, so on the hardware, through the whole frame step (0.6B dims, batch 8 and batch 3, bf16, 40 frames
+    teacher-forced, captured frame graph): (1) `cp_layer_per_step` says which path ran; (2) three runs are identical; (3) the engine's own
+    choices AND its talker hidden states equal those of the same engine with QTTS_CP_LAYER=0 BIT FOR BIT -- every hand-off delivered
+    complete values and the DMA'd operator block is the operator; (4) free-running sampled generation (the bench's mode) is identical too."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    cfg = synth.talker_06b()
+    g = np.load(os.path.join(golden_dir, "talker_06b_b8.npz"))
+    wn = synth.talker_weights(cfg, with_text=False)
+    lens = [int(x) for x in g["lens"]]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+    gc = torch.from_numpy(g["codes"][:, :40].copy())
+    per_step = (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers
+    for nb in (len(lens), 3):
+        res, free = {}, {}
+        for flag in ("1", "0"):
+            with _qlib.options(QTTS_CP_LAYER=flag):
+                eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=nb, max_seq=256, use_graph=True)
+                res[flag] = [eng.generate(emb[:nb], mask[:nb], tr[:nb], pad, teacher_codes=gc[:nb], suppress_tokens=_suppress(cfg)).own.cpu().numpy()
+                             for _ in range(3 if flag == "1" else 1)]
+                o = eng.generate(emb[:nb], mask[:nb], tr[:nb], pad, max_new_tokens=30, min_new_tokens=30, seed=5, suppress_tokens=_suppress(cfg))
+                free[flag] = (o.codes.cpu().numpy(), o.hidden.cpu().numpy())
+                st = eng.stats()
+                assert st["cp_fused_active"] == 1 and st["cp_fused_giveups"] == 0 and st["cp_mlp_per_step"] == per_step and st["cp_fused_per_step"] == per_step, st
+                assert st["cp_layer_per_step"] == (per_step if flag == "1" else 0), st
+                nodes = st["graph_nodes"]
+                del eng
+                torch.cuda.empty_cache()
+            res[flag + "n"] = nodes
+        f, p2 = res["1"], res["0"]
+        assert np.array_equal(f[0], f[1]) and np.array_equal(f[0], f[2]), f"batch {nb}: the layer launch is not run-to-run identical"
+        assert np.array_equal(f[0], p2[0]), f"batch {nb}: the layer launch differs from the two fused launches ({float((f[0] != p2[0]).mean()):.4f} of the decisions)"
+        assert np.array_equal(free["1"][0], free["0"][0]) and np.array_equal(free["1"][1], free["0"][1]), f"batch {nb}: sampled free-running generation differs"
+        assert res["0n"] - res["1n"] == per_step, (res["0n"], res["1n"])
+        print(f"cp_layer vs cp_attn_o + cp_mlp (0.6B, {nb} x 40 frames teacher-forced + 29 sampled frames): bit-identical; frame graph {res['1n']} nodes ({res['0n']} as two launches per layer)")
+
+
 def test_fused_launch_under_contention_codec_stream_and_other_engines(dev, golden_dir):
     """VERDICT r4 item 1(c).  The fused launches wait, inside a launch, for workgroups of the same launch -- so what happens when the device
     is busy with other work?  0.6B dims, batch 8, 40 frames teacher-forced, captured frame graphs; the engine under test generates (a)
@@ -1503,6 +1543,34 @@ def test_speaker_encoder_released_dims_vs_reference_golden(dev, golden_dir):
     assert emb.shape == (2, 2048) and err <= 2e-4 * max(1.0, float(np.abs(ref).max()))
     one = eng.extract_speaker_embedding(x[1].numpy(), 24000).cpu().numpy()
     assert np.abs(one - emb[1]).max() <= 1e-4
+    # round 6: `create_voice_clone_prompt` embeds equal-length clips as batches (SpeakerEncoderEngine.embed_many; the reference loops clip by
+    # clip, IM:440-455): ten clips of three lengths through a batch-8 engine -- in order, each within 2e-4 of the golden / its own single-clip
+    # result (a row's x-vector does not depend on its neighbours), fp32 and bf16 timed
+    big = SpeakerEncoderEngine(synth.cfg_dict(c), _td(w), compute_dtype=torch.float32, device=dev, max_batch=8, max_samples=n)
+    xs = synth.rand_audio(int(g["seed"]), 2, n)
+    more = synth.rand_audio(91, 8, n)
+    clips = [xs[0], more[0][: n - 4800], xs[1], more[1], more[2][: n - 4800], more[3], more[4], more[5][: n // 2], more[6], more[7]]
+    many = [e.cpu().numpy() for e in big.embed_many(clips)]
+    assert len(many) == len(clips) and np.abs(many[0] - ref[0]).max() <= 2e-4 * max(1.0, float(np.abs(ref).max())) and np.abs(many[2] - ref[1]).max() <= 2e-4 * max(1.0, float(np.abs(ref).max()))
+    worst = 0.0
+    for i in (1, 3, 7, 9):
+        solo = big.embed(torch.from_numpy(clips[i][None])).cpu().numpy()[0]
+        worst = max(worst, float(np.abs(solo - many[i]).max()))
+    assert worst <= 1e-4, worst
+    eight = torch.from_numpy(more).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        big.embed(eight)
+    torch.cuda.synchronize()
+    ms8 = 1e3 * (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter()
+    for _ in range(5):
+        for i in range(8):
+            big.embed(eight[i:i + 1])
+    torch.cuda.synchronize()
+    ms1 = 1e3 * (time.perf_counter() - t0) / 5
+    print(f"speaker encoder, 8 x 3 s fp32: one batch {ms8:.2f} ms, clip by clip {ms1:.2f} ms; batched rows vs single-clip rows: max diff {worst:.2e}")
 
 
 @pytest.mark.parametrize("graph", [False, True])

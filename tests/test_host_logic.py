@@ -888,6 +888,22 @@ def test_fused_launches_fit_their_register_shares(libqtts):
     assert n_f32 >= 5
     src = open(os.path.join(ROOT, "qwen3-tts_amd", "csrc", "talker_engine.hip")).read()
     assert "CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 272;" in src
+    # round 6: the layer launch (cp_layer.hip) -- both stages in the two launches' register share (bf16; 360 with the operators in registers in
+    # fp32), and the account's second resource, LDS: dynamic (65 KB with the gate|up block at the released dims: two workgroups per compute unit
+    # with an eighth of the LDS to spare, not three)
+    rows = [k for k in ks if "cp_layer_kernel" in k[".name"]]
+    assert len(rows) >= 6, [k[".name"] for k in rows]
+    for k in rows:
+        regs = (k[".vgpr_count"] + 7) // 8 * 8
+        f32 = "cp_layer_kernelILb0ELb1E" in k[".name"] or "cp_layer_kernelILb1ELb1E" in k[".name"]      # (<QKV, F32 = true, ...>)
+        assert k[".max_flat_workgroup_size"] == 256 and regs <= (360 if f32 else 184), (k[".name"], regs)
+        assert k.get(".private_segment_fixed_size", 0) == 0, k[".name"]
+    assert "CP_SHARE_LAYER = 184, CP_SHARE_LAYER_F32 = 360, CU_LDS_BUDGET = 160 * 1024" in src
+    lay = open(os.path.join(ROOT, "qwen3-tts_amd", "csrc", "cp_layer.hip")).read()
+    assert "static constexpr int GU = F32 ? 0 : KQ * 4 * 4 * 2 * ACT * 16;" in lay
+    gu, att, mlp = 8 * 4 * 4 * 2 * 12 * 16, 4 * 1536 + 2 * 264 * 2 + 2 * 128 * 4 + (4 * 64 * 16 + 4 * 16 * 4), (4 * 64 * 2 * 16 + 4 * 16 * 4) + 4 * 2 * 64 * 16
+    assert "static constexpr int TOTAL = GU + (ATT > MLP ? ATT : MLP);" in lay
+    assert 2 * (gu + max(att, mlp)) <= 160 * 1024 * 7 // 8 < 3 * (gu + max(att, mlp))
 
 
 def test_option_table_through_the_c_abi(libqtts):

@@ -1694,6 +1694,8 @@ def test_talker_fp32_split_k_layer_chain_vs_oracle(emu, qopt, cp_mlp):
         want = (t.num_code_groups - 2) * t.cp_num_hidden_layers if cp_mlp != "0" else 0
         assert st.cp_mlp_per_step == want and st.cp_fused_per_step == (want if cp_mlp == "both" else 0) and st.cp_fused_giveups == 0, (st.cp_mlp_per_step, st.cp_fused_per_step)
         assert st.cp_fused_active == (1 if cp_mlp != "0" else 0) and st.cp_fused_capacity == (512 // 272 if cp_mlp != "0" else 0)
+        # round 6: with both stages fused the whole layer is ONE launch (cp_layer_kernel<.., true, ...>: the merged construction's bit-exact leg)
+        assert st.cp_layer_per_step == (want if cp_mlp == "both" else 0), st.cp_layer_per_step
     finally:
         emu.qtts_talker_destroy(h)
 
@@ -1792,6 +1794,51 @@ def test_talker_bf16_fused_mlp_in_the_frame_step(emu, qopt):
     k = int(np.argmin(same)) if not same.all() else n
     assert k >= 1
     assert np.abs(fused[1][:, :k] - plain[1][:, :k]).max() <= 2e-2 * max(1.0, float(np.abs(plain[1][:, :k]).max()))
+
+
+@pytest.mark.parametrize("cp_hidden,cp_inter", [(256, 1024), (1024, 3072)])
+def test_talker_bf16_whole_layer_as_one_launch_in_the_frame_step(emu, qopt, cp_hidden, cp_inter):
+    """Round 6: the ENGINE side of `cp_layer_kernel` (csrc/cp_layer.hip) -- both fused stages of a code-predictor layer in ONE launch: the
+    hidden rows between the o-projection's reducers and the MLP's phase A travel as tagged granules (a fifth granule buffer), the
+    workgroup's gate|up block arrives by LDS-DMA, the MLP's reducer is the o-projection's (the residual stays in its registers).  Same
+    arithmetic, same summation orders as the two launches: greedy bf16 frames AND hidden states must equal those of the same engine
+    with QTTS_CP_LAYER=0 BIT FOR BIT (256-wide predictor: the q|k|v GEMM stays a launch of its own, eager and captured; 1024-wide = the
+    released width: with the q|k|v front inside the launch, captured), `cp_layer_per_step` says which path ran, and a second generation
+    on the same handle (five granule buffers re-used, serial advanced) repeats the first."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=cp_hidden, cp_intermediate_size=cp_inter, cp_num_hidden_layers=2,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(61), t, [5, 3, 6], 2, scale=0.5)
+    args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
+    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+    per_step = (t.num_code_groups - 2) * t.cp_num_hidden_layers
+    emu.hostemu_set_real_gemm(1)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            qopt(emu, "QTTS_CP_LAYER", mode)
+            for use_graph in ((0, 1) if cp_hidden == 256 else (1,)):
+                h = _talker_emu(emu, t, w, max_batch=4, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=use_graph)
+                try:
+                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=4)
+                    if mode == "1":
+                        codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=4)
+                        assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2), (mode, use_graph)
+                    st = _lib.TalkerStatsC()
+                    _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+                    assert st.cp_layer_per_step == (per_step if mode == "1" else 0), (mode, st.cp_layer_per_step)
+                    assert st.cp_mlp_per_step == per_step and st.cp_fused_per_step == per_step and st.cp_fused_giveups == 0
+                    assert st.cp_fused_capacity == 2
+                    res[(mode, use_graph)] = (codes, hidden)
+                finally:
+                    emu.qtts_talker_destroy(h)
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
+    ref = res[("0", 1)]
+    assert ref[0].shape[1] >= 2
+    for k, v in res.items():
+        assert np.array_equal(v[0], ref[0]) and np.array_equal(v[1], ref[1]), f"QTTS_CP_LAYER={k[0]}, graph {k[1]}: differs from the two launches"
 
 
 def test_fused_code_predictor_launch_is_admitted_per_device_by_residency(emu, qopt):

@@ -15,6 +15,11 @@ from qwen3_tts_amd.talker import TalkerEngine
 
 CONFIGS = {
     "default": {},
+    "cp_layer_off": {"QTTS_CP_LAYER": "0"},      # round 6: the layer as its two fused launches (round 5's frame step)
+    "layer_gu_entry": {"QTTS_CP_LAYER_GU_WHEN": "0"}, "layer_gu_wo": {"QTTS_CP_LAYER_GU_WHEN": "1"},        # the gate|up block's LDS-DMA at entry / behind the o-projection operator's requests (default: behind the attention stage)
+    "layer_hid0": {"QTTS_CP_LAYER_HID_MODE": "0"}, "layer_hid2": {"QTTS_CP_LAYER_HID_MODE": "2"},           # hidden rows: every wave polls its whole quarter / sentinels + a read the L2 may serve (default 1: sentinels + one sc1 read)
+    "layer_h8": {"QTTS_CP_LAYER_PAUSE_H": "8"}, "layer_h12": {"QTTS_CP_LAYER_PAUSE_H": "12"}, "layer_h20": {"QTTS_CP_LAYER_PAUSE_H": "20"},
+    "layer_h24": {"QTTS_CP_LAYER_PAUSE_H": "24"}, "layer_h32": {"QTTS_CP_LAYER_PAUSE_H": "32"}, "layer_h4": {"QTTS_CP_LAYER_PAUSE_H": "4"},
     "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
     "f32_fused_mlp": {"QTTS_CP_MLP_F32": "1"},
     "f32_fused_both": {"QTTS_CP_MLP_F32": "1", "QTTS_CP_ATTN_O_F32": "1"},     # ... and cp_attn_o_kernel<.., .., true>: every launch of passes >= 1 fused       # --dtype f32: cp_mlp_kernel<true, ...> against the fp32 split-K plan (the default there)
@@ -69,7 +74,7 @@ def main():
             res[n].append(round(ms, 4))
             st = eng.stats()
             print(f"[ab_inproc] rep {rep} {n:28s} {ms:.3f} ms/frame   (graph nodes {st['graph_nodes']}, fused launches per step: attention {st['cp_fused_per_step']}, "
-                  f"mlp {st['cp_mlp_per_step']})", flush=True)
+                  f"mlp {st['cp_mlp_per_step']}, whole layer {st.get('cp_layer_per_step', 0)})", flush=True)
             del eng; gc.collect(); torch.cuda.empty_cache()
     out = {n: {"ms_per_frame": v, "min": min(v), "median": float(np.median(v))} for n, v in res.items()}
     print(json.dumps(out))

@@ -32,7 +32,7 @@ CAP = 1 << 15
 
 def drain():
     out = []
-    for unit in ("skinny", "attn", "sample", "cpmlp"):
+    for unit in ("skinny", "attn", "sample", "cpmlp", "cplayer"):
         fn = getattr(lib, f"qtts_debug_tslog_{unit}")
         fn.argtypes = [C.c_void_p, C.c_int]; fn.restype = C.c_int
         buf = np.zeros(CAP, dtype=REC)
@@ -72,12 +72,13 @@ print(f"{len(r)} records ({'eager' if a.no_graph else 'hipGraph'} launches, batc
 TICK_US = 0.01                                  # s_memrealtime: 100 MHz
 order = np.argsort(r["t"][:, 0], kind="stable")
 r = r[order]
-KIND = {0: "decode GEMM", 1: "attn_cp", 2: "attn_tk", 3: "sampler", 4: "cp_attn_o", 5: "cp_mlp"}
+KIND = {0: "decode GEMM", 1: "attn_cp", 2: "attn_tk", 3: "sampler", 4: "cp_attn_o", 5: "cp_mlp", 6: "cp_layer"}
 PHASES = {0: ["issued", "arrived", "mfma+lds", "barrier", "stored"],
           1: ["issued", "arrived", "normed", "barrier", "stored"],
           2: ["arrived", "normed", "keys folded", "barrier", "stored"],
           3: ["arrived", "bound", "ranked", "drawn", "rows out"],
           4: ["arrived", "attended", "published", "ticket", "reduced"],
+          6: ["o part out", "hidden in", "act out", "part out", "reduced"],      # (round 6: the whole layer in one launch; blk bit 16 = a reducer)
           5: ["A mfma", "act out", "slice in", "part out", "reduced"]}      # (round 5: the fused MLP launch; blk bit 16 = a reducer of XCD 7)      # (round 4: attention + o-projection in one launch; blk bit 16 = the chunk's last arriver)
 # boundary: entry of a launch minus the latest stamp of any record of the launch before it.  Two records (first / last
 # workgroup) of one launch share (kind, a, b) and lie within 2 us of each other.
@@ -98,18 +99,18 @@ l_pitch = np.full(n_l, np.nan); l_pitch[1:] = (l_entry[1:] - l_entry[:-1]) * TIC
 for i in range(len(r)): gap[i] = l_gap[launch_id[i]]
 
 rows = []
-keys = sorted({(int(k), int(x), int(y)) for k, x, y in zip(r["kind"], r["a"], r["b"]) if k not in (1, 2, 4, 5)})
-keys += [(1, -1, 0), (2, -1, 0), (4, -1, 0), (4, -1, 1), (5, -1, 0), (5, -1, 1)]        # the attentions: all cache lengths together; cp_attn_o: other workgroups | last arrivers
+keys = sorted({(int(k), int(x), int(y)) for k, x, y in zip(r["kind"], r["a"], r["b"]) if k not in (1, 2, 4, 5, 6)})
+keys += [(1, -1, 0), (2, -1, 0), (4, -1, 0), (4, -1, 1), (5, -1, 0), (5, -1, 1), (6, -1, 0), (6, -1, 1)]        # the attentions: all cache lengths together; cp_attn_o: other workgroups | last arrivers
 for key in keys:
     k = key[0]
     sel = (r["kind"] == k) if key[1] < 0 else ((r["kind"] == k) & (r["a"] == key[1]) & (r["b"] == key[2]))
-    if k in (4, 5): sel = sel & ((r["blk"] >> 16) == key[2])
+    if k in (4, 5, 6): sel = sel & ((r["blk"] >> 16) == key[2])
     if not sel.any(): continue
     rr = r[sel]
     ph = (rr["t"][:, 1:].astype(np.float64) - rr["t"][:, :1].astype(np.float64)) * TICK_US
     ph[rr["t"][:, 1:] == 0] = np.nan
     g = gap[sel]; g = g[np.isfinite(g) & (g < 20)]
-    name = KIND[k] + (f" K={key[1]} N={key[2]}" if k == 0 else (f" V={key[1]}" if k == 3 else ((" (last arriver)" if key[2] else " (others)") if k == 4 else ((" (reducer, XCD 7)" if key[2] else " (others)") if k == 5 else ""))))
+    name = KIND[k] + (f" K={key[1]} N={key[2]}" if k == 0 else (f" V={key[1]}" if k == 3 else ((" (last arriver)" if key[2] else " (others)") if k == 4 else ((" (reducer, XCD 7)" if key[2] else " (others)") if k == 5 else ((" (reducer)" if key[2] else " (others)") if k == 6 else "")))))
     rows.append(dict(kernel=name, records=int(sel.sum()), phases_us={n: round(float(np.nanmean(ph[:, j])), 2) for j, n in enumerate(PHASES[k])},
                      in_kernel_us=round(float(np.nanmean(np.nanmax(ph, axis=1))), 2),
                      boundary_us_median=round(float(np.median(g)), 2) if len(g) else None))
@@ -125,6 +126,10 @@ if (l_kind == 4).any():       # the fused launch ends with its slowest reducer: 
 if (l_kind == 5).any():
     ln = (l_end - l_entry)[l_kind == 5] * TICK_US
     print(f"cp_mlp launch length (first logged entry -> last stamp of any logged workgroup): mean {ln.mean():.2f} us, median {np.median(ln):.2f}, "
+          f"p90 {np.percentile(ln, 90):.2f}, max {ln.max():.2f}, n={len(ln)}")
+if (l_kind == 6).any():
+    ln = (l_end - l_entry)[l_kind == 6] * TICK_US
+    print(f"cp_layer launch length (first logged entry -> last stamp of any logged workgroup): mean {ln.mean():.2f} us, median {np.median(ln):.2f}, "
           f"p90 {np.percentile(ln, 90):.2f}, max {ln.max():.2f}, n={len(ln)}")
 fin = l_pitch[np.isfinite(l_pitch) & (l_pitch < 30)]
 print(f"launch pitch (entry to entry, instrumented launches that follow one another): median {np.median(fin):.2f} us, mean {fin.mean():.2f} us, n={len(fin)}")
