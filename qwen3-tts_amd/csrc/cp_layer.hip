@@ -180,18 +180,24 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
     // the workgroup's block of the gate|up operator -> LDS, each wave the k quarter it will multiply (read back by the same wave only)
     constexpr int GU_WAVE = KQ * 4 * 2 * ACT * 16;      // bytes per wave
     static_assert(F32 || GU_WAVE % 1024 == 0, "cp_layer: a wave's gate|up block must be whole 1-KiB DMA requests");
-    auto dma_gu = [&] {
+    // `pace` (x 64 clocks between requests): 224 workgroups requesting 11 MB at one moment is a burst the reducers' small reads queue behind
+    auto dma_gu = [&](int pace) {
         if constexpr (!F32) {
             const unsigned char* src = reinterpret_cast<const unsigned char*>(P.mlp.Wgu) + ((size_t)b_ * 4 + wave) * GU_WAVE + lane * 16;
 #pragma unroll
-            for (int i = 0; i < GU_WAVE / 1024; ++i) cl_dma16(src + i * 1024, gu_lds + wave * GU_WAVE + i * 1024);
+            for (int i = 0; i < GU_WAVE / 1024; ++i) {
+                cl_dma16(src + i * 1024, gu_lds + wave * GU_WAVE + i * 1024);
+                if (pace > 0) wt_first_pause(pace);
+            }
         }
     };
     // when: 2 (default) -- behind the attention stage (after the partial o-projection is published / the hidden rows are: the workgroup then
     // waits >= 1.6 us for the hidden rows, longer than the block takes to arrive); requested at entry (0) or behind the o-projection's
     // operator (1) the 12.6 MB of a launch compete with the strips and with Wo: the attention stage ran 1.5-2 us late (profiles/r06_cp_layer.md)
-    const int gu_when = (ph == CL_ALL && att_wg) ? P.gu_when : 0;
-    if (run2 && gu_when == 0) dma_gu();
+    // The REDUCERS (32 of the 256 workgroups; everybody's phase B waits for their phase A) request theirs behind the o-projection's operator: their
+    // 1.5 MB are no burst, and their way from the hidden rows' publication to their own phase A stays free.
+    const int gu_when = (ph == CL_ALL && att_wg) ? ((P.gu_when == 2 && reducer) ? (QKV ? 1 : 0) : P.gu_when) : 0;
+    if (run2 && gu_when == 0) dma_gu(0);
     const int done = p.done_flag ? *p.done_flag : 0;
     if (done) return;
     // ================================================================================================ stage 0: the q|k|v strip
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
     if (run1 && att_wg) {
         if constexpr (QKV) {
             load_wo();                                 // arrives while this workgroup waits for its rows and attends
-            if (gu_when == 1) dma_gu();
+            if (gu_when == 1) dma_gu(0);
             const WtBuf qg = wt_buf(P.ao.qkv_gran, (size_t)8 * p.ld * 8);
             int cols[3] = {(g * 2 + hh) * HD, (p.nh + g) * HD, (p.nh + p.nkv + g) * HD};
             uint2 gq[3][2], gn[3][2];
@@ -397,8 +403,8 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             }
         }
         QTTS_TS(1);
-        if (gu_when == 1 && !QKV) dma_gu();
-        if (gu_when == 2 && !reducer) dma_gu();
+        if (gu_when == 1 && !QKV) dma_gu(0);
+        if (gu_when == 2) dma_gu(P.gu_pace);
         // ============================================================================================ stage 2: the o-projection's reducers -> hidden rows
         if (reducer) {
             __syncthreads();                                 // (its own partial sum is in LDS)
@@ -454,7 +460,6 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             }
         }
     }
-    if (run2 && gu_when == 2 && reducer) dma_gu();
     if (!run2 && !run3 && !run4) return;
     // ================================================================================================ stage 3: phase A (gate|up over the hidden rows)
     constexpr int KTM = F32 ? 16 : 32;
@@ -520,6 +525,20 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
                 for (int h2 = 0; h2 < 2; ++h2) fresh = fresh && d[ks][h2][1] == tag && d[ks][h2][3] == tag;
             return fresh;
         };
+        // (bf16) the gate|up tiles: LDS -> registers while the first read of the hidden rows is in flight -- the DMA requests are older than that
+        // read, so "all but the newest 2 KQ requests" covers them; phase A then runs from registers as cp_mlp_kernel's does (second timeline:
+        // with the LDS reads inside the MFMA loop, hidden rows in -> act published took 1.5 us against cp_mlp's 0.5)
+        cu32x4 wg_l[F32 ? 1 : KQ], wu_l[F32 ? 1 : KQ];
+        auto preload_gu = [&] {
+            if constexpr (!F32) {
+#pragma unroll
+                for (int ks = 0; ks < KQ; ++ks) {
+                    const unsigned char* wl = gu_lds + ((size_t)((wave * KQ + ks) * 4 + lq) * (2 * ACT) + (li < ACT ? li : 0)) * 16;
+                    wg_l[ks] = *reinterpret_cast<const cu32x4*>(wl);
+                    wu_l[ks] = *reinterpret_cast<const cu32x4*>(wl + ACT * 16);
+                }
+            }
+        };
         wt_first_pause(P.pause_h);
         if (P.hid_mode != 0) {
             uint2 sv = wt_load8(hgs, soff);
@@ -534,6 +553,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             }
             if (P.hid_mode == 2) load_hid_cached(cur); else load_hid(cur);
         } else load_hid(cur);
+        if constexpr (!F32) { cl_dma_wait<2 * KQ>(); preload_gu(); }
         for (int spins = 0;; ++spins) {                   // (hid_mode 0: the polling loop; otherwise it runs through once unless a granule lags its sentinel)
             if (all_fresh(cur)) break;
             if (spins > GRANULE_SPIN_LIMIT) { cl_give_up(P); break; }
@@ -541,7 +561,6 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
             load_hid(cur);
         }
         QTTS_TS(2);
-        if constexpr (!F32) cl_dma_wait<0>();            // (the gate|up block was requested long ago and every later read has come back; this wave reads back its own requests)
         f32x4 ag4 = (f32x4){0.f, 0.f, 0.f, 0.f}, au4 = (f32x4){0.f, 0.f, 0.f, 0.f};
         float ssq = 0.f;
 #pragma unroll
@@ -559,8 +578,7 @@ __global__ __launch_bounds__(256) void cp_layer_kernel(const void* k0, const voi
                     au4 = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(u4[e]), xe, au4, 0, 0, 0);
                 }
             } else {
-                const unsigned char* wl = gu_lds + ((size_t)((wave * KQ + ks) * 4 + lq) * (2 * ACT) + (li < ACT ? li : 0)) * 16;
-                cu32x4 g4 = *reinterpret_cast<const cu32x4*>(wl), u4 = *reinterpret_cast<const cu32x4*>(wl + ACT * 16);
+                cu32x4 g4 = wg_l[ks], u4 = wu_l[ks];
                 if (li >= ACT) { g4 = (cu32x4){0u, 0u, 0u, 0u}; u4 = g4; }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

@@ -303,6 +303,7 @@ struct CpLayerParams {
     int hid_slot;                 // which region of hid_gran this launch uses (the engine: ao.slot -- a region is touched once per frame)
     int hid_mode;                 // 0: every wave polls its whole k quarter; 1: sentinel granules, then one sc1 read; 2: ... one read the L2 may serve
     int pause_h;                  // x 64 clocks: a workgroup's wait before its first read of the hidden rows
+    int gu_pace;                  // x 64 clocks between the DMA requests of a workgroup that requests behind the attention stage (0: back to back)
     int gu_when;                  // the gate|up block's LDS-DMA: 2 behind the attention stage; 0 at kernel entry, 1 behind the o-projection operator's requests (A/B)
     int phase;                    // 8: the whole kernel.  0..4 (host emulator, or a test): one stage alone
 };

@@ -240,6 +240,7 @@ struct qtts_talker {
     int cp_layer_pause_h = [] { const char* e = QTTS_ENV("QTTS_CP_LAYER_PAUSE_H"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 16; }();   // (A/B: x 64 clocks)
     int cp_layer_gu_when = QTTS_OPT_INT("QTTS_CP_LAYER_GU_WHEN", 2);
     int cp_layer_hid_mode = QTTS_OPT_INT("QTTS_CP_LAYER_HID_MODE", 1);
+    int cp_layer_gu_pace = QTTS_OPT_INT("QTTS_CP_LAYER_GU_PACE", 0);
     static constexpr int CP_HID_SLOTS = 128;            // one region of the hidden-row granules per launch slot (position x layer)
     DevBuf cp_hid;                     // [8 rows][H / 2] granules {2 x bf16 hidden, tag} (fp32 engines: [8][H] {fp32, tag})
     int64_t cp_layer_count = 0;
@@ -389,7 +390,7 @@ struct qtts_talker {
             m.B = M; m.H = d.H; m.I = d.I;
             m.first_pause = cp_mlp_pause_b; m.pause_c = cp_mlp_pause_c; m.poll_step = cp_mlp_step;
             cl.hid_gran = cp_hid.as<float>(); cl.hid_slot = f.slot; cl.hid_mode = cp_layer_hid_mode;
-            cl.pause_h = cp_layer_pause_h; cl.gu_when = cp_layer_gu_when; cl.phase = 8;
+            cl.pause_h = cp_layer_pause_h; cl.gu_when = cp_layer_gu_when; cl.gu_pace = cp_layer_gu_pace; cl.phase = 8;
             if (timing_now) {          // bench.py's roofline leg: timed on its own (stack 5: the layer launch, every operator of the layer)
                 const double eb = bf16 ? 2.0 : 4.0;
                 LaunchEv e{nullptr, nullptr, 5, front ? a.ld + d.H + 3 * d.I : d.H + 3 * d.I, d.H,
@@ -567,10 +568,10 @@ struct qtts_talker {
     // pass L would otherwise share its tag with layer 0 of pass L + 1 and a consumer could take a stale granule as fresh).
     static constexpr int CP_FUSED_MAX_LAYERS = 5;
     static constexpr int CU_REG_BUDGET = 512, CP_SHARE = 184, CP_SHARE_F32 = 272;     // (fp32 engines: the F32 instantiations hold twice the operand registers -- one engine per device)
-    // Round 6: the layer launch (cp_layer.hip) runs both stages in the two launches' register share (176 of 184 in bf16; 360 with the operators
+    // Round 6: the layer launch (cp_layer.hip) runs both stages in the two launches' register share + 8 (192 in bf16; 360 with the operators
     // in registers in fp32) and holds 65 KB of LDS per workgroup (the gate|up block requested by LDS-DMA): the account has a SECOND resource,
     // a compute unit's 160 KB of LDS (a register-only account over-admits the moment a fused launch stages operands in LDS).
-    static constexpr int CP_SHARE_LAYER = 184, CP_SHARE_LAYER_F32 = 360, CU_LDS_BUDGET = 160 * 1024, CP_LDS_TWO_LAUNCHES = 17 * 1024;
+    static constexpr int CP_SHARE_LAYER = 192, CP_SHARE_LAYER_F32 = 360, CU_LDS_BUDGET = 160 * 1024, CP_LDS_TWO_LAUNCHES = 17 * 1024;
     struct FusedDev { int regs = 0, lds = 0, engines = 0; };
     struct FusedRegistry { std::mutex m; std::map<int, FusedDev> dev; };        // device -> (register share, LDS bytes in use, fused engines)
     static FusedRegistry& fused_registry() { static FusedRegistry r; return r; }
@@ -585,7 +586,9 @@ struct qtts_talker {
     // engine) leave room beside two engines for the short waves of other streams.  The first layer kernel (256 registers, 77 KB of LDS) fitted
     // twice EXACTLY -- and then any short wave that lands on a compute unit keeps a pending workgroup out until it has left, while the resident
     // workgroups of both launches wait for the pending ones: on the MI355X two such engines beside a codec stream and a third engine ran into
-    // a give-up (profiles/r06_cp_layer.md).  So layer engines are admitted only while an eighth of the register file AND of the LDS stays free.
+    // a give-up (profiles/r06_cp_layer.md).  Nor did the second version (192 registers, 65 KB): two layer engines alone ran clean, two beside a codec
+    // stream and a third engine gave up again, a layer engine beside a two-launch engine and the same neighbours did not (tools/diag_layer_pair.py).
+    // So layer engines may take HALF a compute unit's LDS together -- one per device -- and 7/8 of its registers; the next engine takes the two launches.
     void fused_admit(int grid_cp, bool occ_ok, int share, int lds, int budget_regs = CU_REG_BUDGET, int budget_lds = CU_LDS_BUDGET) {
         QTTS_CHECK_HIP(hipGetDevice(&fused_device));
         int cus = 0;
@@ -657,7 +660,7 @@ void qtts_talker::finalize() {
         if (cp_mlp_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp_blocks_per_cu(cd.H, cd.I, bf16) >= 1; }
         if (want_layer && cp_layer_blocks_per_cu(cd.H, cd.I, bf16) < 1) want_layer = false;      // (also sets the kernels' dynamic-LDS attribute, outside any capture)
         if (want_layer) fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE_LAYER : CP_SHARE_LAYER_F32, cp_layer_lds_bytes(cd.H, cd.I, bf16),
-                                    CU_REG_BUDGET - CU_REG_BUDGET / 8, CU_LDS_BUDGET - CU_LDS_BUDGET / 8);
+                                    CU_REG_BUDGET - CU_REG_BUDGET / 8, CU_LDS_BUDGET / 2);
         if (!cp_fused_slot) {         // no room for (or no) layer launch: the two launches' smaller shares
             want_layer = false;
             fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE : CP_SHARE_F32, CP_LDS_TWO_LAUNCHES);
@@ -1439,6 +1442,10 @@ int qtts_debug_xcc_map(int32_t grid, int32_t* out_host, void* stream) {
     QTTS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     QTTS_CHECK_HIP(hipMemcpy(out_host, d.p, (size_t)grid * 4, hipMemcpyDeviceToHost));
     QTTS_API_END
+}
+// DIAGNOSTIC (not in include/qtts.h): workgroups of the layer launch one compute unit holds at once, by the occupancy API
+int qtts_debug_cp_layer_occupancy(int32_t H, int32_t I, int32_t bf16) {
+    try { return qtts::cp_layer_blocks_per_cu(H, I, bf16 != 0); } catch (...) { return -1; }
 }
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     QTTS_API_BEGIN

@@ -896,9 +896,9 @@ def test_fused_launches_fit_their_register_shares(libqtts):
     for k in rows:
         regs = (k[".vgpr_count"] + 7) // 8 * 8
         f32 = "cp_layer_kernelILb0ELb1E" in k[".name"] or "cp_layer_kernelILb1ELb1E" in k[".name"]      # (<QKV, F32 = true, ...>)
-        assert k[".max_flat_workgroup_size"] == 256 and regs <= (360 if f32 else 184), (k[".name"], regs)
+        assert k[".max_flat_workgroup_size"] == 256 and regs <= (360 if f32 else 192), (k[".name"], regs)
         assert k.get(".private_segment_fixed_size", 0) == 0, k[".name"]
-    assert "CP_SHARE_LAYER = 184, CP_SHARE_LAYER_F32 = 360, CU_LDS_BUDGET = 160 * 1024" in src
+    assert "CP_SHARE_LAYER = 192, CP_SHARE_LAYER_F32 = 360, CU_LDS_BUDGET = 160 * 1024" in src
     lay = open(os.path.join(ROOT, "qwen3-tts_amd", "csrc", "cp_layer.hip")).read()
     assert "static constexpr int GU = F32 ? 0 : KQ * 4 * 4 * 2 * ACT * 16;" in lay
     gu, att, mlp = 8 * 4 * 4 * 2 * 12 * 16, 4 * 1536 + 2 * 264 * 2 + 2 * 128 * 4 + (4 * 64 * 16 + 4 * 16 * 4), (4 * 64 * 2 * 16 + 4 * 16 * 4) + 4 * 2 * 64 * 16

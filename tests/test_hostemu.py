@@ -1829,7 +1829,7 @@ def test_talker_bf16_whole_layer_as_one_launch_in_the_frame_step(emu, qopt, cp_h
                     _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
                     assert st.cp_layer_per_step == (per_step if mode == "1" else 0), (mode, st.cp_layer_per_step)
                     assert st.cp_mlp_per_step == per_step and st.cp_fused_per_step == per_step and st.cp_fused_giveups == 0
-                    assert st.cp_fused_capacity == 2
+                    assert st.cp_fused_capacity == (1 if mode == "1" and cp_hidden == 1024 else 2)      # (layer engines may take half a compute unit's LDS together: one per device at the released dims -- 65 KB per workgroup)
                     res[(mode, use_graph)] = (codes, hidden)
                 finally:
                     emu.qtts_talker_destroy(h)

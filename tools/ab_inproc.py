@@ -18,6 +18,7 @@ CONFIGS = {
     "cp_layer_off": {"QTTS_CP_LAYER": "0"},      # round 6: the layer as its two fused launches (round 5's frame step)
     "layer_gu_entry": {"QTTS_CP_LAYER_GU_WHEN": "0"}, "layer_gu_wo": {"QTTS_CP_LAYER_GU_WHEN": "1"},        # the gate|up block's LDS-DMA at entry / behind the o-projection operator's requests (default: behind the attention stage)
     "layer_hid0": {"QTTS_CP_LAYER_HID_MODE": "0"}, "layer_hid2": {"QTTS_CP_LAYER_HID_MODE": "2"},           # hidden rows: every wave polls its whole quarter / sentinels + a read the L2 may serve (default 1: sentinels + one sc1 read)
+    "layer_pace2": {"QTTS_CP_LAYER_GU_PACE": "2"}, "layer_pace4": {"QTTS_CP_LAYER_GU_PACE": "4"}, "layer_pace8": {"QTTS_CP_LAYER_GU_PACE": "8"},       # x 64 clocks between the gate|up block's DMA requests (default 0: back to back)
     "layer_h8": {"QTTS_CP_LAYER_PAUSE_H": "8"}, "layer_h12": {"QTTS_CP_LAYER_PAUSE_H": "12"}, "layer_h20": {"QTTS_CP_LAYER_PAUSE_H": "20"},
     "layer_h24": {"QTTS_CP_LAYER_PAUSE_H": "24"}, "layer_h32": {"QTTS_CP_LAYER_PAUSE_H": "32"}, "layer_h4": {"QTTS_CP_LAYER_PAUSE_H": "4"},
     "cp_mlp_off": {"QTTS_CP_MLP": "0"},          # round 5: the code predictor's MLP as two decode GEMMs (round 4's frame step)
