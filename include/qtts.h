@@ -46,8 +46,9 @@ const char* qtts_last_error(void);
  * 3: + qtts_codec_stream_begin, qtts_codec_stream_push; 4: + qtts_encoder_*; 5: + qtts_speaker_*;
  * 6: + qtts_talker_stream_*; 7: + qtts_talker_set_teacher; 8: + qtts_talker_set_profile / get_gemm_profile;
  * 9: + qtts_codec_get_stats; 10: + qtts_set_option / qtts_get_option, qtts_talker_stats grew the fused-launch fields;
- * 11: + qtts_talker_debug_cp_logits, qtts_talker_stats.cp_layer_per_step in the reserved word). */
-#define QTTS_ABI_VERSION 11
+ * 11: + qtts_talker_debug_cp_logits, qtts_talker_stats.cp_layer_per_step in the reserved word;
+ * 12: + qtts_talker_stats.ks_split_per_step (appended)). */
+#define QTTS_ABI_VERSION 12
 int qtts_abi_version(void);
 
 /* A/B switches of the library (measuring tools and tests; a deployment sets none).  Every switch has a name of the form
@@ -403,6 +404,9 @@ typedef struct {
     int32_t cp_mlp_per_step;        /* fused MLP launches (cp_mlp.hip: gate|up + SwiGLU + down of a code-predictor layer; bf16 and fp32) in that frame step */
     int32_t cp_layer_per_step;      /* of those, the launches that ran BOTH stages of a layer as one (cp_layer.hip, round 6): they count in cp_fused_per_step
                                      * and cp_mlp_per_step too.  (ABI v11: the former reserved word.)                                        */
+    int32_t ks_split_per_step;      /* decode GEMMs of that frame step that split K over workgroups and combine inside the launch (skinny.hip: skinny2_ks_kernel;
+                                     * bf16 engines at batch 17..32: the o- / down-projections; ABI v12)                                       */
+    int32_t reserved0;
 } qtts_talker_stats;
 int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out);
 /* Per-class result of the profile mode (qtts_talker_set_profile(t, 1), ABI v8): every launch of the decode GEMM in frames 1..6

@@ -70,7 +70,8 @@ class TalkerStatsC(C.Structure):
                 ("gemm_ms_last", C.c_double), ("gemm_launches_last", C.c_int64), ("long_graphs", C.c_int32),
                 ("attn_nsplit_last", C.c_int32), ("attn_span_last", C.c_int32), ("cp_fused_per_step", C.c_int32),
                 ("cp_fused_launches_last", C.c_int64), ("cp_fused_giveups", C.c_int32), ("cp_fused_capacity", C.c_int32),
-                ("cp_fused_active", C.c_int32), ("cp_mlp_per_step", C.c_int32), ("cp_layer_per_step", C.c_int32)]
+                ("cp_fused_active", C.c_int32), ("cp_mlp_per_step", C.c_int32), ("cp_layer_per_step", C.c_int32),
+                ("ks_split_per_step", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class CodecStatsC(C.Structure):
@@ -82,7 +83,7 @@ class GemmClassC(C.Structure):
                 ("min_us", C.c_double), ("max_us", C.c_double), ("bytes_per_launch", C.c_double)]
 
 
-ABI_VERSION = 11          # include/qtts.h; bumped on any signature change
+ABI_VERSION = 12          # include/qtts.h; bumped on any signature change
 
 # every symbol include/qtts.h declares (checked by tests/test_host_logic.py::test_abi_exports_every_declared_symbol without a GPU)
 SYMBOLS = ["qtts_last_error", "qtts_abi_version", "qtts_set_option", "qtts_get_option", "qtts_codec_create", "qtts_codec_destroy", "qtts_codec_bind",

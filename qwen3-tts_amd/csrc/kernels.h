@@ -83,6 +83,14 @@ struct SkinnyParams {
     const float* xp;             // consumer: x is formed as xp[0] + xp[1] (= residual + half 0, half 1), at xp and xp + xp_stride, [M][ldx]; `x` is not read
     size_t xp_stride;
     float* x_out;                //    ... and workgroup 0 writes the combined rows here (outside the halves)
+    // bf16, batch 17..32, plain GEMM without norm (round 6: skinny2_ks_kernel): K split over the workgroups of a 32-feature strip group, the
+    // partial sums handed to the group's LAST workgroup as tagged granules (granule.h) and added there in k order
+    float* ks_part;              // granule workspace (null: no split) ...
+    size_t ks_part_bytes;        // ... and its size
+    const int* ks_serial;        // device: the frame serial the tags derive from (null: serial 1 -- tests)
+    int ks_slot;                 // this launch's slot among the frame's split launches, < 256: tag = serial << 8 | slot
+    int ks_pause;                // x 64 clocks: the reducer's wait before its first read of the others' granules
+    int* ks_err; int* ks_latch;  // raised by a reducer that gave up (the engine's flag, the generation's stop flag)
     const int* done_flag;        // optional device flag: when non-zero the kernel exits early
     int ablate;                  // `ablate` build variant only (-DQTTS_ABLATE; must be 0 in the product build): 1 no done check, 2 no x loads, 4 no epilogue loads, 8 no weight loads
 };
@@ -91,6 +99,7 @@ void skinny_set_launch_events(hipEvent_t start, hipEvent_t stop);   // (bench.py
 bool skinny_takes_bf16_x(int M, int K, bool bf16);   // bf16 mode: any M <= 64, K % 32 == 0
 bool skinny_f32_inline_norm(int M, int K);
 bool skinny_f32_splitk_takes(int M, int K_producer, int K_consumer);   // fp32 mode: producer may split K in two, its consumer combines            // fp32 mode: the batch <= 8 kernel takes the RMSNorm row statistics itself (no ss_in)
+bool skinny_ksplit_takes(int M, int N, int K, int fs);   // bf16, batch 17..32: the split-K kernel has an instantiation for this (strip width, shape)
 bool skinny_swiglu8_takes(int K);                     // ACT_SWIGLU8 (batch <= 8 kernel): K = 1024 | 2048 | 3072 | 6144
 size_t skinny_packed_bytes(int N, int K, bool bf16);
 // Pack W[N][K] (row-major f32), optionally scaled per input column by g[K], into the streaming tile layout;

@@ -26,6 +26,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "tstamp.h"
+#include "granule.h"
 #include <hip/hip_ext.h>
 
 QTTS_TS_UNIT(skinny)
@@ -311,6 +312,198 @@ __global__ __launch_bounds__(NW * 64) void skinny2_kernel(SkinnyParams p) {
     }
     QTTS_TS_DRAINED(5);                    // stores acknowledged
     QTTS_TS_END(skinny, 0, p.K, p.N);
+}
+
+// ------------------------------------------------------------------------------------------ bf16, batch 17..32, deep K: split-K (round 6)
+// At batch 17..32 (two 16-row tiles of x) a workgroup of skinny2_kernel pulls M x K x 2 B of x whatever its strip width: the talker's
+// down-projection (K = 6144, 256 workgroups of ONE 8-feature strip) moves 393 KB of x against 98 KB of weights per workgroup -- 100 MB
+// of L2 -> CU traffic for a 25 MB operator, 14.5 us per launch against 5.7 us at batch 8 (profiles/r03_skinny_b32_straight.md).  The x
+// traffic of a launch is (N / features per workgroup) x M x K x 2 B: only WIDER workgroups cut it, and then too few of them are left to
+// pull the operator.  So: a workgroup owns 32 features (SPW strips of the packing's FS) and 1 / KS of K -- the same 256 workgroups,
+// a quarter (an eighth) of the x bytes each -- and the KS partial sums of a strip group are combined inside the launch:
+//   * workgroups ks < KS - 1 store their sums as tagged 8-byte granules {fp32, tag} (write-through, granule.h) and leave;
+//   * the group's LAST workgroup (ks = KS - 1, the highest block index of the group) reads them until they carry the launch's tag, adds
+//     p0 + p1 + ... + its own in k order (fixed: run-to-run identical), + bias + residual, and writes the rows (fp32 + bf16 shadow).
+// Tag = frame serial << 8 | launch slot (the engine numbers the split launches of a frame; a granule left by an earlier launch has
+// another tag).  Producers never wait and have lower block indices than their reducer -- workgroups are dispatched in index order -- so a
+// reducer's producers are running or done whenever it polls: no residency account is needed (unlike the all-to-all hand-offs of
+// cp_attn_o / cp_mlp).  A reducer that never sees its tags (GRANULE_SPIN_LIMIT re-reads) raises the engine's flag and latches the
+// generation's stop flag, as the fused launches do.
+// No RMSNorm (o- and down-projections have none), no SwiGLU.  Every request of the launch is issued at entry (straight-line, TPW k-tiles
+// per wave); wave w of the workgroup combines and publishes / reduces (strip, m-tile) pair w, w + NW, ...
+// (tstamp build: thread 0 of the first workgroup -- a producer -- and of the last -- a reducer, blk bit 16 -- append a record of kind 7)
+#if QTTS_TSTAMP
+#define QTTS_KS_TS_END(red_)                                                                                                 \
+    do {                                                                                                                     \
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {                                          \
+            const unsigned i_ = atomicAdd(&qtts::ts_cnt_skinny, 1u);                                                         \
+            if (i_ < qtts::TS_CAP) {                                                                                         \
+                qtts::TsRec r_;                                                                                              \
+                for (int k_ = 0; k_ < 6; ++k_) r_.t[k_] = ts_[k_];                                                           \
+                r_.kind = 7; r_.a = p.K; r_.b = p.N; r_.blk = (int)blockIdx.x | ((red_) << 16);                              \
+                qtts::ts_log_skinny[i_] = r_;                                                                                \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#else
+#define QTTS_KS_TS_END(red_) do { } while (0)
+#endif
+template <int SPW, int FS, int NW, int TPW, int KS>
+__global__ __launch_bounds__(NW * 64) void skinny2_ks_kernel(SkinnyParams p) {
+    constexpr int MT = 2, KT = 32, NP = SPW * MT, PPW = (NP + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sk[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem_sk);             // [NW][NP][64]
+    QTTS_TS_BEGIN();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int sg = blockIdx.x / KS, ks = blockIdx.x - sg * KS;
+    const int nkt = p.K / KT;
+    const int kt0 = ks * (NW * TPW) + wave;                      // this wave's tiles: kt0 + NW i
+    const int strip0 = sg * SPW;
+    const bool wlane = lj < FS;
+    const bool reducer = ks == KS - 1;
+
+    u32x4 wR[TPW][SPW], xR[TPW][MT];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) wR[i][s] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xR[i][m] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    if (FS == 16 || wlane) {                                     // one exec mask for the weight requests (lanes that own a weight row)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+            for (int s = 0; s < SPW; ++s)
+                wR[i][s] = skinny_wload(reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)(strip0 + s) * nkt + kt0 + NW * i) * (FS * 4) + lq * FS + (wlane ? lj : 0));
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        if (m * 16 + lj < p.M) {                                 // ... and one per m-tile for its x requests
+            const unsigned short* xp = reinterpret_cast<const unsigned short*>(p.x) + (size_t)(m * 16 + lj) * p.ldx + lq * 8;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) xR[i][m] = *reinterpret_cast<const u32x4*>(xp + (size_t)(kt0 + NW * i) * KT);
+        }
+    // the reducer's epilogue operands, under the weight stream
+    f32x4 resv[PPW], biasv[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        resv[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; biasv[j] = resv[j];
+        const int pr = wave + NW * j, s = pr / MT, m = pr - s * MT;
+        const int row = m * 16 + lj, col = (strip0 + s) * FS + lq * 4;
+        if (reducer && pr < NP && row < p.M && lq * 4 < FS) {
+            if (p.res) resv[j] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+            if (p.bias) biasv[j] = *reinterpret_cast<const f32x4*>(p.bias + col);
+        }
+    }
+    const unsigned serial = p.ks_serial ? (unsigned)*p.ks_serial : 1u;
+    const int done = p.done_flag ? *p.done_flag : 0;
+    QTTS_TS(1);
+    if (done) return;
+    QTTS_TS_DRAINED(2);
+    const unsigned tag = (serial << 8) | (unsigned)p.ks_slot;
+
+    f32x4 acc[SPW][MT];
+#pragma unroll
+    for (int s = 0; s < SPW; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            bf16x8 xb;
+            *reinterpret_cast<u32x4*>(&xb) = xR[i][m];
+#pragma unroll
+            for (int s = 0; s < SPW; ++s) {
+                bf16x8 wa;
+                *reinterpret_cast<u32x4*>(&wa) = wR[i][s];
+                acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb, acc[s][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+    for (int s = 0; s < SPW; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) red[(wave * NP + s * MT + m) * 64 + lane] = acc[s][m];
+    QTTS_TS_DRAINED(3);
+    __syncthreads();
+
+    const WtBuf part = wt_buf(p.ks_part, p.ks_part_bytes);
+    f32x4 own[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pr = wave + NW * j;
+        own[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (pr < NP) {
+            f32x4 t = red[(0 * NP + pr) * 64 + lane];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) t += red[(w2 * NP + pr) * 64 + lane];     // fixed order
+            own[j] = t;
+            if (!reducer) {
+                const int off = (((int)blockIdx.x * NP + pr) * 64 + lane) * 32;
+                wt_store16(part, off, (cu32x4){__float_as_uint(t[0]), tag, __float_as_uint(t[1]), tag});
+                wt_store16(part, off + 16, (cu32x4){__float_as_uint(t[2]), tag, __float_as_uint(t[3]), tag});
+            }
+        }
+    }
+    if (!reducer) { QTTS_TS_DRAINED(4); QTTS_KS_TS_END(0); return; }
+    // ---- the group's last workgroup: the other KS - 1 partial sums, in k order
+    wt_first_pause(p.ks_pause);
+    cu32x4 g[PPW][KS - 1][2];
+    auto load_all = [&] {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+#pragma unroll
+            for (int k2 = 0; k2 < KS - 1; ++k2) {
+                const int pr = wave + NW * j < NP ? wave + NW * j : 0;
+                const int off = (((sg * KS + k2) * NP + pr) * 64 + lane) * 32;
+                g[j][k2][0] = wt_load16(part, off);
+                g[j][k2][1] = wt_load16(part, off + 16);
+            }
+    };
+    auto all_fresh = [&]() -> bool {
+        bool f = true;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+#pragma unroll
+            for (int k2 = 0; k2 < KS - 1; ++k2)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) f = f && g[j][k2][h][1] == tag && g[j][k2][h][3] == tag;
+        return __ballot(!f) == 0;                                  // (a wave re-reads together: one request stream)
+    };
+    load_all();
+    for (int spins = 0; !all_fresh(); ++spins) {
+        if (spins > GRANULE_SPIN_LIMIT) {
+            if (p.ks_err) __hip_atomic_store(p.ks_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.ks_latch) __hip_atomic_store(p.ks_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        // (the re-read must stay IN the loop: raw buffer loads are read-only intrinsics, and a loop without a store lets the compiler hoist them --
+        // the first build polled once and span on the stale registers; the clobber and the sleep's side effect pin them here)
+        asm volatile("" ::: "memory");
+        wt_first_pause(1);
+        load_all();
+    }
+    QTTS_TS(4);
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int pr = wave + NW * j, s = pr / MT, m = pr - s * MT;
+        const int row = m * 16 + lj, col = (strip0 + s) * FS + lq * 4;
+        if (pr >= NP || row >= p.M || lq * 4 >= FS) continue;
+        f32x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = __uint_as_float(g[j][0][r >> 1][(r & 1) * 2]);
+#pragma unroll
+        for (int k2 = 1; k2 < KS - 1; ++k2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] += __uint_as_float(g[j][k2][r >> 1][(r & 1) * 2]);
+        t += own[j];
+        skinny_store4(p, row, col, t + biasv[j] + resv[j], true);
+    }
+    QTTS_TS_DRAINED(5);
+    QTTS_KS_TS_END(1);
 }
 
 // ------------------------------------------------------------------------------------------ bf16, batch <= 8 (the benchmarked shape)
@@ -881,6 +1074,45 @@ static void launch_f32_mt(const SkinnyParams& p, int spw, int nw, hipStream_t st
     else         { if (spw == 2) launch_f32_one<MT, 2, 4>(p, st); else launch_f32_one<MT, 1, 4>(p, st); }
 }
 
+// batch 17..32, no norm, plain epilogue: the split-K kernel (round 6).  Instantiations = the o- and down-projections of the released
+// stacks under the engine's strip widths: 1 talker down 1.7B (N 2048, K 6144, fs 8), 2 down of the 1024-wide stacks (N 1024, K 3072,
+// fs 8), 3 talker o 1.7B (N 2048, K 2048, fs 16), 4 o of the 1024-wide stacks (N 1024, K 2048, fs 8).  QTTS_SKINNY_KS=0: skinny2_kernel;
+// QTTS_SKINNY_KS_MINK: the smallest K that splits.  Default 6144 -- the talker's down-projection only: 14.65 -> 10.7 us per launch, frame step at
+// batch 32 4.46 -> 4.31 ms (-3.4 %).  At K = 3072 (the 1024-wide stacks' down-projection, 8 parts) the combine costs what the split saves
+// (8.36 -> 8.9 us per launch: 4.39 ms), at K = 2048 it loses (4.55 ms): in-process A/B and timelines in profiles/r06_skinny_ksplit.md.
+static int ksplit_choice(int M, int N, int K, int fs) {
+    if (M <= 16 || M > 32 || N % 32 != 0 || K % 32 != 0) return 0;
+    const int groups = N / 32, nkt = K / 32, ks = groups >= 64 ? 4 : 8;
+    if (fs == 8 && ks == 4 && nkt == 4 * 8 * 6) return 1;
+    if (fs == 8 && ks == 8 && nkt == 8 * 4 * 3) return QTTS_OPT_INT("QTTS_SKINNY_KS_DOWN1024", 8) == 4 ? 5 : 2;      // (A/B: 4 parts of 8 waves x 3 tiles, 128 workgroups)
+    if (fs == 16 && ks == 4 && nkt == 4 * 8 * 2) return 3;
+    if (fs == 8 && ks == 8 && nkt == 8 * 8 * 1) return 4;
+    return 0;
+}
+bool skinny_ksplit_takes(int M, int N, int K, int fs) { return ksplit_choice(M, N, K, fs) != 0; }
+template <int SPW, int FS, int NW, int TPW, int KS>
+static void launch_ks_n(const SkinnyParams& p, hipStream_t st) {
+    const int grid = p.N / (FS * SPW) * KS;
+    const size_t lds = (size_t)NW * SPW * 2 * 64 * 16;
+    QTTS_REQUIRE((size_t)grid * SPW * 2 * 64 * 32 <= p.ks_part_bytes, QTTS_ERR_LIMIT, "skinny: the split-K workspace is too small for this launch");
+    QTTS_REQUIRE(p.ks_slot >= 0 && p.ks_slot < 256, QTTS_ERR_ARG, "skinny: split-K launch slot must be < 256");
+    auto kern = skinny2_ks_kernel<SPW, FS, NW, TPW, KS>;
+    if (lds > 48 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
+    QTTS_SK_LAUNCH(kern, dim3(grid), dim3(NW * 64), lds, st, p);
+}
+static bool launch_skinny_ks(const SkinnyParams& p, int fs, hipStream_t st) {
+    if (!p.ks_part || !p.x_bf16 || p.norm || p.act != ACT_NONE || p.out_bf16 || p.ksplit || QTTS_ABL(p, 15)) return false;
+    if (!QTTS_OPT_ON("QTTS_SKINNY_KS") || p.K < QTTS_OPT_INT("QTTS_SKINNY_KS_MINK", 6144)) return false;
+    switch (ksplit_choice(p.M, p.N, p.K, fs)) {
+        case 1: launch_ks_n<4, 8, 8, 6, 4>(p, st); return true;
+        case 2: launch_ks_n<4, 8, 4, 3, 8>(p, st); return true;
+        case 3: launch_ks_n<2, 16, 8, 2, 4>(p, st); return true;
+        case 4: launch_ks_n<4, 8, 8, 1, 8>(p, st); return true;
+        case 5: launch_ks_n<4, 8, 8, 3, 4>(p, st); return true;
+        default: return false;
+    }
+}
+
 static int skinny_spw(int N, int fs, bool swiglu) {
     if (swiglu) return 2;
     return (fs == 16 && N / 16 >= 1024 && (N / 16) % 2 == 0) ? 2 : 1;
@@ -1063,6 +1295,7 @@ void launch_skinny(const SkinnyParams& p, bool bf16, hipStream_t st) {
     const int nw = (p.K / KT >= 16) ? 8 : 4;     // 8 waves split K unless K is tiny
     const int mt = p.M <= 16 ? 1 : (p.M <= 32 ? 2 : 4);
     if (bf16 && nw == 8 && mt == 1 && launch_skinny8(p, spw, fs, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
+    if (bf16 && mt == 2 && launch_skinny_ks(p, fs, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
     if (!bf16 && !QTTS_ABL(p, 15) && launch_skinny8_f32(p, spw, st)) { QTTS_CHECK_HIP(hipGetLastError()); return; }
     if (bf16) {
         if (nw == 8) { if (mt == 1) launch2_mt<1, 8>(p, spw, fs, st); else if (mt == 2) launch2_mt<2, 8>(p, spw, fs, st); else launch2_mt<4, 8>(p, spw, fs, st); }

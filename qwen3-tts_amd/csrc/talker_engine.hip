@@ -323,6 +323,23 @@ struct qtts_talker {
     // last layer of a stack does not split its down-projection: the stack's output is complete where the caller reads it.
     DevBuf sk_part;                    // [2][8][H_max] floats (fp32 engines only)
     bool sk_pending = false;
+    // bf16 engines, batch 17..32 (round 6; BASELINE configs 4 and 5 run the frame step at batch 32): the o- and down-projections split K over the
+    // workgroups of a 32-feature strip group and combine the partial sums inside the launch (skinny.hip: skinny2_ks_kernel) -- a workgroup then
+    // pulls a quarter / an eighth of the x rows.  QTTS_SKINNY_KS=0 (copied at engine creation: captured graphs bake the choice in).  Launch slots
+    // (tags): talker layer l: 2 l (o), 2 l + 1 (down); code predictor (position, layer): 2 L_talker + 2 (position x layers + layer) + {0, 1}.
+    bool ks_split_env = QTTS_OPT_ON("QTTS_SKINNY_KS");
+    int ks_pause = QTTS_OPT_INT("QTTS_SKINNY_KS_PAUSE", 8);
+    DevBuf ks_part;                    // granule workspace of the split launches (one launch at a time uses it)
+    int64_t ks_split_count = 0;
+    int ks_split_per_step = 0;
+    int ks_mink = QTTS_OPT_INT("QTTS_SKINNY_KS_MINK", 6144);
+    void ks_arm(SkinnyParams& q, int slot) {
+        if (!ks_split_env || !ks_part.p || !bf16 || q.M <= 16 || q.M > 32 || slot < 0 || slot >= 256 || skinny_only) return;
+        if (q.K < ks_mink || !skinny_ksplit_takes(q.M, q.N, q.K, q.fs ? q.fs : 16)) return;
+        q.ks_part = ks_part.as<float>(); q.ks_part_bytes = ks_part.bytes; q.ks_serial = ss.frame_serial; q.ks_slot = slot; q.ks_pause = ks_pause;
+        q.ks_err = ss.n_generated + 5; q.ks_latch = ss.done;
+        ++ks_split_count;
+    }
     // one decoder layer on `M = n_new * B` rows of `xs` (in place)
     void decode_layer(const LayerW& L, const StackDims& d, float* xs, unsigned short* xs16, float* qkvb, float* attb,
                       float* actb, int M, int n_new, KvCache& kv, int layer, const int* len_dev, int len_static,
@@ -433,6 +450,8 @@ struct qtts_talker {
         o.x = attb; o.ldx = d.qd; o.M = M; o.Wp = L.o_p.p; o.N = d.H; o.K = d.qd; o.res = xs; o.ldr = d.H;
         o.out = xs; o.ldo = d.H; o.act = ACT_NONE; o.out16 = h16 ? xs16 : nullptr; o.fs = L.fs_o;
         if (splitk) { o.out = sk_part.as<float>(); o.ksplit = 2; o.part_stride = pstride; }     // (o.res = xs: half 0 = residual + its sums)
+        const int ks_slot0 = len_dev ? 2 * layer : 2 * (int)tl.size() + 2 * (len_static * (int)cl.size() + layer);
+        if (n_new == 1) ks_arm(o, ks_slot0);
         skinny(o, st);
         }
         // bf16 engines, code predictor passes >= 1 at batch <= 8: the MLP as ONE launch (cp_mlp.hip) instead of the two decode GEMMs below
@@ -472,6 +491,7 @@ struct qtts_talker {
         dn.x = actb; dn.ldx = d.I; dn.M = M; dn.Wp = L.d_p.p; dn.N = d.H; dn.K = d.I; dn.res = xs; dn.ldr = d.H;
         dn.out = xs; dn.ldo = d.H; dn.act = ACT_NONE; dn.out16 = h16 ? xs16 : nullptr; dn.fs = L.fs_d;
         if (splitk && !last_layer) { dn.out = sk_part.as<float>(); dn.ksplit = 2; dn.part_stride = pstride; sk_pending = true; }   // (dn.res = xs)
+        if (n_new == 1) ks_arm(dn, (len_dev ? 2 * layer : 2 * (int)tl.size() + 2 * (len_static * (int)cl.size() + layer)) + 1);
         skinny(dn, st);
     }
 
@@ -616,7 +636,7 @@ struct qtts_talker {
     // after a give-up: this engine runs the separate launches from now on (graphs that baked the fused launch in are dropped)
     void fused_retire() {
         ++cp_fused_giveups;
-        cp_attn_o_env = false; cp_mlp_env = false; cp_layer_env = false;
+        cp_attn_o_env = false; cp_mlp_env = false; cp_layer_env = false; ks_split_env = false;
         fused_release();
         destroy_graph();
         graph_nodes = 0;
@@ -795,6 +815,10 @@ void qtts_talker::finalize() {
         sk_part.alloc(2 * 8 * hmax * 4);
         QTTS_CHECK_HIP(hipMemset(sk_part.p, 0, sk_part.bytes));
     }
+    if (bf16 && c.max_batch > 16 && ks_split_env) {      // 256 workgroups x 8 (strip, m-tile) pairs x 64 lanes x 4 granules
+        ks_part.alloc((size_t)8 << 20);
+        QTTS_CHECK_HIP(hipMemset(ks_part.p, 0, ks_part.bytes));
+    }
     if (!cl.empty() && cl[0].gu_mlp.p) {
         mlp_act.alloc((size_t)8 * 8 * (cd.I / (bf16 ? 16 : 8)) * 8);
         mlp_part.alloc((size_t)8 * 8 * cd.H * 8);
@@ -944,7 +968,7 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
                              int max_frames, hipStream_t st) {
     const auto& c = cfg;
     const int G = c.num_code_groups;
-    const int64_t fused_before = cp_attn_o_count, mlp_before = cp_mlp_count, layer_before = cp_layer_count;
+    const int64_t fused_before = cp_attn_o_count, mlp_before = cp_mlp_count, layer_before = cp_layer_count, ks_before = ks_split_count;
     // ---- code predictor: G-1 dependent passes (M:1671-1680, 1250-1312)
     cur_stack = 1;
     for (int j = 0; j < G - 1; ++j) {
@@ -1034,6 +1058,16 @@ void qtts_talker::frame_step(const qtts_sampling& sp, int eos, int min_new, int 
     cp_fused_per_step = (int)(cp_attn_o_count - fused_before);      // (a captured step replays exactly these launches)
     cp_mlp_per_step = (int)(cp_mlp_count - mlp_before);
     cp_layer_per_step = (int)(cp_layer_count - layer_before);
+    ks_split_per_step = (int)(ks_split_count - ks_before);
+}
+
+// A blocking copy of the engine's run-time paths goes through the ENGINE'S stream, never the legacy stream: a `hipMemcpy` orders the legacy stream
+// behind every blocking stream of the process, and while ANOTHER engine's thread captures its frame step (thread-local capture mode) HIP refuses it
+// ("operation would make the legacy stream depend on a capturing blocking stream": bench.py --workload clone-shard with two engines per GPU hit it
+// in 2 of 4 runs on the MI355X in round 6).
+static void copy_on_stream(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    QTTS_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, kind, st));
+    QTTS_CHECK_HIP(hipStreamSynchronize(st));
 }
 
 // ============================================================================================ C ABI
@@ -1238,7 +1272,7 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
             (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipGraphExecDestroy(ge2); (void)hipGraphDestroy(g2);
             // the loop state is no longer meaningful: latch `done` with the one complete frame and stop
             int fin2[2] = {1, 2};
-            QTTS_CHECK_HIP(hipMemcpy(t->ss.done, fin2, sizeof(fin2), hipMemcpyHostToDevice));
+            copy_on_stream(t->ss.done, fin2, sizeof(fin2), hipMemcpyHostToDevice, st);
             done = 1;
             break;
         }
@@ -1267,17 +1301,17 @@ int qtts_talker_generate(qtts_talker* t, const qtts_sampling* sp, int32_t max_ne
     t->frames_run = f;
     if (t->profile == 1) t->aggregate_profile();
     int fin[6];
-    QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    copy_on_stream(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost, st);
     t->check_fused_flag(fin[5], "generate");
     QTTS_REQUIRE(fin[3] == 1, QTTS_ERR_STATE, "generate: loop ended without the stop condition being latched");
     *n_frames_host = fin[4] - 1;
     if (tokens_dev) {   // int32 history -> int64 (B, max_new_tokens)
         std::vector<int> h((size_t)B * max_new_tokens);
-        QTTS_CHECK_HIP(hipMemcpy(h.data(), t->generated.p, h.size() * 4, hipMemcpyDeviceToHost));
+        copy_on_stream(h.data(), t->generated.p, h.size() * 4, hipMemcpyDeviceToHost, st);
         std::vector<int64_t> w(h.size(), -1);
         for (int b = 0; b < B; ++b)
             for (int i = 0; i < fin[4]; ++i) w[(size_t)b * max_new_tokens + i] = h[(size_t)b * max_new_tokens + i];
-        QTTS_CHECK_HIP(hipMemcpy(tokens_dev, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+        copy_on_stream(tokens_dev, w.data(), w.size() * 8, hipMemcpyHostToDevice, st);
     }
     QTTS_API_END
 }
@@ -1373,7 +1407,7 @@ int qtts_talker_stream_step(qtts_talker* t, int32_t max_frames_now, int32_t* fra
     stream_launch_frames(t, max_frames_now, st);
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
     int fin[6];
-    QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    copy_on_stream(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost, st);
     if (fin[5]) g.active = false;                        // (no packet of a burst that lost a fused launch is handed out)
     t->check_fused_flag(fin[5], "stream_step");
     // frames whose codes are final: every launched step that ran before the latch; after the latch exactly final_count - 1
@@ -1391,7 +1425,7 @@ int qtts_talker_stream_end(qtts_talker* t, int64_t* tokens_dev, int32_t* n_frame
     auto& g = t->sg;
     QTTS_CHECK_HIP(hipStreamSynchronize(st));
     int fin[6];
-    QTTS_CHECK_HIP(hipMemcpy(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost));
+    copy_on_stream(fin, t->ss.n_generated, sizeof(fin), hipMemcpyDeviceToHost, st);
     g.active = false;
     t->check_fused_flag(fin[5], "stream_end");
     t->frames_run = g.launched;
@@ -1401,11 +1435,11 @@ int qtts_talker_stream_end(qtts_talker* t, int64_t* tokens_dev, int32_t* n_frame
     if (tokens_dev) {
         const int B = t->B, cap = g.max_new;
         std::vector<int> h((size_t)B * cap);
-        QTTS_CHECK_HIP(hipMemcpy(h.data(), t->generated.p, h.size() * 4, hipMemcpyDeviceToHost));
+        copy_on_stream(h.data(), t->generated.p, h.size() * 4, hipMemcpyDeviceToHost, st);
         std::vector<int64_t> w(h.size(), -1);
         for (int b = 0; b < B; ++b)
             for (int i = 0; i < n_tok && i < cap; ++i) w[(size_t)b * cap + i] = h[(size_t)b * cap + i];
-        QTTS_CHECK_HIP(hipMemcpy(tokens_dev, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+        copy_on_stream(tokens_dev, w.data(), w.size() * 8, hipMemcpyHostToDevice, st);
     }
     QTTS_API_END
 }
@@ -1458,6 +1492,7 @@ int qtts_talker_get_stats(qtts_talker* t, qtts_talker_stats* out) {
     out->cp_fused_giveups = t->cp_fused_giveups; out->cp_fused_capacity = t->fused_capacity; out->cp_fused_active = t->cp_fused_slot ? 1 : 0;
     out->cp_mlp_per_step = t->cp_fused_slot ? t->cp_mlp_per_step : 0;
     out->cp_layer_per_step = t->cp_fused_slot ? t->cp_layer_per_step : 0;
+    out->ks_split_per_step = t->ks_split_env ? t->ks_split_per_step : 0; out->reserved0 = 0;
     QTTS_API_END
 }
 int qtts_talker_get_gemm_profile(qtts_talker* t, qtts_gemm_class* out, int32_t cap, int32_t* n) {

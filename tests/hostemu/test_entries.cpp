@@ -138,6 +138,28 @@ extern "C" int hostemu_skinny_bf16x(const float* x, int ldx, int M, const float*
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
+// Round 6: the bf16 decode GEMM at batch 17..32 through the split-K kernel (skinny2_ks_kernel): `launches` launches in a row on ONE granule
+// workspace (0xFF-filled: no tag matches), each with its own slot -- the second and later ones find the previous launch's granules in place.
+// *took = 1 when the launcher has an instantiation for the shape (otherwise the launch ran skinny2_kernel).
+extern "C" int hostemu_skinny_ksplit(const float* x, int ldx, int M, const float* W, int N, int K, const float* bias, const float* res, int ldr,
+                                     float* out, int ldo, int fs, unsigned short* out16, int launches, int serial, int* took) {
+    try {
+        std::vector<unsigned char> wp(qtts::skinny_packed_bytes(N, K, true));
+        qtts::pack_skinny_weight(W, N, K, true, wp.data(), nullptr, fs);
+        std::vector<qtts::bf16_t> x16((size_t)M * ldx);
+        for (size_t i = 0; i < x16.size(); ++i) x16[i] = qtts::f32_to_bf16(x[i]);
+        std::vector<unsigned char> part((size_t)8 << 20, 0xFF);
+        int err = 0, latch = 0;
+        qtts::SkinnyParams p{};
+        p.x = reinterpret_cast<const float*>(x16.data()); p.x_bf16 = 1; p.ldx = ldx; p.M = M; p.Wp = wp.data(); p.N = N; p.K = K;
+        p.fs = fs; p.bias = bias; p.res = res; p.ldr = ldr; p.out = out; p.ldo = ldo; p.act = qtts::ACT_NONE; p.out16 = out16;
+        p.ks_part = reinterpret_cast<float*>(part.data()); p.ks_part_bytes = part.size(); p.ks_serial = &serial; p.ks_err = &err; p.ks_latch = &latch;
+        *took = qtts::skinny_ksplit_takes(M, N, K, fs) ? 1 : 0;
+        for (int l = 0; l < launches; ++l) { p.ks_slot = 3 + 7 * l; qtts::launch_skinny(p, true, nullptr); }
+        return err || latch ? -7 : 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
 // One launch of sampling.hip's sample_kernel on B rows of logits: HF processors (repetition penalty over `generated`,
 // min-new-tokens EOS block, suppress mask), temperature / top-k / top-p, Philox draw keyed by (seed, stream_id, step).
 extern "C" int hostemu_sample(const float* logits, int ld, int V, int B, const int* generated, int gen_stride, int n_generated,

@@ -718,6 +718,52 @@ def test_pair_kernel_equals_the_generic_decode_gemm_on_the_frame_step(dev, golde
     assert agree0 >= 0.97 and rel <= 5e-3
 
 
+def test_split_k_decode_gemm_at_batch_32_equals_the_unsplit_one_on_the_frame_step(dev, golden_dir):
+    """`skinny2_ks_kernel` (round 6; VERDICT r5 item 3: BASELINE configs 4 and 5 run the frame step at batch 32): the down-projections of the
+    talker (K = 6144) and of the code predictor's passes >= 1 (K = 3072) split K over the workgroups of a 32-feature strip group and add the
+    partial sums inside the launch, against `skinny2_kernel` (QTTS_SKINNY_KS=0) on the hardware through the whole frame step: 1.7B dims,
+    batch 32, bf16, the b32 golden's 43 frames teacher-forced with the reference's codes, captured frame graph.  (1) `ks_split_per_step`
+    says which path ran (28 talker layers + 14 passes x 5 layers = 98 launches per frame step); (2) the split engine run three times
+    gives the same codes and logits bit for bit -- every in-launch combine found complete, current partial sums in k order; (3) both forms
+    add the same bf16 products in another fp32 grouping: cb-0 decisions to 97 % (the bar of the skinny8 / skinny2 test above; 98.8 %
+    measured), cb-0 logits to 1.5 % relative RMS (0.77 % measured: 28 layers x 43 frames of bf16 hidden states and a bf16 KV cache written by
+    either path carry every regrouped sum's rounding forward -- the 0.6B test above sees 0.31 % over 40 frames); (4) against the fp32 reference's codes the split engine agrees as well as the unsplit one (-1 %)."""
+    from qwen3_tts_amd.talker import TalkerEngine
+    cfg = synth.talker_17b()
+    g = np.load(os.path.join(golden_dir, "talker_17b_b32.npz"))
+    wn = synth.talker_weights(cfg, with_text=False)
+    lens = [int(x) for x in g["lens"]]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+    gc = torch.from_numpy(g["codes"].copy())
+    steps = [0, 1, 7, 20, 39]
+    want = cfg.num_hidden_layers + (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers
+    res = {}
+    for flag in ("1", "0"):
+        with _qlib.options(QTTS_SKINNY_KS=flag, QTTS_SKINNY_KS_MINK="3072"):         # (engine-level: copied at creation, the captured graph bakes it in; K floor 3072: both instantiations run -- the default, 6144, splits the talker's 28 only)
+            eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=True)
+            runs = []
+            for _ in range(3 if flag == "1" else 1):
+                out = eng.generate(emb, mask, tr, pad, teacher_codes=gc, logit_steps=steps, suppress_tokens=_suppress(cfg))
+                runs.append((out.own.cpu().numpy(), out.logits_trace.cpu().numpy()))
+            st = eng.stats()
+            assert st["ks_split_per_step"] == (want if flag == "1" else 0) and st["cp_fused_per_step"] == 0 and st["cp_fused_giveups"] == 0, st
+            res[flag] = runs
+            del eng
+            torch.cuda.empty_cache()
+    for own, lt in res["1"][1:]:
+        assert np.array_equal(own, res["1"][0][0]) and np.array_equal(lt, res["1"][0][1]), "the split-K engine is not run-to-run identical"
+    (own1, lt1), (own0, lt0) = res["1"][0], res["0"][0]
+    agree0 = float((own1[:, :, 0] == own0[:, :, 0]).mean())
+    agree = float((own1 == own0).mean())
+    rel = float(np.sqrt(((lt1 - lt0) ** 2).mean()) / np.sqrt((lt0.astype(np.float64) ** 2).mean()))
+    F = g["codes"].shape[1]
+    ref1, ref0 = float((own1[:, :F] == g["codes"]).mean()), float((own0[:, :F] == g["codes"]).mean())
+    print(f"split-K vs unsplit decode GEMM on the frame step (1.7B, 32 x {F} frames, teacher-forced, bf16): {want} split launches per step; cb-0 decisions "
+          f"agree {agree0:.4f}, all 16 codebooks {agree:.4f}, cb-0 logit rel. RMS {rel:.5f}; vs the fp32 reference's codes {ref1:.4f} (unsplit {ref0:.4f})")
+    assert not np.array_equal(lt1, lt0), "QTTS_SKINNY_KS=0 did not select another kernel"
+    assert agree0 >= 0.97 and rel <= 1.5e-2 and ref1 >= ref0 - 0.01
+
+
 def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(dev, golden_dir):
     """`cp_attn_o_kernel` (round 4: the code predictor's attention + o-projection of passes >= 1 in ONE launch, split over k by kv head,
     partial sums published write-through and combined by the last arriver of every 128-feature chunk) against the two launches it

@@ -853,6 +853,22 @@ def test_lds_dma_kernels_wait_for_their_requests_before_the_barrier(libqtts):
         assert tot >= 1 and bad == 0, (k, tot, bad)
 
 
+def test_granule_polling_loads_stay_inside_their_loops(libqtts):
+    """Round 6, found on the MI355X (profiles/r06_skinny_ksplit.md): the first build of `skinny2_ks_kernel` polled its producers' granules ONCE --
+    the sc1 buffer loads are read-only intrinsics, its polling loop held no store and no side effect, and the compiler hoisted the re-read
+    out of the loop (the emulator runs workgroups in order and never needs a second read).  Pinned from the code objects: every kernel that
+    polls granules (sc1 buffer loads) has such loads inside a loop (behind a backward branch)."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_waits
+    d = isa_waits.polling_reloads(os.path.join(ROOT, "qwen3-tts_amd", "libqtts.so"))
+    pollers = {k: v for k, v in d.items() if any(n in k for n in ("skinny2_ks_kernel", "cp_mlp_kernel", "cp_attn_o_kernel", "cp_layer_kernel"))}
+    assert sum("skinny2_ks_kernel" in k for k in pollers) >= 4 and any("cp_mlp_kernel" in k for k in pollers), sorted(d)
+    for k, (n, inside) in pollers.items():
+        assert inside > 0, (k, n, "no sc1 load inside a loop: the polling loop was hoisted")
+
+
 def test_product_library_has_no_packed_fp32_math(libqtts):
     """Round 5 (profiles/r05_packed_fp32_hazard.md): a `v_pk_mul_f32` / `v_pk_fma_f32` sequence returned wrong lanes 48-63 on the MI355X
     while another stream shared the device; the product library is built with packed fp32 math off.  Pinned from the code objects."""

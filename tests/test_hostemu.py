@@ -590,6 +590,65 @@ def test_skinny_bf16_kernel_frame_step_shapes(emu, qopt):
             assert np.all(out16[:, No:] == 0x4242)
 
 
+def test_skinny_bf16_split_k_batch_17_to_32(emu, qopt):
+    """Round 6: `skinny2_ks_kernel` -- the o- and down-projections at batch 17..32 with K split over the workgroups of a 32-feature strip group
+    and the partial sums combined inside the launch (tagged granules, the group's last workgroup adds them in k order) -- in its four
+    instantiations against float64 numpy and, bit for bit, against `skinny2_kernel` regrouped: the split only changes WHERE the k-tiles of a
+    wave are added, so |split - unsplit| stays within fp32 rounding of the sums.  Two launches on one workspace (the second finds the first's
+    granules under another tag), ragged second m-tile, rows >= M and columns >= N untouched, K below QTTS_SKINNY_KS_MINK not split."""
+    g = np.random.default_rng(606)
+    i32, vp = C.c_int32, C.c_void_p
+    emu.hostemu_skinny_ksplit.argtypes = [vp, i32, i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, vp, i32, i32, vp]
+    cases = [(32, 2048, 6144, 8, 0, 1, 1),      # talker down 1.7B: 4 strips x 8 features, KS = 4, six k-tiles per wave
+             (19, 1024, 3072, 8, 1, 1, 1),      # down of the 1024-wide stacks: KS = 8, four waves x three tiles, ragged second m-tile, bias
+             (32, 2048, 2048, 16, 0, 1, 0),     # talker o 1.7B: 2 strips x 16, KS = 4
+             (25, 1024, 2048, 8, 0, 0, 1)]      # o of the 1024-wide stacks: KS = 8, one tile per wave, no residual
+    qopt(emu, "QTTS_SKINNY_KS_MINK", "1024")
+    for (M, N, K, fs, hb, hr, sh) in cases:
+        x = (g.standard_normal((M, K + 8)) * 0.7).astype(np.float32)
+        W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = g.standard_normal(N).astype(np.float32) if hb else None
+        res = g.standard_normal((M, N)).astype(np.float32) if hr else None
+        acc = _bf16_round(x[:, :K])[0].astype(np.float64) @ _bf16_round(W)[0].astype(np.float64).T
+        if hb:
+            acc += bias
+        if hr:
+            acc = acc + res
+        outs = {}
+        for ks_on in ("1", "0"):
+            qopt(emu, "QTTS_SKINNY_KS", ks_on)
+            out = np.full((M + 1, N + 4), 7.0, np.float32)
+            out16 = np.full((M + 1, N + 4), 0x4242, np.uint16)
+            took = C.c_int32(-1)
+            rc = emu.hostemu_skinny_ksplit(_ptr(x), K + 8, M, _ptr(W), N, K, _ptr(bias) if hb else None, _ptr(res) if hr else None, N, _ptr(out), N + 4, fs,
+                                           out16.ctypes.data_as(vp) if sh else None, 2, 5, C.byref(took))
+            assert rc == 0 and took.value == 1, ((M, N, K, fs), rc, took.value, (emu.qtts_last_error() or b"").decode())
+            tol = 2e-3 * max(1.0, float(np.abs(acc).max()))
+            assert np.abs(out[:M, :N] - acc).max() <= tol, (M, N, K, fs, ks_on, float(np.abs(out[:M, :N] - acc).max()))
+            assert np.all(out[:M, N:] == 7.0) and np.all(out[M] == 7.0), "wrote outside its rows / columns"
+            if sh:
+                got = (out16[:M, :N].astype(np.uint32) << 16).view(np.float32)
+                assert np.abs(got - out[:M, :N]).max() <= 8e-3 * max(1.0, float(np.abs(out).max()))
+                assert np.all(out16[:M, N:] == 0x4242) and np.all(out16[M] == 0x4242)
+            outs[ks_on] = out[:M, :N].copy()
+        d = float(np.abs(outs["1"] - outs["0"]).max())
+        assert 0.0 < d <= 2e-5 * max(1.0, float(np.abs(acc).max())), ("split and unsplit sums differ by more than fp32 regrouping (or the split did not run)", d)
+    # below the K floor the launcher keeps skinny2_kernel (bit-identical to QTTS_SKINNY_KS=0)
+    qopt(emu, "QTTS_SKINNY_KS_MINK", None)       # (default 6144)
+    (M, N, K, fs) = (32, 1024, 3072, 8)
+    x = (g.standard_normal((M, K + 8)) * 0.7).astype(np.float32)
+    W = (g.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    res = g.standard_normal((M, N)).astype(np.float32)
+    o = {}
+    for ks_on in ("1", "0"):
+        qopt(emu, "QTTS_SKINNY_KS", ks_on)
+        out = np.zeros((M, N), np.float32)
+        took = C.c_int32(-1)
+        assert emu.hostemu_skinny_ksplit(_ptr(x), K + 8, M, _ptr(W), N, K, None, _ptr(res), N, _ptr(out), N, fs, None, 1, 9, C.byref(took)) == 0
+        o[ks_on] = out
+    assert np.array_equal(o["1"], o["0"])
+
+
 @pytest.mark.parametrize("bf16", [0, 1])
 def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
     """attention.hip's decode kernel from its real source against float64 numpy: q/k RMSNorm + rotate-half RoPE at position
@@ -1839,6 +1898,49 @@ def test_talker_bf16_whole_layer_as_one_launch_in_the_frame_step(emu, qopt, cp_h
     assert ref[0].shape[1] >= 2
     for k, v in res.items():
         assert np.array_equal(v[0], ref[0]) and np.array_equal(v[1], ref[1]), f"QTTS_CP_LAYER={k[0]}, graph {k[1]}: differs from the two launches"
+
+
+def test_talker_bf16_batch_above_16_splits_k_in_the_down_projections(emu, qopt):
+    """Round 6 (BASELINE configs 4 and 5 run the frame step at batch 32): a bf16 engine at batch 17..32 sends the
+    down-projections of the code predictor's passes >= 1 (K = 3072 at the released width) through `skinny2_ks_kernel` -- K split over the
+    workgroups of a strip group, combined inside the launch.  `ks_split_per_step` says so (and 0 with QTTS_SKINNY_KS=0: skinny2_kernel); the
+    split regroups fp32 sums, so hidden states agree to bf16-step accuracy and greedy codes almost everywhere; a second generation on the
+    same handle (workspace re-used, serial advanced) repeats the first bit for bit; pass 0 (two tokens = 36 rows) and batch <= 16 keep
+    skinny2_kernel."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=2,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+    emu.hostemu_set_real_gemm(1)
+    res = {}
+    try:
+        for nb, want in ((18, (t.num_code_groups - 2) * t.cp_num_hidden_layers), (16, 0)):
+            emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(63), t, [3 + i % 4 for i in range(nb)], 2, scale=0.5)
+            args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
+            for mode in ("1", "0"):
+                qopt(emu, "QTTS_SKINNY_KS", mode)
+                qopt(emu, "QTTS_SKINNY_KS_MINK", "3072")       # (the default floor, 6144, splits the talker's down-projection only: profiles/r06_skinny_ksplit.md)
+                h = _talker_emu(emu, t, w, max_batch=32, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=1)
+                try:
+                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=3)
+                    st = _lib.TalkerStatsC()
+                    _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+                    assert st.ks_split_per_step == (want if mode == "1" else 0), (nb, mode, st.ks_split_per_step)
+                    assert st.cp_fused_per_step == 0 and st.cp_fused_giveups == 0
+                    if mode == "1" and want:
+                        codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=3)
+                        assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2)
+                    res[(nb, mode)] = (codes, hidden)
+                finally:
+                    emu.qtts_talker_destroy(h)
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
+    (c1, h1), (c0, h0) = res[(18, "1")], res[(18, "0")]
+    assert c1.shape == c0.shape and c1.shape[1] >= 2
+    assert float(np.abs(h1 - h0).max()) <= 3e-2 * max(1.0, float(np.abs(h0).max())), float(np.abs(h1 - h0).max())
+    assert float((c1 == c0).mean()) >= 0.95
+    assert np.array_equal(res[(16, "1")][0], res[(16, "0")][0]) and np.array_equal(res[(16, "1")][1], res[(16, "0")][1])
 
 
 def test_fused_code_predictor_launch_is_admitted_per_device_by_residency(emu, qopt):

@@ -34,6 +34,12 @@ CONFIGS = {
     "ao_step2": {"QTTS_CP_ATTN_O_STEP": "2"}, "ao_step6": {"QTTS_CP_ATTN_O_STEP": "6"}, "ao_step8": {"QTTS_CP_ATTN_O_STEP": "8"},
     "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
     "skinny8_nw4": {"QTTS_SKINNY8_NW": "4"},
+    # round 6, --batch 32: the o- / down-projections at batch 17..32 with K split over workgroups (skinny2_ks_kernel)
+    "ks_off": {"QTTS_SKINNY_KS": "0"}, "ks_mink2048": {"QTTS_SKINNY_KS_MINK": "2048"}, "ks_mink6144": {"QTTS_SKINNY_KS_MINK": "6144"},
+    "ks_pause0": {"QTTS_SKINNY_KS_PAUSE": "0"}, "ks_pause16": {"QTTS_SKINNY_KS_PAUSE": "16"}, "ks_pause24": {"QTTS_SKINNY_KS_PAUSE": "24"},
+    "ks_pause32": {"QTTS_SKINNY_KS_PAUSE": "32"}, "ks_pause48": {"QTTS_SKINNY_KS_PAUSE": "48"}, "ks_pause64": {"QTTS_SKINNY_KS_PAUSE": "64"},
+    "ks_down4": {"QTTS_SKINNY_KS_DOWN1024": "4"}, "ks_down4_p32": {"QTTS_SKINNY_KS_DOWN1024": "4", "QTTS_SKINNY_KS_PAUSE": "32"},
+    "ks_mink6144_p32": {"QTTS_SKINNY_KS_MINK": "6144", "QTTS_SKINNY_KS_PAUSE": "32"}, "ks_mink6144_p48": {"QTTS_SKINNY_KS_MINK": "6144", "QTTS_SKINNY_KS_PAUSE": "48"},
 }
 KEYS = sorted({k for c in CONFIGS.values() for k in c})
 
@@ -42,6 +48,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=40); ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--batch", type=int, default=8, help="rows of the frame step (32: BASELINE configs 4 / 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"], help="f32: the exact parity mode (fp32 operators; cp_mlp_kernel<true, ...> against the split-K plan)")
     a = ap.parse_args()
     t = synth.talker_17b()
@@ -52,7 +59,7 @@ def main():
         if "norm" in k and k.endswith("weight"): v = v * 0 + 1
         if "head" in k: v = np.random.default_rng(__import__("zlib").crc32(k.encode())).standard_normal(shp, dtype=np.float32) * np.float32(0.08)   # no tied logits
         w[k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
-    B, F = 8, a.frames
+    B, F = a.batch, a.frames
     lens = [24 + 4 * (i % 8) + 12 for i in range(B)]
     emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(1), t, lens, 1)
     sup = [i for i in range(t.vocab_size - 1024, t.vocab_size) if i != t.codec_eos_token_id]
@@ -75,12 +82,12 @@ def main():
             res[n].append(round(ms, 4))
             st = eng.stats()
             print(f"[ab_inproc] rep {rep} {n:28s} {ms:.3f} ms/frame   (graph nodes {st['graph_nodes']}, fused launches per step: attention {st['cp_fused_per_step']}, "
-                  f"mlp {st['cp_mlp_per_step']}, whole layer {st.get('cp_layer_per_step', 0)})", flush=True)
+                  f"mlp {st['cp_mlp_per_step']}, whole layer {st.get('cp_layer_per_step', 0)}; split-K GEMMs {st.get('ks_split_per_step', 0)})", flush=True)
             del eng; gc.collect(); torch.cuda.empty_cache()
     out = {n: {"ms_per_frame": v, "min": min(v), "median": float(np.median(v))} for n, v in res.items()}
     print(json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab_inproc.json" if a.dtype == "bf16" else "ab_inproc_f32.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", ("ab_inproc.json" if a.batch == 8 else f"ab_inproc_b{a.batch}.json") if a.dtype == "bf16" else "ab_inproc_f32.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -61,6 +61,32 @@ def dma_barriers(lib):
     return out
 
 
+def polling_reloads(lib, name_filter=""):
+    """Kernels that poll granules with `sc1` buffer loads (granule.h): {kernel: (sc1 loads, sc1 loads that sit behind a backward branch target,
+    i.e. inside a loop)}.  A raw buffer load is a read-only intrinsic: in a loop without a store or a side effect the compiler hoists it, and
+    the loop then spins on the registers of ONE read (round 6, the first build of skinny2_ks_kernel: found on the MI355X, invisible to the
+    emulator).  The second number must be > 0 for every polling kernel."""
+    out = {}
+    for name, ins in kernels(lib).items():
+        if name_filter and name_filter not in name: continue
+        loads = [i for i, x in enumerate(ins) if x.startswith("buffer_load_dword") and " sc1" in x and " lds" not in x]
+        if not loads: continue
+        # backward branches: `s_cbranch_* N` with N >= 32768 (a 16-bit signed word offset printed unsigned) -> the loop spans [target, branch]
+        inside = set()
+        # instruction sizes are not in the text: approximate the loop body as "every instruction between the nearest preceding s_sleep and the
+        # branch" -- the polling loops of this library all pause with s_sleep inside the loop
+        for i, x in enumerate(ins):
+            m = re.match(r"^s_cbranch_\w+ (\d+)", x)
+            if not m or int(m.group(1)) < 32768: continue
+            words = 65536 - int(m.group(1))
+            j = i
+            while j > 0 and words > 0:           # every instruction is 1 or 2 words: walking back `words` instructions over-covers, `words / 2` under-covers
+                j -= 1; words -= 2
+            inside.update(k for k in loads if j <= k <= i)
+        out[name] = (len(loads), len(inside))
+    return out
+
+
 def packed_fp32(lib):
     """(number of packed fp32 arithmetic instructions, kernels that hold one) in the gfx950 code objects of `lib`.  The product build
     carries none (build.py FLAGS: -packed-fp32-ops off; profiles/r05_packed_fp32_hazard.md)."""

@@ -72,12 +72,13 @@ print(f"{len(r)} records ({'eager' if a.no_graph else 'hipGraph'} launches, batc
 TICK_US = 0.01                                  # s_memrealtime: 100 MHz
 order = np.argsort(r["t"][:, 0], kind="stable")
 r = r[order]
-KIND = {0: "decode GEMM", 1: "attn_cp", 2: "attn_tk", 3: "sampler", 4: "cp_attn_o", 5: "cp_mlp", 6: "cp_layer"}
+KIND = {0: "decode GEMM", 1: "attn_cp", 2: "attn_tk", 3: "sampler", 4: "cp_attn_o", 5: "cp_mlp", 6: "cp_layer", 7: "split-K GEMM"}
 PHASES = {0: ["issued", "arrived", "mfma+lds", "barrier", "stored"],
           1: ["issued", "arrived", "normed", "barrier", "stored"],
           2: ["arrived", "normed", "keys folded", "barrier", "stored"],
           3: ["arrived", "bound", "ranked", "drawn", "rows out"],
           4: ["arrived", "attended", "published", "ticket", "reduced"],
+          7: ["issued", "arrived", "mfma+lds", "parts out|in", "stored"],      # (round 6: skinny2_ks_kernel at batch 17..32; blk bit 16 = the strip group's reducer)
           6: ["o part out", "hidden in", "act out", "part out", "reduced"],      # (round 6: the whole layer in one launch; blk bit 16 = a reducer)
           5: ["A mfma", "act out", "slice in", "part out", "reduced"]}      # (round 5: the fused MLP launch; blk bit 16 = a reducer of XCD 7)      # (round 4: attention + o-projection in one launch; blk bit 16 = the chunk's last arriver)
 # boundary: entry of a launch minus the latest stamp of any record of the launch before it.  Two records (first / last
@@ -99,18 +100,21 @@ l_pitch = np.full(n_l, np.nan); l_pitch[1:] = (l_entry[1:] - l_entry[:-1]) * TIC
 for i in range(len(r)): gap[i] = l_gap[launch_id[i]]
 
 rows = []
-keys = sorted({(int(k), int(x), int(y)) for k, x, y in zip(r["kind"], r["a"], r["b"]) if k not in (1, 2, 4, 5, 6)})
+keys = sorted({(int(k), int(x), int(y)) for k, x, y in zip(r["kind"], r["a"], r["b"]) if k not in (1, 2, 4, 5, 6, 7)})
+ks_keys = sorted({(int(x), int(y)) for k, x, y in zip(r["kind"], r["a"], r["b"]) if k == 7})
 keys += [(1, -1, 0), (2, -1, 0), (4, -1, 0), (4, -1, 1), (5, -1, 0), (5, -1, 1), (6, -1, 0), (6, -1, 1)]        # the attentions: all cache lengths together; cp_attn_o: other workgroups | last arrivers
+keys += [(7, x, y, red) for (x, y) in ks_keys for red in (0, 1)]
 for key in keys:
     k = key[0]
     sel = (r["kind"] == k) if key[1] < 0 else ((r["kind"] == k) & (r["a"] == key[1]) & (r["b"] == key[2]))
     if k in (4, 5, 6): sel = sel & ((r["blk"] >> 16) == key[2])
+    if k == 7: sel = sel & ((r["blk"] >> 16) == key[3])
     if not sel.any(): continue
     rr = r[sel]
     ph = (rr["t"][:, 1:].astype(np.float64) - rr["t"][:, :1].astype(np.float64)) * TICK_US
     ph[rr["t"][:, 1:] == 0] = np.nan
     g = gap[sel]; g = g[np.isfinite(g) & (g < 20)]
-    name = KIND[k] + (f" K={key[1]} N={key[2]}" if k == 0 else (f" V={key[1]}" if k == 3 else ((" (last arriver)" if key[2] else " (others)") if k == 4 else ((" (reducer, XCD 7)" if key[2] else " (others)") if k == 5 else ((" (reducer)" if key[2] else " (others)") if k == 6 else "")))))
+    name = KIND[k] + (f" K={key[1]} N={key[2]}" + (" (reducer)" if key[3] else " (producer)") if k == 7 else f" K={key[1]} N={key[2]}" if k == 0 else (f" V={key[1]}" if k == 3 else ((" (last arriver)" if key[2] else " (others)") if k == 4 else ((" (reducer, XCD 7)" if key[2] else " (others)") if k == 5 else ((" (reducer)" if key[2] else " (others)") if k == 6 else "")))))
     rows.append(dict(kernel=name, records=int(sel.sum()), phases_us={n: round(float(np.nanmean(ph[:, j])), 2) for j, n in enumerate(PHASES[k])},
                      in_kernel_us=round(float(np.nanmean(np.nanmax(ph, axis=1))), 2),
                      boundary_us_median=round(float(np.median(g)), 2) if len(g) else None))
