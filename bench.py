@@ -377,7 +377,7 @@ def clone_shard_job(args, tcfg, ccfg, dev, rank, world, dist, weights=None, keep
     # (`weights` = (talker, codec) numpy dicts a caller already holds -- the `configs` leg of the metric run; `keep`: a dict that receives the engines)
     tw, cw = (td(weights[0]), td(weights[1])) if weights is not None else (td(synth.talker_weights(tcfg, with_text=False)), td(synth.codec_weights(ccfg)))
     talkers = [TalkerEngine(tcfg, tw, weight_dtype=tdt, device=dev, max_batch=B, max_seq=12 + REF + 16 + 8 + Fmax + 8,
-                            use_graph=not args.no_graph) for _ in range(E)]
+                            use_graph=not args.no_graph, shared_device=E > 1) for _ in range(E)]       # (engines that share a device keep the decode GEMMs: talker.py)
     codecs = [CodecDecoderEngine(ccfg, cw, compute_dtype=cdt, device=dev, max_batch=B, max_frames=min(Fmax, 300) + 25) for _ in range(E)]
     del tw, cw
     if keep is not None:
@@ -726,7 +726,8 @@ def fused_cp_report(c, fused_rec, elem_bytes=2):
     qd, kvd, H = c.cp_num_attention_heads * c.cp_head_dim, c.cp_num_key_value_heads * c.cp_head_dim, c.cp_hidden_size
     G, L = c.num_code_groups, c.cp_num_hidden_layers
     alg = {"front": ((qd + 2 * kvd) * H + H * qd) * elem_bytes, "attn_o": H * qd * elem_bytes, "mlp": 3 * c.cp_intermediate_size * H * elem_bytes}
-    per_frame = {"front": (G - 2) * (L - 1), "attn_o": G - 2, "mlp": (G - 2) * L}
+    alg["layer_front"] = alg["front"] + alg["mlp"]; alg["layer"] = alg["attn_o"] + alg["mlp"]      # (round 6: cp_layer_kernel, both stages in one launch)
+    per_frame = {"front": (G - 2) * (L - 1), "attn_o": G - 2, "mlp": (G - 2) * L, "layer_front": (G - 2) * (L - 1), "layer": G - 2}
     fl = {}
     for k, f in fused_rec.items():
         if k in alg and isinstance(f, dict) and f.get("rocprof_avg_launch_us"):
@@ -756,7 +757,7 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
     # stack 3 = the code predictor's fused launch (cp_attn_o_kernel: q|k|v GEMM + attention + o-projection of a layer), timed by the
     # same per-launch events in the same run (round 5); the dominant-kernel figure stays the decode GEMM's own launches
     cls = [c for c in cls_all if c["stack"] in (0, 1, 2)]
-    cls_fused = [c for c in cls_all if c["stack"] in (3, 4)]          # 3: cp_attn_o_kernel; 4: cp_mlp_kernel (gate|up + SwiGLU + down of a code-predictor layer)
+    cls_fused = [c for c in cls_all if c["stack"] in (3, 4, 5)]       # 3: cp_attn_o_kernel; 4: cp_mlp_kernel (gate|up + SwiGLU + down of a code-predictor layer); 5: cp_layer_kernel (round 6: both stages in one launch)
     frames = 6
     out = {"bound": "hbm", "kernel": kernel, "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "method": "per-launch kernel begin/end timestamps (hipExtLaunchKernelGGL events) over every decode-GEMM "
@@ -791,12 +792,16 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
         fl = {}
         for c in cls_fused:
             us = 1e3 * c["total_ms"] / c["launches"]
-            key = "mlp" if c["stack"] == 4 else ("front" if c["N"] > talker.config.cp_hidden_size else "attn_o")
+            cpc = talker.config
+            key = ("mlp" if c["stack"] == 4 else ("front" if c["N"] > cpc.cp_hidden_size else "attn_o")) if c["stack"] != 5 else \
+                  ("layer_front" if c["N"] > cpc.cp_hidden_size + 3 * cpc.cp_intermediate_size else "layer")
             fl[key] = {"launches_per_frame": c["launches"] // frames, "algorithmic_bytes_per_launch": round(c["bytes_per_launch"]),
                        "avg_us": round(us, 3), "min_us": round(c["min_us"], 3),
                        "frac": round(c["bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         fl["weight_bytes_per_frame"] = round(sum(c["launches"] * c["bytes_per_launch"] for c in cls_fused) / frames)
-        fl["kernel"] = ("cp_attn_o_kernel (front: q|k|v GEMM + attention + o-projection of a code-predictor layer in one launch; attn_o: layer 0, "
+        fl["kernel"] = ("cp_layer_kernel (round 6; layer_front: q|k|v GEMM + attention + o-projection + RMSNorm + gate|up + SwiGLU + down + residuals of a code-predictor "
+                        "layer in ONE launch; layer: layer 0, whose q|k|v row comes from the table) where the engine holds the device's layer place; otherwise "
+                        "cp_attn_o_kernel (front: q|k|v GEMM + attention + o-projection of a code-predictor layer in one launch; attn_o: layer 0, "
                         "whose q|k|v row comes from the table) and cp_mlp_kernel (mlp: RMSNorm + gate|up GEMM + SwiGLU + down GEMM + residual of a layer in "
                         "one launch); per-launch events of this run")
         out["fused_cp_launch"] = fl
@@ -806,7 +811,7 @@ def roofline_leg(talker, emb, mask, trailing, pad, gen_kw, wbytes, model, elem_b
         out["weight_launches_per_frame"] = (tot_n + sum(c["launches"] for c in cls_fused)) // frames
         out["weight_bytes_per_frame_timed_all"] = round(b_all / frames)
     st_f = talker.stats()
-    out["cp_fused"] = {k: st_f[k] for k in ("cp_fused_active", "cp_fused_capacity", "cp_fused_per_step", "cp_mlp_per_step", "cp_fused_giveups") if k in st_f}
+    out["cp_fused"] = {k: st_f[k] for k in ("cp_fused_active", "cp_fused_capacity", "cp_fused_per_step", "cp_mlp_per_step", "cp_layer_per_step", "ks_split_per_step", "cp_fused_giveups") if k in st_f}
     if elem_bytes != 2:            # (the parity-mode leg: no PMC pass and no isolated replay for the fp32 engine)
         out["traffic"] = None
         return out

@@ -17,7 +17,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libqtts.so")
-SOURCES = ["gemm_tap.hip", "resunit.hip", "skinny.hip", "elementwise.hip", "attention.hip", "cp_mlp.hip", "cp_layer.hip", "sampling.hip",
+SOURCES = ["gemm_tap.hip", "resunit.hip", "skinny.hip", "elementwise.hip", "attention.hip", "cp_mlp.hip", "cp_mlp32.hip", "cp_layer.hip", "sampling.hip",
            "codec_engine.hip", "talker_engine.hip", "encoder_kernels.hip", "encoder_engine.hip",
            "speaker_kernels.hip", "speaker_engine.hip", "stream_kernels.hip"]
 # sources that only a measuring variant links (never the product library): variant name -> files

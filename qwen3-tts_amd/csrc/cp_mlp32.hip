@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void cp_mlp32_kernel(const void* kWgu, const v
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int t = 0; t < KTW; ++t) offs[m][t] = (int)((((size_t)xcd * RC + rowm[m]) * spairs + (wave * KTW + t) * 16 + lq * 4) * 8);
-        cu32x4 cur[MT][KTW][2], nxt[MT][KTW][2];
+        cu32x4 cur[MT][KTW][2];                                // (one read set, as in phase C)
         auto load_slice = [&](cu32x4 (&d)[MT][KTW][2]) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -161,8 +161,6 @@ __global__ __launch_bounds__(256) void cp_mlp32_kernel(const void* kWgu, const v
         };
         wt_first_pause(P.first_pause);
         load_slice(cur);
-        wt_first_pause(P.poll_step);
-        load_slice(nxt);
         for (int spins = 0;; ++spins) {
             bool fresh = true;
 #pragma unroll
@@ -177,13 +175,9 @@ __global__ __launch_bounds__(256) void cp_mlp32_kernel(const void* kWgu, const v
                 if (P.done_latch) __hip_atomic_store(P.done_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int t = 0; t < KTW; ++t) { cur[m][t][0] = nxt[m][t][0]; cur[m][t][1] = nxt[m][t][1]; }
             asm volatile("" ::: "memory");                 // (the re-read stays in the loop: tests/test_host_logic.py pins it from the ISA)
             wt_first_pause(P.poll_step);
-            load_slice(nxt);
+            load_slice(cur);
         }
         f32x4 acc[2][MT];
 #pragma unroll
@@ -242,7 +236,7 @@ __global__ __launch_bounds__(256) void cp_mlp32_kernel(const void* kWgu, const v
             rowc[rr] = rr * 8 + r_t < P.B ? rr * 8 + r_t : 0;
             res[rr] = P.res[(size_t)rowc[rr] * P.H + col];
         }
-        uint2 pa[4][NP], pn[4][NP];
+        uint2 pa[4][NP];                                       // (one read set: a second one in flight would put the kernel over 224 registers -- two engines per device)
         auto load_slabs = [&](uint2 (&d)[4][NP]) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
@@ -251,8 +245,6 @@ __global__ __launch_bounds__(256) void cp_mlp32_kernel(const void* kWgu, const v
         };
         wt_first_pause(P.pause_c);
         load_slabs(pa);
-        wt_first_pause(P.poll_step);
-        load_slabs(pn);
         for (int spins = 0;; ++spins) {
             bool fresh = true;
 #pragma unroll
@@ -265,13 +257,9 @@ __global__ __launch_bounds__(256) void cp_mlp32_kernel(const void* kWgu, const v
                 if (P.done_latch) __hip_atomic_store(P.done_latch, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                for (int x2 = 0; x2 < NP; ++x2) pa[rr][x2] = pn[rr][x2];
-            asm volatile("" ::: "memory");
+            asm volatile("" ::: "memory");                 // (the re-read stays in the loop: tests/test_host_logic.py pins it from the ISA)
             wt_first_pause(P.poll_step);
-            load_slabs(pn);
+            load_slabs(pa);
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {

@@ -299,6 +299,15 @@ size_t cp_mlp_gu_bytes(int H, int I, bool bf16);
 void pack_cp_mlp_gu(const float* Wg, const float* Wu, const float* g, int H, int I, bool bf16, void* out_host);
 void launch_cp_mlp(const CpMlpParams& P, hipStream_t st);
 void cp_mlp_set_launch_events(hipEvent_t start, hipEvent_t stop);
+// cp_mlp32.hip (round 6): the same launch for batch 9..32 (two 16-row tiles; bf16 engines).  Same parameter block; its granule buffers have 32
+// rows per XCD: act_gran [8][32][I / 16], part [8][32][H] granules.
+bool cp_mlp32_takes(int B, int H, int I);
+bool cp_mlp32_instantiated(int H, int I);
+int cp_mlp32_blocks_per_cu(int H, int I);
+size_t cp_mlp32_act_bytes(int I);
+size_t cp_mlp32_part_bytes(int H);
+void launch_cp_mlp32(const CpMlpParams& P, hipStream_t st);
+void cp_mlp32_set_launch_events(hipEvent_t start, hipEvent_t stop);
 
 // --------------------------------------------------------------------------------- cp_layer.hip
 // A whole decoder layer of the code predictor (passes >= 1, batch <= 8) as ONE launch (round 6): cp_attn_o's stages, then cp_mlp's, the

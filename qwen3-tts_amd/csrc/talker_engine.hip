@@ -231,6 +231,10 @@ struct qtts_talker {
     int cp_mlp_pause_c = [] { const char* e = QTTS_ENV("QTTS_CP_MLP_PAUSE_C"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 24; }();
     int cp_mlp_step = [] { const char* e = QTTS_ENV("QTTS_CP_MLP_STEP"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 4; }();
     DevBuf mlp_act, mlp_part;          // granule buffers of the fused MLP launch
+    // Round 6: the same launch at batch 9..32 (cp_mlp32.hip; BASELINE configs 4 / 5 run the frame step at batch 32): bf16 engines created for more
+    // than 8 rows.  QTTS_CP_MLP32=0 (copied at engine creation): the two decode GEMMs.  Its launches count in cp_mlp_count / cp_mlp_per_step.
+    bool cp_mlp32_env = QTTS_OPT_ON("QTTS_CP_MLP32");
+    DevBuf mlp32_act, mlp32_part;      // its granule buffers (32 rows per XCD)
     int64_t cp_mlp_count = 0;
     int cp_mlp_per_step = 0;
     // Round 6: both fused launches of a layer as ONE (cp_layer.hip: the hidden rows between them travel as granules, the gate|up block is
@@ -267,7 +271,7 @@ struct qtts_talker {
             upload_packed(L.o_p16, ow, d.H, d.qd, nullptr, 16);
         // ... and the MLP as ONE launch (cp_mlp.hip): gate|up packed by workgroup (XCD-major slices of the intermediate vector), down in 16-feature strips
         // (fp32 engines too, round 5: the exact parity mode runs through the same construction; their down operator is in 16-feature strips already)
-        if (!rows && cp_mlp_env && cp_mlp_instantiated(d.H, d.I, bf16)) {
+        if (!rows && ((cp_mlp_env && cp_mlp_instantiated(d.H, d.I, bf16)) || (cp_mlp32_env && bf16 && cp_mlp32_instantiated(d.H, d.I)))) {
             std::vector<char> h(cp_mlp_gu_bytes(d.H, d.I, bf16));
             pack_cp_mlp_gu(PS(p + "mlp.gate_proj.weight", {d.I, d.H}).data(), PS(p + "mlp.up_proj.weight", {d.I, d.H}).data(),
                            PS(p + "post_attention_layernorm.weight", {d.H}).data(), d.H, d.I, bf16, h.data());
@@ -455,7 +459,10 @@ struct qtts_talker {
         skinny(o, st);
         }
         // bf16 engines, code predictor passes >= 1 at batch <= 8: the MLP as ONE launch (cp_mlp.hip) instead of the two decode GEMMs below
-        const bool fuse_mlp = mlp_fusable;
+        // ... and at batch 9..32 the 32-row form of the same launch (cp_mlp32.hip)
+        const bool mlp32_fusable = cp_mlp32_env && !mlp_fusable && bf16 && cp_fused_slot && L.gu_mlp.p && L.d_p16.p && mlp32_act.p && !skinny_only && !len_dev && n_new == 1 &&
+                                   len_static >= 1 && M > 8 && cp_mlp32_takes(M, d.H, d.I) && layer < CP_FUSED_MAX_LAYERS && len_static * CP_FUSED_MAX_LAYERS + layer < 128 && h16;
+        const bool fuse_mlp = mlp_fusable || mlp32_fusable;
         if (fuse_mlp) {
             CpMlpParams m{};
             m.f32 = bf16 ? 0 : 1;
@@ -465,6 +472,13 @@ struct qtts_talker {
             m.err = ss.n_generated + 5; m.done_latch = ss.done; m.done_flag = ss.done; m.first_pause = cp_attn_o_pause; m.poll_step = cp_attn_o_step;
             m.B = M; m.H = d.H; m.I = d.I; m.wd_early = cp_mlp_wd_early;
             m.first_pause = cp_mlp_pause_b; m.pause_c = cp_mlp_pause_c; m.poll_step = cp_mlp_step;
+            if (mlp32_fusable) {       // (its own granule buffers: 32 rows per XCD)
+                m.act_gran = mlp32_act.as<float>(); m.part = mlp32_part.as<float>();
+                launch_cp_mlp32(m, st);
+                ++cp_mlp_count;
+                sk_pending = false;
+                return;
+            }
             if (timing_now) {          // bench.py's roofline leg: timed on its own (stack 4: the fused MLP launch, three operators)
                 LaunchEv e{nullptr, nullptr, 4, 3 * d.I, d.H, (bf16 ? 2.0 : 4.0) * 3.0 * (double)d.I * d.H};
                 QTTS_CHECK_HIP(hipEventCreate(&e.a)); QTTS_CHECK_HIP(hipEventCreate(&e.b));
@@ -591,6 +605,9 @@ struct qtts_talker {
     // Round 6: the layer launch (cp_layer.hip) runs both stages in the two launches' register share + 8 (192 in bf16; 360 with the operators
     // in registers in fp32) and holds 65 KB of LDS per workgroup (the gate|up block requested by LDS-DMA): the account has a SECOND resource,
     // a compute unit's 160 KB of LDS (a register-only account over-admits the moment a fused launch stages operands in LDS).
+    // cp_mlp32.hip (batch 9..32): 208 registers (184 + 24 accumulator), 33 KB of LDS -- two such engines per device inside 7/8 of the register file (the
+    // headroom rule of the layer launch below: launches that fit EXACTLY starve their pending workgroups behind other streams' short waves)
+    static constexpr int CP_SHARE_MLP32 = 208, CP_LDS_MLP32 = 34 * 1024;
     static constexpr int CP_SHARE_LAYER = 192, CP_SHARE_LAYER_F32 = 360, CU_LDS_BUDGET = 160 * 1024, CP_LDS_TWO_LAUNCHES = 17 * 1024;
     struct FusedDev { int regs = 0, lds = 0, engines = 0; };
     struct FusedRegistry { std::mutex m; std::map<int, FusedDev> dev; };        // device -> (register share, LDS bytes in use, fused engines)
@@ -636,7 +653,7 @@ struct qtts_talker {
     // after a give-up: this engine runs the separate launches from now on (graphs that baked the fused launch in are dropped)
     void fused_retire() {
         ++cp_fused_giveups;
-        cp_attn_o_env = false; cp_mlp_env = false; cp_layer_env = false; ks_split_env = false;
+        cp_attn_o_env = false; cp_mlp_env = false; cp_mlp32_env = false; cp_layer_env = false; ks_split_env = false;
         fused_release();
         destroy_graph();
         graph_nodes = 0;
@@ -662,6 +679,8 @@ void qtts_talker::finalize() {
     const int G = c.num_code_groups;
     if (c.cp_num_hidden_layers > CP_FUSED_MAX_LAYERS) { cp_mlp_env = false; cp_attn_o_env = false; }     // (tag uniqueness, see CP_FUSED_MAX_LAYERS)
     if (!cp_mlp_instantiated(cd.H, cd.I, bf16) || c.max_batch > 8) cp_mlp_env = false;
+    // the 32-row form: bf16 engines created for more than 8 rows, at most CP_FUSED_MAX_LAYERS layers (tag uniqueness)
+    if (!bf16 || c.max_batch <= 8 || c.cp_num_hidden_layers > CP_FUSED_MAX_LAYERS || !cp_mlp32_instantiated(cd.H, cd.I)) cp_mlp32_env = false;
     // fp32 engines (the exact parity mode) take the fused MLP launch only on request (QTTS_CP_MLP_F32=1): cp_mlp_kernel<true, ...> is the fused
     // construction's bit-exact leg (tests/test_gpu_parity.py runs the reference goldens through it), but with fp32 operators the MLP is
     // 38 MB per layer and the round-4 plan -- o- and down-projection split over two workgroups per strip -- streams it faster than 256
@@ -673,21 +692,23 @@ void qtts_talker::finalize() {
     const bool want_ao = (bf16 || ao_f32) && cp_attn_o_env && cd.nh == 16 && cd.nkv == 8 && cd.H % 128 == 0;
     // the layer launch (cp_layer.hip) needs both fused stages, its instantiation, and a contiguous page table (the engine's always is)
     bool want_layer = cp_layer_env && want_ao && cp_mlp_env && cp_layer_instantiated(cd.H, cd.I, bf16);
-    if (want_ao || cp_mlp_env) {      // one admission for the engine's fused launches
+    if (want_ao || cp_mlp_env || cp_mlp32_env) {      // one admission for the engine's fused launches
         int grid_cp = 0;
         bool occ_ok = true;
         if (want_ao) { grid_cp = std::max(grid_cp, cp_attn_o_grid(cd.H)); occ_ok = occ_ok && cp_attn_o_blocks_per_cu(!bf16) >= 1; }
         if (cp_mlp_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp_blocks_per_cu(cd.H, cd.I, bf16) >= 1; }
+        if (cp_mlp32_env) { grid_cp = std::max(grid_cp, cp_mlp_grid(cd.H)); occ_ok = occ_ok && cp_mlp32_blocks_per_cu(cd.H, cd.I) >= 1; }
         if (want_layer && cp_layer_blocks_per_cu(cd.H, cd.I, bf16) < 1) want_layer = false;      // (also sets the kernels' dynamic-LDS attribute, outside any capture)
         if (want_layer) fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE_LAYER : CP_SHARE_LAYER_F32, cp_layer_lds_bytes(cd.H, cd.I, bf16),
                                     CU_REG_BUDGET - CU_REG_BUDGET / 8, CU_LDS_BUDGET / 2);
         if (!cp_fused_slot) {         // no room for (or no) layer launch: the two launches' smaller shares
             want_layer = false;
-            fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE : CP_SHARE_F32, CP_LDS_TWO_LAUNCHES);
+            if (cp_mlp32_env) fused_admit(grid_cp, occ_ok, CP_SHARE_MLP32, CP_LDS_MLP32, CU_REG_BUDGET - CU_REG_BUDGET / 8);
+            else fused_admit(grid_cp, occ_ok, bf16 ? CP_SHARE : CP_SHARE_F32, CP_LDS_TWO_LAUNCHES);
         }
     }
     if (!want_ao || !cp_fused_slot) cp_attn_o_env = false;
-    if (!cp_fused_slot) cp_mlp_env = false;
+    if (!cp_fused_slot) { cp_mlp_env = false; cp_mlp32_env = false; }
     cp_layer_env = want_layer && cp_fused_slot;
     tl.resize(c.num_hidden_layers);
     for (int l = 0; l < c.num_hidden_layers; ++l) build_layer(tl[l], "model.layers." + std::to_string(l) + ".", td, true);
@@ -818,6 +839,11 @@ void qtts_talker::finalize() {
     if (bf16 && c.max_batch > 16 && ks_split_env) {      // 256 workgroups x 8 (strip, m-tile) pairs x 64 lanes x 4 granules
         ks_part.alloc((size_t)8 << 20);
         QTTS_CHECK_HIP(hipMemset(ks_part.p, 0, ks_part.bytes));
+    }
+    if (!cl.empty() && cl[0].gu_mlp.p && cp_mlp32_env) {
+        mlp32_act.alloc(cp_mlp32_act_bytes(cd.I)); mlp32_part.alloc(cp_mlp32_part_bytes(cd.H));
+        QTTS_CHECK_HIP(hipMemset(mlp32_act.p, 0, mlp32_act.bytes));
+        QTTS_CHECK_HIP(hipMemset(mlp32_part.p, 0, mlp32_part.bytes));
     }
     if (!cl.empty() && cl[0].gu_mlp.p) {
         mlp_act.alloc((size_t)8 * 8 * (cd.I / (bf16 ? 16 : 8)) * 8);

@@ -87,7 +87,12 @@ class TalkerEngine:
     """Owns one `qtts_talker` handle."""
 
     def __init__(self, config: Any, state_dict: Dict[str, torch.Tensor], weight_dtype: torch.dtype = torch.bfloat16,
-                 device: str = "cuda:0", max_batch: int = 8, max_seq: int = 4096, use_graph: bool = True):
+                 device: str = "cuda:0", max_batch: int = 8, max_seq: int = 4096, use_graph: bool = True, shared_device: bool = False):
+        """`shared_device`: this engine will run BESIDE another talker engine on the same device (a throughput job with several engines per GPU:
+        bench.py --workload clone-shard, `sharding.engine_partition`).  It then keeps the decode GEMMs where an engine that has the device to
+        itself runs the code predictor's MLP as one launch at batch 9..32 (csrc/cp_mlp32.hip): that launch's workgroups wait for each other, and
+        behind another engine's kernels they are placed one by one and spin meanwhile -- measured on the MI355X, two engines x waves of 32:
+        86.6 k tokens/s with it against 125-127 k without (profiles/r06_cp_mlp32.md); alone on the device it is 6 % faster per frame."""
         self.config = TalkerConfig.from_any(config)
         self.device = _lib.hip_device(device, "TalkerEngine")
         self.weight_dtype = weight_dtype
@@ -106,7 +111,8 @@ class TalkerEngine:
         tc.weight_dtype = _lib.QTTS_BF16 if weight_dtype == torch.bfloat16 else _lib.QTTS_F32
         tc.max_batch, tc.max_seq, tc.use_graph = self.max_batch, self.max_seq, 1 if use_graph else 0
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        import contextlib
+        with torch.cuda.device(self.device), (_lib.options(QTTS_CP_MLP32="0") if shared_device else contextlib.nullcontext()):
             _lib.check(self._lib.qtts_talker_create(C.byref(tc), C.byref(self._h)))
             has_prefix = any(k.startswith("talker.") for k in state_dict)
             for name, t in state_dict.items():

@@ -33,7 +33,7 @@ _TAG = ("_asan" if ASAN else "_ubsan" if UBSAN else "") + ("_v" + hashlib.sha256
 OUT = os.path.join(HERE, f"libqtts_hostemu{_TAG}.so")
 GEN = os.path.join(HERE, "gen" + _TAG)
 ENGINES = ["codec_engine.hip", "encoder_engine.hip", "speaker_engine.hip", "talker_engine.hip"]
-SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "cp_mlp.hip", "cp_layer.hip", "sampling.hip",
+SIMT_KERNELS = ["stream_kernels.hip", "encoder_kernels.hip", "speaker_kernels.hip", "attention.hip", "cp_mlp.hip", "cp_mlp32.hip", "cp_layer.hip", "sampling.hip",
                 "elementwise.hip", "skinny.hip", "gemm_tap.hip", "resunit.hip"]
 # kernels without barriers / cross-lane ops run as plain per-thread calls (no fibers): much faster for large grids
 SEQUENTIAL = {"stream_kernels.hip", "speaker_kernels.hip"}

@@ -335,6 +335,33 @@ extern "C" int hostemu_cp_layer_front(const float* x, int B, const float* Wqkv, 
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
+// cp_mlp32_kernel (cp_mlp32.hip, round 6): the fused MLP launch at batch <= 32 (two 16-row tiles), bf16: twice on the same granule buffers under two
+// serials (the second finds the first's granules under another tag).
+extern "C" int hostemu_cp_mlp32(const float* x, int B, const float* Wg, const float* Wu, const float* gnorm, float eps, const float* Wd, int H, int I,
+                                const float* res, float* out, unsigned short* out16, unsigned epoch0) {
+    try {
+        std::vector<qtts::bf16_t> x16((size_t)B * H);
+        for (size_t i = 0; i < x16.size(); ++i) x16[i] = qtts::f32_to_bf16(x[i]);
+        std::vector<unsigned char> wgu(qtts::cp_mlp_gu_bytes(H, I, true)), wd(qtts::skinny_packed_bytes(H, I, true));
+        qtts::pack_cp_mlp_gu(Wg, Wu, gnorm, H, I, true, wgu.data());
+        qtts::pack_skinny_weight(Wd, H, I, true, wd.data(), nullptr, 16);
+        std::vector<unsigned char> act(qtts::cp_mlp32_act_bytes(I), 0xFF), part(qtts::cp_mlp32_part_bytes(H), 0xFF);
+        int serial = (int)epoch0, err = 0, latch = 0;
+        qtts::CpMlpParams m{};
+        m.Wgu = wgu.data(); m.Wd = wd.data(); m.x16 = x16.data(); m.ldx16 = H; m.eps = eps;
+        m.res = out; m.out = out; m.out16 = out16;
+        m.act_gran = reinterpret_cast<float*>(act.data()); m.part = reinterpret_cast<float*>(part.data()); m.serial = &serial; m.slot = 11; m.phase = 3;
+        m.err = &err; m.done_latch = &latch; m.first_pause = 16; m.pause_c = 16; m.poll_step = 4; m.B = B; m.H = H; m.I = I;
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = 0; i < B * H; ++i) out[i] = res[i];
+            if (rep) ++serial;
+            qtts::launch_cp_mlp32(m, nullptr);
+            if (err || latch) return -4;
+        }
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
 // cp_mlp_kernel (cp_mlp.hip): the code predictor's MLP as one launch against the two decode-GEMM launches it replaces, bf16 (f32 = 0) or the
 // exact fp32 mode (f32 = 1: fp32 operators, fp32 rows, fp32 intermediate vector).
 // mode 0: the two launches (bf16: ACT_SWIGLU8 where K % 512 == 0; fp32: strip pairs); mode 3: the fused launch, twice on the same granule buffers
@@ -391,7 +418,7 @@ extern "C" int hostemu_cp_mlp(const float* x, int B, const float* Wg, const floa
         }
         // the two launches: gate|up interleaved (8-row blocks for ACT_SWIGLU8, 16-row strip pairs otherwise), then the down-projection
         std::vector<float> gu((size_t)2 * I * H);
-        const int blk = (bf && H % 512 == 0) ? 8 : 16;
+        const int blk = (bf && H % 512 == 0 && B <= 8) ? 8 : 16;      // (ACT_SWIGLU8 is the batch <= 8 kernel's)
         for (int f = 0; f < I; ++f) {
             memcpy(&gu[((size_t)(f / blk) * 2 * blk + f % blk) * H], Wg + (size_t)f * H, (size_t)H * 4);
             memcpy(&gu[((size_t)(f / blk) * 2 * blk + blk + f % blk) * H], Wu + (size_t)f * H, (size_t)H * 4);

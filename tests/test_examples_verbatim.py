@@ -132,8 +132,9 @@ def _run_example(monkeypatch, tmp_path, env, script):
     monkeypatch.chdir(tmp_path)
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    import qwen_tts
     import qwen3_tts_amd
+    sys.modules.pop("qwen_tts", None)                      # (another test of this process may have re-imported the package since the alias was first resolved)
+    import qwen_tts
     assert qwen_tts.Qwen3TTSModel is qwen3_tts_amd.Qwen3TTSModel, "`from qwen_tts import Qwen3TTSModel` must resolve to this package"
     path = os.path.join(EXAMPLES, script)
     before = open(path, "rb").read()

@@ -739,7 +739,7 @@ def test_split_k_decode_gemm_at_batch_32_equals_the_unsplit_one_on_the_frame_ste
     want = cfg.num_hidden_layers + (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers
     res = {}
     for flag in ("1", "0"):
-        with _qlib.options(QTTS_SKINNY_KS=flag, QTTS_SKINNY_KS_MINK="3072"):         # (engine-level: copied at creation, the captured graph bakes it in; K floor 3072: both instantiations run -- the default, 6144, splits the talker's 28 only)
+        with _qlib.options(QTTS_SKINNY_KS=flag, QTTS_SKINNY_KS_MINK="3072", QTTS_CP_MLP32="0"):         # (engine-level: copied at creation, the captured graph bakes it in; K floor 3072 and the fused MLP launch off: both instantiations run -- by default the talker's 28 split and the code predictor's MLP is one launch)
             eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=True)
             runs = []
             for _ in range(3 if flag == "1" else 1):
@@ -762,6 +762,54 @@ def test_split_k_decode_gemm_at_batch_32_equals_the_unsplit_one_on_the_frame_ste
           f"agree {agree0:.4f}, all 16 codebooks {agree:.4f}, cb-0 logit rel. RMS {rel:.5f}; vs the fp32 reference's codes {ref1:.4f} (unsplit {ref0:.4f})")
     assert not np.array_equal(lt1, lt0), "QTTS_SKINNY_KS=0 did not select another kernel"
     assert agree0 >= 0.97 and rel <= 1.5e-2 and ref1 >= ref0 - 0.01
+
+
+def test_fused_mlp_launch_at_batch_32_equals_the_two_decode_gemms_on_the_frame_step(dev, golden_dir):
+    """`cp_mlp32_kernel` (round 6): the MLP of the code predictor's passes >= 1 as ONE launch at batch 9..32, against the two
+    decode GEMMs (QTTS_CP_MLP32=0) on the hardware through the whole frame step: 1.7B dims, batch 32, bf16, the b32 golden's 43 frames
+    teacher-forced, captured frame graph.  (1) `cp_mlp_per_step` = 14 passes x 5 layers = 70 says which path ran, the engine holds a place
+    of the device's account, no give-up; (2) three runs of the fused engine are bit-identical: every one of its 43 x 70 x 2 in-launch
+    hand-offs (32 rows each) delivered complete, current granules; (3) both forms add the same bf16 products in another fp32 order.  Under
+    teacher forcing the talker's inputs are the reference's codes, so the cb-0 logits do not see the code predictor at all (they must be
+    IDENTICAL: the talker's launches did not change); what sees it are the 15 sub-codebook decisions, which run free inside a frame: all 16
+    codebooks agree >= 95 % (98.7 % measured; the split-K test above, which changes the talker too, 93.9 %); (4) against the fp32
+    reference's codes the fused engine agrees as well as the unfused one (-1 %).  (Kernel level, emulator: every block of 8 rows equals `cp_mlp_kernel`'s bit for bit.)"""
+    from qwen3_tts_amd.talker import TalkerEngine
+    cfg = synth.talker_17b()
+    g = np.load(os.path.join(golden_dir, "talker_17b_b32.npz"))
+    wn = synth.talker_weights(cfg, with_text=False)
+    lens = [int(x) for x in g["lens"]]
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(int(g["seed"])), cfg, lens, int(g["n_trail"]), scale=0.05)
+    gc = torch.from_numpy(g["codes"].copy())
+    steps = [0, 1, 7, 20, 39]
+    want = (cfg.num_code_groups - 2) * cfg.cp_num_hidden_layers
+    res = {}
+    for flag in ("1", "0"):
+        with _qlib.options(QTTS_CP_MLP32=flag):          # (engine-level: copied at creation)
+            eng = TalkerEngine(cfg, _td(wn), weight_dtype=torch.bfloat16, device=dev, max_batch=len(lens), max_seq=256, use_graph=True)
+            runs = []
+            for _ in range(3 if flag == "1" else 1):
+                out = eng.generate(emb, mask, tr, pad, teacher_codes=gc, logit_steps=steps, suppress_tokens=_suppress(cfg))
+                runs.append((out.own.cpu().numpy(), out.logits_trace.cpu().numpy()))
+            st = eng.stats()
+            assert st["cp_mlp_per_step"] == (want if flag == "1" else 0) and st["cp_fused_giveups"] == 0 and st["cp_layer_per_step"] == 0, st
+            if flag == "1":
+                assert st["cp_fused_active"] == 1 and st["cp_fused_capacity"] == 2, st
+            res[flag] = runs
+            del eng
+            torch.cuda.empty_cache()
+    for own, lt in res["1"][1:]:
+        assert np.array_equal(own, res["1"][0][0]) and np.array_equal(lt, res["1"][0][1]), "the fused engine is not run-to-run identical"
+    (own1, lt1), (own0, lt0) = res["1"][0], res["0"][0]
+    agree0 = float((own1[:, :, 0] == own0[:, :, 0]).mean())
+    agree = float((own1 == own0).mean())
+    rel = float(np.sqrt(((lt1 - lt0) ** 2).mean()) / np.sqrt((lt0.astype(np.float64) ** 2).mean()))
+    F = g["codes"].shape[1]
+    ref1, ref0 = float((own1[:, :F] == g["codes"]).mean()), float((own0[:, :F] == g["codes"]).mean())
+    print(f"cp_mlp32 vs the two decode GEMMs on the frame step (1.7B, 32 x {F} frames, teacher-forced, bf16): {want} fused launches per step; cb-0 decisions "
+          f"agree {agree0:.4f}, all 16 codebooks {agree:.4f}, cb-0 logit rel. RMS {rel:.5f}; vs the fp32 reference's codes {ref1:.4f} (unfused {ref0:.4f})")
+    assert agree0 == 1.0 and rel == 0.0, "the talker's launches changed"
+    assert agree >= 0.95 and ref1 >= ref0 - 0.01
 
 
 def test_fused_attention_o_projection_equals_the_two_launches_on_the_frame_step(dev, golden_dir):

@@ -920,6 +920,14 @@ def test_fused_launches_fit_their_register_shares(libqtts):
     gu, att, mlp = 8 * 4 * 4 * 2 * 12 * 16, 4 * 1536 + 2 * 264 * 2 + 2 * 128 * 4 + (4 * 64 * 16 + 4 * 16 * 4), (4 * 64 * 2 * 16 + 4 * 16 * 4) + 4 * 2 * 64 * 16
     assert "static constexpr int TOTAL = GU + (ATT > MLP ? ATT : MLP);" in lay
     assert 2 * (gu + max(att, mlp)) <= 160 * 1024 * 7 // 8 < 3 * (gu + max(att, mlp))
+    # round 6: the fused MLP launch at batch 9..32 (cp_mlp32.hip): 208 registers, two engines per device inside 7/8 of the register file
+    rows = [k for k in ks if "cp_mlp32_kernel" in k[".name"]]
+    assert len(rows) >= 2, [k[".name"] for k in rows]
+    for k in rows:
+        regs = (k[".vgpr_count"] + 7) // 8 * 8
+        assert k[".max_flat_workgroup_size"] == 256 and regs <= 208 and k.get(".private_segment_fixed_size", 0) == 0, (k[".name"], regs)
+        assert k[".group_segment_fixed_size"] <= 34 * 1024, k[".name"]
+    assert "CP_SHARE_MLP32 = 208, CP_LDS_MLP32 = 34 * 1024;" in src and 2 * 208 <= 512 * 7 // 8
 
 
 def test_option_table_through_the_c_abi(libqtts):

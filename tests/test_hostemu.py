@@ -57,6 +57,7 @@ def emu():
     lib.hostemu_cp_layer_front.argtypes = [vp, i32, vp, vp, C.c_float, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, C.c_uint32, i32]
     lib.hostemu_cp_attn_o.argtypes = [vp, i32, i32, vp, vp, C.c_float, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, C.c_uint32]
     lib.hostemu_cp_mlp.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, i32, i32, vp, vp, vp, i32, C.c_uint32, i32]
+    lib.hostemu_cp_mlp32.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, i32, i32, vp, vp, vp, C.c_uint32]
     lib.hostemu_gemm_tap.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp, vp, i32, vp, i32, i32]
     lib.hostemu_skinny.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, C.c_float, vp, vp, i32, i32, vp, i32, i32]
     lib.hostemu_gemm_tap16.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp]
@@ -835,6 +836,69 @@ def test_cp_attn_o_fused_launch_real_source(emu):
             if first is None:
                 first = o1
             assert np.array_equal(o1, first), ("result depends on the wave order / the epoch", B, S0, bo, fo)
+
+
+@pytest.mark.parametrize("H,I", [(256, 1024), (1024, 3072)])
+def test_cp_mlp32_one_launch_at_batch_up_to_32_real_source(emu, H, I):
+    """`cp_mlp32_kernel` (cp_mlp32.hip, round 6): cp_mlp_kernel's construction for batch 9..32 -- both 16-row tiles of the MFMA's batch columns in
+    use, granule buffers of 32 rows per XCD, wave m of a workgroup finishing row tile m, four rows per thread in the reduce.  Per row its
+    arithmetic is the batch <= 8 kernel's statement for statement, so at the real dimensions (1024 / 3072) and at 256 / 1024 every block of 8
+    rows of a batch of 32 / 19 / 8 must equal, BIT FOR BIT, what `cp_mlp_kernel` gives for those 8 rows alone (fp32 rows and their bf16 copy);
+    against float64 numpy and the two decode-GEMM launches to the bf16 bars of the test below; three fiber orders, two launches per call on the
+    same granule buffers (0xFF-filled at first) under two serials; rows >= B untouched."""
+    g = np.random.default_rng(707 + H)
+    eps = 1e-6
+    gn = (1 + 0.1 * g.standard_normal(H)).astype(np.float32)
+    Wg = (g.standard_normal((I, H)) * 0.05).astype(np.float32)
+    Wu = (g.standard_normal((I, H)) * 0.05).astype(np.float32)
+    Wd = (g.standard_normal((H, I)) * 0.03).astype(np.float32)
+    rw = lambda a: _bf16_round(a)[0]
+    Wg_r, Wu_r, Wd_r = rw(Wg * gn[None, :]).astype(np.float64), rw(Wu * gn[None, :]).astype(np.float64), rw(Wd).astype(np.float64)
+    vp = C.c_void_p
+    for B in (32, 19, 8):
+        x = g.standard_normal((B, H)).astype(np.float32)
+        res = g.standard_normal((B, H)).astype(np.float32)
+        x_r = rw(x).astype(np.float64)
+        rs = 1.0 / np.sqrt((x_r ** 2).mean(1, keepdims=True) + eps)
+        gg, uu = (x_r @ Wg_r.T) * rs, (x_r @ Wu_r.T) * rs
+        ref = rw((gg / (1.0 + np.exp(-gg)) * uu).astype(np.float32)).astype(np.float64) @ Wd_r.T + res
+        scale = max(1.0, float(np.abs(ref).max()))
+
+        def run32(fiber_order, epoch0):
+            out = np.full((B + 1, H), 7.0, np.float32)
+            out16 = np.full((B + 1, H), 0x4242, np.uint16)
+            emu.hostemu_set_fiber_order(fiber_order)
+            try:
+                rc = emu.hostemu_cp_mlp32(_ptr(x), B, _ptr(Wg), _ptr(Wu), _ptr(gn), eps, _ptr(Wd), H, I, _ptr(res), _ptr(out), out16.ctypes.data_as(vp), epoch0)
+            finally:
+                emu.hostemu_set_fiber_order(0)
+            assert rc == 0, ((H, I, B), rc, (emu.qtts_last_error() or b"").decode())
+            assert np.all(out[B] == 7.0) and np.all(out16[B] == 0x4242), "wrote a row >= B"
+            return out[:B], out16[:B]
+
+        first = None
+        for (fo, e0) in [(0, 1), (1, 7), (2, 0xFFFFF0)]:
+            o, h = run32(fo, e0)
+            assert float(np.abs(o - ref).max()) <= 2e-2 * scale, (H, B, float(np.abs(o - ref).max()))
+            assert np.array_equal(h, _bf16_round(o)[1]), "bf16 copy of the hidden rows"
+            if first is None:
+                first = (o, h)
+            assert np.array_equal(o, first[0]), ("result depends on the wave order / the epoch", H, B, fo)
+        # every block of <= 8 rows through the batch <= 8 kernel: the same bits
+        for r0 in range(0, B, 8):
+            nb = min(8, B - r0)
+            o8 = np.full((nb, H), np.nan, np.float32)
+            h8 = np.full((nb, H), 0x4242, np.uint16)
+            xb, rb = np.ascontiguousarray(x[r0:r0 + nb]), np.ascontiguousarray(res[r0:r0 + nb])
+            rc = emu.hostemu_cp_mlp(_ptr(xb), nb, _ptr(Wg), _ptr(Wu), _ptr(gn), eps, _ptr(Wd), H, I, _ptr(rb), _ptr(o8), _ptr(h8), 3, 5, 0)
+            assert rc == 0, (emu.qtts_last_error() or b"").decode()
+            assert np.array_equal(o8, first[0][r0:r0 + nb]) and np.array_equal(h8, first[1][r0:r0 + nb]), ("rows", r0, "differ from cp_mlp_kernel's", H, B)
+        # ... and the two decode-GEMM launches it replaces (another fp32 summation order)
+        o0 = np.full((B, H), np.nan, np.float32)
+        h0 = np.full((B, H), 0x4242, np.uint16)
+        rc = emu.hostemu_cp_mlp(_ptr(x), B, _ptr(Wg), _ptr(Wu), _ptr(gn), eps, _ptr(Wd), H, I, _ptr(res), _ptr(o0), _ptr(h0), 0, 0, 0)
+        assert rc == 0, (emu.qtts_last_error() or b"").decode()
+        assert float(np.sqrt(((first[0] - o0) ** 2).mean())) <= 2e-3 * float(np.sqrt((o0 ** 2).mean())), (H, B)
 
 
 @pytest.mark.parametrize("H,I,f32", [(256, 1024, 0), (1024, 3072, 0), (256, 1024, 1), (1024, 3072, 1)])
@@ -1905,8 +1969,7 @@ def test_talker_bf16_batch_above_16_splits_k_in_the_down_projections(emu, qopt):
     down-projections of the code predictor's passes >= 1 (K = 3072 at the released width) through `skinny2_ks_kernel` -- K split over the
     workgroups of a strip group, combined inside the launch.  `ks_split_per_step` says so (and 0 with QTTS_SKINNY_KS=0: skinny2_kernel); the
     split regroups fp32 sums, so hidden states agree to bf16-step accuracy and greedy codes almost everywhere; a second generation on the
-    same handle (workspace re-used, serial advanced) repeats the first bit for bit; pass 0 (two tokens = 36 rows) and batch <= 16 keep
-    skinny2_kernel."""
+    same handle (workspace re-used, serial advanced) repeats the first bit for bit; pass 0 (two tokens = 36 rows) keeps skinny2_kernel."""
     import dataclasses
     t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=2,
                             cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
@@ -1915,12 +1978,13 @@ def test_talker_bf16_batch_above_16_splits_k_in_the_down_projections(emu, qopt):
     emu.hostemu_set_real_gemm(1)
     res = {}
     try:
-        for nb, want in ((18, (t.num_code_groups - 2) * t.cp_num_hidden_layers), (16, 0)):
+        for nb, want in ((18, (t.num_code_groups - 2) * t.cp_num_hidden_layers),):       # (M <= 16 never splits: skinny.hip ksplit_choice, kernel-level test)
             emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(63), t, [3 + i % 4 for i in range(nb)], 2, scale=0.5)
             args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
             for mode in ("1", "0"):
                 qopt(emu, "QTTS_SKINNY_KS", mode)
                 qopt(emu, "QTTS_SKINNY_KS_MINK", "3072")       # (the default floor, 6144, splits the talker's down-projection only: profiles/r06_skinny_ksplit.md)
+                qopt(emu, "QTTS_CP_MLP32", "0")                # (the fused MLP launch at batch 9..32 takes these down-projections by default: its own test below)
                 h = _talker_emu(emu, t, w, max_batch=32, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=1)
                 try:
                     codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=3)
@@ -1940,7 +2004,51 @@ def test_talker_bf16_batch_above_16_splits_k_in_the_down_projections(emu, qopt):
     assert c1.shape == c0.shape and c1.shape[1] >= 2
     assert float(np.abs(h1 - h0).max()) <= 3e-2 * max(1.0, float(np.abs(h0).max())), float(np.abs(h1 - h0).max())
     assert float((c1 == c0).mean()) >= 0.95
-    assert np.array_equal(res[(16, "1")][0], res[(16, "0")][0]) and np.array_equal(res[(16, "1")][1], res[(16, "0")][1])
+
+
+def test_talker_bf16_batch_above_8_runs_the_code_predictors_mlp_as_one_launch(emu, qopt):
+    """Round 6: a bf16 engine created for more than 8 rows runs the MLP of the code predictor's passes >= 1 as ONE launch
+    at batch 9..32 too (`cp_mlp32_kernel`, released width 1024 / 3072, captured frame graph).  `cp_mlp_per_step` says which path ran (0 with
+    QTTS_CP_MLP32=0: the two decode GEMMs), the engine holds a place of the device's account (208 registers: two such engines per device), a
+    second generation on the same handle repeats the first bit for bit; fused and unfused add the same bf16 products in another fp32 order
+    (kernel level: every 8-row block equals cp_mlp_kernel's bit for bit -- test_cp_mlp32_...), so hidden states agree to bf16-step accuracy
+    and greedy codes almost everywhere; at batch <= 8 the same engine keeps skinny8 / the separate launches (cp_mlp_kernel is for engines
+    created for <= 8 rows)."""
+    import dataclasses
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=2,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
+    per_step = (t.num_code_groups - 2) * t.cp_num_hidden_layers
+    emu.hostemu_set_real_gemm(1)
+    res = {}
+    try:
+        for nb in (19,):
+            emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(64), t, [3 + i % 4 for i in range(nb)], 2, scale=0.5)
+            args = (emb.numpy(), mask.numpy(), tr.numpy(), pad.numpy())
+            for mode in ("1", "0"):
+                qopt(emu, "QTTS_CP_MLP32", mode)
+                h = _talker_emu(emu, t, w, max_batch=32, max_seq=64, dtype=_lib.QTTS_BF16, use_graph=1)
+                try:
+                    codes, tokens, hidden = _talker_generate(emu, h, t, *args, max_new=3)
+                    st = _lib.TalkerStatsC()
+                    _ok(emu, emu.qtts_talker_get_stats(h, C.byref(st)))
+                    assert st.cp_mlp_per_step == (per_step if mode == "1" else 0), (nb, mode, st.cp_mlp_per_step)
+                    assert st.cp_fused_giveups == 0 and st.cp_layer_per_step == 0 and st.ks_split_per_step == 0
+                    if mode == "1":
+                        assert st.cp_fused_active == 1 and st.cp_fused_capacity == 2, (st.cp_fused_active, st.cp_fused_capacity)
+                        codes2, tokens2, hidden2 = _talker_generate(emu, h, t, *args, max_new=3)
+                        assert np.array_equal(codes, codes2) and np.array_equal(hidden, hidden2)
+                    res[(nb, mode)] = (codes, hidden)
+                finally:
+                    emu.qtts_talker_destroy(h)
+    finally:
+        emu.hostemu_set_real_gemm(1 if FULL else 0)
+    for nb in (19,):
+        (c1, h1), (c0, h0) = res[(nb, "1")], res[(nb, "0")]
+        assert c1.shape == c0.shape and c1.shape[1] >= 2
+        assert float(np.abs(h1 - h0).max()) <= 3e-2 * max(1.0, float(np.abs(h0).max())), (nb, float(np.abs(h1 - h0).max()))
+        assert float((c1 == c0).mean()) >= 0.95, nb
 
 
 def test_fused_code_predictor_launch_is_admitted_per_device_by_residency(emu, qopt):

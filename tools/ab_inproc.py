@@ -35,6 +35,8 @@ CONFIGS = {
     "skinny8_nw8": {"QTTS_SKINNY8_NW": "8"},
     "skinny8_nw4": {"QTTS_SKINNY8_NW": "4"},
     # round 6, --batch 32: the o- / down-projections at batch 17..32 with K split over workgroups (skinny2_ks_kernel)
+    "mlp32_off": {"QTTS_CP_MLP32": "0"}, "mlp32_off_ks_off": {"QTTS_CP_MLP32": "0", "QTTS_SKINNY_KS": "0"},       # round 6, --batch 32: the code predictor's MLP as one launch at batch 9..32
+    "mlp32_b16": {"QTTS_CP_MLP_PAUSE_B": "16"}, "mlp32_b32": {"QTTS_CP_MLP_PAUSE_B": "32"}, "mlp32_b40": {"QTTS_CP_MLP_PAUSE_B": "40"}, "mlp32_c32": {"QTTS_CP_MLP_PAUSE_C": "32"}, "mlp32_c40": {"QTTS_CP_MLP_PAUSE_C": "40"},
     "ks_off": {"QTTS_SKINNY_KS": "0"}, "ks_mink2048": {"QTTS_SKINNY_KS_MINK": "2048"}, "ks_mink6144": {"QTTS_SKINNY_KS_MINK": "6144"},
     "ks_pause0": {"QTTS_SKINNY_KS_PAUSE": "0"}, "ks_pause16": {"QTTS_SKINNY_KS_PAUSE": "16"}, "ks_pause24": {"QTTS_SKINNY_KS_PAUSE": "24"},
     "ks_pause32": {"QTTS_SKINNY_KS_PAUSE": "32"}, "ks_pause48": {"QTTS_SKINNY_KS_PAUSE": "48"}, "ks_pause64": {"QTTS_SKINNY_KS_PAUSE": "64"},

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_digest():
     h = hashlib.sha256()
-    for f in ("skinny.hip", "talker_engine.hip", "attention.hip", "cp_mlp.hip"):
+    for f in ("skinny.hip", "talker_engine.hip", "attention.hip", "cp_mlp.hip", "cp_layer.hip", "cp_mlp32.hip"):
         with open(os.path.join(ROOT, "qwen3-tts_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -48,7 +48,10 @@ if __name__ == "__main__":
     def fused_key(name):
         if "cp_mlp_kernel<" in name:
             return "mlp"
-        m = re.search(r"cp_attn_o_kernel<(true|false), (true|false)>", name)
+        m = re.search(r"cp_layer_kernel<(true|false), ", name)          # (round 6: <QKV, F32, ...> -- the whole layer in one launch)
+        if m:
+            return "layer_front" if m.group(1) == "true" else "layer"
+        m = re.search(r"cp_attn_o_kernel<(true|false), (true|false)[,>]", name)
         return None if not m else ("front" if m.group(2) == "true" else "attn_o")
     for name, cname, v, g, w in rows:
         if cname != "FETCH_SIZE":
