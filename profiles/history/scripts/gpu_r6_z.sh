@@ -4,7 +4,7 @@
 # this tree's digest, frac_rocprof), the codec's kernel trace and MFMA-busy counters at 8 x 10 s, config 5 as its own job.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../../..}"
-OUT=gpurun_out/r6z
+OUT=gpurun_out/r6z2
 mkdir -p "$OUT"
 export PYTHONUNBUFFERED=1
 run() { local name=$1 lim=$2; shift 2; local t0=$(date +%s)
@@ -12,7 +12,7 @@ run() { local name=$1 lim=$2; shift 2; local t0=$(date +%s)
         echo "$name rc=$rc $(( $(date +%s) - t0 ))s" | tee -a "$OUT/summary.txt"; tail -n ${TAILN:-3} "$OUT/$name.log" | cut -c1-600 | sed "s/^/    /"; }
 prof() { local name=$1; shift; ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 "$@" > "$OLDPWD/$OUT/$name.log" 2>&1 ); echo "$name rc=$?" | tee -a "$OUT/summary.txt"; }
 : > "$OUT/summary.txt"
-TAILN=4 run pytest_gpu 1100 python -m pytest tests -q -m gpu -s
+TAILN=4 run pytest_gpu 1700 python -m pytest tests -q -m gpu -s
 run smoke 200 python __graft_entry__.py --smoke
 # counters first (their own pass), then the trace of the bench command, then the JSON the bench line reads
 prof pmc_fetch --kernel-trace --pmc FETCH_SIZE -d "$PWD/$OUT/pmc1" -o pmc -- python "$PWD/tools/perf_frame.py" --model 1.7b --frames 4 --talker --reps 1 --no-graph

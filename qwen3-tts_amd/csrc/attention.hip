@@ -130,7 +130,130 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(AttnRowsParams p) {
     }
 }
 
+// Round 6: R = 4 consecutive query rows of a (sequence, head) per wave, for the full-causal case (no sliding window: the talker's prefill).  A wave of
+// attn_rows_kernel is a chain of dependent L2 round trips (16 keys per trip, two passes), and a batch-32 prefill is 32 768 of them per layer -- seven
+// residency rounds: 91 us per layer, 2.6 ms of config 4's 12 ms prefill (profiles/r06_kernel_trace_frame_b32.md).  Here a trip's K (and V) rows serve
+// four query rows: a quarter of the waves and of the K / V reads.  Per row NOTHING changes: without a window every row of a sequence starts at the same
+// key (lo = n_pad), so key s belongs to the same 16-lane group, is folded in the same (ascending) order and the groups are combined by the same
+// shuffles -- bit-identical to attn_rows_kernel row by row (emulator test), which is what the fp32 parity mode's goldens need.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_rows4_kernel(AttnRowsParams p) {
+    constexpr int DPL = HD / 16, R = 4, UN = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, li = lane & 15;
+    const int nblk = (p.T + R - 1) / R;
+    const int64_t item = (int64_t)blockIdx.x * 4 + wave;   // (b, h, row block)
+    if (item >= (int64_t)p.B * p.nh * nblk) return;
+    const int t0 = (int)(item % nblk) * R;
+    const int h = (int)((item / nblk) % p.nh);
+    const int b = (int)(item / ((int64_t)nblk * p.nh));
+    const int npad = p.n_pad ? p.n_pad[b] : 0;
+    const int kvh = h / (p.nh / p.nkv);
+    const float scale = rsqrtf((float)HD);
+    const float* base = p.qkv + (size_t)b * p.T * p.ld;
+    float q[R][DPL];
+    bool live[R];                                           // a real, non-pad query row
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        live[r] = t0 + r < p.T && t0 + r >= npad;
+        const float* qp = base + (size_t)(t0 + r < p.T ? t0 + r : p.T - 1) * p.ld + p.q_off + h * HD + li * DPL;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) q[r][d] = qp[d];
+    }
+    const int lo = npad;
+    const int hi = (t0 + R - 1 < p.T ? t0 + R - 1 : p.T - 1);   // the last row's last key; row r stops at key t0 + r
+    const float* kb = base + p.k_off + kvh * HD + li * DPL;
+    const float* vb = base + p.v_off + kvh * HD + li * DPL;
+    float m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) m[r] = -INFINITY;
+    for (int s0 = lo + g; s0 <= hi; s0 += 4 * UN) {          // pass 1: row maxima
+        float kr[UN][DPL];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int sc = s0 + 4 * u <= hi ? s0 + 4 * u : hi;
+            const float* kp = kb + (size_t)sc * p.ld;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) kr[u][e] = kp[e];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (s0 + 4 * u > t0 + r) continue;               // (wave-uniform within a 16-lane group: all its lanes hold the same key)
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) d += q[r][e] * kr[u][e];
+                d = group16_sum(d) * scale;
+                m[r] = fmaxf(m[r], d);
+            }
+    }
+    float l[R], acc[R][DPL];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        m[r] = fmaxf(m[r], __shfl_xor(m[r], 16));
+        m[r] = fmaxf(m[r], __shfl_xor(m[r], 32));
+        l[r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) acc[r][e] = 0.f;
+    }
+    for (int s0 = lo + g; s0 <= hi; s0 += 4 * UN) {          // pass 2: exp, sum, PV
+        float kr[UN][DPL], vr[UN][DPL];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int sc = s0 + 4 * u <= hi ? s0 + 4 * u : hi;
+            const float* kp = kb + (size_t)sc * p.ld;
+            const float* vp = vb + (size_t)sc * p.ld;
+#pragma unroll
+            for (int e = 0; e < DPL; ++e) { kr[u][e] = kp[e]; vr[u][e] = vp[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (s0 + 4 * u > t0 + r) continue;
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) d += q[r][e] * kr[u][e];
+                d = group16_sum(d) * scale;
+                const float pr = expf(d - m[r]);
+                l[r] += pr;
+#pragma unroll
+                for (int e = 0; e < DPL; ++e) acc[r][e] += pr * vr[u][e];
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        l[r] += __shfl_xor(l[r], 16);
+        l[r] += __shfl_xor(l[r], 32);
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            acc[r][e] += __shfl_xor(acc[r][e], 16);
+            acc[r][e] += __shfl_xor(acc[r][e], 32);
+        }
+        if (g != 0 || t0 + r >= p.T) continue;
+        const size_t ooff = ((size_t)b * p.T + t0 + r) * p.ldo + h * HD + li * DPL;
+        float* orow = p.out + ooff;
+        bf16_t* orow16 = reinterpret_cast<bf16_t*>(p.out16) + ooff;
+        const float inv = 1.f / l[r];
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) {
+            const float v = live[r] ? acc[r][e] * inv : 0.f;   // (a left-pad query row: zeros, never read downstream)
+            if (p.out16) orow16[e] = f32_to_bf16(v); else orow[e] = v;
+        }
+    }
+}
+
 void launch_attn_rows(const AttnRowsParams& p, hipStream_t st) {
+    // full-causal attention over more than a few rows (the talker's prefill): four query rows per wave (QTTS_ATTN_ROWS4=0: one)
+    if (p.window <= 0 && p.T >= 8 && (p.hd == 64 || p.hd == 128) && QTTS_OPT_ON("QTTS_ATTN_ROWS4")) {
+        const int64_t items = (int64_t)p.B * p.nh * ((p.T + 3) / 4);
+        const int grid4 = (int)((items + 3) / 4);
+        if (p.hd == 64) hipLaunchKernelGGL(attn_rows4_kernel<64>, dim3(grid4), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_rows4_kernel<128>, dim3(grid4), dim3(256), 0, st, p);
+        QTTS_CHECK_HIP(hipGetLastError());
+        return;
+    }
     const int64_t total = (int64_t)p.B * p.nh * p.T;
     const int grid = (int)((total + 3) / 4);
     if (p.hd == 64) hipLaunchKernelGGL(attn_rows_kernel<64>, dim3(grid), dim3(256), 0, st, p);

@@ -25,7 +25,7 @@
 // A consumer that loses its producers gives up and latches the generation's stop flag (the cold block of its polling loop: nothing
 // else of the loop may depend on it -- attention.hip: cpao_give_up): what the launch still writes is never consumed.
 // bf16 engines, batch <= 8, H % 128 == 0, (I / (H / 4)) in {4, 8, 12, 16}; everything else keeps the two launches.  (24 KB of the down
-// operator: requested behind phase A's MFMAs since the A/B of profiles/r05_cp_mlp.md; `wd_early` is the first version.)
+// operator: requested behind phase A's MFMAs since the A/B of profiles/r05_cp_mlp.md.)
 // fp32 engines (the exact parity mode), on request (QTTS_CP_MLP_F32=1): the F32 instantiation of the same source -- fp32 operators, rows and
 // intermediate vector -- through which the reference's fp32 goldens run bit-exact on the MI355X (tests/test_gpu_parity.py:
 // test_fused_launches_fp32_instantiations_bit_exact_vs_reference_golden); slower there than the split-K plan, hence not the default.
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
         }
     }
     // phase B's block of the down operator: requested BEHIND phase A's operands are consumed (its 24 KB would share the workgroup's memory
-    // pipe with the 48 KB phase A waits for; it streams while the quarters are combined and the granules travel) -- or at entry (wd_early, A/B)
+    // pipe with the 48 KB phase A waits for; it streams while the quarters are combined and the granules travel) (at entry -- round 5's first version -- the frame was 1.8 % slower: profiles/r05_cp_mlp.md; switch retired in round 6)
     auto load_wd = [&] {
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
             for (int t = 0; t < KTW; ++t) wd[t2][t] = dsrc[t * 64];
         }
     };
-    if (P.wd_early || !run_a) load_wd();
+    if (!run_a) load_wd();
     const int done = P.done_flag ? *P.done_flag : 0;
     if (done) return;
     f32x4* qa = reinterpret_cast<f32x4*>(smem);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void cp_mlp_kernel(const void* kWgu, const voi
                 au4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb2, xb, au4, 0, 0, 0);
             }
         }
-        if (!P.wd_early) load_wd();
+        load_wd();
         ssq += __shfl_xor(ssq, 16);
         ssq += __shfl_xor(ssq, 32);                      // every lane: its row's sum over this wave's k quarter
         qa[(wave * 64 + lane) * 2] = ag4;

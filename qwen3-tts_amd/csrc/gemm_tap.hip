@@ -782,12 +782,7 @@ static int g_wide_force = -1;                    // tests / A-B tooling: bm bn b
 static WideTile wide_tile(const GemmTapParams& p, bool a16, int bn_max) {
     const int force_env = QTTS_OPT_INT("QTTS_GEMM_WIDE_TILE", 0);
     const int force = g_wide_force >= 0 ? g_wide_force : force_env;
-    const bool legacy = [] { const char* e = QTTS_ENV("QTTS_GEMM_NARROW"); return e && atoi(e) == 0; }();   // round 2's rule
     WideTile best{128, bn_max, 128};
-    if (legacy) {
-        if (!a16 && bn_max == 128 && p.act != ACT_SWIGLU && cdiv(p.M, 128) * cdiv(p.N, 128) < 128 && p.N % 64 == 0) best.bn = 64;
-        return best;
-    }
     // CU count of the device the launch goes to (256 on MI355X; the three rates in the cost model above are MI355X measurements)
     static const int n_cu = [] {
         int dev = 0, n = 0;
@@ -905,7 +900,6 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
     else if (p.N <= 64) bn = 64;
     else bn = 128;
     // small grids are bound by what the CUs holding a workgroup can pull: the deep-k kernel (bf16, plain Linear), tile by wide_tile()
-    // (QTTS_GEMM_NARROW=0: always 128 rows, and 64 columns only where N asks for it -- round 2's rule, for A/B runs)
     if (bf16 && p.taps == 1 && p.shift[0] == 0 && p.K % 128 == 0 && p.K >= 512 && (bn == 128 || bn == 64) &&
         cdiv(p.M, 128) * cdiv(p.N, bn) <= wide_max_tiles) {
         launch_wide<false>(p, bn, st);

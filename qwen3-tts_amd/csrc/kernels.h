@@ -287,7 +287,6 @@ struct CpMlpParams {
     int* err; int* done_latch;    // give-up flag and the generation's stop latch (set by a consumer that gives up)
     const int* done_flag;         // optional: when non-zero the kernel exits early
     int first_pause, poll_step;   // x 64 clocks, as for cp_attn_o
-    int wd_early;                 // 1: the down operator's block is requested at kernel entry (A/B; default: behind phase A's MFMAs)
     int pause_c;                  // x 64 clocks: the reducer's wait before its first read of the partial sums (first_pause: phase B's before the slice)
     int B, H, I;
 };

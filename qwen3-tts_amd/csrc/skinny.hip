@@ -1021,16 +1021,13 @@ static void launch2_u(const SkinnyParams& p, int nchunks, hipStream_t st) {
     // Round 3: the same for batch 17..32 (two 16-row tiles; chunks of 4 / SPW k-tiles, so K <= 3072 at 8 waves: every code-predictor
     // GEMM and the talker's q|k|v, o and gate|up).  In the generic loop the waves of a launch drift apart by a memory round trip per
     // chunk pair -- in-kernel timestamps at batch 32: 1.0-2.4 us between the first wave's last MFMA and the barrier
-    // (profiles/r03_skinny_b32_straight.md).  QTTS_SKINNY2_STRAIGHT_MT2=0 keeps the loop (A/B; QTTS_ENV).
+    // (profiles/r03_skinny_b32_straight.md; the A/B switch for the loop form was retired in round 6: measured in rounds 3 and 4).
     if constexpr (EXACT && MT == 2 && XB16 && NW == 8) {
-        const char* e = QTTS_ENV("QTTS_SKINNY2_STRAIGHT_MT2");
-        if (!(e && e[0] == '0')) {
-            if (nchunks == 1) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 1>(p, st); return; }
-            if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2>(p, st); return; }
-            if (nchunks == 3) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 3>(p, st); return; }
-            if constexpr (SPW == 2) {      // (chunks of 2 k-tiles: the talker's gate|up, K = 2048, is 4 of them)
-                if (nchunks == 4) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 4>(p, st); return; }
-            }
+        if (nchunks == 1) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 1>(p, st); return; }
+        if (nchunks == 2) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 2>(p, st); return; }
+        if (nchunks == 3) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 3>(p, st); return; }
+        if constexpr (SPW == 2) {      // (chunks of 2 k-tiles: the talker's gate|up, K = 2048, is 4 of them)
+            if (nchunks == 4) { launch2_n<MT, SPW, NW, FS, XB16, U, true, 4>(p, st); return; }
         }
     }
     launch2_n<MT, SPW, NW, FS, XB16, U, EXACT, 0>(p, st);
@@ -1084,7 +1081,7 @@ static int ksplit_choice(int M, int N, int K, int fs) {
     if (M <= 16 || M > 32 || N % 32 != 0 || K % 32 != 0) return 0;
     const int groups = N / 32, nkt = K / 32, ks = groups >= 64 ? 4 : 8;
     if (fs == 8 && ks == 4 && nkt == 4 * 8 * 6) return 1;
-    if (fs == 8 && ks == 8 && nkt == 8 * 4 * 3) return QTTS_OPT_INT("QTTS_SKINNY_KS_DOWN1024", 8) == 4 ? 5 : 2;      // (A/B: 4 parts of 8 waves x 3 tiles, 128 workgroups)
+    if (fs == 8 && ks == 8 && nkt == 8 * 4 * 3) return 2;
     if (fs == 16 && ks == 4 && nkt == 4 * 8 * 2) return 3;
     if (fs == 8 && ks == 8 && nkt == 8 * 8 * 1) return 4;
     return 0;
@@ -1108,7 +1105,6 @@ static bool launch_skinny_ks(const SkinnyParams& p, int fs, hipStream_t st) {
         case 2: launch_ks_n<4, 8, 4, 3, 8>(p, st); return true;
         case 3: launch_ks_n<2, 16, 8, 2, 4>(p, st); return true;
         case 4: launch_ks_n<4, 8, 8, 1, 8>(p, st); return true;
-        case 5: launch_ks_n<4, 8, 8, 3, 4>(p, st); return true;
         default: return false;
     }
 }

@@ -224,7 +224,6 @@ struct qtts_talker {
     DevBuf ao_qkv;                     // [8 rows][q|k|v width] granules {value, tag}
     // The code predictor's MLP of a layer as ONE launch (cp_mlp.hip; round 5).  QTTS_CP_MLP=0 (copied at engine creation): the two decode GEMMs.
     bool cp_mlp_env = QTTS_OPT_ON("QTTS_CP_MLP");
-    int cp_mlp_wd_early = QTTS_OPT_INT("QTTS_CP_MLP_WD_EARLY", 0);      // (A/B: the down operator's block requested at kernel entry)
     // a consumer's wait before its first read of other workgroups' granules, x 64 clocks (A/B sweep profiles/r05_cp_mlp.md: a read that
     // leaves too early comes back stale and costs a round trip -- 8: 2.63, 16: 2.55, 24: 2.50, 32: 2.54 ms per frame with one value for both)
     int cp_mlp_pause_b = [] { const char* e = QTTS_ENV("QTTS_CP_MLP_PAUSE_B"); return e && atoi(e) >= 0 ? std::min(atoi(e), 200) : 24; }();
@@ -470,7 +469,7 @@ struct qtts_talker {
             m.res = xs; m.out = xs; m.out16 = bf16 ? xs16 : nullptr;
             m.act_gran = mlp_act.as<float>(); m.part = mlp_part.as<float>(); m.serial = ss.frame_serial; m.slot = len_static * CP_FUSED_MAX_LAYERS + layer; m.phase = 3;
             m.err = ss.n_generated + 5; m.done_latch = ss.done; m.done_flag = ss.done; m.first_pause = cp_attn_o_pause; m.poll_step = cp_attn_o_step;
-            m.B = M; m.H = d.H; m.I = d.I; m.wd_early = cp_mlp_wd_early;
+            m.B = M; m.H = d.H; m.I = d.I;
             m.first_pause = cp_mlp_pause_b; m.pause_c = cp_mlp_pause_c; m.poll_step = cp_mlp_step;
             if (mlp32_fusable) {       // (its own granule buffers: 32 rows per XCD)
                 m.act_gran = mlp32_act.as<float>(); m.part = mlp32_part.as<float>();

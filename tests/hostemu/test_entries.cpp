@@ -160,6 +160,18 @@ extern "C" int hostemu_skinny_ksplit(const float* x, int ldx, int M, const float
     } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
 }
 
+// attn_rows (attention.hip): the prefill / codec-transformer attention over a fused fp32 q|k|v buffer [B][T][(nh + 2 nkv) hd]; out fp32 [B][T][nh hd]
+// (or its bf16 image when out16 is given).  The launcher's choice (one query row per wave, or four: round 6) follows the option table.
+extern "C" int hostemu_attn_rows(const float* qkv, int B, int T, int nh, int nkv, int hd, const int* n_pad, int window, float* out, unsigned short* out16) {
+    try {
+        qtts::AttnRowsParams p{};
+        p.qkv = qkv; p.ld = (nh + 2 * nkv) * hd; p.q_off = 0; p.k_off = nh * hd; p.v_off = (nh + nkv) * hd;
+        p.B = B; p.T = T; p.nh = nh; p.nkv = nkv; p.hd = hd; p.window = window; p.n_pad = n_pad; p.out = out; p.ldo = nh * hd; p.out16 = out16;
+        qtts::launch_attn_rows(p, nullptr);
+        return 0;
+    } catch (const qtts::Error& e) { return e.code; } catch (...) { return -1; }
+}
+
 // One launch of sampling.hip's sample_kernel on B rows of logits: HF processors (repetition penalty over `generated`,
 // min-new-tokens EOS block, suppress mask), temperature / top-k / top-p, Philox draw keyed by (seed, stream_id, step).
 extern "C" int hostemu_sample(const float* logits, int ld, int V, int B, const int* generated, int gen_stride, int n_generated,

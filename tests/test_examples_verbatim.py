@@ -130,10 +130,12 @@ def _run_example(monkeypatch, tmp_path, env, script):
         return _Resp(clips[str(url).rsplit("/", 1)[-1]])
     monkeypatch.setattr(urllib.request, "urlopen", fake_urlopen)
     monkeypatch.chdir(tmp_path)
-    if ROOT not in sys.path:
-        sys.path.insert(0, ROOT)
+    # `qwen_tts` must resolve to THIS repository's alias package, whatever ran before in this process: tests/test_attach_reference.py imports the
+    # REFERENCE's `qwen_tts` (from /root/reference, which it puts on sys.path) -- in file order it runs right before this module
+    for name in [n for n in sys.modules if n == "qwen_tts" or n.startswith("qwen_tts.")]:
+        monkeypatch.delitem(sys.modules, name)
+    monkeypatch.setattr(sys, "path", [ROOT] + [q for q in sys.path if os.path.abspath(q or ".") not in (ROOT, os.path.abspath(os.path.dirname(EXAMPLES)))])
     import qwen3_tts_amd
-    sys.modules.pop("qwen_tts", None)                      # (another test of this process may have re-imported the package since the alias was first resolved)
     import qwen_tts
     assert qwen_tts.Qwen3TTSModel is qwen3_tts_amd.Qwen3TTSModel, "`from qwen_tts import Qwen3TTSModel` must resolve to this package"
     path = os.path.join(EXAMPLES, script)

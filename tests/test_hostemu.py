@@ -650,6 +650,47 @@ def test_skinny_bf16_split_k_batch_17_to_32(emu, qopt):
     assert np.array_equal(o["1"], o["0"])
 
 
+def test_prefill_attention_four_rows_per_wave_is_bit_identical_to_one_row_per_wave(emu, qopt):
+    """Round 6: `attn_rows4_kernel` (attention.hip) -- the talker prefill's full-causal attention with four consecutive query rows of a
+    (sequence, head) per wave, so that a trip's K / V rows serve four rows (a batch-32 prefill is 32 768 one-row waves per layer: 91 us on the
+    MI355X).  Without a window every row of a sequence starts at the same key, so per row nothing changes: the output must equal
+    `attn_rows_kernel`'s (QTTS_ATTN_ROWS4=0) BIT FOR BIT -- fp32 rows and the bf16 image -- for ragged left-padded batches, T not a multiple
+    of 4, head_dim 128 and 64, GQA 2:1, row blocks that start inside the pad; and float64 numpy to fp32 accuracy.  Windowed attention (the
+    codec's transformer) keeps the one-row kernel (the switch changes nothing there)."""
+    g = np.random.default_rng(414)
+    i32, vp = C.c_int32, C.c_void_p
+    emu.hostemu_attn_rows.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]
+    for (B, T, nh, nkv, hd, pads, window) in [(3, 21, 4, 2, 128, [0, 5, 18], 0), (2, 9, 4, 2, 64, [2, 0], 0), (1, 37, 2, 2, 128, None, 0), (2, 24, 4, 4, 64, [0, 3], 10)]:
+        qkv = g.standard_normal((B, T, (nh + 2 * nkv) * hd)).astype(np.float32)
+        npad = np.array(pads, np.int32) if pads is not None else None
+        res = {}
+        for mode in ("1", "0"):
+            qopt(emu, "QTTS_ATTN_ROWS4", mode)
+            for with16 in (0, 1):
+                out = np.full((B, T, nh * hd), 7.0, np.float32)
+                out16 = np.full((B, T, nh * hd), 0x4242, np.uint16)
+                rc = emu.hostemu_attn_rows(_ptr(qkv), B, T, nh, nkv, hd, npad.ctypes.data_as(vp) if npad is not None else None, window, _ptr(out),
+                                           out16.ctypes.data_as(vp) if with16 else None)
+                assert rc == 0, (emu.qtts_last_error() or b"").decode()
+                res[(mode, with16)] = (out16 if with16 else out).copy()
+        assert np.array_equal(res[("1", 0)], res[("0", 0)]) and np.array_equal(res[("1", 1)], res[("0", 1)]), (B, T, nh, hd, window)
+        # float64 reference (rows inside the pad are zeros)
+        q = qkv[..., :nh * hd].reshape(B, T, nh, hd).astype(np.float64)
+        k = qkv[..., nh * hd:(nh + nkv) * hd].reshape(B, T, nkv, hd).astype(np.float64)
+        v = qkv[..., (nh + nkv) * hd:].reshape(B, T, nkv, hd).astype(np.float64)
+        ref = np.zeros((B, T, nh, hd))
+        for b in range(B):
+            p0 = int(npad[b]) if npad is not None else 0
+            for t in range(p0, T):
+                lo = max(p0, t - window + 1) if window > 0 else p0
+                for h in range(nh):
+                    kh = h // (nh // nkv)
+                    sc = (k[b, lo:t + 1, kh] @ q[b, t, h]) / np.sqrt(hd)
+                    w = np.exp(sc - sc.max()); w /= w.sum()
+                    ref[b, t, h] = w @ v[b, lo:t + 1, kh]
+        assert float(np.abs(res[("1", 0)].reshape(B, T, nh, hd) - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("bf16", [0, 1])
 def test_attn_decode_kernel_real_source_long_sequences(emu, bf16):
     """attention.hip's decode kernel from its real source against float64 numpy: q/k RMSNorm + rotate-half RoPE at position
@@ -1971,7 +2012,7 @@ def test_talker_bf16_batch_above_16_splits_k_in_the_down_projections(emu, qopt):
     split regroups fp32 sums, so hidden states agree to bf16-step accuracy and greedy codes almost everywhere; a second generation on the
     same handle (workspace re-used, serial advanced) repeats the first bit for bit; pass 0 (two tokens = 36 rows) keeps skinny2_kernel."""
     import dataclasses
-    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=2,
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=3, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=2,
                             cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
     w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
     emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]
@@ -2015,7 +2056,7 @@ def test_talker_bf16_batch_above_8_runs_the_code_predictors_mlp_as_one_launch(em
     and greedy codes almost everywhere; at batch <= 8 the same engine keeps skinny8 / the separate launches (cp_mlp_kernel is for engines
     created for <= 8 rows)."""
     import dataclasses
-    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=4, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=2,
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=3, cp_hidden_size=1024, cp_intermediate_size=3072, cp_num_hidden_layers=2,
                             cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
     w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
     emu.qtts_talker_get_stats.argtypes = [C.c_void_p, C.POINTER(_lib.TalkerStatsC)]

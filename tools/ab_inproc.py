@@ -25,7 +25,6 @@ CONFIGS = {
     "f32_fused_mlp": {"QTTS_CP_MLP_F32": "1"},
     "f32_fused_both": {"QTTS_CP_MLP_F32": "1", "QTTS_CP_ATTN_O_F32": "1"},     # ... and cp_attn_o_kernel<.., .., true>: every launch of passes >= 1 fused       # --dtype f32: cp_mlp_kernel<true, ...> against the fp32 split-K plan (the default there)
     "cp_fused_off": {"QTTS_CP_MLP": "0", "QTTS_CP_ATTN_O": "0"},   # ... and q|k|v / attention / o-projection as separate launches (round 3's)
-    "mlp_wd_early": {"QTTS_CP_MLP_WD_EARLY": "1"},                  # the fused MLP's down block requested at kernel entry (round 5's first version)
     "mlp_b16_c24": {"QTTS_CP_MLP_PAUSE_B": "16"}, "mlp_b20_c24": {"QTTS_CP_MLP_PAUSE_B": "20"}, "mlp_b28_c24": {"QTTS_CP_MLP_PAUSE_B": "28"},
     "mlp_b24_c16": {"QTTS_CP_MLP_PAUSE_C": "16"}, "mlp_b24_c20": {"QTTS_CP_MLP_PAUSE_C": "20"}, "mlp_b24_c28": {"QTTS_CP_MLP_PAUSE_C": "28"},
     "mlp_b24_c32": {"QTTS_CP_MLP_PAUSE_C": "32"}, "mlp_b28_c28": {"QTTS_CP_MLP_PAUSE_B": "28", "QTTS_CP_MLP_PAUSE_C": "28"},
@@ -40,7 +39,6 @@ CONFIGS = {
     "ks_off": {"QTTS_SKINNY_KS": "0"}, "ks_mink2048": {"QTTS_SKINNY_KS_MINK": "2048"}, "ks_mink6144": {"QTTS_SKINNY_KS_MINK": "6144"},
     "ks_pause0": {"QTTS_SKINNY_KS_PAUSE": "0"}, "ks_pause16": {"QTTS_SKINNY_KS_PAUSE": "16"}, "ks_pause24": {"QTTS_SKINNY_KS_PAUSE": "24"},
     "ks_pause32": {"QTTS_SKINNY_KS_PAUSE": "32"}, "ks_pause48": {"QTTS_SKINNY_KS_PAUSE": "48"}, "ks_pause64": {"QTTS_SKINNY_KS_PAUSE": "64"},
-    "ks_down4": {"QTTS_SKINNY_KS_DOWN1024": "4"}, "ks_down4_p32": {"QTTS_SKINNY_KS_DOWN1024": "4", "QTTS_SKINNY_KS_PAUSE": "32"},
     "ks_mink6144_p32": {"QTTS_SKINNY_KS_MINK": "6144", "QTTS_SKINNY_KS_PAUSE": "32"}, "ks_mink6144_p48": {"QTTS_SKINNY_KS_MINK": "6144", "QTTS_SKINNY_KS_PAUSE": "48"},
 }
 KEYS = sorted({k for c in CONFIGS.values() for k in c})
