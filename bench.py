@@ -596,8 +596,15 @@ def configs_leg(args, tcfg, ccfg, tw_np, cw_np, dev):
                                                       "achieved": round(streamed / (r5["ms_per_step"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(streamed / (r5["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     log(f"configs: config 5 done (+{time.perf_counter() - t_leg:.1f}s)")
-    # ---- config 4: first packet at batch 32 on one of those engines
-    talker, codec = keep["talkers"][0], keep["codecs"][0]
+    # ---- config 4: first packet at batch 32.  ONE engine serves the 32 streams and has the device to itself (round 6: config 5's engines share
+    # theirs and keep the decode GEMMs -- talker.py: shared_device; an engine alone runs the code predictor's MLP as one launch at batch 32), so
+    # config 5's talkers go first (their places in the device's account with them) and a fresh engine is built; the codec engine is kept
+    codec = keep["codecs"][0]
+    tdt4 = keep["talkers"][0].weight_dtype
+    for t_ in keep.pop("talkers"):
+        t_.__del__()
+    torch.cuda.empty_cache()
+    talker = TalkerEngine(tcfg, td(tw_np), weight_dtype=tdt4, device=dev, max_batch=(2 if small else 32), max_seq=(64 if small else 256), use_graph=not args.no_graph)
     B, NF = (2 if small else 32), (2 if small else 4)
     text = [24 + 4 * (i % 8) for i in range(B)] if not small else [3, 4]     # text tokens, fed one per frame (streaming text input, M:2229-2232)
     lens = [32 + 12 + (i % 5) for i in range(B)] if not small else [6, 5]    # instruct (32) + role / codec prefix rows, ragged
@@ -628,6 +635,7 @@ def configs_leg(args, tcfg, ccfg, tw_np, cw_np, dev):
                                        "trials": len(lat), "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
                                        "min_ms": round(float(lat.min()), 3), "prefill_plus_ar_ms_p50": round(float(np.median([a for a, _ in legs])), 3),
                                        "codec_plus_d2h_ms_p50": round(float(np.median([b for _, b in legs])), 3),
+                                       "cp_fused": {k: talker.stats()[k] for k in ("cp_fused_active", "cp_mlp_per_step", "ks_split_per_step")},
                                        "roofline": {"bound": "hbm", "what": "weight bytes the talker leg must stream (one pass of the talker layers for the prefill + 4 frame "
                                                                            "steps incl. the code predictor's 15 passes each) / prefill_plus_ar_ms_p50",
                                                     "achieved": round(floor_b / (talker_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,

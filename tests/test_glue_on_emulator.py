@@ -127,6 +127,35 @@ def test_top_p_zero_and_integer_like_top_k_python_path(glue, golden_dir):
             eng.generate(*args, max_new_tokens=1, do_sample=True, suppress_tokens=sup, **bad)
 
 
+def test_shared_device_engines_keep_the_decode_gemms_python_path(glue):
+    """Round 6: `TalkerEngine(shared_device=True)` -- an engine that will run beside another talker engine on its device (clone-shard: two engines
+    per GPU) keeps the decode GEMMs where an engine alone on the device runs the code predictor's MLP as one launch at batch 9..32
+    (csrc/cp_mlp32.hip; profiles/r06_cp_mlp32.md: 86.6 k vs 130 k tokens/s for the two-engine job).  Through the Python class on the emulator:
+    `cp_mlp_per_step` says which path each engine took, the flag leaves no override behind in the option table, and both engines decode the
+    same batch of 10 to the same shapes (their bf16 sums differ in order only)."""
+    import dataclasses
+    import synth
+    from qwen3_tts_amd import _lib
+    from qwen3_tts_amd.talker import TalkerEngine
+    t = dataclasses.replace(synth.talker_tiny(), num_code_groups=3, cp_hidden_size=256, cp_intermediate_size=1024, cp_num_hidden_layers=2,
+                            cp_num_attention_heads=16, cp_num_key_value_heads=8, cp_head_dim=128)
+    w = {k: torch.from_numpy(v) for k, v in synth.talker_weights(t, with_text=False).items()}
+    emb, mask, tr, pad = synth.rand_prompt(np.random.default_rng(65), t, [3 + i % 3 for i in range(10)], 2, scale=0.5)
+    sup = glue._suppress(t)
+    outs = {}
+    for shared in (False, True):
+        eng = TalkerEngine(t, w, weight_dtype=torch.bfloat16, device="cpu", max_batch=16, max_seq=64, use_graph=True, shared_device=shared)
+        assert _lib.get_override("QTTS_CP_MLP32") is None
+        o = eng.generate(emb, mask, tr, pad, max_new_tokens=3, min_new_tokens=3, do_sample=False, subtalker_dosample=False, suppress_tokens=sup)
+        st = eng.stats()
+        assert st["cp_mlp_per_step"] == (0 if shared else (t.num_code_groups - 2) * t.cp_num_hidden_layers), (shared, st)
+        assert st["cp_fused_giveups"] == 0
+        outs[shared] = o.codes.numpy()
+        del eng
+    assert outs[False].shape == outs[True].shape == (10, 2, 3)
+    assert float((outs[False] == outs[True]).mean()) >= 0.9
+
+
 def test_codec_graph_replay_python_path(glue):
     """`CodecDecoderEngine.decode_padded` called repeatedly on the same buffers + `stats()`: the GPU test body on the emulator (whether a
     call hits the graph cache depends on the allocator handing the output block back; both outcomes are checked for equal results)."""
