@@ -762,6 +762,284 @@ static void launch_dma(const GemmTapParams& p, int halo, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, p, halo, a_stride);
 }
 
+// ---- round 6: gemm_ring -- gemm_dma's arithmetic (same MFMA sequence per accumulator: results are BIT-IDENTICAL to gemm_dma_kernel's) with the
+// three things profiles/r06_gemm_ring.md measured against it changed:
+//   (1) LDS image without bank conflicts.  gemm_dma's 144-byte rows make every ds_read_b128 a 2-way conflict (SQ_LDS_BANK_CONFLICT = exactly half of
+//       SQ_LDS_IDX_ACTIVE on every launch): the b128 lane groups of gfx950 are {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- a group reads k-chunk c
+//       of 8 rows and chunk c ^ 1 of the 8 rows between them, and for the 16 rows of a fragment every row difference occurs, so no row padding is
+//       conflict-free.  Here a tile row is 32 k = 64 bytes (four 16-byte chunks), rows are dense, and chunk c of row r sits at chunk position
+//       c ^ (2 * ((r >> 2) & 1)): of the four rows of a group that share r % 4 (= the same quarter of a 256-byte bank row), the first and the last read
+//       chunk c, the two between them chunk c ^ 1, and consecutive row quads alternate the XOR -- four distinct positions, WHATEVER the row offset
+//       (the tap shift).  A wave-wide LDS-DMA fills 16 rows (1 KiB, lane l = row l / 4, position l % 4): every lane quad fetches one contiguous
+//       64-byte segment.  (The first build stored [16-row band][chunk][row]: conflict-free too, but consecutive lanes then fetch consecutive ROWS --
+//       64 cache lines per request -- and every shape but dilation 9 lost 15-25 % to gemm_dma.)  No padding: the dilation-9 launches (90 KB, one
+//       workgroup per CU) fit two per CU again.
+//   (2) a ring of NST weight tiles of 32 k (8 KiB each), requested D steps ahead, with COUNTED vmcnt: at the barrier of step t every wave has waited
+//       for its own requests of the tiles <= t + 1 only; the requests of t + 2 .. t + D - 1 stay in flight across the barrier (gemm_dma: one step
+//       deep, vmcnt(0) at every barrier -- a grid of <= 256 tiles spends ~1 us per 64-k step waiting for it).
+//   (3) operand fragments double-buffered in registers: step t + 1's ds_reads are issued before step t's 16 MFMAs (tile t + 1 has landed by barrier t),
+//       so the MFMAs of a step start right behind its barrier and tile t's buffer is free for tile t + D at barrier t (NST = D buffers suffice).
+// Step order: (k-slab of 32 * AH, tap, half h < AH) with the weight tile (tap, k-slab, h) per step; the A slab (AH halves of [bands][1 KiB], with its causal
+// halo) is staged once per slab and reused by every tap, two buffers, requested a whole slab ahead.  AH = 2 reproduces gemm_dma's 64-wide slabs
+// (identical summation order); a plain Linear (taps == 1) runs AH = 1 with the A tile in the ring beside W.
+// Ordering rules (the guide's: LDS-DMA data is visible to another wave's ds_read only behind the REQUESTING wave's vmcnt wait followed by a barrier the
+// reader has passed): a tile is read one barrier after the wait that retires it (wait + barrier t, reads during step t for step t + 1); a buffer is
+// re-requested behind the barrier that follows the lgkmcnt(0) of its last reads.  tests/test_host_logic.py pins the counted waits from the ISA.
+__device__ __forceinline__ void ring_wait_vm(int n) {      // s_waitcnt vmcnt(n) takes an immediate; n is wave-uniform
+#ifndef QTTS_HOST_EMU
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;     // (never less strict than asked)
+    }
+#else
+    (void)n;
+#endif
+}
+__device__ __forceinline__ void ring_barrier() {           // the reads of the step before are in registers, then the workgroup meets: no fence, no vmcnt drain
+#ifndef QTTS_HOST_EMU
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#else
+    __syncthreads();
+#endif
+}
+__device__ __forceinline__ void ring_sched_fence() {
+#ifndef QTTS_HOST_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int N> __device__ __forceinline__ void ring_wait_vm_c() {       // the steady-state wait: an immediate
+#ifndef QTTS_HOST_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+template <int NST, int AH, bool RING_A>
+__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int halo, int nbands /* 16-row bands of an A half-slab: ceil((128 + halo) / 16) */) {
+    constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
+    constexpr int WT = 8192;                           // a weight tile: 128 rows x 32 k = 8 bands of 1 KiB
+    constexpr int D = NST;                             // tiles requested ahead (launcher: NST <= steps per slab, or taps == 1)
+    constexpr int LPS = RING_A ? 4 : 2;                // requests per wave and step that the counted waits rely on (the slab requests of taps > 1 are extra: over-waited, never under)
+    static_assert(!RING_A || AH == 1, "a plain Linear runs 32-wide slabs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_gr[];
+    unsigned char* Wbuf = smem_gr;                     // [NST][WT]
+    unsigned char* Abuf = smem_gr + NST * WT;          // taps > 1: [2][AH][nbands KiB]; taps == 1: [NST][WT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n_tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {   // XCD-aware tile order (as gemm_tap_kernel)
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (bid / n_tiles_n) * BM;
+    const int n0 = (bid % n_tiles_n) * BN;
+    const int a_half = nbands * 1024, a_buf = AH * a_half;
+    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(p.A16);
+    const unsigned char* Wg = reinterpret_cast<const unsigned char*>(p.W);
+
+    // per-lane source offsets (bytes, without the k / tap terms) of the 16-row bands this wave requests: band = wave + 4 i; lane l fills position l % 4 of
+    // row l / 4 of the band = chunk (l % 4) ^ (2 * ((row >> 2) & 1)) of that row (bands start at multiples of 16 rows: the row's bit 2 is the lane's bit 4)
+    const int d_row = lane >> 2, d_chunk = (lane & 3) ^ ((lane >> 3) & 2);
+    unsigned w_off[2], a_off[3];                       // (launcher: both operands < 4 GiB)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int gn = n0 + (wave + 4 * i) * 16 + d_row;
+        gn = gn < p.N ? gn : p.N - 1;
+        w_off[i] = ((unsigned)gn * (unsigned)p.K + d_chunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int gr = m0 - halo + (wave + 4 * i) * 16 + d_row;
+        gr = gr < 0 ? 0 : (gr >= p.M ? p.M - 1 : gr);
+        a_off[i] = ((unsigned)gr * (unsigned)p.lda + d_chunk * 8) * 2u;
+    }
+    const int kslabs = p.K / (32 * AH);
+    const int S = p.taps * AH;                         // steps per slab
+    const int nsteps = kslabs * S;
+    // every cursor below advances by additions only: a step has 16 MFMAs per wave (256 clocks of the matrix pipe) and the scalar unit shares the issue slots
+    const unsigned w_tap_bytes = (unsigned)p.N * (unsigned)p.K * 2u;   // (all byte offsets below are 32-bit: launcher)
+    int sl_ks = 2;                                     // taps > 1: the next slab to request (0 and 1 go out in the prologue)
+    unsigned sl_k = 2u * AH * 64u;                     // ... its k offset in bytes
+    auto req_a_slab = [&](unsigned kbytes, int buf) {    // taps > 1: AH halves of [nbands] bands
+#pragma unroll
+        for (int h = 0; h < AH; ++h)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (wave + 4 * i < nbands) gd_dma16(A16 + (a_off[i] + kbytes + h * 64u), Abuf + buf * a_buf + h * a_half + (wave + 4 * i) * 1024);
+    };
+    // request cursor: tile rt = the next weight tile to request = (k offset r_k, tap r_tap) -> stage r_stage
+    int rt = 0, r_tap = 0, r_h = 0, r_stage = 0;
+    unsigned r_k = 0, r_wtap = 0;                      // bytes: 64 per half-slab; tap * N * K * 2
+    auto request_next = [&]() {
+        if constexpr (RING_A) {                        // the 128 x 32 A tile of the step, 8 bands, beside its weight tile
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gd_dma16(A16 + (a_off[i] + r_k), Abuf + r_stage * WT + (wave + 4 * i) * 1024);
+        }
+        const unsigned wk = r_wtap + r_k;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gd_dma16(Wg + (w_off[i] + wk), Wbuf + r_stage * WT + (wave + 4 * i) * 1024);
+        ++rt;
+        r_stage = r_stage + 1 == NST ? 0 : r_stage + 1;
+        // order: (slab, tap, half): the half moves k by 64 bytes, the tap rewinds the slab's halves, the slab keeps the advance
+        if constexpr (RING_A) r_k += 64u;              // (one tap, 32-wide slabs: the tile index is the slab)
+        else if (++r_h == AH) {
+            r_h = 0;
+            if (++r_tap == p.taps) { r_tap = 0; r_wtap = 0; r_k += 64u; } else { r_wtap += w_tap_bytes; r_k -= (AH - 1) * 64u; }
+        } else r_k += 64u;
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int tpos[TM], arow[TM];                            // position of this lane's output rows inside their sequence; their staged row at shift 0
+    bool near_start = false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        tpos[i] = (m0 + wm * 64 + i * 16 + li) % p.T; arow[i] = wm * 64 + i * 16 + li + halo;
+        near_start |= tpos[i] < halo;
+    }
+    // only a wave that holds rows within `halo` of a sequence start ever zeroes an operand fragment (one tile in T / 128): wave-uniform
+    const bool zeroing = __ballot(near_start) != 0;
+    const int wfrag = (wn * 64 + li) * 64 + ((lq ^ ((li >> 1) & 2)) << 4);      // + j KiB + stage * WT
+
+    // the taps' shifts (<= 0, reach <= 56 rows) packed into one scalar pair: a scalar load from the argument block inside the loop shares lgkmcnt with the
+    // ds_reads and would drain them before the MFMAs (seen in the ISA of the first build)
+    unsigned long long shifts = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) shifts |= (unsigned long long)(unsigned)(i < p.taps ? -p.shift[i] : 0) << (8 * i);
+    // read cursor: the tile whose fragments are read next: A buffer f_buf (taps > 1), half f_h, tap f_tap (its shift = byte f_tap of `shifts`), stage f_stage
+    int f_tap = 0, f_h = 0, f_stage = 0, f_buf = 0;
+    unsigned long long f_shifts = shifts;
+    auto read_frags = [&](bf16x8 (&a)[TM], bf16x8 (&b)[TN], int& sh_out) {
+        const unsigned char* Ab = RING_A ? Abuf + f_stage * WT : Abuf + f_buf * a_buf + f_h * a_half;
+        const unsigned char* Wb = Wbuf + f_stage * WT + wfrag;
+        const int sh = -(int)(f_shifts & 0xffu);       // <= 0
+        sh_out = sh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int R = arow[i] + sh;
+            a[i] = *reinterpret_cast<const bf16x8*>(Ab + (R << 6) + ((lq ^ ((R >> 1) & 2)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 1024);
+        f_stage = f_stage + 1 == NST ? 0 : f_stage + 1;
+        if (++f_h == AH) {
+            f_h = 0;
+            if (++f_tap == p.taps) { f_tap = 0; f_shifts = shifts; f_buf ^= 1; } else f_shifts >>= 8;
+        }
+    };
+
+    // prologue: slabs 0 and 1 (taps > 1), then the first D tiles of the ring
+    if constexpr (!RING_A) { req_a_slab(0u, 0); if (kslabs > 1) req_a_slab(AH * 64u, 1); }
+    for (int t = 0; t < D && t < nsteps; ++t) request_next();
+    {   // tile 0 (and everything older: the slabs) has landed once at most the tiles 1 .. min(D, nsteps) - 1 are outstanding
+        const int later = (D < nsteps ? D : nsteps) - 1;
+        ring_wait_vm(LPS * later);
+        ring_barrier();
+    }
+    bf16x8 fa[2][TM], fb[2][TN];
+    int fsh[2];
+    read_frags(fa[0], fb[0], fsh[0]);
+    const int t_steady = nsteps - D;                   // steps t < t_steady have all of t + 2 .. t + D - 1 outstanding at their wait
+    int sl_cnt = 0;                                    // steps of the current slab behind us (taps > 1)
+    auto step = [&](auto steady, int t, bf16x8 (&ca)[TM], bf16x8 (&cb)[TN], int csh, bf16x8 (&na)[TM], bf16x8 (&nb)[TN], int& nsh) {
+        // own requests of the tiles <= t + 1 are complete when only those of t + 2 .. min(t + D, nsteps) - 1 are outstanding
+        if constexpr (decltype(steady)::value) ring_wait_vm_c<LPS * (D - 2)>();
+        else { int later = nsteps - 2 - t; later = later > 0 ? later : 0; ring_wait_vm(LPS * later); }
+        ring_barrier();                                // tiles <= t + 1 are in LDS for every wave; every wave holds step t's fragments: tile t's buffer is free
+        if constexpr (!RING_A) {
+            if (++sl_cnt == S) {                       // a new slab starts at the next step: the buffer of the slab before it (this step's, already in registers) is free
+                sl_cnt = 0;
+                if (sl_ks < kslabs) req_a_slab(sl_k, sl_ks & 1);
+                ++sl_ks; sl_k += AH * 64u;
+            }
+        }
+        if constexpr (decltype(steady)::value) request_next();       // tile t + D -> the buffer of tile t (t + D < nsteps in the steady state)
+        else if (rt < nsteps) request_next();
+        if (zeroing) {                                 // rows before the start of their own sequence
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                if (tpos[i] + csh < 0) ca[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        // The first MFMAs go out BEFORE the next step's fragment reads: the compiler cannot see the lgkmcnt(0) of ring_barrier() and waits for this
+        // step's fragments (read a step ago) with lgkmcnt(0) at their first use -- behind the new reads that wait would drain them too (seen in the ISA
+        // of the second build: every step waited for its LDS reads with the matrix pipe idle); in front of them it costs nothing.
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[0], acc[0][j], 0, 0, 0);
+        ring_sched_fence();
+        if constexpr (decltype(steady)::value) read_frags(na, nb, nsh);
+        else if (t + 1 < nsteps) read_frags(na, nb, nsh);
+        ring_sched_fence();
+#pragma unroll
+        for (int i = 1; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
+        ring_sched_fence();                            // the step's MFMAs stay in front of the next wait (the first build's sank behind the barrier)
+    };
+    int t = 0;
+    for (; t + 1 < t_steady; t += 2) {                 // the steady state, two steps per trip (the fragment registers alternate)
+        step(std::true_type{}, t, fa[0], fb[0], fsh[0], fa[1], fb[1], fsh[1]);
+        step(std::true_type{}, t + 1, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
+    }
+#pragma unroll 1
+    for (; t < nsteps; t += 2) {                       // the last D (+ 1) steps: the ring drains, the waits follow it
+        step(std::false_type{}, t, fa[0], fb[0], fsh[0], fa[1], fb[1], fsh[1]);
+        if (t + 1 < nsteps) step(std::false_type{}, t + 1, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
+    }
+    tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);
+}
+
+static int ring_lds_bytes(int nst, int ah, int taps, int halo) {
+    const int nbands = (128 + halo + 15) / 16;
+    return nst * 8192 + (taps == 1 ? nst * 8192 : 2 * ah * nbands * 1024);
+}
+template <int NST, int AH, bool RING_A>
+static void launch_ring_t(const GemmTapParams& p, int halo, hipStream_t st) {
+    const int nb = cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int nbands = (128 + halo + 15) / 16;
+    auto kern = gemm_ring_kernel<NST, AH, RING_A>;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), (size_t)ring_lds_bytes(NST, AH, p.taps, halo), st, p, halo, nbands);
+}
+// depth of the ring: QTTS_GEMM_RING_NST (4 | 6 | 8), default 4 (<= 80 KB with the widest halo: two workgroups per CU) -- 8 where the grid leaves
+// every CU at most one workgroup anyway (a workgroup alone on its CU has nobody to hide its waits behind).  A slab is requested a slab's steps
+// (taps * 2) before its first read and must stay older than the tile whose wait covers it: NST <= taps * 2 (the two-tap transposed form: 4).
+static void launch_ring(const GemmTapParams& p, int halo, hipStream_t st) {
+    QTTS_REQUIRE((size_t)p.M * p.lda * 2 < (1ull << 32) && (size_t)p.taps * p.N * p.K * 2 < (1ull << 32), QTTS_ERR_LIMIT, "gemm_ring: an operand of 4 GiB or more");
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    int nst = QTTS_OPT_INT("QTTS_GEMM_RING_NST", 0);
+    if (nst != 4 && nst != 6 && nst != 8) nst = 4;     // (measured: deeper rings lose the second workgroup per CU and gain nothing, profiles/r06_gemm_ring.md)
+    (void)n_cu;
+    if (p.taps == 1) { if (nst == 8) launch_ring_t<8, 1, true>(p, halo, st); else if (nst == 6) launch_ring_t<6, 1, true>(p, halo, st); else launch_ring_t<4, 1, true>(p, halo, st); return; }
+    while (nst > p.taps * 2) nst -= 2;
+    QTTS_REQUIRE(nst >= 4, QTTS_ERR_ARG, "gemm_ring: ring deeper than a slab");
+    if (nst == 8) launch_ring_t<8, 2, false>(p, halo, st); else if (nst == 6) launch_ring_t<6, 2, false>(p, halo, st); else launch_ring_t<4, 2, false>(p, halo, st);
+}
+
 template <int BM, int BN, bool A16, int BK>
 static void launch_wide_k(const GemmTapParams& p, hipStream_t st) {
     const int nb = cdiv(p.M, BM) * cdiv(p.N, BN);
@@ -847,6 +1125,12 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
             // where N is wide (q|k|v 0.87x, 4096^3 0.90x) and loses where K is deep and the grid small (o 1.13x, down 1.11x); first packet
             // 31.9 -> 32.6 ms with it (profiles/r04_gemm_dma.md), so the tile chooser's kernel stays
             const int dma_env2 = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : 0; }();
+            // QTTS_GEMM_RING=2: round 6's ring kernel for the plain bf16 Linear too (A/B; profiles/r06_gemm_ring.md)
+            if (QTTS_OPT_INT("QTTS_GEMM_RING", 1) == 2 && p.N % 128 == 0 && p.K % 64 == 0) {
+                launch_ring(p, 0, st);
+                QTTS_CHECK_HIP(hipGetLastError());
+                return;
+            }
             if ((dma_env2 == 1 || dma_env2 == 2) && p.N % 128 == 0 && p.K % 64 == 0 && cdiv(p.M, 128) * (p.N / 128) >= 128) {
                 launch_dma<128>(p, 0, st);
                 QTTS_CHECK_HIP(hipGetLastError());
@@ -881,6 +1165,8 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         // The LDS-DMA kernel for every 128-column launch of this path (the codec's C = 768 / 384 units and transposed convolutions):
         // measured 2.70 -> 2.54 ms at B = 1 x 10 s and 10.23 -> 9.96 ms at 8 x 10 s (profiles/r04_gemm_dma.md).  QTTS_GEMM_DMA=0: gemm_tap2.
         const int dma_env = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : -1; }();
+        // Round 6: the ring kernel (band layout, counted waits, register-double-buffered fragments) wherever gemm_dma ran; QTTS_GEMM_RING=0: gemm_dma
+        if (dma_env != 0 && bn2 == 128 && p.K % 64 == 0 && QTTS_OPT_INT("QTTS_GEMM_RING", 1) != 0) { launch_ring(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
         if (dma_env != 0 && bn2 == 128 && p.K % 64 == 0) { launch_dma<128>(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
         const int tiles = cdiv(p.M, 128) * cdiv(p.N, bn2);
         const bool bk64 = p.K % 64 == 0 && bn2 == 128 && (bk_env == 64 || (bk_env == 0 && tiles <= n_cu2));
@@ -966,6 +1252,53 @@ int qtts_debug_gemm_tap(int32_t M, int32_t N, int32_t K, int32_t act, int32_t wi
         }
         *us_per_launch = 1000.0 * best / iters;
         (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr); (void)hipStreamDestroy(st);
+        return QTTS_OK;
+    } catch (const qtts::Error& e) { qtts::set_last_error(e.what()); return e.code; }
+    catch (const std::exception& e) { qtts::set_last_error(e.what()); return QTTS_ERR_ARG; }
+}
+
+// DEBUG/test hook (tests/test_gpu_parity.py, tools/bench_gemm_ring.py; not part of the product surface): the bf16-activation tap GEMM (the codec decoder's
+// convolution form: A16 [M][lda] bf16 bits, W [taps][N][K] bf16 bits, shifts <= 0, sequences of T rows) on host data -> fp32 C [M][N] on the host;
+// with iters > 0 also the time per launch of a hipGraph chain of `iters` launches (best of `reps`).  Which kernel runs follows the option table
+// (QTTS_GEMM_RING / QTTS_GEMM_DMA / QTTS_GEMM_RING_NST) exactly as in the codec engine.
+extern "C" __attribute__((visibility("default")))
+int qtts_debug_gemm_tap16(const void* A16_host, int32_t lda, int32_t M, int32_t T, const void* W_host, int32_t N, int32_t K, int32_t taps,
+                          const int32_t* shift, float* C_host, int32_t iters, int32_t reps, double* us_per_launch) {
+    try {
+        QTTS_REQUIRE(A16_host && W_host && shift && M > 0 && T > 0 && N > 0 && K > 0 && taps >= 1 && taps <= 8 && lda >= K, QTTS_ERR_ARG, "bad argument");
+        DevBuf A, W, Cb;
+        A.alloc((size_t)M * lda * 2); W.alloc((size_t)taps * N * K * 2); Cb.alloc((size_t)M * N * 4);
+        QTTS_CHECK_HIP(hipMemcpy(A.p, A16_host, A.bytes, hipMemcpyHostToDevice));
+        QTTS_CHECK_HIP(hipMemcpy(W.p, W_host, W.bytes, hipMemcpyHostToDevice));
+        QTTS_CHECK_HIP(hipMemset(Cb.p, 0xff, Cb.bytes));
+        GemmTapParams p{};
+        p.A16 = A.p; p.lda = lda; p.M = M; p.T = T; p.W = W.p; p.N = N; p.K = K; p.taps = taps;
+        for (int i = 0; i < taps; ++i) p.shift[i] = shift[i];
+        p.C = Cb.as<float>(); p.ldc = N;
+        hipStream_t st;
+        QTTS_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        launch_gemm_tap(p, true, st);
+        QTTS_CHECK_HIP(hipStreamSynchronize(st));
+        if (C_host) QTTS_CHECK_HIP(hipMemcpy(C_host, Cb.p, Cb.bytes, hipMemcpyDeviceToHost));
+        if (iters > 0 && reps > 0 && us_per_launch) {
+            hipGraph_t gr; hipGraphExec_t ge;
+            QTTS_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < iters; ++i) launch_gemm_tap(p, true, st);
+            QTTS_CHECK_HIP(hipStreamEndCapture(st, &gr));
+            QTTS_CHECK_HIP(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+            QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipStreamSynchronize(st));
+            hipEvent_t a, b;
+            QTTS_CHECK_HIP(hipEventCreate(&a)); QTTS_CHECK_HIP(hipEventCreate(&b));
+            float best = 1e30f;
+            for (int r = 0; r < reps; ++r) {
+                QTTS_CHECK_HIP(hipEventRecord(a, st)); QTTS_CHECK_HIP(hipGraphLaunch(ge, st)); QTTS_CHECK_HIP(hipEventRecord(b, st));
+                QTTS_CHECK_HIP(hipStreamSynchronize(st));
+                float ms = 0; QTTS_CHECK_HIP(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
+            }
+            *us_per_launch = 1000.0 * best / iters;
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr);
+        }
+        (void)hipStreamDestroy(st);
         return QTTS_OK;
     } catch (const qtts::Error& e) { qtts::set_last_error(e.what()); return e.code; }
     catch (const std::exception& e) { qtts::set_last_error(e.what()); return QTTS_ERR_ARG; }

@@ -853,6 +853,25 @@ def test_lds_dma_kernels_wait_for_their_requests_before_the_barrier(libqtts):
         assert tot >= 1 and bad == 0, (k, tot, bad)
 
 
+def test_ring_tap_gemm_counted_waits_pinned_from_the_isa(libqtts):
+    """Round 6: gemm_ring_kernel<NST, AH, RING_A> keeps the LDS-DMA requests of the tiles t + 2 .. t + NST - 1 in flight across the barrier of step t.
+    From the gfx950 code objects: each instantiation has 5 barriers (prologue, two steady-state steps, two draining steps); the two steady-state
+    barriers are preceded by exactly `s_waitcnt vmcnt(LPS * (NST - 2))` (LPS = 2 requests per wave and step, 4 when the A tile rides in the ring);
+    every barrier is preceded by `s_waitcnt lgkmcnt(0)` (a buffer is re-requested only when its last fragment reads are in registers)."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_waits
+    d = isa_waits.ring_barriers(os.path.join(ROOT, "qwen3-tts_amd", "libqtts.so"))
+    assert len(d) == 6, sorted(d)
+    for k, (nb, vm, lg, vmax) in d.items():
+        m = re.search(r"gemm_ring_kernel<(\d+), (\d+), (true|false)>", k)
+        nst, lps = int(m.group(1)), 4 if m.group(3) == "true" else 2
+        assert nb == 5 and lg == 5, (k, nb, lg)
+        assert vm[1] == [lps * (nst - 2)] and vm[2] == [lps * (nst - 2)], (k, vm)
+        assert all(v for v in vm[3:]) and vmax <= 28, (k, vm, vmax)
+
+
 def test_granule_polling_loads_stay_inside_their_loops(libqtts):
     """Round 6, found on the MI355X (profiles/r06_skinny_ksplit.md): the first build of `skinny2_ks_kernel` polled its producers' granules ONCE --
     the sc1 buffer loads are read-only intrinsics, its polling loop held no store and no side effect, and the compiler hoisted the re-read

@@ -319,6 +319,11 @@ def test_gemm_dma_lds_dma_staged_kernel_real_source(emu, qopt):
     tile), the two-tap transposed-conv form, a plain Linear with residual and both outputs.  (The emulator completes a DMA at
     once: what it checks is addressing and bookkeeping; the barrier / DMA ordering is checked on the MI355X.)"""
     qopt(emu, "QTTS_GEMM_DMA", "1")
+    qopt(emu, "QTTS_GEMM_RING", "0")
+    _run_gemm_dma_cases(emu, {})
+
+
+def _run_gemm_dma_cases(emu, keep):
     g = np.random.default_rng(48)
     cases = [  # M, T, N, K, shifts, act, bias, res, out32, out16, snake16
         (300, 100, 128, 128, [-6, -5, -4, -3, -2, -1, 0], ACT_SNAKE, 1, 0, 0, 1, 0),
@@ -326,8 +331,11 @@ def test_gemm_dma_lds_dma_staged_kernel_real_source(emu, qopt):
         (260, 130, 256, 64, [0], ACT_NONE, 1, 1, 1, 1, 1),
         (150, 75, 256, 128, [-1, 0], ACT_NONE, 1, 0, 1, 1, 1),
         (129, 43, 128, 192, [-18, -15, -12, -9, -6, -3, 0], ACT_NONE, 0, 0, 1, 0, 0),
+        (140, 70, 128, 640, [-6, -5, -4, -3, -2, -1, 0], ACT_NONE, 1, 0, 1, 1, 0),     # 10 slabs of 64: the ring wraps several times, slabs alternate buffers
+        (130, 130, 128, 512, [0], ACT_NONE, 0, 1, 1, 0, 0),                            # plain Linear, 16 steps of 32
+        (64, 64, 128, 64, [-1, 0], ACT_NONE, 0, 0, 1, 0, 0),                           # fewer steps (4) than an 8-deep ring
     ]
-    for (M, T, N, K, shift, act, hb, hr, o32, o16, s16) in cases:
+    for ci, (M, T, N, K, shift, act, hb, hr, o32, o16, s16) in enumerate(cases):
         A = (g.standard_normal((M, K + 8)) * 0.5).astype(np.float32)
         Av, Abits = _bf16_round(A)
         W = (g.standard_normal((len(shift), N, K)) / np.sqrt(K * len(shift))).astype(np.float32)
@@ -356,6 +364,29 @@ def test_gemm_dma_lds_dma_staged_kernel_real_source(emu, qopt):
             got = (out16[:, :N].astype(np.uint32) << 16).view(np.float32)
             assert np.abs(got - want16).max() <= 1e-2 * max(1.0, float(np.abs(want16).max())), (M, N, K, shift, float(np.abs(got - want16).max()))
             assert np.all(out16[:, N:] == 0x4242)
+        keep[ci] = (out.copy(), out16.copy())
+
+
+def test_gemm_ring_kernel_real_source_bit_identical_to_gemm_dma(emu, qopt):
+    """gemm_ring (round 6): gemm_dma's arithmetic on a conflict-free band layout of the LDS tiles, a ring of 4 / 6 / 8 weight tiles of 32 k requested
+    ahead, operand fragments double-buffered in registers -- the MFMA sequence of every accumulator is gemm_dma's, so every output (fp32 and bf16, every
+    epilogue) is BIT-IDENTICAL to gemm_dma_kernel's, at every ring depth: 7-tap convolutions at dilation 1 / 3 / 9 over several slabs, the two-tap
+    transposed form (ring capped at the slab's 4 steps), plain Linears (A tile in the ring), ragged last tiles, fewer steps than stages.  Against float64
+    numpy too (the shared case runner).  The emulator completes a DMA at once and runs the waves of a workgroup one after the other between barriers:
+    it checks addressing, the cursors and that no buffer is re-requested while a later-running wave still reads it; the counted waits are pinned from
+    the ISA (tests/test_host_logic.py) and checked on the MI355X (tests/test_gpu_parity.py)."""
+    qopt(emu, "QTTS_GEMM_DMA", "1")
+    qopt(emu, "QTTS_GEMM_RING", "0")
+    want = {}
+    _run_gemm_dma_cases(emu, want)
+    for ring, nst in (("1", "4"), ("1", "6"), ("1", "8"), ("1", "0"), ("2", "4"), ("2", "8")):
+        qopt(emu, "QTTS_GEMM_RING", ring)              # "2": the deep-K plain Linear (case 6; gemm_wide's summation order otherwise) takes the ring too
+        qopt(emu, "QTTS_GEMM_RING_NST", nst)
+        got = {}
+        _run_gemm_dma_cases(emu, got)                  # (every case against float64 numpy)
+        for ci in want:
+            if ring == "2" and ci == 6: continue
+            assert np.array_equal(got[ci][0], want[ci][0]) and np.array_equal(got[ci][1], want[ci][1]), (ring, nst, ci)
 
 
 @pytest.mark.parametrize("C,M,T,dil", [(96, 600, 300, 1), (96, 300, 100, 9), (96, 77, 77, 3), (192, 300, 150, 9), (192, 130, 65, 1)])

@@ -46,6 +46,8 @@ def dma_barriers(lib):
         is_dma = lambda i: "global_load_lds" in i or (i.startswith("buffer_load") and i.rstrip().endswith(" lds"))
         if not any(is_dma(i) for i in ins):
             continue
+        if "gemm_ring_kernel" in name:      # counted waits by design: ring_barriers() below
+            continue
         tot = bad = 0
         waited = True
         for i in ins:
@@ -58,6 +60,26 @@ def dma_barriers(lib):
                 tot += 1
                 bad += 0 if waited else 1
         out[name] = (tot, bad)
+    return out
+
+
+def ring_barriers(lib):
+    """gemm_ring_kernel<NST, AH, RING_A> (round 6) keeps LDS-DMA requests in flight across its barriers under COUNTED waits: {kernel: (barriers,
+    the vmcnt immediates found in the 24 instructions before each barrier, barriers with a `s_waitcnt lgkmcnt(0)` among them)}.  What the source
+    promises and the test pins: every barrier has a vmcnt wait right before it; the two barriers of the steady-state loop wait with exactly
+    LPS * (NST - 2) (LPS = 2 requests per wave and step, 4 when the A tile rides in the ring); no wait of the kernel allows more than the
+    prologue's LPS * (NST - 1); every barrier is preceded by lgkmcnt(0) (the fragment reads of the buffer about to be re-requested are in registers)."""
+    out = {}
+    for name, ins in kernels(lib).items():
+        if "gemm_ring_kernel" not in name: continue
+        bars = [i for i, x in enumerate(ins) if x.startswith("s_barrier")]
+        vm, lg = [], 0
+        for b in bars:
+            win = ins[max(0, b - 24):b]
+            vm.append([int(m.group(1)) for x in win for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", x)] if m])
+            lg += any(re.search(r"s_waitcnt.*lgkmcnt\(0\)", x) for x in win)
+        allv = [int(m.group(1)) for x in ins for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", x)] if m]
+        out[name] = (len(bars), vm, lg, max(allv) if allv else -1)
     return out
 
 
