@@ -825,7 +825,10 @@ template <int N> __device__ __forceinline__ void ring_wait_vm_c() {       // the
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
 }
-template <int NST, int AH, bool RING_A>
+// ABL != 0: measuring variants (tools/bench_gemm_ring.py --ablate; results are WRONG by construction): 1 = no requests in the steady steps, 2 = no
+// fragment reads, 4 = no MFMAs, 8 = no barrier, 16 = no address arithmetic for the A fragments (tap shift ignored)
+// TAPS = 7 | 2: the steady state runs whole slabs as straight-line code (`ustep`, version 4); 0: any tap count / the plain Linear (`fstep`)
+template <int NST, int AH, bool RING_A, int TAPS = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int halo, int nbands /* 16-row bands of an A half-slab: ceil((128 + halo) / 16) */) {
     constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
     constexpr int WT = 8192;                           // a weight tile: 128 rows x 32 k = 8 bands of 1 KiB
@@ -964,7 +967,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
     auto step = [&](auto steady, int t, bf16x8 (&ca)[TM], bf16x8 (&cb)[TN], int csh, bf16x8 (&na)[TM], bf16x8 (&nb)[TN], int& nsh) {
         // own requests of the tiles <= t + 1 are complete when only those of t + 2 .. min(t + D, nsteps) - 1 are outstanding
         if constexpr (decltype(steady)::value) ring_wait_vm_c<LPS * (D - 2)>();
-        else { int later = nsteps - 2 - t; later = later > 0 ? later : 0; ring_wait_vm(LPS * later); }
+        else { int later = nsteps - 2 - t; later = later < D - 2 ? later : D - 2; later = later > 0 ? later : 0; ring_wait_vm(LPS * later); }
         ring_barrier();                                // tiles <= t + 1 are in LDS for every wave; every wave holds step t's fragments: tile t's buffer is free
         if constexpr (!RING_A) {
             if (++sl_cnt == S) {                       // a new slab starts at the next step: the buffer of the slab before it (this step's, already in registers) is free
@@ -996,15 +999,219 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
         ring_sched_fence();                            // the step's MFMAs stay in front of the next wait (the first build's sank behind the barrier)
     };
+    // ---- the steady state (version 3).  Versions 1-2 ran `step` above everywhere: correct, conflict-free, requests in flight across the barriers -- and no
+    // faster than gemm_dma (profiles/r06_gemm_ring.md): a step is 16 MFMAs (256 clocks of the matrix pipe) plus ~100 scalar / vector / LDS / DMA
+    // instructions that the wave issued one after the other AROUND the MFMA block (a lone workgroup took ~1 050 clocks per step, 24 % of a CU's rate).
+    // `fstep` is the same step as straight-line code (no branch: the tap / slab cursors advance by selects, the tile's half is a template parameter,
+    // the zeroing variant is its own loop, the slab request sits between two slabs) so that the whole step is ONE scheduling region, and asks the
+    // scheduler for "1 MFMA, then up to 4 others" sixteen times: the requests, address arithmetic and fragment reads issue in the shadow of the MFMAs.
     int t = 0;
-    for (; t + 1 < t_steady; t += 2) {                 // the steady state, two steps per trip (the fragment registers alternate)
-        step(std::true_type{}, t, fa[0], fb[0], fsh[0], fa[1], fb[1], fsh[1]);
-        step(std::true_type{}, t + 1, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
+    auto fstep = [&](auto zero_tag, auto h_tag, bf16x8 (&ca)[TM], bf16x8 (&cb)[TN], int csh, bf16x8 (&na)[TM], bf16x8 (&nb)[TN], int& nsh) {
+        constexpr bool ZERO = decltype(zero_tag)::value;
+        constexpr int H = decltype(h_tag)::value;      // taps > 1: the half of this step's tile (= of the tile requested here: D is even); the next tile's is H ^ 1
+        ring_wait_vm_c<LPS * (D - 2)>();
+        if constexpr (ABL & 8) { ring_sched_fence(); } else ring_barrier();
+        if constexpr (!(ABL & 1)) {   // tile t + D -> the buffer of tile t
+            if constexpr (RING_A) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) gd_dma16(A16 + (a_off[i] + r_k), Abuf + r_stage * WT + (wave + 4 * i) * 1024);
+            }
+            const unsigned wk = r_wtap + r_k;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gd_dma16(Wg + (w_off[i] + wk), Wbuf + r_stage * WT + (wave + 4 * i) * 1024);
+            r_stage = r_stage + 1 == NST ? 0 : r_stage + 1;
+            if constexpr (RING_A || H == 0) r_k += 64u;
+            else {
+                const int nt = r_tap + 1;
+                const bool wrap = nt == p.taps;
+                r_tap = wrap ? 0 : nt; r_wtap = wrap ? 0u : r_wtap + w_tap_bytes; r_k += wrap ? 64u : 0u - 64u;
+            }
+        }
+        if constexpr (ZERO) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                if (tpos[i] + csh < 0) ca[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        {   // the next tile's fragments
+            constexpr int HH = RING_A ? 0 : (H ^ 1);
+            const unsigned char* Ab = RING_A ? Abuf + f_stage * WT : Abuf + f_buf * a_buf + HH * a_half;
+            const unsigned char* Wb = Wbuf + f_stage * WT + wfrag;
+            const int sh = -(int)(f_shifts & 0xffu);
+            nsh = sh;
+            if constexpr (ABL & 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { na[i] = ca[i]; nb[i] = cb[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int R = (RING_A || (ABL & 16)) ? arow[i] : arow[i] + sh;      // (a plain Linear has no shift: the address is loop-invariant)
+                    na[i] = *reinterpret_cast<const bf16x8*>(Ab + (R << 6) + ((lq ^ ((R >> 1) & 2)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 1024);
+            }
+            f_stage = f_stage + 1 == NST ? 0 : f_stage + 1;
+            if constexpr (!RING_A && HH == 1) {        // (the tile after it starts the next tap)
+                const int nt = f_tap + 1;
+                const bool wrap = nt == p.taps;
+                f_tap = wrap ? 0 : nt; f_shifts = wrap ? shifts : f_shifts >> 8; f_buf ^= wrap ? 1 : 0;
+            }
+        }
+        if constexpr (ABL & 4) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][0][0] += __builtin_bit_cast(float, (int)ca[i][0] + (int)cb[i][1]);       // (keeps the fragments alive)
+        } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
+        }
+#ifndef QTTS_HOST_EMU
+#pragma unroll
+        for (int k = 0; k < TM * TN; ++k) {            // (the first MFMA leads: the compiler's lgkmcnt(0) for this step's fragments then sits in front of the new reads)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x096, 4, 0);       // up to four of VALU | SALU | VMEM | DS
+        }
+#endif
+        ring_sched_fence();
+    };
+    // ---- version 4 (TAPS known at compile time): a slab's TAPS * AH steps unrolled.  The ablation of version 3 (profiles/r06_gemm_ring.md) says the step is
+    // bound by instruction ISSUE: with requests, reads and MFMAs all removed the cursors, waits and the loop alone still take half of the step (a SIMD issues
+    // about one instruction per 4-5 clocks whichever wave it comes from: two workgroups per CU do not hide each other's scalar work), i.e. ~90
+    // instructions per 16 MFMAs must become ~30.  Unrolled, a step's tap and half are constants: the fragment addresses of all taps are computed ONCE
+    // (apre: TAPS * 4 registers), the tap's weight offset is one of TAPS scalars, the shift is a constant byte of `shifts`, no cursor is left but the two
+    // ring stages.
+    unsigned apre[TAPS > 0 ? TAPS : 1];                // LDS byte offset of this lane's A fragment 0 at tap tp inside a half-slab (swizzle included); fragment i
+                                                       // sits 16 i rows = i KiB further (a multiple of 16 rows leaves the swizzle bit alone): an immediate of the read
+    unsigned wtap[TAPS > 0 ? TAPS : 1];                // tap * N * K * 2
+    if constexpr (TAPS > 0) {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+            wtap[tp] = tp * w_tap_bytes;
+            const int R = arow[0] + p.shift[tp];
+            apre[tp] = (unsigned)((R << 6) + ((lq ^ ((R >> 1) & 2)) << 4));
+        }
     }
+    unsigned u_sk = 0;                                 // k offset (bytes) of the slab being computed
+    unsigned u_ab[2][AH];                              // LDS byte offset of the halves of (this slab, the next slab)
+#pragma unroll
+    for (int h = 0; h < AH; ++h) { u_ab[0][h] = h * a_half; u_ab[1][h] = a_buf + h * a_half; }
+    auto ustep = [&](auto zero_tag, auto last_tag, auto u_tag, bf16x8 (&ca)[TM], bf16x8 (&cb)[TN], bf16x8 (&na)[TM], bf16x8 (&nb)[TN]) {
+        constexpr bool ZERO = decltype(zero_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;       // the last slab: the ring drains (no request past the slab, the waits follow, no read after the last step)
+        constexpr int U = decltype(u_tag)::value;      // step inside the slab: tap U / AH, half U % AH
+        constexpr int SS = (TAPS > 0 ? TAPS : 1) * AH;
+        // own requests of the tiles <= t + 1 are complete when only those of t + 2 .. min(t + D, nsteps) - 1 are outstanding
+        constexpr int LATER = !LAST ? D - 2 : (SS - 2 - U < D - 2 ? (SS - 2 - U > 0 ? SS - 2 - U : 0) : D - 2);
+        ring_wait_vm_c<LPS * LATER>();
+        if constexpr (ABL & 8) { ring_sched_fence(); } else ring_barrier();
+        if constexpr (!(ABL & 1) && (!LAST || U + D < SS)) {     // tile U + D of this slab, or U + D - SS of the next -> the buffer of this step's tile
+            constexpr int UR = (U + D) % SS;
+            constexpr unsigned kofs = ((U + D) >= SS ? AH * 64u : 0u) + (UR % AH) * 64u;
+            const unsigned wk = wtap[UR / AH] + u_sk + kofs;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gd_dma16(Wg + (w_off[i] + wk), Wbuf + r_stage * WT + (wave + 4 * i) * 1024);
+            r_stage = r_stage + 1 == NST ? 0 : r_stage + 1;
+        }
+        if constexpr (ZERO) {
+            const int csh = -(int)((shifts >> (8 * (U / AH))) & 0xffu);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                if (tpos[i] + csh < 0) ca[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if constexpr (!LAST || U + 1 < SS) {   // the next tile's fragments: tile U + 1 of this slab or tile 0 of the next
+            constexpr int UF = (U + 1) % SS;
+            const unsigned ab = u_ab[(U + 1) >= SS ? 1 : 0][UF % AH];
+            const unsigned char* Wb = Wbuf + f_stage * WT + wfrag;
+            if constexpr (ABL & 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { na[i] = ca[i]; nb[i] = cb[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) na[i] = *reinterpret_cast<const bf16x8*>(Abuf + (apre[UF / AH] + ab) + i * 1024);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const bf16x8*>(Wb + j * 1024);
+            }
+            f_stage = f_stage + 1 == NST ? 0 : f_stage + 1;
+        }
+        if constexpr (ABL & 4) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][0][0] += __builtin_bit_cast(float, (int)ca[i][0] + (int)cb[i][1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
+        }
+#ifndef QTTS_HOST_EMU
+#pragma unroll
+        for (int k = 0; k < TM * TN; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x096, 2, 0);       // up to two of VALU | SALU | VMEM | DS
+        }
+#endif
+        ring_sched_fence();
+    };
+    auto uslab = [&](auto zero_tag, auto last_tag) {   // the TAPS * AH steps of one slab (an even count: the fragment registers end where they began)
+        constexpr int SS = (TAPS > 0 ? TAPS : 1) * AH;
+        static_assert(TAPS == 0 || SS % 2 == 0, "an odd number of steps per slab");
+        auto pair = [&](auto u) {
+            ustep(zero_tag, last_tag, std::integral_constant<int, decltype(u)::value>{}, fa[0], fb[0], fa[1], fb[1]);
+            ustep(zero_tag, last_tag, std::integral_constant<int, decltype(u)::value + 1>{}, fa[1], fb[1], fa[0], fb[0]);
+        };
+        if constexpr (SS >= 2) pair(std::integral_constant<int, 0>{});
+        if constexpr (SS >= 4) pair(std::integral_constant<int, 2>{});
+        if constexpr (SS >= 6) pair(std::integral_constant<int, 4>{});
+        if constexpr (SS >= 8) pair(std::integral_constant<int, 6>{});
+        if constexpr (SS >= 10) pair(std::integral_constant<int, 8>{});
+        if constexpr (SS >= 12) pair(std::integral_constant<int, 10>{});
+        if constexpr (SS >= 14) pair(std::integral_constant<int, 12>{});
+        static_assert(SS <= 14, "more taps than the unrolled slab covers");
+    };
+    auto run_steady = [&](auto zero_tag) {
+        if constexpr (TAPS > 0) {
+            // every slab but the last (all of their steps have t + D < nsteps: D <= S); between two slabs the buffer of the slab just finished takes slab + 2
+            for (int ks = 0; ks + 1 < kslabs; ++ks) {
+                uslab(zero_tag, std::false_type{});
+                t += S;
+                if (ks + 2 < kslabs) req_a_slab(sl_k, ks & 1);
+                sl_k += AH * 64u;
+                u_sk += AH * 64u;
+#pragma unroll
+                for (int h = 0; h < AH; ++h) { const unsigned x = u_ab[0][h]; u_ab[0][h] = u_ab[1][h]; u_ab[1][h] = x; }
+            }
+            uslab(zero_tag, std::true_type{});         // the last slab, its drain known at compile time too
+            t += S;
+        } else if constexpr (RING_A) {
+            for (; t + 1 < t_steady; t += 2) {
+                fstep(zero_tag, std::integral_constant<int, 0>{}, fa[0], fb[0], fsh[0], fa[1], fb[1], fsh[1]);
+                fstep(zero_tag, std::integral_constant<int, 0>{}, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
+            }
+        } else {
+            // every slab but the last: all of its steps have t + D < nsteps (D <= S); between two slabs the buffer of the slab just finished takes slab + 2
+            for (int ks = 0; ks + 1 < kslabs; ++ks) {
+                for (int u = 0; u < p.taps; ++u) {
+                    fstep(zero_tag, std::integral_constant<int, 0>{}, fa[0], fb[0], fsh[0], fa[1], fb[1], fsh[1]);
+                    fstep(zero_tag, std::integral_constant<int, 1>{}, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
+                }
+                t += S;
+                if (ks + 2 < kslabs) req_a_slab(sl_k, ks & 1);
+                sl_k += AH * 64u;
+            }
+            sl_ks = kslabs;                            // (nothing left to request for the generic steps of the last slab)
+        }
+    };
+    if (zeroing) run_steady(std::true_type{}); else run_steady(std::false_type{});
+    if constexpr (TAPS == 0) {                         // (with the taps known every slab ran above, the last one with its drain)
+        rt = t + D < nsteps ? t + D : nsteps;          // the cursors `step` keeps and `fstep` knows statically (t is even here)
+        r_h = 0; f_h = AH - 1; sl_cnt = 0;
 #pragma unroll 1
-    for (; t < nsteps; t += 2) {                       // the last D (+ 1) steps: the ring drains, the waits follow it
-        step(std::false_type{}, t, fa[0], fb[0], fsh[0], fa[1], fb[1], fsh[1]);
-        if (t + 1 < nsteps) step(std::false_type{}, t + 1, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
+        for (; t < nsteps; t += 2) {                   // the last slab / the last D (+ 1) steps: the ring drains, the waits follow it
+            step(std::false_type{}, t, fa[0], fb[0], fsh[0], fa[1], fb[1], fsh[1]);
+            if (t + 1 < nsteps) step(std::false_type{}, t + 1, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
+        }
     }
     tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);
 }
@@ -1013,11 +1220,11 @@ static int ring_lds_bytes(int nst, int ah, int taps, int halo) {
     const int nbands = (128 + halo + 15) / 16;
     return nst * 8192 + (taps == 1 ? nst * 8192 : 2 * ah * nbands * 1024);
 }
-template <int NST, int AH, bool RING_A>
+template <int NST, int AH, bool RING_A, int TAPS = 0, int ABL = 0>
 static void launch_ring_t(const GemmTapParams& p, int halo, hipStream_t st) {
     const int nb = cdiv(p.M, 128) * cdiv(p.N, 128);
     const int nbands = (128 + halo + 15) / 16;
-    auto kern = gemm_ring_kernel<NST, AH, RING_A>;
+    auto kern = gemm_ring_kernel<NST, AH, RING_A, TAPS, ABL>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), (size_t)ring_lds_bytes(NST, AH, p.taps, halo), st, p, halo, nbands);
 }
@@ -1034,9 +1241,26 @@ static void launch_ring(const GemmTapParams& p, int halo, hipStream_t st) {
     int nst = QTTS_OPT_INT("QTTS_GEMM_RING_NST", 0);
     if (nst != 4 && nst != 6 && nst != 8) nst = 4;     // (measured: deeper rings lose the second workgroup per CU and gain nothing, profiles/r06_gemm_ring.md)
     (void)n_cu;
-    if (p.taps == 1) { if (nst == 8) launch_ring_t<8, 1, true>(p, halo, st); else if (nst == 6) launch_ring_t<6, 1, true>(p, halo, st); else launch_ring_t<4, 1, true>(p, halo, st); return; }
+    const int unroll = QTTS_OPT_INT("QTTS_GEMM_RING_UNROLL", 1);       // 0: the generic steady step for every tap count (A/B)
+    if (p.taps == 1) { if (nst == 8) launch_ring_t<8, 1, true>(p, halo, st); else launch_ring_t<4, 1, true>(p, halo, st); return; }
     while (nst > p.taps * 2) nst -= 2;
     QTTS_REQUIRE(nst >= 4, QTTS_ERR_ARG, "gemm_ring: ring deeper than a slab");
+#ifndef QTTS_HOST_EMU
+    if (const int abl = QTTS_OPT_INT("QTTS_GEMM_RING_ABLATE", 0); abl && p.taps == 7) {        // measuring variants of the 4-deep 7-tap kernel (wrong results by construction)
+        switch (abl) {
+            case 1: launch_ring_t<4, 2, false, 7, 1>(p, halo, st); return;
+            case 2: launch_ring_t<4, 2, false, 7, 2>(p, halo, st); return;
+            case 3: launch_ring_t<4, 2, false, 7, 3>(p, halo, st); return;
+            case 4: launch_ring_t<4, 2, false, 7, 4>(p, halo, st); return;
+            case 8: launch_ring_t<4, 2, false, 7, 8>(p, halo, st); return;
+            case 7: launch_ring_t<4, 2, false, 7, 7>(p, halo, st); return;
+            case 15: launch_ring_t<4, 2, false, 7, 15>(p, halo, st); return;
+            default: break;
+        }
+    }
+#endif
+    if (unroll && p.taps == 7) { if (nst == 8) launch_ring_t<8, 2, false, 7>(p, halo, st); else launch_ring_t<4, 2, false, 7>(p, halo, st); return; }
+    if (unroll && p.taps == 2) { launch_ring_t<4, 2, false, 2>(p, halo, st); return; }
     if (nst == 8) launch_ring_t<8, 2, false>(p, halo, st); else if (nst == 6) launch_ring_t<6, 2, false>(p, halo, st); else launch_ring_t<4, 2, false>(p, halo, st);
 }
 
@@ -1125,8 +1349,11 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
             // where N is wide (q|k|v 0.87x, 4096^3 0.90x) and loses where K is deep and the grid small (o 1.13x, down 1.11x); first packet
             // 31.9 -> 32.6 ms with it (profiles/r04_gemm_dma.md), so the tile chooser's kernel stays
             const int dma_env2 = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : 0; }();
-            // QTTS_GEMM_RING=2: round 6's ring kernel for the plain bf16 Linear too (A/B; profiles/r06_gemm_ring.md)
-            if (QTTS_OPT_INT("QTTS_GEMM_RING", 1) == 2 && p.N % 128 == 0 && p.K % 64 == 0) {
+            // Round 6: the ring kernel for the plain bf16 Linear on grids of at least 128 tiles of 128 x 128 (the batch-32 prefill: o 35.1 -> 28.7 us,
+            // down 83.8 -> 65.9, gate|up 130.8 -> 124.0, q|k|v 52.0 -> 51.0; batch 8: q|k|v 26.1 -> 25.3, gate|up 46.1 -> 42.2; a 64-tile grid
+            // (batch-8 down) stays with gemm_wide's 64-row tiles: 44.6 vs 61.0 -- profiles/r06_gemm_ring.md).  QTTS_GEMM_RING=2: every grid; 0: none.
+            const int ring_env = QTTS_OPT_INT("QTTS_GEMM_RING", 1);
+            if (dma_env2 == 0 && (ring_env == 2 || (ring_env == 1 && cdiv(p.M, 128) * (p.N / 128) >= 128)) && p.N % 128 == 0 && p.K % 64 == 0) {
                 launch_ring(p, 0, st);
                 QTTS_CHECK_HIP(hipGetLastError());
                 return;

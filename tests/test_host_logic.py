@@ -855,7 +855,7 @@ def test_lds_dma_kernels_wait_for_their_requests_before_the_barrier(libqtts):
 
 def test_ring_tap_gemm_counted_waits_pinned_from_the_isa(libqtts):
     """Round 6: gemm_ring_kernel<NST, AH, RING_A> keeps the LDS-DMA requests of the tiles t + 2 .. t + NST - 1 in flight across the barrier of step t.
-    From the gfx950 code objects: each instantiation has 5 barriers (prologue, two steady-state steps, two draining steps); the two steady-state
+    From the gfx950 code objects: each instantiation has a prologue barrier, the steady-state steps' barriers and two draining steps'; the steady-state
     barriers are preceded by exactly `s_waitcnt vmcnt(LPS * (NST - 2))` (LPS = 2 requests per wave and step, 4 when the A tile rides in the ring);
     every barrier is preceded by `s_waitcnt lgkmcnt(0)` (a buffer is re-requested only when its last fragment reads are in registers)."""
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
@@ -863,13 +863,21 @@ def test_ring_tap_gemm_counted_waits_pinned_from_the_isa(libqtts):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_waits
     d = isa_waits.ring_barriers(os.path.join(ROOT, "qwen3-tts_amd", "libqtts.so"))
-    assert len(d) == 6, sorted(d)
+    d = {k: v for k, v in d.items() if re.search(r"gemm_ring_kernel<\d+, \d+, (true|false), \d+, 0>", k)}      # (the product instantiations; ABL != 0 are measuring variants)
+    assert len(d) == 8, sorted(d)                      # generic 4 / 6 / 8 deep, plain Linear 4 / 8, 7 taps unrolled 4 / 8, 2 taps unrolled 4
     for k, (nb, vm, lg, vmax) in d.items():
-        m = re.search(r"gemm_ring_kernel<(\d+), (\d+), (true|false)>", k)
+        m = re.search(r"gemm_ring_kernel<(\d+), (\d+), (true|false), (\d+), 0>", k)
         nst, lps = int(m.group(1)), 4 if m.group(3) == "true" else 2
-        assert nb == 5 and lg == 5, (k, nb, lg)
-        assert vm[1] == [lps * (nst - 2)] and vm[2] == [lps * (nst - 2)], (k, vm)
-        assert all(v for v in vm[3:]) and vmax <= 28, (k, vm, vmax)
+        assert nb >= 7 and lg == nb, (k, nb, lg)       # prologue, the steady steps (plain and zeroing loops; whole slabs unrolled when the taps are known), the draining steps
+        taps = int(m.group(4))
+        if taps == 0:                                  # generic steady step: constant waits, then two draining steps behind the run-time switch
+            assert all(v == [lps * (nst - 2)] for v in vm[1:-2]), (k, vm)
+            assert all(v for v in vm[-2:]) and vmax <= 28, (k, vm, vmax)
+        else:                                          # unrolled slabs: every wait an immediate; the steady slabs wait with the full count, the last slab drains to 0
+            assert all(len(v) == 1 and v[0] <= lps * (nst - 2) for v in vm[1:]), (k, vm)
+            full = sum(v == [lps * (nst - 2)] for v in vm[1:])
+            assert full >= 2 * (2 * taps) and sum(v == [0] for v in vm[1:]) >= 2, (k, vm)     # (both loops: plain and zeroing)
+            assert vmax <= 28, (k, vmax)
 
 
 def test_granule_polling_loads_stay_inside_their_loops(libqtts):

@@ -9,6 +9,7 @@ import numpy as np, torch
 from qwen3_tts_amd import _lib
 ap = argparse.ArgumentParser(); ap.add_argument("--screen", type=int, default=3); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--skip-linear", action="store_true")
+ap.add_argument("--ablate", action="store_true", help="time the measuring variants of the 4-deep convolution kernel (QTTS_GEMM_RING_ABLATE) on two shapes and exit")
 a = ap.parse_args()
 lib = _lib.load_library(); torch.zeros(1).cuda()
 f16 = lib.qtts_debug_gemm_tap16
@@ -33,6 +34,19 @@ for B in (1, 8):
                (f"C384 conv1 B{B}", 20000 * B, 20000, 384, 384, [0]), (f"tconv 768->5x384 B{B}", 4000 * B, 4000, 1920, 768, [0, -1]),
                (f"tconv 1536->8x768 B{B}", 500 * B, 500, 6144, 1536, [0, -1])]
 SHAPES.append(("32 x 4-frame C768 d9", 32 * 128, 128, 768, 768, conv7(9)))
+if a.ablate:
+    AB = [(0, "all"), (1, "no requests"), (2, "no fragment reads"), (16, "no A address arithmetic"), (4, "no MFMAs"), (8, "no barrier"), (3, "no requests, no reads"), (7, "no requests / reads / MFMAs"), (15, "nothing but the cursors and waits")]
+    for name, M, T, N, K, shifts in [SHAPES[0], SHAPES[7], SHAPES[8]]:
+        A = bf16bits((g.standard_normal((M, K), dtype=np.float32) * 0.5)); W = bf16bits((g.standard_normal((len(shifts), N, K), dtype=np.float32) / np.sqrt(K * len(shifts))).astype(np.float32))
+        steps = K // 32 * len(shifts)
+        print(f"{name}: {M} x {N} x {K} x {len(shifts)} taps, {steps} steps per workgroup, {((M + 127) // 128) * (N // 128)} workgroups")
+        for code, what in AB:
+            best = 1e30
+            for rep in range(2):
+                with _lib.options(QTTS_GEMM_RING="1", QTTS_GEMM_RING_NST="4", QTTS_GEMM_RING_ABLATE=str(code)):
+                    best = min(best, run(A, W, T, shifts, a.iters)[1])
+            print(f"  ablate {code:2d} ({what:36s}) {best:8.2f} us", flush=True)
+    sys.exit(0)
 print(f"{'shape':28s} {'M':>7s} {'N':>5s} {'K':>5s} taps " + " ".join(f"{n + ' us':>10s} {'TF/s':>6s}" for n, _ in VARIANTS) + "  bitwise")
 bad = 0
 for name, M, T, N, K, shifts in SHAPES:
@@ -60,8 +74,8 @@ if not a.skip_linear:
     LIN = [("prefill b32 q|k|v", 2048, 4096, 2048, 0, 0), ("prefill b32 o", 2048, 2048, 2048, 0, 1), ("prefill b32 gate|up", 2048, 12288, 2048, 2, 0),
            ("prefill b32 down", 2048, 2048, 6144, 0, 1), ("prefill b8 q|k|v", 512, 4096, 2048, 0, 0), ("prefill b8 gate|up", 512, 12288, 2048, 2, 0),
            ("prefill b8 down", 512, 2048, 6144, 0, 1), ("square 4096", 4096, 4096, 4096, 0, 0)]
-    LV = [("wide", {"QTTS_GEMM_RING": "1", "QTTS_GEMM_DMA": "0"}), ("dma", {"QTTS_GEMM_RING": "1", "QTTS_GEMM_DMA": "2"}),
-          ("ring4", {"QTTS_GEMM_RING": "2", "QTTS_GEMM_RING_NST": "4"}), ("ring8", {"QTTS_GEMM_RING": "2", "QTTS_GEMM_RING_NST": "8"})]
+    LV = [("wide", {"QTTS_GEMM_RING": "0", "QTTS_GEMM_DMA": "0"}), ("dma", {"QTTS_GEMM_RING": "0", "QTTS_GEMM_DMA": "2"}),
+          ("ring4", {"QTTS_GEMM_RING": "2", "QTTS_GEMM_RING_NST": "4"}), ("default", {})]
     print(f"\n{'plain Linear (M x N x K)':46s} " + " ".join(f"{n + ' us':>10s} {'TF/s':>6s}" for n, _ in LV))
     for name, M, N, K, act, rs in LIN:
         r = {}
