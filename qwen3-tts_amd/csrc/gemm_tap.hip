@@ -1245,7 +1245,7 @@ static void launch_ring(const GemmTapParams& p, int halo, hipStream_t st) {
     if (p.taps == 1) { if (nst == 8) launch_ring_t<8, 1, true>(p, halo, st); else launch_ring_t<4, 1, true>(p, halo, st); return; }
     while (nst > p.taps * 2) nst -= 2;
     QTTS_REQUIRE(nst >= 4, QTTS_ERR_ARG, "gemm_ring: ring deeper than a slab");
-#ifndef QTTS_HOST_EMU
+#if defined(QTTS_ABLATE) && !defined(QTTS_HOST_EMU)                    // (the `ablate` build variant only: measuring code is never linked into libqtts.so)
     if (const int abl = QTTS_OPT_INT("QTTS_GEMM_RING_ABLATE", 0); abl && p.taps == 7) {        // measuring variants of the 4-deep 7-tap kernel (wrong results by construction)
         switch (abl) {
             case 1: launch_ring_t<4, 2, false, 7, 1>(p, halo, st); return;
@@ -1393,7 +1393,10 @@ void launch_gemm_tap(const GemmTapParams& p_in, bool bf16, hipStream_t st) {
         // measured 2.70 -> 2.54 ms at B = 1 x 10 s and 10.23 -> 9.96 ms at 8 x 10 s (profiles/r04_gemm_dma.md).  QTTS_GEMM_DMA=0: gemm_tap2.
         const int dma_env = [] { const char* e = QTTS_ENV("QTTS_GEMM_DMA"); return e ? atoi(e) : -1; }();
         // Round 6: the ring kernel (band layout, counted waits, register-double-buffered fragments) wherever gemm_dma ran; QTTS_GEMM_RING=0: gemm_dma
-        if (dma_env != 0 && bn2 == 128 && p.K % 64 == 0 && QTTS_OPT_INT("QTTS_GEMM_RING", 1) != 0) { launch_ring(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
+        // (a 1x1 convolution of this path -- K <= 768, three to twelve 64-wide steps, its time is the residual / output traffic of the epilogue -- stays with
+        // gemm_dma: 151.5 vs 167.1 us at C = 384, 8 x 10 s; QTTS_GEMM_RING=2 sends it through the ring as well)
+        const int ring_env = QTTS_OPT_INT("QTTS_GEMM_RING", 1);
+        if (dma_env != 0 && bn2 == 128 && p.K % 64 == 0 && (ring_env == 2 || (ring_env == 1 && p.taps > 1))) { launch_ring(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
         if (dma_env != 0 && bn2 == 128 && p.K % 64 == 0) { launch_dma<128>(p, halo, st); QTTS_CHECK_HIP(hipGetLastError()); return; }
         const int tiles = cdiv(p.M, 128) * cdiv(p.N, bn2);
         const bool bk64 = p.K % 64 == 0 && bn2 == 128 && (bk_env == 64 || (bk_env == 0 && tiles <= n_cu2));

@@ -6,11 +6,13 @@
 import argparse, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
-from qwen3_tts_amd import _lib
 ap = argparse.ArgumentParser(); ap.add_argument("--screen", type=int, default=3); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--skip-linear", action="store_true")
-ap.add_argument("--ablate", action="store_true", help="time the measuring variants of the 4-deep convolution kernel (QTTS_GEMM_RING_ABLATE) on two shapes and exit")
+ap.add_argument("--ablate", action="store_true", help="time the measuring variants of the 4-deep 7-tap kernel (QTTS_GEMM_RING_ABLATE; they exist only in the `ablate` build "
+                "variant: python qwen3-tts_amd/build.py --variant ablate) on three shapes and exit")
 a = ap.parse_args()
+if a.ablate: os.environ.setdefault("QTTS_LIBRARY", os.path.join(ROOT, "qwen3-tts_amd", "libqtts_ablate.so"))
+from qwen3_tts_amd import _lib
 lib = _lib.load_library(); torch.zeros(1).cuda()
 f16 = lib.qtts_debug_gemm_tap16
 f16.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
