@@ -19,6 +19,8 @@
 // 4 x BN/32 MFMA 16x16 tiles.  F32 mode uses v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chain,
 // 157 TF peak), BF16 mode v_mfma_f32_16x16x32_bf16 (A converted fp32->bf16 while staging).
 // Global -> registers -> LDS staging with the next tile's loads in flight during the MFMAs.
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -829,7 +831,8 @@ template <int N> __device__ __forceinline__ void ring_wait_vm_c() {       // the
 // fragment reads, 4 = no MFMAs, 8 = no barrier, 16 = no address arithmetic for the A fragments (tap shift ignored)
 // TAPS = 7 | 2: the steady state runs whole slabs as straight-line code (`ustep`, version 4); 0: any tap count / the plain Linear (`fstep`)
 template <int NST, int AH, bool RING_A, int TAPS = 0, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int halo, int nbands /* 16-row bands of an A half-slab: ceil((128 + halo) / 16) */) {
+__global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int halo, int nbands /* 16-row bands of an A half-slab: ceil((128 + halo) / 16) */,
+                                                                 int ks /* K splits per tile (1 = none) */, f32x4* ks_ws, unsigned* ks_cnt) {
     constexpr int BM = 128, BN = 128, TM = 4, TN = 4;
     constexpr int WT = 8192;                           // a weight tile: 128 rows x 32 k = 8 bands of 1 KiB
     constexpr int D = NST;                             // tiles requested ahead (launcher: NST <= steps per slab, or taps == 1)
@@ -851,8 +854,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (bid / n_tiles_n) * BM;
-    const int n0 = (bid % n_tiles_n) * BN;
+    // split-K (launcher: grids that leave CUs idle): the ks workgroups of a tile are neighbours in the XCD-aware order (same XCD: its L2 holds the partials)
+    const int tile = bid / ks, split = bid - tile * ks;
+    const int m0 = (tile / n_tiles_n) * BM;
+    const int n0 = (tile % n_tiles_n) * BN;
     const int a_half = nbands * 1024, a_buf = AH * a_half;
     const unsigned char* A16 = reinterpret_cast<const unsigned char*>(p.A16);
     const unsigned char* Wg = reinterpret_cast<const unsigned char*>(p.W);
@@ -873,13 +878,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
         gr = gr < 0 ? 0 : (gr >= p.M ? p.M - 1 : gr);
         a_off[i] = ((unsigned)gr * (unsigned)p.lda + d_chunk * 8) * 2u;
     }
-    const int kslabs = p.K / (32 * AH);
+    const int kslabs = p.K / (32 * AH) / ks;           // slabs of this workgroup (launcher: divisible)
+    const unsigned k0 = (unsigned)split * (unsigned)kslabs * (AH * 64u);     // ... starting at this byte offset of a row
     const int S = p.taps * AH;                         // steps per slab
     const int nsteps = kslabs * S;
     // every cursor below advances by additions only: a step has 16 MFMAs per wave (256 clocks of the matrix pipe) and the scalar unit shares the issue slots
     const unsigned w_tap_bytes = (unsigned)p.N * (unsigned)p.K * 2u;   // (all byte offsets below are 32-bit: launcher)
     int sl_ks = 2;                                     // taps > 1: the next slab to request (0 and 1 go out in the prologue)
-    unsigned sl_k = 2u * AH * 64u;                     // ... its k offset in bytes
+    unsigned sl_k = k0 + 2u * AH * 64u;                // ... its k offset in bytes
     auto req_a_slab = [&](unsigned kbytes, int buf) {    // taps > 1: AH halves of [nbands] bands
 #pragma unroll
         for (int h = 0; h < AH; ++h)
@@ -889,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
     };
     // request cursor: tile rt = the next weight tile to request = (k offset r_k, tap r_tap) -> stage r_stage
     int rt = 0, r_tap = 0, r_h = 0, r_stage = 0;
-    unsigned r_k = 0, r_wtap = 0;                      // bytes: 64 per half-slab; tap * N * K * 2
+    unsigned r_k = k0, r_wtap = 0;                     // bytes: 64 per half-slab; tap * N * K * 2
     auto request_next = [&]() {
         if constexpr (RING_A) {                        // the 128 x 32 A tile of the step, 8 bands, beside its weight tile
 #pragma unroll
@@ -952,7 +958,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
     };
 
     // prologue: slabs 0 and 1 (taps > 1), then the first D tiles of the ring
-    if constexpr (!RING_A) { req_a_slab(0u, 0); if (kslabs > 1) req_a_slab(AH * 64u, 1); }
+    if constexpr (!RING_A) { req_a_slab(k0, 0); if (kslabs > 1) req_a_slab(k0 + AH * 64u, 1); }
     for (int t = 0; t < D && t < nsteps; ++t) request_next();
     {   // tile 0 (and everything older: the slabs) has landed once at most the tiles 1 .. min(D, nsteps) - 1 are outstanding
         const int later = (D < nsteps ? D : nsteps) - 1;
@@ -1093,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
             apre[tp] = (unsigned)((R << 6) + ((lq ^ ((R >> 1) & 2)) << 4));
         }
     }
-    unsigned u_sk = 0;                                 // k offset (bytes) of the slab being computed
+    unsigned u_sk = k0;                                // k offset (bytes) of the slab being computed
     unsigned u_ab[2][AH];                              // LDS byte offset of the halves of (this slab, the next slab)
 #pragma unroll
     for (int h = 0; h < AH; ++h) { u_ab[0][h] = h * a_half; u_ab[1][h] = a_buf + h * a_half; }
@@ -1213,6 +1219,42 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
             if (t + 1 < nsteps) step(std::false_type{}, t + 1, fa[1], fb[1], fsh[1], fa[0], fb[0], fsh[0]);
         }
     }
+    if (ks > 1) {
+        // Split-K combine, deterministic and without a spin: every workgroup of the tile stores its partial accumulators (fragment order: one 16-byte vector
+        // per lane and fragment), takes a ticket (ONE agent-scope acq_rel atomic per workgroup, by one lane between two barriers: its release writes the
+        // workgroup's stores back, its acquire invalidates what this CU / XCD may hold of the others'), and the workgroup that draws the LAST ticket sums the
+        // ks partials in split order (its own from registers at its own place) and runs the epilogue; it also re-arms the counter.  Nobody waits for anybody.
+        f32x4* mine = ks_ws + ((size_t)(tile * ks + split) * (TM * TN)) * 256 + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mine[(i * TN + j) * 256] = acc[i][j];
+        int* flag = reinterpret_cast<int*>(smem_gr);   // (the ring is drained: nothing of it is read any more)
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ks_cnt + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(ks - 1);
+            if (last) __hip_atomic_store(ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        f32x4 tot[TM][TN];
+        for (int sp = 0; sp < ks; ++sp) {
+            const f32x4* src = ks_ws + ((size_t)(tile * ks + sp) * (TM * TN)) * 256 + tid;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 v = sp == split ? acc[i][j] : src[(i * TN + j) * 256];
+                    tot[i][j] = sp == 0 ? v : tot[i][j] + v;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
+    }
     tap_epilogue<BN, TM, TN, true>(p, acc, m0, n0, wm, wn, li, lq);
 }
 
@@ -1220,13 +1262,59 @@ static int ring_lds_bytes(int nst, int ah, int taps, int halo) {
     const int nbands = (128 + halo + 15) / 16;
     return nst * 8192 + (taps == 1 ? nst * 8192 : 2 * ah * nbands * 1024);
 }
+// Split-K workspace of the ring kernel: per stream (launches of one stream are ordered; two engines or an engine and its codec run on their own streams),
+// fixed size, allocated at the stream's first split launch (an eager call: every engine's first call is) and kept for the life of the library -- captured
+// graphs hold its address.  512 partial tiles of 64 KiB + one ticket counter per tile.
+constexpr int RING_KS_MAX_PARTS = 512;
+struct RingKsWs { f32x4* ws = nullptr; unsigned* cnt = nullptr; };
+static RingKsWs ring_ks_ws(hipStream_t st) {
+    static std::mutex m;
+    static std::map<std::pair<int, hipStream_t>, RingKsWs> tab;
+    int dev = 0;
+    QTTS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(m);
+    auto it = tab.find({dev, st});
+    if (it != tab.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return RingKsWs{};      // never allocate under a capture: this launch runs unsplit
+    RingKsWs w;
+    void* a = nullptr; void* b = nullptr;
+    QTTS_CHECK_HIP(hipMalloc(&a, (size_t)RING_KS_MAX_PARTS * 128 * 128 * 4));
+    QTTS_CHECK_HIP(hipMalloc(&b, RING_KS_MAX_PARTS * sizeof(unsigned)));
+    QTTS_CHECK_HIP(hipMemsetAsync(b, 0, RING_KS_MAX_PARTS * sizeof(unsigned), st));       // stream-ordered in front of the first launch (a hipMemset on the legacy
+                                                                                         // stream does not order with a non-blocking stream: seen as a wrong first decode on the MI355X)
+    w.ws = static_cast<f32x4*>(a); w.cnt = static_cast<unsigned*>(b);
+    tab[{dev, st}] = w;
+    return w;
+}
+// K splits of a launch: QTTS_GEMM_RING_KS = n > 1: n where the shape admits it (A/B only).  DEFAULT: NONE -- measured on the 192-tile grids it was built for
+// (profiles/r06_gemm_ring.md): the batch-32 prefill's o projection 27.7 -> 48.4 us, down 63.8 -> 86.7, the C = 768 unit at 1 x 10 s 50.9 -> 56.7: the
+// agent-scope release of the ticket writes back the whole L2 (the launch's own fp32 output tiles are dirty in it); only a 64-tile grid gains (batch-8 down:
+// 61.4 -> 40.0 us at 4 splits, gemm_wide 44.2).
+static int ring_splits(const GemmTapParams& p, int nst, int ah, int n_cu) {
+    const int tiles = cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int slabs = p.K / (32 * ah), steps = slabs * p.taps * ah;
+    int ks = QTTS_OPT_INT("QTTS_GEMM_RING_KS", 0);
+    (void)n_cu;
+    if (ks == 0) ks = 1;
+    while (ks > 1 && (slabs % ks != 0 || tiles * ks > RING_KS_MAX_PARTS || steps / ks < 2 * nst || p.act == ACT_SWIGLU)) --ks;
+    return ks < 1 ? 1 : ks;
+}
 template <int NST, int AH, bool RING_A, int TAPS = 0, int ABL = 0>
 static void launch_ring_t(const GemmTapParams& p, int halo, hipStream_t st) {
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
     const int nb = cdiv(p.M, 128) * cdiv(p.N, 128);
     const int nbands = (128 + halo + 15) / 16;
+    int ks = ring_splits(p, NST, AH, n_cu);
+    RingKsWs w{};
+    if (ks > 1) { w = ring_ks_ws(st); if (!w.ws) ks = 1; }
     auto kern = gemm_ring_kernel<NST, AH, RING_A, TAPS, ABL>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), (size_t)ring_lds_bytes(NST, AH, p.taps, halo), st, p, halo, nbands);
+    hipLaunchKernelGGL(kern, dim3(nb * ks), dim3(256), (size_t)ring_lds_bytes(NST, AH, p.taps, halo), st, p, halo, nbands, ks, w.ws, w.cnt);
 }
 // depth of the ring: QTTS_GEMM_RING_NST (4 | 6 | 8), default 4 (<= 80 KB with the widest halo: two workgroups per CU) -- 8 where the grid leaves
 // every CU at most one workgroup anyway (a workgroup alone on its CU has nobody to hide its waits behind).  A slab is requested a slab's steps

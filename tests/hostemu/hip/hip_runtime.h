@@ -56,6 +56,11 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
     std::memcpy(d, s, n);
     return 0;
 }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+    if (simt::capture().open) { simt::capture().open->nodes.push_back([=] { std::memset(d, v, n); }); return 0; }
+    std::memset(d, v, n);
+    return 0;
+}
 inline hipError_t hipMemset(void* d, int v, size_t n) {
     if (simt::capture().open) return 900;
     std::memset(d, v, n);
@@ -80,6 +85,8 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return 0; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone, hipStreamCaptureStatusActive, hipStreamCaptureStatusInvalidated };
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = simt::capture().open ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone; return 0; }
 inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
     if (simt::capture().open) return 900;
     simt::capture().open = new simt::Graph();

@@ -288,6 +288,13 @@ def test_ring_tap_gemm_bit_identical_to_gemm_dma_and_race_screen(dev):
         W = bits((g.standard_normal((len(shifts), N, K), dtype=np.float32) / np.sqrt(K * len(shifts))).astype(np.float32))
         with _qlib.options(QTTS_GEMM_RING="0"):
             ref = run(A, W, T, shifts)
+        # split-K (ordered combine behind a ticket): run-to-run identical, within fp32 summation noise of the unsplit result
+        for ks in ("2", "4"):
+            with _qlib.options(QTTS_GEMM_RING="2", QTTS_GEMM_RING_KS=ks):
+                s1 = run(A, W, T, shifts)
+                for rep in range(6):
+                    assert np.array_equal(run(A, W, T, shifts), s1), (M, N, K, shifts, "split", ks, rep)
+            assert float(np.abs(s1 - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max())), (M, N, K, shifts, ks, float(np.abs(s1 - ref).max()))
         # float64 on a sample of rows (sequence starts included)
         rows = np.unique(np.concatenate([np.arange(0, M, max(1, M // 37)), np.arange(0, M, T)[:8], np.arange(0, M, T)[:8] + 3, [M - 1]]))
         Av, Wv = val(A), val(W)
@@ -300,7 +307,7 @@ def test_ring_tap_gemm_bit_identical_to_gemm_dma_and_race_screen(dev):
         assert err <= 2e-3 * max(1.0, float(np.abs(want).max())), (M, N, K, shifts, err)
         for nst in ("4", "6", "8"):
             for rep in range(12):
-                with _qlib.options(QTTS_GEMM_RING="1", QTTS_GEMM_RING_NST=nst):
+                with _qlib.options(QTTS_GEMM_RING="2", QTTS_GEMM_RING_NST=nst, QTTS_GEMM_RING_KS="1"):
                     got = run(A, W, T, shifts)
                 assert np.array_equal(got, ref), (M, N, K, shifts, nst, rep, int((got != ref).sum()))
         evidence.append(f"{M}x{N}x{K}x{len(shifts)}:{err:.1e}")

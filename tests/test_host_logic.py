@@ -868,6 +868,8 @@ def test_ring_tap_gemm_counted_waits_pinned_from_the_isa(libqtts):
     for k, (nb, vm, lg, vmax) in d.items():
         m = re.search(r"gemm_ring_kernel<(\d+), (\d+), (true|false), (\d+), 0>", k)
         nst, lps = int(m.group(1)), 4 if m.group(3) == "true" else 2
+        assert vm[-2:] == [[0], [0]], (k, vm[-3:])     # the two barriers of the split-K combine (behind the drained ring: a plain __syncthreads each)
+        nb, vm, lg = nb - 2, vm[:-2], lg - 1 if lg == nb - 1 else lg - 2
         assert nb >= 7 and lg == nb, (k, nb, lg)       # prologue, the steady steps (plain and zeroing loops; whole slabs unrolled when the taps are known), the draining steps
         taps = int(m.group(4))
         if taps == 0:                                  # generic steady step: constant waits, then two draining steps behind the run-time switch

@@ -377,6 +377,7 @@ def test_gemm_ring_kernel_real_source_bit_identical_to_gemm_dma(emu, qopt):
     the ISA (tests/test_host_logic.py) and checked on the MI355X (tests/test_gpu_parity.py)."""
     qopt(emu, "QTTS_GEMM_DMA", "1")
     qopt(emu, "QTTS_GEMM_RING", "0")
+    qopt(emu, "QTTS_GEMM_RING_KS", "1")                # (split-K changes the summation order: its own test below)
     want = {}
     _run_gemm_dma_cases(emu, want)
     for ring, nst in (("1", "4"), ("1", "6"), ("1", "8"), ("1", "0"), ("2", "4"), ("2", "8")):
@@ -387,6 +388,27 @@ def test_gemm_ring_kernel_real_source_bit_identical_to_gemm_dma(emu, qopt):
         for ci in want:
             if ring == "2" and ci == 6: continue
             assert np.array_equal(got[ci][0], want[ci][0]) and np.array_equal(got[ci][1], want[ci][1]), (ring, nst, ci)
+
+
+def test_gemm_ring_split_k_ordered_combine_real_source(emu, qopt):
+    """Round 6: the ring kernel with K split over 2 / 3 / 4 workgroups per tile (grids that leave CUs idle): every workgroup stores its partial accumulators,
+    draws a ticket, the one with the last ticket sums the partials in split order and runs the epilogue, and re-arms the counter.  Every case of the
+    shared runner (7-tap convolutions over 10 slabs, transposed form, plain Linears, every epilogue) against float64 numpy at each split count the shape
+    admits (the launcher lowers a count that does not divide the slabs), twice in a row on the same workspace (the counters re-arm), equal both times, and
+    within fp32 summation noise of the unsplit result."""
+    qopt(emu, "QTTS_GEMM_DMA", "1")
+    qopt(emu, "QTTS_GEMM_RING_NST", "4")
+    base = {}
+    qopt(emu, "QTTS_GEMM_RING", "2"); qopt(emu, "QTTS_GEMM_RING_KS", "1")
+    _run_gemm_dma_cases(emu, base)
+    for ks in ("2", "3", "4", "0"):
+        qopt(emu, "QTTS_GEMM_RING_KS", ks)
+        a, b = {}, {}
+        _run_gemm_dma_cases(emu, a)
+        _run_gemm_dma_cases(emu, b)
+        for ci in base:
+            assert np.array_equal(a[ci][0], b[ci][0]) and np.array_equal(a[ci][1], b[ci][1]), (ks, ci)
+            assert np.allclose(a[ci][0], base[ci][0], rtol=0, atol=2e-5 * max(1.0, float(np.abs(base[ci][0]).max()))), (ks, ci)
 
 
 @pytest.mark.parametrize("C,M,T,dil", [(96, 600, 300, 1), (96, 300, 100, 9), (96, 77, 77, 3), (192, 300, 150, 9), (192, 130, 65, 1)])

@@ -26,8 +26,8 @@ def run(A, W, T, shifts, iters):
     rc = f16(A.ctypes.data, K, M, T, W.ctypes.data, N, K, taps, sh, out.ctypes.data, iters, 4 if iters else 0, C.byref(us))
     assert rc == 0, lib.qtts_last_error()
     return out, us.value
-VARIANTS = [("dma", {"QTTS_GEMM_RING": "0"}), ("ring4", {"QTTS_GEMM_RING": "1", "QTTS_GEMM_RING_NST": "4"}),
-            ("ring6", {"QTTS_GEMM_RING": "1", "QTTS_GEMM_RING_NST": "6"}), ("ring8", {"QTTS_GEMM_RING": "1", "QTTS_GEMM_RING_NST": "8"})]
+VARIANTS = [("dma", {"QTTS_GEMM_RING": "0"}), ("ring4", {"QTTS_GEMM_RING": "2", "QTTS_GEMM_RING_NST": "4", "QTTS_GEMM_RING_KS": "1"}),
+            ("ring6", {"QTTS_GEMM_RING": "2", "QTTS_GEMM_RING_NST": "6", "QTTS_GEMM_RING_KS": "1"}), ("ring8", {"QTTS_GEMM_RING": "2", "QTTS_GEMM_RING_NST": "8", "QTTS_GEMM_RING_KS": "1"})]
 conv7 = lambda d: [-(6 - j) * d for j in range(7)]
 SHAPES = []
 for B in (1, 8):
@@ -70,6 +70,33 @@ for name, M, T, N, K, shifts in SHAPES:
     fl = 2.0 * M * N * K * len(shifts)
     print(f"{name:28s} {M:7d} {N:5d} {K:5d} {len(shifts):4d} " + " ".join(f"{res[n]:10.2f} {fl / res[n] / 1e6:6.0f}" for n, _ in VARIANTS) + ("  identical" if same else "  DIFFERENT"), flush=True)
 print("bitwise mismatches:", bad)
+# ---- split-K (ordered combine behind a ticket): time per launch at 1 .. 4 splits, and the default rule
+KSV = [("ks1", "1"), ("ks2", "2"), ("ks3", "3"), ("ks4", "4"), ("default", "0")]
+print(f"\n{'split-K, convolution form':28s} {'M':>7s} {'N':>5s} {'K':>5s} taps " + " ".join(f"{n + ' us':>10s}" for n, _ in KSV))
+for name, M, T, N, K, shifts in [SHAPES[0], SHAPES[1], SHAPES[2], SHAPES[5], SHAPES[6], SHAPES[14]]:
+    A = bf16bits((g.standard_normal((M, K), dtype=np.float32) * 0.5)); W = bf16bits((g.standard_normal((len(shifts), N, K), dtype=np.float32) / np.sqrt(K * len(shifts))).astype(np.float32))
+    r = {}
+    for rep in range(2):
+        for vn, ks in KSV:
+            with _lib.options(QTTS_GEMM_RING="1", QTTS_GEMM_RING_KS=ks):
+                r[vn] = min(r.get(vn, 1e30), run(A, W, T, shifts, a.iters)[1])
+    print(f"{name:28s} {M:7d} {N:5d} {K:5d} {len(shifts):4d} " + " ".join(f"{r[n]:10.2f}" for n, _ in KSV), flush=True)
+if not a.skip_linear:
+    fl2 = lib.qtts_debug_gemm_tap
+    fl2.argtypes = [C.c_int32] * 8 + [C.POINTER(C.c_double)]; fl2.restype = C.c_int
+    LIN2 = [("b32 o (1536 rows)", 1536, 2048, 2048, 0, 1), ("b32 down (1536 rows)", 1536, 2048, 6144, 0, 1), ("b32 q|k|v (1536 rows)", 1536, 4096, 2048, 0, 0),
+            ("b8 o (448 rows)", 448, 2048, 2048, 0, 1), ("b8 down (448 rows)", 448, 2048, 6144, 0, 1), ("b8 q|k|v (448 rows)", 448, 4096, 2048, 0, 0),
+            ("b8 o (512 rows)", 512, 2048, 2048, 0, 1), ("b8 down (512 rows)", 512, 2048, 6144, 0, 1)]
+    print(f"\n{'split-K, plain Linear (M x N x K)':46s} {'wide us':>10s} " + " ".join(f"{n + ' us':>10s}" for n, _ in KSV))
+    for name, M, N, K, act, rs in LIN2:
+        r = {}
+        for rep in range(2):
+            with _lib.options(QTTS_GEMM_RING="0", QTTS_GEMM_DMA="0"):
+                us = C.c_double(); assert fl2(M, N, K, act, rs, 1, 40, 4, C.byref(us)) == 0; r["wide"] = min(r.get("wide", 1e9), us.value)
+            for vn, ks in KSV:
+                with _lib.options(QTTS_GEMM_RING=("1" if vn == "default" else "2"), QTTS_GEMM_RING_KS=ks):
+                    us = C.c_double(); assert fl2(M, N, K, act, rs, 1, 40, 4, C.byref(us)) == 0; r[vn] = min(r.get(vn, 1e9), us.value)
+        print(f"{name:24s} {M:5d} x {N:5d} x {K:5d}   {r['wide']:10.2f} " + " ".join(f"{r[n]:10.2f}" for n, _ in KSV), flush=True)
 if not a.skip_linear:
     fl_ = lib.qtts_debug_gemm_tap
     fl_.argtypes = [C.c_int32] * 8 + [C.POINTER(C.c_double)]; fl_.restype = C.c_int
