@@ -1316,19 +1316,13 @@ static void launch_ring_t(const GemmTapParams& p, int halo, hipStream_t st) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(nb * ks), dim3(256), (size_t)ring_lds_bytes(NST, AH, p.taps, halo), st, p, halo, nbands, ks, w.ws, w.cnt);
 }
-// depth of the ring: QTTS_GEMM_RING_NST (4 | 6 | 8), default 4 (<= 80 KB with the widest halo: two workgroups per CU) -- 8 where the grid leaves
-// every CU at most one workgroup anyway (a workgroup alone on its CU has nobody to hide its waits behind).  A slab is requested a slab's steps
-// (taps * 2) before its first read and must stay older than the tile whose wait covers it: NST <= taps * 2 (the two-tap transposed form: 4).
+// depth of the ring: QTTS_GEMM_RING_NST (4 | 6 | 8), default 4 (<= 80 KB with the widest halo: two workgroups per CU; the deeper rings measured no faster on
+// any grid: the step is bound by instruction issue, not by the requests' latency).  A slab is requested a slab's steps (taps * 2) before its first read and
+// must stay older than the tile whose wait covers it: NST <= taps * 2 (the two-tap transposed form: 4).  The unrolled kernels exist 4 and 8 deep.
 static void launch_ring(const GemmTapParams& p, int halo, hipStream_t st) {
     QTTS_REQUIRE((size_t)p.M * p.lda * 2 < (1ull << 32) && (size_t)p.taps * p.N * p.K * 2 < (1ull << 32), QTTS_ERR_LIMIT, "gemm_ring: an operand of 4 GiB or more");
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
     int nst = QTTS_OPT_INT("QTTS_GEMM_RING_NST", 0);
     if (nst != 4 && nst != 6 && nst != 8) nst = 4;     // (measured: deeper rings lose the second workgroup per CU and gain nothing, profiles/r06_gemm_ring.md)
-    (void)n_cu;
     const int unroll = QTTS_OPT_INT("QTTS_GEMM_RING_UNROLL", 1);       // 0: the generic steady step for every tap count (A/B)
     if (p.taps == 1) { if (nst == 8) launch_ring_t<8, 1, true>(p, halo, st); else launch_ring_t<4, 1, true>(p, halo, st); return; }
     while (nst > p.taps * 2) nst -= 2;
