@@ -76,8 +76,25 @@ def variant_path(variant: str) -> str:
     return os.path.join(HERE, f"libqtts_{variant}.so")
 
 
+# The toolchain the flags above and the ISA-level assumptions of the sources were validated on: the packed-fp32 hazard's flag
+# (tests/test_gpu_parity.py: the contention test; tests/test_host_logic.py: no v_pk_*_f32 in the code objects), the polling loads that must stay
+# inside their loops, the barrier / LDS-DMA wait placement and gemm_ring_kernel's counted waits and MFMA interleave (all pinned from the code
+# objects in tests/test_host_logic.py).  Another compiler may schedule differently: the build says so, the ISA tests decide.
+VALIDATED_TOOLCHAIN = "roc-7.2.0"
+
+
+def toolchain_banner(hipcc: str) -> str:
+    try:
+        return subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception as e:      # noqa: BLE001 -- a missing compiler fails at the first compile with its own message
+        return f"(hipcc --version failed: {e})"
+
+
 def build(force: bool = False, verbose: bool = True, variant: str = None) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if VALIDATED_TOOLCHAIN not in toolchain_banner(hipcc):
+        print(f"[build] WARNING: {hipcc} is not the toolchain these sources were validated on ({VALIDATED_TOOLCHAIN}): re-run the ISA pins "
+              f"(pytest tests/test_host_logic.py -k 'isa or waits or packed or polling or dma') and the GPU contention test before trusting the library", file=sys.stderr)
     extra = []
     out = OUT
     if variant is not None:

@@ -898,6 +898,18 @@ def test_granule_polling_loads_stay_inside_their_loops(libqtts):
         assert inside > 0, (k, n, "no sc1 load inside a loop: the polling loop was hoisted")
 
 
+def test_build_toolchain_is_the_validated_one():
+    """the build records the toolchain its flags and ISA-level assumptions were validated on and warns on another; here the image's hipcc IS
+    that toolchain (a ROCm upgrade makes this test fail first: then the ISA pins of this file and the GPU contention test say whether the library holds)."""
+    sys.path.insert(0, os.path.join(ROOT, "qwen3-tts_amd"))
+    import importlib
+    b = importlib.import_module("build")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    assert b.VALIDATED_TOOLCHAIN in b.toolchain_banner(hipcc), b.toolchain_banner(hipcc)[:300]
+
+
 def test_product_library_has_no_packed_fp32_math(libqtts):
     """Round 5 (profiles/r05_packed_fp32_hazard.md): a `v_pk_mul_f32` / `v_pk_fma_f32` sequence returned wrong lanes 48-63 on the MI355X
     while another stream shared the device; the product library is built with packed fp32 math off.  Pinned from the code objects."""
