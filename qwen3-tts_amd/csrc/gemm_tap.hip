@@ -817,6 +817,9 @@ __device__ __forceinline__ void ring_barrier() {           // the reads of the s
     __syncthreads();
 #endif
 }
+#ifndef QTTS_RING_SGB
+#define QTTS_RING_SGB 3
+#endif
 __device__ __forceinline__ void ring_sched_fence() {
 #ifndef QTTS_HOST_EMU
     __builtin_amdgcn_sched_barrier(0);
@@ -1151,11 +1154,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ring_kernel(GemmTapParams p, int 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
         }
-#ifndef QTTS_HOST_EMU
+#if !defined(QTTS_HOST_EMU) && QTTS_RING_SGB > 0
 #pragma unroll
         for (int k = 0; k < TM * TN; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x096, 2, 0);       // up to two of VALU | SALU | VMEM | DS
+            __builtin_amdgcn_sched_group_barrier(0x096, QTTS_RING_SGB, 0);       // up to three of VALU | SALU | VMEM | DS (build variants ring_sgb0 / 2 / 4: A/B; 3: -10 % on the 192-tile grids, profiles/r06_gemm_ring.md)
         }
 #endif
         ring_sched_fence();
