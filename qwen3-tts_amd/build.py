@@ -59,7 +59,7 @@ VARIANTS = {
     "pk": ["-Xclang", "-target-feature", "-Xclang", "+packed-fp32-ops"],
     # Round 6, gemm_ring_kernel's unrolled step: "1 MFMA, then up to N others" -- N = 3 in the product; 0 = no sched_group_barrier hints at all
     # (tools/bench_gemm_ring.py with QTTS_LIBRARY; profiles/r06_gemm_ring.md)
-    "ring_sgb0": ["-DQTTS_RING_SGB=0"], "ring_sgb2": ["-DQTTS_RING_SGB=2"], "ring_sgb4": ["-DQTTS_RING_SGB=4"],
+    "ring_sgb0": ["-DQTTS_RING_SGB_ALT=1"], "ring_sgb2": ["-DQTTS_RING_SGB_ALT=2"], "ring_sgb4": ["-DQTTS_RING_SGB_ALT=4"],
 }
 # Round 3: kpre (kernarg preload for the decode GEMM) measured 0.973x per frame (profiles/r03_ab_kpre.md) and is now the default code.
 # Round 2 (profiles/r02_ab_variants.md): cp_pretable, cp_qkvtable, attn_cp and sampler_v2 were measured faster and are now the

@@ -270,70 +270,86 @@ __device__ inline size_t kv_offset(const KvCache& c, int layer, int b, int s, in
 }
 
 // =================================================================================== qknorm_rope_store
-// one wave per (b, t, head) for q and k heads (norm + RoPE in place, k also to the cache),
-// v heads are copied to the cache.
+// q and k heads: norm + RoPE in place, k also to the cache; v heads are copied to the cache.
+// Round 6: a workgroup per (b, t) row, its four waves dealing the row's heads -- the rotation's cosine / sine depend on the position and the lane only, so a
+// wave computes them ONCE for its 6-8 heads (one wave per (b, t, head) spent its time in cosf / sinf: 23.7 us for the 1 536-row prefill of config 4, VALU-bound;
+// the same statements per element, so the results are bit-identical).
 template <typename KVT>
 __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(QkNormRopeParams p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int heads = p.nh + 2 * p.nkv;
-    const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-    if (item >= (int64_t)p.B * p.T * heads) return;
-    const int hh = (int)(item % heads);
-    const int t = (int)((item / heads) % p.T);
-    const int b = (int)(item / ((int64_t)heads * p.T));
+    const int t = (int)(blockIdx.x % p.T);
+    const int b = (int)(blockIdx.x / p.T);
     const int npad = p.n_pad[b];
     if (t < npad) return;  // pad rows: K/V slots stay unused (masked by s < n_pad everywhere)
     const int hd = p.hd, half = hd / 2;
-    float* v = p.qkv + ((size_t)b * p.T + t) * p.ld + hh * hd;
     KVT* kc = reinterpret_cast<KVT*>(p.kv.k);
     KVT* vc = reinterpret_cast<KVT*>(p.kv.v);
-    if (hh >= p.nh + p.nkv) {  // value head: straight copy (or, for a transposed-V cache, dim-major inside the page)
-        const int kvh = hh - p.nh - p.nkv;
-        const size_t o = kv_offset(p.kv, p.layer, b, t, kvh);
-        if (p.kv.vt) {
-            const size_t pg = o - (size_t)(t & 15) * hd;              // start of this (page, kv head) block
-            for (int d = lane; d < hd; d += 64) vc[pg + (size_t)d * 16 + (t & 15)] = kv_cast<KVT>(v[d]);
-        } else
-        for (int d = lane; d < hd; d += 64) vc[o + d] = kv_cast<KVT>(v[d]);
-        return;
-    }
-    const bool is_k = hh >= p.nh;
-    const float* w = is_k ? p.kw : p.qw;
-    // hd <= 128: lane owns d = lane and d + 64 (second only when hd == 128) -> pairs (d, d+half)
-    float x0 = lane < hd ? v[lane] : 0.f;
-    float x1 = lane + 64 < hd ? v[lane + 64] : 0.f;
-    float ss = wave_sum64(x0 * x0 + x1 * x1);
-    const float r = rsqrtf(ss / (float)hd + p.eps);
-    x0 = w[lane < hd ? lane : 0] * (x0 * r);
-    x1 = (lane + 64 < hd) ? w[lane + 64] * (x1 * r) : 0.f;
     const float pos = (float)(t - npad);
-    float o0, o1;
-    if (hd == 128) {  // pair (lane, lane+64)
-        const float ang = pos * p.inv_freq[lane];
-        const float c = cosf(ang), s = sinf(ang);
-        o0 = x0 * c - x1 * s;
-        o1 = x1 * c + x0 * s;
-    } else {          // hd == 64: pair (lane, lane^32) inside the wave
-        const float other = __shfl_xor(x0, 32);
-        const float ang = pos * p.inv_freq[lane & 31];
-        const float c = cosf(ang), s = sinf(ang);
-        o0 = (lane < 32) ? x0 * c - other * s : x0 * c + other * s;
-        o1 = 0.f;
-    }
-    if (lane < hd) v[lane] = o0;
-    if (lane + 64 < hd) v[lane + 64] = o1;
-    if (is_k) {
-        const size_t o = kv_offset(p.kv, p.layer, b, t, hh - p.nh);
-        if (lane < hd) kc[o + lane] = kv_cast<KVT>(o0);
-        if (lane + 64 < hd) kc[o + lane + 64] = kv_cast<KVT>(o1);
+    const float ang = pos * p.inv_freq[hd == 128 ? lane : (lane & 31)];
+    const float c = cosf(ang), s = sinf(ang);
+    // the wave's heads (wave, wave + 4, ...) in groups of up to eight: all of a group's elements are requested before the first one is used (a head is a
+    // load -> wave sum -> store chain; eight chains in flight instead of one after the other)
+    float* row = p.qkv + ((size_t)b * p.T + t) * p.ld;
+    for (int h0 = wave; h0 < heads; h0 += 32) {
+        float xa[8], xb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int hh = h0 + 4 * i;
+            const float* v = row + (hh < heads ? hh : h0) * hd;
+            xa[i] = lane < hd ? v[lane] : 0.f;
+            xb[i] = lane + 64 < hd ? v[lane + 64] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int hh = h0 + 4 * i;
+            if (hh >= heads) break;
+            float* v = row + hh * hd;
+            if (hh >= p.nh + p.nkv) {  // value head: straight copy (or, for a transposed-V cache, dim-major inside the page)
+                const int kvh = hh - p.nh - p.nkv;
+                const size_t o = kv_offset(p.kv, p.layer, b, t, kvh);
+                if (p.kv.vt) {
+                    const size_t pg = o - (size_t)(t & 15) * hd;              // start of this (page, kv head) block
+                    if (lane < hd) vc[pg + (size_t)lane * 16 + (t & 15)] = kv_cast<KVT>(xa[i]);
+                    if (lane + 64 < hd) vc[pg + (size_t)(lane + 64) * 16 + (t & 15)] = kv_cast<KVT>(xb[i]);
+                } else {
+                    if (lane < hd) vc[o + lane] = kv_cast<KVT>(xa[i]);
+                    if (lane + 64 < hd) vc[o + lane + 64] = kv_cast<KVT>(xb[i]);
+                }
+                continue;
+            }
+            const bool is_k = hh >= p.nh;
+            const float* w = is_k ? p.kw : p.qw;
+            // hd <= 128: lane owns d = lane and d + 64 (second only when hd == 128) -> pairs (d, d+half)
+            float x0 = xa[i], x1 = xb[i];
+            float ss = wave_sum64(x0 * x0 + x1 * x1);
+            const float r = rsqrtf(ss / (float)hd + p.eps);
+            x0 = w[lane < hd ? lane : 0] * (x0 * r);
+            x1 = (lane + 64 < hd) ? w[lane + 64] * (x1 * r) : 0.f;
+            float o0, o1;
+            if (hd == 128) {  // pair (lane, lane+64)
+                o0 = x0 * c - x1 * s;
+                o1 = x1 * c + x0 * s;
+            } else {          // hd == 64: pair (lane, lane^32) inside the wave
+                const float other = __shfl_xor(x0, 32);
+                o0 = (lane < 32) ? x0 * c - other * s : x0 * c + other * s;
+                o1 = 0.f;
+            }
+            if (lane < hd) v[lane] = o0;
+            if (lane + 64 < hd) v[lane + 64] = o1;
+            if (is_k) {
+                const size_t o = kv_offset(p.kv, p.layer, b, t, hh - p.nh);
+                if (lane < hd) kc[o + lane] = kv_cast<KVT>(o0);
+                if (lane + 64 < hd) kc[o + lane + 64] = kv_cast<KVT>(o1);
+            }
+        }
     }
     (void)half;
 }
 
 void launch_qknorm_rope_store(const QkNormRopeParams& p, hipStream_t st) {
     QTTS_REQUIRE(p.hd == 64 || p.hd == 128, QTTS_ERR_ARG, "qknorm_rope_store: head_dim 64|128");
-    const int64_t total = (int64_t)p.B * p.T * (p.nh + 2 * p.nkv);
-    const int grid = (int)((total + 3) / 4);
+    const int grid = p.B * p.T;                        // a workgroup per (b, t) row
     if (p.kv.bf16) hipLaunchKernelGGL(qknorm_rope_store_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(qknorm_rope_store_kernel<float>, dim3(grid), dim3(256), 0, st, p);
     QTTS_CHECK_HIP(hipGetLastError());

@@ -817,9 +817,11 @@ __device__ __forceinline__ void ring_barrier() {           // the reads of the s
     __syncthreads();
 #endif
 }
-#ifndef QTTS_RING_SGB
-#define QTTS_RING_SGB 3
+#ifndef QTTS_RING_SGB_ALT
+#define QTTS_RING_SGB_ALT 0
 #endif
+// "1 MFMA, then up to QTTS_RING_SGB others": 3 in the product (QTTS_RING_SGB_ALT 0); build variants: ALT 1 = no hints, 2 / 4 = that many
+#define QTTS_RING_SGB (QTTS_RING_SGB_ALT == 0 ? 3 : (QTTS_RING_SGB_ALT == 1 ? 0 : QTTS_RING_SGB_ALT))
 __device__ __forceinline__ void ring_sched_fence() {
 #ifndef QTTS_HOST_EMU
     __builtin_amdgcn_sched_barrier(0);

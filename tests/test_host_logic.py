@@ -901,9 +901,10 @@ def test_granule_polling_loads_stay_inside_their_loops(libqtts):
 def test_build_toolchain_is_the_validated_one():
     """the build records the toolchain its flags and ISA-level assumptions were validated on and warns on another; here the image's hipcc IS
     that toolchain (a ROCm upgrade makes this test fail first: then the ISA pins of this file and the GPU contention test say whether the library holds)."""
-    sys.path.insert(0, os.path.join(ROOT, "qwen3-tts_amd"))
-    import importlib
-    b = importlib.import_module("build")
+    import importlib.util                              # (under its own module name: `build` is also the emulator builder's)
+    spec = importlib.util.spec_from_file_location("qtts_build_tc", os.path.join(ROOT, "qwen3-tts_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
