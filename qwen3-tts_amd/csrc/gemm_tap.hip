@@ -1380,11 +1380,18 @@ static WideTile wide_tile(const GemmTapParams& p, bool a16, int bn_max) {
     }();
     double tb = 1e30;
     const double ab = a16 ? 2.0 : 4.0;
-    for (int cm : {128, 64})
-        for (int cn : {128, 64})
+    // Round 6 (last call): 32-row tiles for launches of at most 128 rows (the codec transformer at 1 x 10 s and in a 32-stream first packet, a
+    // streaming push, a one-utterance prefill): four row tiles instead of two halve the bytes a workgroup pulls per k-step -- the chain bound above --
+    // and put 2-4x the CUs to work; same MFMA sequence per output element (k ascending in 32s), so the results are bit-identical to any other tile.
+    // 32 x 32 has no SwiGLU epilogue (gate / up pairs need two column tiles per wave).
+    for (int cm : {128, 64, 32})
+        for (int cn : {128, 64, 32})
             for (int ck : {128, 256}) {
                 if (cn > bn_max || p.N % cn != 0 || p.K % ck != 0) continue;
-                if (ck == 256 && (cm != 64 || (!a16 && cn != 64))) continue;       // (registers: 64 x 128 fp32 at 256 would spill)
+                if (cm == 32 && (p.M > 128 || ck != 256 || cn > 64)) continue;
+                if (cn == 32 && (cm != 32 || p.act == ACT_SWIGLU)) continue;
+                if (ck == 256 && cm == 64 && !a16 && cn != 64) continue;             // (registers: 64 x 128 fp32 at 256 would spill)
+                if (ck == 256 && cm == 128) continue;
                 if (force && force != (cm * 1000 + cn) * 1000 + ck) continue;
                 const int wgs = cdiv(p.M, cm) * cdiv(p.N, cn), steps = p.K / ck;
                 const double sb = ck * (cm * ab + cn * 2.0) * 1e-3;                    // KB per k-step
@@ -1399,6 +1406,7 @@ static WideTile wide_tile(const GemmTapParams& p, bool a16, int bn_max) {
 template <bool A16>
 static void launch_wide(const GemmTapParams& p, int bn_max, hipStream_t st) {
     const WideTile t = wide_tile(p, A16, bn_max);
+    if (t.bm == 32) { if (t.bn == 64) launch_wide_k<32, 64, A16, 256>(p, st); else launch_wide_k<32, 32, A16, 256>(p, st); return; }
     if (t.bm == 128) { if (t.bn == 128) launch_wide_k<128, 128, A16, 128>(p, st); else launch_wide_k<128, 64, A16, 128>(p, st); }
     else if (t.bk == 128) { if (t.bn == 128) launch_wide_k<64, 128, A16, 128>(p, st); else launch_wide_k<64, 64, A16, 128>(p, st); }
     else if (t.bn == 128) { if constexpr (A16) launch_wide_k<64, 128, true, 256>(p, st); else launch_wide_k<64, 128, false, 128>(p, st); }

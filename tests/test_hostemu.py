@@ -164,17 +164,25 @@ def test_gemm_tap_kernel_real_source(emu, bf16):
         assert np.all(out[:, No:] == 7.0), "wrote outside its columns"
 
 
-@pytest.mark.parametrize("tile", [128128128, 128064128, 64128128, 64064128, 64064256, 64128256])
+_WIDE_TILE_REF = {}
+
+
+@pytest.mark.parametrize("tile", [128128128, 128064128, 64128128, 64064128, 64064256, 64128256, 32064256, 32032256])
 def test_gemm_wide_kernel_every_tile_real_source(emu, tile):
     """The small-grid GEMM of the talker prefill and the codec transformer (gemm_wide_kernel, round 3: 64-row tiles, 256-wide k-steps,
     bf16 activations): every tile instantiation, forced through the test hook, with fp32 and with bf16 activations, ragged M, a
     residual / bias epilogue and the SwiGLU epilogue, against float64 numpy.  (A tile the shape or the registers do not admit -- the
-    256-wide step with 128 fp32 columns -- runs as 128 x 128, which the first parameter covers.)"""
+    256-wide step with 128 fp32 columns -- runs as 128 x 128, which the first parameter covers.)  Round 6: the 32-row tiles (launches of at most
+    128 rows; 32 x 32 has no SwiGLU epilogue) -- the third shape is theirs, and every tile must agree with 128 x 128 on it BIT FOR BIT (the MFMA
+    sequence per output element does not depend on the tile: what lets the chooser change tiles under the goldens)."""
     g = np.random.default_rng(tile % 1000 + tile // 1000000)
+    g3 = np.random.default_rng(3)
     emu.qtts_debug_gemm_wide_tile.argtypes = [C.c_int32]; emu.qtts_debug_gemm_wide_tile.restype = None
     emu.qtts_debug_gemm_wide_tile(tile)
     try:
-        for (M, N, K, act, hb, hr) in ((150, 192, 512, ACT_NONE, 1, 1), (70, 128, 1024, ACT_SWIGLU, 0, 0)):
+        for (M, N, K, act, hb, hr) in ((150, 192, 512, ACT_NONE, 1, 1), (70, 128, 1024, ACT_SWIGLU, 0, 0), (101, 192, 768, ACT_NONE, 1, 1)):
+            if M == 101:
+                g = g3                                                   # the same operands for every tile
             A = (g.standard_normal((M, K)) * 0.5).astype(np.float32)
             W = (g.standard_normal((1, N, K)) / np.sqrt(K)).astype(np.float32)
             bias = g.standard_normal(N).astype(np.float32) if hb else None
@@ -198,6 +206,9 @@ def test_gemm_wide_kernel_every_tile_real_source(emu, tile):
             assert np.abs(out16[:, :No] - want).max() <= tol and np.all(out16[:, No:] == 7.0), (tile, M, N, K, "bf16 activations")
             if tile == 128128128:                                   # the same rounding either way: bf16 activations change nothing
                 assert np.array_equal(out16[:, :No], out[:, :No])
+            if M == 101:
+                ref = _WIDE_TILE_REF.setdefault("out", out[:, :No].copy())
+                assert np.array_equal(out[:, :No], ref) and np.array_equal(out16[:, :No], ref), (tile, "differs from the first tile's bits")
     finally:
         emu.qtts_debug_gemm_wide_tile(-1)
 
@@ -252,14 +263,19 @@ def test_gemm_wide_tile_chooser_follows_its_three_bounds(emu):
             for (M, N, K) in ((512, 4096, 2048), (512, 2048, 2048), (512, 12288, 2048), (512, 2048, 6144), (2048, 4096, 2048), (2048, 12288, 2048),
                               (1000, 3072, 1024), (1000, 1024, 3072), (125, 3072, 1024), (125, 1024, 3072), (37, 192, 512), (8, 2048, 1024)):
                 bm, bn, bk = pick(M, N, K, a16)
-                assert bm in (64, 128) and bn in (64, 128) and bk in (128, 256) and N % bn == 0 and K % bk == 0, (M, N, K, a16, bm, bn, bk)
-                assert bk == 128 or (bm == 64 and (a16 or bn == 64)), (M, N, K, a16, bm, bn, bk)
+                assert bm in (32, 64, 128) and bn in (32, 64, 128) and bk in (128, 256) and N % bn == 0 and K % bk == 0, (M, N, K, a16, bm, bn, bk)
+                assert bk == 128 or (bm == 64 and (a16 or bn == 64)) or bm == 32, (M, N, K, a16, bm, bn, bk)
+                assert (bm == 32) <= (M <= 128 and bk == 256 and bn <= 64) and (bn == 32) <= (bm == 32), (M, N, K, a16, bm, bn, bk)    # round 6: 32-row tiles, <= 128 rows only
             for (M, N, K) in ((512, 4096, 2048), (512, 2048, 2048), (512, 2048, 6144), (1000, 1024, 3072), (125, 3072, 1024), (125, 1024, 3072)):
                 bm, bn, bk = pick(M, N, K, a16)                              # 128 x 128 would hold 128 workgroups or fewer: at least twice as many
                 cd = lambda a, b: -(-a // b)
                 assert cd(M, bm) * cd(N, bn) >= 2 * cd(M, 128) * cd(N, 128), ((M, N, K), a16, (bm, bn, bk))
-            for shape in ((512, 2048, 2048), (512, 2048, 6144), (125, 1024, 3072)):
+            for shape in ((512, 2048, 2048), (512, 2048, 6144)):
                 assert pick(*shape, a16)[:2] == (64, 64), (shape, a16, pick(*shape, a16))     # 64 tiles of 128 x 128: four times as many
+            # round 6, at most 128 rows: the codec transformer's o / down at 1 x 10 s take 32 x 32 (16 workgroups of 128 x 128 -> 128; measured
+            # 10.1 -> 5.8 and 22.3 -> 12.0 us, profiles/r06_gemm_small_tiles_32row.md), q|k|v a 32-row tile (the SwiGLU launch never takes 32 columns: gate / up pairs need two column tiles per wave)
+            assert pick(125, 1024, 3072, a16) == (32, 32, 256) and pick(125, 1024, 1024, a16) == (32, 32, 256)
+            assert pick(125, 3072, 1024, a16)[0] == 32
             for shape in ((2048, 4096, 2048), (2048, 12288, 2048)):
                 assert pick(*shape, a16)[:2] == (128, 128), (shape, a16, pick(*shape, a16))
             assert pick(512, 12288, 2048, a16)[0] == 128                    # row tiles x 50 MB is the bound: 64-row tiles would double it

@@ -7,7 +7,9 @@ SHAPES = [("prefill q|k|v", 512, 4096, 2048, 0, 0), ("prefill o", 512, 2048, 204
           ("prefill down", 512, 2048, 6144, 0, 1),
           ("prefill b32 q|k|v", 2048, 4096, 2048, 0, 0), ("prefill b32 gate|up", 2048, 12288, 2048, 2, 0), ("prefill b32 down", 2048, 2048, 6144, 0, 1),
           ("codec q|k|v", 1000, 3072, 1024, 0, 0), ("codec o", 1000, 1024, 1024, 0, 1), ("codec gate|up", 1000, 6144, 1024, 2, 0),
-          ("codec down", 1000, 1024, 3072, 0, 1), ("codec b1 q|k|v", 125, 3072, 1024, 0, 0), ("codec b1 down", 125, 1024, 3072, 0, 1)]
+          ("codec down", 1000, 1024, 3072, 0, 1), ("codec b1 q|k|v", 125, 3072, 1024, 0, 0), ("codec b1 o", 125, 1024, 1024, 0, 1), ("codec b1 gate|up", 125, 6144, 1024, 2, 0), ("codec b1 down", 125, 1024, 3072, 0, 1),
+          ("prefill 1x40 q|k|v", 40, 4096, 2048, 0, 0), ("prefill 1x40 o", 40, 2048, 2048, 0, 1), ("prefill 1x40 gate|up", 40, 12288, 2048, 2, 0), ("prefill 1x40 down", 40, 2048, 6144, 0, 1)]
+if "--small" in sys.argv: SHAPES = [s for s in SHAPES if s[1] <= 128]
 import torch
 from qwen3_tts_amd import _lib
 lib = _lib.load_library()
@@ -15,7 +17,7 @@ torch.zeros(1).cuda()
 f = lib.qtts_debug_gemm_tap
 f.argtypes = [C.c_int32] * 8 + [C.POINTER(C.c_double)]; f.restype = C.c_int
 lib.qtts_debug_gemm_wide_tile.argtypes = [C.c_int32]; lib.qtts_debug_gemm_wide_tile.restype = None
-cols = [("chooser", 0), ("128x128", 128128128), ("128x64", 128064128), ("64x128", 64128128), ("64x64", 64064128), ("64x128 k256", 64128256), ("64x64 k256", 64064256)]
+cols = [("chooser", 0), ("128x128", 128128128), ("128x64", 128064128), ("64x128", 64128128), ("64x64", 64064128), ("64x128 k256", 64128256), ("64x64 k256", 64064256), ("32x64 k256", 32064256), ("32x32 k256", 32032256)]
 print(f"{'shape (M x N x K)':44s} A    " + "".join(f"{c:>13s}" for c, _ in cols))
 for name, M, N, K, act, rs in SHAPES:
     for a16 in (0, 1):
